@@ -1,0 +1,141 @@
+/* modppl_hip.h — C ABI of the MI355X (gfx950) particle-filter / importance / MH hot path.
+ *
+ * agarret7/modppl has no FFI or plugin seam; its inference library is generic Rust over the
+ * `GenFn` trait and owns the per-particle loops itself (modppl/src/inference/particle_filter.rs:65,76,110;
+ * importance.rs:18-19).  The drop-in boundary therefore sits at the level of `ParticleSystem`
+ * and of the free functions `importance_sampling`/`importance_resampling`/`mh`/`regen_mh`
+ * (modppl/src/inference/mod.rs:8-10).  Each entry point below names the reference item it
+ * replaces.  A Rust `-sys` binding for these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - one opaque handle per filter / chain set; a handle is NOT thread-safe (the reference's
+ *    ParticleSystem is !Send because it owns a ThreadRng: particle_filter.rs:21).
+ *  - every call returns int32 status; 0 = ok.  A non-zero status stands for a reference
+ *    `panic!`/`assert!` (the reference has no Result anywhere); mp_last_error() gives the text.
+ *  - all in/out buffers are caller-owned HOST memory unless a parameter says "device";
+ *    device memory is owned by the handle.  No callbacks cross the ABI: a model is chosen by
+ *    descriptor {kind, dims, params[]} and is compiled into the library as a static
+ *    handler-polymorphic kernel (the GPU stand-in for a `dyngen!` function).
+ *  - randomness: Philox4x32-10 keyed by `seed`, counter = (slot, step, domain|site, attempt);
+ *    see modppl_amd/csrc/mp_philox.h.  The reference's ThreadRng cannot be seeded.
+ *  - `stream`: a hipStream_t passed as void*, or NULL for the handle's own stream.  Work is
+ *    enqueued asynchronously; only calls that return a value to the host synchronise.
+ */
+#ifndef MODPPL_HIP_H
+#define MODPPL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------------------- */
+#define MP_OK 0
+#define MP_ERR_INVALID_ARG 1 /* bad descriptor, null pointer, size mismatch                          */
+#define MP_ERR_STATE 2       /* call order the reference panics on (step/resample before init_step)  */
+#define MP_ERR_CONSTRAINTS 3 /* wrong number of constraints: dynunfold.rs:57,75 asserts               */
+#define MP_ERR_DEGENERATE 4  /* all log-weights -inf: NaN probabilities, categorical.rs:23 assert    */
+#define MP_ERR_HIP 5         /* HIP runtime failure (no device, out of memory, launch failure)       */
+#define MP_ERR_UNSUPPORTED 6 /* model / option not compiled into the library                         */
+
+/* ---- models -------------------------------------------------------------------------- */
+enum mp_model_kind {
+    /* LGSSM d=1 (BASELINE.json configs 1-2).  params = {mu0, sig0, a, sig_x, sig_y}:
+     *   t==0: x ~ normal(mu0, sig0);  t>0: x ~ normal(a*x_prev, sig_x);  y ~ normal(x, sig_y) observed */
+    MP_MODEL_LGSSM1 = 1,
+    /* modppl/tests/dyngenfns/unfold.rs:14-32 spiral_kernel.  no params; state = (r, theta), obs = 2 */
+    MP_MODEL_SPIRAL = 2,
+    /* modppl/tests/hmm/model.rs:33-80.  params = {n_states, n_obs, prior[S], emission[O][S], transition[S][S]}
+     * (column-stochastic, as tests/particle_filter.rs:41-51 builds them); state = 1, obs = 1 (integer valued) */
+    MP_MODEL_HMM = 3,
+    /* bearings-only tracker d=4 (BASELINE.json config 3).  params = {p0x,p0y,sig_p0,sig_v0,sig_a,sig_theta} */
+    MP_MODEL_BEARINGS = 4,
+    /* LGSSM d=D (config 5): x' = A x + sig_x z, y = x + sig_y e.  params = {D, a, band, sig0, sig_x, sig_y} */
+    MP_MODEL_LGSSM_BAND = 5,
+};
+
+typedef struct mp_model_desc {
+    int32_t kind;       /* enum mp_model_kind                     */
+    int32_t dim_state;  /* doubles per particle state             */
+    int32_t dim_obs;    /* doubles per time step of constraints   */
+    int32_t n_params;
+    const double* params;
+} mp_model_desc;
+
+/* Which global slots this process owns (one process per GPU).  NULL = all of them. */
+typedef struct mp_shard {
+    uint64_t n_global;    /* particles in the whole job                          */
+    uint64_t slot_offset; /* first global slot owned by this handle              */
+} mp_shard;
+
+enum mp_resample_scheme {
+    MP_RESAMPLE_MULTINOMIAL = 0, /* particle_filter.rs:37-41 (the only scheme the reference has) */
+    MP_RESAMPLE_SYSTEMATIC = 1,  /* extension named by the north star; no reference counterpart  */
+};
+enum mp_ess_mode {
+    MP_ESS_REFERENCE = 0, /* particle_filter.rs:98-100: from the weights normalised by the LAST resample() (1/N before any) */
+    MP_ESS_FRESH = 1,     /* from the current log-weights                                                                   */
+};
+#define MP_PF_RECORD_HISTORY 1u /* keep x[t] and parent[r] so that `traces[i].retv` can be rebuilt */
+
+typedef struct mp_pf mp_pf;
+
+const char* mp_last_error(void);
+/* Number of visible gfx950 devices (0 when none): lets callers fail loudly before creating anything. */
+int32_t mp_device_count(void);
+
+/* ParticleSystem::new — particle_filter.rs:44-57.  `seed` replaces `rng: ThreadRng`. */
+int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t seed, const mp_shard* shard,
+                     uint32_t flags, int32_t device, void* stream, mp_pf** out);
+/* ParticleSystem::init_step — :60-70 (N x DynUnfold::generate, dynunfold.rs:41-64).
+ * `args0` = the Unfold's initial state argument (dim_state doubles, may be NULL = zeros);
+ * `obs` = constraints of n_steps >= 1 time steps, [n_steps][dim_obs]. */
+int32_t mp_pf_init_step(mp_pf* h, const double* args0, const double* obs, int32_t n_steps);
+/* ParticleSystem::step — :73-96 (N x DynUnfold::update with ArgDiff::Extend, dynunfold.rs:66-100). */
+int32_t mp_pf_step(mp_pf* h, const double* obs, int32_t n_steps);
+/* ParticleSystem::effective_sample_size — :98-100. */
+int32_t mp_pf_effective_sample_size(mp_pf* h, int32_t ess_mode, double* out);
+/* ParticleSystem::resample — :103-116.  Returns the log total weight through `log_total_weight`;
+ * pass NULL to enqueue without synchronising (the value still feeds the log-ML estimate). */
+int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight);
+/* ParticleSystem::log_marginal_likelihood_estimate — :119-121. */
+int32_t mp_pf_log_marginal_likelihood_estimate(mp_pf* h, double* out);
+/* The pub `traces` field (:13): traces[i].retv.last() for all i -> x_out[n_local][dim_state]. */
+int32_t mp_pf_read_state(mp_pf* h, double* x_out);
+/* log_weights (:15) -> out[n_local]. */
+int32_t mp_pf_read_log_weights(mp_pf* h, double* out);
+/* parents (:20) of the most recent resample -> out[n_local] (global slot ids). */
+int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out);
+/* traces[i].retv (Vec<State>) rebuilt from the recorded ancestry -> out[t_steps][dim_state].
+ * Needs MP_PF_RECORD_HISTORY. */
+int32_t mp_pf_read_trajectory(mp_pf* h, uint64_t i, double* out, int32_t* t_steps);
+/* Number of Unfold steps taken so far (trace.args.0). */
+int32_t mp_pf_time(mp_pf* h, int64_t* out);
+/* Whole filter in one call: init_step on obs[0], then for t=1..T-1 {step; resample} with a
+ * resample after the first step too — the loop of modppl/tests/smc.rs:64-90.  Enqueues
+ * everything without host synchronisation.  resample_every = 1 reproduces smc.rs. */
+int32_t mp_pf_run(mp_pf* h, const double* args0, const double* obs, int32_t n_steps, int32_t scheme);
+/* Wait for everything enqueued on the handle; surfaces sticky device-side errors. */
+int32_t mp_pf_synchronize(mp_pf* h);
+int32_t mp_pf_destroy(mp_pf* h);
+
+/* ---- profiling hooks (bench.py: HIP-event timing on the stream the kernels run on) ------ */
+/* Accumulated GPU time (ms) and launch count of kernel family `which` since the last reset,
+ * measured with hipEvents recorded around each launch when timing is enabled. */
+enum mp_kernel_family { MP_K_PROPAGATE = 0, MP_K_NORMALIZE_SCAN = 1, MP_K_RESAMPLE_GATHER = 2, MP_K_COUNT = 3 };
+int32_t mp_pf_set_timing(mp_pf* h, int32_t enabled);
+int32_t mp_pf_get_timing(mp_pf* h, int32_t which, double* total_ms, uint64_t* launches);
+
+/* ---- importance sampling — modppl/src/inference/importance.rs:12-50 -------------------- */
+/* importance_resampling(model, args, constraints, num_samples, num_ret_samples):
+ * N x generate over all n_steps constraints, logsumexp, log_ml = L - ln N, lnw_i = w_i - L,
+ * M categorical draws.  Any of the out pointers may be NULL. */
+int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps,
+                                 uint64_t num_samples, uint64_t num_ret_samples, uint64_t seed, int32_t device,
+                                 double* log_ml_estimate, double* log_normalized_weights, uint64_t* resampled_indices,
+                                 double* final_states);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODPPL_HIP_H */

@@ -1,0 +1,309 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see rng.hpp).
+//
+// capi.cpp — C entry points so that tests/ (ctypes) can drive the restated reference.  The
+// particle-filter entry points mirror include/modppl_hip.h one for one with an `oracle_`
+// prefix, so a parity test issues the same call sequence to both libraries.
+//
+// variant bits of oracle_pf_create:
+//   1 = canonical (mp_math transcendental functions + fixed-point resampling CDF)
+//   2 = SoA "algorithm-faithful" engine instead of the dynamic-handler "structure-faithful" one
+//   4 = (literal, dynamic engine only) binary-search the sequential running sum instead of the
+//       O(N) scan per draw — index-identical, makes N >= 10^4 feasible
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "../../include/modppl_hip.h"
+#include "soa.hpp"
+
+using namespace oracle;
+
+static thread_local std::string g_err;
+static int32_t fail(int32_t code, const std::string& msg) { g_err = msg; return code; }
+static int32_t classify(const Panic& p) {
+    const std::string m = p.what();
+    if (m.find("constraints") != std::string::npos) return MP_ERR_CONSTRAINTS;
+    if (m.find("-inf") != std::string::npos || m.find("sum to 1") != std::string::npos) return MP_ERR_DEGENERATE;
+    if (m.find("before init_step") != std::string::npos || m.find("twice") != std::string::npos) return MP_ERR_STATE;
+    return MP_ERR_INVALID_ARG;
+}
+#define GUARD(...)                                               \
+    try { __VA_ARGS__; return MP_OK; }                           \
+    catch (const Panic& p) { return fail(classify(p), p.what()); } \
+    catch (const std::exception& e) { return fail(MP_ERR_INVALID_ARG, e.what()); }
+
+struct IPf {
+    virtual ~IPf() {}
+    virtual void init_step(const double* args0, const double* obs, int n_steps) = 0;
+    virtual void step(const double* obs, int n_steps) = 0;
+    virtual double ess(int mode) = 0;
+    virtual double resample() = 0;
+    virtual double log_ml() = 0;
+    virtual void read_state(double* out) = 0;
+    virtual void read_logw(double* out) = 0;
+    virtual void read_parents(uint32_t* out) = 0;
+    virtual int64_t time() = 0;
+    virtual size_t trajectory(uint64_t i, double* out) { (void)i; (void)out; throw Panic("trajectory: not recorded by this engine"); }
+};
+
+// ---- structure-faithful engine: ParticleSystem over DynUnfold ---------------------------------
+template <class State>
+struct DynPf : IPf {
+    using PS = ParticleSystem<State, std::vector<DynTrie>, std::vector<State>>;
+    DynUnfold<State> model;
+    std::unique_ptr<PS> ps;
+    int dim_state, dim_obs;
+    std::function<DynTrie(const double*)> mk_constraints;
+    std::function<State(const double*)> mk_state;
+    std::function<void(const State&, double*)> put_state;
+    bool initialised = false;
+
+    std::vector<DynTrie> constraints(const double* obs, int n_steps) const {
+        std::vector<DynTrie> v;
+        for (int k = 0; k < n_steps; ++k) v.push_back(mk_constraints(obs + (size_t)k * dim_obs));
+        return v;
+    }
+    void init_step(const double* args0, const double* obs, int n_steps) override {
+        if (initialised) throw Panic("init_step called twice");
+        std::vector<double> z((size_t)dim_state, 0.);
+        // the reference always passes (1, args) to generate (particle_filter.rs:66); more than one
+        // constraint is the build's multi-step extension: generate at t=0, then Extend.
+        ps->init_step(mk_state(args0 ? args0 : z.data()), constraints(obs, 1));
+        initialised = true;
+        if (n_steps > 1) step(obs + dim_obs, n_steps - 1);
+    }
+    void step(const double* obs, int n_steps) override {
+        if (!initialised) throw Panic("step before init_step");
+        for (int k = 0; k < n_steps; ++k) ps->step(constraints(obs + (size_t)k * dim_obs, 1));
+    }
+    double ess(int mode) override {
+        if (mode == MP_ESS_REFERENCE) return ps->effective_sample_size();
+        if (ps->canonical_resampling) return canonical_normalize(ps->log_weights, ps->num_particles).ess;
+        const double L = logsumexp(ps->log_weights);
+        std::vector<double> two;
+        for (double w : ps->log_weights) two.push_back(2.0 * (w - L));
+        return o_exp(-logsumexp(two));
+    }
+    double resample() override { return ps->resample(); }
+    double log_ml() override { return ps->log_marginal_likelihood_estimate(); }
+    void read_state(double* out) override {
+        for (size_t i = 0; i < ps->traces.size(); ++i) put_state(ps->traces[i].retv->back(), out + i * (size_t)dim_state);
+    }
+    void read_logw(double* out) override { std::memcpy(out, ps->log_weights.data(), ps->num_particles * sizeof(double)); }
+    void read_parents(uint32_t* out) override { for (size_t i = 0; i < ps->num_particles; ++i) out[i] = (uint32_t)ps->parents[i]; }
+    int64_t time() override { return ps->traces.empty() ? 0 : ps->traces[0].args.first; }
+    size_t trajectory(uint64_t i, double* out) override {  // traces[i].retv: Vec<State>
+        const auto& rv = *ps->traces.at(i).retv;
+        for (size_t t = 0; t < rv.size(); ++t) put_state(rv[t], out + t * (size_t)dim_state);
+        return rv.size();
+    }
+};
+
+struct HmmPf : IPf {
+    using PS = ParticleSystem<int, HmmData, std::vector<size_t>>;
+    HMM model;
+    std::unique_ptr<PS> ps;
+    bool initialised = false;
+    explicit HmmPf(HmmParams p) : model(std::move(p)) {}
+    static HmmData mk(const double* obs) { return HmmData{{std::nullopt}, {(size_t)obs[0]}}; }
+    void init_step(const double*, const double* obs, int n_steps) override {
+        if (initialised) throw Panic("init_step called twice");
+        ps->init_step(0, mk(obs));
+        initialised = true;
+        if (n_steps > 1) step(obs + 1, n_steps - 1);
+    }
+    void step(const double* obs, int n_steps) override {
+        if (!initialised) throw Panic("step before init_step");
+        for (int k = 0; k < n_steps; ++k) ps->step(mk(obs + k));
+    }
+    double ess(int mode) override {
+        if (mode == MP_ESS_REFERENCE) return ps->effective_sample_size();
+        if (ps->canonical_resampling) return canonical_normalize(ps->log_weights, ps->num_particles).ess;
+        const double L = logsumexp(ps->log_weights);
+        std::vector<double> two;
+        for (double w : ps->log_weights) two.push_back(2.0 * (w - L));
+        return o_exp(-logsumexp(two));
+    }
+    double resample() override { return ps->resample(); }
+    double log_ml() override { return ps->log_marginal_likelihood_estimate(); }
+    void read_state(double* out) override { for (size_t i = 0; i < ps->traces.size(); ++i) out[i] = (double)*ps->traces[i].data.first.back(); }
+    void read_logw(double* out) override { std::memcpy(out, ps->log_weights.data(), ps->num_particles * sizeof(double)); }
+    void read_parents(uint32_t* out) override { for (size_t i = 0; i < ps->num_particles; ++i) out[i] = (uint32_t)ps->parents[i]; }
+    int64_t time() override { return ps->traces.empty() ? 0 : (int64_t)ps->traces[0].data.first.size(); }
+};
+
+// ---- algorithm-faithful engine -----------------------------------------------------------------
+struct SoaEngine : IPf {
+    std::unique_ptr<SoaModel> model;
+    std::unique_ptr<SoaPf> pf;
+    void init_step(const double* a, const double* obs, int n) override { pf->init_step(a, obs, n); }
+    void step(const double* obs, int n) override { pf->step(obs, n); }
+    double ess(int mode) override { return pf->ess(mode == MP_ESS_FRESH); }
+    double resample() override { return pf->resample(); }
+    double log_ml() override { return pf->log_ml_estimate(); }
+    void read_state(double* out) override { std::memcpy(out, pf->x.data(), pf->x.size() * sizeof(double)); }
+    void read_logw(double* out) override { std::memcpy(out, pf->logw.data(), pf->n * sizeof(double)); }
+    void read_parents(uint32_t* out) override { std::memcpy(out, pf->parents.data(), pf->n * sizeof(uint32_t)); }
+    int64_t time() override { return pf->t; }
+};
+
+struct oracle_pf {
+    std::unique_ptr<IPf> impl;
+    bool canonical;
+    // each call runs under the handle's math mode
+    struct Scope { bool prev; Scope(bool c) : prev(canonical_mode()) { canonical_mode() = c; } ~Scope() { canonical_mode() = prev; } };
+};
+
+static HmmParams hmm_from_params(const double* p, int n) {
+    HmmParams h;
+    if (n < 2) throw Panic("hmm: params too short");
+    h.n_states = (int)p[0]; h.n_obs = (int)p[1];
+    const int S = h.n_states, O = h.n_obs;
+    if (n != 2 + S + O * S + S * S) throw Panic("hmm: params length mismatch");
+    h.prior.assign(p + 2, p + 2 + S);
+    h.emission.assign(p + 2 + S, p + 2 + S + O * S);
+    h.transition.assign(p + 2 + S + O * S, p + 2 + S + O * S + S * S);
+    return h;
+}
+
+extern "C" {
+
+const char* oracle_last_error(void) { return g_err.c_str(); }
+
+int32_t oracle_pf_create(const mp_model_desc* m, uint64_t n, uint64_t seed, const mp_shard* shard, uint32_t flags,
+                         int32_t variant, oracle_pf** out) {
+    (void)flags;
+    GUARD({
+        if (!m || !out || n == 0) throw Panic("null/zero argument");
+        const bool canon = variant & 1, soa = variant & 2, fast = variant & 4;
+        auto h = std::make_unique<oracle_pf>();
+        h->canonical = canon;
+        if (soa) {
+            auto e = std::make_unique<SoaEngine>();
+            if (m->kind == MP_MODEL_LGSSM1) {
+                if (m->n_params != 5) throw Panic("lgssm1: 5 params");
+                e->model = std::make_unique<SoaLgssm1>(LgssmParams{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4]});
+            } else if (m->kind == MP_MODEL_SPIRAL) {
+                e->model = std::make_unique<SoaSpiral>();
+            } else if (m->kind == MP_MODEL_HMM) {
+                e->model = std::make_unique<SoaHmm>(hmm_from_params(m->params, m->n_params));
+            } else throw Panic("unsupported model kind for the SoA engine");
+            e->pf = std::make_unique<SoaPf>(e->model.get(), (size_t)n, seed, canon, shard ? shard->n_global : 0, shard ? shard->slot_offset : 0);
+            h->impl = std::move(e);
+        } else {
+            if (shard && (shard->n_global != n || shard->slot_offset != 0)) throw Panic("dynamic engine is unsharded");
+            if (m->kind == MP_MODEL_LGSSM1) {
+                if (m->n_params != 5) throw Panic("lgssm1: 5 params");
+                auto e = std::make_unique<DynPf<double>>();
+                e->model = make_lgssm_model(LgssmParams{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4]});
+                e->dim_state = 1; e->dim_obs = 1;
+                e->mk_constraints = [](const double* y) { DynTrie c; c.observe("y", arc(y[0])); return c; };
+                e->mk_state = [](const double* a) { return a[0]; };
+                e->put_state = [](const double& s, double* o) { o[0] = s; };
+                e->ps = std::make_unique<DynPf<double>::PS>(e->model, (size_t)n, seed);
+                e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
+                h->impl = std::move(e);
+            } else if (m->kind == MP_MODEL_SPIRAL) {
+                auto e = std::make_unique<DynPf<Vec>>();
+                e->model = make_spiral_model();
+                e->dim_state = 2; e->dim_obs = 2;
+                e->mk_constraints = [](const double* y) { DynTrie c; c.observe("obs", arc(Vec{y[0], y[1]})); return c; };
+                e->mk_state = [](const double* a) { return Vec{a[0], a[1]}; };
+                e->put_state = [](const Vec& s, double* o) { o[0] = s[0]; o[1] = s[1]; };
+                e->ps = std::make_unique<DynPf<Vec>::PS>(e->model, (size_t)n, seed);
+                e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
+                h->impl = std::move(e);
+            } else if (m->kind == MP_MODEL_HMM) {
+                auto e = std::make_unique<HmmPf>(hmm_from_params(m->params, m->n_params));
+                e->ps = std::make_unique<HmmPf::PS>(e->model, (size_t)n, seed);
+                e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
+                h->impl = std::move(e);
+            } else throw Panic("unsupported model kind");
+        }
+        *out = h.release();
+    })
+}
+int32_t oracle_pf_set_threads(oracle_pf* h, int32_t threads) {
+    GUARD({ auto* e = dynamic_cast<SoaEngine*>(h->impl.get()); if (!e) throw Panic("threads: SoA engine only"); e->pf->threads = threads; })
+}
+int32_t oracle_pf_init_step(oracle_pf* h, const double* args0, const double* obs, int32_t n_steps) {
+    GUARD({ if (n_steps < 1) throw Panic("constraints: need at least one step"); oracle_pf::Scope s(h->canonical); h->impl->init_step(args0, obs, n_steps); })
+}
+int32_t oracle_pf_step(oracle_pf* h, const double* obs, int32_t n_steps) {
+    GUARD({ if (n_steps < 1) throw Panic("constraints: need at least one step"); oracle_pf::Scope s(h->canonical); h->impl->step(obs, n_steps); })
+}
+int32_t oracle_pf_effective_sample_size(oracle_pf* h, int32_t mode, double* out) {
+    GUARD({ oracle_pf::Scope s(h->canonical); *out = h->impl->ess(mode); })
+}
+int32_t oracle_pf_resample(oracle_pf* h, int32_t scheme, double* ltw) {
+    GUARD({ if (scheme != MP_RESAMPLE_MULTINOMIAL) throw Panic("oracle: only multinomial (the reference has no other)");
+            oracle_pf::Scope s(h->canonical); const double L = h->impl->resample(); if (ltw) *ltw = L; })
+}
+int32_t oracle_pf_log_marginal_likelihood_estimate(oracle_pf* h, double* out) {
+    GUARD({ oracle_pf::Scope s(h->canonical); *out = h->impl->log_ml(); })
+}
+int32_t oracle_pf_read_state(oracle_pf* h, double* out) { GUARD({ h->impl->read_state(out); }) }
+int32_t oracle_pf_read_log_weights(oracle_pf* h, double* out) { GUARD({ h->impl->read_logw(out); }) }
+int32_t oracle_pf_read_parents(oracle_pf* h, uint32_t* out) { GUARD({ h->impl->read_parents(out); }) }
+int32_t oracle_pf_read_trajectory(oracle_pf* h, uint64_t i, double* out, int32_t* t_steps) {
+    GUARD({ *t_steps = (int32_t)h->impl->trajectory(i, out); })
+}
+int32_t oracle_pf_time(oracle_pf* h, int64_t* out) { GUARD({ *out = h->impl->time(); }) }
+int32_t oracle_pf_destroy(oracle_pf* h) { delete h; return MP_OK; }
+
+// ---- math / rng / distribution probes ---------------------------------------------------------
+void oracle_mp_exp(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_exp(x[i]); }
+void oracle_mp_log(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_log(x[i]); }
+void oracle_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_10(ctr, key, out); }
+void oracle_u01_stream(uint64_t seed, uint32_t slot, uint32_t step, uint32_t domain, uint32_t site, int64_t n, double* out) {
+    Rng r; r.seed = seed; r.slot = slot; r.step = step; r.at(domain, site);
+    for (int64_t i = 0; i < n; ++i) out[i] = r.u01();
+}
+double oracle_logsumexp(const double* x, int64_t n, int32_t canon) {
+    oracle_pf::Scope s(canon); return logsumexp(std::vector<double>(x, x + n));
+}
+double oracle_normal_logpdf(double x, double mu, double std_, int32_t canon) { oracle_pf::Scope s(canon); return normal.logpdf(x, {mu, std_}); }
+double oracle_normal_random(uint64_t seed, uint32_t slot, uint32_t step, uint32_t domain, uint32_t site, double mu, double std_, int32_t canon) {
+    oracle_pf::Scope s(canon); Rng r; r.seed = seed; r.slot = slot; r.step = step; r.at(domain, site); return normal.random(r, {mu, std_});
+}
+double oracle_uniform_logpdf(double x, double a, double b) { try { return uniform.logpdf(x, {a, b}); } catch (const Panic&) { return NAN; } }
+double oracle_bernoulli_logpdf(int32_t v, double p) { return bernoulli.logpdf(v != 0, p); }
+double oracle_uniform2d_logpdf(double x, double y, double xmin, double xmax, double ymin, double ymax) {
+    return uniform_2d.logpdf(Vec{x, y}, Bounds{xmin, xmax, ymin, ymax});
+}
+double oracle_mvnormal_logpdf(int32_t k, const double* x, const double* mu, const double* cov) {
+    return mvnormal.logpdf(Vec(x, x + k), MvNormalParams{Vec(mu, mu + k), Mat(k, Vec(cov, cov + k * k))});
+}
+int64_t oracle_categorical_scan(double u, const double* probs, int64_t n) {
+    try { return Categorical::scan(u, std::vector<double>(probs, probs + n)); } catch (const Panic&) { return -2; }
+}
+void oracle_mvnormal_random(uint64_t seed, uint32_t slot, int32_t k, const double* mu, const double* cov, double* out) {
+    Rng r; r.seed = seed; r.slot = slot; r.at(DOM_MODEL, 0);
+    Vec v = mvnormal.random(r, MvNormalParams{Vec(mu, mu + k), Mat(k, Vec(cov, cov + k * k))});
+    for (int i = 0; i < k; ++i) out[i] = v[(size_t)i];
+}
+// canonical resampling spec, exposed piecewise
+int32_t oracle_canonical_normalize(const double* logw, int64_t n, uint64_t n_global, double* L, double* ess, uint64_t* Q, uint64_t* cum) {
+    CanonNorm c = canonical_normalize(std::vector<double>(logw, logw + n), n_global);
+    *L = c.L; *ess = c.ess; *Q = c.Q;
+    if (cum) std::memcpy(cum, c.cum.data(), (size_t)n * sizeof(uint64_t));
+    return c.m == -INFINITY ? MP_ERR_DEGENERATE : MP_OK;
+}
+uint64_t oracle_canonical_target(uint64_t k52, uint64_t Q) { return canonical_target(k52, Q); }
+double oracle_kalman_log_ml(const double* params, const double* ys, int32_t T) {
+    return kalman_log_ml(LgssmParams{params[0], params[1], params[2], params[3], params[4]}, Vec(ys, ys + T));
+}
+void oracle_lgssm_simulate_observations(const double* params, uint64_t seed, int32_t T, int32_t canon, double* out) {
+    oracle_pf::Scope s(canon);
+    Vec ys = lgssm_simulate_observations(LgssmParams{params[0], params[1], params[2], params[3], params[4]}, seed, T);
+    std::memcpy(out, ys.data(), (size_t)T * sizeof(double));
+}
+double oracle_hmm_forward(const double* params, int32_t n_params, const double* obs, int32_t T) {
+    HmmParams p = hmm_from_params(params, n_params);
+    std::vector<size_t> o; for (int t = 0; t < T; ++t) o.push_back((size_t)obs[t]);
+    return hmm_forward_alg(p, o);
+}
+
+}  // extern "C"
+
+#include "kats.hpp"

@@ -1,0 +1,369 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see rng.hpp).
+//
+// inference.hpp — CPU restatement of the Unfold combinator and of the inference library:
+//   modppl/src/modeling/dynunfold.rs:7-100          DynUnfold (simulate / generate / update Extend)
+//   modppl/src/inference/particle_filter.rs:8-121   ParticleSystem
+//   modppl/src/inference/importance.rs:12-50        importance_sampling / importance_resampling
+//   modppl/src/inference/mh.rs:9-75                 metropolis_hastings / regenerative_metropolis_hastings
+//
+// Seeded-stream convention (the reference has none; mp_philox.h defines it):
+//   * particle i / chain i owns Philox slot i; an Unfold kernel call at time t uses step t;
+//   * the i-th categorical draw of a resample uses (slot i, step = resample count, DOM_RESAMPLE);
+//   * MH iteration `it` (1-based; step 0 is the initial generate) uses step `it`; the accept
+//     uniform is (DOM_ACCEPT, site 0).
+//
+// Resampling arithmetic, two modes:
+//   literal   : particle_filter.rs:27-41 + categorical.rs:22-32 as written (fp64 running sum).
+//   canonical : the order-free fixed-point CDF the GPU uses, spelled out
+//               in `canonical_normalize` / `canonical_parent` below and in DESIGN.md §4.
+#pragma once
+#include <cstring>
+
+#include "dyngenfn.hpp"
+
+namespace oracle {
+
+// ---- dynunfold.rs ---------------------------------------------------------------------
+template <class State>
+struct DynUnfold : GenFn<std::pair<int64_t, State>, std::vector<DynTrie>, std::vector<State>> {
+    using A = std::pair<int64_t, State>;
+    using TraceT = Trace<A, std::vector<DynTrie>, std::vector<State>>;
+    using KH = DynGenFnHandler<A, State>;
+    DynGenFn<A, State> kernel;
+
+    DynUnfold() {}
+    explicit DynUnfold(DynGenFn<A, State> k) : kernel(std::move(k)) {}
+
+    TraceT simulate(Rng& rng, A fa) const override {
+        auto [final_t, state] = fa;
+        if (!(final_t >= 1)) throw Panic("assert final_t >= 1");
+        TraceT vt{{final_t, state}, {}, std::vector<State>{}, 0.};
+        for (int64_t t = 0; t < final_t; ++t) {
+            rng.step = (uint32_t)t;
+            KH g = kernel.handler(KH::Simulate, rng);
+            g.trace = Trace<A, DynTrie, State>{{t, state}, DynTrie(), std::nullopt, 0.};
+            state = kernel.func(g, {t, state});
+            vt.retv->push_back(state);
+            vt.data.push_back(std::move(g.trace.data));
+            vt.logjp += g.trace.logjp;  // stays 0: per-step logjp is never set
+        }
+        return vt;
+    }
+    std::pair<TraceT, double> generate(Rng& rng, A fa, std::vector<DynTrie> vc) const override {
+        auto [final_t, state] = fa;
+        if (!(final_t >= 1)) throw Panic("assert final_t >= 1");
+        TraceT vt{{final_t, state}, {}, std::vector<State>{}, 0.};
+        double gen_weight = 0.;
+        int64_t t = 0;
+        for (auto& constraints : vc) {
+            rng.step = (uint32_t)t;
+            KH g = kernel.handler(KH::Generate, rng);
+            g.trace = Trace<A, DynTrie, State>{{t, state}, DynTrie(), std::nullopt, 0.};
+            g.constraints = std::move(constraints);
+            state = kernel.func(g, {t, state});
+            if (!g.constraints.is_empty()) throw Panic("assert constraints.is_empty()");
+            vt.retv->push_back(state);
+            vt.data.push_back(std::move(g.trace.data));
+            vt.logjp += g.trace.logjp;
+            gen_weight += g.weight;
+            ++t;
+        }
+        return {std::move(vt), gen_weight};
+    }
+    std::tuple<TraceT, std::vector<DynTrie>, double> update(Rng& rng, TraceT vt, A fa, ArgDiff diff, std::vector<DynTrie> vc) const override {
+        const int64_t final_t = fa.first;
+        if (!(final_t >= 1)) throw Panic("assert final_t >= 1");
+        const int64_t prev_t = vt.args.first;
+        if (final_t - prev_t != (int64_t)vc.size()) throw Panic("assert final_t - prev_t == vec_constraints.len()");
+        State state = vt.retv->back();
+        double update_weight = 0.;
+        if (diff != ArgDiff::Extend) throw Panic("Can't handle GF change type");
+        int64_t k = 0;
+        for (auto& constraints : vc) {
+            const int64_t t = prev_t + k;
+            rng.step = (uint32_t)t;
+            KH g = kernel.handler(KH::Generate, rng);
+            g.trace = Trace<A, DynTrie, State>{{t, state}, DynTrie(), std::nullopt, 0.};
+            g.constraints = std::move(constraints);
+            state = kernel.func(g, {t, state});
+            if (!g.constraints.is_empty()) throw Panic("assert constraints.is_empty()");
+            vt.args.first += 1;
+            vt.retv->push_back(state);
+            vt.data.push_back(std::move(g.trace.data));
+            vt.logjp += g.trace.logjp;
+            update_weight += g.weight;
+            ++k;
+        }
+        return {std::move(vt), std::vector<DynTrie>((size_t)(final_t - prev_t)), update_weight};
+    }
+};
+
+// ---- canonical (order-free) normalisation: the spec both oracle and GPU implement ---------
+inline int ceil_log2_u64(uint64_t n) {
+    int b = 0;
+    while (((uint64_t)1 << b) < n) ++b;
+    return b;
+}
+struct CanonNorm {
+    int S = 0;            // fixed-point scale: q = rint(e * 2^S), S = 62 - ceil(log2(N_global))
+    double m = -INFINITY; // max log-weight
+    uint64_t Q = 0;       // sum of q_i
+    uint64_t Q2 = 0;      // sum of rint(e_i^2 * 2^S)
+    double L = -INFINITY; // log total weight = m + log(Q * 2^-S)
+    double ess = 0.;      // (Q*2^-S)^2 / (Q2*2^-S)
+    std::vector<uint64_t> cum;  // inclusive prefix sums of q
+};
+inline double ldexp_pow2(int e) { return std::ldexp(1.0, e); }
+inline CanonNorm canonical_normalize(const std::vector<double>& logw, uint64_t n_global) {
+    CanonNorm c;
+    c.S = 62 - ceil_log2_u64(n_global);
+    for (double x : logw) c.m = std::fmax(c.m, x);
+    c.cum.resize(logw.size());
+    if (c.m == -INFINITY) return c;  // degenerate: caller raises (reference: NaN weights -> assert panic)
+    const double scale = ldexp_pow2(c.S), inv = ldexp_pow2(-c.S);
+    uint64_t run = 0;
+    for (size_t i = 0; i < logw.size(); ++i) {
+        const double e = mp_exp(logw[i] - c.m);
+        const uint64_t q = (uint64_t)std::rint(e * scale);
+        c.Q2 += (uint64_t)std::rint((e * e) * scale);
+        run += q;
+        c.cum[i] = run;
+    }
+    c.Q = run;
+    const double Qs = (double)c.Q * inv, Q2s = (double)c.Q2 * inv;
+    c.L = c.m + mp_log(Qs);
+    c.ess = (Qs * Qs) / Q2s;
+    return c;
+}
+// target = max(1, ceil(k * Q / 2^52)); parent = first i with cum[i] >= target.
+inline uint64_t canonical_target(uint64_t k52, uint64_t Q) {
+    const unsigned __int128 p = (unsigned __int128)k52 * Q + (((unsigned __int128)1 << 52) - 1);
+    const uint64_t t = (uint64_t)(p >> 52);
+    return t < 1 ? 1 : t;
+}
+inline size_t canonical_parent(const std::vector<uint64_t>& cum, uint64_t target) {
+    size_t lo = 0, hi = cum.size();  // first index with cum >= target
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (cum[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// ---- particle_filter.rs ---------------------------------------------------------------
+template <class Args, class Data, class Ret>
+struct ParticleSystem {
+    using F = GenFn<std::pair<int64_t, Args>, Data, Ret>;
+    using TraceT = Trace<std::pair<int64_t, Args>, Data, Ret>;
+    size_t num_particles;
+    const F* model;
+    std::vector<TraceT> traces;
+    std::vector<double> log_weights, log_normalized_weights, two_times_log_normalized_weights, normalized_weights;
+    std::vector<size_t> parents;
+    uint64_t seed;              // stands in for `rng: ThreadRng`
+    uint32_t resample_count = 0;
+    double log_ml_estimate = 0.;
+    bool canonical_resampling = false;
+    bool fast_search = false;   // binary search over the same sequential running sum (index-identical)
+    double canon_ess_stale;     // canonical-mode ESS as of the last resample (1/N before any)
+
+    ParticleSystem(const F& m, size_t n, uint64_t seed_)  // particle_filter.rs:44-57
+        : num_particles(n), model(&m), log_weights(n, 0.), log_normalized_weights(n, 0.),
+          two_times_log_normalized_weights(n, 0.), normalized_weights(n, 0.), parents(n, 0), seed(seed_),
+          canon_ess_stale(1.0 / (double)n) {}
+
+    Rng rng_for(size_t i) const { Rng r; r.seed = seed; r.slot = (uint32_t)i; return r; }
+
+    double normalize_weights() {  // :27-35
+        const double log_total_weight = logsumexp(log_weights);
+        for (size_t i = 0; i < num_particles; ++i) {
+            log_normalized_weights[i] = log_weights[i] - log_total_weight;
+            two_times_log_normalized_weights[i] = 2.0 * log_normalized_weights[i];
+            normalized_weights[i] = o_exp(log_normalized_weights[i]);
+        }
+        return log_total_weight;
+    }
+    void multinomial_resampling() {  // :37-41
+        std::vector<double> cdf;
+        if (fast_search) {
+            Categorical::check_sum(normalized_weights);
+            cdf.resize(num_particles);
+            double t = 0.;
+            for (size_t i = 0; i < num_particles; ++i) { t += normalized_weights[i]; cdf[i] = t; }
+        }
+        for (size_t i = 0; i < num_particles; ++i) {
+            Rng r = rng_for(i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+            int64_t p;
+            if (!fast_search) {
+                p = categorical.random(r, normalized_weights);  // clones + re-sums per draw in the reference
+            } else {
+                const double u = r.u01();
+                if (!(0. < u)) p = -1;
+                else {  // first x with cdf[x] >= u  ==  the while(t<u) scan's exit index
+                    size_t lo = 0, hi = num_particles;
+                    while (lo < hi) { size_t mid = (lo + hi) / 2; if (cdf[mid] >= u) hi = mid; else lo = mid + 1; }
+                    if (lo >= num_particles) throw Panic("categorical: index out of bounds");
+                    p = (int64_t)lo;
+                }
+            }
+            if (p < 0) throw Panic("categorical returned -1 (u == 0): usize index panic in the reference");
+            parents[i] = (size_t)p;
+        }
+    }
+    void init_step(Args args, Data constraints) {  // :60-70
+        for (size_t i = 0; i < num_particles; ++i) {
+            Rng r = rng_for(i);
+            auto [trace, log_weight] = model->generate(r, {1, args}, constraints);
+            traces.push_back(std::move(trace));
+            log_weights[i] = log_weight;
+        }
+    }
+    void step(Data constraints) {  // :73-96 (consumes self in the reference)
+        std::vector<TraceT> tmp_traces;
+        std::vector<double> tmp_log_weights;
+        size_t i = 0;
+        for (auto& trace : traces) {
+            auto args = trace.args;
+            std::pair<int64_t, Args> new_args{args.first + 1, args.second};
+            Rng r = rng_for(i);
+            auto [new_trace, discard, log_weight] = model->update(r, std::move(trace), new_args, ArgDiff::Extend, constraints);
+            (void)discard;
+            tmp_traces.push_back(std::move(new_trace));
+            tmp_log_weights.push_back(log_weights[i] + log_weight);
+            ++i;
+        }
+        traces = std::move(tmp_traces);
+        log_weights = std::move(tmp_log_weights);
+    }
+    double effective_sample_size() const {  // :98-100 (stale buffers: SURVEY §7 quirk)
+        if (canonical_resampling) return canon_ess_stale;
+        return o_exp(-logsumexp(two_times_log_normalized_weights));
+    }
+    double resample() {  // :103-116
+        if (log_weights.size() != num_particles) throw Panic("resample before init_step (index out of bounds)");
+        double log_total_weight;
+        if (!canonical_resampling) {
+            log_total_weight = normalize_weights();
+            log_ml_estimate += log_total_weight - o_ln((double)num_particles);
+            multinomial_resampling();
+        } else {
+            CanonNorm c = canonical_normalize(log_weights, num_particles);
+            if (c.m == -INFINITY) throw Panic("all log-weights are -inf: normalized weights are NaN");
+            log_total_weight = c.L;
+            canon_ess_stale = c.ess;
+            log_ml_estimate += log_total_weight - o_ln((double)num_particles);
+            for (size_t i = 0; i < num_particles; ++i) {
+                Rng r = rng_for(i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+                parents[i] = canonical_parent(c.cum, canonical_target(r.u52(), c.Q));
+            }
+        }
+        ++resample_count;
+        std::vector<TraceT> tmp_traces;
+        tmp_traces.reserve(num_particles);
+        for (size_t i = 0; i < num_particles; ++i) tmp_traces.push_back(traces[parents[i]]);
+        traces = std::move(tmp_traces);
+        std::fill(log_weights.begin(), log_weights.end(), 0.);
+        return log_total_weight;
+    }
+    double log_marginal_likelihood_estimate() const {  // :119-121
+        if (canonical_resampling) {
+            CanonNorm c = canonical_normalize(log_weights, num_particles);
+            return log_ml_estimate + c.L - o_ln((double)num_particles);
+        }
+        return log_ml_estimate + logsumexp(log_weights) - o_ln((double)num_particles);
+    }
+};
+
+// ---- importance.rs --------------------------------------------------------------------
+template <class Args, class Data, class Ret>
+struct ImportanceResult {
+    std::vector<Trace<Args, Data, Ret>> traces;
+    std::vector<double> log_normalized_weights;
+    double log_ml_estimate;
+    std::vector<size_t> resampled_indices;
+};
+template <class Args, class Data, class Ret>
+ImportanceResult<Args, Data, Ret> importance_sampling(uint64_t seed, const GenFn<Args, Data, Ret>& model, Args model_args,
+                                                      Data constraints, uint32_t num_samples, bool canonical = false,
+                                                      CanonNorm* canon_out = nullptr) {
+    ImportanceResult<Args, Data, Ret> out;
+    std::vector<double> w;
+    for (uint32_t i = 0; i < num_samples; ++i) {  // importance.rs:18-20
+        Rng r; r.seed = seed; r.slot = i;
+        auto [tr, wi] = model.generate(r, model_args, constraints);
+        out.traces.push_back(std::move(tr));
+        w.push_back(wi);
+    }
+    double log_total_weight;
+    if (!canonical) {
+        log_total_weight = logsumexp(w);  // :21
+    } else {
+        CanonNorm c = canonical_normalize(w, num_samples);
+        if (c.m == -INFINITY) throw Panic("all log-weights are -inf");
+        log_total_weight = c.L;
+        if (canon_out) *canon_out = std::move(c);
+    }
+    out.log_ml_estimate = log_total_weight - o_ln((double)num_samples);  // :22
+    for (double wi : w) out.log_normalized_weights.push_back(wi - log_total_weight);  // :23-25
+    return out;
+}
+template <class Args, class Data, class Ret>
+ImportanceResult<Args, Data, Ret> importance_resampling(uint64_t seed, const GenFn<Args, Data, Ret>& model, Args model_args,
+                                                        Data constraints, uint32_t num_samples, uint32_t num_ret_samples,
+                                                        bool canonical = false) {
+    CanonNorm c;
+    auto out = importance_sampling(seed, model, model_args, constraints, num_samples, canonical, &c);
+    if (!canonical) {
+        std::vector<double> probs;  // :44
+        for (double w : out.log_normalized_weights) probs.push_back(o_exp(w));
+        for (uint32_t j = 0; j < num_ret_samples; ++j) {  // :45-47
+            Rng r; r.seed = seed; r.slot = j; r.step = 0; r.at(DOM_IS, 0);
+            const int64_t p = categorical.random(r, probs);
+            if (p < 0) throw Panic("categorical returned -1");
+            out.resampled_indices.push_back((size_t)p);
+        }
+    } else {
+        for (uint32_t j = 0; j < num_ret_samples; ++j) {
+            Rng r; r.seed = seed; r.slot = j; r.step = 0; r.at(DOM_IS, 0);
+            out.resampled_indices.push_back(canonical_parent(c.cum, canonical_target(r.u52(), c.Q)));
+        }
+    }
+    return out;
+}
+
+// ---- mh.rs ----------------------------------------------------------------------------
+// The proposal receives (Weak<Trace>, ProposalArgs); here a const pointer to the trace.
+template <class Args, class Ret>
+using DynTraceT = Trace<Args, DynTrie, Ret>;
+
+template <class Args, class Ret, class PArgs>
+std::pair<DynTraceT<Args, Ret>, bool> metropolis_hastings(
+    Rng& rng, const GenFn<Args, DynTrie, Ret>& model, DynTraceT<Args, Ret> trace,
+    const GenFn<std::pair<const DynTraceT<Args, Ret>*, PArgs>, DynTrie, int>& proposal, PArgs proposal_args,
+    double* alpha_out = nullptr) {
+    DynTraceT<Args, Ret> prev_trace = trace;  // mh.rs:15
+    auto [fwd_choices, fwd_weight] = proposal.propose(rng, {&trace, proposal_args});  // :17-19
+    Args args = trace.args;
+    auto [new_trace, discard, weight] = model.update(rng, std::move(trace), args, ArgDiff::NoChange, std::move(fwd_choices));  // :23
+    const double bwd_weight = proposal.assess(rng, {&new_trace, proposal_args}, std::move(discard));  // :25-27
+    const double alpha = weight - fwd_weight + bwd_weight;  // :34
+    if (alpha_out) *alpha_out = alpha;
+    rng.at(DOM_ACCEPT, 0);
+    if (o_ln(rng.u01()) < alpha) return {std::move(new_trace), true};  // :35-36
+    return {std::move(prev_trace), false};
+}
+
+template <class Args, class Ret>
+std::pair<DynTraceT<Args, Ret>, bool> regenerative_metropolis_hastings(
+    Rng& rng, const GenFn<Args, DynTrie, Ret>& model, DynTraceT<Args, Ret> trace, const AddrMap& mask,
+    double* weight_out = nullptr) {
+    DynTraceT<Args, Ret> prev_trace = trace;  // mh.rs:59
+    Args args = trace.args;
+    auto [new_trace, weight] = model.regenerate(rng, std::move(trace), args, ArgDiff::NoChange, mask);  // :61
+    if (weight_out) *weight_out = weight;
+    rng.at(DOM_ACCEPT, 0);
+    if (o_ln(rng.u01()) < weight) return {std::move(new_trace), true};  // :62-63
+    return {std::move(prev_trace), false};
+}
+
+}  // namespace oracle

@@ -1,0 +1,209 @@
+"""ctypes loader for oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+VARIANT_CANONICAL = 1
+VARIANT_SOA = 2
+VARIANT_FAST_SEARCH = 4
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dim_state", C.c_int32), ("dim_obs", C.c_int32), ("n_params", C.c_int32),
+                ("params", C.POINTER(C.c_double))]
+
+
+class Shard(C.Structure):
+    _fields_ = [("n_global", C.c_uint64), ("slot_offset", C.c_uint64)]
+
+
+def build(force=False):
+    srcs = [os.path.join(ORACLE_DIR, "src", f) for f in os.listdir(os.path.join(ORACLE_DIR, "src"))]
+    srcs += [os.path.join(ROOT, "modppl_amd", "csrc", "mp_math.h"), os.path.join(ROOT, "include", "modppl_hip.h")]
+    stale = (not os.path.exists(SO)) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", ORACLE_DIR, "liboracle.so"], check=True, capture_output=True)
+    return SO
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    # On the GPU box the prebuilt .so travels with the snapshot; rebuild only if sources are newer.
+    try:
+        build()
+    except Exception:
+        if not os.path.exists(SO):
+            raise
+    L = C.CDLL(SO)
+    d, i32, u32, i64, u64, p = C.c_double, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_void_p
+    dp = C.POINTER(C.c_double)
+    L.oracle_last_error.restype = C.c_char_p
+    L.oracle_pf_create.argtypes = [C.POINTER(ModelDesc), u64, u64, C.POINTER(Shard), u32, i32, C.POINTER(p)]
+    L.oracle_pf_set_threads.argtypes = [p, i32]
+    L.oracle_pf_init_step.argtypes = [p, dp, dp, i32]
+    L.oracle_pf_step.argtypes = [p, dp, i32]
+    L.oracle_pf_effective_sample_size.argtypes = [p, i32, dp]
+    L.oracle_pf_resample.argtypes = [p, i32, dp]
+    L.oracle_pf_log_marginal_likelihood_estimate.argtypes = [p, dp]
+    L.oracle_pf_read_state.argtypes = [p, dp]
+    L.oracle_pf_read_log_weights.argtypes = [p, dp]
+    L.oracle_pf_read_parents.argtypes = [p, C.POINTER(u32)]
+    L.oracle_pf_read_trajectory.argtypes = [p, u64, dp, C.POINTER(i32)]
+    L.oracle_pf_time.argtypes = [p, C.POINTER(i64)]
+    L.oracle_pf_destroy.argtypes = [p]
+    L.oracle_mp_exp.argtypes = [dp, i64, dp]
+    L.oracle_mp_log.argtypes = [dp, i64, dp]
+    L.oracle_mp_exp.restype = None
+    L.oracle_mp_log.restype = None
+    L.oracle_philox.argtypes = [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.oracle_philox.restype = None
+    L.oracle_u01_stream.argtypes = [u64, u32, u32, u32, u32, i64, dp]
+    L.oracle_u01_stream.restype = None
+    L.oracle_logsumexp.argtypes = [dp, i64, i32]
+    L.oracle_logsumexp.restype = d
+    L.oracle_normal_logpdf.argtypes = [d, d, d, i32]
+    L.oracle_normal_logpdf.restype = d
+    L.oracle_normal_random.argtypes = [u64, u32, u32, u32, u32, d, d, i32]
+    L.oracle_normal_random.restype = d
+    L.oracle_uniform_logpdf.argtypes = [d, d, d]
+    L.oracle_uniform_logpdf.restype = d
+    L.oracle_bernoulli_logpdf.argtypes = [i32, d]
+    L.oracle_bernoulli_logpdf.restype = d
+    L.oracle_uniform2d_logpdf.argtypes = [d] * 6
+    L.oracle_uniform2d_logpdf.restype = d
+    L.oracle_mvnormal_logpdf.argtypes = [i32, dp, dp, dp]
+    L.oracle_mvnormal_logpdf.restype = d
+    L.oracle_mvnormal_random.argtypes = [u64, u32, i32, dp, dp, dp]
+    L.oracle_mvnormal_random.restype = None
+    L.oracle_categorical_scan.argtypes = [d, dp, i64]
+    L.oracle_categorical_scan.restype = i64
+    L.oracle_canonical_normalize.argtypes = [dp, i64, u64, dp, dp, C.POINTER(u64), C.POINTER(u64)]
+    L.oracle_canonical_target.argtypes = [u64, u64]
+    L.oracle_canonical_target.restype = u64
+    L.oracle_kalman_log_ml.argtypes = [dp, dp, i32]
+    L.oracle_kalman_log_ml.restype = d
+    L.oracle_lgssm_simulate_observations.argtypes = [dp, u64, i32, i32, dp]
+    L.oracle_lgssm_simulate_observations.restype = None
+    L.oracle_hmm_forward.argtypes = [dp, i32, dp, i32]
+    L.oracle_hmm_forward.restype = d
+    L.oracle_kat_update_weights.argtypes = [u64, dp]
+    L.oracle_kat_residual_panics.argtypes = [u64]
+    L.oracle_kat_update.argtypes = [u64, dp]
+    L.oracle_kat_regenerate.argtypes = [u64, dp]
+    L.oracle_kat_simulate.argtypes = [u64]
+    L.oracle_kat_simulate.restype = d
+    _lib = L
+    return L
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"oracle status {code}: {msg}")
+        self.code = code
+
+
+class OraclePF:
+    """Drives the restated ParticleSystem with the same call sequence as modppl_amd.ParticleSystem."""
+
+    def __init__(self, kind, dim_state, dim_obs, params, n, seed, variant, shard=None, threads=1):
+        self.L = load()
+        self.n, self.dim_state, self.dim_obs = n, dim_state, dim_obs
+        self._params = np.ascontiguousarray(params, dtype=np.float64)
+        desc = ModelDesc(kind, dim_state, dim_obs, len(self._params), dptr(self._params))
+        sh = Shard(*shard) if shard else None
+        h = C.c_void_p()
+        self._ck(self.L.oracle_pf_create(C.byref(desc), n, seed, C.byref(sh) if sh else None, 0, variant, C.byref(h)))
+        self.h = h
+        if threads > 1:
+            self._ck(self.L.oracle_pf_set_threads(self.h, threads))
+
+    def _ck(self, code):
+        if code != 0:
+            raise OracleError(code, self.L.oracle_last_error().decode())
+
+    def init_step(self, obs, args0=None):
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.dim_obs)
+        a = None if args0 is None else dptr(np.ascontiguousarray(args0, dtype=np.float64))
+        self._ck(self.L.oracle_pf_init_step(self.h, a, dptr(obs), obs.shape[0]))
+
+    def step(self, obs):
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.dim_obs)
+        self._ck(self.L.oracle_pf_step(self.h, dptr(obs), obs.shape[0]))
+
+    def effective_sample_size(self, mode=0):
+        out = C.c_double()
+        self._ck(self.L.oracle_pf_effective_sample_size(self.h, mode, C.byref(out)))
+        return out.value
+
+    def resample(self, scheme=0):
+        out = C.c_double()
+        self._ck(self.L.oracle_pf_resample(self.h, scheme, C.byref(out)))
+        return out.value
+
+    def log_marginal_likelihood_estimate(self):
+        out = C.c_double()
+        self._ck(self.L.oracle_pf_log_marginal_likelihood_estimate(self.h, C.byref(out)))
+        return out.value
+
+    def state(self):
+        x = np.empty((self.n, self.dim_state))
+        self._ck(self.L.oracle_pf_read_state(self.h, dptr(x)))
+        return x
+
+    def log_weights(self):
+        w = np.empty(self.n)
+        self._ck(self.L.oracle_pf_read_log_weights(self.h, dptr(w)))
+        return w
+
+    def parents(self):
+        p = np.empty(self.n, dtype=np.uint32)
+        self._ck(self.L.oracle_pf_read_parents(self.h, p.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return p
+
+    def trajectory(self, i, max_t=4096):
+        out = np.empty((max_t, self.dim_state))
+        t = C.c_int32()
+        self._ck(self.L.oracle_pf_read_trajectory(self.h, i, dptr(out), C.byref(t)))
+        return out[: t.value].copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.oracle_pf_destroy(self.h)
+        except Exception:
+            pass
+
+
+LGSSM_PARAMS = np.array([0.0, 1.0, 0.9, 0.5, 1.0])  # mu0, sig0, a, sig_x, sig_y
+DATA_SEED = 20241008
+
+
+def lgssm_observations(T=50, seed=DATA_SEED, canonical=True, params=LGSSM_PARAMS):
+    L = load()
+    ys = np.empty(T)
+    L.oracle_lgssm_simulate_observations(dptr(np.ascontiguousarray(params)), seed, T, int(canonical), dptr(ys))
+    return ys
+
+
+def kalman_log_ml(ys, params=LGSSM_PARAMS):
+    L = load()
+    ys = np.ascontiguousarray(ys, dtype=np.float64)
+    return L.oracle_kalman_log_ml(dptr(np.ascontiguousarray(params)), dptr(ys), len(ys))
