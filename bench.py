@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py — particle-steps/sec of the LGSSM SMC hot path on MI355X (BASELINE.json metric).
+
+A "step" is one SMC time step over the whole particle population: `ParticleSystem::step`
+(propagate + weight) followed by `ParticleSystem::resample` (normalise, multinomial draw, gather)
+— the loop body of modppl/tests/smc.rs:79-84.  Workload at N=1: BASELINE.json configs[1]
+(LGSSM d=1, 2^20 particles, synthetic observations simulated from the model with Philox seed
+20241008).  State is resident in HBM before the timed region; the timed region is K steps,
+bracketed by barrier + synchronize, max over ranks.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+N_PER_GPU = 1 << 20
+DIM = 1
+# algorithmic bytes per particle per launch (B(d) = 32d + 64 per particle-step)
+BYTES_K = {"propagate": 16 * DIM + 16, "normalize_scan": 8 + 8 + 8, "resample_gather": 8 + 4 + 4 + 16 * DIM + 8}
+BYTES_STEP = 32 * DIM + 64
+
+
+def cpu_baseline(ys, n, target_seconds=12.0):
+    """The CPU restatement (oracle/, literal arithmetic, SoA engine), 1 core, on a bounded sample of
+    the same workload: full N, as many SMC steps as fit in ~target_seconds."""
+    from tests import oracle_lib as O
+
+    pf = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, 20241008, O.VARIANT_SOA, threads=1)
+    pf.init_step(ys[:1])
+    pf.resample()
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < len(ys) - 1 and (time.perf_counter() - t0) < target_seconds:
+        pf.step(ys[steps + 1:steps + 2])
+        pf.resample()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} SMC steps (step+resample) at N={n}, C++ restatement of modppl's CPU path "
+                      f"(SoA engine, literal libm arithmetic, sequential fp64 CDF + binary search), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import modppl_amd
+    from modppl_amd import capi
+    from tests import oracle_lib as O  # observations + closed-form ground truth + cpu_baseline only
+
+    n = args.particles
+    K, W = args.steps, args.warmup
+    T = 1 + W + K
+    ys = O.lgssm_observations(T)
+    kalman = O.kalman_log_ml(ys)
+
+    # round-1: ranks run independent filters on disjoint Philox slot ranges (the sharded filter with
+    # RCCL weight all-reduce + particle all-to-all is wired in modppl_amd.distributed when present)
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, 20241008 + rank, device=local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        pf.synchronize()
+
+    pf.init_step(None, ys[:1])
+    pf.resample(sync=False)
+    for t in range(1, 1 + W):
+        pf.step(ys[t:t + 1])
+        pf.resample(sync=False)
+    barrier()
+    pf.set_timing(True)  # hipEvent pairs around every launch, on the stream the kernels run on
+    t0 = time.perf_counter()
+    for t in range(1 + W, T):
+        pf.step(ys[t:t + 1])
+        pf.resample(sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    fam = {"propagate": pf.get_timing(capi.MP_K_PROPAGATE), "normalize_scan": pf.get_timing(capi.MP_K_NORMALIZE_SCAN),
+           "resample_gather": pf.get_timing(capi.MP_K_RESAMPLE_GATHER)}
+    pf.set_timing(False)
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    lml = pf.log_marginal_likelihood_estimate()
+
+    if rank == 0:
+        avg_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in fam.items()}
+        dom = max(avg_us, key=lambda k: avg_us[k])
+        achieved = BYTES_K[dom] * n / (avg_us[dom] * 1e-6) / 1e9
+        out = {
+            "metric": "particle-steps/sec, 1M-particle LGSSM SMC (step + multinomial resample per time step)",
+            "value": n * world * K / dt,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (observations simulated from the model, Philox seed 20241008)",
+            "config": {"workload": "LGSSM d=1 bootstrap SMC, resample every step (BASELINE.json configs[1])",
+                       "particles_per_gpu": n, "time_steps_timed": K, "parallelism": "1 GPU" if world == 1 else f"{world} independent shards"},
+            "log_ml": lml,
+            "log_ml_abs_err_vs_kalman": abs(lml - kalman),
+            "step_bytes_per_particle": BYTES_STEP,
+            "step_hbm_frac": BYTES_STEP * n * K / dt / 1e9 / HBM_PEAK_GBPS,
+            "kernel_avg_us": avg_us,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "bytes_per_launch": BYTES_K[dom] * n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ys, n)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,28 @@
+/* modppl_hip_probe.h — device self-test probes of libmodppl_hip.so.
+ *
+ * Not part of the drop-in boundary: these evaluate the path's scalar building blocks on the GPU
+ * over caller-provided arrays so that tests can compare them bit for bit with the CPU checker
+ * (deterministic exp/log of mp_math.h, IEEE sqrt/div, the Philox stream, the polar normal
+ * sampler of modppl/src/modeling/dists/normal.rs:19-27).
+ */
+#ifndef MODPPL_HIP_PROBE_H
+#define MODPPL_HIP_PROBE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum mp_probe_op { MP_PROBE_EXP = 0, MP_PROBE_LOG = 1, MP_PROBE_SQRT = 2, MP_PROBE_DIV = 3, MP_PROBE_NORMAL_LOGPDF = 4 };
+/* out[i] = op(a[i], b[i], c[i]) on the device; b, c may be NULL for unary ops (host pointers). */
+int32_t mp_probe_math(int32_t op, const double* a, const double* b, const double* c, int64_t n, double* out, int32_t device);
+/* out[i] = normal.random with Philox (seed, slot = slot0 + i, step, domain, site) and params (mu, sd). */
+int32_t mp_probe_normal_sample(uint64_t seed, uint32_t slot0, uint32_t step, uint32_t domain, uint32_t site, double mu, double sd,
+                               int64_t n, double* out, int32_t device);
+/* out[2*i], out[2*i+1] = the two u01 of Philox block (slot0 + i, step, domain, site, attempt). */
+int32_t mp_probe_u01(uint64_t seed, uint32_t slot0, uint32_t step, uint32_t domain, uint32_t site, uint32_t attempt, int64_t n,
+                     double* out, int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

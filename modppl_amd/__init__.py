@@ -1,0 +1,8 @@
+"""modppl_amd — the MI355X-native SMC / importance / MH hot path of agarret7/modppl.
+
+Only what the path needs: csrc/ (HIP kernels + the C ABI of include/modppl_hip.h) and the host-side
+mirror of the reference's inference entry points.
+"""
+from .capi import ModpplError  # noqa: F401
+from .inference import ParticleSystem  # noqa: F401
+from .models import UnfoldModel, lgssm_model  # noqa: F401

@@ -1,0 +1,90 @@
+"""ctypes binding of include/modppl_hip.h (the C ABI of the MI355X hot path).
+
+There is no CPU fallback: if the library is missing, or no GPU is visible when a handle is
+created, this raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MP_OK = 0
+MP_ERR_INVALID_ARG, MP_ERR_STATE, MP_ERR_CONSTRAINTS, MP_ERR_DEGENERATE, MP_ERR_HIP, MP_ERR_UNSUPPORTED = 1, 2, 3, 4, 5, 6
+
+MP_MODEL_LGSSM1, MP_MODEL_SPIRAL, MP_MODEL_HMM, MP_MODEL_BEARINGS, MP_MODEL_LGSSM_BAND = 1, 2, 3, 4, 5
+MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC = 0, 1
+MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
+MP_PF_RECORD_HISTORY = 1
+MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER = 0, 1, 2
+
+# every symbol include/modppl_hip.h declares (tests/test_capi_symbols.py checks the export table)
+SYMBOLS = [
+    "mp_last_error", "mp_device_count", "mp_pf_create", "mp_pf_init_step", "mp_pf_step", "mp_pf_effective_sample_size",
+    "mp_pf_resample", "mp_pf_log_marginal_likelihood_estimate", "mp_pf_read_state", "mp_pf_read_log_weights",
+    "mp_pf_read_parents", "mp_pf_read_trajectory", "mp_pf_time", "mp_pf_run", "mp_pf_synchronize", "mp_pf_destroy",
+    "mp_pf_set_timing", "mp_pf_get_timing", "mp_importance_resampling",
+    # include/modppl_hip_probe.h
+    "mp_probe_math", "mp_probe_normal_sample", "mp_probe_u01",
+]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dim_state", C.c_int32), ("dim_obs", C.c_int32), ("n_params", C.c_int32),
+                ("params", C.POINTER(C.c_double))]
+
+
+class Shard(C.Structure):
+    _fields_ = [("n_global", C.c_uint64), ("slot_offset", C.c_uint64)]
+
+
+class ModpplError(RuntimeError):
+    """Stands for a reference `panic!` (the reference has no Result type anywhere)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"modppl_hip status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.SO
+    if not os.path.exists(so):
+        raise ModpplError(MP_ERR_HIP, f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                      "(the gfx950 path has no CPU fallback)")
+    L = C.CDLL(so)
+    d, i32, u32, i64, u64, p = C.c_double, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_void_p
+    dp = C.POINTER(C.c_double)
+    L.mp_last_error.restype = C.c_char_p
+    L.mp_device_count.restype = i32
+    L.mp_pf_create.argtypes = [C.POINTER(ModelDesc), u64, u64, C.POINTER(Shard), u32, i32, p, C.POINTER(p)]
+    L.mp_pf_init_step.argtypes = [p, dp, dp, i32]
+    L.mp_pf_step.argtypes = [p, dp, i32]
+    L.mp_pf_effective_sample_size.argtypes = [p, i32, dp]
+    L.mp_pf_resample.argtypes = [p, i32, dp]
+    L.mp_pf_log_marginal_likelihood_estimate.argtypes = [p, dp]
+    L.mp_pf_read_state.argtypes = [p, dp]
+    L.mp_pf_read_log_weights.argtypes = [p, dp]
+    L.mp_pf_read_parents.argtypes = [p, C.POINTER(u32)]
+    L.mp_pf_read_trajectory.argtypes = [p, u64, dp, C.POINTER(i32)]
+    L.mp_pf_time.argtypes = [p, C.POINTER(i64)]
+    L.mp_pf_run.argtypes = [p, dp, dp, i32, i32]
+    L.mp_pf_synchronize.argtypes = [p]
+    L.mp_pf_destroy.argtypes = [p]
+    L.mp_pf_set_timing.argtypes = [p, i32]
+    L.mp_pf_get_timing.argtypes = [p, i32, dp, C.POINTER(u64)]
+    L.mp_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
+    L.mp_probe_math.argtypes = [i32, dp, dp, dp, i64, dp, i32]
+    L.mp_probe_normal_sample.argtypes = [u64, u32, u32, u32, u32, d, d, i64, dp, i32]
+    L.mp_probe_u01.argtypes = [u64, u32, u32, u32, u32, u32, i64, dp, i32]
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != MP_OK:
+        raise ModpplError(code, load().mp_last_error().decode())

@@ -1,0 +1,68 @@
+// mp_dists.h — the distributions of the hot path as inlinable host/device functions, same
+// operations in the same order as modppl's CPU code:
+//   normal      modppl/src/modeling/dists/normal.rs:13-27   (logpdf; Marsaglia polar sampler)
+//   uniform     modppl/src/modeling/dists/uniform.rs:21-33
+//   bernoulli   modppl/src/modeling/dists/bernoulli.rs:11-19
+//   categorical modppl/src/modeling/dists/categorical.rs:22-32 (small fixed-size tables)
+// Transcendentals are mp_exp/mp_log (mp_math.h); compile with -ffp-contract=off.
+#pragma once
+#include "mp_math.h"
+#include "mp_philox.h"
+
+// Sequential uniform stream of ONE site: the n-th uniform is half (n & 1) of Philox block n >> 1
+// (counter layout: mp_philox.h).  `blk` counts whole blocks for samplers that use both halves.
+struct mp_site {
+    mp_stream s;
+    uint32_t domain, site;
+    uint32_t blk;
+    MP_PHD mp_site(const mp_stream& s_, uint32_t domain_, uint32_t site_) : s(s_), domain(domain_), site(site_), blk(0) {}
+    MP_PHD mp_u64x2 next_block() { return s.draw(domain, site, blk++); }
+};
+
+// normal.rs:13-17
+MP_HD double mp_normal_logpdf(double x, double mu, double sd) {
+    const double z = (x - mu) / sd;
+    const double az = fabs(z);
+    return -(az * az + mp_log(MP_2PI)) / 2. - mp_log(sd);
+}
+
+// normal.rs:19-27: u,v = 2*u01-1; r = u*u+v*v; reject r == 0 or r > 1 (the reference recurses);
+// c = sqrt(-2 ln r / r); return u*c*std + mu.  Only u*c is used, as in the reference.
+MP_HD double mp_normal_sample(mp_site& st, double mu, double sd) {
+    for (;;) {
+        const mp_u64x2 b = st.next_block();
+        const double u = mp_u01(b.a) * 2. - 1.;
+        const double v = mp_u01(b.b) * 2. - 1.;
+        const double r = u * u + v * v;
+        if (r == 0. || r > 1.) continue;
+        const double c = mp_sqrt(-2. * mp_log(r) / r);
+        return u * c * sd + mu;
+    }
+}
+
+// uniform.rs:21-33 (bounds are model constants here; a >= b is rejected on the host)
+MP_HD double mp_uniform_logpdf(double x, double a, double b) { return (a <= x && x <= b) ? -mp_log(b - a) : MP_NEG_INF; }
+MP_HD double mp_uniform_sample(mp_site& st, double a, double b) {
+    const mp_u64x2 blk = st.next_block();
+    return mp_u01(blk.a) * (b - a) + a;
+}
+
+// bernoulli.rs:11-19
+MP_HD double mp_bernoulli_logpdf(bool v, double p) { return mp_log(v ? p : 1. - p); }
+MP_HD bool mp_bernoulli_sample(mp_site& st, double p) {
+    const mp_u64x2 blk = st.next_block();
+    return p > mp_u01(blk.a);
+}
+
+// categorical.rs:22-32 over a small table: t=0; x=0; while t<u {t+=p[x]; x+=1}; return x-1.
+// u == 0 returns -1 in the reference (and then panics as a usize index); here it is clamped to 0.
+// Running past the table (sum < u) is an index panic there; here it is clamped to n-1.
+MP_HD int mp_categorical_scan(double u, const double* probs, int n) {
+    double t = 0.;
+    int x = 0;
+    while (t < u && x < n) {
+        t += probs[x];
+        x += 1;
+    }
+    return x > 0 ? x - 1 : 0;
+}

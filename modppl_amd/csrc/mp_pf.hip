@@ -1,0 +1,824 @@
+// mp_pf.hip — gfx950 kernels and C-ABI implementation of the particle-filter hot path
+// (include/modppl_hip.h).  Written for MI355X only: 64-lane wavefronts, LDS-staged reductions,
+// SoA particle state in HBM.
+//
+// Data layout in HBM (per handle, n = local particles, d = dim_state):
+//   x[2][d][n]  f64   particle states, double-buffered (resample gathers from one into the other)
+//   logw[n]     f64   log-weights                              (particle_filter.rs:15)
+//   cum[n]      u64   tile-local inclusive prefix sums of the fixed-point weights
+//   parent[n]   u32   parents of the last resample             (particle_filter.rs:20)
+//   blockmax[]  f64   per-workgroup maxima of logw (written by every kernel that changes logw)
+//   tilesum[], tilesum2[] u64  per-tile totals of q and q^2-weights
+//   scal        mp_dev_scalars   log_ml_estimate, last log total weight, ESS ... (device-resident so
+//                                that a whole filter run needs no host round trip)
+//
+// Kernels (one Unfold step + resample = K1, K2, K3; no inter-workgroup communication inside a
+// launch, so nothing depends on dispatch order or XCD placement):
+//   K1 k_propagate        ParticleSystem::init_step/step  : per particle run the model kernel in
+//                         Generate mode, logw (+)= weight, per-workgroup max          [16d+16 B/particle]
+//   K2 k_normalize_scan   normalize_weights (:27-35) as an order-free fixed-point CDF: m = max,
+//                         q = rint(exp(lw-m) * 2^S), tile-local inclusive scan, tile totals [8+8 B]
+//   K3 k_resample_gather  multinomial_resampling + the clone loop of resample (:37-41,:109-114):
+//                         LDS scan of tile totals, Philox draw, two-level binary search, gather
+//                         x[parent], logw = 0; workgroup 0 also folds L into log_ml  [8+4+4+16d+8 B]
+// Fixed point: S = 62 - ceil(log2 N_global); integer sums are associative, so any reduction order
+// gives the same bits (DESIGN.md §4 states the spec; oracle/src/inference.hpp restates it on the CPU).
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/modppl_hip.h"
+#include "mp_models.h"
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int32_t mp_fail(int32_t code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCK(call)                                                                                  \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return mp_fail(MP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device scalars
+// ---------------------------------------------------------------------------------------------
+struct mp_dev_scalars {
+    double m;          // max log-weight seen by the last K2
+    double L;          // log total weight of the last resample (resample()'s return value)
+    double log_ml;     // log_ml_estimate (particle_filter.rs:24)
+    double ess_stale;  // ESS of the weights normalised by the last resample (:98-100 semantics)
+    double ess_fresh;  // outputs of the query path (k_lse_finalize)
+    double lml_fresh;
+    u64 Q, Q2;
+    int degenerate;    // sticky: all log-weights were -inf (or +inf) at a normalisation
+    int pad;
+};
+
+constexpr int K1_THREADS = 256;
+constexpr int K1_MAX_BLOCKS = 2048;
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_ITEMS = 4;
+constexpr int TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096 particles per scan tile
+constexpr int K3_THREADS = 256;
+constexpr int K3_MAX_BLOCKS = 4096;
+constexpr int MAX_TILES = 8192;                  // LDS prefix of tile totals: 64 KiB
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: propagate + weight + per-workgroup max
+// ---------------------------------------------------------------------------------------------
+template <class Model>
+__global__ __launch_bounds__(K1_THREADS) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
+                                                          long long t, const double* x_in, double* x_out, double* logw,
+                                                          mp_obs obs, mp_state0 s0, int overwrite, double* __restrict__ blockmax) {
+    constexpr int D = Model::DIM_STATE;
+    double lmax = MP_NEG_INF;
+    for (u64 i = (u64)blockIdx.x * K1_THREADS + threadIdx.x; i < n; i += (u64)gridDim.x * K1_THREADS) {
+        double prev[D], next[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[(u64)d * n + i];
+        mp_stream rng;
+        rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
+        mp_generate_handler<Model> g(rng, obs.v);
+        model(g, t, prev, next);
+#pragma unroll
+        for (int d = 0; d < D; ++d) x_out[(u64)d * n + i] = next[d];
+        const double w = overwrite ? g.weight : logw[i] + g.weight;  // particle_filter.rs:68 / :81
+        logw[i] = w;
+        lmax = fmax(lmax, w);
+    }
+    __shared__ double s_max[K1_THREADS / 64];
+    lmax = wave_max(lmax);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_max[wave] = lmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_max[0];
+#pragma unroll
+        for (int w = 1; w < K1_THREADS / 64; ++w) m = fmax(m, s_max[w]);
+        blockmax[blockIdx.x] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: fixed-point normalisation + tile-local inclusive scan
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mp_quantize(double e, double scale) {
+    const double r = rint(e * scale);
+    return (r >= 0.) ? (u64)r : 0ull;  // NaN -> 0
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_normalize_scan(const double* __restrict__ logw, u64 n,
+                                                                 const double* __restrict__ blockmax, int nb, int S,
+                                                                 u64* __restrict__ cum, u64* __restrict__ tilesum,
+                                                                 u64* __restrict__ tilesum2, mp_dev_scalars* scal) {
+    __shared__ double s_red[SCAN_THREADS / 64];
+    __shared__ u64 s_wsum[SCAN_THREADS / 64];
+    __shared__ u64 s_wsum2[SCAN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // m = max over the per-workgroup maxima (exact in any order)
+    double m = MP_NEG_INF;
+    for (int j = tid; j < nb; j += SCAN_THREADS) m = fmax(m, blockmax[j]);
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < SCAN_THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    if (blockIdx.x == 0 && tid == 0) {
+        scal->m = m;
+        if (!ok) scal->degenerate = 1;
+    }
+
+    const double scale = mp_u2f((u64)(1023 + S) << 52);  // 2^S
+    const u64 base = (u64)blockIdx.x * TILE + (u64)tid * SCAN_ITEMS;
+    double w[SCAN_ITEMS];
+    if (base + SCAN_ITEMS <= n) {
+        const double2 a = *reinterpret_cast<const double2*>(logw + base);
+        const double2 b = *reinterpret_cast<const double2*>(logw + base + 2);
+        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) w[j] = (base + j < n) ? logw[base + j] : MP_NEG_INF;
+    }
+    u64 c[SCAN_ITEMS];
+    u64 run = 0, run2 = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        const bool live = ok && (base + j < n);
+        const double e = live ? mp_exp(w[j] - m) : 0.;
+        run += mp_quantize(e, scale);
+        run2 += mp_quantize(e * e, scale);
+        c[j] = run;
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    const u64 wtot2 = wave_sum_u64(run2);
+    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) s_wsum2[wave] = wtot2;
+    __syncthreads();
+    u64 woff = 0;
+    for (int k = 0; k < wave; ++k) woff += s_wsum[k];
+    const u64 off = woff + (incl - run);
+    if (base + SCAN_ITEMS <= n) {
+        ulonglong2 o0, o1;
+        o0.x = off + c[0]; o0.y = off + c[1]; o1.x = off + c[2]; o1.y = off + c[3];
+        *reinterpret_cast<ulonglong2*>(cum + base) = o0;
+        *reinterpret_cast<ulonglong2*>(cum + base + 2) = o1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j)
+            if (base + j < n) cum[base + j] = off + c[j];
+    }
+    if (tid == SCAN_THREADS - 1) tilesum[blockIdx.x] = off + run;
+    if (tid == 0) {
+        u64 t2 = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_THREADS / 64; ++k) t2 += s_wsum2[k];
+        tilesum2[blockIdx.x] = t2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared helper: workgroup-wide inclusive scan of nt (<= MAX_TILES) u64 values into LDS
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ void block_scan_tiles(const u64* __restrict__ tilesum, int nt, u64* s_incl, u64* s_wtot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nt + THREADS - 1) / THREADS;
+    const int b0 = tid * per;
+    u64 run = 0;
+    for (int j = 0; j < per; ++j) {
+        const int idx = b0 + j;
+        if (idx < nt) {
+            run += tilesum[idx];
+            s_incl[idx] = run;
+        }
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    u64 woff = 0;
+    for (int k = 0; k < wave; ++k) woff += s_wtot[k];
+    const u64 off = woff + (incl - run);
+    for (int j = 0; j < per; ++j) {
+        const int idx = b0 + j;
+        if (idx < nt) s_incl[idx] += off;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void finalize_scalars(u64 Q, u64 Q2, int S, double* L_out, double* ess_out, double m) {
+    const double inv = mp_u2f((u64)(1023 - S) << 52);  // 2^-S
+    const double Qs = (double)Q * inv, Q2s = (double)Q2 * inv;
+    *L_out = m + mp_log(Qs);
+    *ess_out = (Qs * Qs) / Q2s;
+}
+
+// target = max(1, ceil(k * Q / 2^52)), k < 2^52, Q < 2^63
+__device__ __forceinline__ u64 mp_target(u64 k52, u64 Q) {
+    u64 lo = k52 * Q;
+    u64 hi = __umul64hi(k52, Q);
+    const u64 add = (1ull << 52) - 1ull;
+    const u64 lo2 = lo + add;
+    hi += (lo2 < lo) ? 1ull : 0ull;
+    const u64 t = (hi << 12) | (lo2 >> 52);
+    return t < 1ull ? 1ull : t;
+}
+
+// first index in [0, len) with a[idx] >= target (len if none)
+template <class Ptr>
+__device__ __forceinline__ uint32_t lower_bound_u64(Ptr a, uint32_t len, u64 target) {
+    uint32_t lo = 0, hi = len;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] >= target) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: draw, search, gather, reset
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1,
+                                                                uint32_t rc, int S, int D, const u64* __restrict__ cum,
+                                                                const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2,
+                                                                int nt, const double* __restrict__ x_old, double* __restrict__ x_new,
+                                                                uint32_t* __restrict__ parent, double* __restrict__ logw,
+                                                                double* __restrict__ blockmax, int nb, mp_dev_scalars* scal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);  // [nt]
+    u64* s_wtot = s_incl + nt;                   // [K3_THREADS/64]
+    block_scan_tiles<K3_THREADS>(tilesum, nt, s_incl, s_wtot);
+    const u64 Q = s_incl[nt - 1];
+
+    if (blockIdx.x == 0) {  // workgroup-uniform: fold this normalisation into the filter scalars
+        u64 q2 = 0;
+        for (int j = threadIdx.x; j < nt; j += K3_THREADS) q2 += tilesum2[j];
+        q2 = wave_sum_u64(q2);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_wtot[threadIdx.x >> 6] = q2;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 Q2 = 0;
+            for (int k = 0; k < K3_THREADS / 64; ++k) Q2 += s_wtot[k];
+            double L, ess;
+            finalize_scalars(Q, Q2, S, &L, &ess, scal->m);
+            scal->L = L;
+            scal->ess_stale = ess;
+            scal->Q = Q;
+            scal->Q2 = Q2;
+            scal->log_ml += L - mp_log((double)n_global);  // particle_filter.rs:105
+        }
+        for (int j = threadIdx.x; j < nb; j += K3_THREADS) blockmax[j] = 0.;  // logw is 0 after a resample
+    }
+
+    for (u64 i = (u64)blockIdx.x * K3_THREADS + threadIdx.x; i < n; i += (u64)gridDim.x * K3_THREADS) {
+        const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+        const u64 target = mp_target(mp_u52(r.a), Q);
+        uint32_t b = lower_bound_u64(s_incl, (uint32_t)nt, target);
+        if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
+        const u64 excl = b ? s_incl[b - 1] : 0ull;
+        const u64 lt = target - excl;
+        const u64 tbase = (u64)b * TILE;
+        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+        uint32_t j = lower_bound_u64(cum + tbase, tlen, lt);
+        if (j > tlen - 1) j = tlen - 1;
+        const u64 p = tbase + j;
+        parent[i] = (uint32_t)(slot_offset + p);
+        for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = x_old[(u64)d * n + p];  // traces[i] = traces[parents[i]].clone()
+        logw[i] = 0.;                                                              // log_weights.fill(0.)
+    }
+}
+
+// query path: log_marginal_likelihood_estimate / fresh ESS from the current log-weights (after K2)
+__global__ __launch_bounds__(K3_THREADS) void k_lse_finalize(const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2, int nt, int S,
+                                                             u64 n_global, mp_dev_scalars* scal) {
+    __shared__ u64 s_a[K3_THREADS / 64], s_b[K3_THREADS / 64];
+    u64 q = 0, q2 = 0;
+    for (int j = threadIdx.x; j < nt; j += K3_THREADS) {
+        q += tilesum[j];
+        q2 += tilesum2[j];
+    }
+    q = wave_sum_u64(q);
+    q2 = wave_sum_u64(q2);
+    if ((threadIdx.x & 63) == 0) {
+        s_a[threadIdx.x >> 6] = q;
+        s_b[threadIdx.x >> 6] = q2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 Q = 0, Q2 = 0;
+        for (int k = 0; k < K3_THREADS / 64; ++k) {
+            Q += s_a[k];
+            Q2 += s_b[k];
+        }
+        double L, ess;
+        finalize_scalars(Q, Q2, S, &L, &ess, scal->m);
+        scal->ess_fresh = ess;
+        scal->lml_fresh = scal->log_ml + L - mp_log((double)n_global);  // particle_filter.rs:119-121
+    }
+}
+
+// transpose SoA [d][n] -> host-facing AoS [n][d]
+__global__ void k_soa_to_aos(const double* __restrict__ x, u64 n, int D, double* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        for (int d = 0; d < D; ++d) out[i * D + d] = x[(u64)d * n + i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int ceil_log2_u64(u64 n) {
+    int b = 0;
+    while ((1ull << b) < n) ++b;
+    return b;
+}
+
+struct PropagateArgs {
+    u64 n, slot_offset;
+    uint32_t k0, k1;
+    long long t;
+    const double* x_in;
+    double* x_out;
+    double* logw;
+    mp_obs obs;
+    mp_state0 s0;
+    int overwrite;
+    double* blockmax;
+    int grid;
+    hipStream_t stream;
+};
+struct ModelOps {
+    int dim_state = 0, dim_obs = 0;
+    virtual ~ModelOps() {}
+    virtual void propagate(const PropagateArgs& a) const = 0;
+};
+template <class Model>
+struct ModelOpsT : ModelOps {
+    Model model;
+    explicit ModelOpsT(const Model& m) : model(m) {
+        dim_state = Model::DIM_STATE;
+        dim_obs = Model::DIM_OBS;
+    }
+    void propagate(const PropagateArgs& a) const override {
+        hipLaunchKernelGGL(k_propagate<Model>, dim3(a.grid), dim3(K1_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.blockmax);
+    }
+};
+
+static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out) {
+    if (!m) return mp_fail(MP_ERR_INVALID_ARG, "model descriptor is null");
+    switch (m->kind) {
+    case MP_MODEL_LGSSM1: {
+        if (m->n_params != 5 || !m->params) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM1 takes 5 params {mu0,sig0,a,sig_x,sig_y}");
+        if (m->dim_state != 1 || m->dim_obs != 1) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM1: dim_state = dim_obs = 1");
+        mp_lgssm1 k{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4]};
+        if (!(k.sig0 > 0.) || !(k.sig_x > 0.) || !(k.sig_y > 0.)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM1: standard deviations must be > 0");
+        out.reset(new ModelOpsT<mp_lgssm1>(k));
+        return MP_OK;
+    }
+    default:
+        return mp_fail(MP_ERR_UNSUPPORTED, "model kind " + std::to_string(m->kind) + " is not compiled into this library");
+    }
+}
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+    int family;
+};
+
+struct mp_pf {
+    std::unique_ptr<ModelOps> ops;
+    u64 n = 0, n_global = 0, slot_offset = 0, seed = 0;
+    uint32_t flags = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int S = 0;
+    int nb = 0;  // K1 grid == entries of blockmax
+    int nt = 0;  // scan tiles
+    int k3_grid = 0;
+    // device buffers
+    double* x[2] = {nullptr, nullptr};
+    int cur = 0;
+    double* logw = nullptr;
+    u64* cum = nullptr;
+    uint32_t* parent = nullptr;
+    double* blockmax = nullptr;
+    u64* tilesum = nullptr;
+    u64* tilesum2 = nullptr;
+    mp_dev_scalars* scal = nullptr;
+    double* aos = nullptr;  // staging for read_state
+    mp_dev_scalars* h_scal = nullptr;  // pinned
+    // host-side filter state
+    long long t = 0;  // Unfold steps taken (trace.args.0)
+    uint32_t resample_count = 0;
+    bool initialised = false;
+    // timing
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+    double fam_ms[MP_K_COUNT] = {0, 0, 0};
+    uint64_t fam_launches[MP_K_COUNT] = {0, 0, 0};
+};
+
+static hipEvent_t get_event(mp_pf* h) {
+    if (!h->event_pool.empty()) {
+        hipEvent_t e = h->event_pool.back();
+        h->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct LaunchTimer {
+    mp_pf* h;
+    TimedLaunch tl;
+    bool on;
+    LaunchTimer(mp_pf* h_, int family) : h(h_), on(h_->timing) {
+        if (on) {
+            tl.family = family;
+            tl.start = get_event(h);
+            tl.stop = get_event(h);
+            (void)hipEventRecord(tl.start, h->stream);
+        }
+    }
+    ~LaunchTimer() {
+        if (on) {
+            (void)hipEventRecord(tl.stop, h->stream);
+            h->timed.push_back(tl);
+        }
+    }
+};
+static int32_t drain_timing(mp_pf* h) {
+    if (h->timed.empty()) return MP_OK;
+    HIPCK(hipStreamSynchronize(h->stream));
+    for (auto& tl : h->timed) {
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, tl.start, tl.stop));
+        h->fam_ms[tl.family] += (double)ms;
+        h->fam_launches[tl.family] += 1;
+        h->event_pool.push_back(tl.start);
+        h->event_pool.push_back(tl.stop);
+    }
+    h->timed.clear();
+    return MP_OK;
+}
+
+static int32_t check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mp_fail(MP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return MP_OK;
+}
+
+static int32_t fetch_scalars(mp_pf* h) {
+    HIPCK(hipMemcpyAsync(h->h_scal, h->scal, sizeof(mp_dev_scalars), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (h->h_scal->degenerate)
+        return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
+    return MP_OK;
+}
+
+static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs, bool overwrite) {
+    PropagateArgs a;
+    a.n = h->n; a.slot_offset = h->slot_offset;
+    a.k0 = (uint32_t)h->seed; a.k1 = (uint32_t)(h->seed >> 32);
+    a.t = h->t;
+    a.x_in = h->x[h->cur]; a.x_out = h->x[h->cur];
+    a.logw = h->logw;
+    for (int j = 0; j < MP_MAX_OBS; ++j) a.obs.v[j] = (j < h->ops->dim_obs) ? obs[j] : 0.;
+    for (int j = 0; j < MP_MAX_STATE; ++j) a.s0.v[j] = (args0 && j < h->ops->dim_state) ? args0[j] : 0.;
+    a.overwrite = overwrite ? 1 : 0;
+    a.blockmax = h->blockmax;
+    a.grid = h->nb;
+    a.stream = h->stream;
+    {
+        LaunchTimer lt(h, MP_K_PROPAGATE);
+        h->ops->propagate(a);
+    }
+    h->t += 1;
+    return check_launch("k_propagate");
+}
+
+static int32_t launch_normalize(mp_pf* h) {
+    LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
+    hipLaunchKernelGGL(k_normalize_scan, dim3(h->nt), dim3(SCAN_THREADS), 0, h->stream, h->logw, h->n, h->blockmax, h->nb, h->S, h->cum,
+                       h->tilesum, h->tilesum2, h->scal);
+    return check_launch("k_normalize_scan");
+}
+
+extern "C" {
+
+const char* mp_last_error(void) { return g_err.c_str(); }
+
+int32_t mp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t seed, const mp_shard* shard, uint32_t flags,
+                     int32_t device, void* stream, mp_pf** out) {
+    if (!out) return mp_fail(MP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (n_particles == 0) return mp_fail(MP_ERR_INVALID_ARG, "n_particles must be > 0");
+    if (n_particles > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "n_particles must fit u32 parent indices");
+    std::unique_ptr<mp_pf> h(new mp_pf());
+    int32_t rc = make_model(model, h->ops);
+    if (rc != MP_OK) return rc;
+    if (flags & MP_PF_RECORD_HISTORY) return mp_fail(MP_ERR_UNSUPPORTED, "MP_PF_RECORD_HISTORY: not in this build yet");
+    h->n = n_particles;
+    h->n_global = shard ? shard->n_global : n_particles;
+    h->slot_offset = shard ? shard->slot_offset : 0;
+    if (h->n_global < h->n + h->slot_offset || h->n_global > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "shard does not fit n_global (< 2^32)");
+    if (shard && (h->n_global != h->n)) return mp_fail(MP_ERR_UNSUPPORTED, "sharded handles use the mp_pf_shard_* entry points (not in this build yet)");
+    h->seed = seed;
+    h->flags = flags;
+    h->device = device;
+    h->S = 62 - ceil_log2_u64(h->n_global);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return mp_fail(MP_ERR_HIP, "no HIP device visible: the gfx950 path has no CPU fallback");
+    }
+    HIPCK(hipSetDevice(device));
+    if (stream) {
+        h->stream = (hipStream_t)stream;
+    } else {
+        HIPCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    const u64 n = h->n;
+    const int d = h->ops->dim_state;
+    h->nb = (int)((n + K1_THREADS - 1) / K1_THREADS);
+    if (h->nb > K1_MAX_BLOCKS) h->nb = K1_MAX_BLOCKS;
+    h->nt = (int)((n + TILE - 1) / TILE);
+    if (h->nt > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "n_particles per handle is limited to 2^25 in this build");
+    h->k3_grid = (int)((n + K3_THREADS - 1) / K3_THREADS);
+    if (h->k3_grid > K3_MAX_BLOCKS) h->k3_grid = K3_MAX_BLOCKS;
+    HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
+    HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
+    HIPCK(hipMalloc(&h->logw, sizeof(double) * n));
+    HIPCK(hipMalloc(&h->cum, sizeof(u64) * n));
+    HIPCK(hipMalloc(&h->parent, sizeof(uint32_t) * n));
+    HIPCK(hipMalloc(&h->blockmax, sizeof(double) * K1_MAX_BLOCKS));
+    HIPCK(hipMalloc(&h->tilesum, sizeof(u64) * h->nt));
+    HIPCK(hipMalloc(&h->tilesum2, sizeof(u64) * h->nt));
+    HIPCK(hipMalloc(&h->scal, sizeof(mp_dev_scalars)));
+    HIPCK(hipMalloc(&h->aos, sizeof(double) * n * d));
+    HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
+    // ParticleSystem::new: log_weights = 0, parents = 0, log_ml_estimate = 0 (particle_filter.rs:44-57)
+    HIPCK(hipMemsetAsync(h->x[0], 0, sizeof(double) * n * d, h->stream));
+    HIPCK(hipMemsetAsync(h->x[1], 0, sizeof(double) * n * d, h->stream));
+    HIPCK(hipMemsetAsync(h->logw, 0, sizeof(double) * n, h->stream));
+    HIPCK(hipMemsetAsync(h->parent, 0, sizeof(uint32_t) * n, h->stream));
+    HIPCK(hipMemsetAsync(h->blockmax, 0, sizeof(double) * K1_MAX_BLOCKS, h->stream));
+    mp_dev_scalars init{};
+    init.ess_stale = 1.0 / (double)h->n_global;  // exp(-logsumexp(zeros)) before any resample
+    *h->h_scal = init;
+    HIPCK(hipMemcpyAsync(h->scal, h->h_scal, sizeof(mp_dev_scalars), hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    *out = h.release();
+    return MP_OK;
+}
+
+int32_t mp_pf_init_step(mp_pf* h, const double* args0, const double* obs, int32_t n_steps) {
+    if (!h || !obs) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (n_steps < 1) return mp_fail(MP_ERR_CONSTRAINTS, "init_step needs the constraints of at least one time step");
+    if (h->initialised) return mp_fail(MP_ERR_STATE, "init_step called twice");
+    HIPCK(hipSetDevice(h->device));
+    for (int k = 0; k < n_steps; ++k) {
+        int32_t rc = launch_propagate(h, args0, obs + (size_t)k * h->ops->dim_obs, k == 0);
+        if (rc != MP_OK) return rc;
+    }
+    h->initialised = true;
+    return MP_OK;
+}
+
+int32_t mp_pf_step(mp_pf* h, const double* obs, int32_t n_steps) {
+    if (!h || !obs) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (n_steps < 1) return mp_fail(MP_ERR_CONSTRAINTS, "step needs the constraints of at least one time step");
+    if (!h->initialised) return mp_fail(MP_ERR_STATE, "step before init_step");
+    HIPCK(hipSetDevice(h->device));
+    for (int k = 0; k < n_steps; ++k) {
+        int32_t rc = launch_propagate(h, nullptr, obs + (size_t)k * h->ops->dim_obs, false);
+        if (rc != MP_OK) return rc;
+    }
+    return MP_OK;
+}
+
+int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
+    if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
+    if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
+    if (scheme != MP_RESAMPLE_MULTINOMIAL) return mp_fail(MP_ERR_UNSUPPORTED, "only MP_RESAMPLE_MULTINOMIAL in this build");
+    HIPCK(hipSetDevice(h->device));
+    int32_t rc = launch_normalize(h);
+    if (rc != MP_OK) return rc;
+    const int d = h->ops->dim_state;
+    const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
+    {
+        LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
+        hipLaunchKernelGGL(k_resample_gather, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cum, h->tilesum, h->tilesum2,
+                           h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
+    }
+    rc = check_launch("k_resample_gather");
+    if (rc != MP_OK) return rc;
+    h->cur ^= 1;
+    h->resample_count += 1;
+    if (log_total_weight) {
+        rc = fetch_scalars(h);
+        if (rc != MP_OK) return rc;
+        *log_total_weight = h->h_scal->L;
+    }
+    return MP_OK;
+}
+
+static int32_t query(mp_pf* h) {
+    int32_t rc = launch_normalize(h);
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(k_lse_finalize, dim3(1), dim3(K3_THREADS), 0, h->stream, h->tilesum, h->tilesum2, h->nt, h->S, h->n_global, h->scal);
+    rc = check_launch("k_lse_finalize");
+    if (rc != MP_OK) return rc;
+    return fetch_scalars(h);
+}
+
+int32_t mp_pf_effective_sample_size(mp_pf* h, int32_t ess_mode, double* out) {
+    if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    if (ess_mode == MP_ESS_REFERENCE) {
+        int32_t rc = fetch_scalars(h);
+        if (rc != MP_OK) return rc;
+        *out = h->h_scal->ess_stale;
+        return MP_OK;
+    }
+    if (ess_mode != MP_ESS_FRESH) return mp_fail(MP_ERR_INVALID_ARG, "unknown ess mode");
+    if (!h->initialised) return mp_fail(MP_ERR_STATE, "effective_sample_size(FRESH) before init_step");
+    int32_t rc = query(h);
+    if (rc != MP_OK) return rc;
+    *out = h->h_scal->ess_fresh;
+    return MP_OK;
+}
+
+int32_t mp_pf_log_marginal_likelihood_estimate(mp_pf* h, double* out) {
+    if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    int32_t rc = query(h);
+    if (rc != MP_OK) return rc;
+    *out = h->h_scal->lml_fresh;
+    return MP_OK;
+}
+
+int32_t mp_pf_read_state(mp_pf* h, double* x_out) {
+    if (!h || !x_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    const int d = h->ops->dim_state;
+    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->x[h->cur], h->n, d, h->aos);
+    int32_t rc = check_launch("k_soa_to_aos");
+    if (rc != MP_OK) return rc;
+    HIPCK(hipMemcpyAsync(x_out, h->aos, sizeof(double) * h->n * d, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    return MP_OK;
+}
+
+int32_t mp_pf_read_log_weights(mp_pf* h, double* out) {
+    if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    HIPCK(hipMemcpyAsync(out, h->logw, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    return MP_OK;
+}
+
+int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
+    if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    HIPCK(hipMemcpyAsync(out, h->parent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    return MP_OK;
+}
+
+int32_t mp_pf_read_trajectory(mp_pf* h, uint64_t i, double* out, int32_t* t_steps) {
+    (void)h; (void)i; (void)out; (void)t_steps;
+    return mp_fail(MP_ERR_UNSUPPORTED, "read_trajectory needs MP_PF_RECORD_HISTORY (not in this build yet)");
+}
+
+int32_t mp_pf_time(mp_pf* h, int64_t* out) {
+    if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    *out = h->t;
+    return MP_OK;
+}
+
+int32_t mp_pf_run(mp_pf* h, const double* args0, const double* obs, int32_t n_steps, int32_t scheme) {
+    if (!h || !obs) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (n_steps < 1) return mp_fail(MP_ERR_CONSTRAINTS, "run needs at least one time step");
+    int32_t rc = mp_pf_init_step(h, args0, obs, 1);
+    if (rc != MP_OK) return rc;
+    rc = mp_pf_resample(h, scheme, nullptr);
+    if (rc != MP_OK) return rc;
+    for (int t = 1; t < n_steps; ++t) {
+        rc = mp_pf_step(h, obs + (size_t)t * h->ops->dim_obs, 1);
+        if (rc != MP_OK) return rc;
+        rc = mp_pf_resample(h, scheme, nullptr);
+        if (rc != MP_OK) return rc;
+    }
+    return MP_OK;
+}
+
+int32_t mp_pf_synchronize(mp_pf* h) {
+    if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
+    HIPCK(hipSetDevice(h->device));
+    return fetch_scalars(h);
+}
+
+int32_t mp_pf_set_timing(mp_pf* h, int32_t enabled) {
+    if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
+    int32_t rc = drain_timing(h);
+    if (rc != MP_OK) return rc;
+    h->timing = enabled != 0;
+    for (int f = 0; f < MP_K_COUNT; ++f) {
+        h->fam_ms[f] = 0.;
+        h->fam_launches[f] = 0;
+    }
+    return MP_OK;
+}
+
+int32_t mp_pf_get_timing(mp_pf* h, int32_t which, double* total_ms, uint64_t* launches) {
+    if (!h || which < 0 || which >= MP_K_COUNT) return mp_fail(MP_ERR_INVALID_ARG, "bad argument");
+    int32_t rc = drain_timing(h);
+    if (rc != MP_OK) return rc;
+    if (total_ms) *total_ms = h->fam_ms[which];
+    if (launches) *launches = h->fam_launches[which];
+    return MP_OK;
+}
+
+int32_t mp_pf_destroy(mp_pf* h) {
+    if (!h) return MP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& tl : h->timed) {
+        (void)hipEventDestroy(tl.start);
+        (void)hipEventDestroy(tl.stop);
+    }
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    (void)hipFree(h->x[0]);
+    (void)hipFree(h->x[1]);
+    (void)hipFree(h->logw);
+    (void)hipFree(h->cum);
+    (void)hipFree(h->parent);
+    (void)hipFree(h->blockmax);
+    (void)hipFree(h->tilesum);
+    (void)hipFree(h->tilesum2);
+    (void)hipFree(h->scal);
+    (void)hipFree(h->aos);
+    (void)hipHostFree(h->h_scal);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MP_OK;
+}
+
+int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples,
+                                 uint64_t num_ret_samples, uint64_t seed, int32_t device, double* log_ml_estimate,
+                                 double* log_normalized_weights, uint64_t* resampled_indices, double* final_states) {
+    (void)model; (void)args0; (void)obs; (void)n_steps; (void)num_samples; (void)num_ret_samples; (void)seed; (void)device;
+    (void)log_ml_estimate; (void)log_normalized_weights; (void)resampled_indices; (void)final_states;
+    return mp_fail(MP_ERR_UNSUPPORTED, "importance_resampling: not in this build yet");
+}
+
+}  // extern "C"

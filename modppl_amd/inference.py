@@ -1,0 +1,138 @@
+"""Host-side mirror of modppl's inference entry points for the MI355X path.
+
+Same names, argument meaning and error behaviour as the reference (a reference `panic!` becomes a
+`ModpplError`), calling the HIP kernels through the C ABI of include/modppl_hip.h:
+
+    ParticleSystem.{new, init_step, step, effective_sample_size, resample,
+                    log_marginal_likelihood_estimate}      modppl/src/inference/particle_filter.rs:44-121
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_DP = C.POINTER(C.c_double)
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_DP)
+
+
+class ParticleSystem:
+    """`ParticleSystem<Args,Data,Ret,F>` over an Unfold model (alias `DynParticles`, dynunfold.rs:20).
+
+    `seed` replaces `rng: ThreadRng` (which cannot be seeded in the reference).
+    """
+
+    def __init__(self, model, num_particles, seed, *, device=0, stream=None, flags=0):
+        self._L = capi.load()
+        self.model = model
+        self.num_particles = int(num_particles)
+        self._desc = model.desc()
+        h = C.c_void_p()
+        capi.check(self._L.mp_pf_create(C.byref(self._desc), self.num_particles, int(seed), None, int(flags), int(device),
+                                        C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+
+    # ParticleSystem::new
+    @classmethod
+    def new(cls, model, num_particles, seed, **kw):
+        return cls(model, num_particles, seed, **kw)
+
+    def _obs(self, constraints):
+        obs = np.ascontiguousarray(constraints, dtype=np.float64)
+        if obs.size == 0 or obs.size % self.model.dim_obs:
+            raise capi.ModpplError(capi.MP_ERR_CONSTRAINTS, "constraints must hold dim_obs values per time step")
+        return obs.reshape(-1, self.model.dim_obs)
+
+    def init_step(self, args, constraints):
+        """init_step(args, constraints): N x generate((1, args), constraints) — particle_filter.rs:60-70."""
+        obs = self._obs(constraints)
+        a = None
+        if args is not None:
+            a = np.ascontiguousarray(args, dtype=np.float64).reshape(-1)
+            if a.size != self.model.dim_state:
+                raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "args must hold dim_state values")
+        capi.check(self._L.mp_pf_init_step(self._h, _dptr(a) if a is not None else None, _dptr(obs), obs.shape[0]))
+
+    def step(self, constraints):
+        """step(constraints) -> Self: N x update(.., ArgDiff::Extend, constraints) — particle_filter.rs:73-96."""
+        obs = self._obs(constraints)
+        capi.check(self._L.mp_pf_step(self._h, _dptr(obs), obs.shape[0]))
+        return self
+
+    def effective_sample_size(self, fresh=False):
+        """particle_filter.rs:98-100.  The reference reads the weights normalised by the LAST resample
+        (1/N before any); fresh=True evaluates the current log-weights instead."""
+        out = C.c_double()
+        capi.check(self._L.mp_pf_effective_sample_size(self._h, capi.MP_ESS_FRESH if fresh else capi.MP_ESS_REFERENCE, C.byref(out)))
+        return out.value
+
+    def resample(self, scheme=capi.MP_RESAMPLE_MULTINOMIAL, sync=True):
+        """resample() -> log total weight — particle_filter.rs:103-116.  sync=False only enqueues."""
+        if not sync:
+            capi.check(self._L.mp_pf_resample(self._h, scheme, None))
+            return None
+        out = C.c_double()
+        capi.check(self._L.mp_pf_resample(self._h, scheme, C.byref(out)))
+        return out.value
+
+    def log_marginal_likelihood_estimate(self):
+        """particle_filter.rs:119-121."""
+        out = C.c_double()
+        capi.check(self._L.mp_pf_log_marginal_likelihood_estimate(self._h, C.byref(out)))
+        return out.value
+
+    def run(self, args, constraints, scheme=capi.MP_RESAMPLE_MULTINOMIAL):
+        """The loop of modppl/tests/smc.rs:64-90 (init_step; resample; {step; resample}*) enqueued in one call."""
+        obs = self._obs(constraints)
+        a = None if args is None else np.ascontiguousarray(args, dtype=np.float64).reshape(-1)
+        capi.check(self._L.mp_pf_run(self._h, _dptr(a) if a is not None else None, _dptr(obs), obs.shape[0], scheme))
+        return self
+
+    def synchronize(self):
+        capi.check(self._L.mp_pf_synchronize(self._h))
+
+    # the pub `traces` field, flattened: traces[i].retv.last()
+    def states(self):
+        x = np.empty((self.num_particles, self.model.dim_state))
+        capi.check(self._L.mp_pf_read_state(self._h, _dptr(x)))
+        return x
+
+    @property
+    def log_weights(self):
+        w = np.empty(self.num_particles)
+        capi.check(self._L.mp_pf_read_log_weights(self._h, _dptr(w)))
+        return w
+
+    @property
+    def parents(self):
+        p = np.empty(self.num_particles, dtype=np.uint32)
+        capi.check(self._L.mp_pf_read_parents(self._h, p.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return p
+
+    @property
+    def time(self):
+        t = C.c_int64()
+        capi.check(self._L.mp_pf_time(self._h, C.byref(t)))
+        return t.value
+
+    def set_timing(self, enabled):
+        capi.check(self._L.mp_pf_set_timing(self._h, int(enabled)))
+
+    def get_timing(self, family):
+        ms, n = C.c_double(), C.c_uint64()
+        capi.check(self._L.mp_pf_get_timing(self._h, family, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mp_pf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
