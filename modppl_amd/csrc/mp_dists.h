@@ -19,11 +19,23 @@ struct mp_site {
     MP_PHD mp_u64x2 next_block() { return s.draw(domain, site, blk++); }
 };
 
-// normal.rs:13-17
-MP_HD double mp_normal_logpdf(double x, double mu, double sd) {
+// mp_log(2*pi) evaluated once (tests/test_math.py checks the bits against mp_log itself).
+#define MP_LN_2PI_CANON (mp_u2f(0x3FFD67F1C864BEB4ull))
+
+// normal.rs:13-17; `ln_sd` = mp_log(sd), hoisted by callers whose sd is a model constant.
+MP_HD double mp_normal_logpdf_ln(double x, double mu, double sd, double ln_sd) {
     const double z = (x - mu) / sd;
     const double az = fabs(z);
-    return -(az * az + mp_log(MP_2PI)) / 2. - mp_log(sd);
+    return -(az * az + MP_LN_2PI_CANON) / 2. - ln_sd;
+}
+MP_HD double mp_normal_logpdf(double x, double mu, double sd) { return mp_normal_logpdf_ln(x, mu, sd, mp_log(sd)); }
+
+// The accepted pair (u, r = u*u + v*v) of the polar method does not depend on (mu, sd), so the
+// rejection loop can run ahead of the model (mp_pf.hip, k_propagate) and the model consumes it here.
+// normal.rs:25-26: c = sqrt(-2 ln r / r); u*c*std + mu.
+MP_HD double mp_normal_from_pair(double u, double r, double mu, double sd) {
+    const double c = mp_sqrt(-2. * mp_log(r) / r);
+    return u * c * sd + mu;
 }
 
 // normal.rs:19-27: u,v = 2*u01-1; r = u*u+v*v; reject r == 0 or r > 1 (the reference recurses);
@@ -35,8 +47,7 @@ MP_HD double mp_normal_sample(mp_site& st, double mu, double sd) {
         const double v = mp_u01(b.b) * 2. - 1.;
         const double r = u * u + v * v;
         if (r == 0. || r > 1.) continue;
-        const double c = mp_sqrt(-2. * mp_log(r) / r);
-        return u * c * sd + mu;
+        return mp_normal_from_pair(u, r, mu, sd);
     }
 }
 

@@ -5,7 +5,8 @@
 // Data layout in HBM (per handle, n = local particles, d = dim_state):
 //   x[2][d][n]  f64   particle states, double-buffered (resample gathers from one into the other)
 //   logw[n]     f64   log-weights                              (particle_filter.rs:15)
-//   cum[n]      u64   tile-local inclusive prefix sums of the fixed-point weights
+//   cx[n]       {u64,f64}  resampling table rows: tile-local inclusive prefix sum of the fixed-point weights + x[0]
+//   guide[nt][2048] u16  per-tile bucketed inverse CDF (first row of each bucket)
 //   parent[n]   u32   parents of the last resample             (particle_filter.rs:20)
 //   blockmax[]  f64   per-workgroup maxima of logw (written by every kernel that changes logw)
 //   tilesum[], tilesum2[] u64  per-tile totals of q and q^2-weights
@@ -65,11 +66,13 @@ struct mp_dev_scalars {
 };
 
 constexpr int K1_THREADS = 256;
+constexpr int K1_ITEMS = 4;
 constexpr int K1_MAX_BLOCKS = 2048;
-constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_THREADS = 512;
 constexpr int SCAN_ITEMS = 4;
-constexpr int TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096 particles per scan tile
+constexpr int TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 particles per scan tile
 constexpr int K3_THREADS = 256;
+constexpr int K3_ITEMS = 4;
 constexpr int K3_MAX_BLOCKS = 4096;
 constexpr int MAX_TILES = 8192;                  // LDS prefix of tile totals: 64 KiB
 
@@ -96,25 +99,70 @@ __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
 // ---------------------------------------------------------------------------------------------
 // K1: propagate + weight + per-workgroup max
 // ---------------------------------------------------------------------------------------------
+// Each lane owns K1_ITEMS particles (slots base + p*K1_THREADS + tid: coalesced per p).
+// Phase 1 runs every polar rejection loop of the lane as ONE lane-local work queue over its
+// (particle, normal site) items: a wave iterates max-over-lanes of the SUM of attempts instead of
+// the sum over items of the max, i.e. ~1.9 Philox blocks per item at 4 items instead of ~3.6
+// (acceptance pi/4, 64 lanes).  Phase 2 runs the model kernel per particle on the accepted pairs.
 template <class Model>
 __global__ __launch_bounds__(K1_THREADS) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                           long long t, const double* x_in, double* x_out, double* logw,
                                                           mp_obs obs, mp_state0 s0, int overwrite, double* __restrict__ blockmax) {
     constexpr int D = Model::DIM_STATE;
+    constexpr int NS = Model::MAX_NORMALS;
+    constexpr int M = K1_ITEMS * NS;
     double lmax = MP_NEG_INF;
-    for (u64 i = (u64)blockIdx.x * K1_THREADS + threadIdx.x; i < n; i += (u64)gridDim.x * K1_THREADS) {
-        double prev[D], next[D];
+    const int ns = model.n_normals(t);  // wave-uniform
+    for (u64 i0 = (u64)blockIdx.x * (K1_THREADS * K1_ITEMS) + threadIdx.x; i0 < n; i0 += (u64)gridDim.x * (K1_THREADS * K1_ITEMS)) {
+        // ---- phase 1: accepted (u, r) pairs for every (particle, normal site) of this lane ----
+        double pu[M], pr[M];
 #pragma unroll
-        for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[(u64)d * n + i];
-        mp_stream rng;
-        rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
-        mp_generate_handler<Model> g(rng, obs.v);
-        model(g, t, prev, next);
+        for (int q = 0; q < M; ++q) { pu[q] = 0.; pr[q] = 1.; }
+        {
+            int p = 0, sidx = 0;         // current item: particle p, normal site index sidx
+            uint32_t att = 0;
+            // skip particles past the end
+            while (p < K1_ITEMS && ns > 0) {
+                const u64 i = i0 + (u64)p * K1_THREADS;
+                if (i >= n) break;
+                const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
+                                                    ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
+                const double u = mp_u01(b.a) * 2. - 1.;
+                const double v = mp_u01(b.b) * 2. - 1.;
+                const double r = u * u + v * v;
+                if (r == 0. || r > 1.) {  // normal.rs:22
+                    ++att;
+                } else {
+                    const int q = p * NS + sidx;
 #pragma unroll
-        for (int d = 0; d < D; ++d) x_out[(u64)d * n + i] = next[d];
-        const double w = overwrite ? g.weight : logw[i] + g.weight;  // particle_filter.rs:68 / :81
-        logw[i] = w;
-        lmax = fmax(lmax, w);
+                    for (int qq = 0; qq < M; ++qq) {
+                        pu[qq] = (qq == q) ? u : pu[qq];
+                        pr[qq] = (qq == q) ? r : pr[qq];
+                    }
+                    att = 0;
+                    if (++sidx == ns) { sidx = 0; ++p; }
+                }
+            }
+        }
+        // ---- phase 2: the model kernel in Generate mode --------------------------------------
+#pragma unroll
+        for (int p = 0; p < K1_ITEMS; ++p) {
+            const u64 i = i0 + (u64)p * K1_THREADS;
+            if (i < n) {
+                double prev[D], next[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[(u64)d * n + i];
+                mp_stream rng;
+                rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
+                mp_generate_handler<Model> g(rng, obs.v, &pu[p * NS], &pr[p * NS]);
+                model(g, t, prev, next);
+#pragma unroll
+                for (int d = 0; d < D; ++d) x_out[(u64)d * n + i] = next[d];
+                const double w = overwrite ? g.weight : logw[i] + g.weight;  // particle_filter.rs:68 / :81
+                logw[i] = w;
+                lmax = fmax(lmax, w);
+            }
+        }
     }
     __shared__ double s_max[K1_THREADS / 64];
     lmax = wave_max(lmax);
@@ -137,20 +185,62 @@ __device__ __forceinline__ u64 mp_quantize(double e, double scale) {
     return (r >= 0.) ? (u64)r : 0ull;  // NaN -> 0
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_normalize_scan(const double* __restrict__ logw, u64 n,
+// One row of the resampling table: tile-local inclusive fixed-point CDF value and the first state
+// component of the same particle, so that the probe that finds a parent also fetches its state.
+struct __attribute__((aligned(16))) mp_cx {
+    u64 cum;
+    double x0;
+};
+constexpr int GUIDE_BITS = 11;              // one guide bucket per table row (GUIDE_N == TILE): 2 B per particle
+constexpr int GUIDE_N = 1 << GUIDE_BITS;
+static_assert(GUIDE_N == TILE, "k_normalize_scan zeroes/stores the guide with one 8-byte word per thread");
+constexpr int GUIDE_DIRECT = 8;             // bucket runs longer than this are filled by the whole wave
+
+// Guide table (bucketed inverse CDF, per tile): bucket g covers tile-local targets t with
+// (t >> shift) == g, shift = max(0, bitlen(W) - 11) for the tile total W; guide[g] = first local
+// index j with cum_j >= max(1, g << shift).  A draw then starts its scan at guide[t >> shift]
+// and walks forward (expected < 2 rows).  Integer shifts only: no rounding anywhere.
+__device__ __forceinline__ int mp_guide_shift(u64 W) {
+    const int bits = 64 - __clzll((long long)W);  // W == 0 -> clz = 64 -> bits = 0
+    return bits > GUIDE_BITS ? bits - GUIDE_BITS : 0;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_normalize_scan(const double* __restrict__ logw, const double* __restrict__ x0, u64 n,
                                                                  const double* __restrict__ blockmax, int nb, int S,
-                                                                 u64* __restrict__ cum, u64* __restrict__ tilesum,
-                                                                 u64* __restrict__ tilesum2, mp_dev_scalars* scal) {
+                                                                 mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
+                                                                 u64* __restrict__ tilesum, u64* __restrict__ tilesum2,
+                                                                 mp_dev_scalars* scal) {
     __shared__ double s_red[SCAN_THREADS / 64];
     __shared__ u64 s_wsum[SCAN_THREADS / 64];
     __shared__ u64 s_wsum2[SCAN_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) unsigned short s_guide[GUIDE_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+    // issue the tile's loads first: they overlap the max reduction below
+    const double scale = mp_u2f((u64)(1023 + S) << 52);  // 2^S
+    const u64 base = (u64)blockIdx.x * TILE + (u64)tid * SCAN_ITEMS;
+    const bool full = base + SCAN_ITEMS <= n;
+    double w[SCAN_ITEMS], xv[SCAN_ITEMS];
+    if (full) {
+        const double2 a = *reinterpret_cast<const double2*>(logw + base);
+        const double2 b = *reinterpret_cast<const double2*>(logw + base + 2);
+        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+        const double2 xa = *reinterpret_cast<const double2*>(x0 + base);
+        const double2 xb = *reinterpret_cast<const double2*>(x0 + base + 2);
+        xv[0] = xa.x; xv[1] = xa.y; xv[2] = xb.x; xv[3] = xb.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) {
+            w[j] = (base + j < n) ? logw[base + j] : MP_NEG_INF;
+            xv[j] = (base + j < n) ? x0[base + j] : 0.;
+        }
+    }
     // m = max over the per-workgroup maxima (exact in any order)
     double m = MP_NEG_INF;
     for (int j = tid; j < nb; j += SCAN_THREADS) m = fmax(m, blockmax[j]);
     m = wave_max(m);
     if (lane == 0) s_red[wave] = m;
+    reinterpret_cast<u64*>(s_guide)[tid] = 0ull;  // SCAN_THREADS x 8 B = the whole guide
     __syncthreads();
     m = s_red[0];
 #pragma unroll
@@ -161,17 +251,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_normalize_scan(const double* _
         if (!ok) scal->degenerate = 1;
     }
 
-    const double scale = mp_u2f((u64)(1023 + S) << 52);  // 2^S
-    const u64 base = (u64)blockIdx.x * TILE + (u64)tid * SCAN_ITEMS;
-    double w[SCAN_ITEMS];
-    if (base + SCAN_ITEMS <= n) {
-        const double2 a = *reinterpret_cast<const double2*>(logw + base);
-        const double2 b = *reinterpret_cast<const double2*>(logw + base + 2);
-        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
-    } else {
-#pragma unroll
-        for (int j = 0; j < SCAN_ITEMS; ++j) w[j] = (base + j < n) ? logw[base + j] : MP_NEG_INF;
-    }
     u64 c[SCAN_ITEMS];
     u64 run = 0, run2 = 0;
 #pragma unroll
@@ -187,26 +266,60 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_normalize_scan(const double* _
     if (lane == 63) s_wsum[wave] = incl;
     if (lane == 0) s_wsum2[wave] = wtot2;
     __syncthreads();
-    u64 woff = 0;
-    for (int k = 0; k < wave; ++k) woff += s_wsum[k];
-    const u64 off = woff + (incl - run);
-    if (base + SCAN_ITEMS <= n) {
-        ulonglong2 o0, o1;
-        o0.x = off + c[0]; o0.y = off + c[1]; o1.x = off + c[2]; o1.y = off + c[3];
-        *reinterpret_cast<ulonglong2*>(cum + base) = o0;
-        *reinterpret_cast<ulonglong2*>(cum + base + 2) = o1;
-    } else {
+    u64 woff = 0, W = 0;
 #pragma unroll
-        for (int j = 0; j < SCAN_ITEMS; ++j)
-            if (base + j < n) cum[base + j] = off + c[j];
+    for (int k = 0; k < SCAN_THREADS / 64; ++k) {
+        const u64 v = s_wsum[k];
+        if (k < wave) woff += v;
+        W += v;
     }
-    if (tid == SCAN_THREADS - 1) tilesum[blockIdx.x] = off + run;
+    const u64 off = woff + (incl - run);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < n) {
+            mp_cx row;
+            row.cum = off + c[j];
+            row.x0 = xv[j];
+            cx[base + j] = row;
+        }
+    }
     if (tid == 0) {
+        tilesum[blockIdx.x] = W;
         u64 t2 = 0;
 #pragma unroll
         for (int k = 0; k < SCAN_THREADS / 64; ++k) t2 += s_wsum2[k];
         tilesum2[blockIdx.x] = t2;
     }
+
+    // ---- guide table of this tile ------------------------------------------------------------
+    const int shift = mp_guide_shift(W);
+    u64 prev = off;
+    int long_lo = 0, long_hi = -1, long_j = 0;  // at most one long run is kept per thread; extra ones fall back to direct writes
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        const u64 cur = off + c[j];
+        if (cur > prev) {
+            const int g_lo = prev ? (int)(prev >> shift) + 1 : 0;
+            const int g_hi = (int)(cur >> shift);
+            const unsigned short idx = (unsigned short)(tid * SCAN_ITEMS + j);
+            if (g_hi - g_lo < GUIDE_DIRECT || long_hi >= long_lo) {
+                for (int g = g_lo; g <= g_hi; ++g) s_guide[g] = idx;
+            } else {
+                long_lo = g_lo; long_hi = g_hi; long_j = idx;
+            }
+        }
+        prev = cur;
+    }
+    // wave-cooperative fill of long runs (a particle holding a large share of the tile's weight)
+    u64 pending = __ballot(long_hi >= long_lo);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int lo = __shfl(long_lo, leader, 64), hi = __shfl(long_hi, leader, 64), jj = __shfl(long_j, leader, 64);
+        for (int g = lo + lane; g <= hi; g += 64) s_guide[g] = (unsigned short)jj;
+        pending &= pending - 1;
+    }
+    __syncthreads();
+    reinterpret_cast<u64*>(guide + (u64)blockIdx.x * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -245,6 +358,15 @@ __device__ __forceinline__ void finalize_scalars(u64 Q, u64 Q2, int S, double* L
     *ess_out = (Qs * Qs) / Q2s;
 }
 
+__device__ __forceinline__ mp_cx load_row_nt(const mp_cx* p) {
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(p));
+    mp_cx r;
+    r.cum = v.x;
+    r.x0 = __builtin_bit_cast(double, (u64)v.y);
+    return r;
+}
+
 // target = max(1, ceil(k * Q / 2^52)), k < 2^52, Q < 2^63
 __device__ __forceinline__ u64 mp_target(u64 k52, u64 Q) {
     u64 lo = k52 * Q;
@@ -271,8 +393,11 @@ __device__ __forceinline__ uint32_t lower_bound_u64(Ptr a, uint32_t len, u64 tar
 // ---------------------------------------------------------------------------------------------
 // K3: draw, search, gather, reset
 // ---------------------------------------------------------------------------------------------
+// ABL > 0 are timing-only ablations used by tools/k3_ablate.hip (1: no global reads, 2: guide only).
+template <int ABL>
 __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1,
-                                                                uint32_t rc, int S, int D, const u64* __restrict__ cum,
+                                                                uint32_t rc, int S, int D, const mp_cx* __restrict__ cx,
+                                                                const unsigned short* __restrict__ guide,
                                                                 const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2,
                                                                 int nt, const double* __restrict__ x_old, double* __restrict__ x_new,
                                                                 uint32_t* __restrict__ parent, double* __restrict__ logw,
@@ -280,10 +405,15 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_glo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* s_incl = reinterpret_cast<u64*>(smem);  // [nt]
     u64* s_wtot = s_incl + nt;                   // [K3_THREADS/64]
-    block_scan_tiles<K3_THREADS>(tilesum, nt, s_incl, s_wtot);
+    if (ABL == 5) {  // timing-only: no tile-total loads / scan
+        for (int jj = threadIdx.x; jj < nt; jj += K3_THREADS) s_incl[jj] = (u64)(jj + 1) << 40;
+        __syncthreads();
+    } else {
+        block_scan_tiles<K3_THREADS>(tilesum, nt, s_incl, s_wtot);
+    }
     const u64 Q = s_incl[nt - 1];
 
-    if (blockIdx.x == 0) {  // workgroup-uniform: fold this normalisation into the filter scalars
+    if (blockIdx.x == 0 && ABL == 0) {  // workgroup-uniform: fold this normalisation into the filter scalars
         u64 q2 = 0;
         for (int j = threadIdx.x; j < nt; j += K3_THREADS) q2 += tilesum2[j];
         q2 = wave_sum_u64(q2);
@@ -304,21 +434,68 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_glo
         for (int j = threadIdx.x; j < nb; j += K3_THREADS) blockmax[j] = 0.;  // logw is 0 after a resample
     }
 
-    for (u64 i = (u64)blockIdx.x * K3_THREADS + threadIdx.x; i < n; i += (u64)gridDim.x * K3_THREADS) {
-        const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
-        const u64 target = mp_target(mp_u52(r.a), Q);
-        uint32_t b = lower_bound_u64(s_incl, (uint32_t)nt, target);
-        if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
-        const u64 excl = b ? s_incl[b - 1] : 0ull;
-        const u64 lt = target - excl;
-        const u64 tbase = (u64)b * TILE;
-        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
-        uint32_t j = lower_bound_u64(cum + tbase, tlen, lt);
-        if (j > tlen - 1) j = tlen - 1;
-        const u64 p = tbase + j;
-        parent[i] = (uint32_t)(slot_offset + p);
-        for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = x_old[(u64)d * n + p];  // traces[i] = traces[parents[i]].clone()
-        logw[i] = 0.;                                                              // log_weights.fill(0.)
+    // Each thread resolves K3_ITEMS draws with independent load chains (Philox -> LDS tile search ->
+    // guide entry -> two table rows), so that K3_ITEMS x 64 cache-line requests per wave are in flight
+    // at every hop instead of 64: the kernel is bound by the latency of these dependent hops.
+    for (u64 i0 = (u64)blockIdx.x * (K3_THREADS * K3_ITEMS) + threadIdx.x; i0 < n; i0 += (u64)gridDim.x * (K3_THREADS * K3_ITEMS)) {
+        u64 lt[K3_ITEMS], tbase[K3_ITEMS];
+        uint32_t tlen[K3_ITEMS], j[K3_ITEMS];
+        const unsigned short* gp[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {
+            const u64 i = i0 + (u64)k * K3_THREADS;
+            mp_u64x2 r;
+            if (ABL == 3) r.a = (i * 0x9E3779B97F4A7C15ull) ^ ((u64)rc << 20);  // timing-only: no Philox
+            else r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+            const u64 target = mp_target(mp_u52(r.a), Q);
+            uint32_t b = (ABL == 4) ? (uint32_t)((target >> 7) % (u64)nt)  // timing-only: no LDS search
+                                    : lower_bound_u64(s_incl, (uint32_t)nt, target);
+            if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
+            const u64 incl_b = s_incl[b];
+            const u64 excl = b ? s_incl[b - 1] : 0ull;
+            lt[k] = target - excl;                        // tile-local target, 1 <= lt <= W
+            const int shift = mp_guide_shift(incl_b - excl);
+            tbase[k] = (u64)b * TILE;
+            tlen[k] = (uint32_t)((n - tbase[k]) < (u64)TILE ? (n - tbase[k]) : (u64)TILE);
+            uint32_t g = (uint32_t)(lt[k] >> shift);
+            if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+            gp[k] = guide + (u64)b * GUIDE_N + g;
+        }
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) j[k] = (ABL == 1 || ABL >= 3) ? (uint32_t)(lt[k] & (TILE - 1)) : *gp[k];
+        mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {
+            if (j[k] > tlen[k] - 1) j[k] = tlen[k] - 1;
+            const uint32_t j1 = (j[k] + 1 < tlen[k]) ? j[k] + 1 : j[k];
+            if (ABL == 0) {
+                r0[k] = load_row_nt(cx + tbase[k] + j[k]);   // streamed: must not evict the guide from L2
+                r1[k] = load_row_nt(cx + tbase[k] + j1);
+            } else {
+                r0[k].cum = lt[k]; r0[k].x0 = (double)j[k]; r1[k] = r0[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {
+            const u64 i = i0 + (u64)k * K3_THREADS;
+            mp_cx row = r0[k];
+            uint32_t jj = j[k];
+            if (row.cum < lt[k] && jj + 1 < tlen[k]) {    // first row with cum >= lt
+                row = r1[k];
+                ++jj;
+                while (row.cum < lt[k] && jj + 1 < tlen[k]) {
+                    ++jj;
+                    row = load_row_nt(cx + tbase[k] + jj);
+                }
+            }
+            if (i < n) {
+                const u64 p = tbase[k] + jj;
+                parent[i] = (uint32_t)(slot_offset + p);
+                x_new[i] = row.x0;                        // traces[i] = traces[parents[i]].clone()
+                for (int d = 1; d < D; ++d) x_new[(u64)d * n + i] = x_old[(u64)d * n + p];
+                logw[i] = 0.;                             // log_weights.fill(0.)
+            }
+        }
     }
 }
 
@@ -405,8 +582,9 @@ static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out
     case MP_MODEL_LGSSM1: {
         if (m->n_params != 5 || !m->params) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM1 takes 5 params {mu0,sig0,a,sig_x,sig_y}");
         if (m->dim_state != 1 || m->dim_obs != 1) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM1: dim_state = dim_obs = 1");
-        mp_lgssm1 k{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4]};
+        mp_lgssm1 k{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4], 0.};
         if (!(k.sig0 > 0.) || !(k.sig_x > 0.) || !(k.sig_y > 0.)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM1: standard deviations must be > 0");
+        k.ln_sig_y = mp_log(k.sig_y);
         out.reset(new ModelOpsT<mp_lgssm1>(k));
         return MP_OK;
     }
@@ -435,7 +613,8 @@ struct mp_pf {
     double* x[2] = {nullptr, nullptr};
     int cur = 0;
     double* logw = nullptr;
-    u64* cum = nullptr;
+    mp_cx* cx = nullptr;
+    unsigned short* guide = nullptr;
     uint32_t* parent = nullptr;
     double* blockmax = nullptr;
     u64* tilesum = nullptr;
@@ -536,8 +715,8 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
 
 static int32_t launch_normalize(mp_pf* h) {
     LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
-    hipLaunchKernelGGL(k_normalize_scan, dim3(h->nt), dim3(SCAN_THREADS), 0, h->stream, h->logw, h->n, h->blockmax, h->nb, h->S, h->cum,
-                       h->tilesum, h->tilesum2, h->scal);
+    hipLaunchKernelGGL(k_normalize_scan, dim3(h->nt), dim3(SCAN_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->n, h->blockmax, h->nb, h->S,
+                       h->cx, h->guide, h->tilesum, h->tilesum2, h->scal);
     return check_launch("k_normalize_scan");
 }
 
@@ -587,16 +766,17 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     }
     const u64 n = h->n;
     const int d = h->ops->dim_state;
-    h->nb = (int)((n + K1_THREADS - 1) / K1_THREADS);
+    h->nb = (int)((n + K1_THREADS * K1_ITEMS - 1) / (K1_THREADS * K1_ITEMS));
     if (h->nb > K1_MAX_BLOCKS) h->nb = K1_MAX_BLOCKS;
     h->nt = (int)((n + TILE - 1) / TILE);
-    if (h->nt > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "n_particles per handle is limited to 2^25 in this build");
-    h->k3_grid = (int)((n + K3_THREADS - 1) / K3_THREADS);
+    if (h->nt > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "n_particles per handle is limited to 2^24 in this build");
+    h->k3_grid = (int)((n + K3_THREADS * K3_ITEMS - 1) / (K3_THREADS * K3_ITEMS));
     if (h->k3_grid > K3_MAX_BLOCKS) h->k3_grid = K3_MAX_BLOCKS;
     HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
     HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
     HIPCK(hipMalloc(&h->logw, sizeof(double) * n));
-    HIPCK(hipMalloc(&h->cum, sizeof(u64) * n));
+    HIPCK(hipMalloc(&h->cx, sizeof(mp_cx) * n));
+    HIPCK(hipMalloc(&h->guide, sizeof(unsigned short) * (size_t)h->nt * GUIDE_N));
     HIPCK(hipMalloc(&h->parent, sizeof(uint32_t) * n));
     HIPCK(hipMalloc(&h->blockmax, sizeof(double) * K1_MAX_BLOCKS));
     HIPCK(hipMalloc(&h->tilesum, sizeof(u64) * h->nt));
@@ -655,8 +835,8 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_resample_gather, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,
-                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cum, h->tilesum, h->tilesum2,
+        hipLaunchKernelGGL(k_resample_gather<0>, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide, h->tilesum, h->tilesum2,
                            h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
     }
     rc = check_launch("k_resample_gather");
@@ -800,7 +980,8 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->x[0]);
     (void)hipFree(h->x[1]);
     (void)hipFree(h->logw);
-    (void)hipFree(h->cum);
+    (void)hipFree(h->cx);
+    (void)hipFree(h->guide);
     (void)hipFree(h->parent);
     (void)hipFree(h->blockmax);
     (void)hipFree(h->tilesum);

@@ -40,14 +40,10 @@ struct mp_u64x2 {
 };
 
 MP_PHD void mp_mulhilo32(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    hi = __umulhi(a, b);
-    lo = a * b;
-#else
+    // one 32x32->64 multiply (v_mad_u64_u32 on gfx950) instead of a mul_lo/mul_hi pair
     const uint64_t p = (uint64_t)a * (uint64_t)b;
     hi = (uint32_t)(p >> 32);
     lo = (uint32_t)p;
-#endif
 }
 
 MP_PHD mp_u64x2 mp_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

@@ -1,0 +1,123 @@
+"""CPU: internal consistency of the oracle's particle filter variants and the canonical
+(order-free, fixed-point) resampling spec the GPU implements."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+
+def run(variant, n, T, seed, kind=1, ds=1, do=1, params=O.LGSSM_PARAMS, ys=None, args0=None):
+    ys = O.lgssm_observations(T) if ys is None else ys
+    pf = O.OraclePF(kind, ds, do, params, n, seed, variant)
+    pf.init_step(ys[:1], args0)
+    Ls, pars = [], []
+    for t in range(1, T):
+        Ls.append(pf.resample())
+        pars.append(pf.parents().copy())
+        pf.step(ys[t:t + 1])
+    return dict(L=np.array(Ls), par=np.array(pars), x=pf.state().copy(), lw=pf.log_weights().copy(),
+                lml=pf.log_marginal_likelihood_estimate(), pf=pf)
+
+
+def test_structure_faithful_equals_algorithm_faithful():
+    """Dynamic-handler ParticleSystem (string-keyed tries, O(N) categorical scan) vs the SoA engine."""
+    for canon in (0, 1):
+        a = run(canon, 300, 12, 5)
+        b = run(canon | O.VARIANT_SOA, 300, 12, 5)
+        assert np.array_equal(a["par"], b["par"])
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["lw"], b["lw"])
+        assert a["lml"] == b["lml"] and np.array_equal(a["L"], b["L"])
+
+
+def test_fast_search_is_index_identical_to_linear_scan():
+    a = run(0, 500, 10, 9)
+    b = run(O.VARIANT_FAST_SEARCH, 500, 10, 9)
+    assert np.array_equal(a["par"], b["par"]) and a["lml"] == b["lml"]
+
+
+def test_literal_vs_canonical_agree():
+    """libm + sequential fp64 sums (the reference's arithmetic) vs mp_math + fixed-point CDF."""
+    a = run(O.VARIANT_SOA, 20000, 20, 77)
+    b = run(O.VARIANT_SOA | O.VARIANT_CANONICAL, 20000, 20, 77)
+    assert abs(a["lml"] - b["lml"]) <= 1e-12 * abs(a["lml"])
+    mism = int((a["par"] != b["par"]).sum())
+    assert mism <= 2  # expected ~ N*sqrt(N)*eps per draw: essentially never at this size
+    assert np.allclose(a["x"], b["x"], rtol=0, atol=1e-13) or mism > 0
+
+
+def test_c1_config_against_kalman():
+    """BASELINE.json configs[0]: LGSSM d=1, T=50, 1k particles on the CPU path; Kalman ground truth."""
+    ys = O.lgssm_observations(50)
+    exact = O.kalman_log_ml(ys)
+    est = [run(O.VARIANT_SOA, 1000, 50, s, ys=ys)["lml"] for s in range(8)]
+    assert abs(np.mean(est) - exact) < 0.15
+    assert np.std(est) < 0.3
+    big = run(O.VARIANT_SOA | O.VARIANT_CANONICAL, 100000, 50, 3, ys=ys)["lml"]
+    assert abs(big - exact) < 0.05
+
+
+def test_stale_ess_quirk():
+    """particle_filter.rs:98-100 reads buffers only refreshed inside resample(): 1/N before any."""
+    for variant in (0, O.VARIANT_SOA, O.VARIANT_SOA | O.VARIANT_CANONICAL):
+        pf = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, 64, 1, variant)
+        assert pf.effective_sample_size() == pytest.approx(1.0 / 64, rel=1e-15)
+        pf.init_step([0.5])
+        assert pf.effective_sample_size() == pytest.approx(1.0 / 64, rel=1e-15)
+        pf.resample()
+        ess = pf.effective_sample_size()
+        assert 1.0 <= ess <= 64.0
+        pf.step([0.1])
+        assert pf.effective_sample_size() == ess  # still the value of the last resample
+
+
+def test_canonical_spec_pieces(oracle):
+    rng = np.random.default_rng(0)
+    n = 5000
+    lw = rng.normal(-1.0, 2.0, n)
+    L, ess, Q = C.c_double(), C.c_double(), C.c_uint64()
+    cum = np.empty(n, dtype=np.uint64)
+    rc = oracle.oracle_canonical_normalize(O.dptr(lw), n, n, C.byref(L), C.byref(ess), C.byref(Q), cum.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == 0
+    S = 62 - 13
+    assert int(cum[-1]) == Q.value and Q.value < 2 ** 63
+    assert np.all(np.diff(cum.astype(object)) >= 0)
+    assert int(np.diff(np.concatenate([[0], cum]).astype(object)).max()) == 2 ** S  # the max particle gets exactly 2^S
+    ref = float(np.logaddexp.reduce(lw))
+    assert abs(L.value - ref) < 1e-12
+    w = np.exp(lw - ref)
+    assert abs(ess.value - 1.0 / np.sum(w * w)) < 1e-6 * ess.value
+    # target rule: max(1, ceil(k Q / 2^52)); k = 0 -> 1 (first positive-weight particle), k = 2^52-1 -> <= Q
+    assert oracle.oracle_canonical_target(0, Q.value) == 1
+    assert oracle.oracle_canonical_target(2 ** 52 - 1, Q.value) <= Q.value
+    for k in (1, 12345, 2 ** 51, 2 ** 52 - 1):
+        assert oracle.oracle_canonical_target(k, Q.value) == max(1, -((-k * Q.value) // 2 ** 52))
+    # shard independence: normalising with n_global > n only changes the scale
+    rc = oracle.oracle_canonical_normalize(O.dptr(lw), n, 8 * n, C.byref(L), C.byref(ess), C.byref(Q), None)
+    assert abs(L.value - ref) < 1e-11
+
+
+def test_degenerate_weights_status():
+    pf = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, 32, 1, O.VARIANT_SOA | O.VARIANT_CANONICAL)
+    pf.init_step([np.inf])
+    with pytest.raises(O.OracleError) as e:
+        pf.resample()
+    assert e.value.code == 4
+    pf2 = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, 32, 1, 0)
+    with pytest.raises(O.OracleError) as e:
+        pf2.step([0.0])
+    assert e.value.code == 2
+
+
+def test_spiral_model_runs_like_smc_rs():
+    """modppl/tests/smc.rs:48-91 shape: spiral Unfold, 500 particles x 20 steps, resample each step."""
+    T, n = 20, 500
+    ang = 0.7
+    obs = np.array([[0.4 * np.cos(2 * np.pi * t / T + ang), 0.4 * np.sin(2 * np.pi * t / T + ang)] for t in range(T)])
+    a = run(0 | O.VARIANT_FAST_SEARCH, n, T, 3, kind=2, ds=2, do=2, params=np.zeros(0), ys=obs, args0=[0.0, 0.0])
+    b = run(O.VARIANT_SOA, n, T, 3, kind=2, ds=2, do=2, params=np.zeros(0), ys=obs, args0=[0.0, 0.0])
+    assert np.array_equal(a["par"], b["par"]) and np.array_equal(a["x"], b["x"])
+    assert np.isfinite(a["lml"])
+    traj = a["pf"].trajectory(0)
+    assert traj.shape == (T, 2)  # traces[i].retv: one state per step (smc.rs:67 reads .last())
