@@ -77,3 +77,29 @@ MP_HD int mp_categorical_scan(double u, const double* probs, int n) {
     }
     return x > 0 ? x - 1 : 0;
 }
+
+// mvnormal.rs:14-22 with the per-call determinant/inverse hoisted: cov_inv (row-major KxK) and
+// ln_det = mp_log(det cov) are model constants.  Quadratic form in the reference's order:
+// (c^T * cov_inv) first, then dotted with c.
+template <int K>
+MP_HD double mp_mvnormal_logpdf_pre(const double* x, const double* mu, const double* cov_inv, double ln_det) {
+    double c[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) c[i] = x[i] - mu[i];
+    double maha = 0.;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        double r = 0.;
+#pragma unroll
+        for (int i = 0; i < K; ++i) r += c[i] * cov_inv[i * K + j];
+        maha += r * c[j];
+    }
+    return -((double)K * MP_LN_2PI_CANON + ln_det + maha) / 2.;
+}
+
+// categorical.rs:12-32 over a small probability table
+MP_HD double mp_categorical_logpdf(int x, const double* probs, int n) { return (x >= 0 && x < n) ? mp_log(probs[x]) : MP_NEG_INF; }
+MP_HD int mp_categorical_sample(mp_site& st, const double* probs, int n) {
+    const mp_u64x2 blk = st.next_block();
+    return mp_categorical_scan(mp_u01(blk.a), probs, n);
+}

@@ -33,7 +33,6 @@ MP_HD double mp_u2f(uint64_t u) { return __builtin_bit_cast(double, u); }
 
 #define MP_INF (mp_u2f(0x7FF0000000000000ull))
 #define MP_NEG_INF (mp_u2f(0xFFF0000000000000ull))
-#define MP_LN_2PI 1.8378770664093453  /* ln(2*pi), nearest double: 0x3FFD67F1C864BEB5 */
 #define MP_2PI 6.283185307179586      /* 2*pi as the reference computes it: 2.*PI */
 #define MP_PI 3.141592653589793
 
@@ -121,3 +120,142 @@ MP_HD double mp_log(double x) {
 // sqrt and division are IEEE-754 correctly rounded for fp64 both in SSE2 and in the gfx950
 // expansion hipcc emits without fast-math (checked bit-for-bit in tests/test_gpu_math.py).
 MP_HD double mp_sqrt(double x) { return sqrt(x); }
+
+// ---------------------------------------------------------------------------------------
+// sin / cos / atan2 — same contract as mp_exp/mp_log: one definition, IEEE ops only, evaluated
+// identically on host and device.  Classical fdlibm schemes (k_sin.c, k_cos.c, e_rem_pio2.c medium
+// case, s_atan.c, e_atan2.c; Sun Microsystems notice above applies), constants as published.
+// Domain of the argument reduction: |x| < 2^20 * pi/2 (~1.6e6); beyond that NaN is returned (the
+// models on the path keep angles within a few turns).
+// ---------------------------------------------------------------------------------------
+MP_HD double mp_ksin(double x, double y) {  // |x| <= pi/4, y = tail
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x;
+    const double w = z * z;
+    const double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    const double v = z * x;
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+MP_HD double mp_kcos(double x, double y) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double w = z * z;
+    const double r = z * (C1 + z * (C2 + z * C3)) + w * w * (C4 + z * (C5 + z * C6));
+    const double hz = 0.5 * z;
+    const double ww = 1.0 - hz;
+    return ww + (((1.0 - ww) - hz) + (z * r - x * y));
+}
+// x = n*(pi/2) + (y0 + y1), |y0| <= pi/4 (+tiny); returns n mod 4 (non-negative), or -1 out of domain
+MP_HD int mp_rem_pio2(double x, double* y0, double* y1) {
+    const double INVPIO2 = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632673412561417e+00;   // first 33 bits of pi/2
+    const double P1T = 6.07710050650619224932e-11;  // pi/2 - P1
+    const double P2 = 6.07710050630396597660e-11;   // second 33 bits
+    const double P2T = 2.02226624879595063154e-21;  // pi/2 - (P1 + P2)
+    if (!(fabs(x) < 1647099.0)) return -1;           // also catches NaN / inf
+    const double fn = rint(x * INVPIO2);
+    double r = x - fn * P1;                          // exact: fn < 2^21, P1 has 33 bits
+    double w = fn * P1T;
+    double y = r - w;
+    // second iteration when cancellation ate too many bits (difference of exponents > 16)
+    const int ex = (int)((mp_f2u(x) >> 52) & 0x7FF);
+    const int ey = (int)((mp_f2u(y) >> 52) & 0x7FF);
+    if (ex - ey > 16) {
+        const double t = r;
+        w = fn * P2;
+        r = t - w;
+        w = fn * P2T - ((t - r) - w);
+        y = r - w;
+    }
+    *y0 = y;
+    *y1 = (r - y) - w;
+    const long long n = (long long)fn;
+    return (int)(n & 3);
+}
+MP_HD double mp_sin(double x) {
+    if (fabs(x) <= 0.78539816339744828) return mp_ksin(x, 0.);
+    double y0, y1;
+    const int n = mp_rem_pio2(x, &y0, &y1);
+    if (n < 0) return mp_u2f(0x7FF8000000000000ull);
+    switch (n) {
+    case 0: return mp_ksin(y0, y1);
+    case 1: return mp_kcos(y0, y1);
+    case 2: return -mp_ksin(y0, y1);
+    default: return -mp_kcos(y0, y1);
+    }
+}
+MP_HD double mp_cos(double x) {
+    if (fabs(x) <= 0.78539816339744828) return mp_kcos(x, 0.);
+    double y0, y1;
+    const int n = mp_rem_pio2(x, &y0, &y1);
+    if (n < 0) return mp_u2f(0x7FF8000000000000ull);
+    switch (n) {
+    case 0: return mp_kcos(y0, y1);
+    case 1: return -mp_ksin(y0, y1);
+    case 2: return -mp_kcos(y0, y1);
+    default: return mp_ksin(y0, y1);
+    }
+}
+
+MP_HD double mp_atan(double x) {
+    const double atanhi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00};
+    const double atanlo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    const double aT[11] = {3.33333333333329318027e-01,  -1.99999999998764832476e-01, 1.42857142725034663711e-01,  -1.11111104054623557880e-01,
+                           9.09088713343650656196e-02,  -7.69187620504482999495e-02, 6.66107313738753120669e-02,  -5.83357013379057348645e-02,
+                           4.97687799461593236017e-02,  -3.65315727442169155270e-02, 1.62858201153657823623e-02};
+    if (x != x) return x;
+    const bool neg = (mp_f2u(x) >> 63) != 0;
+    double ax = fabs(x);
+    int id;
+    if (ax >= 7.3786976294838206e19) {  // 2^66
+        const double r = atanhi[3] + 7.52316384526264005100e-37;
+        return neg ? -r : r;
+    }
+    if (ax < 0.4375) {
+        if (ax < 3.7252902984619141e-09) return x;  // 2^-28
+        id = -1;
+    } else if (ax < 1.1875) {
+        if (ax < 0.6875) { id = 0; ax = (2.0 * ax - 1.0) / (2.0 + ax); }
+        else { id = 1; ax = (ax - 1.0) / (ax + 1.0); }
+    } else {
+        if (ax < 2.4375) { id = 2; ax = (ax - 1.5) / (1.0 + 1.5 * ax); }
+        else { id = 3; ax = -1.0 / ax; }
+    }
+    const double z = ax * ax;
+    const double w = z * z;
+    const double s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const double s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) {
+        const double r = ax - ax * (s1 + s2);
+        return neg ? -r : r;
+    }
+    const double r = atanhi[id] - ((ax * (s1 + s2) - atanlo[id]) - ax);
+    return neg ? -r : r;
+}
+// atan2(y, x) with the usual IEEE special cases (f64::atan2 semantics)
+MP_HD double mp_atan2(double y, double x) {
+    const double PI = 3.1415926535897931160E+00, PI_LO = 1.2246467991473531772E-16;
+    if (x != x || y != y) return x + y;
+    const uint64_t ux = mp_f2u(x), uy = mp_f2u(y);
+    const bool xneg = (ux >> 63) != 0, yneg = (uy >> 63) != 0;
+    const double ax = fabs(x), ay = fabs(y);
+    if (ux == 0x3FF0000000000000ull) return mp_atan(y);  // x == 1
+    if (ay == 0.) return xneg ? (yneg ? -PI : PI) : y;   // y = +-0
+    if (ax == 0.) return yneg ? -PI / 2 : PI / 2;
+    if (ax == MP_INF) {
+        if (ay == MP_INF) { const double r = xneg ? 3.0 * (PI / 4) : PI / 4; return yneg ? -r : r; }
+        const double r = xneg ? PI : 0.0;
+        return yneg ? -r : r;
+    }
+    if (ay == MP_INF) return yneg ? -PI / 2 : PI / 2;
+    const int ex = (int)((ux >> 52) & 0x7FF), ey = (int)((uy >> 52) & 0x7FF);
+    double z;
+    if (ey - ex > 60) z = PI / 2 + 0.5 * PI_LO;           // |y/x| > 2^60
+    else if (xneg && (ex - ey) > 60) z = 0.0;             // |y/x| < 2^-60, x < 0
+    else z = mp_atan(fabs(y / x));
+    if (!xneg) return yneg ? -z : z;
+    const double r = PI - (z - PI_LO);
+    return yneg ? -r : r;
+}

@@ -69,6 +69,26 @@ struct mp_generate_handler {
     MP_HD double normal(double mu, double sd) {
         return normal<SITE>(mu, sd, mp_log(sd));
     }
+    // constrained mvnormal site with hoisted covariance constants (dim K = Model::DIM_OBS slots k..k+K-1)
+    template <int SITE, int K>
+    MP_HD void mvnormal_observed(const double* mu, const double* cov_inv, double ln_det) {
+        constexpr int k = Model::obs_of(SITE);
+        static_assert(k >= 0, "mvnormal_observed: the site must be constrained on this path");
+        weight += mp_mvnormal_logpdf_pre<K>(obs + k, mu, cov_inv, ln_det);
+    }
+    // categorical over a small table; values travel as doubles in the constraint / state arrays
+    template <int SITE>
+    MP_HD int categorical(const double* probs, int n) {
+        constexpr int k = Model::obs_of(SITE);
+        if constexpr (k >= 0) {
+            const int x = (int)obs[k];
+            weight += mp_categorical_logpdf(x, probs, n);
+            return x;
+        } else {
+            mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
+            return mp_categorical_sample(st, probs, n);
+        }
+    }
     template <int SITE>
     MP_HD double uniform(double a, double b) {
         constexpr int k = Model::obs_of(SITE);
@@ -106,5 +126,148 @@ struct mp_lgssm1 {
         else x = g.template normal<X>(a * prev[0], sig_x);
         g.template normal<Y>(x, sig_y, ln_sig_y);
         next[0] = x;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// spiral_kernel — modppl/tests/dyngenfns/unfold.rs:14-32 (the reference's own DynUnfold model):
+//   t==0: r ~ uniform(0,1) %= "r"; theta ~ uniform(0,2pi) %= "theta"
+//   t>0 : dr ~ normal(0,0.1) %= "dr"; dtheta ~ normal(0.4,0.2) %= "dtheta"; pol = prev + (dr, dtheta)
+//   mvnormal(polar_to_cartesian(pol), 0.001*I) %= "obs"
+// ---------------------------------------------------------------------------------------
+struct mp_spiral {
+    static constexpr int DIM_STATE = 2, DIM_OBS = 2;
+    enum { R = 0, THETA = 1, OBS = 2 };
+    static constexpr int obs_of(int site) { return site == OBS ? 0 : -1; }
+    static constexpr int MAX_NORMALS = 2;
+    static constexpr int normal_index(int site) { return site; }  // dr -> 0, dtheta -> 1
+    MP_HD int n_normals(int64_t t) const { return t == 0 ? 0 : 2; }
+    MP_HD uint32_t normal_site(int idx) const { return (uint32_t)idx; }
+    double cov_inv[4];
+    double ln_det;
+
+    template <class H>
+    MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
+        double pol0, pol1;
+        if (t == 0) {
+            pol0 = g.template uniform<R>(0., 1.);
+            pol1 = g.template uniform<THETA>(0., 2. * MP_PI);
+        } else {
+            const double dr = g.template normal<R>(0., 0.1);
+            const double dtheta = g.template normal<THETA>(0.4, 0.2);
+            pol0 = prev[0] + dr;
+            pol1 = prev[1] + dtheta;
+        }
+        const double pos[2] = {pol0 * mp_cos(pol1), pol0 * mp_sin(pol1)};
+        g.template mvnormal_observed<OBS, 2>(pos, cov_inv, ln_det);
+        next[0] = pol0;
+        next[1] = pol1;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// HMM — modppl/tests/hmm/model.rs:33-80: new_state ~ categorical(prior | transition column);
+// weight = categorical.logpdf(observation, emission column of the new state).
+// Column-stochastic tables, stored emission[o][s], transition[s2][s1] as the reference builds them.
+// ---------------------------------------------------------------------------------------
+#define MP_HMM_MAX 8
+struct mp_hmm {
+    static constexpr int DIM_STATE = 1, DIM_OBS = 1;
+    enum { STATE = 0, OBSV = 1 };
+    static constexpr int obs_of(int site) { return site == OBSV ? 0 : -1; }
+    static constexpr int MAX_NORMALS = 1;  // none used; arrays need a non-zero extent
+    static constexpr int normal_index(int) { return 0; }
+    MP_HD int n_normals(int64_t) const { return 0; }
+    MP_HD uint32_t normal_site(int) const { return 0; }
+    int n_states, n_obs;
+    double prior[MP_HMM_MAX];
+    double emission_col[MP_HMM_MAX][MP_HMM_MAX];    // [state][obs]  : column `state` of the emission matrix
+    double transition_col[MP_HMM_MAX][MP_HMM_MAX];  // [prev][next]  : column `prev` of the transition matrix
+
+    template <class H>
+    MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
+        int s;
+        if (t == 0) {
+            s = g.template categorical<STATE>(prior, n_states);
+        } else {
+            int ps = (int)prev[0];
+            ps = ps < 0 ? 0 : (ps >= n_states ? n_states - 1 : ps);
+            s = g.template categorical<STATE>(transition_col[ps], n_states);
+        }
+        g.template categorical<OBSV>(emission_col[s], n_obs);
+        next[0] = (double)s;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Bearings-only tracker, d=4 (BASELINE.json config 3), dt = 1:
+//   t==0: px ~ normal(p0x, sig_p0); py ~ normal(p0y, sig_p0); vx ~ normal(0, sig_v0); vy ~ normal(0, sig_v0)
+//   t>0 : ax ~ normal(0, sig_a); ay ~ normal(0, sig_a); v' = v + a; p' = (p + v) + 0.5*a
+//   theta ~ normal(atan2(py, px), sig_theta) observed (no wrap)
+// ---------------------------------------------------------------------------------------
+struct mp_bearings {
+    static constexpr int DIM_STATE = 4, DIM_OBS = 1;
+    enum { S0 = 0, S1 = 1, S2 = 2, S3 = 3, THETA = 4 };
+    static constexpr int obs_of(int site) { return site == THETA ? 0 : -1; }
+    static constexpr int MAX_NORMALS = 4;
+    static constexpr int normal_index(int site) { return site; }
+    MP_HD int n_normals(int64_t t) const { return t == 0 ? 4 : 2; }
+    MP_HD uint32_t normal_site(int idx) const { return (uint32_t)idx; }
+    double p0x, p0y, sig_p0, sig_v0, sig_a, sig_theta;
+    double ln_sig_theta;
+
+    template <class H>
+    MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
+        double px, py, vx, vy;
+        if (t == 0) {
+            px = g.template normal<S0>(p0x, sig_p0);
+            py = g.template normal<S1>(p0y, sig_p0);
+            vx = g.template normal<S2>(0., sig_v0);
+            vy = g.template normal<S3>(0., sig_v0);
+        } else {
+            const double ax = g.template normal<S0>(0., sig_a);
+            const double ay = g.template normal<S1>(0., sig_a);
+            px = (prev[0] + prev[2]) + 0.5 * ax;
+            py = (prev[1] + prev[3]) + 0.5 * ay;
+            vx = prev[2] + ax;
+            vy = prev[3] + ay;
+        }
+        g.template normal<THETA>(mp_atan2(py, px), sig_theta, ln_sig_theta);
+        next[0] = px; next[1] = py; next[2] = vx; next[3] = vy;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Banded LGSSM, d = D (BASELINE.json config 5): A = a*(I + band*B), B = ones on the two off-diagonals
+//   t==0: x_j ~ normal(0, sig0) %= "x/j";  t>0: x_j ~ normal(a*(x_j + band*(x_{j-1}+x_{j+1})), sig_x) %= "x/j"
+//   normal(x_j, sig_y) %= "y/j" observed, j = 0..D-1.    sites: x/j -> j, y/j -> D + j
+// ---------------------------------------------------------------------------------------
+template <int D>
+struct mp_lgssm_band {
+    static constexpr int DIM_STATE = D, DIM_OBS = D;
+    static constexpr int obs_of(int site) { return site >= D ? site - D : -1; }
+    static constexpr int MAX_NORMALS = D;
+    static constexpr int normal_index(int site) { return site; }
+    MP_HD int n_normals(int64_t) const { return D; }
+    MP_HD uint32_t normal_site(int idx) const { return (uint32_t)idx; }
+    double a, band, sig0, sig_x, sig_y;
+    double ln_sig_y;
+
+    template <class H, int J>
+    MP_HD void site(H& g, int64_t t, const double* prev, double* next) const {
+        double x;
+        if (t == 0) {
+            x = g.template normal<J>(0., sig0);
+        } else {
+            const double nb = (J > 0 ? prev[J > 0 ? J - 1 : 0] : 0.) + (J < D - 1 ? prev[J < D - 1 ? J + 1 : 0] : 0.);
+            x = g.template normal<J>(a * (prev[J] + band * nb), sig_x);
+        }
+        g.template normal<D + J>(x, sig_y, ln_sig_y);
+        next[J] = x;
+        if constexpr (J + 1 < D) site<H, J + 1>(g, t, prev, next);
+    }
+    template <class H>
+    MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
+        site<H, 0>(g, t, prev, next);
     }
 };

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "../../include/modppl_hip.h"
+#include "mp_linalg.h"
 #include "mp_models.h"
 
 typedef unsigned long long u64;
@@ -66,7 +67,9 @@ struct mp_dev_scalars {
 };
 
 constexpr int K1_THREADS = 256;
-constexpr int K1_ITEMS = 4;
+// particles per lane in k_propagate: 4 pre-drawn (u, r) pairs per lane whatever the model's number of normal sites
+template <class Model>
+constexpr int k1_items() { return Model::MAX_NORMALS >= 4 ? 1 : 4 / Model::MAX_NORMALS; }
 constexpr int K1_MAX_BLOCKS = 2048;
 constexpr int SCAN_THREADS = 512;
 constexpr int SCAN_ITEMS = 4;
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_propagate(Model model, u64 n, u6
                                                           mp_obs obs, mp_state0 s0, int overwrite, double* __restrict__ blockmax) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
+    constexpr int K1_ITEMS = k1_items<Model>();
     constexpr int M = K1_ITEMS * NS;
     double lmax = MP_NEG_INF;
     const int ns = model.n_normals(t);  // wave-uniform
@@ -560,6 +564,7 @@ struct PropagateArgs {
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
+    int k1_items = 1;
     virtual ~ModelOps() {}
     virtual void propagate(const PropagateArgs& a) const = 0;
 };
@@ -569,6 +574,8 @@ struct ModelOpsT : ModelOps {
     explicit ModelOpsT(const Model& m) : model(m) {
         dim_state = Model::DIM_STATE;
         dim_obs = Model::DIM_OBS;
+        k1_items = ::k1_items<Model>();
+        static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
     }
     void propagate(const PropagateArgs& a) const override {
         hipLaunchKernelGGL(k_propagate<Model>, dim3(a.grid), dim3(K1_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
@@ -587,6 +594,66 @@ static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out
         k.ln_sig_y = mp_log(k.sig_y);
         out.reset(new ModelOpsT<mp_lgssm1>(k));
         return MP_OK;
+    }
+    case MP_MODEL_SPIRAL: {
+        if (m->dim_state != 2 || m->dim_obs != 2) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_SPIRAL: dim_state = dim_obs = 2");
+        mp_spiral k;
+        const std::vector<double> cov = {0.001, 0., 0., 0.001};  // unfold.rs:29
+        std::vector<double> inv;
+        if (!mp_host_inverse(cov, 2, inv)) return mp_fail(MP_ERR_INVALID_ARG, "covariance not invertible");
+        for (int i = 0; i < 4; ++i) k.cov_inv[i] = inv[i];
+        k.ln_det = mp_log(mp_host_det(cov, 2));
+        out.reset(new ModelOpsT<mp_spiral>(k));
+        return MP_OK;
+    }
+    case MP_MODEL_HMM: {
+        if (m->n_params < 2 || !m->params) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_HMM: params = {S, O, prior[S], emission[O][S], transition[S][S]}");
+        const int S = (int)m->params[0], O = (int)m->params[1];
+        if (S < 1 || O < 1 || S > MP_HMM_MAX || O > MP_HMM_MAX) return mp_fail(MP_ERR_UNSUPPORTED, "MP_MODEL_HMM: 1..8 states / observations");
+        if (m->n_params != 2 + S + O * S + S * S) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_HMM: params length mismatch");
+        if (m->dim_state != 1 || m->dim_obs != 1) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_HMM: dim_state = dim_obs = 1");
+        mp_hmm k{};
+        k.n_states = S; k.n_obs = O;
+        const double* prior = m->params + 2;
+        const double* emis = prior + S;
+        const double* trans = emis + O * S;
+        auto sums_to_one = [](const double* p, int n, int stride) {  // categorical.rs:13,23: assert |sum - 1| <= 1e-8
+            double s_ = 0.;
+            for (int i = 0; i < n; ++i) s_ += p[i * stride];
+            return std::fabs(s_ - 1.0) <= 1e-8;
+        };
+        if (!sums_to_one(prior, S, 1)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_HMM: prior does not sum to 1 (eps 1e-8)");
+        for (int s_ = 0; s_ < S; ++s_) {
+            if (!sums_to_one(emis + s_, O, S)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_HMM: emission column does not sum to 1");
+            if (!sums_to_one(trans + s_, S, S)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_HMM: transition column does not sum to 1");
+        }
+        for (int s_ = 0; s_ < S; ++s_) k.prior[s_] = prior[s_];
+        for (int s_ = 0; s_ < S; ++s_) {
+            for (int o = 0; o < O; ++o) k.emission_col[s_][o] = emis[o * S + s_];
+            for (int s2 = 0; s2 < S; ++s2) k.transition_col[s_][s2] = trans[s2 * S + s_];
+        }
+        out.reset(new ModelOpsT<mp_hmm>(k));
+        return MP_OK;
+    }
+    case MP_MODEL_BEARINGS: {
+        if (m->n_params != 6 || !m->params) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_BEARINGS takes 6 params {p0x,p0y,sig_p0,sig_v0,sig_a,sig_theta}");
+        if (m->dim_state != 4 || m->dim_obs != 1) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_BEARINGS: dim_state = 4, dim_obs = 1");
+        mp_bearings k{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4], m->params[5], 0.};
+        if (!(k.sig_p0 > 0.) || !(k.sig_v0 > 0.) || !(k.sig_a > 0.) || !(k.sig_theta > 0.)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_BEARINGS: standard deviations must be > 0");
+        k.ln_sig_theta = mp_log(k.sig_theta);
+        out.reset(new ModelOpsT<mp_bearings>(k));
+        return MP_OK;
+    }
+    case MP_MODEL_LGSSM_BAND: {
+        if (m->n_params != 6 || !m->params) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM_BAND takes 6 params {D,a,band,sig0,sig_x,sig_y}");
+        const int D = (int)m->params[0];
+        if (m->dim_state != D || m->dim_obs != D) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM_BAND: dim_state = dim_obs = D");
+        if (!(m->params[3] > 0.) || !(m->params[4] > 0.) || !(m->params[5] > 0.)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM_BAND: standard deviations must be > 0");
+        const double ln_sy = mp_log(m->params[5]);
+        if (D == 16) { out.reset(new ModelOpsT<mp_lgssm_band<16>>(mp_lgssm_band<16>{m->params[1], m->params[2], m->params[3], m->params[4], m->params[5], ln_sy})); return MP_OK; }
+        if (D == 4) { out.reset(new ModelOpsT<mp_lgssm_band<4>>(mp_lgssm_band<4>{m->params[1], m->params[2], m->params[3], m->params[4], m->params[5], ln_sy})); return MP_OK; }
+        if (D == 2) { out.reset(new ModelOpsT<mp_lgssm_band<2>>(mp_lgssm_band<2>{m->params[1], m->params[2], m->params[3], m->params[4], m->params[5], ln_sy})); return MP_OK; }
+        return mp_fail(MP_ERR_UNSUPPORTED, "MP_MODEL_LGSSM_BAND: D in {2, 4, 16} is compiled in");
     }
     default:
         return mp_fail(MP_ERR_UNSUPPORTED, "model kind " + std::to_string(m->kind) + " is not compiled into this library");
@@ -766,7 +833,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     }
     const u64 n = h->n;
     const int d = h->ops->dim_state;
-    h->nb = (int)((n + K1_THREADS * K1_ITEMS - 1) / (K1_THREADS * K1_ITEMS));
+    h->nb = (int)((n + (u64)K1_THREADS * h->ops->k1_items - 1) / ((u64)K1_THREADS * h->ops->k1_items));
     if (h->nb > K1_MAX_BLOCKS) h->nb = K1_MAX_BLOCKS;
     h->nt = (int)((n + TILE - 1) / TILE);
     if (h->nt > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "n_particles per handle is limited to 2^24 in this build");

@@ -254,6 +254,9 @@ int32_t oracle_pf_destroy(oracle_pf* h) { delete h; return MP_OK; }
 // ---- math / rng / distribution probes ---------------------------------------------------------
 void oracle_mp_exp(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_exp(x[i]); }
 void oracle_mp_log(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_log(x[i]); }
+void oracle_mp_sin(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_sin(x[i]); }
+void oracle_mp_cos(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_cos(x[i]); }
+void oracle_mp_atan2(const double* y, const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_atan2(y[i], x[i]); }
 void oracle_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_10(ctr, key, out); }
 void oracle_u01_stream(uint64_t seed, uint32_t slot, uint32_t step, uint32_t domain, uint32_t site, int64_t n, double* out) {
     Rng r; r.seed = seed; r.slot = slot; r.step = step; r.at(domain, site);

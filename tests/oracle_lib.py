@@ -68,6 +68,11 @@ def load():
     L.oracle_mp_exp.argtypes = [dp, i64, dp]
     L.oracle_mp_log.argtypes = [dp, i64, dp]
     L.oracle_mp_exp.restype = None
+    for f in (L.oracle_mp_sin, L.oracle_mp_cos):
+        f.argtypes = [dp, i64, dp]
+        f.restype = None
+    L.oracle_mp_atan2.argtypes = [dp, dp, i64, dp]
+    L.oracle_mp_atan2.restype = None
     L.oracle_mp_log.restype = None
     L.oracle_philox.argtypes = [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.oracle_philox.restype = None
