@@ -29,3 +29,30 @@ def lgssm_model(mu0=0.0, sig0=1.0, a=0.9, sig_x=0.5, sig_y=1.0):
     """Linear-Gaussian SSM, d=1 (BASELINE.json configs 1-2):
     t==0: x ~ normal(mu0, sig0); t>0: x ~ normal(a*x_prev, sig_x); y ~ normal(x, sig_y) observed."""
     return UnfoldModel(capi.MP_MODEL_LGSSM1, 1, 1, [mu0, sig0, a, sig_x, sig_y], "lgssm1")
+
+
+def spiral_model():
+    """`spiral_model` of modppl/tests/dyngenfns/unfold.rs:14-32: polar random walk observed through
+    mvnormal(pos, 0.001 I).  State (r, theta); init_step's `args` is the (unused) initial state."""
+    return UnfoldModel(capi.MP_MODEL_SPIRAL, 2, 2, [], "spiral")
+
+
+def hmm_model(prior, emission_matrix, transition_matrix):
+    """`hmm::HMM` of modppl/tests/hmm/model.rs.  Matrices column-stochastic as the reference builds them
+    (`dmatrix![...].transpose()`): emission_matrix[o, s] = p(o | s), transition_matrix[s2, s1] = p(s2 | s1)."""
+    prior = np.asarray(prior, dtype=np.float64)
+    e = np.asarray(emission_matrix, dtype=np.float64)
+    t = np.asarray(transition_matrix, dtype=np.float64)
+    S, O = prior.size, e.shape[0]
+    assert e.shape == (O, S) and t.shape == (S, S)
+    return UnfoldModel(capi.MP_MODEL_HMM, 1, 1, np.concatenate([[S, O], prior, e.reshape(-1), t.reshape(-1)]), "hmm")
+
+
+def bearings_model(p0x=1.0, p0y=1.0, sig_p0=1.0, sig_v0=0.1, sig_a=0.05, sig_theta=0.02):
+    """Bearings-only tracker, d=4 (BASELINE.json config 3): constant velocity + accel noise, theta = atan2(py, px) + noise."""
+    return UnfoldModel(capi.MP_MODEL_BEARINGS, 4, 1, [p0x, p0y, sig_p0, sig_v0, sig_a, sig_theta], "bearings")
+
+
+def lgssm_band_model(D=16, a=0.9, band=0.05, sig0=1.0, sig_x=0.5, sig_y=1.0):
+    """Banded LGSSM d=D (BASELINE.json config 5): x' = a (I + band B) x + sig_x z, y = x + sig_y e."""
+    return UnfoldModel(capi.MP_MODEL_LGSSM_BAND, D, D, [D, a, band, sig0, sig_x, sig_y], f"lgssm_band{D}")

@@ -187,6 +187,12 @@ int32_t oracle_pf_create(const mp_model_desc* m, uint64_t n, uint64_t seed, cons
                 e->model = std::make_unique<SoaSpiral>();
             } else if (m->kind == MP_MODEL_HMM) {
                 e->model = std::make_unique<SoaHmm>(hmm_from_params(m->params, m->n_params));
+            } else if (m->kind == MP_MODEL_BEARINGS) {
+                if (m->n_params != 6) throw Panic("bearings: 6 params");
+                e->model = std::make_unique<SoaBearings>(BearingsParams{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4], m->params[5]});
+            } else if (m->kind == MP_MODEL_LGSSM_BAND) {
+                if (m->n_params != 6) throw Panic("lgssm_band: 6 params");
+                e->model = std::make_unique<SoaLgssmBand>(BandParams{(int)m->params[0], m->params[1], m->params[2], m->params[3], m->params[4], m->params[5]});
             } else throw Panic("unsupported model kind for the SoA engine");
             e->pf = std::make_unique<SoaPf>(e->model.get(), (size_t)n, seed, canon, shard ? shard->n_global : 0, shard ? shard->slot_offset : 0);
             h->impl = std::move(e);
@@ -210,6 +216,26 @@ int32_t oracle_pf_create(const mp_model_desc* m, uint64_t n, uint64_t seed, cons
                 e->mk_constraints = [](const double* y) { DynTrie c; c.observe("obs", arc(Vec{y[0], y[1]})); return c; };
                 e->mk_state = [](const double* a) { return Vec{a[0], a[1]}; };
                 e->put_state = [](const Vec& s, double* o) { o[0] = s[0]; o[1] = s[1]; };
+                e->ps = std::make_unique<DynPf<Vec>::PS>(e->model, (size_t)n, seed);
+                e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
+                h->impl = std::move(e);
+            } else if (m->kind == MP_MODEL_BEARINGS || m->kind == MP_MODEL_LGSSM_BAND) {
+                auto e = std::make_unique<DynPf<Vec>>();
+                int d, dobs;
+                if (m->kind == MP_MODEL_BEARINGS) {
+                    if (m->n_params != 6) throw Panic("bearings: 6 params");
+                    e->model = make_bearings_model(BearingsParams{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4], m->params[5]});
+                    d = 4; dobs = 1;
+                    e->mk_constraints = [](const double* y) { DynTrie c; c.observe("theta", arc(y[0])); return c; };
+                } else {
+                    if (m->n_params != 6) throw Panic("lgssm_band: 6 params");
+                    d = dobs = (int)m->params[0];
+                    e->model = make_lgssm_band_model(BandParams{d, m->params[1], m->params[2], m->params[3], m->params[4], m->params[5]});
+                    e->mk_constraints = [d](const double* y) { DynTrie c; for (int j = 0; j < d; ++j) c.observe("y/" + std::to_string(j), arc(y[j])); return c; };
+                }
+                e->dim_state = d; e->dim_obs = dobs;
+                e->mk_state = [d](const double* a) { return Vec(a, a + d); };
+                e->put_state = [d](const Vec& s, double* o) { for (int j = 0; j < d; ++j) o[j] = s[(size_t)j]; };
                 e->ps = std::make_unique<DynPf<Vec>::PS>(e->model, (size_t)n, seed);
                 e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
                 h->impl = std::move(e);

@@ -70,8 +70,9 @@ inline Vec lgssm_simulate_observations(LgssmParams p, uint64_t seed, int T) {
 // ---------------------------------------------------------------------------------------
 // spiral model — tests/dyngenfns/unfold.rs:10-32
 // ---------------------------------------------------------------------------------------
-inline double o_cos(double x) { return std::cos(x); }
-inline double o_sin(double x) { return std::sin(x); }
+inline double o_cos(double x) { return canonical_mode() ? mp_cos(x) : std::cos(x); }
+inline double o_sin(double x) { return canonical_mode() ? mp_sin(x) : std::sin(x); }
+inline double o_atan2(double y, double x) { return canonical_mode() ? mp_atan2(y, x) : std::atan2(y, x); }
 inline Vec polar_to_cartesian(const Vec& pol) { return {pol[0] * o_cos(pol[1]), pol[0] * o_sin(pol[1])}; }
 
 inline DynUnfold<Vec> make_spiral_model() {
@@ -100,6 +101,77 @@ inline DynUnfold<Vec> make_spiral_model() {
             if (a == "r" || a == "dr") return 0u;
             if (a == "theta" || a == "dtheta") return 1u;
             return 2u;  // obs
+        });
+    return DynUnfold<Vec>(std::move(k));
+}
+
+// ---------------------------------------------------------------------------------------
+// Bearings-only tracker d=4 (BASELINE.json config 3), dt = 1.  State (px,py,vx,vy).
+// ---------------------------------------------------------------------------------------
+struct BearingsParams { double p0x, p0y, sig_p0, sig_v0, sig_a, sig_theta; };
+inline DynUnfold<Vec> make_bearings_model(BearingsParams p) {
+    using A = std::pair<int64_t, Vec>;
+    using H = DynGenFnHandler<A, Vec>;
+    DynGenFn<A, Vec> k(
+        [p](H& g, A ta) -> Vec {
+            const int64_t t = ta.first;
+            const Vec& prev = ta.second;
+            double px, py, vx, vy;
+            if (t == 0) {
+                px = g.template sample_at<double>(normal, NormalParams{p.p0x, p.sig_p0}, "px");
+                py = g.template sample_at<double>(normal, NormalParams{p.p0y, p.sig_p0}, "py");
+                vx = g.template sample_at<double>(normal, NormalParams{0., p.sig_v0}, "vx");
+                vy = g.template sample_at<double>(normal, NormalParams{0., p.sig_v0}, "vy");
+            } else {
+                const double ax = g.template sample_at<double>(normal, NormalParams{0., p.sig_a}, "ax");
+                const double ay = g.template sample_at<double>(normal, NormalParams{0., p.sig_a}, "ay");
+                px = (prev[0] + prev[2]) + 0.5 * ax;
+                py = (prev[1] + prev[3]) + 0.5 * ay;
+                vx = prev[2] + ax;
+                vy = prev[3] + ay;
+            }
+            g.template sample_at<double>(normal, NormalParams{o_atan2(py, px), p.sig_theta}, "theta");
+            return Vec{px, py, vx, vy};
+        },
+        [](const std::string& a) -> uint32_t {
+            if (a == "px" || a == "ax") return 0u;
+            if (a == "py" || a == "ay") return 1u;
+            if (a == "vx") return 2u;
+            if (a == "vy") return 3u;
+            return 4u;  // theta
+        });
+    return DynUnfold<Vec>(std::move(k));
+}
+
+// ---------------------------------------------------------------------------------------
+// Banded LGSSM d=D (BASELINE.json config 5): sites "x/j" -> j, "y/j" -> D + j.
+// ---------------------------------------------------------------------------------------
+struct BandParams { int D; double a, band, sig0, sig_x, sig_y; };
+inline DynUnfold<Vec> make_lgssm_band_model(BandParams p) {
+    using A = std::pair<int64_t, Vec>;
+    using H = DynGenFnHandler<A, Vec>;
+    const int D = p.D;
+    DynGenFn<A, Vec> k(
+        [p](H& g, A ta) -> Vec {
+            const int64_t t = ta.first;
+            const Vec& prev = ta.second;
+            const int D_ = p.D;
+            Vec x((size_t)D_);
+            for (int j = 0; j < D_; ++j) {
+                const std::string sj = std::to_string(j);
+                if (t == 0) {
+                    x[(size_t)j] = g.template sample_at<double>(normal, NormalParams{0., p.sig0}, "x/" + sj);
+                } else {
+                    const double nb = (j > 0 ? prev[(size_t)j - 1] : 0.) + (j < D_ - 1 ? prev[(size_t)j + 1] : 0.);
+                    x[(size_t)j] = g.template sample_at<double>(normal, NormalParams{p.a * (prev[(size_t)j] + p.band * nb), p.sig_x}, "x/" + sj);
+                }
+                g.template sample_at<double>(normal, NormalParams{x[(size_t)j], p.sig_y}, "y/" + sj);
+            }
+            return x;
+        },
+        [D](const std::string& a) -> uint32_t {
+            const uint32_t j = (uint32_t)std::stoi(a.substr(2));
+            return a[0] == 'x' ? j : (uint32_t)D + j;
         });
     return DynUnfold<Vec>(std::move(k));
 }

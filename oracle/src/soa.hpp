@@ -56,6 +56,49 @@ struct SoaSpiral : SoaModel {  // tests/dyngenfns/unfold.rs:14-32
     }
 };
 
+struct SoaBearings : SoaModel {
+    BearingsParams p;
+    explicit SoaBearings(BearingsParams p_) : p(p_) { dim_state = 4; dim_obs = 1; }
+    double kernel(Rng& r, int64_t t, const double* prev, double* next, const double* obs) const override {
+        double px, py, vx, vy;
+        if (t == 0) {
+            r.at(DOM_MODEL, 0); px = normal.random(r, {p.p0x, p.sig_p0});
+            r.at(DOM_MODEL, 1); py = normal.random(r, {p.p0y, p.sig_p0});
+            r.at(DOM_MODEL, 2); vx = normal.random(r, {0., p.sig_v0});
+            r.at(DOM_MODEL, 3); vy = normal.random(r, {0., p.sig_v0});
+        } else {
+            r.at(DOM_MODEL, 0); const double ax = normal.random(r, {0., p.sig_a});
+            r.at(DOM_MODEL, 1); const double ay = normal.random(r, {0., p.sig_a});
+            px = (prev[0] + prev[2]) + 0.5 * ax;
+            py = (prev[1] + prev[3]) + 0.5 * ay;
+            vx = prev[2] + ax;
+            vy = prev[3] + ay;
+        }
+        next[0] = px; next[1] = py; next[2] = vx; next[3] = vy;
+        return normal.logpdf(obs[0], {o_atan2(py, px), p.sig_theta});
+    }
+};
+
+struct SoaLgssmBand : SoaModel {
+    BandParams p;
+    explicit SoaLgssmBand(BandParams p_) : p(p_) { dim_state = p.D; dim_obs = p.D; }
+    double kernel(Rng& r, int64_t t, const double* prev, double* next, const double* obs) const override {
+        double w = 0.;
+        for (int j = 0; j < p.D; ++j) {
+            r.at(DOM_MODEL, (uint32_t)j);
+            double x;
+            if (t == 0) x = normal.random(r, {0., p.sig0});
+            else {
+                const double nb = (j > 0 ? prev[j - 1] : 0.) + (j < p.D - 1 ? prev[j + 1] : 0.);
+                x = normal.random(r, {p.a * (prev[j] + p.band * nb), p.sig_x});
+            }
+            next[j] = x;
+            w += normal.logpdf(obs[j], {x, p.sig_y});
+        }
+        return w;
+    }
+};
+
 struct SoaHmm : SoaModel {  // tests/hmm/model.rs:33-80
     HmmParams p;
     explicit SoaHmm(HmmParams p_) : p(std::move(p_)) { dim_state = 1; dim_obs = 1; }
