@@ -26,6 +26,7 @@
 // gives the same bits (DESIGN.md §4 states the spec; oracle/src/inference.hpp restates it on the CPU).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -399,7 +400,8 @@ __device__ __forceinline__ uint32_t lower_bound_u64(Ptr a, uint32_t len, u64 tar
 // ---------------------------------------------------------------------------------------------
 // ABL > 0 are timing-only ablations used by tools/k3_ablate.hip (1: no global reads, 2: guide only).
 template <int ABL>
-__global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1,
+__global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out, u64 n_global, u64 slot_offset, uint32_t domain,
+                                                                uint32_t k0, uint32_t k1,
                                                                 uint32_t rc, int S, int D, const mp_cx* __restrict__ cx,
                                                                 const unsigned short* __restrict__ guide,
                                                                 const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2,
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_glo
     }
     const u64 Q = s_incl[nt - 1];
 
-    if (blockIdx.x == 0 && ABL == 0) {  // workgroup-uniform: fold this normalisation into the filter scalars
+    if (blockIdx.x == 0 && ABL == 0 && scal != nullptr) {  // workgroup-uniform: fold this normalisation into the filter scalars
         u64 q2 = 0;
         for (int j = threadIdx.x; j < nt; j += K3_THREADS) q2 += tilesum2[j];
         q2 = wave_sum_u64(q2);
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_glo
     // Each thread resolves K3_ITEMS draws with independent load chains (Philox -> LDS tile search ->
     // guide entry -> two table rows), so that K3_ITEMS x 64 cache-line requests per wave are in flight
     // at every hop instead of 64: the kernel is bound by the latency of these dependent hops.
-    for (u64 i0 = (u64)blockIdx.x * (K3_THREADS * K3_ITEMS) + threadIdx.x; i0 < n; i0 += (u64)gridDim.x * (K3_THREADS * K3_ITEMS)) {
+    for (u64 i0 = (u64)blockIdx.x * (K3_THREADS * K3_ITEMS) + threadIdx.x; i0 < n_out; i0 += (u64)gridDim.x * (K3_THREADS * K3_ITEMS)) {
         u64 lt[K3_ITEMS], tbase[K3_ITEMS];
         uint32_t tlen[K3_ITEMS], j[K3_ITEMS];
         const unsigned short* gp[K3_ITEMS];
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_glo
             const u64 i = i0 + (u64)k * K3_THREADS;
             mp_u64x2 r;
             if (ABL == 3) r.a = (i * 0x9E3779B97F4A7C15ull) ^ ((u64)rc << 20);  // timing-only: no Philox
-            else r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+            else r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
             const u64 target = mp_target(mp_u52(r.a), Q);
             uint32_t b = (ABL == 4) ? (uint32_t)((target >> 7) % (u64)nt)  // timing-only: no LDS search
                                     : lower_bound_u64(s_incl, (uint32_t)nt, target);
@@ -492,12 +494,14 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_glo
                     row = load_row_nt(cx + tbase[k] + jj);
                 }
             }
-            if (i < n) {
+            if (i < n_out) {
                 const u64 p = tbase[k] + jj;
-                parent[i] = (uint32_t)(slot_offset + p);
-                x_new[i] = row.x0;                        // traces[i] = traces[parents[i]].clone()
-                for (int d = 1; d < D; ++d) x_new[(u64)d * n + i] = x_old[(u64)d * n + p];
-                logw[i] = 0.;                             // log_weights.fill(0.)
+                parent[i] = (uint32_t)p;
+                if (x_new) {
+                    x_new[i] = row.x0;                    // traces[i] = traces[parents[i]].clone()
+                    for (int d = 1; d < D; ++d) x_new[(u64)d * n_out + i] = x_old[(u64)d * n + p];
+                }
+                if (logw) logw[i] = 0.;                   // log_weights.fill(0.)
             }
         }
     }
@@ -902,8 +906,8 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_resample_gather<0>, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,
-                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide, h->tilesum, h->tilesum2,
+        hipLaunchKernelGGL(k_resample_gather<0>, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
+                           (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide, h->tilesum, h->tilesum2,
                            h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
     }
     rc = check_launch("k_resample_gather");
@@ -1061,12 +1065,81 @@ int32_t mp_pf_destroy(mp_pf* h) {
     return MP_OK;
 }
 
+// out[i] = a[i] - *b  (log_normalized_weights = w_i - log_total_weight, importance.rs:23-25)
+__global__ void k_sub_scalar(const double* __restrict__ a, const double* __restrict__ b, u64 n, double* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] - *b;
+}
+// IS query: log total weight and log_ml = L - ln N from the tile totals (importance.rs:21-22)
+__global__ __launch_bounds__(K3_THREADS) void k_is_finalize(const u64* __restrict__ tilesum, int nt, int S, u64 n, mp_dev_scalars* scal) {
+    __shared__ u64 s_a[K3_THREADS / 64];
+    u64 q = 0;
+    for (int j = threadIdx.x; j < nt; j += K3_THREADS) q += tilesum[j];
+    q = wave_sum_u64(q);
+    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 Q = 0;
+        for (int k = 0; k < K3_THREADS / 64; ++k) Q += s_a[k];
+        const double inv = mp_u2f((u64)(1023 - S) << 52);
+        const double L = scal->m + mp_log((double)Q * inv);
+        scal->L = L;
+        scal->lml_fresh = L - mp_log((double)n);
+    }
+}
+
 int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples,
                                  uint64_t num_ret_samples, uint64_t seed, int32_t device, double* log_ml_estimate,
                                  double* log_normalized_weights, uint64_t* resampled_indices, double* final_states) {
-    (void)model; (void)args0; (void)obs; (void)n_steps; (void)num_samples; (void)num_ret_samples; (void)seed; (void)device;
-    (void)log_ml_estimate; (void)log_normalized_weights; (void)resampled_indices; (void)final_states;
-    return mp_fail(MP_ERR_UNSUPPORTED, "importance_resampling: not in this build yet");
+    if (!model || !obs) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (num_ret_samples > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "num_ret_samples must fit u32");
+    mp_pf* h = nullptr;
+    int32_t rc = mp_pf_create(model, num_samples, seed, nullptr, 0, device, nullptr, &h);
+    if (rc != MP_OK) return rc;
+    struct Guard { mp_pf* h; ~Guard() { mp_pf_destroy(h); } } guard{h};
+    // importance_sampling: N x generate(model_args, constraints) over all n_steps constraints (importance.rs:18-20)
+    rc = mp_pf_init_step(h, args0, obs, n_steps);
+    if (rc != MP_OK) return rc;
+    rc = launch_normalize(h);
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(k_is_finalize, dim3(1), dim3(K3_THREADS), 0, h->stream, h->tilesum, h->nt, h->S, h->n, h->scal);
+    rc = check_launch("k_is_finalize");
+    if (rc != MP_OK) return rc;
+    rc = fetch_scalars(h);
+    if (rc != MP_OK) return rc;
+    if (log_ml_estimate) *log_ml_estimate = h->h_scal->lml_fresh;
+    if (log_normalized_weights) {
+        double* tmp = h->aos;  // n doubles of scratch (dim_state >= 1)
+        hipLaunchKernelGGL(k_sub_scalar, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->logw, &h->scal->L, h->n, tmp);
+        rc = check_launch("k_sub_scalar");
+        if (rc != MP_OK) return rc;
+        HIPCK(hipMemcpyAsync(log_normalized_weights, tmp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    if (final_states) {
+        rc = mp_pf_read_state(h, final_states);
+        if (rc != MP_OK) return rc;
+    }
+    if (resampled_indices && num_ret_samples > 0) {
+        // importance_resampling: M categorical draws over exp(lnw) (importance.rs:44-47), slot j of DOM_IS
+        uint32_t* d_idx = nullptr;
+        HIPCK(hipMalloc(&d_idx, sizeof(uint32_t) * num_ret_samples));
+        const int grid = (int)std::min<u64>((num_ret_samples + K3_THREADS * K3_ITEMS - 1) / (K3_THREADS * K3_ITEMS), (u64)K3_MAX_BLOCKS);
+        const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
+        hipLaunchKernelGGL(k_resample_gather<0>, dim3(grid), dim3(K3_THREADS), lds, h->stream, h->n, (u64)num_ret_samples, h->n_global, (u64)0,
+                           (uint32_t)MP_DOM_IS, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), 0u, h->S, h->ops->dim_state, h->cx, h->guide,
+                           h->tilesum, h->tilesum2, h->nt, (const double*)nullptr, (double*)nullptr, d_idx, (double*)nullptr,
+                           (double*)nullptr, 0, (mp_dev_scalars*)nullptr);
+        rc = check_launch("k_resample_gather(IS)");
+        std::vector<uint32_t> idx(num_ret_samples);
+        hipError_t e1 = hipMemcpyAsync(idx.data(), d_idx, sizeof(uint32_t) * num_ret_samples, hipMemcpyDeviceToHost, h->stream);
+        hipError_t e2 = hipStreamSynchronize(h->stream);
+        (void)hipFree(d_idx);
+        if (rc != MP_OK) return rc;
+        if (e1 != hipSuccess || e2 != hipSuccess) return mp_fail(MP_ERR_HIP, "importance_resampling: index copy failed");
+        for (uint64_t j = 0; j < num_ret_samples; ++j) resampled_indices[j] = idx[j];
+    }
+    return MP_OK;
 }
 
 }  // extern "C"

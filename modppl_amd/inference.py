@@ -136,3 +136,38 @@ class ParticleSystem:
             self.close()
         except Exception:
             pass
+
+
+def importance_sampling(model, model_args, constraints, num_samples, seed, *, device=0):
+    """`importance_sampling(model, model_args, constraints, num_samples)` — modppl/src/inference/importance.rs:12-28.
+
+    Returns (traces, log_normalized_weights, log_ml_estimate); `traces` is the array of final states
+    (`traces[i].retv.last()`), since choices live in SoA columns on the device."""
+    states, lnw, lml, _ = _importance(model, model_args, constraints, num_samples, 0, seed, device)
+    return states, lnw, lml
+
+
+def importance_resampling(model, model_args, constraints, num_samples, num_ret_samples, seed, *, device=0):
+    """`importance_resampling(model, model_args, constraints, num_samples, num_ret_samples)` — importance.rs:37-50.
+
+    Returns (traces, resampled_indices, log_ml_estimate) like the reference (ALL traces plus M indices)."""
+    states, _, lml, idx = _importance(model, model_args, constraints, num_samples, num_ret_samples, seed, device)
+    return states, idx, lml
+
+
+def _importance(model, model_args, constraints, num_samples, num_ret, seed, device):
+    L = capi.load()
+    obs = np.ascontiguousarray(constraints, dtype=np.float64)
+    if obs.size == 0 or obs.size % model.dim_obs:
+        raise capi.ModpplError(capi.MP_ERR_CONSTRAINTS, "constraints must hold dim_obs values per time step")
+    obs = obs.reshape(-1, model.dim_obs)
+    a = None if model_args is None else np.ascontiguousarray(model_args, dtype=np.float64).reshape(-1)
+    desc = model.desc()
+    lml = C.c_double()
+    lnw = np.empty(int(num_samples))
+    states = np.empty((int(num_samples), model.dim_state))
+    idx = np.empty(int(num_ret), dtype=np.uint64)
+    capi.check(L.mp_importance_resampling(C.byref(desc), _dptr(a) if a is not None else None, _dptr(obs), obs.shape[0], int(num_samples),
+                                          int(num_ret), int(seed), int(device), C.byref(lml), _dptr(lnw),
+                                          idx.ctypes.data_as(C.POINTER(C.c_uint64)) if num_ret else None, _dptr(states)))
+    return states, lnw, lml.value, idx

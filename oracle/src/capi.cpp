@@ -277,6 +277,75 @@ int32_t oracle_pf_read_trajectory(oracle_pf* h, uint64_t i, double* out, int32_t
 int32_t oracle_pf_time(oracle_pf* h, int64_t* out) { GUARD({ *out = h->impl->time(); }) }
 int32_t oracle_pf_destroy(oracle_pf* h) { delete h; return MP_OK; }
 
+// ---- importance.rs:12-50 ------------------------------------------------------------------------
+// variant bit 1 = canonical, bit 2 = SoA engine (else the generic importance_resampling over the dynamic DynUnfold).
+int32_t oracle_importance_resampling(const mp_model_desc* m, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples,
+                                     uint64_t num_ret_samples, uint64_t seed, int32_t variant, double* log_ml_estimate,
+                                     double* log_normalized_weights, uint64_t* resampled_indices, double* final_states) {
+    GUARD({
+        const bool canon = variant & 1, soa = variant & 2;
+        oracle_pf::Scope scope(canon);
+        if (soa) {
+            oracle_pf* h = nullptr;
+            if (oracle_pf_create(m, num_samples, seed, nullptr, 0, variant, &h) != MP_OK) throw Panic(g_err);
+            std::unique_ptr<oracle_pf> guard(h);
+            auto* e = dynamic_cast<SoaEngine*>(h->impl.get());
+            e->pf->init_step(args0, obs, n_steps);
+            const std::vector<double>& w = e->pf->logw;
+            double L;
+            CanonNorm c;
+            if (canon) { c = canonical_normalize(w, num_samples); if (c.m == -INFINITY) throw Panic("all log-weights are -inf"); L = c.L; }
+            else L = logsumexp(w);
+            if (log_ml_estimate) *log_ml_estimate = L - o_ln((double)num_samples);
+            std::vector<double> probs;
+            for (size_t i = 0; i < w.size(); ++i) {
+                const double lnw = w[i] - L;
+                if (log_normalized_weights) log_normalized_weights[i] = lnw;
+                if (!canon) probs.push_back(o_exp(lnw));
+            }
+            if (final_states) std::memcpy(final_states, e->pf->x.data(), e->pf->x.size() * sizeof(double));
+            if (resampled_indices) {
+                std::vector<double> cdf;
+                if (!canon) { Categorical::check_sum(probs); double t = 0.; for (double p : probs) { t += p; cdf.push_back(t); } }
+                for (uint64_t j = 0; j < num_ret_samples; ++j) {
+                    Rng r; r.seed = seed; r.slot = (uint32_t)j; r.step = 0; r.at(DOM_IS, 0);
+                    if (canon) resampled_indices[j] = canonical_parent(c.cum, canonical_target(r.u52(), c.Q));
+                    else {
+                        const double u = r.u01();
+                        if (!(0. < u)) throw Panic("categorical returned -1 (u == 0)");
+                        const size_t p = (size_t)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+                        if (p >= cdf.size()) throw Panic("categorical: index out of bounds");
+                        resampled_indices[j] = p;
+                    }
+                }
+            }
+        } else {
+            auto run = [&](auto& model, auto mk_state, auto mk_constraints, auto put_state, int d, int dobs) {
+                std::vector<DynTrie> cons;
+                for (int k = 0; k < n_steps; ++k) cons.push_back(mk_constraints(obs + (size_t)k * dobs));
+                std::vector<double> z((size_t)d, 0.);
+                auto res = importance_resampling(seed, model, std::make_pair((int64_t)n_steps, mk_state(args0 ? args0 : z.data())), cons,
+                                                 (uint32_t)num_samples, (uint32_t)num_ret_samples, canon);
+                if (log_ml_estimate) *log_ml_estimate = res.log_ml_estimate;
+                for (size_t i = 0; i < res.traces.size(); ++i) {
+                    if (log_normalized_weights) log_normalized_weights[i] = res.log_normalized_weights[i];
+                    if (final_states) put_state(res.traces[i].retv->back(), final_states + i * (size_t)d);
+                }
+                if (resampled_indices) for (size_t j = 0; j < res.resampled_indices.size(); ++j) resampled_indices[j] = res.resampled_indices[j];
+            };
+            if (m->kind == MP_MODEL_LGSSM1) {
+                auto model = make_lgssm_model(LgssmParams{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4]});
+                run(model, [](const double* a) { return a[0]; }, [](const double* y) { DynTrie c; c.observe("y", arc(y[0])); return c; },
+                    [](const double& s_, double* o) { o[0] = s_; }, 1, 1);
+            } else if (m->kind == MP_MODEL_SPIRAL) {
+                auto model = make_spiral_model();
+                run(model, [](const double* a) { return Vec{a[0], a[1]}; }, [](const double* y) { DynTrie c; c.observe("obs", arc(Vec{y[0], y[1]})); return c; },
+                    [](const Vec& s_, double* o) { o[0] = s_[0]; o[1] = s_[1]; }, 2, 2);
+            } else throw Panic("dynamic importance_resampling: lgssm1 / spiral only");
+        }
+    })
+}
+
 // ---- math / rng / distribution probes ---------------------------------------------------------
 void oracle_mp_exp(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_exp(x[i]); }
 void oracle_mp_log(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_log(x[i]); }

@@ -65,6 +65,7 @@ def load():
     L.oracle_pf_read_trajectory.argtypes = [p, u64, dp, C.POINTER(i32)]
     L.oracle_pf_time.argtypes = [p, C.POINTER(i64)]
     L.oracle_pf_destroy.argtypes = [p]
+    L.oracle_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
     L.oracle_mp_exp.argtypes = [dp, i64, dp]
     L.oracle_mp_log.argtypes = [dp, i64, dp]
     L.oracle_mp_exp.restype = None
@@ -212,3 +213,21 @@ def kalman_log_ml(ys, params=LGSSM_PARAMS):
     L = load()
     ys = np.ascontiguousarray(ys, dtype=np.float64)
     return L.oracle_kalman_log_ml(dptr(np.ascontiguousarray(params)), dptr(ys), len(ys))
+
+
+def importance_resampling(kind, dim_state, dim_obs, params, obs, num_samples, num_ret, seed, variant, args0=None):
+    """oracle importance_resampling -> (log_ml, log_normalized_weights, indices, final_states)."""
+    L = load()
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    desc = ModelDesc(kind, dim_state, dim_obs, len(params), dptr(params))
+    obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, dim_obs)
+    lml = C.c_double()
+    lnw = np.empty(num_samples)
+    idx = np.empty(num_ret, dtype=np.uint64)
+    xs = np.empty((num_samples, dim_state))
+    a = None if args0 is None else dptr(np.ascontiguousarray(args0, dtype=np.float64))
+    rc = L.oracle_importance_resampling(C.byref(desc), a, dptr(obs), obs.shape[0], num_samples, num_ret, seed, variant, C.byref(lml),
+                                        dptr(lnw), idx.ctypes.data_as(C.POINTER(C.c_uint64)), dptr(xs))
+    if rc != 0:
+        raise OracleError(rc, L.oracle_last_error().decode())
+    return lml.value, lnw, idx, xs

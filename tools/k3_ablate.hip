@@ -13,8 +13,8 @@ float run_k3(mp_pf* h, int iters) {
     const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
     hipEventRecord(a, h->stream);
     for (int it = 0; it < iters; ++it)
-        hipLaunchKernelGGL(k_resample_gather<ABL>, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,
-                           1u, 2u, (uint32_t)it, h->S, 1, h->cx, h->guide, h->tilesum, h->tilesum2, h->nt, h->x[0], h->x[1], h->parent,
+        hipLaunchKernelGGL(k_resample_gather<ABL>, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
+                           (uint32_t)MP_DOM_RESAMPLE, 1u, 2u, (uint32_t)it, h->S, 1, h->cx, h->guide, h->tilesum, h->tilesum2, h->nt, h->x[0], h->x[1], h->parent,
                            h->aos /* scratch instead of logw */, h->blockmax + 1024, 0, h->scal);
     hipEventRecord(b, h->stream);
     hipEventSynchronize(b);
