@@ -135,6 +135,41 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
                                  double* log_ml_estimate, double* log_normalized_weights, uint64_t* resampled_indices,
                                  double* final_states);
 
+/* ---- Metropolis-Hastings — modppl/src/inference/mh.rs:9-75 -------------------------------- */
+/* N independent chains advanced in lockstep (chains never communicate: replicas only).  The model
+ * is the reference's `hierarchical_model` (modppl/tests/dyngenfns/hierarchical.rs:33-47):
+ *   is_linear ~ bernoulli(0.7); coeffs = linear() | quadratic() (a, b[, c] ~ normal(0,1));
+ *   y_i ~ normal(a + b x_i [+ c x_i^2], 0.1) observed.
+ * Static site ids (the stand-in for trie addresses): */
+enum mp_mh_site { MP_SITE_IS_LINEAR = 0, MP_SITE_A = 1, MP_SITE_B = 2, MP_SITE_C = 3 };
+enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1 };
+enum mp_mh_proposal_kind {
+    MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1, /* hierarchical_drift_proposal(tr, drift_std): hierarchical.rs:62-70; args = {drift_std} */
+};
+typedef struct mp_mh mp_mh;
+
+/* Initial traces: model.generate(xs, observations) per chain (modppl/tests/mh.rs:91), Philox step 0.
+ * constrain_is_linear: -1 = sampled from its prior, 0 / 1 = constrained to false / true.  n_data <= 16. */
+int32_t mp_mh_create(int32_t model_kind, const double* xs, const double* ys, int32_t n_data, int32_t constrain_is_linear,
+                     uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out);
+/* n_iters x `mh(model, trace, proposal, proposal_args)` per chain (mh.rs:9-51).  `accepted` (nullable)
+ * receives the total number of accepted moves over all chains and iterations of this call. */
+int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, int32_t n_iters,
+                   uint64_t* accepted);
+/* n_iters x `regen_mh(model, trace, mask)` per chain (mh.rs:54-75; DynGenFn::regenerate dyngenfn.rs:563-583).
+ * mask_sites: subset of {MP_SITE_A, MP_SITE_B, MP_SITE_C} ("coeffs/a" ...).  cycle = 0: every iteration
+ * masks all listed sites at once; cycle = 1: iteration k masks only mask_sites[k % n_mask].
+ * Masking is_linear or passing an empty mask is MP_ERR_UNSUPPORTED: the reference either panics on the
+ * quadratic->linear structure change (dyngenfn.rs:425,526-529) or re-simulates the observed sites (:571). */
+int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted);
+/* Chain states -> out[n_chains][4] = {is_linear (0/1), a, b, c}  (c is NaN-free but meaningless when is_linear). */
+int32_t mp_mh_read_state(mp_mh* h, double* out);
+/* trace.logjp per chain, summed in site order (the reference's value is the trie's running weight: same to ~1e-15 rel). */
+int32_t mp_mh_read_logjp(mp_mh* h, double* out);
+/* MH iterations applied so far (the Philox step of the next iteration is this + 1). */
+int32_t mp_mh_iterations(mp_mh* h, uint64_t* out);
+int32_t mp_mh_destroy(mp_mh* h);
+
 #ifdef __cplusplus
 }
 #endif

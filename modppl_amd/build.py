@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libmodppl_hip.so")
-SOURCES = ["mp_pf.hip", "mp_probe.hip"]
+SOURCES = ["mp_pf.hip", "mp_mh.hip", "mp_probe.hip"]
 HEADERS = ["mp_math.h", "mp_philox.h", "mp_dists.h", "mp_models.h", os.path.join("..", "..", "include", "modppl_hip.h"),
            os.path.join("..", "..", "include", "modppl_hip_probe.h")]
 # -ffp-contract=off: the only fused multiply-adds are the explicit fma() calls in mp_math.h, so the

@@ -16,6 +16,9 @@ MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC = 0, 1
 MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
 MP_PF_RECORD_HISTORY = 1
 MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER = 0, 1, 2
+MP_SITE_IS_LINEAR, MP_SITE_A, MP_SITE_B, MP_SITE_C = 0, 1, 2, 3
+MP_MH_MODEL_HIERARCHICAL = 1
+MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1
 
 # every symbol include/modppl_hip.h declares (tests/test_capi_symbols.py checks the export table)
 SYMBOLS = [
@@ -23,6 +26,7 @@ SYMBOLS = [
     "mp_pf_resample", "mp_pf_log_marginal_likelihood_estimate", "mp_pf_read_state", "mp_pf_read_log_weights",
     "mp_pf_read_parents", "mp_pf_read_trajectory", "mp_pf_time", "mp_pf_run", "mp_pf_synchronize", "mp_pf_destroy",
     "mp_pf_set_timing", "mp_pf_get_timing", "mp_importance_resampling",
+    "mp_mh_create", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_iterations", "mp_mh_destroy",
     # include/modppl_hip_probe.h
     "mp_probe_math", "mp_probe_normal_sample", "mp_probe_u01",
 ]
@@ -78,6 +82,13 @@ def load():
     L.mp_pf_set_timing.argtypes = [p, i32]
     L.mp_pf_get_timing.argtypes = [p, i32, dp, C.POINTER(u64)]
     L.mp_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
+    L.mp_mh_create.argtypes = [i32, dp, dp, i32, i32, u64, u64, i32, p, C.POINTER(p)]
+    L.mp_mh_step.argtypes = [p, i32, dp, i32, i32, C.POINTER(u64)]
+    L.mp_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
+    L.mp_mh_read_state.argtypes = [p, dp]
+    L.mp_mh_read_logjp.argtypes = [p, dp]
+    L.mp_mh_iterations.argtypes = [p, C.POINTER(u64)]
+    L.mp_mh_destroy.argtypes = [p]
     L.mp_probe_math.argtypes = [i32, dp, dp, dp, i64, dp, i32]
     L.mp_probe_normal_sample.argtypes = [u64, u32, u32, u32, u32, d, d, i64, dp, i32]
     L.mp_probe_u01.argtypes = [u64, u32, u32, u32, u32, u32, i64, dp, i32]

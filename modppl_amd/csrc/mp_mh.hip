@@ -1,0 +1,334 @@
+// mp_mh.hip — batched Metropolis-Hastings / regenerative MH over independent chains (gfx950).
+//
+//   K7a k_mh_drift   metropolis_hastings (modppl/src/inference/mh.rs:9-40) with hierarchical_drift_proposal
+//   K7b k_regen_mh   regenerative_metropolis_hastings (mh.rs:54-67) -> DynGenFn::regenerate
+// One lane = one chain; the chain state (is_linear, a, b, c) and the cached per-observation
+// log-densities live in registers for all n_iters iterations of a launch, so HBM traffic is
+// 2 x 32 B per chain per launch: these kernels are fp64-VALU bound, not HBM bound.
+//
+// Weight rules restated from the handler (one model source, static dispatch):
+//   Regenerate (dyngenfn.rs:213-273, 393-446): masked site -> redraw from the prior, diff = Unknown, no weight;
+//     unmasked site visited while diff == NoChange -> early return; unmasked site visited after the flip ->
+//     weight += logp_new - logp_prev (in visiting order); the `coeffs` sub-call contributes its own weight
+//     (0.0 here: a, b, c have constant priors) and flips the outer diff, so every y_i is rescored.
+//   Update (dyngenfn.rs:143-211, 321-391) under the drift proposal: constrained site with a previous value ->
+//     weight -= prev.weight; weight += logp_new; then the y_i as above.  alpha = weight - fwd + bwd (mh.rs:34).
+// Philox: chain = slot, MH iteration (1-based) = step; model redraws DOM_MODEL, proposal draws DOM_PROPOSAL,
+// accept uniform DOM_ACCEPT site 0.
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/modppl_hip.h"
+#include "mp_dists.h"
+
+typedef unsigned long long u64;
+#define MH_MAX_DATA 16
+#define MH_THREADS 256
+
+static thread_local std::string g_mh_err;
+extern "C" const char* mp_last_error(void);
+int32_t mp_set_error(int32_t code, const std::string& msg);  // mp_pf.hip
+#define MHCK(call)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return mp_set_error(MP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct mh_data {
+    int n;
+    double xs[MH_MAX_DATA], ys[MH_MAX_DATA];
+};
+
+// mean of y_i: hierarchical.rs:38 / :43   `coeffs.0 + coeffs.1 * x` / `... + coeffs.2 * x * x`
+__device__ __forceinline__ double mh_mean(bool is_lin, double a, double b, double c, double x) {
+    return is_lin ? a + b * x : a + b * x + c * x * x;
+}
+#define MH_NOISE 0.1
+// mp_log(0.1), hoisted: computed on the host with the same mp_log and passed in
+
+__global__ __launch_bounds__(MH_THREADS) void k_mh_init(u64 n, uint32_t k0, uint32_t k1, int constrain, mh_data data, double ln_noise,
+                                                        int* __restrict__ is_lin_out, double* __restrict__ a_out, double* __restrict__ b_out,
+                                                        double* __restrict__ c_out) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    mp_stream s;
+    s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = 0;
+    bool is_lin;
+    if (constrain >= 0) {
+        is_lin = constrain != 0;  // constrained: scored, not sampled (dyngenfn.rs:122-131)
+    } else {
+        mp_site st(s, MP_DOM_MODEL, MP_SITE_IS_LINEAR);
+        is_lin = mp_bernoulli_sample(st, 0.7);
+    }
+    mp_site sa(s, MP_DOM_MODEL, MP_SITE_A), sb(s, MP_DOM_MODEL, MP_SITE_B), sc(s, MP_DOM_MODEL, MP_SITE_C);
+    const double a = mp_normal_sample(sa, 0., 1.);
+    const double b = mp_normal_sample(sb, 0., 1.);
+    const double c = is_lin ? 0. : mp_normal_sample(sc, 0., 1.);
+    is_lin_out[i] = is_lin ? 1 : 0;
+    a_out[i] = a; b_out[i] = b; c_out[i] = c;
+}
+
+// trace.logjp: sum of all choice log-densities in site order
+__global__ __launch_bounds__(MH_THREADS) void k_mh_logjp(u64 n, mh_data data, double ln_noise, const int* __restrict__ is_lin_in,
+                                                         const double* __restrict__ a_in, const double* __restrict__ b_in,
+                                                         const double* __restrict__ c_in, double* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const bool is_lin = is_lin_in[i] != 0;
+    const double a = a_in[i], b = b_in[i], c = c_in[i];
+    double lj = mp_bernoulli_logpdf(is_lin, 0.7);
+    lj += mp_normal_logpdf_ln(a, 0., 1., 0.);
+    lj += mp_normal_logpdf_ln(b, 0., 1., 0.);
+    if (!is_lin) lj += mp_normal_logpdf_ln(c, 0., 1., 0.);
+    for (int k = 0; k < data.n; ++k) lj += mp_normal_logpdf_ln(data.ys[k], mh_mean(is_lin, a, b, c, data.xs[k]), MH_NOISE, ln_noise);
+    out[i] = lj;
+}
+
+struct mh_mask {
+    int n;
+    int cycle;
+    int sites[4];
+};
+
+template <bool DRIFT>
+__global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, uint32_t k1, uint32_t iter0, int n_iters, mh_data data,
+                                                           double ln_noise, mh_mask mask, double drift_std, double ln_drift_std,
+                                                           int* __restrict__ is_lin_io, double* __restrict__ a_io, double* __restrict__ b_io,
+                                                           double* __restrict__ c_io, u64* __restrict__ accepted_total) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    u64 acc = 0;
+    if (i < n) {
+        const bool is_lin = is_lin_io[i] != 0;
+        double a = a_io[i], b = b_io[i], c = c_io[i];
+        double ly[MH_MAX_DATA];
+#pragma unroll
+        for (int k = 0; k < MH_MAX_DATA; ++k)
+            ly[k] = (k < data.n) ? mp_normal_logpdf_ln(data.ys[k], mh_mean(is_lin, a, b, c, data.xs[k]), MH_NOISE, ln_noise) : 0.;
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i;
+        for (int it = 0; it < n_iters; ++it) {
+            s.step = iter0 + (uint32_t)it;
+            double na = a, nb = b, nc = c;
+            double w = 0.;
+            double fwd = 0., bwd = 0.;
+            if (DRIFT) {
+                // ---- proposal.propose: simulate hierarchical_drift_proposal (hierarchical.rs:62-70) ----
+                mp_site pa(s, MP_DOM_PROPOSAL, MP_SITE_A), pb(s, MP_DOM_PROPOSAL, MP_SITE_B), pc(s, MP_DOM_PROPOSAL, MP_SITE_C);
+                na = mp_normal_sample(pa, a, drift_std);
+                fwd += mp_normal_logpdf_ln(na, a, drift_std, ln_drift_std);
+                nb = mp_normal_sample(pb, b, drift_std);
+                fwd += mp_normal_logpdf_ln(nb, b, drift_std, ln_drift_std);
+                if (!is_lin) {
+                    nc = mp_normal_sample(pc, c, drift_std);
+                    fwd += mp_normal_logpdf_ln(nc, c, drift_std, ln_drift_std);
+                }
+                // ---- model.update(trace, args, NoChange, fwd_choices): inner update of `coeffs` ----
+                double dw = 0.;
+                dw -= mp_normal_logpdf_ln(a, 0., 1., 0.);
+                dw += mp_normal_logpdf_ln(na, 0., 1., 0.);
+                dw -= mp_normal_logpdf_ln(b, 0., 1., 0.);
+                dw += mp_normal_logpdf_ln(nb, 0., 1., 0.);
+                if (!is_lin) {
+                    dw -= mp_normal_logpdf_ln(c, 0., 1., 0.);
+                    dw += mp_normal_logpdf_ln(nc, 0., 1., 0.);
+                }
+                dw = dw - 0.;  // gc: weight - complement_weight (nothing unvisited)
+                w += dw;
+            } else {
+                // ---- model.regenerate(trace, args, NoChange, mask): inner regenerate of `coeffs` ----
+                bool flipped = false;
+                double dw = 0.;
+                const int nm = mask.cycle ? 1 : mask.n;
+                int m0 = 0;
+                if (mask.cycle) m0 = (int)((iter0 - 1u + (uint32_t)it) % (uint32_t)mask.n);
+                bool ma = false, mb = false, mc = false;
+                for (int q = 0; q < nm; ++q) {
+                    const int site = mask.sites[mask.cycle ? m0 : q];
+                    ma |= site == MP_SITE_A; mb |= site == MP_SITE_B; mc |= site == MP_SITE_C;
+                }
+                if (ma) { mp_site st(s, MP_DOM_MODEL, MP_SITE_A); na = mp_normal_sample(st, 0., 1.); flipped = true; }
+                else if (flipped) dw += 0.;  // logp_new - logp_prev of an unchanged value under a constant prior
+                if (mb) { mp_site st(s, MP_DOM_MODEL, MP_SITE_B); nb = mp_normal_sample(st, 0., 1.); flipped = true; }
+                else if (flipped) dw += 0.;
+                if (!is_lin) {
+                    if (mc) { mp_site st(s, MP_DOM_MODEL, MP_SITE_C); nc = mp_normal_sample(st, 0., 1.); flipped = true; }
+                    else if (flipped) dw += 0.;
+                }
+                w += dw;
+            }
+            // ---- the observed sites: diff is Unknown, every y_i is rescored in visiting order ----
+            double lnew[MH_MAX_DATA];
+#pragma unroll
+            for (int k = 0; k < MH_MAX_DATA; ++k) {
+                if (k < data.n) {
+                    lnew[k] = mp_normal_logpdf_ln(data.ys[k], mh_mean(is_lin, na, nb, nc, data.xs[k]), MH_NOISE, ln_noise);
+                    w += lnew[k] - ly[k];
+                } else {
+                    lnew[k] = 0.;
+                }
+            }
+            double alpha = w;
+            if (DRIFT) {
+                w = w - 0.;  // gc of the outer update
+                // ---- proposal.assess((new trace, args), discard): generate with the old values constrained ----
+                bwd += mp_normal_logpdf_ln(a, na, drift_std, ln_drift_std);
+                bwd += mp_normal_logpdf_ln(b, nb, drift_std, ln_drift_std);
+                if (!is_lin) bwd += mp_normal_logpdf_ln(c, nc, drift_std, ln_drift_std);
+                alpha = w - fwd + bwd;  // mh.rs:34
+            }
+            const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
+            if (mp_log(mp_u01(ub.a)) < alpha) {  // mh.rs:35 / :62
+                a = na; b = nb; c = nc;
+#pragma unroll
+                for (int k = 0; k < MH_MAX_DATA; ++k) ly[k] = lnew[k];
+                ++acc;
+            }
+        }
+        a_io[i] = a; b_io[i] = b; c_io[i] = c;
+    }
+    // one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(accepted_total, acc);
+}
+
+struct mp_mh {
+    u64 n = 0, seed = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    mh_data data{};
+    double ln_noise = 0.;
+    int* is_lin = nullptr;
+    double *a = nullptr, *b = nullptr, *c = nullptr, *tmp = nullptr;
+    u64* d_acc = nullptr;
+    u64 iters = 0;
+};
+
+extern "C" {
+
+int32_t mp_mh_create(int32_t model_kind, const double* xs, const double* ys, int32_t n_data, int32_t constrain_is_linear,
+                     uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out) {
+    if (!out) return mp_set_error(MP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (model_kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_UNSUPPORTED, "only MP_MH_MODEL_HIERARCHICAL is compiled in");
+    if (!xs || !ys || n_data < 1 || n_data > MH_MAX_DATA) return mp_set_error(MP_ERR_INVALID_ARG, "1 <= n_data <= 16 and xs, ys non-null");
+    if (n_chains == 0 || n_chains > 0xFFFFFFFFull) return mp_set_error(MP_ERR_INVALID_ARG, "n_chains must be in [1, 2^32)");
+    if (constrain_is_linear < -1 || constrain_is_linear > 1) return mp_set_error(MP_ERR_INVALID_ARG, "constrain_is_linear in {-1, 0, 1}");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return mp_set_error(MP_ERR_HIP, "no HIP device visible: the gfx950 path has no CPU fallback");
+    }
+    std::unique_ptr<mp_mh> h(new mp_mh());
+    h->n = n_chains; h->seed = seed; h->device = device;
+    h->data.n = n_data;
+    for (int k = 0; k < MH_MAX_DATA; ++k) { h->data.xs[k] = k < n_data ? xs[k] : 0.; h->data.ys[k] = k < n_data ? ys[k] : 0.; }
+    h->ln_noise = mp_log(MH_NOISE);
+    MHCK(hipSetDevice(device));
+    if (stream) h->stream = (hipStream_t)stream;
+    else { MHCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    MHCK(hipMalloc(&h->is_lin, sizeof(int) * n_chains));
+    MHCK(hipMalloc(&h->a, sizeof(double) * n_chains));
+    MHCK(hipMalloc(&h->b, sizeof(double) * n_chains));
+    MHCK(hipMalloc(&h->c, sizeof(double) * n_chains));
+    MHCK(hipMalloc(&h->tmp, sizeof(double) * n_chains * 4));
+    MHCK(hipMalloc(&h->d_acc, sizeof(u64)));
+    hipLaunchKernelGGL(k_mh_init, dim3((unsigned)((n_chains + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), constrain_is_linear, h->data, h->ln_noise, h->is_lin, h->a, h->b, h->c);
+    MHCK(hipGetLastError());
+    MHCK(hipStreamSynchronize(h->stream));
+    *out = h.release();
+    return MP_OK;
+}
+
+static int32_t mh_run(mp_mh* h, bool drift, const mh_mask& mask, double drift_std, int32_t n_iters, uint64_t* accepted) {
+    if (n_iters < 0) return mp_set_error(MP_ERR_INVALID_ARG, "n_iters < 0");
+    MHCK(hipSetDevice(h->device));
+    MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64), h->stream));
+    const unsigned grid = (unsigned)((h->n + MH_THREADS - 1) / MH_THREADS);
+    const uint32_t iter0 = (uint32_t)(h->iters + 1);
+    const double ln_ds = drift ? mp_log(drift_std) : 0.;
+    if (drift)
+        hipLaunchKernelGGL(k_mh_iterate<true>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc);
+    else
+        hipLaunchKernelGGL(k_mh_iterate<false>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc);
+    MHCK(hipGetLastError());
+    h->iters += (u64)n_iters;
+    if (accepted) {
+        MHCK(hipMemcpyAsync(accepted, h->d_acc, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+        MHCK(hipStreamSynchronize(h->stream));
+    }
+    return MP_OK;
+}
+
+int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, int32_t n_iters, uint64_t* accepted) {
+    if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
+    if (proposal_kind != MP_MH_PROPOSAL_HIERARCHICAL_DRIFT) return mp_set_error(MP_ERR_UNSUPPORTED, "only MP_MH_PROPOSAL_HIERARCHICAL_DRIFT is compiled in");
+    if (!proposal_args || n_proposal_args != 1 || !(proposal_args[0] > 0.)) return mp_set_error(MP_ERR_INVALID_ARG, "drift proposal takes {drift_std > 0}");
+    mh_mask none{};
+    return mh_run(h, true, none, proposal_args[0], n_iters, accepted);
+}
+
+int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
+    if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
+    if (n_mask < 1 || !mask_sites)
+        return mp_set_error(MP_ERR_UNSUPPORTED, "empty mask: the reference regenerates every site including the observed ones (dyngenfn.rs:571)");
+    if (n_mask > 3) return mp_set_error(MP_ERR_INVALID_ARG, "at most 3 mask sites");
+    mh_mask m{};
+    m.n = n_mask; m.cycle = cycle ? 1 : 0;
+    for (int q = 0; q < n_mask; ++q) {
+        if (mask_sites[q] == MP_SITE_IS_LINEAR)
+            return mp_set_error(MP_ERR_UNSUPPORTED, "masking is_linear: quadratic->linear leaves residual constraints and panics in the reference (dyngenfn.rs:425,526-529)");
+        if (mask_sites[q] < MP_SITE_A || mask_sites[q] > MP_SITE_C) return mp_set_error(MP_ERR_INVALID_ARG, "unknown mask site");
+        m.sites[q] = mask_sites[q];
+    }
+    return mh_run(h, false, m, 1., n_iters, accepted);
+}
+
+int32_t mp_mh_read_state(mp_mh* h, double* out) {
+    if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
+    MHCK(hipSetDevice(h->device));
+    std::vector<int> il(h->n);
+    std::vector<double> a(h->n), b(h->n), c(h->n);
+    MHCK(hipMemcpyAsync(il.data(), h->is_lin, sizeof(int) * h->n, hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipMemcpyAsync(a.data(), h->a, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipMemcpyAsync(b.data(), h->b, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipMemcpyAsync(c.data(), h->c, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipStreamSynchronize(h->stream));
+    for (u64 i = 0; i < h->n; ++i) { out[4 * i] = il[i]; out[4 * i + 1] = a[i]; out[4 * i + 2] = b[i]; out[4 * i + 3] = c[i]; }
+    return MP_OK;
+}
+
+int32_t mp_mh_read_logjp(mp_mh* h, double* out) {
+    if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
+    MHCK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_mh_logjp, dim3((unsigned)((h->n + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n, h->data, h->ln_noise,
+                       h->is_lin, h->a, h->b, h->c, h->tmp);
+    MHCK(hipGetLastError());
+    MHCK(hipMemcpyAsync(out, h->tmp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipStreamSynchronize(h->stream));
+    return MP_OK;
+}
+
+int32_t mp_mh_iterations(mp_mh* h, uint64_t* out) {
+    if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
+    *out = h->iters;
+    return MP_OK;
+}
+
+int32_t mp_mh_destroy(mp_mh* h) {
+    if (!h) return MP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->is_lin); (void)hipFree(h->a); (void)hipFree(h->b); (void)hipFree(h->c); (void)hipFree(h->tmp); (void)hipFree(h->d_acc);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MP_OK;
+}
+
+}  // extern "C"

@@ -45,6 +45,7 @@ static int32_t mp_fail(int32_t code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+int32_t mp_set_error(int32_t code, const std::string& msg) { return mp_fail(code, msg); }  // shared with mp_mh.hip
 #define HIPCK(call)                                                                                  \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \

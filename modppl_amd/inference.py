@@ -171,3 +171,73 @@ def _importance(model, model_args, constraints, num_samples, num_ret, seed, devi
                                           int(num_ret), int(seed), int(device), C.byref(lml), _dptr(lnw),
                                           idx.ctypes.data_as(C.POINTER(C.c_uint64)) if num_ret else None, _dptr(states)))
     return states, lnw, lml.value, idx
+
+
+class HierarchicalChains:
+    """N independent MH chains over the reference's `hierarchical_model`
+    (modppl/tests/dyngenfns/hierarchical.rs:33-47), advanced by the reference's MH entry points:
+
+        mh(model, trace, proposal, proposal_args)      modppl/src/inference/mh.rs:9-51
+        regen_mh(model, trace, mask)                   modppl/src/inference/mh.rs:54-75
+
+    Creation runs `hierarchical_model.generate(xs, observations)` per chain (modppl/tests/mh.rs:91)."""
+
+    A, B, C_ = capi.MP_SITE_A, capi.MP_SITE_B, capi.MP_SITE_C
+    _ADDR = {"coeffs/a": capi.MP_SITE_A, "coeffs / a": capi.MP_SITE_A, "coeffs/b": capi.MP_SITE_B, "coeffs / b": capi.MP_SITE_B,
+             "coeffs/c": capi.MP_SITE_C, "coeffs / c": capi.MP_SITE_C, "is_linear": capi.MP_SITE_IS_LINEAR}
+
+    def __init__(self, xs, ys, num_chains, seed, *, constrain_is_linear=None, device=0, stream=None):
+        self._L = capi.load()
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        if xs.shape != ys.shape or xs.ndim != 1:
+            raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "xs and ys must be 1-D arrays of equal length")
+        self.num_chains = int(num_chains)
+        c = -1 if constrain_is_linear is None else int(bool(constrain_is_linear))
+        h = C.c_void_p()
+        capi.check(self._L.mp_mh_create(capi.MP_MH_MODEL_HIERARCHICAL, _dptr(xs), _dptr(ys), len(xs), c, self.num_chains, int(seed), int(device),
+                                        C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+
+    def mh(self, drift_std, n_iters=1):
+        """n_iters x mh(&hierarchical_model, trace, &hierarchical_drift_proposal, drift_std); returns accepted moves."""
+        a = np.array([drift_std], dtype=np.float64)
+        acc = C.c_uint64()
+        capi.check(self._L.mp_mh_step(self._h, capi.MP_MH_PROPOSAL_HIERARCHICAL_DRIFT, _dptr(a), 1, int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def regen_mh(self, mask, n_iters=1, cycle=False):
+        """n_iters x regen_mh(&hierarchical_model, trace, &mask); mask = addresses ("coeffs/a", ...) or site ids."""
+        sites = [self._ADDR[m] if isinstance(m, str) else int(m) for m in mask]
+        m = (C.c_int32 * max(len(sites), 1))(*sites)
+        acc = C.c_uint64()
+        capi.check(self._L.mp_regen_mh_step(self._h, m if sites else None, len(sites), int(cycle), int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def states(self):
+        """[num_chains, 4] = is_linear, a, b, c  (read_coeffs of hierarchical.rs:5-16)."""
+        out = np.empty((self.num_chains, 4))
+        capi.check(self._L.mp_mh_read_state(self._h, _dptr(out)))
+        return out
+
+    def logjp(self):
+        out = np.empty(self.num_chains)
+        capi.check(self._L.mp_mh_read_logjp(self._h, _dptr(out)))
+        return out
+
+    @property
+    def iterations(self):
+        it = C.c_uint64()
+        capi.check(self._L.mp_mh_iterations(self._h, C.byref(it)))
+        return it.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mp_mh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

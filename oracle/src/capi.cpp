@@ -346,6 +346,83 @@ int32_t oracle_importance_resampling(const mp_model_desc* m, const double* args0
     })
 }
 
+// ---- mh.rs over N independent chains of hierarchical_model ------------------------------------
+struct oracle_mh {
+    Hierarchical hm;
+    std::vector<Hierarchical::TraceT> traces;
+    Vec xs;
+    uint64_t seed = 0, iters = 0;
+    bool canonical = false;
+};
+int32_t oracle_mh_create(const double* xs, const double* ys, int32_t n_data, int32_t constrain_is_linear, uint64_t n_chains, uint64_t seed,
+                         int32_t canon, oracle_mh** out) {
+    GUARD({
+        auto h = std::make_unique<oracle_mh>();
+        h->seed = seed; h->canonical = canon != 0;
+        h->xs.assign(xs, xs + n_data);
+        oracle_pf::Scope scope(h->canonical);
+        for (uint64_t i = 0; i < n_chains; ++i) {
+            DynTrie observations;  // tests/mh.rs:89
+            for (int k = 0; k < n_data; ++k) observations.observe("(y, " + std::to_string(k) + ")", arc(ys[k]));
+            if (constrain_is_linear >= 0) observations.observe("is_linear", arc(constrain_is_linear != 0));
+            Rng r; r.seed = seed; r.slot = (uint32_t)i; r.step = 0;
+            h->traces.push_back(h->hm.model.generate(r, h->xs, observations).first);  // tests/mh.rs:91
+        }
+        *out = h.release();
+    })
+}
+int32_t oracle_mh_step(oracle_mh* h, double drift_std, int32_t n_iters, uint64_t* accepted) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        auto proposal = h->hm.drift_proposal();
+        uint64_t acc = 0;
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            for (int k = 0; k < n_iters; ++k) {
+                Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = (uint32_t)(h->iters + 1 + (uint64_t)k);
+                auto [tr, ok] = metropolis_hastings<Vec, Vec, double>(r, h->hm.model, std::move(h->traces[i]), proposal, drift_std);
+                h->traces[i] = std::move(tr);
+                acc += ok;
+            }
+        }
+        h->iters += (uint64_t)n_iters;
+        if (accepted) *accepted = acc;
+    })
+}
+int32_t oracle_regen_mh_step(oracle_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        static const char* names[4] = {"is_linear", "coeffs/a", "coeffs/b", "coeffs/c"};
+        uint64_t acc = 0;
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            for (int k = 0; k < n_iters; ++k) {
+                AddrMap mask;
+                if (cycle) mask.visit(names[mask_sites[(h->iters + (uint64_t)k) % (uint64_t)n_mask]]);
+                else for (int q = 0; q < n_mask; ++q) mask.visit(names[mask_sites[q]]);
+                Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = (uint32_t)(h->iters + 1 + (uint64_t)k);
+                auto [tr, ok] = regenerative_metropolis_hastings<Vec, Vec>(r, h->hm.model, std::move(h->traces[i]), mask);
+                h->traces[i] = std::move(tr);
+                acc += ok;
+            }
+        }
+        h->iters += (uint64_t)n_iters;
+        if (accepted) *accepted = acc;
+    })
+}
+int32_t oracle_mh_read_state(oracle_mh* h, double* out) {
+    GUARD({
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            const auto& d = h->traces[i].data;
+            const bool il = d.read<bool>("is_linear");
+            out[4 * i] = il ? 1. : 0.;
+            out[4 * i + 1] = d.read<double>("coeffs/a");
+            out[4 * i + 2] = d.read<double>("coeffs/b");
+            out[4 * i + 3] = il ? 0. : d.read<double>("coeffs/c");
+        }
+    })
+}
+int32_t oracle_mh_read_logjp(oracle_mh* h, double* out) { GUARD({ for (size_t i = 0; i < h->traces.size(); ++i) out[i] = h->traces[i].logjp; }) }
+int32_t oracle_mh_destroy(oracle_mh* h) { delete h; return MP_OK; }
+
 // ---- math / rng / distribution probes ---------------------------------------------------------
 void oracle_mp_exp(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_exp(x[i]); }
 void oracle_mp_log(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_log(x[i]); }

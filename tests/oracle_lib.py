@@ -66,6 +66,12 @@ def load():
     L.oracle_pf_time.argtypes = [p, C.POINTER(i64)]
     L.oracle_pf_destroy.argtypes = [p]
     L.oracle_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
+    L.oracle_mh_create.argtypes = [dp, dp, i32, i32, u64, u64, i32, C.POINTER(p)]
+    L.oracle_mh_step.argtypes = [p, d, i32, C.POINTER(u64)]
+    L.oracle_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
+    L.oracle_mh_read_state.argtypes = [p, dp]
+    L.oracle_mh_read_logjp.argtypes = [p, dp]
+    L.oracle_mh_destroy.argtypes = [p]
     L.oracle_mp_exp.argtypes = [dp, i64, dp]
     L.oracle_mp_log.argtypes = [dp, i64, dp]
     L.oracle_mp_exp.restype = None
@@ -231,3 +237,47 @@ def importance_resampling(kind, dim_state, dim_obs, params, obs, num_samples, nu
     if rc != 0:
         raise OracleError(rc, L.oracle_last_error().decode())
     return lml.value, lnw, idx, xs
+
+
+class OracleMH:
+    """N independent chains of the restated hierarchical_model driven by the restated mh / regen_mh."""
+
+    def __init__(self, xs, ys, n_chains, seed, constrain_is_linear=-1, canonical=True):
+        self.L = load()
+        self.n = n_chains
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        h = C.c_void_p()
+        self._ck(self.L.oracle_mh_create(dptr(xs), dptr(ys), len(xs), constrain_is_linear, n_chains, seed, int(canonical), C.byref(h)))
+        self.h = h
+
+    def _ck(self, code):
+        if code != 0:
+            raise OracleError(code, self.L.oracle_last_error().decode())
+
+    def mh(self, drift_std, n_iters=1):
+        acc = C.c_uint64()
+        self._ck(self.L.oracle_mh_step(self.h, drift_std, n_iters, C.byref(acc)))
+        return acc.value
+
+    def regen_mh(self, mask_sites, n_iters=1, cycle=False):
+        m = (C.c_int32 * len(mask_sites))(*mask_sites)
+        acc = C.c_uint64()
+        self._ck(self.L.oracle_regen_mh_step(self.h, m, len(mask_sites), int(cycle), n_iters, C.byref(acc)))
+        return acc.value
+
+    def state(self):
+        out = np.empty((self.n, 4))
+        self._ck(self.L.oracle_mh_read_state(self.h, dptr(out)))
+        return out
+
+    def logjp(self):
+        out = np.empty(self.n)
+        self._ck(self.L.oracle_mh_read_logjp(self.h, dptr(out)))
+        return out
+
+    def __del__(self):
+        try:
+            self.L.oracle_mh_destroy(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,108 @@
+"""GPU parity of mh / regen_mh (modppl/src/inference/mh.rs) over the reference's hierarchical model:
+chain states bit-exact against the structure-faithful oracle (dynamic tries, restated Update /
+Regenerate handlers) in canonical arithmetic, accept counts equal, logjp to 1e-12."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+XS = np.arange(-5.0, 6.0)  # tests/mh.rs:81
+
+
+def make_ys(seed=0):
+    rng = np.random.default_rng(seed)
+    return 0.3 + 0.4 * XS + 0.5 * XS * XS + 0.1 * rng.normal(size=XS.size)  # tests/mh.rs:84-87
+
+
+def pair(n, seed, constrain):
+    import modppl_amd
+
+    ys = make_ys()
+    g = modppl_amd.HierarchicalChains(XS, ys, n, seed, constrain_is_linear=constrain)
+    o = O.OracleMH(XS, ys, n, seed, -1 if constrain is None else int(constrain), canonical=True)
+    assert np.array_equal(g.states(), o.state())
+    return g, o
+
+
+def check(g, o):
+    assert np.array_equal(g.states(), o.state())
+    assert np.allclose(g.logjp(), o.logjp(), rtol=1e-12, atol=1e-9)
+
+
+def test_initial_generate_free_branch():
+    g, o = pair(3000, 5, None)
+    st = g.states()
+    assert 0.6 < st[:, 0].mean() < 0.8  # is_linear ~ bernoulli(0.7)
+    check(g, o)
+
+
+def test_regen_mh_cycle_quadratic_branch():
+    """C4 of BASELINE.json: masks cycle {coeffs/a},{coeffs/b},{coeffs/c} with the chain held in the quadratic branch."""
+    g, o = pair(2000, 11, False)
+    for _ in range(3):
+        assert g.regen_mh(["coeffs/a", "coeffs/b", "coeffs/c"], n_iters=7, cycle=True) == o.regen_mh([1, 2, 3], n_iters=7, cycle=True)
+        check(g, o)
+    assert g.iterations == 21
+
+
+def test_regen_mh_joint_masks_and_mixed_branches():
+    g, o = pair(2000, 12, None)
+    assert g.regen_mh(["coeffs/a"], 3) == o.regen_mh([1], 3)
+    check(g, o)
+    assert g.regen_mh(["coeffs/b", "coeffs/c"], 4) == o.regen_mh([2, 3], 4)
+    check(g, o)
+    assert g.regen_mh(["coeffs/c"], 2) == o.regen_mh([3], 2)   # on linear chains: nothing changes, always accepted
+    check(g, o)
+
+
+def test_mh_drift_proposal():
+    """tests/mh.rs:96-106: hierarchical_drift_proposal with std 0.1 then 0.01."""
+    g, o = pair(2000, 13, None)
+    for std, k in ((0.1, 3), (0.01, 10), (0.1, 3)):
+        assert g.mh(std, k) == o.mh(std, k)
+        check(g, o)
+
+
+def test_interleaved_kernels():
+    g, o = pair(500, 14, False)
+    for r in range(4):
+        assert g.mh(0.1, 2) == o.mh(0.1, 2)
+        assert g.regen_mh(["coeffs/a", "coeffs/b", "coeffs/c"], 3, cycle=True) == o.regen_mh([1, 2, 3], 3, cycle=True)
+    check(g, o)
+
+
+def test_unsupported_masks():
+    import modppl_amd
+    from modppl_amd import capi
+
+    g = modppl_amd.HierarchicalChains(XS, make_ys(), 16, 1)
+    with pytest.raises(modppl_amd.ModpplError) as e:
+        g.regen_mh(["is_linear"])
+    assert e.value.code == capi.MP_ERR_UNSUPPORTED
+    with pytest.raises(modppl_amd.ModpplError) as e:
+        g.regen_mh([])
+    assert e.value.code == capi.MP_ERR_UNSUPPORTED
+
+
+def test_c4_full_size_posterior():
+    """BASELINE config 4 size: 2^20 chains x 100 drift sweeps + regen cycles; the chains concentrate on the
+    least-squares coefficients (data noise 0.1, 11 points)."""
+    import modppl_amd
+
+    ys = make_ys()
+    n = 1 << 20
+    g = modppl_amd.HierarchicalChains(XS, ys, n, 3, constrain_is_linear=False)
+    g.regen_mh(["coeffs/a", "coeffs/b", "coeffs/c"], 30, cycle=True)
+    acc = 0
+    for std in (0.5, 0.1, 0.02):
+        acc += g.mh(std, 100)
+    acc += g.mh(0.02, 200)
+    st = g.states()
+    A = np.stack([np.ones_like(XS), XS, XS * XS], axis=1)
+    ols = np.linalg.lstsq(A, ys, rcond=None)[0]
+    med = np.median(st[:, 1:], axis=0)
+    assert np.all(np.abs(med - ols) < 0.05), (med, ols)
+    assert 0 < acc < n * 500
+    assert g.iterations == 530
