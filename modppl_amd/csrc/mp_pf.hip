@@ -537,6 +537,179 @@ __global__ __launch_bounds__(K3_THREADS) void k_lse_finalize(const u64* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// sharded filter phases (include/modppl_hip.h "sharded filter")
+// ---------------------------------------------------------------------------------------------
+constexpr int SH_THREADS = 256;
+constexpr int SH_MAX_WORLD = 64;
+
+__global__ __launch_bounds__(SH_THREADS) void k_reduce_max(const double* __restrict__ v, int nv, double* __restrict__ out) {
+    __shared__ double s_m[SH_THREADS / 64];
+    double m = MP_NEG_INF;
+    for (int j = threadIdx.x; j < nv; j += SH_THREADS) m = fmax(m, v[j]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < SH_THREADS / 64; ++k) m = fmax(m, s_m[k]);
+        out[0] = fmax(m, s_m[0]);
+    }
+}
+__global__ __launch_bounds__(SH_THREADS) void k_sum_tiles(const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2, int nt,
+                                                          u64* __restrict__ out) {
+    __shared__ u64 s_a[SH_THREADS / 64], s_b[SH_THREADS / 64];
+    u64 q = 0, q2 = 0;
+    for (int j = threadIdx.x; j < nt; j += SH_THREADS) { q += tilesum[j]; q2 += tilesum2[j]; }
+    q = wave_sum_u64(q); q2 = wave_sum_u64(q2);
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = q; s_b[threadIdx.x >> 6] = q2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 Q = 0, Q2 = 0;
+        for (int k = 0; k < SH_THREADS / 64; ++k) { Q += s_a[k]; Q2 += s_b[k]; }
+        out[0] = Q; out[1] = Q2;
+    }
+}
+
+// pass 1: target of every local slot -> owner rank + shard-local target; per-workgroup owner histogram
+__global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
+                                                              const u64* __restrict__ totals_all, int world,
+                                                              unsigned char* __restrict__ dest, u64* __restrict__ lt_out,
+                                                              uint32_t* __restrict__ blockcount) {
+    __shared__ u64 s_incl[SH_MAX_WORLD];
+    __shared__ uint32_t s_cnt[SH_MAX_WORLD];
+    if (threadIdx.x < SH_MAX_WORLD) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (int r = 0; r < world; ++r) { run += totals_all[2 * r]; s_incl[r] = run; }
+    }
+    __syncthreads();
+    const u64 Q = s_incl[world - 1];
+    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    if (i < n) {
+        const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+        const u64 target = mp_target(mp_u52(r.a), Q);
+        int s = 0;
+        while (s < world - 1 && s_incl[s] < target) ++s;  // first rank whose inclusive total reaches the target
+        const u64 excl = s ? s_incl[s - 1] : 0ull;
+        dest[i] = (unsigned char)s;
+        lt_out[i] = target - excl;
+        atomicAdd(&s_cnt[s], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < world) blockcount[(u64)blockIdx.x * world + threadIdx.x] = s_cnt[threadIdx.x];
+}
+// pass 2 (one workgroup): per-owner totals and exclusive per-workgroup offsets
+__global__ __launch_bounds__(SH_THREADS) void k_shard_offsets(const uint32_t* __restrict__ blockcount, int nblk, int world,
+                                                              uint32_t* __restrict__ blockoff, long long* __restrict__ counts) {
+    // thread r < world walks the workgroups sequentially (nblk <= 65536, world <= 64: a few tens of microseconds at worst)
+    const int r = threadIdx.x;
+    if (r < world) {
+        uint32_t run = 0;
+        for (int b = 0; b < nblk; ++b) {
+            blockoff[(u64)b * world + r] = run;
+            run += blockcount[(u64)b * world + r];
+        }
+        counts[r] = (long long)run;
+    }
+}
+// pass 3: stable pack of the requests grouped by owner
+__global__ __launch_bounds__(SH_THREADS) void k_shard_pack(u64 n, const unsigned char* __restrict__ dest, const u64* __restrict__ lt_in,
+                                                           const uint32_t* __restrict__ blockoff, const long long* __restrict__ counts, int world,
+                                                           u64* __restrict__ req_out, uint32_t* __restrict__ req_slot) {
+    __shared__ uint32_t s_wcnt[SH_THREADS / 64][SH_MAX_WORLD];
+    __shared__ u64 s_gstart[SH_MAX_WORLD];
+    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = (i < n) ? (int)dest[i] : -1;
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (int r = 0; r < world; ++r) { s_gstart[r] = run; run += (u64)counts[r]; }
+    }
+    uint32_t my_rank_in_wave = 0;
+    for (int r = 0; r < world; ++r) {
+        const u64 bal = __ballot(s == r);
+        if (s == r) my_rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wcnt[wave][r] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (s >= 0) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wcnt[w][s];
+        const u64 pos = s_gstart[s] + blockoff[(u64)blockIdx.x * world + s] + before + my_rank_in_wave;
+        req_out[pos] = lt_in[i];
+        req_slot[pos] = (uint32_t)i;
+    }
+}
+// owner side: shard-local targets -> parent rows
+__global__ __launch_bounds__(K3_THREADS) void k_shard_resolve(u64 n, u64 n_req, u64 slot_offset, int D, const u64* __restrict__ req,
+                                                              const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                              const u64* __restrict__ tilesum, int nt, const double* __restrict__ x,
+                                                              double* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_wtot = s_incl + nt;
+    block_scan_tiles<K3_THREADS>(tilesum, nt, s_incl, s_wtot);
+    for (u64 q = (u64)blockIdx.x * K3_THREADS + threadIdx.x; q < n_req; q += (u64)gridDim.x * K3_THREADS) {
+        const u64 target = req[q];
+        uint32_t b = lower_bound_u64(s_incl, (uint32_t)nt, target);
+        if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
+        const u64 incl_b = s_incl[b];
+        const u64 excl = b ? s_incl[b - 1] : 0ull;
+        const u64 lt = target - excl;
+        const int shift = mp_guide_shift(incl_b - excl);
+        const u64 tbase = (u64)b * TILE;
+        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+        uint32_t g = (uint32_t)(lt >> shift);
+        if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+        uint32_t j = guide[(u64)b * GUIDE_N + g];
+        if (j > tlen - 1) j = tlen - 1;
+        mp_cx row = load_row_nt(cx + tbase + j);
+        while (row.cum < lt && j + 1 < tlen) {
+            ++j;
+            row = load_row_nt(cx + tbase + j);
+        }
+        const u64 p = tbase + j;
+        double* out = rows + q * (u64)(D + 1);
+        out[0] = row.x0;
+        for (int d = 1; d < D; ++d) out[d] = x[(u64)d * n + p];
+        out[D] = (double)(slot_offset + p);
+    }
+}
+// requester side
+__global__ __launch_bounds__(SH_THREADS) void k_shard_scatter(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ req_slot,
+                                                              double* __restrict__ x_new, uint32_t* __restrict__ parent, double* __restrict__ logw,
+                                                              double* __restrict__ blockmax, int nb) {
+    const u64 pos = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    if (pos < n) {
+        const uint32_t i = req_slot[pos];
+        const double* in = rows + pos * (u64)(D + 1);
+        for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = in[d];
+        parent[i] = (uint32_t)in[D];
+        logw[i] = 0.;
+    }
+    if (blockIdx.x == 0)
+        for (int j = threadIdx.x; j < nb; j += SH_THREADS) blockmax[j] = 0.;
+}
+// scalars of a sharded normalisation from the gathered totals; mode 0 = resample (fold into log_ml), 1 = query
+__global__ void k_shard_finalize(const u64* __restrict__ totals_all, int world, int S, u64 n_global, int mode, mp_dev_scalars* scal) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        u64 Q = 0, Q2 = 0;
+        for (int r = 0; r < world; ++r) { Q += totals_all[2 * r]; Q2 += totals_all[2 * r + 1]; }
+        double L, ess;
+        finalize_scalars(Q, Q2, S, &L, &ess, scal->m);
+        if (mode == 0) {
+            scal->L = L;
+            scal->ess_stale = ess;
+            scal->Q = Q; scal->Q2 = Q2;
+            scal->log_ml += L - mp_log((double)n_global);
+        } else {
+            scal->ess_fresh = ess;
+            scal->lml_fresh = scal->log_ml + L - mp_log((double)n_global);
+        }
+    }
+}
+
 // transpose SoA [d][n] -> host-facing AoS [n][d]
 __global__ void k_soa_to_aos(const double* __restrict__ x, u64 n, int D, double* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,6 +867,16 @@ struct mp_pf {
     mp_dev_scalars* scal = nullptr;
     double* aos = nullptr;  // staging for read_state
     mp_dev_scalars* h_scal = nullptr;  // pinned
+    // sharded-resample scratch (allocated on first use)
+    unsigned char* sh_dest = nullptr;
+    u64* sh_lt = nullptr;
+    uint32_t* sh_req_slot = nullptr;
+    uint32_t* sh_blockcount = nullptr;
+    uint32_t* sh_blockoff = nullptr;
+    long long* sh_counts = nullptr;
+    long long* h_counts = nullptr;  // pinned
+    int sh_world = 0;
+    bool sharded = false;
     // host-side filter state
     long long t = 0;  // Unfold steps taken (trace.args.0)
     uint32_t resample_count = 0;
@@ -819,7 +1002,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     h->n_global = shard ? shard->n_global : n_particles;
     h->slot_offset = shard ? shard->slot_offset : 0;
     if (h->n_global < h->n + h->slot_offset || h->n_global > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "shard does not fit n_global (< 2^32)");
-    if (shard && (h->n_global != h->n)) return mp_fail(MP_ERR_UNSUPPORTED, "sharded handles use the mp_pf_shard_* entry points (not in this build yet)");
+    h->sharded = shard && (h->n_global != h->n);
     h->seed = seed;
     h->flags = flags;
     h->device = device;
@@ -900,6 +1083,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
     if (scheme != MP_RESAMPLE_MULTINOMIAL) return mp_fail(MP_ERR_UNSUPPORTED, "only MP_RESAMPLE_MULTINOMIAL in this build");
+    if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: resample runs through the mp_pf_shard_* phases");
     HIPCK(hipSetDevice(h->device));
     int32_t rc = launch_normalize(h);
     if (rc != MP_OK) return rc;
@@ -924,6 +1108,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
 }
 
 static int32_t query(mp_pf* h) {
+    if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: use mp_pf_shard_query");
     int32_t rc = launch_normalize(h);
     if (rc != MP_OK) return rc;
     hipLaunchKernelGGL(k_lse_finalize, dim3(1), dim3(K3_THREADS), 0, h->stream, h->tilesum, h->tilesum2, h->nt, h->S, h->n_global, h->scal);
@@ -983,6 +1168,117 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
     HIPCK(hipSetDevice(h->device));
     HIPCK(hipMemcpyAsync(out, h->parent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
+    return MP_OK;
+}
+
+// ---- sharded phases ------------------------------------------------------------------------------
+int32_t mp_pf_shard_local_max(mp_pf* h, double* d_out) {
+    if (!h || !d_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
+    HIPCK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(SH_THREADS), 0, h->stream, h->blockmax, h->nb, d_out);
+    return check_launch("k_reduce_max");
+}
+
+int32_t mp_pf_shard_normalize(mp_pf* h, const double* d_global_max, uint64_t* d_totals_out) {
+    if (!h || !d_global_max || !d_totals_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
+    HIPCK(hipSetDevice(h->device));
+    {
+        LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
+        hipLaunchKernelGGL(k_normalize_scan, dim3(h->nt), dim3(SCAN_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->n, d_global_max, 1, h->S,
+                           h->cx, h->guide, h->tilesum, h->tilesum2, h->scal);
+    }
+    int32_t rc = check_launch("k_normalize_scan");
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(k_sum_tiles, dim3(1), dim3(SH_THREADS), 0, h->stream, h->tilesum, h->tilesum2, h->nt, (u64*)d_totals_out);
+    return check_launch("k_sum_tiles");
+}
+
+int32_t mp_pf_shard_route(mp_pf* h, const uint64_t* d_totals_all, int32_t world, int32_t rank, uint64_t* d_req_out, int64_t* send_counts) {
+    if (!h || !d_totals_all || !d_req_out || !send_counts) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (world < 1 || world > SH_MAX_WORLD || rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, 0 <= rank < world");
+    HIPCK(hipSetDevice(h->device));
+    const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
+    if (!h->sh_dest || h->sh_world < world) {
+        (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
+        (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts);
+        if (h->h_counts) (void)hipHostFree(h->h_counts);
+        HIPCK(hipMalloc(&h->sh_dest, h->n));
+        HIPCK(hipMalloc(&h->sh_lt, sizeof(u64) * h->n));
+        HIPCK(hipMalloc(&h->sh_req_slot, sizeof(uint32_t) * h->n));
+        HIPCK(hipMalloc(&h->sh_blockcount, sizeof(uint32_t) * (size_t)nblk * world));
+        HIPCK(hipMalloc(&h->sh_blockoff, sizeof(uint32_t) * (size_t)nblk * world));
+        HIPCK(hipMalloc(&h->sh_counts, sizeof(long long) * SH_MAX_WORLD));
+        HIPCK(hipHostMalloc(&h->h_counts, sizeof(long long) * SH_MAX_WORLD));
+        h->sh_world = world;
+    }
+    {
+        LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
+        hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->slot_offset, (uint32_t)h->seed,
+                           (uint32_t)(h->seed >> 32), h->resample_count, (const u64*)d_totals_all, world, h->sh_dest, h->sh_lt, h->sh_blockcount);
+        hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(SH_THREADS), 0, h->stream, h->sh_blockcount, nblk, world, h->sh_blockoff, h->sh_counts);
+        hipLaunchKernelGGL(k_shard_pack, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->sh_dest, h->sh_lt, h->sh_blockoff, h->sh_counts, world,
+                           (u64*)d_req_out, h->sh_req_slot);
+    }
+    int32_t rc = check_launch("k_shard_targets/offsets/pack");
+    if (rc != MP_OK) return rc;
+    // the finalisation of this normalisation (L, ESS, log-ML) only needs the gathered totals
+    hipLaunchKernelGGL(k_shard_finalize, dim3(1), dim3(64), 0, h->stream, (const u64*)d_totals_all, world, h->S, h->n_global, 0, h->scal);
+    rc = check_launch("k_shard_finalize");
+    if (rc != MP_OK) return rc;
+    HIPCK(hipMemcpyAsync(h->h_counts, h->sh_counts, sizeof(long long) * world, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    for (int r = 0; r < world; ++r) send_counts[r] = h->h_counts[r];
+    return MP_OK;
+}
+
+int32_t mp_pf_shard_resolve(mp_pf* h, const uint64_t* d_req_in, uint64_t n_req, double* d_rows_out) {
+    if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
+    if (n_req == 0) return MP_OK;
+    if (!d_req_in || !d_rows_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    int grid = (int)std::min<u64>((n_req + K3_THREADS - 1) / K3_THREADS, (u64)K3_MAX_BLOCKS);
+    const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
+    {
+        LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
+        hipLaunchKernelGGL(k_shard_resolve, dim3(grid), dim3(K3_THREADS), lds, h->stream, h->n, (u64)n_req, h->slot_offset, h->ops->dim_state,
+                           (const u64*)d_req_in, h->cx, h->guide, h->tilesum, h->nt, h->x[h->cur], d_rows_out);
+    }
+    return check_launch("k_shard_resolve");
+}
+
+int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total_weight) {
+    if (!h || !d_rows_in) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (!h->sh_req_slot) return mp_fail(MP_ERR_STATE, "shard_scatter before shard_route");
+    HIPCK(hipSetDevice(h->device));
+    {
+        LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
+        hipLaunchKernelGGL(k_shard_scatter, dim3((unsigned)((h->n + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, h->stream, h->n,
+                           h->ops->dim_state, d_rows_in, h->sh_req_slot, h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb);
+    }
+    int32_t rc = check_launch("k_shard_scatter");
+    if (rc != MP_OK) return rc;
+    h->cur ^= 1;
+    h->resample_count += 1;
+    if (log_total_weight) {
+        rc = fetch_scalars(h);
+        if (rc != MP_OK) return rc;
+        *log_total_weight = h->h_scal->L;
+    }
+    return MP_OK;
+}
+
+int32_t mp_pf_shard_query(mp_pf* h, const uint64_t* d_totals_all, int32_t world, double* log_ml, double* ess) {
+    if (!h || !d_totals_all) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_shard_finalize, dim3(1), dim3(64), 0, h->stream, (const u64*)d_totals_all, world, h->S, h->n_global, 1, h->scal);
+    int32_t rc = check_launch("k_shard_finalize");
+    if (rc != MP_OK) return rc;
+    rc = fetch_scalars(h);
+    if (rc != MP_OK) return rc;
+    if (log_ml) *log_ml = h->h_scal->lml_fresh;
+    if (ess) *ess = h->h_scal->ess_fresh;
     return MP_OK;
 }
 
@@ -1060,6 +1356,9 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->tilesum2);
     (void)hipFree(h->scal);
     (void)hipFree(h->aos);
+    (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
+    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts);
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
     (void)hipHostFree(h->h_scal);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;

@@ -1,0 +1,249 @@
+"""Sharded particle filter: one process per GPU, particles split into contiguous global-slot ranges.
+
+Collectives per resample (torch.distributed; backend "nccl" IS RCCL on ROCm, over xGMI on one node):
+
+    all_reduce(MAX)  1 f64      global max log-weight              (exact in any order)
+    all_gather       2 u64      per-shard fixed-point totals        (integer sums: exact in any order)
+    all_to_all       counts     how many draws each rank asks of each owner
+    all_to_all       u64        the draws, routed to the rank that owns their CDF range
+    all_to_all       f64 rows   the parents' states + global ids back to the asking rank (the particle exchange)
+
+Because Philox is keyed by GLOBAL slot and the fixed-point scale is global, the filter's results do not
+depend on the number of shards (tests/test_distributed_cpu.py checks this bit for bit with 2 ranks).
+"""
+import contextlib
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+class HipShardEngine:
+    """The product's local engine: the gfx950 kernels through the C ABI (device pointers)."""
+
+    def __init__(self, model, n_local, n_global, slot_offset, seed, device_index=0):
+        self._L = capi.load()
+        self.model = model
+        self.n = int(n_local)
+        self.device = torch.device("cuda", device_index)
+        self._desc = model.desc()
+        sh = capi.Shard(int(n_global), int(slot_offset))
+        h = C.c_void_p()
+        # One dedicated (non-default) stream shared by the kernels, torch's copies and the collectives: torch's
+        # default stream has handle 0, which the C ABI reads as "create your own".
+        self._stream = torch.cuda.Stream(self.device)
+        capi.check(self._L.mp_pf_create(C.byref(self._desc), self.n, int(seed), C.byref(sh), 0, device_index,
+                                        C.c_void_p(self._stream.cuda_stream), C.byref(h)))
+        self._h = h
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self._stream)
+
+    def init_step(self, args0, obs):
+        a = None if args0 is None else np.ascontiguousarray(args0, dtype=np.float64)
+        capi.check(self._L.mp_pf_init_step(self._h, a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None,
+                                           obs.ctypes.data_as(C.POINTER(C.c_double)), obs.shape[0]))
+
+    def step(self, obs):
+        capi.check(self._L.mp_pf_step(self._h, obs.ctypes.data_as(C.POINTER(C.c_double)), obs.shape[0]))
+
+    def shard_local_max(self, out_ptr):
+        capi.check(self._L.mp_pf_shard_local_max(self._h, out_ptr))
+
+    def shard_normalize(self, gmax_ptr, totals_ptr):
+        capi.check(self._L.mp_pf_shard_normalize(self._h, gmax_ptr, totals_ptr))
+
+    def shard_route(self, totals_all_ptr, world, rank, req_ptr):
+        counts = (C.c_int64 * world)()
+        capi.check(self._L.mp_pf_shard_route(self._h, totals_all_ptr, world, rank, req_ptr, counts))
+        return list(counts)
+
+    def shard_resolve(self, req_ptr, n_req, rows_ptr):
+        capi.check(self._L.mp_pf_shard_resolve(self._h, req_ptr, n_req, rows_ptr))
+
+    def shard_scatter(self, rows_ptr, want_value):
+        out = C.c_double()
+        capi.check(self._L.mp_pf_shard_scatter(self._h, rows_ptr, C.byref(out) if want_value else None))
+        return out.value if want_value else None
+
+    def shard_query(self, totals_all_ptr, world):
+        lml, ess = C.c_double(), C.c_double()
+        capi.check(self._L.mp_pf_shard_query(self._h, totals_all_ptr, world, C.byref(lml), C.byref(ess)))
+        return lml.value, ess.value
+
+    def ess_reference(self):
+        out = C.c_double()
+        capi.check(self._L.mp_pf_effective_sample_size(self._h, capi.MP_ESS_REFERENCE, C.byref(out)))
+        return out.value
+
+    def states(self):
+        x = np.empty((self.n, self.model.dim_state))
+        capi.check(self._L.mp_pf_read_state(self._h, x.ctypes.data_as(C.POINTER(C.c_double))))
+        return x
+
+    def log_weights(self):
+        w = np.empty(self.n)
+        capi.check(self._L.mp_pf_read_log_weights(self._h, w.ctypes.data_as(C.POINTER(C.c_double))))
+        return w
+
+    def parents(self):
+        p = np.empty(self.n, dtype=np.uint32)
+        capi.check(self._L.mp_pf_read_parents(self._h, p.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return p
+
+    def synchronize(self):
+        capi.check(self._L.mp_pf_synchronize(self._h))
+
+    def set_timing(self, on):
+        capi.check(self._L.mp_pf_set_timing(self._h, int(on)))
+
+    def get_timing(self, family):
+        ms, n = C.c_double(), C.c_uint64()
+        capi.check(self._L.mp_pf_get_timing(self._h, family, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mp_pf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedParticleSystem:
+    """`ParticleSystem` (modppl/src/inference/particle_filter.rs) over a process group: same methods, same results
+    as one filter with `num_particles` particles, whatever the world size.
+
+    `host_staging=True` moves the exchanged buffers through host memory (for process groups whose backend
+    cannot take device tensors, e.g. gloo with ranks sharing one GPU in tests)."""
+
+    def __init__(self, model, num_particles, seed, *, group=None, engine_cls=HipShardEngine, engine_kwargs=None, host_staging=False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if num_particles % self.world:
+            raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "num_particles must be divisible by the world size")
+        self.model = model
+        self.num_particles = int(num_particles)
+        self.n = self.num_particles // self.world
+        self.slot_offset = self.rank * self.n
+        self.engine = engine_cls(model, self.n, self.num_particles, self.slot_offset, seed, **(engine_kwargs or {}))
+        self.dev = torch.device(self.engine.device)
+        self.comm_dev = torch.device("cpu") if host_staging else self.dev
+        self._ctx = getattr(self.engine, "stream_ctx", contextlib.nullcontext)
+        d = model.dim_state
+        self._gmax = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self._totals = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self._totals_all = torch.zeros(self.world * 2, dtype=torch.int64, device=self.dev)
+        self._req = torch.zeros(self.n, dtype=torch.int64, device=self.dev)
+        self._rows = torch.zeros(self.n * (d + 1), dtype=torch.float64, device=self.dev)
+
+    # ---- collectives (identical for nccl/device tensors and gloo/CPU tensors) ----
+    def _c(self, t):
+        return t if t.device == self.comm_dev else t.to(self.comm_dev)
+
+    def _all_reduce_max(self, t):
+        if self.world > 1:
+            c = self._c(t)
+            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
+            if c is not t:
+                t.copy_(c)
+
+    def _all_gather(self, out, t):
+        if self.world == 1:
+            out.copy_(t)
+            return
+        c_in, c_out = self._c(t), self._c(out)
+        dist.all_gather_into_tensor(c_out, c_in, group=self.group) if c_out.device.type != "cpu" else \
+            dist.all_gather(list(c_out.view(self.world, -1).unbind(0)), c_in, group=self.group)
+        if c_out is not out:
+            out.copy_(c_out)
+
+    def _all_to_all(self, send, send_counts, recv_counts, width):
+        """variable all-to-all of rows of `width` elements; returns the receive buffer (on self.dev)."""
+        n_recv = int(sum(recv_counts))
+        if self.world == 1:
+            return send[: n_recv * width]
+        c_send = self._c(send[: int(sum(send_counts)) * width].contiguous())
+        c_recv = torch.empty(n_recv * width, dtype=send.dtype, device=self.comm_dev)
+        dist.all_to_all_single(c_recv, c_send, output_split_sizes=[int(c) * width for c in recv_counts],
+                               input_split_sizes=[int(c) * width for c in send_counts], group=self.group)
+        return c_recv if c_recv.device == self.dev else c_recv.to(self.dev)
+
+    # ---- ParticleSystem methods ----
+    def _obs(self, constraints):
+        obs = np.ascontiguousarray(constraints, dtype=np.float64)
+        if obs.size == 0 or obs.size % self.model.dim_obs:
+            raise capi.ModpplError(capi.MP_ERR_CONSTRAINTS, "constraints must hold dim_obs values per time step")
+        return obs.reshape(-1, self.model.dim_obs)
+
+    def init_step(self, args, constraints):
+        self.engine.init_step(args, self._obs(constraints))
+
+    def step(self, constraints):
+        self.engine.step(self._obs(constraints))
+        return self
+
+    def _normalize(self):
+        self.engine.shard_local_max(C.c_void_p(self._gmax.data_ptr()))
+        self._all_reduce_max(self._gmax)                                            # RCCL all-reduce of the log-weight max
+        self.engine.shard_normalize(C.c_void_p(self._gmax.data_ptr()), C.c_void_p(self._totals.data_ptr()))
+        self._all_gather(self._totals_all, self._totals)                            # shard totals
+
+    def resample(self, sync=True):
+        """resample() -> log total weight (particle_filter.rs:103-116), multinomial over ALL shards."""
+        with self._ctx():
+            return self._resample(sync)
+
+    def _resample(self, sync):
+        d = self.model.dim_state
+        self._normalize()
+        send_counts = self.engine.shard_route(C.c_void_p(self._totals_all.data_ptr()), self.world, self.rank, C.c_void_p(self._req.data_ptr()))
+        if self.world > 1:
+            sc = torch.tensor(send_counts, dtype=torch.int64, device=self.comm_dev)
+            rc = torch.empty(self.world, dtype=torch.int64, device=self.comm_dev)
+            dist.all_to_all_single(rc, sc, group=self.group)
+            recv_counts = rc.tolist()
+        else:
+            recv_counts = list(send_counts)
+        req_in = self._all_to_all(self._req, send_counts, recv_counts, 1)           # draws -> owners
+        n_req = int(sum(recv_counts))
+        rows_out = torch.empty(max(n_req, 1) * (d + 1), dtype=torch.float64, device=self.dev)
+        self.engine.shard_resolve(C.c_void_p(req_in.data_ptr()), n_req, C.c_void_p(rows_out.data_ptr()))
+        rows_in = self._all_to_all(rows_out, recv_counts, send_counts, d + 1)       # parents' states -> askers (particle exchange)
+        if rows_in.data_ptr() != self._rows.data_ptr():
+            self._rows[: rows_in.numel()].copy_(rows_in)
+        return self.engine.shard_scatter(C.c_void_p(self._rows.data_ptr()), sync)
+
+    def log_marginal_likelihood_estimate(self):
+        with self._ctx():
+            self._normalize()
+            return self.engine.shard_query(C.c_void_p(self._totals_all.data_ptr()), self.world)[0]
+
+    def effective_sample_size(self, fresh=False):
+        if not fresh:
+            return self.engine.ess_reference()
+        with self._ctx():
+            self._normalize()
+            return self.engine.shard_query(C.c_void_p(self._totals_all.data_ptr()), self.world)[1]
+
+    def states(self):
+        return self.engine.states()
+
+    @property
+    def log_weights(self):
+        return self.engine.log_weights()
+
+    @property
+    def parents(self):
+        return self.engine.parents()
+
+    def synchronize(self):
+        self.engine.synchronize()

@@ -277,6 +277,29 @@ int32_t oracle_pf_read_trajectory(oracle_pf* h, uint64_t i, double* out, int32_t
 int32_t oracle_pf_time(oracle_pf* h, int64_t* out) { GUARD({ *out = h->impl->time(); }) }
 int32_t oracle_pf_destroy(oracle_pf* h) { delete h; return MP_OK; }
 
+// ---- sharded phases (SoA engine, canonical) ------------------------------------------------------
+static SoaPf* soa_of(oracle_pf* h) {
+    auto* e = dynamic_cast<SoaEngine*>(h->impl.get());
+    if (!e || !h->canonical) throw Panic("shard phases: SoA engine in canonical mode only");
+    return e->pf.get();
+}
+int32_t oracle_pf_shard_local_max(oracle_pf* h, double* out) { GUARD({ *out = soa_of(h)->shard_local_max(); }) }
+int32_t oracle_pf_shard_normalize(oracle_pf* h, const double* gmax, uint64_t* totals) {
+    GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_normalize(*gmax, totals); })
+}
+int32_t oracle_pf_shard_route(oracle_pf* h, const uint64_t* totals_all, int32_t world, int32_t rank, uint64_t* req_out, int64_t* send_counts) {
+    GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_route(totals_all, world, rank, req_out, send_counts); })
+}
+int32_t oracle_pf_shard_resolve(oracle_pf* h, const uint64_t* req_in, uint64_t n_req, double* rows) {
+    GUARD({ soa_of(h)->shard_resolve(req_in, n_req, rows); })
+}
+int32_t oracle_pf_shard_scatter(oracle_pf* h, const double* rows, double* L) {
+    GUARD({ const double l = soa_of(h)->shard_scatter(rows); if (L) *L = l; })
+}
+int32_t oracle_pf_shard_query(oracle_pf* h, const uint64_t* totals_all, int32_t world, double* lml, double* ess) {
+    GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_query(totals_all, world, lml, ess); })
+}
+
 // ---- importance.rs:12-50 ------------------------------------------------------------------------
 // variant bit 1 = canonical, bit 2 = SoA engine (else the generic importance_resampling over the dynamic DynUnfold).
 int32_t oracle_importance_resampling(const mp_model_desc* m, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples,

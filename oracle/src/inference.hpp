@@ -114,10 +114,12 @@ struct CanonNorm {
     std::vector<uint64_t> cum;  // inclusive prefix sums of q
 };
 inline double ldexp_pow2(int e) { return std::ldexp(1.0, e); }
-inline CanonNorm canonical_normalize(const std::vector<double>& logw, uint64_t n_global) {
+// `forced_max`: a sharded filter normalises every shard against the GLOBAL max (nullptr = this vector's own max)
+inline CanonNorm canonical_normalize(const std::vector<double>& logw, uint64_t n_global, const double* forced_max = nullptr) {
     CanonNorm c;
     c.S = 62 - ceil_log2_u64(n_global);
-    for (double x : logw) c.m = std::fmax(c.m, x);
+    if (forced_max) c.m = *forced_max;
+    else for (double x : logw) c.m = std::fmax(c.m, x);
     c.cum.resize(logw.size());
     if (c.m == -INFINITY) return c;  // degenerate: caller raises (reference: NaN weights -> assert panic)
     const double scale = ldexp_pow2(c.S), inv = ldexp_pow2(-c.S);

@@ -224,6 +224,84 @@ struct SoaPf {
         std::fill(logw.begin(), logw.end(), 0.);
         return L;
     }
+    // ---- sharded resample, phase by phase (mirrors mp_pf_shard_* of include/modppl_hip.h) ----------
+    CanonNorm sh_c;
+    std::vector<uint32_t> sh_req_slot;
+    double sh_L = 0.;
+    double shard_local_max() const { double m = -INFINITY; for (double w : logw) m = std::fmax(m, w); return m; }
+    void shard_normalize(double gmax, uint64_t* totals) {
+        if (!initialised) throw Panic("resample before init_step");
+        sh_c = canonical_normalize(logw, n_global, &gmax);
+        totals[0] = sh_c.Q; totals[1] = sh_c.Q2;
+    }
+    static void shard_scalars(const uint64_t* totals_all, int world, int S, double m, double* L, double* ess, uint64_t* Q) {
+        uint64_t q = 0, q2 = 0;
+        for (int r = 0; r < world; ++r) { q += totals_all[2 * r]; q2 += totals_all[2 * r + 1]; }
+        const double inv = ldexp_pow2(-S);
+        const double Qs = (double)q * inv, Q2s = (double)q2 * inv;
+        *L = m + mp_log(Qs);
+        *ess = (Qs * Qs) / Q2s;
+        *Q = q;
+    }
+    void shard_route(const uint64_t* totals_all, int world, int rank, uint64_t* req_out, int64_t* send_counts) {
+        (void)rank;
+        if (sh_c.m == -INFINITY) throw Panic("all log-weights are -inf");
+        double L, ess; uint64_t Q;
+        shard_scalars(totals_all, world, sh_c.S, sh_c.m, &L, &ess, &Q);
+        std::vector<uint64_t> incl((size_t)world);
+        uint64_t run = 0;
+        for (int r = 0; r < world; ++r) { run += totals_all[2 * r]; incl[(size_t)r] = run; }
+        std::vector<int> dest(n);
+        std::vector<uint64_t> lt(n);
+        for (int r = 0; r < world; ++r) send_counts[r] = 0;
+        for (size_t i = 0; i < n; ++i) {
+            Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+            const uint64_t target = canonical_target(r.u52(), Q);
+            int s_ = 0;
+            while (s_ < world - 1 && incl[(size_t)s_] < target) ++s_;
+            dest[i] = s_;
+            lt[i] = target - (s_ ? incl[(size_t)s_ - 1] : 0);
+            send_counts[s_] += 1;
+        }
+        std::vector<uint64_t> start((size_t)world, 0);
+        for (int r = 1; r < world; ++r) start[(size_t)r] = start[(size_t)r - 1] + (uint64_t)send_counts[r - 1];
+        sh_req_slot.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) {  // stable
+            const uint64_t pos = start[(size_t)dest[i]]++;
+            req_out[pos] = lt[i];
+            sh_req_slot[pos] = (uint32_t)i;
+        }
+        sh_L = L;
+        ess_stale = ess;
+        log_ml += L - o_ln((double)n_global);
+    }
+    void shard_resolve(const uint64_t* req_in, uint64_t n_req, double* rows) const {
+        const int d = model->dim_state;
+        for (uint64_t q = 0; q < n_req; ++q) {
+            const size_t p = canonical_parent(sh_c.cum, req_in[q]);
+            for (int j = 0; j < d; ++j) rows[q * (uint64_t)(d + 1) + j] = x[p * d + j];
+            rows[q * (uint64_t)(d + 1) + d] = (double)(slot_offset + p);
+        }
+    }
+    double shard_scatter(const double* rows) {
+        const int d = model->dim_state;
+        for (size_t pos = 0; pos < n; ++pos) {
+            const size_t i = sh_req_slot[pos];
+            for (int j = 0; j < d; ++j) x_tmp[i * d + j] = rows[pos * (size_t)(d + 1) + j];
+            parents[i] = (uint32_t)rows[pos * (size_t)(d + 1) + d];
+        }
+        x.swap(x_tmp);
+        std::fill(logw.begin(), logw.end(), 0.);
+        ++resample_count;
+        return sh_L;
+    }
+    void shard_query(const uint64_t* totals_all, int world, double* lml, double* ess) const {
+        double L, e; uint64_t Q;
+        shard_scalars(totals_all, world, sh_c.S, sh_c.m, &L, &e, &Q);
+        if (lml) *lml = log_ml + L - o_ln((double)n_global);
+        if (ess) *ess = e;
+    }
+
     double log_ml_estimate() const {
         if (canonical) return log_ml + canonical_normalize(logw, n_global).L - o_ln((double)n_global);
         return log_ml + logsumexp(logw) - o_ln((double)n);

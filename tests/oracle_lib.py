@@ -66,6 +66,12 @@ def load():
     L.oracle_pf_time.argtypes = [p, C.POINTER(i64)]
     L.oracle_pf_destroy.argtypes = [p]
     L.oracle_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
+    L.oracle_pf_shard_local_max.argtypes = [p, p]
+    L.oracle_pf_shard_normalize.argtypes = [p, p, p]
+    L.oracle_pf_shard_route.argtypes = [p, p, i32, i32, p, C.POINTER(i64)]
+    L.oracle_pf_shard_resolve.argtypes = [p, p, u64, p]
+    L.oracle_pf_shard_scatter.argtypes = [p, p, dp]
+    L.oracle_pf_shard_query.argtypes = [p, p, i32, dp, dp]
     L.oracle_mh_create.argtypes = [dp, dp, i32, i32, u64, u64, i32, C.POINTER(p)]
     L.oracle_mh_step.argtypes = [p, d, i32, C.POINTER(u64)]
     L.oracle_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
@@ -281,3 +287,79 @@ class OracleMH:
             self.L.oracle_mh_destroy(self.h)
         except Exception:
             pass
+
+
+class OracleShardEngine:
+    """Local engine for modppl_amd.distributed.ShardedParticleSystem backed by the CPU checker:
+    used by the CPU (gloo) tests of the multi-rank orchestration.  Never used by the product."""
+
+    device = "cpu"
+
+    def __init__(self, model, n_local, n_global, slot_offset, seed, **_):
+        self.L = load()
+        self.model = model
+        self.n = n_local
+        self._params = np.ascontiguousarray(model.params, dtype=np.float64)
+        desc = ModelDesc(model.kind, model.dim_state, model.dim_obs, len(self._params), dptr(self._params))
+        sh = Shard(n_global, slot_offset)
+        h = C.c_void_p()
+        self._ck(self.L.oracle_pf_create(C.byref(desc), n_local, seed, C.byref(sh), 0, VARIANT_CANONICAL | VARIANT_SOA, C.byref(h)))
+        self.h = h
+
+    def _ck(self, code):
+        if code != 0:
+            raise OracleError(code, self.L.oracle_last_error().decode())
+
+    def init_step(self, args0, obs):
+        a = None if args0 is None else dptr(np.ascontiguousarray(args0, dtype=np.float64))
+        self._ck(self.L.oracle_pf_init_step(self.h, a, dptr(obs), obs.shape[0]))
+
+    def step(self, obs):
+        self._ck(self.L.oracle_pf_step(self.h, dptr(obs), obs.shape[0]))
+
+    def shard_local_max(self, out_ptr):
+        self._ck(self.L.oracle_pf_shard_local_max(self.h, out_ptr))
+
+    def shard_normalize(self, gmax_ptr, totals_ptr):
+        self._ck(self.L.oracle_pf_shard_normalize(self.h, gmax_ptr, totals_ptr))
+
+    def shard_route(self, totals_all_ptr, world, rank, req_ptr):
+        counts = (C.c_int64 * world)()
+        self._ck(self.L.oracle_pf_shard_route(self.h, totals_all_ptr, world, rank, req_ptr, counts))
+        return list(counts)
+
+    def shard_resolve(self, req_ptr, n_req, rows_ptr):
+        self._ck(self.L.oracle_pf_shard_resolve(self.h, req_ptr, n_req, rows_ptr))
+
+    def shard_scatter(self, rows_ptr, want_value):
+        out = C.c_double()
+        self._ck(self.L.oracle_pf_shard_scatter(self.h, rows_ptr, C.byref(out) if want_value else None))
+        return out.value if want_value else None
+
+    def shard_query(self, totals_all_ptr, world):
+        lml, ess = C.c_double(), C.c_double()
+        self._ck(self.L.oracle_pf_shard_query(self.h, totals_all_ptr, world, C.byref(lml), C.byref(ess)))
+        return lml.value, ess.value
+
+    def ess_reference(self):
+        out = C.c_double()
+        self._ck(self.L.oracle_pf_effective_sample_size(self.h, 0, C.byref(out)))
+        return out.value
+
+    def states(self):
+        x = np.empty((self.n, self.model.dim_state))
+        self._ck(self.L.oracle_pf_read_state(self.h, dptr(x)))
+        return x
+
+    def log_weights(self):
+        w = np.empty(self.n)
+        self._ck(self.L.oracle_pf_read_log_weights(self.h, dptr(w)))
+        return w
+
+    def parents(self):
+        p_ = np.empty(self.n, dtype=np.uint32)
+        self._ck(self.L.oracle_pf_read_parents(self.h, p_.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return p_
+
+    def synchronize(self):
+        pass
