@@ -70,7 +70,9 @@ typedef struct mp_shard {
 
 enum mp_resample_scheme {
     MP_RESAMPLE_MULTINOMIAL = 0, /* particle_filter.rs:37-41 (the only scheme the reference has) */
-    MP_RESAMPLE_SYSTEMATIC = 1,  /* extension named by the north star; no reference counterpart  */
+    MP_RESAMPLE_SYSTEMATIC = 1,  /* extension named by the north star; no reference counterpart: one uniform u0 per resample,
+                                  * u_g = (g + u0) / N; parents come out sorted, so the gather is coalesced and the multi-GPU
+                                  * exchange near-neighbour */
 };
 enum mp_ess_mode {
     MP_ESS_REFERENCE = 0, /* particle_filter.rs:98-100: from the weights normalised by the LAST resample() (1/N before any) */
@@ -139,7 +141,8 @@ int32_t mp_pf_shard_local_max(mp_pf* h, double* d_out);
 int32_t mp_pf_shard_normalize(mp_pf* h, const double* d_global_max, uint64_t* d_totals_out);
 /* Draw this shard's n targets, find their owner ranks from the gathered totals d_totals_all[world][2], and pack the
  * shard-local targets grouped by owner (stable) into d_req_out[n].  send_counts[world] (HOST, synchronises) = requests per owner. */
-int32_t mp_pf_shard_route(mp_pf* h, const uint64_t* d_totals_all, int32_t world, int32_t rank, uint64_t* d_req_out, int64_t* send_counts);
+int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const uint64_t* d_totals_all, int32_t world, int32_t rank, uint64_t* d_req_out,
+                          int64_t* send_counts);
 /* Owner side: resolve n_req shard-local targets to parents; d_rows_out[n_req][dim_state + 1] = parent state, then the
  * parent's global slot id as a double. */
 int32_t mp_pf_shard_resolve(mp_pf* h, const uint64_t* d_req_in, uint64_t n_req, double* d_rows_out);

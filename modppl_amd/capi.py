@@ -53,6 +53,24 @@ class ModpplError(RuntimeError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1
+    (same SONAMEs as /opt/rocm's); if this library pulled in /opt/rocm's copy first, a later `import torch` in the
+    same process would find "No HIP GPUs".  So when torch is installed its bundled runtime is loaded first (without
+    importing torch) and libmodppl_hip.so binds to it."""
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -61,6 +79,7 @@ def load():
     if not os.path.exists(so):
         raise ModpplError(MP_ERR_HIP, f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                       "(the gfx950 path has no CPU fallback)")
+    _preload_hip_runtime()
     L = C.CDLL(so)
     d, i32, u32, i64, u64, p = C.c_double, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_void_p
     dp = C.POINTER(C.c_double)
@@ -85,7 +104,7 @@ def load():
     L.mp_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
     L.mp_pf_shard_local_max.argtypes = [p, p]
     L.mp_pf_shard_normalize.argtypes = [p, p, p]
-    L.mp_pf_shard_route.argtypes = [p, p, i32, i32, p, C.POINTER(i64)]
+    L.mp_pf_shard_route.argtypes = [p, i32, p, i32, i32, p, C.POINTER(i64)]
     L.mp_pf_shard_resolve.argtypes = [p, p, u64, p]
     L.mp_pf_shard_scatter.argtypes = [p, p, dp]
     L.mp_pf_shard_query.argtypes = [p, p, i32, dp, dp]

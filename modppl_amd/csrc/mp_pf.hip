@@ -384,6 +384,29 @@ __device__ __forceinline__ u64 mp_target(u64 k52, u64 Q) {
     return t < 1ull ? 1ull : t;
 }
 
+// Systematic resampling (extension; the reference only has multinomial): one uniform u0 = k32 / 2^32 per resample
+// (Philox slot 0, site 1), u_g = (g + u0) / N for global output slot g; target = floor(u_g * Q) + 1, evaluated
+// exactly in integers: p = g * 2^32 + k32, A = (p * Q) >> 32, target = A / N + 1   (1 <= target <= Q).
+__device__ __forceinline__ u64 mp_target_systematic(u64 g, uint32_t k32, u64 Q, u64 n_global) {
+    const u64 p = (g << 32) | (u64)k32;
+    const u64 lo = p * Q;
+    const u64 hi = __umul64hi(p, Q);
+    const u64 a_lo = (lo >> 32) | (hi << 32);   // A = (hi:lo) >> 32, A < 2^95
+    const u64 a_hi = hi >> 32;                  // < 2^31
+    // long division of (a_hi : a_lo) by n_global < 2^32, base 2^32
+    u64 r = a_hi % n_global;                    // a_hi / n_global contributes to bits >= 64 of the quotient: zero since A / N < Q < 2^63
+    u64 cur = (r << 32) | (a_lo >> 32);
+    const u64 q1 = cur / n_global;
+    r = cur % n_global;
+    cur = (r << 32) | (a_lo & 0xFFFFFFFFull);
+    const u64 q0 = cur / n_global;
+    return ((q1 << 32) | q0) + 1ull;
+}
+__device__ __forceinline__ uint32_t mp_systematic_k32(uint32_t rc, uint32_t k0, uint32_t k1) {
+    const mp_u64x2 r = mp_philox4x32_10(0u, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | 1u, 0u, k0, k1);
+    return (uint32_t)(r.a >> 32);
+}
+
 // first index in [0, len) with a[idx] >= target (len if none)
 template <class Ptr>
 __device__ __forceinline__ uint32_t lower_bound_u64(Ptr a, uint32_t len, u64 target) {
@@ -400,7 +423,7 @@ __device__ __forceinline__ uint32_t lower_bound_u64(Ptr a, uint32_t len, u64 tar
 // K3: draw, search, gather, reset
 // ---------------------------------------------------------------------------------------------
 // ABL > 0 are timing-only ablations used by tools/k3_ablate.hip (1: no global reads, 2: guide only).
-template <int ABL>
+template <int ABL, bool SYSTEMATIC = false>
 __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out, u64 n_global, u64 slot_offset, uint32_t domain,
                                                                 uint32_t k0, uint32_t k1,
                                                                 uint32_t rc, int S, int D, const mp_cx* __restrict__ cx,
@@ -441,6 +464,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
         for (int j = threadIdx.x; j < nb; j += K3_THREADS) blockmax[j] = 0.;  // logw is 0 after a resample
     }
 
+    const uint32_t sys_k32 = SYSTEMATIC ? mp_systematic_k32(rc, k0, k1) : 0u;
     // Each thread resolves K3_ITEMS draws with independent load chains (Philox -> LDS tile search ->
     // guide entry -> two table rows), so that K3_ITEMS x 64 cache-line requests per wave are in flight
     // at every hop instead of 64: the kernel is bound by the latency of these dependent hops.
@@ -451,10 +475,15 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
 #pragma unroll
         for (int k = 0; k < K3_ITEMS; ++k) {
             const u64 i = i0 + (u64)k * K3_THREADS;
-            mp_u64x2 r;
-            if (ABL == 3) r.a = (i * 0x9E3779B97F4A7C15ull) ^ ((u64)rc << 20);  // timing-only: no Philox
-            else r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
-            const u64 target = mp_target(mp_u52(r.a), Q);
+            u64 target;
+            if (SYSTEMATIC) {
+                target = mp_target_systematic(slot_offset + (i < n_out ? i : 0), sys_k32, Q, n_global);
+            } else {
+                mp_u64x2 r;
+                if (ABL == 3) r.a = (i * 0x9E3779B97F4A7C15ull) ^ ((u64)rc << 20);  // timing-only: no Philox
+                else r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
+                target = mp_target(mp_u52(r.a), Q);
+            }
             uint32_t b = (ABL == 4) ? (uint32_t)((target >> 7) % (u64)nt)  // timing-only: no LDS search
                                     : lower_bound_u64(s_incl, (uint32_t)nt, target);
             if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
@@ -572,8 +601,8 @@ __global__ __launch_bounds__(SH_THREADS) void k_sum_tiles(const u64* __restrict_
 }
 
 // pass 1: target of every local slot -> owner rank + shard-local target; per-workgroup owner histogram
-__global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
-                                                              const u64* __restrict__ totals_all, int world,
+__global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
+                                                              int systematic, const u64* __restrict__ totals_all, int world,
                                                               unsigned char* __restrict__ dest, u64* __restrict__ lt_out,
                                                               uint32_t* __restrict__ blockcount) {
     __shared__ u64 s_incl[SH_MAX_WORLD];
@@ -587,8 +616,13 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 slot_of
     const u64 Q = s_incl[world - 1];
     const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
     if (i < n) {
-        const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
-        const u64 target = mp_target(mp_u52(r.a), Q);
+        u64 target;
+        if (systematic) {
+            target = mp_target_systematic(slot_offset + i, mp_systematic_k32(rc, k0, k1), Q, n_global);
+        } else {
+            const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+            target = mp_target(mp_u52(r.a), Q);
+        }
         int s = 0;
         while (s < world - 1 && s_incl[s] < target) ++s;  // first rank whose inclusive total reaches the target
         const u64 excl = s ? s_incl[s - 1] : 0ull;
@@ -1082,7 +1116,7 @@ int32_t mp_pf_step(mp_pf* h, const double* obs, int32_t n_steps) {
 int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
-    if (scheme != MP_RESAMPLE_MULTINOMIAL) return mp_fail(MP_ERR_UNSUPPORTED, "only MP_RESAMPLE_MULTINOMIAL in this build");
+    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC) return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: resample runs through the mp_pf_shard_* phases");
     HIPCK(hipSetDevice(h->device));
     int32_t rc = launch_normalize(h);
@@ -1091,9 +1125,14 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_resample_gather<0>, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
-                           (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide, h->tilesum, h->tilesum2,
-                           h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
+        if (scheme == MP_RESAMPLE_SYSTEMATIC)
+            hipLaunchKernelGGL((k_resample_gather<0, true>), dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
+                               (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide,
+                               h->tilesum, h->tilesum2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
+        else
+            hipLaunchKernelGGL((k_resample_gather<0, false>), dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
+                               (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide,
+                               h->tilesum, h->tilesum2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
     }
     rc = check_launch("k_resample_gather");
     if (rc != MP_OK) return rc;
@@ -1195,8 +1234,10 @@ int32_t mp_pf_shard_normalize(mp_pf* h, const double* d_global_max, uint64_t* d_
     return check_launch("k_sum_tiles");
 }
 
-int32_t mp_pf_shard_route(mp_pf* h, const uint64_t* d_totals_all, int32_t world, int32_t rank, uint64_t* d_req_out, int64_t* send_counts) {
+int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const uint64_t* d_totals_all, int32_t world, int32_t rank, uint64_t* d_req_out,
+                          int64_t* send_counts) {
     if (!h || !d_totals_all || !d_req_out || !send_counts) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC) return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (world < 1 || world > SH_MAX_WORLD || rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, 0 <= rank < world");
     HIPCK(hipSetDevice(h->device));
     const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
@@ -1215,8 +1256,9 @@ int32_t mp_pf_shard_route(mp_pf* h, const uint64_t* d_totals_all, int32_t world,
     }
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->slot_offset, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, (const u64*)d_totals_all, world, h->sh_dest, h->sh_lt, h->sh_blockcount);
+        hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
+                           (uint32_t)(h->seed >> 32), h->resample_count, scheme == MP_RESAMPLE_SYSTEMATIC ? 1 : 0, (const u64*)d_totals_all, world,
+                           h->sh_dest, h->sh_lt, h->sh_blockcount);
         hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(SH_THREADS), 0, h->stream, h->sh_blockcount, nblk, world, h->sh_blockoff, h->sh_counts);
         hipLaunchKernelGGL(k_shard_pack, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->sh_dest, h->sh_lt, h->sh_blockoff, h->sh_counts, world,
                            (u64*)d_req_out, h->sh_req_slot);
@@ -1426,7 +1468,7 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
         HIPCK(hipMalloc(&d_idx, sizeof(uint32_t) * num_ret_samples));
         const int grid = (int)std::min<u64>((num_ret_samples + K3_THREADS * K3_ITEMS - 1) / (K3_THREADS * K3_ITEMS), (u64)K3_MAX_BLOCKS);
         const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
-        hipLaunchKernelGGL(k_resample_gather<0>, dim3(grid), dim3(K3_THREADS), lds, h->stream, h->n, (u64)num_ret_samples, h->n_global, (u64)0,
+        hipLaunchKernelGGL((k_resample_gather<0, false>), dim3(grid), dim3(K3_THREADS), lds, h->stream, h->n, (u64)num_ret_samples, h->n_global, (u64)0,
                            (uint32_t)MP_DOM_IS, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), 0u, h->S, h->ops->dim_state, h->cx, h->guide,
                            h->tilesum, h->tilesum2, h->nt, (const double*)nullptr, (double*)nullptr, d_idx, (double*)nullptr,
                            (double*)nullptr, 0, (mp_dev_scalars*)nullptr);

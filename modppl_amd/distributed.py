@@ -56,9 +56,9 @@ class HipShardEngine:
     def shard_normalize(self, gmax_ptr, totals_ptr):
         capi.check(self._L.mp_pf_shard_normalize(self._h, gmax_ptr, totals_ptr))
 
-    def shard_route(self, totals_all_ptr, world, rank, req_ptr):
+    def shard_route(self, scheme, totals_all_ptr, world, rank, req_ptr):
         counts = (C.c_int64 * world)()
-        capi.check(self._L.mp_pf_shard_route(self._h, totals_all_ptr, world, rank, req_ptr, counts))
+        capi.check(self._L.mp_pf_shard_route(self._h, scheme, totals_all_ptr, world, rank, req_ptr, counts))
         return list(counts)
 
     def shard_resolve(self, req_ptr, n_req, rows_ptr):
@@ -197,15 +197,16 @@ class ShardedParticleSystem:
         self.engine.shard_normalize(C.c_void_p(self._gmax.data_ptr()), C.c_void_p(self._totals.data_ptr()))
         self._all_gather(self._totals_all, self._totals)                            # shard totals
 
-    def resample(self, sync=True):
+    def resample(self, scheme=capi.MP_RESAMPLE_MULTINOMIAL, sync=True):
         """resample() -> log total weight (particle_filter.rs:103-116), multinomial over ALL shards."""
         with self._ctx():
-            return self._resample(sync)
+            return self._resample(scheme, sync)
 
-    def _resample(self, sync):
+    def _resample(self, scheme, sync):
         d = self.model.dim_state
         self._normalize()
-        send_counts = self.engine.shard_route(C.c_void_p(self._totals_all.data_ptr()), self.world, self.rank, C.c_void_p(self._req.data_ptr()))
+        send_counts = self.engine.shard_route(scheme, C.c_void_p(self._totals_all.data_ptr()), self.world, self.rank,
+                                              C.c_void_p(self._req.data_ptr()))
         if self.world > 1:
             sc = torch.tensor(send_counts, dtype=torch.int64, device=self.comm_dev)
             rc = torch.empty(self.world, dtype=torch.int64, device=self.comm_dev)

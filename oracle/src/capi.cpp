@@ -38,6 +38,7 @@ struct IPf {
     virtual void step(const double* obs, int n_steps) = 0;
     virtual double ess(int mode) = 0;
     virtual double resample() = 0;
+    virtual void set_scheme(int s_) { if (s_ != MP_RESAMPLE_MULTINOMIAL) throw Panic("oracle: only multinomial here (the reference has no other); systematic lives in the canonical SoA engine"); }
     virtual double log_ml() = 0;
     virtual void read_state(double* out) = 0;
     virtual void read_logw(double* out) = 0;
@@ -140,6 +141,7 @@ struct SoaEngine : IPf {
     void step(const double* obs, int n) override { pf->step(obs, n); }
     double ess(int mode) override { return pf->ess(mode == MP_ESS_FRESH); }
     double resample() override { return pf->resample(); }
+    void set_scheme(int s_) override { pf->scheme = s_; }
     double log_ml() override { return pf->log_ml_estimate(); }
     void read_state(double* out) override { std::memcpy(out, pf->x.data(), pf->x.size() * sizeof(double)); }
     void read_logw(double* out) override { std::memcpy(out, pf->logw.data(), pf->n * sizeof(double)); }
@@ -262,7 +264,7 @@ int32_t oracle_pf_effective_sample_size(oracle_pf* h, int32_t mode, double* out)
     GUARD({ oracle_pf::Scope s(h->canonical); *out = h->impl->ess(mode); })
 }
 int32_t oracle_pf_resample(oracle_pf* h, int32_t scheme, double* ltw) {
-    GUARD({ if (scheme != MP_RESAMPLE_MULTINOMIAL) throw Panic("oracle: only multinomial (the reference has no other)");
+    GUARD({ h->impl->set_scheme(scheme);
             oracle_pf::Scope s(h->canonical); const double L = h->impl->resample(); if (ltw) *ltw = L; })
 }
 int32_t oracle_pf_log_marginal_likelihood_estimate(oracle_pf* h, double* out) {
@@ -287,8 +289,8 @@ int32_t oracle_pf_shard_local_max(oracle_pf* h, double* out) { GUARD({ *out = so
 int32_t oracle_pf_shard_normalize(oracle_pf* h, const double* gmax, uint64_t* totals) {
     GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_normalize(*gmax, totals); })
 }
-int32_t oracle_pf_shard_route(oracle_pf* h, const uint64_t* totals_all, int32_t world, int32_t rank, uint64_t* req_out, int64_t* send_counts) {
-    GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_route(totals_all, world, rank, req_out, send_counts); })
+int32_t oracle_pf_shard_route(oracle_pf* h, int32_t scheme, const uint64_t* totals_all, int32_t world, int32_t rank, uint64_t* req_out, int64_t* send_counts) {
+    GUARD({ oracle_pf::Scope s(true); soa_of(h)->scheme = scheme; soa_of(h)->shard_route(totals_all, world, rank, req_out, send_counts); })
 }
 int32_t oracle_pf_shard_resolve(oracle_pf* h, const uint64_t* req_in, uint64_t n_req, double* rows) {
     GUARD({ soa_of(h)->shard_resolve(req_in, n_req, rows); })

@@ -143,6 +143,16 @@ inline uint64_t canonical_target(uint64_t k52, uint64_t Q) {
     const uint64_t t = (uint64_t)(p >> 52);
     return t < 1 ? 1 : t;
 }
+// systematic (extension): p = g*2^32 + k32; target = ((p*Q) >> 32) / N + 1
+inline uint64_t canonical_target_systematic(uint64_t g, uint32_t k32, uint64_t Q, uint64_t n_global) {
+    const unsigned __int128 p = ((unsigned __int128)g << 32) | k32;
+    const unsigned __int128 a = (p * Q) >> 32;
+    return (uint64_t)(a / n_global) + 1;
+}
+inline uint32_t canonical_systematic_k32(uint64_t seed, uint32_t rc) {
+    Rng r; r.seed = seed; r.slot = 0; r.step = rc; r.at(DOM_RESAMPLE, 1);
+    return (uint32_t)(r.bits64() >> 32);
+}
 inline size_t canonical_parent(const std::vector<uint64_t>& cum, uint64_t target) {
     size_t lo = 0, hi = cum.size();  // first index with cum >= target
     while (lo < hi) {

@@ -176,8 +176,10 @@ struct SoaPf {
         for (size_t i = 0; i < n; ++i) two[i] = 2.0 * (logw[i] - L);
         return o_exp(-logsumexp(two));
     }
+    int scheme = 0;  // 0 multinomial, 1 systematic (canonical mode only)
     double resample() {
         if (!initialised) throw Panic("resample before init_step");
+        if (scheme == 1 && !canonical) throw Panic("systematic resampling: canonical mode only (no reference counterpart)");
         const int d = model->dim_state;
         double L;
         if (!canonical) {
@@ -213,7 +215,8 @@ struct SoaPf {
             parallel_for([&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) {
                     Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
-                    parents[i] = (uint32_t)canonical_parent(c.cum, canonical_target(r.u52(), c.Q));
+                    if (scheme == 1) parents[i] = (uint32_t)canonical_parent(c.cum, canonical_target_systematic(slot_offset + i, canonical_systematic_k32(seed, resample_count), c.Q, n_global));
+                    else parents[i] = (uint32_t)canonical_parent(c.cum, canonical_target(r.u52(), c.Q));
                 }
             });
         }
@@ -256,7 +259,8 @@ struct SoaPf {
         for (int r = 0; r < world; ++r) send_counts[r] = 0;
         for (size_t i = 0; i < n; ++i) {
             Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
-            const uint64_t target = canonical_target(r.u52(), Q);
+            const uint64_t target = scheme == 1 ? canonical_target_systematic(slot_offset + i, canonical_systematic_k32(seed, resample_count), Q, n_global)
+                                                : canonical_target(r.u52(), Q);
             int s_ = 0;
             while (s_ < world - 1 && incl[(size_t)s_] < target) ++s_;
             dest[i] = s_;

@@ -68,7 +68,7 @@ def load():
     L.oracle_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
     L.oracle_pf_shard_local_max.argtypes = [p, p]
     L.oracle_pf_shard_normalize.argtypes = [p, p, p]
-    L.oracle_pf_shard_route.argtypes = [p, p, i32, i32, p, C.POINTER(i64)]
+    L.oracle_pf_shard_route.argtypes = [p, i32, p, i32, i32, p, C.POINTER(i64)]
     L.oracle_pf_shard_resolve.argtypes = [p, p, u64, p]
     L.oracle_pf_shard_scatter.argtypes = [p, p, dp]
     L.oracle_pf_shard_query.argtypes = [p, p, i32, dp, dp]
@@ -323,9 +323,9 @@ class OracleShardEngine:
     def shard_normalize(self, gmax_ptr, totals_ptr):
         self._ck(self.L.oracle_pf_shard_normalize(self.h, gmax_ptr, totals_ptr))
 
-    def shard_route(self, totals_all_ptr, world, rank, req_ptr):
+    def shard_route(self, scheme, totals_all_ptr, world, rank, req_ptr):
         counts = (C.c_int64 * world)()
-        self._ck(self.L.oracle_pf_shard_route(self.h, totals_all_ptr, world, rank, req_ptr, counts))
+        self._ck(self.L.oracle_pf_shard_route(self.h, scheme, totals_all_ptr, world, rank, req_ptr, counts))
         return list(counts)
 
     def shard_resolve(self, req_ptr, n_req, rows_ptr):

@@ -13,7 +13,7 @@ float run_k3(mp_pf* h, int iters) {
     const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
     hipEventRecord(a, h->stream);
     for (int it = 0; it < iters; ++it)
-        hipLaunchKernelGGL(k_resample_gather<ABL>, dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
+        hipLaunchKernelGGL((k_resample_gather<ABL, false>), dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
                            (uint32_t)MP_DOM_RESAMPLE, 1u, 2u, (uint32_t)it, h->S, 1, h->cx, h->guide, h->tilesum, h->tilesum2, h->nt, h->x[0], h->x[1], h->parent,
                            h->aos /* scratch instead of logw */, h->blockmax + 1024, 0, h->scal);
     hipEventRecord(b, h->stream);
@@ -51,6 +51,18 @@ int main(int argc, char** argv) {
     printf("K3 floor - LDS search       : %8.2f us\n", run_k3<4>(h, 20));
     printf("K3 floor - tile scan        : %8.2f us\n", run_k3<5>(h, 20));
     printf("K3 full again               : %8.2f us\n", run_k3<0>(h, 20));
+    {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
+        hipEventRecord(a, h->stream);
+        for (int it = 0; it < 20; ++it)
+            hipLaunchKernelGGL((k_resample_gather<0, true>), dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
+                               (uint32_t)MP_DOM_RESAMPLE, 1u, 2u, (uint32_t)it, h->S, 1, h->cx, h->guide, h->tilesum, h->tilesum2, h->nt, h->x[0], h->x[1],
+                               h->parent, h->aos, h->blockmax + 1024, 0, h->scal);
+        hipEventRecord(b, h->stream); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("K3 systematic (coalesced)   : %8.2f us\n", ms / 20 * 1e3);
+    }
     // K1 timing
     {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
