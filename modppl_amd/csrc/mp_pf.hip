@@ -911,6 +911,9 @@ struct mp_pf {
     long long* h_counts = nullptr;  // pinned
     int sh_world = 0;
     bool sharded = false;
+    // ancestry record (MP_PF_RECORD_HISTORY): the event log from which `traces[i].retv` is rebuilt
+    struct HistEvent { int kind; void* buf; };  // kind 0: states after an Unfold step ([d][n] f64); 1: parents of a resample ([n] u32)
+    std::vector<HistEvent> hist;
     // host-side filter state
     long long t = 0;  // Unfold steps taken (trace.args.0)
     uint32_t resample_count = 0;
@@ -999,7 +1002,16 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         h->ops->propagate(a);
     }
     h->t += 1;
-    return check_launch("k_propagate");
+    int32_t rc_ = check_launch("k_propagate");
+    if (rc_ != MP_OK) return rc_;
+    if (h->flags & MP_PF_RECORD_HISTORY) {
+        double* buf = nullptr;
+        const size_t bytes = sizeof(double) * h->n * (size_t)h->ops->dim_state;
+        HIPCK(hipMalloc(&buf, bytes));
+        HIPCK(hipMemcpyAsync(buf, h->x[h->cur], bytes, hipMemcpyDeviceToDevice, h->stream));
+        h->hist.push_back({0, buf});
+    }
+    return MP_OK;
 }
 
 static int32_t launch_normalize(mp_pf* h) {
@@ -1031,7 +1043,6 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     std::unique_ptr<mp_pf> h(new mp_pf());
     int32_t rc = make_model(model, h->ops);
     if (rc != MP_OK) return rc;
-    if (flags & MP_PF_RECORD_HISTORY) return mp_fail(MP_ERR_UNSUPPORTED, "MP_PF_RECORD_HISTORY: not in this build yet");
     h->n = n_particles;
     h->n_global = shard ? shard->n_global : n_particles;
     h->slot_offset = shard ? shard->slot_offset : 0;
@@ -1138,6 +1149,12 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (rc != MP_OK) return rc;
     h->cur ^= 1;
     h->resample_count += 1;
+    if (h->flags & MP_PF_RECORD_HISTORY) {
+        uint32_t* buf = nullptr;
+        HIPCK(hipMalloc(&buf, sizeof(uint32_t) * h->n));
+        HIPCK(hipMemcpyAsync(buf, h->parent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToDevice, h->stream));
+        h->hist.push_back({1, buf});
+    }
     if (log_total_weight) {
         rc = fetch_scalars(h);
         if (rc != MP_OK) return rc;
@@ -1325,8 +1342,31 @@ int32_t mp_pf_shard_query(mp_pf* h, const uint64_t* d_totals_all, int32_t world,
 }
 
 int32_t mp_pf_read_trajectory(mp_pf* h, uint64_t i, double* out, int32_t* t_steps) {
-    (void)h; (void)i; (void)out; (void)t_steps;
-    return mp_fail(MP_ERR_UNSUPPORTED, "read_trajectory needs MP_PF_RECORD_HISTORY (not in this build yet)");
+    if (!h || !out || !t_steps) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (!(h->flags & MP_PF_RECORD_HISTORY)) return mp_fail(MP_ERR_STATE, "read_trajectory needs a filter created with MP_PF_RECORD_HISTORY");
+    if (h->sharded) return mp_fail(MP_ERR_UNSUPPORTED, "read_trajectory: ancestors of a sharded filter live on other ranks");
+    if (i >= h->n) return mp_fail(MP_ERR_INVALID_ARG, "particle index out of range");
+    HIPCK(hipSetDevice(h->device));
+    HIPCK(hipStreamSynchronize(h->stream));
+    // walk the event log backwards: a resample maps slot -> parent slot (traces[i] = traces[parents[i]].clone(),
+    // particle_filter.rs:109-113); a step contributes the state of the current ancestor slot (retv.push, dynunfold.rs:58,92)
+    const int d = h->ops->dim_state;
+    int t = (int)h->t;
+    uint64_t a = i;
+    for (size_t e = h->hist.size(); e-- > 0;) {
+        const auto& ev = h->hist[e];
+        if (ev.kind == 1) {
+            uint32_t p = 0;
+            HIPCK(hipMemcpy(&p, (const uint32_t*)ev.buf + a, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            a = p;
+        } else {
+            --t;
+            for (int k = 0; k < d; ++k)
+                HIPCK(hipMemcpy(out + (size_t)t * d + k, (const double*)ev.buf + (size_t)k * h->n + a, sizeof(double), hipMemcpyDeviceToHost));
+        }
+    }
+    *t_steps = (int32_t)h->t;
+    return MP_OK;
 }
 
 int32_t mp_pf_time(mp_pf* h, int64_t* out) {
@@ -1387,6 +1427,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
         (void)hipEventDestroy(tl.stop);
     }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    for (auto& ev : h->hist) (void)hipFree(ev.buf);
     (void)hipFree(h->x[0]);
     (void)hipFree(h->x[1]);
     (void)hipFree(h->logw);

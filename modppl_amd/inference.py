@@ -118,6 +118,13 @@ class ParticleSystem:
         capi.check(self._L.mp_pf_time(self._h, C.byref(t)))
         return t.value
 
+    def trajectory(self, i):
+        """traces[i].retv — the Vec<State> of particle i's lineage (needs flags=MP_PF_RECORD_HISTORY)."""
+        out = np.empty((max(self.time, 1), self.model.dim_state))
+        t = C.c_int32()
+        capi.check(self._L.mp_pf_read_trajectory(self._h, int(i), _dptr(out), C.byref(t)))
+        return out[: t.value]
+
     def set_timing(self, enabled):
         capi.check(self._L.mp_pf_set_timing(self._h, int(enabled)))
 
