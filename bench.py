@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 N_PER_GPU = 1 << 20
 DIM = 1
@@ -141,6 +142,12 @@ def main():
             avg_us = {k: float("nan") for k in fam}
         dom = max(avg_us, key=lambda k: avg_us[k])
         achieved = BYTES_K[dom] * n / (avg_us[dom] * 1e-6) / 1e9
+        traffic = None
+        if n == N_PER_GPU and os.path.exists(TRAFFIC_JSON):  # PMC passes cannot run inside this process: committed summary, same workload
+            try:
+                traffic = json.load(open(TRAFFIC_JSON))[dom]["traffic_bytes"]
+            except Exception:
+                traffic = None
         out = {
             "metric": "particle-steps/sec, 1M-particle LGSSM SMC (step + multinomial resample per time step)",
             "value": n * world * K / dt,
@@ -163,7 +170,7 @@ def main():
             "step_hbm_frac": BYTES_STEP * n * K / dt / 1e9 / HBM_PEAK_GBPS,
             "kernel_avg_us": avg_us,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_launch": BYTES_K[dom] * n},
         }
         if world == 1 and not args.no_cpu_baseline:

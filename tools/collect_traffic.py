@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Parse rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: one pass each, as MI355X_MICROARCH.md §rocprofv3 PMC slots
+requires) of `bench.py --no-kernel-timing` into per-launch HBM-side traffic per kernel family.
+
+    python tools/collect_traffic.py gpurun_out/r1 > profiles/r01/traffic.json
+
+Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction (guide §HBM): FETCH_SIZE reports half of the
+bytes of a wide coalesced streaming read, so the streaming kernels (propagate, normalize_scan) are doubled; the resample
+kernel's reads are random 16-byte rows, a width the guide leaves uncalibrated, so its raw value is kept and flagged."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+FAM = {"k_propagate": "propagate", "k_normalize_scan": "normalize_scan", "k_resample_gather": "resample_gather"}
+STREAMING = {"propagate", "normalize_scan"}
+
+
+def per_kernel(dirname, counter):
+    files = glob.glob(f"{dirname}/*/*_counter_collection.csv")
+    out = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            for key, fam in FAM.items():
+                if key in r["Kernel_Name"]:
+                    out[fam].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+def main(root):
+    fetch, nf = per_kernel(f"{root}/pmc_fetch", "FETCH_SIZE")
+    write, nw = per_kernel(f"{root}/pmc_write", "WRITE_SIZE")
+    res = {}
+    for fam in FAM.values():
+        f_raw = fetch.get(fam, 0.0) * 1024.0
+        w = write.get(fam, 0.0) * 1024.0
+        f_corr = f_raw * 2.0 if fam in STREAMING else f_raw
+        res[fam] = {"fetch_bytes_raw": f_raw, "fetch_bytes_corrected": f_corr, "write_bytes": w, "traffic_bytes": f_corr + w,
+                    "fetch_correction": "x2 (wide coalesced stream)" if fam in STREAMING else "none (random 16-B rows: uncalibrated width; true value in [1x, 2x] of raw)",
+                    "launches_sampled": [nf.get(fam, 0), nw.get(fam, 0)]}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
