@@ -1,0 +1,149 @@
+// modppl.hpp — header-only C++ host wrapper over the C ABI (include/modppl_hip.h), mirroring the reference's names:
+//   modppl::ParticleSystem   ::new / init_step / step / effective_sample_size / resample /
+//                            log_marginal_likelihood_estimate      (modppl/src/inference/particle_filter.rs:44-121)
+//   modppl::importance_resampling                                   (modppl/src/inference/importance.rs:37-50)
+//   modppl::HierarchicalChains::mh / regen_mh                       (modppl/src/inference/mh.rs:9-75)
+// A reference `panic!` becomes a modppl::Panic exception carrying the status code.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/modppl_hip.h"
+
+namespace modppl {
+
+struct Panic : std::runtime_error {
+    int32_t code;
+    Panic(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int32_t rc) {
+    if (rc != MP_OK) throw Panic(rc, mp_last_error());
+}
+
+// Counterpart of DynUnfold<State>: a model descriptor {kind, dims, params}.
+struct UnfoldModel {
+    int32_t kind, dim_state, dim_obs;
+    std::vector<double> params;
+    mp_model_desc desc() const { return mp_model_desc{kind, dim_state, dim_obs, (int32_t)params.size(), params.data()}; }
+    static UnfoldModel lgssm(double mu0 = 0., double sig0 = 1., double a = 0.9, double sig_x = 0.5, double sig_y = 1.) {
+        return {MP_MODEL_LGSSM1, 1, 1, {mu0, sig0, a, sig_x, sig_y}};
+    }
+    static UnfoldModel spiral() { return {MP_MODEL_SPIRAL, 2, 2, {}}; }
+    static UnfoldModel bearings(double p0x = 1., double p0y = 1., double sig_p0 = 1., double sig_v0 = .1, double sig_a = .05, double sig_th = .02) {
+        return {MP_MODEL_BEARINGS, 4, 1, {p0x, p0y, sig_p0, sig_v0, sig_a, sig_th}};
+    }
+    static UnfoldModel lgssm_band(int D = 16, double a = 0.9, double band = 0.05, double sig0 = 1., double sig_x = 0.5, double sig_y = 1.) {
+        return {MP_MODEL_LGSSM_BAND, D, D, {(double)D, a, band, sig0, sig_x, sig_y}};
+    }
+};
+
+class ParticleSystem {
+    mp_pf* h_ = nullptr;
+    UnfoldModel model_;
+    uint64_t n_;
+
+public:
+    // ParticleSystem::new(model, num_particles, rng): `seed` replaces the unseedable ThreadRng
+    ParticleSystem(UnfoldModel model, uint64_t num_particles, uint64_t seed, uint32_t flags = 0, int device = 0, void* stream = nullptr)
+        : model_(std::move(model)), n_(num_particles) {
+        const mp_model_desc d = model_.desc();
+        check(mp_pf_create(&d, num_particles, seed, nullptr, flags, device, stream, &h_));
+    }
+    ParticleSystem(const ParticleSystem&) = delete;
+    ParticleSystem& operator=(const ParticleSystem&) = delete;
+    ~ParticleSystem() { mp_pf_destroy(h_); }
+
+    void init_step(const std::vector<double>& args, const std::vector<double>& constraints) {
+        check(mp_pf_init_step(h_, args.empty() ? nullptr : args.data(), constraints.data(), (int32_t)(constraints.size() / model_.dim_obs)));
+    }
+    ParticleSystem& step(const std::vector<double>& constraints) {
+        check(mp_pf_step(h_, constraints.data(), (int32_t)(constraints.size() / model_.dim_obs)));
+        return *this;
+    }
+    double effective_sample_size(bool fresh = false) {
+        double v;
+        check(mp_pf_effective_sample_size(h_, fresh ? MP_ESS_FRESH : MP_ESS_REFERENCE, &v));
+        return v;
+    }
+    double resample(int32_t scheme = MP_RESAMPLE_MULTINOMIAL) {
+        double v;
+        check(mp_pf_resample(h_, scheme, &v));
+        return v;
+    }
+    void resample_async(int32_t scheme = MP_RESAMPLE_MULTINOMIAL) { check(mp_pf_resample(h_, scheme, nullptr)); }
+    double log_marginal_likelihood_estimate() {
+        double v;
+        check(mp_pf_log_marginal_likelihood_estimate(h_, &v));
+        return v;
+    }
+    // traces[i].retv.last() for all i, row-major [n][dim_state]
+    std::vector<double> states() {
+        std::vector<double> x(n_ * (size_t)model_.dim_state);
+        check(mp_pf_read_state(h_, x.data()));
+        return x;
+    }
+    std::vector<double> log_weights() {
+        std::vector<double> w(n_);
+        check(mp_pf_read_log_weights(h_, w.data()));
+        return w;
+    }
+    std::vector<uint32_t> parents() {
+        std::vector<uint32_t> p(n_);
+        check(mp_pf_read_parents(h_, p.data()));
+        return p;
+    }
+    void synchronize() { check(mp_pf_synchronize(h_)); }
+    mp_pf* raw() { return h_; }
+};
+
+struct ImportanceResult {
+    std::vector<double> final_states, log_normalized_weights;
+    std::vector<uint64_t> resampled_indices;
+    double log_ml_estimate;
+};
+inline ImportanceResult importance_resampling(const UnfoldModel& model, const std::vector<double>& model_args, const std::vector<double>& constraints,
+                                              uint64_t num_samples, uint64_t num_ret_samples, uint64_t seed, int device = 0) {
+    ImportanceResult r;
+    r.final_states.resize(num_samples * (size_t)model.dim_state);
+    r.log_normalized_weights.resize(num_samples);
+    r.resampled_indices.resize(num_ret_samples);
+    const mp_model_desc d = model.desc();
+    check(mp_importance_resampling(&d, model_args.empty() ? nullptr : model_args.data(), constraints.data(),
+                                   (int32_t)(constraints.size() / model.dim_obs), num_samples, num_ret_samples, seed, device, &r.log_ml_estimate,
+                                   r.log_normalized_weights.data(), num_ret_samples ? r.resampled_indices.data() : nullptr, r.final_states.data()));
+    return r;
+}
+
+class HierarchicalChains {
+    mp_mh* h_ = nullptr;
+    uint64_t n_;
+
+public:
+    HierarchicalChains(const std::vector<double>& xs, const std::vector<double>& ys, uint64_t num_chains, uint64_t seed, int constrain_is_linear = -1,
+                       int device = 0, void* stream = nullptr)
+        : n_(num_chains) {
+        check(mp_mh_create(MP_MH_MODEL_HIERARCHICAL, xs.data(), ys.data(), (int32_t)xs.size(), constrain_is_linear, num_chains, seed, device, stream, &h_));
+    }
+    HierarchicalChains(const HierarchicalChains&) = delete;
+    ~HierarchicalChains() { mp_mh_destroy(h_); }
+    uint64_t mh(double drift_std, int32_t n_iters = 1) {
+        uint64_t acc;
+        check(mp_mh_step(h_, MP_MH_PROPOSAL_HIERARCHICAL_DRIFT, &drift_std, 1, n_iters, &acc));
+        return acc;
+    }
+    uint64_t regen_mh(const std::vector<int32_t>& mask_sites, int32_t n_iters = 1, bool cycle = false) {
+        uint64_t acc;
+        check(mp_regen_mh_step(h_, mask_sites.data(), (int32_t)mask_sites.size(), cycle ? 1 : 0, n_iters, &acc));
+        return acc;
+    }
+    std::vector<double> states() {
+        std::vector<double> s(n_ * 4);
+        check(mp_mh_read_state(h_, s.data()));
+        return s;
+    }
+};
+
+}  // namespace modppl

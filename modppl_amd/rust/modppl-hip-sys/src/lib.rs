@@ -1,0 +1,73 @@
+//! Raw declarations of include/modppl_hip.h.  SOURCE ONLY (no rustc in the build image).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+pub const MP_OK: i32 = 0;
+pub const MP_ERR_INVALID_ARG: i32 = 1;
+pub const MP_ERR_STATE: i32 = 2;
+pub const MP_ERR_CONSTRAINTS: i32 = 3;
+pub const MP_ERR_DEGENERATE: i32 = 4;
+pub const MP_ERR_HIP: i32 = 5;
+pub const MP_ERR_UNSUPPORTED: i32 = 6;
+
+pub const MP_MODEL_LGSSM1: i32 = 1;
+pub const MP_MODEL_SPIRAL: i32 = 2;
+pub const MP_MODEL_HMM: i32 = 3;
+pub const MP_MODEL_BEARINGS: i32 = 4;
+pub const MP_MODEL_LGSSM_BAND: i32 = 5;
+pub const MP_RESAMPLE_MULTINOMIAL: i32 = 0;
+pub const MP_RESAMPLE_SYSTEMATIC: i32 = 1;
+pub const MP_ESS_REFERENCE: i32 = 0;
+pub const MP_ESS_FRESH: i32 = 1;
+pub const MP_PF_RECORD_HISTORY: u32 = 1;
+
+#[repr(C)]
+pub struct mp_model_desc {
+    pub kind: i32,
+    pub dim_state: i32,
+    pub dim_obs: i32,
+    pub n_params: i32,
+    pub params: *const f64,
+}
+#[repr(C)]
+pub struct mp_shard {
+    pub n_global: u64,
+    pub slot_offset: u64,
+}
+#[repr(C)]
+pub struct mp_pf { _private: [u8; 0] }
+#[repr(C)]
+pub struct mp_mh { _private: [u8; 0] }
+
+extern "C" {
+    pub fn mp_last_error() -> *const c_char;
+    pub fn mp_device_count() -> i32;
+    pub fn mp_pf_create(model: *const mp_model_desc, n_particles: u64, seed: u64, shard: *const mp_shard, flags: u32,
+                        device: i32, stream: *mut c_void, out: *mut *mut mp_pf) -> i32;
+    pub fn mp_pf_init_step(h: *mut mp_pf, args0: *const f64, obs: *const f64, n_steps: i32) -> i32;
+    pub fn mp_pf_step(h: *mut mp_pf, obs: *const f64, n_steps: i32) -> i32;
+    pub fn mp_pf_effective_sample_size(h: *mut mp_pf, ess_mode: i32, out: *mut f64) -> i32;
+    pub fn mp_pf_resample(h: *mut mp_pf, scheme: i32, log_total_weight: *mut f64) -> i32;
+    pub fn mp_pf_log_marginal_likelihood_estimate(h: *mut mp_pf, out: *mut f64) -> i32;
+    pub fn mp_pf_read_state(h: *mut mp_pf, x_out: *mut f64) -> i32;
+    pub fn mp_pf_read_log_weights(h: *mut mp_pf, out: *mut f64) -> i32;
+    pub fn mp_pf_read_parents(h: *mut mp_pf, out: *mut u32) -> i32;
+    pub fn mp_pf_read_trajectory(h: *mut mp_pf, i: u64, out: *mut f64, t_steps: *mut i32) -> i32;
+    pub fn mp_pf_time(h: *mut mp_pf, out: *mut i64) -> i32;
+    pub fn mp_pf_run(h: *mut mp_pf, args0: *const f64, obs: *const f64, n_steps: i32, scheme: i32) -> i32;
+    pub fn mp_pf_synchronize(h: *mut mp_pf) -> i32;
+    pub fn mp_pf_destroy(h: *mut mp_pf) -> i32;
+    pub fn mp_importance_resampling(model: *const mp_model_desc, args0: *const f64, obs: *const f64, n_steps: i32,
+                                    num_samples: u64, num_ret_samples: u64, seed: u64, device: i32,
+                                    log_ml_estimate: *mut f64, log_normalized_weights: *mut f64,
+                                    resampled_indices: *mut u64, final_states: *mut f64) -> i32;
+    pub fn mp_mh_create(model_kind: i32, xs: *const f64, ys: *const f64, n_data: i32, constrain_is_linear: i32,
+                        n_chains: u64, seed: u64, device: i32, stream: *mut c_void, out: *mut *mut mp_mh) -> i32;
+    pub fn mp_mh_step(h: *mut mp_mh, proposal_kind: i32, proposal_args: *const f64, n_proposal_args: i32, n_iters: i32,
+                      accepted: *mut u64) -> i32;
+    pub fn mp_regen_mh_step(h: *mut mp_mh, mask_sites: *const i32, n_mask: i32, cycle: i32, n_iters: i32, accepted: *mut u64) -> i32;
+    pub fn mp_mh_read_state(h: *mut mp_mh, out: *mut f64) -> i32;
+    pub fn mp_mh_read_logjp(h: *mut mp_mh, out: *mut f64) -> i32;
+    pub fn mp_mh_iterations(h: *mut mp_mh, out: *mut u64) -> i32;
+    pub fn mp_mh_destroy(h: *mut mp_mh) -> i32;
+}
