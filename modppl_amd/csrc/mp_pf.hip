@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -76,6 +77,14 @@ constexpr int K1_MAX_BLOCKS = 2048;
 constexpr int SCAN_THREADS = 512;
 constexpr int SCAN_ITEMS = 4;
 constexpr int TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 particles per scan tile
+constexpr int BIN_CHUNK = 1024;       // output slots per chunk of the binned resampler
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_ITEMS = BIN_CHUNK / BIN_THREADS;
+constexpr int BIN_GROUP = 8;          // chunks per k_resolve_bins workgroup
+// Position of entry e of segment (bin, chunk) in the sparse segment arrays [bin][chunk][1024].  Only ~128 entries of
+// each 1024-entry window are used; rotating the start by (chunk % 8) * 128 spreads the used parts over all memory
+// channels instead of the ones the first eighth of every 8 KB window maps to.
+#define MP_SEG_POS(bin, c, e, nchunks) ((((u64)(bin) * (u64)(nchunks) + (u64)(c)) * BIN_CHUNK) + (u64)((((uint32_t)(e)) + (((uint32_t)(c)) & 7u) * 128u) & 1023u))
 constexpr int K3_THREADS = 256;
 constexpr int K3_ITEMS = 4;
 constexpr int K3_MAX_BLOCKS = 4096;
@@ -112,7 +121,9 @@ __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
 template <class Model>
 __global__ __launch_bounds__(K1_THREADS) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                           long long t, const double* x_in, double* x_out, double* logw,
-                                                          mp_obs obs, mp_state0 s0, int overwrite, double* __restrict__ blockmax) {
+                                                          mp_obs obs, mp_state0 s0, int overwrite, double* __restrict__ blockmax,
+                                                          const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
+                                                          u64 res_stride, int nchunks) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int K1_ITEMS = k1_items<Model>();
@@ -156,15 +167,26 @@ __global__ __launch_bounds__(K1_THREADS) void k_propagate(Model model, u64 n, u6
             const u64 i = i0 + (u64)p * K1_THREADS;
             if (i < n) {
                 double prev[D], next[D];
+                if (perm) {
+                    // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at
+                    // segment (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i]
+                    const uint32_t pr = perm[i];
+                    const u64 pos = MP_SEG_POS(pr >> 10, i >> 10, pr & 1023u, nchunks);
 #pragma unroll
-                for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[(u64)d * n + i];
+                    for (int d = 0; d < D; ++d) prev[d] = res_x[(u64)d * res_stride + pos];
+                } else {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[(u64)d * n + i];
+                }
                 mp_stream rng;
                 rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
                 mp_generate_handler<Model> g(rng, obs.v, &pu[p * NS], &pr[p * NS]);
                 model(g, t, prev, next);
 #pragma unroll
                 for (int d = 0; d < D; ++d) x_out[(u64)d * n + i] = next[d];
-                const double w = overwrite ? g.weight : logw[i] + g.weight;  // particle_filter.rs:68 / :81
+                // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to
+                // be all zero after a resample (log_weights.fill(0.), :114) and are not re-read
+                const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
                 logw[i] = w;
                 lmax = fmax(lmax, w);
             }
@@ -482,7 +504,9 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
                 mp_u64x2 r;
                 if (ABL == 3) r.a = (i * 0x9E3779B97F4A7C15ull) ^ ((u64)rc << 20);  // timing-only: no Philox
                 else r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
-                target = mp_target(mp_u52(r.a), Q);
+                u64 k52 = mp_u52(r.a);
+                if (ABL == 6) k52 = (k52 >> 3) | ((u64)(blockIdx.x & 7u) << 49);  // timing-only: draws confined to the XCD's eighth of the CDF
+                target = mp_target(k52, Q);
             }
             uint32_t b = (ABL == 4) ? (uint32_t)((target >> 7) % (u64)nt)  // timing-only: no LDS search
                                     : lower_bound_u64(s_incl, (uint32_t)nt, target);
@@ -535,6 +559,210 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// XCD-binned multinomial resampling (same parents per slot as k_resample_gather, bit for bit)
+// ---------------------------------------------------------------------------------------------
+// The row table (16 B x N) does not fit one XCD's 4 MB L2, so random row reads cross the fabric a full line at a
+// time (profiles/r01/k3_ablation_n2e20.txt).  But the top 3 bits of a draw's uniform say which EIGHTH of the CDF
+// it lands in, and they do not depend on the weights.  So:
+//   K3a k_bin_draws     every chunk of 1024 output slots splits its draws into 8 bins by those bits (stable order):
+//                       segment [bin][chunk][<=1024] of uniforms (sparse addressing, dense traffic) and perm[slot] =
+//                       (bin << 10 | position in its segment).
+//   K3b k_resolve_bins  workgroup (group of 8 chunks, bin b) with blockIdx % 8 == b — workgroups are dealt
+//                       round-robin over the 8 XCDs, so all lookups of bin b run on one XCD whose L2 then holds
+//                       that eighth of the table (speed only: any placement gives the same result).
+
+// K3a: per draw Philox -> target -> tile (LDS search over the tile totals) -> tile-local target lt and guide slot;
+// stable split of the chunk's draws into the 8 CDF-eighth bins.  No random global access here.
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S, int nchunks,
+                                                           const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2, int nt,
+                                                           u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_gidx,
+                                                           unsigned short* __restrict__ perm, unsigned short* __restrict__ seg_cnt,
+                                                           double* __restrict__ blockmax, int nb, mp_dev_scalars* scal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);                               // [nt]
+    u64* s_wtot = s_incl + nt;                                                // [BIN_THREADS/64]
+    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + BIN_THREADS / 64);  // [BIN_ITEMS][BIN_THREADS/64][8]
+    block_scan_tiles<BIN_THREADS>(tilesum, nt, s_incl, s_wtot);
+    const u64 Q = s_incl[nt - 1];
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    if (blockIdx.x == 0) {  // fold this normalisation into the filter scalars (as k_resample_gather does)
+        u64 q2 = 0;
+        for (int j = threadIdx.x; j < nt; j += BIN_THREADS) q2 += tilesum2[j];
+        q2 = wave_sum_u64(q2);
+        __syncthreads();
+        if (lane == 0) s_wtot[wave] = q2;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 Q2 = 0;
+            for (int k = 0; k < BIN_THREADS / 64; ++k) Q2 += s_wtot[k];
+            double L, ess;
+            finalize_scalars(Q, Q2, S, &L, &ess, scal->m);
+            scal->L = L;
+            scal->ess_stale = ess;
+            scal->Q = Q;
+            scal->Q2 = Q2;
+            scal->log_ml += L - mp_log((double)n_global);  // particle_filter.rs:105
+        }
+        for (int j = threadIdx.x; j < nb; j += BIN_THREADS) blockmax[j] = 0.;
+    }
+
+    u64 lt[BIN_ITEMS];
+    uint32_t gidx[BIN_ITEMS];
+    int bin[BIN_ITEMS];
+    uint32_t rank_in_wave[BIN_ITEMS];
+#pragma unroll
+    for (int q = 0; q < BIN_ITEMS; ++q) {
+        const u64 i = (u64)c * BIN_CHUNK + (u64)q * BIN_THREADS + threadIdx.x;
+        const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+        const u64 k52 = mp_u52(r.a);
+        const u64 target = mp_target(k52, Q);
+        uint32_t b = lower_bound_u64(s_incl, (uint32_t)nt, target);
+        if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
+        const u64 incl_b = s_incl[b];
+        const u64 excl = b ? s_incl[b - 1] : 0ull;
+        lt[q] = target - excl;                           // tile-local target, 1 <= lt <= W
+        uint32_t g = (uint32_t)(lt[q] >> mp_guide_shift(incl_b - excl));
+        if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+        gidx[q] = b * (uint32_t)GUIDE_N + g;
+        bin[q] = (i < n) ? (int)(k52 >> 49) : -1;
+        rank_in_wave[q] = 0;
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const u64 bal = __ballot(bin[q] == bb);
+            if (bin[q] == bb) rank_in_wave[q] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wcnt[(q * (BIN_THREADS / 64) + wave) * 8 + bb] = (uint32_t)__popcll(bal);
+        }
+    }
+    __syncthreads();
+    // stable order inside the chunk: item q-major (slots q*256 .. q*256+255), then wave, then lane == increasing slot
+#pragma unroll
+    for (int q = 0; q < BIN_ITEMS; ++q) {
+        if (bin[q] >= 0) {
+            uint32_t before = 0;
+            for (int qq = 0; qq < q; ++qq)
+                for (int w = 0; w < BIN_THREADS / 64; ++w) before += s_wcnt[(qq * (BIN_THREADS / 64) + w) * 8 + bin[q]];
+            for (int w = 0; w < wave; ++w) before += s_wcnt[(q * (BIN_THREADS / 64) + w) * 8 + bin[q]];
+            const uint32_t pos = before + rank_in_wave[q];
+            const u64 sp = MP_SEG_POS(bin[q], c, pos, nchunks);
+            seg_lt[sp] = lt[q];
+            seg_gidx[sp] = gidx[q];
+            perm[(u64)c * BIN_CHUNK + q * BIN_THREADS + threadIdx.x] = (unsigned short)((bin[q] << 10) | pos);
+        }
+    }
+    if (threadIdx.x < 8) {
+        uint32_t tot = 0;
+        for (int q = 0; q < BIN_ITEMS; ++q)
+            for (int w = 0; w < BIN_THREADS / 64; ++w) tot += s_wcnt[(q * (BIN_THREADS / 64) + w) * 8 + threadIdx.x];
+        seg_cnt[(u64)threadIdx.x * nchunks + c] = (unsigned short)tot;
+    }
+}
+
+// K3b: pure lookup, three dependent hops (segment entry -> guide -> rows), all inside the bin's eighth of the table.
+// Thread (quad, e) = (tid >> 7, tid & 127) owns entry e of the 4 segments of chunks group*8 + quad*4 + {0..3}; a
+// segment holds 128 +- 11 entries, so nearly every lane is live and each has 4 independent chains in flight.
+// Results stay in SEGMENT order (res_x[d][bin][chunk][pos], res_parent likewise: coalesced stores); the next
+// k_propagate reads its inputs through perm[], k_unpermute materialises slot order when the host asks.
+// V: timing-only ablation bits (tools/k3_ablate.hip): 1 = no result stores, 4 = no guide/row loads
+template <int V = 0>
+__global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int nchunks, const u64* __restrict__ seg_lt,
+                                                             const uint32_t* __restrict__ seg_gidx, const unsigned short* __restrict__ seg_cnt,
+                                                             const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                             const double* __restrict__ x_old, double* __restrict__ res_x, u64 res_stride,
+                                                             uint32_t* __restrict__ res_parent) {
+    const int bin = blockIdx.x & 7;
+    const int group = blockIdx.x >> 3;
+    const int e0 = threadIdx.x & 127, quad = threadIdx.x >> 7;
+    int cnt[K3_ITEMS], chunk_of[K3_ITEMS];
+    u64 lt[K3_ITEMS], spos[K3_ITEMS];
+    uint32_t gidx[K3_ITEMS];
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        const int c = group * BIN_GROUP + quad * K3_ITEMS + k;
+        const bool ok = c < nchunks;
+        chunk_of[k] = ok ? c : 0;
+        cnt[k] = ok ? (int)seg_cnt[(u64)bin * nchunks + c] : 0;
+        spos[k] = MP_SEG_POS(bin, chunk_of[k], e0, nchunks);
+        lt[k] = seg_lt[spos[k]];        // in bounds for every thread; masked by cnt below
+        gidx[k] = seg_gidx[spos[k]];
+    }
+    auto resolve = [&](u64 ltx, uint32_t gi, u64 sp, bool prefetched, uint32_t j, mp_cx r0, mp_cx r1) {
+        const u64 tbase = (u64)(gi / (uint32_t)GUIDE_N) * TILE;
+        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+        if (!prefetched) {
+            j = guide[gi];
+            if (j > tlen - 1) j = tlen - 1;
+            r0 = cx[tbase + j];
+            r1 = r0;
+            if (j + 1 < tlen && r0.cum < ltx) r1 = cx[tbase + j + 1];
+        }
+        mp_cx row = r0;
+        if (row.cum < ltx && j + 1 < tlen) {  // first row with cum >= lt
+            row = r1;
+            ++j;
+            while (row.cum < ltx && j + 1 < tlen) {
+                ++j;
+                row = cx[tbase + j];
+            }
+        }
+        const u64 p = tbase + j;
+        if (!(V & 1) || row.x0 == 1.2345e301) {
+            res_parent[sp] = (uint32_t)p;
+            res_x[sp] = row.x0;
+            for (int d = 1; d < D; ++d) res_x[(u64)d * res_stride + sp] = x_old[(u64)d * n + p];
+        }
+    };
+    bool live[K3_ITEMS];
+    uint32_t j[K3_ITEMS];
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        live[k] = e0 < cnt[k];
+        j[k] = (live[k] && !(V & 4)) ? guide[gidx[k]] : 0u;
+    }
+    mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        const u64 tbase = (u64)(gidx[k] / (uint32_t)GUIDE_N) * TILE;
+        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+        if (j[k] > tlen - 1) j[k] = tlen - 1;
+        const uint32_t j1 = (j[k] + 1 < tlen) ? j[k] + 1 : j[k];
+        if (live[k] && !(V & 4)) {
+            r0[k] = cx[tbase + j[k]];
+            r1[k] = cx[tbase + j1];
+        } else {
+            r0[k].cum = ~0ull; r0[k].x0 = 0.; r1[k] = r0[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k)
+        if (live[k]) resolve(lt[k], gidx[k], spos[k], true, j[k], r0[k], r1[k]);
+    // entries 128.. of a segment (about 5 % of the entries: the upper tail of Binomial(1024, 1/8))
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        for (int e = 128 + e0; e < cnt[k]; e += 128) {
+            const u64 sp = MP_SEG_POS(bin, chunk_of[k], e, nchunks);
+            mp_cx z; z.cum = 0; z.x0 = 0.;
+            resolve(seg_lt[sp], seg_gidx[sp], sp, false, 0u, z, z);
+        }
+    }
+}
+
+// slot order from segment order: traces[i] = traces[parents[i]].clone(); log_weights.fill(0.) (particle_filter.rs:109-114)
+__global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __restrict__ perm, const double* __restrict__ res_x, u64 res_stride,
+                            const uint32_t* __restrict__ res_parent, double* __restrict__ x_new, uint32_t* __restrict__ parent,
+                            double* __restrict__ logw) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pr = perm[i];
+    const u64 pos = MP_SEG_POS(pr >> 10, i >> 10, pr & 1023u, nchunks);
+    for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = res_x[(u64)d * res_stride + pos];
+    parent[i] = res_parent[pos];
+    logw[i] = 0.;
 }
 
 // query path: log_marginal_likelihood_estimate / fresh ESS from the current log-weights (after K2)
@@ -773,6 +1001,10 @@ struct PropagateArgs {
     double* blockmax;
     int grid;
     hipStream_t stream;
+    const unsigned short* perm;
+    const double* res_x;
+    u64 res_stride;
+    int nchunks;
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
@@ -791,7 +1023,7 @@ struct ModelOpsT : ModelOps {
     }
     void propagate(const PropagateArgs& a) const override {
         hipLaunchKernelGGL(k_propagate<Model>, dim3(a.grid), dim3(K1_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.blockmax);
+                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.blockmax, a.perm, a.res_x, a.res_stride, a.nchunks);
     }
 };
 
@@ -901,6 +1133,17 @@ struct mp_pf {
     mp_dev_scalars* scal = nullptr;
     double* aos = nullptr;  // staging for read_state
     mp_dev_scalars* h_scal = nullptr;  // pinned
+    // binned resampling scratch: segments [bin][chunk][1024]
+    u64* seg_lt = nullptr;              // [8 * nchunks * 1024]: tile-local target of every binned draw
+    uint32_t* seg_gidx = nullptr;       // guide slot (tile * 2048 + bucket) of every binned draw
+    unsigned short* perm = nullptr;     // [n]: (bin << 10 | position) of every slot's draw
+    unsigned short* seg_cnt = nullptr;
+    double* res_x = nullptr;            // [d][8 * nchunks * 1024]: resampled states in segment order
+    uint32_t* res_parent = nullptr;     // [8 * nchunks * 1024]
+    u64 res_stride = 0;
+    bool permuted = false;              // the current states / parents / (zero) log-weights live in res_* (lazy slot order)
+    int nchunks = 0;
+    int use_binned = 1;  // MP_BINNED_RESAMPLE=0 selects the single-kernel path (A/B measurements)
     // sharded-resample scratch (allocated on first use)
     unsigned char* sh_dest = nullptr;
     u64* sh_lt = nullptr;
@@ -984,6 +1227,15 @@ static int32_t fetch_scalars(mp_pf* h) {
     return MP_OK;
 }
 
+// Slot-order x / parent / logw after a binned resample (only when something other than the next step needs them).
+static int32_t materialize(mp_pf* h) {
+    if (!h->permuted) return MP_OK;
+    hipLaunchKernelGGL(k_unpermute, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->ops->dim_state, h->nchunks, h->perm,
+                       h->res_x, h->res_stride, h->res_parent, h->x[h->cur], h->parent, h->logw);
+    h->permuted = false;
+    return check_launch("k_unpermute");
+}
+
 static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs, bool overwrite) {
     PropagateArgs a;
     a.n = h->n; a.slot_offset = h->slot_offset;
@@ -993,7 +1245,11 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.logw = h->logw;
     for (int j = 0; j < MP_MAX_OBS; ++j) a.obs.v[j] = (j < h->ops->dim_obs) ? obs[j] : 0.;
     for (int j = 0; j < MP_MAX_STATE; ++j) a.s0.v[j] = (args0 && j < h->ops->dim_state) ? args0[j] : 0.;
-    a.overwrite = overwrite ? 1 : 0;
+    a.overwrite = overwrite ? 1 : (h->permuted ? 2 : 0);
+    a.perm = h->permuted ? h->perm : nullptr;
+    a.res_x = h->res_x;
+    a.res_stride = h->res_stride;
+    a.nchunks = h->nchunks;
     a.blockmax = h->blockmax;
     a.grid = h->nb;
     a.stream = h->stream;
@@ -1002,6 +1258,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         h->ops->propagate(a);
     }
     h->t += 1;
+    h->permuted = false;  // k_propagate wrote x[cur] and logw in slot order
     int32_t rc_ = check_launch("k_propagate");
     if (rc_ != MP_OK) return rc_;
     if (h->flags & MP_PF_RECORD_HISTORY) {
@@ -1015,6 +1272,8 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
 }
 
 static int32_t launch_normalize(mp_pf* h) {
+    int32_t rcm = materialize(h);
+    if (rcm != MP_OK) return rcm;
     LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
     hipLaunchKernelGGL(k_normalize_scan, dim3(h->nt), dim3(SCAN_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->n, h->blockmax, h->nb, h->S,
                        h->cx, h->guide, h->tilesum, h->tilesum2, h->scal);
@@ -1083,6 +1342,18 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     HIPCK(hipMalloc(&h->tilesum2, sizeof(u64) * h->nt));
     HIPCK(hipMalloc(&h->scal, sizeof(mp_dev_scalars)));
     HIPCK(hipMalloc(&h->aos, sizeof(double) * n * d));
+    h->nchunks = (int)((n + BIN_CHUNK - 1) / BIN_CHUNK);
+    {
+        const char* env = getenv("MP_BINNED_RESAMPLE");
+        if (env && env[0] == '0') h->use_binned = 0;
+    }
+    HIPCK(hipMalloc(&h->seg_lt, sizeof(u64) * 8 * (size_t)h->nchunks * BIN_CHUNK));
+    HIPCK(hipMalloc(&h->seg_gidx, sizeof(uint32_t) * 8 * (size_t)h->nchunks * BIN_CHUNK));
+    h->res_stride = 8ull * (u64)h->nchunks * BIN_CHUNK;
+    HIPCK(hipMalloc(&h->perm, sizeof(unsigned short) * (size_t)h->nchunks * BIN_CHUNK));
+    HIPCK(hipMalloc(&h->res_x, sizeof(double) * h->res_stride * (size_t)d));
+    HIPCK(hipMalloc(&h->res_parent, sizeof(uint32_t) * h->res_stride));
+    HIPCK(hipMalloc(&h->seg_cnt, sizeof(unsigned short) * 8 * (size_t)h->nchunks));
     HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
     // ParticleSystem::new: log_weights = 0, parents = 0, log_ml_estimate = 0 (particle_filter.rs:44-57)
     HIPCK(hipMemsetAsync(h->x[0], 0, sizeof(double) * n * d, h->stream));
@@ -1134,9 +1405,19 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (rc != MP_OK) return rc;
     const int d = h->ops->dim_state;
     const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
+    bool binned = false;
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        if (scheme == MP_RESAMPLE_SYSTEMATIC)
+        if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
+            const size_t lds_a = sizeof(u64) * ((size_t)h->nt + BIN_THREADS / 64) + sizeof(uint32_t) * BIN_ITEMS * (BIN_THREADS / 64) * 8;
+            hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
+                               (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tilesum, h->tilesum2, h->nt, h->seg_lt, h->seg_gidx,
+                               h->perm, h->seg_cnt, h->blockmax, h->nb, h->scal);
+            const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
+            hipLaunchKernelGGL(k_resolve_bins<0>, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, d, h->nchunks, h->seg_lt, h->seg_gidx,
+                               h->seg_cnt, h->cx, h->guide, h->x[h->cur], h->res_x, h->res_stride, h->res_parent);
+            binned = true;
+        } else if (scheme == MP_RESAMPLE_SYSTEMATIC)
             hipLaunchKernelGGL((k_resample_gather<0, true>), dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
                                (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide,
                                h->tilesum, h->tilesum2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
@@ -1147,9 +1428,12 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     }
     rc = check_launch("k_resample_gather");
     if (rc != MP_OK) return rc;
-    h->cur ^= 1;
+    if (binned) h->permuted = true;   // results stay in segment order; x[cur] is the (stale) pre-resample state
+    else h->cur ^= 1;
     h->resample_count += 1;
     if (h->flags & MP_PF_RECORD_HISTORY) {
+        rc = materialize(h);
+        if (rc != MP_OK) return rc;
         uint32_t* buf = nullptr;
         HIPCK(hipMalloc(&buf, sizeof(uint32_t) * h->n));
         HIPCK(hipMemcpyAsync(buf, h->parent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToDevice, h->stream));
@@ -1202,6 +1486,7 @@ int32_t mp_pf_log_marginal_likelihood_estimate(mp_pf* h, double* out) {
 int32_t mp_pf_read_state(mp_pf* h, double* x_out) {
     if (!h || !x_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
+    { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
     const int d = h->ops->dim_state;
     hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->x[h->cur], h->n, d, h->aos);
     int32_t rc = check_launch("k_soa_to_aos");
@@ -1214,6 +1499,7 @@ int32_t mp_pf_read_state(mp_pf* h, double* x_out) {
 int32_t mp_pf_read_log_weights(mp_pf* h, double* out) {
     if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
+    { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
     HIPCK(hipMemcpyAsync(out, h->logw, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
     return MP_OK;
@@ -1222,6 +1508,7 @@ int32_t mp_pf_read_log_weights(mp_pf* h, double* out) {
 int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
     if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
+    { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
     HIPCK(hipMemcpyAsync(out, h->parent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
     return MP_OK;
@@ -1439,6 +1726,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->tilesum2);
     (void)hipFree(h->scal);
     (void)hipFree(h->aos);
+    (void)hipFree(h->seg_lt); (void)hipFree(h->seg_gidx); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts);
     if (h->h_counts) (void)hipHostFree(h->h_counts);

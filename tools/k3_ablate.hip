@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
     printf("K3 floor - Philox           : %8.2f us\n", run_k3<3>(h, 20));
     printf("K3 floor - LDS search       : %8.2f us\n", run_k3<4>(h, 20));
     printf("K3 floor - tile scan        : %8.2f us\n", run_k3<5>(h, 20));
+    printf("K3 full, draws in XCD eighth: %8.2f us\n", run_k3<6>(h, 20));
     printf("K3 full again               : %8.2f us\n", run_k3<0>(h, 20));
     {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -62,6 +63,28 @@ int main(int argc, char** argv) {
         hipEventRecord(b, h->stream); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("K3 systematic (coalesced)   : %8.2f us\n", ms / 20 * 1e3);
+    }
+    // binned path pieces
+    {
+        auto timeit = [&](const char* name, auto fn) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            fn(); hipEventRecord(a, h->stream);
+            for (int it = 0; it < 20; ++it) fn();
+            hipEventRecord(b, h->stream); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("%-28s: %8.2f us\n", name, ms / 20 * 1e3);
+        };
+        const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
+        const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
+        const size_t lds_a = sizeof(u64) * ((size_t)h->nt + BIN_THREADS / 64) + sizeof(uint32_t) * BIN_ITEMS * (BIN_THREADS / 64) * 8;
+        auto k3a = [&] { hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, 1u, 2u, 3u, h->S, h->nchunks, h->tilesum, h->tilesum2, h->nt, h->seg_lt, h->seg_gidx, h->perm, h->seg_cnt, h->blockmax + 1024, 0, h->scal); };
+#define K3B(V) [&] { hipLaunchKernelGGL(k_resolve_bins<V>, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, 1, h->nchunks, h->seg_lt, h->seg_gidx, h->seg_cnt, h->cx, h->guide, h->x[0], h->res_x, h->res_stride, h->res_parent); }
+        timeit("K3a bin draws", k3a);
+        timeit("K3b resolve bins", K3B(0));
+        timeit("K3b no result stores", K3B(1));
+        timeit("K3b no guide/row loads", K3B(4));
+        h->permuted = true;
+        timeit("K1 propagate (perm input)", [&] { h->t = 5; h->permuted = true; launch_propagate(h, nullptr, &y1, false); });
     }
     // K1 timing
     {
