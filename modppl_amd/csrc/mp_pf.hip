@@ -562,6 +562,17 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
 }
 
 
+// Tile of a global target: tile totals are nearly equal (each sums 2048 weights), so target * nt / Q lands within a
+// tile or two of the answer; walk from there.  Same result as lower_bound_u64(s_incl, nt, target), fewer LDS reads.
+__device__ __forceinline__ uint32_t tile_of_target(const u64* s_incl, uint32_t nt, u64 target, double nt_over_Q) {
+    int b = (int)((double)target * nt_over_Q);
+    if (b > (int)nt - 1) b = (int)nt - 1;
+    if (b < 0) b = 0;
+    while (b > 0 && s_incl[b - 1] >= target) --b;          // first b with incl[b] >= target ...
+    while (b < (int)nt - 1 && s_incl[b] < target) ++b;     // ... from either side
+    return (uint32_t)b;
+}
+
 // ---------------------------------------------------------------------------------------------
 // XCD-binned multinomial resampling (same parents per slot as k_resample_gather, bit for bit)
 // ---------------------------------------------------------------------------------------------
@@ -579,13 +590,15 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
 // stable split of the chunk's draws into the 8 CDF-eighth bins.  No random global access here.
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S, int nchunks,
                                                            const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2, int nt,
-                                                           u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_gidx,
+                                                           const unsigned short* __restrict__ guide,
+                                                           u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row,
                                                            unsigned short* __restrict__ perm, unsigned short* __restrict__ seg_cnt,
                                                            double* __restrict__ blockmax, int nb, mp_dev_scalars* scal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* s_incl = reinterpret_cast<u64*>(smem);                               // [nt]
     u64* s_wtot = s_incl + nt;                                                // [BIN_THREADS/64]
-    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + BIN_THREADS / 64);  // [BIN_ITEMS][BIN_THREADS/64][8]
+    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + BIN_THREADS / 64);  // [BIN_ITEMS][BIN_THREADS/64][8] counts
+    uint32_t* s_woff = s_wcnt + BIN_ITEMS * (BIN_THREADS / 64) * 8;             // same shape: exclusive offsets (+ [8] totals)
     block_scan_tiles<BIN_THREADS>(tilesum, nt, s_incl, s_wtot);
     const u64 Q = s_incl[nt - 1];
     const int c = blockIdx.x;
@@ -613,17 +626,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
     }
 
     u64 lt[BIN_ITEMS];
-    uint32_t gidx[BIN_ITEMS];
+    uint32_t gidx[BIN_ITEMS], tile_of[BIN_ITEMS];
     int bin[BIN_ITEMS];
     uint32_t rank_in_wave[BIN_ITEMS];
+    const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
 #pragma unroll
     for (int q = 0; q < BIN_ITEMS; ++q) {
         const u64 i = (u64)c * BIN_CHUNK + (u64)q * BIN_THREADS + threadIdx.x;
         const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
         const u64 k52 = mp_u52(r.a);
         const u64 target = mp_target(k52, Q);
-        uint32_t b = lower_bound_u64(s_incl, (uint32_t)nt, target);
-        if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
+        const uint32_t b = tile_of_target(s_incl, (uint32_t)nt, target, nt_over_Q);
         const u64 incl_b = s_incl[b];
         const u64 excl = b ? s_incl[b - 1] : 0ull;
         lt[q] = target - excl;                           // tile-local target, 1 <= lt <= W
@@ -631,6 +644,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
         if (g > GUIDE_N - 1) g = GUIDE_N - 1;
         gidx[q] = b * (uint32_t)GUIDE_N + g;
         bin[q] = (i < n) ? (int)(k52 >> 49) : -1;
+        tile_of[q] = b;
         rank_in_wave[q] = 0;
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) {
@@ -639,40 +653,48 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
             if (lane == 0) s_wcnt[(q * (BIN_THREADS / 64) + wave) * 8 + bb] = (uint32_t)__popcll(bal);
         }
     }
+    // the guide lookups go out now (the 2 MB guide is L2-resident on every XCD) and land while the offsets are built
+    uint32_t j0[BIN_ITEMS];
+#pragma unroll
+    for (int q = 0; q < BIN_ITEMS; ++q) j0[q] = guide[gidx[q]];
     __syncthreads();
-    // stable order inside the chunk: item q-major (slots q*256 .. q*256+255), then wave, then lane == increasing slot
+    // exclusive offsets in the stable order: item q-major (slots q*256 .. q*256+255), then wave, then lane == increasing slot
+    constexpr int NW = BIN_THREADS / 64;
+    if (threadIdx.x < 8) {
+        uint32_t run = 0;
+        for (int q = 0; q < BIN_ITEMS; ++q)
+            for (int w = 0; w < NW; ++w) {
+                s_woff[(q * NW + w) * 8 + threadIdx.x] = run;
+                run += s_wcnt[(q * NW + w) * 8 + threadIdx.x];
+            }
+        seg_cnt[(u64)threadIdx.x * nchunks + c] = (unsigned short)run;
+    }
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < BIN_ITEMS; ++q) {
         if (bin[q] >= 0) {
-            uint32_t before = 0;
-            for (int qq = 0; qq < q; ++qq)
-                for (int w = 0; w < BIN_THREADS / 64; ++w) before += s_wcnt[(qq * (BIN_THREADS / 64) + w) * 8 + bin[q]];
-            for (int w = 0; w < wave; ++w) before += s_wcnt[(q * (BIN_THREADS / 64) + w) * 8 + bin[q]];
-            const uint32_t pos = before + rank_in_wave[q];
+            const uint32_t pos = s_woff[(q * NW + wave) * 8 + bin[q]] + rank_in_wave[q];
             const u64 sp = MP_SEG_POS(bin[q], c, pos, nchunks);
+            const u64 tbase = (u64)tile_of[q] * TILE;
+            const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+            const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
             seg_lt[sp] = lt[q];
-            seg_gidx[sp] = gidx[q];
+            seg_row[sp] = (uint32_t)tbase + jj;   // row where the forward scan starts
             perm[(u64)c * BIN_CHUNK + q * BIN_THREADS + threadIdx.x] = (unsigned short)((bin[q] << 10) | pos);
         }
     }
-    if (threadIdx.x < 8) {
-        uint32_t tot = 0;
-        for (int q = 0; q < BIN_ITEMS; ++q)
-            for (int w = 0; w < BIN_THREADS / 64; ++w) tot += s_wcnt[(q * (BIN_THREADS / 64) + w) * 8 + threadIdx.x];
-        seg_cnt[(u64)threadIdx.x * nchunks + c] = (unsigned short)tot;
-    }
 }
 
-// K3b: pure lookup, three dependent hops (segment entry -> guide -> rows), all inside the bin's eighth of the table.
+// K3b: pure lookup, two dependent hops (segment entry -> table rows), all inside the bin's eighth of the table.
 // Thread (quad, e) = (tid >> 7, tid & 127) owns entry e of the 4 segments of chunks group*8 + quad*4 + {0..3}; a
 // segment holds 128 +- 11 entries, so nearly every lane is live and each has 4 independent chains in flight.
 // Results stay in SEGMENT order (res_x[d][bin][chunk][pos], res_parent likewise: coalesced stores); the next
 // k_propagate reads its inputs through perm[], k_unpermute materialises slot order when the host asks.
-// V: timing-only ablation bits (tools/k3_ablate.hip): 1 = no result stores, 4 = no guide/row loads
+// V: timing-only ablation bits (tools/k3_ablate.hip): 1 = no result stores, 4 = no row loads
 template <int V = 0>
 __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int nchunks, const u64* __restrict__ seg_lt,
-                                                             const uint32_t* __restrict__ seg_gidx, const unsigned short* __restrict__ seg_cnt,
-                                                             const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                             const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_cnt,
+                                                             const mp_cx* __restrict__ cx,
                                                              const double* __restrict__ x_old, double* __restrict__ res_x, u64 res_stride,
                                                              uint32_t* __restrict__ res_parent) {
     const int bin = blockIdx.x & 7;
@@ -680,7 +702,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int n
     const int e0 = threadIdx.x & 127, quad = threadIdx.x >> 7;
     int cnt[K3_ITEMS], chunk_of[K3_ITEMS];
     u64 lt[K3_ITEMS], spos[K3_ITEMS];
-    uint32_t gidx[K3_ITEMS];
+    uint32_t row0[K3_ITEMS];
 #pragma unroll
     for (int k = 0; k < K3_ITEMS; ++k) {
         const int c = group * BIN_GROUP + quad * K3_ITEMS + k;
@@ -689,65 +711,56 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int n
         cnt[k] = ok ? (int)seg_cnt[(u64)bin * nchunks + c] : 0;
         spos[k] = MP_SEG_POS(bin, chunk_of[k], e0, nchunks);
         lt[k] = seg_lt[spos[k]];        // in bounds for every thread; masked by cnt below
-        gidx[k] = seg_gidx[spos[k]];
+        row0[k] = seg_row[spos[k]];
     }
-    auto resolve = [&](u64 ltx, uint32_t gi, u64 sp, bool prefetched, uint32_t j, mp_cx r0, mp_cx r1) {
-        const u64 tbase = (u64)(gi / (uint32_t)GUIDE_N) * TILE;
-        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
-        if (!prefetched) {
-            j = guide[gi];
-            if (j > tlen - 1) j = tlen - 1;
-            r0 = cx[tbase + j];
-            r1 = r0;
-            if (j + 1 < tlen && r0.cum < ltx) r1 = cx[tbase + j + 1];
-        }
-        mp_cx row = r0;
-        if (row.cum < ltx && j + 1 < tlen) {  // first row with cum >= lt
-            row = r1;
-            ++j;
-            while (row.cum < ltx && j + 1 < tlen) {
-                ++j;
-                row = cx[tbase + j];
+    // first row >= lt, walking forward from `row` inside its tile; r0/r1 = that row and the next one when already loaded
+    auto finish = [&](u64 ltx, uint32_t row, u64 sp, mp_cx r0, mp_cx r1) {
+        const u64 tend = (((u64)row / TILE) + 1) * TILE;
+        const u64 last = (tend < n ? tend : n) - 1;      // last row of the tile
+        mp_cx cur = r0;
+        u64 p = row;
+        if (cur.cum < ltx && p < last) {
+            cur = r1;
+            ++p;
+            while (cur.cum < ltx && p < last) {
+                ++p;
+                cur = cx[p];
             }
         }
-        const u64 p = tbase + j;
-        if (!(V & 1) || row.x0 == 1.2345e301) {
+        if (!(V & 1) || cur.x0 == 1.2345e301) {
             res_parent[sp] = (uint32_t)p;
-            res_x[sp] = row.x0;
+            res_x[sp] = cur.x0;
             for (int d = 1; d < D; ++d) res_x[(u64)d * res_stride + sp] = x_old[(u64)d * n + p];
         }
     };
     bool live[K3_ITEMS];
-    uint32_t j[K3_ITEMS];
-#pragma unroll
-    for (int k = 0; k < K3_ITEMS; ++k) {
-        live[k] = e0 < cnt[k];
-        j[k] = (live[k] && !(V & 4)) ? guide[gidx[k]] : 0u;
-    }
     mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
 #pragma unroll
     for (int k = 0; k < K3_ITEMS; ++k) {
-        const u64 tbase = (u64)(gidx[k] / (uint32_t)GUIDE_N) * TILE;
-        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
-        if (j[k] > tlen - 1) j[k] = tlen - 1;
-        const uint32_t j1 = (j[k] + 1 < tlen) ? j[k] + 1 : j[k];
+        live[k] = e0 < cnt[k];
         if (live[k] && !(V & 4)) {
-            r0[k] = cx[tbase + j[k]];
-            r1[k] = cx[tbase + j1];
+            const u64 tend = (((u64)row0[k] / TILE) + 1) * TILE;
+            const u64 last = (tend < n ? tend : n) - 1;
+            r0[k] = cx[row0[k]];
+            r1[k] = cx[(u64)row0[k] + ((u64)row0[k] < last ? 1 : 0)];
         } else {
             r0[k].cum = ~0ull; r0[k].x0 = 0.; r1[k] = r0[k];
         }
     }
 #pragma unroll
     for (int k = 0; k < K3_ITEMS; ++k)
-        if (live[k]) resolve(lt[k], gidx[k], spos[k], true, j[k], r0[k], r1[k]);
+        if (live[k]) finish(lt[k], row0[k], spos[k], r0[k], r1[k]);
     // entries 128.. of a segment (about 5 % of the entries: the upper tail of Binomial(1024, 1/8))
 #pragma unroll
     for (int k = 0; k < K3_ITEMS; ++k) {
         for (int e = 128 + e0; e < cnt[k]; e += 128) {
             const u64 sp = MP_SEG_POS(bin, chunk_of[k], e, nchunks);
-            mp_cx z; z.cum = 0; z.x0 = 0.;
-            resolve(seg_lt[sp], seg_gidx[sp], sp, false, 0u, z, z);
+            const uint32_t row = seg_row[sp];
+            const u64 tend = (((u64)row / TILE) + 1) * TILE;
+            const u64 last = (tend < n ? tend : n) - 1;
+            const mp_cx a = cx[row];
+            const mp_cx bq = cx[(u64)row + ((u64)row < last ? 1 : 0)];
+            finish(seg_lt[sp], row, sp, a, bq);
         }
     }
 }
@@ -1135,7 +1148,7 @@ struct mp_pf {
     mp_dev_scalars* h_scal = nullptr;  // pinned
     // binned resampling scratch: segments [bin][chunk][1024]
     u64* seg_lt = nullptr;              // [8 * nchunks * 1024]: tile-local target of every binned draw
-    uint32_t* seg_gidx = nullptr;       // guide slot (tile * 2048 + bucket) of every binned draw
+    uint32_t* seg_row = nullptr;        // table row where the forward scan of every binned draw starts
     unsigned short* perm = nullptr;     // [n]: (bin << 10 | position) of every slot's draw
     unsigned short* seg_cnt = nullptr;
     double* res_x = nullptr;            // [d][8 * nchunks * 1024]: resampled states in segment order
@@ -1348,7 +1361,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (env && env[0] == '0') h->use_binned = 0;
     }
     HIPCK(hipMalloc(&h->seg_lt, sizeof(u64) * 8 * (size_t)h->nchunks * BIN_CHUNK));
-    HIPCK(hipMalloc(&h->seg_gidx, sizeof(uint32_t) * 8 * (size_t)h->nchunks * BIN_CHUNK));
+    HIPCK(hipMalloc(&h->seg_row, sizeof(uint32_t) * 8 * (size_t)h->nchunks * BIN_CHUNK));
     h->res_stride = 8ull * (u64)h->nchunks * BIN_CHUNK;
     HIPCK(hipMalloc(&h->perm, sizeof(unsigned short) * (size_t)h->nchunks * BIN_CHUNK));
     HIPCK(hipMalloc(&h->res_x, sizeof(double) * h->res_stride * (size_t)d));
@@ -1409,13 +1422,13 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
-            const size_t lds_a = sizeof(u64) * ((size_t)h->nt + BIN_THREADS / 64) + sizeof(uint32_t) * BIN_ITEMS * (BIN_THREADS / 64) * 8;
+            const size_t lds_a = sizeof(u64) * ((size_t)h->nt + BIN_THREADS / 64) + sizeof(uint32_t) * (2 * BIN_ITEMS * (BIN_THREADS / 64) * 8 + 8);
             hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                               (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tilesum, h->tilesum2, h->nt, h->seg_lt, h->seg_gidx,
-                               h->perm, h->seg_cnt, h->blockmax, h->nb, h->scal);
+                               (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tilesum, h->tilesum2, h->nt, h->guide, h->seg_lt,
+                               h->seg_row, h->perm, h->seg_cnt, h->blockmax, h->nb, h->scal);
             const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
-            hipLaunchKernelGGL(k_resolve_bins<0>, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, d, h->nchunks, h->seg_lt, h->seg_gidx,
-                               h->seg_cnt, h->cx, h->guide, h->x[h->cur], h->res_x, h->res_stride, h->res_parent);
+            hipLaunchKernelGGL(k_resolve_bins<0>, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, d, h->nchunks, h->seg_lt, h->seg_row,
+                               h->seg_cnt, h->cx, h->x[h->cur], h->res_x, h->res_stride, h->res_parent);
             binned = true;
         } else if (scheme == MP_RESAMPLE_SYSTEMATIC)
             hipLaunchKernelGGL((k_resample_gather<0, true>), dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
@@ -1726,7 +1739,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->tilesum2);
     (void)hipFree(h->scal);
     (void)hipFree(h->aos);
-    (void)hipFree(h->seg_lt); (void)hipFree(h->seg_gidx); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
+    (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts);
     if (h->h_counts) (void)hipHostFree(h->h_counts);

@@ -13,28 +13,34 @@ import glob
 import json
 import sys
 
-FAM = {"k_propagate": "propagate", "k_normalize_scan": "normalize_scan", "k_resample_gather": "resample_gather"}
+FAM = {"k_propagate": "propagate", "k_normalize_scan": "normalize_scan", "k_resample_gather": "resample_gather",
+       "k_bin_draws": "resample_gather", "k_resolve_bins": "resample_gather"}  # the resample family = K3a + K3b (or the single-kernel K3)
 STREAMING = {"propagate", "normalize_scan"}
 
 
 def per_kernel(dirname, counter):
+    """mean per launch of each kernel, summed over the kernels of a family (one launch of each per resample)"""
     files = glob.glob(f"{dirname}/*/*_counter_collection.csv")
-    out = collections.defaultdict(list)
+    per = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            for key, fam in FAM.items():
+            for key in FAM:
                 if key in r["Kernel_Name"]:
-                    out[fam].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+                    per[key].append(float(r["Counter_Value"]))
+    out, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for key, v in per.items():
+        out[FAM[key]] += sum(v) / len(v)
+        cnt[FAM[key]] = max(cnt[FAM[key]], len(v))
+    return dict(out), dict(cnt)
 
 
 def main(root):
     fetch, nf = per_kernel(f"{root}/pmc_fetch", "FETCH_SIZE")
     write, nw = per_kernel(f"{root}/pmc_write", "WRITE_SIZE")
     res = {}
-    for fam in FAM.values():
+    for fam in sorted(set(FAM.values())):
         f_raw = fetch.get(fam, 0.0) * 1024.0
         w = write.get(fam, 0.0) * 1024.0
         f_corr = f_raw * 2.0 if fam in STREAMING else f_raw

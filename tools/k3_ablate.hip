@@ -76,9 +76,9 @@ int main(int argc, char** argv) {
         };
         const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
         const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
-        const size_t lds_a = sizeof(u64) * ((size_t)h->nt + BIN_THREADS / 64) + sizeof(uint32_t) * BIN_ITEMS * (BIN_THREADS / 64) * 8;
-        auto k3a = [&] { hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, 1u, 2u, 3u, h->S, h->nchunks, h->tilesum, h->tilesum2, h->nt, h->seg_lt, h->seg_gidx, h->perm, h->seg_cnt, h->blockmax + 1024, 0, h->scal); };
-#define K3B(V) [&] { hipLaunchKernelGGL(k_resolve_bins<V>, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, 1, h->nchunks, h->seg_lt, h->seg_gidx, h->seg_cnt, h->cx, h->guide, h->x[0], h->res_x, h->res_stride, h->res_parent); }
+        const size_t lds_a = sizeof(u64) * ((size_t)h->nt + BIN_THREADS / 64) + sizeof(uint32_t) * (2 * BIN_ITEMS * (BIN_THREADS / 64) * 8 + 8);
+        auto k3a = [&] { hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, 1u, 2u, 3u, h->S, h->nchunks, h->tilesum, h->tilesum2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->blockmax + 1024, 0, h->scal); };
+#define K3B(V) [&] { hipLaunchKernelGGL(k_resolve_bins<V>, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, 1, h->nchunks, h->seg_lt, h->seg_row, h->seg_cnt, h->cx, h->x[0], h->res_x, h->res_stride, h->res_parent); }
         timeit("K3a bin draws", k3a);
         timeit("K3b resolve bins", K3B(0));
         timeit("K3b no result stores", K3B(1));
