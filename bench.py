@@ -25,8 +25,11 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "traffic.json")  # tools/co
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 N_PER_GPU = 1 << 20
 DIM = 1
-# algorithmic bytes per particle per launch (B(d) = 32d + 64 per particle-step)
-BYTES_K = {"propagate": 16 * DIM + 16, "normalize_scan": 8 + 8 + 8, "resample_gather": 8 + 4 + 4 + 16 * DIM + 8}
+# algorithmic bytes per particle per kernel family (B(d) = 32d + 64 per particle-step):
+#   propagate       = propagate+weight (16d+16) and level 0 of the normalisation fused into it (LSE read 8 + normalise/scan 8+8)
+#   normalize_scan  = the standalone form of that level 0 (only launched when the weights changed without a propagate)
+#   resample_gather = search 8+4, gather 4+16d, weight reset 8   (K3a + K3b together)
+BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "resample_gather": 8 + 4 + 4 + 16 * DIM + 8}
 BYTES_STEP = 32 * DIM + 64
 
 
@@ -137,7 +140,8 @@ def main():
         timer.set_timing(False)
 
     if rank == 0:
-        avg_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in fam.items()}
+        # per SMC step: total family time / K (the resample family is two launches per step: K3a + K3b)
+        avg_us = {k: (v[0] / K) * 1e3 for k, v in fam.items()}
         if not any(v[1] for v in fam.values()):
             avg_us = {k: float("nan") for k in fam}
         dom = max(avg_us, key=lambda k: avg_us[k])
@@ -169,6 +173,7 @@ def main():
             "step_bytes_per_particle": BYTES_STEP,
             "step_hbm_frac": BYTES_STEP * n * K / dt / 1e9 / HBM_PEAK_GBPS,
             "kernel_avg_us": avg_us,
+            "kernel_launches_per_step": {k: v[1] / K for k, v in fam.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_launch": BYTES_K[dom] * n},

@@ -122,35 +122,36 @@ int32_t mp_pf_synchronize(mp_pf* h);
 int32_t mp_pf_destroy(mp_pf* h);
 
 /* ---- sharded filter: one process per GPU, particles split into contiguous global-slot ranges ----
- * A handle created with a `shard` {n_global, slot_offset} owns n_particles of n_global slots; Philox is
- * keyed by GLOBAL slot and the fixed-point scale S = 62 - ceil(log2 n_global) is global, so results do not
- * depend on the number of shards.  init_step / step / read_* work unchanged; resample is split into
- * phases with the collectives (RCCL via torch.distributed, or any transport) run by the caller in
- * between.  All pointers in this group are in the handle's memory space (DEVICE pointers for this
- * library), enqueued on the handle's stream:
+ * A handle created with a `shard` {n_global, slot_offset} owns n_particles of n_global slots (equal, tile-aligned
+ * shards: slot_offset and n_particles multiples of 2048).  Philox is keyed by GLOBAL slot and the normalisation is
+ * hierarchical over tiles of 2048 global slots, so results do not depend on the number of shards.
+ * init_step / step / read_* work unchanged; resample is split into phases with the collectives (RCCL via
+ * torch.distributed, or any transport) run by the caller in between.  All pointers in this group are in the handle's
+ * memory space (DEVICE pointers for this library), enqueued on the handle's stream:
  *
- *   shard_local_max   -> [all-reduce MAX of 1 f64]        the "all-reduce of log-weights"
- *   shard_normalize   -> [all-gather of 2 u64 per rank]   shard totals (sum q, sum q^2)
- *   shard_route       -> [all-to-all of u64 requests]     each draw goes to the rank that owns its CDF range
- *   shard_resolve     -> [all-to-all of f64 rows back]    the particle exchange over xGMI
+ *   shard_tiles    -> [all-gather of 24 B per tile]    per-tile max log-weight + fixed-point totals: every rank then
+ *                                                      builds the same tile table (no separate max all-reduce)
+ *   shard_route    -> [all-to-all of request pairs]    each draw goes to the rank that owns its tile
+ *   shard_resolve  -> [all-to-all of f64 rows back]    the particle exchange over xGMI
  *   shard_scatter
  */
-/* max over this shard's log-weights -> d_out[0] */
-int32_t mp_pf_shard_local_max(mp_pf* h, double* d_out);
-/* fixed-point normalisation against the GLOBAL max; d_totals_out[0] = sum q, [1] = sum q^2 of this shard */
-int32_t mp_pf_shard_normalize(mp_pf* h, const double* d_global_max, uint64_t* d_totals_out);
-/* Draw this shard's n targets, find their owner ranks from the gathered totals d_totals_all[world][2], and pack the
- * shard-local targets grouped by owner (stable) into d_req_out[n].  send_counts[world] (HOST, synchronises) = requests per owner. */
-int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const uint64_t* d_totals_all, int32_t world, int32_t rank, uint64_t* d_req_out,
-                          int64_t* send_counts);
-/* Owner side: resolve n_req shard-local targets to parents; d_rows_out[n_req][dim_state + 1] = parent state, then the
+/* level 0 of the normalisation of this shard: d_tile_m / d_tile_W / d_tile_W2 [n_particles / 2048 (rounded up)] */
+int32_t mp_pf_shard_tiles(mp_pf* h, double* d_tile_m, uint64_t* d_tile_W, uint64_t* d_tile_W2);
+/* Draw this shard's n targets against the gathered tiles of ALL ranks (rank-major, world * tiles-per-shard entries each),
+ * find tile and owner, and pack the requests grouped by owner (stable): d_req_out[n][2] = {tile inside the owner's
+ * shard, tile-local target}.  send_counts[world] (HOST, synchronises) = requests per owner.  Also folds the global log
+ * total weight into the log-ML estimate. */
+int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const double* d_tile_m_all, const uint64_t* d_tile_W_all, const uint64_t* d_tile_W2_all,
+                          int32_t world, int32_t rank, uint64_t* d_req_out, int64_t* send_counts);
+/* Owner side: resolve n_req request pairs to parents; d_rows_out[n_req][dim_state + 1] = parent state, then the
  * parent's global slot id as a double. */
 int32_t mp_pf_shard_resolve(mp_pf* h, const uint64_t* d_req_in, uint64_t n_req, double* d_rows_out);
-/* Requester side: rows (in the order the requests were packed) -> new states / parents; log-weights = 0; folds the
- * global log total weight into the log-ML estimate; returns it through log_total_weight if non-NULL (synchronises). */
+/* Requester side: rows (in the order the requests were packed) -> new states / parents; log-weights = 0; returns the
+ * global log total weight through log_total_weight if non-NULL (synchronises). */
 int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total_weight);
-/* log_marginal_likelihood_estimate / fresh ESS of the whole job from gathered totals (after shard_normalize). */
-int32_t mp_pf_shard_query(mp_pf* h, const uint64_t* d_totals_all, int32_t world, double* log_ml, double* ess);
+/* log_marginal_likelihood_estimate / fresh ESS of the whole job from the gathered tiles (after shard_tiles). */
+int32_t mp_pf_shard_query(mp_pf* h, const double* d_tile_m_all, const uint64_t* d_tile_W_all, const uint64_t* d_tile_W2_all, int32_t world,
+                          double* log_ml, double* ess);
 
 /* ---- profiling hooks (bench.py: HIP-event timing on the stream the kernels run on) ------ */
 /* Accumulated GPU time (ms) and launch count of kernel family `which` since the last reset,

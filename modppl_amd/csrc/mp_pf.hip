@@ -2,28 +2,28 @@
 // (include/modppl_hip.h).  Written for MI355X only: 64-lane wavefronts, LDS-staged reductions,
 // SoA particle state in HBM.
 //
-// Data layout in HBM (per handle, n = local particles, d = dim_state):
-//   x[2][d][n]  f64   particle states, double-buffered (resample gathers from one into the other)
+// Data layout in HBM (per handle, n = local particles, d = dim_state, tiles of 2048 rows):
+//   x[2][d][n]  f64   particle states (slot order)
 //   logw[n]     f64   log-weights                              (particle_filter.rs:15)
-//   cx[n]       {u64,f64}  resampling table rows: tile-local inclusive prefix sum of the fixed-point weights + x[0]
+//   cx[n]       {u64,f64}  resampling table rows: tile-local inclusive prefix of the fixed-point weights + x[0]
 //   guide[nt][2048] u16  per-tile bucketed inverse CDF (first row of each bucket)
+//   tile_m/W/W2[nt]      per-tile max log-weight and fixed-point totals (level 0 of the normalisation)
+//   seg_lt/seg_row/perm/res_x/res_parent  the XCD-binned resampler's segments and segment-ordered results
 //   parent[n]   u32   parents of the last resample             (particle_filter.rs:20)
-//   blockmax[]  f64   per-workgroup maxima of logw (written by every kernel that changes logw)
-//   tilesum[], tilesum2[] u64  per-tile totals of q and q^2-weights
 //   scal        mp_dev_scalars   log_ml_estimate, last log total weight, ESS ... (device-resident so
 //                                that a whole filter run needs no host round trip)
 //
-// Kernels (one Unfold step + resample = K1, K2, K3; no inter-workgroup communication inside a
-// launch, so nothing depends on dispatch order or XCD placement):
-//   K1 k_propagate        ParticleSystem::init_step/step  : per particle run the model kernel in
-//                         Generate mode, logw (+)= weight, per-workgroup max          [16d+16 B/particle]
-//   K2 k_normalize_scan   normalize_weights (:27-35) as an order-free fixed-point CDF: m = max,
-//                         q = rint(exp(lw-m) * 2^S), tile-local inclusive scan, tile totals [8+8 B]
-//   K3 k_resample_gather  multinomial_resampling + the clone loop of resample (:37-41,:109-114):
-//                         LDS scan of tile totals, Philox draw, two-level binary search, gather
-//                         x[parent], logw = 0; workgroup 0 also folds L into log_ml  [8+4+4+16d+8 B]
-// Fixed point: S = 62 - ceil(log2 N_global); integer sums are associative, so any reduction order
-// gives the same bits (DESIGN.md §4 states the spec; oracle/src/inference.hpp restates it on the CPU).
+// Kernels of one SMC time step (no inter-workgroup communication inside a launch, so nothing depends on
+// dispatch order or XCD placement; all cross-workgroup sums are integer):
+//   K1  k_propagate       ParticleSystem::init_step/step: one workgroup per 2048-row tile runs the model kernel in
+//                         Generate mode (logw (+)= weight) and, in the same pass, level 0 of normalize_weights
+//                         (:27-35): tile max, exp, 51-bit fixed point, tile-local scan, rows, guide
+//   K3a k_bin_draws       multinomial_resampling (:37-41), part 1: tile table (level 1), Philox draw, target,
+//                         tile + guide lookup, stable split of the draws into 8 CDF-eighth bins
+//   K3b k_resolve_bins    part 2 + the clone loop of resample (:109-114): row lookups per bin on one XCD
+//   (K3 k_resample_gather single-kernel form: importance_resampling's M draws and systematic resampling)
+// The normalisation spec (hierarchical fixed point) is stated in DESIGN.md §4 and restated on the CPU in
+// oracle/src/inference.hpp.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -58,37 +58,40 @@ int32_t mp_set_error(int32_t code, const std::string& msg) { return mp_fail(code
 // device scalars
 // ---------------------------------------------------------------------------------------------
 struct mp_dev_scalars {
-    double m;          // max log-weight seen by the last K2
+    double m;          // global max log-weight of the last level-1 combine
     double L;          // log total weight of the last resample (resample()'s return value)
     double log_ml;     // log_ml_estimate (particle_filter.rs:24)
     double ess_stale;  // ESS of the weights normalised by the last resample (:98-100 semantics)
-    double ess_fresh;  // outputs of the query path (k_lse_finalize)
+    double ess_fresh;  // outputs of the query path (k_finalize_tiles mode 1)
     double lml_fresh;
     u64 Q, Q2;
     int degenerate;    // sticky: all log-weights were -inf (or +inf) at a normalisation
     int pad;
 };
 
-constexpr int K1_THREADS = 256;
-// particles per lane in k_propagate: 4 pre-drawn (u, r) pairs per lane whatever the model's number of normal sites
-template <class Model>
-constexpr int k1_items() { return Model::MAX_NORMALS >= 4 ? 1 : 4 / Model::MAX_NORMALS; }
-constexpr int K1_MAX_BLOCKS = 2048;
-constexpr int SCAN_THREADS = 512;
-constexpr int SCAN_ITEMS = 4;
-constexpr int TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 particles per scan tile
-constexpr int BIN_CHUNK = 1024;       // output slots per chunk of the binned resampler
+constexpr int TILE_THREADS = 512;
+constexpr int TILE_ITEMS = 4;
+constexpr int TILE = TILE_THREADS * TILE_ITEMS;  // 2048 rows per tile: a constant of the normalisation spec
+constexpr int GUIDE_BITS = 11;                   // one guide bucket per table row (GUIDE_N == TILE): 2 B per particle
+constexpr int GUIDE_N = 1 << GUIDE_BITS;
+static_assert(GUIDE_N == TILE, "normalize_tile zeroes/stores the guide with one 8-byte word per thread");
+constexpr int GUIDE_DIRECT = 8;                  // bucket runs longer than this are filled by the whole wave
+constexpr int FIX_BITS = 51;                     // level-0 fixed point: q = rint(exp(lw - m_tile) * 2^51), 2048 * 2^51 < 2^63
+constexpr int BIN_CHUNK = 1024;                  // output slots per chunk of the binned resampler
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_ITEMS = BIN_CHUNK / BIN_THREADS;
-constexpr int BIN_GROUP = 8;          // chunks per k_resolve_bins workgroup
+constexpr int BIN_GROUP = 8;                     // chunks per k_resolve_bins workgroup
 // Position of entry e of segment (bin, chunk) in the sparse segment arrays [bin][chunk][1024].  Only ~128 entries of
-// each 1024-entry window are used; rotating the start by (chunk % 8) * 128 spreads the used parts over all memory
-// channels instead of the ones the first eighth of every 8 KB window maps to.
+// each 1024-entry window are used; the start is rotated by (chunk % 8) * 128 so the used parts spread over the address space.
 #define MP_SEG_POS(bin, c, e, nchunks) ((((u64)(bin) * (u64)(nchunks) + (u64)(c)) * BIN_CHUNK) + (u64)((((uint32_t)(e)) + (((uint32_t)(c)) & 7u) * 128u) & 1023u))
 constexpr int K3_THREADS = 256;
 constexpr int K3_ITEMS = 4;
 constexpr int K3_MAX_BLOCKS = 4096;
-constexpr int MAX_TILES = 8192;                  // LDS prefix of tile totals: 64 KiB
+constexpr int MAX_TILES = 8192;                  // LDS tile table: 16 B per tile
+
+// particles per predraw round in k_propagate: 4 pre-drawn (u, r) pairs per lane whatever the model's number of normal sites
+template <class Model>
+constexpr int k1_items() { return Model::MAX_NORMALS >= 4 ? 1 : 4 / Model::MAX_NORMALS; }
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -109,38 +112,190 @@ __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
     }
     return v;
 }
+__device__ __forceinline__ u64 mp_quantize(double e, double scale) {
+    const double r = rint(e * scale);
+    return (r >= 0.) ? (u64)r : 0ull;  // NaN -> 0
+}
+
+// One row of the resampling table: tile-local inclusive fixed-point CDF value and the first state
+// component of the same particle, so that the probe that finds a parent also fetches its state.
+struct __attribute__((aligned(16))) mp_cx {
+    u64 cum;
+    double x0;
+};
+
+// Guide table (bucketed inverse CDF, per tile): bucket g covers tile-local targets t with
+// (t >> shift) == g, shift = max(0, bitlen(W) - 11) for the tile total W; guide[g] = first local
+// index j with cum_j >= max(1, g << shift).  A draw then starts its scan at guide[t >> shift]
+// and walks forward (expected < 2 rows).  Integer shifts only: no rounding anywhere.
+__device__ __forceinline__ int mp_guide_shift(u64 W) {
+    const int bits = 64 - __clzll((long long)W);  // W == 0 -> clz = 64 -> bits = 0
+    return bits > GUIDE_BITS ? bits - GUIDE_BITS : 0;
+}
 
 // ---------------------------------------------------------------------------------------------
-// K1: propagate + weight + per-workgroup max
+// level 0 of the normalisation for ONE tile, by the workgroup (TILE_THREADS threads) that owns it.
+// Thread t holds rows tile*2048 + 4t .. 4t+3: log-weights lw[] and first state components xv[].
+//   m_b = max lw;  a = mp_exp(lw - m_b);  q = rint(a * 2^51);  rows = tile-local inclusive prefix;  W_b, W2_b;  guide.
 // ---------------------------------------------------------------------------------------------
-// Each lane owns K1_ITEMS particles (slots base + p*K1_THREADS + tid: coalesced per p).
-// Phase 1 runs every polar rejection loop of the lane as ONE lane-local work queue over its
-// (particle, normal site) items: a wave iterates max-over-lanes of the SUM of attempts instead of
-// the sum over items of the max, i.e. ~1.9 Philox blocks per item at 4 items instead of ~3.6
-// (acceptance pi/4, 64 lanes).  Phase 2 runs the model kernel per particle on the accepted pairs.
+__device__ __forceinline__ void normalize_tile(const double (&lw)[TILE_ITEMS], const double (&xv)[TILE_ITEMS], u64 n, u64 tile,
+                                               mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
+                                               double* __restrict__ tile_m, u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
+    __shared__ double s_red[TILE_THREADS / 64];
+    __shared__ u64 s_wsum[TILE_THREADS / 64];
+    __shared__ u64 s_wsum2[TILE_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) unsigned short s_guide[GUIDE_N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = tile * TILE + (u64)tid * TILE_ITEMS;
+
+    double m = MP_NEG_INF;
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j)
+        if (base + j < n) m = fmax(m, lw[j]);
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    reinterpret_cast<u64*>(s_guide)[tid] = 0ull;  // TILE_THREADS x 8 B = the whole guide
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < TILE_THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+
+    const double scale = mp_u2f((u64)(1023 + FIX_BITS) << 52);  // 2^51
+    u64 c[TILE_ITEMS];
+    u64 run = 0, run2 = 0;
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j) {
+        const bool live = ok && (base + j < n);
+        const double a = live ? mp_exp(lw[j] - m) : 0.;
+        run += mp_quantize(a, scale);
+        run2 += mp_quantize(a * a, scale);
+        c[j] = run;
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    const u64 wtot2 = wave_sum_u64(run2);
+    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) s_wsum2[wave] = wtot2;
+    __syncthreads();
+    u64 woff = 0, W = 0;
+#pragma unroll
+    for (int k = 0; k < TILE_THREADS / 64; ++k) {
+        const u64 v = s_wsum[k];
+        if (k < wave) woff += v;
+        W += v;
+    }
+    const u64 off = woff + (incl - run);
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j) {
+        if (base + j < n) {
+            mp_cx row;
+            row.cum = off + c[j];
+            row.x0 = xv[j];
+            cx[base + j] = row;
+        }
+    }
+    if (tid == 0) {
+        u64 t2 = 0;
+#pragma unroll
+        for (int k = 0; k < TILE_THREADS / 64; ++k) t2 += s_wsum2[k];
+        tile_m[tile] = m;
+        tile_W[tile] = W;
+        tile_W2[tile] = t2;
+    }
+
+    // ---- guide table of this tile ------------------------------------------------------------
+    const int shift = mp_guide_shift(W);
+    u64 prev = off;
+    int long_lo = 0, long_hi = -1, long_j = 0;  // at most one long run is kept per thread; extra ones fall back to direct writes
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j) {
+        const u64 cur = off + c[j];
+        if (cur > prev) {
+            const int g_lo = prev ? (int)(prev >> shift) + 1 : 0;
+            const int g_hi = (int)(cur >> shift);
+            const unsigned short idx = (unsigned short)(tid * TILE_ITEMS + j);
+            if (g_hi - g_lo < GUIDE_DIRECT || long_hi >= long_lo) {
+                for (int g = g_lo; g <= g_hi; ++g) s_guide[g] = idx;
+            } else {
+                long_lo = g_lo; long_hi = g_hi; long_j = idx;
+            }
+        }
+        prev = cur;
+    }
+    // wave-cooperative fill of long runs (a particle holding a large share of the tile's weight)
+    u64 pending = __ballot(long_hi >= long_lo);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int lo = __shfl(long_lo, leader, 64), hi = __shfl(long_hi, leader, 64), jj = __shfl(long_j, leader, 64);
+        for (int g = lo + lane; g <= hi; g += 64) s_guide[g] = (unsigned short)jj;
+        pending &= pending - 1;
+    }
+    __syncthreads();
+    reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
+}
+
+// standalone form: used when the log-weights changed without a propagate (after a resample, before a query or a
+// second resample)
+__global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* __restrict__ logw, const double* __restrict__ x0, u64 n,
+                                                                  mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
+                                                                  double* __restrict__ tile_m, u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
+    const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * TILE_ITEMS;
+    double lw[TILE_ITEMS], xv[TILE_ITEMS];
+    if (base + TILE_ITEMS <= n) {
+        const double2 a = *reinterpret_cast<const double2*>(logw + base);
+        const double2 b = *reinterpret_cast<const double2*>(logw + base + 2);
+        lw[0] = a.x; lw[1] = a.y; lw[2] = b.x; lw[3] = b.y;
+        const double2 xa = *reinterpret_cast<const double2*>(x0 + base);
+        const double2 xb = *reinterpret_cast<const double2*>(x0 + base + 2);
+        xv[0] = xa.x; xv[1] = xa.y; xv[2] = xb.x; xv[3] = xb.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < TILE_ITEMS; ++j) {
+            lw[j] = (base + j < n) ? logw[base + j] : MP_NEG_INF;
+            xv[j] = (base + j < n) ? x0[base + j] : 0.;
+        }
+    }
+    normalize_tile(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: propagate + weight + level 0 of the normalisation, one workgroup per tile
+// ---------------------------------------------------------------------------------------------
+// A lane owns the 4 consecutive particles 4*tid .. 4*tid+3 of its tile, processed in rounds of k1_items<Model>()
+// particles.  Per round, phase 1 runs every polar rejection loop of the lane as ONE lane-local work queue over its
+// (particle, normal site) items: a wave iterates max-over-lanes of the SUM of attempts instead of the sum over
+// items of the max, i.e. ~1.9 Philox blocks per item at 4 items instead of ~3.6 (acceptance pi/4, 64 lanes).
+// Phase 2 runs the model kernel per particle on the accepted pairs.
 template <class Model>
-__global__ __launch_bounds__(K1_THREADS) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
-                                                          long long t, const double* x_in, double* x_out, double* logw,
-                                                          mp_obs obs, mp_state0 s0, int overwrite, double* __restrict__ blockmax,
-                                                          const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
-                                                          u64 res_stride, int nchunks) {
+__global__ __launch_bounds__(TILE_THREADS) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
+                                                            long long t, const double* x_in, double* x_out, double* logw,
+                                                            mp_obs obs, mp_state0 s0, int overwrite,
+                                                            const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
+                                                            u64 res_stride, int nchunks, mp_cx* __restrict__ cx,
+                                                            unsigned short* __restrict__ guide, double* __restrict__ tile_m,
+                                                            u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
-    constexpr int K1_ITEMS = k1_items<Model>();
-    constexpr int M = K1_ITEMS * NS;
-    double lmax = MP_NEG_INF;
+    constexpr int ITEMS = k1_items<Model>();
+    constexpr int ROUNDS = TILE_ITEMS / ITEMS;
+    constexpr int M = ITEMS * NS;
     const int ns = model.n_normals(t);  // wave-uniform
-    for (u64 i0 = (u64)blockIdx.x * (K1_THREADS * K1_ITEMS) + threadIdx.x; i0 < n; i0 += (u64)gridDim.x * (K1_THREADS * K1_ITEMS)) {
-        // ---- phase 1: accepted (u, r) pairs for every (particle, normal site) of this lane ----
+    const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * TILE_ITEMS;
+    double lw[TILE_ITEMS], xv[TILE_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j) { lw[j] = MP_NEG_INF; xv[j] = 0.; }
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const u64 i0 = base + (u64)rd * ITEMS;
+        // ---- phase 1: accepted (u, r) pairs for every (particle, normal site) of this round ----
         double pu[M], pr[M];
 #pragma unroll
         for (int q = 0; q < M; ++q) { pu[q] = 0.; pr[q] = 1.; }
         {
-            int p = 0, sidx = 0;         // current item: particle p, normal site index sidx
+            int p = 0, sidx = 0;  // current item: particle p of the round, normal site index sidx
             uint32_t att = 0;
-            // skip particles past the end
-            while (p < K1_ITEMS && ns > 0) {
-                const u64 i = i0 + (u64)p * K1_THREADS;
+            while (p < ITEMS && ns > 0) {
+                const u64 i = i0 + (u64)p;
                 if (i >= n) break;
                 const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
                                                     ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
@@ -163,15 +318,15 @@ __global__ __launch_bounds__(K1_THREADS) void k_propagate(Model model, u64 n, u6
         }
         // ---- phase 2: the model kernel in Generate mode --------------------------------------
 #pragma unroll
-        for (int p = 0; p < K1_ITEMS; ++p) {
-            const u64 i = i0 + (u64)p * K1_THREADS;
+        for (int p = 0; p < ITEMS; ++p) {
+            const u64 i = i0 + (u64)p;
             if (i < n) {
                 double prev[D], next[D];
                 if (perm) {
                     // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at
                     // segment (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i]
-                    const uint32_t pr = perm[i];
-                    const u64 pos = MP_SEG_POS(pr >> 10, i >> 10, pr & 1023u, nchunks);
+                    const uint32_t pr_ = perm[i];
+                    const u64 pos = MP_SEG_POS(pr_ >> 10, i >> 10, pr_ & 1023u, nchunks);
 #pragma unroll
                     for (int d = 0; d < D; ++d) prev[d] = res_x[(u64)d * res_stride + pos];
                 } else {
@@ -188,182 +343,46 @@ __global__ __launch_bounds__(K1_THREADS) void k_propagate(Model model, u64 n, u6
                 // be all zero after a resample (log_weights.fill(0.), :114) and are not re-read
                 const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
                 logw[i] = w;
-                lmax = fmax(lmax, w);
+                lw[rd * ITEMS + p] = w;
+                xv[rd * ITEMS + p] = next[0];
             }
         }
     }
-    __shared__ double s_max[K1_THREADS / 64];
-    lmax = wave_max(lmax);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_max[wave] = lmax;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double m = s_max[0];
-#pragma unroll
-        for (int w = 1; w < K1_THREADS / 64; ++w) m = fmax(m, s_max[w]);
-        blockmax[blockIdx.x] = m;
-    }
+    // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----
+    normalize_tile(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: fixed-point normalisation + tile-local inclusive scan
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 mp_quantize(double e, double scale) {
-    const double r = rint(e * scale);
-    return (r >= 0.) ? (u64)r : 0ull;  // NaN -> 0
-}
-
-// One row of the resampling table: tile-local inclusive fixed-point CDF value and the first state
-// component of the same particle, so that the probe that finds a parent also fetches its state.
-struct __attribute__((aligned(16))) mp_cx {
-    u64 cum;
-    double x0;
-};
-constexpr int GUIDE_BITS = 11;              // one guide bucket per table row (GUIDE_N == TILE): 2 B per particle
-constexpr int GUIDE_N = 1 << GUIDE_BITS;
-static_assert(GUIDE_N == TILE, "k_normalize_scan zeroes/stores the guide with one 8-byte word per thread");
-constexpr int GUIDE_DIRECT = 8;             // bucket runs longer than this are filled by the whole wave
-
-// Guide table (bucketed inverse CDF, per tile): bucket g covers tile-local targets t with
-// (t >> shift) == g, shift = max(0, bitlen(W) - 11) for the tile total W; guide[g] = first local
-// index j with cum_j >= max(1, g << shift).  A draw then starts its scan at guide[t >> shift]
-// and walks forward (expected < 2 rows).  Integer shifts only: no rounding anywhere.
-__device__ __forceinline__ int mp_guide_shift(u64 W) {
-    const int bits = 64 - __clzll((long long)W);  // W == 0 -> clz = 64 -> bits = 0
-    return bits > GUIDE_BITS ? bits - GUIDE_BITS : 0;
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_normalize_scan(const double* __restrict__ logw, const double* __restrict__ x0, u64 n,
-                                                                 const double* __restrict__ blockmax, int nb, int S,
-                                                                 mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
-                                                                 u64* __restrict__ tilesum, u64* __restrict__ tilesum2,
-                                                                 mp_dev_scalars* scal) {
-    __shared__ double s_red[SCAN_THREADS / 64];
-    __shared__ u64 s_wsum[SCAN_THREADS / 64];
-    __shared__ u64 s_wsum2[SCAN_THREADS / 64];
-    __shared__ __attribute__((aligned(16))) unsigned short s_guide[GUIDE_N];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // issue the tile's loads first: they overlap the max reduction below
-    const double scale = mp_u2f((u64)(1023 + S) << 52);  // 2^S
-    const u64 base = (u64)blockIdx.x * TILE + (u64)tid * SCAN_ITEMS;
-    const bool full = base + SCAN_ITEMS <= n;
-    double w[SCAN_ITEMS], xv[SCAN_ITEMS];
-    if (full) {
-        const double2 a = *reinterpret_cast<const double2*>(logw + base);
-        const double2 b = *reinterpret_cast<const double2*>(logw + base + 2);
-        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
-        const double2 xa = *reinterpret_cast<const double2*>(x0 + base);
-        const double2 xb = *reinterpret_cast<const double2*>(x0 + base + 2);
-        xv[0] = xa.x; xv[1] = xa.y; xv[2] = xb.x; xv[3] = xb.y;
-    } else {
-#pragma unroll
-        for (int j = 0; j < SCAN_ITEMS; ++j) {
-            w[j] = (base + j < n) ? logw[base + j] : MP_NEG_INF;
-            xv[j] = (base + j < n) ? x0[base + j] : 0.;
-        }
-    }
-    // m = max over the per-workgroup maxima (exact in any order)
-    double m = MP_NEG_INF;
-    for (int j = tid; j < nb; j += SCAN_THREADS) m = fmax(m, blockmax[j]);
-    m = wave_max(m);
-    if (lane == 0) s_red[wave] = m;
-    reinterpret_cast<u64*>(s_guide)[tid] = 0ull;  // SCAN_THREADS x 8 B = the whole guide
-    __syncthreads();
-    m = s_red[0];
-#pragma unroll
-    for (int w = 1; w < SCAN_THREADS / 64; ++w) m = fmax(m, s_red[w]);
-    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
-    if (blockIdx.x == 0 && tid == 0) {
-        scal->m = m;
-        if (!ok) scal->degenerate = 1;
-    }
-
-    u64 c[SCAN_ITEMS];
-    u64 run = 0, run2 = 0;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        const bool live = ok && (base + j < n);
-        const double e = live ? mp_exp(w[j] - m) : 0.;
-        run += mp_quantize(e, scale);
-        run2 += mp_quantize(e * e, scale);
-        c[j] = run;
-    }
-    const u64 incl = wave_incl_scan_u64(run, lane);
-    const u64 wtot2 = wave_sum_u64(run2);
-    if (lane == 63) s_wsum[wave] = incl;
-    if (lane == 0) s_wsum2[wave] = wtot2;
-    __syncthreads();
-    u64 woff = 0, W = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_THREADS / 64; ++k) {
-        const u64 v = s_wsum[k];
-        if (k < wave) woff += v;
-        W += v;
-    }
-    const u64 off = woff + (incl - run);
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        if (base + j < n) {
-            mp_cx row;
-            row.cum = off + c[j];
-            row.x0 = xv[j];
-            cx[base + j] = row;
-        }
-    }
-    if (tid == 0) {
-        tilesum[blockIdx.x] = W;
-        u64 t2 = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_THREADS / 64; ++k) t2 += s_wsum2[k];
-        tilesum2[blockIdx.x] = t2;
-    }
-
-    // ---- guide table of this tile ------------------------------------------------------------
-    const int shift = mp_guide_shift(W);
-    u64 prev = off;
-    int long_lo = 0, long_hi = -1, long_j = 0;  // at most one long run is kept per thread; extra ones fall back to direct writes
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        const u64 cur = off + c[j];
-        if (cur > prev) {
-            const int g_lo = prev ? (int)(prev >> shift) + 1 : 0;
-            const int g_hi = (int)(cur >> shift);
-            const unsigned short idx = (unsigned short)(tid * SCAN_ITEMS + j);
-            if (g_hi - g_lo < GUIDE_DIRECT || long_hi >= long_lo) {
-                for (int g = g_lo; g <= g_hi; ++g) s_guide[g] = idx;
-            } else {
-                long_lo = g_lo; long_hi = g_hi; long_j = idx;
-            }
-        }
-        prev = cur;
-    }
-    // wave-cooperative fill of long runs (a particle holding a large share of the tile's weight)
-    u64 pending = __ballot(long_hi >= long_lo);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int lo = __shfl(long_lo, leader, 64), hi = __shfl(long_hi, leader, 64), jj = __shfl(long_j, leader, 64);
-        for (int g = lo + lane; g <= hi; g += 64) s_guide[g] = (unsigned short)jj;
-        pending &= pending - 1;
-    }
-    __syncthreads();
-    reinterpret_cast<u64*>(guide + (u64)blockIdx.x * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
-}
-
-// ---------------------------------------------------------------------------------------------
-// shared helper: workgroup-wide inclusive scan of nt (<= MAX_TILES) u64 values into LDS
+// level 1: the tile table of a workgroup.  T_b = rint((double)W_b * mp_exp(m_b - m) * 2^(S-51)), inclusive prefix in
+// s_incl[nt], W_b in s_W[nt]; returns the global max m (every thread).  s_red needs THREADS/64 doubles, s_wtot
+// THREADS/64 u64.
 // ---------------------------------------------------------------------------------------------
 template <int THREADS>
-__device__ __forceinline__ void block_scan_tiles(const u64* __restrict__ tilesum, int nt, u64* s_incl, u64* s_wtot) {
+__device__ __forceinline__ double block_tile_table(const double* __restrict__ tile_m, const u64* __restrict__ tile_W, int nt, int S,
+                                                   u64* s_incl, u64* s_W, double* s_red, u64* s_wtot) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (nt + THREADS - 1) / THREADS;
     const int b0 = tid * per;
+    double m = MP_NEG_INF;
+    for (int j = 0; j < per; ++j)
+        if (b0 + j < nt) m = fmax(m, tile_m[b0 + j]);
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);  // 2^(S-51)
     u64 run = 0;
     for (int j = 0; j < per; ++j) {
         const int idx = b0 + j;
         if (idx < nt) {
-            run += tilesum[idx];
+            const u64 W = tile_W[idx];
+            const double f = ok ? mp_exp(tile_m[idx] - m) : 0.;
+            run += mp_quantize((double)W * f * sc, 1.0);
             s_incl[idx] = run;
+            s_W[idx] = W;
         }
     }
     const u64 incl = wave_incl_scan_u64(run, lane);
@@ -377,13 +396,60 @@ __device__ __forceinline__ void block_scan_tiles(const u64* __restrict__ tilesum
         if (idx < nt) s_incl[idx] += off;
     }
     __syncthreads();
+    return m;
 }
-
+// tile-local target of residual r in (0, T] of a tile with totals (W, T):
+// lt = clamp((u64)ceil((double)r * ((double)W / (double)T)), 1, W)
+__device__ __forceinline__ u64 mp_local_target(u64 r, u64 W, u64 T) {
+    const double ratio = (double)W / (double)T;
+    const double v = ceil((double)r * ratio);
+    u64 x = (v >= 1.) ? (u64)v : 1ull;
+    if (x > W) x = W;
+    if (x < 1ull) x = 1ull;
+    return x;
+}
+// Q2 = sum_b rint((double)W2_b * mp_exp(2 (m_b - m)) * 2^(S-51)) by one workgroup; result valid in thread 0
+template <int THREADS>
+__device__ __forceinline__ u64 block_sum_T2(const double* __restrict__ tile_m, const u64* __restrict__ tile_W2, int nt, int S, double m, u64* s_wtot) {
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
+    u64 q2 = 0;
+    for (int j = threadIdx.x; j < nt; j += THREADS) {
+        const double f2 = ok ? mp_exp(2. * (tile_m[j] - m)) : 0.;
+        q2 += mp_quantize((double)tile_W2[j] * f2 * sc, 1.0);
+    }
+    q2 = wave_sum_u64(q2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_wtot[threadIdx.x >> 6] = q2;
+    __syncthreads();
+    u64 Q2 = 0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < THREADS / 64; ++k) Q2 += s_wtot[k];
+    return Q2;
+}
 __device__ __forceinline__ void finalize_scalars(u64 Q, u64 Q2, int S, double* L_out, double* ess_out, double m) {
     const double inv = mp_u2f((u64)(1023 - S) << 52);  // 2^-S
     const double Qs = (double)Q * inv, Q2s = (double)Q2 * inv;
     *L_out = m + mp_log(Qs);
     *ess_out = (Qs * Qs) / Q2s;
+}
+// thread 0 of a workgroup that has the tile table folds a normalisation into the filter scalars
+__device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2, int S, double m, u64 n_global, int mode) {
+    double L, ess;
+    finalize_scalars(Q, Q2, S, &L, &ess, m);
+    scal->m = m;
+    if (!(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0) scal->degenerate = 1;
+    if (mode == 0) {  // resample (particle_filter.rs:104-105)
+        scal->L = L;
+        scal->ess_stale = ess;
+        scal->Q = Q;
+        scal->Q2 = Q2;
+        scal->log_ml += L - mp_log((double)n_global);
+    } else {          // query (particle_filter.rs:119-121; fresh ESS)
+        scal->L = L;
+        scal->ess_fresh = ess;
+        scal->lml_fresh = scal->log_ml + L - mp_log((double)n_global);
+    }
 }
 
 __device__ __forceinline__ mp_cx load_row_nt(const mp_cx* p) {
@@ -429,71 +495,57 @@ __device__ __forceinline__ uint32_t mp_systematic_k32(uint32_t rc, uint32_t k0, 
     return (uint32_t)(r.a >> 32);
 }
 
-// first index in [0, len) with a[idx] >= target (len if none)
-template <class Ptr>
-__device__ __forceinline__ uint32_t lower_bound_u64(Ptr a, uint32_t len, u64 target) {
-    uint32_t lo = 0, hi = len;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a[mid] >= target) hi = mid;
-        else lo = mid + 1;
-    }
-    return lo;
+// Tile of a global target: tile totals are nearly equal (each sums 2048 weights), so target * nt / Q lands within a
+// tile or two of the answer; walk from there.  Same result as a lower_bound over s_incl, fewer LDS reads.
+__device__ __forceinline__ uint32_t tile_of_target(const u64* s_incl, uint32_t nt, u64 target, double nt_over_Q) {
+    int b = (int)((double)target * nt_over_Q);
+    if (b > (int)nt - 1) b = (int)nt - 1;
+    if (b < 0) b = 0;
+    while (b > 0 && s_incl[b - 1] >= target) --b;          // first b with incl[b] >= target ...
+    while (b < (int)nt - 1 && s_incl[b] < target) ++b;     // ... from either side
+    return (uint32_t)b;
+}
+// global target -> (tile, tile-local target, guide slot)
+__device__ __forceinline__ void mp_locate(const u64* s_incl, const u64* s_W, uint32_t nt, u64 target, double nt_over_Q, uint32_t* tile, u64* lt,
+                                          uint32_t* gslot) {
+    const uint32_t b = tile_of_target(s_incl, nt, target, nt_over_Q);
+    const u64 excl = b ? s_incl[b - 1] : 0ull;
+    const u64 T = s_incl[b] - excl;
+    const u64 W = s_W[b];
+    const u64 x = mp_local_target(target - excl, W, T);
+    uint32_t g = (uint32_t)(x >> mp_guide_shift(W));
+    if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+    *tile = b; *lt = x; *gslot = b * (uint32_t)GUIDE_N + g;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: draw, search, gather, reset
+// K3 (single-kernel form): draw, search, gather, reset.  Used for importance_resampling's M draws (domain IS) and
+// for systematic resampling (sorted parents: coalesced by construction).  n_out draws over a table of n rows.
 // ---------------------------------------------------------------------------------------------
-// ABL > 0 are timing-only ablations used by tools/k3_ablate.hip (1: no global reads, 2: guide only).
-template <int ABL, bool SYSTEMATIC = false>
+template <bool SYSTEMATIC>
 __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out, u64 n_global, u64 slot_offset, uint32_t domain,
-                                                                uint32_t k0, uint32_t k1,
-                                                                uint32_t rc, int S, int D, const mp_cx* __restrict__ cx,
-                                                                const unsigned short* __restrict__ guide,
-                                                                const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2,
-                                                                int nt, const double* __restrict__ x_old, double* __restrict__ x_new,
-                                                                uint32_t* __restrict__ parent, double* __restrict__ logw,
-                                                                double* __restrict__ blockmax, int nb, mp_dev_scalars* scal) {
+                                                                uint32_t k0, uint32_t k1, uint32_t rc, int S, int D,
+                                                                const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                                const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                                const u64* __restrict__ tile_W2, int nt,
+                                                                const double* __restrict__ x_old, double* __restrict__ x_new,
+                                                                uint32_t* __restrict__ parent, double* __restrict__ logw, mp_dev_scalars* scal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* s_incl = reinterpret_cast<u64*>(smem);  // [nt]
-    u64* s_wtot = s_incl + nt;                   // [K3_THREADS/64]
-    if (ABL == 5) {  // timing-only: no tile-total loads / scan
-        for (int jj = threadIdx.x; jj < nt; jj += K3_THREADS) s_incl[jj] = (u64)(jj + 1) << 40;
-        __syncthreads();
-    } else {
-        block_scan_tiles<K3_THREADS>(tilesum, nt, s_incl, s_wtot);
-    }
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt;
+    double* s_red = reinterpret_cast<double*>(s_W + nt);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + K3_THREADS / 64);
+    const double m = block_tile_table<K3_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
     const u64 Q = s_incl[nt - 1];
-
-    if (blockIdx.x == 0 && ABL == 0 && scal != nullptr) {  // workgroup-uniform: fold this normalisation into the filter scalars
-        u64 q2 = 0;
-        for (int j = threadIdx.x; j < nt; j += K3_THREADS) q2 += tilesum2[j];
-        q2 = wave_sum_u64(q2);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) s_wtot[threadIdx.x >> 6] = q2;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            u64 Q2 = 0;
-            for (int k = 0; k < K3_THREADS / 64; ++k) Q2 += s_wtot[k];
-            double L, ess;
-            finalize_scalars(Q, Q2, S, &L, &ess, scal->m);
-            scal->L = L;
-            scal->ess_stale = ess;
-            scal->Q = Q;
-            scal->Q2 = Q2;
-            scal->log_ml += L - mp_log((double)n_global);  // particle_filter.rs:105
-        }
-        for (int j = threadIdx.x; j < nb; j += K3_THREADS) blockmax[j] = 0.;  // logw is 0 after a resample
+    if (blockIdx.x == 0 && scal != nullptr) {  // workgroup-uniform: fold this normalisation into the filter scalars
+        const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+        if (threadIdx.x == 0) fold_scalars(scal, Q, Q2, S, m, n_global, 0);
     }
-
     const uint32_t sys_k32 = SYSTEMATIC ? mp_systematic_k32(rc, k0, k1) : 0u;
-    // Each thread resolves K3_ITEMS draws with independent load chains (Philox -> LDS tile search ->
-    // guide entry -> two table rows), so that K3_ITEMS x 64 cache-line requests per wave are in flight
-    // at every hop instead of 64: the kernel is bound by the latency of these dependent hops.
+    const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
     for (u64 i0 = (u64)blockIdx.x * (K3_THREADS * K3_ITEMS) + threadIdx.x; i0 < n_out; i0 += (u64)gridDim.x * (K3_THREADS * K3_ITEMS)) {
         u64 lt[K3_ITEMS], tbase[K3_ITEMS];
-        uint32_t tlen[K3_ITEMS], j[K3_ITEMS];
-        const unsigned short* gp[K3_ITEMS];
+        uint32_t tlen[K3_ITEMS], j[K3_ITEMS], gslot[K3_ITEMS];
 #pragma unroll
         for (int k = 0; k < K3_ITEMS; ++k) {
             const u64 i = i0 + (u64)k * K3_THREADS;
@@ -501,39 +553,23 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
             if (SYSTEMATIC) {
                 target = mp_target_systematic(slot_offset + (i < n_out ? i : 0), sys_k32, Q, n_global);
             } else {
-                mp_u64x2 r;
-                if (ABL == 3) r.a = (i * 0x9E3779B97F4A7C15ull) ^ ((u64)rc << 20);  // timing-only: no Philox
-                else r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
-                u64 k52 = mp_u52(r.a);
-                if (ABL == 6) k52 = (k52 >> 3) | ((u64)(blockIdx.x & 7u) << 49);  // timing-only: draws confined to the XCD's eighth of the CDF
-                target = mp_target(k52, Q);
+                const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
+                target = mp_target(mp_u52(r.a), Q);
             }
-            uint32_t b = (ABL == 4) ? (uint32_t)((target >> 7) % (u64)nt)  // timing-only: no LDS search
-                                    : lower_bound_u64(s_incl, (uint32_t)nt, target);
-            if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
-            const u64 incl_b = s_incl[b];
-            const u64 excl = b ? s_incl[b - 1] : 0ull;
-            lt[k] = target - excl;                        // tile-local target, 1 <= lt <= W
-            const int shift = mp_guide_shift(incl_b - excl);
+            uint32_t b;
+            mp_locate(s_incl, s_W, (uint32_t)nt, target, nt_over_Q, &b, &lt[k], &gslot[k]);
             tbase[k] = (u64)b * TILE;
             tlen[k] = (uint32_t)((n - tbase[k]) < (u64)TILE ? (n - tbase[k]) : (u64)TILE);
-            uint32_t g = (uint32_t)(lt[k] >> shift);
-            if (g > GUIDE_N - 1) g = GUIDE_N - 1;
-            gp[k] = guide + (u64)b * GUIDE_N + g;
         }
 #pragma unroll
-        for (int k = 0; k < K3_ITEMS; ++k) j[k] = (ABL == 1 || ABL >= 3) ? (uint32_t)(lt[k] & (TILE - 1)) : *gp[k];
+        for (int k = 0; k < K3_ITEMS; ++k) j[k] = guide[gslot[k]];
         mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
 #pragma unroll
         for (int k = 0; k < K3_ITEMS; ++k) {
             if (j[k] > tlen[k] - 1) j[k] = tlen[k] - 1;
             const uint32_t j1 = (j[k] + 1 < tlen[k]) ? j[k] + 1 : j[k];
-            if (ABL == 0) {
-                r0[k] = load_row_nt(cx + tbase[k] + j[k]);   // streamed: must not evict the guide from L2
-                r1[k] = load_row_nt(cx + tbase[k] + j1);
-            } else {
-                r0[k].cum = lt[k]; r0[k].x0 = (double)j[k]; r1[k] = r0[k];
-            }
+            r0[k] = load_row_nt(cx + tbase[k] + j[k]);
+            r1[k] = load_row_nt(cx + tbase[k] + j1);
         }
 #pragma unroll
         for (int k = 0; k < K3_ITEMS; ++k) {
@@ -561,72 +597,44 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
     }
 }
 
-
-// Tile of a global target: tile totals are nearly equal (each sums 2048 weights), so target * nt / Q lands within a
-// tile or two of the answer; walk from there.  Same result as lower_bound_u64(s_incl, nt, target), fewer LDS reads.
-__device__ __forceinline__ uint32_t tile_of_target(const u64* s_incl, uint32_t nt, u64 target, double nt_over_Q) {
-    int b = (int)((double)target * nt_over_Q);
-    if (b > (int)nt - 1) b = (int)nt - 1;
-    if (b < 0) b = 0;
-    while (b > 0 && s_incl[b - 1] >= target) --b;          // first b with incl[b] >= target ...
-    while (b < (int)nt - 1 && s_incl[b] < target) ++b;     // ... from either side
-    return (uint32_t)b;
-}
-
 // ---------------------------------------------------------------------------------------------
 // XCD-binned multinomial resampling (same parents per slot as k_resample_gather, bit for bit)
 // ---------------------------------------------------------------------------------------------
 // The row table (16 B x N) does not fit one XCD's 4 MB L2, so random row reads cross the fabric a full line at a
-// time (profiles/r01/k3_ablation_n2e20.txt).  But the top 3 bits of a draw's uniform say which EIGHTH of the CDF
-// it lands in, and they do not depend on the weights.  So:
-//   K3a k_bin_draws     every chunk of 1024 output slots splits its draws into 8 bins by those bits (stable order):
-//                       segment [bin][chunk][<=1024] of uniforms (sparse addressing, dense traffic) and perm[slot] =
-//                       (bin << 10 | position in its segment).
+// time.  But the top 3 bits of a draw's uniform say which EIGHTH of the CDF it lands in.  So:
+//   K3a k_bin_draws     every chunk of 1024 output slots: tile table, Philox, target, tile, guide lookup (the 2 MB
+//                       guide is L2-resident everywhere), stable split of the chunk's draws into the 8 bins:
+//                       segment [bin][chunk][<=1024] of (tile-local target, start row) and perm[slot] = (bin << 10 | pos).
 //   K3b k_resolve_bins  workgroup (group of 8 chunks, bin b) with blockIdx % 8 == b — workgroups are dealt
-//                       round-robin over the 8 XCDs, so all lookups of bin b run on one XCD whose L2 then holds
+//                       round-robin over the 8 XCDs, so the row lookups of bin b run on one XCD whose L2 then holds
 //                       that eighth of the table (speed only: any placement gives the same result).
-
-// K3a: per draw Philox -> target -> tile (LDS search over the tile totals) -> tile-local target lt and guide slot;
-// stable split of the chunk's draws into the 8 CDF-eighth bins.  No random global access here.
+// Measured (profiles/r01): L2 hit rate 0.58 -> 0.86, fabric traffic 107 -> 52 MB per resample of 2^20, 46 -> 30 us.
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S, int nchunks,
-                                                           const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2, int nt,
+                                                           const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                           const u64* __restrict__ tile_W2, int nt,
                                                            const unsigned short* __restrict__ guide,
                                                            u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row,
                                                            unsigned short* __restrict__ perm, unsigned short* __restrict__ seg_cnt,
-                                                           double* __restrict__ blockmax, int nb, mp_dev_scalars* scal) {
+                                                           mp_dev_scalars* scal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* s_incl = reinterpret_cast<u64*>(smem);                               // [nt]
-    u64* s_wtot = s_incl + nt;                                                // [BIN_THREADS/64]
-    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + BIN_THREADS / 64);  // [BIN_ITEMS][BIN_THREADS/64][8] counts
-    uint32_t* s_woff = s_wcnt + BIN_ITEMS * (BIN_THREADS / 64) * 8;             // same shape: exclusive offsets (+ [8] totals)
-    block_scan_tiles<BIN_THREADS>(tilesum, nt, s_incl, s_wtot);
+    constexpr int NW = BIN_THREADS / 64;
+    u64* s_incl = reinterpret_cast<u64*>(smem);                        // [nt]
+    u64* s_W = s_incl + nt;                                            // [nt]
+    double* s_red = reinterpret_cast<double*>(s_W + nt);               // [NW]
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + NW);                  // [NW]
+    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + NW);       // [BIN_ITEMS][NW][8] counts
+    uint32_t* s_woff = s_wcnt + BIN_ITEMS * NW * 8;                    // same shape: exclusive offsets
+    const double m = block_tile_table<BIN_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
     const u64 Q = s_incl[nt - 1];
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    if (blockIdx.x == 0) {  // fold this normalisation into the filter scalars (as k_resample_gather does)
-        u64 q2 = 0;
-        for (int j = threadIdx.x; j < nt; j += BIN_THREADS) q2 += tilesum2[j];
-        q2 = wave_sum_u64(q2);
-        __syncthreads();
-        if (lane == 0) s_wtot[wave] = q2;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            u64 Q2 = 0;
-            for (int k = 0; k < BIN_THREADS / 64; ++k) Q2 += s_wtot[k];
-            double L, ess;
-            finalize_scalars(Q, Q2, S, &L, &ess, scal->m);
-            scal->L = L;
-            scal->ess_stale = ess;
-            scal->Q = Q;
-            scal->Q2 = Q2;
-            scal->log_ml += L - mp_log((double)n_global);  // particle_filter.rs:105
-        }
-        for (int j = threadIdx.x; j < nb; j += BIN_THREADS) blockmax[j] = 0.;
+    if (blockIdx.x == 0) {  // fold this normalisation into the filter scalars
+        const u64 Q2 = block_sum_T2<BIN_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+        if (threadIdx.x == 0) fold_scalars(scal, Q, Q2, S, m, n_global, 0);
     }
 
     u64 lt[BIN_ITEMS];
-    uint32_t gidx[BIN_ITEMS], tile_of[BIN_ITEMS];
+    uint32_t gslot[BIN_ITEMS], tile_of[BIN_ITEMS];
     int bin[BIN_ITEMS];
     uint32_t rank_in_wave[BIN_ITEMS];
     const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
@@ -635,31 +643,22 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
         const u64 i = (u64)c * BIN_CHUNK + (u64)q * BIN_THREADS + threadIdx.x;
         const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
         const u64 k52 = mp_u52(r.a);
-        const u64 target = mp_target(k52, Q);
-        const uint32_t b = tile_of_target(s_incl, (uint32_t)nt, target, nt_over_Q);
-        const u64 incl_b = s_incl[b];
-        const u64 excl = b ? s_incl[b - 1] : 0ull;
-        lt[q] = target - excl;                           // tile-local target, 1 <= lt <= W
-        uint32_t g = (uint32_t)(lt[q] >> mp_guide_shift(incl_b - excl));
-        if (g > GUIDE_N - 1) g = GUIDE_N - 1;
-        gidx[q] = b * (uint32_t)GUIDE_N + g;
+        mp_locate(s_incl, s_W, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
         bin[q] = (i < n) ? (int)(k52 >> 49) : -1;
-        tile_of[q] = b;
         rank_in_wave[q] = 0;
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) {
             const u64 bal = __ballot(bin[q] == bb);
             if (bin[q] == bb) rank_in_wave[q] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wcnt[(q * (BIN_THREADS / 64) + wave) * 8 + bb] = (uint32_t)__popcll(bal);
+            if (lane == 0) s_wcnt[(q * NW + wave) * 8 + bb] = (uint32_t)__popcll(bal);
         }
     }
-    // the guide lookups go out now (the 2 MB guide is L2-resident on every XCD) and land while the offsets are built
+    // the guide lookups go out now (the guide is L2-resident on every XCD) and land while the offsets are built
     uint32_t j0[BIN_ITEMS];
 #pragma unroll
-    for (int q = 0; q < BIN_ITEMS; ++q) j0[q] = guide[gidx[q]];
+    for (int q = 0; q < BIN_ITEMS; ++q) j0[q] = guide[gslot[q]];
     __syncthreads();
     // exclusive offsets in the stable order: item q-major (slots q*256 .. q*256+255), then wave, then lane == increasing slot
-    constexpr int NW = BIN_THREADS / 64;
     if (threadIdx.x < 8) {
         uint32_t run = 0;
         for (int q = 0; q < BIN_ITEMS; ++q)
@@ -690,8 +689,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
 // segment holds 128 +- 11 entries, so nearly every lane is live and each has 4 independent chains in flight.
 // Results stay in SEGMENT order (res_x[d][bin][chunk][pos], res_parent likewise: coalesced stores); the next
 // k_propagate reads its inputs through perm[], k_unpermute materialises slot order when the host asks.
-// V: timing-only ablation bits (tools/k3_ablate.hip): 1 = no result stores, 4 = no row loads
-template <int V = 0>
 __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int nchunks, const u64* __restrict__ seg_lt,
                                                              const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_cnt,
                                                              const mp_cx* __restrict__ cx,
@@ -713,7 +710,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int n
         lt[k] = seg_lt[spos[k]];        // in bounds for every thread; masked by cnt below
         row0[k] = seg_row[spos[k]];
     }
-    // first row >= lt, walking forward from `row` inside its tile; r0/r1 = that row and the next one when already loaded
+    // first row >= lt, walking forward from `row` inside its tile; r0/r1 = that row and the next one, already loaded
     auto finish = [&](u64 ltx, uint32_t row, u64 sp, mp_cx r0, mp_cx r1) {
         const u64 tend = (((u64)row / TILE) + 1) * TILE;
         const u64 last = (tend < n ? tend : n) - 1;      // last row of the tile
@@ -727,18 +724,16 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int n
                 cur = cx[p];
             }
         }
-        if (!(V & 1) || cur.x0 == 1.2345e301) {
-            res_parent[sp] = (uint32_t)p;
-            res_x[sp] = cur.x0;
-            for (int d = 1; d < D; ++d) res_x[(u64)d * res_stride + sp] = x_old[(u64)d * n + p];
-        }
+        res_parent[sp] = (uint32_t)p;
+        res_x[sp] = cur.x0;
+        for (int d = 1; d < D; ++d) res_x[(u64)d * res_stride + sp] = x_old[(u64)d * n + p];
     };
     bool live[K3_ITEMS];
     mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
 #pragma unroll
     for (int k = 0; k < K3_ITEMS; ++k) {
         live[k] = e0 < cnt[k];
-        if (live[k] && !(V & 4)) {
+        if (live[k]) {
             const u64 tend = (((u64)row0[k] / TILE) + 1) * TILE;
             const u64 last = (tend < n ? tend : n) - 1;
             r0[k] = cx[row0[k]];
@@ -778,83 +773,56 @@ __global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __r
     logw[i] = 0.;
 }
 
-// query path: log_marginal_likelihood_estimate / fresh ESS from the current log-weights (after K2)
-__global__ __launch_bounds__(K3_THREADS) void k_lse_finalize(const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2, int nt, int S,
-                                                             u64 n_global, mp_dev_scalars* scal) {
-    __shared__ u64 s_a[K3_THREADS / 64], s_b[K3_THREADS / 64];
-    u64 q = 0, q2 = 0;
-    for (int j = threadIdx.x; j < nt; j += K3_THREADS) {
-        q += tilesum[j];
-        q2 += tilesum2[j];
-    }
-    q = wave_sum_u64(q);
-    q2 = wave_sum_u64(q2);
-    if ((threadIdx.x & 63) == 0) {
-        s_a[threadIdx.x >> 6] = q;
-        s_b[threadIdx.x >> 6] = q2;
-    }
-    __syncthreads();
+// Level 1 on its own (one workgroup): mode 1 = query (log_marginal_likelihood_estimate / fresh ESS), mode 0 = fold a
+// sharded resample, mode 2 = importance sampling (L and log_ml = L - ln N, importance.rs:21-22).
+__global__ __launch_bounds__(K3_THREADS) void k_finalize_tiles(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                               const u64* __restrict__ tile_W2, int nt, int S, u64 n_global, int mode,
+                                                               mp_dev_scalars* scal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt;
+    double* s_red = reinterpret_cast<double*>(s_W + nt);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + K3_THREADS / 64);
+    const double m = block_tile_table<K3_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
+    const u64 Q = s_incl[nt - 1];
+    const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
     if (threadIdx.x == 0) {
-        u64 Q = 0, Q2 = 0;
-        for (int k = 0; k < K3_THREADS / 64; ++k) {
-            Q += s_a[k];
-            Q2 += s_b[k];
+        if (mode == 2) {
+            double L, ess;
+            finalize_scalars(Q, Q2, S, &L, &ess, m);
+            scal->m = m;
+            if (!(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0) scal->degenerate = 1;
+            scal->L = L;
+            scal->lml_fresh = L - mp_log((double)n_global);
+        } else {
+            fold_scalars(scal, Q, Q2, S, m, n_global, mode);
         }
-        double L, ess;
-        finalize_scalars(Q, Q2, S, &L, &ess, scal->m);
-        scal->ess_fresh = ess;
-        scal->lml_fresh = scal->log_ml + L - mp_log((double)n_global);  // particle_filter.rs:119-121
     }
 }
 
-
 // ---------------------------------------------------------------------------------------------
-// sharded filter phases (include/modppl_hip.h "sharded filter")
+// sharded filter phases (include/modppl_hip.h "sharded filter").  Shards are tile-aligned, so a shard's tiles are
+// tiles of the job; every rank gathers all tiles' (m, W, W2) and builds the same table.
 // ---------------------------------------------------------------------------------------------
 constexpr int SH_THREADS = 256;
 constexpr int SH_MAX_WORLD = 64;
 
-__global__ __launch_bounds__(SH_THREADS) void k_reduce_max(const double* __restrict__ v, int nv, double* __restrict__ out) {
-    __shared__ double s_m[SH_THREADS / 64];
-    double m = MP_NEG_INF;
-    for (int j = threadIdx.x; j < nv; j += SH_THREADS) m = fmax(m, v[j]);
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < SH_THREADS / 64; ++k) m = fmax(m, s_m[k]);
-        out[0] = fmax(m, s_m[0]);
-    }
-}
-__global__ __launch_bounds__(SH_THREADS) void k_sum_tiles(const u64* __restrict__ tilesum, const u64* __restrict__ tilesum2, int nt,
-                                                          u64* __restrict__ out) {
-    __shared__ u64 s_a[SH_THREADS / 64], s_b[SH_THREADS / 64];
-    u64 q = 0, q2 = 0;
-    for (int j = threadIdx.x; j < nt; j += SH_THREADS) { q += tilesum[j]; q2 += tilesum2[j]; }
-    q = wave_sum_u64(q); q2 = wave_sum_u64(q2);
-    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = q; s_b[threadIdx.x >> 6] = q2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 Q = 0, Q2 = 0;
-        for (int k = 0; k < SH_THREADS / 64; ++k) { Q += s_a[k]; Q2 += s_b[k]; }
-        out[0] = Q; out[1] = Q2;
-    }
-}
-
-// pass 1: target of every local slot -> owner rank + shard-local target; per-workgroup owner histogram
+// pass 1: target of every local slot -> owner rank, tile inside the owner's shard, tile-local target; owner histogram
 __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
-                                                              int systematic, const u64* __restrict__ totals_all, int world,
+                                                              int systematic, int S, const double* __restrict__ tm_all,
+                                                              const u64* __restrict__ tW_all, int nt_all, int nt_local, int world,
                                                               unsigned char* __restrict__ dest, u64* __restrict__ lt_out,
-                                                              uint32_t* __restrict__ blockcount) {
-    __shared__ u64 s_incl[SH_MAX_WORLD];
-    __shared__ uint32_t s_cnt[SH_MAX_WORLD];
+                                                              uint32_t* __restrict__ tile_out, uint32_t* __restrict__ blockcount) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt_all;
+    double* s_red = reinterpret_cast<double*>(s_W + nt_all);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + SH_THREADS / 64);
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_wtot + SH_THREADS / 64);  // [SH_MAX_WORLD]
     if (threadIdx.x < SH_MAX_WORLD) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        u64 run = 0;
-        for (int r = 0; r < world; ++r) { run += totals_all[2 * r]; s_incl[r] = run; }
-    }
-    __syncthreads();
-    const u64 Q = s_incl[world - 1];
+    block_tile_table<SH_THREADS>(tm_all, tW_all, nt_all, S, s_incl, s_W, s_red, s_wtot);
+    const u64 Q = s_incl[nt_all - 1];
+    const double nt_over_Q = (double)nt_all / (double)Q;
     const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
     if (i < n) {
         u64 target;
@@ -864,11 +832,13 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_globa
             const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
             target = mp_target(mp_u52(r.a), Q);
         }
-        int s = 0;
-        while (s < world - 1 && s_incl[s] < target) ++s;  // first rank whose inclusive total reaches the target
-        const u64 excl = s ? s_incl[s - 1] : 0ull;
+        uint32_t b, gs;
+        u64 lt;
+        mp_locate(s_incl, s_W, (uint32_t)nt_all, target, nt_over_Q, &b, &lt, &gs);
+        const int s = (int)(b / (uint32_t)nt_local);
         dest[i] = (unsigned char)s;
-        lt_out[i] = target - excl;
+        lt_out[i] = lt;
+        tile_out[i] = b % (uint32_t)nt_local;
         atomicAdd(&s_cnt[s], 1u);
     }
     __syncthreads();
@@ -877,7 +847,6 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_globa
 // pass 2 (one workgroup): per-owner totals and exclusive per-workgroup offsets
 __global__ __launch_bounds__(SH_THREADS) void k_shard_offsets(const uint32_t* __restrict__ blockcount, int nblk, int world,
                                                               uint32_t* __restrict__ blockoff, long long* __restrict__ counts) {
-    // thread r < world walks the workgroups sequentially (nblk <= 65536, world <= 64: a few tens of microseconds at worst)
     const int r = threadIdx.x;
     if (r < world) {
         uint32_t run = 0;
@@ -888,10 +857,11 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_offsets(const uint32_t* __
         counts[r] = (long long)run;
     }
 }
-// pass 3: stable pack of the requests grouped by owner
+// pass 3: stable pack of the requests (tile in owner, tile-local target) grouped by owner
 __global__ __launch_bounds__(SH_THREADS) void k_shard_pack(u64 n, const unsigned char* __restrict__ dest, const u64* __restrict__ lt_in,
-                                                           const uint32_t* __restrict__ blockoff, const long long* __restrict__ counts, int world,
-                                                           u64* __restrict__ req_out, uint32_t* __restrict__ req_slot) {
+                                                           const uint32_t* __restrict__ tile_in, const uint32_t* __restrict__ blockoff,
+                                                           const long long* __restrict__ counts, int world, u64* __restrict__ req_out,
+                                                           uint32_t* __restrict__ req_slot) {
     __shared__ uint32_t s_wcnt[SH_THREADS / 64][SH_MAX_WORLD];
     __shared__ u64 s_gstart[SH_MAX_WORLD];
     const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
@@ -912,32 +882,25 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_pack(u64 n, const unsigned
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += s_wcnt[w][s];
         const u64 pos = s_gstart[s] + blockoff[(u64)blockIdx.x * world + s] + before + my_rank_in_wave;
-        req_out[pos] = lt_in[i];
+        req_out[2 * pos] = (u64)tile_in[i];
+        req_out[2 * pos + 1] = lt_in[i];
         req_slot[pos] = (uint32_t)i;
     }
 }
-// owner side: shard-local targets -> parent rows
+// owner side: (tile, tile-local target) -> parent rows
 __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve(u64 n, u64 n_req, u64 slot_offset, int D, const u64* __restrict__ req,
                                                               const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
-                                                              const u64* __restrict__ tilesum, int nt, const double* __restrict__ x,
+                                                              const u64* __restrict__ tile_W, const double* __restrict__ x,
                                                               double* __restrict__ rows) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* s_incl = reinterpret_cast<u64*>(smem);
-    u64* s_wtot = s_incl + nt;
-    block_scan_tiles<K3_THREADS>(tilesum, nt, s_incl, s_wtot);
     for (u64 q = (u64)blockIdx.x * K3_THREADS + threadIdx.x; q < n_req; q += (u64)gridDim.x * K3_THREADS) {
-        const u64 target = req[q];
-        uint32_t b = lower_bound_u64(s_incl, (uint32_t)nt, target);
-        if (b > (uint32_t)(nt - 1)) b = (uint32_t)(nt - 1);
-        const u64 incl_b = s_incl[b];
-        const u64 excl = b ? s_incl[b - 1] : 0ull;
-        const u64 lt = target - excl;
-        const int shift = mp_guide_shift(incl_b - excl);
-        const u64 tbase = (u64)b * TILE;
+        const u64 b = req[2 * q];
+        const u64 lt = req[2 * q + 1];
+        const int shift = mp_guide_shift(tile_W[b]);
+        const u64 tbase = b * TILE;
         const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
         uint32_t g = (uint32_t)(lt >> shift);
         if (g > GUIDE_N - 1) g = GUIDE_N - 1;
-        uint32_t j = guide[(u64)b * GUIDE_N + g];
+        uint32_t j = guide[b * GUIDE_N + g];
         if (j > tlen - 1) j = tlen - 1;
         mp_cx row = load_row_nt(cx + tbase + j);
         while (row.cum < lt && j + 1 < tlen) {
@@ -953,8 +916,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve(u64 n, u64 n_req, 
 }
 // requester side
 __global__ __launch_bounds__(SH_THREADS) void k_shard_scatter(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ req_slot,
-                                                              double* __restrict__ x_new, uint32_t* __restrict__ parent, double* __restrict__ logw,
-                                                              double* __restrict__ blockmax, int nb) {
+                                                              double* __restrict__ x_new, uint32_t* __restrict__ parent, double* __restrict__ logw) {
     const u64 pos = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
     if (pos < n) {
         const uint32_t i = req_slot[pos];
@@ -962,26 +924,6 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_scatter(u64 n, int D, cons
         for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = in[d];
         parent[i] = (uint32_t)in[D];
         logw[i] = 0.;
-    }
-    if (blockIdx.x == 0)
-        for (int j = threadIdx.x; j < nb; j += SH_THREADS) blockmax[j] = 0.;
-}
-// scalars of a sharded normalisation from the gathered totals; mode 0 = resample (fold into log_ml), 1 = query
-__global__ void k_shard_finalize(const u64* __restrict__ totals_all, int world, int S, u64 n_global, int mode, mp_dev_scalars* scal) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        u64 Q = 0, Q2 = 0;
-        for (int r = 0; r < world; ++r) { Q += totals_all[2 * r]; Q2 += totals_all[2 * r + 1]; }
-        double L, ess;
-        finalize_scalars(Q, Q2, S, &L, &ess, scal->m);
-        if (mode == 0) {
-            scal->L = L;
-            scal->ess_stale = ess;
-            scal->Q = Q; scal->Q2 = Q2;
-            scal->log_ml += L - mp_log((double)n_global);
-        } else {
-            scal->ess_fresh = ess;
-            scal->lml_fresh = scal->log_ml + L - mp_log((double)n_global);
-        }
     }
 }
 
@@ -991,6 +933,11 @@ __global__ void k_soa_to_aos(const double* __restrict__ x, u64 n, int D, double*
     if (i < n)
         for (int d = 0; d < D; ++d) out[i * D + d] = x[(u64)d * n + i];
 }
+// out[i] = a[i] - *b  (log_normalized_weights = w_i - log_total_weight, importance.rs:23-25)
+__global__ void k_sub_scalar(const double* __restrict__ a, const double* __restrict__ b, u64 n, double* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] - *b;
+}
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -999,6 +946,9 @@ static int ceil_log2_u64(u64 n) {
     int b = 0;
     while ((1ull << b) < n) ++b;
     return b;
+}
+static size_t table_lds(int nt, int threads) {  // s_incl[nt] + s_W[nt] + s_red + s_wtot
+    return sizeof(u64) * 2 * (size_t)nt + (sizeof(double) + sizeof(u64)) * (size_t)(threads / 64);
 }
 
 struct PropagateArgs {
@@ -1011,17 +961,20 @@ struct PropagateArgs {
     mp_obs obs;
     mp_state0 s0;
     int overwrite;
-    double* blockmax;
     int grid;
     hipStream_t stream;
     const unsigned short* perm;
     const double* res_x;
     u64 res_stride;
     int nchunks;
+    mp_cx* cx;
+    unsigned short* guide;
+    double* tile_m;
+    u64* tile_W;
+    u64* tile_W2;
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
-    int k1_items = 1;
     virtual ~ModelOps() {}
     virtual void propagate(const PropagateArgs& a) const = 0;
 };
@@ -1031,12 +984,13 @@ struct ModelOpsT : ModelOps {
     explicit ModelOpsT(const Model& m) : model(m) {
         dim_state = Model::DIM_STATE;
         dim_obs = Model::DIM_OBS;
-        k1_items = ::k1_items<Model>();
         static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
+        static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
     }
     void propagate(const PropagateArgs& a) const override {
-        hipLaunchKernelGGL(k_propagate<Model>, dim3(a.grid), dim3(K1_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.blockmax, a.perm, a.res_x, a.res_stride, a.nchunks);
+        hipLaunchKernelGGL(k_propagate<Model>, dim3(a.grid), dim3(TILE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.res_stride, a.nchunks, a.cx, a.guide,
+                           a.tile_m, a.tile_W, a.tile_W2);
     }
 };
 
@@ -1130,8 +1084,7 @@ struct mp_pf {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int S = 0;
-    int nb = 0;  // K1 grid == entries of blockmax
-    int nt = 0;  // scan tiles
+    int nt = 0;  // tiles of this handle (== K1 grid)
     int k3_grid = 0;
     // device buffers
     double* x[2] = {nullptr, nullptr};
@@ -1140,26 +1093,28 @@ struct mp_pf {
     mp_cx* cx = nullptr;
     unsigned short* guide = nullptr;
     uint32_t* parent = nullptr;
-    double* blockmax = nullptr;
-    u64* tilesum = nullptr;
-    u64* tilesum2 = nullptr;
+    double* tile_m = nullptr;
+    u64* tile_W = nullptr;
+    u64* tile_W2 = nullptr;
     mp_dev_scalars* scal = nullptr;
-    double* aos = nullptr;  // staging for read_state
+    double* aos = nullptr;             // staging for read_state
     mp_dev_scalars* h_scal = nullptr;  // pinned
     // binned resampling scratch: segments [bin][chunk][1024]
-    u64* seg_lt = nullptr;              // [8 * nchunks * 1024]: tile-local target of every binned draw
+    u64* seg_lt = nullptr;              // tile-local target of every binned draw
     uint32_t* seg_row = nullptr;        // table row where the forward scan of every binned draw starts
     unsigned short* perm = nullptr;     // [n]: (bin << 10 | position) of every slot's draw
     unsigned short* seg_cnt = nullptr;
     double* res_x = nullptr;            // [d][8 * nchunks * 1024]: resampled states in segment order
     uint32_t* res_parent = nullptr;     // [8 * nchunks * 1024]
     u64 res_stride = 0;
-    bool permuted = false;              // the current states / parents / (zero) log-weights live in res_* (lazy slot order)
     int nchunks = 0;
-    int use_binned = 1;  // MP_BINNED_RESAMPLE=0 selects the single-kernel path (A/B measurements)
+    int use_binned = 1;                 // MP_BINNED_RESAMPLE=0 selects the single-kernel path (A/B measurements)
+    bool permuted = false;              // the current states / parents / (zero) log-weights live in res_* (lazy slot order)
+    bool rows_fresh = false;            // cx / guide / tile_* describe the current log-weights
     // sharded-resample scratch (allocated on first use)
     unsigned char* sh_dest = nullptr;
     u64* sh_lt = nullptr;
+    uint32_t* sh_tile = nullptr;
     uint32_t* sh_req_slot = nullptr;
     uint32_t* sh_blockcount = nullptr;
     uint32_t* sh_blockoff = nullptr;
@@ -1263,15 +1218,16 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.res_x = h->res_x;
     a.res_stride = h->res_stride;
     a.nchunks = h->nchunks;
-    a.blockmax = h->blockmax;
-    a.grid = h->nb;
+    a.cx = h->cx; a.guide = h->guide; a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
+    a.grid = h->nt;
     a.stream = h->stream;
     {
         LaunchTimer lt(h, MP_K_PROPAGATE);
         h->ops->propagate(a);
     }
     h->t += 1;
-    h->permuted = false;  // k_propagate wrote x[cur] and logw in slot order
+    h->permuted = false;   // k_propagate wrote x[cur] and logw in slot order ...
+    h->rows_fresh = true;  // ... and level 0 of their normalisation
     int32_t rc_ = check_launch("k_propagate");
     if (rc_ != MP_OK) return rc_;
     if (h->flags & MP_PF_RECORD_HISTORY) {
@@ -1284,13 +1240,18 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     return MP_OK;
 }
 
-static int32_t launch_normalize(mp_pf* h) {
-    int32_t rcm = materialize(h);
-    if (rcm != MP_OK) return rcm;
-    LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
-    hipLaunchKernelGGL(k_normalize_scan, dim3(h->nt), dim3(SCAN_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->n, h->blockmax, h->nb, h->S,
-                       h->cx, h->guide, h->tilesum, h->tilesum2, h->scal);
-    return check_launch("k_normalize_scan");
+// level 0 for the current log-weights when no propagate produced it (after a resample: the weights are zero)
+static int32_t ensure_rows(mp_pf* h) {
+    int32_t rc = materialize(h);
+    if (rc != MP_OK) return rc;
+    if (h->rows_fresh) return MP_OK;
+    {
+        LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
+        hipLaunchKernelGGL(k_normalize_tiles, dim3(h->nt), dim3(TILE_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->n, h->cx, h->guide,
+                           h->tile_m, h->tile_W, h->tile_W2);
+    }
+    h->rows_fresh = true;
+    return check_launch("k_normalize_tiles");
 }
 
 extern "C" {
@@ -1320,6 +1281,8 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     h->slot_offset = shard ? shard->slot_offset : 0;
     if (h->n_global < h->n + h->slot_offset || h->n_global > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "shard does not fit n_global (< 2^32)");
     h->sharded = shard && (h->n_global != h->n);
+    if (h->sharded && ((h->slot_offset % TILE) || (h->n % TILE)))
+        return mp_fail(MP_ERR_INVALID_ARG, "shards must be tile-aligned: slot_offset and n_particles multiples of 2048");
     h->seed = seed;
     h->flags = flags;
     h->device = device;
@@ -1338,42 +1301,51 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     }
     const u64 n = h->n;
     const int d = h->ops->dim_state;
-    h->nb = (int)((n + (u64)K1_THREADS * h->ops->k1_items - 1) / ((u64)K1_THREADS * h->ops->k1_items));
-    if (h->nb > K1_MAX_BLOCKS) h->nb = K1_MAX_BLOCKS;
     h->nt = (int)((n + TILE - 1) / TILE);
-    if (h->nt > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "n_particles per handle is limited to 2^24 in this build");
+    if ((h->n_global + TILE - 1) / TILE > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "at most 2^24 particles per job in this build (tile table in LDS)");
     h->k3_grid = (int)((n + K3_THREADS * K3_ITEMS - 1) / (K3_THREADS * K3_ITEMS));
     if (h->k3_grid > K3_MAX_BLOCKS) h->k3_grid = K3_MAX_BLOCKS;
-    HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
-    HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
-    HIPCK(hipMalloc(&h->logw, sizeof(double) * n));
-    HIPCK(hipMalloc(&h->cx, sizeof(mp_cx) * n));
-    HIPCK(hipMalloc(&h->guide, sizeof(unsigned short) * (size_t)h->nt * GUIDE_N));
-    HIPCK(hipMalloc(&h->parent, sizeof(uint32_t) * n));
-    HIPCK(hipMalloc(&h->blockmax, sizeof(double) * K1_MAX_BLOCKS));
-    HIPCK(hipMalloc(&h->tilesum, sizeof(u64) * h->nt));
-    HIPCK(hipMalloc(&h->tilesum2, sizeof(u64) * h->nt));
-    HIPCK(hipMalloc(&h->scal, sizeof(mp_dev_scalars)));
-    HIPCK(hipMalloc(&h->aos, sizeof(double) * n * d));
     h->nchunks = (int)((n + BIN_CHUNK - 1) / BIN_CHUNK);
     {
         const char* env = getenv("MP_BINNED_RESAMPLE");
         if (env && env[0] == '0') h->use_binned = 0;
     }
-    HIPCK(hipMalloc(&h->seg_lt, sizeof(u64) * 8 * (size_t)h->nchunks * BIN_CHUNK));
-    HIPCK(hipMalloc(&h->seg_row, sizeof(uint32_t) * 8 * (size_t)h->nchunks * BIN_CHUNK));
+    HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
+    HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
+    HIPCK(hipMalloc(&h->logw, sizeof(double) * n));
+    HIPCK(hipMalloc(&h->cx, sizeof(mp_cx) * (size_t)h->nt * TILE));
+    HIPCK(hipMalloc(&h->guide, sizeof(unsigned short) * (size_t)h->nt * GUIDE_N));
+    HIPCK(hipMalloc(&h->parent, sizeof(uint32_t) * n));
+    HIPCK(hipMalloc(&h->tile_m, sizeof(double) * h->nt));
+    HIPCK(hipMalloc(&h->tile_W, sizeof(u64) * h->nt));
+    HIPCK(hipMalloc(&h->tile_W2, sizeof(u64) * h->nt));
+    HIPCK(hipMalloc(&h->scal, sizeof(mp_dev_scalars)));
+    HIPCK(hipMalloc(&h->aos, sizeof(double) * n * d));
+    HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
     h->res_stride = 8ull * (u64)h->nchunks * BIN_CHUNK;
+    HIPCK(hipMalloc(&h->seg_lt, sizeof(u64) * h->res_stride));
+    HIPCK(hipMalloc(&h->seg_row, sizeof(uint32_t) * h->res_stride));
     HIPCK(hipMalloc(&h->perm, sizeof(unsigned short) * (size_t)h->nchunks * BIN_CHUNK));
+    HIPCK(hipMalloc(&h->seg_cnt, sizeof(unsigned short) * 8 * (size_t)h->nchunks));
     HIPCK(hipMalloc(&h->res_x, sizeof(double) * h->res_stride * (size_t)d));
     HIPCK(hipMalloc(&h->res_parent, sizeof(uint32_t) * h->res_stride));
-    HIPCK(hipMalloc(&h->seg_cnt, sizeof(unsigned short) * 8 * (size_t)h->nchunks));
-    HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
+    // tile tables above 64 KiB of LDS need the limit raised once per kernel
+    {
+        const int nt_job = (int)((h->n_global + TILE - 1) / TILE);
+        const size_t need = table_lds(nt_job, K3_THREADS) + 1024;
+        if (need > 48 * 1024) {
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+        }
+    }
     // ParticleSystem::new: log_weights = 0, parents = 0, log_ml_estimate = 0 (particle_filter.rs:44-57)
     HIPCK(hipMemsetAsync(h->x[0], 0, sizeof(double) * n * d, h->stream));
     HIPCK(hipMemsetAsync(h->x[1], 0, sizeof(double) * n * d, h->stream));
     HIPCK(hipMemsetAsync(h->logw, 0, sizeof(double) * n, h->stream));
     HIPCK(hipMemsetAsync(h->parent, 0, sizeof(uint32_t) * n, h->stream));
-    HIPCK(hipMemsetAsync(h->blockmax, 0, sizeof(double) * K1_MAX_BLOCKS, h->stream));
     mp_dev_scalars init{};
     init.ess_stale = 1.0 / (double)h->n_global;  // exp(-logsumexp(zeros)) before any resample
     *h->h_scal = init;
@@ -1414,35 +1386,38 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC) return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: resample runs through the mp_pf_shard_* phases");
     HIPCK(hipSetDevice(h->device));
-    int32_t rc = launch_normalize(h);
+    int32_t rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
     const int d = h->ops->dim_state;
-    const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
     bool binned = false;
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
-            const size_t lds_a = sizeof(u64) * ((size_t)h->nt + BIN_THREADS / 64) + sizeof(uint32_t) * (2 * BIN_ITEMS * (BIN_THREADS / 64) * 8 + 8);
+            const size_t lds_a = table_lds(h->nt, BIN_THREADS) + sizeof(uint32_t) * 2 * BIN_ITEMS * (BIN_THREADS / 64) * 8;
             hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                               (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tilesum, h->tilesum2, h->nt, h->guide, h->seg_lt,
-                               h->seg_row, h->perm, h->seg_cnt, h->blockmax, h->nb, h->scal);
+                               (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->guide,
+                               h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal);
             const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
-            hipLaunchKernelGGL(k_resolve_bins<0>, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, d, h->nchunks, h->seg_lt, h->seg_row,
+            hipLaunchKernelGGL(k_resolve_bins, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, d, h->nchunks, h->seg_lt, h->seg_row,
                                h->seg_cnt, h->cx, h->x[h->cur], h->res_x, h->res_stride, h->res_parent);
             binned = true;
-        } else if (scheme == MP_RESAMPLE_SYSTEMATIC)
-            hipLaunchKernelGGL((k_resample_gather<0, true>), dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
-                               (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide,
-                               h->tilesum, h->tilesum2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
-        else
-            hipLaunchKernelGGL((k_resample_gather<0, false>), dim3(h->k3_grid), dim3(K3_THREADS), lds, h->stream, h->n, h->n, h->n_global, h->slot_offset,
-                               (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, d, h->cx, h->guide,
-                               h->tilesum, h->tilesum2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb, h->scal);
+        } else if (scheme == MP_RESAMPLE_SYSTEMATIC) {
+            hipLaunchKernelGGL(k_resample_gather<true>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
+                               h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
+                               h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
+                               h->scal);
+        } else {
+            hipLaunchKernelGGL(k_resample_gather<false>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
+                               h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
+                               h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
+                               h->scal);
+        }
     }
-    rc = check_launch("k_resample_gather");
+    rc = check_launch("resample kernels");
     if (rc != MP_OK) return rc;
     if (binned) h->permuted = true;   // results stay in segment order; x[cur] is the (stale) pre-resample state
     else h->cur ^= 1;
+    h->rows_fresh = false;            // the log-weights are now all zero
     h->resample_count += 1;
     if (h->flags & MP_PF_RECORD_HISTORY) {
         rc = materialize(h);
@@ -1462,10 +1437,11 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
 
 static int32_t query(mp_pf* h) {
     if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: use mp_pf_shard_query");
-    int32_t rc = launch_normalize(h);
+    int32_t rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(k_lse_finalize, dim3(1), dim3(K3_THREADS), 0, h->stream, h->tilesum, h->tilesum2, h->nt, h->S, h->n_global, h->scal);
-    rc = check_launch("k_lse_finalize");
+    hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->tile_m, h->tile_W, h->tile_W2, h->nt,
+                       h->S, h->n_global, 1, h->scal);
+    rc = check_launch("k_finalize_tiles");
     if (rc != MP_OK) return rc;
     return fetch_scalars(h);
 }
@@ -1528,42 +1504,34 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
 }
 
 // ---- sharded phases ------------------------------------------------------------------------------
-int32_t mp_pf_shard_local_max(mp_pf* h, double* d_out) {
-    if (!h || !d_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+int32_t mp_pf_shard_tiles(mp_pf* h, double* d_tile_m, uint64_t* d_tile_W, uint64_t* d_tile_W2) {
+    if (!h || !d_tile_m || !d_tile_W || !d_tile_W2) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
     HIPCK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(SH_THREADS), 0, h->stream, h->blockmax, h->nb, d_out);
-    return check_launch("k_reduce_max");
-}
-
-int32_t mp_pf_shard_normalize(mp_pf* h, const double* d_global_max, uint64_t* d_totals_out) {
-    if (!h || !d_global_max || !d_totals_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
-    HIPCK(hipSetDevice(h->device));
-    {
-        LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
-        hipLaunchKernelGGL(k_normalize_scan, dim3(h->nt), dim3(SCAN_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->n, d_global_max, 1, h->S,
-                           h->cx, h->guide, h->tilesum, h->tilesum2, h->scal);
-    }
-    int32_t rc = check_launch("k_normalize_scan");
+    int32_t rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(k_sum_tiles, dim3(1), dim3(SH_THREADS), 0, h->stream, h->tilesum, h->tilesum2, h->nt, (u64*)d_totals_out);
-    return check_launch("k_sum_tiles");
+    HIPCK(hipMemcpyAsync(d_tile_m, h->tile_m, sizeof(double) * h->nt, hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(hipMemcpyAsync(d_tile_W, h->tile_W, sizeof(u64) * h->nt, hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(hipMemcpyAsync(d_tile_W2, h->tile_W2, sizeof(u64) * h->nt, hipMemcpyDeviceToDevice, h->stream));
+    return MP_OK;
 }
 
-int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const uint64_t* d_totals_all, int32_t world, int32_t rank, uint64_t* d_req_out,
-                          int64_t* send_counts) {
-    if (!h || !d_totals_all || !d_req_out || !send_counts) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const double* d_tm_all, const uint64_t* d_tW_all, const uint64_t* d_tW2_all, int32_t world,
+                          int32_t rank, uint64_t* d_req_out, int64_t* send_counts) {
+    if (!h || !d_tm_all || !d_tW_all || !d_tW2_all || !d_req_out || !send_counts) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC) return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (world < 1 || world > SH_MAX_WORLD || rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, 0 <= rank < world");
+    if ((u64)world * h->n != h->n_global) return mp_fail(MP_ERR_INVALID_ARG, "equal tile-aligned shards: world * n_particles must equal n_global");
     HIPCK(hipSetDevice(h->device));
     const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
+    const int nt_all = h->nt * world;
     if (!h->sh_dest || h->sh_world < world) {
-        (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
+        (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
         (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts);
         if (h->h_counts) (void)hipHostFree(h->h_counts);
         HIPCK(hipMalloc(&h->sh_dest, h->n));
         HIPCK(hipMalloc(&h->sh_lt, sizeof(u64) * h->n));
+        HIPCK(hipMalloc(&h->sh_tile, sizeof(uint32_t) * h->n));
         HIPCK(hipMalloc(&h->sh_req_slot, sizeof(uint32_t) * h->n));
         HIPCK(hipMalloc(&h->sh_blockcount, sizeof(uint32_t) * (size_t)nblk * world));
         HIPCK(hipMalloc(&h->sh_blockoff, sizeof(uint32_t) * (size_t)nblk * world));
@@ -1573,18 +1541,20 @@ int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const uint64_t* d_totals_all
     }
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, scheme == MP_RESAMPLE_SYSTEMATIC ? 1 : 0, (const u64*)d_totals_all, world,
-                           h->sh_dest, h->sh_lt, h->sh_blockcount);
+        const size_t lds = table_lds(nt_all, SH_THREADS) + sizeof(uint32_t) * SH_MAX_WORLD;
+        hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
+                           (uint32_t)(h->seed >> 32), h->resample_count, scheme == MP_RESAMPLE_SYSTEMATIC ? 1 : 0, h->S, d_tm_all, (const u64*)d_tW_all,
+                           nt_all, h->nt, world, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockcount);
         hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(SH_THREADS), 0, h->stream, h->sh_blockcount, nblk, world, h->sh_blockoff, h->sh_counts);
-        hipLaunchKernelGGL(k_shard_pack, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->sh_dest, h->sh_lt, h->sh_blockoff, h->sh_counts, world,
-                           (u64*)d_req_out, h->sh_req_slot);
+        hipLaunchKernelGGL(k_shard_pack, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockoff, h->sh_counts,
+                           world, (u64*)d_req_out, h->sh_req_slot);
     }
     int32_t rc = check_launch("k_shard_targets/offsets/pack");
     if (rc != MP_OK) return rc;
-    // the finalisation of this normalisation (L, ESS, log-ML) only needs the gathered totals
-    hipLaunchKernelGGL(k_shard_finalize, dim3(1), dim3(64), 0, h->stream, (const u64*)d_totals_all, world, h->S, h->n_global, 0, h->scal);
-    rc = check_launch("k_shard_finalize");
+    // the finalisation of this normalisation (L, ESS, log-ML) only needs the gathered tiles
+    hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, d_tm_all, (const u64*)d_tW_all,
+                       (const u64*)d_tW2_all, nt_all, h->S, h->n_global, 0, h->scal);
+    rc = check_launch("k_finalize_tiles");
     if (rc != MP_OK) return rc;
     HIPCK(hipMemcpyAsync(h->h_counts, h->sh_counts, sizeof(long long) * world, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
@@ -1598,11 +1568,10 @@ int32_t mp_pf_shard_resolve(mp_pf* h, const uint64_t* d_req_in, uint64_t n_req, 
     if (!d_req_in || !d_rows_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
     int grid = (int)std::min<u64>((n_req + K3_THREADS - 1) / K3_THREADS, (u64)K3_MAX_BLOCKS);
-    const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_shard_resolve, dim3(grid), dim3(K3_THREADS), lds, h->stream, h->n, (u64)n_req, h->slot_offset, h->ops->dim_state,
-                           (const u64*)d_req_in, h->cx, h->guide, h->tilesum, h->nt, h->x[h->cur], d_rows_out);
+        hipLaunchKernelGGL(k_shard_resolve, dim3(grid), dim3(K3_THREADS), 0, h->stream, h->n, (u64)n_req, h->slot_offset, h->ops->dim_state,
+                           (const u64*)d_req_in, h->cx, h->guide, h->tile_W, h->x[h->cur], d_rows_out);
     }
     return check_launch("k_shard_resolve");
 }
@@ -1614,11 +1583,12 @@ int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         hipLaunchKernelGGL(k_shard_scatter, dim3((unsigned)((h->n + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, h->stream, h->n,
-                           h->ops->dim_state, d_rows_in, h->sh_req_slot, h->x[h->cur ^ 1], h->parent, h->logw, h->blockmax, h->nb);
+                           h->ops->dim_state, d_rows_in, h->sh_req_slot, h->x[h->cur ^ 1], h->parent, h->logw);
     }
     int32_t rc = check_launch("k_shard_scatter");
     if (rc != MP_OK) return rc;
     h->cur ^= 1;
+    h->rows_fresh = false;
     h->resample_count += 1;
     if (log_total_weight) {
         rc = fetch_scalars(h);
@@ -1628,11 +1598,14 @@ int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total
     return MP_OK;
 }
 
-int32_t mp_pf_shard_query(mp_pf* h, const uint64_t* d_totals_all, int32_t world, double* log_ml, double* ess) {
-    if (!h || !d_totals_all) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+int32_t mp_pf_shard_query(mp_pf* h, const double* d_tm_all, const uint64_t* d_tW_all, const uint64_t* d_tW2_all, int32_t world, double* log_ml,
+                          double* ess) {
+    if (!h || !d_tm_all || !d_tW_all || !d_tW2_all) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_shard_finalize, dim3(1), dim3(64), 0, h->stream, (const u64*)d_totals_all, world, h->S, h->n_global, 1, h->scal);
-    int32_t rc = check_launch("k_shard_finalize");
+    const int nt_all = h->nt * world;
+    hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, d_tm_all, (const u64*)d_tW_all,
+                       (const u64*)d_tW2_all, nt_all, h->S, h->n_global, 1, h->scal);
+    int32_t rc = check_launch("k_finalize_tiles");
     if (rc != MP_OK) return rc;
     rc = fetch_scalars(h);
     if (rc != MP_OK) return rc;
@@ -1728,48 +1701,17 @@ int32_t mp_pf_destroy(mp_pf* h) {
     }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     for (auto& ev : h->hist) (void)hipFree(ev.buf);
-    (void)hipFree(h->x[0]);
-    (void)hipFree(h->x[1]);
-    (void)hipFree(h->logw);
-    (void)hipFree(h->cx);
-    (void)hipFree(h->guide);
-    (void)hipFree(h->parent);
-    (void)hipFree(h->blockmax);
-    (void)hipFree(h->tilesum);
-    (void)hipFree(h->tilesum2);
-    (void)hipFree(h->scal);
+    (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->guide);
+    (void)hipFree(h->parent); (void)hipFree(h->tile_m); (void)hipFree(h->tile_W); (void)hipFree(h->tile_W2); (void)hipFree(h->scal);
     (void)hipFree(h->aos);
     (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
-    (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
+    (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     (void)hipHostFree(h->h_scal);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;
-}
-
-// out[i] = a[i] - *b  (log_normalized_weights = w_i - log_total_weight, importance.rs:23-25)
-__global__ void k_sub_scalar(const double* __restrict__ a, const double* __restrict__ b, u64 n, double* __restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] - *b;
-}
-// IS query: log total weight and log_ml = L - ln N from the tile totals (importance.rs:21-22)
-__global__ __launch_bounds__(K3_THREADS) void k_is_finalize(const u64* __restrict__ tilesum, int nt, int S, u64 n, mp_dev_scalars* scal) {
-    __shared__ u64 s_a[K3_THREADS / 64];
-    u64 q = 0;
-    for (int j = threadIdx.x; j < nt; j += K3_THREADS) q += tilesum[j];
-    q = wave_sum_u64(q);
-    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = q;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 Q = 0;
-        for (int k = 0; k < K3_THREADS / 64; ++k) Q += s_a[k];
-        const double inv = mp_u2f((u64)(1023 - S) << 52);
-        const double L = scal->m + mp_log((double)Q * inv);
-        scal->L = L;
-        scal->lml_fresh = L - mp_log((double)n);
-    }
 }
 
 int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples,
@@ -1784,10 +1726,11 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
     // importance_sampling: N x generate(model_args, constraints) over all n_steps constraints (importance.rs:18-20)
     rc = mp_pf_init_step(h, args0, obs, n_steps);
     if (rc != MP_OK) return rc;
-    rc = launch_normalize(h);
+    rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(k_is_finalize, dim3(1), dim3(K3_THREADS), 0, h->stream, h->tilesum, h->nt, h->S, h->n, h->scal);
-    rc = check_launch("k_is_finalize");
+    hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->tile_m, h->tile_W, h->tile_W2, h->nt,
+                       h->S, h->n, 2, h->scal);
+    rc = check_launch("k_finalize_tiles");
     if (rc != MP_OK) return rc;
     rc = fetch_scalars(h);
     if (rc != MP_OK) return rc;
@@ -1809,11 +1752,10 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
         uint32_t* d_idx = nullptr;
         HIPCK(hipMalloc(&d_idx, sizeof(uint32_t) * num_ret_samples));
         const int grid = (int)std::min<u64>((num_ret_samples + K3_THREADS * K3_ITEMS - 1) / (K3_THREADS * K3_ITEMS), (u64)K3_MAX_BLOCKS);
-        const size_t lds = sizeof(u64) * ((size_t)h->nt + K3_THREADS / 64);
-        hipLaunchKernelGGL((k_resample_gather<0, false>), dim3(grid), dim3(K3_THREADS), lds, h->stream, h->n, (u64)num_ret_samples, h->n_global, (u64)0,
-                           (uint32_t)MP_DOM_IS, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), 0u, h->S, h->ops->dim_state, h->cx, h->guide,
-                           h->tilesum, h->tilesum2, h->nt, (const double*)nullptr, (double*)nullptr, d_idx, (double*)nullptr,
-                           (double*)nullptr, 0, (mp_dev_scalars*)nullptr);
+        hipLaunchKernelGGL(k_resample_gather<false>, dim3(grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, (u64)num_ret_samples,
+                           h->n_global, (u64)0, (uint32_t)MP_DOM_IS, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), 0u, h->S, h->ops->dim_state, h->cx,
+                           h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, (const double*)nullptr, (double*)nullptr, d_idx, (double*)nullptr,
+                           (mp_dev_scalars*)nullptr);
         rc = check_launch("k_resample_gather(IS)");
         std::vector<uint32_t> idx(num_ret_samples);
         hipError_t e1 = hipMemcpyAsync(idx.data(), d_idx, sizeof(uint32_t) * num_ret_samples, hipMemcpyDeviceToHost, h->stream);

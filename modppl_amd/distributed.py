@@ -2,8 +2,8 @@
 
 Collectives per resample (torch.distributed; backend "nccl" IS RCCL on ROCm, over xGMI on one node):
 
-    all_reduce(MAX)  1 f64      global max log-weight              (exact in any order)
-    all_gather       2 u64      per-shard fixed-point totals        (integer sums: exact in any order)
+    all_gather       24 B/tile  per-tile max log-weight + fixed-point totals of every shard: the weight "all-reduce";
+                                every rank builds the same tile table from them
     all_to_all       counts     how many draws each rank asks of each owner
     all_to_all       u64        the draws, routed to the rank that owns their CDF range
     all_to_all       f64 rows   the parents' states + global ids back to the asking rank (the particle exchange)
@@ -50,15 +50,12 @@ class HipShardEngine:
     def step(self, obs):
         capi.check(self._L.mp_pf_step(self._h, obs.ctypes.data_as(C.POINTER(C.c_double)), obs.shape[0]))
 
-    def shard_local_max(self, out_ptr):
-        capi.check(self._L.mp_pf_shard_local_max(self._h, out_ptr))
+    def shard_tiles(self, tm_ptr, tw_ptr, tw2_ptr):
+        capi.check(self._L.mp_pf_shard_tiles(self._h, tm_ptr, tw_ptr, tw2_ptr))
 
-    def shard_normalize(self, gmax_ptr, totals_ptr):
-        capi.check(self._L.mp_pf_shard_normalize(self._h, gmax_ptr, totals_ptr))
-
-    def shard_route(self, scheme, totals_all_ptr, world, rank, req_ptr):
+    def shard_route(self, scheme, tm_ptr, tw_ptr, tw2_ptr, nt_all, world, rank, req_ptr):
         counts = (C.c_int64 * world)()
-        capi.check(self._L.mp_pf_shard_route(self._h, scheme, totals_all_ptr, world, rank, req_ptr, counts))
+        capi.check(self._L.mp_pf_shard_route(self._h, scheme, tm_ptr, tw_ptr, tw2_ptr, world, rank, req_ptr, counts))
         return list(counts)
 
     def shard_resolve(self, req_ptr, n_req, rows_ptr):
@@ -69,10 +66,14 @@ class HipShardEngine:
         capi.check(self._L.mp_pf_shard_scatter(self._h, rows_ptr, C.byref(out) if want_value else None))
         return out.value if want_value else None
 
-    def shard_query(self, totals_all_ptr, world):
+    def shard_query(self, tm_ptr, tw_ptr, tw2_ptr, nt_all):
         lml, ess = C.c_double(), C.c_double()
-        capi.check(self._L.mp_pf_shard_query(self._h, totals_all_ptr, world, C.byref(lml), C.byref(ess)))
+        capi.check(self._L.mp_pf_shard_query(self._h, tm_ptr, tw_ptr, tw2_ptr, self._world_of(nt_all), C.byref(lml), C.byref(ess)))
         return lml.value, ess.value
+
+    def _world_of(self, nt_all):
+        nt_local = (self.n + 2047) // 2048
+        return nt_all // nt_local
 
     def ess_reference(self):
         out = C.c_double()
@@ -139,10 +140,16 @@ class ShardedParticleSystem:
         self.comm_dev = torch.device("cpu") if host_staging else self.dev
         self._ctx = getattr(self.engine, "stream_ctx", contextlib.nullcontext)
         d = model.dim_state
-        self._gmax = torch.zeros(1, dtype=torch.float64, device=self.dev)
-        self._totals = torch.zeros(2, dtype=torch.int64, device=self.dev)
-        self._totals_all = torch.zeros(self.world * 2, dtype=torch.int64, device=self.dev)
-        self._req = torch.zeros(self.n, dtype=torch.int64, device=self.dev)
+        if self.world > 1 and self.n % 2048:
+            raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "shards must be tile-aligned: num_particles / world_size must be a multiple of 2048")
+        self.nt = (self.n + 2047) // 2048
+        # level-0 tiles of this shard, packed [3][nt] as int64 (row 0 = bits of the f64 tile maxima) so ONE all-gather moves them
+        self._tiles = torch.zeros(3 * self.nt, dtype=torch.int64, device=self.dev)
+        self._tiles_all = torch.zeros(self.world * 3 * self.nt, dtype=torch.int64, device=self.dev)   # rank-major [world][3][nt]
+        self._tm_all = torch.zeros(self.world * self.nt, dtype=torch.int64, device=self.dev)           # field-major [world*nt] each
+        self._tw_all = torch.zeros(self.world * self.nt, dtype=torch.int64, device=self.dev)
+        self._tw2_all = torch.zeros(self.world * self.nt, dtype=torch.int64, device=self.dev)
+        self._req = torch.zeros(2 * self.n, dtype=torch.int64, device=self.dev)
         self._rows = torch.zeros(self.n * (d + 1), dtype=torch.float64, device=self.dev)
 
     # ---- collectives (identical for nccl/device tensors and gloo/CPU tensors) ----
@@ -192,10 +199,18 @@ class ShardedParticleSystem:
         return self
 
     def _normalize(self):
-        self.engine.shard_local_max(C.c_void_p(self._gmax.data_ptr()))
-        self._all_reduce_max(self._gmax)                                            # RCCL all-reduce of the log-weight max
-        self.engine.shard_normalize(C.c_void_p(self._gmax.data_ptr()), C.c_void_p(self._totals.data_ptr()))
-        self._all_gather(self._totals_all, self._totals)                            # shard totals
+        """level 0 on every shard, then ONE all-gather of the tiles (24 B each): the all-reduce of log-weights."""
+        nt, w = self.nt, self.world
+        t = self._tiles
+        self.engine.shard_tiles(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr() + 8 * nt), C.c_void_p(t.data_ptr() + 16 * nt))
+        self._all_gather(self._tiles_all, t)
+        g = self._tiles_all.view(w, 3, nt)
+        self._tm_all.copy_(g[:, 0, :].reshape(-1))
+        self._tw_all.copy_(g[:, 1, :].reshape(-1))
+        self._tw2_all.copy_(g[:, 2, :].reshape(-1))
+
+    def _tile_ptrs(self):
+        return (C.c_void_p(self._tm_all.data_ptr()), C.c_void_p(self._tw_all.data_ptr()), C.c_void_p(self._tw2_all.data_ptr()), self.world * self.nt)
 
     def resample(self, scheme=capi.MP_RESAMPLE_MULTINOMIAL, sync=True):
         """resample() -> log total weight (particle_filter.rs:103-116), multinomial over ALL shards."""
@@ -205,8 +220,8 @@ class ShardedParticleSystem:
     def _resample(self, scheme, sync):
         d = self.model.dim_state
         self._normalize()
-        send_counts = self.engine.shard_route(scheme, C.c_void_p(self._totals_all.data_ptr()), self.world, self.rank,
-                                              C.c_void_p(self._req.data_ptr()))
+        tm, tw, tw2, nt_all = self._tile_ptrs()
+        send_counts = self.engine.shard_route(scheme, tm, tw, tw2, nt_all, self.world, self.rank, C.c_void_p(self._req.data_ptr()))
         if self.world > 1:
             sc = torch.tensor(send_counts, dtype=torch.int64, device=self.comm_dev)
             rc = torch.empty(self.world, dtype=torch.int64, device=self.comm_dev)
@@ -214,7 +229,7 @@ class ShardedParticleSystem:
             recv_counts = rc.tolist()
         else:
             recv_counts = list(send_counts)
-        req_in = self._all_to_all(self._req, send_counts, recv_counts, 1)           # draws -> owners
+        req_in = self._all_to_all(self._req, send_counts, recv_counts, 2)           # draws (tile, target) -> owners
         n_req = int(sum(recv_counts))
         rows_out = torch.empty(max(n_req, 1) * (d + 1), dtype=torch.float64, device=self.dev)
         self.engine.shard_resolve(C.c_void_p(req_in.data_ptr()), n_req, C.c_void_p(rows_out.data_ptr()))
@@ -226,14 +241,14 @@ class ShardedParticleSystem:
     def log_marginal_likelihood_estimate(self):
         with self._ctx():
             self._normalize()
-            return self.engine.shard_query(C.c_void_p(self._totals_all.data_ptr()), self.world)[0]
+            return self.engine.shard_query(*self._tile_ptrs())[0]
 
     def effective_sample_size(self, fresh=False):
         if not fresh:
             return self.engine.ess_reference()
         with self._ctx():
             self._normalize()
-            return self.engine.shard_query(C.c_void_p(self._totals_all.data_ptr()), self.world)[1]
+            return self.engine.shard_query(*self._tile_ptrs())[1]
 
     def states(self):
         return self.engine.states()

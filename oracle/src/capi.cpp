@@ -79,7 +79,7 @@ struct DynPf : IPf {
     }
     double ess(int mode) override {
         if (mode == MP_ESS_REFERENCE) return ps->effective_sample_size();
-        if (ps->canonical_resampling) return canonical_normalize(ps->log_weights, ps->num_particles).ess;
+        if (ps->canonical_resampling) return canonical_normalize(ps->log_weights, ps->num_particles).c.ess;
         const double L = logsumexp(ps->log_weights);
         std::vector<double> two;
         for (double w : ps->log_weights) two.push_back(2.0 * (w - L));
@@ -119,7 +119,7 @@ struct HmmPf : IPf {
     }
     double ess(int mode) override {
         if (mode == MP_ESS_REFERENCE) return ps->effective_sample_size();
-        if (ps->canonical_resampling) return canonical_normalize(ps->log_weights, ps->num_particles).ess;
+        if (ps->canonical_resampling) return canonical_normalize(ps->log_weights, ps->num_particles).c.ess;
         const double L = logsumexp(ps->log_weights);
         std::vector<double> two;
         for (double w : ps->log_weights) two.push_back(2.0 * (w - L));
@@ -285,12 +285,12 @@ static SoaPf* soa_of(oracle_pf* h) {
     if (!e || !h->canonical) throw Panic("shard phases: SoA engine in canonical mode only");
     return e->pf.get();
 }
-int32_t oracle_pf_shard_local_max(oracle_pf* h, double* out) { GUARD({ *out = soa_of(h)->shard_local_max(); }) }
-int32_t oracle_pf_shard_normalize(oracle_pf* h, const double* gmax, uint64_t* totals) {
-    GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_normalize(*gmax, totals); })
+int32_t oracle_pf_shard_tiles(oracle_pf* h, double* tm, uint64_t* tW, uint64_t* tW2) {
+    GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_tiles(tm, tW, tW2); })
 }
-int32_t oracle_pf_shard_route(oracle_pf* h, int32_t scheme, const uint64_t* totals_all, int32_t world, int32_t rank, uint64_t* req_out, int64_t* send_counts) {
-    GUARD({ oracle_pf::Scope s(true); soa_of(h)->scheme = scheme; soa_of(h)->shard_route(totals_all, world, rank, req_out, send_counts); })
+int32_t oracle_pf_shard_route(oracle_pf* h, int32_t scheme, const double* tm_all, const uint64_t* tW_all, const uint64_t* tW2_all, uint64_t nt_all,
+                              int32_t world, int32_t rank, uint64_t* req_out, int64_t* send_counts) {
+    GUARD({ oracle_pf::Scope s(true); soa_of(h)->scheme = scheme; soa_of(h)->shard_route(tm_all, tW_all, tW2_all, (size_t)nt_all, world, rank, req_out, send_counts); })
 }
 int32_t oracle_pf_shard_resolve(oracle_pf* h, const uint64_t* req_in, uint64_t n_req, double* rows) {
     GUARD({ soa_of(h)->shard_resolve(req_in, n_req, rows); })
@@ -298,8 +298,8 @@ int32_t oracle_pf_shard_resolve(oracle_pf* h, const uint64_t* req_in, uint64_t n
 int32_t oracle_pf_shard_scatter(oracle_pf* h, const double* rows, double* L) {
     GUARD({ const double l = soa_of(h)->shard_scatter(rows); if (L) *L = l; })
 }
-int32_t oracle_pf_shard_query(oracle_pf* h, const uint64_t* totals_all, int32_t world, double* lml, double* ess) {
-    GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_query(totals_all, world, lml, ess); })
+int32_t oracle_pf_shard_query(oracle_pf* h, const double* tm_all, const uint64_t* tW_all, const uint64_t* tW2_all, uint64_t nt_all, double* lml, double* ess) {
+    GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_query(tm_all, tW_all, tW2_all, (size_t)nt_all, lml, ess); })
 }
 
 // ---- importance.rs:12-50 ------------------------------------------------------------------------
@@ -318,8 +318,8 @@ int32_t oracle_importance_resampling(const mp_model_desc* m, const double* args0
             e->pf->init_step(args0, obs, n_steps);
             const std::vector<double>& w = e->pf->logw;
             double L;
-            CanonNorm c;
-            if (canon) { c = canonical_normalize(w, num_samples); if (c.m == -INFINITY) throw Panic("all log-weights are -inf"); L = c.L; }
+            CanonFull c;
+            if (canon) { c = canonical_normalize(w, num_samples); if (c.c.degenerate()) throw Panic("all log-weights are -inf"); L = c.c.L; }
             else L = logsumexp(w);
             if (log_ml_estimate) *log_ml_estimate = L - o_ln((double)num_samples);
             std::vector<double> probs;
@@ -334,7 +334,7 @@ int32_t oracle_importance_resampling(const mp_model_desc* m, const double* args0
                 if (!canon) { Categorical::check_sum(probs); double t = 0.; for (double p : probs) { t += p; cdf.push_back(t); } }
                 for (uint64_t j = 0; j < num_ret_samples; ++j) {
                     Rng r; r.seed = seed; r.slot = (uint32_t)j; r.step = 0; r.at(DOM_IS, 0);
-                    if (canon) resampled_indices[j] = canonical_parent(c.cum, canonical_target(r.u52(), c.Q));
+                    if (canon) resampled_indices[j] = canonical_parent(c, canonical_target(r.u52(), c.c.Q));
                     else {
                         const double u = r.u01();
                         if (!(0. < u)) throw Panic("categorical returned -1 (u == 0)");
@@ -484,10 +484,10 @@ void oracle_mvnormal_random(uint64_t seed, uint32_t slot, int32_t k, const doubl
 }
 // canonical resampling spec, exposed piecewise
 int32_t oracle_canonical_normalize(const double* logw, int64_t n, uint64_t n_global, double* L, double* ess, uint64_t* Q, uint64_t* cum) {
-    CanonNorm c = canonical_normalize(std::vector<double>(logw, logw + n), n_global);
-    *L = c.L; *ess = c.ess; *Q = c.Q;
-    if (cum) std::memcpy(cum, c.cum.data(), (size_t)n * sizeof(uint64_t));
-    return c.m == -INFINITY ? MP_ERR_DEGENERATE : MP_OK;
+    CanonFull c = canonical_normalize(std::vector<double>(logw, logw + n), n_global);
+    *L = c.c.L; *ess = c.c.ess; *Q = c.c.Q;
+    if (cum) std::memcpy(cum, c.t.cum.data(), (size_t)n * sizeof(uint64_t));  // tile-local inclusive prefixes
+    return c.c.degenerate() ? MP_ERR_DEGENERATE : MP_OK;
 }
 uint64_t oracle_canonical_target(uint64_t k52, uint64_t Q) { return canonical_target(k52, Q); }
 double oracle_kalman_log_ml(const double* params, const double* ys, int32_t T) {

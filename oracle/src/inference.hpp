@@ -104,32 +104,74 @@ inline int ceil_log2_u64(uint64_t n) {
     while (((uint64_t)1 << b) < n) ++b;
     return b;
 }
-struct CanonNorm {
-    int S = 0;            // fixed-point scale: q = rint(e * 2^S), S = 62 - ceil(log2(N_global))
-    double m = -INFINITY; // max log-weight
-    uint64_t Q = 0;       // sum of q_i
-    uint64_t Q2 = 0;      // sum of rint(e_i^2 * 2^S)
-    double L = -INFINITY; // log total weight = m + log(Q * 2^-S)
-    double ess = 0.;      // (Q*2^-S)^2 / (Q2*2^-S)
-    std::vector<uint64_t> cum;  // inclusive prefix sums of q
+// The spec is hierarchical so that the per-particle work needs no global quantity (the GPU does it inside the
+// propagate kernel) and so that shards never need each other's maxima:
+//   level 0, tile b = 2048 consecutive GLOBAL slots:  m_b = max lw;  a_i = mp_exp(lw_i - m_b);
+//            q_i = rint(a_i * 2^51);  cum = tile-local inclusive prefix;  W_b = sum q_i;  W2_b = sum rint(a_i^2 * 2^51)
+//   level 1, over tiles:  m = max_b m_b;  S = 62 - ceil(log2 N_global);
+//            T_b  = rint((double)W_b  * mp_exp(m_b - m)      * 2^(S-51));   Q  = sum T_b
+//            T2_b = rint((double)W2_b * mp_exp(2*(m_b - m))  * 2^(S-51));   Q2 = sum T2_b
+//            L = m + mp_log(Q * 2^-S);  ESS = (Q*2^-S)^2 / (Q2*2^-S)
+//   draw:    target in [1, Q] (canonical_target / _systematic);  tile b = first with inclT_b >= target;
+//            r = target - exclT_b;  lt = clamp((u64)ceil((double)r * ((double)W_b / (double)T_b)), 1, W_b);
+//            parent = first row of tile b with cum >= lt.
+// All sums are integer (any order / sharding gives the same bits); the only fp operations are single IEEE ops and
+// mp_exp / mp_log, evaluated identically on host and device.
+constexpr uint64_t CANON_TILE = 2048;
+struct CanonTiles {  // level 0 of a contiguous run of slots starting at a tile boundary
+    std::vector<double> m;       // per tile
+    std::vector<uint64_t> W, W2; // per tile
+    std::vector<uint64_t> cum;   // per element: tile-local inclusive prefix
 };
-inline double ldexp_pow2(int e) { return std::ldexp(1.0, e); }
-// `forced_max`: a sharded filter normalises every shard against the GLOBAL max (nullptr = this vector's own max)
-inline CanonNorm canonical_normalize(const std::vector<double>& logw, uint64_t n_global, const double* forced_max = nullptr) {
+inline CanonTiles canonical_tiles(const std::vector<double>& logw) {
+    CanonTiles t;
+    const size_t n = logw.size(), nt = (n + CANON_TILE - 1) / CANON_TILE;
+    t.m.assign(nt, -INFINITY); t.W.assign(nt, 0); t.W2.assign(nt, 0); t.cum.assign(n, 0);
+    const double scale = std::ldexp(1.0, 51);
+    for (size_t b = 0; b < nt; ++b) {
+        const size_t lo = b * CANON_TILE, hi = std::min(n, lo + CANON_TILE);
+        double mb = -INFINITY;
+        for (size_t i = lo; i < hi; ++i) mb = std::fmax(mb, logw[i]);
+        t.m[b] = mb;
+        const bool ok = (mb > -INFINITY) && (mb < INFINITY);
+        uint64_t run = 0, run2 = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const double a = ok ? mp_exp(logw[i] - mb) : 0.;
+            const double r = std::rint(a * scale), r2 = std::rint((a * a) * scale);
+            run += (r >= 0.) ? (uint64_t)r : 0;
+            run2 += (r2 >= 0.) ? (uint64_t)r2 : 0;
+            t.cum[i] = run;
+        }
+        t.W[b] = run; t.W2[b] = run2;
+    }
+    return t;
+}
+struct CanonNorm {
+    int S = 0;
+    double m = -INFINITY; // global max log-weight
+    uint64_t Q = 0, Q2 = 0;
+    double L = -INFINITY, ess = 0.;
+    std::vector<uint64_t> inclT;  // inclusive prefix of T_b over ALL tiles of the job
+    std::vector<uint64_t> W;      // W_b of all tiles
+    bool degenerate() const { return !(m > -INFINITY) || !(m < INFINITY) || Q == 0; }
+};
+// level 1 from the (m_b, W_b, W2_b) of all tiles of the job
+inline CanonNorm canonical_combine(const std::vector<double>& tm, const std::vector<uint64_t>& tW, const std::vector<uint64_t>& tW2, uint64_t n_global) {
     CanonNorm c;
     c.S = 62 - ceil_log2_u64(n_global);
-    if (forced_max) c.m = *forced_max;
-    else for (double x : logw) c.m = std::fmax(c.m, x);
-    c.cum.resize(logw.size());
-    if (c.m == -INFINITY) return c;  // degenerate: caller raises (reference: NaN weights -> assert panic)
-    const double scale = ldexp_pow2(c.S), inv = ldexp_pow2(-c.S);
+    for (double x : tm) c.m = std::fmax(c.m, x);
+    c.W = tW;
+    c.inclT.assign(tm.size(), 0);
+    if (!(c.m > -INFINITY) || !(c.m < INFINITY)) return c;
+    const double sc = std::ldexp(1.0, c.S - 51), inv = std::ldexp(1.0, -c.S);
     uint64_t run = 0;
-    for (size_t i = 0; i < logw.size(); ++i) {
-        const double e = mp_exp(logw[i] - c.m);
-        const uint64_t q = (uint64_t)std::rint(e * scale);
-        c.Q2 += (uint64_t)std::rint((e * e) * scale);
-        run += q;
-        c.cum[i] = run;
+    for (size_t b = 0; b < tm.size(); ++b) {
+        const double f = mp_exp(tm[b] - c.m);
+        const double t = std::rint((double)tW[b] * f * sc);
+        const double t2 = std::rint((double)tW2[b] * mp_exp(2. * (tm[b] - c.m)) * sc);
+        run += (t >= 0.) ? (uint64_t)t : 0;
+        c.Q2 += (t2 >= 0.) ? (uint64_t)t2 : 0;
+        c.inclT[b] = run;
     }
     c.Q = run;
     const double Qs = (double)c.Q * inv, Q2s = (double)c.Q2 * inv;
@@ -137,7 +179,41 @@ inline CanonNorm canonical_normalize(const std::vector<double>& logw, uint64_t n
     c.ess = (Qs * Qs) / Q2s;
     return c;
 }
-// target = max(1, ceil(k * Q / 2^52)); parent = first i with cum[i] >= target.
+// tile and tile-local target of a global target
+inline void canonical_locate(const CanonNorm& c, uint64_t target, size_t* tile, uint64_t* lt) {
+    size_t lo = 0, hi = c.inclT.size();
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (c.inclT[mid] >= target) hi = mid; else lo = mid + 1; }
+    if (lo >= c.inclT.size()) lo = c.inclT.size() - 1;
+    const uint64_t excl = lo ? c.inclT[lo - 1] : 0;
+    const uint64_t T = c.inclT[lo] - excl, r = target - excl;
+    const double ratio = (double)c.W[lo] / (double)T;
+    double v = std::ceil((double)r * ratio);
+    uint64_t x = (v >= 1.) ? (uint64_t)v : 1;
+    if (x > c.W[lo]) x = c.W[lo];
+    if (x < 1) x = 1;
+    *tile = lo; *lt = x;
+}
+// first row of tile `tile` (rows [tile*2048 - first_slot, ...) of `cum`) with cum >= lt; index into `cum`
+inline size_t canonical_row(const std::vector<uint64_t>& cum, size_t local_tile, uint64_t lt) {
+    const size_t lo0 = local_tile * CANON_TILE, hi0 = std::min(cum.size(), lo0 + CANON_TILE);
+    size_t lo = lo0, hi = hi0;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (cum[mid] >= lt) hi = mid; else lo = mid + 1; }
+    return lo < hi0 ? lo : hi0 - 1;
+}
+// convenience for an unsharded weight vector: everything at once
+struct CanonFull { CanonTiles t; CanonNorm c; };
+inline CanonFull canonical_normalize(const std::vector<double>& logw, uint64_t n_global) {
+    CanonFull f;
+    f.t = canonical_tiles(logw);
+    f.c = canonical_combine(f.t.m, f.t.W, f.t.W2, n_global);
+    return f;
+}
+inline size_t canonical_parent(const CanonFull& f, uint64_t target) {
+    size_t tile; uint64_t lt;
+    canonical_locate(f.c, target, &tile, &lt);
+    return canonical_row(f.t.cum, tile, lt);
+}
+// target = max(1, ceil(k * Q / 2^52))
 inline uint64_t canonical_target(uint64_t k52, uint64_t Q) {
     const unsigned __int128 p = (unsigned __int128)k52 * Q + (((unsigned __int128)1 << 52) - 1);
     const uint64_t t = (uint64_t)(p >> 52);
@@ -152,14 +228,6 @@ inline uint64_t canonical_target_systematic(uint64_t g, uint32_t k32, uint64_t Q
 inline uint32_t canonical_systematic_k32(uint64_t seed, uint32_t rc) {
     Rng r; r.seed = seed; r.slot = 0; r.step = rc; r.at(DOM_RESAMPLE, 1);
     return (uint32_t)(r.bits64() >> 32);
-}
-inline size_t canonical_parent(const std::vector<uint64_t>& cum, uint64_t target) {
-    size_t lo = 0, hi = cum.size();  // first index with cum >= target
-    while (lo < hi) {
-        const size_t mid = (lo + hi) / 2;
-        if (cum[mid] >= target) hi = mid; else lo = mid + 1;
-    }
-    return lo;
 }
 
 // ---- particle_filter.rs ---------------------------------------------------------------
@@ -259,14 +327,14 @@ struct ParticleSystem {
             log_ml_estimate += log_total_weight - o_ln((double)num_particles);
             multinomial_resampling();
         } else {
-            CanonNorm c = canonical_normalize(log_weights, num_particles);
-            if (c.m == -INFINITY) throw Panic("all log-weights are -inf: normalized weights are NaN");
-            log_total_weight = c.L;
-            canon_ess_stale = c.ess;
+            CanonFull c = canonical_normalize(log_weights, num_particles);
+            if (c.c.degenerate()) throw Panic("all log-weights are -inf: normalized weights are NaN");
+            log_total_weight = c.c.L;
+            canon_ess_stale = c.c.ess;
             log_ml_estimate += log_total_weight - o_ln((double)num_particles);
             for (size_t i = 0; i < num_particles; ++i) {
                 Rng r = rng_for(i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
-                parents[i] = canonical_parent(c.cum, canonical_target(r.u52(), c.Q));
+                parents[i] = canonical_parent(c, canonical_target(r.u52(), c.c.Q));
             }
         }
         ++resample_count;
@@ -279,8 +347,8 @@ struct ParticleSystem {
     }
     double log_marginal_likelihood_estimate() const {  // :119-121
         if (canonical_resampling) {
-            CanonNorm c = canonical_normalize(log_weights, num_particles);
-            return log_ml_estimate + c.L - o_ln((double)num_particles);
+            CanonFull c = canonical_normalize(log_weights, num_particles);
+            return log_ml_estimate + c.c.L - o_ln((double)num_particles);
         }
         return log_ml_estimate + logsumexp(log_weights) - o_ln((double)num_particles);
     }
@@ -297,7 +365,7 @@ struct ImportanceResult {
 template <class Args, class Data, class Ret>
 ImportanceResult<Args, Data, Ret> importance_sampling(uint64_t seed, const GenFn<Args, Data, Ret>& model, Args model_args,
                                                       Data constraints, uint32_t num_samples, bool canonical = false,
-                                                      CanonNorm* canon_out = nullptr) {
+                                                      CanonFull* canon_out = nullptr) {
     ImportanceResult<Args, Data, Ret> out;
     std::vector<double> w;
     for (uint32_t i = 0; i < num_samples; ++i) {  // importance.rs:18-20
@@ -310,9 +378,9 @@ ImportanceResult<Args, Data, Ret> importance_sampling(uint64_t seed, const GenFn
     if (!canonical) {
         log_total_weight = logsumexp(w);  // :21
     } else {
-        CanonNorm c = canonical_normalize(w, num_samples);
-        if (c.m == -INFINITY) throw Panic("all log-weights are -inf");
-        log_total_weight = c.L;
+        CanonFull c = canonical_normalize(w, num_samples);
+        if (c.c.degenerate()) throw Panic("all log-weights are -inf");
+        log_total_weight = c.c.L;
         if (canon_out) *canon_out = std::move(c);
     }
     out.log_ml_estimate = log_total_weight - o_ln((double)num_samples);  // :22
@@ -323,7 +391,7 @@ template <class Args, class Data, class Ret>
 ImportanceResult<Args, Data, Ret> importance_resampling(uint64_t seed, const GenFn<Args, Data, Ret>& model, Args model_args,
                                                         Data constraints, uint32_t num_samples, uint32_t num_ret_samples,
                                                         bool canonical = false) {
-    CanonNorm c;
+    CanonFull c;
     auto out = importance_sampling(seed, model, model_args, constraints, num_samples, canonical, &c);
     if (!canonical) {
         std::vector<double> probs;  // :44
@@ -337,7 +405,7 @@ ImportanceResult<Args, Data, Ret> importance_resampling(uint64_t seed, const Gen
     } else {
         for (uint32_t j = 0; j < num_ret_samples; ++j) {
             Rng r; r.seed = seed; r.slot = j; r.step = 0; r.at(DOM_IS, 0);
-            out.resampled_indices.push_back(canonical_parent(c.cum, canonical_target(r.u52(), c.Q)));
+            out.resampled_indices.push_back(canonical_parent(c, canonical_target(r.u52(), c.c.Q)));
         }
     }
     return out;

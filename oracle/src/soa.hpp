@@ -170,7 +170,7 @@ struct SoaPf {
     }
     double ess(bool fresh) const {
         if (!fresh) return ess_stale;
-        if (canonical) return canonical_normalize(logw, n_global).ess;
+        if (canonical) return canonical_normalize(logw, n_global).c.ess;
         const double L = logsumexp(logw);
         std::vector<double> two(n);
         for (size_t i = 0; i < n; ++i) two[i] = 2.0 * (logw[i] - L);
@@ -207,16 +207,16 @@ struct SoaPf {
                 }
             });
         } else {
-            CanonNorm c = canonical_normalize(logw, n_global);
-            if (c.m == -INFINITY) throw Panic("all log-weights are -inf");
-            L = c.L;
-            ess_stale = c.ess;
+            CanonFull c = canonical_normalize(logw, n_global);
+            if (c.c.degenerate()) throw Panic("all log-weights are -inf");
+            L = c.c.L;
+            ess_stale = c.c.ess;
             log_ml += L - o_ln((double)n_global);
             parallel_for([&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) {
                     Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
-                    if (scheme == 1) parents[i] = (uint32_t)canonical_parent(c.cum, canonical_target_systematic(slot_offset + i, canonical_systematic_k32(seed, resample_count), c.Q, n_global));
-                    else parents[i] = (uint32_t)canonical_parent(c.cum, canonical_target(r.u52(), c.Q));
+                    if (scheme == 1) parents[i] = (uint32_t)canonical_parent(c, canonical_target_systematic(slot_offset + i, canonical_systematic_k32(seed, resample_count), c.c.Q, n_global));
+                    else parents[i] = (uint32_t)canonical_parent(c, canonical_target(r.u52(), c.c.Q));
                 }
             });
         }
@@ -228,61 +228,58 @@ struct SoaPf {
         return L;
     }
     // ---- sharded resample, phase by phase (mirrors mp_pf_shard_* of include/modppl_hip.h) ----------
+    // Shards are tile-aligned (slot_offset and n multiples of 2048), so a shard's level-0 tiles are tiles of the job.
+    CanonTiles sh_t;
     CanonNorm sh_c;
     std::vector<uint32_t> sh_req_slot;
-    double sh_L = 0.;
-    double shard_local_max() const { double m = -INFINITY; for (double w : logw) m = std::fmax(m, w); return m; }
-    void shard_normalize(double gmax, uint64_t* totals) {
+    void shard_tiles(double* tm, uint64_t* tW, uint64_t* tW2) {
         if (!initialised) throw Panic("resample before init_step");
-        sh_c = canonical_normalize(logw, n_global, &gmax);
-        totals[0] = sh_c.Q; totals[1] = sh_c.Q2;
+        if (slot_offset % CANON_TILE) throw Panic("shards must start at a tile boundary");
+        sh_t = canonical_tiles(logw);
+        for (size_t b = 0; b < sh_t.m.size(); ++b) { tm[b] = sh_t.m[b]; tW[b] = sh_t.W[b]; tW2[b] = sh_t.W2[b]; }
     }
-    static void shard_scalars(const uint64_t* totals_all, int world, int S, double m, double* L, double* ess, uint64_t* Q) {
-        uint64_t q = 0, q2 = 0;
-        for (int r = 0; r < world; ++r) { q += totals_all[2 * r]; q2 += totals_all[2 * r + 1]; }
-        const double inv = ldexp_pow2(-S);
-        const double Qs = (double)q * inv, Q2s = (double)q2 * inv;
-        *L = m + mp_log(Qs);
-        *ess = (Qs * Qs) / Q2s;
-        *Q = q;
+    size_t n_tiles() const { return (n + CANON_TILE - 1) / CANON_TILE; }
+    void shard_combine(const double* tm_all, const uint64_t* tW_all, const uint64_t* tW2_all, size_t nt_all) {
+        sh_c = canonical_combine(std::vector<double>(tm_all, tm_all + nt_all), std::vector<uint64_t>(tW_all, tW_all + nt_all),
+                                 std::vector<uint64_t>(tW2_all, tW2_all + nt_all), n_global);
     }
-    void shard_route(const uint64_t* totals_all, int world, int rank, uint64_t* req_out, int64_t* send_counts) {
+    // requests are pairs (tile index inside the owner's shard, tile-local target)
+    void shard_route(const double* tm_all, const uint64_t* tW_all, const uint64_t* tW2_all, size_t nt_all, int world, int rank,
+                     uint64_t* req_out, int64_t* send_counts) {
         (void)rank;
-        if (sh_c.m == -INFINITY) throw Panic("all log-weights are -inf");
-        double L, ess; uint64_t Q;
-        shard_scalars(totals_all, world, sh_c.S, sh_c.m, &L, &ess, &Q);
-        std::vector<uint64_t> incl((size_t)world);
-        uint64_t run = 0;
-        for (int r = 0; r < world; ++r) { run += totals_all[2 * r]; incl[(size_t)r] = run; }
+        shard_combine(tm_all, tW_all, tW2_all, nt_all);
+        if (sh_c.degenerate()) throw Panic("all log-weights are -inf");
+        const size_t nt_local = nt_all / (size_t)world;
         std::vector<int> dest(n);
-        std::vector<uint64_t> lt(n);
+        std::vector<uint64_t> rt(n), rl(n);
         for (int r = 0; r < world; ++r) send_counts[r] = 0;
         for (size_t i = 0; i < n; ++i) {
             Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
-            const uint64_t target = scheme == 1 ? canonical_target_systematic(slot_offset + i, canonical_systematic_k32(seed, resample_count), Q, n_global)
-                                                : canonical_target(r.u52(), Q);
-            int s_ = 0;
-            while (s_ < world - 1 && incl[(size_t)s_] < target) ++s_;
-            dest[i] = s_;
-            lt[i] = target - (s_ ? incl[(size_t)s_ - 1] : 0);
-            send_counts[s_] += 1;
+            const uint64_t target = scheme == 1 ? canonical_target_systematic(slot_offset + i, canonical_systematic_k32(seed, resample_count), sh_c.Q, n_global)
+                                                : canonical_target(r.u52(), sh_c.Q);
+            size_t tile; uint64_t lt;
+            canonical_locate(sh_c, target, &tile, &lt);
+            dest[i] = (int)(tile / nt_local);
+            rt[i] = tile % nt_local;
+            rl[i] = lt;
+            send_counts[dest[i]] += 1;
         }
         std::vector<uint64_t> start((size_t)world, 0);
         for (int r = 1; r < world; ++r) start[(size_t)r] = start[(size_t)r - 1] + (uint64_t)send_counts[r - 1];
         sh_req_slot.assign(n, 0);
         for (size_t i = 0; i < n; ++i) {  // stable
             const uint64_t pos = start[(size_t)dest[i]]++;
-            req_out[pos] = lt[i];
+            req_out[2 * pos] = rt[i];
+            req_out[2 * pos + 1] = rl[i];
             sh_req_slot[pos] = (uint32_t)i;
         }
-        sh_L = L;
-        ess_stale = ess;
-        log_ml += L - o_ln((double)n_global);
+        ess_stale = sh_c.ess;
+        log_ml += sh_c.L - o_ln((double)n_global);
     }
     void shard_resolve(const uint64_t* req_in, uint64_t n_req, double* rows) const {
         const int d = model->dim_state;
         for (uint64_t q = 0; q < n_req; ++q) {
-            const size_t p = canonical_parent(sh_c.cum, req_in[q]);
+            const size_t p = canonical_row(sh_t.cum, (size_t)req_in[2 * q], req_in[2 * q + 1]);
             for (int j = 0; j < d; ++j) rows[q * (uint64_t)(d + 1) + j] = x[p * d + j];
             rows[q * (uint64_t)(d + 1) + d] = (double)(slot_offset + p);
         }
@@ -297,17 +294,16 @@ struct SoaPf {
         x.swap(x_tmp);
         std::fill(logw.begin(), logw.end(), 0.);
         ++resample_count;
-        return sh_L;
+        return sh_c.L;
     }
-    void shard_query(const uint64_t* totals_all, int world, double* lml, double* ess) const {
-        double L, e; uint64_t Q;
-        shard_scalars(totals_all, world, sh_c.S, sh_c.m, &L, &e, &Q);
-        if (lml) *lml = log_ml + L - o_ln((double)n_global);
-        if (ess) *ess = e;
+    void shard_query(const double* tm_all, const uint64_t* tW_all, const uint64_t* tW2_all, size_t nt_all, double* lml, double* ess) {
+        shard_combine(tm_all, tW_all, tW2_all, nt_all);
+        if (lml) *lml = log_ml + sh_c.L - o_ln((double)n_global);
+        if (ess) *ess = sh_c.ess;
     }
 
     double log_ml_estimate() const {
-        if (canonical) return log_ml + canonical_normalize(logw, n_global).L - o_ln((double)n_global);
+        if (canonical) return log_ml + canonical_normalize(logw, n_global).c.L - o_ln((double)n_global);
         return log_ml + logsumexp(logw) - o_ln((double)n);
     }
 };

@@ -66,12 +66,11 @@ def load():
     L.oracle_pf_time.argtypes = [p, C.POINTER(i64)]
     L.oracle_pf_destroy.argtypes = [p]
     L.oracle_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
-    L.oracle_pf_shard_local_max.argtypes = [p, p]
-    L.oracle_pf_shard_normalize.argtypes = [p, p, p]
-    L.oracle_pf_shard_route.argtypes = [p, i32, p, i32, i32, p, C.POINTER(i64)]
+    L.oracle_pf_shard_tiles.argtypes = [p, p, p, p]
+    L.oracle_pf_shard_route.argtypes = [p, i32, p, p, p, u64, i32, i32, p, C.POINTER(i64)]
     L.oracle_pf_shard_resolve.argtypes = [p, p, u64, p]
     L.oracle_pf_shard_scatter.argtypes = [p, p, dp]
-    L.oracle_pf_shard_query.argtypes = [p, p, i32, dp, dp]
+    L.oracle_pf_shard_query.argtypes = [p, p, p, p, u64, dp, dp]
     L.oracle_mh_create.argtypes = [dp, dp, i32, i32, u64, u64, i32, C.POINTER(p)]
     L.oracle_mh_step.argtypes = [p, d, i32, C.POINTER(u64)]
     L.oracle_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
@@ -317,15 +316,12 @@ class OracleShardEngine:
     def step(self, obs):
         self._ck(self.L.oracle_pf_step(self.h, dptr(obs), obs.shape[0]))
 
-    def shard_local_max(self, out_ptr):
-        self._ck(self.L.oracle_pf_shard_local_max(self.h, out_ptr))
+    def shard_tiles(self, tm_ptr, tw_ptr, tw2_ptr):
+        self._ck(self.L.oracle_pf_shard_tiles(self.h, tm_ptr, tw_ptr, tw2_ptr))
 
-    def shard_normalize(self, gmax_ptr, totals_ptr):
-        self._ck(self.L.oracle_pf_shard_normalize(self.h, gmax_ptr, totals_ptr))
-
-    def shard_route(self, scheme, totals_all_ptr, world, rank, req_ptr):
+    def shard_route(self, scheme, tm_ptr, tw_ptr, tw2_ptr, nt_all, world, rank, req_ptr):
         counts = (C.c_int64 * world)()
-        self._ck(self.L.oracle_pf_shard_route(self.h, scheme, totals_all_ptr, world, rank, req_ptr, counts))
+        self._ck(self.L.oracle_pf_shard_route(self.h, scheme, tm_ptr, tw_ptr, tw2_ptr, nt_all, world, rank, req_ptr, counts))
         return list(counts)
 
     def shard_resolve(self, req_ptr, n_req, rows_ptr):
@@ -336,9 +332,9 @@ class OracleShardEngine:
         self._ck(self.L.oracle_pf_shard_scatter(self.h, rows_ptr, C.byref(out) if want_value else None))
         return out.value if want_value else None
 
-    def shard_query(self, totals_all_ptr, world):
+    def shard_query(self, tm_ptr, tw_ptr, tw2_ptr, nt_all):
         lml, ess = C.c_double(), C.c_double()
-        self._ck(self.L.oracle_pf_shard_query(self.h, totals_all_ptr, world, C.byref(lml), C.byref(ess)))
+        self._ck(self.L.oracle_pf_shard_query(self.h, tm_ptr, tw_ptr, tw2_ptr, nt_all, C.byref(lml), C.byref(ess)))
         return lml.value, ess.value
 
     def ess_reference(self):

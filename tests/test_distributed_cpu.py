@@ -72,7 +72,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("model,n,t", [("lgssm", 6000, 8), ("band", 2048, 6)])
+@pytest.mark.parametrize("model,n,t", [("lgssm", 8192, 8), ("band", 4096, 6)])  # shards are tile-aligned (2048)
 def test_two_rank_filter_equals_single_filter(tmp_path, model, n, t):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)

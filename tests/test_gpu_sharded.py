@@ -88,7 +88,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("n,d", [(40000, 1), (8192, 16)])
+@pytest.mark.parametrize("n,d", [(40960, 1), (8192, 16)])  # shards are tile-aligned (2048)
 def test_two_ranks_one_gpu_equal_single_filter(tmp_path, n, d):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)

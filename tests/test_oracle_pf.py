@@ -73,6 +73,7 @@ def test_stale_ess_quirk():
 
 
 def test_canonical_spec_pieces(oracle):
+    """level 0 per tile of 2048 (51-bit fixed point relative to the tile max), level 1 over tiles."""
     rng = np.random.default_rng(0)
     n = 5000
     lw = rng.normal(-1.0, 2.0, n)
@@ -80,20 +81,24 @@ def test_canonical_spec_pieces(oracle):
     cum = np.empty(n, dtype=np.uint64)
     rc = oracle.oracle_canonical_normalize(O.dptr(lw), n, n, C.byref(L), C.byref(ess), C.byref(Q), cum.ctypes.data_as(C.POINTER(C.c_uint64)))
     assert rc == 0
-    S = 62 - 13
-    assert int(cum[-1]) == Q.value and Q.value < 2 ** 63
-    assert np.all(np.diff(cum.astype(object)) >= 0)
-    assert int(np.diff(np.concatenate([[0], cum]).astype(object)).max()) == 2 ** S  # the max particle gets exactly 2^S
+    assert Q.value < 2 ** 63
+    for b in range(3):   # tiles [0,2048), [2048,4096), [4096,5000): tile-local inclusive prefixes
+        seg = cum[b * 2048:(b + 1) * 2048].astype(object)
+        assert np.all(np.diff(seg) >= 0)
+        q = np.diff(np.concatenate([[0], seg]))
+        assert int(q.max()) == 2 ** 51                     # the tile's max particle gets exactly 2^51
+        w = np.exp(lw[b * 2048:(b + 1) * 2048] - lw[b * 2048:(b + 1) * 2048].max())
+        assert np.allclose(q.astype(float) / 2 ** 51, w, rtol=0, atol=2 ** -50)
     ref = float(np.logaddexp.reduce(lw))
     assert abs(L.value - ref) < 1e-12
     w = np.exp(lw - ref)
-    assert abs(ess.value - 1.0 / np.sum(w * w)) < 1e-6 * ess.value
+    assert abs(ess.value - 1.0 / np.sum(w * w)) < 1e-9 * ess.value
     # target rule: max(1, ceil(k Q / 2^52)); k = 0 -> 1 (first positive-weight particle), k = 2^52-1 -> <= Q
     assert oracle.oracle_canonical_target(0, Q.value) == 1
     assert oracle.oracle_canonical_target(2 ** 52 - 1, Q.value) <= Q.value
     for k in (1, 12345, 2 ** 51, 2 ** 52 - 1):
         assert oracle.oracle_canonical_target(k, Q.value) == max(1, -((-k * Q.value) // 2 ** 52))
-    # shard independence: normalising with n_global > n only changes the scale
+    # the scale S = 62 - ceil(log2 N_global) only enters level 1: a larger job changes Q, not L
     rc = oracle.oracle_canonical_normalize(O.dptr(lw), n, 8 * n, C.byref(L), C.byref(ess), C.byref(Q), None)
     assert abs(L.value - ref) < 1e-11
 
