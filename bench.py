@@ -29,7 +29,10 @@ DIM = 1
 #   propagate       = propagate+weight (16d+16) and level 0 of the normalisation fused into it (LSE read 8 + normalise/scan 8+8)
 #   normalize_scan  = the standalone form of that level 0 (only launched when the weights changed without a propagate)
 #   resample_gather = search 8+4, gather 4+16d, weight reset 8   (K3a + K3b together)
-BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "resample_gather": 8 + 4 + 4 + 16 * DIM + 8}
+#   bin_draws       = the search half of the resample (8 + 4)
+#   resample_gather = the gather half: 4 + 16d, weight reset 8
+BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "bin_draws": 8 + 4, "resample_gather": 4 + 16 * DIM + 8}
+KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_bin_draws", "resample_gather": "k_resolve_bins"}
 BYTES_STEP = 32 * DIM + 64
 
 
@@ -128,7 +131,7 @@ def main():
     lml = pf.log_marginal_likelihood_estimate()
     # ---- per-kernel durations: the same K steps again with a hipEvent pair around every launch, recorded on the
     # stream the kernels run on (the pairs cost ~20 us per step, so they stay out of the region `value` is taken from)
-    fam = {"propagate": (0.0, 0), "normalize_scan": (0.0, 0), "resample_gather": (0.0, 0)}
+    fam = {"propagate": (0.0, 0), "normalize_scan": (0.0, 0), "bin_draws": (0.0, 0), "resample_gather": (0.0, 0)}
     if not args.no_kernel_timing:
         timer.set_timing(True)
         for t in range(1 + W, T):
@@ -136,15 +139,15 @@ def main():
             pf.resample(sync=False)
         barrier()
         fam = {"propagate": timer.get_timing(capi.MP_K_PROPAGATE), "normalize_scan": timer.get_timing(capi.MP_K_NORMALIZE_SCAN),
-               "resample_gather": timer.get_timing(capi.MP_K_RESAMPLE_GATHER)}
+               "bin_draws": timer.get_timing(capi.MP_K_BIN_DRAWS), "resample_gather": timer.get_timing(capi.MP_K_RESAMPLE_GATHER)}
         timer.set_timing(False)
 
     if rank == 0:
-        # per SMC step: total family time / K (the resample family is two launches per step: K3a + K3b)
-        avg_us = {k: (v[0] / K) * 1e3 for k, v in fam.items()}
+        # mean duration of one launch of each kernel (single GPU: one launch of each per step)
+        avg_us = {k: (v[0] / v[1]) * 1e3 if v[1] else 0.0 for k, v in fam.items()}
         if not any(v[1] for v in fam.values()):
             avg_us = {k: float("nan") for k in fam}
-        dom = max(avg_us, key=lambda k: avg_us[k])
+        dom = max(fam, key=lambda k: fam[k][0])   # the kernel with the largest total time
         achieved = BYTES_K[dom] * n / (avg_us[dom] * 1e-6) / 1e9
         traffic = None
         if n == N_PER_GPU and os.path.exists(TRAFFIC_JSON):  # PMC passes cannot run inside this process: committed summary, same workload
@@ -174,7 +177,7 @@ def main():
             "step_hbm_frac": BYTES_STEP * n * K / dt / 1e9 / HBM_PEAK_GBPS,
             "kernel_avg_us": avg_us,
             "kernel_launches_per_step": {k: v[1] / K for k, v in fam.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "bytes_per_launch": BYTES_K[dom] * n},
         }

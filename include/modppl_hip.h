@@ -156,7 +156,13 @@ int32_t mp_pf_shard_query(mp_pf* h, const double* d_tile_m_all, const uint64_t* 
 /* ---- profiling hooks (bench.py: HIP-event timing on the stream the kernels run on) ------ */
 /* Accumulated GPU time (ms) and launch count of kernel family `which` since the last reset,
  * measured with hipEvents recorded around each launch when timing is enabled. */
-enum mp_kernel_family { MP_K_PROPAGATE = 0, MP_K_NORMALIZE_SCAN = 1, MP_K_RESAMPLE_GATHER = 2, MP_K_COUNT = 3 };
+enum mp_kernel_family {
+    MP_K_PROPAGATE = 0,       /* k_propagate: model kernel + level 0 of the normalisation            */
+    MP_K_NORMALIZE_SCAN = 1,  /* k_normalize_tiles: level 0 alone (weights changed without a propagate) */
+    MP_K_RESAMPLE_GATHER = 2, /* k_resolve_bins, or the single-kernel k_resample_gather / shard kernels */
+    MP_K_BIN_DRAWS = 3,       /* k_bin_draws                                                          */
+    MP_K_COUNT = 4
+};
 int32_t mp_pf_set_timing(mp_pf* h, int32_t enabled);
 int32_t mp_pf_get_timing(mp_pf* h, int32_t which, double* total_ms, uint64_t* launches);
 

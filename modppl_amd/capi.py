@@ -15,7 +15,7 @@ MP_MODEL_LGSSM1, MP_MODEL_SPIRAL, MP_MODEL_HMM, MP_MODEL_BEARINGS, MP_MODEL_LGSS
 MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC = 0, 1
 MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
 MP_PF_RECORD_HISTORY = 1
-MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER = 0, 1, 2
+MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER, MP_K_BIN_DRAWS = 0, 1, 2, 3
 MP_SITE_IS_LINEAR, MP_SITE_A, MP_SITE_B, MP_SITE_C = 0, 1, 2, 3
 MP_MH_MODEL_HIERARCHICAL = 1
 MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1

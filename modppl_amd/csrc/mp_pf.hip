@@ -1133,8 +1133,8 @@ struct mp_pf {
     bool timing = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
-    double fam_ms[MP_K_COUNT] = {0, 0, 0};
-    uint64_t fam_launches[MP_K_COUNT] = {0, 0, 0};
+    double fam_ms[MP_K_COUNT] = {0, 0, 0, 0};
+    uint64_t fam_launches[MP_K_COUNT] = {0, 0, 0, 0};
 };
 
 static hipEvent_t get_event(mp_pf* h) {
@@ -1390,13 +1390,16 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (rc != MP_OK) return rc;
     const int d = h->ops->dim_state;
     bool binned = false;
+    if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
+        LaunchTimer lt(h, MP_K_BIN_DRAWS);
+        const size_t lds_a = table_lds(h->nt, BIN_THREADS) + sizeof(uint32_t) * 2 * BIN_ITEMS * (BIN_THREADS / 64) * 8;
+        hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
+                           (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->guide,
+                           h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal);
+    }
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
-            const size_t lds_a = table_lds(h->nt, BIN_THREADS) + sizeof(uint32_t) * 2 * BIN_ITEMS * (BIN_THREADS / 64) * 8;
-            hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                               (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->guide,
-                               h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal);
             const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
             hipLaunchKernelGGL(k_resolve_bins, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, d, h->nchunks, h->seg_lt, h->seg_row,
                                h->seg_cnt, h->cx, h->x[h->cur], h->res_x, h->res_stride, h->res_parent);

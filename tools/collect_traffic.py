@@ -13,9 +13,9 @@ import glob
 import json
 import sys
 
-FAM = {"k_propagate": "propagate", "k_normalize_scan": "normalize_scan", "k_resample_gather": "resample_gather",
-       "k_bin_draws": "resample_gather", "k_resolve_bins": "resample_gather"}  # the resample family = K3a + K3b (or the single-kernel K3)
-STREAMING = {"propagate", "normalize_scan"}
+FAM = {"k_propagate": "propagate", "k_normalize_tiles": "normalize_scan", "k_resample_gather": "resample_gather",
+       "k_bin_draws": "bin_draws", "k_resolve_bins": "resample_gather"}
+STREAMING = {"propagate", "normalize_scan", "bin_draws"}
 
 
 def per_kernel(dirname, counter):
