@@ -13,6 +13,7 @@ depend on the number of shards (tests/test_distributed_cpu.py checks this bit fo
 """
 import contextlib
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -129,6 +130,8 @@ class ShardedParticleSystem:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # MP_SHARD_ALWAYS_COLLECTIVE=1: issue the collectives even in a world of one (exercises the backend's API path)
+        self._always = dist.is_initialized() and os.environ.get("MP_SHARD_ALWAYS_COLLECTIVE", "0") == "1"
         if num_particles % self.world:
             raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "num_particles must be divisible by the world size")
         self.model = model
@@ -157,14 +160,14 @@ class ShardedParticleSystem:
         return t if t.device == self.comm_dev else t.to(self.comm_dev)
 
     def _all_reduce_max(self, t):
-        if self.world > 1:
+        if self.world > 1 or self._always:
             c = self._c(t)
             dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
             if c is not t:
                 t.copy_(c)
 
     def _all_gather(self, out, t):
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             out.copy_(t)
             return
         c_in, c_out = self._c(t), self._c(out)
@@ -176,7 +179,7 @@ class ShardedParticleSystem:
     def _all_to_all(self, send, send_counts, recv_counts, width):
         """variable all-to-all of rows of `width` elements; returns the receive buffer (on self.dev)."""
         n_recv = int(sum(recv_counts))
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             return send[: n_recv * width]
         c_send = self._c(send[: int(sum(send_counts)) * width].contiguous())
         c_recv = torch.empty(n_recv * width, dtype=send.dtype, device=self.comm_dev)
@@ -222,7 +225,7 @@ class ShardedParticleSystem:
         self._normalize()
         tm, tw, tw2, nt_all = self._tile_ptrs()
         send_counts = self.engine.shard_route(scheme, tm, tw, tw2, nt_all, self.world, self.rank, C.c_void_p(self._req.data_ptr()))
-        if self.world > 1:
+        if self.world > 1 or self._always:
             sc = torch.tensor(send_counts, dtype=torch.int64, device=self.comm_dev)
             rc = torch.empty(self.world, dtype=torch.int64, device=self.comm_dev)
             dist.all_to_all_single(rc, sc, group=self.group)

@@ -100,3 +100,42 @@ def test_two_ranks_one_gpu_equal_single_filter(tmp_path, n, d):
     line = [l for l in res.stdout.splitlines() if l.startswith("RESULT")]
     assert line, res.stdout[-2000:] + res.stderr[-2000:]
     assert '"ok": true' in line[0], line[0]
+
+
+NCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["MP_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import modppl_amd
+from modppl_amd.distributed import ShardedParticleSystem
+from tests import oracle_lib as O
+ys = O.lgssm_observations(6)
+n, seed = 1 << 16, 9
+a = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+b = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)   # device tensors through RCCL
+a.init_step(None, ys[:1]); b.init_step(None, ys[:1])
+ok = True
+for t in range(1, 6):
+    ok &= a.resample() == b.resample()
+    ok &= bool(np.array_equal(a.parents, b.parents)) and bool(np.array_equal(a.states(), b.states()))
+    a.step(ys[t:t + 1]); b.step(ys[t:t + 1])
+ok &= a.log_marginal_likelihood_estimate() == b.log_marginal_likelihood_estimate()
+print("RESULT ok" if ok else "RESULT mismatch")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_collectives_world_of_one(tmp_path):
+    """The bench's transport (backend nccl = RCCL, device tensors) with every collective forced in a world of one:
+    all_gather_into_tensor, all_to_all_single with split sizes, on the shared stream."""
+    script = tmp_path / "worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, MP_ROOT=ROOT, MP_SHARD_ALWAYS_COLLECTIVE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "RESULT ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
