@@ -72,6 +72,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
+    # stdout carries exactly one JSON line: RCCL and the HIP runtime print banners on fd 1, so park it on stderr until then
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     if not torch.cuda.is_available():
@@ -94,7 +99,14 @@ def main():
     kalman = O.kalman_log_ml(ys)
 
     model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
-    if world == 1:
+    force_sharded = os.environ.get("MP_BENCH_FORCE_SHARDED", "0") == "1"  # diagnostics: the sharded code path in a world of one
+    if force_sharded and dist is None:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    if world == 1 and not force_sharded:
         pf = modppl_amd.ParticleSystem(model, n, 20241008, device=local_rank)
         timer = pf
     else:
@@ -170,7 +182,7 @@ def main():
             "data": "synthetic (observations simulated from the model, Philox seed 20241008)",
             "config": {"workload": "LGSSM d=1 bootstrap SMC, resample every step (BASELINE.json configs[1])",
                        "particles_per_gpu": n, "time_steps_timed": K, "particles_total": n * world,
-                       "parallelism": "1 GPU" if world == 1 else f"one filter sharded over {world} GPUs (RCCL all-reduce max + all-gather totals + all-to-all exchange)"},
+                       "parallelism": "1 GPU" if world == 1 else f"one filter sharded over {world} GPUs (RCCL all-gather of tile totals + all-to-all particle exchange)"},
             "log_ml": lml,
             "log_ml_abs_err_vs_kalman": abs(lml - kalman),
             "step_bytes_per_particle": BYTES_STEP,
@@ -183,7 +195,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ys, n)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

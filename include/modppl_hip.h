@@ -37,6 +37,7 @@ extern "C" {
 #define MP_ERR_DEGENERATE 4  /* all log-weights -inf: NaN probabilities, categorical.rs:23 assert    */
 #define MP_ERR_HIP 5         /* HIP runtime failure (no device, out of memory, launch failure)       */
 #define MP_ERR_UNSUPPORTED 6 /* model / option not compiled into the library                         */
+#define MP_ERR_CAPACITY 7    /* fixed-capacity sharded exchange overflowed: nothing committed, repeat variable-size */
 
 /* ---- models -------------------------------------------------------------------------- */
 enum mp_model_kind {
@@ -152,6 +153,20 @@ int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total
 /* log_marginal_likelihood_estimate / fresh ESS of the whole job from the gathered tiles (after shard_tiles). */
 int32_t mp_pf_shard_query(mp_pf* h, const double* d_tile_m_all, const uint64_t* d_tile_W_all, const uint64_t* d_tile_W2_all, int32_t world,
                           double* log_ml, double* ess);
+
+/* Fixed-capacity form of the same phases: nothing synchronises with the host and the all-to-alls have equal splits.
+ * Tiles travel packed, [3][tiles] 8-byte words per rank (bits of the f64 maxima, W, W2), gathered rank-major.  Requests:
+ * d_req[world][capacity + 1][2] with entry 0 = {count, overflow flag}; rows: d_rows[world][capacity][dim_state + 1].
+ * mp_pf_shard_scatter_fixed makes the one host round trip: if any pair of ranks needed more than `capacity` draws (every
+ * rank sees the same answer) it commits nothing and returns MP_ERR_CAPACITY; the caller then repeats the resample with
+ * the variable-size phases (mp_pf_shard_route/resolve/scatter), which read the same rows, tiles and Philox counters.
+ * Shard masses are equal up to O(cv / sqrt n), so a capacity of 1.25 n / world is only exceeded by collapsed weights. */
+int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out);
+int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
+                                uint64_t* d_req_out);
+int32_t mp_pf_shard_resolve_fixed(mp_pf* h, const uint64_t* d_req_in, int32_t world, uint64_t capacity, double* d_rows_out);
+int32_t mp_pf_shard_scatter_fixed(mp_pf* h, const double* d_rows_in, int32_t world, uint64_t capacity, double* log_total_weight);
+int32_t mp_pf_shard_query_packed(mp_pf* h, const uint64_t* d_tiles_all, int32_t world, double* log_ml, double* ess);
 
 /* ---- profiling hooks (bench.py: HIP-event timing on the stream the kernels run on) ------ */
 /* Accumulated GPU time (ms) and launch count of kernel family `which` since the last reset,

@@ -927,6 +927,120 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_scatter(u64 n, int D, cons
     }
 }
 
+
+// ---- fixed-capacity exchange (no host round trip) -------------------------------------------------
+// Gathered tiles arrive rank-major, [world][3][nt_local] 8-byte words (row 0: bits of the f64 tile maxima, row 1: W,
+// row 2: W2).  Requests travel in fixed segments: req[dst][cap + 1][2], entry 0 = {count, 0}; rows likewise
+// rows[src][cap][D + 1].  A pair (src, dst) exchanging more than `cap` draws sets the sticky overflow flag (the filter
+// then reports MP_ERR_UNSUPPORTED at the next synchronising call instead of continuing with dropped draws).
+__global__ __launch_bounds__(K3_THREADS) void k_pack_tiles(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                           const u64* __restrict__ tile_W2, int nt, u64* __restrict__ out) {
+    const int i = blockIdx.x * K3_THREADS + threadIdx.x;
+    if (i < nt) {
+        out[i] = mp_f2u(tile_m[i]);
+        out[nt + i] = tile_W[i];
+        out[2 * nt + i] = tile_W2[i];
+    }
+}
+__global__ __launch_bounds__(K3_THREADS) void k_unpack_tiles(const u64* __restrict__ packed, int world, int nt_local, double* __restrict__ tm,
+                                                             u64* __restrict__ tW, u64* __restrict__ tW2) {
+    const int i = blockIdx.x * K3_THREADS + threadIdx.x;
+    if (i < world * nt_local) {
+        const int r = i / nt_local, b = i % nt_local;
+        const u64* base = packed + (u64)r * 3 * nt_local;
+        tm[i] = mp_u2f(base[b]);
+        tW[i] = base[nt_local + b];
+        tW2[i] = base[2 * nt_local + b];
+    }
+}
+// pack into fixed segments (after k_shard_targets / k_shard_offsets)
+__global__ __launch_bounds__(SH_THREADS) void k_shard_pack_fixed(u64 n, const unsigned char* __restrict__ dest, const u64* __restrict__ lt_in,
+                                                                 const uint32_t* __restrict__ tile_in, const uint32_t* __restrict__ blockoff,
+                                                                 const long long* __restrict__ counts, int world, u64 cap,
+                                                                 u64* __restrict__ req_out, uint32_t* __restrict__ req_slot, int* overflow) {
+    __shared__ uint32_t s_wcnt[SH_THREADS / 64][SH_MAX_WORLD];
+    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = (i < n) ? (int)dest[i] : -1;
+    uint32_t my_rank_in_wave = 0;
+    for (int r = 0; r < world; ++r) {
+        const u64 bal = __ballot(s == r);
+        if (s == r) my_rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wcnt[wave][r] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {  // segment headers: {count, "some pair of mine overflowed"} — every owner learns it with the requests
+        int any = 0;
+        for (int r = 0; r < world; ++r) any |= ((u64)counts[r] > cap) ? 1 : 0;
+        if (threadIdx.x < world) {
+            const u64 c = (u64)counts[threadIdx.x];
+            u64* seg = req_out + (u64)threadIdx.x * (cap + 1) * 2;
+            seg[0] = c < cap ? c : cap;
+            seg[1] = (u64)any;
+        }
+        if (threadIdx.x == 0 && any) *overflow = 1;
+    }
+    if (s >= 0) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wcnt[w][s];
+        const u64 j = (u64)blockoff[(u64)blockIdx.x * world + s] + before + my_rank_in_wave;  // position inside the owner's segment
+        if (j < cap) {
+            u64* seg = req_out + (u64)s * (cap + 1) * 2;
+            seg[2 * (j + 1)] = (u64)tile_in[i];
+            seg[2 * (j + 1) + 1] = lt_in[i];
+            req_slot[(u64)s * cap + j] = (uint32_t)i;
+        }
+    }
+}
+// owner side over fixed segments: blockIdx.y = source rank
+__global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_fixed(u64 n, u64 cap, u64 slot_offset, int D, const u64* __restrict__ req,
+                                                                    const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                                    const u64* __restrict__ tile_W, const double* __restrict__ x,
+                                                                    double* __restrict__ rows, int* overflow) {
+    const int src = blockIdx.y;
+    const u64* seg = req + (u64)src * (cap + 1) * 2;
+    const u64 cnt = seg[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && seg[1]) *overflow = 1;
+    double* out_seg = rows + (u64)src * cap * (u64)(D + 1);
+    for (u64 q = (u64)blockIdx.x * K3_THREADS + threadIdx.x; q < cnt; q += (u64)gridDim.x * K3_THREADS) {
+        const u64 b = seg[2 * (q + 1)];
+        const u64 lt = seg[2 * (q + 1) + 1];
+        const int shift = mp_guide_shift(tile_W[b]);
+        const u64 tbase = b * TILE;
+        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+        uint32_t g = (uint32_t)(lt >> shift);
+        if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+        uint32_t j = guide[b * GUIDE_N + g];
+        if (j > tlen - 1) j = tlen - 1;
+        mp_cx row = load_row_nt(cx + tbase + j);
+        while (row.cum < lt && j + 1 < tlen) {
+            ++j;
+            row = load_row_nt(cx + tbase + j);
+        }
+        const u64 p = tbase + j;
+        double* out = out_seg + q * (u64)(D + 1);
+        out[0] = row.x0;
+        for (int d = 1; d < D; ++d) out[d] = x[(u64)d * n + p];
+        out[D] = (double)(slot_offset + p);
+    }
+}
+// requester side over fixed segments: blockIdx.y = owner rank
+__global__ __launch_bounds__(SH_THREADS) void k_shard_scatter_fixed(u64 n, u64 cap, int D, const double* __restrict__ rows,
+                                                                    const uint32_t* __restrict__ req_slot, const long long* __restrict__ counts,
+                                                                    double* __restrict__ x_new, uint32_t* __restrict__ parent,
+                                                                    double* __restrict__ logw) {
+    const int owner = blockIdx.y;
+    const u64 cnt = (u64)counts[owner] < cap ? (u64)counts[owner] : cap;
+    const double* seg = rows + (u64)owner * cap * (u64)(D + 1);
+    for (u64 j = (u64)blockIdx.x * SH_THREADS + threadIdx.x; j < cnt; j += (u64)gridDim.x * SH_THREADS) {
+        const uint32_t i = req_slot[(u64)owner * cap + j];
+        const double* in = seg + j * (u64)(D + 1);
+        for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = in[d];
+        parent[i] = (uint32_t)in[D];
+        logw[i] = 0.;
+    }
+}
+
 // transpose SoA [d][n] -> host-facing AoS [n][d]
 __global__ void k_soa_to_aos(const double* __restrict__ x, u64 n, int D, double* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1121,6 +1235,12 @@ struct mp_pf {
     long long* sh_counts = nullptr;
     long long* h_counts = nullptr;  // pinned
     int sh_world = 0;
+    u64 sh_cap = 0;                 // fixed-capacity exchange: request slots per (src, dst) pair
+    double* sh_tm_all = nullptr;    // unpacked gathered tiles
+    u64* sh_tW_all = nullptr;
+    u64* sh_tW2_all = nullptr;
+    int* sh_overflow = nullptr;
+    int* h_overflow = nullptr;      // pinned
     bool sharded = false;
     // ancestry record (MP_PF_RECORD_HISTORY): the event log from which `traces[i].retv` is rebuilt
     struct HistEvent { int kind; void* buf; };  // kind 0: states after an Unfold step ([d][n] f64); 1: parents of a resample ([n] u32)
@@ -1507,6 +1627,8 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
 }
 
 // ---- sharded phases ------------------------------------------------------------------------------
+static int32_t shard_scratch(mp_pf* h, int world, u64 cap);
+
 int32_t mp_pf_shard_tiles(mp_pf* h, double* d_tile_m, uint64_t* d_tile_W, uint64_t* d_tile_W2) {
     if (!h || !d_tile_m || !d_tile_W || !d_tile_W2) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
@@ -1528,19 +1650,9 @@ int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const double* d_tm_all, cons
     HIPCK(hipSetDevice(h->device));
     const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
     const int nt_all = h->nt * world;
-    if (!h->sh_dest || h->sh_world < world) {
-        (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
-        (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts);
-        if (h->h_counts) (void)hipHostFree(h->h_counts);
-        HIPCK(hipMalloc(&h->sh_dest, h->n));
-        HIPCK(hipMalloc(&h->sh_lt, sizeof(u64) * h->n));
-        HIPCK(hipMalloc(&h->sh_tile, sizeof(uint32_t) * h->n));
-        HIPCK(hipMalloc(&h->sh_req_slot, sizeof(uint32_t) * h->n));
-        HIPCK(hipMalloc(&h->sh_blockcount, sizeof(uint32_t) * (size_t)nblk * world));
-        HIPCK(hipMalloc(&h->sh_blockoff, sizeof(uint32_t) * (size_t)nblk * world));
-        HIPCK(hipMalloc(&h->sh_counts, sizeof(long long) * SH_MAX_WORLD));
-        HIPCK(hipHostMalloc(&h->h_counts, sizeof(long long) * SH_MAX_WORLD));
-        h->sh_world = world;
+    {
+        int32_t rcs = shard_scratch(h, world, h->sh_cap ? h->sh_cap : 1);
+        if (rcs != MP_OK) return rcs;
     }
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
@@ -1609,6 +1721,135 @@ int32_t mp_pf_shard_query(mp_pf* h, const double* d_tm_all, const uint64_t* d_tW
     hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, d_tm_all, (const u64*)d_tW_all,
                        (const u64*)d_tW2_all, nt_all, h->S, h->n_global, 1, h->scal);
     int32_t rc = check_launch("k_finalize_tiles");
+    if (rc != MP_OK) return rc;
+    rc = fetch_scalars(h);
+    if (rc != MP_OK) return rc;
+    if (log_ml) *log_ml = h->h_scal->lml_fresh;
+    if (ess) *ess = h->h_scal->ess_fresh;
+    return MP_OK;
+}
+
+
+// ---- fixed-capacity phases: nothing here synchronises with the host -------------------------------------
+static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
+    const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
+    if (h->sh_dest && h->sh_world >= world && h->sh_cap >= cap && h->sh_tm_all) return MP_OK;
+    (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
+    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all);
+    (void)hipFree(h->sh_overflow);
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
+    const u64 slots = std::max<u64>(h->n, (u64)world * cap);
+    HIPCK(hipMalloc(&h->sh_dest, h->n));
+    HIPCK(hipMalloc(&h->sh_lt, sizeof(u64) * h->n));
+    HIPCK(hipMalloc(&h->sh_tile, sizeof(uint32_t) * h->n));
+    HIPCK(hipMalloc(&h->sh_req_slot, sizeof(uint32_t) * slots));
+    HIPCK(hipMalloc(&h->sh_blockcount, sizeof(uint32_t) * (size_t)nblk * world));
+    HIPCK(hipMalloc(&h->sh_blockoff, sizeof(uint32_t) * (size_t)nblk * world));
+    HIPCK(hipMalloc(&h->sh_counts, sizeof(long long) * SH_MAX_WORLD));
+    HIPCK(hipMalloc(&h->sh_tm_all, sizeof(double) * (size_t)h->nt * world));
+    HIPCK(hipMalloc(&h->sh_tW_all, sizeof(u64) * (size_t)h->nt * world));
+    HIPCK(hipMalloc(&h->sh_tW2_all, sizeof(u64) * (size_t)h->nt * world));
+    HIPCK(hipMalloc(&h->sh_overflow, sizeof(int)));
+    HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
+    HIPCK(hipHostMalloc(&h->h_counts, sizeof(long long) * SH_MAX_WORLD));
+    if (!h->h_overflow) HIPCK(hipHostMalloc(&h->h_overflow, sizeof(int)));
+    h->sh_world = world;
+    h->sh_cap = cap;
+    return MP_OK;
+}
+
+int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out) {
+    if (!h || !d_tiles_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
+    HIPCK(hipSetDevice(h->device));
+    int32_t rc = ensure_rows(h);
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(k_pack_tiles, dim3((h->nt + K3_THREADS - 1) / K3_THREADS), dim3(K3_THREADS), 0, h->stream, h->tile_m, h->tile_W, h->tile_W2, h->nt,
+                       (u64*)d_tiles_out);
+    return check_launch("k_pack_tiles");
+}
+
+int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
+                                uint64_t* d_req_out) {
+    if (!h || !d_tiles_all || !d_req_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC) return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
+    if (world < 1 || world > SH_MAX_WORLD || rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, 0 <= rank < world");
+    if ((u64)world * h->n != h->n_global) return mp_fail(MP_ERR_INVALID_ARG, "equal tile-aligned shards: world * n_particles must equal n_global");
+    if (capacity == 0) return mp_fail(MP_ERR_INVALID_ARG, "capacity must be > 0");
+    HIPCK(hipSetDevice(h->device));
+    int32_t rc = shard_scratch(h, world, capacity);
+    if (rc != MP_OK) return rc;
+    const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
+    const int nt_all = h->nt * world;
+    {
+        LaunchTimer lt(h, MP_K_BIN_DRAWS);
+        hipLaunchKernelGGL(k_unpack_tiles, dim3((nt_all + K3_THREADS - 1) / K3_THREADS), dim3(K3_THREADS), 0, h->stream, (const u64*)d_tiles_all, world,
+                           h->nt, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all);
+        const size_t lds = table_lds(nt_all, SH_THREADS) + sizeof(uint32_t) * SH_MAX_WORLD;
+        hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
+                           (uint32_t)(h->seed >> 32), h->resample_count, scheme == MP_RESAMPLE_SYSTEMATIC ? 1 : 0, h->S, h->sh_tm_all, h->sh_tW_all,
+                           nt_all, h->nt, world, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockcount);
+        hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(SH_THREADS), 0, h->stream, h->sh_blockcount, nblk, world, h->sh_blockoff, h->sh_counts);
+        hipLaunchKernelGGL(k_shard_pack_fixed, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockoff,
+                           h->sh_counts, world, (u64)capacity, (u64*)d_req_out, h->sh_req_slot, h->sh_overflow);
+        hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, h->sh_tm_all, h->sh_tW_all,
+                           h->sh_tW2_all, nt_all, h->S, h->n_global, 0, h->scal);
+    }
+    return check_launch("shard_route_fixed kernels");
+}
+
+int32_t mp_pf_shard_resolve_fixed(mp_pf* h, const uint64_t* d_req_in, int32_t world, uint64_t capacity, double* d_rows_out) {
+    if (!h || !d_req_in || !d_rows_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    const unsigned gx = (unsigned)std::min<u64>((capacity + K3_THREADS - 1) / K3_THREADS, 1024);
+    {
+        LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
+        hipLaunchKernelGGL(k_shard_resolve_fixed, dim3(gx, world), dim3(K3_THREADS), 0, h->stream, h->n, (u64)capacity, h->slot_offset,
+                           h->ops->dim_state, (const u64*)d_req_in, h->cx, h->guide, h->tile_W, h->x[h->cur], d_rows_out, h->sh_overflow);
+    }
+    return check_launch("k_shard_resolve_fixed");
+}
+
+int32_t mp_pf_shard_scatter_fixed(mp_pf* h, const double* d_rows_in, int32_t world, uint64_t capacity, double* log_total_weight) {
+    if (!h || !d_rows_in) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (!h->sh_req_slot || h->sh_cap < capacity) return mp_fail(MP_ERR_STATE, "shard_scatter_fixed before shard_route_fixed");
+    HIPCK(hipSetDevice(h->device));
+    const unsigned gx = (unsigned)std::min<u64>((capacity + SH_THREADS - 1) / SH_THREADS, 1024);
+    {
+        LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
+        hipLaunchKernelGGL(k_shard_scatter_fixed, dim3(gx, world), dim3(SH_THREADS), 0, h->stream, h->n, (u64)capacity, h->ops->dim_state, d_rows_in,
+                           h->sh_req_slot, h->sh_counts, h->x[h->cur ^ 1], h->parent, h->logw);
+    }
+    int32_t rc = check_launch("k_shard_scatter_fixed");
+    if (rc != MP_OK) return rc;
+    // The one host round trip of this form: did any pair of ranks exceed the capacity?  (Every rank reaches the same
+    // answer: senders flag it in the request headers.)  If so nothing is committed; the caller repeats this resample with
+    // the variable-size phases, which read the same rows, tiles and Philox counters.
+    HIPCK(hipMemcpyAsync(h->h_overflow, h->sh_overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (log_total_weight) HIPCK(hipMemcpyAsync(h->h_scal, h->scal, sizeof(mp_dev_scalars), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (*h->h_overflow) {
+        HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
+        return mp_fail(MP_ERR_CAPACITY, "sharded exchange: one pair of ranks needs more than `capacity` draws; repeat with the variable-size phases");
+    }
+    h->cur ^= 1;
+    h->rows_fresh = false;
+    h->resample_count += 1;
+    if (log_total_weight) *log_total_weight = h->h_scal->L;
+    return MP_OK;
+}
+
+int32_t mp_pf_shard_query_packed(mp_pf* h, const uint64_t* d_tiles_all, int32_t world, double* log_ml, double* ess) {
+    if (!h || !d_tiles_all) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    int32_t rc = shard_scratch(h, world, h->sh_cap ? h->sh_cap : 1);
+    if (rc != MP_OK) return rc;
+    const int nt_all = h->nt * world;
+    hipLaunchKernelGGL(k_unpack_tiles, dim3((nt_all + K3_THREADS - 1) / K3_THREADS), dim3(K3_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt,
+                       h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all);
+    hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all,
+                       nt_all, h->S, h->n_global, 1, h->scal);
+    rc = check_launch("k_finalize_tiles");
     if (rc != MP_OK) return rc;
     rc = fetch_scalars(h);
     if (rc != MP_OK) return rc;
@@ -1709,8 +1950,10 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->aos);
     (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
-    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts);
+    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all);
+    (void)hipFree(h->sh_overflow);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
+    if (h->h_overflow) (void)hipHostFree(h->h_overflow);
     (void)hipHostFree(h->h_scal);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;

@@ -4,9 +4,13 @@ Collectives per resample (torch.distributed; backend "nccl" IS RCCL on ROCm, ove
 
     all_gather       24 B/tile  per-tile max log-weight + fixed-point totals of every shard: the weight "all-reduce";
                                 every rank builds the same tile table from them
-    all_to_all       counts     how many draws each rank asks of each owner
-    all_to_all       u64        the draws, routed to the rank that owns their CDF range
+    all_to_all       u64        the draws (tile, local target), routed to the rank that owns their CDF range
     all_to_all       f64 rows   the parents' states + global ids back to the asking rank (the particle exchange)
+
+Device-resident groups (RCCL) use fixed-capacity, equal-split all-to-alls (counts travel in the segment headers), so a
+resample enqueues 4 library calls + 3 collectives and touches the host once, at the end.  If one pair of ranks needs
+more than the capacity (collapsed weights) that resample is repeated with exact split sizes, which costs one more
+all-to-all of counts and a host round trip in the middle.  Host-staged groups (gloo) always use the exact-size form.
 
 Because Philox is keyed by GLOBAL slot and the fixed-point scale is global, the filter's results do not
 depend on the number of shards (tests/test_distributed_cpu.py checks this bit for bit with 2 ranks).
@@ -66,6 +70,32 @@ class HipShardEngine:
         out = C.c_double()
         capi.check(self._L.mp_pf_shard_scatter(self._h, rows_ptr, C.byref(out) if want_value else None))
         return out.value if want_value else None
+
+    # fixed-capacity form (no host round trip until the scatter): see include/modppl_hip.h
+    supports_fixed = True
+
+    def shard_tiles_packed(self, tiles_ptr):
+        capi.check(self._L.mp_pf_shard_tiles_packed(self._h, tiles_ptr))
+
+    def shard_route_fixed(self, scheme, tiles_all_ptr, world, rank, cap, req_ptr):
+        capi.check(self._L.mp_pf_shard_route_fixed(self._h, scheme, tiles_all_ptr, world, rank, cap, req_ptr))
+
+    def shard_resolve_fixed(self, req_ptr, world, cap, rows_ptr):
+        capi.check(self._L.mp_pf_shard_resolve_fixed(self._h, req_ptr, world, cap, rows_ptr))
+
+    def shard_scatter_fixed(self, rows_ptr, world, cap, want_value):
+        """-> (committed, log total weight or None)"""
+        out = C.c_double()
+        code = self._L.mp_pf_shard_scatter_fixed(self._h, rows_ptr, world, cap, C.byref(out) if want_value else None)
+        if code == capi.MP_ERR_CAPACITY:
+            return False, None
+        capi.check(code)
+        return True, (out.value if want_value else None)
+
+    def shard_query_packed(self, tiles_all_ptr, world):
+        lml, ess = C.c_double(), C.c_double()
+        capi.check(self._L.mp_pf_shard_query_packed(self._h, tiles_all_ptr, world, C.byref(lml), C.byref(ess)))
+        return lml.value, ess.value
 
     def shard_query(self, tm_ptr, tw_ptr, tw2_ptr, nt_all):
         lml, ess = C.c_double(), C.c_double()
@@ -154,6 +184,25 @@ class ShardedParticleSystem:
         self._tw2_all = torch.zeros(self.world * self.nt, dtype=torch.int64, device=self.dev)
         self._req = torch.zeros(2 * self.n, dtype=torch.int64, device=self.dev)
         self._rows = torch.zeros(self.n * (d + 1), dtype=torch.float64, device=self.dev)
+        # fixed-capacity exchange (device-resident process groups): equal-split all-to-alls, no host round trip until the
+        # scatter; a pair of ranks needing more than `cap` draws falls back to the variable-size phases for that resample
+        self._fixed = bool(getattr(self.engine, "supports_fixed", False)) and not host_staging \
+            and os.environ.get("MP_SHARD_FIXED", "1") == "1"
+        self.fallbacks = 0
+        if self._fixed:
+            slack = float(os.environ.get("MP_SHARD_SLACK", "1.25"))
+            per = self.n // self.world
+            self.cap = self.n if self.world == 1 else min(self.n, int(per * slack) + 1024)
+            self.cap = int(os.environ.get("MP_SHARD_CAP", self.cap))   # tests: force the overflow path
+            w, cap = self.world, self.cap
+            self._fx_req_out = torch.zeros(w * (cap + 1) * 2, dtype=torch.int64, device=self.dev)
+            self._fx_req_in = self._fx_req_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_req_out)
+            self._fx_rows_out = torch.zeros(w * cap * (d + 1), dtype=torch.float64, device=self.dev)
+            self._fx_rows_in = self._fx_rows_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_rows_out)
+            self._p_tiles = C.c_void_p(self._tiles.data_ptr())
+            self._p_tiles_all = C.c_void_p(self._tiles.data_ptr() if (w == 1 and not self._always) else self._tiles_all.data_ptr())
+            self._p_req_out, self._p_req_in = C.c_void_p(self._fx_req_out.data_ptr()), C.c_void_p(self._fx_req_in.data_ptr())
+            self._p_rows_out, self._p_rows_in = C.c_void_p(self._fx_rows_out.data_ptr()), C.c_void_p(self._fx_rows_in.data_ptr())
 
     # ---- collectives (identical for nccl/device tensors and gloo/CPU tensors) ----
     def _c(self, t):
@@ -220,7 +269,30 @@ class ShardedParticleSystem:
         with self._ctx():
             return self._resample(scheme, sync)
 
+    def _gather_tiles_packed(self):
+        self.engine.shard_tiles_packed(self._p_tiles)
+        if self.world > 1 or self._always:
+            dist.all_gather_into_tensor(self._tiles_all, self._tiles, group=self.group)
+
+    def _resample_fixed(self, scheme, sync):
+        """3 collectives (all-gather of tiles, all-to-all of draws, all-to-all of rows), 4 library calls, one host
+        round trip at the end."""
+        e, w, cap = self.engine, self.world, self.cap
+        self._gather_tiles_packed()
+        e.shard_route_fixed(scheme, self._p_tiles_all, w, self.rank, cap, self._p_req_out)
+        if w > 1 or self._always:
+            dist.all_to_all_single(self._fx_req_in, self._fx_req_out, group=self.group)
+        e.shard_resolve_fixed(self._p_req_in, w, cap, self._p_rows_out)
+        if w > 1 or self._always:
+            dist.all_to_all_single(self._fx_rows_in, self._fx_rows_out, group=self.group)
+        return e.shard_scatter_fixed(self._p_rows_in, w, cap, sync)
+
     def _resample(self, scheme, sync):
+        if self._fixed:
+            done, value = self._resample_fixed(scheme, sync)
+            if done:
+                return value
+            self.fallbacks += 1   # collapsed weights: one owner serves (nearly) everybody — exact sizes this time
         d = self.model.dim_state
         self._normalize()
         tm, tw, tw2, nt_all = self._tile_ptrs()
@@ -241,17 +313,21 @@ class ShardedParticleSystem:
             self._rows[: rows_in.numel()].copy_(rows_in)
         return self.engine.shard_scatter(C.c_void_p(self._rows.data_ptr()), sync)
 
-    def log_marginal_likelihood_estimate(self):
+    def _query(self):
         with self._ctx():
+            if self._fixed:
+                self._gather_tiles_packed()
+                return self.engine.shard_query_packed(self._p_tiles_all, self.world)
             self._normalize()
-            return self.engine.shard_query(*self._tile_ptrs())[0]
+            return self.engine.shard_query(*self._tile_ptrs())
+
+    def log_marginal_likelihood_estimate(self):
+        return self._query()[0]
 
     def effective_sample_size(self, fresh=False):
         if not fresh:
             return self.engine.ess_reference()
-        with self._ctx():
-            self._normalize()
-            return self.engine.shard_query(*self._tile_ptrs())[1]
+        return self._query()[1]
 
     def states(self):
         return self.engine.states()

@@ -122,20 +122,143 @@ for t in range(1, 6):
     ok &= bool(np.array_equal(a.parents, b.parents)) and bool(np.array_equal(a.states(), b.states()))
     a.step(ys[t:t + 1]); b.step(ys[t:t + 1])
 ok &= a.log_marginal_likelihood_estimate() == b.log_marginal_likelihood_estimate()
-print("RESULT ok" if ok else "RESULT mismatch")
+want_fb = os.environ.get("MP_EXPECT_FALLBACK", "0") == "1"
+ok &= (b.fallbacks > 0) == want_fb
+print("RESULT ok" if ok else "RESULT mismatch", b.fallbacks)
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-def test_rccl_collectives_world_of_one(tmp_path):
-    """The bench's transport (backend nccl = RCCL, device tensors) with every collective forced in a world of one:
-    all_gather_into_tensor, all_to_all_single with split sizes, on the shared stream."""
+@pytest.mark.parametrize("mode", ["fixed", "fixed_overflow", "variable"])
+def test_rccl_collectives_world_of_one(tmp_path, mode):
+    """The bench's transport (backend nccl = RCCL, device tensors) with every collective forced in a world of one, on the
+    shared stream: fixed-capacity equal-split all-to-alls; the same with a capacity too small (every resample falls back
+    to the exact-size phases without committing anything); exact-size phases only."""
     script = tmp_path / "worker.py"
     script.write_text(NCCL_WORKER)
-    env = dict(os.environ, MP_ROOT=ROOT, MP_SHARD_ALWAYS_COLLECTIVE="1")
+    extra = {"fixed": {}, "fixed_overflow": {"MP_SHARD_CAP": "1000", "MP_EXPECT_FALLBACK": "1"}, "variable": {"MP_SHARD_FIXED": "0"}}[mode]
+    env = dict(os.environ, MP_ROOT=ROOT, MP_SHARD_ALWAYS_COLLECTIVE="1", **extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "RESULT ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("d,cap_frac", [(1, 1.0), (4, 0.75)])
+def test_fixed_capacity_exchange_two_shards_in_process(d, cap_frac):
+    """World = 2 through the fixed-capacity phases, the collectives done by hand between two handles on the one GPU:
+    segment layout, per-source counts in the headers, scatter by owner.  Equal to ONE unsharded filter bit for bit."""
+    import ctypes as C
+
+    import torch
+
+    import modppl_amd
+    from modppl_amd.distributed import HipShardEngine
+
+    n, world, seed, T = 8192, 2, 77, 6
+    N = n * world
+    cap = int(n * cap_frac)
+    if d == 1:
+        model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+        obs = O.lgssm_observations(T).reshape(T, 1)
+    else:
+        model = modppl_amd.lgssm_band_model(d)
+        obs = np.random.default_rng(3).normal(0, 1.2, size=(T, d))
+    one = modppl_amd.ParticleSystem(model, N, seed)
+    eng = [HipShardEngine(model, n, N, r * n, seed) for r in range(world)]
+    nt = n // 2048
+    dev = eng[0].device
+    tiles = [torch.zeros(3 * nt, dtype=torch.int64, device=dev) for _ in range(world)]
+    req_out = [torch.zeros(world * (cap + 1) * 2, dtype=torch.int64, device=dev) for _ in range(world)]
+    rows_out = [torch.zeros(world * cap * (d + 1), dtype=torch.float64, device=dev) for _ in range(world)]
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+
+    def sync():
+        for e in eng:
+            e.synchronize()
+        torch.cuda.synchronize()
+
+    one.init_step(None, obs[:1])
+    for e in eng:
+        e.init_step(None, obs[:1])
+    for t in range(1, T):
+        for r, e in enumerate(eng):
+            e.shard_tiles_packed(ptr(tiles[r]))
+        sync()
+        tiles_all = torch.cat(tiles)                                   # all_gather_into_tensor
+        for r, e in enumerate(eng):
+            e.shard_route_fixed(0, ptr(tiles_all), world, r, cap, ptr(req_out[r]))
+        sync()
+        seg = (cap + 1) * 2                                            # all_to_all_single, equal splits
+        req_in = [torch.cat([req_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
+        for r, e in enumerate(eng):
+            e.shard_resolve_fixed(ptr(req_in[r]), world, cap, ptr(rows_out[r]))
+        sync()
+        seg = cap * (d + 1)
+        rows_in = [torch.cat([rows_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
+        res = [e.shard_scatter_fixed(ptr(rows_in[r]), world, cap, True) for r, e in enumerate(eng)]
+        L = one.resample()
+        assert all(done for done, _ in res)
+        assert all(v == L for _, v in res)
+        assert np.array_equal(np.concatenate([e.parents() for e in eng]), one.parents)
+        assert np.array_equal(np.concatenate([e.states() for e in eng]), one.states())
+        one.step(obs[t:t + 1])
+        for e in eng:
+            e.step(obs[t:t + 1])
+    assert np.array_equal(np.concatenate([e.log_weights() for e in eng]), one.log_weights)
+    for r, e in enumerate(eng):
+        e.shard_tiles_packed(ptr(tiles[r]))
+    sync()
+    tiles_all = torch.cat(tiles)
+    assert eng[0].shard_query_packed(ptr(tiles_all), world)[0] == one.log_marginal_likelihood_estimate()
+
+
+def test_fixed_capacity_overflow_commits_nothing():
+    """Capacity far too small for two shards: every rank reports MP_ERR_CAPACITY (the flag travels in the request
+    headers) and nothing is committed — states, weights and the resample counter are untouched."""
+    import ctypes as C
+
+    import torch
+
+    import modppl_amd
+    from modppl_amd.distributed import HipShardEngine
+
+    n, world, seed, cap = 4096, 2, 3, 512
+    N = n * world
+    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    obs = O.lgssm_observations(2).reshape(2, 1)
+    eng = [HipShardEngine(model, n, N, r * n, seed) for r in range(world)]
+    for e in eng:
+        e.init_step(None, obs[:1])
+    before = [(e.states().copy(), e.log_weights().copy()) for e in eng]
+    nt, dev = n // 2048, eng[0].device
+    tiles = [torch.zeros(3 * nt, dtype=torch.int64, device=dev) for _ in range(world)]
+    req_out = [torch.zeros(world * (cap + 1) * 2, dtype=torch.int64, device=dev) for _ in range(world)]
+    rows_out = [torch.zeros(world * cap * 2, dtype=torch.float64, device=dev) for _ in range(world)]
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+
+    def sync():
+        for e in eng:
+            e.synchronize()
+        torch.cuda.synchronize()
+
+    for r, e in enumerate(eng):
+        e.shard_tiles_packed(ptr(tiles[r]))
+    sync()
+    tiles_all = torch.cat(tiles)
+    for r, e in enumerate(eng):
+        e.shard_route_fixed(0, ptr(tiles_all), world, r, cap, ptr(req_out[r]))
+    sync()
+    seg = (cap + 1) * 2
+    req_in = [torch.cat([req_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
+    for r, e in enumerate(eng):
+        e.shard_resolve_fixed(ptr(req_in[r]), world, cap, ptr(rows_out[r]))
+    sync()
+    seg = cap * 2
+    rows_in = [torch.cat([rows_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
+    res = [e.shard_scatter_fixed(ptr(rows_in[r]), world, cap, True) for r, e in enumerate(eng)]
+    assert all(not done for done, _ in res)
+    for e, (x, w) in zip(eng, before):
+        assert np.array_equal(e.states(), x)
