@@ -154,18 +154,26 @@ int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total
 int32_t mp_pf_shard_query(mp_pf* h, const double* d_tile_m_all, const uint64_t* d_tile_W_all, const uint64_t* d_tile_W2_all, int32_t world,
                           double* log_ml, double* ess);
 
-/* Fixed-capacity form of the same phases: nothing synchronises with the host and the all-to-alls have equal splits.
- * Tiles travel packed, [3][tiles] 8-byte words per rank (bits of the f64 maxima, W, W2), gathered rank-major.  Requests:
- * d_req[world][capacity + 1][2] with entry 0 = {count, overflow flag}; rows: d_rows[world][capacity][dim_state + 1].
- * mp_pf_shard_scatter_fixed makes the one host round trip: if any pair of ranks needed more than `capacity` draws (every
+/* Fixed-capacity form of the same phases: nothing synchronises with the host until the scatter and the all-to-alls
+ * have equal splits.  Tiles travel packed, [3][tiles] 8-byte words per rank (bits of the f64 maxima, W, W2), gathered
+ * rank-major.  Draws are grouped by (owner rank, eighth of the owner's tiles) so the owner resolves each group on one XCD:
+ *   d_req [world][8][capacity + 1][2] u64   entry 0 of a sub-segment = {count, overflow flag}, then {tile, local target}
+ *   d_rows[world][8][capacity][dim_state + 1] f64   the parents' states and global ids, in request order
+ * mp_pf_shard_commit_fixed makes the one host wait: if any sub-segment needed more than `capacity` draws (every
  * rank sees the same answer) it commits nothing and returns MP_ERR_CAPACITY; the caller then repeats the resample with
  * the variable-size phases (mp_pf_shard_route/resolve/scatter), which read the same rows, tiles and Philox counters.
- * Shard masses are equal up to O(cv / sqrt n), so a capacity of 1.25 n / world is only exceeded by collapsed weights. */
-int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out);
+ * Sub-segment loads are equal up to O(cv sqrt(8 world / n)), so a capacity of 1.25 n / (8 world) is only exceeded by
+ * collapsed weights.  The order of requests inside a sub-segment is not deterministic; the filter's results are. */
+int32_t mp_pf_shard_bind_tiles(mp_pf* h, uint64_t* d_tiles);   /* from now on the filter keeps its packed tiles in this caller-owned
+                                                                  * buffer ([3][tiles] words): the all-gather reads it in place  */
+int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out); /* normalise if needed; copy unless d_tiles_out is the bound one */
 int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
                                 uint64_t* d_req_out);
 int32_t mp_pf_shard_resolve_fixed(mp_pf* h, const uint64_t* d_req_in, int32_t world, uint64_t capacity, double* d_rows_out);
-int32_t mp_pf_shard_scatter_fixed(mp_pf* h, const double* d_rows_in, int32_t world, uint64_t capacity, double* log_total_weight);
+/* Waits for the resolve only (not for the all-to-all that is carrying the rows into d_rows_in) and commits: the next
+ * mp_pf_step reads the parents' states straight from d_rows_in, which must therefore be filled by work enqueued on the
+ * filter's stream before that step and stay untouched until it has run; any other reader first copies them into slot order. */
+int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_total_weight);
 int32_t mp_pf_shard_query_packed(mp_pf* h, const uint64_t* d_tiles_all, int32_t world, double* log_ml, double* ess);
 
 /* ---- profiling hooks (bench.py: HIP-event timing on the stream the kernels run on) ------ */

@@ -25,6 +25,7 @@
 // The normalisation spec (hierarchical fixed point) is stated in DESIGN.md §4 and restated on the CPU in
 // oracle/src/inference.hpp.
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 #include <algorithm>
 #include <cstdlib>
@@ -273,7 +274,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_propagate(Model model, u64 n, 
                                                             const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
                                                             u64 res_stride, int nchunks, mp_cx* __restrict__ cx,
                                                             unsigned short* __restrict__ guide, double* __restrict__ tile_m,
-                                                            u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
+                                                            u64* __restrict__ tile_W, u64* __restrict__ tile_W2,
+                                                            const uint32_t* __restrict__ inv) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int ITEMS = k1_items<Model>();
@@ -322,7 +324,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_propagate(Model model, u64 n, 
             const u64 i = i0 + (u64)p;
             if (i < n) {
                 double prev[D], next[D];
-                if (perm) {
+                if (inv) {
+                    // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row
+                    // {x[0..D), parent id} is row inv[i] of the exchange buffer (res_x here)
+                    const double* row = res_x + (u64)inv[i] * (u64)(D + 1);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) prev[d] = row[d];
+                } else if (perm) {
                     // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at
                     // segment (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i]
                     const uint32_t pr_ = perm[i];
@@ -777,7 +785,7 @@ __global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __r
 // sharded resample, mode 2 = importance sampling (L and log_ml = L - ln N, importance.rs:21-22).
 __global__ __launch_bounds__(K3_THREADS) void k_finalize_tiles(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
                                                                const u64* __restrict__ tile_W2, int nt, int S, u64 n_global, int mode,
-                                                               mp_dev_scalars* scal) {
+                                                               mp_dev_scalars* scal, mp_dev_scalars* undo = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* s_incl = reinterpret_cast<u64*>(smem);
     u64* s_W = s_incl + nt;
@@ -787,6 +795,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_finalize_tiles(const double* __r
     const u64 Q = s_incl[nt - 1];
     const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
     if (threadIdx.x == 0) {
+        if (undo) *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
         if (mode == 2) {
             double L, ess;
             finalize_scalars(Q, Q2, S, &L, &ess, m);
@@ -844,18 +853,35 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_globa
     __syncthreads();
     if (threadIdx.x < world) blockcount[(u64)blockIdx.x * world + threadIdx.x] = s_cnt[threadIdx.x];
 }
-// pass 2 (one workgroup): per-owner totals and exclusive per-workgroup offsets
+// pass 2 (one workgroup per owner): per-owner totals and exclusive per-workgroup offsets
 __global__ __launch_bounds__(SH_THREADS) void k_shard_offsets(const uint32_t* __restrict__ blockcount, int nblk, int world,
                                                               uint32_t* __restrict__ blockoff, long long* __restrict__ counts) {
-    const int r = threadIdx.x;
-    if (r < world) {
-        uint32_t run = 0;
-        for (int b = 0; b < nblk; ++b) {
-            blockoff[(u64)b * world + r] = run;
-            run += blockcount[(u64)b * world + r];
-        }
-        counts[r] = (long long)run;
+    __shared__ uint32_t s_wave[SH_THREADS / 64];
+    const int r = blockIdx.x;
+    const int per = (nblk + SH_THREADS - 1) / SH_THREADS;
+    const int b0 = threadIdx.x * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    uint32_t mine = 0;
+    for (int b = b0; b < b1; ++b) mine += blockcount[(u64)b * world + r];
+    // exclusive scan of `mine` over the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
     }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < SH_THREADS / 64; ++w) {
+        if (w < wave) base += s_wave[w];
+        total += s_wave[w];
+    }
+    uint32_t run = base + inc - mine;
+    for (int b = b0; b < b1; ++b) {
+        blockoff[(u64)b * world + r] = run;
+        run += blockcount[(u64)b * world + r];
+    }
+    if (threadIdx.x == 0) counts[r] = (long long)total;
 }
 // pass 3: stable pack of the requests (tile in owner, tile-local target) grouped by owner
 __global__ __launch_bounds__(SH_THREADS) void k_shard_pack(u64 n, const unsigned char* __restrict__ dest, const u64* __restrict__ lt_in,
@@ -933,18 +959,10 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_scatter(u64 n, int D, cons
 // row 2: W2).  Requests travel in fixed segments: req[dst][cap + 1][2], entry 0 = {count, 0}; rows likewise
 // rows[src][cap][D + 1].  A pair (src, dst) exchanging more than `cap` draws sets the sticky overflow flag (the filter
 // then reports MP_ERR_UNSUPPORTED at the next synchronising call instead of continuing with dropped draws).
-__global__ __launch_bounds__(K3_THREADS) void k_pack_tiles(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
-                                                           const u64* __restrict__ tile_W2, int nt, u64* __restrict__ out) {
-    const int i = blockIdx.x * K3_THREADS + threadIdx.x;
-    if (i < nt) {
-        out[i] = mp_f2u(tile_m[i]);
-        out[nt + i] = tile_W[i];
-        out[2 * nt + i] = tile_W2[i];
-    }
-}
 __global__ __launch_bounds__(K3_THREADS) void k_unpack_tiles(const u64* __restrict__ packed, int world, int nt_local, double* __restrict__ tm,
-                                                             u64* __restrict__ tW, u64* __restrict__ tW2) {
+                                                             u64* __restrict__ tW, u64* __restrict__ tW2, long long* zero_counts = nullptr) {
     const int i = blockIdx.x * K3_THREADS + threadIdx.x;
+    if (zero_counts && i < 512) zero_counts[i] = 0;  // the per-(owner, eighth) request counters of the route that follows (SH_MAX_KEYS)
     if (i < world * nt_local) {
         const int r = i / nt_local, b = i % nt_local;
         const u64* base = packed + (u64)r * 3 * nt_local;
@@ -953,92 +971,192 @@ __global__ __launch_bounds__(K3_THREADS) void k_unpack_tiles(const u64* __restri
         tW2[i] = base[2 * nt_local + b];
     }
 }
-// pack into fixed segments (after k_shard_targets / k_shard_offsets)
-__global__ __launch_bounds__(SH_THREADS) void k_shard_pack_fixed(u64 n, const unsigned char* __restrict__ dest, const u64* __restrict__ lt_in,
-                                                                 const uint32_t* __restrict__ tile_in, const uint32_t* __restrict__ blockoff,
-                                                                 const long long* __restrict__ counts, int world, u64 cap,
-                                                                 u64* __restrict__ req_out, uint32_t* __restrict__ req_slot, int* overflow) {
-    __shared__ uint32_t s_wcnt[SH_THREADS / 64][SH_MAX_WORLD];
-    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = (i < n) ? (int)dest[i] : -1;
-    uint32_t my_rank_in_wave = 0;
-    for (int r = 0; r < world; ++r) {
-        const u64 bal = __ballot(s == r);
-        if (s == r) my_rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wcnt[wave][r] = (uint32_t)__popcll(bal);
+// Fixed-capacity route in ONE pass: target -> owner / tile / local target, and the request is written straight into the
+// sub-segment (owner, eighth of the owner's tiles).  Places come from one global atomic per (workgroup, sub-segment), so
+// the order of requests inside a sub-segment varies from run to run; the results do not (inv[i] remembers where the
+// request of slot i went, which is where its row comes back).  Grouping by eighth lets the owner resolve each group on one XCD, whose L2 then holds
+// that eighth of its rows (the same trick as k_bin_draws / k_resolve_bins).
+// what the owner-side resolve publishes to host-mapped memory when its last workgroup finishes
+struct mp_shard_pub {
+    int overflow;
+    int degenerate;
+    double L;
+};
+constexpr int SHF_ITEMS = 4;
+constexpr int SH_BINS = 8;
+constexpr int SH_MAX_KEYS = SH_MAX_WORLD * SH_BINS;
+__global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
+                                                                  int systematic, int S, const double* __restrict__ tm_all,
+                                                                  const u64* __restrict__ tW_all, int nt_all, int nt_local, int world, u64 capb,
+                                                                  unsigned long long* __restrict__ counts, u64* __restrict__ req_out,
+                                                                  uint32_t* __restrict__ inv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt_all;
+    double* s_red = reinterpret_cast<double*>(s_W + nt_all);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + SH_THREADS / 64);
+    u64* s_base = s_wtot + SH_THREADS / 64;                                   // [keys] start inside the sub-segment
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_base + SH_MAX_KEYS);      // [keys] draws of this workgroup per sub-segment
+    const int keys = world * SH_BINS;
+    for (int k = threadIdx.x; k < keys; k += SH_THREADS) s_cnt[k] = 0;
+    block_tile_table<SH_THREADS>(tm_all, tW_all, nt_all, S, s_incl, s_W, s_red, s_wtot);   // ends with a barrier
+    const u64 Q = s_incl[nt_all - 1];
+    const double nt_over_Q = (double)nt_all / (double)Q;
+    const u64 i0 = (u64)blockIdx.x * (SH_THREADS * SHF_ITEMS) + threadIdx.x;
+    const uint32_t k32 = systematic ? mp_systematic_k32(rc, k0, k1) : 0u;
+    int key[SHF_ITEMS];
+    uint32_t tl[SHF_ITEMS], place[SHF_ITEMS];
+    u64 lt[SHF_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SHF_ITEMS; ++k) {
+        const u64 i = i0 + (u64)k * SH_THREADS;
+        key[k] = -1;
+        if (i < n) {
+            u64 target;
+            if (systematic) {
+                target = mp_target_systematic(slot_offset + i, k32, Q, n_global);
+            } else {
+                const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+                target = mp_target(mp_u52(r.a), Q);
+            }
+            uint32_t b, gs;
+            mp_locate(s_incl, s_W, (uint32_t)nt_all, target, nt_over_Q, &b, &lt[k], &gs);
+            const uint32_t own = b / (uint32_t)nt_local;
+            tl[k] = b - own * (uint32_t)nt_local;
+            key[k] = (int)(own * SH_BINS + (tl[k] * SH_BINS) / (uint32_t)nt_local);
+            place[k] = atomicAdd(&s_cnt[key[k]], 1u);
+        }
     }
     __syncthreads();
-    if (blockIdx.x == 0) {  // segment headers: {count, "some pair of mine overflowed"} — every owner learns it with the requests
-        int any = 0;
-        for (int r = 0; r < world; ++r) any |= ((u64)counts[r] > cap) ? 1 : 0;
-        if (threadIdx.x < world) {
-            const u64 c = (u64)counts[threadIdx.x];
-            u64* seg = req_out + (u64)threadIdx.x * (cap + 1) * 2;
-            seg[0] = c < cap ? c : cap;
-            seg[1] = (u64)any;
-        }
-        if (threadIdx.x == 0 && any) *overflow = 1;
-    }
-    if (s >= 0) {
-        uint32_t before = 0;
-        for (int w = 0; w < wave; ++w) before += s_wcnt[w][s];
-        const u64 j = (u64)blockoff[(u64)blockIdx.x * world + s] + before + my_rank_in_wave;  // position inside the owner's segment
-        if (j < cap) {
-            u64* seg = req_out + (u64)s * (cap + 1) * 2;
-            seg[2 * (j + 1)] = (u64)tile_in[i];
-            seg[2 * (j + 1) + 1] = lt_in[i];
-            req_slot[(u64)s * cap + j] = (uint32_t)i;
+    for (int k = threadIdx.x; k < keys; k += SH_THREADS)
+        s_base[k] = s_cnt[k] ? atomicAdd(&counts[k], (unsigned long long)s_cnt[k]) : 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SHF_ITEMS; ++k) {
+        if (key[k] >= 0) {
+            const u64 j = s_base[key[k]] + place[k];
+            if (j < capb) {
+                ulonglong2* sub = reinterpret_cast<ulonglong2*>(req_out) + (u64)key[k] * (capb + 1);
+                sub[j + 1] = make_ulonglong2((u64)tl[k], lt[k]);
+                inv[i0 + (u64)k * SH_THREADS] = (uint32_t)((u64)key[k] * capb + j);
+            }
         }
     }
 }
-// owner side over fixed segments: blockIdx.y = source rank
-__global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_fixed(u64 n, u64 cap, u64 slot_offset, int D, const u64* __restrict__ req,
-                                                                    const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
-                                                                    const u64* __restrict__ tile_W, const double* __restrict__ x,
-                                                                    double* __restrict__ rows, int* overflow) {
-    const int src = blockIdx.y;
-    const u64* seg = req + (u64)src * (cap + 1) * 2;
-    const u64 cnt = seg[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && seg[1]) *overflow = 1;
-    double* out_seg = rows + (u64)src * cap * (u64)(D + 1);
-    for (u64 q = (u64)blockIdx.x * K3_THREADS + threadIdx.x; q < cnt; q += (u64)gridDim.x * K3_THREADS) {
-        const u64 b = seg[2 * (q + 1)];
-        const u64 lt = seg[2 * (q + 1) + 1];
-        const int shift = mp_guide_shift(tile_W[b]);
-        const u64 tbase = b * TILE;
-        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
-        uint32_t g = (uint32_t)(lt >> shift);
-        if (g > GUIDE_N - 1) g = GUIDE_N - 1;
-        uint32_t j = guide[b * GUIDE_N + g];
-        if (j > tlen - 1) j = tlen - 1;
-        mp_cx row = load_row_nt(cx + tbase + j);
-        while (row.cum < lt && j + 1 < tlen) {
-            ++j;
-            row = load_row_nt(cx + tbase + j);
-        }
-        const u64 p = tbase + j;
-        double* out = out_seg + q * (u64)(D + 1);
-        out[0] = row.x0;
-        for (int d = 1; d < D; ++d) out[d] = x[(u64)d * n + p];
-        out[D] = (double)(slot_offset + p);
+// Level 1 of a sharded resample + the sub-segment headers {count, "some sub-segment of mine overflowed"}, once every
+// workgroup of the route has reserved its places.  One workgroup.
+__global__ __launch_bounds__(K3_THREADS) void k_shard_finalize(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                               const u64* __restrict__ tile_W2, int nt, int S, u64 n_global, mp_dev_scalars* scal,
+                                                               mp_dev_scalars* undo, const unsigned long long* __restrict__ counts, int world,
+                                                               u64 capb, u64* __restrict__ req_out, int* overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt;
+    double* s_red = reinterpret_cast<double*>(s_W + nt);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + K3_THREADS / 64);
+    const int keys = world * SH_BINS;
+    int mine = 0;
+    for (int k = threadIdx.x; k < keys; k += K3_THREADS) mine |= (counts[k] > capb) ? 1 : 0;
+    const int any = __syncthreads_or(mine);
+    for (int k = threadIdx.x; k < keys; k += K3_THREADS) {
+        const u64 c = counts[k];
+        u64* sub = req_out + (u64)k * (capb + 1) * 2;
+        sub[0] = c < capb ? c : capb;
+        sub[1] = (u64)any;
+    }
+    if (threadIdx.x == 0 && any) *overflow = 1;
+    const double m = block_tile_table<K3_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
+    const u64 Q = s_incl[nt - 1];
+    const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+    if (threadIdx.x == 0) {
+        *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
+        fold_scalars(scal, Q, Q2, S, m, n_global, 0);
     }
 }
-// requester side over fixed segments: blockIdx.y = owner rank
-__global__ __launch_bounds__(SH_THREADS) void k_shard_scatter_fixed(u64 n, u64 cap, int D, const double* __restrict__ rows,
-                                                                    const uint32_t* __restrict__ req_slot, const long long* __restrict__ counts,
-                                                                    double* __restrict__ x_new, uint32_t* __restrict__ parent,
-                                                                    double* __restrict__ logw) {
-    const int owner = blockIdx.y;
-    const u64 cnt = (u64)counts[owner] < cap ? (u64)counts[owner] : cap;
-    const double* seg = rows + (u64)owner * cap * (u64)(D + 1);
-    for (u64 j = (u64)blockIdx.x * SH_THREADS + threadIdx.x; j < cnt; j += (u64)gridDim.x * SH_THREADS) {
-        const uint32_t i = req_slot[(u64)owner * cap + j];
-        const double* in = seg + j * (u64)(D + 1);
-        for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = in[d];
-        parent[i] = (uint32_t)in[D];
-        logw[i] = 0.;
+// owner side: blockIdx.x & 7 = eighth of this shard's tiles (workgroups are dealt round-robin to the 8 XCDs, gridDim.x is
+// a multiple of 8), blockIdx.y = asking rank.  Per request: guide cell -> first row -> short forward walk, all inside
+// the eighth.  Rows go back in the order the requests came.
+__global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 capb, u64 slot_offset, int D, const u64* __restrict__ req,
+                                                                     const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                                     const u64* __restrict__ tile_W, const double* __restrict__ x,
+                                                                     double* __restrict__ rows, int* overflow) {
+    const int bin = blockIdx.x & (SH_BINS - 1), grp = blockIdx.x >> 3, ngrp = gridDim.x >> 3;
+    const u64 key = (u64)blockIdx.y * SH_BINS + bin;
+    const ulonglong2* sub = reinterpret_cast<const ulonglong2*>(req) + key * (capb + 1);
+    const ulonglong2 head = sub[0];
+    const u64 cnt = head.x < capb ? head.x : capb;
+    if (grp == 0 && threadIdx.x == 0 && head.y) *overflow = 1;
+    double* out_sub = rows + key * capb * (u64)(D + 1);
+    for (u64 q0 = (u64)grp * (K3_THREADS * K3_ITEMS); q0 < cnt; q0 += (u64)ngrp * (K3_THREADS * K3_ITEMS)) {
+        u64 lt[K3_ITEMS], tbase[K3_ITEMS], last[K3_ITEMS];
+        uint32_t gi[K3_ITEMS];
+        bool live[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 0: the requests (coalesced)
+            const u64 q = q0 + (u64)k * K3_THREADS + threadIdx.x;
+            live[k] = q < cnt;
+            const ulonglong2 e = live[k] ? sub[q + 1] : make_ulonglong2(0ull, 1ull);
+            const u64 b = e.x;
+            lt[k] = e.y;
+            tbase[k] = b * TILE;
+            const u64 tend = tbase[k] + TILE;
+            last[k] = (tend < n ? tend : n) - 1;
+            uint32_t g = (uint32_t)(lt[k] >> mp_guide_shift(tile_W[b]));
+            if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+            gi[k] = (uint32_t)b * (uint32_t)GUIDE_N + g;
+        }
+        u64 p[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 1: guide cells
+            u64 j = tbase[k] + guide[gi[k]];
+            p[k] = j < last[k] ? j : last[k];
+        }
+        mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 2: the row and its successor
+            r0[k] = cx[p[k]];
+            r1[k] = cx[p[k] + (p[k] < last[k] ? 1 : 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {
+            if (!live[k]) continue;
+            mp_cx cur = r0[k];
+            u64 pp = p[k];
+            if (cur.cum < lt[k] && pp < last[k]) {
+                cur = r1[k];
+                ++pp;
+                while (cur.cum < lt[k] && pp < last[k]) {
+                    ++pp;
+                    cur = cx[pp];
+                }
+            }
+            const u64 q = q0 + (u64)k * K3_THREADS + threadIdx.x;
+            double* out = out_sub + q * (u64)(D + 1);
+            if (D == 1) {
+                *reinterpret_cast<double2*>(out) = make_double2(cur.x0, (double)(slot_offset + pp));
+            } else {
+                out[0] = cur.x0;
+                for (int d = 1; d < D; ++d) out[d] = x[(u64)d * n + pp];
+                out[D] = (double)(slot_offset + pp);
+            }
+        }
     }
+}
+// after the resolve: "somebody overflowed" and the scalars of this normalisation, where the host reads them after waiting
+// for ev_resolved (host-mapped memory: no copy command, no stream sync)
+__global__ void k_shard_publish(const int* overflow, const mp_dev_scalars* scal, mp_shard_pub* pub) {
+    pub->L = scal->L;
+    pub->degenerate = scal->degenerate;
+    pub->overflow = *overflow;
+}
+// requester side, only when something other than the next propagate needs slot order: x[i], parent[i] from row inv[i]
+__global__ __launch_bounds__(SH_THREADS) void k_shard_adopt_rows(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ inv,
+                                                                 double* __restrict__ x_new, uint32_t* __restrict__ parent) {
+    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const double* in = rows + (u64)inv[i] * (u64)(D + 1);
+    for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = in[d];
+    parent[i] = (uint32_t)in[D];
 }
 
 // transpose SoA [d][n] -> host-facing AoS [n][d]
@@ -1086,6 +1204,7 @@ struct PropagateArgs {
     double* tile_m;
     u64* tile_W;
     u64* tile_W2;
+    const uint32_t* inv;
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
@@ -1104,7 +1223,7 @@ struct ModelOpsT : ModelOps {
     void propagate(const PropagateArgs& a) const override {
         hipLaunchKernelGGL(k_propagate<Model>, dim3(a.grid), dim3(TILE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.res_stride, a.nchunks, a.cx, a.guide,
-                           a.tile_m, a.tile_W, a.tile_W2);
+                           a.tile_m, a.tile_W, a.tile_W2, a.inv);
     }
 };
 
@@ -1240,7 +1359,15 @@ struct mp_pf {
     u64* sh_tW_all = nullptr;
     u64* sh_tW2_all = nullptr;
     int* sh_overflow = nullptr;
-    int* h_overflow = nullptr;      // pinned
+    u64* tiles_own = nullptr;       // the allocation behind tile_m / tile_W / tile_W2 unless the caller bound its own buffer
+    mp_shard_pub* h_pub = nullptr;  // pinned, host-mapped
+    mp_shard_pub* d_pub = nullptr;  // its device address
+    hipEvent_t ev_resolved = nullptr;
+    bool sh_lazy = false;           // the states of the last sharded resample still sit in the exchange buffer sh_rows, slot i at row sh_req_slot[i]
+    const double* sh_rows = nullptr;
+    u64 sh_rows_cap = 0;
+    bool logw_zero = false;         // log-weights are all zero (after a sharded resample) and the buffer has not been cleared
+    mp_dev_scalars* scal_undo = nullptr;  // the scalars before a fixed-capacity route folded this resample in
     bool sharded = false;
     // ancestry record (MP_PF_RECORD_HISTORY): the event log from which `traces[i].retv` is rebuilt
     struct HistEvent { int kind; void* buf; };  // kind 0: states after an Unfold step ([d][n] f64); 1: parents of a resample ([n] u32)
@@ -1317,6 +1444,17 @@ static int32_t fetch_scalars(mp_pf* h) {
 
 // Slot-order x / parent / logw after a binned resample (only when something other than the next step needs them).
 static int32_t materialize(mp_pf* h) {
+    if (h->sh_lazy) {
+        hipLaunchKernelGGL(k_shard_adopt_rows, dim3((unsigned)((h->n + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, h->stream, h->n,
+                           h->ops->dim_state, h->sh_rows, h->sh_req_slot, h->x[h->cur], h->parent);
+        h->sh_lazy = false;
+        int32_t rc = check_launch("k_shard_adopt_rows");
+        if (rc != MP_OK) return rc;
+    }
+    if (h->logw_zero) {
+        HIPCK(hipMemsetAsync(h->logw, 0, sizeof(double) * h->n, h->stream));
+        h->logw_zero = false;
+    }
     if (!h->permuted) return MP_OK;
     hipLaunchKernelGGL(k_unpermute, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->ops->dim_state, h->nchunks, h->perm,
                        h->res_x, h->res_stride, h->res_parent, h->x[h->cur], h->parent, h->logw);
@@ -1333,9 +1471,10 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.logw = h->logw;
     for (int j = 0; j < MP_MAX_OBS; ++j) a.obs.v[j] = (j < h->ops->dim_obs) ? obs[j] : 0.;
     for (int j = 0; j < MP_MAX_STATE; ++j) a.s0.v[j] = (args0 && j < h->ops->dim_state) ? args0[j] : 0.;
-    a.overwrite = overwrite ? 1 : (h->permuted ? 2 : 0);
+    a.overwrite = overwrite ? 1 : ((h->permuted || h->logw_zero) ? 2 : 0);
     a.perm = h->permuted ? h->perm : nullptr;
-    a.res_x = h->res_x;
+    a.res_x = h->sh_lazy ? h->sh_rows : h->res_x;
+    a.inv = h->sh_lazy ? h->sh_req_slot : nullptr;
     a.res_stride = h->res_stride;
     a.nchunks = h->nchunks;
     a.cx = h->cx; a.guide = h->guide; a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
@@ -1346,6 +1485,8 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         h->ops->propagate(a);
     }
     h->t += 1;
+    h->logw_zero = false;
+    h->sh_lazy = false;
     h->permuted = false;   // k_propagate wrote x[cur] and logw in slot order ...
     h->rows_fresh = true;  // ... and level 0 of their normalisation
     int32_t rc_ = check_launch("k_propagate");
@@ -1436,9 +1577,10 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     HIPCK(hipMalloc(&h->cx, sizeof(mp_cx) * (size_t)h->nt * TILE));
     HIPCK(hipMalloc(&h->guide, sizeof(unsigned short) * (size_t)h->nt * GUIDE_N));
     HIPCK(hipMalloc(&h->parent, sizeof(uint32_t) * n));
-    HIPCK(hipMalloc(&h->tile_m, sizeof(double) * h->nt));
-    HIPCK(hipMalloc(&h->tile_W, sizeof(u64) * h->nt));
-    HIPCK(hipMalloc(&h->tile_W2, sizeof(u64) * h->nt));
+    HIPCK(hipMalloc(&h->tiles_own, sizeof(u64) * 3 * h->nt));   // packed [3][nt]: m (f64 bits), W, W2 — the unit the shards all-gather
+    h->tile_m = reinterpret_cast<double*>(h->tiles_own);
+    h->tile_W = h->tiles_own + h->nt;
+    h->tile_W2 = h->tiles_own + 2 * (size_t)h->nt;
     HIPCK(hipMalloc(&h->scal, sizeof(mp_dev_scalars)));
     HIPCK(hipMalloc(&h->aos, sizeof(double) * n * d));
     HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
@@ -1660,7 +1802,7 @@ int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const double* d_tm_all, cons
         hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
                            (uint32_t)(h->seed >> 32), h->resample_count, scheme == MP_RESAMPLE_SYSTEMATIC ? 1 : 0, h->S, d_tm_all, (const u64*)d_tW_all,
                            nt_all, h->nt, world, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockcount);
-        hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(SH_THREADS), 0, h->stream, h->sh_blockcount, nblk, world, h->sh_blockoff, h->sh_counts);
+        hipLaunchKernelGGL(k_shard_offsets, dim3(world), dim3(SH_THREADS), 0, h->stream, h->sh_blockcount, nblk, world, h->sh_blockoff, h->sh_counts);
         hipLaunchKernelGGL(k_shard_pack, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockoff, h->sh_counts,
                            world, (u64*)d_req_out, h->sh_req_slot);
     }
@@ -1738,23 +1880,39 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all);
     (void)hipFree(h->sh_overflow);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
-    const u64 slots = std::max<u64>(h->n, (u64)world * cap);
+    const u64 slots = std::max<u64>(h->n, (u64)world * SH_BINS * cap);
     HIPCK(hipMalloc(&h->sh_dest, h->n));
     HIPCK(hipMalloc(&h->sh_lt, sizeof(u64) * h->n));
     HIPCK(hipMalloc(&h->sh_tile, sizeof(uint32_t) * h->n));
     HIPCK(hipMalloc(&h->sh_req_slot, sizeof(uint32_t) * slots));
     HIPCK(hipMalloc(&h->sh_blockcount, sizeof(uint32_t) * (size_t)nblk * world));
     HIPCK(hipMalloc(&h->sh_blockoff, sizeof(uint32_t) * (size_t)nblk * world));
-    HIPCK(hipMalloc(&h->sh_counts, sizeof(long long) * SH_MAX_WORLD));
+    HIPCK(hipMalloc(&h->sh_counts, sizeof(long long) * SH_MAX_KEYS));
     HIPCK(hipMalloc(&h->sh_tm_all, sizeof(double) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_tW_all, sizeof(u64) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_tW2_all, sizeof(u64) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_overflow, sizeof(int)));
+    if (!h->scal_undo) HIPCK(hipMalloc(&h->scal_undo, sizeof(mp_dev_scalars)));
     HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
     HIPCK(hipHostMalloc(&h->h_counts, sizeof(long long) * SH_MAX_WORLD));
-    if (!h->h_overflow) HIPCK(hipHostMalloc(&h->h_overflow, sizeof(int)));
+    if (!h->h_pub) {
+        HIPCK(hipHostMalloc(&h->h_pub, sizeof(mp_shard_pub), hipHostMallocMapped));
+        std::memset(h->h_pub, 0, sizeof(mp_shard_pub));
+        HIPCK(hipHostGetDevicePointer((void**)&h->d_pub, h->h_pub, 0));
+        HIPCK(hipEventCreateWithFlags(&h->ev_resolved, hipEventDisableTiming));
+    }
     h->sh_world = world;
     h->sh_cap = cap;
+    return MP_OK;
+}
+
+int32_t mp_pf_shard_bind_tiles(mp_pf* h, uint64_t* d_tiles) {
+    if (!h || !d_tiles) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(h->device));
+    HIPCK(hipMemcpyAsync(d_tiles, h->tile_m, sizeof(u64) * 3 * h->nt, hipMemcpyDeviceToDevice, h->stream));
+    h->tile_m = reinterpret_cast<double*>(d_tiles);
+    h->tile_W = (u64*)d_tiles + h->nt;
+    h->tile_W2 = (u64*)d_tiles + 2 * (size_t)h->nt;
     return MP_OK;
 }
 
@@ -1764,9 +1922,9 @@ int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out) {
     HIPCK(hipSetDevice(h->device));
     int32_t rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(k_pack_tiles, dim3((h->nt + K3_THREADS - 1) / K3_THREADS), dim3(K3_THREADS), 0, h->stream, h->tile_m, h->tile_W, h->tile_W2, h->nt,
-                       (u64*)d_tiles_out);
-    return check_launch("k_pack_tiles");
+    if ((void*)d_tiles_out != (void*)h->tile_m)   // a bound buffer already holds them
+        HIPCK(hipMemcpyAsync(d_tiles_out, h->tile_m, sizeof(u64) * 3 * h->nt, hipMemcpyDeviceToDevice, h->stream));
+    return MP_OK;
 }
 
 int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
@@ -1779,63 +1937,71 @@ int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     HIPCK(hipSetDevice(h->device));
     int32_t rc = shard_scratch(h, world, capacity);
     if (rc != MP_OK) return rc;
-    const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
     const int nt_all = h->nt * world;
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        hipLaunchKernelGGL(k_unpack_tiles, dim3((nt_all + K3_THREADS - 1) / K3_THREADS), dim3(K3_THREADS), 0, h->stream, (const u64*)d_tiles_all, world,
-                           h->nt, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all);
-        const size_t lds = table_lds(nt_all, SH_THREADS) + sizeof(uint32_t) * SH_MAX_WORLD;
-        hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
+        const int cover = std::max(nt_all, SH_MAX_KEYS);
+        hipLaunchKernelGGL(k_unpack_tiles, dim3((cover + K3_THREADS - 1) / K3_THREADS), dim3(K3_THREADS), 0, h->stream, (const u64*)d_tiles_all, world,
+                           h->nt, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_counts);
+        const size_t lds = table_lds(nt_all, SH_THREADS) + (sizeof(uint32_t) + sizeof(u64)) * SH_MAX_KEYS;
+        const int nblk_f = (int)((h->n + SH_THREADS * SHF_ITEMS - 1) / (SH_THREADS * SHF_ITEMS));
+        hipLaunchKernelGGL(k_shard_route_fused, dim3(nblk_f), dim3(SH_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
                            (uint32_t)(h->seed >> 32), h->resample_count, scheme == MP_RESAMPLE_SYSTEMATIC ? 1 : 0, h->S, h->sh_tm_all, h->sh_tW_all,
-                           nt_all, h->nt, world, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockcount);
-        hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(SH_THREADS), 0, h->stream, h->sh_blockcount, nblk, world, h->sh_blockoff, h->sh_counts);
-        hipLaunchKernelGGL(k_shard_pack_fixed, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockoff,
-                           h->sh_counts, world, (u64)capacity, (u64*)d_req_out, h->sh_req_slot, h->sh_overflow);
-        hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, h->sh_tm_all, h->sh_tW_all,
-                           h->sh_tW2_all, nt_all, h->S, h->n_global, 0, h->scal);
+                           nt_all, h->nt, world, (u64)capacity, (unsigned long long*)h->sh_counts, (u64*)d_req_out, h->sh_req_slot);
+        hipLaunchKernelGGL(k_shard_finalize, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, h->sh_tm_all, h->sh_tW_all,
+                           h->sh_tW2_all, nt_all, h->S, h->n_global, h->scal, h->scal_undo, (const unsigned long long*)h->sh_counts, world,
+                           (u64)capacity, (u64*)d_req_out, h->sh_overflow);
     }
     return check_launch("shard_route_fixed kernels");
 }
 
 int32_t mp_pf_shard_resolve_fixed(mp_pf* h, const uint64_t* d_req_in, int32_t world, uint64_t capacity, double* d_rows_out) {
     if (!h || !d_req_in || !d_rows_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (world < 1 || world > SH_MAX_WORLD || capacity == 0) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, capacity > 0");
+    if (!h->h_pub) return mp_fail(MP_ERR_STATE, "shard_resolve_fixed before shard_route_fixed");
     HIPCK(hipSetDevice(h->device));
-    const unsigned gx = (unsigned)std::min<u64>((capacity + K3_THREADS - 1) / K3_THREADS, 1024);
+    // workgroups per (asking rank, eighth): enough to fill the chip, each takes K3_THREADS * K3_ITEMS requests per round
+    const u64 per = (u64)K3_THREADS * K3_ITEMS;
+    const unsigned groups = (unsigned)std::max<u64>(1, std::min<u64>((capacity + per - 1) / per, std::max<u64>(1, 512 / (u64)world)));
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_shard_resolve_fixed, dim3(gx, world), dim3(K3_THREADS), 0, h->stream, h->n, (u64)capacity, h->slot_offset,
+        hipLaunchKernelGGL(k_shard_resolve_binned, dim3(groups * SH_BINS, world), dim3(K3_THREADS), 0, h->stream, h->n, (u64)capacity, h->slot_offset,
                            h->ops->dim_state, (const u64*)d_req_in, h->cx, h->guide, h->tile_W, h->x[h->cur], d_rows_out, h->sh_overflow);
+        hipLaunchKernelGGL(k_shard_publish, dim3(1), dim3(1), 0, h->stream, h->sh_overflow, h->scal, h->d_pub);
     }
-    return check_launch("k_shard_resolve_fixed");
+    int32_t rc = check_launch("k_shard_resolve_binned");
+    if (rc != MP_OK) return rc;
+    HIPCK(hipEventRecord(h->ev_resolved, h->stream));   // mp_pf_shard_commit_fixed waits for this, not for what follows on the stream
+    return MP_OK;
 }
 
-int32_t mp_pf_shard_scatter_fixed(mp_pf* h, const double* d_rows_in, int32_t world, uint64_t capacity, double* log_total_weight) {
+int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_total_weight) {
     if (!h || !d_rows_in) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    if (!h->sh_req_slot || h->sh_cap < capacity) return mp_fail(MP_ERR_STATE, "shard_scatter_fixed before shard_route_fixed");
+    if (!h->h_pub) return mp_fail(MP_ERR_STATE, "shard_commit_fixed before shard_resolve_fixed");
     HIPCK(hipSetDevice(h->device));
-    const unsigned gx = (unsigned)std::min<u64>((capacity + SH_THREADS - 1) / SH_THREADS, 1024);
-    {
-        LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_shard_scatter_fixed, dim3(gx, world), dim3(SH_THREADS), 0, h->stream, h->n, (u64)capacity, h->ops->dim_state, d_rows_in,
-                           h->sh_req_slot, h->sh_counts, h->x[h->cur ^ 1], h->parent, h->logw);
-    }
-    int32_t rc = check_launch("k_shard_scatter_fixed");
-    if (rc != MP_OK) return rc;
-    // The one host round trip of this form: did any pair of ranks exceed the capacity?  (Every rank reaches the same
-    // answer: senders flag it in the request headers.)  If so nothing is committed; the caller repeats this resample with
-    // the variable-size phases, which read the same rows, tiles and Philox counters.
-    HIPCK(hipMemcpyAsync(h->h_overflow, h->sh_overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (log_total_weight) HIPCK(hipMemcpyAsync(h->h_scal, h->scal, sizeof(mp_dev_scalars), hipMemcpyDeviceToHost, h->stream));
-    HIPCK(hipStreamSynchronize(h->stream));
-    if (*h->h_overflow) {
+    // The one host wait of this form, and only for the resolve: the all-to-all that carries the rows back may still be
+    // running.  Did any sub-segment exceed the capacity?  (Every rank reaches the same answer: senders flag it in the
+    // request headers.)  If so nothing is committed; the caller repeats this resample with the variable-size phases,
+    // which read the same rows, tiles and Philox counters.
+    HIPCK(hipEventSynchronize(h->ev_resolved));
+    if (h->h_pub->overflow) {
         HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
-        return mp_fail(MP_ERR_CAPACITY, "sharded exchange: one pair of ranks needs more than `capacity` draws; repeat with the variable-size phases");
+        HIPCK(hipMemcpyAsync(h->scal, h->scal_undo, sizeof(mp_dev_scalars), hipMemcpyDeviceToDevice, h->stream));  // un-fold the log-ML increment
+        return mp_fail(MP_ERR_CAPACITY, "sharded exchange: a sub-segment needs more than `capacity` draws; repeat with the variable-size phases");
     }
+    // traces[i] = traces[parents[i]].clone() (particle_filter.rs:109-113), lazily: the next propagate reads slot i's state
+    // from row sh_req_slot[i] of the exchange buffer; anything else first copies states and parents into slot order.
+    h->sh_rows = d_rows_in;
+    h->sh_lazy = true;
+    h->logw_zero = true;   // log_weights.fill(0.) (:114): the next propagate does not re-read them; anything else clears the buffer first
     h->cur ^= 1;
     h->rows_fresh = false;
     h->resample_count += 1;
-    if (log_total_weight) *log_total_weight = h->h_scal->L;
+    if (log_total_weight) {
+        if (h->h_pub->degenerate)
+            return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
+        *log_total_weight = h->h_pub->L;
+    }
     return MP_OK;
 }
 
@@ -1946,14 +2112,15 @@ int32_t mp_pf_destroy(mp_pf* h) {
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     for (auto& ev : h->hist) (void)hipFree(ev.buf);
     (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->guide);
-    (void)hipFree(h->parent); (void)hipFree(h->tile_m); (void)hipFree(h->tile_W); (void)hipFree(h->tile_W2); (void)hipFree(h->scal);
+    (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->scal);
     (void)hipFree(h->aos);
     (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all);
-    (void)hipFree(h->sh_overflow);
+    (void)hipFree(h->sh_overflow); (void)hipFree(h->scal_undo);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
-    if (h->h_overflow) (void)hipHostFree(h->h_overflow);
+    if (h->h_pub) (void)hipHostFree(h->h_pub);
+    if (h->ev_resolved) (void)hipEventDestroy(h->ev_resolved);
     (void)hipHostFree(h->h_scal);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;

@@ -74,6 +74,9 @@ class HipShardEngine:
     # fixed-capacity form (no host round trip until the scatter): see include/modppl_hip.h
     supports_fixed = True
 
+    def shard_bind_tiles(self, tiles_ptr):
+        capi.check(self._L.mp_pf_shard_bind_tiles(self._h, tiles_ptr))
+
     def shard_tiles_packed(self, tiles_ptr):
         capi.check(self._L.mp_pf_shard_tiles_packed(self._h, tiles_ptr))
 
@@ -83,10 +86,10 @@ class HipShardEngine:
     def shard_resolve_fixed(self, req_ptr, world, cap, rows_ptr):
         capi.check(self._L.mp_pf_shard_resolve_fixed(self._h, req_ptr, world, cap, rows_ptr))
 
-    def shard_scatter_fixed(self, rows_ptr, world, cap, want_value):
+    def shard_commit_fixed(self, rows_ptr, want_value):
         """-> (committed, log total weight or None)"""
         out = C.c_double()
-        code = self._L.mp_pf_shard_scatter_fixed(self._h, rows_ptr, world, cap, C.byref(out) if want_value else None)
+        code = self._L.mp_pf_shard_commit_fixed(self._h, rows_ptr, C.byref(out) if want_value else None)
         if code == capi.MP_ERR_CAPACITY:
             return False, None
         capi.check(code)
@@ -191,15 +194,16 @@ class ShardedParticleSystem:
         self.fallbacks = 0
         if self._fixed:
             slack = float(os.environ.get("MP_SHARD_SLACK", "1.25"))
-            per = self.n // self.world
-            self.cap = self.n if self.world == 1 else min(self.n, int(per * slack) + 1024)
+            per = self.n // (min(8, self.nt) * self.world)   # draws per (owner, eighth of the owner's tiles) sub-segment, on average
+            self.cap = min(self.n, int(per * slack) + 512)
             self.cap = int(os.environ.get("MP_SHARD_CAP", self.cap))   # tests: force the overflow path
             w, cap = self.world, self.cap
-            self._fx_req_out = torch.zeros(w * (cap + 1) * 2, dtype=torch.int64, device=self.dev)
+            self._fx_req_out = torch.zeros(w * 8 * (cap + 1) * 2, dtype=torch.int64, device=self.dev)
             self._fx_req_in = self._fx_req_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_req_out)
-            self._fx_rows_out = torch.zeros(w * cap * (d + 1), dtype=torch.float64, device=self.dev)
+            self._fx_rows_out = torch.zeros(w * 8 * cap * (d + 1), dtype=torch.float64, device=self.dev)
             self._fx_rows_in = self._fx_rows_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_rows_out)
             self._p_tiles = C.c_void_p(self._tiles.data_ptr())
+            self.engine.shard_bind_tiles(self._p_tiles)   # the filter keeps its tiles in the tensor the all-gather reads
             self._p_tiles_all = C.c_void_p(self._tiles.data_ptr() if (w == 1 and not self._always) else self._tiles_all.data_ptr())
             self._p_req_out, self._p_req_in = C.c_void_p(self._fx_req_out.data_ptr()), C.c_void_p(self._fx_req_in.data_ptr())
             self._p_rows_out, self._p_rows_in = C.c_void_p(self._fx_rows_out.data_ptr()), C.c_void_p(self._fx_rows_in.data_ptr())
@@ -275,8 +279,8 @@ class ShardedParticleSystem:
             dist.all_gather_into_tensor(self._tiles_all, self._tiles, group=self.group)
 
     def _resample_fixed(self, scheme, sync):
-        """3 collectives (all-gather of tiles, all-to-all of draws, all-to-all of rows), 4 library calls, one host
-        round trip at the end."""
+        """3 collectives (all-gather of tiles, all-to-all of draws, all-to-all of rows), 4 library calls, one host wait
+        (for the owner-side resolve, while the rows travel)."""
         e, w, cap = self.engine, self.world, self.cap
         self._gather_tiles_packed()
         e.shard_route_fixed(scheme, self._p_tiles_all, w, self.rank, cap, self._p_req_out)
@@ -285,7 +289,7 @@ class ShardedParticleSystem:
         e.shard_resolve_fixed(self._p_req_in, w, cap, self._p_rows_out)
         if w > 1 or self._always:
             dist.all_to_all_single(self._fx_rows_in, self._fx_rows_out, group=self.group)
-        return e.shard_scatter_fixed(self._p_rows_in, w, cap, sync)
+        return e.shard_commit_fixed(self._p_rows_in, sync)   # waits for the resolve only; the rows may still be in flight
 
     def _resample(self, scheme, sync):
         if self._fixed:

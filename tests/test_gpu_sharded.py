@@ -146,10 +146,11 @@ def test_rccl_collectives_world_of_one(tmp_path, mode):
     assert "RESULT ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
-@pytest.mark.parametrize("d,cap_frac", [(1, 1.0), (4, 0.75)])
-def test_fixed_capacity_exchange_two_shards_in_process(d, cap_frac):
+@pytest.mark.parametrize("d,cap_frac,peek", [(1, 1.0, True), (4, 0.2, True), (1, 0.3, False), (4, 0.2, False)])
+def test_fixed_capacity_exchange_two_shards_in_process(d, cap_frac, peek):
     """World = 2 through the fixed-capacity phases, the collectives done by hand between two handles on the one GPU:
-    segment layout, per-source counts in the headers, scatter by owner.  Equal to ONE unsharded filter bit for bit."""
+    sub-segment layout, counts in the headers, rows adopted lazily.  Equal to ONE unsharded filter bit for bit.
+    peek=False never reads states between steps, so every propagate takes its inputs straight from the exchange buffer."""
     import ctypes as C
 
     import torch
@@ -171,8 +172,8 @@ def test_fixed_capacity_exchange_two_shards_in_process(d, cap_frac):
     nt = n // 2048
     dev = eng[0].device
     tiles = [torch.zeros(3 * nt, dtype=torch.int64, device=dev) for _ in range(world)]
-    req_out = [torch.zeros(world * (cap + 1) * 2, dtype=torch.int64, device=dev) for _ in range(world)]
-    rows_out = [torch.zeros(world * cap * (d + 1), dtype=torch.float64, device=dev) for _ in range(world)]
+    req_out = [torch.zeros(world * 8 * (cap + 1) * 2, dtype=torch.int64, device=dev) for _ in range(world)]
+    rows_out = [torch.zeros(world * 8 * cap * (d + 1), dtype=torch.float64, device=dev) for _ in range(world)]
     ptr = lambda t: C.c_void_p(t.data_ptr())
 
     def sync():
@@ -191,23 +192,25 @@ def test_fixed_capacity_exchange_two_shards_in_process(d, cap_frac):
         for r, e in enumerate(eng):
             e.shard_route_fixed(0, ptr(tiles_all), world, r, cap, ptr(req_out[r]))
         sync()
-        seg = (cap + 1) * 2                                            # all_to_all_single, equal splits
+        seg = 8 * (cap + 1) * 2                                        # all_to_all_single, equal splits
         req_in = [torch.cat([req_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
         for r, e in enumerate(eng):
             e.shard_resolve_fixed(ptr(req_in[r]), world, cap, ptr(rows_out[r]))
         sync()
-        seg = cap * (d + 1)
+        seg = 8 * cap * (d + 1)
         rows_in = [torch.cat([rows_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
-        res = [e.shard_scatter_fixed(ptr(rows_in[r]), world, cap, True) for r, e in enumerate(eng)]
+        res = [e.shard_commit_fixed(ptr(rows_in[r]), True) for r, e in enumerate(eng)]
         L = one.resample()
         assert all(done for done, _ in res)
         assert all(v == L for _, v in res)
-        assert np.array_equal(np.concatenate([e.parents() for e in eng]), one.parents)
-        assert np.array_equal(np.concatenate([e.states() for e in eng]), one.states())
+        if peek:
+            assert np.array_equal(np.concatenate([e.parents() for e in eng]), one.parents)
+            assert np.array_equal(np.concatenate([e.states() for e in eng]), one.states())
         one.step(obs[t:t + 1])
         for e in eng:
             e.step(obs[t:t + 1])
     assert np.array_equal(np.concatenate([e.log_weights() for e in eng]), one.log_weights)
+    assert np.array_equal(np.concatenate([e.states() for e in eng]), one.states())
     for r, e in enumerate(eng):
         e.shard_tiles_packed(ptr(tiles[r]))
     sync()
@@ -225,7 +228,7 @@ def test_fixed_capacity_overflow_commits_nothing():
     import modppl_amd
     from modppl_amd.distributed import HipShardEngine
 
-    n, world, seed, cap = 4096, 2, 3, 512
+    n, world, seed, cap = 4096, 2, 3, 64
     N = n * world
     model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
     obs = O.lgssm_observations(2).reshape(2, 1)
@@ -235,8 +238,8 @@ def test_fixed_capacity_overflow_commits_nothing():
     before = [(e.states().copy(), e.log_weights().copy()) for e in eng]
     nt, dev = n // 2048, eng[0].device
     tiles = [torch.zeros(3 * nt, dtype=torch.int64, device=dev) for _ in range(world)]
-    req_out = [torch.zeros(world * (cap + 1) * 2, dtype=torch.int64, device=dev) for _ in range(world)]
-    rows_out = [torch.zeros(world * cap * 2, dtype=torch.float64, device=dev) for _ in range(world)]
+    req_out = [torch.zeros(world * 8 * (cap + 1) * 2, dtype=torch.int64, device=dev) for _ in range(world)]
+    rows_out = [torch.zeros(world * 8 * cap * 2, dtype=torch.float64, device=dev) for _ in range(world)]
     ptr = lambda t: C.c_void_p(t.data_ptr())
 
     def sync():
@@ -251,14 +254,15 @@ def test_fixed_capacity_overflow_commits_nothing():
     for r, e in enumerate(eng):
         e.shard_route_fixed(0, ptr(tiles_all), world, r, cap, ptr(req_out[r]))
     sync()
-    seg = (cap + 1) * 2
+    seg = 8 * (cap + 1) * 2
     req_in = [torch.cat([req_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
     for r, e in enumerate(eng):
         e.shard_resolve_fixed(ptr(req_in[r]), world, cap, ptr(rows_out[r]))
     sync()
-    seg = cap * 2
+    seg = 8 * cap * 2
     rows_in = [torch.cat([rows_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
-    res = [e.shard_scatter_fixed(ptr(rows_in[r]), world, cap, True) for r, e in enumerate(eng)]
+    res = [e.shard_commit_fixed(ptr(rows_in[r]), True) for r, e in enumerate(eng)]
     assert all(not done for done, _ in res)
     for e, (x, w) in zip(eng, before):
         assert np.array_equal(e.states(), x)
+        assert np.array_equal(e.log_weights(), w)
