@@ -57,6 +57,24 @@ extern "C" {
     pub fn mp_pf_run(h: *mut mp_pf, args0: *const f64, obs: *const f64, n_steps: i32, scheme: i32) -> i32;
     pub fn mp_pf_synchronize(h: *mut mp_pf) -> i32;
     pub fn mp_pf_destroy(h: *mut mp_pf) -> i32;
+    // sharded filter: device pointers; the caller runs the collectives between the phases (include/modppl_hip.h)
+    pub fn mp_pf_shard_tiles(h: *mut mp_pf, d_tile_m: *mut f64, d_tile_w: *mut u64, d_tile_w2: *mut u64) -> i32;
+    pub fn mp_pf_shard_route(h: *mut mp_pf, scheme: i32, d_tm_all: *const f64, d_tw_all: *const u64, d_tw2_all: *const u64,
+                             world: i32, rank: i32, d_req_out: *mut u64, send_counts: *mut i64) -> i32;
+    pub fn mp_pf_shard_resolve(h: *mut mp_pf, d_req_in: *const u64, n_req: u64, d_rows_out: *mut f64) -> i32;
+    pub fn mp_pf_shard_scatter(h: *mut mp_pf, d_rows_in: *const f64, log_total_weight: *mut f64) -> i32;
+    pub fn mp_pf_shard_query(h: *mut mp_pf, d_tm_all: *const f64, d_tw_all: *const u64, d_tw2_all: *const u64, world: i32,
+                             log_ml: *mut f64, ess: *mut f64) -> i32;
+    pub fn mp_pf_shard_bind_tiles(h: *mut mp_pf, d_tiles: *mut u64) -> i32;
+    pub fn mp_pf_shard_tiles_packed(h: *mut mp_pf, d_tiles_out: *mut u64) -> i32;
+    pub fn mp_pf_shard_route_fixed(h: *mut mp_pf, scheme: i32, d_tiles_all: *const u64, world: i32, rank: i32, capacity: u64,
+                                   d_req_out: *mut u64) -> i32;
+    pub fn mp_pf_shard_resolve_fixed(h: *mut mp_pf, d_req_in: *const u64, world: i32, capacity: u64, d_rows_out: *mut f64) -> i32;
+    pub fn mp_pf_shard_commit_fixed(h: *mut mp_pf, d_rows_in: *const f64, log_total_weight: *mut f64) -> i32;
+    pub fn mp_pf_shard_query_packed(h: *mut mp_pf, d_tiles_all: *const u64, world: i32, log_ml: *mut f64, ess: *mut f64) -> i32;
+    // per-kernel-family hipEvent timing (bench)
+    pub fn mp_pf_set_timing(h: *mut mp_pf, enabled: i32) -> i32;
+    pub fn mp_pf_get_timing(h: *mut mp_pf, family: i32, total_ms: *mut f64, launches: *mut u64) -> i32;
     pub fn mp_importance_resampling(model: *const mp_model_desc, args0: *const f64, obs: *const f64, n_steps: i32,
                                     num_samples: u64, num_ret_samples: u64, seed: u64, device: i32,
                                     log_ml_estimate: *mut f64, log_normalized_weights: *mut f64,
