@@ -237,7 +237,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE_ITEMS], c
 
 // standalone form: used when the log-weights changed without a propagate (after a resample, before a query or a
 // second resample)
-__global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* __restrict__ logw, const double* __restrict__ x0, u64 n,
+__global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* __restrict__ logw, const double* __restrict__ x0, int D, u64 n,
                                                                   mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
                                                                   double* __restrict__ tile_m, u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
     const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * TILE_ITEMS;
@@ -246,14 +246,19 @@ __global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* 
         const double2 a = *reinterpret_cast<const double2*>(logw + base);
         const double2 b = *reinterpret_cast<const double2*>(logw + base + 2);
         lw[0] = a.x; lw[1] = a.y; lw[2] = b.x; lw[3] = b.y;
-        const double2 xa = *reinterpret_cast<const double2*>(x0 + base);
-        const double2 xb = *reinterpret_cast<const double2*>(x0 + base + 2);
-        xv[0] = xa.x; xv[1] = xa.y; xv[2] = xb.x; xv[3] = xb.y;
+        if (D == 1) {
+            const double2 xa = *reinterpret_cast<const double2*>(x0 + base);
+            const double2 xb = *reinterpret_cast<const double2*>(x0 + base + 2);
+            xv[0] = xa.x; xv[1] = xa.y; xv[2] = xb.x; xv[3] = xb.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < TILE_ITEMS; ++j) xv[j] = x0[(base + j) * (u64)D];   // states are particle-major: x[i][d]
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < TILE_ITEMS; ++j) {
             lw[j] = (base + j < n) ? logw[base + j] : MP_NEG_INF;
-            xv[j] = (base + j < n) ? x0[base + j] : 0.;
+            xv[j] = (base + j < n) ? x0[(base + j) * (u64)D] : 0.;
         }
     }
     normalize_tile(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_propagate(Model model, u64 n, 
                                                             u64 res_stride, int nchunks, mp_cx* __restrict__ cx,
                                                             unsigned short* __restrict__ guide, double* __restrict__ tile_m,
                                                             u64* __restrict__ tile_W, u64* __restrict__ tile_W2,
-                                                            const uint32_t* __restrict__ inv) {
+                                                            const uint32_t* __restrict__ inv, const uint32_t* __restrict__ res_parent) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int ITEMS = k1_items<Model>();
@@ -335,18 +340,25 @@ __global__ __launch_bounds__(TILE_THREADS) void k_propagate(Model model, u64 n, 
                     // segment (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i]
                     const uint32_t pr_ = perm[i];
                     const u64 pos = MP_SEG_POS(pr_ >> 10, i >> 10, pr_ & 1023u, nchunks);
+                    if constexpr (D == 1) {
+                        prev[0] = res_x[pos];              // k_resolve_bins had it in the table row it found
+                    } else {
+                        // wider states are gathered here, straight from the parent's (particle-major) row of the
+                        // pre-resample buffer: one line per particle, hidden under this kernel's arithmetic
+                        const double* src = x_in + (u64)res_parent[pos] * D;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) prev[d] = res_x[(u64)d * res_stride + pos];
+                        for (int d = 0; d < D; ++d) prev[d] = src[d];
+                    }
                 } else {
 #pragma unroll
-                    for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[(u64)d * n + i];
+                    for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[i * D + d];
                 }
                 mp_stream rng;
                 rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
                 mp_generate_handler<Model> g(rng, obs.v, &pu[p * NS], &pr[p * NS]);
                 model(g, t, prev, next);
 #pragma unroll
-                for (int d = 0; d < D; ++d) x_out[(u64)d * n + i] = next[d];
+                for (int d = 0; d < D; ++d) x_out[i * D + d] = next[d];
                 // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to
                 // be all zero after a resample (log_weights.fill(0.), :114) and are not re-read
                 const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
@@ -596,8 +608,8 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
                 const u64 p = tbase[k] + jj;
                 parent[i] = (uint32_t)p;
                 if (x_new) {
-                    x_new[i] = row.x0;                    // traces[i] = traces[parents[i]].clone()
-                    for (int d = 1; d < D; ++d) x_new[(u64)d * n_out + i] = x_old[(u64)d * n + p];
+                    x_new[i * D] = row.x0;                // traces[i] = traces[parents[i]].clone()
+                    for (int d = 1; d < D; ++d) x_new[i * D + d] = x_old[p * D + d];
                 }
                 if (logw) logw[i] = 0.;                   // log_weights.fill(0.)
             }
@@ -734,7 +746,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int n
         }
         res_parent[sp] = (uint32_t)p;
         res_x[sp] = cur.x0;
-        for (int d = 1; d < D; ++d) res_x[(u64)d * res_stride + sp] = x_old[(u64)d * n + p];
+        // D > 1: the rest of the state is gathered by the next k_propagate (or k_unpermute) from res_parent
     };
     bool live[K3_ITEMS];
     mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
@@ -770,14 +782,19 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int n
 
 // slot order from segment order: traces[i] = traces[parents[i]].clone(); log_weights.fill(0.) (particle_filter.rs:109-114)
 __global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __restrict__ perm, const double* __restrict__ res_x, u64 res_stride,
-                            const uint32_t* __restrict__ res_parent, double* __restrict__ x_new, uint32_t* __restrict__ parent,
-                            double* __restrict__ logw) {
+                            const uint32_t* __restrict__ res_parent, const double* __restrict__ x_old, double* __restrict__ x_new,
+                            uint32_t* __restrict__ parent, double* __restrict__ logw) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t pr = perm[i];
     const u64 pos = MP_SEG_POS(pr >> 10, i >> 10, pr & 1023u, nchunks);
-    for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = res_x[(u64)d * res_stride + pos];
-    parent[i] = res_parent[pos];
+    const uint32_t p = res_parent[pos];
+    if (D == 1) {
+        x_new[i] = res_x[pos];
+    } else {
+        for (int d = 0; d < D; ++d) x_new[i * D + d] = x_old[(u64)p * D + d];
+    }
+    parent[i] = p;
     logw[i] = 0.;
 }
 
@@ -936,7 +953,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve(u64 n, u64 n_req, 
         const u64 p = tbase + j;
         double* out = rows + q * (u64)(D + 1);
         out[0] = row.x0;
-        for (int d = 1; d < D; ++d) out[d] = x[(u64)d * n + p];
+        for (int d = 1; d < D; ++d) out[d] = x[p * D + d];
         out[D] = (double)(slot_offset + p);
     }
 }
@@ -947,7 +964,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_scatter(u64 n, int D, cons
     if (pos < n) {
         const uint32_t i = req_slot[pos];
         const double* in = rows + pos * (u64)(D + 1);
-        for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = in[d];
+        for (int d = 0; d < D; ++d) x_new[(u64)i * D + d] = in[d];
         parent[i] = (uint32_t)in[D];
         logw[i] = 0.;
     }
@@ -1136,7 +1153,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
                 *reinterpret_cast<double2*>(out) = make_double2(cur.x0, (double)(slot_offset + pp));
             } else {
                 out[0] = cur.x0;
-                for (int d = 1; d < D; ++d) out[d] = x[(u64)d * n + pp];
+                for (int d = 1; d < D; ++d) out[d] = x[pp * D + d];
                 out[D] = (double)(slot_offset + pp);
             }
         }
@@ -1155,16 +1172,10 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_adopt_rows(u64 n, int D, c
     const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
     if (i >= n) return;
     const double* in = rows + (u64)inv[i] * (u64)(D + 1);
-    for (int d = 0; d < D; ++d) x_new[(u64)d * n + i] = in[d];
+    for (int d = 0; d < D; ++d) x_new[i * D + d] = in[d];
     parent[i] = (uint32_t)in[D];
 }
 
-// transpose SoA [d][n] -> host-facing AoS [n][d]
-__global__ void k_soa_to_aos(const double* __restrict__ x, u64 n, int D, double* __restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        for (int d = 0; d < D; ++d) out[i * D + d] = x[(u64)d * n + i];
-}
 // out[i] = a[i] - *b  (log_normalized_weights = w_i - log_total_weight, importance.rs:23-25)
 __global__ void k_sub_scalar(const double* __restrict__ a, const double* __restrict__ b, u64 n, double* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1205,6 +1216,7 @@ struct PropagateArgs {
     u64* tile_W;
     u64* tile_W2;
     const uint32_t* inv;
+    const uint32_t* res_parent;
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
@@ -1223,7 +1235,7 @@ struct ModelOpsT : ModelOps {
     void propagate(const PropagateArgs& a) const override {
         hipLaunchKernelGGL(k_propagate<Model>, dim3(a.grid), dim3(TILE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.res_stride, a.nchunks, a.cx, a.guide,
-                           a.tile_m, a.tile_W, a.tile_W2, a.inv);
+                           a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent);
     }
 };
 
@@ -1457,7 +1469,9 @@ static int32_t materialize(mp_pf* h) {
     }
     if (!h->permuted) return MP_OK;
     hipLaunchKernelGGL(k_unpermute, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->ops->dim_state, h->nchunks, h->perm,
-                       h->res_x, h->res_stride, h->res_parent, h->x[h->cur], h->parent, h->logw);
+                       h->res_x, h->res_stride, h->res_parent, h->x[h->cur], h->ops->dim_state == 1 ? h->x[h->cur] : h->x[h->cur ^ 1], h->parent,
+                       h->logw);
+    if (h->ops->dim_state > 1) h->cur ^= 1;   // wider states were gathered from the pre-resample buffer into the other one
     h->permuted = false;
     return check_launch("k_unpermute");
 }
@@ -1467,7 +1481,11 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.n = h->n; a.slot_offset = h->slot_offset;
     a.k0 = (uint32_t)h->seed; a.k1 = (uint32_t)(h->seed >> 32);
     a.t = h->t;
-    a.x_in = h->x[h->cur]; a.x_out = h->x[h->cur];
+    // after a binned resample of a filter with dim_state > 1 this propagate gathers the parents' states itself, from the
+    // pre-resample buffer into the other one
+    const bool gather_here = h->permuted && !h->sh_lazy && h->ops->dim_state > 1;
+    a.x_in = h->x[h->cur]; a.x_out = gather_here ? h->x[h->cur ^ 1] : h->x[h->cur];
+    a.res_parent = h->res_parent;
     a.logw = h->logw;
     for (int j = 0; j < MP_MAX_OBS; ++j) a.obs.v[j] = (j < h->ops->dim_obs) ? obs[j] : 0.;
     for (int j = 0; j < MP_MAX_STATE; ++j) a.s0.v[j] = (args0 && j < h->ops->dim_state) ? args0[j] : 0.;
@@ -1485,6 +1503,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         h->ops->propagate(a);
     }
     h->t += 1;
+    if (gather_here) h->cur ^= 1;
     h->logw_zero = false;
     h->sh_lazy = false;
     h->permuted = false;   // k_propagate wrote x[cur] and logw in slot order ...
@@ -1508,7 +1527,7 @@ static int32_t ensure_rows(mp_pf* h) {
     if (h->rows_fresh) return MP_OK;
     {
         LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
-        hipLaunchKernelGGL(k_normalize_tiles, dim3(h->nt), dim3(TILE_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->n, h->cx, h->guide,
+        hipLaunchKernelGGL(k_normalize_tiles, dim3(h->nt), dim3(TILE_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->ops->dim_state, h->n, h->cx, h->guide,
                            h->tile_m, h->tile_W, h->tile_W2);
     }
     h->rows_fresh = true;
@@ -1582,14 +1601,14 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     h->tile_W = h->tiles_own + h->nt;
     h->tile_W2 = h->tiles_own + 2 * (size_t)h->nt;
     HIPCK(hipMalloc(&h->scal, sizeof(mp_dev_scalars)));
-    HIPCK(hipMalloc(&h->aos, sizeof(double) * n * d));
+    HIPCK(hipMalloc(&h->aos, sizeof(double) * n));   // scratch for importance sampling's normalised log-weights
     HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
     h->res_stride = 8ull * (u64)h->nchunks * BIN_CHUNK;
     HIPCK(hipMalloc(&h->seg_lt, sizeof(u64) * h->res_stride));
     HIPCK(hipMalloc(&h->seg_row, sizeof(uint32_t) * h->res_stride));
     HIPCK(hipMalloc(&h->perm, sizeof(unsigned short) * (size_t)h->nchunks * BIN_CHUNK));
     HIPCK(hipMalloc(&h->seg_cnt, sizeof(unsigned short) * 8 * (size_t)h->nchunks));
-    HIPCK(hipMalloc(&h->res_x, sizeof(double) * h->res_stride * (size_t)d));
+    HIPCK(hipMalloc(&h->res_x, sizeof(double) * h->res_stride));   // first state component only (dim_state == 1 needs nothing else)
     HIPCK(hipMalloc(&h->res_parent, sizeof(uint32_t) * h->res_stride));
     // tile tables above 64 KiB of LDS need the limit raised once per kernel
     {
@@ -1741,11 +1760,8 @@ int32_t mp_pf_read_state(mp_pf* h, double* x_out) {
     if (!h || !x_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
     { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
-    const int d = h->ops->dim_state;
-    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->x[h->cur], h->n, d, h->aos);
-    int32_t rc = check_launch("k_soa_to_aos");
-    if (rc != MP_OK) return rc;
-    HIPCK(hipMemcpyAsync(x_out, h->aos, sizeof(double) * h->n * d, hipMemcpyDeviceToHost, h->stream));
+    const int d = h->ops->dim_state;   // device layout = host layout: particle-major x[i][d]
+    HIPCK(hipMemcpyAsync(x_out, h->x[h->cur], sizeof(double) * h->n * d, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
     return MP_OK;
 }
@@ -2044,8 +2060,7 @@ int32_t mp_pf_read_trajectory(mp_pf* h, uint64_t i, double* out, int32_t* t_step
             a = p;
         } else {
             --t;
-            for (int k = 0; k < d; ++k)
-                HIPCK(hipMemcpy(out + (size_t)t * d + k, (const double*)ev.buf + (size_t)k * h->n + a, sizeof(double), hipMemcpyDeviceToHost));
+            HIPCK(hipMemcpy(out + (size_t)t * d, (const double*)ev.buf + (size_t)a * d, sizeof(double) * d, hipMemcpyDeviceToHost));
         }
     }
     *t_steps = (int32_t)h->t;
