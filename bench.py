@@ -36,12 +36,10 @@ KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1>", "normalize_scan": "k_normali
 BYTES_STEP = 32 * DIM + 64
 
 
-def cpu_baseline(ys, n, target_seconds=12.0):
-    """The CPU restatement (oracle/, literal arithmetic, SoA engine), 1 core, on a bounded sample of
-    the same workload: full N, as many SMC steps as fit in ~target_seconds."""
+def _cpu_run(ys, n, variant, threads, target_seconds):
     from tests import oracle_lib as O
 
-    pf = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, 20241008, O.VARIANT_SOA, threads=1)
+    pf = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, 20241008, variant, threads=threads)
     pf.init_step(ys[:1])
     pf.resample()
     t0 = time.perf_counter()
@@ -51,9 +49,29 @@ def cpu_baseline(ys, n, target_seconds=12.0):
         pf.resample()
         steps += 1
     dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+    return n * steps / dt, steps, dt
+
+
+def cpu_baseline(ys, n):
+    """The CPU restatement (oracle/), on bounded samples of the same workload:
+      value               SoA engine, literal libm arithmetic, sequential fp64 CDF + binary search, 1 core (the
+                          reference is single-threaded), full N, as many SMC steps as fit in ~10 s;
+      all_cores           the same with the element-wise loops on every host core (sums stay sequential), ~5 s;
+      structure_faithful  the reference's own structure — trie-addressed traces and its O(N^2) multinomial — at
+                          N = 10^4 (at 2^20 one resample would take hours), a few steps."""
+    from tests import oracle_lib as O
+
+    v, steps, dt = _cpu_run(ys, n, O.VARIANT_SOA, 1, 10.0)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    va, sa, dta = _cpu_run(ys, n, O.VARIANT_SOA, cores, 5.0)
+    n_sf = 10000
+    vs, ss, dts = _cpu_run(ys, n_sf, 0, 1, 2.0)
+    return {"value": v, "unit": "particle-steps/s", "cores": 1, "kind": "port",
             "sample": f"{steps} SMC steps (step+resample) at N={n}, C++ restatement of modppl's CPU path "
-                      f"(SoA engine, literal libm arithmetic, sequential fp64 CDF + binary search), {dt:.1f} s"}
+                      f"(SoA engine, literal libm arithmetic, sequential fp64 CDF + binary search), {dt:.1f} s",
+            "all_cores": {"value": va, "cores": cores, "sample": f"{sa} steps at N={n}, std::thread over the element-wise loops, {dta:.1f} s"},
+            "structure_faithful": {"value": vs, "cores": 1,
+                                   "sample": f"{ss} steps at N={n_sf}, trie-addressed traces + the reference's O(N^2) multinomial, {dts:.1f} s"}}
 
 
 def main():
@@ -154,6 +172,21 @@ def main():
                "bin_draws": timer.get_timing(capi.MP_K_BIN_DRAWS), "resample_gather": timer.get_timing(capi.MP_K_RESAMPLE_GATHER)}
         timer.set_timing(False)
 
+    # what a plain device-to-device copy reaches on this box (read + write bytes), for scale next to the 8 TB/s spec peak
+    copy_gbps = None
+    if rank == 0:
+        a_ = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+        b_ = torch.empty_like(a_)
+        b_.copy_(a_)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b_.copy_(a_)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * a_.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a_, b_
     if rank == 0:
         # mean duration of one launch of each kernel (single GPU: one launch of each per step)
         avg_us = {k: (v[0] / v[1]) * 1e3 if v[1] else 0.0 for k, v in fam.items()}
@@ -187,6 +220,7 @@ def main():
             "log_ml_abs_err_vs_kalman": abs(lml - kalman),
             "step_bytes_per_particle": BYTES_STEP,
             "step_hbm_frac": BYTES_STEP * n * K / dt / 1e9 / HBM_PEAK_GBPS,
+            "hbm_copy_measured_GBps": copy_gbps,
             "kernel_avg_us": avg_us,
             "kernel_launches_per_step": {k: v[1] / K for k, v in fam.items()},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

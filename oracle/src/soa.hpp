@@ -141,6 +141,20 @@ struct SoaPf {
         }
         for (auto& t_ : th) t_.join();
     }
+    // lib.rs:34-45 with the exps evaluated in parallel and summed in index order (bit-identical to logsumexp())
+    double logsumexp_mt(const std::vector<double>& xs) {
+        if (threads <= 1) return logsumexp(xs);
+        double max = -INFINITY;
+        for (double v : xs) max = std::fmax(max, v);
+        if (max == -INFINITY) return -INFINITY;
+        std::vector<double> ev(xs.size());
+        parallel_for([&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) ev[i] = o_exp(xs[i] - max);
+        });
+        double sum_exp = 0.;
+        for (double v : ev) sum_exp += v;
+        return max + o_ln(sum_exp);
+    }
     void propagate(const double* args0, const double* obs, int n_steps, bool init) {
         const int d = model->dim_state;
         for (int k = 0; k < n_steps; ++k) {
@@ -183,18 +197,24 @@ struct SoaPf {
         const int d = model->dim_state;
         double L;
         if (!canonical) {
-            L = logsumexp(logw);
-            std::vector<double> cdf(n), two(n);
+            // Element-wise work (exp) may run on several threads; every SUM keeps the reference's sequential order
+            // (lib.rs:41 fold, categorical.rs:26-31 running sum), so the results do not depend on the thread count.
+            L = logsumexp_mt(logw);
+            std::vector<double> cdf(n), two(n), wv(n);
+            parallel_for([&](size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) {
+                    lnw[i] = logw[i] - L;
+                    two[i] = 2.0 * lnw[i];
+                    wv[i] = o_exp(lnw[i]);
+                }
+            });
             double run = 0., sum = 0.;
             for (size_t i = 0; i < n; ++i) {
-                lnw[i] = logw[i] - L;
-                two[i] = 2.0 * lnw[i];
-                const double w = o_exp(lnw[i]);
-                sum += w;
-                run += w; cdf[i] = run;
+                sum += wv[i];
+                run += wv[i]; cdf[i] = run;
             }
             if (!(std::fabs(sum - 1.0) <= 1e-8)) throw Panic("categorical: probs do not sum to 1 (eps 1e-8)");
-            ess_stale = o_exp(-logsumexp(two));
+            ess_stale = o_exp(-logsumexp_mt(two));
             log_ml += L - o_ln((double)n);
             parallel_for([&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) {
@@ -221,8 +241,10 @@ struct SoaPf {
             });
         }
         ++resample_count;
-        for (size_t i = 0; i < n; ++i)
-            for (int j = 0; j < d; ++j) x_tmp[i * d + j] = x[(size_t)parents[i] * d + j];
+        parallel_for([&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i)
+                for (int j = 0; j < d; ++j) x_tmp[i * d + j] = x[(size_t)parents[i] * d + j];
+        });
         x.swap(x_tmp);
         std::fill(logw.begin(), logw.end(), 0.);
         return L;
