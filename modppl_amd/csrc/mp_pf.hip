@@ -139,34 +139,37 @@ __device__ __forceinline__ int mp_guide_shift(u64 W) {
 // Thread t holds rows tile*2048 + 4t .. 4t+3: log-weights lw[] and first state components xv[].
 //   m_b = max lw;  a = mp_exp(lw - m_b);  q = rint(a * 2^51);  rows = tile-local inclusive prefix;  W_b, W2_b;  guide.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void normalize_tile(const double (&lw)[TILE_ITEMS], const double (&xv)[TILE_ITEMS], u64 n, u64 tile,
+template <int THREADS>
+__device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS], const double (&xv)[TILE / THREADS], u64 n, u64 tile,
                                                mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
                                                double* __restrict__ tile_m, u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
-    __shared__ double s_red[TILE_THREADS / 64];
-    __shared__ u64 s_wsum[TILE_THREADS / 64];
-    __shared__ u64 s_wsum2[TILE_THREADS / 64];
+    constexpr int ITEMS_ = TILE / THREADS;   // 512 x 4 or 1024 x 2: a tile is always 2048 consecutive slots
+    __shared__ double s_red[THREADS / 64];
+    __shared__ u64 s_wsum[THREADS / 64];
+    __shared__ u64 s_wsum2[THREADS / 64];
     __shared__ __attribute__((aligned(16))) unsigned short s_guide[GUIDE_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 base = tile * TILE + (u64)tid * TILE_ITEMS;
+    const u64 base = tile * TILE + (u64)tid * ITEMS_;
 
     double m = MP_NEG_INF;
 #pragma unroll
-    for (int j = 0; j < TILE_ITEMS; ++j)
+    for (int j = 0; j < ITEMS_; ++j)
         if (base + j < n) m = fmax(m, lw[j]);
     m = wave_max(m);
     if (lane == 0) s_red[wave] = m;
-    reinterpret_cast<u64*>(s_guide)[tid] = 0ull;  // TILE_THREADS x 8 B = the whole guide
+    if constexpr (THREADS == 512) reinterpret_cast<u64*>(s_guide)[tid] = 0ull;  // THREADS x (8 | 4) B = the whole guide
+    else reinterpret_cast<uint32_t*>(s_guide)[tid] = 0u;
     __syncthreads();
     m = s_red[0];
 #pragma unroll
-    for (int w = 1; w < TILE_THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_red[w]);
     const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
 
     const double scale = mp_u2f((u64)(1023 + FIX_BITS) << 52);  // 2^51
-    u64 c[TILE_ITEMS];
+    u64 c[ITEMS_];
     u64 run = 0, run2 = 0;
 #pragma unroll
-    for (int j = 0; j < TILE_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS_; ++j) {
         const bool live = ok && (base + j < n);
         const double a = live ? mp_exp(lw[j] - m) : 0.;
         run += mp_quantize(a, scale);
@@ -180,14 +183,14 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE_ITEMS], c
     __syncthreads();
     u64 woff = 0, W = 0;
 #pragma unroll
-    for (int k = 0; k < TILE_THREADS / 64; ++k) {
+    for (int k = 0; k < THREADS / 64; ++k) {
         const u64 v = s_wsum[k];
         if (k < wave) woff += v;
         W += v;
     }
     const u64 off = woff + (incl - run);
 #pragma unroll
-    for (int j = 0; j < TILE_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS_; ++j) {
         if (base + j < n) {
             mp_cx row;
             row.cum = off + c[j];
@@ -198,7 +201,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE_ITEMS], c
     if (tid == 0) {
         u64 t2 = 0;
 #pragma unroll
-        for (int k = 0; k < TILE_THREADS / 64; ++k) t2 += s_wsum2[k];
+        for (int k = 0; k < THREADS / 64; ++k) t2 += s_wsum2[k];
         tile_m[tile] = m;
         tile_W[tile] = W;
         tile_W2[tile] = t2;
@@ -209,12 +212,12 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE_ITEMS], c
     u64 prev = off;
     int long_lo = 0, long_hi = -1, long_j = 0;  // at most one long run is kept per thread; extra ones fall back to direct writes
 #pragma unroll
-    for (int j = 0; j < TILE_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS_; ++j) {
         const u64 cur = off + c[j];
         if (cur > prev) {
             const int g_lo = prev ? (int)(prev >> shift) + 1 : 0;
             const int g_hi = (int)(cur >> shift);
-            const unsigned short idx = (unsigned short)(tid * TILE_ITEMS + j);
+            const unsigned short idx = (unsigned short)(tid * ITEMS_ + j);
             if (g_hi - g_lo < GUIDE_DIRECT || long_hi >= long_lo) {
                 for (int g = g_lo; g <= g_hi; ++g) s_guide[g] = idx;
             } else {
@@ -232,7 +235,8 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE_ITEMS], c
         pending &= pending - 1;
     }
     __syncthreads();
-    reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
+    if constexpr (THREADS == 512) reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
+    else reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint32_t*>(s_guide)[tid];
 }
 
 // standalone form: used when the log-weights changed without a propagate (after a resample, before a query or a
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* 
             xv[j] = (base + j < n) ? x0[(base + j) * (u64)D] : 0.;
         }
     }
-    normalize_tile(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
+    normalize_tile<TILE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,8 +276,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* 
 // (particle, normal site) items: a wave iterates max-over-lanes of the SUM of attempts instead of the sum over
 // items of the max, i.e. ~1.9 Philox blocks per item at 4 items instead of ~3.6 (acceptance pi/4, 64 lanes).
 // Phase 2 runs the model kernel per particle on the accepted pairs.
-template <class Model>
-__global__ __launch_bounds__(TILE_THREADS) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
+template <class Model, int THREADS>
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
                                                             mp_obs obs, mp_state0 s0, int overwrite,
                                                             const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
@@ -283,14 +287,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_propagate(Model model, u64 n, 
                                                             const uint32_t* __restrict__ inv, const uint32_t* __restrict__ res_parent) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
-    constexpr int ITEMS = k1_items<Model>();
-    constexpr int ROUNDS = TILE_ITEMS / ITEMS;
+    constexpr int LANE_ITEMS = TILE / THREADS;
+    constexpr int ITEMS = k1_items<Model>() < LANE_ITEMS ? k1_items<Model>() : LANE_ITEMS;
+    constexpr int ROUNDS = LANE_ITEMS / ITEMS;
     constexpr int M = ITEMS * NS;
     const int ns = model.n_normals(t);  // wave-uniform
-    const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * TILE_ITEMS;
-    double lw[TILE_ITEMS], xv[TILE_ITEMS];
+    const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * LANE_ITEMS;
+    double lw[LANE_ITEMS], xv[LANE_ITEMS];
 #pragma unroll
-    for (int j = 0; j < TILE_ITEMS; ++j) { lw[j] = MP_NEG_INF; xv[j] = 0.; }
+    for (int j = 0; j < LANE_ITEMS; ++j) { lw[j] = MP_NEG_INF; xv[j] = 0.; }
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const u64 i0 = base + (u64)rd * ITEMS;
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_propagate(Model model, u64 n, 
         }
     }
     // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----
-    normalize_tile(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
+    normalize_tile<THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1233,7 +1238,9 @@ struct ModelOpsT : ModelOps {
         static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
     }
     void propagate(const PropagateArgs& a) const override {
-        hipLaunchKernelGGL(k_propagate<Model>, dim3(a.grid), dim3(TILE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+        // light kernels (few registers) run 1024 threads x 2 particles per tile: twice the waves in flight for the same 2048-slot tile
+        constexpr int THREADS = (Model::MAX_NORMALS <= 2 && Model::DIM_STATE <= 2) ? 1024 : TILE_THREADS;
+        hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.res_stride, a.nchunks, a.cx, a.guide,
                            a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent);
     }

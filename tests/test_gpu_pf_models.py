@@ -168,3 +168,53 @@ def test_lgssm_band_parity(D):
                 e.step(obs[t:t + 1])
         assert dyn.log_marginal_likelihood_estimate() == soa.log_marginal_likelihood_estimate()
         assert np.array_equal(dyn.state(), soa.state())
+
+
+def band_kalman_log_ml(obs, D, a, band, sig0, sig_x, sig_y):
+    """Exact log marginal likelihood of the banded LGSSM (matrix Kalman filter, numpy): x0 ~ N(0, sig0^2 I),
+    x' = A x + sig_x z with A = a (I + band (shift up + shift down)), y = x + sig_y e."""
+    A = a * (np.eye(D) + band * (np.eye(D, k=1) + np.eye(D, k=-1)))
+    Q, R = sig_x ** 2 * np.eye(D), sig_y ** 2 * np.eye(D)
+    m, P = np.zeros(D), sig0 ** 2 * np.eye(D)
+    ll = 0.0
+    for t, y in enumerate(obs):
+        if t > 0:
+            m, P = A @ m, A @ P @ A.T + Q
+        S = P + R
+        r = y - m
+        ll += -0.5 * (D * math.log(2 * math.pi) + np.linalg.slogdet(S)[1] + r @ np.linalg.solve(S, r))
+        K = P @ np.linalg.inv(S)
+        m, P = m + K @ r, (np.eye(D) - K) @ P
+    return ll
+
+
+def test_lgssm_band16_c5_shard_size_properties():
+    """BASELINE config 5, one GPU's share (2^21 particles, d = 16) through mp_pf_run: finite, reproducible, parents in
+    range, and the log-ML estimate against the exact matrix Kalman filter (observations simulated from the model, so the
+    bootstrap filter keeps a usable ESS in 16 dimensions; tolerance 0.5 nats on a value of a few hundred)."""
+    import modppl_amd
+
+    D, T, n = 16, 12, 1 << 21
+    a, band, sig0, sig_x, sig_y = 0.9, 0.05, 1.0, 0.5, 1.0
+    rng = np.random.default_rng(16)
+    A = a * (np.eye(D) + band * (np.eye(D, k=1) + np.eye(D, k=-1)))
+    x = sig0 * rng.normal(size=D)
+    obs = []
+    for t in range(T):
+        if t > 0:
+            x = A @ x + sig_x * rng.normal(size=D)
+        obs.append(x + sig_y * rng.normal(size=D))
+    obs = np.array(obs)
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_band_model(D, a, band, sig0, sig_x, sig_y), n, 5)
+    pf.run(None, obs)
+    lml = pf.log_marginal_likelihood_estimate()
+    exact = band_kalman_log_ml(obs, D, a, band, sig0, sig_x, sig_y)
+    assert np.isfinite(lml) and abs(lml - exact) < 0.5, (lml, exact)
+    xs = pf.states()
+    assert xs.shape == (n, D) and np.all(np.isfinite(xs))
+    par = pf.parents
+    assert par.max() < n and np.all(pf.log_weights == 0.0)
+    # traces[i] = traces[parents[i]]: after the final resample every state row is one of the pre-resample rows
+    pf2 = modppl_amd.ParticleSystem(modppl_amd.lgssm_band_model(D, a, band, sig0, sig_x, sig_y), n, 5)
+    pf2.run(None, obs)
+    assert np.array_equal(pf2.parents, par) and pf2.log_marginal_likelihood_estimate() == lml and np.array_equal(pf2.states(), xs)
