@@ -74,6 +74,7 @@ enum mp_resample_scheme {
     MP_RESAMPLE_SYSTEMATIC = 1,  /* extension named by the north star; no reference counterpart: one uniform u0 per resample,
                                   * u_g = (g + u0) / N; parents come out sorted, so the gather is coalesced and the multi-GPU
                                   * exchange near-neighbour */
+    MP_RESAMPLE_STRATIFIED = 2,  /* extension: the same lattice with one uniform per output slot, u_g = (g + u_g') / N; sorted parents too */
 };
 enum mp_ess_mode {
     MP_ESS_REFERENCE = 0, /* particle_filter.rs:98-100: from the weights normalised by the LAST resample() (1/N before any) */
@@ -101,6 +102,10 @@ int32_t mp_pf_effective_sample_size(mp_pf* h, int32_t ess_mode, double* out);
 /* ParticleSystem::resample — :103-116.  Returns the log total weight through `log_total_weight`;
  * pass NULL to enqueue without synchronising (the value still feeds the log-ML estimate). */
 int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight);
+/* ESS-triggered resampling (extension named by the north star): resample with `scheme` iff the effective sample size of the
+ * CURRENT weights is below ess_fraction * n_particles.  *resampled = 0 / 1; ess_out and log_total_weight may be NULL. */
+int32_t mp_pf_resample_if_ess_below(mp_pf* h, int32_t scheme, double ess_fraction, int32_t* resampled, double* ess_out,
+                                    double* log_total_weight);
 /* ParticleSystem::log_marginal_likelihood_estimate — :119-121. */
 int32_t mp_pf_log_marginal_likelihood_estimate(mp_pf* h, double* out);
 /* The pub `traces` field (:13): traces[i].retv.last() for all i -> x_out[n_local][dim_state]. */

@@ -12,7 +12,7 @@ MP_OK = 0
 MP_ERR_INVALID_ARG, MP_ERR_STATE, MP_ERR_CONSTRAINTS, MP_ERR_DEGENERATE, MP_ERR_HIP, MP_ERR_UNSUPPORTED, MP_ERR_CAPACITY = 1, 2, 3, 4, 5, 6, 7
 
 MP_MODEL_LGSSM1, MP_MODEL_SPIRAL, MP_MODEL_HMM, MP_MODEL_BEARINGS, MP_MODEL_LGSSM_BAND = 1, 2, 3, 4, 5
-MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC = 0, 1
+MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC, MP_RESAMPLE_STRATIFIED = 0, 1, 2
 MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
 MP_PF_RECORD_HISTORY = 1
 MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER, MP_K_BIN_DRAWS = 0, 1, 2, 3
@@ -23,7 +23,7 @@ MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1
 # every symbol include/modppl_hip.h declares (tests/test_capi_symbols.py checks the export table)
 SYMBOLS = [
     "mp_last_error", "mp_device_count", "mp_pf_create", "mp_pf_init_step", "mp_pf_step", "mp_pf_effective_sample_size",
-    "mp_pf_resample", "mp_pf_log_marginal_likelihood_estimate", "mp_pf_read_state", "mp_pf_read_log_weights",
+    "mp_pf_resample", "mp_pf_resample_if_ess_below", "mp_pf_log_marginal_likelihood_estimate", "mp_pf_read_state", "mp_pf_read_log_weights",
     "mp_pf_read_parents", "mp_pf_read_trajectory", "mp_pf_time", "mp_pf_run", "mp_pf_synchronize", "mp_pf_destroy",
     "mp_pf_set_timing", "mp_pf_get_timing", "mp_importance_resampling",
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
@@ -91,6 +91,7 @@ def load():
     L.mp_pf_step.argtypes = [p, dp, i32]
     L.mp_pf_effective_sample_size.argtypes = [p, i32, dp]
     L.mp_pf_resample.argtypes = [p, i32, dp]
+    L.mp_pf_resample_if_ess_below.argtypes = [p, i32, C.c_double, C.POINTER(C.c_int32), dp, dp]
     L.mp_pf_log_marginal_likelihood_estimate.argtypes = [p, dp]
     L.mp_pf_read_state.argtypes = [p, dp]
     L.mp_pf_read_log_weights.argtypes = [p, dp]

@@ -519,6 +519,16 @@ __device__ __forceinline__ uint32_t mp_systematic_k32(uint32_t rc, uint32_t k0, 
     const mp_u64x2 r = mp_philox4x32_10(0u, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | 1u, 0u, k0, k1);
     return (uint32_t)(r.a >> 32);
 }
+// Stratified resampling (extension): the same lattice with one uniform PER output slot, u_g = (g + k32_g / 2^32) / N
+// (Philox slot g, site 2); parents still come out sorted.
+__device__ __forceinline__ uint32_t mp_stratified_k32(u64 g, uint32_t rc, uint32_t k0, uint32_t k1) {
+    const mp_u64x2 r = mp_philox4x32_10((uint32_t)g, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | 2u, 0u, k0, k1);
+    return (uint32_t)(r.a >> 32);
+}
+// target of global output slot g under scheme 1 (systematic, shared k32) or 2 (stratified)
+__device__ __forceinline__ u64 mp_target_lattice(int scheme, u64 g, uint32_t shared_k32, uint32_t rc, uint32_t k0, uint32_t k1, u64 Q, u64 n_global) {
+    return mp_target_systematic(g, scheme == 2 ? mp_stratified_k32(g, rc, k0, k1) : shared_k32, Q, n_global);
+}
 
 // Tile of a global target: tile totals are nearly equal (each sums 2048 weights), so target * nt / Q lands within a
 // tile or two of the answer; walk from there.  Same result as a lower_bound over s_incl, fewer LDS reads.
@@ -547,7 +557,7 @@ __device__ __forceinline__ void mp_locate(const u64* s_incl, const u64* s_W, uin
 // K3 (single-kernel form): draw, search, gather, reset.  Used for importance_resampling's M draws (domain IS) and
 // for systematic resampling (sorted parents: coalesced by construction).  n_out draws over a table of n rows.
 // ---------------------------------------------------------------------------------------------
-template <bool SYSTEMATIC>
+template <int SCHEME>
 __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out, u64 n_global, u64 slot_offset, uint32_t domain,
                                                                 uint32_t k0, uint32_t k1, uint32_t rc, int S, int D,
                                                                 const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
@@ -566,7 +576,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
         const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
         if (threadIdx.x == 0) fold_scalars(scal, Q, Q2, S, m, n_global, 0);
     }
-    const uint32_t sys_k32 = SYSTEMATIC ? mp_systematic_k32(rc, k0, k1) : 0u;
+    const uint32_t sys_k32 = SCHEME == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
     const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
     for (u64 i0 = (u64)blockIdx.x * (K3_THREADS * K3_ITEMS) + threadIdx.x; i0 < n_out; i0 += (u64)gridDim.x * (K3_THREADS * K3_ITEMS)) {
         u64 lt[K3_ITEMS], tbase[K3_ITEMS];
@@ -575,8 +585,8 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
         for (int k = 0; k < K3_ITEMS; ++k) {
             const u64 i = i0 + (u64)k * K3_THREADS;
             u64 target;
-            if (SYSTEMATIC) {
-                target = mp_target_systematic(slot_offset + (i < n_out ? i : 0), sys_k32, Q, n_global);
+            if (SCHEME != 0) {
+                target = mp_target_lattice(SCHEME, slot_offset + (i < n_out ? i : 0), sys_k32, rc, k0, k1, Q, n_global);
             } else {
                 const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
                 target = mp_target(mp_u52(r.a), Q);
@@ -857,8 +867,8 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_globa
     const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
     if (i < n) {
         u64 target;
-        if (systematic) {
-            target = mp_target_systematic(slot_offset + i, mp_systematic_k32(rc, k0, k1), Q, n_global);
+        if (systematic) {   // 1 systematic, 2 stratified
+            target = mp_target_lattice(systematic, slot_offset + i, systematic == 1 ? mp_systematic_k32(rc, k0, k1) : 0u, rc, k0, k1, Q, n_global);
         } else {
             const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
             target = mp_target(mp_u52(r.a), Q);
@@ -1025,7 +1035,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
     const u64 Q = s_incl[nt_all - 1];
     const double nt_over_Q = (double)nt_all / (double)Q;
     const u64 i0 = (u64)blockIdx.x * (SH_THREADS * SHF_ITEMS) + threadIdx.x;
-    const uint32_t k32 = systematic ? mp_systematic_k32(rc, k0, k1) : 0u;
+    const uint32_t k32 = systematic == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
     int key[SHF_ITEMS];
     uint32_t tl[SHF_ITEMS], place[SHF_ITEMS];
     u64 lt[SHF_ITEMS];
@@ -1035,8 +1045,8 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
         key[k] = -1;
         if (i < n) {
             u64 target;
-            if (systematic) {
-                target = mp_target_systematic(slot_offset + i, k32, Q, n_global);
+            if (systematic) {   // 1 systematic, 2 stratified
+                target = mp_target_lattice(systematic, slot_offset + i, k32, rc, k0, k1, Q, n_global);
             } else {
                 const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
                 target = mp_target(mp_u52(r.a), Q);
@@ -1622,8 +1632,8 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         const int nt_job = (int)((h->n_global + TILE - 1) / TILE);
         const size_t need = table_lds(nt_job, K3_THREADS) + 1024;
         if (need > 48 * 1024) {
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
@@ -1671,7 +1681,8 @@ int32_t mp_pf_step(mp_pf* h, const double* obs, int32_t n_steps) {
 int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
-    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC) return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
+    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC && scheme != MP_RESAMPLE_STRATIFIED)
+        return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: resample runs through the mp_pf_shard_* phases");
     HIPCK(hipSetDevice(h->device));
     int32_t rc = ensure_rows(h);
@@ -1692,13 +1703,18 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
             hipLaunchKernelGGL(k_resolve_bins, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, d, h->nchunks, h->seg_lt, h->seg_row,
                                h->seg_cnt, h->cx, h->x[h->cur], h->res_x, h->res_stride, h->res_parent);
             binned = true;
+        } else if (scheme == MP_RESAMPLE_STRATIFIED) {
+            hipLaunchKernelGGL(k_resample_gather<2>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
+                               h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
+                               h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
+                               h->scal);
         } else if (scheme == MP_RESAMPLE_SYSTEMATIC) {
-            hipLaunchKernelGGL(k_resample_gather<true>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
+            hipLaunchKernelGGL(k_resample_gather<1>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
                                h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
                                h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
                                h->scal);
         } else {
-            hipLaunchKernelGGL(k_resample_gather<false>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
+            hipLaunchKernelGGL(k_resample_gather<0>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
                                h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
                                h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
                                h->scal);
@@ -1752,6 +1768,21 @@ int32_t mp_pf_effective_sample_size(mp_pf* h, int32_t ess_mode, double* out) {
     if (rc != MP_OK) return rc;
     *out = h->h_scal->ess_fresh;
     return MP_OK;
+}
+
+// ESS-triggered (adaptive) resampling: the usual SMC policy on top of the reference's unconditional `resample`
+// (tests/smc.rs:79-84 resamples every step).  Uses the CURRENT weights (MP_ESS_FRESH), one host round trip.
+int32_t mp_pf_resample_if_ess_below(mp_pf* h, int32_t scheme, double ess_fraction, int32_t* resampled, double* ess_out, double* log_total_weight) {
+    if (!h || !resampled) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (!(ess_fraction >= 0.) || ess_fraction > 1.) return mp_fail(MP_ERR_INVALID_ARG, "ess_fraction must be in [0, 1]");
+    if (h->sharded) return mp_fail(MP_ERR_UNSUPPORTED, "sharded filters decide from mp_pf_shard_query_packed on every rank");
+    double ess = 0.;
+    int32_t rc = mp_pf_effective_sample_size(h, MP_ESS_FRESH, &ess);
+    if (rc != MP_OK) return rc;
+    if (ess_out) *ess_out = ess;
+    *resampled = (ess < ess_fraction * (double)h->n) ? 1 : 0;
+    if (!*resampled) return MP_OK;
+    return mp_pf_resample(h, scheme, log_total_weight);
 }
 
 int32_t mp_pf_log_marginal_likelihood_estimate(mp_pf* h, double* out) {
@@ -1809,7 +1840,8 @@ int32_t mp_pf_shard_tiles(mp_pf* h, double* d_tile_m, uint64_t* d_tile_W, uint64
 int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const double* d_tm_all, const uint64_t* d_tW_all, const uint64_t* d_tW2_all, int32_t world,
                           int32_t rank, uint64_t* d_req_out, int64_t* send_counts) {
     if (!h || !d_tm_all || !d_tW_all || !d_tW2_all || !d_req_out || !send_counts) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC) return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
+    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC && scheme != MP_RESAMPLE_STRATIFIED)
+        return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (world < 1 || world > SH_MAX_WORLD || rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, 0 <= rank < world");
     if ((u64)world * h->n != h->n_global) return mp_fail(MP_ERR_INVALID_ARG, "equal tile-aligned shards: world * n_particles must equal n_global");
     HIPCK(hipSetDevice(h->device));
@@ -1823,7 +1855,7 @@ int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const double* d_tm_all, cons
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         const size_t lds = table_lds(nt_all, SH_THREADS) + sizeof(uint32_t) * SH_MAX_WORLD;
         hipLaunchKernelGGL(k_shard_targets, dim3(nblk), dim3(SH_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, scheme == MP_RESAMPLE_SYSTEMATIC ? 1 : 0, h->S, d_tm_all, (const u64*)d_tW_all,
+                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, h->S, d_tm_all, (const u64*)d_tW_all,
                            nt_all, h->nt, world, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockcount);
         hipLaunchKernelGGL(k_shard_offsets, dim3(world), dim3(SH_THREADS), 0, h->stream, h->sh_blockcount, nblk, world, h->sh_blockoff, h->sh_counts);
         hipLaunchKernelGGL(k_shard_pack, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->sh_dest, h->sh_lt, h->sh_tile, h->sh_blockoff, h->sh_counts,
@@ -1953,7 +1985,8 @@ int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out) {
 int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
                                 uint64_t* d_req_out) {
     if (!h || !d_tiles_all || !d_req_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC) return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
+    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC && scheme != MP_RESAMPLE_STRATIFIED)
+        return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (world < 1 || world > SH_MAX_WORLD || rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, 0 <= rank < world");
     if ((u64)world * h->n != h->n_global) return mp_fail(MP_ERR_INVALID_ARG, "equal tile-aligned shards: world * n_particles must equal n_global");
     if (capacity == 0) return mp_fail(MP_ERR_INVALID_ARG, "capacity must be > 0");
@@ -1969,7 +2002,7 @@ int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         const size_t lds = table_lds(nt_all, SH_THREADS) + (sizeof(uint32_t) + sizeof(u64)) * SH_MAX_KEYS;
         const int nblk_f = (int)((h->n + SH_THREADS * SHF_ITEMS - 1) / (SH_THREADS * SHF_ITEMS));
         hipLaunchKernelGGL(k_shard_route_fused, dim3(nblk_f), dim3(SH_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, scheme == MP_RESAMPLE_SYSTEMATIC ? 1 : 0, h->S, h->sh_tm_all, h->sh_tW_all,
+                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, h->S, h->sh_tm_all, h->sh_tW_all,
                            nt_all, h->nt, world, (u64)capacity, (unsigned long long*)h->sh_counts, (u64*)d_req_out, h->sh_req_slot);
         hipLaunchKernelGGL(k_shard_finalize, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, h->sh_tm_all, h->sh_tW_all,
                            h->sh_tW2_all, nt_all, h->S, h->n_global, h->scal, h->scal_undo, (const unsigned long long*)h->sh_counts, world,
@@ -2187,7 +2220,7 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
         uint32_t* d_idx = nullptr;
         HIPCK(hipMalloc(&d_idx, sizeof(uint32_t) * num_ret_samples));
         const int grid = (int)std::min<u64>((num_ret_samples + K3_THREADS * K3_ITEMS - 1) / (K3_THREADS * K3_ITEMS), (u64)K3_MAX_BLOCKS);
-        hipLaunchKernelGGL(k_resample_gather<false>, dim3(grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, (u64)num_ret_samples,
+        hipLaunchKernelGGL(k_resample_gather<0>, dim3(grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, (u64)num_ret_samples,
                            h->n_global, (u64)0, (uint32_t)MP_DOM_IS, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), 0u, h->S, h->ops->dim_state, h->cx,
                            h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, (const double*)nullptr, (double*)nullptr, d_idx, (double*)nullptr,
                            (mp_dev_scalars*)nullptr);

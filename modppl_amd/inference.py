@@ -78,6 +78,13 @@ class ParticleSystem:
         capi.check(self._L.mp_pf_resample(self._h, scheme, C.byref(out)))
         return out.value
 
+    def maybe_resample(self, ess_fraction=0.5, scheme=capi.MP_RESAMPLE_MULTINOMIAL):
+        """ESS-triggered resampling (extension): resample iff ESS(current weights) < ess_fraction * N.
+        -> (resampled, ess, log total weight or None)."""
+        did, ess, ltw = C.c_int32(), C.c_double(), C.c_double()
+        capi.check(self._L.mp_pf_resample_if_ess_below(self._h, scheme, float(ess_fraction), C.byref(did), C.byref(ess), C.byref(ltw)))
+        return bool(did.value), ess.value, (ltw.value if did.value else None)
+
     def log_marginal_likelihood_estimate(self):
         """particle_filter.rs:119-121."""
         out = C.c_double()

@@ -48,6 +48,8 @@ extern "C" {
     pub fn mp_pf_step(h: *mut mp_pf, obs: *const f64, n_steps: i32) -> i32;
     pub fn mp_pf_effective_sample_size(h: *mut mp_pf, ess_mode: i32, out: *mut f64) -> i32;
     pub fn mp_pf_resample(h: *mut mp_pf, scheme: i32, log_total_weight: *mut f64) -> i32;
+    pub fn mp_pf_resample_if_ess_below(h: *mut mp_pf, scheme: i32, ess_fraction: f64, resampled: *mut i32, ess_out: *mut f64,
+                                       log_total_weight: *mut f64) -> i32;
     pub fn mp_pf_log_marginal_likelihood_estimate(h: *mut mp_pf, out: *mut f64) -> i32;
     pub fn mp_pf_read_state(h: *mut mp_pf, x_out: *mut f64) -> i32;
     pub fn mp_pf_read_log_weights(h: *mut mp_pf, out: *mut f64) -> i32;

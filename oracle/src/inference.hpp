@@ -229,6 +229,15 @@ inline uint32_t canonical_systematic_k32(uint64_t seed, uint32_t rc) {
     Rng r; r.seed = seed; r.slot = 0; r.step = rc; r.at(DOM_RESAMPLE, 1);
     return (uint32_t)(r.bits64() >> 32);
 }
+// stratified (extension): one k32 per global output slot g (site 2)
+inline uint32_t canonical_stratified_k32(uint64_t seed, uint32_t rc, uint64_t g) {
+    Rng r; r.seed = seed; r.slot = (uint32_t)g; r.step = rc; r.at(DOM_RESAMPLE, 2);
+    return (uint32_t)(r.bits64() >> 32);
+}
+// scheme 1 (systematic) or 2 (stratified)
+inline uint64_t canonical_target_lattice(int scheme, uint64_t seed, uint32_t rc, uint64_t g, uint64_t Q, uint64_t n_global) {
+    return canonical_target_systematic(g, scheme == 2 ? canonical_stratified_k32(seed, rc, g) : canonical_systematic_k32(seed, rc), Q, n_global);
+}
 
 // ---- particle_filter.rs ---------------------------------------------------------------
 template <class Args, class Data, class Ret>

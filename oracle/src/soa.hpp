@@ -190,10 +190,10 @@ struct SoaPf {
         for (size_t i = 0; i < n; ++i) two[i] = 2.0 * (logw[i] - L);
         return o_exp(-logsumexp(two));
     }
-    int scheme = 0;  // 0 multinomial, 1 systematic (canonical mode only)
+    int scheme = 0;  // 0 multinomial, 1 systematic, 2 stratified (1, 2: canonical mode only)
     double resample() {
         if (!initialised) throw Panic("resample before init_step");
-        if (scheme == 1 && !canonical) throw Panic("systematic resampling: canonical mode only (no reference counterpart)");
+        if (scheme != 0 && !canonical) throw Panic("systematic / stratified resampling: canonical mode only (no reference counterpart)");
         const int d = model->dim_state;
         double L;
         if (!canonical) {
@@ -235,7 +235,7 @@ struct SoaPf {
             parallel_for([&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) {
                     Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
-                    if (scheme == 1) parents[i] = (uint32_t)canonical_parent(c, canonical_target_systematic(slot_offset + i, canonical_systematic_k32(seed, resample_count), c.c.Q, n_global));
+                    if (scheme != 0) parents[i] = (uint32_t)canonical_parent(c, canonical_target_lattice(scheme, seed, resample_count, slot_offset + i, c.c.Q, n_global));
                     else parents[i] = (uint32_t)canonical_parent(c, canonical_target(r.u52(), c.c.Q));
                 }
             });
@@ -277,7 +277,7 @@ struct SoaPf {
         for (int r = 0; r < world; ++r) send_counts[r] = 0;
         for (size_t i = 0; i < n; ++i) {
             Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
-            const uint64_t target = scheme == 1 ? canonical_target_systematic(slot_offset + i, canonical_systematic_k32(seed, resample_count), sh_c.Q, n_global)
+            const uint64_t target = scheme != 0 ? canonical_target_lattice(scheme, seed, resample_count, slot_offset + i, sh_c.Q, n_global)
                                                 : canonical_target(r.u52(), sh_c.Q);
             size_t tile; uint64_t lt;
             canonical_locate(sh_c, target, &tile, &lt);

@@ -1,17 +1,21 @@
-"""GPU: systematic resampling (extension; modppl has multinomial only, particle_filter.rs:37-41).
-Checked against the canonical checker bit for bit and through the properties that define it."""
+"""GPU: systematic and stratified resampling, ESS-triggered resampling (extensions; modppl has unconditional multinomial
+only, particle_filter.rs:37-41).  Checked against the canonical checker bit for bit and through the properties that
+define them."""
 import numpy as np
 import pytest
 
 from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
-SYS = 1
+SYS, STRAT = 1, 2
 
 
+@pytest.mark.parametrize("scheme", [SYS, STRAT])
 @pytest.mark.parametrize("n", [1000, 4097, 100000, 1 << 20])
-def test_systematic_bit_exact_and_properties(n):
+def test_systematic_bit_exact_and_properties(n, scheme):
     import modppl_amd
+
+    SYS = scheme   # same lattice; stratified draws one uniform per output slot
 
     ys = O.lgssm_observations(6)
     seed = 3 + n
@@ -28,13 +32,14 @@ def test_systematic_bit_exact_and_properties(n):
         assert np.all(np.diff(par.astype(np.int64)) >= 0)            # sorted parents: coalesced gather
         p = np.exp(w - np.logaddexp.reduce(w))
         counts = np.bincount(par, minlength=n)
-        assert np.all(np.abs(counts - n * p) < 1.0 + 1e-6 * n)        # offspring within 1 of N w_i
+        assert np.all(np.abs(counts - n * p) < (1.0 if scheme == 1 else 2.0) + 1e-6 * n)   # offspring within 1 (2: stratified) of N w_i
         pf.step(ys[t:t + 1])
         ref.step(ys[t:t + 1])
     assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
 
 
-def test_systematic_sharded_world1():
+@pytest.mark.parametrize("SYS", [1, 2])
+def test_systematic_sharded_world1(SYS):
     import modppl_amd
     from modppl_amd.distributed import ShardedParticleSystem
 
@@ -49,3 +54,31 @@ def test_systematic_sharded_world1():
         assert np.array_equal(a.parents, b.parents) and np.array_equal(a.states(), b.states())
         a.step(ys[t:t + 1])
         b.step(ys[t:t + 1])
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.5, 1.0])
+def test_ess_triggered_resampling(frac):
+    """maybe_resample(): the same decisions and results as the checker driven by its own fresh ESS."""
+    import modppl_amd
+
+    ys = O.lgssm_observations(12)
+    n, seed = 20000, 44
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, threads=4)
+    pf.init_step(None, ys[:1])
+    ref.init_step(ys[:1])
+    n_res = 0
+    for t in range(1, 12):
+        did, ess, ltw = pf.maybe_resample(frac)
+        ess_ref = ref.effective_sample_size(1)
+        assert ess == ess_ref
+        assert did == (ess_ref < frac * n)
+        if did:
+            n_res += 1
+            assert ltw == ref.resample()
+            assert np.array_equal(pf.parents, ref.parents())
+        pf.step(ys[t:t + 1])
+        ref.step(ys[t:t + 1])
+    assert np.array_equal(pf.log_weights, ref.log_weights())
+    assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+    assert (n_res == 0) if frac == 0.0 else (n_res > 0)

@@ -126,3 +126,27 @@ def test_spiral_model_runs_like_smc_rs():
     assert np.isfinite(a["lml"])
     traj = a["pf"].trajectory(0)
     assert traj.shape == (T, 2)  # traces[i].retv: one state per step (smc.rs:67 reads .last())
+
+
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_lattice_schemes_properties(scheme):
+    """Systematic (1) / stratified (2) resampling of the canonical checker (extensions, no reference counterpart): sorted
+    parents, offspring counts within 1 (2) of N w_i, unbiased-by-construction targets in [1, Q]; the literal engine
+    refuses them."""
+    n, seed = 5000, 12
+    ys = O.lgssm_observations(5)
+    pf = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    pf.init_step(ys[:1])
+    for t in range(1, 5):
+        w = pf.log_weights().copy()
+        pf.resample(scheme)
+        par = pf.parents().astype(np.int64)
+        assert np.all(np.diff(par) >= 0) and par.min() >= 0 and par.max() < n
+        p = np.exp(w - np.logaddexp.reduce(w))
+        counts = np.bincount(par, minlength=n)
+        assert np.all(np.abs(counts - n * p) < (1.0 if scheme == 1 else 2.0) + 1e-9 * n)
+        pf.step(ys[t:t + 1])
+    lit = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, 100, seed, O.VARIANT_SOA)
+    lit.init_step(ys[:1])
+    with pytest.raises(O.OracleError):
+        lit.resample(scheme)
