@@ -32,7 +32,7 @@ DIM = 1
 #   bin_draws       = the search half of the resample (8 + 4)
 #   resample_gather = the gather half: 4 + 16d, weight reset 8
 BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "bin_draws": 8 + 4, "resample_gather": 4 + 16 * DIM + 8}
-KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_bin_draws", "resample_gather": "k_resolve_bins"}
+KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_bin_draws", "resample_gather": "k_resolve_bins"}
 BYTES_STEP = 32 * DIM + 64
 
 
@@ -56,13 +56,15 @@ def cpu_baseline(ys, n):
     """The CPU restatement (oracle/), on bounded samples of the same workload:
       value               SoA engine, literal libm arithmetic, sequential fp64 CDF + binary search, 1 core (the
                           reference is single-threaded), full N, as many SMC steps as fit in ~10 s;
-      all_cores           the same with the element-wise loops on every host core (sums stay sequential), ~5 s;
+      all_cores           the same with the element-wise loops on this GPU's share of the host cores (<= 16; sums stay
+                          sequential), ~5 s;
       structure_faithful  the reference's own structure — trie-addressed traces and its O(N^2) multinomial — at
                           N = 10^4 (at 2^20 one resample would take hours), a few steps."""
     from tests import oracle_lib as O
 
     v, steps, dt = _cpu_run(ys, n, O.VARIANT_SOA, 1, 10.0)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)   # one GPU's share of the host (the box shows every core of the node)
     va, sa, dta = _cpu_run(ys, n, O.VARIANT_SOA, cores, 5.0)
     n_sf = 10000
     vs, ss, dts = _cpu_run(ys, n_sf, 0, 1, 2.0)

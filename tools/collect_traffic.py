@@ -20,7 +20,7 @@ STREAMING = {"propagate", "normalize_scan", "bin_draws"}
 
 def per_kernel(dirname, counter):
     """mean per launch of each kernel, summed over the kernels of a family (one launch of each per resample)"""
-    files = glob.glob(f"{dirname}/*/*_counter_collection.csv")
+    files = glob.glob(f"{dirname}/*/*_counter_collection.csv") + glob.glob(f"{dirname}/*_counter_collection.csv")
     per = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
