@@ -197,7 +197,11 @@ def main():
         dom = max(fam, key=lambda k: fam[k][0])   # the kernel with the largest total time
         achieved = BYTES_K[dom] * n / (avg_us[dom] * 1e-6) / 1e9
         traffic = None
-        if n == N_PER_GPU and os.path.exists(TRAFFIC_JSON):  # PMC passes cannot run inside this process: committed summary, same workload
+        sharded_path = world > 1 or force_sharded
+        if sharded_path:   # the sharded filter runs other kernels for the resample
+            KERNEL_OF.update({"bin_draws": "k_shard_route_fused", "resample_gather": "k_shard_resolve_binned"})
+        if n == N_PER_GPU and os.path.exists(TRAFFIC_JSON) and not (sharded_path and dom != "propagate"):
+            # PMC passes cannot run inside this process: committed summary of the same single-GPU workload
             try:
                 traffic = json.load(open(TRAFFIC_JSON))[dom]["traffic_bytes"]
             except Exception:
