@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libmodppl_hip.so")
 SOURCES = ["mp_pf.hip", "mp_mh.hip", "mp_probe.hip"]
-HEADERS = ["mp_math.h", "mp_philox.h", "mp_dists.h", "mp_models.h", os.path.join("..", "..", "include", "modppl_hip.h"),
+HEADERS = ["mp_math.h", "mp_philox.h", "mp_dists.h", "mp_models.h", "mp_linalg.h", "mp_pf_kernels.h", "mp_pf_shard_kernels.h", os.path.join("..", "..", "include", "modppl_hip.h"),
            os.path.join("..", "..", "include", "modppl_hip_probe.h")]
 # -ffp-contract=off: the only fused multiply-adds are the explicit fma() calls in mp_math.h, so the
 # device evaluates exp/log with exactly the operations the CPU checker uses (bit-exact indices).

@@ -1,0 +1,790 @@
+// mp_pf_kernels.h — device code of the single-GPU particle-filter step (included by mp_pf.hip only): level 0 / level 1
+// of the normalisation, K1 k_propagate, the single-kernel resample K3, the XCD-binned resample K3a / K3b.
+// Spec: DESIGN.md §4; CPU restatement: oracle/src/inference.hpp.
+#pragma once
+// ---------------------------------------------------------------------------------------------
+// device scalars
+// ---------------------------------------------------------------------------------------------
+struct mp_dev_scalars {
+    double m;          // global max log-weight of the last level-1 combine
+    double L;          // log total weight of the last resample (resample()'s return value)
+    double log_ml;     // log_ml_estimate (particle_filter.rs:24)
+    double ess_stale;  // ESS of the weights normalised by the last resample (:98-100 semantics)
+    double ess_fresh;  // outputs of the query path (k_finalize_tiles mode 1)
+    double lml_fresh;
+    u64 Q, Q2;
+    int degenerate;    // sticky: all log-weights were -inf (or +inf) at a normalisation
+    int pad;
+};
+
+constexpr int TILE_THREADS = 512;
+constexpr int TILE_ITEMS = 4;
+constexpr int TILE = TILE_THREADS * TILE_ITEMS;  // 2048 rows per tile: a constant of the normalisation spec
+constexpr int GUIDE_BITS = 11;                   // one guide bucket per table row (GUIDE_N == TILE): 2 B per particle
+constexpr int GUIDE_N = 1 << GUIDE_BITS;
+static_assert(GUIDE_N == TILE, "normalize_tile zeroes/stores the guide with one 8-byte word per thread");
+constexpr int GUIDE_DIRECT = 8;                  // bucket runs longer than this are filled by the whole wave
+constexpr int FIX_BITS = 51;                     // level-0 fixed point: q = rint(exp(lw - m_tile) * 2^51), 2048 * 2^51 < 2^63
+constexpr int BIN_CHUNK = 1024;                  // output slots per chunk of the binned resampler
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_ITEMS = BIN_CHUNK / BIN_THREADS;
+constexpr int BIN_GROUP = 8;                     // chunks per k_resolve_bins workgroup
+// Position of entry e of segment (bin, chunk) in the sparse segment arrays [bin][chunk][1024].  Only ~128 entries of
+// each 1024-entry window are used; the start is rotated by (chunk % 8) * 128 so the used parts spread over the address space.
+#define MP_SEG_POS(bin, c, e, nchunks) ((((u64)(bin) * (u64)(nchunks) + (u64)(c)) * BIN_CHUNK) + (u64)((((uint32_t)(e)) + (((uint32_t)(c)) & 7u) * 128u) & 1023u))
+constexpr int K3_THREADS = 256;
+constexpr int K3_ITEMS = 4;
+constexpr int K3_MAX_BLOCKS = 4096;
+constexpr int MAX_TILES = 8192;                  // LDS tile table: 16 B per tile
+
+// particles per predraw round in k_propagate: 4 pre-drawn (u, r) pairs per lane whatever the model's number of normal sites
+template <class Model>
+constexpr int k1_items() { return Model::MAX_NORMALS >= 4 ? 1 : 4 / Model::MAX_NORMALS; }
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 mp_quantize(double e, double scale) {
+    const double r = rint(e * scale);
+    return (r >= 0.) ? (u64)r : 0ull;  // NaN -> 0
+}
+
+// One row of the resampling table: tile-local inclusive fixed-point CDF value and the first state
+// component of the same particle, so that the probe that finds a parent also fetches its state.
+struct __attribute__((aligned(16))) mp_cx {
+    u64 cum;
+    double x0;
+};
+
+// Guide table (bucketed inverse CDF, per tile): bucket g covers tile-local targets t with
+// (t >> shift) == g, shift = max(0, bitlen(W) - 11) for the tile total W; guide[g] = first local
+// index j with cum_j >= max(1, g << shift).  A draw then starts its scan at guide[t >> shift]
+// and walks forward (expected < 2 rows).  Integer shifts only: no rounding anywhere.
+__device__ __forceinline__ int mp_guide_shift(u64 W) {
+    const int bits = 64 - __clzll((long long)W);  // W == 0 -> clz = 64 -> bits = 0
+    return bits > GUIDE_BITS ? bits - GUIDE_BITS : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 0 of the normalisation for ONE tile, by the workgroup (TILE_THREADS threads) that owns it.
+// Thread t holds rows tile*2048 + 4t .. 4t+3: log-weights lw[] and first state components xv[].
+//   m_b = max lw;  a = mp_exp(lw - m_b);  q = rint(a * 2^51);  rows = tile-local inclusive prefix;  W_b, W2_b;  guide.
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS], const double (&xv)[TILE / THREADS], u64 n, u64 tile,
+                                               mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
+                                               double* __restrict__ tile_m, u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
+    constexpr int ITEMS_ = TILE / THREADS;   // 512 x 4 or 1024 x 2: a tile is always 2048 consecutive slots
+    __shared__ double s_red[THREADS / 64];
+    __shared__ u64 s_wsum[THREADS / 64];
+    __shared__ u64 s_wsum2[THREADS / 64];
+    __shared__ __attribute__((aligned(16))) unsigned short s_guide[GUIDE_N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = tile * TILE + (u64)tid * ITEMS_;
+
+    double m = MP_NEG_INF;
+#pragma unroll
+    for (int j = 0; j < ITEMS_; ++j)
+        if (base + j < n) m = fmax(m, lw[j]);
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    if constexpr (THREADS == 512) reinterpret_cast<u64*>(s_guide)[tid] = 0ull;  // THREADS x (8 | 4) B = the whole guide
+    else reinterpret_cast<uint32_t*>(s_guide)[tid] = 0u;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+
+    const double scale = mp_u2f((u64)(1023 + FIX_BITS) << 52);  // 2^51
+    u64 c[ITEMS_];
+    u64 run = 0, run2 = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS_; ++j) {
+        const bool live = ok && (base + j < n);
+        const double a = live ? mp_exp(lw[j] - m) : 0.;
+        run += mp_quantize(a, scale);
+        run2 += mp_quantize(a * a, scale);
+        c[j] = run;
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    const u64 wtot2 = wave_sum_u64(run2);
+    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) s_wsum2[wave] = wtot2;
+    __syncthreads();
+    u64 woff = 0, W = 0;
+#pragma unroll
+    for (int k = 0; k < THREADS / 64; ++k) {
+        const u64 v = s_wsum[k];
+        if (k < wave) woff += v;
+        W += v;
+    }
+    const u64 off = woff + (incl - run);
+#pragma unroll
+    for (int j = 0; j < ITEMS_; ++j) {
+        if (base + j < n) {
+            mp_cx row;
+            row.cum = off + c[j];
+            row.x0 = xv[j];
+            cx[base + j] = row;
+        }
+    }
+    if (tid == 0) {
+        u64 t2 = 0;
+#pragma unroll
+        for (int k = 0; k < THREADS / 64; ++k) t2 += s_wsum2[k];
+        tile_m[tile] = m;
+        tile_W[tile] = W;
+        tile_W2[tile] = t2;
+    }
+
+    // ---- guide table of this tile ------------------------------------------------------------
+    const int shift = mp_guide_shift(W);
+    u64 prev = off;
+    int long_lo = 0, long_hi = -1, long_j = 0;  // at most one long run is kept per thread; extra ones fall back to direct writes
+#pragma unroll
+    for (int j = 0; j < ITEMS_; ++j) {
+        const u64 cur = off + c[j];
+        if (cur > prev) {
+            const int g_lo = prev ? (int)(prev >> shift) + 1 : 0;
+            const int g_hi = (int)(cur >> shift);
+            const unsigned short idx = (unsigned short)(tid * ITEMS_ + j);
+            if (g_hi - g_lo < GUIDE_DIRECT || long_hi >= long_lo) {
+                for (int g = g_lo; g <= g_hi; ++g) s_guide[g] = idx;
+            } else {
+                long_lo = g_lo; long_hi = g_hi; long_j = idx;
+            }
+        }
+        prev = cur;
+    }
+    // wave-cooperative fill of long runs (a particle holding a large share of the tile's weight)
+    u64 pending = __ballot(long_hi >= long_lo);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int lo = __shfl(long_lo, leader, 64), hi = __shfl(long_hi, leader, 64), jj = __shfl(long_j, leader, 64);
+        for (int g = lo + lane; g <= hi; g += 64) s_guide[g] = (unsigned short)jj;
+        pending &= pending - 1;
+    }
+    __syncthreads();
+    if constexpr (THREADS == 512) reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
+    else reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint32_t*>(s_guide)[tid];
+}
+
+// standalone form: used when the log-weights changed without a propagate (after a resample, before a query or a
+// second resample)
+__global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* __restrict__ logw, const double* __restrict__ x0, int D, u64 n,
+                                                                  mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
+                                                                  double* __restrict__ tile_m, u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
+    const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * TILE_ITEMS;
+    double lw[TILE_ITEMS], xv[TILE_ITEMS];
+    if (base + TILE_ITEMS <= n) {
+        const double2 a = *reinterpret_cast<const double2*>(logw + base);
+        const double2 b = *reinterpret_cast<const double2*>(logw + base + 2);
+        lw[0] = a.x; lw[1] = a.y; lw[2] = b.x; lw[3] = b.y;
+        if (D == 1) {
+            const double2 xa = *reinterpret_cast<const double2*>(x0 + base);
+            const double2 xb = *reinterpret_cast<const double2*>(x0 + base + 2);
+            xv[0] = xa.x; xv[1] = xa.y; xv[2] = xb.x; xv[3] = xb.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < TILE_ITEMS; ++j) xv[j] = x0[(base + j) * (u64)D];   // states are particle-major: x[i][d]
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TILE_ITEMS; ++j) {
+            lw[j] = (base + j < n) ? logw[base + j] : MP_NEG_INF;
+            xv[j] = (base + j < n) ? x0[(base + j) * (u64)D] : 0.;
+        }
+    }
+    normalize_tile<TILE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: propagate + weight + level 0 of the normalisation, one workgroup per tile
+// ---------------------------------------------------------------------------------------------
+// A lane owns the 4 consecutive particles 4*tid .. 4*tid+3 of its tile, processed in rounds of k1_items<Model>()
+// particles.  Per round, phase 1 runs every polar rejection loop of the lane as ONE lane-local work queue over its
+// (particle, normal site) items: a wave iterates max-over-lanes of the SUM of attempts instead of the sum over
+// items of the max, i.e. ~1.9 Philox blocks per item at 4 items instead of ~3.6 (acceptance pi/4, 64 lanes).
+// Phase 2 runs the model kernel per particle on the accepted pairs.
+template <class Model, int THREADS>
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
+                                                            long long t, const double* x_in, double* x_out, double* logw,
+                                                            mp_obs obs, mp_state0 s0, int overwrite,
+                                                            const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
+                                                            u64 res_stride, int nchunks, mp_cx* __restrict__ cx,
+                                                            unsigned short* __restrict__ guide, double* __restrict__ tile_m,
+                                                            u64* __restrict__ tile_W, u64* __restrict__ tile_W2,
+                                                            const uint32_t* __restrict__ inv, const uint32_t* __restrict__ res_parent) {
+    constexpr int D = Model::DIM_STATE;
+    constexpr int NS = Model::MAX_NORMALS;
+    constexpr int LANE_ITEMS = TILE / THREADS;
+    constexpr int ITEMS = k1_items<Model>() < LANE_ITEMS ? k1_items<Model>() : LANE_ITEMS;
+    constexpr int ROUNDS = LANE_ITEMS / ITEMS;
+    constexpr int M = ITEMS * NS;
+    const int ns = model.n_normals(t);  // wave-uniform
+    const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * LANE_ITEMS;
+    double lw[LANE_ITEMS], xv[LANE_ITEMS];
+#pragma unroll
+    for (int j = 0; j < LANE_ITEMS; ++j) { lw[j] = MP_NEG_INF; xv[j] = 0.; }
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const u64 i0 = base + (u64)rd * ITEMS;
+        // ---- phase 1: accepted (u, r) pairs for every (particle, normal site) of this round ----
+        double pu[M], pr[M];
+#pragma unroll
+        for (int q = 0; q < M; ++q) { pu[q] = 0.; pr[q] = 1.; }
+        {
+            int p = 0, sidx = 0;  // current item: particle p of the round, normal site index sidx
+            uint32_t att = 0;
+            while (p < ITEMS && ns > 0) {
+                const u64 i = i0 + (u64)p;
+                if (i >= n) break;
+                const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
+                                                    ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
+                const double u = mp_u01(b.a) * 2. - 1.;
+                const double v = mp_u01(b.b) * 2. - 1.;
+                const double r = u * u + v * v;
+                if (r == 0. || r > 1.) {  // normal.rs:22
+                    ++att;
+                } else {
+                    const int q = p * NS + sidx;
+#pragma unroll
+                    for (int qq = 0; qq < M; ++qq) {
+                        pu[qq] = (qq == q) ? u : pu[qq];
+                        pr[qq] = (qq == q) ? r : pr[qq];
+                    }
+                    att = 0;
+                    if (++sidx == ns) { sidx = 0; ++p; }
+                }
+            }
+        }
+        // ---- phase 2: the model kernel in Generate mode --------------------------------------
+#pragma unroll
+        for (int p = 0; p < ITEMS; ++p) {
+            const u64 i = i0 + (u64)p;
+            if (i < n) {
+                double prev[D], next[D];
+                if (inv) {
+                    // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row
+                    // {x[0..D), parent id} is row inv[i] of the exchange buffer (res_x here)
+                    const double* row = res_x + (u64)inv[i] * (u64)(D + 1);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) prev[d] = row[d];
+                } else if (perm) {
+                    // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at
+                    // segment (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i]
+                    const uint32_t pr_ = perm[i];
+                    const u64 pos = MP_SEG_POS(pr_ >> 10, i >> 10, pr_ & 1023u, nchunks);
+                    if constexpr (D == 1) {
+                        prev[0] = res_x[pos];              // k_resolve_bins had it in the table row it found
+                    } else {
+                        // wider states are gathered here, straight from the parent's (particle-major) row of the
+                        // pre-resample buffer: one line per particle, hidden under this kernel's arithmetic
+                        const double* src = x_in + (u64)res_parent[pos] * D;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) prev[d] = src[d];
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[i * D + d];
+                }
+                mp_stream rng;
+                rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
+                mp_generate_handler<Model> g(rng, obs.v, &pu[p * NS], &pr[p * NS]);
+                model(g, t, prev, next);
+#pragma unroll
+                for (int d = 0; d < D; ++d) x_out[i * D + d] = next[d];
+                // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to
+                // be all zero after a resample (log_weights.fill(0.), :114) and are not re-read
+                const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
+                logw[i] = w;
+                lw[rd * ITEMS + p] = w;
+                xv[rd * ITEMS + p] = next[0];
+            }
+        }
+    }
+    // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----
+    normalize_tile<THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 1: the tile table of a workgroup.  T_b = rint((double)W_b * mp_exp(m_b - m) * 2^(S-51)), inclusive prefix in
+// s_incl[nt], W_b in s_W[nt]; returns the global max m (every thread).  s_red needs THREADS/64 doubles, s_wtot
+// THREADS/64 u64.
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ double block_tile_table(const double* __restrict__ tile_m, const u64* __restrict__ tile_W, int nt, int S,
+                                                   u64* s_incl, u64* s_W, double* s_red, u64* s_wtot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nt + THREADS - 1) / THREADS;
+    const int b0 = tid * per;
+    double m = MP_NEG_INF;
+    for (int j = 0; j < per; ++j)
+        if (b0 + j < nt) m = fmax(m, tile_m[b0 + j]);
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);  // 2^(S-51)
+    u64 run = 0;
+    for (int j = 0; j < per; ++j) {
+        const int idx = b0 + j;
+        if (idx < nt) {
+            const u64 W = tile_W[idx];
+            const double f = ok ? mp_exp(tile_m[idx] - m) : 0.;
+            run += mp_quantize((double)W * f * sc, 1.0);
+            s_incl[idx] = run;
+            s_W[idx] = W;
+        }
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    u64 woff = 0;
+    for (int k = 0; k < wave; ++k) woff += s_wtot[k];
+    const u64 off = woff + (incl - run);
+    for (int j = 0; j < per; ++j) {
+        const int idx = b0 + j;
+        if (idx < nt) s_incl[idx] += off;
+    }
+    __syncthreads();
+    return m;
+}
+// tile-local target of residual r in (0, T] of a tile with totals (W, T):
+// lt = clamp((u64)ceil((double)r * ((double)W / (double)T)), 1, W)
+__device__ __forceinline__ u64 mp_local_target(u64 r, u64 W, u64 T) {
+    const double ratio = (double)W / (double)T;
+    const double v = ceil((double)r * ratio);
+    u64 x = (v >= 1.) ? (u64)v : 1ull;
+    if (x > W) x = W;
+    if (x < 1ull) x = 1ull;
+    return x;
+}
+// Q2 = sum_b rint((double)W2_b * mp_exp(2 (m_b - m)) * 2^(S-51)) by one workgroup; result valid in thread 0
+template <int THREADS>
+__device__ __forceinline__ u64 block_sum_T2(const double* __restrict__ tile_m, const u64* __restrict__ tile_W2, int nt, int S, double m, u64* s_wtot) {
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
+    u64 q2 = 0;
+    for (int j = threadIdx.x; j < nt; j += THREADS) {
+        const double f2 = ok ? mp_exp(2. * (tile_m[j] - m)) : 0.;
+        q2 += mp_quantize((double)tile_W2[j] * f2 * sc, 1.0);
+    }
+    q2 = wave_sum_u64(q2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_wtot[threadIdx.x >> 6] = q2;
+    __syncthreads();
+    u64 Q2 = 0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < THREADS / 64; ++k) Q2 += s_wtot[k];
+    return Q2;
+}
+__device__ __forceinline__ void finalize_scalars(u64 Q, u64 Q2, int S, double* L_out, double* ess_out, double m) {
+    const double inv = mp_u2f((u64)(1023 - S) << 52);  // 2^-S
+    const double Qs = (double)Q * inv, Q2s = (double)Q2 * inv;
+    *L_out = m + mp_log(Qs);
+    *ess_out = (Qs * Qs) / Q2s;
+}
+// thread 0 of a workgroup that has the tile table folds a normalisation into the filter scalars
+__device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2, int S, double m, u64 n_global, int mode) {
+    double L, ess;
+    finalize_scalars(Q, Q2, S, &L, &ess, m);
+    scal->m = m;
+    if (!(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0) scal->degenerate = 1;
+    if (mode == 0) {  // resample (particle_filter.rs:104-105)
+        scal->L = L;
+        scal->ess_stale = ess;
+        scal->Q = Q;
+        scal->Q2 = Q2;
+        scal->log_ml += L - mp_log((double)n_global);
+    } else {          // query (particle_filter.rs:119-121; fresh ESS)
+        scal->L = L;
+        scal->ess_fresh = ess;
+        scal->lml_fresh = scal->log_ml + L - mp_log((double)n_global);
+    }
+}
+
+__device__ __forceinline__ mp_cx load_row_nt(const mp_cx* p) {
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(p));
+    mp_cx r;
+    r.cum = v.x;
+    r.x0 = __builtin_bit_cast(double, (u64)v.y);
+    return r;
+}
+
+// target = max(1, ceil(k * Q / 2^52)), k < 2^52, Q < 2^63
+__device__ __forceinline__ u64 mp_target(u64 k52, u64 Q) {
+    u64 lo = k52 * Q;
+    u64 hi = __umul64hi(k52, Q);
+    const u64 add = (1ull << 52) - 1ull;
+    const u64 lo2 = lo + add;
+    hi += (lo2 < lo) ? 1ull : 0ull;
+    const u64 t = (hi << 12) | (lo2 >> 52);
+    return t < 1ull ? 1ull : t;
+}
+
+// Systematic resampling (extension; the reference only has multinomial): one uniform u0 = k32 / 2^32 per resample
+// (Philox slot 0, site 1), u_g = (g + u0) / N for global output slot g; target = floor(u_g * Q) + 1, evaluated
+// exactly in integers: p = g * 2^32 + k32, A = (p * Q) >> 32, target = A / N + 1   (1 <= target <= Q).
+__device__ __forceinline__ u64 mp_target_systematic(u64 g, uint32_t k32, u64 Q, u64 n_global) {
+    const u64 p = (g << 32) | (u64)k32;
+    const u64 lo = p * Q;
+    const u64 hi = __umul64hi(p, Q);
+    const u64 a_lo = (lo >> 32) | (hi << 32);   // A = (hi:lo) >> 32, A < 2^95
+    const u64 a_hi = hi >> 32;                  // < 2^31
+    // long division of (a_hi : a_lo) by n_global < 2^32, base 2^32
+    u64 r = a_hi % n_global;                    // a_hi / n_global contributes to bits >= 64 of the quotient: zero since A / N < Q < 2^63
+    u64 cur = (r << 32) | (a_lo >> 32);
+    const u64 q1 = cur / n_global;
+    r = cur % n_global;
+    cur = (r << 32) | (a_lo & 0xFFFFFFFFull);
+    const u64 q0 = cur / n_global;
+    return ((q1 << 32) | q0) + 1ull;
+}
+__device__ __forceinline__ uint32_t mp_systematic_k32(uint32_t rc, uint32_t k0, uint32_t k1) {
+    const mp_u64x2 r = mp_philox4x32_10(0u, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | 1u, 0u, k0, k1);
+    return (uint32_t)(r.a >> 32);
+}
+// Stratified resampling (extension): the same lattice with one uniform PER output slot, u_g = (g + k32_g / 2^32) / N
+// (Philox slot g, site 2); parents still come out sorted.
+__device__ __forceinline__ uint32_t mp_stratified_k32(u64 g, uint32_t rc, uint32_t k0, uint32_t k1) {
+    const mp_u64x2 r = mp_philox4x32_10((uint32_t)g, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | 2u, 0u, k0, k1);
+    return (uint32_t)(r.a >> 32);
+}
+// target of global output slot g under scheme 1 (systematic, shared k32) or 2 (stratified)
+__device__ __forceinline__ u64 mp_target_lattice(int scheme, u64 g, uint32_t shared_k32, uint32_t rc, uint32_t k0, uint32_t k1, u64 Q, u64 n_global) {
+    return mp_target_systematic(g, scheme == 2 ? mp_stratified_k32(g, rc, k0, k1) : shared_k32, Q, n_global);
+}
+
+// Tile of a global target: tile totals are nearly equal (each sums 2048 weights), so target * nt / Q lands within a
+// tile or two of the answer; walk from there.  Same result as a lower_bound over s_incl, fewer LDS reads.
+__device__ __forceinline__ uint32_t tile_of_target(const u64* s_incl, uint32_t nt, u64 target, double nt_over_Q) {
+    int b = (int)((double)target * nt_over_Q);
+    if (b > (int)nt - 1) b = (int)nt - 1;
+    if (b < 0) b = 0;
+    while (b > 0 && s_incl[b - 1] >= target) --b;          // first b with incl[b] >= target ...
+    while (b < (int)nt - 1 && s_incl[b] < target) ++b;     // ... from either side
+    return (uint32_t)b;
+}
+// global target -> (tile, tile-local target, guide slot)
+__device__ __forceinline__ void mp_locate(const u64* s_incl, const u64* s_W, uint32_t nt, u64 target, double nt_over_Q, uint32_t* tile, u64* lt,
+                                          uint32_t* gslot) {
+    const uint32_t b = tile_of_target(s_incl, nt, target, nt_over_Q);
+    const u64 excl = b ? s_incl[b - 1] : 0ull;
+    const u64 T = s_incl[b] - excl;
+    const u64 W = s_W[b];
+    const u64 x = mp_local_target(target - excl, W, T);
+    uint32_t g = (uint32_t)(x >> mp_guide_shift(W));
+    if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+    *tile = b; *lt = x; *gslot = b * (uint32_t)GUIDE_N + g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 (single-kernel form): draw, search, gather, reset.  Used for importance_resampling's M draws (domain IS) and
+// for systematic resampling (sorted parents: coalesced by construction).  n_out draws over a table of n rows.
+// ---------------------------------------------------------------------------------------------
+template <int SCHEME>
+__global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out, u64 n_global, u64 slot_offset, uint32_t domain,
+                                                                uint32_t k0, uint32_t k1, uint32_t rc, int S, int D,
+                                                                const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                                const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                                const u64* __restrict__ tile_W2, int nt,
+                                                                const double* __restrict__ x_old, double* __restrict__ x_new,
+                                                                uint32_t* __restrict__ parent, double* __restrict__ logw, mp_dev_scalars* scal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt;
+    double* s_red = reinterpret_cast<double*>(s_W + nt);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + K3_THREADS / 64);
+    const double m = block_tile_table<K3_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
+    const u64 Q = s_incl[nt - 1];
+    if (blockIdx.x == 0 && scal != nullptr) {  // workgroup-uniform: fold this normalisation into the filter scalars
+        const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+        if (threadIdx.x == 0) fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+    }
+    const uint32_t sys_k32 = SCHEME == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+    const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
+    for (u64 i0 = (u64)blockIdx.x * (K3_THREADS * K3_ITEMS) + threadIdx.x; i0 < n_out; i0 += (u64)gridDim.x * (K3_THREADS * K3_ITEMS)) {
+        u64 lt[K3_ITEMS], tbase[K3_ITEMS];
+        uint32_t tlen[K3_ITEMS], j[K3_ITEMS], gslot[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {
+            const u64 i = i0 + (u64)k * K3_THREADS;
+            u64 target;
+            if (SCHEME != 0) {
+                target = mp_target_lattice(SCHEME, slot_offset + (i < n_out ? i : 0), sys_k32, rc, k0, k1, Q, n_global);
+            } else {
+                const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
+                target = mp_target(mp_u52(r.a), Q);
+            }
+            uint32_t b;
+            mp_locate(s_incl, s_W, (uint32_t)nt, target, nt_over_Q, &b, &lt[k], &gslot[k]);
+            tbase[k] = (u64)b * TILE;
+            tlen[k] = (uint32_t)((n - tbase[k]) < (u64)TILE ? (n - tbase[k]) : (u64)TILE);
+        }
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) j[k] = guide[gslot[k]];
+        mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {
+            if (j[k] > tlen[k] - 1) j[k] = tlen[k] - 1;
+            const uint32_t j1 = (j[k] + 1 < tlen[k]) ? j[k] + 1 : j[k];
+            r0[k] = load_row_nt(cx + tbase[k] + j[k]);
+            r1[k] = load_row_nt(cx + tbase[k] + j1);
+        }
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {
+            const u64 i = i0 + (u64)k * K3_THREADS;
+            mp_cx row = r0[k];
+            uint32_t jj = j[k];
+            if (row.cum < lt[k] && jj + 1 < tlen[k]) {    // first row with cum >= lt
+                row = r1[k];
+                ++jj;
+                while (row.cum < lt[k] && jj + 1 < tlen[k]) {
+                    ++jj;
+                    row = load_row_nt(cx + tbase[k] + jj);
+                }
+            }
+            if (i < n_out) {
+                const u64 p = tbase[k] + jj;
+                parent[i] = (uint32_t)p;
+                if (x_new) {
+                    x_new[i * D] = row.x0;                // traces[i] = traces[parents[i]].clone()
+                    for (int d = 1; d < D; ++d) x_new[i * D + d] = x_old[p * D + d];
+                }
+                if (logw) logw[i] = 0.;                   // log_weights.fill(0.)
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// XCD-binned multinomial resampling (same parents per slot as k_resample_gather, bit for bit)
+// ---------------------------------------------------------------------------------------------
+// The row table (16 B x N) does not fit one XCD's 4 MB L2, so random row reads cross the fabric a full line at a
+// time.  But the top 3 bits of a draw's uniform say which EIGHTH of the CDF it lands in.  So:
+//   K3a k_bin_draws     every chunk of 1024 output slots: tile table, Philox, target, tile, guide lookup (the 2 MB
+//                       guide is L2-resident everywhere), stable split of the chunk's draws into the 8 bins:
+//                       segment [bin][chunk][<=1024] of (tile-local target, start row) and perm[slot] = (bin << 10 | pos).
+//   K3b k_resolve_bins  workgroup (group of 8 chunks, bin b) with blockIdx % 8 == b — workgroups are dealt
+//                       round-robin over the 8 XCDs, so the row lookups of bin b run on one XCD whose L2 then holds
+//                       that eighth of the table (speed only: any placement gives the same result).
+// Measured (profiles/r01): L2 hit rate 0.58 -> 0.86, fabric traffic 107 -> 52 MB per resample of 2^20, 46 -> 30 us.
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S, int nchunks,
+                                                           const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                           const u64* __restrict__ tile_W2, int nt,
+                                                           const unsigned short* __restrict__ guide,
+                                                           u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row,
+                                                           unsigned short* __restrict__ perm, unsigned short* __restrict__ seg_cnt,
+                                                           mp_dev_scalars* scal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW = BIN_THREADS / 64;
+    u64* s_incl = reinterpret_cast<u64*>(smem);                        // [nt]
+    u64* s_W = s_incl + nt;                                            // [nt]
+    double* s_red = reinterpret_cast<double*>(s_W + nt);               // [NW]
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + NW);                  // [NW]
+    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + NW);       // [BIN_ITEMS][NW][8] counts
+    uint32_t* s_woff = s_wcnt + BIN_ITEMS * NW * 8;                    // same shape: exclusive offsets
+    const double m = block_tile_table<BIN_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
+    const u64 Q = s_incl[nt - 1];
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0) {  // fold this normalisation into the filter scalars
+        const u64 Q2 = block_sum_T2<BIN_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+        if (threadIdx.x == 0) fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+    }
+
+    u64 lt[BIN_ITEMS];
+    uint32_t gslot[BIN_ITEMS], tile_of[BIN_ITEMS];
+    int bin[BIN_ITEMS];
+    uint32_t rank_in_wave[BIN_ITEMS];
+    const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
+#pragma unroll
+    for (int q = 0; q < BIN_ITEMS; ++q) {
+        const u64 i = (u64)c * BIN_CHUNK + (u64)q * BIN_THREADS + threadIdx.x;
+        const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+        const u64 k52 = mp_u52(r.a);
+        mp_locate(s_incl, s_W, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
+        bin[q] = (i < n) ? (int)(k52 >> 49) : -1;
+        rank_in_wave[q] = 0;
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const u64 bal = __ballot(bin[q] == bb);
+            if (bin[q] == bb) rank_in_wave[q] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wcnt[(q * NW + wave) * 8 + bb] = (uint32_t)__popcll(bal);
+        }
+    }
+    // the guide lookups go out now (the guide is L2-resident on every XCD) and land while the offsets are built
+    uint32_t j0[BIN_ITEMS];
+#pragma unroll
+    for (int q = 0; q < BIN_ITEMS; ++q) j0[q] = guide[gslot[q]];
+    __syncthreads();
+    // exclusive offsets in the stable order: item q-major (slots q*256 .. q*256+255), then wave, then lane == increasing slot
+    if (threadIdx.x < 8) {
+        uint32_t run = 0;
+        for (int q = 0; q < BIN_ITEMS; ++q)
+            for (int w = 0; w < NW; ++w) {
+                s_woff[(q * NW + w) * 8 + threadIdx.x] = run;
+                run += s_wcnt[(q * NW + w) * 8 + threadIdx.x];
+            }
+        seg_cnt[(u64)threadIdx.x * nchunks + c] = (unsigned short)run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BIN_ITEMS; ++q) {
+        if (bin[q] >= 0) {
+            const uint32_t pos = s_woff[(q * NW + wave) * 8 + bin[q]] + rank_in_wave[q];
+            const u64 sp = MP_SEG_POS(bin[q], c, pos, nchunks);
+            const u64 tbase = (u64)tile_of[q] * TILE;
+            const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+            const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
+            seg_lt[sp] = lt[q];
+            seg_row[sp] = (uint32_t)tbase + jj;   // row where the forward scan starts
+            perm[(u64)c * BIN_CHUNK + q * BIN_THREADS + threadIdx.x] = (unsigned short)((bin[q] << 10) | pos);
+        }
+    }
+}
+
+// K3b: pure lookup, two dependent hops (segment entry -> table rows), all inside the bin's eighth of the table.
+// Thread (quad, e) = (tid >> 7, tid & 127) owns entry e of the 4 segments of chunks group*8 + quad*4 + {0..3}; a
+// segment holds 128 +- 11 entries, so nearly every lane is live and each has 4 independent chains in flight.
+// Results stay in SEGMENT order (res_x[d][bin][chunk][pos], res_parent likewise: coalesced stores); the next
+// k_propagate reads its inputs through perm[], k_unpermute materialises slot order when the host asks.
+__global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int nchunks, const u64* __restrict__ seg_lt,
+                                                             const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_cnt,
+                                                             const mp_cx* __restrict__ cx,
+                                                             const double* __restrict__ x_old, double* __restrict__ res_x, u64 res_stride,
+                                                             uint32_t* __restrict__ res_parent) {
+    const int bin = blockIdx.x & 7;
+    const int group = blockIdx.x >> 3;
+    const int e0 = threadIdx.x & 127, quad = threadIdx.x >> 7;
+    int cnt[K3_ITEMS], chunk_of[K3_ITEMS];
+    u64 lt[K3_ITEMS], spos[K3_ITEMS];
+    uint32_t row0[K3_ITEMS];
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        const int c = group * BIN_GROUP + quad * K3_ITEMS + k;
+        const bool ok = c < nchunks;
+        chunk_of[k] = ok ? c : 0;
+        cnt[k] = ok ? (int)seg_cnt[(u64)bin * nchunks + c] : 0;
+        spos[k] = MP_SEG_POS(bin, chunk_of[k], e0, nchunks);
+        lt[k] = seg_lt[spos[k]];        // in bounds for every thread; masked by cnt below
+        row0[k] = seg_row[spos[k]];
+    }
+    // first row >= lt, walking forward from `row` inside its tile; r0/r1 = that row and the next one, already loaded
+    auto finish = [&](u64 ltx, uint32_t row, u64 sp, mp_cx r0, mp_cx r1) {
+        const u64 tend = (((u64)row / TILE) + 1) * TILE;
+        const u64 last = (tend < n ? tend : n) - 1;      // last row of the tile
+        mp_cx cur = r0;
+        u64 p = row;
+        if (cur.cum < ltx && p < last) {
+            cur = r1;
+            ++p;
+            while (cur.cum < ltx && p < last) {
+                ++p;
+                cur = cx[p];
+            }
+        }
+        res_parent[sp] = (uint32_t)p;
+        res_x[sp] = cur.x0;
+        // D > 1: the rest of the state is gathered by the next k_propagate (or k_unpermute) from res_parent
+    };
+    bool live[K3_ITEMS];
+    mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        live[k] = e0 < cnt[k];
+        if (live[k]) {
+            const u64 tend = (((u64)row0[k] / TILE) + 1) * TILE;
+            const u64 last = (tend < n ? tend : n) - 1;
+            r0[k] = cx[row0[k]];
+            r1[k] = cx[(u64)row0[k] + ((u64)row0[k] < last ? 1 : 0)];
+        } else {
+            r0[k].cum = ~0ull; r0[k].x0 = 0.; r1[k] = r0[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k)
+        if (live[k]) finish(lt[k], row0[k], spos[k], r0[k], r1[k]);
+    // entries 128.. of a segment (about 5 % of the entries: the upper tail of Binomial(1024, 1/8))
+#pragma unroll
+    for (int k = 0; k < K3_ITEMS; ++k) {
+        for (int e = 128 + e0; e < cnt[k]; e += 128) {
+            const u64 sp = MP_SEG_POS(bin, chunk_of[k], e, nchunks);
+            const uint32_t row = seg_row[sp];
+            const u64 tend = (((u64)row / TILE) + 1) * TILE;
+            const u64 last = (tend < n ? tend : n) - 1;
+            const mp_cx a = cx[row];
+            const mp_cx bq = cx[(u64)row + ((u64)row < last ? 1 : 0)];
+            finish(seg_lt[sp], row, sp, a, bq);
+        }
+    }
+}
+
+// slot order from segment order: traces[i] = traces[parents[i]].clone(); log_weights.fill(0.) (particle_filter.rs:109-114)
+__global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __restrict__ perm, const double* __restrict__ res_x, u64 res_stride,
+                            const uint32_t* __restrict__ res_parent, const double* __restrict__ x_old, double* __restrict__ x_new,
+                            uint32_t* __restrict__ parent, double* __restrict__ logw) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pr = perm[i];
+    const u64 pos = MP_SEG_POS(pr >> 10, i >> 10, pr & 1023u, nchunks);
+    const uint32_t p = res_parent[pos];
+    if (D == 1) {
+        x_new[i] = res_x[pos];
+    } else {
+        for (int d = 0; d < D; ++d) x_new[i * D + d] = x_old[(u64)p * D + d];
+    }
+    parent[i] = p;
+    logw[i] = 0.;
+}
+
+// Level 1 on its own (one workgroup): mode 1 = query (log_marginal_likelihood_estimate / fresh ESS), mode 0 = fold a
+// sharded resample, mode 2 = importance sampling (L and log_ml = L - ln N, importance.rs:21-22).
+__global__ __launch_bounds__(K3_THREADS) void k_finalize_tiles(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                               const u64* __restrict__ tile_W2, int nt, int S, u64 n_global, int mode,
+                                                               mp_dev_scalars* scal, mp_dev_scalars* undo = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt;
+    double* s_red = reinterpret_cast<double*>(s_W + nt);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + K3_THREADS / 64);
+    const double m = block_tile_table<K3_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
+    const u64 Q = s_incl[nt - 1];
+    const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+    if (threadIdx.x == 0) {
+        if (undo) *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
+        if (mode == 2) {
+            double L, ess;
+            finalize_scalars(Q, Q2, S, &L, &ess, m);
+            scal->m = m;
+            if (!(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0) scal->degenerate = 1;
+            scal->L = L;
+            scal->lml_fresh = L - mp_log((double)n_global);
+        } else {
+            fold_scalars(scal, Q, Q2, S, m, n_global, mode);
+        }
+    }
+}
+

@@ -1,0 +1,360 @@
+// mp_pf_shard_kernels.h — device code of the sharded filter's resample phases (included by mp_pf.hip only, after
+// mp_pf_kernels.h): variable-size three-pass route, fixed-capacity single-pass route, owner-side resolve, adoption.
+// Protocol: include/modppl_hip.h "sharded filter", DESIGN.md §8.
+#pragma once
+// ---------------------------------------------------------------------------------------------
+// sharded filter phases (include/modppl_hip.h "sharded filter").  Shards are tile-aligned, so a shard's tiles are
+// tiles of the job; every rank gathers all tiles' (m, W, W2) and builds the same table.
+// ---------------------------------------------------------------------------------------------
+constexpr int SH_THREADS = 256;
+constexpr int SH_MAX_WORLD = 64;
+
+// pass 1: target of every local slot -> owner rank, tile inside the owner's shard, tile-local target; owner histogram
+__global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
+                                                              int systematic, int S, const double* __restrict__ tm_all,
+                                                              const u64* __restrict__ tW_all, int nt_all, int nt_local, int world,
+                                                              unsigned char* __restrict__ dest, u64* __restrict__ lt_out,
+                                                              uint32_t* __restrict__ tile_out, uint32_t* __restrict__ blockcount) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt_all;
+    double* s_red = reinterpret_cast<double*>(s_W + nt_all);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + SH_THREADS / 64);
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_wtot + SH_THREADS / 64);  // [SH_MAX_WORLD]
+    if (threadIdx.x < SH_MAX_WORLD) s_cnt[threadIdx.x] = 0;
+    block_tile_table<SH_THREADS>(tm_all, tW_all, nt_all, S, s_incl, s_W, s_red, s_wtot);
+    const u64 Q = s_incl[nt_all - 1];
+    const double nt_over_Q = (double)nt_all / (double)Q;
+    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    if (i < n) {
+        u64 target;
+        if (systematic) {   // 1 systematic, 2 stratified
+            target = mp_target_lattice(systematic, slot_offset + i, systematic == 1 ? mp_systematic_k32(rc, k0, k1) : 0u, rc, k0, k1, Q, n_global);
+        } else {
+            const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+            target = mp_target(mp_u52(r.a), Q);
+        }
+        uint32_t b, gs;
+        u64 lt;
+        mp_locate(s_incl, s_W, (uint32_t)nt_all, target, nt_over_Q, &b, &lt, &gs);
+        const int s = (int)(b / (uint32_t)nt_local);
+        dest[i] = (unsigned char)s;
+        lt_out[i] = lt;
+        tile_out[i] = b % (uint32_t)nt_local;
+        atomicAdd(&s_cnt[s], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < world) blockcount[(u64)blockIdx.x * world + threadIdx.x] = s_cnt[threadIdx.x];
+}
+// pass 2 (one workgroup per owner): per-owner totals and exclusive per-workgroup offsets
+__global__ __launch_bounds__(SH_THREADS) void k_shard_offsets(const uint32_t* __restrict__ blockcount, int nblk, int world,
+                                                              uint32_t* __restrict__ blockoff, long long* __restrict__ counts) {
+    __shared__ uint32_t s_wave[SH_THREADS / 64];
+    const int r = blockIdx.x;
+    const int per = (nblk + SH_THREADS - 1) / SH_THREADS;
+    const int b0 = threadIdx.x * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    uint32_t mine = 0;
+    for (int b = b0; b < b1; ++b) mine += blockcount[(u64)b * world + r];
+    // exclusive scan of `mine` over the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < SH_THREADS / 64; ++w) {
+        if (w < wave) base += s_wave[w];
+        total += s_wave[w];
+    }
+    uint32_t run = base + inc - mine;
+    for (int b = b0; b < b1; ++b) {
+        blockoff[(u64)b * world + r] = run;
+        run += blockcount[(u64)b * world + r];
+    }
+    if (threadIdx.x == 0) counts[r] = (long long)total;
+}
+// pass 3: stable pack of the requests (tile in owner, tile-local target) grouped by owner
+__global__ __launch_bounds__(SH_THREADS) void k_shard_pack(u64 n, const unsigned char* __restrict__ dest, const u64* __restrict__ lt_in,
+                                                           const uint32_t* __restrict__ tile_in, const uint32_t* __restrict__ blockoff,
+                                                           const long long* __restrict__ counts, int world, u64* __restrict__ req_out,
+                                                           uint32_t* __restrict__ req_slot) {
+    __shared__ uint32_t s_wcnt[SH_THREADS / 64][SH_MAX_WORLD];
+    __shared__ u64 s_gstart[SH_MAX_WORLD];
+    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = (i < n) ? (int)dest[i] : -1;
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (int r = 0; r < world; ++r) { s_gstart[r] = run; run += (u64)counts[r]; }
+    }
+    uint32_t my_rank_in_wave = 0;
+    for (int r = 0; r < world; ++r) {
+        const u64 bal = __ballot(s == r);
+        if (s == r) my_rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wcnt[wave][r] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (s >= 0) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wcnt[w][s];
+        const u64 pos = s_gstart[s] + blockoff[(u64)blockIdx.x * world + s] + before + my_rank_in_wave;
+        req_out[2 * pos] = (u64)tile_in[i];
+        req_out[2 * pos + 1] = lt_in[i];
+        req_slot[pos] = (uint32_t)i;
+    }
+}
+// owner side: (tile, tile-local target) -> parent rows
+__global__ __launch_bounds__(K3_THREADS) void k_shard_resolve(u64 n, u64 n_req, u64 slot_offset, int D, const u64* __restrict__ req,
+                                                              const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                              const u64* __restrict__ tile_W, const double* __restrict__ x,
+                                                              double* __restrict__ rows) {
+    for (u64 q = (u64)blockIdx.x * K3_THREADS + threadIdx.x; q < n_req; q += (u64)gridDim.x * K3_THREADS) {
+        const u64 b = req[2 * q];
+        const u64 lt = req[2 * q + 1];
+        const int shift = mp_guide_shift(tile_W[b]);
+        const u64 tbase = b * TILE;
+        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+        uint32_t g = (uint32_t)(lt >> shift);
+        if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+        uint32_t j = guide[b * GUIDE_N + g];
+        if (j > tlen - 1) j = tlen - 1;
+        mp_cx row = load_row_nt(cx + tbase + j);
+        while (row.cum < lt && j + 1 < tlen) {
+            ++j;
+            row = load_row_nt(cx + tbase + j);
+        }
+        const u64 p = tbase + j;
+        double* out = rows + q * (u64)(D + 1);
+        out[0] = row.x0;
+        for (int d = 1; d < D; ++d) out[d] = x[p * D + d];
+        out[D] = (double)(slot_offset + p);
+    }
+}
+// requester side
+__global__ __launch_bounds__(SH_THREADS) void k_shard_scatter(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ req_slot,
+                                                              double* __restrict__ x_new, uint32_t* __restrict__ parent, double* __restrict__ logw) {
+    const u64 pos = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    if (pos < n) {
+        const uint32_t i = req_slot[pos];
+        const double* in = rows + pos * (u64)(D + 1);
+        for (int d = 0; d < D; ++d) x_new[(u64)i * D + d] = in[d];
+        parent[i] = (uint32_t)in[D];
+        logw[i] = 0.;
+    }
+}
+
+
+// ---- fixed-capacity exchange (no host round trip) -------------------------------------------------
+// Gathered tiles arrive rank-major, [world][3][nt_local] 8-byte words (row 0: bits of the f64 tile maxima, row 1: W,
+// row 2: W2).  Requests travel in fixed segments: req[dst][cap + 1][2], entry 0 = {count, 0}; rows likewise
+// rows[src][cap][D + 1].  A pair (src, dst) exchanging more than `cap` draws sets the sticky overflow flag (the filter
+// then reports MP_ERR_UNSUPPORTED at the next synchronising call instead of continuing with dropped draws).
+__global__ __launch_bounds__(K3_THREADS) void k_unpack_tiles(const u64* __restrict__ packed, int world, int nt_local, double* __restrict__ tm,
+                                                             u64* __restrict__ tW, u64* __restrict__ tW2, long long* zero_counts = nullptr) {
+    const int i = blockIdx.x * K3_THREADS + threadIdx.x;
+    if (zero_counts && i < 512) zero_counts[i] = 0;  // the per-(owner, eighth) request counters of the route that follows (SH_MAX_KEYS)
+    if (i < world * nt_local) {
+        const int r = i / nt_local, b = i % nt_local;
+        const u64* base = packed + (u64)r * 3 * nt_local;
+        tm[i] = mp_u2f(base[b]);
+        tW[i] = base[nt_local + b];
+        tW2[i] = base[2 * nt_local + b];
+    }
+}
+// Fixed-capacity route in ONE pass: target -> owner / tile / local target, and the request is written straight into the
+// sub-segment (owner, eighth of the owner's tiles).  Places come from one global atomic per (workgroup, sub-segment), so
+// the order of requests inside a sub-segment varies from run to run; the results do not (inv[i] remembers where the
+// request of slot i went, which is where its row comes back).  Grouping by eighth lets the owner resolve each group on one XCD, whose L2 then holds
+// that eighth of its rows (the same trick as k_bin_draws / k_resolve_bins).
+// what the owner-side resolve publishes to host-mapped memory when its last workgroup finishes
+struct mp_shard_pub {
+    int overflow;
+    int degenerate;
+    double L;
+};
+constexpr int SHF_ITEMS = 4;
+constexpr int SH_BINS = 8;
+constexpr int SH_MAX_KEYS = SH_MAX_WORLD * SH_BINS;
+__global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
+                                                                  int systematic, int S, const double* __restrict__ tm_all,
+                                                                  const u64* __restrict__ tW_all, int nt_all, int nt_local, int world, u64 capb,
+                                                                  unsigned long long* __restrict__ counts, u64* __restrict__ req_out,
+                                                                  uint32_t* __restrict__ inv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt_all;
+    double* s_red = reinterpret_cast<double*>(s_W + nt_all);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + SH_THREADS / 64);
+    u64* s_base = s_wtot + SH_THREADS / 64;                                   // [keys] start inside the sub-segment
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_base + SH_MAX_KEYS);      // [keys] draws of this workgroup per sub-segment
+    const int keys = world * SH_BINS;
+    for (int k = threadIdx.x; k < keys; k += SH_THREADS) s_cnt[k] = 0;
+    block_tile_table<SH_THREADS>(tm_all, tW_all, nt_all, S, s_incl, s_W, s_red, s_wtot);   // ends with a barrier
+    const u64 Q = s_incl[nt_all - 1];
+    const double nt_over_Q = (double)nt_all / (double)Q;
+    const u64 i0 = (u64)blockIdx.x * (SH_THREADS * SHF_ITEMS) + threadIdx.x;
+    const uint32_t k32 = systematic == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+    int key[SHF_ITEMS];
+    uint32_t tl[SHF_ITEMS], place[SHF_ITEMS];
+    u64 lt[SHF_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SHF_ITEMS; ++k) {
+        const u64 i = i0 + (u64)k * SH_THREADS;
+        key[k] = -1;
+        if (i < n) {
+            u64 target;
+            if (systematic) {   // 1 systematic, 2 stratified
+                target = mp_target_lattice(systematic, slot_offset + i, k32, rc, k0, k1, Q, n_global);
+            } else {
+                const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+                target = mp_target(mp_u52(r.a), Q);
+            }
+            uint32_t b, gs;
+            mp_locate(s_incl, s_W, (uint32_t)nt_all, target, nt_over_Q, &b, &lt[k], &gs);
+            const uint32_t own = b / (uint32_t)nt_local;
+            tl[k] = b - own * (uint32_t)nt_local;
+            key[k] = (int)(own * SH_BINS + (tl[k] * SH_BINS) / (uint32_t)nt_local);
+            place[k] = atomicAdd(&s_cnt[key[k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < keys; k += SH_THREADS)
+        s_base[k] = s_cnt[k] ? atomicAdd(&counts[k], (unsigned long long)s_cnt[k]) : 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SHF_ITEMS; ++k) {
+        if (key[k] >= 0) {
+            const u64 j = s_base[key[k]] + place[k];
+            if (j < capb) {
+                ulonglong2* sub = reinterpret_cast<ulonglong2*>(req_out) + (u64)key[k] * (capb + 1);
+                sub[j + 1] = make_ulonglong2((u64)tl[k], lt[k]);
+                inv[i0 + (u64)k * SH_THREADS] = (uint32_t)((u64)key[k] * capb + j);
+            }
+        }
+    }
+}
+// Level 1 of a sharded resample + the sub-segment headers {count, "some sub-segment of mine overflowed"}, once every
+// workgroup of the route has reserved its places.  One workgroup.
+__global__ __launch_bounds__(K3_THREADS) void k_shard_finalize(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
+                                                               const u64* __restrict__ tile_W2, int nt, int S, u64 n_global, mp_dev_scalars* scal,
+                                                               mp_dev_scalars* undo, const unsigned long long* __restrict__ counts, int world,
+                                                               u64 capb, u64* __restrict__ req_out, int* overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl = reinterpret_cast<u64*>(smem);
+    u64* s_W = s_incl + nt;
+    double* s_red = reinterpret_cast<double*>(s_W + nt);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + K3_THREADS / 64);
+    const int keys = world * SH_BINS;
+    int mine = 0;
+    for (int k = threadIdx.x; k < keys; k += K3_THREADS) mine |= (counts[k] > capb) ? 1 : 0;
+    const int any = __syncthreads_or(mine);
+    for (int k = threadIdx.x; k < keys; k += K3_THREADS) {
+        const u64 c = counts[k];
+        u64* sub = req_out + (u64)k * (capb + 1) * 2;
+        sub[0] = c < capb ? c : capb;
+        sub[1] = (u64)any;
+    }
+    if (threadIdx.x == 0 && any) *overflow = 1;
+    const double m = block_tile_table<K3_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
+    const u64 Q = s_incl[nt - 1];
+    const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+    if (threadIdx.x == 0) {
+        *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
+        fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+    }
+}
+// owner side: blockIdx.x & 7 = eighth of this shard's tiles (workgroups are dealt round-robin to the 8 XCDs, gridDim.x is
+// a multiple of 8), blockIdx.y = asking rank.  Per request: guide cell -> first row -> short forward walk, all inside
+// the eighth.  Rows go back in the order the requests came.
+__global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 capb, u64 slot_offset, int D, const u64* __restrict__ req,
+                                                                     const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                                     const u64* __restrict__ tile_W, const double* __restrict__ x,
+                                                                     double* __restrict__ rows, int* overflow) {
+    const int bin = blockIdx.x & (SH_BINS - 1), grp = blockIdx.x >> 3, ngrp = gridDim.x >> 3;
+    const u64 key = (u64)blockIdx.y * SH_BINS + bin;
+    const ulonglong2* sub = reinterpret_cast<const ulonglong2*>(req) + key * (capb + 1);
+    const ulonglong2 head = sub[0];
+    const u64 cnt = head.x < capb ? head.x : capb;
+    if (grp == 0 && threadIdx.x == 0 && head.y) *overflow = 1;
+    double* out_sub = rows + key * capb * (u64)(D + 1);
+    for (u64 q0 = (u64)grp * (K3_THREADS * K3_ITEMS); q0 < cnt; q0 += (u64)ngrp * (K3_THREADS * K3_ITEMS)) {
+        u64 lt[K3_ITEMS], tbase[K3_ITEMS], last[K3_ITEMS];
+        uint32_t gi[K3_ITEMS];
+        bool live[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 0: the requests (coalesced)
+            const u64 q = q0 + (u64)k * K3_THREADS + threadIdx.x;
+            live[k] = q < cnt;
+            const ulonglong2 e = live[k] ? sub[q + 1] : make_ulonglong2(0ull, 1ull);
+            const u64 b = e.x;
+            lt[k] = e.y;
+            tbase[k] = b * TILE;
+            const u64 tend = tbase[k] + TILE;
+            last[k] = (tend < n ? tend : n) - 1;
+            uint32_t g = (uint32_t)(lt[k] >> mp_guide_shift(tile_W[b]));
+            if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+            gi[k] = (uint32_t)b * (uint32_t)GUIDE_N + g;
+        }
+        u64 p[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 1: guide cells
+            u64 j = tbase[k] + guide[gi[k]];
+            p[k] = j < last[k] ? j : last[k];
+        }
+        mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 2: the row and its successor
+            r0[k] = cx[p[k]];
+            r1[k] = cx[p[k] + (p[k] < last[k] ? 1 : 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < K3_ITEMS; ++k) {
+            if (!live[k]) continue;
+            mp_cx cur = r0[k];
+            u64 pp = p[k];
+            if (cur.cum < lt[k] && pp < last[k]) {
+                cur = r1[k];
+                ++pp;
+                while (cur.cum < lt[k] && pp < last[k]) {
+                    ++pp;
+                    cur = cx[pp];
+                }
+            }
+            const u64 q = q0 + (u64)k * K3_THREADS + threadIdx.x;
+            double* out = out_sub + q * (u64)(D + 1);
+            if (D == 1) {
+                *reinterpret_cast<double2*>(out) = make_double2(cur.x0, (double)(slot_offset + pp));
+            } else {
+                out[0] = cur.x0;
+                for (int d = 1; d < D; ++d) out[d] = x[pp * D + d];
+                out[D] = (double)(slot_offset + pp);
+            }
+        }
+    }
+}
+// after the resolve: "somebody overflowed" and the scalars of this normalisation, where the host reads them after waiting
+// for ev_resolved (host-mapped memory: no copy command, no stream sync)
+__global__ void k_shard_publish(const int* overflow, const mp_dev_scalars* scal, mp_shard_pub* pub) {
+    pub->L = scal->L;
+    pub->degenerate = scal->degenerate;
+    pub->overflow = *overflow;
+}
+// requester side, only when something other than the next propagate needs slot order: x[i], parent[i] from row inv[i]
+__global__ __launch_bounds__(SH_THREADS) void k_shard_adopt_rows(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ inv,
+                                                                 double* __restrict__ x_new, uint32_t* __restrict__ parent) {
+    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const double* in = rows + (u64)inv[i] * (u64)(D + 1);
+    for (int d = 0; d < D; ++d) x_new[i * D + d] = in[d];
+    parent[i] = (uint32_t)in[D];
+}
+
+// out[i] = a[i] - *b  (log_normalized_weights = w_i - log_total_weight, importance.rs:23-25)
+__global__ void k_sub_scalar(const double* __restrict__ a, const double* __restrict__ b, u64 n, double* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] - *b;
+}
+
