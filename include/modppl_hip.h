@@ -213,6 +213,8 @@ enum mp_mh_site { MP_SITE_IS_LINEAR = 0, MP_SITE_A = 1, MP_SITE_B = 2, MP_SITE_C
 enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1 };
 enum mp_mh_proposal_kind {
     MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1, /* hierarchical_drift_proposal(tr, drift_std): hierarchical.rs:62-70; args = {drift_std} */
+    MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE = 2, /* add_or_remove_param_proposal(tr): hierarchical.rs:48-61, the structure-changing move of
+                                                    * tests/mh.rs:94 (is_linear re-proposed, coeffs/c added or removed); no args */
 };
 typedef struct mp_mh mp_mh;
 

@@ -19,6 +19,7 @@ MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER, MP_K_BIN_DRAWS = 0, 1
 MP_SITE_IS_LINEAR, MP_SITE_A, MP_SITE_B, MP_SITE_C = 0, 1, 2, 3
 MP_MH_MODEL_HIERARCHICAL = 1
 MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1
+MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE = 2
 
 # every symbol include/modppl_hip.h declares (tests/test_capi_symbols.py checks the export table)
 SYMBOLS = [

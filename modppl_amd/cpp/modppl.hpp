@@ -134,6 +134,12 @@ public:
         check(mp_mh_step(h_, MP_MH_PROPOSAL_HIERARCHICAL_DRIFT, &drift_std, 1, n_iters, &acc));
         return acc;
     }
+    // mh(&hierarchical_model, trace, &add_or_remove_param_proposal, ()) — tests/mh.rs:94
+    uint64_t mh_add_or_remove(int32_t n_iters = 1) {
+        uint64_t acc;
+        check(mp_mh_step(h_, MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE, nullptr, 0, n_iters, &acc));
+        return acc;
+    }
     uint64_t regen_mh(const std::vector<int32_t>& mask_sites, int32_t n_iters = 1, bool cycle = false) {
         uint64_t acc;
         check(mp_regen_mh_step(h_, mask_sites.data(), (int32_t)mask_sites.size(), cycle ? 1 : 0, n_iters, &acc));

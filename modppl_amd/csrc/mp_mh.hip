@@ -93,7 +93,8 @@ struct mh_mask {
     int sites[4];
 };
 
-template <bool DRIFT>
+// KIND: 0 regenerative MH, 1 MH with hierarchical_drift_proposal, 2 MH with add_or_remove_param_proposal
+template <int KIND>
 __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, uint32_t k1, uint32_t iter0, int n_iters, mh_data data,
                                                            double ln_noise, mh_mask mask, double drift_std, double ln_drift_std,
                                                            int* __restrict__ is_lin_io, double* __restrict__ a_io, double* __restrict__ b_io,
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
     const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
     u64 acc = 0;
     if (i < n) {
-        const bool is_lin = is_lin_io[i] != 0;
+        bool is_lin = is_lin_io[i] != 0;
         double a = a_io[i], b = b_io[i], c = c_io[i];
         double ly[MH_MAX_DATA];
 #pragma unroll
@@ -112,9 +113,10 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
         for (int it = 0; it < n_iters; ++it) {
             s.step = iter0 + (uint32_t)it;
             double na = a, nb = b, nc = c;
+            bool nl = is_lin;   // proposed structure (only add_or_remove changes it)
             double w = 0.;
             double fwd = 0., bwd = 0.;
-            if (DRIFT) {
+            if (KIND == 1) {
                 // ---- proposal.propose: simulate hierarchical_drift_proposal (hierarchical.rs:62-70) ----
                 mp_site pa(s, MP_DOM_PROPOSAL, MP_SITE_A), pb(s, MP_DOM_PROPOSAL, MP_SITE_B), pc(s, MP_DOM_PROPOSAL, MP_SITE_C);
                 na = mp_normal_sample(pa, a, drift_std);
@@ -136,6 +138,41 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
                     dw += mp_normal_logpdf_ln(nc, 0., 1., 0.);
                 }
                 dw = dw - 0.;  // gc: weight - complement_weight (nothing unvisited)
+                w += dw;
+            } else if (KIND == 2) {
+                // ---- proposal.propose: simulate add_or_remove_param_proposal (hierarchical.rs:48-61), std 0.025 passed as
+                // drift_std; visiting order coeffs/a, coeffs/b, is_linear, coeffs/c ----
+                mp_site pa(s, MP_DOM_PROPOSAL, MP_SITE_A), pb(s, MP_DOM_PROPOSAL, MP_SITE_B), pl(s, MP_DOM_PROPOSAL, MP_SITE_IS_LINEAR),
+                    pc(s, MP_DOM_PROPOSAL, MP_SITE_C);
+                na = mp_normal_sample(pa, a, drift_std);
+                fwd += mp_normal_logpdf_ln(na, a, drift_std, ln_drift_std);
+                nb = mp_normal_sample(pb, b, drift_std);
+                fwd += mp_normal_logpdf_ln(nb, b, drift_std, ln_drift_std);
+                nl = mp_bernoulli_sample(pl, 0.5);
+                fwd += mp_bernoulli_logpdf(nl, 0.5);
+                if (!nl) {
+                    const double prev_c = is_lin ? 0. : c;   // tr.data.search("coeffs/c") (:54-58)
+                    nc = mp_normal_sample(pc, prev_c, drift_std);
+                    fwd += mp_normal_logpdf_ln(nc, prev_c, drift_std, ln_drift_std);
+                }
+                // ---- model.update(trace, args, NoChange, fwd_choices) (dyngenfn.rs:143-211, 321-391): is_linear is a
+                // constrained site with a previous value; `coeffs` is updated by linear() or quadratic() as the NEW
+                // is_linear says, on the previous sub-trace: c constrained with or without a previous value, or left
+                // unvisited and collected by the inner gc (its weight leaves, the value goes to the discard) ----
+                w -= mp_bernoulli_logpdf(is_lin, 0.7);
+                w += mp_bernoulli_logpdf(nl, 0.7);
+                double dw = 0.;
+                dw -= mp_normal_logpdf_ln(a, 0., 1., 0.);
+                dw += mp_normal_logpdf_ln(na, 0., 1., 0.);
+                dw -= mp_normal_logpdf_ln(b, 0., 1., 0.);
+                dw += mp_normal_logpdf_ln(nb, 0., 1., 0.);
+                if (!nl) {
+                    if (!is_lin) dw -= mp_normal_logpdf_ln(c, 0., 1., 0.);
+                    dw += mp_normal_logpdf_ln(nc, 0., 1., 0.);
+                    dw = dw - 0.;
+                } else {
+                    dw = dw - (is_lin ? 0. : mp_normal_logpdf_ln(c, 0., 1., 0.));
+                }
                 w += dw;
             } else {
                 // ---- model.regenerate(trace, args, NoChange, mask): inner regenerate of `coeffs` ----
@@ -164,14 +201,24 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
 #pragma unroll
             for (int k = 0; k < MH_MAX_DATA; ++k) {
                 if (k < data.n) {
-                    lnew[k] = mp_normal_logpdf_ln(data.ys[k], mh_mean(is_lin, na, nb, nc, data.xs[k]), MH_NOISE, ln_noise);
+                    lnew[k] = mp_normal_logpdf_ln(data.ys[k], mh_mean(nl, na, nb, nc, data.xs[k]), MH_NOISE, ln_noise);
                     w += lnew[k] - ly[k];
                 } else {
                     lnew[k] = 0.;
                 }
             }
             double alpha = w;
-            if (DRIFT) {
+            if (KIND == 2) {
+                w = w - 0.;  // gc of the outer update
+                // ---- proposal.assess((new trace, ()), discard): the backward proposal scores the old values; its c site
+                // exists iff the OLD is_linear was false, centred on the new c if the new trace has one ----
+                bwd += mp_normal_logpdf_ln(a, na, drift_std, ln_drift_std);
+                bwd += mp_normal_logpdf_ln(b, nb, drift_std, ln_drift_std);
+                bwd += mp_bernoulli_logpdf(is_lin, 0.5);
+                if (!is_lin) bwd += mp_normal_logpdf_ln(c, nl ? 0. : nc, drift_std, ln_drift_std);
+                alpha = w - fwd + bwd;  // mh.rs:34
+            }
+            if (KIND == 1) {
                 w = w - 0.;  // gc of the outer update
                 // ---- proposal.assess((new trace, args), discard): generate with the old values constrained ----
                 bwd += mp_normal_logpdf_ln(a, na, drift_std, ln_drift_std);
@@ -181,13 +228,15 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
             }
             const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
             if (mp_log(mp_u01(ub.a)) < alpha) {  // mh.rs:35 / :62
-                a = na; b = nb; c = nc;
+                a = na; b = nb; c = nl ? 0. : nc;   // a linear trace has no coeffs/c (read_coeffs, hierarchical.rs:5-16)
+                is_lin = nl;
 #pragma unroll
                 for (int k = 0; k < MH_MAX_DATA; ++k) ly[k] = lnew[k];
                 ++acc;
             }
         }
         a_io[i] = a; b_io[i] = b; c_io[i] = c;
+        if (KIND == 2) is_lin_io[i] = is_lin ? 1 : 0;
     }
     // one atomic per wave
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -244,18 +293,21 @@ int32_t mp_mh_create(int32_t model_kind, const double* xs, const double* ys, int
     return MP_OK;
 }
 
-static int32_t mh_run(mp_mh* h, bool drift, const mh_mask& mask, double drift_std, int32_t n_iters, uint64_t* accepted) {
+static int32_t mh_run(mp_mh* h, int kind, const mh_mask& mask, double drift_std, int32_t n_iters, uint64_t* accepted) {
     if (n_iters < 0) return mp_set_error(MP_ERR_INVALID_ARG, "n_iters < 0");
     MHCK(hipSetDevice(h->device));
     MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64), h->stream));
     const unsigned grid = (unsigned)((h->n + MH_THREADS - 1) / MH_THREADS);
     const uint32_t iter0 = (uint32_t)(h->iters + 1);
-    const double ln_ds = drift ? mp_log(drift_std) : 0.;
-    if (drift)
-        hipLaunchKernelGGL(k_mh_iterate<true>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
+    const double ln_ds = kind ? mp_log(drift_std) : 0.;
+    if (kind == 2)
+        hipLaunchKernelGGL(k_mh_iterate<2>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc);
+    else if (kind == 1)
+        hipLaunchKernelGGL(k_mh_iterate<1>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
                            n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc);
     else
-        hipLaunchKernelGGL(k_mh_iterate<false>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
+        hipLaunchKernelGGL(k_mh_iterate<0>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
                            n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc);
     MHCK(hipGetLastError());
     h->iters += (u64)n_iters;
@@ -268,10 +320,14 @@ static int32_t mh_run(mp_mh* h, bool drift, const mh_mask& mask, double drift_st
 
 int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, int32_t n_iters, uint64_t* accepted) {
     if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
-    if (proposal_kind != MP_MH_PROPOSAL_HIERARCHICAL_DRIFT) return mp_set_error(MP_ERR_UNSUPPORTED, "only MP_MH_PROPOSAL_HIERARCHICAL_DRIFT is compiled in");
-    if (!proposal_args || n_proposal_args != 1 || !(proposal_args[0] > 0.)) return mp_set_error(MP_ERR_INVALID_ARG, "drift proposal takes {drift_std > 0}");
     mh_mask none{};
-    return mh_run(h, true, none, proposal_args[0], n_iters, accepted);
+    if (proposal_kind == MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE) {
+        if (n_proposal_args != 0) return mp_set_error(MP_ERR_INVALID_ARG, "add_or_remove_param_proposal takes no arguments");
+        return mh_run(h, 2, none, 0.025, n_iters, accepted);   // hierarchical.rs:51-59: every normal of the proposal has std 0.025
+    }
+    if (proposal_kind != MP_MH_PROPOSAL_HIERARCHICAL_DRIFT) return mp_set_error(MP_ERR_UNSUPPORTED, "unknown proposal kind");
+    if (!proposal_args || n_proposal_args != 1 || !(proposal_args[0] > 0.)) return mp_set_error(MP_ERR_INVALID_ARG, "drift proposal takes {drift_std > 0}");
+    return mh_run(h, 1, none, proposal_args[0], n_iters, accepted);
 }
 
 int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
@@ -287,7 +343,7 @@ int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, in
         if (mask_sites[q] < MP_SITE_A || mask_sites[q] > MP_SITE_C) return mp_set_error(MP_ERR_INVALID_ARG, "unknown mask site");
         m.sites[q] = mask_sites[q];
     }
-    return mh_run(h, false, m, 1., n_iters, accepted);
+    return mh_run(h, 0, m, 1., n_iters, accepted);
 }
 
 int32_t mp_mh_read_state(mp_mh* h, double* out) {

@@ -220,6 +220,12 @@ class HierarchicalChains:
         capi.check(self._L.mp_mh_step(self._h, capi.MP_MH_PROPOSAL_HIERARCHICAL_DRIFT, _dptr(a), 1, int(n_iters), C.byref(acc)))
         return acc.value
 
+    def mh_add_or_remove(self, n_iters=1):
+        """n_iters x mh(&hierarchical_model, trace, &add_or_remove_param_proposal, ()) (tests/mh.rs:94); returns accepted moves."""
+        acc = C.c_uint64()
+        capi.check(self._L.mp_mh_step(self._h, capi.MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE, None, 0, int(n_iters), C.byref(acc)))
+        return acc.value
+
     def regen_mh(self, mask, n_iters=1, cycle=False):
         """n_iters x regen_mh(&hierarchical_model, trace, &mask); mask = addresses ("coeffs/a", ...) or site ids."""
         sites = [self._ADDR[m] if isinstance(m, str) else int(m) for m in mask]

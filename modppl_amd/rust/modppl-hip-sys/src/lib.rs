@@ -9,6 +9,7 @@ pub const MP_ERR_CONSTRAINTS: i32 = 3;
 pub const MP_ERR_DEGENERATE: i32 = 4;
 pub const MP_ERR_HIP: i32 = 5;
 pub const MP_ERR_UNSUPPORTED: i32 = 6;
+pub const MP_ERR_CAPACITY: i32 = 7;
 
 pub const MP_MODEL_LGSSM1: i32 = 1;
 pub const MP_MODEL_SPIRAL: i32 = 2;
@@ -17,6 +18,10 @@ pub const MP_MODEL_BEARINGS: i32 = 4;
 pub const MP_MODEL_LGSSM_BAND: i32 = 5;
 pub const MP_RESAMPLE_MULTINOMIAL: i32 = 0;
 pub const MP_RESAMPLE_SYSTEMATIC: i32 = 1;
+pub const MP_RESAMPLE_STRATIFIED: i32 = 2;
+pub const MP_MH_MODEL_HIERARCHICAL: i32 = 1;
+pub const MP_MH_PROPOSAL_HIERARCHICAL_DRIFT: i32 = 1;
+pub const MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE: i32 = 2;
 pub const MP_ESS_REFERENCE: i32 = 0;
 pub const MP_ESS_FRESH: i32 = 1;
 pub const MP_PF_RECORD_HISTORY: u32 = 1;

@@ -396,10 +396,10 @@ int32_t oracle_mh_create(const double* xs, const double* ys, int32_t n_data, int
         *out = h.release();
     })
 }
-int32_t oracle_mh_step(oracle_mh* h, double drift_std, int32_t n_iters, uint64_t* accepted) {
+static int32_t oracle_mh_run(oracle_mh* h, int kind, double drift_std, int32_t n_iters, uint64_t* accepted) {
     GUARD({
         oracle_pf::Scope scope(h->canonical);
-        auto proposal = h->hm.drift_proposal();
+        auto proposal = kind == 2 ? h->hm.add_or_remove_proposal() : h->hm.drift_proposal();
         uint64_t acc = 0;
         for (size_t i = 0; i < h->traces.size(); ++i) {
             for (int k = 0; k < n_iters; ++k) {
@@ -413,6 +413,9 @@ int32_t oracle_mh_step(oracle_mh* h, double drift_std, int32_t n_iters, uint64_t
         if (accepted) *accepted = acc;
     })
 }
+int32_t oracle_mh_step(oracle_mh* h, double drift_std, int32_t n_iters, uint64_t* accepted) { return oracle_mh_run(h, 1, drift_std, n_iters, accepted); }
+// mh(&hierarchical_model, trace, &add_or_remove_param_proposal, ())  — tests/mh.rs:94
+int32_t oracle_mh_step_add_or_remove(oracle_mh* h, int32_t n_iters, uint64_t* accepted) { return oracle_mh_run(h, 2, 0., n_iters, accepted); }
 int32_t oracle_regen_mh_step(oracle_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
     GUARD({
         oracle_pf::Scope scope(h->canonical);

@@ -240,6 +240,21 @@ struct Hierarchical {
                 return 0;
             }, site_of, DOM_PROPOSAL);
     }
+    // add_or_remove_param_proposal — hierarchical.rs:48-61 (the structure-changing move of tests/mh.rs:94); the
+    // proposal argument `()` travels as an unused double
+    DynGenFn<PArgs, int> add_or_remove_proposal() const {
+        return DynGenFn<PArgs, int>(
+            [](DynGenFnHandler<PArgs, int>& g, PArgs pa) -> int {
+                const TraceT* tr = pa.first;
+                g.template sample_at<double>(normal, NormalParams{tr->data.read<double>("coeffs/a"), 0.025}, "coeffs/a");
+                g.template sample_at<double>(normal, NormalParams{tr->data.read<double>("coeffs/b"), 0.025}, "coeffs/b");
+                if (!g.template sample_at<bool>(bernoulli, 0.5, "is_linear")) {
+                    const double prev_c = tr->data.search("coeffs/c") ? tr->data.read<double>("coeffs/c") : 0.;
+                    g.template sample_at<double>(normal, NormalParams{prev_c, 0.025}, "coeffs/c");
+                }
+                return 0;
+            }, site_of, DOM_PROPOSAL);
+    }
 };
 
 // ---------------------------------------------------------------------------------------

@@ -73,6 +73,7 @@ def load():
     L.oracle_pf_shard_query.argtypes = [p, p, p, p, u64, dp, dp]
     L.oracle_mh_create.argtypes = [dp, dp, i32, i32, u64, u64, i32, C.POINTER(p)]
     L.oracle_mh_step.argtypes = [p, d, i32, C.POINTER(u64)]
+    L.oracle_mh_step_add_or_remove.argtypes = [p, i32, C.POINTER(u64)]
     L.oracle_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
     L.oracle_mh_read_state.argtypes = [p, dp]
     L.oracle_mh_read_logjp.argtypes = [p, dp]
@@ -263,6 +264,11 @@ class OracleMH:
     def mh(self, drift_std, n_iters=1):
         acc = C.c_uint64()
         self._ck(self.L.oracle_mh_step(self.h, drift_std, n_iters, C.byref(acc)))
+        return acc.value
+
+    def mh_add_or_remove(self, n_iters=1):
+        acc = C.c_uint64()
+        self._ck(self.L.oracle_mh_step_add_or_remove(self.h, n_iters, C.byref(acc)))
         return acc.value
 
     def regen_mh(self, mask_sites, n_iters=1, cycle=False):

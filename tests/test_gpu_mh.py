@@ -65,6 +65,26 @@ def test_mh_drift_proposal():
         check(g, o)
 
 
+@pytest.mark.parametrize("constrain", [None, False, True])
+def test_mh_add_or_remove_reference_loop(constrain):
+    """The loop of the reference's own test (tests/mh.rs:93-106): one structure-changing add_or_remove_param_proposal
+    move, three drift moves at 0.1, ten at 0.01 — chains switch between the linear and the quadratic branch."""
+    g, o = pair(1500, 21, constrain)
+    flips = 0
+    for _ in range(6):
+        before = g.states()[:, 0].copy()
+        assert g.mh_add_or_remove(1) == o.mh_add_or_remove(1)
+        check(g, o)
+        flips += int((g.states()[:, 0] != before).sum())
+        assert g.mh(0.1, 3) == o.mh(0.1, 3)
+        check(g, o)
+        assert g.mh(0.01, 10) == o.mh(0.01, 10)
+        check(g, o)
+    assert flips > 0
+    st = g.states()
+    assert np.all(st[st[:, 0] == 1.0][:, 3] == 0.0)   # linear traces carry no coeffs/c
+
+
 def test_interleaved_kernels():
     g, o = pair(500, 14, False)
     for r in range(4):
