@@ -210,11 +210,12 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
  *   y_i ~ normal(a + b x_i [+ c x_i^2], 0.1) observed.
  * Static site ids (the stand-in for trie addresses): */
 enum mp_mh_site { MP_SITE_IS_LINEAR = 0, MP_SITE_A = 1, MP_SITE_B = 2, MP_SITE_C = 3 };
-enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1 };
+enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1, MP_MH_MODEL_POINTED_2D = 2 };
 enum mp_mh_proposal_kind {
     MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1, /* hierarchical_drift_proposal(tr, drift_std): hierarchical.rs:62-70; args = {drift_std} */
     MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE = 2, /* add_or_remove_param_proposal(tr): hierarchical.rs:48-61, the structure-changing move of
                                                     * tests/mh.rs:94 (is_linear re-proposed, coeffs/c added or removed); no args */
+    MP_MH_PROPOSAL_POINTED_DRIFT = 3, /* pointed_2d_drift_proposal(tr, noise): simple.rs:36-41; args = the 2x2 noise covariance, row-major */
 };
 typedef struct mp_mh mp_mh;
 
@@ -222,6 +223,13 @@ typedef struct mp_mh mp_mh;
  * constrain_is_linear: -1 = sampled from its prior, 0 / 1 = constrained to false / true.  n_data <= 16. */
 int32_t mp_mh_create(int32_t model_kind, const double* xs, const double* ys, int32_t n_data, int32_t constrain_is_linear,
                      uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out);
+/* The reference's other MH model, `pointed_2d_model` (modppl/tests/dyngenfns/simple.rs:27-34, driven by tests/mh.rs:50-68):
+ *   latent ~ uniform_2d(bounds); obs ~ mvnormal(latent, obs_cov), observed.
+ * bounds = {xmin, xmax, ymin, ymax}; obs_cov 2x2 row-major; obs[2].  Chains of this model take MP_MH_PROPOSAL_POINTED_DRIFT
+ * (latent' ~ mvnormal(latent, noise): mvnormal.random = L z + mu, L the lower Cholesky factor, mvnormal.rs:24-37);
+ * mp_mh_read_state then writes out[n_chains][2] = latent. */
+int32_t mp_mh_create_pointed(const double* bounds, const double* obs_cov, const double* obs, uint64_t n_chains, uint64_t seed, int32_t device,
+                             void* stream, mp_mh** out);
 /* n_iters x `mh(model, trace, proposal, proposal_args)` per chain (mh.rs:9-51).  `accepted` (nullable)
  * receives the total number of accepted moves over all chains and iterations of this call. */
 int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, int32_t n_iters,
@@ -232,7 +240,8 @@ int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args,
  * Masking is_linear or passing an empty mask is MP_ERR_UNSUPPORTED: the reference either panics on the
  * quadratic->linear structure change (dyngenfn.rs:425,526-529) or re-simulates the observed sites (:571). */
 int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted);
-/* Chain states -> out[n_chains][4] = {is_linear (0/1), a, b, c}  (c is NaN-free but meaningless when is_linear). */
+/* Chain states -> out[n_chains][4] = {is_linear (0/1), a, b, c}  (c = 0 when is_linear: such a trace has no coeffs/c);
+ * pointed model: out[n_chains][2]. */
 int32_t mp_mh_read_state(mp_mh* h, double* out);
 /* trace.logjp per chain, summed in site order (the reference's value is the trie's running weight: same to ~1e-15 rel). */
 int32_t mp_mh_read_logjp(mp_mh* h, double* out);

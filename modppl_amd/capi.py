@@ -18,8 +18,10 @@ MP_PF_RECORD_HISTORY = 1
 MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER, MP_K_BIN_DRAWS = 0, 1, 2, 3
 MP_SITE_IS_LINEAR, MP_SITE_A, MP_SITE_B, MP_SITE_C = 0, 1, 2, 3
 MP_MH_MODEL_HIERARCHICAL = 1
+MP_MH_MODEL_POINTED_2D = 2
 MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1
 MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE = 2
+MP_MH_PROPOSAL_POINTED_DRIFT = 3
 
 # every symbol include/modppl_hip.h declares (tests/test_capi_symbols.py checks the export table)
 SYMBOLS = [
@@ -29,7 +31,7 @@ SYMBOLS = [
     "mp_pf_set_timing", "mp_pf_get_timing", "mp_importance_resampling",
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
-    "mp_mh_create", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_iterations", "mp_mh_destroy",
+    "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_iterations", "mp_mh_destroy",
     # include/modppl_hip_probe.h
     "mp_probe_math", "mp_probe_normal_sample", "mp_probe_u01",
 ]
@@ -117,6 +119,7 @@ def load():
     L.mp_pf_shard_scatter.argtypes = [p, p, dp]
     L.mp_pf_shard_query.argtypes = [p, p, p, p, i32, dp, dp]
     L.mp_mh_create.argtypes = [i32, dp, dp, i32, i32, u64, u64, i32, p, C.POINTER(p)]
+    L.mp_mh_create_pointed.argtypes = [dp, dp, dp, u64, u64, i32, p, C.POINTER(p)]
     L.mp_mh_step.argtypes = [p, i32, dp, i32, i32, C.POINTER(u64)]
     L.mp_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
     L.mp_mh_read_state.argtypes = [p, dp]

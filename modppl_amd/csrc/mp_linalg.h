@@ -56,3 +56,21 @@ inline bool mp_host_inverse(std::vector<double> m, int n, std::vector<double>& i
     }
     return true;
 }
+
+// lower Cholesky factor (mvnormal.rs:27-29 `cov.cholesky().l()`): false if the matrix is not positive definite (the
+// reference then falls back to an eigendecomposition, which is not restated)
+inline bool mp_host_cholesky(const std::vector<double>& m, int n, std::vector<double>& L) {
+    L.assign((size_t)n * n, 0.);
+    for (int j = 0; j < n; ++j) {
+        double d = m[j * n + j];
+        for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+        if (!(d > 0.)) return false;
+        L[j * n + j] = std::sqrt(d);
+        for (int i = j + 1; i < n; ++i) {
+            double s = m[i * n + j];
+            for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = s / L[j * n + j];
+        }
+    }
+    return true;
+}

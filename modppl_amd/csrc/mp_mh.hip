@@ -23,6 +23,7 @@
 
 #include "../../include/modppl_hip.h"
 #include "mp_dists.h"
+#include "mp_linalg.h"
 
 typedef unsigned long long u64;
 #define MH_MAX_DATA 16
@@ -243,6 +244,84 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(accepted_total, acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// pointed 2-D model (modppl/tests/dyngenfns/simple.rs:27-41): latent ~ uniform_2d(bounds); obs ~ mvnormal(latent, cov),
+// observed; mh with pointed_2d_drift_proposal: latent' ~ mvnormal(latent, noise)  (tests/mh.rs:50-68).
+// Sites: latent = 1, obs = 2.  mvnormal.random = L z + mu with z_j ~ normal(0, 1) in index order, L = lower Cholesky
+// (mvnormal.rs:24-37); determinant, inverse and Cholesky factor are per-model constants here, per call in modppl.
+// ---------------------------------------------------------------------------------------------
+struct pointed_params {
+    double xmin, xmax, ymin, ymax;
+    double neg_ln_area;       // -mp_log((xmax - xmin) * (ymax - ymin)): types_2d.rs uniform_2d.logpdf inside the bounds
+    double cov_inv[4], ln_det_cov;
+    double obs[2];
+};
+struct pointed_noise {
+    double l00, l10, l11;     // lower Cholesky factor of the proposal covariance
+    double inv[4], ln_det;
+};
+__device__ __forceinline__ double pointed_prior(const pointed_params& P, const double* p) {
+    return (P.xmin <= p[0] && p[0] <= P.xmax && P.ymin <= p[1] && p[1] <= P.ymax) ? P.neg_ln_area : MP_NEG_INF;
+}
+__global__ __launch_bounds__(MH_THREADS) void k_pointed_init(u64 n, uint32_t k0, uint32_t k1, pointed_params P, double* __restrict__ lat) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    mp_stream s;
+    s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = 0;
+    const mp_u64x2 b = s.draw(MP_DOM_MODEL, 1u, 0u);   // the two uniforms of uniform_2d.random: halves of one block
+    lat[2 * i] = mp_u01(b.a) * (P.xmax - P.xmin) + P.xmin;
+    lat[2 * i + 1] = mp_u01(b.b) * (P.ymax - P.ymin) + P.ymin;
+}
+__global__ __launch_bounds__(MH_THREADS) void k_pointed_iterate(u64 n, uint32_t k0, uint32_t k1, uint32_t iter0, int n_iters, pointed_params P,
+                                                                pointed_noise N, double* __restrict__ lat, u64* __restrict__ accepted_total) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    u64 acc = 0;
+    if (i < n) {
+        double x[2] = {lat[2 * i], lat[2 * i + 1]};
+        double lp_lat = pointed_prior(P, x);
+        double lp_obs = mp_mvnormal_logpdf_pre<2>(P.obs, x, P.cov_inv, P.ln_det_cov);
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i;
+        for (int it = 0; it < n_iters; ++it) {
+            s.step = iter0 + (uint32_t)it;
+            // proposal.propose: latent' = L z + latent
+            mp_site ps(s, MP_DOM_PROPOSAL, 1u);
+            const double z0 = mp_normal_sample(ps, 0., 1.);
+            const double z1 = mp_normal_sample(ps, 0., 1.);
+            double nx[2];
+            nx[0] = (0. + N.l00 * z0) + x[0];
+            nx[1] = ((0. + N.l10 * z0) + N.l11 * z1) + x[1];
+            const double fwd = mp_mvnormal_logpdf_pre<2>(nx, x, N.inv, N.ln_det);
+            // model.update: latent constrained with a previous value, obs rescored (diff is Unknown), gc of nothing
+            double w = 0.;
+            w -= lp_lat;
+            const double nlp_lat = pointed_prior(P, nx);
+            w += nlp_lat;
+            const double nlp_obs = mp_mvnormal_logpdf_pre<2>(P.obs, nx, P.cov_inv, P.ln_det_cov);
+            w += nlp_obs - lp_obs;
+            w = w - 0.;
+            // proposal.assess on the new trace: the old latent under mvnormal(latent', noise)
+            const double bwd = mp_mvnormal_logpdf_pre<2>(x, nx, N.inv, N.ln_det);
+            const double alpha = w - fwd + bwd;  // mh.rs:34
+            const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
+            if (mp_log(mp_u01(ub.a)) < alpha) {
+                x[0] = nx[0]; x[1] = nx[1];
+                lp_lat = nlp_lat; lp_obs = nlp_obs;
+                ++acc;
+            }
+        }
+        lat[2 * i] = x[0]; lat[2 * i + 1] = x[1];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(accepted_total, acc);
+}
+__global__ __launch_bounds__(MH_THREADS) void k_pointed_logjp(u64 n, pointed_params P, const double* __restrict__ lat, double* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const double x[2] = {lat[2 * i], lat[2 * i + 1]};
+    out[i] = pointed_prior(P, x) + mp_mvnormal_logpdf_pre<2>(P.obs, x, P.cov_inv, P.ln_det_cov);
+}
+
 struct mp_mh {
     u64 n = 0, seed = 0;
     int device = 0;
@@ -254,6 +333,9 @@ struct mp_mh {
     double *a = nullptr, *b = nullptr, *c = nullptr, *tmp = nullptr;
     u64* d_acc = nullptr;
     u64 iters = 0;
+    int kind = MP_MH_MODEL_HIERARCHICAL;
+    pointed_params pointed{};
+    double* lat = nullptr;   // pointed model: [n][2]
 };
 
 extern "C" {
@@ -318,9 +400,72 @@ static int32_t mh_run(mp_mh* h, int kind, const mh_mask& mask, double drift_std,
     return MP_OK;
 }
 
+int32_t mp_mh_create_pointed(const double* bounds, const double* obs_cov, const double* obs, uint64_t n_chains, uint64_t seed, int32_t device,
+                             void* stream, mp_mh** out) {
+    if (!out) return mp_set_error(MP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!bounds || !obs_cov || !obs) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
+    if (!(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2])) return mp_set_error(MP_ERR_INVALID_ARG, "bounds = {xmin, xmax, ymin, ymax} with xmax > xmin, ymax > ymin");
+    if (n_chains == 0 || n_chains > 0xFFFFFFFFull) return mp_set_error(MP_ERR_INVALID_ARG, "n_chains must be in [1, 2^32)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return mp_set_error(MP_ERR_HIP, "no HIP device visible: the gfx950 path has no CPU fallback");
+    }
+    const std::vector<double> cov(obs_cov, obs_cov + 4);
+    std::vector<double> inv;
+    const double det = mp_host_det(cov, 2);
+    if (!(det > 0.) || !mp_host_inverse(cov, 2, inv)) return mp_set_error(MP_ERR_INVALID_ARG, "obs covariance must be invertible with a positive determinant");
+    std::unique_ptr<mp_mh> h(new mp_mh());
+    h->kind = MP_MH_MODEL_POINTED_2D;
+    h->n = n_chains; h->seed = seed; h->device = device;
+    pointed_params& P = h->pointed;
+    P.xmin = bounds[0]; P.xmax = bounds[1]; P.ymin = bounds[2]; P.ymax = bounds[3];
+    P.neg_ln_area = -mp_log((P.xmax - P.xmin) * (P.ymax - P.ymin));
+    for (int q = 0; q < 4; ++q) P.cov_inv[q] = inv[q];
+    P.ln_det_cov = mp_log(det);
+    P.obs[0] = obs[0]; P.obs[1] = obs[1];
+    MHCK(hipSetDevice(device));
+    if (stream) h->stream = (hipStream_t)stream;
+    else { MHCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    MHCK(hipMalloc(&h->lat, sizeof(double) * 2 * n_chains));
+    MHCK(hipMalloc(&h->tmp, sizeof(double) * n_chains));
+    MHCK(hipMalloc(&h->d_acc, sizeof(u64)));
+    hipLaunchKernelGGL(k_pointed_init, dim3((unsigned)((n_chains + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), P, h->lat);
+    MHCK(hipGetLastError());
+    *out = h.release();
+    return MP_OK;
+}
+
 int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, int32_t n_iters, uint64_t* accepted) {
     if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
     mh_mask none{};
+    if (proposal_kind == MP_MH_PROPOSAL_POINTED_DRIFT) {
+        if (h->kind != MP_MH_MODEL_POINTED_2D) return mp_set_error(MP_ERR_INVALID_ARG, "pointed_2d_drift_proposal needs chains of the pointed 2-D model");
+        if (!proposal_args || n_proposal_args != 4) return mp_set_error(MP_ERR_INVALID_ARG, "pointed_2d_drift_proposal takes the 2x2 noise covariance (row-major)");
+        if (n_iters < 0) return mp_set_error(MP_ERR_INVALID_ARG, "n_iters < 0");
+        const std::vector<double> cov(proposal_args, proposal_args + 4);
+        std::vector<double> L, inv;
+        if (!mp_host_cholesky(cov, 2, L)) return mp_set_error(MP_ERR_UNSUPPORTED, "noise covariance is not positive definite (the reference's eigen fallback, mvnormal.rs:30-33, is not built)");
+        if (!mp_host_inverse(cov, 2, inv)) return mp_set_error(MP_ERR_INVALID_ARG, "noise covariance is not invertible");
+        pointed_noise N;
+        N.l00 = L[0]; N.l10 = L[2]; N.l11 = L[3];
+        for (int q = 0; q < 4; ++q) N.inv[q] = inv[q];
+        N.ln_det = mp_log(mp_host_det(cov, 2));
+        MHCK(hipSetDevice(h->device));
+        MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64), h->stream));
+        hipLaunchKernelGGL(k_pointed_iterate, dim3((unsigned)((h->n + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n,
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), (uint32_t)(h->iters + 1), n_iters, h->pointed, N, h->lat, h->d_acc);
+        MHCK(hipGetLastError());
+        h->iters += (u64)n_iters;
+        if (accepted) {
+            MHCK(hipMemcpyAsync(accepted, h->d_acc, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+            MHCK(hipStreamSynchronize(h->stream));
+        }
+        return MP_OK;
+    }
+    if (h->kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_INVALID_ARG, "this proposal belongs to the hierarchical model");
     if (proposal_kind == MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE) {
         if (n_proposal_args != 0) return mp_set_error(MP_ERR_INVALID_ARG, "add_or_remove_param_proposal takes no arguments");
         return mh_run(h, 2, none, 0.025, n_iters, accepted);   // hierarchical.rs:51-59: every normal of the proposal has std 0.025
@@ -332,6 +477,7 @@ int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args,
 
 int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
     if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
+    if (h->kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_UNSUPPORTED, "regen_mh is compiled for the hierarchical model only");
     if (n_mask < 1 || !mask_sites)
         return mp_set_error(MP_ERR_UNSUPPORTED, "empty mask: the reference regenerates every site including the observed ones (dyngenfn.rs:571)");
     if (n_mask > 3) return mp_set_error(MP_ERR_INVALID_ARG, "at most 3 mask sites");
@@ -349,6 +495,11 @@ int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, in
 int32_t mp_mh_read_state(mp_mh* h, double* out) {
     if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
     MHCK(hipSetDevice(h->device));
+    if (h->kind == MP_MH_MODEL_POINTED_2D) {
+        MHCK(hipMemcpyAsync(out, h->lat, sizeof(double) * 2 * h->n, hipMemcpyDeviceToHost, h->stream));
+        MHCK(hipStreamSynchronize(h->stream));
+        return MP_OK;
+    }
     std::vector<int> il(h->n);
     std::vector<double> a(h->n), b(h->n), c(h->n);
     MHCK(hipMemcpyAsync(il.data(), h->is_lin, sizeof(int) * h->n, hipMemcpyDeviceToHost, h->stream));
@@ -363,6 +514,10 @@ int32_t mp_mh_read_state(mp_mh* h, double* out) {
 int32_t mp_mh_read_logjp(mp_mh* h, double* out) {
     if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
     MHCK(hipSetDevice(h->device));
+    if (h->kind == MP_MH_MODEL_POINTED_2D)
+        hipLaunchKernelGGL(k_pointed_logjp, dim3((unsigned)((h->n + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n, h->pointed, h->lat,
+                           h->tmp);
+    else
     hipLaunchKernelGGL(k_mh_logjp, dim3((unsigned)((h->n + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n, h->data, h->ln_noise,
                        h->is_lin, h->a, h->b, h->c, h->tmp);
     MHCK(hipGetLastError());
@@ -382,6 +537,7 @@ int32_t mp_mh_destroy(mp_mh* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->is_lin); (void)hipFree(h->a); (void)hipFree(h->b); (void)hipFree(h->c); (void)hipFree(h->tmp); (void)hipFree(h->d_acc);
+    (void)hipFree(h->lat);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;

@@ -261,3 +261,48 @@ class HierarchicalChains:
             self.close()
         except Exception:
             pass
+
+
+class PointedChains:
+    """N independent MH chains over the reference's `pointed_2d_model` (modppl/tests/dyngenfns/simple.rs:27-34):
+    latent ~ uniform_2d(bounds), obs ~ mvnormal(latent, obs_cov) observed — the model of `test_metropolis_hastings_dyngenfn`
+    (tests/mh.rs:50-68).  `mh(noise)` = mh(&pointed_2d_model, trace, &pointed_2d_drift_proposal, noise)."""
+
+    def __init__(self, bounds, obs_cov, obs, num_chains, seed, *, device=0, stream=None):
+        self._L = capi.load()
+        b = np.ascontiguousarray(bounds, dtype=np.float64).reshape(4)
+        c = np.ascontiguousarray(obs_cov, dtype=np.float64).reshape(4)
+        o = np.ascontiguousarray(obs, dtype=np.float64).reshape(2)
+        self.num_chains = int(num_chains)
+        h = C.c_void_p()
+        capi.check(self._L.mp_mh_create_pointed(_dptr(b), _dptr(c), _dptr(o), self.num_chains, int(seed), int(device),
+                                                C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+
+    def mh(self, noise, n_iters=1):
+        nz = np.ascontiguousarray(noise, dtype=np.float64).reshape(4)
+        acc = C.c_uint64()
+        capi.check(self._L.mp_mh_step(self._h, capi.MP_MH_PROPOSAL_POINTED_DRIFT, _dptr(nz), 4, int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def states(self):
+        """[num_chains, 2] = latent."""
+        out = np.empty((self.num_chains, 2))
+        capi.check(self._L.mp_mh_read_state(self._h, _dptr(out)))
+        return out
+
+    def logjp(self):
+        out = np.empty(self.num_chains)
+        capi.check(self._L.mp_mh_read_logjp(self._h, _dptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mp_mh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

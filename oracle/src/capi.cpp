@@ -451,6 +451,58 @@ int32_t oracle_mh_read_state(oracle_mh* h, double* out) {
 int32_t oracle_mh_read_logjp(oracle_mh* h, double* out) { GUARD({ for (size_t i = 0; i < h->traces.size(); ++i) out[i] = h->traces[i].logjp; }) }
 int32_t oracle_mh_destroy(oracle_mh* h) { delete h; return MP_OK; }
 
+// ---- pointed 2-D model under mh (tests/mh.rs:50-68) ---------------------------------------------
+struct oracle_mh_pointed {
+    Pointed2D pm;
+    std::vector<Pointed2D::TraceT> traces;
+    uint64_t seed = 0, iters = 0;
+    bool canonical = false;
+};
+static Mat mat2(const double* m) { return Mat(2, std::vector<double>{m[0], m[1], m[2], m[3]}); }
+int32_t oracle_mh_pointed_create(const double* bounds, const double* cov, const double* obs, uint64_t n_chains, uint64_t seed, int32_t canon,
+                                 oracle_mh_pointed** out) {
+    GUARD({
+        auto h = std::make_unique<oracle_mh_pointed>();
+        h->seed = seed; h->canonical = canon != 0;
+        oracle_pf::Scope scope(h->canonical);
+        const Bounds b{bounds[0], bounds[1], bounds[2], bounds[3]};
+        for (uint64_t i = 0; i < n_chains; ++i) {
+            DynTrie observations;  // tests/mh.rs:58-59
+            observations.observe("obs", arc(Vec{obs[0], obs[1]}));
+            Rng r; r.seed = seed; r.slot = (uint32_t)i; r.step = 0;
+            h->traces.push_back(h->pm.model.generate(r, {b, mat2(cov)}, observations).first);  // :61
+        }
+        *out = h.release();
+    })
+}
+int32_t oracle_mh_pointed_step(oracle_mh_pointed* h, const double* noise, int32_t n_iters, uint64_t* accepted) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        auto proposal = h->pm.drift_proposal();
+        uint64_t acc = 0;
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            for (int k = 0; k < n_iters; ++k) {
+                Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = (uint32_t)(h->iters + 1 + (uint64_t)k);
+                auto [tr, ok] = metropolis_hastings<Pointed2D::Args, Vec, Mat>(r, h->pm.model, std::move(h->traces[i]), proposal, mat2(noise));  // :64
+                h->traces[i] = std::move(tr);
+                acc += ok;
+            }
+        }
+        h->iters += (uint64_t)n_iters;
+        if (accepted) *accepted = acc;
+    })
+}
+int32_t oracle_mh_pointed_read_state(oracle_mh_pointed* h, double* out) {
+    GUARD({
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            const Vec v = h->traces[i].data.read<Vec>("latent");
+            out[2 * i] = v[0]; out[2 * i + 1] = v[1];
+        }
+    })
+}
+int32_t oracle_mh_pointed_read_logjp(oracle_mh_pointed* h, double* out) { GUARD({ for (size_t i = 0; i < h->traces.size(); ++i) out[i] = h->traces[i].logjp; }) }
+int32_t oracle_mh_pointed_destroy(oracle_mh_pointed* h) { delete h; return MP_OK; }
+
 // ---- math / rng / distribution probes ---------------------------------------------------------
 void oracle_mp_exp(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_exp(x[i]); }
 void oracle_mp_log(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_log(x[i]); }

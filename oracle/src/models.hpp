@@ -258,6 +258,32 @@ struct Hierarchical {
 };
 
 // ---------------------------------------------------------------------------------------
+// pointed 2-D model + drift proposal — tests/dyngenfns/simple.rs:27-41 (driven by tests/mh.rs:50-68)
+// ---------------------------------------------------------------------------------------
+struct Pointed2D {
+    using Args = std::pair<Bounds, Mat>;                 // (bounds, cov)
+    using TraceT = Trace<Args, DynTrie, Vec>;
+    using PArgs = std::pair<const TraceT*, Mat>;         // (Weak<trace>, noise)
+    static uint32_t site_of(const std::string& a) { return a == "latent" ? 1u : 2u; }
+    DynGenFn<Args, Vec> model;
+    Pointed2D() {
+        model = DynGenFn<Args, Vec>(
+            [](DynGenFnHandler<Args, Vec>& g, Args a) -> Vec {
+                const Vec latent = g.template sample_at<Vec>(uniform_2d, a.first, "latent");
+                return g.template sample_at<Vec>(mvnormal, MvNormalParams{latent, a.second}, "obs");
+            }, site_of);
+    }
+    DynGenFn<PArgs, int> drift_proposal() const {
+        return DynGenFn<PArgs, int>(
+            [](DynGenFnHandler<PArgs, int>& g, PArgs pa) -> int {
+                const Vec prev_latent = pa.first->data.read<Vec>("latent");
+                g.template sample_at<Vec>(mvnormal, MvNormalParams{prev_latent, pa.second}, "latent");
+                return 0;
+            }, site_of, DOM_PROPOSAL);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
 // HMM — tests/hmm/model.rs:8-80, tests/hmm/forward.rs:3-22, tests/hmm/trace.rs
 // Matrices are stored column-stochastic as the reference builds them (dmatrix![..].transpose()):
 // column j = distribution given state j.

@@ -74,6 +74,11 @@ def load():
     L.oracle_mh_create.argtypes = [dp, dp, i32, i32, u64, u64, i32, C.POINTER(p)]
     L.oracle_mh_step.argtypes = [p, d, i32, C.POINTER(u64)]
     L.oracle_mh_step_add_or_remove.argtypes = [p, i32, C.POINTER(u64)]
+    L.oracle_mh_pointed_create.argtypes = [dp, dp, dp, u64, u64, i32, C.POINTER(p)]
+    L.oracle_mh_pointed_step.argtypes = [p, dp, i32, C.POINTER(u64)]
+    L.oracle_mh_pointed_read_state.argtypes = [p, dp]
+    L.oracle_mh_pointed_read_logjp.argtypes = [p, dp]
+    L.oracle_mh_pointed_destroy.argtypes = [p]
     L.oracle_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
     L.oracle_mh_read_state.argtypes = [p, dp]
     L.oracle_mh_read_logjp.argtypes = [p, dp]
@@ -365,3 +370,41 @@ class OracleShardEngine:
 
     def synchronize(self):
         pass
+
+
+class OraclePointedMH:
+    """N chains of the restated pointed_2d_model under mh with pointed_2d_drift_proposal (tests/mh.rs:50-68)."""
+
+    def __init__(self, bounds, obs_cov, obs, n_chains, seed, canonical=True):
+        self.L = load()
+        self.n = n_chains
+        h = C.c_void_p()
+        b, c, o = (np.ascontiguousarray(v, dtype=np.float64).reshape(-1) for v in (bounds, obs_cov, obs))
+        self._ck(self.L.oracle_mh_pointed_create(dptr(b), dptr(c), dptr(o), n_chains, seed, int(canonical), C.byref(h)))
+        self.h = h
+
+    def _ck(self, code):
+        if code != 0:
+            raise OracleError(code, self.L.oracle_last_error().decode())
+
+    def mh(self, noise, n_iters=1):
+        nz = np.ascontiguousarray(noise, dtype=np.float64).reshape(-1)
+        acc = C.c_uint64()
+        self._ck(self.L.oracle_mh_pointed_step(self.h, dptr(nz), n_iters, C.byref(acc)))
+        return acc.value
+
+    def state(self):
+        out = np.empty((self.n, 2))
+        self._ck(self.L.oracle_mh_pointed_read_state(self.h, dptr(out)))
+        return out
+
+    def logjp(self):
+        out = np.empty(self.n)
+        self._ck(self.L.oracle_mh_pointed_read_logjp(self.h, dptr(out)))
+        return out
+
+    def __del__(self):
+        try:
+            self.L.oracle_mh_pointed_destroy(self.h)
+        except Exception:
+            pass

@@ -126,3 +126,41 @@ def test_c4_full_size_posterior():
     assert np.all(np.abs(med - ols) < 0.05), (med, ols)
     assert 0 < acc < n * 500
     assert g.iterations == 530
+
+
+BOUNDS = [-5.0, 5.0, -5.0, 5.0]            # tests/mh.rs:55
+OBS_COV = [[1.0, -0.6], [-0.6, 2.0]]       # :61
+NOISE = [[0.25, 0.0], [0.0, 0.25]]         # :64
+
+
+@pytest.mark.parametrize("noise", [NOISE, [[0.3, 0.1], [0.1, 0.2]], [[9.0, 0.0], [0.0, 9.0]]])
+def test_pointed_2d_mh_reference_loop(noise):
+    """test_metropolis_hastings_dyngenfn (tests/mh.rs:50-68): uniform_2d prior, dense mvnormal likelihood and proposal
+    (mvnormal.random = L z + mu).  Chain states and accept counts bit-exact; the wide proposal leaves the bounds
+    (prior -inf -> rejected, never NaN)."""
+    import modppl_amd
+
+    n, seed = 3000, 4
+    g = modppl_amd.PointedChains(BOUNDS, OBS_COV, [0.0, 0.0], n, seed)
+    o = O.OraclePointedMH(BOUNDS, OBS_COV, [0.0, 0.0], n, seed, canonical=True)
+    assert np.array_equal(g.states(), o.state())
+    for it in (1, 4, 20):
+        assert g.mh(noise, it) == o.mh(noise, it)
+        assert np.array_equal(g.states(), o.state())
+        assert np.allclose(g.logjp(), o.logjp(), rtol=1e-12, atol=1e-12)
+    st = g.states()
+    assert np.all(np.abs(st) <= 5.0) and np.all(np.isfinite(st))
+
+
+def test_pointed_2d_posterior_full_size():
+    """2^20 chains, 200 sweeps: the posterior of latent given obs = 0 under a flat prior on the box is (nearly) the
+    mvnormal(0, obs_cov) likelihood itself."""
+    import modppl_amd
+
+    g = modppl_amd.PointedChains(BOUNDS, OBS_COV, [0.0, 0.0], 1 << 20, 9)
+    acc = g.mh(NOISE, 200)
+    assert 0.3 < acc / (200 * (1 << 20)) < 0.95
+    st = g.states()
+    cov = np.cov(st.T)
+    assert np.allclose(st.mean(axis=0), 0.0, atol=0.01)
+    assert np.allclose(cov, np.array(OBS_COV), atol=0.03)
