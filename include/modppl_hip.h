@@ -53,6 +53,11 @@ enum mp_model_kind {
     MP_MODEL_BEARINGS = 4,
     /* LGSSM d=D (config 5): x' = A x + sig_x z, y = x + sig_y e.  params = {D, a, band, sig0, sig_x, sig_y} */
     MP_MODEL_LGSSM_BAND = 5,
+    /* static (single-step) models of modppl/tests/importance.rs, for mp_importance_resampling with n_steps = 1:
+     * pointed_2d_model (tests/dyngenfns/simple.rs:27-34): params = {xmin,xmax,ymin,ymax, cov[4] row-major}; state = latent (2), obs = 2 */
+    MP_MODEL_POINTED_2D = 6,
+    /* line_model (simple.rs:9-24): params = xs[11]; state = (slope, intercept), obs = ys[11] */
+    MP_MODEL_LINE = 7,
 };
 
 typedef struct mp_model_desc {

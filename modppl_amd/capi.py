@@ -11,7 +11,7 @@ from . import build as _build
 MP_OK = 0
 MP_ERR_INVALID_ARG, MP_ERR_STATE, MP_ERR_CONSTRAINTS, MP_ERR_DEGENERATE, MP_ERR_HIP, MP_ERR_UNSUPPORTED, MP_ERR_CAPACITY = 1, 2, 3, 4, 5, 6, 7
 
-MP_MODEL_LGSSM1, MP_MODEL_SPIRAL, MP_MODEL_HMM, MP_MODEL_BEARINGS, MP_MODEL_LGSSM_BAND = 1, 2, 3, 4, 5
+MP_MODEL_LGSSM1, MP_MODEL_SPIRAL, MP_MODEL_HMM, MP_MODEL_BEARINGS, MP_MODEL_LGSSM_BAND, MP_MODEL_POINTED_2D, MP_MODEL_LINE = 1, 2, 3, 4, 5, 6, 7
 MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC, MP_RESAMPLE_STRATIFIED = 0, 1, 2
 MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
 MP_PF_RECORD_HISTORY = 1

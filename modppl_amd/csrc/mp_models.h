@@ -89,6 +89,14 @@ struct mp_generate_handler {
             return mp_categorical_sample(st, probs, n);
         }
     }
+    // uniform_2d (modppl/tests/pointed_model/types_2d.rs:14-32): both coordinates from ONE site, i.e. from consecutive
+    // uniforms of its stream = the two halves of one Philox block.  Free sites only on this path.
+    template <int SITE>
+    MP_HD void uniform_2d(double xmin, double xmax, double ymin, double ymax, double* out) {
+        const mp_u64x2 b = rng.draw(MP_DOM_MODEL, (uint32_t)SITE, 0u);
+        out[0] = mp_u01(b.a) * (xmax - xmin) + xmin;
+        out[1] = mp_u01(b.b) * (ymax - ymin) + ymin;
+    }
     template <int SITE>
     MP_HD double uniform(double a, double b) {
         constexpr int k = Model::obs_of(SITE);
@@ -269,5 +277,63 @@ struct mp_lgssm_band {
     template <class H>
     MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
         site<H, 0>(g, t, prev, next);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Static (T = 1) models of the reference's importance tests (modppl/tests/importance.rs), run through the Unfold entry
+// points with a single time step; later steps leave the state alone and score nothing.
+//   pointed_2d_model — tests/dyngenfns/simple.rs:27-34: latent ~ uniform_2d(bounds); mvnormal(latent, cov) %= "obs"
+//   line_model       — tests/dyngenfns/simple.rs:9-24: slope ~ normal(0,1); intercept ~ normal(0,2);
+//                      ys/i ~ normal(slope * x_i + intercept, 0.1), observed
+// ---------------------------------------------------------------------------------------
+struct mp_pointed2d {
+    static constexpr int DIM_STATE = 2, DIM_OBS = 2;
+    enum { LATENT = 0, OBS = 1 };
+    static constexpr int obs_of(int site) { return site == OBS ? 0 : -1; }
+    static constexpr int MAX_NORMALS = 1;  // none used
+    static constexpr int normal_index(int) { return 0; }
+    MP_HD int n_normals(int64_t) const { return 0; }
+    MP_HD uint32_t normal_site(int) const { return 0; }
+    double xmin, xmax, ymin, ymax;
+    double cov_inv[4];
+    double ln_det;
+
+    template <class H>
+    MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
+        if (t != 0) { next[0] = prev[0]; next[1] = prev[1]; return; }
+        double latent[2];
+        g.template uniform_2d<LATENT>(xmin, xmax, ymin, ymax, latent);
+        g.template mvnormal_observed<OBS, 2>(latent, cov_inv, ln_det);
+        next[0] = latent[0];
+        next[1] = latent[1];
+    }
+};
+
+template <int N>
+struct mp_line {
+    static constexpr int DIM_STATE = 2, DIM_OBS = N;
+    enum { SLOPE = 0, INTERCEPT = 1, YS = 2 };   // ys/i = site YS + i
+    static constexpr int obs_of(int site) { return site >= YS ? site - YS : -1; }
+    static constexpr int MAX_NORMALS = 2;
+    static constexpr int normal_index(int site) { return site; }
+    MP_HD int n_normals(int64_t t) const { return t == 0 ? 2 : 0; }
+    MP_HD uint32_t normal_site(int idx) const { return (uint32_t)idx; }
+    double xs[N];
+    double ln_noise;   // mp_log(0.1)
+
+    template <class H, int J>
+    MP_HD void ys(H& g, double slope, double intercept) const {
+        g.template normal<YS + J>(slope * xs[J] + intercept, 0.1, ln_noise);
+        if constexpr (J + 1 < N) ys<H, J + 1>(g, slope, intercept);
+    }
+    template <class H>
+    MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
+        if (t != 0) { next[0] = prev[0]; next[1] = prev[1]; return; }
+        const double slope = g.template normal<SLOPE>(0., 1.);
+        const double intercept = g.template normal<INTERCEPT>(0., 2.);
+        ys<H, 0>(g, slope, intercept);
+        next[0] = slope;
+        next[1] = intercept;
     }
 };

@@ -189,6 +189,30 @@ static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out
         if (D == 2) { out.reset(new ModelOpsT<mp_lgssm_band<2>>(mp_lgssm_band<2>{m->params[1], m->params[2], m->params[3], m->params[4], m->params[5], ln_sy})); return MP_OK; }
         return mp_fail(MP_ERR_UNSUPPORTED, "MP_MODEL_LGSSM_BAND: D in {2, 4, 16} is compiled in");
     }
+    case MP_MODEL_POINTED_2D: {
+        if (m->n_params != 8 || !m->params) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_POINTED_2D takes 8 params {xmin,xmax,ymin,ymax, cov row-major}");
+        if (m->dim_state != 2 || m->dim_obs != 2) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_POINTED_2D: dim_state = dim_obs = 2");
+        if (!(m->params[1] > m->params[0]) || !(m->params[3] > m->params[2])) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_POINTED_2D: xmax > xmin and ymax > ymin");
+        mp_pointed2d k{};
+        k.xmin = m->params[0]; k.xmax = m->params[1]; k.ymin = m->params[2]; k.ymax = m->params[3];
+        const std::vector<double> cov(m->params + 4, m->params + 8);
+        std::vector<double> inv;
+        const double det = mp_host_det(cov, 2);
+        if (!(det > 0.) || !mp_host_inverse(cov, 2, inv)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_POINTED_2D: covariance must be invertible with a positive determinant");
+        for (int i = 0; i < 4; ++i) k.cov_inv[i] = inv[i];
+        k.ln_det = mp_log(det);
+        out.reset(new ModelOpsT<mp_pointed2d>(k));
+        return MP_OK;
+    }
+    case MP_MODEL_LINE: {
+        if (m->n_params != 11 || !m->params || m->dim_obs != 11 || m->dim_state != 2)
+            return mp_fail(MP_ERR_UNSUPPORTED, "MP_MODEL_LINE: the 11-point design of tests/importance.rs:62 is compiled in (params = xs[11], dim_state = 2, dim_obs = 11)");
+        mp_line<11> k{};
+        for (int i = 0; i < 11; ++i) k.xs[i] = m->params[i];
+        k.ln_noise = mp_log(0.1);
+        out.reset(new ModelOpsT<mp_line<11>>(k));
+        return MP_OK;
+    }
     default:
         return mp_fail(MP_ERR_UNSUPPORTED, "model kind " + std::to_string(m->kind) + " is not compiled into this library");
     }

@@ -56,3 +56,16 @@ def bearings_model(p0x=1.0, p0y=1.0, sig_p0=1.0, sig_v0=0.1, sig_a=0.05, sig_the
 def lgssm_band_model(D=16, a=0.9, band=0.05, sig0=1.0, sig_x=0.5, sig_y=1.0):
     """Banded LGSSM d=D (BASELINE.json config 5): x' = a (I + band B) x + sig_x z, y = x + sig_y e."""
     return UnfoldModel(capi.MP_MODEL_LGSSM_BAND, D, D, [D, a, band, sig0, sig_x, sig_y], f"lgssm_band{D}")
+
+
+def pointed_2d_model(bounds=(-5.0, 5.0, -5.0, 5.0), cov=((1.0, -0.6), (-0.6, 2.0))):
+    """`pointed_2d_model` of modppl/tests/dyngenfns/simple.rs:27-34 (static: one generate, n_steps = 1):
+    latent ~ uniform_2d(bounds), obs ~ mvnormal(latent, cov) observed.  Defaults: tests/importance.rs:24-25."""
+    c = np.asarray(cov, dtype=np.float64).reshape(4)
+    return UnfoldModel(capi.MP_MODEL_POINTED_2D, 2, 2, list(bounds) + list(c), "pointed_2d")
+
+
+def line_model(xs=tuple(float(v) for v in range(-5, 6))):
+    """`line_model` of modppl/tests/dyngenfns/simple.rs:9-24 (static): slope ~ normal(0,1), intercept ~ normal(0,2),
+    ys/i ~ normal(slope x_i + intercept, 0.1) observed.  Default design: tests/importance.rs:62."""
+    return UnfoldModel(capi.MP_MODEL_LINE, 2, len(xs), list(xs), "line")

@@ -195,6 +195,12 @@ int32_t oracle_pf_create(const mp_model_desc* m, uint64_t n, uint64_t seed, cons
             } else if (m->kind == MP_MODEL_LGSSM_BAND) {
                 if (m->n_params != 6) throw Panic("lgssm_band: 6 params");
                 e->model = std::make_unique<SoaLgssmBand>(BandParams{(int)m->params[0], m->params[1], m->params[2], m->params[3], m->params[4], m->params[5]});
+            } else if (m->kind == MP_MODEL_POINTED_2D) {
+                if (m->n_params != 8) throw Panic("pointed_2d: 8 params");
+                e->model = std::make_unique<SoaPointed>(Bounds{m->params[0], m->params[1], m->params[2], m->params[3]},
+                                                        Mat(2, std::vector<double>(m->params + 4, m->params + 8)));
+            } else if (m->kind == MP_MODEL_LINE) {
+                e->model = std::make_unique<SoaLine>(Vec(m->params, m->params + m->n_params));
             } else throw Panic("unsupported model kind for the SoA engine");
             e->pf = std::make_unique<SoaPf>(e->model.get(), (size_t)n, seed, canon, shard ? shard->n_global : 0, shard ? shard->slot_offset : 0);
             h->impl = std::move(e);
@@ -238,6 +244,26 @@ int32_t oracle_pf_create(const mp_model_desc* m, uint64_t n, uint64_t seed, cons
                 e->dim_state = d; e->dim_obs = dobs;
                 e->mk_state = [d](const double* a) { return Vec(a, a + d); };
                 e->put_state = [d](const Vec& s, double* o) { for (int j = 0; j < d; ++j) o[j] = s[(size_t)j]; };
+                e->ps = std::make_unique<DynPf<Vec>::PS>(e->model, (size_t)n, seed);
+                e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
+                h->impl = std::move(e);
+            } else if (m->kind == MP_MODEL_POINTED_2D || m->kind == MP_MODEL_LINE) {
+                auto e = std::make_unique<DynPf<Vec>>();
+                int dobs;
+                if (m->kind == MP_MODEL_POINTED_2D) {
+                    if (m->n_params != 8) throw Panic("pointed_2d: 8 params");
+                    e->model = make_pointed_unfold(Bounds{m->params[0], m->params[1], m->params[2], m->params[3]},
+                                                   Mat(2, std::vector<double>(m->params + 4, m->params + 8)));
+                    dobs = 2;
+                    e->mk_constraints = [](const double* y) { DynTrie c; c.observe("obs", arc(Vec{y[0], y[1]})); return c; };
+                } else {
+                    dobs = m->n_params;
+                    e->model = make_line_unfold(Vec(m->params, m->params + m->n_params));
+                    e->mk_constraints = [dobs](const double* y) { DynTrie c; for (int j = 0; j < dobs; ++j) c.observe("ys/" + std::to_string(j), arc(y[j])); return c; };
+                }
+                e->dim_state = 2; e->dim_obs = dobs;
+                e->mk_state = [](const double* a) { return Vec{a ? a[0] : 0., a ? a[1] : 0.}; };
+                e->put_state = [](const Vec& s_, double* o) { o[0] = s_[0]; o[1] = s_[1]; };
                 e->ps = std::make_unique<DynPf<Vec>::PS>(e->model, (size_t)n, seed);
                 e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
                 h->impl = std::move(e);
@@ -366,7 +392,17 @@ int32_t oracle_importance_resampling(const mp_model_desc* m, const double* args0
                 auto model = make_spiral_model();
                 run(model, [](const double* a) { return Vec{a[0], a[1]}; }, [](const double* y) { DynTrie c; c.observe("obs", arc(Vec{y[0], y[1]})); return c; },
                     [](const Vec& s_, double* o) { o[0] = s_[0]; o[1] = s_[1]; }, 2, 2);
-            } else throw Panic("dynamic importance_resampling: lgssm1 / spiral only");
+            } else if (m->kind == MP_MODEL_POINTED_2D) {   // tests/importance.rs:17-50 (the model of test_importance_handcoded, DynGenFn form)
+                auto model = make_pointed_unfold(Bounds{m->params[0], m->params[1], m->params[2], m->params[3]}, Mat(2, std::vector<double>(m->params + 4, m->params + 8)));
+                run(model, [](const double* a) { return Vec{a[0], a[1]}; }, [](const double* y) { DynTrie c; c.observe("obs", arc(Vec{y[0], y[1]})); return c; },
+                    [](const Vec& s_, double* o) { o[0] = s_[0]; o[1] = s_[1]; }, 2, 2);
+            } else if (m->kind == MP_MODEL_LINE) {         // tests/importance.rs:54-76 (test_importance_dyngenfn)
+                const int dobs = m->n_params;
+                auto model = make_line_unfold(Vec(m->params, m->params + dobs));
+                run(model, [](const double* a) { return Vec{a[0], a[1]}; },
+                    [dobs](const double* y) { DynTrie c; for (int j = 0; j < dobs; ++j) c.observe("ys/" + std::to_string(j), arc(y[j])); return c; },
+                    [](const Vec& s_, double* o) { o[0] = s_[0]; o[1] = s_[1]; }, 2, dobs);
+            } else throw Panic("dynamic importance_resampling: lgssm1 / spiral / pointed_2d / line only");
         }
     })
 }

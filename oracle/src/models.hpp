@@ -177,6 +177,48 @@ inline DynUnfold<Vec> make_lgssm_band_model(BandParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// static models of tests/importance.rs, wrapped as single-step Unfold kernels (t > 0: no sites, state unchanged)
+//   pointed_2d_model — tests/dyngenfns/simple.rs:27-34;  line_model + obs_model — simple.rs:9-24
+// ---------------------------------------------------------------------------------------
+inline DynUnfold<Vec> make_pointed_unfold(Bounds b, Mat cov) {
+    using A = std::pair<int64_t, Vec>;
+    using H = DynGenFnHandler<A, Vec>;
+    DynGenFn<A, Vec> k(
+        [b, cov](H& g, A ta) -> Vec {
+            if (ta.first != 0) return ta.second;
+            const Vec latent = g.template sample_at<Vec>(uniform_2d, b, "latent");
+            g.template sample_at<Vec>(mvnormal, MvNormalParams{latent, cov}, "obs");
+            return latent;
+        },
+        [](const std::string& a) -> uint32_t { return a == "latent" ? 0u : 1u; });
+    return DynUnfold<Vec>(std::move(k));
+}
+inline DynUnfold<Vec> make_line_unfold(Vec xs) {
+    using A = std::pair<int64_t, Vec>;
+    using H = DynGenFnHandler<A, Vec>;
+    // obs_model(slope, intercept, xs) /= "ys": a sub-generative-function call, as in the reference
+    auto obs_model = std::make_shared<DynGenFn<std::tuple<double, double, Vec>, Vec>>(
+        [](DynGenFnHandler<std::tuple<double, double, Vec>, Vec>& g, std::tuple<double, double, Vec> a) -> Vec {
+            const auto& [slope, intercept, xs_] = a;
+            Vec out;
+            for (size_t i = 0; i < xs_.size(); ++i)
+                out.push_back(g.template sample_at<double>(normal, NormalParams{slope * xs_[i] + intercept, 0.1}, std::to_string(i)));
+            return out;
+        },
+        [](const std::string& a) -> uint32_t { return 2u + (uint32_t)std::stoul(a); });
+    DynGenFn<A, Vec> k(
+        [xs, obs_model](H& g, A ta) -> Vec {
+            if (ta.first != 0) return ta.second;
+            const double slope = g.template sample_at<double>(normal, NormalParams{0., 1.}, "slope");
+            const double intercept = g.template sample_at<double>(normal, NormalParams{0., 2.}, "intercept");
+            g.template trace_at<std::tuple<double, double, Vec>, Vec>(*obs_model, {slope, intercept, xs}, "ys");
+            return Vec{slope, intercept};
+        },
+        [](const std::string& a) -> uint32_t { return a == "slope" ? 0u : (a == "intercept" ? 1u : 2u); });
+    return DynUnfold<Vec>(std::move(k));
+}
+
+// ---------------------------------------------------------------------------------------
 // hierarchical model + proposals — tests/dyngenfns/hierarchical.rs:18-70
 // ---------------------------------------------------------------------------------------
 struct Hierarchical {

@@ -56,6 +56,32 @@ struct SoaSpiral : SoaModel {  // tests/dyngenfns/unfold.rs:14-32
     }
 };
 
+// static models of tests/importance.rs (one generate; later steps leave the state alone)
+struct SoaPointed : SoaModel {   // tests/dyngenfns/simple.rs:27-34
+    Bounds b; Mat cov;
+    SoaPointed(Bounds b_, Mat c) : b(b_), cov(std::move(c)) { dim_state = 2; dim_obs = 2; }
+    double kernel(Rng& r, int64_t t, const double* prev, double* next, const double* obs) const override {
+        if (t != 0) { next[0] = prev[0]; next[1] = prev[1]; return 0.; }
+        r.at(DOM_MODEL, 0);
+        const Vec latent = uniform_2d.random(r, b);
+        next[0] = latent[0]; next[1] = latent[1];
+        return mvnormal.logpdf(Vec{obs[0], obs[1]}, MvNormalParams{latent, cov});
+    }
+};
+struct SoaLine : SoaModel {      // tests/dyngenfns/simple.rs:9-24
+    Vec xs;
+    explicit SoaLine(Vec xs_) : xs(std::move(xs_)) { dim_state = 2; dim_obs = (int)xs.size(); }
+    double kernel(Rng& r, int64_t t, const double* prev, double* next, const double* obs) const override {
+        if (t != 0) { next[0] = prev[0]; next[1] = prev[1]; return 0.; }
+        r.at(DOM_MODEL, 0); const double slope = normal.random(r, {0., 1.});
+        r.at(DOM_MODEL, 1); const double intercept = normal.random(r, {0., 2.});
+        double w = 0.;
+        for (size_t i = 0; i < xs.size(); ++i) w += normal.logpdf(obs[i], {slope * xs[i] + intercept, 0.1});
+        next[0] = slope; next[1] = intercept;
+        return w;
+    }
+};
+
 struct SoaBearings : SoaModel {
     BearingsParams p;
     explicit SoaBearings(BearingsParams p_) : p(p_) { dim_state = 4; dim_obs = 1; }

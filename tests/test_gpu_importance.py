@@ -50,3 +50,39 @@ def test_importance_one_million():
     states, idx, lml = modppl_amd.importance_resampling(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), None, ys, n, 1024, 3)
     assert abs(lml - O.kalman_log_ml(ys)) < 0.05
     assert idx.max() < n and states.shape == (n, 1)
+
+
+def test_importance_reference_models():
+    """The two models of the reference's own importance tests, 10 000 samples and 1 000 resampled traces as there:
+    pointed_2d_model (tests/importance.rs:17-50: uniform_2d prior, dense mvnormal likelihood) and line_model
+    (:54-76: two normal priors, 11 observations through the obs_model sub-call).  Bit-exact against the SoA checker
+    and, at a smaller size, against the generic importance_resampling over the trie-addressed restatement."""
+    import modppl_amd
+
+    n, m, seed = 10000, 1000, 12
+    bounds, cov = [-5.0, 5.0, -5.0, 5.0], [1.0, -0.6, -0.6, 2.0]
+    obs = np.array([[0.0, 0.0]])
+    pparams = np.array(bounds + cov)
+    states, idx, lml = modppl_amd.importance_resampling(modppl_amd.pointed_2d_model(bounds, cov), [0.0, 0.0], obs, n, m, seed)
+    r_lml, r_lnw, r_idx, r_xs = O.importance_resampling(6, 2, 2, pparams, obs, n, m, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, args0=[0.0, 0.0])
+    assert lml == r_lml and np.array_equal(idx, r_idx) and np.array_equal(states, r_xs)
+    assert np.all(np.abs(states) <= 5.0)
+    # evidence of obs = 0 under a flat prior on the 10 x 10 box: integral of the mvnormal density / 100 ~ 1/100
+    assert abs(lml - np.log(1.0 / 100.0)) < 0.05
+    post = states[idx]
+    assert np.allclose(np.cov(post.T), np.array(cov).reshape(2, 2), atol=0.35)
+    d_lml, d_lnw, d_idx, d_xs = O.importance_resampling(6, 2, 2, pparams, obs, 1500, 40, seed, O.VARIANT_CANONICAL, args0=[0.0, 0.0])
+    s3, i3, l3 = modppl_amd.importance_resampling(modppl_amd.pointed_2d_model(bounds, cov), [0.0, 0.0], obs, 1500, 40, seed)
+    assert l3 == d_lml and np.array_equal(i3, d_idx) and np.array_equal(s3, d_xs)
+
+    xs = np.arange(-5.0, 6.0)
+    rng = np.random.default_rng(0)
+    ys = (0.5 * xs - 1.0 + 0.1 * rng.normal(size=xs.size)).reshape(1, -1)   # tests/importance.rs:66-67
+    states, idx, lml = modppl_amd.importance_resampling(modppl_amd.line_model(xs), [0.0, 0.0], ys, n, m, seed)
+    r_lml, r_lnw, r_idx, r_xs = O.importance_resampling(7, 2, 11, xs, ys, n, m, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, args0=[0.0, 0.0])
+    assert lml == r_lml and np.array_equal(idx, r_idx) and np.array_equal(states, r_xs)
+    best = states[idx[0]]
+    assert abs(best[0] - 0.5) < 0.2 and abs(best[1] + 1.0) < 0.5   # the resampled traces sit near slope 0.5, intercept -1
+    d_lml, d_lnw, d_idx, d_xs = O.importance_resampling(7, 2, 11, xs, ys, 1500, 40, seed, O.VARIANT_CANONICAL, args0=[0.0, 0.0])
+    s3, i3, l3 = modppl_amd.importance_resampling(modppl_amd.line_model(xs), [0.0, 0.0], ys, 1500, 40, seed)
+    assert l3 == d_lml and np.array_equal(i3, d_idx) and np.array_equal(s3, d_xs)
