@@ -47,5 +47,126 @@ def main():
     print(json.dumps(meta)[:300])
 
 
+# ---- second fixture: the other paths (small sizes; canonical arithmetic, which the device implements) ---------------------
+XS = np.arange(-5.0, 6.0)
+BOUNDS, COV, NOISE = [-5.0, 5.0, -5.0, 5.0], [1.0, -0.6, -0.6, 2.0], [0.25, 0.0, 0.0, 0.25]
+CANON_SOA = O.VARIANT_CANONICAL | O.VARIANT_SOA
+
+
+def paths_inputs():
+    rng = np.random.default_rng(20241008)
+    return dict(
+        mh_ys=0.3 + 0.4 * XS + 0.5 * XS * XS + 0.1 * rng.normal(size=XS.size),       # tests/mh.rs:84-87
+        line_ys=(0.5 * XS - 1.0 + 0.1 * rng.normal(size=XS.size)).reshape(1, -1),     # tests/importance.rs:66-67
+        spiral_obs=rng.normal(0.0, 0.5, size=(6, 2)),
+        bearings_obs=np.arctan2(1.0 + 0.05 * np.arange(6), 1.0 + 0.1 * np.arange(6)).reshape(6, 1) + 0.02 * rng.normal(size=(6, 1)),
+        band_obs=rng.normal(0.0, 1.2, size=(5, 4)))
+
+
+def paths_outputs(mk_mh, mk_pointed, importance, mk_pf, inp):
+    """One driver for the oracle (make / CPU test) and the HIP path (GPU test): the callables hide which engine runs."""
+    out = {}
+    h = mk_mh(inp["mh_ys"], 64, 31)
+    acc = []
+    for _ in range(3):                                      # the loop of tests/mh.rs:93-106, then regen_mh sweeps
+        acc += [h.mh_add_or_remove(1), h.mh(0.1, 3), h.mh(0.01, 10)]
+    out["mh_loop_states"], out["mh_loop_acc"] = h.states().copy(), np.array(acc, dtype=np.int64)
+    h2 = mk_mh(inp["mh_ys"], 64, 32, constrain=False)
+    out["regen_acc"] = np.array([h2.regen_mh([1, 2, 3], 9, True)], dtype=np.int64)
+    out["regen_states"] = h2.states().copy()
+    p = mk_pointed(64, 33)
+    out["pointed_acc"] = np.array([p.mh(NOISE, 25)], dtype=np.int64)
+    out["pointed_states"] = p.states().copy()
+    out["is_pointed"] = importance(6, 2, 2, np.array(BOUNDS + COV), np.array([[0.0, 0.0]]), 512, 32, 34)
+    out["is_line"] = importance(7, 2, 11, XS, inp["line_ys"], 512, 32, 35)
+    for name, kind, ds, do, params, obs, scheme in (("sys", 1, 1, 1, O.LGSSM_PARAMS, O.lgssm_observations(5).reshape(5, 1), 1),
+                                                    ("strat", 1, 1, 1, O.LGSSM_PARAMS, O.lgssm_observations(5).reshape(5, 1), 2),
+                                                    ("spiral", 2, 2, 2, np.zeros(0), inp["spiral_obs"], 0),
+                                                    ("bearings", 4, 4, 1, np.array([1.0, 1.0, 1.0, 0.1, 0.05, 0.02]), inp["bearings_obs"], 0),
+                                                    ("band4", 5, 4, 4, np.array([4, 0.9, 0.05, 1.0, 0.5, 1.0]), inp["band_obs"], 0)):
+        pf = mk_pf(kind, ds, do, params, 3000, 36)
+        pf.init_step([0.0] * ds, obs[:1])
+        par = []
+        for t in range(1, len(obs)):
+            pf.resample(scheme)
+            par.append(np.asarray(pf.parents_now(), dtype=np.uint32).copy())
+            pf.step(obs[t:t + 1])
+        out[f"{name}_parents"] = np.array(par)
+        out[f"{name}_x"] = pf.states_now().copy()
+        out[f"{name}_lml"] = np.array([pf.log_marginal_likelihood_estimate()])
+    flat = {}
+    for k, v in out.items():
+        if isinstance(v, tuple):
+            flat[k + "_lml"], flat[k + "_lnw"], flat[k + "_idx"], flat[k + "_x"] = np.array([v[0]]), v[1], np.asarray(v[2], dtype=np.uint64), v[3]
+        else:
+            flat[k] = v
+    return flat
+
+
+class _OraclePfAdapter:
+    def __init__(self, kind, ds, do, params, n, seed):
+        self.pf = O.OraclePF(kind, ds, do, params, n, seed, CANON_SOA)
+
+    def init_step(self, args0, obs):
+        self.pf.init_step(obs, args0)
+
+    def step(self, obs):
+        self.pf.step(obs)
+
+    def resample(self, scheme):
+        return self.pf.resample(scheme)
+
+    def parents_now(self):
+        return self.pf.parents()
+
+    def states_now(self):
+        return self.pf.state()
+
+    def log_marginal_likelihood_estimate(self):
+        return self.pf.log_marginal_likelihood_estimate()
+
+
+class _OracleMhAdapter:
+    def __init__(self, ys, n, seed, constrain=None):
+        self.h = O.OracleMH(XS, ys, n, seed, -1 if constrain is None else int(constrain), canonical=True)
+
+    def mh(self, std, it):
+        return self.h.mh(std, it)
+
+    def mh_add_or_remove(self, it):
+        return self.h.mh_add_or_remove(it)
+
+    def regen_mh(self, sites, it, cycle):
+        return self.h.regen_mh(sites, it, cycle)
+
+    def states(self):
+        return self.h.state()
+
+
+class _OraclePointedAdapter:
+    def __init__(self, n, seed):
+        self.h = O.OraclePointedMH(BOUNDS, COV, [0.0, 0.0], n, seed, canonical=True)
+
+    def mh(self, noise, it):
+        return self.h.mh(noise, it)
+
+    def states(self):
+        return self.h.state()
+
+
+def oracle_paths(inp):
+    return paths_outputs(lambda ys, n, seed, constrain=None: _OracleMhAdapter(ys, n, seed, constrain), _OraclePointedAdapter,
+                         lambda kind, ds, do, params, obs, n, m, seed: O.importance_resampling(kind, ds, do, params, obs, n, m, seed, CANON_SOA, args0=[0.0] * ds),
+                         _OraclePfAdapter, inp)
+
+
+def main_paths():
+    inp = paths_inputs()
+    out = oracle_paths(inp)
+    np.savez_compressed(os.path.join(HERE, "paths_small.npz"), **{"in_" + k: v for k, v in inp.items()}, **out)
+    print("paths_small.npz:", sorted(out)[:6], "...", len(out), "arrays")
+
+
 if __name__ == "__main__":
     main()
+    main_paths()

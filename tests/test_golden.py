@@ -54,3 +54,87 @@ def test_hip_reproduces_golden():
     assert np.array_equal(pf.states()[:, 0], z["can_final_x"])
     assert np.array_equal(pf.log_weights, z["can_final_logw"])
     assert abs(pf.log_marginal_likelihood_estimate() - meta["lit_lml"]) <= 1e-12 * abs(meta["lit_lml"])
+
+
+# ---- second fixture: MH (three proposals + regen), pointed MH, importance on the reference's models, systematic /
+# stratified parents, spiral / bearings / banded filters (tests/golden/paths_small.npz) -----------------------------------
+def _paths():
+    z = np.load(os.path.join(G, "paths_small.npz"))
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    exp = {k: z[k] for k in z.files if not k.startswith("in_")}
+    return inp, exp
+
+
+def _compare(got, exp):
+    assert sorted(got) == sorted(exp)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+
+
+def test_oracle_reproduces_paths_golden():
+    from tests.golden import make_golden as M
+
+    inp, exp = _paths()
+    for k, v in M.paths_inputs().items():
+        assert np.array_equal(v, inp[k]), k
+    _compare(M.oracle_paths(inp), exp)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_paths_golden():
+    """The device against the committed vectors alone (no checker in the loop)."""
+    import modppl_amd
+    from modppl_amd import capi
+    from tests.golden import make_golden as M
+
+    inp, exp = _paths()
+    kinds = {1: lambda p: modppl_amd.lgssm_model(*p), 2: lambda p: modppl_amd.spiral_model(), 4: lambda p: modppl_amd.bearings_model(*p),
+             5: lambda p: modppl_amd.lgssm_band_model(int(p[0]), *p[1:]), 6: lambda p: modppl_amd.pointed_2d_model(list(p[:4]), list(p[4:])),
+             7: lambda p: modppl_amd.line_model(list(p))}
+
+    class Pf:
+        def __init__(self, kind, ds, do, params, n, seed):
+            self.pf = modppl_amd.ParticleSystem(kinds[kind](params), n, seed)
+
+        def init_step(self, args0, obs):
+            self.pf.init_step(args0, obs)
+
+        def step(self, obs):
+            self.pf.step(obs)
+
+        def resample(self, scheme):
+            return self.pf.resample(scheme=scheme)
+
+        def parents_now(self):
+            return self.pf.parents
+
+        def states_now(self):
+            return self.pf.states()
+
+        def log_marginal_likelihood_estimate(self):
+            return self.pf.log_marginal_likelihood_estimate()
+
+    class Mh:
+        def __init__(self, ys, n, seed, constrain=None):
+            self.h = modppl_amd.HierarchicalChains(M.XS, ys, n, seed, constrain_is_linear=constrain)
+
+        def mh(self, std, it):
+            return self.h.mh(std, it)
+
+        def mh_add_or_remove(self, it):
+            return self.h.mh_add_or_remove(it)
+
+        def regen_mh(self, sites, it, cycle):
+            return self.h.regen_mh(sites, it, cycle)
+
+        def states(self):
+            return self.h.states()
+
+    def importance(kind, ds, do, params, obs, n, m, seed):
+        states, idx, lml = modppl_amd.importance_resampling(kinds[kind](params), [0.0] * ds, obs, n, m, seed)
+        _, lnw, _ = modppl_amd.importance_sampling(kinds[kind](params), [0.0] * ds, obs, n, seed)
+        return lml, lnw, idx, states
+
+    got = M.paths_outputs(lambda ys, n, seed, constrain=None: Mh(ys, n, seed, constrain),
+                          lambda n, seed: modppl_amd.PointedChains(M.BOUNDS, M.COV, [0.0, 0.0], n, seed), importance, Pf, inp)
+    _compare(got, exp)
