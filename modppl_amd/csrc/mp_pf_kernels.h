@@ -64,6 +64,13 @@ __device__ __forceinline__ u64 mp_quantize(double e, double scale) {
     const double r = rint(e * scale);
     return (r >= 0.) ? (u64)r : 0ull;  // NaN -> 0
 }
+// rint(e * 2^51) as an integer for e in [0, 1] (level 0: e = exp(lw - max) <= 1), without rint / f64 -> u64 conversion
+// sequences: x + 2^52 rounds x to the nearest-even integer (ulp = 1 in [2^52, 2^53)) and leaves it in the mantissa.
+__device__ __forceinline__ u64 mp_quantize51(double e) {
+    const double x = e * mp_u2f((u64)(1023 + FIX_BITS) << 52);
+    const u64 q = mp_f2u(x + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
+    return (x >= 0.) ? q : 0ull;  // NaN -> 0
+}
 
 // One row of the resampling table: tile-local inclusive fixed-point CDF value and the first state
 // component of the same particle, so that the probe that finds a parent also fetches its state.
@@ -112,15 +119,14 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_red[w]);
     const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
 
-    const double scale = mp_u2f((u64)(1023 + FIX_BITS) << 52);  // 2^51
     u64 c[ITEMS_];
     u64 run = 0, run2 = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS_; ++j) {
         const bool live = ok && (base + j < n);
         const double a = live ? mp_exp(lw[j] - m) : 0.;
-        run += mp_quantize(a, scale);
-        run2 += mp_quantize(a * a, scale);
+        run += mp_quantize51(a);
+        run2 += mp_quantize51(a * a);
         c[j] = run;
     }
     const u64 incl = wave_incl_scan_u64(run, lane);

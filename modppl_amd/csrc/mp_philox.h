@@ -75,7 +75,8 @@ MP_PHD mp_u64x2 mp_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
 // 64 random bits -> the 52-bit grid in [0,1) that rand-0.8 `Uniform::new(0., 1.)` produces
 // (bits >> 12 placed in the mantissa of [1,2), minus 1): k * 2^-52, k in [0, 2^52).
 MP_PHD uint64_t mp_u52(uint64_t bits) { return bits >> 12; }
-MP_PHD double mp_u01(uint64_t bits) { return (double)(bits >> 12) * 2.220446049250313e-16; }
+// k * 2^-52 without an integer-to-double conversion: 1.mantissa in [1, 2) has spacing 2^-52, so (1 + k 2^-52) - 1 is exact.
+MP_PHD double mp_u01(uint64_t bits) { return __builtin_bit_cast(double, (bits >> 12) | 0x3FF0000000000000ull) - 1.0; }
 
 struct mp_stream {
     uint32_t k0, k1;  // seed
