@@ -134,11 +134,14 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     if (lane == 63) s_wsum[wave] = incl;
     if (lane == 0) s_wsum2[wave] = wtot2;
     __syncthreads();
+    // cross-wave offsets on the scalar unit: the per-wave totals and `wave` are wave-uniform, so the sums need no VALU issue
     u64 woff = 0, W = 0;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
     for (int k = 0; k < THREADS / 64; ++k) {
-        const u64 v = s_wsum[k];
-        if (k < wave) woff += v;
+        const u64 vv = s_wsum[k];
+        const u64 v = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) | (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)vv);
+        if (k < wave_s) woff += v;
         W += v;
     }
     const u64 off = woff + (incl - run);
