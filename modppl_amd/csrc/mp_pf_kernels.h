@@ -640,7 +640,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) {
             const u64 bal = __ballot(bin[q] == bb);
-            if (bin[q] == bb) rank_in_wave[q] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            // lanes of this bin below me: v_mbcnt on the (scalar) ballot
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (bin[q] == bb) rank_in_wave[q] = below;
             if (lane == 0) s_wcnt[(q * NW + wave) * 8 + bb] = (uint32_t)__popcll(bal);
         }
     }
