@@ -218,3 +218,56 @@ def test_lgssm_band16_c5_shard_size_properties():
     pf2 = modppl_amd.ParticleSystem(modppl_amd.lgssm_band_model(D, a, band, sig0, sig_x, sig_y), n, 5)
     pf2.run(None, obs)
     assert np.array_equal(pf2.parents, par) and pf2.log_marginal_likelihood_estimate() == lml and np.array_equal(pf2.states(), xs)
+
+
+def test_hmm_impossible_emissions_minus_inf_weights():
+    """Erasures of this domain: particles whose log-weight is -inf (an emission the particle's state cannot produce).
+    They must never be chosen as parents, the ESS counts only the live ones, and everything stays bit-exact."""
+    import modppl_amd
+
+    prior = [0.5, 0.5]
+    emis = [[1.0, 0.2], [0.0, 0.8]]          # emission[o][s]: state 0 never emits symbol 1
+    trans = [[0.9, 0.3], [0.1, 0.7]]
+    params = np.concatenate([[2, 2], prior, np.array(emis).reshape(-1), np.array(trans).reshape(-1)])
+    data = np.array([1.0, 0.0, 1.0, 1.0, 0.0])
+    n = 6000
+    pf = modppl_amd.ParticleSystem(modppl_amd.hmm_model(prior, emis, trans), n, 7)
+    ref = O.OraclePF(3, 1, 1, params, n, 7, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    pf.init_step(None, data[:1])
+    ref.init_step(data[:1])
+    for t in range(1, len(data)):
+        w, x = pf.log_weights, pf.states()[:, 0]
+        dead = np.isneginf(w)
+        if data[t - 1] == 1.0:
+            assert dead.any() and np.array_equal(dead, x == 0.0)      # exactly the particles in state 0
+        assert pf.effective_sample_size(fresh=True) == ref.effective_sample_size(1)
+        assert pf.effective_sample_size(fresh=True) <= (~dead).sum() + 1e-9
+        assert pf.resample() == ref.resample()
+        par = pf.parents
+        assert np.array_equal(par, ref.parents())
+        assert not dead[par].any()                                     # a dead particle has no offspring
+        pf.step(data[t:t + 1])
+        ref.step(data[t:t + 1])
+    assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+
+
+def test_maximum_job_size_and_beyond():
+    """2^24 particles (the tile table's limit) run; one more tile is refused with a status, not a fault."""
+    import modppl_amd
+    from modppl_amd import ModpplError, capi
+
+    n = 1 << 24
+    ys = O.lgssm_observations(3)
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, 5)
+    pf.init_step(None, ys[:1])
+    L0 = pf.resample()
+    pf.step(ys[1:2])
+    assert pf.effective_sample_size(fresh=True) > 0.3 * n
+    pf.resample()
+    par = pf.parents
+    assert par.shape == (n,) and int(par.max()) < n
+    assert np.isfinite(L0) and abs(pf.log_marginal_likelihood_estimate() - O.kalman_log_ml(ys[:2])) < 0.01
+    del pf
+    with pytest.raises(ModpplError) as e:
+        modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n + 1, 5)
+    assert e.value.code == capi.MP_ERR_UNSUPPORTED
