@@ -50,7 +50,7 @@ __device__ __forceinline__ double mh_mean(bool is_lin, double a, double b, doubl
 #define MH_NOISE 0.1
 // mp_log(0.1), hoisted: computed on the host with the same mp_log and passed in
 
-__global__ __launch_bounds__(MH_THREADS) void k_mh_init(u64 n, uint32_t k0, uint32_t k1, int constrain, mh_data data, double ln_noise,
+__global__ __launch_bounds__(MH_THREADS) void k_mh_init(u64 n, uint32_t k0, uint32_t k1, int constrain,
                                                         int* __restrict__ is_lin_out, double* __restrict__ a_out, double* __restrict__ b_out,
                                                         double* __restrict__ c_out) {
     const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
@@ -368,7 +368,7 @@ int32_t mp_mh_create(int32_t model_kind, const double* xs, const double* ys, int
     MHCK(hipMalloc(&h->tmp, sizeof(double) * n_chains * 4));
     MHCK(hipMalloc(&h->d_acc, sizeof(u64)));
     hipLaunchKernelGGL(k_mh_init, dim3((unsigned)((n_chains + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), constrain_is_linear, h->data, h->ln_noise, h->is_lin, h->a, h->b, h->c);
+                       (uint32_t)seed, (uint32_t)(seed >> 32), constrain_is_linear, h->is_lin, h->a, h->b, h->c);
     MHCK(hipGetLastError());
     MHCK(hipStreamSynchronize(h->stream));
     *out = h.release();

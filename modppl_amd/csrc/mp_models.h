@@ -4,8 +4,8 @@
 // are four interpretations of it (modppl/src/modeling/dyngenfn.rs:39-93; macro rewrite
 // `dist(args) %= addr` -> `g.sample_at(&dist, args, addr)`: modppl-macros/src/lib.rs:20-113).
 // A closure over `Arc<dyn Any>` tries cannot run on a GPU, so here a model is ONE functor
-// templated on the handler type; addresses become compile-time site ids, choices become SoA
-// columns, and the handler policies (mp_handlers below, MH policies in mp_mh.h) restate the
+// templated on the handler type; addresses become compile-time site ids, choices become dense per-particle
+// rows, and the handler policies (mp_generate_handler below, the MH policies in mp_mh.hip) restate the
 // weight rules of sample_at.  A kernel is
 //
 //     template <class H> void operator()(H& g, int64_t t, const double* prev, double* next) const

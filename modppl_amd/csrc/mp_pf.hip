@@ -84,7 +84,6 @@ struct PropagateArgs {
     hipStream_t stream;
     const unsigned short* perm;
     const double* res_x;
-    u64 res_stride;
     int nchunks;
     mp_cx* cx;
     unsigned short* guide;
@@ -112,7 +111,7 @@ struct ModelOpsT : ModelOps {
         // light kernels (few registers) run 1024 threads x 2 particles per tile: twice the waves in flight for the same 2048-slot tile
         constexpr int THREADS = (Model::MAX_NORMALS <= 2 && Model::DIM_STATE <= 2) ? 1024 : TILE_THREADS;
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.res_stride, a.nchunks, a.cx, a.guide,
+                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
                            a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent);
     }
 };
@@ -284,7 +283,7 @@ struct mp_pf {
     mp_dev_scalars* scal_undo = nullptr;  // the scalars before a fixed-capacity route folded this resample in
     bool sharded = false;
     // ancestry record (MP_PF_RECORD_HISTORY): the event log from which `traces[i].retv` is rebuilt
-    struct HistEvent { int kind; void* buf; };  // kind 0: states after an Unfold step ([d][n] f64); 1: parents of a resample ([n] u32)
+    struct HistEvent { int kind; void* buf; };  // kind 0: states after an Unfold step ([n][d] f64); 1: parents of a resample ([n] u32)
     std::vector<HistEvent> hist;
     // host-side filter state
     long long t = 0;  // Unfold steps taken (trace.args.0)
@@ -371,7 +370,7 @@ static int32_t materialize(mp_pf* h) {
     }
     if (!h->permuted) return MP_OK;
     hipLaunchKernelGGL(k_unpermute, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->ops->dim_state, h->nchunks, h->perm,
-                       h->res_x, h->res_stride, h->res_parent, h->x[h->cur], h->ops->dim_state == 1 ? h->x[h->cur] : h->x[h->cur ^ 1], h->parent,
+                       h->res_x, h->res_parent, h->x[h->cur], h->ops->dim_state == 1 ? h->x[h->cur] : h->x[h->cur ^ 1], h->parent,
                        h->logw);
     if (h->ops->dim_state > 1) h->cur ^= 1;   // wider states were gathered from the pre-resample buffer into the other one
     h->permuted = false;
@@ -395,7 +394,6 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.perm = h->permuted ? h->perm : nullptr;
     a.res_x = h->sh_lazy ? h->sh_rows : h->res_x;
     a.inv = h->sh_lazy ? h->sh_req_slot : nullptr;
-    a.res_stride = h->res_stride;
     a.nchunks = h->nchunks;
     a.cx = h->cx; a.guide = h->guide; a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
     a.grid = h->nt;
@@ -585,8 +583,8 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
             const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
-            hipLaunchKernelGGL(k_resolve_bins, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, d, h->nchunks, h->seg_lt, h->seg_row,
-                               h->seg_cnt, h->cx, h->x[h->cur], h->res_x, h->res_stride, h->res_parent);
+            hipLaunchKernelGGL(k_resolve_bins, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, h->nchunks, h->seg_lt, h->seg_row,
+                               h->seg_cnt, h->cx, h->res_x, h->res_parent);
             binned = true;
         } else if (scheme == MP_RESAMPLE_STRATIFIED) {
             hipLaunchKernelGGL(k_resample_gather<2>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagat
                                                             long long t, const double* x_in, double* x_out, double* logw,
                                                             mp_obs obs, mp_state0 s0, int overwrite,
                                                             const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
-                                                            u64 res_stride, int nchunks, mp_cx* __restrict__ cx,
+                                                            int nchunks, mp_cx* __restrict__ cx,
                                                             unsigned short* __restrict__ guide, double* __restrict__ tile_m,
                                                             u64* __restrict__ tile_W, u64* __restrict__ tile_W2,
                                                             const uint32_t* __restrict__ inv, const uint32_t* __restrict__ res_parent) {
@@ -682,10 +682,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
 // segment holds 128 +- 11 entries, so nearly every lane is live and each has 4 independent chains in flight.
 // Results stay in SEGMENT order (res_x[d][bin][chunk][pos], res_parent likewise: coalesced stores); the next
 // k_propagate reads its inputs through perm[], k_unpermute materialises slot order when the host asks.
-__global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int nchunks, const u64* __restrict__ seg_lt,
+__global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int nchunks, const u64* __restrict__ seg_lt,
                                                              const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_cnt,
-                                                             const mp_cx* __restrict__ cx,
-                                                             const double* __restrict__ x_old, double* __restrict__ res_x, u64 res_stride,
+                                                             const mp_cx* __restrict__ cx, double* __restrict__ res_x,
                                                              uint32_t* __restrict__ res_parent) {
     const int bin = blockIdx.x & 7;
     const int group = blockIdx.x >> 3;
@@ -754,7 +753,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int D, int n
 }
 
 // slot order from segment order: traces[i] = traces[parents[i]].clone(); log_weights.fill(0.) (particle_filter.rs:109-114)
-__global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __restrict__ perm, const double* __restrict__ res_x, u64 res_stride,
+__global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
                             const uint32_t* __restrict__ res_parent, const double* __restrict__ x_old, double* __restrict__ x_new,
                             uint32_t* __restrict__ parent, double* __restrict__ logw) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_globa
         atomicAdd(&s_cnt[s], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < world) blockcount[(u64)blockIdx.x * world + threadIdx.x] = s_cnt[threadIdx.x];
+    if ((int)threadIdx.x < world) blockcount[(u64)blockIdx.x * world + threadIdx.x] = s_cnt[threadIdx.x];
 }
 // pass 2 (one workgroup per owner): per-owner totals and exclusive per-workgroup offsets
 __global__ __launch_bounds__(SH_THREADS) void k_shard_offsets(const uint32_t* __restrict__ blockcount, int nblk, int world,

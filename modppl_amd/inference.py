@@ -156,7 +156,7 @@ def importance_sampling(model, model_args, constraints, num_samples, seed, *, de
     """`importance_sampling(model, model_args, constraints, num_samples)` — modppl/src/inference/importance.rs:12-28.
 
     Returns (traces, log_normalized_weights, log_ml_estimate); `traces` is the array of final states
-    (`traces[i].retv.last()`), since choices live in SoA columns on the device."""
+    (`traces[i].retv.last()`), since choices live in dense per-particle rows on the device."""
     states, lnw, lml, _ = _importance(model, model_args, constraints, num_samples, 0, seed, device)
     return states, lnw, lml
 
