@@ -310,12 +310,15 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
             r0[k] = cx[p[k]];
             r1[k] = cx[p[k] + (p[k] < last[k] ? 1 : 0)];
         }
+        // lanes of a row group when states are wider than one double: G lanes copy one parent's row together, so that a
+        // row is one coalesced request instead of D scattered 8-byte ones
+        const int G = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : 16));
+        const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < K3_ITEMS; ++k) {
-            if (!live[k]) continue;
             mp_cx cur = r0[k];
             u64 pp = p[k];
-            if (cur.cum < lt[k] && pp < last[k]) {
+            if (live[k] && cur.cum < lt[k] && pp < last[k]) {
                 cur = r1[k];
                 ++pp;
                 while (cur.cum < lt[k] && pp < last[k]) {
@@ -324,13 +327,23 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
                 }
             }
             const u64 q = q0 + (u64)k * K3_THREADS + threadIdx.x;
-            double* out = out_sub + q * (u64)(D + 1);
             if (D == 1) {
-                *reinterpret_cast<double2*>(out) = make_double2(cur.x0, (double)(slot_offset + pp));
+                if (live[k]) *reinterpret_cast<double2*>(out_sub + q * 2) = make_double2(cur.x0, (double)(slot_offset + pp));
             } else {
-                out[0] = cur.x0;
-                for (int d = 1; d < D; ++d) out[d] = x[pp * D + d];
-                out[D] = (double)(slot_offset + pp);
+                if (live[k]) out_sub[q * (u64)(D + 1) + D] = (double)(slot_offset + pp);
+                // the wave's 64 requests of this round, 64 / G at a time (wave-uniform trip count; D <= 16)
+                const uint32_t pp_lo = (uint32_t)pp, pp_hi = (uint32_t)(pp >> 32);
+                const uint32_t ql = (uint32_t)(q - q0);   // < K3_THREADS * K3_ITEMS
+                const int comp = lane % G;
+                for (int base = 0; base < 64; base += 64 / G) {
+                    const int src = base + lane / G;
+                    const int lv = __shfl((int)live[k], src, 64);
+                    const u64 spp = ((u64)(uint32_t)__shfl((int)pp_hi, src, 64) << 32) | (u64)(uint32_t)__shfl((int)pp_lo, src, 64);
+                    const u64 sq = q0 + (u64)(uint32_t)__shfl((int)ql, src, 64);
+                    if (lv) {
+                        for (int d = comp; d < D; d += G) out_sub[sq * (u64)(D + 1) + d] = x[spp * D + d];
+                    }
+                }
             }
         }
     }

@@ -15,11 +15,29 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def pf_case(name, model, n, obs, steps, warmup, bytes_per_particle):
+def pf_case(name, model, n, obs, steps, warmup, bytes_per_particle, sharded=False):
     import modppl_amd
     from modppl_amd import capi
 
-    pf = modppl_amd.ParticleSystem(model, n, 20241008)
+    if sharded:   # the sharded code path in a world of one (no collectives): what the exchange machinery costs locally
+        from modppl_amd.distributed import ShardedParticleSystem
+
+        sp = ShardedParticleSystem(model, n, 20241008)
+
+        class _Wrap:
+            def __getattr__(self, k):
+                return getattr(sp, k)
+
+            def set_timing(self, on):
+                sp.engine.set_timing(on)
+
+            def get_timing(self, fam):
+                return sp.engine.get_timing(fam)
+
+        pf = _Wrap()
+        name += " [sharded path, world of one]"
+    else:
+        pf = modppl_amd.ParticleSystem(model, n, 20241008)
     pf.init_step(None, obs[:1])
     pf.resample(sync=False)
     for t in range(1, 1 + warmup):
@@ -51,6 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--which", default="c2,c3,c5,c4")
+    ap.add_argument("--sharded", action="store_true", help="run the filters through ShardedParticleSystem (world of one)")
     args = ap.parse_args()
     import modppl_amd
     from tests import oracle_lib as O
@@ -61,13 +80,13 @@ def main():
     which = args.which.split(",")
     if "c2" in which:
         out.append(pf_case("C2 LGSSM d=1", modppl_amd.lgssm_model(*O.LGSSM_PARAMS), 1 << 20, O.lgssm_observations(T).reshape(T, 1),
-                           args.steps, args.warmup, 96))
+                           args.steps, args.warmup, 96, args.sharded))
     if "c3" in which:
         th = np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + rng.normal(0, 0.02, T)
-        out.append(pf_case("C3 bearings d=4", modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), args.steps, args.warmup, 192))
+        out.append(pf_case("C3 bearings d=4", modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), args.steps, args.warmup, 192, args.sharded))
     if "c5" in which:
         out.append(pf_case("C5 LGSSM band d=16 (one GPU's shard of 2^24 / 8)", modppl_amd.lgssm_band_model(16), 1 << 21,
-                           rng.normal(0, 1.2, size=(T, 16)), args.steps, args.warmup, 576))
+                           rng.normal(0, 1.2, size=(T, 16)), args.steps, args.warmup, 576, args.sharded))
     if "c4" in which:
         xs = np.arange(-5, 6, dtype=np.float64)
         ys = 0.3 + 0.4 * xs + 0.5 * xs * xs + rng.normal(0, 0.1, xs.size)
