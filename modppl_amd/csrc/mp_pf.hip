@@ -271,6 +271,7 @@ struct mp_pf {
     double* sh_tm_all = nullptr;    // unpacked gathered tiles
     u64* sh_tW_all = nullptr;
     u64* sh_tW2_all = nullptr;
+    u64* sh_incl_all = nullptr;     // the job's tile table (inclusive prefix of T_b), built once per resample by k_shard_table
     int* sh_overflow = nullptr;
     u64* tiles_own = nullptr;       // the allocation behind tile_m / tile_W / tile_W2 unless the caller bound its own buffer
     mp_shard_pub* h_pub = nullptr;  // pinned, host-mapped
@@ -513,13 +514,14 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     // tile tables above 64 KiB of LDS need the limit raised once per kernel
     {
         const int nt_job = (int)((h->n_global + TILE - 1) / TILE);
-        const size_t need = table_lds(nt_job, K3_THREADS) + 1024;
+        const size_t need = table_lds(nt_job, K3_THREADS) + 8192;   // + the per-key counters of the sharded route
         if (need > 48 * 1024) {
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_table), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
         }
     }
     // ParticleSystem::new: log_weights = 0, parents = 0, log_ml_estimate = 0 (particle_filter.rs:44-57)
@@ -815,7 +817,7 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
     if (h->sh_dest && h->sh_world >= world && h->sh_cap >= cap && h->sh_tm_all) return MP_OK;
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
-    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all);
+    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all);
     (void)hipFree(h->sh_overflow);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     const u64 slots = std::max<u64>(h->n, (u64)world * SH_BINS * cap);
@@ -829,6 +831,7 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     HIPCK(hipMalloc(&h->sh_tm_all, sizeof(double) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_tW_all, sizeof(u64) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_tW2_all, sizeof(u64) * (size_t)h->nt * world));
+    HIPCK(hipMalloc(&h->sh_incl_all, sizeof(u64) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_overflow, sizeof(int)));
     if (!h->scal_undo) HIPCK(hipMalloc(&h->scal_undo, sizeof(mp_dev_scalars)));
     HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
@@ -879,17 +882,14 @@ int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     const int nt_all = h->nt * world;
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        const int cover = std::max(nt_all, SH_MAX_KEYS);
-        hipLaunchKernelGGL(k_unpack_tiles, dim3((cover + K3_THREADS - 1) / K3_THREADS), dim3(K3_THREADS), 0, h->stream, (const u64*)d_tiles_all, world,
-                           h->nt, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_counts);
-        const size_t lds = table_lds(nt_all, SH_THREADS) + (sizeof(uint32_t) + sizeof(u64)) * SH_MAX_KEYS;
+        hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), table_lds(nt_all, SHT_THREADS), h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
+                           h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_counts, h->scal, h->scal_undo);
         const int nblk_f = (int)((h->n + SH_THREADS * SHF_ITEMS - 1) / (SH_THREADS * SHF_ITEMS));
-        hipLaunchKernelGGL(k_shard_route_fused, dim3(nblk_f), dim3(SH_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, h->S, h->sh_tm_all, h->sh_tW_all,
+        hipLaunchKernelGGL(k_shard_route_fused, dim3(nblk_f), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
+                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all,
                            nt_all, h->nt, world, (u64)capacity, (unsigned long long*)h->sh_counts, (u64*)d_req_out, h->sh_req_slot);
-        hipLaunchKernelGGL(k_shard_finalize, dim3(1), dim3(K3_THREADS), table_lds(nt_all, K3_THREADS), h->stream, h->sh_tm_all, h->sh_tW_all,
-                           h->sh_tW2_all, nt_all, h->S, h->n_global, h->scal, h->scal_undo, (const unsigned long long*)h->sh_counts, world,
-                           (u64)capacity, (u64*)d_req_out, h->sh_overflow);
+        hipLaunchKernelGGL(k_shard_headers, dim3(1), dim3(K3_THREADS), 0, h->stream, (const unsigned long long*)h->sh_counts, world, (u64)capacity,
+                           (u64*)d_req_out, h->sh_overflow);
     }
     return check_launch("shard_route_fixed kernels");
 }
@@ -1054,7 +1054,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->aos);
     (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
-    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all);
+    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all);
     (void)hipFree(h->sh_overflow); (void)hipFree(h->scal_undo);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     if (h->h_pub) (void)hipHostFree(h->h_pub);

@@ -179,20 +179,20 @@ constexpr int SHF_ITEMS = 4;
 constexpr int SH_BINS = 8;
 constexpr int SH_MAX_KEYS = SH_MAX_WORLD * SH_BINS;
 __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
-                                                                  int systematic, int S, const double* __restrict__ tm_all,
+                                                                  int systematic, const u64* __restrict__ incl_all,
                                                                   const u64* __restrict__ tW_all, int nt_all, int nt_local, int world, u64 capb,
                                                                   unsigned long long* __restrict__ counts, u64* __restrict__ req_out,
                                                                   uint32_t* __restrict__ inv) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* s_incl = reinterpret_cast<u64*>(smem);
-    u64* s_W = s_incl + nt_all;
-    double* s_red = reinterpret_cast<double*>(s_W + nt_all);
-    u64* s_wtot = reinterpret_cast<u64*>(s_red + SH_THREADS / 64);
-    u64* s_base = s_wtot + SH_THREADS / 64;                                   // [keys] start inside the sub-segment
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_base + SH_MAX_KEYS);      // [keys] draws of this workgroup per sub-segment
+    __shared__ u64 s_base[SH_MAX_KEYS];        // [keys] start inside the sub-segment
+    __shared__ uint32_t s_cnt[SH_MAX_KEYS];    // [keys] draws of this workgroup per sub-segment
     const int keys = world * SH_BINS;
     for (int k = threadIdx.x; k < keys; k += SH_THREADS) s_cnt[k] = 0;
-    block_tile_table<SH_THREADS>(tm_all, tW_all, nt_all, S, s_incl, s_W, s_red, s_wtot);   // ends with a barrier
+    // The job's tile table was built once by k_shard_table and is probed where it lies (L2-resident: 16 B per tile of the
+    // whole job).  It covers world x nt_local tiles: rebuilding it, or even copying it into LDS, in every workgroup costs
+    // more than the draws themselves from 4 ranks up, and the LDS footprint would halve the occupancy.
+    const u64* s_incl = incl_all;
+    const u64* s_W = tW_all;
+    __syncthreads();
     const u64 Q = s_incl[nt_all - 1];
     const double nt_over_Q = (double)nt_all / (double)Q;
     const u64 i0 = (u64)blockIdx.x * (SH_THREADS * SHF_ITEMS) + threadIdx.x;
@@ -236,17 +236,42 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
         }
     }
 }
-// Level 1 of a sharded resample + the sub-segment headers {count, "some sub-segment of mine overflowed"}, once every
-// workgroup of the route has reserved its places.  One workgroup.
-__global__ __launch_bounds__(K3_THREADS) void k_shard_finalize(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
-                                                               const u64* __restrict__ tile_W2, int nt, int S, u64 n_global, mp_dev_scalars* scal,
-                                                               mp_dev_scalars* undo, const unsigned long long* __restrict__ counts, int world,
-                                                               u64 capb, u64* __restrict__ req_out, int* overflow) {
+// Before the route, one workgroup: unpack the gathered tiles, build the job's tile table ONCE (inclusive prefix of T_b to
+// global memory), zero the request counters, and fold this normalisation into the filter scalars (L, ESS, log-ML),
+// keeping a copy for the case that the fixed-capacity exchange overflows.
+constexpr int SHT_THREADS = 1024;
+__global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
+                                                             double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
+                                                             u64* __restrict__ incl_all, long long* __restrict__ zero_counts,
+                                                             mp_dev_scalars* scal, mp_dev_scalars* undo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nt = world * nt_local;
     u64* s_incl = reinterpret_cast<u64*>(smem);
     u64* s_W = s_incl + nt;
     double* s_red = reinterpret_cast<double*>(s_W + nt);
-    u64* s_wtot = reinterpret_cast<u64*>(s_red + K3_THREADS / 64);
+    u64* s_wtot = reinterpret_cast<u64*>(s_red + SHT_THREADS / 64);
+    if (threadIdx.x < SH_MAX_KEYS) zero_counts[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < nt; i += SHT_THREADS) {
+        const int r = i / nt_local, b = i % nt_local;
+        const u64* base = packed + (u64)r * 3 * nt_local;
+        tm[i] = mp_u2f(base[b]);
+        tW[i] = base[nt_local + b];
+        tW2[i] = base[2 * nt_local + b];
+    }
+    __threadfence_block();
+    __syncthreads();
+    const double m = block_tile_table<SHT_THREADS>(tm, tW, nt, S, s_incl, s_W, s_red, s_wtot);
+    for (int i = threadIdx.x; i < nt; i += SHT_THREADS) incl_all[i] = s_incl[i];
+    const u64 Q = s_incl[nt - 1];
+    const u64 Q2 = block_sum_T2<SHT_THREADS>(tm, tW2, nt, S, m, s_wtot);
+    if (threadIdx.x == 0) {
+        *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
+        fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+    }
+}
+// After the route: the sub-segment headers {count, "some sub-segment of mine overflowed"}.  One workgroup.
+__global__ __launch_bounds__(K3_THREADS) void k_shard_headers(const unsigned long long* __restrict__ counts, int world, u64 capb,
+                                                              u64* __restrict__ req_out, int* overflow) {
     const int keys = world * SH_BINS;
     int mine = 0;
     for (int k = threadIdx.x; k < keys; k += K3_THREADS) mine |= (counts[k] > capb) ? 1 : 0;
@@ -258,13 +283,6 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_finalize(const double* __r
         sub[1] = (u64)any;
     }
     if (threadIdx.x == 0 && any) *overflow = 1;
-    const double m = block_tile_table<K3_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
-    const u64 Q = s_incl[nt - 1];
-    const u64 Q2 = block_sum_T2<K3_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
-    if (threadIdx.x == 0) {
-        *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
-        fold_scalars(scal, Q, Q2, S, m, n_global, 0);
-    }
 }
 // owner side: blockIdx.x & 7 = eighth of this shard's tiles (workgroups are dealt round-robin to the 8 XCDs, gridDim.x is
 // a multiple of 8), blockIdx.y = asking rank.  Per request: guide cell -> first row -> short forward walk, all inside

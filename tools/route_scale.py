@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""What the sharded route costs on ONE rank as the world grows (the tile table every workgroup builds covers the whole job):
+a filter created as rank 0 of `world`, fed a gathered-tiles buffer made of `world` copies of its own tiles."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    import modppl_amd
+    from modppl_amd import capi
+    from modppl_amd.distributed import HipShardEngine
+    from tests import oracle_lib as O
+
+    n = 1 << 20
+    ys = O.lgssm_observations(3).reshape(3, 1)
+    for world in (1, 2, 4, 8):
+        eng = HipShardEngine(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, n * world, 0, 7)
+        nt = n // 2048
+        dev = eng.device
+        tiles = torch.zeros(3 * nt, dtype=torch.int64, device=dev)
+        eng.shard_bind_tiles(C.c_void_p(tiles.data_ptr()))
+        eng.init_step(None, ys[:1])
+        eng.shard_tiles_packed(C.c_void_p(tiles.data_ptr()))
+        eng.synchronize()
+        tiles_all = tiles.repeat(world).contiguous()
+        cap = int(n // (8 * world) * 1.25) + 512
+        req = torch.zeros(world * 8 * (cap + 1) * 2, dtype=torch.int64, device=dev)
+        rows = torch.zeros(world * 8 * cap * 2, dtype=torch.float64, device=dev)
+        eng.set_timing(True)
+        for _ in range(12):
+            eng.shard_route_fixed(0, C.c_void_p(tiles_all.data_ptr()), world, 0, cap, C.c_void_p(req.data_ptr()))
+            eng.shard_resolve_fixed(C.c_void_p(req.data_ptr()), world, cap, C.c_void_p(rows.data_ptr()))
+        eng.synchronize()
+        r = eng.get_timing(capi.MP_K_BIN_DRAWS)
+        g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
+        print(f"world {world}: route (unpack + route + finalize) {r[0] / r[1] * 1e3:.1f} us, resolve + publish {g[0] / g[1] * 1e3:.1f} us", flush=True)
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()
