@@ -66,6 +66,7 @@ static int ceil_log2_u64(u64 n) {
     while ((1ull << b) < n) ++b;
     return b;
 }
+constexpr int PREBUILT_TABLE_MIN_TILES = 2048;   // from 2^22 particles up (measured: a loss at 1024 tiles, a gain at 2048) the tile table is built once per resample, not per workgroup
 static size_t table_lds(int nt, int threads) {  // s_incl[nt] + s_W[nt] + s_red + s_wtot
     return sizeof(u64) * 2 * (size_t)nt + (sizeof(double) + sizeof(u64)) * (size_t)(threads / 64);
 }
@@ -435,6 +436,8 @@ static int32_t ensure_rows(mp_pf* h) {
     return check_launch("k_normalize_tiles");
 }
 
+static int32_t shard_scratch(mp_pf* h, int world, u64 cap);
+
 extern "C" {
 
 const char* mp_last_error(void) { return g_err.c_str(); }
@@ -518,7 +521,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (need > 48 * 1024) {
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_table), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
@@ -576,10 +579,22 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     bool binned = false;
     if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        const size_t lds_a = table_lds(h->nt, BIN_THREADS) + sizeof(uint32_t) * 2 * BIN_ITEMS * (BIN_THREADS / 64) * 8;
-        hipLaunchKernelGGL(k_bin_draws, dim3(h->nchunks), dim3(BIN_THREADS), lds_a, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->guide,
-                           h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal);
+        const size_t lds_bins = sizeof(uint32_t) * 2 * BIN_ITEMS * (BIN_THREADS / 64) * 8;
+        if (!h->sharded && h->nt >= PREBUILT_TABLE_MIN_TILES) {
+            // big unsharded filters: the tile table once (k_shard_table over this filter's own packed tiles, a world of one)
+            rc = shard_scratch(h, 1, h->sh_cap ? h->sh_cap : 1);
+            if (rc != MP_OK) return rc;
+            hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), table_lds(h->nt, SHT_THREADS), h->stream, (const u64*)h->tile_m, 1, h->nt, h->S,
+                               h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_counts, h->scal, h->scal_undo);
+            hipLaunchKernelGGL(k_bin_draws<true>, dim3(h->nchunks), dim3(BIN_THREADS), 2 * (sizeof(double) + sizeof(u64)) * (BIN_THREADS / 64) + lds_bins, h->stream,
+                               h->n, h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks,
+                               h->tile_m, h->tile_W, h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal,
+                               (const u64*)h->sh_incl_all);
+        } else {
+            hipLaunchKernelGGL(k_bin_draws<false>, dim3(h->nchunks), dim3(BIN_THREADS), table_lds(h->nt, BIN_THREADS) + lds_bins, h->stream, h->n,
+                               h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m,
+                               h->tile_W, h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)nullptr);
+        }
     }
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
@@ -708,7 +723,6 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
 }
 
 // ---- sharded phases ------------------------------------------------------------------------------
-static int32_t shard_scratch(mp_pf* h, int world, u64 cap);
 
 int32_t mp_pf_shard_tiles(mp_pf* h, double* d_tile_m, uint64_t* d_tile_W, uint64_t* d_tile_W2) {
     if (!h || !d_tile_m || !d_tile_W || !d_tile_W2) return mp_fail(MP_ERR_INVALID_ARG, "null argument");

@@ -600,29 +600,38 @@ __global__ __launch_bounds__(K3_THREADS) void k_resample_gather(u64 n, u64 n_out
 //                       round-robin over the 8 XCDs, so the row lookups of bin b run on one XCD whose L2 then holds
 //                       that eighth of the table (speed only: any placement gives the same result).
 // Measured (profiles/r01): L2 hit rate 0.58 -> 0.86, fabric traffic 107 -> 52 MB per resample of 2^20, 46 -> 30 us.
+// PREBUILT: the tile table (inclusive prefix of T_b) was built once by k_shard_table and is probed in L2 (`incl_pre`); the
+// scalars are already folded.  Used from 1024 tiles up, where rebuilding the table in every workgroup costs as much
+// as the draws.
+template <bool PREBUILT>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S, int nchunks,
                                                            const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
                                                            const u64* __restrict__ tile_W2, int nt,
                                                            const unsigned short* __restrict__ guide,
                                                            u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row,
                                                            unsigned short* __restrict__ perm, unsigned short* __restrict__ seg_cnt,
-                                                           mp_dev_scalars* scal) {
+                                                           mp_dev_scalars* scal, const u64* __restrict__ incl_pre) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = BIN_THREADS / 64;
-    u64* s_incl = reinterpret_cast<u64*>(smem);                        // [nt]
-    u64* s_W = s_incl + nt;                                            // [nt]
-    double* s_red = reinterpret_cast<double*>(s_W + nt);               // [NW]
+    const int nt_lds = PREBUILT ? 0 : nt;
+    u64* s_incl_lds = reinterpret_cast<u64*>(smem);                    // [nt]
+    u64* s_W_lds = s_incl_lds + nt_lds;                                // [nt]
+    double* s_red = reinterpret_cast<double*>(s_W_lds + nt_lds);       // [NW]
     u64* s_wtot = reinterpret_cast<u64*>(s_red + NW);                  // [NW]
     uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + NW);       // [BIN_ITEMS][NW][8] counts
     uint32_t* s_woff = s_wcnt + BIN_ITEMS * NW * 8;                    // same shape: exclusive offsets
-    const double m = block_tile_table<BIN_THREADS>(tile_m, tile_W, nt, S, s_incl, s_W, s_red, s_wtot);
-    const u64 Q = s_incl[nt - 1];
+    const u64* s_incl = PREBUILT ? incl_pre : s_incl_lds;
+    const u64* s_W = PREBUILT ? tile_W : s_W_lds;
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0) {  // fold this normalisation into the filter scalars
-        const u64 Q2 = block_sum_T2<BIN_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
-        if (threadIdx.x == 0) fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+    if constexpr (!PREBUILT) {
+        const double m = block_tile_table<BIN_THREADS>(tile_m, tile_W, nt, S, s_incl_lds, s_W_lds, s_red, s_wtot);
+        if (blockIdx.x == 0) {  // fold this normalisation into the filter scalars
+            const u64 Q2 = block_sum_T2<BIN_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+            if (threadIdx.x == 0) fold_scalars(scal, s_incl_lds[nt - 1], Q2, S, m, n_global, 0);
+        }
     }
+    const u64 Q = s_incl[nt - 1];
 
     u64 lt[BIN_ITEMS];
     uint32_t gslot[BIN_ITEMS], tile_of[BIN_ITEMS];

@@ -99,10 +99,12 @@ def test_full_size_run_and_properties():
     assert pf2.log_marginal_likelihood_estimate() == lml
 
 
-def test_full_size_bit_exact_three_steps():
-    """N=2^20 against the canonical SoA checker for a few steps (a full T=50 takes the CPU ~10 s)."""
+@pytest.mark.parametrize("n", [1 << 20, (1 << 22) + 4097])
+def test_full_size_bit_exact_three_steps(n):
+    """N=2^20 against the canonical SoA checker for a few steps (a full T=50 takes the CPU ~10 s); from 2^22 the
+    resample takes its tile table from the once-per-resample table kernel instead of building it in every workgroup."""
     ys = O.lgssm_observations(4)
-    n, seed = 1 << 20, 99
+    seed = 99
     pf = _mk(n, seed)
     ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, threads=8)
     pf.init_step(None, ys[:1])
