@@ -164,7 +164,7 @@ int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total
 int32_t mp_pf_shard_query(mp_pf* h, const double* d_tile_m_all, const uint64_t* d_tile_W_all, const uint64_t* d_tile_W2_all, int32_t world,
                           double* log_ml, double* ess);
 
-/* Fixed-capacity form of the same phases: nothing synchronises with the host until the scatter and the all-to-alls
+/* Fixed-capacity form of the same phases: nothing synchronises with the host until the commit and the all-to-alls
  * have equal splits.  Tiles travel packed, [3][tiles] 8-byte words per rank (bits of the f64 maxima, W, W2), gathered
  * rank-major.  Draws are grouped by (owner rank, eighth of the owner's tiles) so the owner resolves each group on one XCD:
  *   d_req [world][8][capacity + 1][2] u64   entry 0 of a sub-segment = {count, overflow flag}, then {tile, local target}
@@ -193,7 +193,7 @@ enum mp_kernel_family {
     MP_K_PROPAGATE = 0,       /* k_propagate: model kernel + level 0 of the normalisation            */
     MP_K_NORMALIZE_SCAN = 1,  /* k_normalize_tiles: level 0 alone (weights changed without a propagate) */
     MP_K_RESAMPLE_GATHER = 2, /* k_resolve_bins, or the single-kernel k_resample_gather / shard kernels */
-    MP_K_BIN_DRAWS = 3,       /* k_bin_draws                                                          */
+    MP_K_BIN_DRAWS = 3,       /* k_bin_draws, or the sharded route (k_shard_table / route_fused / headers) */
     MP_K_COUNT = 4
 };
 int32_t mp_pf_set_timing(mp_pf* h, int32_t enabled);
