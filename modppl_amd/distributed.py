@@ -195,18 +195,25 @@ class ShardedParticleSystem:
         if self._fixed:
             slack = float(os.environ.get("MP_SHARD_SLACK", "1.25"))
             per = self.n // (min(8, self.nt) * self.world)   # draws per (owner, eighth of the owner's tiles) sub-segment, on average
-            self.cap = min(self.n, int(per * slack) + 512)
-            self.cap = int(os.environ.get("MP_SHARD_CAP", self.cap))   # tests: force the overflow path
-            w, cap = self.world, self.cap
-            self._fx_req_out = torch.zeros(w * 8 * (cap + 1) * 2, dtype=torch.int64, device=self.dev)
-            self._fx_req_in = self._fx_req_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_req_out)
-            self._fx_rows_out = torch.zeros(w * 8 * cap * (d + 1), dtype=torch.float64, device=self.dev)
-            self._fx_rows_in = self._fx_rows_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_rows_out)
+            cap = min(self.n, int(per * slack) + 512)
+            self._cap_forced = "MP_SHARD_CAP" in os.environ       # tests: force the overflow path
+            cap = int(os.environ.get("MP_SHARD_CAP", cap))
             self._p_tiles = C.c_void_p(self._tiles.data_ptr())
             self.engine.shard_bind_tiles(self._p_tiles)   # the filter keeps its tiles in the tensor the all-gather reads
+            w = self.world
             self._p_tiles_all = C.c_void_p(self._tiles.data_ptr() if (w == 1 and not self._always) else self._tiles_all.data_ptr())
-            self._p_req_out, self._p_req_in = C.c_void_p(self._fx_req_out.data_ptr()), C.c_void_p(self._fx_req_in.data_ptr())
-            self._p_rows_out, self._p_rows_in = C.c_void_p(self._fx_rows_out.data_ptr()), C.c_void_p(self._fx_rows_in.data_ptr())
+            self._alloc_fixed(cap)
+
+    def _alloc_fixed(self, cap):
+        """exchange buffers for `cap` draws per (owner, eighth) sub-segment"""
+        w, d = self.world, self.model.dim_state
+        self.cap = int(cap)
+        self._fx_req_out = torch.zeros(w * 8 * (cap + 1) * 2, dtype=torch.int64, device=self.dev)
+        self._fx_req_in = self._fx_req_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_req_out)
+        self._fx_rows_out = torch.zeros(w * 8 * cap * (d + 1), dtype=torch.float64, device=self.dev)
+        self._fx_rows_in = self._fx_rows_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_rows_out)
+        self._p_req_out, self._p_req_in = C.c_void_p(self._fx_req_out.data_ptr()), C.c_void_p(self._fx_req_in.data_ptr())
+        self._p_rows_out, self._p_rows_in = C.c_void_p(self._fx_rows_out.data_ptr()), C.c_void_p(self._fx_rows_in.data_ptr())
 
     # ---- collectives (identical for nccl/device tensors and gloo/CPU tensors) ----
     def _c(self, t):
@@ -297,6 +304,16 @@ class ShardedParticleSystem:
             if done:
                 return value
             self.fallbacks += 1   # collapsed weights: one owner serves (nearly) everybody — exact sizes this time
+            value = self._resample_variable(scheme, sync)
+            if not self._cap_forced and self.cap < self.n:
+                # every rank took this branch (the overflow flag is global), so every rank grows alike; nothing refers to the
+                # old buffers any more (the exact-size path scatters eagerly)
+                self.synchronize()
+                self._alloc_fixed(min(self.n, self.cap + self.cap // 2))
+            return value
+        return self._resample_variable(scheme, sync)
+
+    def _resample_variable(self, scheme, sync):
         d = self.model.dim_state
         self._normalize()
         tm, tw, tw2, nt_all = self._tile_ptrs()

@@ -266,3 +266,27 @@ def test_fixed_capacity_overflow_commits_nothing():
     for e, (x, w) in zip(eng, before):
         assert np.array_equal(e.states(), x)
         assert np.array_equal(e.log_weights(), w)
+
+
+def test_collapsed_weights_fall_back_and_capacity_grows():
+    """An observation far in the tail leaves a handful of particles with all the weight: one sub-segment of the
+    fixed-capacity exchange would need (nearly) every draw.  That resample is repeated with exact sizes, the capacity
+    grows for the next ones, and the results stay those of the unsharded filter."""
+    import modppl_amd
+    from modppl_amd.distributed import ShardedParticleSystem
+
+    n, seed = 1 << 16, 13
+    ys = np.array([0.1, 9.5, 9.0, 0.3, 0.2])
+    a = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    b = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    cap0 = b.cap
+    a.init_step(None, ys[:1])
+    b.init_step(None, ys[:1])
+    for t in range(1, len(ys)):
+        a.step(ys[t:t + 1])
+        b.step(ys[t:t + 1])
+        assert a.effective_sample_size(fresh=True) == b.effective_sample_size(fresh=True)
+        assert a.resample() == b.resample()
+        assert np.array_equal(a.parents, b.parents) and np.array_equal(a.states(), b.states())
+    assert b.fallbacks >= 1 and b.cap > cap0
+    assert a.log_marginal_likelihood_estimate() == b.log_marginal_likelihood_estimate()
