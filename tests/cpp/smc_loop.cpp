@@ -1,0 +1,36 @@
+// The reference's SMC loop (modppl/tests/smc.rs:64-90) through the C++ wrapper (modppl_amd/cpp/modppl.hpp):
+//   new -> init_step -> resample -> (step -> resample)*, then the log-ML estimate and a state checksum.
+// Prints one line "lml=<%.17g> x0=<%.17g> parents0=<u>" that tests/test_cpp_wrapper.py compares with the Python mirror
+// (both sit on the same C ABI, so the values must be identical).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../modppl_amd/cpp/modppl.hpp"
+
+int main(int argc, char** argv) {
+    const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 4096;
+    const uint64_t seed = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 7;
+    const std::vector<double> ys = {0.31, -0.12, 0.58, 1.02, 0.44, -0.27};
+    try {
+        modppl::ParticleSystem filter(modppl::UnfoldModel::lgssm(), n, seed);
+        filter.init_step({}, {ys[0]});
+        filter.resample();
+        for (size_t t = 1; t < ys.size(); ++t) {
+            filter.step({ys[t]});
+            filter.resample();
+        }
+        const double lml = filter.log_marginal_likelihood_estimate();
+        const std::vector<double> x = filter.states();
+        const std::vector<uint32_t> par = filter.parents();
+        std::printf("lml=%.17g x0=%.17g parents0=%u\n", lml, x[0], par[0]);
+        modppl::HierarchicalChains chains({-1., 0., 1.}, {0.2, 0.9, 2.2}, 256, seed);
+        const uint64_t a1 = chains.mh_add_or_remove(2);
+        const uint64_t a2 = chains.mh(0.1, 3);
+        std::printf("accepted=%llu,%llu\n", (unsigned long long)a1, (unsigned long long)a2);
+    } catch (const modppl::Panic& p) {
+        std::fprintf(stderr, "panic %d: %s\n", p.code, p.what());
+        return 2;
+    }
+    return 0;
+}
