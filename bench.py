@@ -4,7 +4,7 @@
 A "step" is one SMC time step over the whole particle population: `ParticleSystem::step`
 (propagate + weight) followed by `ParticleSystem::resample` (normalise, multinomial draw, gather)
 — the loop body of modppl/tests/smc.rs:79-84.  Workload at N=1: BASELINE.json configs[1]
-(LGSSM d=1, 2^20 particles, synthetic observations simulated from the model with Philox seed
+(LGSSM d=1, 2^20 particles, synthetic observations simulated from the model with numpy seed
 20241008).  State is resident in HBM before the timed region; the timed region is K steps,
 bracketed by barrier + synchronize, max over ranks.
 
@@ -36,10 +36,40 @@ KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024>", "normalize_scan": "k_n
 BYTES_STEP = 32 * DIM + 64
 
 
+LGSSM_PARAMS = (0.0, 1.0, 0.9, 0.5, 1.0)   # mu0, sig0, a, sig_x, sig_y
+
+
+def lgssm_observations(T, seed=20241008):
+    """y_0..y_{T-1} simulated once from the model (x_0 ~ N(mu0, sig0), x_t ~ N(a x_{t-1}, sig_x), y_t ~ N(x_t, sig_y))."""
+    mu0, sig0, a, sig_x, sig_y = LGSSM_PARAMS
+    rng = np.random.default_rng(seed)
+    ys = np.empty(T)
+    x = mu0 + sig0 * rng.normal()
+    for t in range(T):
+        if t > 0:
+            x = a * x + sig_x * rng.normal()
+        ys[t] = x + sig_y * rng.normal()
+    return ys
+
+
+def kalman_log_ml(ys):
+    """closed-form log marginal likelihood of the same model (scalar Kalman filter): the ground truth of log_ml"""
+    mu0, sig0, a, sig_x, sig_y = LGSSM_PARAMS
+    m, P, ll = mu0, sig0 * sig0, 0.0
+    for t, y in enumerate(ys):
+        if t > 0:
+            m, P = a * m, a * a * P + sig_x * sig_x
+        S = P + sig_y * sig_y
+        ll += -0.5 * (np.log(2.0 * np.pi * S) + (y - m) ** 2 / S)
+        K = P / S
+        m, P = m + K * (y - m), (1.0 - K) * P
+    return float(ll)
+
+
 def _cpu_run(ys, n, variant, threads, target_seconds):
     from tests import oracle_lib as O
 
-    pf = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, 20241008, variant, threads=threads)
+    pf = O.OraclePF(1, 1, 1, np.array(LGSSM_PARAMS), n, 20241008, variant, threads=threads)
     pf.init_step(ys[:1])
     pf.resample()
     t0 = time.perf_counter()
@@ -110,15 +140,14 @@ def main():
 
     import modppl_amd
     from modppl_amd import capi
-    from tests import oracle_lib as O  # observations + closed-form ground truth + cpu_baseline only
 
     n = args.particles
     K, W = args.steps, args.warmup
     T = 1 + W + K
-    ys = O.lgssm_observations(T)
-    kalman = O.kalman_log_ml(ys)
+    ys = lgssm_observations(T)     # nothing under oracle/ is touched outside cpu_baseline()
+    kalman = kalman_log_ml(ys)
 
-    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    model = modppl_amd.lgssm_model(*LGSSM_PARAMS)
     force_sharded = os.environ.get("MP_BENCH_FORCE_SHARDED", "0") == "1"  # diagnostics: the sharded code path in a world of one
     if force_sharded and dist is None:
         import torch.distributed as dist
@@ -218,7 +247,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (observations simulated from the model, Philox seed 20241008)",
+            "data": "synthetic (observations simulated from the model, seed 20241008)",
             "config": {"workload": "LGSSM d=1 bootstrap SMC, resample every step (BASELINE.json configs[1])",
                        "particles_per_gpu": n, "time_steps_timed": K, "particles_total": n * world,
                        "parallelism": "1 GPU" if world == 1 else f"one filter sharded over {world} GPUs (RCCL all-gather of tile totals + all-to-all particle exchange)"},

@@ -55,3 +55,18 @@ def test_product_never_imports_oracle():
                              (re.search(r"^\s*(from|import)\s+.*oracle", line) is not None) or \
                              ("liboracle" in code) or ("oracle_lib" in code)
                     assert not is_dep, (os.path.join(dirpath, f), line)
+
+
+def test_only_the_cpu_baseline_leg_of_bench_touches_the_oracle():
+    """bench.py may use oracle/ in cpu_baseline() only; the tools not at all."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    lines = src.splitlines()
+    uses = [i for i, l in enumerate(lines) if "oracle_lib" in l and not l.lstrip().startswith("#")]
+    assert uses, "cpu_baseline should still import the checker"
+    defs = [(i, l) for i, l in enumerate(lines) if l.startswith("def ")]
+    for i in uses:
+        owner = [name for j, name in defs if j <= i][-1]
+        assert owner.startswith(("def _cpu_run", "def cpu_baseline")), (i + 1, owner)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            assert "oracle_lib" not in open(os.path.join(ROOT, "tools", f)).read(), f

@@ -72,14 +72,14 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="run the filters through ShardedParticleSystem (world of one)")
     args = ap.parse_args()
     import modppl_amd
-    from tests import oracle_lib as O
+    import bench as B   # observations only; nothing under oracle/ is used by the tools
 
     T = 1 + args.warmup + args.steps
     rng = np.random.default_rng(20241008)
     out = []
     which = args.which.split(",")
     if "c2" in which:
-        out.append(pf_case("C2 LGSSM d=1", modppl_amd.lgssm_model(*O.LGSSM_PARAMS), 1 << 20, O.lgssm_observations(T).reshape(T, 1),
+        out.append(pf_case("C2 LGSSM d=1", modppl_amd.lgssm_model(*B.LGSSM_PARAMS), 1 << 20, B.lgssm_observations(T).reshape(T, 1),
                            args.steps, args.warmup, 96, args.sharded))
     if "c3" in which:
         th = np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + rng.normal(0, 0.02, T)

@@ -16,12 +16,12 @@ def main():
     import modppl_amd
     from modppl_amd import capi
     from modppl_amd.distributed import HipShardEngine
-    from tests import oracle_lib as O
+    import bench as B   # observations only; nothing under oracle/ is used by the tools
 
     n = 1 << 20
-    ys = O.lgssm_observations(3).reshape(3, 1)
+    ys = B.lgssm_observations(3).reshape(3, 1)
     for world in (1, 2, 4, 8):
-        eng = HipShardEngine(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, n * world, 0, 7)
+        eng = HipShardEngine(modppl_amd.lgssm_model(*B.LGSSM_PARAMS), n, n * world, 0, 7)
         nt = n // 2048
         dev = eng.device
         tiles = torch.zeros(3 * nt, dtype=torch.int64, device=dev)
