@@ -524,7 +524,6 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_table), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
         }
     }
     // ParticleSystem::new: log_weights = 0, parents = 0, log_ml_estimate = 0 (particle_filter.rs:44-57)
@@ -584,7 +583,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
             // big unsharded filters: the tile table once (k_shard_table over this filter's own packed tiles, a world of one)
             rc = shard_scratch(h, 1, h->sh_cap ? h->sh_cap : 1);
             if (rc != MP_OK) return rc;
-            hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), table_lds(h->nt, SHT_THREADS), h->stream, (const u64*)h->tile_m, 1, h->nt, h->S,
+            hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)h->tile_m, 1, h->nt, h->S,
                                h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_counts, h->scal, h->scal_undo);
             hipLaunchKernelGGL(k_bin_draws<true>, dim3(h->nchunks), dim3(BIN_THREADS), 2 * (sizeof(double) + sizeof(u64)) * (BIN_THREADS / 64) + lds_bins, h->stream,
                                h->n, h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks,
@@ -896,7 +895,7 @@ int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     const int nt_all = h->nt * world;
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), table_lds(nt_all, SHT_THREADS), h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
+        hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
                            h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_counts, h->scal, h->scal_undo);
         const int nblk_f = (int)((h->n + SH_THREADS * SHF_ITEMS - 1) / (SH_THREADS * SHF_ITEMS));
         hipLaunchKernelGGL(k_shard_route_fused, dim3(nblk_f), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,

@@ -240,31 +240,81 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
 // global memory), zero the request counters, and fold this normalisation into the filter scalars (L, ESS, log-ML),
 // keeping a copy for the case that the fixed-capacity exchange overflows.
 constexpr int SHT_THREADS = 1024;
+constexpr int SHT_PER = MAX_TILES / SHT_THREADS;   // tiles per thread, held in registers (8)
 __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
                                                              double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
                                                              u64* __restrict__ incl_all, long long* __restrict__ zero_counts,
                                                              mp_dev_scalars* scal, mp_dev_scalars* undo) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double s_red[SHT_THREADS / 64];
+    __shared__ u64 s_wtot[SHT_THREADS / 64];
+    __shared__ u64 s_wtot2[SHT_THREADS / 64];
     const int nt = world * nt_local;
-    u64* s_incl = reinterpret_cast<u64*>(smem);
-    u64* s_W = s_incl + nt;
-    double* s_red = reinterpret_cast<double*>(s_W + nt);
-    u64* s_wtot = reinterpret_cast<u64*>(s_red + SHT_THREADS / 64);
-    if (threadIdx.x < SH_MAX_KEYS) zero_counts[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < nt; i += SHT_THREADS) {
-        const int r = i / nt_local, b = i % nt_local;
-        const u64* base = packed + (u64)r * 3 * nt_local;
-        tm[i] = mp_u2f(base[b]);
-        tW[i] = base[nt_local + b];
-        tW2[i] = base[2 * nt_local + b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < SH_MAX_KEYS) zero_counts[tid] = 0;
+    // thread t owns tiles t * per .. t * per + per - 1 (consecutive, so that a thread-local running sum is a prefix); each
+    // tile is read once, kept in registers, and its unpacked copy written for the kernels that want plain arrays
+    const int per = (nt + SHT_THREADS - 1) / SHT_THREADS;   // <= SHT_PER since nt <= MAX_TILES
+    const int b0 = tid * per;
+    double mb[SHT_PER];
+    u64 Wb[SHT_PER], W2b[SHT_PER];
+    double m = MP_NEG_INF;
+#pragma unroll
+    for (int j = 0; j < SHT_PER; ++j) {
+        const int i = b0 + j;
+        mb[j] = MP_NEG_INF; Wb[j] = 0; W2b[j] = 0;
+        if (j < per && i < nt) {
+            const int r = i / nt_local, b = i - r * nt_local;
+            const u64* base = packed + (u64)r * 3 * nt_local;
+            mb[j] = mp_u2f(base[b]);
+            Wb[j] = base[nt_local + b];
+            W2b[j] = base[2 * nt_local + b];
+            tm[i] = mb[j]; tW[i] = Wb[j]; tW2[i] = W2b[j];
+            m = fmax(m, mb[j]);
+        }
     }
-    __threadfence_block();
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
     __syncthreads();
-    const double m = block_tile_table<SHT_THREADS>(tm, tW, nt, S, s_incl, s_W, s_red, s_wtot);
-    for (int i = threadIdx.x; i < nt; i += SHT_THREADS) incl_all[i] = s_incl[i];
-    const u64 Q = s_incl[nt - 1];
-    const u64 Q2 = block_sum_T2<SHT_THREADS>(tm, tW2, nt, S, m, s_wtot);
-    if (threadIdx.x == 0) {
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < SHT_THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    // level 1 exactly as block_tile_table / block_sum_T2 state it: T_b = rint(W_b exp(m_b - m) 2^(S-51)), T2_b likewise with
+    // exp(2 (m_b - m)); integer sums, so the order of the reduction is immaterial
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
+    u64 pre[SHT_PER];
+    u64 run = 0, run2 = 0;
+#pragma unroll
+    for (int j = 0; j < SHT_PER; ++j) {
+        const int i = b0 + j;
+        pre[j] = 0;
+        if (j < per && i < nt) {
+            const double f = ok ? mp_exp(mb[j] - m) : 0.;
+            const double f2 = ok ? mp_exp(2. * (mb[j] - m)) : 0.;
+            run += mp_quantize((double)Wb[j] * f * sc, 1.0);
+            run2 += mp_quantize((double)W2b[j] * f2 * sc, 1.0);
+            pre[j] = run;
+        }
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    const u64 tot2 = wave_sum_u64(run2);
+    if (lane == 63) s_wtot[wave] = incl;
+    if (lane == 0) s_wtot2[wave] = tot2;
+    __syncthreads();
+    u64 woff = 0, Q = 0, Q2 = 0;
+#pragma unroll
+    for (int w = 0; w < SHT_THREADS / 64; ++w) {
+        if (w < wave) woff += s_wtot[w];
+        Q += s_wtot[w];
+        Q2 += s_wtot2[w];
+    }
+    const u64 off = woff + (incl - run);
+#pragma unroll
+    for (int j = 0; j < SHT_PER; ++j) {
+        const int i = b0 + j;
+        if (j < per && i < nt) incl_all[i] = off + pre[j];
+    }
+    if (tid == 0) {
         *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
         fold_scalars(scal, Q, Q2, S, m, n_global, 0);
     }
