@@ -274,6 +274,7 @@ struct mp_pf {
     u64* sh_tW2_all = nullptr;
     u64* sh_incl_all = nullptr;     // the job's tile table (inclusive prefix of T_b), built once per resample by k_shard_table
     int* sh_overflow = nullptr;
+    unsigned int* sh_done = nullptr;   // [2] tickets of the route / resolve workgroups (the last one writes headers / publishes)
     u64* tiles_own = nullptr;       // the allocation behind tile_m / tile_W / tile_W2 unless the caller bound its own buffer
     mp_shard_pub* h_pub = nullptr;  // pinned, host-mapped
     mp_shard_pub* d_pub = nullptr;  // its device address
@@ -831,7 +832,7 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     if (h->sh_dest && h->sh_world >= world && h->sh_cap >= cap && h->sh_tm_all) return MP_OK;
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all);
-    (void)hipFree(h->sh_overflow);
+    (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     const u64 slots = std::max<u64>(h->n, (u64)world * SH_BINS * cap);
     HIPCK(hipMalloc(&h->sh_dest, h->n));
@@ -846,6 +847,8 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     HIPCK(hipMalloc(&h->sh_tW2_all, sizeof(u64) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_incl_all, sizeof(u64) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_overflow, sizeof(int)));
+    HIPCK(hipMalloc(&h->sh_done, 2 * sizeof(unsigned int)));
+    HIPCK(hipMemsetAsync(h->sh_done, 0, 2 * sizeof(unsigned int), h->stream));
     if (!h->scal_undo) HIPCK(hipMalloc(&h->scal_undo, sizeof(mp_dev_scalars)));
     HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
     HIPCK(hipHostMalloc(&h->h_counts, sizeof(long long) * SH_MAX_WORLD));
@@ -900,9 +903,8 @@ int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         const int nblk_f = (int)((h->n + SH_THREADS * SHF_ITEMS - 1) / (SH_THREADS * SHF_ITEMS));
         hipLaunchKernelGGL(k_shard_route_fused, dim3(nblk_f), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
                            (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all,
-                           nt_all, h->nt, world, (u64)capacity, (unsigned long long*)h->sh_counts, (u64*)d_req_out, h->sh_req_slot);
-        hipLaunchKernelGGL(k_shard_headers, dim3(1), dim3(K3_THREADS), 0, h->stream, (const unsigned long long*)h->sh_counts, world, (u64)capacity,
-                           (u64*)d_req_out, h->sh_overflow);
+                           nt_all, h->nt, world, (u64)capacity, (unsigned long long*)h->sh_counts, (u64*)d_req_out, h->sh_req_slot, h->sh_done,
+                           h->sh_overflow);
     }
     return check_launch("shard_route_fixed kernels");
 }
@@ -918,8 +920,8 @@ int32_t mp_pf_shard_resolve_fixed(mp_pf* h, const uint64_t* d_req_in, int32_t wo
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         hipLaunchKernelGGL(k_shard_resolve_binned, dim3(groups * SH_BINS, world), dim3(K3_THREADS), 0, h->stream, h->n, (u64)capacity, h->slot_offset,
-                           h->ops->dim_state, (const u64*)d_req_in, h->cx, h->guide, h->tile_W, h->x[h->cur], d_rows_out, h->sh_overflow);
-        hipLaunchKernelGGL(k_shard_publish, dim3(1), dim3(1), 0, h->stream, h->sh_overflow, h->scal, h->d_pub);
+                           h->ops->dim_state, (const u64*)d_req_in, h->cx, h->guide, h->tile_W, h->x[h->cur], d_rows_out, h->sh_overflow,
+                           h->sh_done + 1, h->scal, h->d_pub);
     }
     int32_t rc = check_launch("k_shard_resolve_binned");
     if (rc != MP_OK) return rc;
@@ -1068,7 +1070,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all);
-    (void)hipFree(h->sh_overflow); (void)hipFree(h->scal_undo);
+    (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done); (void)hipFree(h->scal_undo);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     if (h->h_pub) (void)hipHostFree(h->h_pub);
     if (h->ev_resolved) (void)hipEventDestroy(h->ev_resolved);

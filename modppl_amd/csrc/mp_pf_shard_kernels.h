@@ -182,7 +182,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
                                                                   int systematic, const u64* __restrict__ incl_all,
                                                                   const u64* __restrict__ tW_all, int nt_all, int nt_local, int world, u64 capb,
                                                                   unsigned long long* __restrict__ counts, u64* __restrict__ req_out,
-                                                                  uint32_t* __restrict__ inv) {
+                                                                  uint32_t* __restrict__ inv, unsigned int* done, int* overflow) {
     __shared__ u64 s_base[SH_MAX_KEYS];        // [keys] start inside the sub-segment
     __shared__ uint32_t s_cnt[SH_MAX_KEYS];    // [keys] draws of this workgroup per sub-segment
     const int keys = world * SH_BINS;
@@ -233,6 +233,27 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
                 sub[j + 1] = make_ulonglong2((u64)tl[k], lt[k]);
                 inv[i0 + (u64)k * SH_THREADS] = (uint32_t)((u64)key[k] * capb + j);
             }
+        }
+    }
+    // The last workgroup to get here writes the sub-segment headers {count, "some sub-segment of mine overflowed"}.  Only
+    // atomically updated words are read across workgroups (the counters, each workgroup's additions complete before its
+    // ticket), so no fence is needed; the headers themselves are read by the next kernel / collective.
+    __shared__ unsigned int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(done, 1u);
+    __syncthreads();
+    if (s_ticket == gridDim.x - 1) {
+        int mine = 0;
+        for (int k = threadIdx.x; k < keys; k += SH_THREADS) mine |= (atomicAdd(&counts[k], 0ull) > capb) ? 1 : 0;
+        const int any = __syncthreads_or(mine);
+        for (int k = threadIdx.x; k < keys; k += SH_THREADS) {
+            const u64 c = atomicAdd(&counts[k], 0ull);
+            u64* sub = req_out + (u64)k * (capb + 1) * 2;
+            sub[0] = c < capb ? c : capb;
+            sub[1] = (u64)any;
+        }
+        if (threadIdx.x == 0) {
+            if (any) atomicOr(overflow, 1);
+            atomicExch(done, 0u);
         }
     }
 }
@@ -319,34 +340,20 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
         fold_scalars(scal, Q, Q2, S, m, n_global, 0);
     }
 }
-// After the route: the sub-segment headers {count, "some sub-segment of mine overflowed"}.  One workgroup.
-__global__ __launch_bounds__(K3_THREADS) void k_shard_headers(const unsigned long long* __restrict__ counts, int world, u64 capb,
-                                                              u64* __restrict__ req_out, int* overflow) {
-    const int keys = world * SH_BINS;
-    int mine = 0;
-    for (int k = threadIdx.x; k < keys; k += K3_THREADS) mine |= (counts[k] > capb) ? 1 : 0;
-    const int any = __syncthreads_or(mine);
-    for (int k = threadIdx.x; k < keys; k += K3_THREADS) {
-        const u64 c = counts[k];
-        u64* sub = req_out + (u64)k * (capb + 1) * 2;
-        sub[0] = c < capb ? c : capb;
-        sub[1] = (u64)any;
-    }
-    if (threadIdx.x == 0 && any) *overflow = 1;
-}
 // owner side: blockIdx.x & 7 = eighth of this shard's tiles (workgroups are dealt round-robin to the 8 XCDs, gridDim.x is
 // a multiple of 8), blockIdx.y = asking rank.  Per request: guide cell -> first row -> short forward walk, all inside
 // the eighth.  Rows go back in the order the requests came.
 __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 capb, u64 slot_offset, int D, const u64* __restrict__ req,
                                                                      const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
                                                                      const u64* __restrict__ tile_W, const double* __restrict__ x,
-                                                                     double* __restrict__ rows, int* overflow) {
+                                                                     double* __restrict__ rows, int* overflow, unsigned int* done,
+                                                                     const mp_dev_scalars* scal, mp_shard_pub* pub) {
     const int bin = blockIdx.x & (SH_BINS - 1), grp = blockIdx.x >> 3, ngrp = gridDim.x >> 3;
     const u64 key = (u64)blockIdx.y * SH_BINS + bin;
     const ulonglong2* sub = reinterpret_cast<const ulonglong2*>(req) + key * (capb + 1);
     const ulonglong2 head = sub[0];
     const u64 cnt = head.x < capb ? head.x : capb;
-    if (grp == 0 && threadIdx.x == 0 && head.y) *overflow = 1;
+    if (grp == 0 && threadIdx.x == 0 && head.y) atomicOr(overflow, 1);
     double* out_sub = rows + key * capb * (u64)(D + 1);
     for (u64 q0 = (u64)grp * (K3_THREADS * K3_ITEMS); q0 < cnt; q0 += (u64)ngrp * (K3_THREADS * K3_ITEMS)) {
         u64 lt[K3_ITEMS], tbase[K3_ITEMS], last[K3_ITEMS];
@@ -415,13 +422,16 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
             }
         }
     }
-}
-// after the resolve: "somebody overflowed" and the scalars of this normalisation, where the host reads them after waiting
-// for ev_resolved (host-mapped memory: no copy command, no stream sync)
-__global__ void k_shard_publish(const int* overflow, const mp_dev_scalars* scal, mp_shard_pub* pub) {
-    pub->L = scal->L;
-    pub->degenerate = scal->degenerate;
-    pub->overflow = *overflow;
+    // The last workgroup publishes "somebody overflowed" (flags are only ever OR-ed atomically) and the scalars of this
+    // normalisation (written by k_shard_table, an earlier kernel) where the host reads them after waiting for ev_resolved:
+    // host-mapped memory, no copy command, no stream sync.
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1) {
+        pub->L = scal->L;
+        pub->degenerate = scal->degenerate;
+        pub->overflow = atomicOr(overflow, 0);
+        atomicExch(done, 0u);
+    }
 }
 // requester side, only when something other than the next propagate needs slot order: x[i], parent[i] from row inv[i]
 __global__ __launch_bounds__(SH_THREADS) void k_shard_adopt_rows(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ inv,
