@@ -920,8 +920,8 @@ int32_t mp_pf_shard_resolve_fixed(mp_pf* h, const uint64_t* d_req_in, int32_t wo
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         hipLaunchKernelGGL(k_shard_resolve_binned, dim3(groups * SH_BINS, world), dim3(K3_THREADS), 0, h->stream, h->n, (u64)capacity, h->slot_offset,
-                           h->ops->dim_state, (const u64*)d_req_in, h->cx, h->guide, h->tile_W, h->x[h->cur], d_rows_out, h->sh_overflow,
-                           h->sh_done + 1, h->scal, h->d_pub);
+                           h->ops->dim_state, (const u64*)d_req_in, h->cx, h->guide, h->tile_W, h->x[h->cur], d_rows_out, h->sh_overflow);
+        hipLaunchKernelGGL(k_shard_publish, dim3(1), dim3(1), 0, h->stream, h->sh_overflow, h->scal, h->d_pub);
     }
     int32_t rc = check_launch("k_shard_resolve_binned");
     if (rc != MP_OK) return rc;
