@@ -26,7 +26,7 @@ static_assert(GUIDE_N == TILE, "normalize_tile zeroes/stores the guide with one 
 constexpr int GUIDE_DIRECT = 8;                  // bucket runs longer than this are filled by the whole wave
 constexpr int FIX_BITS = 51;                     // level-0 fixed point: q = rint(exp(lw - m_tile) * 2^51), 2048 * 2^51 < 2^63
 constexpr int BIN_CHUNK = 1024;                  // output slots per chunk of the binned resampler
-constexpr int BIN_THREADS = 256;
+constexpr int BIN_THREADS = 512;                  // x 2 draws per thread (256 x 4: 20.4 us, 512 x 2: 18.4 us, 1024 x 1: 23.9 us at 2^20)
 constexpr int BIN_ITEMS = BIN_CHUNK / BIN_THREADS;
 constexpr int BIN_GROUP = 8;                     // chunks per k_resolve_bins workgroup
 // Position of entry e of segment (bin, chunk) in the sparse segment arrays [bin][chunk][1024].  Only ~128 entries of
