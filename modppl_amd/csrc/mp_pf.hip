@@ -600,7 +600,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
             const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
-            hipLaunchKernelGGL(k_resolve_bins, dim3(ngroups * 8), dim3(K3_THREADS), 0, h->stream, h->n, h->nchunks, h->seg_lt, h->seg_row,
+            hipLaunchKernelGGL(k_resolve_bins, dim3(ngroups * 8), dim3(K3B_THREADS), 0, h->stream, h->n, h->nchunks, h->seg_lt, h->seg_row,
                                h->seg_cnt, h->cx, h->res_x, h->res_parent);
             binned = true;
         } else if (scheme == MP_RESAMPLE_STRATIFIED) {
@@ -915,7 +915,7 @@ int32_t mp_pf_shard_resolve_fixed(mp_pf* h, const uint64_t* d_req_in, int32_t wo
     if (!h->h_pub) return mp_fail(MP_ERR_STATE, "shard_resolve_fixed before shard_route_fixed");
     HIPCK(hipSetDevice(h->device));
     // workgroups per (asking rank, eighth): enough to fill the chip, each takes K3_THREADS * K3_ITEMS requests per round
-    const u64 per = (u64)K3_THREADS * K3_ITEMS;
+    const u64 per = (u64)K3_THREADS * SHR_ITEMS;
     const unsigned groups = (unsigned)std::max<u64>(1, std::min<u64>((capacity + per - 1) / per, std::max<u64>(1, 512 / (u64)world)));
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);

@@ -28,7 +28,9 @@ constexpr int FIX_BITS = 51;                     // level-0 fixed point: q = rin
 constexpr int BIN_CHUNK = 1024;                  // output slots per chunk of the binned resampler
 constexpr int BIN_THREADS = 512;                  // x 2 draws per thread (256 x 4: 20.4 us, 512 x 2: 18.4 us, 1024 x 1: 23.9 us at 2^20)
 constexpr int BIN_ITEMS = BIN_CHUNK / BIN_THREADS;
-constexpr int BIN_GROUP = 8;                     // chunks per k_resolve_bins workgroup
+constexpr int K3B_THREADS = 256;                  // k_resolve_bins: 128 lanes per quad of K3B_ITEMS chunks
+constexpr int K3B_ITEMS = 1;                      // segments per thread: 4 / 2 / 1 measured 19.0 / 17.5 / 16.2 us (more waves hide the two dependent hops better than 4 chains per lane)
+constexpr int BIN_GROUP = (K3B_THREADS / 128) * K3B_ITEMS;   // chunks per k_resolve_bins workgroup
 // Position of entry e of segment (bin, chunk) in the sparse segment arrays [bin][chunk][1024].  Only ~128 entries of
 // each 1024-entry window are used; the start is rotated by (chunk % 8) * 128 so the used parts spread over the address space.
 #define MP_SEG_POS(bin, c, e, nchunks) ((((u64)(bin) * (u64)(nchunks) + (u64)(c)) * BIN_CHUNK) + (u64)((((uint32_t)(e)) + (((uint32_t)(c)) & 7u) * 128u) & 1023u))
@@ -691,19 +693,19 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
 // segment holds 128 +- 11 entries, so nearly every lane is live and each has 4 independent chains in flight.
 // Results stay in SEGMENT order (res_x[d][bin][chunk][pos], res_parent likewise: coalesced stores); the next
 // k_propagate reads its inputs through perm[], k_unpermute materialises slot order when the host asks.
-__global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int nchunks, const u64* __restrict__ seg_lt,
+__global__ __launch_bounds__(K3B_THREADS) void k_resolve_bins(u64 n, int nchunks, const u64* __restrict__ seg_lt,
                                                              const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_cnt,
                                                              const mp_cx* __restrict__ cx, double* __restrict__ res_x,
                                                              uint32_t* __restrict__ res_parent) {
     const int bin = blockIdx.x & 7;
     const int group = blockIdx.x >> 3;
     const int e0 = threadIdx.x & 127, quad = threadIdx.x >> 7;
-    int cnt[K3_ITEMS], chunk_of[K3_ITEMS];
-    u64 lt[K3_ITEMS], spos[K3_ITEMS];
-    uint32_t row0[K3_ITEMS];
+    int cnt[K3B_ITEMS], chunk_of[K3B_ITEMS];
+    u64 lt[K3B_ITEMS], spos[K3B_ITEMS];
+    uint32_t row0[K3B_ITEMS];
 #pragma unroll
-    for (int k = 0; k < K3_ITEMS; ++k) {
-        const int c = group * BIN_GROUP + quad * K3_ITEMS + k;
+    for (int k = 0; k < K3B_ITEMS; ++k) {
+        const int c = group * BIN_GROUP + quad * K3B_ITEMS + k;
         const bool ok = c < nchunks;
         chunk_of[k] = ok ? c : 0;
         cnt[k] = ok ? (int)seg_cnt[(u64)bin * nchunks + c] : 0;
@@ -729,10 +731,10 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int nchunks,
         res_x[sp] = cur.x0;
         // D > 1: the rest of the state is gathered by the next k_propagate (or k_unpermute) from res_parent
     };
-    bool live[K3_ITEMS];
-    mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
+    bool live[K3B_ITEMS];
+    mp_cx r0[K3B_ITEMS], r1[K3B_ITEMS];
 #pragma unroll
-    for (int k = 0; k < K3_ITEMS; ++k) {
+    for (int k = 0; k < K3B_ITEMS; ++k) {
         live[k] = e0 < cnt[k];
         if (live[k]) {
             const u64 tend = (((u64)row0[k] / TILE) + 1) * TILE;
@@ -744,11 +746,11 @@ __global__ __launch_bounds__(K3_THREADS) void k_resolve_bins(u64 n, int nchunks,
         }
     }
 #pragma unroll
-    for (int k = 0; k < K3_ITEMS; ++k)
+    for (int k = 0; k < K3B_ITEMS; ++k)
         if (live[k]) finish(lt[k], row0[k], spos[k], r0[k], r1[k]);
     // entries 128.. of a segment (about 5 % of the entries: the upper tail of Binomial(1024, 1/8))
 #pragma unroll
-    for (int k = 0; k < K3_ITEMS; ++k) {
+    for (int k = 0; k < K3B_ITEMS; ++k) {
         for (int e = 128 + e0; e < cnt[k]; e += 128) {
             const u64 sp = MP_SEG_POS(bin, chunk_of[k], e, nchunks);
             const uint32_t row = seg_row[sp];

@@ -343,6 +343,7 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
 // owner side: blockIdx.x & 7 = eighth of this shard's tiles (workgroups are dealt round-robin to the 8 XCDs, gridDim.x is
 // a multiple of 8), blockIdx.y = asking rank.  Per request: guide cell -> first row -> short forward walk, all inside
 // the eighth.  Rows go back in the order the requests came.
+constexpr int SHR_ITEMS = 1;   // requests per thread and round
 __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 capb, u64 slot_offset, int D, const u64* __restrict__ req,
                                                                      const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
                                                                      const u64* __restrict__ tile_W, const double* __restrict__ x,
@@ -354,12 +355,12 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
     const u64 cnt = head.x < capb ? head.x : capb;
     if (grp == 0 && threadIdx.x == 0 && head.y) atomicOr(overflow, 1);
     double* out_sub = rows + key * capb * (u64)(D + 1);
-    for (u64 q0 = (u64)grp * (K3_THREADS * K3_ITEMS); q0 < cnt; q0 += (u64)ngrp * (K3_THREADS * K3_ITEMS)) {
-        u64 lt[K3_ITEMS], tbase[K3_ITEMS], last[K3_ITEMS];
-        uint32_t gi[K3_ITEMS];
-        bool live[K3_ITEMS];
+    for (u64 q0 = (u64)grp * (K3_THREADS * SHR_ITEMS); q0 < cnt; q0 += (u64)ngrp * (K3_THREADS * SHR_ITEMS)) {
+        u64 lt[SHR_ITEMS], tbase[SHR_ITEMS], last[SHR_ITEMS];
+        uint32_t gi[SHR_ITEMS];
+        bool live[SHR_ITEMS];
 #pragma unroll
-        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 0: the requests (coalesced)
+        for (int k = 0; k < SHR_ITEMS; ++k) {   // hop 0: the requests (coalesced)
             const u64 q = q0 + (u64)k * K3_THREADS + threadIdx.x;
             live[k] = q < cnt;
             const ulonglong2 e = live[k] ? sub[q + 1] : make_ulonglong2(0ull, 1ull);
@@ -372,15 +373,15 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
             if (g > GUIDE_N - 1) g = GUIDE_N - 1;
             gi[k] = (uint32_t)b * (uint32_t)GUIDE_N + g;
         }
-        u64 p[K3_ITEMS];
+        u64 p[SHR_ITEMS];
 #pragma unroll
-        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 1: guide cells
+        for (int k = 0; k < SHR_ITEMS; ++k) {   // hop 1: guide cells
             u64 j = tbase[k] + guide[gi[k]];
             p[k] = j < last[k] ? j : last[k];
         }
-        mp_cx r0[K3_ITEMS], r1[K3_ITEMS];
+        mp_cx r0[SHR_ITEMS], r1[SHR_ITEMS];
 #pragma unroll
-        for (int k = 0; k < K3_ITEMS; ++k) {   // hop 2: the row and its successor
+        for (int k = 0; k < SHR_ITEMS; ++k) {   // hop 2: the row and its successor
             r0[k] = cx[p[k]];
             r1[k] = cx[p[k] + (p[k] < last[k] ? 1 : 0)];
         }
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
         const int G = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : 16));
         const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int k = 0; k < K3_ITEMS; ++k) {
+        for (int k = 0; k < SHR_ITEMS; ++k) {
             mp_cx cur = r0[k];
             u64 pp = p[k];
             if (live[k] && cur.cum < lt[k] && pp < last[k]) {
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
                 if (live[k]) out_sub[q * (u64)(D + 1) + D] = (double)(slot_offset + pp);
                 // the wave's 64 requests of this round, 64 / G at a time (wave-uniform trip count; D <= 16)
                 const uint32_t pp_lo = (uint32_t)pp, pp_hi = (uint32_t)(pp >> 32);
-                const uint32_t ql = (uint32_t)(q - q0);   // < K3_THREADS * K3_ITEMS
+                const uint32_t ql = (uint32_t)(q - q0);   // < K3_THREADS * SHR_ITEMS
                 const int comp = lane % G;
                 for (int base = 0; base < 64; base += 64 / G) {
                     const int src = base + lane / G;
