@@ -110,7 +110,7 @@ struct ModelOpsT : ModelOps {
     }
     void propagate(const PropagateArgs& a) const override {
         // light kernels (few registers) run 1024 threads x 2 particles per tile: twice the waves in flight for the same 2048-slot tile
-        constexpr int THREADS = (Model::MAX_NORMALS <= 2 && Model::DIM_STATE <= 2) ? 1024 : TILE_THREADS;
+        constexpr int THREADS = (Model::MAX_NORMALS <= 4 && Model::DIM_STATE <= 4) ? 1024 : TILE_THREADS;
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
                            a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent);
