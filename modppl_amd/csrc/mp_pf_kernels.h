@@ -464,6 +464,10 @@ __device__ __forceinline__ u64 mp_target_systematic(u64 g, uint32_t k32, u64 Q, 
     const u64 hi = __umul64hi(p, Q);
     const u64 a_lo = (lo >> 32) | (hi << 32);   // A = (hi:lo) >> 32, A < 2^95
     const u64 a_hi = hi >> 32;                  // < 2^31
+    if ((n_global & (n_global - 1ull)) == 0ull) {   // power-of-two populations (the usual case): a shift instead of two 64-bit divisions
+        const int sh = __ffsll((long long)n_global) - 1;   // 0 .. 31
+        return (sh == 0 ? a_lo : ((a_lo >> sh) | (a_hi << (64 - sh)))) + 1ull;
+    }
     // long division of (a_hi : a_lo) by n_global < 2^32, base 2^32
     u64 r = a_hi % n_global;                    // a_hi / n_global contributes to bits >= 64 of the quotient: zero since A / N < Q < 2^63
     u64 cur = (r << 32) | (a_lo >> 32);

@@ -27,3 +27,20 @@ def hiplib():
     from modppl_amd import capi
 
     return capi.load()
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: bring PyTorch's HIP context up BEFORE the first kernel of this library runs.  Some tests (the sharded
+    filter) import torch only late in the session; twice on the GPU pool the first `import torch` + stream creation after
+    tens of tests' worth of HIP work in the same process stalled for minutes, while the order "torch first" (what bench.py
+    and every isolated test run do) never has."""
+    if not any("gpu" in item.keywords for item in items):
+        return
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda").item()
+    except Exception:   # no torch / no GPU: the tests that need them say so themselves
+        pass

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def pf_case(name, model, n, obs, steps, warmup, bytes_per_particle, sharded=False):
+def pf_case(name, model, n, obs, steps, warmup, bytes_per_particle, sharded=False, scheme=0):
     import modppl_amd
     from modppl_amd import capi
 
@@ -39,21 +39,21 @@ def pf_case(name, model, n, obs, steps, warmup, bytes_per_particle, sharded=Fals
     else:
         pf = modppl_amd.ParticleSystem(model, n, 20241008)
     pf.init_step(None, obs[:1])
-    pf.resample(sync=False)
+    pf.resample(scheme, sync=False)
     for t in range(1, 1 + warmup):
         pf.step(obs[t:t + 1])
-        pf.resample(sync=False)
+        pf.resample(scheme, sync=False)
     pf.synchronize()
     t0 = time.perf_counter()
     for t in range(1 + warmup, 1 + warmup + steps):
         pf.step(obs[t:t + 1])
-        pf.resample(sync=False)
+        pf.resample(scheme, sync=False)
     pf.synchronize()
     dt = time.perf_counter() - t0
     pf.set_timing(True)
     for t in range(1 + warmup, 1 + warmup + steps):
         pf.step(obs[t:t + 1])
-        pf.resample(sync=False)
+        pf.resample(scheme, sync=False)
     pf.synchronize()
     fam = {k: pf.get_timing(v) for k, v in (("propagate", capi.MP_K_PROPAGATE), ("bin_draws", capi.MP_K_BIN_DRAWS),
                                             ("resample_gather", capi.MP_K_RESAMPLE_GATHER))}
@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--which", default="c2,c3,c5,c4")
+    ap.add_argument("--scheme", type=int, default=0, help="0 multinomial, 1 systematic, 2 stratified")
     ap.add_argument("--sharded", action="store_true", help="run the filters through ShardedParticleSystem (world of one)")
     args = ap.parse_args()
     import modppl_amd
@@ -80,13 +81,13 @@ def main():
     which = args.which.split(",")
     if "c2" in which:
         out.append(pf_case("C2 LGSSM d=1", modppl_amd.lgssm_model(*B.LGSSM_PARAMS), 1 << 20, B.lgssm_observations(T).reshape(T, 1),
-                           args.steps, args.warmup, 96, args.sharded))
+                           args.steps, args.warmup, 96, args.sharded, args.scheme))
     if "c3" in which:
         th = np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + rng.normal(0, 0.02, T)
-        out.append(pf_case("C3 bearings d=4", modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), args.steps, args.warmup, 192, args.sharded))
+        out.append(pf_case("C3 bearings d=4", modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), args.steps, args.warmup, 192, args.sharded, args.scheme))
     if "c5" in which:
         out.append(pf_case("C5 LGSSM band d=16 (one GPU's shard of 2^24 / 8)", modppl_amd.lgssm_band_model(16), 1 << 21,
-                           rng.normal(0, 1.2, size=(T, 16)), args.steps, args.warmup, 576, args.sharded))
+                           rng.normal(0, 1.2, size=(T, 16)), args.steps, args.warmup, 576, args.sharded, args.scheme))
     if "c4" in which:
         xs = np.arange(-5, 6, dtype=np.float64)
         ys = 0.3 + 0.4 * xs + 0.5 * xs * xs + rng.normal(0, 0.1, xs.size)
