@@ -272,6 +272,7 @@ struct mp_pf {
     double* sh_tm_all = nullptr;    // unpacked gathered tiles
     u64* sh_tW_all = nullptr;
     u64* sh_tW2_all = nullptr;
+    double* sh_ratio_all = nullptr;   // and its per-tile (double)W / (double)T
     u64* sh_incl_all = nullptr;     // the job's tile table (inclusive prefix of T_b), built once per resample by k_shard_table
     int* sh_overflow = nullptr;
     unsigned int* sh_done = nullptr;   // [2] tickets of the route / resolve workgroups (the last one writes headers / publishes)
@@ -585,15 +586,16 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
             rc = shard_scratch(h, 1, h->sh_cap ? h->sh_cap : 1);
             if (rc != MP_OK) return rc;
             hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)h->tile_m, 1, h->nt, h->S,
-                               h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_counts, h->scal, h->scal_undo);
+                               h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo);
             hipLaunchKernelGGL(k_bin_draws<true>, dim3(h->nchunks), dim3(BIN_THREADS), 2 * (sizeof(double) + sizeof(u64)) * (BIN_THREADS / 64) + lds_bins, h->stream,
                                h->n, h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks,
                                h->tile_m, h->tile_W, h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal,
-                               (const u64*)h->sh_incl_all);
+                               (const u64*)h->sh_incl_all, (const double*)h->sh_ratio_all);
         } else {
             hipLaunchKernelGGL(k_bin_draws<false>, dim3(h->nchunks), dim3(BIN_THREADS), table_lds(h->nt, BIN_THREADS) + lds_bins, h->stream, h->n,
                                h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m,
-                               h->tile_W, h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)nullptr);
+                               h->tile_W, h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)nullptr,
+                               (const double*)nullptr);
         }
     }
     {
@@ -831,7 +833,7 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     const int nblk = (int)((h->n + SH_THREADS - 1) / SH_THREADS);
     if (h->sh_dest && h->sh_world >= world && h->sh_cap >= cap && h->sh_tm_all) return MP_OK;
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
-    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all);
+    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all); (void)hipFree(h->sh_ratio_all);
     (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     const u64 slots = std::max<u64>(h->n, (u64)world * SH_BINS * cap);
@@ -846,6 +848,7 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     HIPCK(hipMalloc(&h->sh_tW_all, sizeof(u64) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_tW2_all, sizeof(u64) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_incl_all, sizeof(u64) * (size_t)h->nt * world));
+    HIPCK(hipMalloc(&h->sh_ratio_all, sizeof(double) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_overflow, sizeof(int)));
     HIPCK(hipMalloc(&h->sh_done, 2 * sizeof(unsigned int)));
     HIPCK(hipMemsetAsync(h->sh_done, 0, 2 * sizeof(unsigned int), h->stream));
@@ -899,10 +902,10 @@ int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
         hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
-                           h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_counts, h->scal, h->scal_undo);
+                           h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo);
         const int nblk_f = (int)((h->n + SH_THREADS * SHF_ITEMS - 1) / (SH_THREADS * SHF_ITEMS));
         hipLaunchKernelGGL(k_shard_route_fused, dim3(nblk_f), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all,
+                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all, (const double*)h->sh_ratio_all,
                            nt_all, h->nt, world, (u64)capacity, (unsigned long long*)h->sh_counts, (u64*)d_req_out, h->sh_req_slot, h->sh_done,
                            h->sh_overflow);
     }
@@ -1069,7 +1072,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->aos);
     (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
-    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all);
+    (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all); (void)hipFree(h->sh_ratio_all);
     (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done); (void)hipFree(h->scal_undo);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     if (h->h_pub) (void)hipHostFree(h->h_pub);

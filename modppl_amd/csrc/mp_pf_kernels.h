@@ -383,6 +383,14 @@ __device__ __forceinline__ double block_tile_table(const double* __restrict__ ti
 }
 // tile-local target of residual r in (0, T] of a tile with totals (W, T):
 // lt = clamp((u64)ceil((double)r * ((double)W / (double)T)), 1, W)
+// (the ratio is a per-tile constant: a table that is built once may carry it — mp_local_target_r — instead of dividing per draw)
+__device__ __forceinline__ u64 mp_local_target_r(u64 r, u64 W, double ratio) {
+    const double v = ceil((double)r * ratio);
+    u64 x = (v >= 1.) ? (u64)v : 1ull;
+    if (x > W) x = W;
+    if (x < 1ull) x = 1ull;
+    return x;
+}
 __device__ __forceinline__ u64 mp_local_target(u64 r, u64 W, u64 T) {
     const double ratio = (double)W / (double)T;
     const double v = ceil((double)r * ratio);
@@ -502,6 +510,17 @@ __device__ __forceinline__ uint32_t tile_of_target(const u64* s_incl, uint32_t n
     while (b < (int)nt - 1 && s_incl[b] < target) ++b;     // ... from either side
     return (uint32_t)b;
 }
+// the same with the per-tile ratios (double)W_b / (double)T_b precomputed (k_shard_table)
+__device__ __forceinline__ void mp_locate_r(const u64* s_incl, const u64* s_W, const double* s_ratio, uint32_t nt, u64 target, double nt_over_Q,
+                                            uint32_t* tile, u64* lt, uint32_t* gslot) {
+    const uint32_t b = tile_of_target(s_incl, nt, target, nt_over_Q);
+    const u64 excl = b ? s_incl[b - 1] : 0ull;
+    const u64 W = s_W[b];
+    const u64 x = mp_local_target_r(target - excl, W, s_ratio[b]);
+    uint32_t g = (uint32_t)(x >> mp_guide_shift(W));
+    if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+    *tile = b; *lt = x; *gslot = b * (uint32_t)GUIDE_N + g;
+}
 // global target -> (tile, tile-local target, guide slot)
 __device__ __forceinline__ void mp_locate(const u64* s_incl, const u64* s_W, uint32_t nt, u64 target, double nt_over_Q, uint32_t* tile, u64* lt,
                                           uint32_t* gslot) {
@@ -616,7 +635,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
                                                            const unsigned short* __restrict__ guide,
                                                            u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row,
                                                            unsigned short* __restrict__ perm, unsigned short* __restrict__ seg_cnt,
-                                                           mp_dev_scalars* scal, const u64* __restrict__ incl_pre) {
+                                                           mp_dev_scalars* scal, const u64* __restrict__ incl_pre,
+                                                           const double* __restrict__ ratio_pre) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = BIN_THREADS / 64;
     const int nt_lds = PREBUILT ? 0 : nt;
@@ -649,7 +669,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
         const u64 i = (u64)c * BIN_CHUNK + (u64)q * BIN_THREADS + threadIdx.x;
         const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
         const u64 k52 = mp_u52(r.a);
-        mp_locate(s_incl, s_W, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
+        if constexpr (PREBUILT) mp_locate_r(s_incl, s_W, ratio_pre, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
+        else mp_locate(s_incl, s_W, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
         bin[q] = (i < n) ? (int)(k52 >> 49) : -1;
         rank_in_wave[q] = 0;
 #pragma unroll

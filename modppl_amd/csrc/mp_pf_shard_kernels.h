@@ -180,7 +180,7 @@ constexpr int SH_BINS = 8;
 constexpr int SH_MAX_KEYS = SH_MAX_WORLD * SH_BINS;
 __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc,
                                                                   int systematic, const u64* __restrict__ incl_all,
-                                                                  const u64* __restrict__ tW_all, int nt_all, int nt_local, int world, u64 capb,
+                                                                  const u64* __restrict__ tW_all, const double* __restrict__ ratio_all, int nt_all, int nt_local, int world, u64 capb,
                                                                   unsigned long long* __restrict__ counts, u64* __restrict__ req_out,
                                                                   uint32_t* __restrict__ inv, unsigned int* done, int* overflow) {
     __shared__ u64 s_base[SH_MAX_KEYS];        // [keys] start inside the sub-segment
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
                 target = mp_target(mp_u52(r.a), Q);
             }
             uint32_t b, gs;
-            mp_locate(s_incl, s_W, (uint32_t)nt_all, target, nt_over_Q, &b, &lt[k], &gs);
+            mp_locate_r(s_incl, s_W, ratio_all, (uint32_t)nt_all, target, nt_over_Q, &b, &lt[k], &gs);
             const uint32_t own = b / (uint32_t)nt_local;
             tl[k] = b - own * (uint32_t)nt_local;
             key[k] = (int)(own * SH_BINS + (tl[k] * SH_BINS) / (uint32_t)nt_local);
@@ -264,8 +264,8 @@ constexpr int SHT_THREADS = 1024;
 constexpr int SHT_PER = MAX_TILES / SHT_THREADS;   // tiles per thread, held in registers (8)
 __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
                                                              double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
-                                                             u64* __restrict__ incl_all, long long* __restrict__ zero_counts,
-                                                             mp_dev_scalars* scal, mp_dev_scalars* undo) {
+                                                             u64* __restrict__ incl_all, double* __restrict__ ratio_all,
+                                                             long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo) {
     __shared__ double s_red[SHT_THREADS / 64];
     __shared__ u64 s_wtot[SHT_THREADS / 64];
     __shared__ u64 s_wtot2[SHT_THREADS / 64];
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
     const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
     const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
     u64 pre[SHT_PER];
+    double ratio[SHT_PER];
     u64 run = 0, run2 = 0;
 #pragma unroll
     for (int j = 0; j < SHT_PER; ++j) {
@@ -312,9 +313,11 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
         if (j < per && i < nt) {
             const double f = ok ? mp_exp(mb[j] - m) : 0.;
             const double f2 = ok ? mp_exp(2. * (mb[j] - m)) : 0.;
-            run += mp_quantize((double)Wb[j] * f * sc, 1.0);
+            const u64 T = mp_quantize((double)Wb[j] * f * sc, 1.0);
+            run += T;
             run2 += mp_quantize((double)W2b[j] * f2 * sc, 1.0);
             pre[j] = run;
+            ratio[j] = (double)Wb[j] / (double)T;   // of mp_local_target; never used for a tile with T = 0 (no target lands in it)
         }
     }
     const u64 incl = wave_incl_scan_u64(run, lane);
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
 #pragma unroll
     for (int j = 0; j < SHT_PER; ++j) {
         const int i = b0 + j;
-        if (j < per && i < nt) incl_all[i] = off + pre[j];
+        if (j < per && i < nt) { incl_all[i] = off + pre[j]; ratio_all[i] = ratio[j]; }
     }
     if (tid == 0) {
         *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
