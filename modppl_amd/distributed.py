@@ -219,13 +219,6 @@ class ShardedParticleSystem:
     def _c(self, t):
         return t if t.device == self.comm_dev else t.to(self.comm_dev)
 
-    def _all_reduce_max(self, t):
-        if self.world > 1 or self._always:
-            c = self._c(t)
-            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
-            if c is not t:
-                t.copy_(c)
-
     def _all_gather(self, out, t):
         if self.world == 1 and not self._always:
             out.copy_(t)
