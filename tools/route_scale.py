@@ -4,11 +4,9 @@ a filter created as rank 0 of `world`, fed a gathered-tiles buffer made of `worl
 import ctypes as C
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
