@@ -199,6 +199,13 @@ enum mp_kernel_family {
 int32_t mp_pf_set_timing(mp_pf* h, int32_t enabled);
 int32_t mp_pf_get_timing(mp_pf* h, int32_t which, double* total_ms, uint64_t* launches);
 
+/* ---- GenFn::simulate over an Unfold model — DynUnfold::simulate, modppl/src/modeling/dynunfold.rs:22-39 ---- */
+/* n independent traces of n_steps kernel calls with EVERY site sampled (the sites that are observations on the filtering
+ * path too): states_out[n][n_steps][dim_state], obs_out[n][n_steps][dim_obs] (host).  Trace i uses Philox slot i, step t.
+ * MP_MODEL_HMM: MP_ERR_UNSUPPORTED (the reference's HMM leaves simulate unimplemented). */
+int32_t mp_unfold_simulate(const mp_model_desc* model, const double* args0, int32_t n_steps, uint64_t n, uint64_t seed, int32_t device,
+                           double* states_out, double* obs_out);
+
 /* ---- importance sampling — modppl/src/inference/importance.rs:12-50 -------------------- */
 /* importance_resampling(model, args, constraints, num_samples, num_ret_samples):
  * N x generate over all n_steps constraints, logsumexp, log_ml = L - ln N, lnw_i = w_i - L,

@@ -71,7 +71,7 @@ struct mp_generate_handler {
     }
     // constrained mvnormal site with hoisted covariance constants (dim K = Model::DIM_OBS slots k..k+K-1)
     template <int SITE, int K>
-    MP_HD void mvnormal_observed(const double* mu, const double* cov_inv, double ln_det) {
+    MP_HD void mvnormal_observed(const double* mu, const double* cov_inv, double ln_det, const double* /*chol: Simulate only*/) {
         constexpr int k = Model::obs_of(SITE);
         static_assert(k >= 0, "mvnormal_observed: the site must be constrained on this path");
         weight += mp_mvnormal_logpdf_pre<K>(obs + k, mu, cov_inv, ln_det);
@@ -108,6 +108,61 @@ struct mp_generate_handler {
             mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
             return mp_uniform_sample(st, a, b);
         }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Simulate-mode handler of DynUnfold::simulate (dynunfold.rs:22-39; sample_at Simulate arm, dyngenfn.rs:104-113): every
+// site is drawn from its distribution, the ones that are observations on the filtering path too (their values go to
+// obs_out in constraint-slot order).  No weight: a simulated trace only has choices.
+// ---------------------------------------------------------------------------------------
+template <class Model>
+struct mp_simulate_handler {
+    mp_stream rng;
+    double* obs_out;
+    MP_HD mp_simulate_handler(const mp_stream& r, double* o) : rng(r), obs_out(o) {}
+
+    template <int SITE>
+    MP_HD double normal(double mu, double sd, double /*ln_sd*/) {
+        mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
+        const double x = mp_normal_sample(st, mu, sd);
+        constexpr int k = Model::obs_of(SITE);
+        if constexpr (k >= 0) obs_out[k] = x;
+        return x;
+    }
+    template <int SITE>
+    MP_HD double normal(double mu, double sd) { return normal<SITE>(mu, sd, 0.); }
+    // mvnormal.random (mvnormal.rs:24-37): L z + mu, z_j ~ normal(0, 1) in index order from the site's stream
+    template <int SITE, int K>
+    MP_HD void mvnormal_observed(const double* mu, const double*, double, const double* chol) {
+        constexpr int k = Model::obs_of(SITE);
+        mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
+        double z[K];
+        for (int j = 0; j < K; ++j) z[j] = mp_normal_sample(st, 0., 1.);
+        for (int i = 0; i < K; ++i) {
+            double acc = 0.;
+            for (int j = 0; j <= i; ++j) acc += chol[i * K + j] * z[j];
+            obs_out[k + i] = acc + mu[i];
+        }
+    }
+    template <int SITE>
+    MP_HD int categorical(const double* probs, int n) {
+        mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
+        const int x = mp_categorical_sample(st, probs, n);
+        constexpr int k = Model::obs_of(SITE);
+        if constexpr (k >= 0) obs_out[k] = (double)x;
+        return x;
+    }
+    template <int SITE>
+    MP_HD void uniform_2d(double xmin, double xmax, double ymin, double ymax, double* out) {
+        const mp_u64x2 b = rng.draw(MP_DOM_MODEL, (uint32_t)SITE, 0u);
+        out[0] = mp_u01(b.a) * (xmax - xmin) + xmin;
+        out[1] = mp_u01(b.b) * (ymax - ymin) + ymin;
+    }
+    template <int SITE>
+    MP_HD double uniform(double a, double b) {
+        mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
+        return mp_uniform_sample(st, a, b);
     }
 };
 
@@ -153,6 +208,7 @@ struct mp_spiral {
     MP_HD uint32_t normal_site(int idx) const { return (uint32_t)idx; }
     double cov_inv[4];
     double ln_det;
+    double chol[4];   // lower Cholesky factor of the covariance, row-major (mvnormal.random in Simulate mode)
 
     template <class H>
     MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
@@ -167,7 +223,7 @@ struct mp_spiral {
             pol1 = prev[1] + dtheta;
         }
         const double pos[2] = {pol0 * mp_cos(pol1), pol0 * mp_sin(pol1)};
-        g.template mvnormal_observed<OBS, 2>(pos, cov_inv, ln_det);
+        g.template mvnormal_observed<OBS, 2>(pos, cov_inv, ln_det, chol);
         next[0] = pol0;
         next[1] = pol1;
     }
@@ -298,13 +354,14 @@ struct mp_pointed2d {
     double xmin, xmax, ymin, ymax;
     double cov_inv[4];
     double ln_det;
+    double chol[4];   // lower Cholesky factor of the covariance, row-major (mvnormal.random in Simulate mode)
 
     template <class H>
     MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
         if (t != 0) { next[0] = prev[0]; next[1] = prev[1]; return; }
         double latent[2];
         g.template uniform_2d<LATENT>(xmin, xmax, ymin, ymax, latent);
-        g.template mvnormal_observed<OBS, 2>(latent, cov_inv, ln_det);
+        g.template mvnormal_observed<OBS, 2>(latent, cov_inv, ln_det, chol);
         next[0] = latent[0];
         next[1] = latent[1];
     }

@@ -98,6 +98,7 @@ struct ModelOps {
     int dim_state = 0, dim_obs = 0;
     virtual ~ModelOps() {}
     virtual void propagate(const PropagateArgs& a) const = 0;
+    virtual void simulate(u64 n, uint32_t k0, uint32_t k1, int n_steps, const mp_state0& s0, double* states, double* obs, hipStream_t st) const = 0;
 };
 template <class Model>
 struct ModelOpsT : ModelOps {
@@ -107,6 +108,9 @@ struct ModelOpsT : ModelOps {
         dim_obs = Model::DIM_OBS;
         static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
         static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
+    }
+    void simulate(u64 n, uint32_t k0, uint32_t k1, int n_steps, const mp_state0& s0, double* states, double* obs, hipStream_t st) const override {
+        hipLaunchKernelGGL(k_simulate<Model>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, model, n, k0, k1, n_steps, s0, states, obs);
     }
     void propagate(const PropagateArgs& a) const override {
         // light kernels (few registers) run 1024 threads x 2 particles per tile: twice the waves in flight for the same 2048-slot tile
@@ -137,6 +141,9 @@ static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out
         if (!mp_host_inverse(cov, 2, inv)) return mp_fail(MP_ERR_INVALID_ARG, "covariance not invertible");
         for (int i = 0; i < 4; ++i) k.cov_inv[i] = inv[i];
         k.ln_det = mp_log(mp_host_det(cov, 2));
+        std::vector<double> L;
+        if (!mp_host_cholesky(cov, 2, L)) return mp_fail(MP_ERR_INVALID_ARG, "covariance not positive definite");
+        for (int i = 0; i < 4; ++i) k.chol[i] = L[i];
         out.reset(new ModelOpsT<mp_spiral>(k));
         return MP_OK;
     }
@@ -201,6 +208,9 @@ static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out
         if (!(det > 0.) || !mp_host_inverse(cov, 2, inv)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_POINTED_2D: covariance must be invertible with a positive determinant");
         for (int i = 0; i < 4; ++i) k.cov_inv[i] = inv[i];
         k.ln_det = mp_log(det);
+        std::vector<double> L;
+        if (!mp_host_cholesky(cov, 2, L)) return mp_fail(MP_ERR_UNSUPPORTED, "MP_MODEL_POINTED_2D: covariance without a Cholesky factor (the reference's eigen fallback is not built)");
+        for (int i = 0; i < 4; ++i) k.chol[i] = L[i];
         out.reset(new ModelOpsT<mp_pointed2d>(k));
         return MP_OK;
     }
@@ -1080,6 +1090,38 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipHostFree(h->h_scal);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    return MP_OK;
+}
+
+// GenFn::simulate over an Unfold model — DynUnfold::simulate (modppl/src/modeling/dynunfold.rs:22-39): n independent traces of
+// n_steps kernel calls, every site sampled (the observation sites too).
+int32_t mp_unfold_simulate(const mp_model_desc* model, const double* args0, int32_t n_steps, uint64_t n, uint64_t seed, int32_t device,
+                           double* states_out, double* obs_out) {
+    if (!model || !states_out || !obs_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (n_steps < 1) return mp_fail(MP_ERR_INVALID_ARG, "assert final_t >= 1 (dynunfold.rs:24)");
+    if (n == 0 || n > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "n must be in [1, 2^32)");
+    if (model->kind == MP_MODEL_HMM) return mp_fail(MP_ERR_UNSUPPORTED, "the reference's HMM has no simulate (tests/hmm/model.rs: unimplemented)");
+    std::unique_ptr<ModelOps> ops;
+    int32_t rc = make_model(model, ops);
+    if (rc != MP_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return mp_fail(MP_ERR_HIP, "no HIP device visible: the gfx950 path has no CPU fallback");
+    }
+    HIPCK(hipSetDevice(device));
+    const size_t nx = (size_t)n * n_steps * ops->dim_state, ny = (size_t)n * n_steps * ops->dim_obs;
+    double *dx = nullptr, *dy = nullptr;
+    HIPCK(hipMalloc(&dx, sizeof(double) * nx));
+    if (hipMalloc(&dy, sizeof(double) * ny) != hipSuccess) { (void)hipFree(dx); return mp_fail(MP_ERR_HIP, "hipMalloc failed"); }
+    mp_state0 s0{};
+    for (int j = 0; j < MP_MAX_STATE; ++j) s0.v[j] = (args0 && j < ops->dim_state) ? args0[j] : 0.;
+    ops->simulate(n, (uint32_t)seed, (uint32_t)(seed >> 32), n_steps, s0, dx, dy, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(states_out, dx, sizeof(double) * nx, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(obs_out, dy, sizeof(double) * ny, hipMemcpyDeviceToHost);
+    (void)hipFree(dx); (void)hipFree(dy);
+    if (e != hipSuccess) return mp_fail(MP_ERR_HIP, std::string("mp_unfold_simulate: ") + hipGetErrorString(e));
     return MP_OK;
 }
 

@@ -226,6 +226,30 @@ __global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* 
     normalize_tile<TILE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
 }
 
+// GenFn::simulate over an Unfold model (dynunfold.rs:22-39): one lane = one trace of n_steps kernel calls, every site
+// sampled.  states[i][t][d], obs[i][t][dim_obs] (particle-major, like everything that crosses the ABI).
+template <class Model>
+__global__ __launch_bounds__(256) void k_simulate(Model model, u64 n, uint32_t k0, uint32_t k1, int n_steps, mp_state0 s0,
+                                                  double* __restrict__ states, double* __restrict__ obs) {
+    constexpr int D = Model::DIM_STATE, DO = Model::DIM_OBS;
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double prev[D], next[D], y[DO];
+    for (int d = 0; d < D; ++d) prev[d] = s0.v[d];
+    mp_stream rng;
+    rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)i;
+    for (int t = 0; t < n_steps; ++t) {
+        rng.step = (uint32_t)t;
+        for (int j = 0; j < DO; ++j) y[j] = 0.;
+        mp_simulate_handler<Model> g(rng, y);
+        model(g, (long long)t, prev, next);
+        double* xs = states + (i * (u64)n_steps + (u64)t) * D;
+        double* ys = obs + (i * (u64)n_steps + (u64)t) * DO;
+        for (int d = 0; d < D; ++d) { xs[d] = next[d]; prev[d] = next[d]; }
+        for (int j = 0; j < DO; ++j) ys[j] = y[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: propagate + weight + level 0 of the normalisation, one workgroup per tile
 // ---------------------------------------------------------------------------------------------

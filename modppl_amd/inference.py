@@ -187,6 +187,20 @@ def _importance(model, model_args, constraints, num_samples, num_ret, seed, devi
     return states, lnw, lml.value, idx
 
 
+def simulate(model, args, n_steps, num_traces, seed, *, device=0):
+    """`model.simulate((n_steps, args))` for `num_traces` independent traces — DynUnfold::simulate
+    (modppl/src/modeling/dynunfold.rs:22-39): every site sampled, the observation sites too.
+    -> (states [num_traces, n_steps, dim_state], observations [num_traces, n_steps, dim_obs])."""
+    L = capi.load()
+    desc = model.desc()
+    xs = np.empty((int(num_traces), int(n_steps), model.dim_state))
+    ys = np.empty((int(num_traces), int(n_steps), model.dim_obs))
+    a = None if args is None else np.ascontiguousarray(args, dtype=np.float64)
+    capi.check(L.mp_unfold_simulate(C.byref(desc), _dptr(a) if a is not None else None, int(n_steps), int(num_traces), int(seed), int(device),
+                                    _dptr(xs), _dptr(ys)))
+    return xs, ys
+
+
 class HierarchicalChains:
     """N independent MH chains over the reference's `hierarchical_model`
     (modppl/tests/dyngenfns/hierarchical.rs:33-47), advanced by the reference's MH entry points:

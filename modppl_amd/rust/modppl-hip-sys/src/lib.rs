@@ -84,6 +84,8 @@ extern "C" {
     // per-kernel-family hipEvent timing (bench)
     pub fn mp_pf_set_timing(h: *mut mp_pf, enabled: i32) -> i32;
     pub fn mp_pf_get_timing(h: *mut mp_pf, family: i32, total_ms: *mut f64, launches: *mut u64) -> i32;
+    pub fn mp_unfold_simulate(model: *const mp_model_desc, args0: *const f64, n_steps: i32, n: u64, seed: u64, device: i32,
+                              states_out: *mut f64, obs_out: *mut f64) -> i32;
     pub fn mp_importance_resampling(model: *const mp_model_desc, args0: *const f64, obs: *const f64, n_steps: i32,
                                     num_samples: u64, num_ret_samples: u64, seed: u64, device: i32,
                                     log_ml_estimate: *mut f64, log_normalized_weights: *mut f64,

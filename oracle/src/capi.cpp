@@ -407,6 +407,50 @@ int32_t oracle_importance_resampling(const mp_model_desc* m, const double* args0
     })
 }
 
+// ---- DynUnfold::simulate (dynunfold.rs:22-39) over n traces: states[n][T][d], obs[n][T][dobs] ------------------------
+int32_t oracle_unfold_simulate(const mp_model_desc* m, const double* args0, int32_t n_steps, uint64_t n, uint64_t seed, int32_t canon,
+                               double* states, double* obs) {
+    GUARD({
+        oracle_pf::Scope scope(canon != 0);
+        auto run = [&](auto& model, auto mk_state, auto put_state, auto read_obs, int d, int dobs) {
+            std::vector<double> z((size_t)d, 0.);
+            for (uint64_t i = 0; i < n; ++i) {
+                Rng r; r.seed = seed; r.slot = (uint32_t)i; r.step = 0;
+                auto tr = model.simulate(r, std::make_pair((int64_t)n_steps, mk_state(args0 ? args0 : z.data())));
+                for (int t = 0; t < n_steps; ++t) {
+                    put_state((*tr.retv)[(size_t)t], states + (i * (uint64_t)n_steps + (uint64_t)t) * (uint64_t)d);
+                    read_obs(tr.data[(size_t)t], obs + (i * (uint64_t)n_steps + (uint64_t)t) * (uint64_t)dobs);
+                }
+            }
+        };
+        auto vec_state = [](int d) { return [d](const double* a) { return Vec(a, a + d); }; };
+        auto vec_put = [](int d) { return [d](const Vec& s_, double* o) { for (int j = 0; j < d; ++j) o[j] = s_[(size_t)j]; }; };
+        if (m->kind == MP_MODEL_LGSSM1) {
+            auto model = make_lgssm_model(LgssmParams{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4]});
+            run(model, [](const double* a) { return a[0]; }, [](const double& s_, double* o) { o[0] = s_; },
+                [](const DynTrie& c, double* o) { o[0] = c.read<double>("y"); }, 1, 1);
+        } else if (m->kind == MP_MODEL_SPIRAL) {
+            auto model = make_spiral_model();
+            run(model, vec_state(2), vec_put(2), [](const DynTrie& c, double* o) { const Vec v = c.read<Vec>("obs"); o[0] = v[0]; o[1] = v[1]; }, 2, 2);
+        } else if (m->kind == MP_MODEL_BEARINGS) {
+            auto model = make_bearings_model(BearingsParams{m->params[0], m->params[1], m->params[2], m->params[3], m->params[4], m->params[5]});
+            run(model, vec_state(4), vec_put(4), [](const DynTrie& c, double* o) { o[0] = c.read<double>("theta"); }, 4, 1);
+        } else if (m->kind == MP_MODEL_LGSSM_BAND) {
+            const int d = (int)m->params[0];
+            auto model = make_lgssm_band_model(BandParams{d, m->params[1], m->params[2], m->params[3], m->params[4], m->params[5]});
+            run(model, vec_state(d), vec_put(d), [d](const DynTrie& c, double* o) { for (int j = 0; j < d; ++j) o[j] = c.read<double>("y/" + std::to_string(j)); }, d, d);
+        } else if (m->kind == MP_MODEL_POINTED_2D) {
+            auto model = make_pointed_unfold(Bounds{m->params[0], m->params[1], m->params[2], m->params[3]}, Mat(2, std::vector<double>(m->params + 4, m->params + 8)));
+            run(model, vec_state(2), vec_put(2), [](const DynTrie& c, double* o) { if (c.search("obs")) { const Vec v = c.read<Vec>("obs"); o[0] = v[0]; o[1] = v[1]; } else { o[0] = o[1] = 0.; } }, 2, 2);
+        } else if (m->kind == MP_MODEL_LINE) {
+            const int dobs = m->n_params;
+            auto model = make_line_unfold(Vec(m->params, m->params + dobs));
+            run(model, vec_state(2), vec_put(2),
+                [dobs](const DynTrie& c, double* o) { for (int j = 0; j < dobs; ++j) o[j] = c.search("ys") ? c.read<double>("ys/" + std::to_string(j)) : 0.; }, 2, dobs);
+        } else throw Panic("simulate: unsupported model kind");
+    })
+}
+
 // ---- mh.rs over N independent chains of hierarchical_model ------------------------------------
 struct oracle_mh {
     Hierarchical hm;

@@ -73,6 +73,7 @@ def load():
     L.oracle_pf_shard_query.argtypes = [p, p, p, p, u64, dp, dp]
     L.oracle_mh_create.argtypes = [dp, dp, i32, i32, u64, u64, i32, C.POINTER(p)]
     L.oracle_mh_step.argtypes = [p, d, i32, C.POINTER(u64)]
+    L.oracle_unfold_simulate.argtypes = [C.POINTER(ModelDesc), dp, i32, u64, u64, i32, dp, dp]
     L.oracle_mh_step_add_or_remove.argtypes = [p, i32, C.POINTER(u64)]
     L.oracle_mh_pointed_create.argtypes = [dp, dp, dp, u64, u64, i32, C.POINTER(p)]
     L.oracle_mh_pointed_step.argtypes = [p, dp, i32, C.POINTER(u64)]
@@ -248,6 +249,20 @@ def importance_resampling(kind, dim_state, dim_obs, params, obs, num_samples, nu
     if rc != 0:
         raise OracleError(rc, L.oracle_last_error().decode())
     return lml.value, lnw, idx, xs
+
+
+def unfold_simulate(kind, dim_state, dim_obs, params, n_steps, n, seed, args0=None, canonical=True):
+    """oracle DynUnfold::simulate over n traces -> (states[n][T][d], obs[n][T][dobs])."""
+    L = load()
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    desc = ModelDesc(kind, dim_state, dim_obs, len(params), dptr(params))
+    xs = np.empty((n, n_steps, dim_state))
+    ys = np.empty((n, n_steps, dim_obs))
+    a = None if args0 is None else dptr(np.ascontiguousarray(args0, dtype=np.float64))
+    rc = L.oracle_unfold_simulate(C.byref(desc), a, n_steps, n, seed, int(canonical), dptr(xs), dptr(ys))
+    if rc != 0:
+        raise OracleError(rc, L.oracle_last_error().decode())
+    return xs, ys
 
 
 class OracleMH:

@@ -170,3 +170,13 @@ def test_full_size_literal_vs_canonical_indices():
         can.step(ys[t:t + 1])
     a, b = lit.log_marginal_likelihood_estimate(), can.log_marginal_likelihood_estimate()
     assert abs(a - b) <= 1e-12 * abs(a)
+
+
+def test_simulate_moments():
+    """DynUnfold::simulate of the checker: every site sampled, the LGSSM's stationary structure in the moments."""
+    xs, ys = O.unfold_simulate(1, 1, 1, O.LGSSM_PARAMS, 4, 40000, 3)
+    assert xs.shape == (40000, 4, 1) and ys.shape == (40000, 4, 1)
+    assert abs(xs[:, 0, 0].std() - 1.0) < 0.02 and abs((ys[:, 0, 0] - xs[:, 0, 0]).std() - 1.0) < 0.02
+    assert abs((xs[:, 1, 0] - 0.9 * xs[:, 0, 0]).std() - 0.5) < 0.01
+    a, b = O.unfold_simulate(1, 1, 1, O.LGSSM_PARAMS, 4, 100, 3)
+    assert np.array_equal(a, xs[:100]) and np.array_equal(b, ys[:100])   # trace i depends on (seed, i) only
