@@ -353,7 +353,8 @@ int32_t mp_mh_create(int32_t model_kind, const double* xs, const double* ys, int
         (void)hipGetLastError();
         return mp_set_error(MP_ERR_HIP, "no HIP device visible: the gfx950 path has no CPU fallback");
     }
-    std::unique_ptr<mp_mh> h(new mp_mh());
+    struct Cleanup { void operator()(mp_mh* p) const { (void)mp_mh_destroy(p); } };   // an early return frees what was allocated so far
+    std::unique_ptr<mp_mh, Cleanup> h(new mp_mh());
     h->n = n_chains; h->seed = seed; h->device = device;
     h->data.n = n_data;
     for (int k = 0; k < MH_MAX_DATA; ++k) { h->data.xs[k] = k < n_data ? xs[k] : 0.; h->data.ys[k] = k < n_data ? ys[k] : 0.; }
@@ -416,7 +417,8 @@ int32_t mp_mh_create_pointed(const double* bounds, const double* obs_cov, const 
     std::vector<double> inv;
     const double det = mp_host_det(cov, 2);
     if (!(det > 0.) || !mp_host_inverse(cov, 2, inv)) return mp_set_error(MP_ERR_INVALID_ARG, "obs covariance must be invertible with a positive determinant");
-    std::unique_ptr<mp_mh> h(new mp_mh());
+    struct Cleanup { void operator()(mp_mh* p) const { (void)mp_mh_destroy(p); } };   // an early return frees what was allocated so far
+    std::unique_ptr<mp_mh, Cleanup> h(new mp_mh());
     h->kind = MP_MH_MODEL_POINTED_2D;
     h->n = n_chains; h->seed = seed; h->device = device;
     pointed_params& P = h->pointed;

@@ -469,7 +469,8 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     *out = nullptr;
     if (n_particles == 0) return mp_fail(MP_ERR_INVALID_ARG, "n_particles must be > 0");
     if (n_particles > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "n_particles must fit u32 parent indices");
-    std::unique_ptr<mp_pf> h(new mp_pf());
+    struct Cleanup { void operator()(mp_pf* p) const { (void)mp_pf_destroy(p); } };   // an early return frees what was allocated so far
+    std::unique_ptr<mp_pf, Cleanup> h(new mp_pf());
     int32_t rc = make_model(model, h->ops);
     if (rc != MP_OK) return rc;
     h->n = n_particles;
