@@ -190,6 +190,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     lml = pf.log_marginal_likelihood_estimate()
+    # ---- supplementary: the same K steps with systematic resampling (named next to multinomial in the north star; not `value`)
+    dt_sys = None
+    if world == 1 and not force_sharded:
+        barrier()
+        t0 = time.perf_counter()
+        for t in range(1 + W, T):
+            pf.step(ys[t:t + 1])
+            pf.resample(scheme=1, sync=False)
+        barrier()
+        dt_sys = time.perf_counter() - t0
     # ---- per-kernel durations: the same K steps again with a hipEvent pair around every launch, recorded on the
     # stream the kernels run on (the pairs cost ~20 us per step, so they stay out of the region `value` is taken from)
     fam = {"propagate": (0.0, 0), "normalize_scan": (0.0, 0), "bin_draws": (0.0, 0), "resample_gather": (0.0, 0)}
@@ -252,6 +262,7 @@ def main():
                        "particles_per_gpu": n, "time_steps_timed": K, "particles_total": n * world,
                        "parallelism": "1 GPU" if world == 1 else f"one filter sharded over {world} GPUs (RCCL all-gather of tile totals + all-to-all particle exchange)"},
             "log_ml": lml,
+            "systematic_resampling_particle_steps_per_s": (n * K / dt_sys) if dt_sys else None,
             "log_ml_abs_err_vs_kalman": abs(lml - kalman),
             "step_bytes_per_particle": BYTES_STEP,
             "step_hbm_frac": BYTES_STEP * n * K / dt / 1e9 / HBM_PEAK_GBPS,
