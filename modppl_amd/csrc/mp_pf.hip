@@ -500,7 +500,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     const int d = h->ops->dim_state;
     h->nt = (int)((n + TILE - 1) / TILE);
     if ((h->n_global + TILE - 1) / TILE > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "at most 2^24 particles per job in this build (tile table in LDS)");
-    h->k3_grid = (int)((n + K3_THREADS * K3_ITEMS - 1) / (K3_THREADS * K3_ITEMS));
+    h->k3_grid = (int)((n + KG_THREADS * KG_ITEMS - 1) / (KG_THREADS * KG_ITEMS));
     if (h->k3_grid > K3_MAX_BLOCKS) h->k3_grid = K3_MAX_BLOCKS;
     h->nchunks = (int)((n + BIN_CHUNK - 1) / BIN_CHUNK);
     {
@@ -534,6 +534,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (need > 48 * 1024) {
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
@@ -617,17 +618,17 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
                                h->seg_cnt, h->cx, h->res_x, h->res_parent);
             binned = true;
         } else if (scheme == MP_RESAMPLE_STRATIFIED) {
-            hipLaunchKernelGGL(k_resample_gather<2>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
+            hipLaunchKernelGGL(k_resample_gather<2>, dim3(h->k3_grid), dim3(KG_THREADS), table_lds(h->nt, KG_THREADS), h->stream, h->n, h->n,
                                h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
                                h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
                                h->scal);
         } else if (scheme == MP_RESAMPLE_SYSTEMATIC) {
-            hipLaunchKernelGGL(k_resample_gather<1>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
+            hipLaunchKernelGGL(k_resample_gather<1>, dim3(h->k3_grid), dim3(KG_THREADS), table_lds(h->nt, KG_THREADS), h->stream, h->n, h->n,
                                h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
                                h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
                                h->scal);
         } else {
-            hipLaunchKernelGGL(k_resample_gather<0>, dim3(h->k3_grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, h->n,
+            hipLaunchKernelGGL(k_resample_gather<0>, dim3(h->k3_grid), dim3(KG_THREADS), table_lds(h->nt, KG_THREADS), h->stream, h->n, h->n,
                                h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
                                h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
                                h->scal);
@@ -1163,8 +1164,8 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
         // importance_resampling: M categorical draws over exp(lnw) (importance.rs:44-47), slot j of DOM_IS
         uint32_t* d_idx = nullptr;
         HIPCK(hipMalloc(&d_idx, sizeof(uint32_t) * num_ret_samples));
-        const int grid = (int)std::min<u64>((num_ret_samples + K3_THREADS * K3_ITEMS - 1) / (K3_THREADS * K3_ITEMS), (u64)K3_MAX_BLOCKS);
-        hipLaunchKernelGGL(k_resample_gather<0>, dim3(grid), dim3(K3_THREADS), table_lds(h->nt, K3_THREADS), h->stream, h->n, (u64)num_ret_samples,
+        const int grid = (int)std::min<u64>((num_ret_samples + KG_THREADS * KG_ITEMS - 1) / (KG_THREADS * KG_ITEMS), (u64)K3_MAX_BLOCKS);
+        hipLaunchKernelGGL(k_resample_gather<0>, dim3(grid), dim3(KG_THREADS), table_lds(h->nt, KG_THREADS), h->stream, h->n, (u64)num_ret_samples,
                            h->n_global, (u64)0, (uint32_t)MP_DOM_IS, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), 0u, h->S, h->ops->dim_state, h->cx,
                            h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, (const double*)nullptr, (double*)nullptr, d_idx, (double*)nullptr,
                            (mp_dev_scalars*)nullptr);

@@ -82,3 +82,23 @@ def test_ess_triggered_resampling(frac):
     assert np.array_equal(pf.log_weights, ref.log_weights())
     assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
     assert (n_res == 0) if frac == 0.0 else (n_res > 0)
+
+
+@pytest.mark.parametrize("scheme", [SYS, STRAT])
+def test_lattice_schemes_beyond_48k_lds(scheme):
+    """2^23 particles = 4096 tiles: the tile table of the single-kernel resample needs more than the default 48 KB of
+    dynamic LDS (every instantiation must have asked for it)."""
+    import modppl_amd
+
+    n = 1 << 23
+    ys = O.lgssm_observations(3)
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, 4)
+    pf.init_step(None, ys[:1])
+    pf.step(ys[1:2])
+    w = pf.log_weights
+    pf.resample(scheme=scheme)
+    par = pf.parents.astype(np.int64)
+    assert par.shape == (n,) and np.all(np.diff(par) >= 0) and par[-1] < n
+    p = np.exp(w - np.logaddexp.reduce(w))
+    counts = np.bincount(par, minlength=n)
+    assert np.all(np.abs(counts - n * p) < (1.0 if scheme == SYS else 2.0) + 1e-6 * n)
