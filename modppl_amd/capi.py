@@ -30,6 +30,7 @@ SYMBOLS = [
     "mp_pf_read_parents", "mp_pf_read_trajectory", "mp_pf_time", "mp_pf_run", "mp_pf_synchronize", "mp_pf_destroy",
     "mp_pf_set_timing", "mp_pf_get_timing", "mp_unfold_simulate", "mp_importance_resampling",
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
+    "mp_pf_shard_owned_count", "mp_pf_shard_owned_expand", "mp_pf_shard_owned_commit",
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
     "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_iterations", "mp_mh_destroy",
     # include/modppl_hip_probe.h
@@ -114,6 +115,9 @@ def load():
     L.mp_pf_shard_resolve_fixed.argtypes = [p, p, i32, u64, p]
     L.mp_pf_shard_commit_fixed.argtypes = [p, p, dp]
     L.mp_pf_shard_query_packed.argtypes = [p, p, i32, dp, dp]
+    L.mp_pf_shard_owned_count.argtypes = [p, i32, p, i32, i32, C.POINTER(u64)]
+    L.mp_pf_shard_owned_expand.argtypes = [p, i32, i32, u64, p, p, u64]
+    L.mp_pf_shard_owned_commit.argtypes = [p, p, dp, C.POINTER(u64)]
     L.mp_pf_shard_tiles.argtypes = [p, p, p, p]
     L.mp_pf_shard_route.argtypes = [p, i32, p, p, p, i32, i32, p, C.POINTER(i64)]
     L.mp_pf_shard_resolve.argtypes = [p, p, u64, p]

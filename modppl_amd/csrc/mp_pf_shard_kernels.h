@@ -174,6 +174,7 @@ struct mp_shard_pub {
     int overflow;
     int degenerate;
     double L;
+    unsigned long long counts[SH_MAX_WORLD];   // "owner keeps" form: offspring per rank of the last resample
 };
 constexpr int SHF_ITEMS = 8;   // draws per thread: 4 / 8 / 16 measured 22.7 / 19.9 / 25.6 us at world 1 and 35.0 / 27.6 / 32.6 us at world 8
 constexpr int SH_BINS = 8;
@@ -265,13 +266,17 @@ constexpr int SHT_PER = MAX_TILES / SHT_THREADS;   // tiles per thread, held in 
 __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
                                                              double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
                                                              u64* __restrict__ incl_all, double* __restrict__ ratio_all,
-                                                             long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo) {
+                                                             long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
+                                                             unsigned long long* __restrict__ zero_call = nullptr, uint32_t* __restrict__ zero_tcnt = nullptr) {
     __shared__ double s_red[SHT_THREADS / 64];
     __shared__ u64 s_wtot[SHT_THREADS / 64];
     __shared__ u64 s_wtot2[SHT_THREADS / 64];
     const int nt = world * nt_local;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SH_MAX_KEYS) zero_counts[tid] = 0;
+    if (zero_call && tid < SH_MAX_WORLD) zero_call[tid] = 0ull;
+    if (zero_tcnt)
+        for (int j = tid; j < nt_local; j += SHT_THREADS) zero_tcnt[j] = 0u;
     // thread t owns tiles t * per .. t * per + per - 1 (consecutive, so that a thread-local running sum is a prefix); each
     // tile is read once, kept in registers, and its unpacked copy written for the kernels that want plain arrays
     const int per = (nt + SHT_THREADS - 1) / SHT_THREADS;   // <= SHT_PER since nt <= MAX_TILES
@@ -424,6 +429,234 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
                 }
             }
         }
+    }
+}
+// ---------------------------------------------------------------------------------------------
+// "Owner keeps" form of the sharded resample.  Every rank enumerates ALL N draws of the job (the draws of the single
+// filter: same Philox counters, same targets), keeps those that land in its own rows and counts them per row; offspring
+// then stay on the rank that owns their parent, in parent order, and only the surplus over n slots travels (to the ranks
+// that drew fewer than n): the xGMI traffic of a resample drops from ~40 B per particle to a few thousand rows.  The
+// multiset of parents is that of the single filter; WHERE an offspring sits depends on the number of ranks.
+//   k_shard_count_owned : draws -> (mine?) -> tile, guide, walk -> cnt[row] += 1, tcnt[tile] += 1; c_all[rank] for every rank
+//   k_shard_expand_owned: counts -> slots (parent order), surplus rows -> send buffer, deficit slots -> rows of the receive buffer
+// ---------------------------------------------------------------------------------------------
+constexpr int SHO_ITEMS = 8;
+__global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme,
+                                                                  const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
+                                                                  const double* __restrict__ ratio_all, int nt_all, int nt_local, int world, int rank,
+                                                                  const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
+                                                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ tcnt,
+                                                                  unsigned long long* __restrict__ c_all) {
+    __shared__ u64 s_bound[SH_MAX_WORLD];       // inclusive prefix of T_b at the end of every rank's tiles
+    __shared__ uint32_t s_above[SH_MAX_WORLD];  // draws of this workgroup whose target lies above s_bound[r]
+    __shared__ u64 s_q[SH_THREADS * SHO_ITEMS]; // targets of this workgroup's draws that land in this rank's range
+    __shared__ uint32_t s_qn, s_live;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int r = tid; r < world; r += SH_THREADS) {
+        s_bound[r] = incl_all[(u64)(r + 1) * nt_local - 1];
+        s_above[r] = 0u;
+    }
+    if (tid == 0) { s_qn = 0u; s_live = 0u; }
+    __syncthreads();
+    const u64 Q = s_bound[world - 1];
+    const u64 lo = rank ? s_bound[rank - 1] : 0ull, hi = s_bound[rank];
+    const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+    const u64 g0 = (u64)blockIdx.x * (SH_THREADS * SHO_ITEMS) + tid;
+    u64 target[SHO_ITEMS];
+    uint32_t nlive = 0;
+#pragma unroll
+    for (int k = 0; k < SHO_ITEMS; ++k) {
+        const u64 g = g0 + (u64)k * SH_THREADS;
+        target[k] = 0ull;   // below every boundary, and never "mine" (targets are >= 1)
+        if (g < n_global) {
+            if (scheme) {
+                target[k] = mp_target_lattice(scheme, g, k32, rc, k0, k1, Q, n_global);
+            } else {
+                const mp_u64x2 r = mp_philox4x32_10((uint32_t)g, rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
+                target[k] = mp_target(mp_u52(r.a), Q);
+            }
+            ++nlive;
+        }
+        // queue the draws of this rank (one LDS atomic per wave and round)
+        const bool mine = target[k] > lo && target[k] <= hi;
+        const u64 bal = __ballot(mine);
+        if (bal) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_qn, (uint32_t)__popcll(bal));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            if (mine) s_q[base + before] = target[k];
+        }
+    }
+    // offspring per rank: (# above the previous boundary) - (# above this one), counted per wave with ballots
+    for (int r = 0; r + 1 < world; ++r) {
+        const u64 B = s_bound[r];
+        uint32_t a = 0;
+#pragma unroll
+        for (int k = 0; k < SHO_ITEMS; ++k) a += (uint32_t)__popcll(__ballot(target[k] > B));
+        if (lane == 0 && a) atomicAdd(&s_above[r], a);
+    }
+    {
+        uint32_t v = nlive;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && v) atomicAdd(&s_live, v);
+    }
+    __syncthreads();
+    for (int r = tid; r < world; r += SH_THREADS) {
+        const uint32_t above_prev = r ? s_above[r - 1] : s_live;
+        const uint32_t above = (r + 1 < world) ? s_above[r] : 0u;
+        if (above_prev > above) atomicAdd(&c_all[r], (unsigned long long)(above_prev - above));
+    }
+    // the queued draws, dense lanes: tile of the target, guide cell, short forward walk (as k_shard_resolve_binned)
+    const uint32_t qn = s_qn;
+    const double nt_over_Q = (double)nt_all / (double)Q;
+    for (uint32_t q = tid; q < qn; q += SH_THREADS) {
+        uint32_t b, gs;
+        u64 lt;
+        mp_locate_r(incl_all, tW_all, ratio_all, (uint32_t)nt_all, s_q[q], nt_over_Q, &b, &lt, &gs);
+        const uint32_t tl = b - (uint32_t)rank * (uint32_t)nt_local;
+        const u64 tbase = (u64)tl * TILE;
+        const u64 tend = tbase + TILE;
+        const u64 last = (tend < n ? tend : n) - 1;
+        const u64 j = tbase + guide[(u64)tl * GUIDE_N + (gs - b * (uint32_t)GUIDE_N)];
+        u64 p = j < last ? j : last;
+        mp_cx cur = cx[p];
+        while (cur.cum < lt && p < last) {
+            ++p;
+            cur = cx[p];
+        }
+        atomicAdd(&cnt[p], 1u);
+        atomicAdd(&tcnt[tl], 1u);
+    }
+}
+
+// the exchange plan: unit u of the surplus (donors in rank order) fills unit u of the deficit (receivers in rank order)
+struct mp_owned_plan {
+    u64 S[SH_MAX_WORLD], D[SH_MAX_WORLD], PS[SH_MAX_WORLD], PD[SH_MAX_WORLD];
+};
+constexpr int SHE_THREADS = 256;
+constexpr int SHE_PER = TILE / SHE_THREADS;
+__global__ __launch_bounds__(SHE_THREADS) void k_shard_expand_owned(u64 n, u64 slot_offset, int D, int world, int rank, u64 cap, u64 recv_rows,
+                                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tcnt,
+                                                                    const unsigned long long* __restrict__ c_all, const double* __restrict__ x,
+                                                                    double* __restrict__ rows, double* __restrict__ send,
+                                                                    uint32_t* __restrict__ inv, int* overflow) {
+    __shared__ mp_owned_plan pl;
+    __shared__ uint32_t s_off[TILE + 1];
+    __shared__ u64 s_part[SHE_THREADS / 64];
+    __shared__ uint32_t s_wtot[SHE_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 b = blockIdx.x;
+    if (tid == 0) {
+        u64 ps = 0, pd = 0;
+        for (int r = 0; r < world; ++r) {
+            const u64 c = c_all[r];
+            pl.S[r] = c > n ? c - n : 0ull;
+            pl.D[r] = c < n ? n - c : 0ull;
+            pl.PS[r] = ps; pl.PD[r] = pd;
+            ps += pl.S[r]; pd += pl.D[r];
+        }
+    }
+    // first slot of this tile's offspring = offspring of the tiles before it
+    u64 part = 0;
+    for (u64 j = tid; j < b; j += SHE_THREADS) part += tcnt[j];
+    part = wave_sum_u64(part);
+    if (lane == 0) s_part[wave] = part;
+    // exclusive scan of the tile's 2048 counts (8 consecutive rows per thread)
+    const u64 row0 = b * TILE + (u64)tid * SHE_PER;
+    uint32_t c[SHE_PER], run = 0;
+#pragma unroll
+    for (int j = 0; j < SHE_PER; ++j) {
+        c[j] = run;
+        run += (row0 + j < n) ? cnt[row0 + j] : 0u;
+    }
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    u64 O = 0;
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SHE_THREADS / 64; ++w) {
+        O += s_part[w];
+        if (w < wave) woff += s_wtot[w];
+        total += s_wtot[w];
+    }
+    const uint32_t off = woff + (incl - run);
+#pragma unroll
+    for (int j = 0; j < SHE_PER; ++j) s_off[tid * SHE_PER + j] = off + c[j];
+    if (tid == 0) s_off[TILE] = total;
+    __syncthreads();
+    const u64 PS_me = pl.PS[rank];
+    if (cap && b == 0) {
+        // every rank must reach the same verdict on "some pair needs more than cap rows" (the collectives that follow are
+        // symmetric), so every rank looks at every pair of the plan, not only at its own
+        for (int pq = tid; pq < world * world; pq += SHE_THREADS) {
+            const int r = pq / world, s2 = pq - r * world;
+            const u64 a0 = pl.PS[r] > pl.PD[s2] ? pl.PS[r] : pl.PD[s2];
+            const u64 e0 = pl.PS[r] + pl.S[r], e1 = pl.PD[s2] + pl.D[s2];
+            const u64 a1 = e0 < e1 ? e0 : e1;
+            if (a1 > a0 && a1 - a0 > cap) atomicOr(overflow, 1);
+        }
+    }
+    for (uint32_t pr = tid; pr < total; pr += SHE_THREADS) {
+        // the row whose run of offspring contains position pr: the last index with s_off[idx] <= pr
+        uint32_t lo = 0, hi = TILE;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_off[mid] <= pr) lo = mid; else hi = mid;
+        }
+        const u64 i = b * TILE + lo;
+        const u64 p = O + pr;
+        double* dst;
+        if (p < n) {
+            dst = rows + (recv_rows + p) * (u64)(D + 1);
+            inv[p] = (uint32_t)(recv_rows + p);
+        } else {
+            const u64 u = PS_me + (p - n);
+            int s = 0;
+            while (s + 1 < world && !(pl.D[s] && u < pl.PD[s] + pl.D[s])) ++s;
+            if (cap) {
+                const u64 first = PS_me > pl.PD[s] ? PS_me : pl.PD[s];
+                const u64 j = u - first;
+                if (j >= cap) { atomicOr(overflow, 1); continue; }
+                dst = send + ((u64)s * cap + j) * (u64)(D + 1);
+            } else {
+                dst = send + (u - PS_me) * (u64)(D + 1);
+            }
+        }
+        for (int d = 0; d < D; ++d) dst[d] = x[i * D + d];
+        dst[D] = (double)(slot_offset + i);
+    }
+    // slots this rank could not fill itself: where in the receive buffer their rows will arrive
+    const u64 c_me = c_all[rank];
+    const u64 PD_me = pl.PD[rank], D_me = pl.D[rank];
+    for (u64 k = b * SHE_THREADS + tid; k < D_me; k += (u64)gridDim.x * SHE_THREADS) {
+        u64 idx = k;
+        if (cap) {
+            const u64 u = PD_me + k;
+            int r = 0;
+            while (r + 1 < world && !(pl.S[r] && u < pl.PS[r] + pl.S[r])) ++r;
+            const u64 first = pl.PS[r] > PD_me ? pl.PS[r] : PD_me;
+            const u64 j = u - first;
+            if (j >= cap) { atomicOr(overflow, 1); idx = 0; }
+            else idx = (u64)r * cap + j;
+        }
+        inv[c_me + k] = (uint32_t)idx;
+    }
+}
+__global__ void k_shard_publish_owned(int* overflow, const mp_dev_scalars* scal, const unsigned long long* c_all, int world, mp_shard_pub* pub) {
+    const int r = threadIdx.x;
+    if (r < world) pub->counts[r] = c_all[r];
+    if (r == 0) {
+        pub->L = scal->L;
+        pub->degenerate = scal->degenerate;
+        pub->overflow = atomicOr(overflow, 0);
     }
 }
 // After the resolve: "somebody overflowed" (flags are only ever OR-ed atomically) and the scalars of this normalisation,

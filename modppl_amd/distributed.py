@@ -13,7 +13,15 @@ more than the capacity (collapsed weights) that resample is repeated with exact 
 all-to-all of counts and a host round trip in the middle.  Host-staged groups (gloo) always use the exact-size form.
 
 Because Philox is keyed by GLOBAL slot and the fixed-point scale is global, the filter's results do not
-depend on the number of shards (tests/test_distributed_cpu.py checks this bit for bit with 2 ranks).
+depend on the number of shards (tests/test_distributed_cpu.py checks this bit for bit with 2 ranks): exchange="exact".
+
+exchange="owned" (the default) is the form that fits point-to-point xGMI: the same N draws, but an offspring stays on the rank
+that owns its parent and only each rank's surplus over its n slots travels (include/modppl_hip.h, "owner keeps"):
+
+    all_gather       24 B/tile  as above
+    all_to_all       f64 rows   the surplus: O(sqrt(N)) rows, fixed capacity per pair (exact sizes after an overflow)
+
+The multiset of parents is the single filter's; which slot an offspring occupies depends on the world size.
 """
 import contextlib
 import ctypes as C
@@ -95,6 +103,30 @@ class HipShardEngine:
         capi.check(code)
         return True, (out.value if want_value else None)
 
+    # "owner keeps" form
+    supports_owned = True
+
+    def shard_owned_count(self, scheme, tiles_all_ptr, world, rank, want_counts=True):
+        counts = (C.c_uint64 * world)()
+        capi.check(self._L.mp_pf_shard_owned_count(self._h, scheme, tiles_all_ptr, world, rank, counts if want_counts else None))
+        return list(counts) if want_counts else None
+
+    def shard_owned_expand(self, world, rank, cap, send_ptr, rows_ptr, recv_rows):
+        capi.check(self._L.mp_pf_shard_owned_expand(self._h, world, rank, cap, send_ptr, rows_ptr, recv_rows))
+
+    def shard_owned_commit(self, rows_ptr, recv_rows, want_value):
+        """-> (committed, log total weight or None, offspring per rank)"""
+        out = C.c_double()
+        counts = (C.c_uint64 * self._L_world())()
+        code = self._L.mp_pf_shard_owned_commit(self._h, rows_ptr, C.byref(out) if want_value else None, counts)
+        if code == capi.MP_ERR_CAPACITY:
+            return False, None, list(counts)
+        capi.check(code)
+        return True, (out.value if want_value else None), list(counts)
+
+    def _L_world(self):
+        return 64
+
     def shard_query_packed(self, tiles_all_ptr, world):
         lml, ess = C.c_double(), C.c_double()
         capi.check(self._L.mp_pf_shard_query_packed(self._h, tiles_all_ptr, world, C.byref(lml), C.byref(ess)))
@@ -159,8 +191,12 @@ class ShardedParticleSystem:
     `host_staging=True` moves the exchanged buffers through host memory (for process groups whose backend
     cannot take device tensors, e.g. gloo with ranks sharing one GPU in tests)."""
 
-    def __init__(self, model, num_particles, seed, *, group=None, engine_cls=HipShardEngine, engine_kwargs=None, host_staging=False):
+    def __init__(self, model, num_particles, seed, *, group=None, engine_cls=HipShardEngine, engine_kwargs=None, host_staging=False,
+                 exchange=None):
         self.group = group
+        self.exchange = exchange or os.environ.get("MP_SHARD_EXCHANGE", "owned")
+        if self.exchange not in ("owned", "exact"):
+            raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "exchange must be 'owned' or 'exact'")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # MP_SHARD_ALWAYS_COLLECTIVE=1: issue the collectives even in a world of one (exercises the backend's API path)
@@ -192,6 +228,20 @@ class ShardedParticleSystem:
         self._fixed = bool(getattr(self.engine, "supports_fixed", False)) and not host_staging \
             and os.environ.get("MP_SHARD_FIXED", "1") == "1"
         self.fallbacks = 0
+        self._owned = self.exchange == "owned"
+        if self._owned and not getattr(self.engine, "supports_owned", False):
+            raise capi.ModpplError(capi.MP_ERR_UNSUPPORTED, "this engine has no owner-keeps exchange")
+        self._host_staging = host_staging
+        self._ow_keep = None
+        if self._owned:
+            # surplus rows per pair of ranks in the equal-split all-to-all: the surplus of a rank is the spread of a
+            # Binomial(N, ~1/world) count plus the imbalance of the shard masses, both O(sqrt) of n
+            self._ow_fixed = self._fixed
+            ocap = max(4096, self.n // 64)
+            self._ow_cap_forced = "MP_SHARD_OWNED_CAP" in os.environ   # tests: force the overflow path
+            self._ow_cap = min(self.n, int(os.environ.get("MP_SHARD_OWNED_CAP", ocap)))
+            if self._ow_fixed:
+                self._alloc_owned(self._ow_cap)
         if self._fixed:
             slack = float(os.environ.get("MP_SHARD_SLACK", "1.25"))
             per = self.n // (min(8, self.nt) * self.world)   # draws per (owner, eighth of the owner's tiles) sub-segment, on average
@@ -202,7 +252,8 @@ class ShardedParticleSystem:
             self.engine.shard_bind_tiles(self._p_tiles)   # the filter keeps its tiles in the tensor the all-gather reads
             w = self.world
             self._p_tiles_all = C.c_void_p(self._tiles.data_ptr() if (w == 1 and not self._always) else self._tiles_all.data_ptr())
-            self._alloc_fixed(cap)
+            if not self._owned:
+                self._alloc_fixed(cap)
 
     def _alloc_fixed(self, cap):
         """exchange buffers for `cap` draws per (owner, eighth) sub-segment"""
@@ -214,6 +265,14 @@ class ShardedParticleSystem:
         self._fx_rows_in = self._fx_rows_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_rows_out)
         self._p_req_out, self._p_req_in = C.c_void_p(self._fx_req_out.data_ptr()), C.c_void_p(self._fx_req_in.data_ptr())
         self._p_rows_out, self._p_rows_in = C.c_void_p(self._fx_rows_out.data_ptr()), C.c_void_p(self._fx_rows_in.data_ptr())
+
+    def _alloc_owned(self, cap):
+        w, d = self.world, self.model.dim_state
+        self._ow_cap = int(cap)
+        self._ow_send = torch.zeros(w * cap * (d + 1), dtype=torch.float64, device=self.dev)
+        # two row buffers, used alternately: the one the previous resample filled is still read by the propagate in flight
+        self._ow_rows = [torch.zeros((w * cap + self.n) * (d + 1), dtype=torch.float64, device=self.dev) for _ in range(2)]
+        self._ow_flip = 0
 
     # ---- collectives (identical for nccl/device tensors and gloo/CPU tensors) ----
     def _c(self, t):
@@ -291,7 +350,65 @@ class ShardedParticleSystem:
             dist.all_to_all_single(self._fx_rows_in, self._fx_rows_out, group=self.group)
         return e.shard_commit_fixed(self._p_rows_in, sync)   # waits for the resolve only; the rows may still be in flight
 
+    @staticmethod
+    def owned_plan(c_all, n):
+        """amount[r][s]: rows rank r sends to rank s when unit u of the surplus fills unit u of the deficit"""
+        w = len(c_all)
+        S = [max(int(c) - n, 0) for c in c_all]
+        D = [max(n - int(c), 0) for c in c_all]
+        PS = [sum(S[:r]) for r in range(w)]
+        PD = [sum(D[:r]) for r in range(w)]
+        return [[max(0, min(PS[r] + S[r], PD[s] + D[s]) - max(PS[r], PD[s])) for s in range(w)] for r in range(w)]
+
+    def _resample_owned(self, scheme, sync):
+        e, w, d = self.engine, self.world, self.model.dim_state
+        p_tiles = C.c_void_p(self._tiles.data_ptr())
+        e.shard_tiles_packed(p_tiles)
+        solo = w == 1 and not self._always
+        if solo:
+            p_tiles_all = p_tiles
+        else:
+            self._all_gather(self._tiles_all, self._tiles)
+            p_tiles_all = C.c_void_p(self._tiles_all.data_ptr())
+        counts = None
+        if self._ow_fixed:
+            # 2 collectives, 3 library calls, one host wait (for the expand, while the surplus rows travel)
+            cap = self._ow_cap
+            rows = self._ow_rows[self._ow_flip]
+            self._ow_flip ^= 1
+            e.shard_owned_count(scheme, p_tiles_all, w, self.rank, want_counts=False)
+            e.shard_owned_expand(w, self.rank, cap, C.c_void_p(self._ow_send.data_ptr()), C.c_void_p(rows.data_ptr()), w * cap)
+            if not solo:
+                dist.all_to_all_single(rows[: w * cap * (d + 1)], self._ow_send, group=self.group)
+            done, value, counts = e.shard_owned_commit(C.c_void_p(rows.data_ptr()), w * cap, sync)
+            if done:
+                return value
+            self.fallbacks += 1      # some pair of ranks exchanges more than cap rows: exact sizes this time
+        else:
+            counts = e.shard_owned_count(scheme, p_tiles_all, w, self.rank, want_counts=True)
+        amount = self.owned_plan(counts[:w], self.n)
+        send_counts = amount[self.rank]
+        recv_counts = [amount[r][self.rank] for r in range(w)]
+        n_send, n_recv = sum(send_counts), sum(recv_counts)
+        send = torch.empty(max(n_send, 1) * (d + 1), dtype=torch.float64, device=self.dev)
+        rows = torch.empty((n_recv + self.n) * (d + 1), dtype=torch.float64, device=self.dev)
+        e.shard_owned_expand(w, self.rank, 0, C.c_void_p(send.data_ptr()), C.c_void_p(rows.data_ptr()), n_recv)
+        if solo or sum(map(sum, amount)) == 0:
+            recv = send          # nobody has a surplus (every rank sees the same counts, so every rank skips the collective)
+        else:
+            recv = self._all_to_all(send, send_counts, recv_counts, d + 1)
+        if n_recv:
+            rows[: n_recv * (d + 1)].copy_(recv[: n_recv * (d + 1)])
+        done, value, _ = e.shard_owned_commit(C.c_void_p(rows.data_ptr()), n_recv, sync)
+        self._ow_keep = (rows, send)   # the next propagate reads its parents' states from `rows`
+        if self._ow_fixed and not self._ow_cap_forced and self._ow_cap < self.n:
+            self.synchronize()
+            self._alloc_owned(min(self.n, max(2 * self._ow_cap, 2 * max(max(a) for a in amount))))
+        return value
+
     def _resample(self, scheme, sync):
+        if self._owned:
+            return self._resample_owned(scheme, sync)
         if self._fixed:
             done, value = self._resample_fixed(scheme, sync)
             if done:

@@ -327,6 +327,17 @@ int32_t oracle_pf_shard_scatter(oracle_pf* h, const double* rows, double* L) {
 int32_t oracle_pf_shard_query(oracle_pf* h, const double* tm_all, const uint64_t* tW_all, const uint64_t* tW2_all, uint64_t nt_all, double* lml, double* ess) {
     GUARD({ oracle_pf::Scope s(true); soa_of(h)->shard_query(tm_all, tW_all, tW2_all, (size_t)nt_all, lml, ess); })
 }
+// "owner keeps" form (mirrors mp_pf_shard_owned_count / _expand / _commit of include/modppl_hip.h)
+int32_t oracle_pf_shard_owned_count(oracle_pf* h, int32_t scheme, const double* tm_all, const uint64_t* tW_all, const uint64_t* tW2_all, uint64_t nt_all,
+                                    int32_t world, int32_t rank, uint64_t* counts) {
+    GUARD({ oracle_pf::Scope s(true); soa_of(h)->scheme = scheme; soa_of(h)->shard_owned_count(tm_all, tW_all, tW2_all, (size_t)nt_all, world, rank, counts); })
+}
+int32_t oracle_pf_shard_owned_expand(oracle_pf* h, int32_t rank, double* send, uint64_t* n_sent) {
+    GUARD({ const uint64_t s = soa_of(h)->shard_owned_expand(rank, send); if (n_sent) *n_sent = s; })
+}
+int32_t oracle_pf_shard_owned_adopt(oracle_pf* h, int32_t rank, const double* recv, uint64_t n_recv, double* L) {
+    GUARD({ const double l = soa_of(h)->shard_owned_adopt(rank, recv, n_recv); if (L) *L = l; })
+}
 
 // ---- importance.rs:12-50 ------------------------------------------------------------------------
 // variant bit 1 = canonical, bit 2 = SoA engine (else the generic importance_resampling over the dynamic DynUnfold).

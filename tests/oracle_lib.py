@@ -71,6 +71,9 @@ def load():
     L.oracle_pf_shard_resolve.argtypes = [p, p, u64, p]
     L.oracle_pf_shard_scatter.argtypes = [p, p, dp]
     L.oracle_pf_shard_query.argtypes = [p, p, p, p, u64, dp, dp]
+    L.oracle_pf_shard_owned_count.argtypes = [p, i32, p, p, p, u64, i32, i32, C.POINTER(u64)]
+    L.oracle_pf_shard_owned_expand.argtypes = [p, i32, p, C.POINTER(u64)]
+    L.oracle_pf_shard_owned_adopt.argtypes = [p, i32, p, u64, dp]
     L.oracle_mh_create.argtypes = [dp, dp, i32, i32, u64, u64, i32, C.POINTER(p)]
     L.oracle_mh_step.argtypes = [p, d, i32, C.POINTER(u64)]
     L.oracle_unfold_simulate.argtypes = [C.POINTER(ModelDesc), dp, i32, u64, u64, i32, dp, dp]
@@ -362,6 +365,37 @@ class OracleShardEngine:
         lml, ess = C.c_double(), C.c_double()
         self._ck(self.L.oracle_pf_shard_query(self.h, tm_ptr, tw_ptr, tw2_ptr, nt_all, C.byref(lml), C.byref(ess)))
         return lml.value, ess.value
+
+    # "owner keeps" form: same method names and arguments as HipShardEngine's (packed = exact-size buffers only here)
+    supports_owned = True
+
+    def shard_tiles_packed(self, tiles_ptr):
+        nt = (self.n + 2047) // 2048
+        b = tiles_ptr.value
+        self._ck(self.L.oracle_pf_shard_tiles(self.h, C.c_void_p(b), C.c_void_p(b + 8 * nt), C.c_void_p(b + 16 * nt)))
+
+    def shard_owned_count(self, scheme, tiles_all_ptr, world, rank, want_counts=True):
+        nt = (self.n + 2047) // 2048
+        g = np.ctypeslib.as_array((C.c_int64 * (world * 3 * nt)).from_address(tiles_all_ptr.value)).reshape(world, 3, nt)
+        tm = np.ascontiguousarray(g[:, 0, :]).reshape(-1)
+        tw = np.ascontiguousarray(g[:, 1, :]).reshape(-1)
+        tw2 = np.ascontiguousarray(g[:, 2, :]).reshape(-1)
+        counts = (C.c_uint64 * world)()
+        self._rank = rank
+        self._ck(self.L.oracle_pf_shard_owned_count(self.h, scheme, C.c_void_p(tm.ctypes.data), C.c_void_p(tw.ctypes.data),
+                                                    C.c_void_p(tw2.ctypes.data), world * nt, world, rank, counts))
+        return list(counts)
+
+    def shard_owned_expand(self, world, rank, cap, send_ptr, rows_ptr, recv_rows):
+        assert cap == 0, "the checker only has the exact-size form"
+        sent = C.c_uint64()
+        self._ck(self.L.oracle_pf_shard_owned_expand(self.h, rank, send_ptr, C.byref(sent)))
+        return sent.value
+
+    def shard_owned_commit(self, rows_ptr, recv_rows, want_value):
+        out = C.c_double()
+        self._ck(self.L.oracle_pf_shard_owned_adopt(self.h, self._rank, rows_ptr, recv_rows, C.byref(out)))
+        return True, (out.value if want_value else None), None
 
     def ess_reference(self):
         out = C.c_double()

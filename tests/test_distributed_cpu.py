@@ -29,7 +29,7 @@ else:
     D = 4
     params = np.array([D, 0.9, 0.05, 1.0, 0.5, 1.0]); model, okind, ds, do = modppl_amd.lgssm_band_model(D), 5, D, D
     obs = np.random.default_rng(1).normal(0, 1.2, size=(T, D))
-pf = ShardedParticleSystem(model, N, seed, engine_cls=O.OracleShardEngine)
+pf = ShardedParticleSystem(model, N, seed, engine_cls=O.OracleShardEngine, exchange="exact")
 ref = O.OraclePF(okind, ds, do, params, N, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA) if rank == 0 else None
 n = N // world
 sl = slice(rank * n, (rank + 1) * n)
@@ -84,3 +84,106 @@ def test_two_rank_filter_equals_single_filter(tmp_path, model, n, t):
     line = [l for l in res.stdout.splitlines() if l.startswith("RESULT")]
     assert line, res.stdout[-2000:] + res.stderr[-2000:]
     assert '"ok": true' in line[0], line[0]
+
+
+# ---- exchange="owned": offspring stay with the owner of their parent, only the surplus travels ----------------------
+OWNED_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["MP_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+dist.init_process_group("gloo")
+import modppl_amd
+from modppl_amd.distributed import ShardedParticleSystem
+from tests import oracle_lib as O
+from tests.owned_ref import OwnedReference
+rank, world = dist.get_rank(), dist.get_world_size()
+N, T, seed = int(os.environ["MP_N"]), int(os.environ["MP_T"]), 78
+scheme = int(os.environ["MP_SCHEME"])
+if os.environ["MP_MODEL"] == "lgssm":
+    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    obs = O.lgssm_observations(T).reshape(T, 1)
+else:
+    model = modppl_amd.lgssm_band_model(4)
+    obs = np.random.default_rng(1).normal(0, 1.2, size=(T, 4))
+pf = ShardedParticleSystem(model, N, seed, engine_cls=O.OracleShardEngine, exchange="owned")
+ref = OwnedReference(model, N, seed, world) if rank == 0 else None
+def gather(a):
+    out = [None] * world
+    dist.all_gather_object(out, a)
+    return np.concatenate(out)
+pf.init_step(None, obs[:1])
+if ref: ref.init_step(None, obs[:1])
+ok, moved = True, 0
+for t in range(1, T):
+    L = pf.resample(scheme)
+    par, x = gather(pf.parents), gather(pf.states())
+    if ref:
+        ok &= L == ref.resample(scheme)
+        ok &= bool(np.array_equal(par, ref.parents())) and bool(np.array_equal(x, ref.states()))
+        moved += sum(max(c - N // world, 0) for c in ref.counts)
+    pf.step(obs[t:t + 1])
+    if ref: ref.step(obs[t:t + 1])
+lw = gather(pf.log_weights)
+lml = pf.log_marginal_likelihood_estimate()
+if ref:
+    ok &= bool(np.array_equal(lw, ref.log_weights()))
+    print("RESULT", json.dumps({"ok": bool(ok), "lml": lml, "moved": int(moved)}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("model,n,t,scheme", [("lgssm", 8192, 8, 0), ("band", 4096, 5, 0), ("lgssm", 4096, 5, 1)])
+def test_two_rank_owner_keeps_exchange(tmp_path, model, n, t, scheme):
+    """gloo, 2 ranks, exact-size all-to-all of the surplus == the same protocol with all shards in one process"""
+    script = tmp_path / "worker.py"
+    script.write_text(OWNED_WORKER)
+    env = dict(os.environ, MP_ROOT=ROOT, MP_MODEL=model, MP_N=str(n), MP_T=str(t), MP_SCHEME=str(scheme), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, res.stdout[-2000:] + res.stderr[-2000:]
+    assert '"ok": true' in line[0], line[0]
+    import json
+    assert json.loads(line[0][len("RESULT"):])["moved"] > 0    # the exchange really carried rows
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_owner_keeps_is_the_single_filters_resample_placed_by_owner(world, scheme):
+    """The parents are the single filter's draws (same multiset); the placement follows the rule of include/modppl_hip.h,
+    restated here with numpy from the single filter's parent vector."""
+    import modppl_amd
+    from tests import oracle_lib as O
+    from tests.owned_ref import OwnedReference, owned_placement
+    N, T, seed = 8192, 4, 5
+    obs = O.lgssm_observations(T).reshape(T, 1)
+    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    one = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, N, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    ref = OwnedReference(model, N, seed, world)
+    one.init_step(obs[:1])
+    ref.init_step(None, obs[:1])
+    assert np.array_equal(one.log_weights(), ref.log_weights())
+    x_before = one.state().reshape(N, 1)
+    L1 = one.resample(scheme)
+    L = ref.resample(scheme)
+    assert L == L1
+    x_exp, par_exp = owned_placement(one.parents(), x_before, N // world, world)
+    assert np.array_equal(ref.parents(), par_exp)
+    assert np.array_equal(ref.states().reshape(N, 1), x_exp)
+    assert np.array_equal(np.sort(ref.parents()), np.sort(one.parents()))
+    assert sum(ref.counts) == N
+
+
+def test_owned_plan_conserves_rows():
+    from modppl_amd.distributed import ShardedParticleSystem as S
+    rng = np.random.default_rng(3)
+    for w in (1, 2, 3, 8):
+        n = 1000
+        for _ in range(50):
+            c = rng.multinomial(n * w, rng.dirichlet(np.ones(w) * rng.choice([0.1, 1, 50])))
+            a = np.array(S.owned_plan(list(c), n))
+            assert np.array_equal(a.sum(1), np.maximum(c - n, 0)) and np.array_equal(a.sum(0), np.maximum(n - c, 0))
+            assert (np.diag(a) == 0).all()
