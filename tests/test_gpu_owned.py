@@ -1,0 +1,252 @@
+"""GPU: the "owner keeps" sharded resample (mp_pf_shard_owned_*): offspring stay with the rank that owns their parent, only the
+surplus travels.  Checked bit for bit against the CPU checker running the same protocol (tests/owned_ref.py), whose placement
+is itself pinned to the single filter's parent vector in tests/test_distributed_cpu.py."""
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from tests.owned_ref import OwnedReference
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(d, T):
+    import modppl_amd
+    if d == 1:
+        return modppl_amd.lgssm_model(*O.LGSSM_PARAMS), O.lgssm_observations(T).reshape(T, 1)
+    return modppl_amd.lgssm_band_model(d), np.random.default_rng(3).normal(0, 1.2, size=(T, d))
+
+
+class _ByHand:
+    """`world` HIP shard engines on the one GPU; the all-gather and the all-to-all are tensor copies."""
+
+    def __init__(self, model, n, world, seed):
+        import torch
+        from modppl_amd.distributed import HipShardEngine
+        self.torch, self.n, self.world, self.d = torch, n, world, model.dim_state
+        self.eng = [HipShardEngine(model, n, n * world, r * n, seed) for r in range(world)]
+        self.dev = self.eng[0].device
+        self.nt = (n + 2047) // 2048
+        self.tiles = [torch.zeros(3 * self.nt, dtype=torch.int64, device=self.dev) for _ in range(world)]
+        self.keep = None
+        self.fallbacks = 0
+
+    def sync(self):
+        for e in self.eng:
+            e.synchronize()
+        self.torch.cuda.synchronize()
+
+    def resample(self, cap, scheme=0):
+        from modppl_amd.distributed import ShardedParticleSystem
+        torch, w, n, d = self.torch, self.world, self.n, self.d
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        z = lambda k: torch.zeros(max(k, 1) * (d + 1), dtype=torch.float64, device=self.dev)
+        for r, e in enumerate(self.eng):
+            e.shard_tiles_packed(ptr(self.tiles[r]))
+        self.sync()
+        tiles_all = torch.cat(self.tiles)
+        counts = None
+        if cap:
+            send = [z(w * cap) for _ in range(w)]
+            rows = [z(w * cap + n) for _ in range(w)]
+            for r, e in enumerate(self.eng):
+                e.shard_owned_count(scheme, ptr(tiles_all), w, r, want_counts=False)
+                e.shard_owned_expand(w, r, cap, ptr(send[r]), ptr(rows[r]), w * cap)
+            self.sync()
+            seg = cap * (d + 1)
+            for s in range(w):
+                rows[s][: w * seg] = torch.cat([send[r][s * seg:(s + 1) * seg] for r in range(w)])
+            torch.cuda.synchronize()
+            res = [e.shard_owned_commit(ptr(rows[r]), w * cap, True) for r, e in enumerate(self.eng)]
+            assert len({done for done, _, _ in res}) == 1           # every rank reaches the same verdict
+            assert all(c[:w] == res[0][2][:w] for _, _, c in res)
+            self.counts = res[0][2][:w]
+            if res[0][0]:
+                self.keep = rows
+                assert all(v == res[0][1] for _, v, _ in res)
+                return res[0][1]
+            self.fallbacks += 1
+            counts = self.counts
+        else:
+            cs = [e.shard_owned_count(scheme, ptr(tiles_all), w, r, want_counts=True) for r, e in enumerate(self.eng)]
+            assert all(c == cs[0] for c in cs)
+            counts = self.counts = cs[0]
+        amount = ShardedParticleSystem.owned_plan(counts, n)
+        n_recv = [sum(amount[r][s] for r in range(w)) for s in range(w)]
+        send = [z(sum(amount[r])) for r in range(w)]
+        rows = [z(n_recv[s] + n) for s in range(w)]
+        for r, e in enumerate(self.eng):
+            e.shard_owned_expand(w, r, 0, ptr(send[r]), ptr(rows[r]), n_recv[r])
+        self.sync()
+        for s in range(w):
+            parts = [send[r][sum(amount[r][:s]) * (d + 1): (sum(amount[r][:s]) + amount[r][s]) * (d + 1)] for r in range(w)]
+            if n_recv[s]:
+                rows[s][: n_recv[s] * (d + 1)] = torch.cat(parts)
+        torch.cuda.synchronize()
+        res = [e.shard_owned_commit(ptr(rows[r]), n_recv[r], True) for r, e in enumerate(self.eng)]
+        assert all(done for done, _, _ in res)
+        self.keep = rows
+        assert all(v == res[0][1] for _, v, _ in res)
+        return res[0][1]
+
+    def cat(self, f):
+        return np.concatenate([f(e) for e in self.eng])
+
+
+@pytest.mark.parametrize("d,world,n,cap,peek,scheme", [
+    (1, 2, 8192, 8192, True, 0),      # equal splits, generous capacity
+    (1, 2, 8192, 8192, False, 0),     # never read states between steps: every propagate reads the exchange buffer
+    (4, 2, 4096, 4096, True, 0),
+    (1, 4, 4096, 0, True, 0),         # exact sizes only
+    (1, 4, 4096, 16, True, 0),        # capacity too small for some pairs: verdict on every rank, repeat with exact sizes
+    (4, 4, 2048, 8, False, 0),
+    (1, 2, 8192, 8192, True, 1),      # systematic
+    (1, 3, 4096, 64, True, 2),        # stratified, odd world
+    (16, 2, 2048, 2048, True, 0),
+])
+def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme):
+    model, obs = _model(d, 7)
+    if d == 1:
+        obs = obs.copy()
+        obs[3] = 6.0          # an observation in the tail: the shard masses differ, the surplus is large
+    N, seed = n * world, 31
+    hip = _ByHand(model, n, world, seed)
+    ref = OwnedReference(model, N, seed, world)
+    for e in hip.eng:
+        e.init_step(None, obs[:1])
+    ref.init_step(None, obs[:1])
+    moved = 0
+    for t in range(1, len(obs)):
+        L = hip.resample(cap, scheme)
+        assert L == ref.resample(scheme)
+        assert list(hip.counts) == list(ref.counts)
+        moved += sum(max(c - n, 0) for c in ref.counts)
+        if peek:
+            assert np.array_equal(hip.cat(lambda e: e.parents()), ref.parents())
+            assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
+        for e in hip.eng:
+            e.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(hip.cat(lambda e: e.log_weights()), ref.log_weights())
+    assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
+    assert moved > 0
+    if cap and cap < 64:
+        assert hip.fallbacks > 0
+
+
+def test_owner_keeps_world_of_one_and_its_law():
+    """One shard (n not a multiple of the tile): sorted placement of the single filter's parents; log-ML stays the filter's."""
+    import modppl_amd
+    from modppl_amd.distributed import ShardedParticleSystem
+    n, seed, T = 300000, 8, 12
+    ys = O.lgssm_observations(T)
+    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    a = modppl_amd.ParticleSystem(model, n, seed)
+    b = ShardedParticleSystem(model, n, seed, exchange="owned")
+    a.init_step(None, ys[:1])
+    b.init_step(None, ys[:1])
+    assert a.resample() == b.resample()
+    assert np.array_equal(np.sort(a.parents), b.parents)          # same multiset, in parent order
+    assert np.array_equal(a.states()[np.argsort(a.parents, kind="stable")], b.states())
+    for t in range(1, T):
+        b.step(ys[t:t + 1])
+        b.resample()
+    assert abs(b.log_marginal_likelihood_estimate() - O.kalman_log_ml(ys)) < 0.05
+
+
+NCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["MP_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import modppl_amd
+from modppl_amd.distributed import ShardedParticleSystem
+from tests import oracle_lib as O
+from tests.owned_ref import OwnedReference
+ys = O.lgssm_observations(6).reshape(6, 1)
+n, seed = 1 << 16, 9
+model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+b = ShardedParticleSystem(model, n, seed, exchange="owned")   # device tensors through RCCL, every collective issued
+ref = OwnedReference(model, n, seed, 1)
+b.init_step(None, ys[:1]); ref.init_step(None, ys[:1])
+ok = True
+for t in range(1, 6):
+    ok &= b.resample() == ref.resample()
+    if t % 2:
+        ok &= bool(np.array_equal(b.parents, ref.parents())) and bool(np.array_equal(b.states(), ref.states()))
+    b.step(ys[t:t + 1]); ref.step(ys[t:t + 1])
+ok &= bool(np.array_equal(b.log_weights, ref.log_weights()))
+print("RESULT ok" if ok else "RESULT mismatch", b.fallbacks)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+GLOO_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["MP_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+dist.init_process_group("gloo")
+import modppl_amd
+from modppl_amd.distributed import ShardedParticleSystem
+from tests import oracle_lib as O
+from tests.owned_ref import OwnedReference
+rank, world = dist.get_rank(), dist.get_world_size()
+N, T, seed = 16384, 7, 5
+model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+obs = O.lgssm_observations(T).reshape(T, 1)
+pf = ShardedParticleSystem(model, N, seed, host_staging=True, exchange="owned")   # both ranks on cuda:0, exact-size exchange
+ref = OwnedReference(model, N, seed, world) if rank == 0 else None
+def gather(a):
+    out = [None] * world
+    dist.all_gather_object(out, a)
+    return np.concatenate(out)
+pf.init_step(None, obs[:1])
+if ref: ref.init_step(None, obs[:1])
+ok = True
+for t in range(1, T):
+    L = pf.resample()
+    par, x = gather(pf.parents), gather(pf.states())
+    if ref:
+        ok &= L == ref.resample()
+        ok &= bool(np.array_equal(par, ref.parents())) and bool(np.array_equal(x, ref.states()))
+    pf.step(obs[t:t + 1])
+    if ref: ref.step(obs[t:t + 1])
+lw = gather(pf.log_weights)
+if ref:
+    ok &= bool(np.array_equal(lw, ref.log_weights()))
+    print("RESULT ok" if ok else "RESULT mismatch")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("which,nproc", [("nccl", 1), ("gloo", 2)])
+def test_owner_keeps_through_process_groups(tmp_path, which, nproc):
+    """RCCL with every collective forced in a world of one (the bench's transport, equal-split all-to-all); two ranks sharing
+    the GPU over gloo with host staging (exact-size all-to-all)."""
+    script = tmp_path / "worker.py"
+    script.write_text(NCCL_WORKER if which == "nccl" else GLOO_WORKER)
+    env = dict(os.environ, MP_ROOT=ROOT, OMP_NUM_THREADS="2")
+    if which == "nccl":
+        env["MP_SHARD_ALWAYS_COLLECTIVE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "RESULT ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]

@@ -23,7 +23,7 @@ def test_world1_sharded_equals_unsharded():
     ys = O.lgssm_observations(10)
     n, seed = 50000, 21
     a = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
-    b = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    b = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed, exchange="exact")
     a.init_step(None, ys[:1])
     b.init_step(None, ys[:1])
     for t in range(1, 10):
@@ -54,7 +54,7 @@ if D == 1:
 else:
     params = np.array([D, 0.9, 0.05, 1.0, 0.5, 1.0]); model, okind = modppl_amd.lgssm_band_model(D), 5
     obs = np.random.default_rng(1).normal(0, 1.2, size=(T, D))
-pf = ShardedParticleSystem(model, N, seed, host_staging=True)   # both ranks on cuda:0
+pf = ShardedParticleSystem(model, N, seed, host_staging=True, exchange="exact")   # both ranks on cuda:0
 ref = O.OraclePF(okind, D, D, params, N, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, threads=4) if rank == 0 else None
 def gather(a):
     out = [None] * world
@@ -114,7 +114,7 @@ from tests import oracle_lib as O
 ys = O.lgssm_observations(6)
 n, seed = 1 << 16, 9
 a = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
-b = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)   # device tensors through RCCL
+b = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed, exchange="exact")   # device tensors through RCCL
 a.init_step(None, ys[:1]); b.init_step(None, ys[:1])
 ok = True
 for t in range(1, 6):
@@ -278,7 +278,7 @@ def test_collapsed_weights_fall_back_and_capacity_grows():
     n, seed = 1 << 16, 13
     ys = np.array([0.1, 9.5, 9.0, 0.3, 0.2])
     a = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
-    b = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    b = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed, exchange="exact")
     cap0 = b.cap
     a.init_step(None, ys[:1])
     b.init_step(None, ys[:1])
