@@ -159,8 +159,9 @@ def main():
         pf = modppl_amd.ParticleSystem(model, n, 20241008, device=local_rank)
         timer = pf
     else:
-        # ONE filter of world*n particles sharded over the ranks: RCCL all-reduce of the log-weight max, all-gather of
-        # the shard totals, all-to-all of the draws and of the parents' states (the particle exchange over xGMI)
+        # ONE filter of world*n particles sharded over the ranks: RCCL all-gather of the tile totals (the weight
+        # "all-reduce"), all-to-all of the parents' states (the particle exchange over xGMI; MP_SHARD_EXCHANGE=owned, the
+        # default, moves only each rank's surplus, =exact keeps slot order and moves (G-1)/G of the particles)
         from modppl_amd.distributed import ShardedParticleSystem
 
         pf = ShardedParticleSystem(model, n * world, 20241008, engine_kwargs={"device_index": local_rank})
@@ -238,7 +239,10 @@ def main():
         traffic = None
         sharded_path = world > 1 or force_sharded
         if sharded_path:   # the sharded filter runs other kernels for the resample
-            KERNEL_OF.update({"bin_draws": "k_shard_route_fused", "resample_gather": "k_shard_resolve_binned"})
+            if getattr(pf, "exchange", "") == "owned":
+                KERNEL_OF.update({"bin_draws": "k_shard_table + k_shard_count_owned", "resample_gather": "k_shard_expand_owned"})
+            else:
+                KERNEL_OF.update({"bin_draws": "k_shard_route_fused", "resample_gather": "k_shard_resolve_binned"})
         if n == N_PER_GPU and os.path.exists(TRAFFIC_JSON) and not (sharded_path and dom != "propagate"):
             # PMC passes cannot run inside this process: committed summary of the same single-GPU workload
             try:
@@ -260,7 +264,8 @@ def main():
             "data": "synthetic (observations simulated from the model, seed 20241008)",
             "config": {"workload": "LGSSM d=1 bootstrap SMC, resample every step (BASELINE.json configs[1])",
                        "particles_per_gpu": n, "time_steps_timed": K, "particles_total": n * world,
-                       "parallelism": "1 GPU" if world == 1 else f"one filter sharded over {world} GPUs (RCCL all-gather of tile totals + all-to-all particle exchange)"},
+                       "parallelism": "1 GPU" if world == 1 else f"one filter sharded over {world} GPUs (RCCL all-gather of tile totals + all-to-all particle exchange)",
+                       "exchange": getattr(pf, "exchange", None)},
             "log_ml": lml,
             "systematic_resampling_particle_steps_per_s": (n * K / dt_sys) if dt_sys else None,
             "log_ml_abs_err_vs_kalman": abs(lml - kalman),

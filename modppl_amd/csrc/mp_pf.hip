@@ -1008,12 +1008,13 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         HIPCK(hipMemsetAsync(h->ow_cnt, 0, sizeof(uint32_t) * h->n, h->stream));
         hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
                            h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo,
-                           h->ow_call, h->ow_tcnt);
+                           h->ow_call, (uint32_t*)nullptr);
         const unsigned nblk = (unsigned)((h->n_global + SH_THREADS * SHO_ITEMS - 1) / (SH_THREADS * SHO_ITEMS));
         hipLaunchKernelGGL(k_shard_count_owned, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, (uint32_t)h->seed,
                            (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all,
                            (const double*)h->sh_ratio_all, nt_all, h->nt, world, rank, (const mp_cx*)h->cx, (const unsigned short*)h->guide, h->ow_cnt,
-                           h->ow_tcnt, h->ow_call);
+                           h->ow_call);
+        hipLaunchKernelGGL(k_shard_tile_counts, dim3(h->nt), dim3(SHE_THREADS_), 0, h->stream, h->n, (const uint32_t*)h->ow_cnt, h->ow_tcnt);
     }
     h->ow_world = world;
     rc = check_launch("shard_owned_count kernels");

@@ -437,16 +437,18 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
 // then stay on the rank that owns their parent, in parent order, and only the surplus over n slots travels (to the ranks
 // that drew fewer than n): the xGMI traffic of a resample drops from ~40 B per particle to a few thousand rows.  The
 // multiset of parents is that of the single filter; WHERE an offspring sits depends on the number of ranks.
-//   k_shard_count_owned : draws -> (mine?) -> tile, guide, walk -> cnt[row] += 1, tcnt[tile] += 1; c_all[rank] for every rank
+//   k_shard_count_owned : draws -> (mine?) -> tile, guide, walk -> cnt[row] += 1; c_all[rank] for every rank
+//   k_shard_tile_counts : tcnt[tile] = sum of cnt over the tile
 //   k_shard_expand_owned: counts -> slots (parent order), surplus rows -> send buffer, deficit slots -> rows of the receive buffer
 // ---------------------------------------------------------------------------------------------
 constexpr int SHO_ITEMS = 8;
+constexpr int SHE_THREADS_ = 256;   // k_shard_tile_counts / k_shard_expand_owned: 8 rows of a tile per thread
+static_assert(TILE / SHE_THREADS_ == 8, "k_shard_tile_counts reads two uint4 per thread");
 __global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme,
                                                                   const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
                                                                   const double* __restrict__ ratio_all, int nt_all, int nt_local, int world, int rank,
                                                                   const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
-                                                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ tcnt,
-                                                                  unsigned long long* __restrict__ c_all) {
+                                                                  uint32_t* __restrict__ cnt, unsigned long long* __restrict__ c_all) {
     __shared__ u64 s_bound[SH_MAX_WORLD];       // inclusive prefix of T_b at the end of every rank's tiles
     __shared__ uint32_t s_above[SH_MAX_WORLD];  // draws of this workgroup whose target lies above s_bound[r]
     __shared__ u64 s_q[SH_THREADS * SHO_ITEMS]; // targets of this workgroup's draws that land in this rank's range
@@ -508,7 +510,10 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_g
         const uint32_t above = (r + 1 < world) ? s_above[r] : 0u;
         if (above_prev > above) atomicAdd(&c_all[r], (unsigned long long)(above_prev - above));
     }
-    // the queued draws, dense lanes: tile of the target, guide cell, short forward walk (as k_shard_resolve_binned)
+    // the queued draws, dense lanes: tile of the target, guide cell, short forward walk (as k_shard_resolve_binned), one atomic
+    // per draw.  Measured for 2^20 own draws (whole count phase, world of one): 72 us as written; 66 with plain stores in place
+    // of the atomics (so the atomics are not the cost: the scattered guide / row lines are); 87 with the draws first binned by
+    // eighth of the rank's tiles and each bin resolved on one XCD; 89 with a thread's 8 entries taken hop by hop.
     const uint32_t qn = s_qn;
     const double nt_over_Q = (double)nt_all / (double)Q;
     for (uint32_t q = tid; q < qn; q += SH_THREADS) {
@@ -527,7 +532,29 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_g
             cur = cx[p];
         }
         atomicAdd(&cnt[p], 1u);
-        atomicAdd(&tcnt[tl], 1u);
+    }
+}
+// offspring per tile (2^20 atomics on the 512 per-tile counters from k_shard_count_owned serialise per address: 350 us; this
+// pass over the 4-byte counts costs a launch)
+__global__ __launch_bounds__(SHE_THREADS_) void k_shard_tile_counts(u64 n, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ tcnt) {
+    __shared__ uint32_t s_w[SHE_THREADS_ / 64];
+    const u64 row0 = (u64)blockIdx.x * TILE + (u64)threadIdx.x * (TILE / SHE_THREADS_);
+    uint32_t v = 0;
+    if (row0 + (TILE / SHE_THREADS_) <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(cnt + row0);
+        const uint4 b = *reinterpret_cast<const uint4*>(cnt + row0 + 4);
+        v = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
+        for (int j = 0; j < TILE / SHE_THREADS_; ++j) v += (row0 + j < n) ? cnt[row0 + j] : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < SHE_THREADS_ / 64; ++w) t += s_w[w];
+        tcnt[blockIdx.x] = t;
     }
 }
 
@@ -535,7 +562,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_g
 struct mp_owned_plan {
     u64 S[SH_MAX_WORLD], D[SH_MAX_WORLD], PS[SH_MAX_WORLD], PD[SH_MAX_WORLD];
 };
-constexpr int SHE_THREADS = 256;
+constexpr int SHE_THREADS = SHE_THREADS_;
 constexpr int SHE_PER = TILE / SHE_THREADS;
 __global__ __launch_bounds__(SHE_THREADS) void k_shard_expand_owned(u64 n, u64 slot_offset, int D, int world, int rank, u64 cap, u64 recv_rows,
                                                                     const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tcnt,

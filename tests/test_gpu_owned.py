@@ -100,22 +100,24 @@ class _ByHand:
         return np.concatenate([f(e) for e in self.eng])
 
 
-@pytest.mark.parametrize("d,world,n,cap,peek,scheme", [
-    (1, 2, 8192, 8192, True, 0),      # equal splits, generous capacity
-    (1, 2, 8192, 8192, False, 0),     # never read states between steps: every propagate reads the exchange buffer
-    (4, 2, 4096, 4096, True, 0),
-    (1, 4, 4096, 0, True, 0),         # exact sizes only
-    (1, 4, 4096, 16, True, 0),        # capacity too small for some pairs: verdict on every rank, repeat with exact sizes
-    (4, 4, 2048, 8, False, 0),
-    (1, 2, 8192, 8192, True, 1),      # systematic
-    (1, 3, 4096, 64, True, 2),        # stratified, odd world
-    (16, 2, 2048, 2048, True, 0),
+@pytest.mark.parametrize("d,world,n,cap,peek,scheme,tail", [
+    (1, 2, 8192, 8192, True, 0, 6.0),      # equal splits, generous capacity
+    (1, 2, 8192, 8192, True, 0, 14.0),     # a handful of particles carry everything: one bin of one rank takes (nearly) all draws
+    (1, 4, 4096, 512, False, 0, 14.0),
+    (1, 2, 8192, 8192, False, 0, 6.0),     # never read states between steps: every propagate reads the exchange buffer
+    (4, 2, 4096, 4096, True, 0, 6.0),
+    (1, 4, 4096, 0, True, 0, 6.0),         # exact sizes only
+    (1, 4, 4096, 16, True, 0, 6.0),        # capacity too small for some pairs: verdict on every rank, repeat with exact sizes
+    (4, 4, 2048, 8, False, 0, 6.0),
+    (1, 2, 8192, 8192, True, 1, 6.0),      # systematic
+    (1, 3, 4096, 64, True, 2, 6.0),        # stratified, odd world
+    (16, 2, 2048, 2048, True, 0, 6.0),
 ])
-def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme):
+def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme, tail):
     model, obs = _model(d, 7)
     if d == 1:
         obs = obs.copy()
-        obs[3] = 6.0          # an observation in the tail: the shard masses differ, the surplus is large
+        obs[3] = tail         # an observation in the tail: the shard masses differ, the surplus is large
     N, seed = n * world, 31
     hip = _ByHand(model, n, world, seed)
     ref = OwnedReference(model, N, seed, world)
