@@ -511,9 +511,11 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_g
         if (above_prev > above) atomicAdd(&c_all[r], (unsigned long long)(above_prev - above));
     }
     // the queued draws, dense lanes: tile of the target, guide cell, short forward walk (as k_shard_resolve_binned), one atomic
-    // per draw.  Measured for 2^20 own draws (whole count phase, world of one): 72 us as written; 66 with plain stores in place
-    // of the atomics (so the atomics are not the cost: the scattered guide / row lines are); 87 with the draws first binned by
-    // eighth of the rank's tiles and each bin resolved on one XCD; 89 with a thread's 8 entries taken hop by hop.
+    // per draw.  Measured for 2^20 own draws (whole count phase, world of one, ablations): 73 us as written; 68 without the
+    // guide / row walk; 63 without the tile lookup either (the atomic goes to a pseudo-random row); 27 without this loop.  So
+    // the 2^20 scattered 4-byte read-modify-writes are half of the phase (plain stores instead: 66), the lookups a seventh.
+    // Tried and not kept: draws first binned by eighth of the rank's tiles, one XCD per bin (87 us); a thread's 8 entries
+    // taken hop by hop (89 us); a second atomic per draw on the 512 per-tile totals (377 us: same-address serialisation).
     const uint32_t qn = s_qn;
     const double nt_over_Q = (double)nt_all / (double)Q;
     for (uint32_t q = tid; q < qn; q += SH_THREADS) {
