@@ -190,25 +190,30 @@ int32_t mp_pf_shard_query_packed(mp_pf* h, const uint64_t* d_tiles_all, int32_t 
  * `traces[i] = traces[parents[i]].clone()` (particle_filter.rs:109-113) treats particles as exchangeable: WHICH slot an
  * offspring lands in carries no meaning.  With iid parents, keeping slot order across G ranks moves (G-1)/G of all
  * particles over the links at every resample.  Here every rank enumerates all N draws of the job (the draws of the single
- * filter: same Philox counters and targets, hence the same multiset of parents), keeps the ones that land in its own rows,
- * and places the offspring on the rank that owns their parent, in parent order; only each rank's surplus over its n slots
- * travels, to the ranks that drew fewer than n: unit u of the job's surplus (donors in rank order, each donor's offspring
- * n, n+1, ... in order) fills unit u of the job's deficit (receivers in rank order, slots c_s, c_s+1, ...).  The traffic
- * is O(sqrt(N)) rows instead of O(N); one collective (all-to-all of rows) instead of two.  The price: slot contents depend
- * on the number of ranks (same law, same parents, different places); results are deterministic for a given (seed, world).
+ * filter: same Philox counters and targets, hence the same parent for every draw g), keeps the ones that land in its own
+ * rows, and places the offspring on the rank that owns their parent, in the order of their draws; only each rank's surplus
+ * over its n slots travels, to the ranks that drew fewer than n: unit u of the job's surplus (donors in rank order, each
+ * donor's offspring n, n+1, ... in order) fills unit u of the job's deficit (receivers in rank order, slots c_s, c_s+1,
+ * ...).  The traffic is O(sqrt(N)) rows instead of O(N); one all-to-all (of rows) instead of two.  The price: slot contents
+ * depend on the number of ranks (same parents, different places; a world of one IS the single filter); results are
+ * deterministic for a given (seed, world).
  *
- *   mp_pf_shard_owned_count   all-gathered packed tiles -> tile table, log-ML fold, offspring per row / tile / rank.
- *                             counts_out (host, [world]) non-null: wait and return the offspring per rank (exact-size form).
- *   mp_pf_shard_owned_expand  offspring -> rows of d_rows ([recv_rows + n][dim_state + 1]: the first recv_rows rows are
+ *   mp_pf_shard_owned_count   all-gathered packed tiles -> tile table, log-ML fold, every rank's offspring count, this
+ *                             rank's own draws in draw order, the exchange plan and — capacity > 0 — the verdict "some pair
+ *                             of ranks exchanges more than `capacity` rows".  counts_out (host, [world]) non-null: wait and
+ *                             return the offspring per rank (exact-size form).
+ *   mp_pf_shard_owned_expand  own draws -> rows of d_rows ([recv_rows + n][dim_state + 1]: the first recv_rows rows are
  *                             where the received surplus arrives, the rest are this rank's own offspring), surplus rows ->
  *                             d_send_out.  capacity > 0: equal splits, d_send_out = [world][capacity] rows, recv_rows =
  *                             world * capacity, pair (r -> s) at [s][j]; capacity == 0: exact sizes, surplus in unit order
  *                             (= destination order), received rows in unit order (= source order).
- *   mp_pf_shard_owned_commit  waits for the expand (not for the exchange), commits as mp_pf_shard_commit_fixed does
- *                             (the next step reads states from d_rows).  MP_ERR_CAPACITY: some pair of ranks needs more
- *                             than `capacity` rows (all ranks reach the same verdict); nothing was committed, counts_out
- *                             holds the offspring per rank, repeat the expand with capacity 0 and exact-size buffers. */
-int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t* counts_out);
+ *   mp_pf_shard_owned_commit  waits for the plan of the count (not for the expand or the exchange: they are ordered before
+ *                             the next step on the filter's stream) and commits as mp_pf_shard_commit_fixed does (the next
+ *                             step reads states from d_rows).  MP_ERR_CAPACITY: the verdict above (all ranks reach the same
+ *                             one); nothing was committed, counts_out holds the offspring per rank, repeat the expand with
+ *                             capacity 0 and exact-size buffers, exchange, commit again. */
+int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
+                                uint64_t* counts_out);
 int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t capacity, double* d_send_out, double* d_rows, uint64_t recv_rows);
 int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_total_weight, uint64_t* counts_out);
 

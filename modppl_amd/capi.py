@@ -115,7 +115,7 @@ def load():
     L.mp_pf_shard_resolve_fixed.argtypes = [p, p, i32, u64, p]
     L.mp_pf_shard_commit_fixed.argtypes = [p, p, dp]
     L.mp_pf_shard_query_packed.argtypes = [p, p, i32, dp, dp]
-    L.mp_pf_shard_owned_count.argtypes = [p, i32, p, i32, i32, C.POINTER(u64)]
+    L.mp_pf_shard_owned_count.argtypes = [p, i32, p, i32, i32, u64, C.POINTER(u64)]
     L.mp_pf_shard_owned_expand.argtypes = [p, i32, i32, u64, p, p, u64]
     L.mp_pf_shard_owned_commit.argtypes = [p, p, dp, C.POINTER(u64)]
     L.mp_pf_shard_tiles.argtypes = [p, p, p, p]

@@ -295,9 +295,12 @@ struct mp_pf {
     u64 sh_rows_cap = 0;
     bool logw_zero = false;         // log-weights are all zero (after a sharded resample) and the buffer has not been cleared
     mp_dev_scalars* scal_undo = nullptr;  // the scalars before a fixed-capacity route folded this resample in
-    uint32_t* ow_cnt = nullptr;           // "owner keeps" form: offspring per row [n], per tile [nt], per rank [SH_MAX_WORLD]
-    uint32_t* ow_tcnt = nullptr;
-    unsigned long long* ow_call = nullptr;
+    u64* ow_gq = nullptr;                 // "owner keeps" form: own targets of every k_shard_own_draws workgroup [ow_nblk][SHO_CHUNK]
+    uint32_t* ow_wgcnt = nullptr;         // own draws per workgroup, and their exclusive scan
+    uint32_t* ow_base = nullptr;
+    unsigned long long* ow_call = nullptr;   // offspring per rank [SH_MAX_WORLD]
+    mp_owned_plan* ow_plan = nullptr;
+    int ow_nblk = 0;
     int ow_world = 0;
     bool sharded = false;
     // ancestry record (MP_PF_RECORD_HISTORY): the event log from which `traces[i].retv` is rebuilt
@@ -980,14 +983,18 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
 
 // ---- "owner keeps" form: offspring stay with the rank that owns their parent; only the surplus travels ----
 static int32_t owned_scratch(mp_pf* h) {
-    if (h->ow_cnt) return MP_OK;
-    HIPCK(hipMalloc(&h->ow_cnt, sizeof(uint32_t) * h->n));
-    HIPCK(hipMalloc(&h->ow_tcnt, sizeof(uint32_t) * (size_t)h->nt));
+    if (h->ow_gq) return MP_OK;
+    h->ow_nblk = (int)((h->n_global + SHO_CHUNK - 1) / SHO_CHUNK);
+    HIPCK(hipMalloc(&h->ow_gq, sizeof(u64) * (size_t)h->ow_nblk * SHO_CHUNK));
+    HIPCK(hipMalloc(&h->ow_wgcnt, sizeof(uint32_t) * (size_t)h->ow_nblk));
+    HIPCK(hipMalloc(&h->ow_base, sizeof(uint32_t) * (size_t)h->ow_nblk));
     HIPCK(hipMalloc(&h->ow_call, sizeof(unsigned long long) * SH_MAX_WORLD));
+    HIPCK(hipMalloc(&h->ow_plan, sizeof(mp_owned_plan)));
     return MP_OK;
 }
 
-int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t* counts_out) {
+int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
+                                uint64_t* counts_out) {
     if (!h || !d_tiles_all) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
     if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC && scheme != MP_RESAMPLE_STRATIFIED)
@@ -1002,26 +1009,24 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     if (rc != MP_OK) return rc;
     rc = owned_scratch(h);
     if (rc != MP_OK) return rc;
-    const int nt_all = h->nt * world;
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        HIPCK(hipMemsetAsync(h->ow_cnt, 0, sizeof(uint32_t) * h->n, h->stream));
         hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
                            h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo,
-                           h->ow_call, (uint32_t*)nullptr);
-        const unsigned nblk = (unsigned)((h->n_global + SH_THREADS * SHO_ITEMS - 1) / (SH_THREADS * SHO_ITEMS));
-        hipLaunchKernelGGL(k_shard_count_owned, dim3(nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all,
-                           (const double*)h->sh_ratio_all, nt_all, h->nt, world, rank, (const mp_cx*)h->cx, (const unsigned short*)h->guide, h->ow_cnt,
                            h->ow_call);
-        hipLaunchKernelGGL(k_shard_tile_counts, dim3(h->nt), dim3(SHE_THREADS_), 0, h->stream, h->n, (const uint32_t*)h->ow_cnt, h->ow_tcnt);
+        hipLaunchKernelGGL(k_shard_own_draws, dim3(h->ow_nblk), dim3(SH_THREADS), 0, h->stream, h->n_global, (uint32_t)h->seed,
+                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, h->nt, world, rank, h->ow_gq,
+                           h->ow_wgcnt, h->ow_call);
+        hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, h->n, world, (u64)capacity, h->ow_nblk,
+                           (const uint32_t*)h->ow_wgcnt, (const unsigned long long*)h->ow_call, (const mp_dev_scalars*)h->scal, h->ow_base, h->ow_plan,
+                           h->d_pub);
     }
     h->ow_world = world;
     rc = check_launch("shard_owned_count kernels");
     if (rc != MP_OK) return rc;
+    HIPCK(hipEventRecord(h->ev_resolved, h->stream));   // mp_pf_shard_owned_commit waits for this: verdict, L and counts are out
     if (counts_out) {
-        hipLaunchKernelGGL(k_shard_publish_owned, dim3(1), dim3(SH_MAX_WORLD), 0, h->stream, h->sh_overflow, h->scal, h->ow_call, world, h->d_pub);
-        HIPCK(hipStreamSynchronize(h->stream));
+        HIPCK(hipEventSynchronize(h->ev_resolved));
         if (h->h_pub->degenerate)
             return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
         for (int r = 0; r < world; ++r) counts_out[r] = h->h_pub->counts[r];
@@ -1031,35 +1036,33 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
 
 int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t capacity, double* d_send_out, double* d_rows, uint64_t recv_rows) {
     if (!h || !d_send_out || !d_rows) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    if (!h->ow_cnt || h->ow_world != world) return mp_fail(MP_ERR_STATE, "shard_owned_expand before shard_owned_count");
+    if (!h->ow_gq || h->ow_world != world) return mp_fail(MP_ERR_STATE, "shard_owned_expand before shard_owned_count");
     if (rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "0 <= rank < world");
     if (capacity && recv_rows != (uint64_t)world * capacity) return mp_fail(MP_ERR_INVALID_ARG, "fixed capacity: recv_rows must be world * capacity");
     if (recv_rows + h->n >= (1ull << 32)) return mp_fail(MP_ERR_INVALID_ARG, "exchange buffer rows must be < 2^32");
     HIPCK(hipSetDevice(h->device));
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_shard_expand_owned, dim3(h->nt), dim3(SHE_THREADS), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank,
-                           (u64)capacity, (u64)recv_rows, (const uint32_t*)h->ow_cnt, (const uint32_t*)h->ow_tcnt, (const unsigned long long*)h->ow_call,
-                           (const double*)h->x[h->cur], d_rows, d_send_out, h->sh_req_slot, h->sh_overflow);
-        hipLaunchKernelGGL(k_shard_publish_owned, dim3(1), dim3(SH_MAX_WORLD), 0, h->stream, h->sh_overflow, h->scal, h->ow_call, world, h->d_pub);
+        hipLaunchKernelGGL(k_shard_own_place, dim3(h->ow_nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank,
+                           h->nt * world, h->nt, (u64)capacity, (u64)recv_rows, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all,
+                           (const double*)h->sh_ratio_all, (const mp_cx*)h->cx, (const unsigned short*)h->guide, (const double*)h->x[h->cur],
+                           (const u64*)h->ow_gq, (const uint32_t*)h->ow_wgcnt, (const uint32_t*)h->ow_base, (const mp_owned_plan*)h->ow_plan,
+                           (const unsigned long long*)h->ow_call, d_rows, d_send_out, h->sh_req_slot);
     }
-    int32_t rc = check_launch("k_shard_expand_owned");
-    if (rc != MP_OK) return rc;
-    HIPCK(hipEventRecord(h->ev_resolved, h->stream));   // mp_pf_shard_owned_commit waits for this, not for the exchange that follows
-    return MP_OK;
+    return check_launch("k_shard_own_place");
 }
 
 int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_total_weight, uint64_t* counts_out) {
     if (!h || !d_rows) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    if (!h->ow_cnt || !h->h_pub) return mp_fail(MP_ERR_STATE, "shard_owned_commit before shard_owned_expand");
+    if (!h->ow_gq || !h->h_pub) return mp_fail(MP_ERR_STATE, "shard_owned_commit before shard_owned_expand");
     HIPCK(hipSetDevice(h->device));
-    HIPCK(hipEventSynchronize(h->ev_resolved));   // the one host wait; the surplus rows may still be travelling
+    HIPCK(hipEventSynchronize(h->ev_resolved));   // the one host wait, for the plan only: the rows may still be written / travelling
     if (counts_out)
         for (int r = 0; r < h->ow_world; ++r) counts_out[r] = h->h_pub->counts[r];
     if (h->h_pub->overflow) {
         // a pair of ranks exchanges more than `capacity` rows (every rank reaches this verdict from the same counts): nothing
-        // is committed; the counts stay valid, the caller repeats the expand with exact sizes (capacity 0)
-        HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
+        // is committed; the own draws stay queued, the caller repeats the expand with exact sizes (capacity 0)
+        h->h_pub->overflow = 0;
         return mp_fail(MP_ERR_CAPACITY, "owner-keeps exchange: a pair of ranks needs more than `capacity` rows; repeat the expand with exact sizes");
     }
     h->sh_rows = d_rows;
@@ -1188,7 +1191,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all); (void)hipFree(h->sh_ratio_all);
     (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done); (void)hipFree(h->scal_undo);
-    (void)hipFree(h->ow_cnt); (void)hipFree(h->ow_tcnt); (void)hipFree(h->ow_call);
+    (void)hipFree(h->ow_gq); (void)hipFree(h->ow_wgcnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     if (h->h_pub) (void)hipHostFree(h->h_pub);
     if (h->ev_resolved) (void)hipEventDestroy(h->ev_resolved);

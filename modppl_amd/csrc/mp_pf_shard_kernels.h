@@ -267,7 +267,7 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
                                                              double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
                                                              u64* __restrict__ incl_all, double* __restrict__ ratio_all,
                                                              long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
-                                                             unsigned long long* __restrict__ zero_call = nullptr, uint32_t* __restrict__ zero_tcnt = nullptr) {
+                                                             unsigned long long* __restrict__ zero_call = nullptr) {
     __shared__ double s_red[SHT_THREADS / 64];
     __shared__ u64 s_wtot[SHT_THREADS / 64];
     __shared__ u64 s_wtot2[SHT_THREADS / 64];
@@ -275,8 +275,6 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SH_MAX_KEYS) zero_counts[tid] = 0;
     if (zero_call && tid < SH_MAX_WORLD) zero_call[tid] = 0ull;
-    if (zero_tcnt)
-        for (int j = tid; j < nt_local; j += SHT_THREADS) zero_tcnt[j] = 0u;
     // thread t owns tiles t * per .. t * per + per - 1 (consecutive, so that a thread-local running sum is a prefix); each
     // tile is read once, kept in registers, and its unpacked copy written for the kernels that want plain arrays
     const int per = (nt + SHT_THREADS - 1) / SHT_THREADS;   // <= SHT_PER since nt <= MAX_TILES
@@ -433,38 +431,42 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
 }
 // ---------------------------------------------------------------------------------------------
 // "Owner keeps" form of the sharded resample.  Every rank enumerates ALL N draws of the job (the draws of the single
-// filter: same Philox counters, same targets), keeps those that land in its own rows and counts them per row; offspring
-// then stay on the rank that owns their parent, in parent order, and only the surplus over n slots travels (to the ranks
-// that drew fewer than n): the xGMI traffic of a resample drops from ~40 B per particle to a few thousand rows.  The
-// multiset of parents is that of the single filter; WHERE an offspring sits depends on the number of ranks.
-//   k_shard_count_owned : draws -> (mine?) -> tile, guide, walk -> cnt[row] += 1; c_all[rank] for every rank
-//   k_shard_tile_counts : tcnt[tile] = sum of cnt over the tile
-//   k_shard_expand_owned: counts -> slots (parent order), surplus rows -> send buffer, deficit slots -> rows of the receive buffer
+// filter: same Philox counters, same targets, hence the same parent for every draw g) and keeps those that land in its own
+// rows; offspring then stay on the rank that owns their parent, in the order of their draws, and only the surplus over n
+// slots travels (to the ranks that drew fewer than n): the xGMI traffic of a resample drops from ~40 B per particle to a
+// few thousand rows.  WHERE an offspring sits depends on the number of ranks (a world of one is the single filter).
+//   k_shard_own_draws : draws -> (mine?) -> this workgroup's own targets, compacted in draw order; offspring per rank (ballots)
+//   k_shard_own_plan  : one workgroup: first offspring position of every k_shard_own_draws workgroup (scan), the exchange
+//                       plan, the verdict "some pair needs more than cap rows", what the host reads
+//   k_shard_own_place : own target -> tile, guide, walk -> row {x, parent id} written at the offspring's position: lane q
+//                       of a workgroup handles its q-th own draw, so positions are consecutive and the writes coalesced.
+// No counting, no scattered writes: a first version counted offspring per row with one atomic per draw and expanded the
+// counts per tile (parent order); its 2^20 scattered 4-byte read-modify-writes alone cost 36 us of a 73 us count phase.
 // ---------------------------------------------------------------------------------------------
 constexpr int SHO_ITEMS = 8;
-constexpr int SHE_THREADS_ = 256;   // k_shard_tile_counts / k_shard_expand_owned: 8 rows of a tile per thread
-static_assert(TILE / SHE_THREADS_ == 8, "k_shard_tile_counts reads two uint4 per thread");
-__global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme,
-                                                                  const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
-                                                                  const double* __restrict__ ratio_all, int nt_all, int nt_local, int world, int rank,
-                                                                  const mp_cx* __restrict__ cx, const unsigned short* __restrict__ guide,
-                                                                  uint32_t* __restrict__ cnt, unsigned long long* __restrict__ c_all) {
+constexpr int SHO_CHUNK = SH_THREADS * SHO_ITEMS;   // draws per k_shard_own_draws workgroup
+__global__ __launch_bounds__(SH_THREADS) void k_shard_own_draws(u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme,
+                                                                const u64* __restrict__ incl_all, int nt_local, int world, int rank,
+                                                                u64* __restrict__ gq, uint32_t* __restrict__ wgcnt,
+                                                                unsigned long long* __restrict__ c_all) {
     __shared__ u64 s_bound[SH_MAX_WORLD];       // inclusive prefix of T_b at the end of every rank's tiles
     __shared__ uint32_t s_above[SH_MAX_WORLD];  // draws of this workgroup whose target lies above s_bound[r]
-    __shared__ u64 s_q[SH_THREADS * SHO_ITEMS]; // targets of this workgroup's draws that land in this rank's range
-    __shared__ uint32_t s_qn, s_live;
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ uint32_t s_wc[SHO_ITEMS][SH_THREADS / 64];   // own draws of (round k, wave w)
+    __shared__ uint32_t s_live;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int r = tid; r < world; r += SH_THREADS) {
         s_bound[r] = incl_all[(u64)(r + 1) * nt_local - 1];
         s_above[r] = 0u;
     }
-    if (tid == 0) { s_qn = 0u; s_live = 0u; }
+    if (tid == 0) s_live = 0u;
     __syncthreads();
     const u64 Q = s_bound[world - 1];
     const u64 lo = rank ? s_bound[rank - 1] : 0ull, hi = s_bound[rank];
     const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
-    const u64 g0 = (u64)blockIdx.x * (SH_THREADS * SHO_ITEMS) + tid;
+    const u64 g0 = (u64)blockIdx.x * SHO_CHUNK + tid;
     u64 target[SHO_ITEMS];
+    uint32_t before[SHO_ITEMS];   // own draws of the same round in lower lanes of this wave
+    bool mine[SHO_ITEMS];
     uint32_t nlive = 0;
 #pragma unroll
     for (int k = 0; k < SHO_ITEMS; ++k) {
@@ -479,16 +481,10 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_g
             }
             ++nlive;
         }
-        // queue the draws of this rank (one LDS atomic per wave and round)
-        const bool mine = target[k] > lo && target[k] <= hi;
-        const u64 bal = __ballot(mine);
-        if (bal) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_qn, (uint32_t)__popcll(bal));
-            base = (uint32_t)__shfl((int)base, 0, 64);
-            if (mine) s_q[base + before] = target[k];
-        }
+        mine[k] = target[k] > lo && target[k] <= hi;
+        const u64 bal = __ballot(mine[k]);
+        before[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (lane == 0) s_wc[k][wave] = (uint32_t)__popcll(bal);
     }
     // offspring per rank: (# above the previous boundary) - (# above this one), counted per wave with ballots
     for (int r = 0; r + 1 < world; ++r) {
@@ -510,73 +506,34 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_count_owned(u64 n, u64 n_g
         const uint32_t above = (r + 1 < world) ? s_above[r] : 0u;
         if (above_prev > above) atomicAdd(&c_all[r], (unsigned long long)(above_prev - above));
     }
-    // the queued draws, dense lanes: tile of the target, guide cell, short forward walk (as k_shard_resolve_binned), one atomic
-    // per draw.  Measured for 2^20 own draws (whole count phase, world of one, ablations): 73 us as written; 68 without the
-    // guide / row walk; 63 without the tile lookup either (the atomic goes to a pseudo-random row); 27 without this loop.  So
-    // the 2^20 scattered 4-byte read-modify-writes are half of the phase (plain stores instead: 66), the lookups a seventh.
-    // Tried and not kept: draws first binned by eighth of the rank's tiles, one XCD per bin (87 us); a thread's 8 entries
-    // taken hop by hop (89 us); a second atomic per draw on the 512 per-tile totals (377 us: same-address serialisation).
-    const uint32_t qn = s_qn;
-    const double nt_over_Q = (double)nt_all / (double)Q;
-    for (uint32_t q = tid; q < qn; q += SH_THREADS) {
-        uint32_t b, gs;
-        u64 lt;
-        mp_locate_r(incl_all, tW_all, ratio_all, (uint32_t)nt_all, s_q[q], nt_over_Q, &b, &lt, &gs);
-        const uint32_t tl = b - (uint32_t)rank * (uint32_t)nt_local;
-        const u64 tbase = (u64)tl * TILE;
-        const u64 tend = tbase + TILE;
-        const u64 last = (tend < n ? tend : n) - 1;
-        const u64 j = tbase + guide[(u64)tl * GUIDE_N + (gs - b * (uint32_t)GUIDE_N)];
-        u64 p = j < last ? j : last;
-        mp_cx cur = cx[p];
-        while (cur.cum < lt && p < last) {
-            ++p;
-            cur = cx[p];
-        }
-        atomicAdd(&cnt[p], 1u);
-    }
-}
-// offspring per tile (2^20 atomics on the 512 per-tile counters from k_shard_count_owned serialise per address: 350 us; this
-// pass over the 4-byte counts costs a launch)
-__global__ __launch_bounds__(SHE_THREADS_) void k_shard_tile_counts(u64 n, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ tcnt) {
-    __shared__ uint32_t s_w[SHE_THREADS_ / 64];
-    const u64 row0 = (u64)blockIdx.x * TILE + (u64)threadIdx.x * (TILE / SHE_THREADS_);
-    uint32_t v = 0;
-    if (row0 + (TILE / SHE_THREADS_) <= n) {
-        const uint4 a = *reinterpret_cast<const uint4*>(cnt + row0);
-        const uint4 b = *reinterpret_cast<const uint4*>(cnt + row0 + 4);
-        v = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-    } else {
-        for (int j = 0; j < TILE / SHE_THREADS_; ++j) v += (row0 + j < n) ? cnt[row0 + j] : 0u;
-    }
+    // compaction in draw order: draw g = chunk + k * 256 + tid, so (round k, wave, lane) ascending IS g ascending
+    u64* q_out = gq + (u64)blockIdx.x * SHO_CHUNK;
+    uint32_t run = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < SHE_THREADS_ / 64; ++w) t += s_w[w];
-        tcnt[blockIdx.x] = t;
+    for (int k = 0; k < SHO_ITEMS; ++k) {
+        uint32_t off = run;
+#pragma unroll
+        for (int w = 0; w < SH_THREADS / 64; ++w) {
+            const uint32_t c = s_wc[k][w];
+            if (w < wave) off += c;
+            run += c;
+        }
+        if (mine[k]) q_out[off + before[k]] = target[k];
     }
+    if (tid == 0) wgcnt[blockIdx.x] = run;
 }
 
 // the exchange plan: unit u of the surplus (donors in rank order) fills unit u of the deficit (receivers in rank order)
 struct mp_owned_plan {
     u64 S[SH_MAX_WORLD], D[SH_MAX_WORLD], PS[SH_MAX_WORLD], PD[SH_MAX_WORLD];
 };
-constexpr int SHE_THREADS = SHE_THREADS_;
-constexpr int SHE_PER = TILE / SHE_THREADS;
-__global__ __launch_bounds__(SHE_THREADS) void k_shard_expand_owned(u64 n, u64 slot_offset, int D, int world, int rank, u64 cap, u64 recv_rows,
-                                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tcnt,
-                                                                    const unsigned long long* __restrict__ c_all, const double* __restrict__ x,
-                                                                    double* __restrict__ rows, double* __restrict__ send,
-                                                                    uint32_t* __restrict__ inv, int* overflow) {
+constexpr int SHP_THREADS = 1024;
+__global__ __launch_bounds__(SHP_THREADS) void k_shard_own_plan(u64 n, int world, u64 cap, int nblk, const uint32_t* __restrict__ wgcnt,
+                                                                const unsigned long long* __restrict__ c_all, const mp_dev_scalars* scal,
+                                                                uint32_t* __restrict__ base, mp_owned_plan* __restrict__ plan_out, mp_shard_pub* pub) {
     __shared__ mp_owned_plan pl;
-    __shared__ uint32_t s_off[TILE + 1];
-    __shared__ u64 s_part[SHE_THREADS / 64];
-    __shared__ uint32_t s_wtot[SHE_THREADS / 64];
+    __shared__ u64 s_wtot[SHP_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 b = blockIdx.x;
     if (tid == 0) {
         u64 ps = 0, pd = 0;
         for (int r = 0; r < world; ++r) {
@@ -585,63 +542,81 @@ __global__ __launch_bounds__(SHE_THREADS) void k_shard_expand_owned(u64 n, u64 s
             pl.D[r] = c < n ? n - c : 0ull;
             pl.PS[r] = ps; pl.PD[r] = pd;
             ps += pl.S[r]; pd += pl.D[r];
+            pub->counts[r] = c;
         }
+        pub->L = scal->L;
+        pub->degenerate = scal->degenerate;
     }
-    // first slot of this tile's offspring = offspring of the tiles before it
-    u64 part = 0;
-    for (u64 j = tid; j < b; j += SHE_THREADS) part += tcnt[j];
-    part = wave_sum_u64(part);
-    if (lane == 0) s_part[wave] = part;
-    // exclusive scan of the tile's 2048 counts (8 consecutive rows per thread)
-    const u64 row0 = b * TILE + (u64)tid * SHE_PER;
-    uint32_t c[SHE_PER], run = 0;
-#pragma unroll
-    for (int j = 0; j < SHE_PER; ++j) {
-        c[j] = run;
-        run += (row0 + j < n) ? cnt[row0 + j] : 0u;
-    }
-    uint32_t incl = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
+    // exclusive scan of the workgroup counts: thread t owns entries [t * per, (t + 1) * per)
+    const int per = (nblk + SHP_THREADS - 1) / SHP_THREADS;
+    const int b0 = tid * per;
+    u64 run = 0;
+    for (int j = 0; j < per; ++j)
+        if (b0 + j < nblk) run += wgcnt[b0 + j];
+    const u64 incl = wave_incl_scan_u64(run, lane);
     if (lane == 63) s_wtot[wave] = incl;
     __syncthreads();
-    u64 O = 0;
-    uint32_t woff = 0, total = 0;
+    u64 woff = 0;
 #pragma unroll
-    for (int w = 0; w < SHE_THREADS / 64; ++w) {
-        O += s_part[w];
+    for (int w = 0; w < SHP_THREADS / 64; ++w)
         if (w < wave) woff += s_wtot[w];
-        total += s_wtot[w];
+    u64 off = woff + (incl - run);
+    for (int j = 0; j < per; ++j) {
+        if (b0 + j < nblk) {
+            base[b0 + j] = (uint32_t)off;
+            off += wgcnt[b0 + j];
+        }
     }
-    const uint32_t off = woff + (incl - run);
-#pragma unroll
-    for (int j = 0; j < SHE_PER; ++j) s_off[tid * SHE_PER + j] = off + c[j];
-    if (tid == 0) s_off[TILE] = total;
-    __syncthreads();
-    const u64 PS_me = pl.PS[rank];
-    if (cap && b == 0) {
-        // every rank must reach the same verdict on "some pair needs more than cap rows" (the collectives that follow are
-        // symmetric), so every rank looks at every pair of the plan, not only at its own
-        for (int pq = tid; pq < world * world; pq += SHE_THREADS) {
+    // every rank must reach the same verdict on "some pair needs more than cap rows" (the collective that follows is symmetric),
+    // so every rank looks at every pair of the plan
+    int over = 0;
+    if (cap) {
+        for (int pq = tid; pq < world * world; pq += SHP_THREADS) {
             const int r = pq / world, s2 = pq - r * world;
             const u64 a0 = pl.PS[r] > pl.PD[s2] ? pl.PS[r] : pl.PD[s2];
             const u64 e0 = pl.PS[r] + pl.S[r], e1 = pl.PD[s2] + pl.D[s2];
             const u64 a1 = e0 < e1 ? e0 : e1;
-            if (a1 > a0 && a1 - a0 > cap) atomicOr(overflow, 1);
+            if (a1 > a0 && a1 - a0 > cap) over = 1;
         }
     }
-    for (uint32_t pr = tid; pr < total; pr += SHE_THREADS) {
-        // the row whose run of offspring contains position pr: the last index with s_off[idx] <= pr
-        uint32_t lo = 0, hi = TILE;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_off[mid] <= pr) lo = mid; else hi = mid;
+    over = __syncthreads_or(over);
+    if (tid == 0) pub->overflow = over;
+    for (int r = tid; r < world; r += SHP_THREADS) {
+        plan_out->S[r] = pl.S[r]; plan_out->D[r] = pl.D[r]; plan_out->PS[r] = pl.PS[r]; plan_out->PD[r] = pl.PD[r];
+    }
+}
+
+__global__ __launch_bounds__(SH_THREADS) void k_shard_own_place(u64 n, u64 slot_offset, int D, int world, int rank, int nt_all, int nt_local, u64 cap,
+                                                                u64 recv_rows, const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
+                                                                const double* __restrict__ ratio_all, const mp_cx* __restrict__ cx,
+                                                                const unsigned short* __restrict__ guide, const double* __restrict__ x,
+                                                                const u64* __restrict__ gq, const uint32_t* __restrict__ wgcnt,
+                                                                const uint32_t* __restrict__ base, const mp_owned_plan* __restrict__ plan,
+                                                                const unsigned long long* __restrict__ c_all, double* __restrict__ rows,
+                                                                double* __restrict__ send, uint32_t* __restrict__ inv) {
+    const int tid = threadIdx.x;
+    const uint32_t qn = wgcnt[blockIdx.x];
+    const u64 p0 = base[blockIdx.x];
+    const u64 Q = incl_all[nt_all - 1];
+    const double nt_over_Q = (double)nt_all / (double)Q;
+    const u64 PS_me = plan->PS[rank];
+    const u64* q_in = gq + (u64)blockIdx.x * SHO_CHUNK;
+    for (uint32_t q = tid; q < qn; q += SH_THREADS) {
+        uint32_t b, gs;
+        u64 lt;
+        mp_locate_r(incl_all, tW_all, ratio_all, (uint32_t)nt_all, q_in[q], nt_over_Q, &b, &lt, &gs);
+        const uint32_t tl = b - (uint32_t)rank * (uint32_t)nt_local;
+        const u64 tbase = (u64)tl * TILE;
+        const u64 tend = tbase + TILE;
+        const u64 last = (tend < n ? tend : n) - 1;
+        const u64 j = tbase + guide[(u64)tl * GUIDE_N + (gs - b * (uint32_t)GUIDE_N)];
+        u64 i = j < last ? j : last;
+        mp_cx cur = cx[i];
+        while (cur.cum < lt && i < last) {
+            ++i;
+            cur = cx[i];
         }
-        const u64 i = b * TILE + lo;
-        const u64 p = O + pr;
+        const u64 p = p0 + q;
         double* dst;
         if (p < n) {
             dst = rows + (recv_rows + p) * (u64)(D + 1);
@@ -649,43 +624,37 @@ __global__ __launch_bounds__(SHE_THREADS) void k_shard_expand_owned(u64 n, u64 s
         } else {
             const u64 u = PS_me + (p - n);
             int s = 0;
-            while (s + 1 < world && !(pl.D[s] && u < pl.PD[s] + pl.D[s])) ++s;
+            while (s + 1 < world && !(plan->D[s] && u < plan->PD[s] + plan->D[s])) ++s;
             if (cap) {
-                const u64 first = PS_me > pl.PD[s] ? PS_me : pl.PD[s];
-                const u64 j = u - first;
-                if (j >= cap) { atomicOr(overflow, 1); continue; }
-                dst = send + ((u64)s * cap + j) * (u64)(D + 1);
+                const u64 first = PS_me > plan->PD[s] ? PS_me : plan->PD[s];
+                const u64 jj = u - first;
+                if (jj >= cap) continue;   // k_shard_own_plan has flagged it: nothing of this attempt is committed
+                dst = send + ((u64)s * cap + jj) * (u64)(D + 1);
             } else {
                 dst = send + (u - PS_me) * (u64)(D + 1);
             }
         }
-        for (int d = 0; d < D; ++d) dst[d] = x[i * D + d];
-        dst[D] = (double)(slot_offset + i);
+        if (D == 1) {
+            *reinterpret_cast<double2*>(dst) = make_double2(cur.x0, (double)(slot_offset + i));
+        } else {
+            for (int d = 0; d < D; ++d) dst[d] = x[i * D + d];
+            dst[D] = (double)(slot_offset + i);
+        }
     }
     // slots this rank could not fill itself: where in the receive buffer their rows will arrive
     const u64 c_me = c_all[rank];
-    const u64 PD_me = pl.PD[rank], D_me = pl.D[rank];
-    for (u64 k = b * SHE_THREADS + tid; k < D_me; k += (u64)gridDim.x * SHE_THREADS) {
+    const u64 PD_me = plan->PD[rank], D_me = plan->D[rank];
+    for (u64 k = (u64)blockIdx.x * SH_THREADS + tid; k < D_me; k += (u64)gridDim.x * SH_THREADS) {
         u64 idx = k;
         if (cap) {
             const u64 u = PD_me + k;
             int r = 0;
-            while (r + 1 < world && !(pl.S[r] && u < pl.PS[r] + pl.S[r])) ++r;
-            const u64 first = pl.PS[r] > PD_me ? pl.PS[r] : PD_me;
-            const u64 j = u - first;
-            if (j >= cap) { atomicOr(overflow, 1); idx = 0; }
-            else idx = (u64)r * cap + j;
+            while (r + 1 < world && !(plan->S[r] && u < plan->PS[r] + plan->S[r])) ++r;
+            const u64 first = plan->PS[r] > PD_me ? plan->PS[r] : PD_me;
+            const u64 jj = u - first;
+            idx = jj >= cap ? 0ull : (u64)r * cap + jj;
         }
         inv[c_me + k] = (uint32_t)idx;
-    }
-}
-__global__ void k_shard_publish_owned(int* overflow, const mp_dev_scalars* scal, const unsigned long long* c_all, int world, mp_shard_pub* pub) {
-    const int r = threadIdx.x;
-    if (r < world) pub->counts[r] = c_all[r];
-    if (r == 0) {
-        pub->L = scal->L;
-        pub->degenerate = scal->degenerate;
-        pub->overflow = atomicOr(overflow, 0);
     }
 }
 // After the resolve: "somebody overflowed" (flags are only ever OR-ed atomically) and the scalars of this normalisation,

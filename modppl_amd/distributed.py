@@ -106,9 +106,9 @@ class HipShardEngine:
     # "owner keeps" form
     supports_owned = True
 
-    def shard_owned_count(self, scheme, tiles_all_ptr, world, rank, want_counts=True):
+    def shard_owned_count(self, scheme, tiles_all_ptr, world, rank, cap=0, want_counts=True):
         counts = (C.c_uint64 * world)()
-        capi.check(self._L.mp_pf_shard_owned_count(self._h, scheme, tiles_all_ptr, world, rank, counts if want_counts else None))
+        capi.check(self._L.mp_pf_shard_owned_count(self._h, scheme, tiles_all_ptr, world, rank, cap, counts if want_counts else None))
         return list(counts) if want_counts else None
 
     def shard_owned_expand(self, world, rank, cap, send_ptr, rows_ptr, recv_rows):
@@ -372,11 +372,11 @@ class ShardedParticleSystem:
             p_tiles_all = C.c_void_p(self._tiles_all.data_ptr())
         counts = None
         if self._ow_fixed:
-            # 2 collectives, 3 library calls, one host wait (for the expand, while the surplus rows travel)
+            # 2 collectives, 3 library calls, one host wait (for the plan, while the rows are written and travel)
             cap = self._ow_cap
             rows = self._ow_rows[self._ow_flip]
             self._ow_flip ^= 1
-            e.shard_owned_count(scheme, p_tiles_all, w, self.rank, want_counts=False)
+            e.shard_owned_count(scheme, p_tiles_all, w, self.rank, cap, want_counts=False)
             e.shard_owned_expand(w, self.rank, cap, C.c_void_p(self._ow_send.data_ptr()), C.c_void_p(rows.data_ptr()), w * cap)
             if not solo:
                 dist.all_to_all_single(rows[: w * cap * (d + 1)], self._ow_send, group=self.group)
@@ -385,7 +385,7 @@ class ShardedParticleSystem:
                 return value
             self.fallbacks += 1      # some pair of ranks exchanges more than cap rows: exact sizes this time
         else:
-            counts = e.shard_owned_count(scheme, p_tiles_all, w, self.rank, want_counts=True)
+            counts = e.shard_owned_count(scheme, p_tiles_all, w, self.rank, 0, want_counts=True)
         amount = self.owned_plan(counts[:w], self.n)
         send_counts = amount[self.rank]
         recv_counts = [amount[r][self.rank] for r in range(w)]

@@ -81,7 +81,7 @@ extern "C" {
     pub fn mp_pf_shard_resolve_fixed(h: *mut mp_pf, d_req_in: *const u64, world: i32, capacity: u64, d_rows_out: *mut f64) -> i32;
     pub fn mp_pf_shard_commit_fixed(h: *mut mp_pf, d_rows_in: *const f64, log_total_weight: *mut f64) -> i32;
     pub fn mp_pf_shard_query_packed(h: *mut mp_pf, d_tiles_all: *const u64, world: i32, log_ml: *mut f64, ess: *mut f64) -> i32;
-    pub fn mp_pf_shard_owned_count(h: *mut mp_pf, scheme: i32, d_tiles_all: *const u64, world: i32, rank: i32, counts_out: *mut u64) -> i32;
+    pub fn mp_pf_shard_owned_count(h: *mut mp_pf, scheme: i32, d_tiles_all: *const u64, world: i32, rank: i32, capacity: u64, counts_out: *mut u64) -> i32;
     pub fn mp_pf_shard_owned_expand(h: *mut mp_pf, world: i32, rank: i32, capacity: u64, d_send_out: *mut f64, d_rows: *mut f64, recv_rows: u64) -> i32;
     pub fn mp_pf_shard_owned_commit(h: *mut mp_pf, d_rows: *const f64, log_total_weight: *mut f64, counts_out: *mut u64) -> i32;
     // per-kernel-family hipEvent timing (bench)

@@ -351,19 +351,19 @@ struct SoaPf {
     }
 
     // ---- "owner keeps" form of the sharded resample (mirrors mp_pf_shard_owned_* of include/modppl_hip.h) ----
-    // The N draws are those of the single filter (same Philox counters, same targets, hence the same MULTISET of
-    // parents as particle_filter.rs:37-41 over the whole population); what changes is where an offspring is put: it stays
-    // on the rank that owns its parent, in parent order, and only the surplus over n slots travels to ranks that drew
-    // fewer than n.  Unit u of the job's surplus (donors in rank order, each donor's offspring n, n+1, ... in order)
-    // fills unit u of the job's deficit (receivers in rank order, each receiver's slots c_s, c_s+1, ... in order).
-    std::vector<uint32_t> sh_cnt;        // offspring per local row
+    // The N draws are those of the single filter (same Philox counters, same targets, hence the same parent for every
+    // draw g as particle_filter.rs:37-41 over the whole population); what changes is where an offspring is put: it stays
+    // on the rank that owns its parent.  A rank's offspring, in the order of their draws g, fill its slots 0, 1, ...; what
+    // exceeds n slots is its surplus.  Unit u of the job's surplus (donors in rank order, each donor's offspring n, n+1,
+    // ... in order) fills unit u of the job's deficit (receivers in rank order, each receiver's slots c_s, c_s+1, ...).
+    std::vector<uint32_t> sh_own;        // local parent row of every own offspring, in draw order
     std::vector<uint64_t> sh_call;       // offspring per rank
     void shard_owned_count(const double* tm_all, const uint64_t* tW_all, const uint64_t* tW2_all, size_t nt_all, int world, int rank,
                            uint64_t* c_all) {
         shard_combine(tm_all, tW_all, tW2_all, nt_all);
         if (sh_c.degenerate()) throw Panic("all log-weights are -inf");
         const size_t nt_local = nt_all / (size_t)world;
-        sh_cnt.assign(n, 0);
+        sh_own.clear();
         sh_call.assign((size_t)world, 0);
         for (uint64_t g = 0; g < n_global; ++g) {
             Rng r; r.seed = seed; r.slot = (uint32_t)g; r.step = resample_count; r.at(DOM_RESAMPLE, 0);
@@ -373,28 +373,27 @@ struct SoaPf {
             canonical_locate(sh_c, target, &tile, &lt);
             const int own = (int)(tile / nt_local);
             sh_call[(size_t)own] += 1;
-            if (own == rank) sh_cnt[canonical_row(sh_t.cum, tile % nt_local, lt)] += 1;
+            if (own == rank) sh_own.push_back((uint32_t)canonical_row(sh_t.cum, tile % nt_local, lt));
         }
         for (int r = 0; r < world; ++r) c_all[r] = sh_call[(size_t)r];
         ess_stale = sh_c.ess;
         log_ml += sh_c.L - o_ln((double)n_global);
     }
-    // slots [0, min(c, n)) <- own offspring in parent order; the surplus rows {x[0..d), global parent id} in unit order to `send`
+    // slots [0, min(c, n)) <- own offspring in draw order; the surplus rows {x[0..d), global parent id} in unit order to `send`
     // (its length is max(c - n, 0)); returns the number of rows written to `send`
     uint64_t shard_owned_expand(int rank, double* send) {
         const int d = model->dim_state;
-        uint64_t p = 0, sent = 0;
+        uint64_t sent = 0;
         (void)rank;
-        for (size_t i = 0; i < n; ++i) {
-            for (uint32_t k = 0; k < sh_cnt[i]; ++k, ++p) {
-                if (p < n) {
-                    for (int j = 0; j < d; ++j) x_tmp[p * d + j] = x[i * d + j];
-                    parents[p] = (uint32_t)(slot_offset + i);
-                } else {
-                    for (int j = 0; j < d; ++j) send[sent * (uint64_t)(d + 1) + j] = x[i * d + j];
-                    send[sent * (uint64_t)(d + 1) + d] = (double)(slot_offset + i);
-                    ++sent;
-                }
+        for (size_t p = 0; p < sh_own.size(); ++p) {
+            const size_t i = sh_own[p];
+            if (p < n) {
+                for (int j = 0; j < d; ++j) x_tmp[p * d + j] = x[i * d + j];
+                parents[p] = (uint32_t)(slot_offset + i);
+            } else {
+                for (int j = 0; j < d; ++j) send[sent * (uint64_t)(d + 1) + j] = x[i * d + j];
+                send[sent * (uint64_t)(d + 1) + d] = (double)(slot_offset + i);
+                ++sent;
             }
         }
         return sent;

@@ -374,7 +374,7 @@ class OracleShardEngine:
         b = tiles_ptr.value
         self._ck(self.L.oracle_pf_shard_tiles(self.h, C.c_void_p(b), C.c_void_p(b + 8 * nt), C.c_void_p(b + 16 * nt)))
 
-    def shard_owned_count(self, scheme, tiles_all_ptr, world, rank, want_counts=True):
+    def shard_owned_count(self, scheme, tiles_all_ptr, world, rank, cap=0, want_counts=True):
         nt = (self.n + 2047) // 2048
         g = np.ctypeslib.as_array((C.c_int64 * (world * 3 * nt)).from_address(tiles_all_ptr.value)).reshape(world, 3, nt)
         tm = np.ascontiguousarray(g[:, 0, :]).reshape(-1)

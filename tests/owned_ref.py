@@ -12,9 +12,9 @@ def owned_placement(parents_global, x_before, n, world):
     """Where the owner-keeps rule puts the offspring of ONE filter's resample, restated from its definition with numpy only:
     parents_global[g] = parent of draw g in the single filter (N = n * world draws), x_before = [N][d] states before the
     resample.  -> (x_after [N][d], parent ids [N]) in rank-major slot order."""
-    P = np.sort(np.asarray(parents_global, dtype=np.int64))   # offspring grouped by owner, in parent order
+    P = np.asarray(parents_global, dtype=np.int64)
     owner = P // n
-    lists = [P[owner == r] for r in range(world)]
+    lists = [P[owner == r] for r in range(world)]              # a rank's offspring in the order of their draws
     c = [len(l) for l in lists]
     surplus = np.concatenate([l[n:] for l in lists]) if world > 1 else np.empty(0, dtype=np.int64)   # unit order: donors by rank
     out = np.empty(n * world, dtype=np.int64)

@@ -47,12 +47,12 @@ def main():
         eng.set_timing(False)
         eng.set_timing(True)
         for _ in range(12):
-            eng.shard_owned_count(0, C.c_void_p(tiles_all.data_ptr()), world, 0, want_counts=False)
+            eng.shard_owned_count(0, C.c_void_p(tiles_all.data_ptr()), world, 0, ocap, want_counts=False)
             eng.shard_owned_expand(world, 0, ocap, C.c_void_p(send.data_ptr()), C.c_void_p(orow.data_ptr()), world * ocap)
         eng.synchronize()
         r = eng.get_timing(capi.MP_K_BIN_DRAWS)
         g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
-        print(f"world {world}: owner-keeps count (memset + table + count) {r[0] / r[1] * 1e3:.1f} us, expand + publish {g[0] / g[1] * 1e3:.1f} us", flush=True)
+        print(f"world {world}: owner-keeps count (table + own draws + plan) {r[0] / r[1] * 1e3:.1f} us, place {g[0] / g[1] * 1e3:.1f} us", flush=True)
         eng.close()
 
 
