@@ -601,44 +601,66 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_own_place(u64 n, u64 slot_
     const double nt_over_Q = (double)nt_all / (double)Q;
     const u64 PS_me = plan->PS[rank];
     const u64* q_in = gq + (u64)blockIdx.x * SHO_CHUNK;
-    for (uint32_t q = tid; q < qn; q += SH_THREADS) {
-        uint32_t b, gs;
-        u64 lt;
-        mp_locate_r(incl_all, tW_all, ratio_all, (uint32_t)nt_all, q_in[q], nt_over_Q, &b, &lt, &gs);
-        const uint32_t tl = b - (uint32_t)rank * (uint32_t)nt_local;
-        const u64 tbase = (u64)tl * TILE;
-        const u64 tend = tbase + TILE;
-        const u64 last = (tend < n ? tend : n) - 1;
-        const u64 j = tbase + guide[(u64)tl * GUIDE_N + (gs - b * (uint32_t)GUIDE_N)];
-        u64 i = j < last ? j : last;
-        mp_cx cur = cx[i];
-        while (cur.cum < lt && i < last) {
-            ++i;
+    const int lane = tid & 63;
+    // lanes of a row group when states are wider than one double (as k_shard_resolve_binned): G lanes copy one parent's row
+    // together, a row is then one coalesced request instead of D scattered 8-byte ones
+    const int G = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : 16));
+    for (uint32_t q0 = 0; q0 < qn; q0 += SH_THREADS) {   // wave-uniform trip count
+        const uint32_t q = q0 + tid;
+        u64 i = 0;
+        double* dst = nullptr;
+        mp_cx cur;
+        cur.cum = 0; cur.x0 = 0.;
+        if (q < qn) {
+            uint32_t b, gs;
+            u64 lt;
+            mp_locate_r(incl_all, tW_all, ratio_all, (uint32_t)nt_all, q_in[q], nt_over_Q, &b, &lt, &gs);
+            const uint32_t tl = b - (uint32_t)rank * (uint32_t)nt_local;
+            const u64 tbase = (u64)tl * TILE;
+            const u64 tend = tbase + TILE;
+            const u64 last = (tend < n ? tend : n) - 1;
+            const u64 j = tbase + guide[(u64)tl * GUIDE_N + (gs - b * (uint32_t)GUIDE_N)];
+            i = j < last ? j : last;
             cur = cx[i];
-        }
-        const u64 p = p0 + q;
-        double* dst;
-        if (p < n) {
-            dst = rows + (recv_rows + p) * (u64)(D + 1);
-            inv[p] = (uint32_t)(recv_rows + p);
-        } else {
-            const u64 u = PS_me + (p - n);
-            int s = 0;
-            while (s + 1 < world && !(plan->D[s] && u < plan->PD[s] + plan->D[s])) ++s;
-            if (cap) {
-                const u64 first = PS_me > plan->PD[s] ? PS_me : plan->PD[s];
-                const u64 jj = u - first;
-                if (jj >= cap) continue;   // k_shard_own_plan has flagged it: nothing of this attempt is committed
-                dst = send + ((u64)s * cap + jj) * (u64)(D + 1);
+            while (cur.cum < lt && i < last) {
+                ++i;
+                cur = cx[i];
+            }
+            const u64 p = p0 + q;
+            if (p < n) {
+                dst = rows + (recv_rows + p) * (u64)(D + 1);
+                inv[p] = (uint32_t)(recv_rows + p);
             } else {
-                dst = send + (u - PS_me) * (u64)(D + 1);
+                const u64 u = PS_me + (p - n);
+                int s = 0;
+                while (s + 1 < world && !(plan->D[s] && u < plan->PD[s] + plan->D[s])) ++s;
+                if (cap) {
+                    const u64 first = PS_me > plan->PD[s] ? PS_me : plan->PD[s];
+                    const u64 jj = u - first;
+                    // jj >= cap: k_shard_own_plan has flagged it, nothing of this attempt is committed
+                    if (jj < cap) dst = send + ((u64)s * cap + jj) * (u64)(D + 1);
+                } else {
+                    dst = send + (u - PS_me) * (u64)(D + 1);
+                }
             }
         }
         if (D == 1) {
-            *reinterpret_cast<double2*>(dst) = make_double2(cur.x0, (double)(slot_offset + i));
+            if (dst) *reinterpret_cast<double2*>(dst) = make_double2(cur.x0, (double)(slot_offset + i));
         } else {
-            for (int d = 0; d < D; ++d) dst[d] = x[i * D + d];
-            dst[D] = (double)(slot_offset + i);
+            if (dst) dst[D] = (double)(slot_offset + i);
+            const u64 dbits = (u64)(uintptr_t)dst;
+            const uint32_t d_lo = (uint32_t)dbits, d_hi = (uint32_t)(dbits >> 32);
+            const uint32_t i_lo = (uint32_t)i, i_hi = (uint32_t)(i >> 32);
+            const int comp = lane % G;
+            for (int base_l = 0; base_l < 64; base_l += 64 / G) {
+                const int src = base_l + lane / G;
+                const u64 sd = ((u64)(uint32_t)__shfl((int)d_hi, src, 64) << 32) | (u64)(uint32_t)__shfl((int)d_lo, src, 64);
+                const u64 si = ((u64)(uint32_t)__shfl((int)i_hi, src, 64) << 32) | (u64)(uint32_t)__shfl((int)i_lo, src, 64);
+                if (sd) {
+                    double* out = reinterpret_cast<double*>((uintptr_t)sd);
+                    for (int d = comp; d < D; d += G) out[d] = x[si * D + d];
+                }
+            }
         }
     }
     // slots this rank could not fill itself: where in the receive buffer their rows will arrive
