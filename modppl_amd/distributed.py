@@ -117,15 +117,12 @@ class HipShardEngine:
     def shard_owned_commit(self, rows_ptr, recv_rows, want_value):
         """-> (committed, log total weight or None, offspring per rank)"""
         out = C.c_double()
-        counts = (C.c_uint64 * self._L_world())()
+        counts = (C.c_uint64 * 64)()   # SH_MAX_WORLD entries: the library writes the world's
         code = self._L.mp_pf_shard_owned_commit(self._h, rows_ptr, C.byref(out) if want_value else None, counts)
         if code == capi.MP_ERR_CAPACITY:
             return False, None, list(counts)
         capi.check(code)
         return True, (out.value if want_value else None), list(counts)
-
-    def _L_world(self):
-        return 64
 
     def shard_query_packed(self, tiles_all_ptr, world):
         lml, ess = C.c_double(), C.c_double()
