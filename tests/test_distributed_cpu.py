@@ -150,7 +150,7 @@ def test_two_rank_owner_keeps_exchange(tmp_path, model, n, t, scheme):
     assert json.loads(line[0][len("RESULT"):])["moved"] > 0    # the exchange really carried rows
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
 @pytest.mark.parametrize("scheme", [0, 1, 2])
 def test_owner_keeps_is_the_single_filters_resample_placed_by_owner(world, scheme):
     """The parents are the single filter's draws (same multiset); the placement follows the rule of include/modppl_hip.h,
@@ -158,7 +158,7 @@ def test_owner_keeps_is_the_single_filters_resample_placed_by_owner(world, schem
     import modppl_amd
     from tests import oracle_lib as O
     from tests.owned_ref import OwnedReference, owned_placement
-    N, T, seed = 8192, 4, 5
+    N, T, seed = 16384, 4, 5
     obs = O.lgssm_observations(T).reshape(T, 1)
     model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
     one = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, N, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)

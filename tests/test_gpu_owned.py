@@ -112,6 +112,8 @@ class _ByHand:
     (1, 2, 8192, 8192, True, 1, 6.0),      # systematic
     (1, 3, 4096, 64, True, 2, 6.0),        # stratified, odd world
     (16, 2, 2048, 2048, True, 0, 6.0),
+    (1, 8, 2048, 256, True, 0, 6.0),       # eight ranks: several donors and receivers in the plan
+    (2, 8, 2048, 0, False, 0, 14.0),
 ])
 def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme, tail):
     model, obs = _model(d, 7)
