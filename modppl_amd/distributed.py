@@ -457,6 +457,15 @@ class ShardedParticleSystem:
             return self.engine.ess_reference()
         return self._query()[1]
 
+    def maybe_resample(self, ess_fraction=0.5, scheme=capi.MP_RESAMPLE_MULTINOMIAL):
+        """ESS-triggered resampling (extension, as ParticleSystem.maybe_resample): resample iff the ESS of the current
+        weights over ALL shards is below ess_fraction * N.  Every rank computes the same ESS from the gathered tiles, so
+        every rank takes the same branch.  -> (resampled, ess, log total weight or None)."""
+        ess = self.effective_sample_size(fresh=True)
+        if ess < float(ess_fraction) * self.num_particles:
+            return True, ess, self.resample(scheme)
+        return False, ess, None
+
     def states(self):
         return self.engine.states()
 

@@ -187,3 +187,31 @@ def test_owned_plan_conserves_rows():
             a = np.array(S.owned_plan(list(c), n))
             assert np.array_equal(a.sum(1), np.maximum(c - n, 0)) and np.array_equal(a.sum(0), np.maximum(n - c, 0))
             assert (np.diag(a) == 0).all()
+
+
+@pytest.mark.parametrize("exchange", ["owned", "exact"])
+def test_sharded_maybe_resample_follows_the_fresh_ess(exchange):
+    """ESS-triggered resampling over shards (a world of one here, the checker as local engine): the decisions and results of
+    one filter that is resampled whenever its fresh ESS drops below the threshold."""
+    import modppl_amd
+    from modppl_amd.distributed import ShardedParticleSystem
+    from tests import oracle_lib as O
+    N, T, seed, frac = 4096, 10, 11, 0.6
+    obs = O.lgssm_observations(T).reshape(T, 1)
+    pf = ShardedParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), N, seed, engine_cls=O.OracleShardEngine, exchange=exchange)
+    one = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, N, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    pf.init_step(None, obs[:1])
+    one.init_step(obs[:1])
+    n_res = 0
+    for t in range(1, T):
+        did, ess, ltw = pf.maybe_resample(frac)
+        ess1 = one.effective_sample_size(1)
+        assert ess == ess1 and did == (ess1 < frac * N)
+        if did:
+            n_res += 1
+            assert ltw == one.resample()
+            assert np.array_equal(pf.states().reshape(-1), one.state().reshape(-1))
+        pf.step(obs[t:t + 1])
+        one.step(obs[t:t + 1])
+    assert 0 < n_res < T - 1
+    assert pf.log_marginal_likelihood_estimate() == one.log_marginal_likelihood_estimate()
