@@ -256,3 +256,45 @@ def test_owner_keeps_through_process_groups(tmp_path, which, nproc):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "RESULT ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_owner_keeps_error_paths():
+    """Misuse of the phases is a status code, not a fault (the reference panics; the wrapper re-raises)."""
+    import torch
+
+    import modppl_amd
+    from modppl_amd import ModpplError, capi
+    from modppl_amd.distributed import HipShardEngine
+
+    n = 4096
+    model, obs = _model(1, 2)
+    e = HipShardEngine(model, n, 2 * n, 0, 3)
+    dev = e.device
+    tiles = torch.zeros(2 * 3 * (n // 2048), dtype=torch.int64, device=dev)
+    buf = torch.zeros(8 * n, dtype=torch.float64, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    with pytest.raises(ModpplError) as err:                       # before init_step
+        e.shard_owned_count(0, ptr(tiles), 2, 0, 0, want_counts=False)
+    assert err.value.code == capi.MP_ERR_STATE
+    e.init_step(None, obs[:1])
+    with pytest.raises(ModpplError) as err:                       # expand before count
+        e.shard_owned_expand(2, 0, 0, ptr(buf), ptr(buf), 0)
+    assert err.value.code == capi.MP_ERR_STATE
+    with pytest.raises(ModpplError) as err:                       # world * n != n_global
+        e.shard_owned_count(0, ptr(tiles), 4, 0, 0, want_counts=False)
+    assert err.value.code == capi.MP_ERR_INVALID_ARG
+    with pytest.raises(ModpplError) as err:                       # unknown scheme
+        e.shard_owned_count(9, ptr(tiles), 2, 0, 0, want_counts=False)
+    assert err.value.code == capi.MP_ERR_INVALID_ARG
+    e.shard_tiles_packed(ptr(tiles[: 3 * (n // 2048)]))
+    tiles[3 * (n // 2048):] = tiles[: 3 * (n // 2048)]
+    torch.cuda.synchronize()
+    counts = e.shard_owned_count(0, ptr(tiles), 2, 0, 0, want_counts=True)
+    assert sum(counts) == 2 * n
+    with pytest.raises(ModpplError) as err:                       # fixed capacity needs recv_rows == world * capacity
+        e.shard_owned_expand(2, 0, 64, ptr(buf), ptr(buf), 100)
+    assert err.value.code == capi.MP_ERR_INVALID_ARG
+    with pytest.raises(ModpplError) as err:                       # world differs from the count's
+        e.shard_owned_expand(1, 0, 0, ptr(buf), ptr(buf), 0)
+    assert err.value.code == capi.MP_ERR_STATE
+    e.close()
