@@ -22,6 +22,12 @@ pub const MP_RESAMPLE_MULTINOMIAL: i32 = 0;
 pub const MP_RESAMPLE_SYSTEMATIC: i32 = 1;
 pub const MP_RESAMPLE_STRATIFIED: i32 = 2;
 pub const MP_MH_MODEL_HIERARCHICAL: i32 = 1;
+pub const MP_MH_MODEL_POINTED_2D: i32 = 2;
+pub const MP_MH_PROPOSAL_POINTED_DRIFT: i32 = 3;
+pub const MP_SITE_IS_LINEAR: i32 = 0;
+pub const MP_SITE_A: i32 = 1;
+pub const MP_SITE_B: i32 = 2;
+pub const MP_SITE_C: i32 = 3;
 pub const MP_MH_PROPOSAL_HIERARCHICAL_DRIFT: i32 = 1;
 pub const MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE: i32 = 2;
 pub const MP_ESS_REFERENCE: i32 = 0;
@@ -95,6 +101,8 @@ extern "C" {
                                     resampled_indices: *mut u64, final_states: *mut f64) -> i32;
     pub fn mp_mh_create(model_kind: i32, xs: *const f64, ys: *const f64, n_data: i32, constrain_is_linear: i32,
                         n_chains: u64, seed: u64, device: i32, stream: *mut c_void, out: *mut *mut mp_mh) -> i32;
+    pub fn mp_mh_create_pointed(bounds: *const f64, obs_cov: *const f64, obs: *const f64, n_chains: u64, seed: u64, device: i32,
+                                stream: *mut c_void, out: *mut *mut mp_mh) -> i32;
     pub fn mp_mh_step(h: *mut mp_mh, proposal_kind: i32, proposal_args: *const f64, n_proposal_args: i32, n_iters: i32,
                       accepted: *mut u64) -> i32;
     pub fn mp_regen_mh_step(h: *mut mp_mh, mask_sites: *const i32, n_mask: i32, cycle: i32, n_iters: i32, accepted: *mut u64) -> i32;

@@ -70,6 +70,116 @@ impl ParticleSystem {
     }
 }
 
+impl ParticleSystem {
+    /// Extension: systematic / stratified resampling (`sys::MP_RESAMPLE_*`); the reference only has multinomial.
+    pub fn resample_with(&mut self, scheme: i32) -> f64 {
+        let mut v = 0.0;
+        check(unsafe { sys::mp_pf_resample(self.h, scheme, &mut v) });
+        v
+    }
+    /// Extension: resample iff the ESS of the current weights is below `ess_fraction * N`.  -> (resampled, ess)
+    pub fn maybe_resample(&mut self, ess_fraction: f64, scheme: i32) -> (bool, f64) {
+        let (mut did, mut ess, mut ltw) = (0i32, 0.0f64, 0.0f64);
+        check(unsafe { sys::mp_pf_resample_if_ess_below(self.h, scheme, ess_fraction, &mut did, &mut ess, &mut ltw) });
+        (did != 0, ess)
+    }
+    /// `log_weights` (pub field of the reference's struct)
+    pub fn log_weights(&self) -> Vec<f64> {
+        let mut w = vec![0.0; self.num_particles];
+        check(unsafe { sys::mp_pf_read_log_weights(self.h, w.as_mut_ptr()) });
+        w
+    }
+    /// `parents` (pub field): the indices of the last resample
+    pub fn parents(&self) -> Vec<u32> {
+        let mut p = vec![0u32; self.num_particles];
+        check(unsafe { sys::mp_pf_read_parents(self.h, p.as_mut_ptr()) });
+        p
+    }
+}
+
 impl Drop for ParticleSystem {
     fn drop(&mut self) { unsafe { sys::mp_pf_destroy(self.h); } }
+}
+
+/// `importance_resampling(model, args, constraints, num_samples)` (modppl/src/inference/importance.rs:37-50) with
+/// `num_ret_samples` draws: -> (log_ml_estimate, log_normalized_weights, resampled indices, the resampled final states).
+pub fn importance_resampling(model: &UnfoldModel, args: &[f64], constraints: &[f64], num_samples: usize, num_ret_samples: usize,
+                             seed: u64) -> (f64, Vec<f64>, Vec<u64>, Vec<f64>) {
+    let desc = sys::mp_model_desc { kind: model.kind, dim_state: model.dim_state, dim_obs: model.dim_obs,
+                                    n_params: model.params.len() as i32, params: model.params.as_ptr() };
+    let a = if args.is_empty() { ptr::null() } else { args.as_ptr() };
+    let n_steps = (constraints.len() / model.dim_obs as usize) as i32;
+    let mut lml = 0.0;
+    let mut lnw = vec![0.0; num_samples];
+    let mut idx = vec![0u64; num_ret_samples];
+    let mut xs = vec![0.0; num_ret_samples * model.dim_state as usize];
+    check(unsafe {
+        sys::mp_importance_resampling(&desc, a, constraints.as_ptr(), n_steps, num_samples as u64, num_ret_samples as u64, seed, 0,
+                                      &mut lml, lnw.as_mut_ptr(), idx.as_mut_ptr(), xs.as_mut_ptr())
+    });
+    (lml, lnw, idx, xs)
+}
+
+/// `DynUnfold::simulate` for `n` independent traces of `n_steps` kernel calls (modppl/src/modeling/dynunfold.rs:22-39):
+/// -> (states `[n][n_steps][dim_state]`, observations `[n][n_steps][dim_obs]`).
+pub fn simulate(model: &UnfoldModel, args: &[f64], n_steps: usize, n: usize, seed: u64) -> (Vec<f64>, Vec<f64>) {
+    let desc = sys::mp_model_desc { kind: model.kind, dim_state: model.dim_state, dim_obs: model.dim_obs,
+                                    n_params: model.params.len() as i32, params: model.params.as_ptr() };
+    let a = if args.is_empty() { ptr::null() } else { args.as_ptr() };
+    let mut xs = vec![0.0; n * n_steps * model.dim_state as usize];
+    let mut ys = vec![0.0; n * n_steps * model.dim_obs as usize];
+    check(unsafe { sys::mp_unfold_simulate(&desc, a, n_steps as i32, n as u64, seed, 0, xs.as_mut_ptr(), ys.as_mut_ptr()) });
+    (xs, ys)
+}
+
+/// `n_chains` independent chains over the reference's `hierarchical_model` (modppl/tests/dyngenfns/hierarchical.rs:18-47):
+/// `mh` / `regen_mh` (modppl/src/inference/mh.rs:9-75) advance every chain by `n_iters` iterations per call.
+pub struct HierarchicalChains { h: *mut sys::mp_mh, n_chains: usize }
+
+impl HierarchicalChains {
+    /// `constrain_is_linear`: -1 leaves `is_linear` free, 0 / 1 constrain it (tests/mh.rs:81-89 constrains the data only)
+    pub fn new(xs: &[f64], ys: &[f64], constrain_is_linear: i32, n_chains: usize, seed: u64) -> Self {
+        assert_eq!(xs.len(), ys.len());
+        let mut h = ptr::null_mut();
+        check(unsafe {
+            sys::mp_mh_create(sys::MP_MH_MODEL_HIERARCHICAL, xs.as_ptr(), ys.as_ptr(), xs.len() as i32, constrain_is_linear,
+                              n_chains as u64, seed, 0, ptr::null_mut(), &mut h)
+        });
+        HierarchicalChains { h, n_chains }
+    }
+    /// `mh(model, trace, hierarchical_drift_proposal, (drift_std,))` x n_iters per chain -> accepted moves
+    pub fn mh(&mut self, drift_std: f64, n_iters: i32) -> u64 {
+        let mut acc = 0u64;
+        check(unsafe { sys::mp_mh_step(self.h, sys::MP_MH_PROPOSAL_HIERARCHICAL_DRIFT, &drift_std, 1, n_iters, &mut acc) });
+        acc
+    }
+    /// `mh(model, trace, add_or_remove_param_proposal, ())` x n_iters per chain (the structure-changing move of tests/mh.rs:94)
+    pub fn mh_add_or_remove(&mut self, n_iters: i32) -> u64 {
+        let mut acc = 0u64;
+        check(unsafe { sys::mp_mh_step(self.h, sys::MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE, ptr::null(), 0, n_iters, &mut acc) });
+        acc
+    }
+    /// `regen_mh(model, trace, mask)` x n_iters per chain; `mask` = `sys::MP_SITE_*`; `cycle`: one site of the mask per
+    /// iteration, in turn, instead of all of them at once
+    pub fn regen_mh(&mut self, mask: &[i32], cycle: bool, n_iters: i32) -> u64 {
+        let mut acc = 0u64;
+        check(unsafe { sys::mp_regen_mh_step(self.h, mask.as_ptr(), mask.len() as i32, cycle as i32, n_iters, &mut acc) });
+        acc
+    }
+    /// per chain `[is_linear, a, b, c]`
+    pub fn states(&self) -> Vec<f64> {
+        let mut x = vec![0.0; self.n_chains * 4];
+        check(unsafe { sys::mp_mh_read_state(self.h, x.as_mut_ptr()) });
+        x
+    }
+    /// `trace.logjp` per chain
+    pub fn logjp(&self) -> Vec<f64> {
+        let mut x = vec![0.0; self.n_chains];
+        check(unsafe { sys::mp_mh_read_logjp(self.h, x.as_mut_ptr()) });
+        x
+    }
+}
+
+impl Drop for HierarchicalChains {
+    fn drop(&mut self) { unsafe { sys::mp_mh_destroy(self.h); } }
 }

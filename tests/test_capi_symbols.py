@@ -70,3 +70,14 @@ def test_only_the_cpu_baseline_leg_of_bench_touches_the_oracle():
     for f in os.listdir(os.path.join(ROOT, "tools")):
         if f.endswith(".py"):
             assert "oracle_lib" not in open(os.path.join(ROOT, "tools", f)).read(), f
+
+
+def test_rust_sys_crate_declares_every_entry_point():
+    """The source-only Rust FFI crate (no rustc in this image) must at least name every function of include/modppl_hip.h."""
+    import re
+
+    from modppl_amd import capi
+    src = open(os.path.join(ROOT, "modppl_amd", "rust", "modppl-hip-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub fn (mp_\w+)\(", src))
+    wanted = {s for s in capi.SYMBOLS if not s.startswith("mp_probe")}
+    assert wanted <= declared, sorted(wanted - declared)
