@@ -298,3 +298,26 @@ def test_owner_keeps_error_paths():
         e.shard_owned_expand(1, 0, 0, ptr(buf), ptr(buf), 0)
     assert err.value.code == capi.MP_ERR_STATE
     e.close()
+
+
+@pytest.mark.parametrize("world,n,cap", [(4, 1 << 18, 4096), (2, 1 << 19, 0), (8, 1 << 17, 2048)])
+def test_owner_keeps_million_particles(world, n, cap):
+    """2^20 particles over 2 / 4 / 8 shards: hundreds of workgroups per phase, several rounds per lane in the place kernel;
+    the surplus stays a few hundred rows (O(sqrt n)), far below the capacity."""
+    model, obs = _model(1, 4)
+    N, seed = n * world, 99
+    hip = _ByHand(model, n, world, seed)
+    ref = OwnedReference(model, N, seed, world)
+    for e in hip.eng:
+        e.init_step(None, obs[:1])
+    ref.init_step(None, obs[:1])
+    for t in range(1, len(obs)):
+        assert hip.resample(cap, 0) == ref.resample(0)
+        assert list(hip.counts) == list(ref.counts)
+        assert max(abs(int(c) - n) for c in ref.counts) < 20 * int(np.sqrt(n))
+        assert np.array_equal(hip.cat(lambda e: e.parents()), ref.parents())
+        for e in hip.eng:
+            e.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(hip.cat(lambda e: e.log_weights()), ref.log_weights())
+    assert hip.fallbacks == 0
