@@ -1,4 +1,6 @@
 // tools/k3_ablate.hip — timing-only microbenchmark of the step kernels (not part of the product).
+// HISTORICAL: written against the kernel signatures of mid round 1 (before k_bin_draws<PREBUILT> and the particle-major
+// k_resolve_bins); it produced profiles/r01/k3_ablation_n2e20.txt and no longer compiles against the current kernels.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -o tools/k3_ablate tools/k3_ablate.hip
 #include "../modppl_amd/csrc/mp_pf.hip"
 #include <cstdio>
