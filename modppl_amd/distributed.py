@@ -234,8 +234,9 @@ class ShardedParticleSystem:
             # surplus rows per pair of ranks in the equal-split all-to-all: the surplus of a rank is the spread of a
             # Binomial(N, ~1/world) count plus the imbalance of the shard masses, both O(sqrt) of n
             self._ow_fixed = self._fixed
-            # (a few hundred rows at 2^20 particles per rank; a pair that needs more falls back once and the capacity doubles)
-            ocap = max(2048, self.n // 256)
+            # (std of a rank's surplus ~ sqrt(2 n): 1400 rows at 2^20 particles per rank, so 8192 rows per pair is ~6 sigma;
+            # a pair that needs more falls back once and the capacity doubles)
+            ocap = max(4096, self.n // 128)
             self._ow_cap_forced = "MP_SHARD_OWNED_CAP" in os.environ   # tests: force the overflow path
             self._ow_cap = min(self.n, int(os.environ.get("MP_SHARD_OWNED_CAP", ocap)))
             if self._ow_fixed:

@@ -40,7 +40,7 @@ def main():
         g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
         print(f"world {world}: route (unpack + route + finalize) {r[0] / r[1] * 1e3:.1f} us, resolve + publish {g[0] / g[1] * 1e3:.1f} us", flush=True)
         # the owner-keeps form: every rank enumerates all world * n draws, keeps its own
-        ocap = max(2048, n // 256)
+        ocap = max(4096, n // 128)
         send = torch.zeros(world * ocap * 2, dtype=torch.float64, device=dev)
         orow = torch.zeros((world * ocap + n) * 2, dtype=torch.float64, device=dev)
         eng.synchronize()
