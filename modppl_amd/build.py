@@ -2,40 +2,80 @@
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the .so is
 git-ignored but travels to the GPU box with the snapshot.
+
+Staleness is decided by CONTENT: a sha256 over every source, header and the flag list is stored next
+to the library (`<lib>.srchash`); a library whose stamp differs from the tree's hash is rebuilt
+where hipcc exists and refused (loudly) where it does not, so a binary that does not correspond to
+the checked-out sources is never loaded silently.
 """
+import hashlib
 import os
+import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libmodppl_hip.so")
+SO_STAMPS = os.path.join(CSRC, "libmodppl_hip_stamps.so")   # diagnostics build (-DMP_STAMPS), tools/stamp_probe.py only
 SOURCES = ["mp_pf.hip", "mp_mh.hip", "mp_probe.hip"]
-HEADERS = ["mp_math.h", "mp_philox.h", "mp_dists.h", "mp_models.h", "mp_linalg.h", "mp_pf_kernels.h", "mp_pf_shard_kernels.h", os.path.join("..", "..", "include", "modppl_hip.h"),
-           os.path.join("..", "..", "include", "modppl_hip_probe.h")]
 # -ffp-contract=off: the only fused multiply-adds are the explicit fma() calls in mp_math.h, so the
 # device evaluates exp/log with exactly the operations the CPU checker uses (bit-exact indices).
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
-def is_stale():
-    if not os.path.exists(SO):
+def _dep_files():
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".hpp"))]
+    inc = os.path.join(HERE, "..", "include")
+    deps += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
+    return deps
+
+
+def source_hash(extra_flags=()):
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS + list(extra_flags)).encode())
+    for d in _dep_files():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp_path(so):
+    return so + ".srchash"
+
+
+def is_stale(so=SO, extra_flags=()):
+    if not os.path.exists(so) or not os.path.exists(_stamp_path(so)):
         return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    with open(_stamp_path(so)) as f:
+        return f.read().strip() != source_hash(extra_flags)
 
 
-def build(force=False, verbose=False):
-    if not force and not is_stale():
-        return SO
-    cmd = ["hipcc"] + FLAGS + ["-o", SO] + [os.path.join(CSRC, s) for s in SOURCES]
+def build(force=False, verbose=False, so=SO, extra_flags=()):
+    if not force and not is_stale(so, extra_flags):
+        return so
+    if shutil.which("hipcc") is None:
+        raise RuntimeError(f"{so} does not correspond to the sources in this tree (content hash differs) and hipcc is not available to rebuild it")
+    cmd = ["hipcc"] + FLAGS + list(extra_flags) + ["-o", so] + [os.path.join(CSRC, s) for s in SOURCES]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    with open(_stamp_path(so), "w") as f:
+        f.write(source_hash(extra_flags) + "\n")
     if verbose:
         print(res.stderr)
-    return SO
+    return so
+
+
+def build_stamps(force=False):
+    """the diagnostics library: same sources with per-workgroup clock stamps compiled in (never loaded by the product)"""
+    return build(force=force, so=SO_STAMPS, extra_flags=("-DMP_STAMPS",))
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    if len(sys.argv) > 1 and sys.argv[1] == "stamps":
+        print(build_stamps(force=True))
+    else:
+        print(build(force=True, verbose=True))

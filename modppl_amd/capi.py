@@ -80,7 +80,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    so = _build.SO
+    so = os.environ.get("MODPPL_HIP_LIB") or _build.SO   # the override is for the diagnostics build (tools/stamp_probe.py)
+    if so == _build.SO and _build.is_stale():
+        # never load a binary that does not correspond to the checked-out sources (content hash, not mtime): rebuild it
+        # where hipcc exists, fail loudly where it does not — there is no CPU fallback either way
+        try:
+            _build.build()
+        except RuntimeError as e:
+            raise ModpplError(MP_ERR_HIP, f"{so} is missing or stale and could not be rebuilt: {e}")
     if not os.path.exists(so):
         raise ModpplError(MP_ERR_HIP, f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                       "(the gfx950 path has no CPU fallback)")

@@ -33,9 +33,21 @@ MP_HD double mp_normal_logpdf(double x, double mu, double sd) { return mp_normal
 // The accepted pair (u, r = u*u + v*v) of the polar method does not depend on (mu, sd), so the
 // rejection loop can run ahead of the model (mp_pf.hip, k_propagate) and the model consumes it here.
 // normal.rs:25-26: c = sqrt(-2 ln r / r); u*c*std + mu.
-MP_HD double mp_normal_from_pair(double u, double r, double mu, double sd) {
+// The standard deviate z = u*c is the parameter-free part: `u * c * std + mu` evaluates as ((u*c)*std) + mu, so a kernel may
+// produce z anywhere (another lane, another launch) and the model finishes with z*sd + mu — same operations, same order.
+MP_HD double mp_std_normal_from_pair(double u, double r) {
     const double c = mp_sqrt(-2. * mp_log(r) / r);
-    return u * c * sd + mu;
+    return u * c;
+}
+MP_HD double mp_normal_from_pair(double u, double r, double mu, double sd) { return mp_std_normal_from_pair(u, r) * sd + mu; }
+// one attempt of the polar method on a Philox block: (u, r) and whether normal.rs:22 accepts it
+MP_HD bool mp_polar_attempt(const mp_u64x2& b, double* u_out, double* r_out) {
+    const double u = mp_u01(b.a) * 2. - 1.;
+    const double v = mp_u01(b.b) * 2. - 1.;
+    const double r = u * u + v * v;
+    *u_out = u;
+    *r_out = r;
+    return !(r == 0. || r > 1.);
 }
 
 // normal.rs:19-27: u,v = 2*u01-1; r = u*u+v*v; reject r == 0 or r > 1 (the reference recurses);

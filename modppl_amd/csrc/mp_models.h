@@ -34,19 +34,18 @@ struct mp_state0 {
 // Model::obs_of(site) >= 0 names the constraint slot of a site (compile time).
 // ---------------------------------------------------------------------------------------
 //
-// Free normal sites may be fed from pre-drawn polar pairs (pu/pr, indexed by Model::normal_index):
-// the pair of a site does not depend on its parameters, so k_propagate runs all rejection loops
-// of a lane first (a lane-local work queue over particles x sites) and the wave does not idle on
-// its slowest lane once per site.  With pu == nullptr the loop runs in place.
+// Free normal sites may be fed from pre-drawn STANDARD deviates z = u*c of the polar method (pz, indexed by
+// Model::normal_index): z does not depend on the site's parameters, so the rejection loops run ahead of the model
+// (workgroup-cooperatively in k_propagate, or one launch earlier inside the resample's lookup kernel) and the model
+// finishes with z*sd + mu (mp_dists.h).  With pz == nullptr the loop runs in place.
 template <class Model>
 struct mp_generate_handler {
     mp_stream rng;
     const double* obs;
-    const double* pu;
-    const double* pr;
+    const double* pz;
     double weight;
-    MP_HD mp_generate_handler(const mp_stream& r, const double* o, const double* pu_ = nullptr, const double* pr_ = nullptr)
-        : rng(r), obs(o), pu(pu_), pr(pr_), weight(0.) {}
+    MP_HD mp_generate_handler(const mp_stream& r, const double* o, const double* pz_ = nullptr)
+        : rng(r), obs(o), pz(pz_), weight(0.) {}
 
     // ln_sd: mp_log(sd) when the caller has it hoisted (a model constant), else NaN -> computed here
     template <int SITE>
@@ -57,9 +56,9 @@ struct mp_generate_handler {
             weight += mp_normal_logpdf_ln(x, mu, sd, ln_sd);
             return x;
         } else {
-            if (pu) {
+            if (pz) {
                 constexpr int ni = Model::normal_index(SITE);
-                return mp_normal_from_pair(pu[ni], pr[ni], mu, sd);
+                return pz[ni] * sd + mu;
             }
             mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
             return mp_normal_sample(st, mu, sd);

@@ -66,7 +66,7 @@ static int ceil_log2_u64(u64 n) {
     while ((1ull << b) < n) ++b;
     return b;
 }
-constexpr int PREBUILT_TABLE_MIN_TILES = 2048;   // from 2^22 particles up (measured: a loss at 1024 tiles, a gain at 2048) the tile table is built once per resample, not per workgroup
+constexpr int K1_TABLE_LDS_MAX_TILES = 1024;   // k_bin_draws copies the prebuilt tile table (24 B per tile) into LDS up to here, probes it in L2 beyond
 static size_t table_lds(int nt, int threads) {  // s_incl[nt] + s_W[nt] + s_red + s_wtot
     return sizeof(u64) * 2 * (size_t)nt + (sizeof(double) + sizeof(u64)) * (size_t)(threads / 64);
 }
@@ -93,11 +93,32 @@ struct PropagateArgs {
     u64* tile_W2;
     const uint32_t* inv;
     const uint32_t* res_parent;
+    mp_k1_aux aux;
+};
+struct ResolveArgs {   // k_resolve_bins (+ the next step's deviates when zpre != null)
+    u64 n;
+    int nchunks, grid;
+    const u64* seg_lt;
+    const uint32_t* seg_row;
+    const unsigned short* seg_cnt;
+    const mp_cx* cx;
+    double* res_x;
+    uint32_t* res_parent;
+    long long t_next;
+    u64 slot_offset;
+    uint32_t k0, k1;
+    double* zpre;
+    u64 pre_per;
+    hipStream_t stream;
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
+    int max_normals = 0;
+    bool coop = false;   // few normal sites per particle: deviates can be drawn cooperatively / one launch ahead
     virtual ~ModelOps() {}
     virtual void propagate(const PropagateArgs& a) const = 0;
+    virtual void resolve(const ResolveArgs& a) const = 0;
+    virtual int n_normals(long long t) const = 0;
     virtual void simulate(u64 n, uint32_t k0, uint32_t k1, int n_steps, const mp_state0& s0, double* states, double* obs, hipStream_t st) const = 0;
 };
 template <class Model>
@@ -106,6 +127,8 @@ struct ModelOpsT : ModelOps {
     explicit ModelOpsT(const Model& m) : model(m) {
         dim_state = Model::DIM_STATE;
         dim_obs = Model::DIM_OBS;
+        max_normals = Model::MAX_NORMALS;
+        coop = mp_coop_model<Model>();
         static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
         static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
     }
@@ -117,7 +140,19 @@ struct ModelOpsT : ModelOps {
         constexpr int THREADS = (Model::MAX_NORMALS <= 4 && Model::DIM_STATE <= 4) ? 1024 : TILE_THREADS;
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
-                           a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent);
+                           a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent, a.aux);
+    }
+    int n_normals(long long t) const override { return model.n_normals(t); }
+    void resolve(const ResolveArgs& a) const override {
+        if constexpr (mp_coop_model<Model>()) {
+            if (a.zpre) {
+                hipLaunchKernelGGL((k_resolve_bins<Model, true>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
+                                   a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, a.zpre, a.pre_per);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_resolve_bins<Model, false>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
+                           a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, (double*)nullptr, (u64)0);
     }
 };
 
@@ -267,6 +302,17 @@ struct mp_pf {
     int nchunks = 0;
     int use_binned = 1;                 // MP_BINNED_RESAMPLE=0 selects the single-kernel path (A/B measurements)
     bool permuted = false;              // the current states / parents / (zero) log-weights live in res_* (lazy slot order)
+    bool parents_lazy = false;          // parents of the last (binned) resample still sit in res_parent / perm (a step may have moved the states on)
+    bool sh_parents_lazy = false;       // ... or in column D of the exchange rows sh_rows / sh_req_slot
+    // level-1 table built by the last workgroup of the level-0 launch (mp_tab); deviates drawn one launch ahead
+    unsigned int* tab_ticket = nullptr;
+    u64* tab_incl = nullptr;
+    double* tab_ratio = nullptr;
+    mp_tab_head* tab_head = nullptr;
+    int use_k1_table = 1;               // MP_K1_TABLE=0: every k_bin_draws workgroup builds the table itself (A/B measurements)
+    double* zpre = nullptr;             // [n][ns] standard deviates of time step zpre_t, drawn by k_resolve_bins
+    long long zpre_t = -1;
+    int use_predraw = 1;                // MP_PREDRAW=0: k_propagate draws its own deviates
     bool rows_fresh = false;            // cx / guide / tile_* describe the current log-weights
     // sharded-resample scratch (allocated on first use)
     unsigned char* sh_dest = nullptr;
@@ -317,6 +363,17 @@ struct mp_pf {
     double fam_ms[MP_K_COUNT] = {0, 0, 0, 0};
     uint64_t fam_launches[MP_K_COUNT] = {0, 0, 0, 0};
 };
+
+static mp_tab tab_of(const mp_pf* h) {
+    mp_tab t;
+    const bool on = h->use_k1_table && !h->sharded && h->tab_ticket;
+    t.ticket = on ? h->tab_ticket : nullptr;
+    t.incl = h->tab_incl;
+    t.ratio = h->tab_ratio;
+    t.head = h->tab_head;
+    t.S = h->S;
+    return t;
+}
 
 static hipEvent_t get_event(mp_pf* h) {
     if (!h->event_pool.empty()) {
@@ -382,6 +439,7 @@ static int32_t materialize(mp_pf* h) {
         hipLaunchKernelGGL(k_shard_adopt_rows, dim3((unsigned)((h->n + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, h->stream, h->n,
                            h->ops->dim_state, h->sh_rows, h->sh_req_slot, h->x[h->cur], h->parent);
         h->sh_lazy = false;
+        h->sh_parents_lazy = false;
         int32_t rc = check_launch("k_shard_adopt_rows");
         if (rc != MP_OK) return rc;
     }
@@ -395,6 +453,7 @@ static int32_t materialize(mp_pf* h) {
                        h->logw);
     if (h->ops->dim_state > 1) h->cur ^= 1;   // wider states were gathered from the pre-resample buffer into the other one
     h->permuted = false;
+    h->parents_lazy = false;                  // k_unpermute wrote parent[] too
     return check_launch("k_unpermute");
 }
 
@@ -419,13 +478,20 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.cx = h->cx; a.guide = h->guide; a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
     a.grid = h->nt;
     a.stream = h->stream;
+    a.aux.zpre = (h->zpre && h->zpre_t == h->t) ? h->zpre : nullptr;   // drawn for exactly this time step by the last resample's lookup kernel
+    a.aux.tab = tab_of(h);
     {
         LaunchTimer lt(h, MP_K_PROPAGATE);
         h->ops->propagate(a);
     }
+    h->zpre_t = -1;
     h->t += 1;
     if (gather_here) h->cur ^= 1;
     h->logw_zero = false;
+    // parents of that resample stay where they are (res_parent / perm, or the exchange rows) until somebody asks for them
+    // or the next resample replaces them: mp_pf_read_parents (particle_filter.rs:20 keeps `parents` across `step`)
+    if (h->permuted) h->parents_lazy = true;
+    if (h->sh_lazy) h->sh_parents_lazy = true;
     h->sh_lazy = false;
     h->permuted = false;   // k_propagate wrote x[cur] and logw in slot order ...
     h->rows_fresh = true;  // ... and level 0 of their normalisation
@@ -449,7 +515,7 @@ static int32_t ensure_rows(mp_pf* h) {
     {
         LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
         hipLaunchKernelGGL(k_normalize_tiles, dim3(h->nt), dim3(TILE_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->ops->dim_state, h->n, h->cx, h->guide,
-                           h->tile_m, h->tile_W, h->tile_W2);
+                           h->tile_m, h->tile_W, h->tile_W2, tab_of(h));
     }
     h->rows_fresh = true;
     return check_launch("k_normalize_tiles");
@@ -513,6 +579,10 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     {
         const char* env = getenv("MP_BINNED_RESAMPLE");
         if (env && env[0] == '0') h->use_binned = 0;
+        env = getenv("MP_K1_TABLE");
+        if (env && env[0] == '0') h->use_k1_table = 0;
+        env = getenv("MP_PREDRAW");
+        if (env && env[0] == '0') h->use_predraw = 0;
     }
     HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
     HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
@@ -525,6 +595,15 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     h->tile_W = h->tiles_own + h->nt;
     h->tile_W2 = h->tiles_own + 2 * (size_t)h->nt;
     HIPCK(hipMalloc(&h->scal, sizeof(mp_dev_scalars)));
+    if (!h->sharded) {
+        HIPCK(hipMalloc(&h->tab_ticket, 64));   // a line of its own
+        HIPCK(hipMemsetAsync(h->tab_ticket, 0, 64, h->stream));
+        HIPCK(hipMalloc(&h->tab_incl, sizeof(u64) * h->nt));
+        HIPCK(hipMalloc(&h->tab_ratio, sizeof(double) * h->nt));
+        HIPCK(hipMalloc(&h->tab_head, sizeof(mp_tab_head)));
+        if (h->use_predraw && h->use_binned && h->ops->coop && h->ops->max_normals > 0)
+            HIPCK(hipMalloc(&h->zpre, sizeof(double) * n * (size_t)h->ops->max_normals));
+    }
     HIPCK(hipMalloc(&h->aos, sizeof(double) * n));   // scratch for importance sampling's normalised log-weights
     HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
     h->res_stride = 8ull * (u64)h->nchunks * BIN_CHUNK;
@@ -542,7 +621,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
         }
@@ -595,34 +674,47 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     HIPCK(hipSetDevice(h->device));
     int32_t rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
+    h->parents_lazy = false;   // this resample's parents replace whatever was still waiting to be read
+    h->sh_parents_lazy = false;
     const int d = h->ops->dim_state;
     bool binned = false;
     if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        const size_t lds_bins = sizeof(uint32_t) * 2 * BIN_ITEMS * (BIN_THREADS / 64) * 8;
-        if (!h->sharded && h->nt >= PREBUILT_TABLE_MIN_TILES) {
-            // big unsharded filters: the tile table once (k_shard_table over this filter's own packed tiles, a world of one)
-            rc = shard_scratch(h, 1, h->sh_cap ? h->sh_cap : 1);
-            if (rc != MP_OK) return rc;
-            hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)h->tile_m, 1, h->nt, h->S,
-                               h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo);
-            hipLaunchKernelGGL(k_bin_draws<true>, dim3(h->nchunks), dim3(BIN_THREADS), 2 * (sizeof(double) + sizeof(u64)) * (BIN_THREADS / 64) + lds_bins, h->stream,
-                               h->n, h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks,
-                               h->tile_m, h->tile_W, h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal,
-                               (const u64*)h->sh_incl_all, (const double*)h->sh_ratio_all);
+        const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (BIN_THREADS / 64) + sizeof(uint32_t) * 8;
+        const mp_tab tab = tab_of(h);
+        if (tab.ticket && h->nt <= K1_TABLE_LDS_MAX_TILES) {
+            // the table was built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles): copy to LDS
+            hipLaunchKernelGGL(k_bin_draws<1>, dim3(h->nchunks), dim3(BIN_THREADS), 24 * (size_t)h->nt + lds_tail, h->stream, h->n, h->n_global,
+                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W,
+                               h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)h->tab_incl,
+                               (const double*)h->tab_ratio, (const mp_tab_head*)h->tab_head);
+        } else if (tab.ticket) {
+            hipLaunchKernelGGL(k_bin_draws<2>, dim3(h->nchunks), dim3(BIN_THREADS), lds_tail, h->stream, h->n, h->n_global,
+                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W,
+                               h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)h->tab_incl,
+                               (const double*)h->tab_ratio, (const mp_tab_head*)h->tab_head);
         } else {
-            hipLaunchKernelGGL(k_bin_draws<false>, dim3(h->nchunks), dim3(BIN_THREADS), table_lds(h->nt, BIN_THREADS) + lds_bins, h->stream, h->n,
-                               h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m,
-                               h->tile_W, h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)nullptr,
-                               (const double*)nullptr);
+            hipLaunchKernelGGL(k_bin_draws<0>, dim3(h->nchunks), dim3(BIN_THREADS), 16 * (size_t)h->nt + lds_tail, h->stream, h->n, h->n_global,
+                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W,
+                               h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)nullptr,
+                               (const double*)nullptr, (const mp_tab_head*)nullptr);
         }
     }
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
             const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
-            hipLaunchKernelGGL(k_resolve_bins, dim3(ngroups * 8), dim3(K3B_THREADS), 0, h->stream, h->n, h->nchunks, h->seg_lt, h->seg_row,
-                               h->seg_cnt, h->cx, h->res_x, h->res_parent);
+            ResolveArgs r;
+            r.n = h->n; r.nchunks = h->nchunks; r.grid = ngroups * 8;
+            r.seg_lt = h->seg_lt; r.seg_row = h->seg_row; r.seg_cnt = h->seg_cnt; r.cx = h->cx; r.res_x = h->res_x; r.res_parent = h->res_parent;
+            r.t_next = h->t; r.slot_offset = h->slot_offset; r.k0 = (uint32_t)h->seed; r.k1 = (uint32_t)(h->seed >> 32);
+            // the deviates of the NEXT time step (kernel time index h->t) are drawn while the lookups are in flight
+            const bool pre = h->zpre && h->ops->n_normals(h->t) > 0;
+            r.zpre = pre ? h->zpre : nullptr;
+            r.pre_per = (u64)K3B_THREADS * ((h->n + (u64)K3B_THREADS * (u64)r.grid - 1) / ((u64)K3B_THREADS * (u64)r.grid));
+            r.stream = h->stream;
+            h->ops->resolve(r);
+            if (pre) h->zpre_t = h->t;
             binned = true;
         } else if (scheme == MP_RESAMPLE_STRATIFIED) {
             hipLaunchKernelGGL(k_resample_gather<2>, dim3(h->k3_grid), dim3(KG_THREADS), table_lds(h->nt, KG_THREADS), h->stream, h->n, h->n,
@@ -738,6 +830,21 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
     if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
     { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
+    // a step after a lazy resample moved the states on but left the parents where the resample put them
+    if (h->parents_lazy) {
+        hipLaunchKernelGGL(k_parents_from_segments, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->nchunks, h->perm,
+                           h->res_parent, h->parent);
+        h->parents_lazy = false;
+        int32_t rcp = check_launch("k_parents_from_segments");
+        if (rcp != MP_OK) return rcp;
+    }
+    if (h->sh_parents_lazy) {
+        hipLaunchKernelGGL(k_shard_adopt_parents, dim3((unsigned)((h->n + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, h->stream, h->n,
+                           h->ops->dim_state, h->sh_rows, h->sh_req_slot, h->parent);
+        h->sh_parents_lazy = false;
+        int32_t rcp = check_launch("k_shard_adopt_parents");
+        if (rcp != MP_OK) return rcp;
+    }
     HIPCK(hipMemcpyAsync(out, h->parent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
     return MP_OK;
@@ -819,6 +926,8 @@ int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total
     }
     int32_t rc = check_launch("k_shard_scatter");
     if (rc != MP_OK) return rc;
+    h->parents_lazy = false;   // k_shard_scatter wrote parent[]
+    h->sh_parents_lazy = false;
     h->cur ^= 1;
     h->rows_fresh = false;
     h->resample_count += 1;
@@ -969,6 +1078,8 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
     // from row sh_req_slot[i] of the exchange buffer; anything else first copies states and parents into slot order.
     h->sh_rows = d_rows_in;
     h->sh_lazy = true;
+    h->parents_lazy = false;
+    h->sh_parents_lazy = false;
     h->logw_zero = true;   // log_weights.fill(0.) (:114): the next propagate does not re-read them; anything else clears the buffer first
     h->cur ^= 1;
     h->rows_fresh = false;
@@ -1067,6 +1178,8 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
     }
     h->sh_rows = d_rows;
     h->sh_lazy = true;     // the next propagate reads slot i's state from row sh_req_slot[i] of d_rows
+    h->parents_lazy = false;
+    h->sh_parents_lazy = false;
     h->logw_zero = true;
     h->cur ^= 1;
     h->rows_fresh = false;
@@ -1187,6 +1300,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->guide);
     (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->scal);
     (void)hipFree(h->aos);
+    (void)hipFree(h->tab_ticket); (void)hipFree(h->tab_incl); (void)hipFree(h->tab_ratio); (void)hipFree(h->tab_head); (void)hipFree(h->zpre);
     (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all); (void)hipFree(h->sh_ratio_all);
@@ -1286,5 +1400,21 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
     }
     return MP_OK;
 }
+
+#ifdef MP_STAMPS
+// diagnostics only (libmodppl_hip_stamps.so, tools/stamp_probe.py): enable / read the per-workgroup stamps
+int32_t mp_debug_stamps(unsigned long long* host_out /* [KERNELS][MAX_WG][SLOTS] or NULL to (re)arm */) {
+    static unsigned long long* d_buf = nullptr;
+    const size_t bytes = sizeof(unsigned long long) * MP_STAMP_KERNELS * MP_STAMP_MAX_WG * MP_STAMP_SLOTS;
+    if (!d_buf) {
+        HIPCK(hipMalloc(&d_buf, bytes));
+        HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_mp_stamp_buf), &d_buf, sizeof(d_buf)));
+    }
+    HIPCK(hipDeviceSynchronize());
+    if (host_out) HIPCK(hipMemcpy(host_out, d_buf, bytes, hipMemcpyDeviceToHost));
+    else HIPCK(hipMemset(d_buf, 0, bytes));
+    return MP_OK;
+}
+#endif
 
 }  // extern "C"

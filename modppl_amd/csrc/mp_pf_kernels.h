@@ -3,6 +3,31 @@
 // Spec: DESIGN.md §4; CPU restatement: oracle/src/inference.hpp.
 #pragma once
 // ---------------------------------------------------------------------------------------------
+// diagnostic stamps (tools/stamp_probe.py; compiled only with -DMP_STAMPS into libmodppl_hip_stamps.so, never into the
+// product library): wave 0 of every workgroup records shader-clock / 100 MHz real-time stamps into a buffer of its own.
+// ---------------------------------------------------------------------------------------------
+#ifdef MP_STAMPS
+constexpr int MP_STAMP_MAX_WG = 16384, MP_STAMP_SLOTS = 8, MP_STAMP_KERNELS = 4;
+__device__ unsigned long long* g_mp_stamp_buf = nullptr;
+__device__ __forceinline__ void mp_stamp(int kernel, int slot, int what /*0 shader clock, 1 real time, 2 hw id*/) {
+    if (threadIdx.x == 0 && g_mp_stamp_buf && blockIdx.x < MP_STAMP_MAX_WG) {
+        unsigned long long t = 0;
+        if (what == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        else if (what == 1) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        else {
+            unsigned int a, b;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(a), "=s"(b));
+            t = ((unsigned long long)b << 32) | a;
+        }
+        g_mp_stamp_buf[((size_t)kernel * MP_STAMP_MAX_WG + blockIdx.x) * MP_STAMP_SLOTS + slot] = t;
+    }
+}
+#define MP_STAMP(k, s, w) mp_stamp(k, s, w)
+#else
+#define MP_STAMP(k, s, w) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // device scalars
 // ---------------------------------------------------------------------------------------------
 struct mp_dev_scalars {
@@ -27,7 +52,8 @@ constexpr int GUIDE_DIRECT = 8;                  // bucket runs longer than this
 constexpr int FIX_BITS = 51;                     // level-0 fixed point: q = rint(exp(lw - m_tile) * 2^51), 2048 * 2^51 < 2^63
 constexpr int BIN_CHUNK = 1024;                  // output slots per chunk of the binned resampler
 constexpr int BIN_THREADS = 512;                  // x 2 draws per thread (256 x 4: 20.4 us, 512 x 2: 18.4 us, 1024 x 1: 23.9 us at 2^20)
-constexpr int BIN_ITEMS = BIN_CHUNK / BIN_THREADS;
+constexpr int BIN_ITEMS = BIN_CHUNK / BIN_THREADS;   // = 2: a thread owns two ADJACENT output slots (one Philox block)
+static_assert(BIN_ITEMS == 2, "k_bin_draws: two adjacent draws per thread");
 constexpr int K3B_THREADS = 256;                  // k_resolve_bins: 128 lanes per quad of K3B_ITEMS chunks
 constexpr int K3B_ITEMS = 1;                      // segments per thread: 4 / 2 / 1 measured 19.0 / 17.5 / 16.2 us (more waves hide the two dependent hops better than 4 chains per lane)
 constexpr int BIN_GROUP = (K3B_THREADS / 128) * K3B_ITEMS;   // chunks per k_resolve_bins workgroup
@@ -91,18 +117,145 @@ __device__ __forceinline__ int mp_guide_shift(u64 W) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 0 of the normalisation for ONE tile, by the workgroup (TILE_THREADS threads) that owns it.
-// Thread t holds rows tile*2048 + 4t .. 4t+3: log-weights lw[] and first state components xv[].
+// level 1 built ONCE per normalisation, by the last workgroup of the level-0 launch to finish (atomic ticket): the
+// job's tile table as global arrays, for the draw kernels of the resample that follows (no launch in between).
+//   incl[b] = inclusive prefix of T_b;  ratio[b] = (double)W_b / (double)T_b;  head = {m, Q, Q2}.
+// Cross-workgroup hand-off inside the launch (cdna_hip_programming.md G16, counter form): every workgroup stores its
+// (m_b, W_b, W2_b) write-through (agent-scope atomic stores = sc1), drains them, then takes a ticket with an agent-scope
+// atomic add; the workgroup whose add came last reads all of them with agent-scope (sc1) loads after a workgroup barrier.
+// Nothing depends on which workgroup that is.  The ticket word is reset by that workgroup for the next launch.
+// ---------------------------------------------------------------------------------------------
+struct mp_tab_head {
+    double m;
+    u64 Q, Q2;
+    int S, nt;
+};
+struct mp_tab {               // null ticket = no table is built (sharded handles: the job's tiles live on other ranks)
+    unsigned int* ticket;
+    u64* incl;
+    double* ratio;
+    mp_tab_head* head;
+    int S;
+};
+__device__ __forceinline__ double mp_ld_agent(const double* p) {
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ u64 mp_ld_agent(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mp_st_agent(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<u64*>(p), __builtin_bit_cast(u64, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mp_st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// by ONE workgroup of THREADS threads; thread t owns the `per` consecutive tiles t*per ..  (three short passes with O(1)
+// registers: this code sits in the tail of k_propagate and must not raise its register count)
+template <int THREADS>
+__device__ __forceinline__ void build_tile_table_global(const double* tile_m, const u64* tile_W, const u64* tile_W2, int nt, const mp_tab& tab) {
+    __shared__ double s_tred[THREADS / 64];
+    __shared__ u64 s_ttot[THREADS / 64];
+    __shared__ u64 s_ttot2[THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nt + THREADS - 1) / THREADS;
+    const int b0 = tid * per;
+    double m = MP_NEG_INF;
+#pragma unroll 1
+    for (int j = 0; j < per; ++j)
+        if (b0 + j < nt) m = fmax(m, mp_ld_agent(tile_m + b0 + j));
+    m = wave_max(m);
+    if (lane == 0) s_tred[wave] = m;
+    __syncthreads();
+    m = s_tred[0];
+#pragma unroll 1
+    for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_tred[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + tab.S - FIX_BITS) << 52);  // 2^(S-51)
+    u64 run = 0, run2 = 0;
+#pragma unroll 1
+    for (int j = 0; j < 2 * per; ++j) {   // even j: T_b, odd j: T2_b — one mp_exp body, so the tail of k_propagate stays within its registers
+        const int b = b0 + (j >> 1);
+        if (b < nt) {
+            const bool second = (j & 1) != 0;
+            const double d = mp_ld_agent(tile_m + b) - m;
+            const double f = ok ? mp_exp(second ? 2. * d : d) : 0.;
+            const u64 T = mp_quantize((double)mp_ld_agent((second ? tile_W2 : tile_W) + b) * f * sc, 1.0);
+            if (second) {
+                run2 += T;
+            } else {
+                tab.incl[b] = T;   // parked; this thread turns it into the prefix below
+                run += T;
+            }
+        }
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    const u64 tot2 = wave_sum_u64(run2);
+    if (lane == 63) s_ttot[wave] = incl;
+    if (lane == 0) s_ttot2[wave] = tot2;
+    __syncthreads();
+    u64 woff = 0, Q = 0, Q2 = 0;
+#pragma unroll 1
+    for (int k = 0; k < THREADS / 64; ++k) {
+        if (k < wave) woff += s_ttot[k];
+        Q += s_ttot[k];
+        Q2 += s_ttot2[k];
+    }
+    u64 cum = woff + (incl - run);
+#pragma unroll 1
+    for (int j = 0; j < per; ++j) {
+        if (b0 + j < nt) {
+            const u64 T = tab.incl[b0 + j];
+            cum += T;
+            tab.incl[b0 + j] = cum;
+            tab.ratio[b0 + j] = (double)mp_ld_agent(tile_W + b0 + j) / (double)T;
+        }
+    }
+    if (tid == 0) {
+        mp_tab_head h;
+        h.m = m; h.Q = Q; h.Q2 = Q2; h.S = tab.S; h.nt = nt;
+        *tab.head = h;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 0 of the normalisation for ONE tile, by the workgroup (THREADS threads) that owns it.
+// Thread t holds rows tile*2048 + ITEMS*t ..: log-weights lw[] and first state components xv[].
 //   m_b = max lw;  a = mp_exp(lw - m_b);  q = rint(a * 2^51);  rows = tile-local inclusive prefix;  W_b, W2_b;  guide.
 // ---------------------------------------------------------------------------------------------
+// mp_exp for arguments <= 0 (level 0: lw - max): the overflow arms of mp_exp cannot be taken; same bits for every x <= 0 and NaN
+__device__ __forceinline__ double mp_exp_nonpos(double x) {
+    if (x != x) return x;
+    if (x < -745.1332191019412) return 0.0;
+    const double INV_LN2 = 1.4426950408889634;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    const double kf = rint(x * INV_LN2);
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.388888888888889e-03);
+    p = fma(p, r, 8.333333333333333e-03);
+    p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    const double y = 1.0 + fma(r * r, p, r);
+    const int k = (int)kf;   // <= 0
+    if (k < -1022) return y * mp_u2f((uint64_t)(k + 54 + 1023) << 52) * 5.551115123125783e-17;  // 2^-54
+    return y * mp_u2f((uint64_t)(k + 1023) << 52);
+}
+
 template <int THREADS>
 __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS], const double (&xv)[TILE / THREADS], u64 n, u64 tile,
                                                mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
-                                               double* __restrict__ tile_m, u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
+                                               double* tile_m, u64* tile_W, u64* tile_W2, const mp_tab& tab) {
     constexpr int ITEMS_ = TILE / THREADS;   // 512 x 4 or 1024 x 2: a tile is always 2048 consecutive slots
     __shared__ double s_red[THREADS / 64];
     __shared__ u64 s_wsum[THREADS / 64];
-    __shared__ u64 s_wsum2[THREADS / 64];
+    __shared__ u64 s_W2;
+    __shared__ int s_last;
     __shared__ __attribute__((aligned(16))) unsigned short s_guide[GUIDE_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 base = tile * TILE + (u64)tid * ITEMS_;
@@ -113,6 +266,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
         if (base + j < n) m = fmax(m, lw[j]);
     m = wave_max(m);
     if (lane == 0) s_red[wave] = m;
+    if (tid == 0) s_W2 = 0ull;
     if constexpr (THREADS == 512) reinterpret_cast<u64*>(s_guide)[tid] = 0ull;  // THREADS x (8 | 4) B = the whole guide
     else reinterpret_cast<uint32_t*>(s_guide)[tid] = 0u;
     __syncthreads();
@@ -126,15 +280,15 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
 #pragma unroll
     for (int j = 0; j < ITEMS_; ++j) {
         const bool live = ok && (base + j < n);
-        const double a = live ? mp_exp(lw[j] - m) : 0.;
+        const double a = live ? mp_exp_nonpos(lw[j] - m) : 0.;
         run += mp_quantize51(a);
         run2 += mp_quantize51(a * a);
         c[j] = run;
     }
     const u64 incl = wave_incl_scan_u64(run, lane);
-    const u64 wtot2 = wave_sum_u64(run2);
     if (lane == 63) s_wsum[wave] = incl;
-    if (lane == 0) s_wsum2[wave] = wtot2;
+    // W2_b is an integer sum, so any order gives the same bits: one LDS atomic per lane instead of a wave reduction
+    atomicAdd(reinterpret_cast<unsigned long long*>(&s_W2), (unsigned long long)run2);
     __syncthreads();
     // cross-wave offsets on the scalar unit: the per-wave totals and `wave` are wave-uniform, so the sums need no VALU issue
     u64 woff = 0, W = 0;
@@ -147,6 +301,22 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
         W += v;
     }
     const u64 off = woff + (incl - run);
+    MP_STAMP(0, 7, 0);
+    // the tile's scalars go out (and the ticket is taken) now: its round trip is covered by the row stores and the guide
+    unsigned int my_ticket = 0;
+    if (tid == 0) {
+        if (tab.ticket) {
+            mp_st_agent(tile_m + tile, m);
+            mp_st_agent(tile_W + tile, W);
+            mp_st_agent(tile_W2 + tile, s_W2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores are out before the ticket says so
+            my_ticket = __hip_atomic_fetch_add(tab.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            tile_m[tile] = m;
+            tile_W[tile] = W;
+            tile_W2[tile] = s_W2;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS_; ++j) {
         if (base + j < n) {
@@ -155,14 +325,6 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
             row.x0 = xv[j];
             cx[base + j] = row;
         }
-    }
-    if (tid == 0) {
-        u64 t2 = 0;
-#pragma unroll
-        for (int k = 0; k < THREADS / 64; ++k) t2 += s_wsum2[k];
-        tile_m[tile] = m;
-        tile_W[tile] = W;
-        tile_W2[tile] = t2;
     }
 
     // ---- guide table of this tile ------------------------------------------------------------
@@ -192,16 +354,23 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
         for (int g = lo + lane; g <= hi; g += 64) s_guide[g] = (unsigned short)jj;
         pending &= pending - 1;
     }
+    if (tid == 0) s_last = (tab.ticket != nullptr && my_ticket == gridDim.x - 1u) ? 1 : 0;
     __syncthreads();
     if constexpr (THREADS == 512) reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
     else reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint32_t*>(s_guide)[tid];
+    if (s_last) {   // workgroup-uniform: every other workgroup's scalars are out (their tickets precede ours)
+#ifndef MP_TEST_NOTABLE
+        build_tile_table_global<THREADS>(tile_m, tile_W, tile_W2, (int)gridDim.x, tab);
+#endif
+        if (tid == 0) __hip_atomic_store(tab.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // standalone form: used when the log-weights changed without a propagate (after a resample, before a query or a
 // second resample)
 __global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* __restrict__ logw, const double* __restrict__ x0, int D, u64 n,
                                                                   mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
-                                                                  double* __restrict__ tile_m, u64* __restrict__ tile_W, u64* __restrict__ tile_W2) {
+                                                                  double* tile_m, u64* tile_W, u64* tile_W2, mp_tab tab) {
     const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * TILE_ITEMS;
     double lw[TILE_ITEMS], xv[TILE_ITEMS];
     if (base + TILE_ITEMS <= n) {
@@ -223,7 +392,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* 
             xv[j] = (base + j < n) ? x0[(base + j) * (u64)D] : 0.;
         }
     }
-    normalize_tile<TILE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
+    normalize_tile<TILE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2, tab);
 }
 
 // GenFn::simulate over an Unfold model (dynunfold.rs:22-39): one lane = one trace of n_steps kernel calls, every site
@@ -251,52 +420,194 @@ __global__ __launch_bounds__(256) void k_simulate(Model model, u64 n, uint32_t k
 }
 
 // ---------------------------------------------------------------------------------------------
+// Standard deviates of the polar method for a block of particles, workgroup-cooperatively.
+// z[p * NS + s] = u * c (normal.rs:19-26) of particle (lane's p-th) and free normal site s, from the attempts
+// att = 0, 1, 2 ... of Philox stream (slot, t, MODEL | site): the first accepted one, exactly what the reference's
+// recursion returns.  A lane-local rejection loop makes a wave iterate max-over-lanes of the attempts (~2.7 Philox
+// blocks per deviate at 2 deviates per lane, more for the slowest wave of a workgroup, which the tile's barrier then
+// waits for); here every lane makes attempt 0 of its own deviates, the rejected ones (21.5 %) are queued in LDS and
+// retried by the workgroup's first lanes, one attempt per round (the attempt number is the round: wave-uniform),
+// until fewer than a wave's worth is left, which one wave finishes.  ~1.35 blocks per deviate, equal work per wave.
+// Results depend on nothing but the counters: which lane computes an attempt changes no bit.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t MP_MAX_ATTEMPTS = 1u << 16;   // exit condition of every retry loop (acceptance pi/4: never reached)
+template <class Model, int THREADS, int LANE_ITEMS>
+struct mp_coop {
+    static constexpr int NS = Model::MAX_NORMALS;
+    static constexpr int M = LANE_ITEMS * NS;
+    static constexpr int NITEMS = THREADS * M;
+    // retry queue capacity: the expected load is 0.215 * NITEMS; an item that does not fit is retried by its own lane
+    static constexpr int CAP = NITEMS >= 4096 ? NITEMS / 3 : (NITEMS >= 512 ? NITEMS / 2 : NITEMS);
+};
+template <class Model, int THREADS, int LANE_ITEMS>
+__device__ __forceinline__ void mp_coop_std_normals(const Model& model, int ns, long long t, u64 wg_slot0 /* global slot of the block's first particle */,
+                                                    uint32_t n_live /* particles of the block that exist */, uint32_t k0, uint32_t k1,
+                                                    double (&z)[LANE_ITEMS * Model::MAX_NORMALS]) {
+    using C = mp_coop<Model, THREADS, LANE_ITEMS>;
+    constexpr int NS = C::NS, M = C::M, CAP = C::CAP;
+    __shared__ uint32_t s_q[2][CAP];           // (item | result index << 16) of the deviates still to be drawn
+    __shared__ double s_res[CAP][2];           // accepted (u, r) by result index
+    __shared__ uint32_t s_qn[3];               // queue lengths, rotating: read / push / zero
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t dom = (uint32_t)MP_DOM_MODEL << 16;
+    if (tid < 3) s_qn[tid] = 0u;
+    __syncthreads();
+    double pu[M], pr[M];
+    int res_idx[M];                            // -1: accepted at attempt 0; >= 0: result index; -2: retried by this lane
+    // ---- attempt 0 of every deviate of this lane --------------------------------------------
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+        const int p = q / NS, sidx = q % NS;
+        const uint32_t pl = (uint32_t)(tid * LANE_ITEMS + p);       // particle of the block
+        const bool live = sidx < ns && pl < n_live;
+        pu[q] = 0.; pr[q] = 1.; res_idx[q] = -1;
+        bool rej = false;
+        if (live) {
+            const mp_u64x2 b = mp_philox4x32_10((uint32_t)(wg_slot0 + pl), (uint32_t)t, dom | model.normal_site(sidx), 0u, k0, k1);
+            rej = !mp_polar_attempt(b, &pu[q], &pr[q]);
+        }
+        const u64 bal = __ballot(rej);
+        if (bal) {   // wave-uniform
+            const int leader = __ffsll((long long)bal) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&s_qn[0], (uint32_t)__popcll(bal));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (rej) {
+                const uint32_t e = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (e < (uint32_t)CAP) {
+                    s_q[0][e] = (pl * NS + (uint32_t)sidx) | (e << 16);
+                    res_idx[q] = (int)e;
+                } else {
+                    res_idx[q] = -2;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- retry rounds: attempt number = round ------------------------------------------------
+    uint32_t nq = s_qn[0] < (uint32_t)CAP ? s_qn[0] : (uint32_t)CAP;
+    int cur = 0;
+    uint32_t att = 1;
+    while (nq > 64u && att < MP_MAX_ATTEMPTS) {   // workgroup-uniform
+        const int rd = (int)((att - 1) % 3), wr = (int)(att % 3), zr = (int)((att + 1) % 3);
+        (void)rd;
+        if (tid == 0) s_qn[zr] = 0u;              // next round's push counter: nobody touches it in this round
+        for (uint32_t e = (uint32_t)tid; e < nq; e += THREADS) {
+            const uint32_t ent = s_q[cur][e];
+            const uint32_t item = ent & 0xFFFFu, ri = ent >> 16;
+            const uint32_t pl = item / NS, sidx = item % NS;
+            const mp_u64x2 b = mp_philox4x32_10((uint32_t)(wg_slot0 + pl), (uint32_t)t, dom | model.normal_site((int)sidx), att, k0, k1);
+            double u, r;
+            const bool rej = !mp_polar_attempt(b, &u, &r);
+            if (!rej) { s_res[ri][0] = u; s_res[ri][1] = r; }
+            const u64 bal = __ballot(rej);
+            if (bal) {
+                const int leader = __ffsll((long long)bal) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&s_qn[wr], (uint32_t)__popcll(bal));
+                base = (uint32_t)__shfl((int)base, leader, 64);
+                if (rej) s_q[cur ^ 1][base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = ent;
+            }
+        }
+        __syncthreads();
+        nq = s_qn[wr];
+        cur ^= 1;
+        ++att;
+    }
+    if (tid < 64 && (uint32_t)tid < nq) {         // at most one wave's worth left: finished by lane-local loops
+        const uint32_t ent = s_q[cur][tid];
+        const uint32_t item = ent & 0xFFFFu, ri = ent >> 16;
+        const uint32_t pl = item / NS, sidx = item % NS;
+        double u = 0., r = 1.;
+        for (uint32_t a = att; a < MP_MAX_ATTEMPTS; ++a) {
+            const mp_u64x2 b = mp_philox4x32_10((uint32_t)(wg_slot0 + pl), (uint32_t)t, dom | model.normal_site((int)sidx), a, k0, k1);
+            if (mp_polar_attempt(b, &u, &r)) break;
+        }
+        s_res[ri][0] = u; s_res[ri][1] = r;
+    }
+    __syncthreads();
+    // ---- every lane: collect its retried deviates, then the parameter-free part of normal.rs:25-26 once per deviate ----
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+        const int p = q / NS, sidx = q % NS;
+        if (res_idx[q] >= 0) { pu[q] = s_res[res_idx[q]][0]; pr[q] = s_res[res_idx[q]][1]; }
+        if (res_idx[q] == -2) {   // did not fit the queue (never, in practice): own loop
+            const uint32_t pl = (uint32_t)(tid * LANE_ITEMS + p);
+            for (uint32_t a = 1; a < MP_MAX_ATTEMPTS; ++a) {
+                const mp_u64x2 b = mp_philox4x32_10((uint32_t)(wg_slot0 + pl), (uint32_t)t, dom | model.normal_site(sidx), a, k0, k1);
+                if (mp_polar_attempt(b, &pu[q], &pr[q])) break;
+            }
+        }
+        z[q] = mp_std_normal_from_pair(pu[q], pr[q]);
+    }
+}
+
+// whether a model's deviates are drawn cooperatively / ahead of the step (few sites per particle) or by the lane-local
+// queue of k_propagate (many sites per particle: the queue is long enough to even out the attempts, and the LDS is not)
+template <class Model>
+constexpr bool mp_coop_model() { return Model::MAX_NORMALS <= 4; }
+
+// ---------------------------------------------------------------------------------------------
 // K1: propagate + weight + level 0 of the normalisation, one workgroup per tile
 // ---------------------------------------------------------------------------------------------
-// A lane owns the 4 consecutive particles 4*tid .. 4*tid+3 of its tile, processed in rounds of k1_items<Model>()
-// particles.  Per round, phase 1 runs every polar rejection loop of the lane as ONE lane-local work queue over its
-// (particle, normal site) items: a wave iterates max-over-lanes of the SUM of attempts instead of the sum over
-// items of the max, i.e. ~1.9 Philox blocks per item at 4 items instead of ~3.6 (acceptance pi/4, 64 lanes).
-// Phase 2 runs the model kernel per particle on the accepted pairs.
+// A lane owns LANE_ITEMS consecutive particles of its tile.  Standard deviates of the free normal sites come
+//   (a) from zpre[slot][site] when the resample's lookup kernel drew them for this time step (k_resolve_bins), or
+//   (b) from mp_coop_std_normals (few sites per particle), or
+//   (c) from a lane-local work queue over the lane's (particle, site) items (many sites: ~1.6 blocks per item at 16).
+// Then the model kernel runs per particle in Generate mode on them.
+struct mp_k1_aux {
+    const double* zpre;     // [n][ns] standard deviates for THIS time step, or null
+    mp_tab tab;
+};
 template <class Model, int THREADS>
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
                                                             mp_obs obs, mp_state0 s0, int overwrite,
                                                             const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
                                                             int nchunks, mp_cx* __restrict__ cx,
-                                                            unsigned short* __restrict__ guide, double* __restrict__ tile_m,
-                                                            u64* __restrict__ tile_W, u64* __restrict__ tile_W2,
-                                                            const uint32_t* __restrict__ inv, const uint32_t* __restrict__ res_parent) {
+                                                            unsigned short* __restrict__ guide, double* tile_m,
+                                                            u64* tile_W, u64* tile_W2,
+                                                            const uint32_t* __restrict__ inv, const uint32_t* __restrict__ res_parent, mp_k1_aux aux) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int LANE_ITEMS = TILE / THREADS;
-    constexpr int ITEMS = k1_items<Model>() < LANE_ITEMS ? k1_items<Model>() : LANE_ITEMS;
-    constexpr int ROUNDS = LANE_ITEMS / ITEMS;
-    constexpr int M = ITEMS * NS;
     const int ns = model.n_normals(t);  // wave-uniform
+    MP_STAMP(0, 0, 0); MP_STAMP(0, 1, 1); MP_STAMP(0, 6, 2);
     const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * LANE_ITEMS;
     double lw[LANE_ITEMS], xv[LANE_ITEMS];
+    double z[LANE_ITEMS * NS];
 #pragma unroll
     for (int j = 0; j < LANE_ITEMS; ++j) { lw[j] = MP_NEG_INF; xv[j] = 0.; }
+    // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
+    if (aux.zpre) {
 #pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) {
-        const u64 i0 = base + (u64)rd * ITEMS;
-        // ---- phase 1: accepted (u, r) pairs for every (particle, normal site) of this round ----
-        double pu[M], pr[M];
+        for (int p = 0; p < LANE_ITEMS; ++p)
 #pragma unroll
-        for (int q = 0; q < M; ++q) { pu[q] = 0.; pr[q] = 1.; }
-        {
+            for (int s = 0; s < NS; ++s) z[p * NS + s] = (s < ns && base + p < n) ? aux.zpre[(base + p) * (u64)ns + s] : 0.;
+    } else if constexpr (mp_coop_model<Model>()) {
+        const u64 tile0 = (u64)blockIdx.x * TILE;
+        const uint32_t n_live = (uint32_t)((n - tile0) < (u64)TILE ? (n - tile0) : (u64)TILE);
+        if (ns > 0) mp_coop_std_normals<Model, THREADS, LANE_ITEMS>(model, ns, t, slot_offset + tile0, n_live, k0, k1, z);
+    } else {
+        // lane-local queue, rounds of ITEMS particles (ITEMS * NS accepted pairs in registers at a time)
+        constexpr int ITEMS = k1_items<Model>() < LANE_ITEMS ? k1_items<Model>() : LANE_ITEMS;
+        constexpr int ROUNDS = LANE_ITEMS / ITEMS;
+        constexpr int M = ITEMS * NS;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const u64 i0 = base + (u64)rd * ITEMS;
+            double pu[M], pr[M];
+#pragma unroll
+            for (int q = 0; q < M; ++q) { pu[q] = 0.; pr[q] = 1.; }
             int p = 0, sidx = 0;  // current item: particle p of the round, normal site index sidx
             uint32_t att = 0;
-            while (p < ITEMS && ns > 0) {
+            while (p < ITEMS && ns > 0 && att < MP_MAX_ATTEMPTS) {
                 const u64 i = i0 + (u64)p;
                 if (i >= n) break;
                 const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
                                                     ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
-                const double u = mp_u01(b.a) * 2. - 1.;
-                const double v = mp_u01(b.b) * 2. - 1.;
-                const double r = u * u + v * v;
-                if (r == 0. || r > 1.) {  // normal.rs:22
+                double u, r;
+                if (!mp_polar_attempt(b, &u, &r)) {  // normal.rs:22
                     ++att;
                 } else {
                     const int q = p * NS + sidx;
@@ -309,54 +620,59 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagat
                     if (++sidx == ns) { sidx = 0; ++p; }
                 }
             }
-        }
-        // ---- phase 2: the model kernel in Generate mode --------------------------------------
 #pragma unroll
-        for (int p = 0; p < ITEMS; ++p) {
-            const u64 i = i0 + (u64)p;
-            if (i < n) {
-                double prev[D], next[D];
-                if (inv) {
-                    // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row
-                    // {x[0..D), parent id} is row inv[i] of the exchange buffer (res_x here)
-                    const double* row = res_x + (u64)inv[i] * (u64)(D + 1);
-#pragma unroll
-                    for (int d = 0; d < D; ++d) prev[d] = row[d];
-                } else if (perm) {
-                    // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at
-                    // segment (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i]
-                    const uint32_t pr_ = perm[i];
-                    const u64 pos = MP_SEG_POS(pr_ >> 10, i >> 10, pr_ & 1023u, nchunks);
-                    if constexpr (D == 1) {
-                        prev[0] = res_x[pos];              // k_resolve_bins had it in the table row it found
-                    } else {
-                        // wider states are gathered here, straight from the parent's (particle-major) row of the
-                        // pre-resample buffer: one line per particle, hidden under this kernel's arithmetic
-                        const double* src = x_in + (u64)res_parent[pos] * D;
-#pragma unroll
-                        for (int d = 0; d < D; ++d) prev[d] = src[d];
-                    }
-                } else {
-#pragma unroll
-                    for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[i * D + d];
-                }
-                mp_stream rng;
-                rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
-                mp_generate_handler<Model> g(rng, obs.v, &pu[p * NS], &pr[p * NS]);
-                model(g, t, prev, next);
-#pragma unroll
-                for (int d = 0; d < D; ++d) x_out[i * D + d] = next[d];
-                // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to
-                // be all zero after a resample (log_weights.fill(0.), :114) and are not re-read
-                const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
-                logw[i] = w;
-                lw[rd * ITEMS + p] = w;
-                xv[rd * ITEMS + p] = next[0];
-            }
+            for (int q = 0; q < M; ++q) z[rd * M + q] = mp_std_normal_from_pair(pu[q], pr[q]);
         }
     }
+    MP_STAMP(0, 2, 0);
+    // ---- phase 2: the model kernel in Generate mode --------------------------------------
+#pragma unroll
+    for (int p = 0; p < LANE_ITEMS; ++p) {
+        const u64 i = base + (u64)p;
+        if (i < n) {
+            double prev[D], next[D];
+            if (inv) {
+                // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row
+                // {x[0..D), parent id} is row inv[i] of the exchange buffer (res_x here)
+                const double* row = res_x + (u64)inv[i] * (u64)(D + 1);
+#pragma unroll
+                for (int d = 0; d < D; ++d) prev[d] = row[d];
+            } else if (perm) {
+                // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at
+                // segment (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i]
+                const uint32_t pr_ = perm[i];
+                const u64 pos = MP_SEG_POS(pr_ >> 10, i >> 10, pr_ & 1023u, nchunks);
+                if constexpr (D == 1) {
+                    prev[0] = res_x[pos];              // k_resolve_bins had it in the table row it found
+                } else {
+                    // wider states are gathered here, straight from the parent's (particle-major) row of the
+                    // pre-resample buffer: one line per particle, hidden under this kernel's arithmetic
+                    const double* src = x_in + (u64)res_parent[pos] * D;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) prev[d] = src[d];
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[i * D + d];
+            }
+            mp_stream rng;
+            rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
+            mp_generate_handler<Model> g(rng, obs.v, &z[p * NS]);
+            model(g, t, prev, next);
+#pragma unroll
+            for (int d = 0; d < D; ++d) x_out[i * D + d] = next[d];
+            // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to
+            // be all zero after a resample (log_weights.fill(0.), :114) and are not re-read
+            const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
+            logw[i] = w;
+            lw[p] = w;
+            xv[p] = next[0];
+        }
+    }
+    MP_STAMP(0, 3, 0);
     // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----
-    normalize_tile<THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2);
+    normalize_tile<THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2, aux.tab);
+    MP_STAMP(0, 4, 0); MP_STAMP(0, 5, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -513,11 +829,23 @@ __device__ __forceinline__ uint32_t mp_systematic_k32(uint32_t rc, uint32_t k0, 
     const mp_u64x2 r = mp_philox4x32_10(0u, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | 1u, 0u, k0, k1);
     return (uint32_t)(r.a >> 32);
 }
-// Stratified resampling (extension): the same lattice with one uniform PER output slot, u_g = (g + k32_g / 2^32) / N
-// (Philox slot g, site 2); parents still come out sorted.
+// Stratified resampling (extension): the same lattice with one 32-bit uniform PER output slot, u_g = (g + k32_g / 2^32) / N:
+// word (g & 3) of Philox block g >> 2 at site 2 (oracle/src/rng.hpp resample_k32); parents still come out sorted.
 __device__ __forceinline__ uint32_t mp_stratified_k32(u64 g, uint32_t rc, uint32_t k0, uint32_t k1) {
-    const mp_u64x2 r = mp_philox4x32_10((uint32_t)g, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | 2u, 0u, k0, k1);
-    return (uint32_t)(r.a >> 32);
+    const mp_u64x2 r = mp_philox4x32_10((uint32_t)(g >> 2), rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | 2u, 0u, k0, k1);
+    const u64 w = (g & 2) ? r.b : r.a;
+    return (g & 1) ? (uint32_t)(w >> 32) : (uint32_t)w;
+}
+// The categorical draws of one resample (domain RESAMPLE) or of importance_resampling (domain IS) are ONE sequential
+// uniform stream, like the reference's loop over one rng (particle_filter.rs:38-40): draw g is half (g & 1) of Philox
+// block g >> 1, the block index in the counter's slot field (oracle/src/rng.hpp resample_rng).  A lane that owns the
+// adjacent draws 2j, 2j + 1 pays one block for both.
+__device__ __forceinline__ mp_u64x2 mp_resample_block(u64 g_pair, uint32_t rc, uint32_t domain, uint32_t k0, uint32_t k1) {
+    return mp_philox4x32_10((uint32_t)g_pair, rc, domain << 16, 0u, k0, k1);
+}
+__device__ __forceinline__ u64 mp_resample_k52(u64 g, uint32_t rc, uint32_t domain, uint32_t k0, uint32_t k1) {
+    const mp_u64x2 r = mp_resample_block(g >> 1, rc, domain, k0, k1);
+    return mp_u52((g & 1) ? r.b : r.a);
 }
 // target of global output slot g under scheme 1 (systematic, shared k32) or 2 (stratified)
 __device__ __forceinline__ u64 mp_target_lattice(int scheme, u64 g, uint32_t shared_k32, uint32_t rc, uint32_t k0, uint32_t k1, u64 Q, u64 n_global) {
@@ -595,8 +923,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_resample_gather(u64 n, u64 n_out
             if (SCHEME != 0) {
                 target = mp_target_lattice(SCHEME, slot_offset + (i < n_out ? i : 0), sys_k32, rc, k0, k1, Q, n_global);
             } else {
-                const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, (domain << 16), 0u, k0, k1);
-                target = mp_target(mp_u52(r.a), Q);
+                target = mp_target(mp_resample_k52(slot_offset + i, rc, domain, k0, k1), Q);
             }
             uint32_t b;
             mp_locate(s_incl, s_W, (uint32_t)nt, target, nt_over_Q, &b, &lt[k], &gslot[k]);
@@ -644,17 +971,19 @@ __global__ __launch_bounds__(KG_THREADS) void k_resample_gather(u64 n, u64 n_out
 // ---------------------------------------------------------------------------------------------
 // The row table (16 B x N) does not fit one XCD's 4 MB L2, so random row reads cross the fabric a full line at a
 // time.  But the top 3 bits of a draw's uniform say which EIGHTH of the CDF it lands in.  So:
-//   K3a k_bin_draws     every chunk of 1024 output slots: tile table, Philox, target, tile, guide lookup (the 2 MB
-//                       guide is L2-resident everywhere), stable split of the chunk's draws into the 8 bins:
-//                       segment [bin][chunk][<=1024] of (tile-local target, start row) and perm[slot] = (bin << 10 | pos).
-//   K3b k_resolve_bins  workgroup (group of 8 chunks, bin b) with blockIdx % 8 == b — workgroups are dealt
+//   K3a k_bin_draws     every chunk of 1024 output slots: tile table, Philox (one block per two adjacent slots), target,
+//                       tile + guide lookup (the 2 MB guide is L2-resident everywhere), split of the chunk's draws into
+//                       the 8 bins: segment [bin][chunk][<=1024] of (tile-local target, start row), perm[slot] = (bin << 10 | pos).
+//                       A draw's place in its segment is handed out by an LDS counter (arrival order: nothing but perm[] reads
+//                       the places, so results do not depend on it).
+//   K3b k_resolve_bins  workgroup (group of chunks, bin b) with blockIdx % 8 == b — workgroups are dealt
 //                       round-robin over the 8 XCDs, so the row lookups of bin b run on one XCD whose L2 then holds
 //                       that eighth of the table (speed only: any placement gives the same result).
 // Measured (profiles/r01): L2 hit rate 0.58 -> 0.86, fabric traffic 107 -> 52 MB per resample of 2^20, 46 -> 30 us.
-// PREBUILT: the tile table (inclusive prefix of T_b) was built once by k_shard_table and is probed in L2 (`incl_pre`); the
-// scalars are already folded.  Used from 1024 tiles up, where rebuilding the table in every workgroup costs as much
-// as the draws.
-template <bool PREBUILT>
+// Tile table (TABMODE): 0 = every workgroup builds it in LDS from the tile scalars (handles without a k_propagate-built
+// table); 1 = built once by the last workgroup of the level-0 launch (build_tile_table_global) and copied to LDS here;
+// 2 = the same, probed where it lies in L2 (more tiles than fit LDS).
+template <int TABMODE>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S, int nchunks,
                                                            const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
                                                            const u64* __restrict__ tile_W2, int nt,
@@ -662,108 +991,109 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_draws(u64 n, u64 n_global, 
                                                            u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row,
                                                            unsigned short* __restrict__ perm, unsigned short* __restrict__ seg_cnt,
                                                            mp_dev_scalars* scal, const u64* __restrict__ incl_pre,
-                                                           const double* __restrict__ ratio_pre) {
+                                                           const double* __restrict__ ratio_pre, const mp_tab_head* __restrict__ head) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = BIN_THREADS / 64;
-    const int nt_lds = PREBUILT ? 0 : nt;
+    const int nt_lds = TABMODE == 2 ? 0 : nt;
     u64* s_incl_lds = reinterpret_cast<u64*>(smem);                    // [nt]
     u64* s_W_lds = s_incl_lds + nt_lds;                                // [nt]
-    double* s_red = reinterpret_cast<double*>(s_W_lds + nt_lds);       // [NW]
+    double* s_ratio_lds = reinterpret_cast<double*>(s_W_lds + nt_lds); // [nt] (TABMODE 1)
+    double* s_red = s_ratio_lds + (TABMODE == 1 ? nt_lds : 0);         // [NW]
     u64* s_wtot = reinterpret_cast<u64*>(s_red + NW);                  // [NW]
-    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + NW);       // [BIN_ITEMS][NW][8] counts
-    uint32_t* s_woff = s_wcnt + BIN_ITEMS * NW * 8;                    // same shape: exclusive offsets
-    const u64* s_incl = PREBUILT ? incl_pre : s_incl_lds;
-    const u64* s_W = PREBUILT ? tile_W : s_W_lds;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_wtot + NW);        // [8] draws of this chunk per bin
+    const u64* s_incl = TABMODE == 2 ? incl_pre : s_incl_lds;
+    const u64* s_W = TABMODE == 2 ? tile_W : s_W_lds;
+    const double* s_ratio = TABMODE == 2 ? ratio_pre : s_ratio_lds;
     const int c = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if constexpr (!PREBUILT) {
+    const int tid = threadIdx.x;
+    MP_STAMP(1, 0, 0); MP_STAMP(1, 1, 1); MP_STAMP(1, 6, 2);
+    if (tid < 8) s_cnt[tid] = 0u;
+    if constexpr (TABMODE == 0) {
         const double m = block_tile_table<BIN_THREADS>(tile_m, tile_W, nt, S, s_incl_lds, s_W_lds, s_red, s_wtot);
         if (blockIdx.x == 0) {  // fold this normalisation into the filter scalars
             const u64 Q2 = block_sum_T2<BIN_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
             if (threadIdx.x == 0) fold_scalars(scal, s_incl_lds[nt - 1], Q2, S, m, n_global, 0);
         }
+    } else {
+        if constexpr (TABMODE == 1) {
+            for (int b = tid; b < nt; b += BIN_THREADS) {
+                s_incl_lds[b] = incl_pre[b];
+                s_W_lds[b] = tile_W[b];
+                s_ratio_lds[b] = ratio_pre[b];
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) fold_scalars(scal, head->Q, head->Q2, S, head->m, n_global, 0);
+        __syncthreads();
     }
     const u64 Q = s_incl[nt - 1];
+    MP_STAMP(1, 2, 0);
 
-    u64 lt[BIN_ITEMS];
-    uint32_t gslot[BIN_ITEMS], tile_of[BIN_ITEMS];
-    int bin[BIN_ITEMS];
-    uint32_t rank_in_wave[BIN_ITEMS];
+    // this thread's two adjacent output slots share one Philox block
+    const u64 i0 = (u64)c * BIN_CHUNK + 2u * (u64)tid;
+    const mp_u64x2 blk = mp_resample_block((slot_offset + i0) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
     const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
+    u64 lt[2];
+    uint32_t gslot[2], tile_of[2], bin[2], pos[2], j0[2];
+    bool live[2];
 #pragma unroll
-    for (int q = 0; q < BIN_ITEMS; ++q) {
-        const u64 i = (u64)c * BIN_CHUNK + (u64)q * BIN_THREADS + threadIdx.x;
-        const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
-        const u64 k52 = mp_u52(r.a);
-        if constexpr (PREBUILT) mp_locate_r(s_incl, s_W, ratio_pre, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
-        else mp_locate(s_incl, s_W, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
-        bin[q] = (i < n) ? (int)(k52 >> 49) : -1;
-        rank_in_wave[q] = 0;
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            const u64 bal = __ballot(bin[q] == bb);
-            // lanes of this bin below me: v_mbcnt on the (scalar) ballot
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (bin[q] == bb) rank_in_wave[q] = below;
-            if (lane == 0) s_wcnt[(q * NW + wave) * 8 + bb] = (uint32_t)__popcll(bal);
-        }
+    for (int q = 0; q < 2; ++q) {
+        const u64 k52 = mp_u52(q ? blk.b : blk.a);
+        if constexpr (TABMODE == 0) mp_locate(s_incl, s_W, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
+        else mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
+        bin[q] = (uint32_t)(k52 >> 49);
+        live[q] = i0 + q < n;
     }
-    // the guide lookups go out now (the guide is L2-resident on every XCD) and land while the offsets are built
-    uint32_t j0[BIN_ITEMS];
+    // the guide lookups go out now (the guide is L2-resident on every XCD) and land while the places are handed out
 #pragma unroll
-    for (int q = 0; q < BIN_ITEMS; ++q) j0[q] = guide[gslot[q]];
-    __syncthreads();
-    // exclusive offsets in the stable order: item q-major (slots q*256 .. q*256+255), then wave, then lane == increasing slot
-    if (threadIdx.x < 8) {
-        uint32_t run = 0;
-        for (int q = 0; q < BIN_ITEMS; ++q)
-            for (int w = 0; w < NW; ++w) {
-                s_woff[(q * NW + w) * 8 + threadIdx.x] = run;
-                run += s_wcnt[(q * NW + w) * 8 + threadIdx.x];
-            }
-        seg_cnt[(u64)threadIdx.x * nchunks + c] = (unsigned short)run;
-    }
-    __syncthreads();
+    for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];
 #pragma unroll
-    for (int q = 0; q < BIN_ITEMS; ++q) {
-        if (bin[q] >= 0) {
-            const uint32_t pos = s_woff[(q * NW + wave) * 8 + bin[q]] + rank_in_wave[q];
-            const u64 sp = MP_SEG_POS(bin[q], c, pos, nchunks);
+    for (int q = 0; q < 2; ++q) pos[q] = live[q] ? atomicAdd(&s_cnt[bin[q]], 1u) : 0u;
+    MP_STAMP(1, 3, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (live[q]) {
+            const u64 sp = MP_SEG_POS(bin[q], c, pos[q], nchunks);
             const u64 tbase = (u64)tile_of[q] * TILE;
             const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
             const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
             seg_lt[sp] = lt[q];
             seg_row[sp] = (uint32_t)tbase + jj;   // row where the forward scan starts
-            perm[(u64)c * BIN_CHUNK + q * BIN_THREADS + threadIdx.x] = (unsigned short)((bin[q] << 10) | pos);
         }
     }
+    const uint32_t pw0 = (bin[0] << 10) | pos[0], pw1 = (bin[1] << 10) | pos[1];
+    if (live[1]) reinterpret_cast<uint32_t*>(perm)[i0 >> 1] = pw0 | (pw1 << 16);   // i0 is even: one aligned 4-byte store
+    else if (live[0]) perm[i0] = (unsigned short)pw0;
+    __syncthreads();
+    if (tid < 8) seg_cnt[(u64)tid * nchunks + c] = (unsigned short)s_cnt[tid];
+    MP_STAMP(1, 4, 0); MP_STAMP(1, 5, 1);
 }
 
 // K3b: pure lookup, two dependent hops (segment entry -> table rows), all inside the bin's eighth of the table.
-// Thread (quad, e) = (tid >> 7, tid & 127) owns entry e of the 4 segments of chunks group*8 + quad*4 + {0..3}; a
-// segment holds 128 +- 11 entries, so nearly every lane is live and each has 4 independent chains in flight.
-// Results stay in SEGMENT order (res_x[d][bin][chunk][pos], res_parent likewise: coalesced stores); the next
-// k_propagate reads its inputs through perm[], k_unpermute materialises slot order when the host asks.
-__global__ __launch_bounds__(K3B_THREADS) void k_resolve_bins(u64 n, int nchunks, const u64* __restrict__ seg_lt,
+// Thread (quad, e) = (tid >> 7, tid & 127) owns entry e of the segment of chunk group*2 + quad; a segment holds
+// 128 +- 11 entries, so nearly every lane is live.  Results stay in SEGMENT order (res_x[bin][chunk][pos], res_parent
+// likewise: coalesced stores); the next k_propagate reads its inputs through perm[], k_unpermute materialises slot
+// order when the host asks.
+// PREDRAW: while its lookups are in flight (this kernel is bound by their latency and leaves the vector ALUs idle) the
+// workgroup also draws the standard deviates that the NEXT time step's k_propagate will need for a block of slots —
+// zpre[slot][site], mp_coop_std_normals: they depend on nothing but (slot, t_next, site) — which takes the rejection
+// loops and their log / divide / sqrt out of the kernel that is bound by vector issue.
+template <class Model, bool PREDRAW>
+__global__ __launch_bounds__(K3B_THREADS) void k_resolve_bins(Model model, u64 n, int nchunks, const u64* __restrict__ seg_lt,
                                                              const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_cnt,
                                                              const mp_cx* __restrict__ cx, double* __restrict__ res_x,
-                                                             uint32_t* __restrict__ res_parent) {
+                                                             uint32_t* __restrict__ res_parent, long long t_next, u64 slot_offset,
+                                                             uint32_t k0, uint32_t k1, double* __restrict__ zpre, u64 pre_per) {
     const int bin = blockIdx.x & 7;
     const int group = blockIdx.x >> 3;
     const int e0 = threadIdx.x & 127, quad = threadIdx.x >> 7;
-    int cnt[K3B_ITEMS], chunk_of[K3B_ITEMS];
-    u64 lt[K3B_ITEMS], spos[K3B_ITEMS];
-    uint32_t row0[K3B_ITEMS];
-#pragma unroll
-    for (int k = 0; k < K3B_ITEMS; ++k) {
-        const int c = group * BIN_GROUP + quad * K3B_ITEMS + k;
-        const bool ok = c < nchunks;
-        chunk_of[k] = ok ? c : 0;
-        cnt[k] = ok ? (int)seg_cnt[(u64)bin * nchunks + c] : 0;
-        spos[k] = MP_SEG_POS(bin, chunk_of[k], e0, nchunks);
-        lt[k] = seg_lt[spos[k]];        // in bounds for every thread; masked by cnt below
-        row0[k] = seg_row[spos[k]];
-    }
+    MP_STAMP(2, 0, 0); MP_STAMP(2, 1, 1); MP_STAMP(2, 6, 2);
+    const int cq = group * BIN_GROUP + quad;
+    const bool okc = cq < nchunks;
+    const int chunk = okc ? cq : 0;
+    const int cnt = okc ? (int)seg_cnt[(u64)bin * nchunks + chunk] : 0;
+    const u64 spos = MP_SEG_POS(bin, chunk, e0, nchunks);
+    const u64 lt = seg_lt[spos];        // in bounds for every thread; masked by cnt below
+    const uint32_t row0 = seg_row[spos];
     // first row >= lt, walking forward from `row` inside its tile; r0/r1 = that row and the next one, already loaded
     auto finish = [&](u64 ltx, uint32_t row, u64 sp, mp_cx r0, mp_cx r1) {
         const u64 tend = (((u64)row / TILE) + 1) * TILE;
@@ -782,36 +1112,55 @@ __global__ __launch_bounds__(K3B_THREADS) void k_resolve_bins(u64 n, int nchunks
         res_x[sp] = cur.x0;
         // D > 1: the rest of the state is gathered by the next k_propagate (or k_unpermute) from res_parent
     };
-    bool live[K3B_ITEMS];
-    mp_cx r0[K3B_ITEMS], r1[K3B_ITEMS];
+    const bool live = e0 < cnt;
+    mp_cx r0, r1;
+    if (live) {
+        const u64 tend = (((u64)row0 / TILE) + 1) * TILE;
+        const u64 last = (tend < n ? tend : n) - 1;
+        r0 = cx[row0];
+        r1 = cx[(u64)row0 + ((u64)row0 < last ? 1 : 0)];
+    } else {
+        r0.cum = ~0ull; r0.x0 = 0.; r1 = r0;
+    }
+    if constexpr (PREDRAW) {
+        constexpr int NS = Model::MAX_NORMALS;
+        const int ns = model.n_normals(t_next);   // workgroup-uniform
+        const u64 lo = (u64)blockIdx.x * pre_per;
+        const u64 hi = (lo + pre_per < n) ? lo + pre_per : n;
+        if (ns > 0) {
+            for (u64 s0 = lo; s0 < hi; s0 += K3B_THREADS) {   // workgroup-uniform trip count (barriers inside)
+                double z[NS];
+                const uint32_t n_live = (uint32_t)((hi - s0) < (u64)K3B_THREADS ? (hi - s0) : (u64)K3B_THREADS);
+                mp_coop_std_normals<Model, K3B_THREADS, 1>(model, ns, t_next, slot_offset + s0, n_live, k0, k1, z);
+                if (threadIdx.x < n_live) {
 #pragma unroll
-    for (int k = 0; k < K3B_ITEMS; ++k) {
-        live[k] = e0 < cnt[k];
-        if (live[k]) {
-            const u64 tend = (((u64)row0[k] / TILE) + 1) * TILE;
-            const u64 last = (tend < n ? tend : n) - 1;
-            r0[k] = cx[row0[k]];
-            r1[k] = cx[(u64)row0[k] + ((u64)row0[k] < last ? 1 : 0)];
-        } else {
-            r0[k].cum = ~0ull; r0[k].x0 = 0.; r1[k] = r0[k];
+                    for (int s = 0; s < NS; ++s)
+                        if (s < ns) zpre[(s0 + threadIdx.x) * (u64)ns + s] = z[s];
+                }
+            }
         }
     }
-#pragma unroll
-    for (int k = 0; k < K3B_ITEMS; ++k)
-        if (live[k]) finish(lt[k], row0[k], spos[k], r0[k], r1[k]);
+    if (live) finish(lt, row0, spos, r0, r1);
     // entries 128.. of a segment (about 5 % of the entries: the upper tail of Binomial(1024, 1/8))
-#pragma unroll
-    for (int k = 0; k < K3B_ITEMS; ++k) {
-        for (int e = 128 + e0; e < cnt[k]; e += 128) {
-            const u64 sp = MP_SEG_POS(bin, chunk_of[k], e, nchunks);
-            const uint32_t row = seg_row[sp];
-            const u64 tend = (((u64)row / TILE) + 1) * TILE;
-            const u64 last = (tend < n ? tend : n) - 1;
-            const mp_cx a = cx[row];
-            const mp_cx bq = cx[(u64)row + ((u64)row < last ? 1 : 0)];
-            finish(seg_lt[sp], row, sp, a, bq);
-        }
+    for (int e = 128 + e0; e < cnt; e += 128) {
+        const u64 sp = MP_SEG_POS(bin, chunk, e, nchunks);
+        const uint32_t row = seg_row[sp];
+        const u64 tend = (((u64)row / TILE) + 1) * TILE;
+        const u64 last = (tend < n ? tend : n) - 1;
+        const mp_cx a = cx[row];
+        const mp_cx bq = cx[(u64)row + ((u64)row < last ? 1 : 0)];
+        finish(seg_lt[sp], row, sp, a, bq);
     }
+    MP_STAMP(2, 4, 0); MP_STAMP(2, 5, 1);
+}
+
+// parents in slot order from the segment-ordered results of the last binned resample (the states may have moved on)
+__global__ void k_parents_from_segments(u64 n, int nchunks, const unsigned short* __restrict__ perm, const uint32_t* __restrict__ res_parent,
+                                        uint32_t* __restrict__ parent) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pr = perm[i];
+    parent[i] = res_parent[MP_SEG_POS(pr >> 10, i >> 10, pr & 1023u, nchunks)];
 }
 
 // slot order from segment order: traces[i] = traces[parents[i]].clone(); log_weights.fill(0.) (particle_filter.rs:109-114)

@@ -31,8 +31,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_globa
         if (systematic) {   // 1 systematic, 2 stratified
             target = mp_target_lattice(systematic, slot_offset + i, systematic == 1 ? mp_systematic_k32(rc, k0, k1) : 0u, rc, k0, k1, Q, n_global);
         } else {
-            const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
-            target = mp_target(mp_u52(r.a), Q);
+            target = mp_target(mp_resample_k52(slot_offset + i, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1), Q);
         }
         uint32_t b, gs;
         u64 lt;
@@ -210,8 +209,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
             if (systematic) {   // 1 systematic, 2 stratified
                 target = mp_target_lattice(systematic, slot_offset + i, k32, rc, k0, k1, Q, n_global);
             } else {
-                const mp_u64x2 r = mp_philox4x32_10((uint32_t)(slot_offset + i), rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
-                target = mp_target(mp_u52(r.a), Q);
+                target = mp_target(mp_resample_k52(slot_offset + i, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1), Q);
             }
             uint32_t b, gs;
             mp_locate_r(s_incl, s_W, ratio_all, (uint32_t)nt_all, target, nt_over_Q, &b, &lt[k], &gs);
@@ -476,8 +474,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_own_draws(u64 n_global, ui
             if (scheme) {
                 target[k] = mp_target_lattice(scheme, g, k32, rc, k0, k1, Q, n_global);
             } else {
-                const mp_u64x2 r = mp_philox4x32_10((uint32_t)g, rc, ((uint32_t)MP_DOM_RESAMPLE << 16), 0u, k0, k1);
-                target[k] = mp_target(mp_u52(r.a), Q);
+                target[k] = mp_target(mp_resample_k52(g, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1), Q);
             }
             ++nlive;
         }
@@ -695,6 +692,14 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_adopt_rows(u64 n, int D, c
     const double* in = rows + (u64)inv[i] * (u64)(D + 1);
     for (int d = 0; d < D; ++d) x_new[i * D + d] = in[d];
     parent[i] = (uint32_t)in[D];
+}
+
+// parents alone (a step has already consumed the states of those rows)
+__global__ __launch_bounds__(SH_THREADS) void k_shard_adopt_parents(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ inv,
+                                                                    uint32_t* __restrict__ parent) {
+    const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    parent[i] = (uint32_t)rows[(u64)inv[i] * (u64)(D + 1) + D];
 }
 
 // out[i] = a[i] - *b  (log_normalized_weights = w_i - log_total_weight, importance.rs:23-25)

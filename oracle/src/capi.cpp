@@ -370,7 +370,7 @@ int32_t oracle_importance_resampling(const mp_model_desc* m, const double* args0
                 std::vector<double> cdf;
                 if (!canon) { Categorical::check_sum(probs); double t = 0.; for (double p : probs) { t += p; cdf.push_back(t); } }
                 for (uint64_t j = 0; j < num_ret_samples; ++j) {
-                    Rng r; r.seed = seed; r.slot = (uint32_t)j; r.step = 0; r.at(DOM_IS, 0);
+                    Rng r = resample_rng(seed, DOM_IS, 0, j);
                     if (canon) resampled_indices[j] = canonical_parent(c, canonical_target(r.u52(), c.c.Q));
                     else {
                         const double u = r.u01();

@@ -8,7 +8,8 @@
 //
 // Seeded-stream convention (the reference has none; mp_philox.h defines it):
 //   * particle i / chain i owns Philox slot i; an Unfold kernel call at time t uses step t;
-//   * the i-th categorical draw of a resample uses (slot i, step = resample count, DOM_RESAMPLE);
+//   * the i-th categorical draw of a resample is uniform number i of the resample's stream (rng.hpp resample_rng:
+//     Philox block i >> 1 of (step = resample count, DOM_RESAMPLE), half i & 1);
 //   * MH iteration `it` (1-based; step 0 is the initial generate) uses step `it`; the accept
 //     uniform is (DOM_ACCEPT, site 0).
 //
@@ -231,8 +232,7 @@ inline uint32_t canonical_systematic_k32(uint64_t seed, uint32_t rc) {
 }
 // stratified (extension): one k32 per global output slot g (site 2)
 inline uint32_t canonical_stratified_k32(uint64_t seed, uint32_t rc, uint64_t g) {
-    Rng r; r.seed = seed; r.slot = (uint32_t)g; r.step = rc; r.at(DOM_RESAMPLE, 2);
-    return (uint32_t)(r.bits64() >> 32);
+    return resample_k32(seed, DOM_RESAMPLE, 2, rc, g);
 }
 // scheme 1 (systematic) or 2 (stratified)
 inline uint64_t canonical_target_lattice(int scheme, uint64_t seed, uint32_t rc, uint64_t g, uint64_t Q, uint64_t n_global) {
@@ -281,7 +281,7 @@ struct ParticleSystem {
             for (size_t i = 0; i < num_particles; ++i) { t += normalized_weights[i]; cdf[i] = t; }
         }
         for (size_t i = 0; i < num_particles; ++i) {
-            Rng r = rng_for(i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+            Rng r = resample_rng(seed, DOM_RESAMPLE, resample_count, i);
             int64_t p;
             if (!fast_search) {
                 p = categorical.random(r, normalized_weights);  // clones + re-sums per draw in the reference
@@ -342,7 +342,7 @@ struct ParticleSystem {
             canon_ess_stale = c.c.ess;
             log_ml_estimate += log_total_weight - o_ln((double)num_particles);
             for (size_t i = 0; i < num_particles; ++i) {
-                Rng r = rng_for(i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+                Rng r = resample_rng(seed, DOM_RESAMPLE, resample_count, i);
                 parents[i] = canonical_parent(c, canonical_target(r.u52(), c.c.Q));
             }
         }
@@ -406,14 +406,14 @@ ImportanceResult<Args, Data, Ret> importance_resampling(uint64_t seed, const Gen
         std::vector<double> probs;  // :44
         for (double w : out.log_normalized_weights) probs.push_back(o_exp(w));
         for (uint32_t j = 0; j < num_ret_samples; ++j) {  // :45-47
-            Rng r; r.seed = seed; r.slot = j; r.step = 0; r.at(DOM_IS, 0);
+            Rng r = resample_rng(seed, DOM_IS, 0, j);
             const int64_t p = categorical.random(r, probs);
             if (p < 0) throw Panic("categorical returned -1");
             out.resampled_indices.push_back((size_t)p);
         }
     } else {
         for (uint32_t j = 0; j < num_ret_samples; ++j) {
-            Rng r; r.seed = seed; r.slot = j; r.step = 0; r.at(DOM_IS, 0);
+            Rng r = resample_rng(seed, DOM_IS, 0, j);
             out.resampled_indices.push_back(canonical_parent(c, canonical_target(r.u52(), c.c.Q)));
         }
     }

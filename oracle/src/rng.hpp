@@ -59,4 +59,26 @@ struct Rng {
     double u01() { return (double)u52() * 0x1p-52; }
 };
 
+// The categorical draws of ONE resample (or of importance_resampling's M draws) are one sequential uniform stream, as in the
+// reference, whose `for i in 0..N { categorical.random(&mut rng, ..) }` consumes one rng (particle_filter.rs:38-40,
+// importance.rs:45-47): draw g is uniform number g of that stream = half (g & 1) of Philox block g >> 1, the block index
+// carried in the counter's slot field (site 0 of `domain`).
+inline Rng resample_rng(uint64_t seed, uint32_t domain, uint32_t step, uint64_t g) {
+    Rng r; r.seed = seed; r.slot = (uint32_t)(g >> 1); r.step = step; r.at(domain, 0);
+    r.n = (uint32_t)(g & 1);
+    return r;
+}
+inline uint64_t resample_u52(uint64_t seed, uint32_t domain, uint32_t step, uint64_t g) { return resample_rng(seed, domain, step, g).u52(); }
+inline double resample_u01(uint64_t seed, uint32_t domain, uint32_t step, uint64_t g) {
+    return (double)resample_u52(seed, domain, step, g) * 0x1p-52;
+}
+// 32-bit uniforms of a lattice scheme, one per output slot (stratified): word (g & 3) of Philox block g >> 2 at `site`
+inline uint32_t resample_k32(uint64_t seed, uint32_t domain, uint32_t site, uint32_t step, uint64_t g) {
+    const uint32_t ctr[4] = {(uint32_t)(g >> 2), step, (domain << 16) | site, 0u};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    philox4x32_10(ctr, key, o);
+    return o[g & 3];
+}
+
 }  // namespace oracle

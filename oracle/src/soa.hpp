@@ -244,7 +244,7 @@ struct SoaPf {
             log_ml += L - o_ln((double)n);
             parallel_for([&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) {
-                    Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+                    Rng r = resample_rng(seed, DOM_RESAMPLE, resample_count, slot_offset + i);
                     const double u = r.u01();
                     if (!(0. < u)) throw Panic("categorical returned -1 (u == 0)");
                     const size_t p = (size_t)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
@@ -260,7 +260,7 @@ struct SoaPf {
             log_ml += L - o_ln((double)n_global);
             parallel_for([&](size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) {
-                    Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+                    Rng r = resample_rng(seed, DOM_RESAMPLE, resample_count, slot_offset + i);
                     if (scheme != 0) parents[i] = (uint32_t)canonical_parent(c, canonical_target_lattice(scheme, seed, resample_count, slot_offset + i, c.c.Q, n_global));
                     else parents[i] = (uint32_t)canonical_parent(c, canonical_target(r.u52(), c.c.Q));
                 }
@@ -302,7 +302,7 @@ struct SoaPf {
         std::vector<uint64_t> rt(n), rl(n);
         for (int r = 0; r < world; ++r) send_counts[r] = 0;
         for (size_t i = 0; i < n; ++i) {
-            Rng r; r.seed = seed; r.slot = (uint32_t)(slot_offset + i); r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+            Rng r = resample_rng(seed, DOM_RESAMPLE, resample_count, slot_offset + i);
             const uint64_t target = scheme != 0 ? canonical_target_lattice(scheme, seed, resample_count, slot_offset + i, sh_c.Q, n_global)
                                                 : canonical_target(r.u52(), sh_c.Q);
             size_t tile; uint64_t lt;
@@ -366,7 +366,7 @@ struct SoaPf {
         sh_own.clear();
         sh_call.assign((size_t)world, 0);
         for (uint64_t g = 0; g < n_global; ++g) {
-            Rng r; r.seed = seed; r.slot = (uint32_t)g; r.step = resample_count; r.at(DOM_RESAMPLE, 0);
+            Rng r = resample_rng(seed, DOM_RESAMPLE, resample_count, g);
             const uint64_t target = scheme != 0 ? canonical_target_lattice(scheme, seed, resample_count, g, sh_c.Q, n_global)
                                                 : canonical_target(r.u52(), sh_c.Q);
             size_t tile; uint64_t lt;

@@ -26,12 +26,31 @@ class Shard(C.Structure):
     _fields_ = [("n_global", C.c_uint64), ("slot_offset", C.c_uint64)]
 
 
+def _source_hash():
+    import hashlib
+
+    srcs = sorted(os.path.join(ORACLE_DIR, "src", f) for f in os.listdir(os.path.join(ORACLE_DIR, "src")))
+    srcs += [os.path.join(ORACLE_DIR, "Makefile")]
+    csrc = os.path.join(ROOT, "modppl_amd", "csrc")
+    srcs += sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h"))   # the oracle includes mp_math.h & co
+    srcs += [os.path.join(ROOT, "include", "modppl_hip.h")]
+    h = hashlib.sha256()
+    for s in srcs:
+        h.update(os.path.basename(s).encode())
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    srcs = [os.path.join(ORACLE_DIR, "src", f) for f in os.listdir(os.path.join(ORACLE_DIR, "src"))]
-    srcs += [os.path.join(ROOT, "modppl_amd", "csrc", "mp_math.h"), os.path.join(ROOT, "include", "modppl_hip.h")]
-    stale = (not os.path.exists(SO)) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
-    if force or stale:
-        subprocess.run(["make", "-C", ORACLE_DIR, "liboracle.so"], check=True, capture_output=True)
+    """content-hash staleness (a checkout can give edited files older mtimes): the hash of every source is kept next to the .so"""
+    stamp = SO + ".srchash"
+    want = _source_hash()
+    have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(SO) else None
+    if force or have != want:
+        subprocess.run(["make", "-B", "-C", ORACLE_DIR, "liboracle.so"], check=True, capture_output=True)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     return SO
 
 
@@ -42,12 +61,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    # On the GPU box the prebuilt .so travels with the snapshot; rebuild only if sources are newer.
-    try:
-        build()
-    except Exception:
-        if not os.path.exists(SO):
-            raise
+    # On the GPU box the prebuilt .so travels with the snapshot (with its source hash); a mismatch rebuilds it (g++ is there).
+    build()
     L = C.CDLL(SO)
     d, i32, u32, i64, u64, p = C.c_double, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_void_p
     dp = C.POINTER(C.c_double)
