@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/modppl_hip.h"
@@ -66,7 +67,6 @@ static int ceil_log2_u64(u64 n) {
     while ((1ull << b) < n) ++b;
     return b;
 }
-constexpr int K1_TABLE_LDS_MAX_TILES = 1024;   // k_bin_draws copies the prebuilt tile table (24 B per tile) into LDS up to here, probes it in L2 beyond
 static size_t table_lds(int nt, int threads) {  // s_incl[nt] + s_W[nt] + s_red + s_wtot
     return sizeof(u64) * 2 * (size_t)nt + (sizeof(double) + sizeof(u64)) * (size_t)(threads / 64);
 }
@@ -109,6 +109,7 @@ struct ResolveArgs {   // k_resolve_bins (+ the next step's deviates when zpre !
     uint32_t k0, k1;
     double* zpre;
     u64 pre_per;
+    int items;
     hipStream_t stream;
 };
 struct ModelOps {
@@ -138,6 +139,21 @@ struct ModelOpsT : ModelOps {
     void propagate(const PropagateArgs& a) const override {
         // light kernels (few registers) run 1024 threads x 2 particles per tile: twice the waves in flight for the same 2048-slot tile
         constexpr int THREADS = (Model::MAX_NORMALS <= 4 && Model::DIM_STATE <= 4) ? 1024 : TILE_THREADS;
+        static const int k1t = [] { const char* e = getenv("MP_K1_THREADS"); return e ? atoi(e) : 0; }();   // A/B measurements
+        if constexpr (std::is_same<Model, mp_lgssm1>::value) {
+            if (k1t == 256) {
+                hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
+                                   a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent, a.aux);
+                return;
+            }
+            if (k1t == 512) {
+                hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
+                                   a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent, a.aux);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
                            a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent, a.aux);
@@ -146,13 +162,21 @@ struct ModelOpsT : ModelOps {
     void resolve(const ResolveArgs& a) const override {
         if constexpr (mp_coop_model<Model>()) {
             if (a.zpre) {
-                hipLaunchKernelGGL((k_resolve_bins<Model, true>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
+                hipLaunchKernelGGL((k_resolve_bins<Model, true, 1>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
                                    a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, a.zpre, a.pre_per);
                 return;
             }
         }
-        hipLaunchKernelGGL((k_resolve_bins<Model, false>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
-                           a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, (double*)nullptr, (u64)0);
+        // ITEMS segments per thread (a.items; the grid shrinks accordingly)
+        if (a.items == 4)
+            hipLaunchKernelGGL((k_resolve_bins<Model, false, 4>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
+                               a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, (double*)nullptr, (u64)0);
+        else if (a.items == 2)
+            hipLaunchKernelGGL((k_resolve_bins<Model, false, 2>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
+                               a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, (double*)nullptr, (u64)0);
+        else
+            hipLaunchKernelGGL((k_resolve_bins<Model, false, 1>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
+                               a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, (double*)nullptr, (u64)0);
     }
 };
 
@@ -312,7 +336,7 @@ struct mp_pf {
     int use_k1_table = 1;               // MP_K1_TABLE=0: every k_bin_draws workgroup builds the table itself (A/B measurements)
     double* zpre = nullptr;             // [n][ns] standard deviates of time step zpre_t, drawn by k_resolve_bins
     long long zpre_t = -1;
-    int use_predraw = 1;                // MP_PREDRAW=0: k_propagate draws its own deviates
+    int use_predraw = 0;                // MP_PREDRAW=1: the resample's lookup launch also draws the next step's deviates (measured: a loss at 2^20 x d = 1)
     bool rows_fresh = false;            // cx / guide / tile_* describe the current log-weights
     // sharded-resample scratch (allocated on first use)
     unsigned char* sh_dest = nullptr;
@@ -582,7 +606,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         env = getenv("MP_K1_TABLE");
         if (env && env[0] == '0') h->use_k1_table = 0;
         env = getenv("MP_PREDRAW");
-        if (env && env[0] == '0') h->use_predraw = 0;
+        if (env) h->use_predraw = env[0] == '1' ? 1 : 0;
     }
     HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
     HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
@@ -680,7 +704,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     bool binned = false;
     if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (BIN_THREADS / 64) + sizeof(uint32_t) * 8;
+        const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (BIN_THREADS / 64) + sizeof(uint32_t) * 8 * (BIN_THREADS / 64);
         const mp_tab tab = tab_of(h);
         if (tab.ticket && h->nt <= K1_TABLE_LDS_MAX_TILES) {
             // the table was built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles): copy to LDS
@@ -703,15 +727,21 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
-            const int ngroups = (h->nchunks + BIN_GROUP - 1) / BIN_GROUP;
+            static const int k3b_items = [] { const char* e = getenv("MP_K3B_ITEMS"); const int v = e ? atoi(e) : 1; return (v == 2 || v == 4) ? v : 1; }();
+            // the deviates of the NEXT time step (kernel time index h->t) are drawn by extra workgroups of the same launch
+            const bool pre = h->zpre && h->ops->n_normals(h->t) > 0;
             ResolveArgs r;
+            r.items = pre ? 1 : k3b_items;
+            const int per_wg = BIN_GROUP * r.items;
+            const int ngroups = (h->nchunks + per_wg - 1) / per_wg;
             r.n = h->n; r.nchunks = h->nchunks; r.grid = ngroups * 8;
             r.seg_lt = h->seg_lt; r.seg_row = h->seg_row; r.seg_cnt = h->seg_cnt; r.cx = h->cx; r.res_x = h->res_x; r.res_parent = h->res_parent;
             r.t_next = h->t; r.slot_offset = h->slot_offset; r.k0 = (uint32_t)h->seed; r.k1 = (uint32_t)(h->seed >> 32);
-            // the deviates of the NEXT time step (kernel time index h->t) are drawn while the lookups are in flight
-            const bool pre = h->zpre && h->ops->n_normals(h->t) > 0;
             r.zpre = pre ? h->zpre : nullptr;
-            r.pre_per = (u64)K3B_THREADS * ((h->n + (u64)K3B_THREADS * (u64)r.grid - 1) / ((u64)K3B_THREADS * (u64)r.grid));
+            // with deviates: of every 16 workgroups 8 look up and 8 draw (k_resolve_bins); each drawing workgroup takes pre_per slots
+            const u64 unit = (u64)K3B_THREADS * PRE_ITEMS;
+            r.pre_per = unit * ((h->n + unit * (u64)r.grid - 1) / (unit * (u64)r.grid));
+            if (pre) r.grid *= 2;
             r.stream = h->stream;
             h->ops->resolve(r);
             if (pre) h->zpre_t = h->t;

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Phase breakdown of k_propagate from a raw stamp dump (tools/stamp_probe.py --raw): mean shader cycles of wave 0 between stamps."""
+import sys
+
+import numpy as np
+
+b = np.load(sys.argv[1])
+x = b[0]
+x = x[x[:, 1] != 0].astype(np.int64)
+names = [(0, 2, "deviates (load / draw)"), (2, 3, "state fetch + model"), (3, 8, "wave max"), (8, 9, "barrier 1"), (9, 10, "exp + quantise"),
+         (10, 11, "wave scan"), (11, 12, "LDS atomic + barrier 2"), (12, 7, "cross-wave offsets"), (7, 13, "scalars/ticket + row stores"),
+         (13, 14, "guide build"), (14, 15, "barrier 3"), (15, 4, "guide store (+ table)")]
+tot = (x[:, 4] - x[:, 0]).mean()
+print("k_propagate: %d workgroups, wave 0 lifetime %.0f cycles = %.2f us real time" % (len(x), tot, ((x[:, 5] - x[:, 1]).mean()) / 100.0))
+for a, c, nm in names:
+    d = (x[:, c] - x[:, a])
+    print("  %-32s %8.0f cycles  %5.1f %%   (p10 %.0f, p90 %.0f)" % (nm, d.mean(), 100 * d.mean() / tot, np.percentile(d, 10), np.percentile(d, 90)))
+for k, nm in ((1, "k_bin_draws"), (2, "k_resolve_bins")):
+    y = b[k]
+    y = y[y[:, 1] != 0].astype(np.int64)
+    if len(y):
+        print("%s: %d workgroups, span %.2f us, mean lifetime %.2f us, clock %.0f MHz" % (nm, len(y), (y[:, 5].max() - y[:, 1].min()) / 100.0, (y[:, 5] - y[:, 1]).mean() / 100.0,
+                                                                                      np.median((y[:, 4] - y[:, 0]) / np.maximum(y[:, 5] - y[:, 1], 1) * 100)))
