@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command;
+# it carries the content hash of the kernel sources it was measured with: a summary of another build is refused
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 N_PER_GPU = 1 << 20
 DIM = 1
@@ -32,7 +33,7 @@ DIM = 1
 #   bin_draws       = the search half of the resample (8 + 4)
 #   resample_gather = the gather half: 4 + 16d, weight reset 8
 BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "bin_draws": 8 + 4, "resample_gather": 4 + 16 * DIM + 8}
-KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_bin_draws", "resample_gather": "k_resolve_bins"}
+KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_bin_draws<1>", "resample_gather": "k_resolve_bins<mp_lgssm1, false, 1>"}
 BYTES_STEP = 32 * DIM + 64
 
 
@@ -106,6 +107,88 @@ def cpu_baseline(ys, n):
                                    "sample": f"{ss} steps at N={n_sf}, trie-addressed traces + the reference's O(N^2) multinomial, {dts:.1f} s"}}
 
 
+def cpu_baseline_parity(model_fn, seed=20241008):
+    """Part of the cpu_baseline leg (the only place bench.py touches oracle/, as the checker).
+    BASELINE.md §3: the GPU filter beside the LITERAL CPU restatement (libm, sequential fp64 sums, the reference's
+    `while t < u` scan) on the same seed and observations — (i) the C1 shape, N = 1000, T = 50, every resample compared;
+    (ii) a 3-resample slice of the bench workload at N = 2^20.  Returns the relative log-ML difference and the number
+    of resample indices that differ (the GPU evaluates the canonical fixed-point CDF)."""
+    import modppl_amd
+    from tests import oracle_lib as O
+
+    out = {}
+    worst_rel, mism, draws = 0.0, 0, 0
+    for tag, n, T in (("c1_n1000_t50", 1000, 50), ("c2_slice_n2e20_t4", 1 << 20, 4)):
+        ys = lgssm_observations(T)
+        pf = modppl_amd.ParticleSystem(model_fn(), n, seed)
+        ref = O.OraclePF(1, 1, 1, np.array(LGSSM_PARAMS), n, seed, O.VARIANT_SOA | O.VARIANT_FAST_SEARCH if n > 4096 else 0)
+        pf.init_step(None, ys[:1])
+        ref.init_step(ys[:1])
+        m = 0
+        for t in range(1, T):
+            pf.resample()
+            ref.resample()
+            m += int((pf.parents != ref.parents()).sum())
+            pf.step(ys[t:t + 1])
+            ref.step(ys[t:t + 1])
+        a, b = pf.log_marginal_likelihood_estimate(), ref.log_marginal_likelihood_estimate()
+        rel = abs(a - b) / abs(b)
+        out[tag] = {"log_ml_gpu": a, "log_ml_cpu": b, "log_ml_rel_err": rel, "index_mismatches": m, "draws": n * (T - 1)}
+        worst_rel = max(worst_rel, rel)
+        mism += m
+        draws += n * (T - 1)
+    return worst_rel, mism, draws, out
+
+
+def sub_benches(steps, warmup, which):
+    """The other BASELINE.json configurations, from the same process, as driver-run numbers (not `value`):
+    c3 bearings-only d = 4, 2^22 particles; c5_shard LGSSM d = 16, one GPU's share 2^21 of the 2^24-particle job;
+    c4 regen-MH, 2^20 chains.  One step = step + multinomial resample; bytes per particle-step B(d) = 32 d + 64."""
+    import modppl_amd
+
+    rng = np.random.default_rng(20241008)
+    T = 1 + warmup + steps
+    res = {}
+
+    def pf_case(model, n, obs, d):
+        pf = modppl_amd.ParticleSystem(model, n, 20241008)
+        pf.init_step(None, obs[:1])
+        pf.resample(sync=False)
+        for t in range(1, 1 + warmup):
+            pf.step(obs[t:t + 1])
+            pf.resample(sync=False)
+        pf.synchronize()
+        t0 = time.perf_counter()
+        for t in range(1 + warmup, T):
+            pf.step(obs[t:t + 1])
+            pf.resample(sync=False)
+        pf.synchronize()
+        dt = time.perf_counter() - t0
+        b = 32 * d + 64
+        return {"particles": n, "dim_state": d, "steps": steps, "us_per_step": dt / steps * 1e6, "particle_steps_per_s": n * steps / dt,
+                "step_bytes_per_particle": b, "step_hbm_frac": b * n * steps / dt / 1e9 / HBM_PEAK_GBPS,
+                "log_ml": pf.log_marginal_likelihood_estimate()}
+
+    if "c3" in which:
+        th = np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + rng.normal(0, 0.02, T)
+        res["c3"] = dict(pf_case(modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), 4), workload="bearings-only tracker d=4, 2^22 particles (BASELINE.json configs[2])")
+    if "c5" in which:
+        res["c5_shard"] = dict(pf_case(modppl_amd.lgssm_band_model(16), 1 << 21, rng.normal(0, 1.2, size=(T, 16)), 16),
+                               workload="LGSSM d=16, 2^21 particles = one GPU's share of configs[4] (16M over 8 GPUs), unsharded code path")
+    if "c4" in which:
+        xs = np.arange(-5, 6, dtype=np.float64)
+        ys = 0.3 + 0.4 * xs + 0.5 * xs * xs + rng.normal(0, 0.1, xs.size)
+        ch = modppl_amd.HierarchicalChains(xs, ys, 1 << 20, 20241008, constrain_is_linear=False)
+        ch.regen_mh([1, 2, 3], n_iters=3, cycle=True)
+        sweeps = max(4, steps // 5)
+        t0 = time.perf_counter()
+        ch.regen_mh([1, 2, 3], n_iters=3 * sweeps, cycle=True)
+        dt = time.perf_counter() - t0
+        res["c4"] = {"workload": "regen-MH on the hierarchical model, 2^20 chains, masks cycling a, b, c (BASELINE.json configs[3])",
+                     "chains": 1 << 20, "chain_iterations": 3 * sweeps, "chain_iterations_per_s": (1 << 20) * 3 * sweeps / dt}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +197,7 @@ def main():
     ap.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record hipEvents around each launch in the timed region")
+    ap.add_argument("--no-sub-benches", action="store_true", help="skip the c3 / c4 / c5 sub-objects")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -229,26 +313,73 @@ def main():
         torch.cuda.synchronize()
         copy_gbps = 2 * a_.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a_, b_
+    # ---- N > 1: the workload that CAN scale (BASELINE.json configs[4]): LGSSM d = 16, 2^21 particles per GPU, same K steps,
+    # through the same sharded filter (every rank runs it; rank 0 reports).  Not `value`.
+    c5 = None
+    if world > 1:
+        from modppl_amd.distributed import ShardedParticleSystem
+
+        n5 = 1 << 21
+        obs5 = np.random.default_rng(20241008).normal(0, 1.2, size=(T, 16))
+        pf5 = ShardedParticleSystem(modppl_amd.lgssm_band_model(16), n5 * world, 20241008, engine_kwargs={"device_index": local_rank})
+        pf5.init_step(None, obs5[:1])
+        pf5.resample(sync=False)
+        for t in range(1, 1 + W):
+            pf5.step(obs5[t:t + 1])
+            pf5.resample(sync=False)
+        dist.barrier(); torch.cuda.synchronize(); pf5.synchronize()
+        t0 = time.perf_counter()
+        for t in range(1 + W, T):
+            pf5.step(obs5[t:t + 1])
+            pf5.resample(sync=False)
+        dist.barrier(); torch.cuda.synchronize(); pf5.synchronize()
+        dt5 = time.perf_counter() - t0
+        tt = torch.tensor([dt5], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt5 = float(tt.item())
+        surplus = getattr(pf5, "last_exchange_rows", None)
+        c5 = {"workload": "LGSSM d=16 bootstrap SMC, 2^21 particles per GPU, one sharded filter (BASELINE.json configs[4] at 8 GPUs)",
+              "particles_per_gpu": n5, "particles_total": n5 * world, "steps": K, "ms_per_step": dt5 / K * 1e3,
+              "particle_steps_per_s": n5 * world * K / dt5, "step_bytes_per_particle": 32 * 16 + 64,
+              "step_hbm_frac_per_gpu": (32 * 16 + 64) * n5 * K / dt5 / 1e9 / HBM_PEAK_GBPS, "exchange": getattr(pf5, "exchange", None),
+              "exchange_rows_last_step": surplus, "exchange_bytes_per_row": 8 * 17, "log_ml": pf5.log_marginal_likelihood_estimate()}
+        del pf5
     if rank == 0:
         # mean duration of one launch of each kernel (single GPU: one launch of each per step)
-        avg_us = {k: (v[0] / v[1]) * 1e3 if v[1] else 0.0 for k, v in fam.items()}
-        if not any(v[1] for v in fam.values()):
-            avg_us = {k: float("nan") for k in fam}
-        dom = max(fam, key=lambda k: fam[k][0])   # the kernel with the largest total time
-        achieved = BYTES_K[dom] * n / (avg_us[dom] * 1e-6) / 1e9
-        traffic = None
+        timed = any(v[1] for v in fam.values())
+        avg_us = {k: ((v[0] / v[1]) * 1e3 if v[1] else 0.0) for k, v in fam.items()} if timed else None
         sharded_path = world > 1 or force_sharded
         if sharded_path:   # the sharded filter runs other kernels for the resample
             if getattr(pf, "exchange", "") == "owned":
                 KERNEL_OF.update({"bin_draws": "k_shard_table + k_shard_own_draws + k_shard_own_plan", "resample_gather": "k_shard_own_place"})
             else:
                 KERNEL_OF.update({"bin_draws": "k_shard_route_fused", "resample_gather": "k_shard_resolve_binned"})
-        if n == N_PER_GPU and os.path.exists(TRAFFIC_JSON) and not (sharded_path and dom != "propagate"):
-            # PMC passes cannot run inside this process: committed summary of the same single-GPU workload
-            try:
-                traffic = json.load(open(TRAFFIC_JSON))[dom]["traffic_bytes"]
-            except Exception:
-                traffic = None
+        roofline = None
+        if timed:
+            dom = max(fam, key=lambda k: fam[k][0])   # the kernel with the largest total time
+            achieved = BYTES_K[dom] * n / (avg_us[dom] * 1e-6) / 1e9
+            # HBM-side bytes per launch of that kernel: PMC passes cannot run inside this process, so this is the committed
+            # summary of the same single-GPU command — accepted only if it names this kernel AND was measured with this build
+            # (content hash of the kernel sources), otherwise null with the reason
+            traffic, traffic_note = None, None
+            if n == N_PER_GPU and os.path.exists(TRAFFIC_JSON) and not sharded_path:
+                try:
+                    from modppl_amd import build as _b
+
+                    tj = json.load(open(TRAFFIC_JSON))
+                    meta = tj.get("_measured", {})
+                    if meta.get("source_hash") != _b.source_hash():
+                        traffic_note = f"profiles summary is from another build (commit {meta.get('commit')}): re-run tools/profile_round.sh"
+                    elif KERNEL_OF.get(dom) not in meta.get("kernels", {}).get(dom, ""):
+                        traffic_note = f"profiles summary names {meta.get('kernels', {}).get(dom)!r}, the dominant kernel is {KERNEL_OF.get(dom)!r}"
+                    else:
+                        traffic = tj[dom]["traffic_bytes"]
+                        traffic_note = f"rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, commit {meta.get('commit')}"
+                except Exception as e:   # noqa: BLE001
+                    traffic_note = f"unreadable profiles summary: {e}"
+            roofline = {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
+                        "bytes_per_launch": BYTES_K[dom] * n}
         out = {
             "metric": "particle-steps/sec, 1M-particle LGSSM SMC (step + multinomial resample per time step)",
             "value": n * world * K / dt,
@@ -273,16 +404,26 @@ def main():
             "step_hbm_frac": BYTES_STEP * n * K / dt / 1e9 / HBM_PEAK_GBPS,
             "hbm_copy_measured_GBps": copy_gbps,
             "kernel_avg_us": avg_us,
-            "kernel_launches_per_step": {k: v[1] / K for k, v in fam.items()},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "bytes_per_launch": BYTES_K[dom] * n},
+            "kernel_launches_per_step": {k: v[1] / K for k, v in fam.items()} if timed else None,
         }
+        if roofline is not None:
+            out["roofline"] = roofline
+        if c5 is not None:
+            out["c5"] = c5
+        if world == 1 and not force_sharded and not args.no_sub_benches:
+            del pf
+            out.update(sub_benches(max(10, min(K, 40)), min(W, 5), ("c3", "c5", "c4")))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ys, n)
+            # parity beside the CPU restatement: relative log-ML difference, resample-index mismatches
+            rel, mism, draws, detail = cpu_baseline_parity(lambda: modppl_amd.lgssm_model(*LGSSM_PARAMS))
+            out["log_ml_rel_err_vs_cpu"] = rel
+            out["resample_index_mismatches_vs_cpu"] = mism
+            out["parity_vs_cpu"] = dict(detail, resample_draws_compared=draws,
+                                        cpu="literal arithmetic (libm, sequential fp64 sums, linear `while t < u` scan at N=1000; binary search over the same running sum at 2^20)")
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, allow_nan=False), flush=True)
         os.dup2(2, 1)
     if dist is not None:
         dist.barrier()

@@ -449,9 +449,18 @@ static int32_t check_launch(const char* what) {
     return MP_OK;
 }
 
+// Wait for the handle's stream by polling: a blocking hipStreamSynchronize wakes the host tens of microseconds after the
+// last kernel has finished, which is several SMC steps' worth at 2^20 particles (the handle is single-threaded: nothing
+// else wants this core meanwhile).
+static hipError_t stream_wait(hipStream_t s) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+    }
+}
 static int32_t fetch_scalars(mp_pf* h) {
     HIPCK(hipMemcpyAsync(h->h_scal, h->scal, sizeof(mp_dev_scalars), hipMemcpyDeviceToHost, h->stream));
-    HIPCK(hipStreamSynchronize(h->stream));
+    HIPCK(stream_wait(h->stream));
     if (h->h_scal->degenerate)
         return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
     return MP_OK;

@@ -18,9 +18,12 @@ FAM = {"k_propagate": "propagate", "k_normalize_tiles": "normalize_scan", "k_res
 STREAMING = {"propagate", "normalize_scan", "bin_draws"}
 
 
+NAMES = {}   # family -> kernel names seen (bench.py checks them against the kernels it times)
+
+
 def per_kernel(dirname, counter):
     """mean per launch of each kernel, summed over the kernels of a family (one launch of each per resample)"""
-    files = glob.glob(f"{dirname}/*/*_counter_collection.csv") + glob.glob(f"{dirname}/*_counter_collection.csv")
+    files = glob.glob(f"{dirname}/**/*_counter_collection.csv", recursive=True)
     per = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -29,6 +32,7 @@ def per_kernel(dirname, counter):
             for key in FAM:
                 if key in r["Kernel_Name"]:
                     per[key].append(float(r["Counter_Value"]))
+                    NAMES.setdefault(FAM[key], set()).add(r["Kernel_Name"].split("(")[0].replace("void ", ""))
     out, cnt = collections.defaultdict(float), collections.defaultdict(int)
     for key, v in per.items():
         out[FAM[key]] += sum(v) / len(v)
@@ -37,8 +41,8 @@ def per_kernel(dirname, counter):
 
 
 def main(root):
-    fetch, nf = per_kernel(f"{root}/pmc_fetch", "FETCH_SIZE")
-    write, nw = per_kernel(f"{root}/pmc_write", "WRITE_SIZE")
+    fetch, nf = per_kernel(root, "FETCH_SIZE")
+    write, nw = per_kernel(root, "WRITE_SIZE")
     res = {}
     for fam in sorted(set(FAM.values())):
         f_raw = fetch.get(fam, 0.0) * 1024.0
@@ -47,6 +51,20 @@ def main(root):
         res[fam] = {"fetch_bytes_raw": f_raw, "fetch_bytes_corrected": f_corr, "write_bytes": w, "traffic_bytes": f_corr + w,
                     "fetch_correction": "x2 (wide coalesced stream)" if fam in STREAMING else "none (random 16-B rows: uncalibrated width; true value in [1x, 2x] of raw)",
                     "launches_sampled": [nf.get(fam, 0), nw.get(fam, 0)]}
+    import os
+    import subprocess
+
+    root_repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root_repo)
+    from modppl_amd import build as B
+
+    try:
+        commit = subprocess.run(["git", "-C", root_repo, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        commit = None
+    # what this summary was measured with: bench.py refuses it for any other build of the kernels
+    res["_measured"] = {"commit": commit or os.environ.get("MP_COMMIT"), "source_hash": B.source_hash(),
+                        "kernels": {fam: " + ".join(sorted(v)) for fam, v in NAMES.items()}}
     print(json.dumps(res, indent=1))
 
 

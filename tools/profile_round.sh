@@ -1,18 +1,22 @@
 #!/bin/bash
-# Round profile of the bench command: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc passes
-# (MI355X_MICROARCH.md: one counter group per pass), each bounded.  Outputs under gpurun_out/r1; summaries are copied
-# into profiles/ by hand (tools/collect_traffic.py for the PMC passes).
+# Round profile of the bench command (run on the GPU box from the repo root): kernel-trace stats, then FETCH_SIZE and
+# WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md: one counter group per pass), SQ instruction counters, then
+# the bench itself.  Outputs under gpurun_out/$1 (default r02_prof); the summaries are copied into profiles/rNN by
+# tools/collect_profiles.sh on the build side.
 set -u
-ROOT=/root/repo
-OUT=$ROOT/gpurun_out/r1
+R=$PWD
+OUT=$R/gpurun_out/${1:-r02_prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-timing > $OUT/trace.log 2>&1 || { echo "trace pass failed"; exit 1; }
+B="python3 $R/bench.py --no-cpu-baseline --no-kernel-timing --no-sub-benches"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $B --steps 50 --warmup 10 > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -n 5 $OUT/trace.log; exit 1; }
 echo "trace done"
-timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $OUT/fetch.log 2>&1 || { echo "fetch pass failed"; exit 1; }
-echo "fetch done"
-timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $OUT/write.log 2>&1 || { echo "write pass failed"; exit 1; }
-echo "write done"
-cd $ROOT && timeout -k 10 300 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { echo "bench failed"; exit 1; }
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum"; do
+  i=$((i+1))
+  timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -o p -- $B --steps 10 --warmup 3 > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -n 5 $OUT/pmc$i.log; exit 1; }
+  echo "pmc pass $i done ($grp)"
+done
+cd $R && timeout -k 10 600 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { echo "bench failed"; tail -n 5 $OUT/bench_n1.err; exit 1; }
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1_k20.json 2>> $OUT/bench_n1.err || { echo "bench k20 failed"; exit 1; }
 echo "bench done"
-find $OUT -name "*.csv" | head -20
