@@ -58,6 +58,10 @@ enum mp_model_kind {
     MP_MODEL_POINTED_2D = 6,
     /* line_model (simple.rs:9-24): params = xs[11]; state = (slope, intercept), obs = ys[11] */
     MP_MODEL_LINE = 7,
+    /* Dense LGSSM, dim_state = dim_obs = D (16 compiled in): t==0: x ~ mvnormal(0, sig0^2 I); t>0: x ~ mvnormal(A x_prev, Q);
+     * mvnormal(x, R) observed — two mvnormal sites (mvnormal.rs:14-38; Q may be singular: eigen transform, :30-33).
+     * params = {D, sig0, A[D*D], Q[D*D], R[D*D]} row-major.  The matrix products run on the matrix cores. */
+    MP_MODEL_LGSSM_DENSE = 8,
 };
 
 typedef struct mp_model_desc {

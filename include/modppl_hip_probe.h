@@ -22,6 +22,16 @@ int32_t mp_probe_normal_sample(uint64_t seed, uint32_t slot0, uint32_t step, uin
 int32_t mp_probe_u01(uint64_t seed, uint32_t slot0, uint32_t step, uint32_t domain, uint32_t site, uint32_t attempt, int64_t n,
                      double* out, int32_t device);
 
+/* mvnormal of dimension k <= 16 (modppl/src/modeling/dists/mvnormal.rs:14-38), determinant / inverse / transform hoisted to the
+ * host once: logpdf_out[i] = logpdf(x[i][0..k); mu, cov) when logpdf_out != NULL; sample_out[i][0..k) = random with the Philox
+ * stream (seed, slot0 + i, step, domain, site) when sample_out != NULL (covariances without a Cholesky factor take the
+ * eigen transform, :30-33).  chain = 0: the reference's multiply-then-add order; 1: the matrix cores' fma chain. */
+int32_t mp_probe_mvnormal(int32_t k, int32_t chain, const double* x, const double* mu, const double* cov, int64_t n, double* logpdf_out,
+                          uint64_t seed, uint32_t slot0, uint32_t step, uint32_t domain, uint32_t site, double* sample_out, int32_t device);
+/* One v_mfma_f64_16x16x4_f64 on one wave: D = A * B + C (row-major A[16][4], B[4][16], C, D[16][16]): pins the matrix
+ * core's accumulation order, which the dense-transition kernels and the CPU checker's canonical matvec restate. */
+int32_t mp_probe_mfma_f64(const double* A16x4, const double* B4x16, const double* C16x16, double* D16x16, int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

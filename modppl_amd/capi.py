@@ -12,6 +12,7 @@ MP_OK = 0
 MP_ERR_INVALID_ARG, MP_ERR_STATE, MP_ERR_CONSTRAINTS, MP_ERR_DEGENERATE, MP_ERR_HIP, MP_ERR_UNSUPPORTED, MP_ERR_CAPACITY = 1, 2, 3, 4, 5, 6, 7
 
 MP_MODEL_LGSSM1, MP_MODEL_SPIRAL, MP_MODEL_HMM, MP_MODEL_BEARINGS, MP_MODEL_LGSSM_BAND, MP_MODEL_POINTED_2D, MP_MODEL_LINE = 1, 2, 3, 4, 5, 6, 7
+MP_MODEL_LGSSM_DENSE = 8
 MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC, MP_RESAMPLE_STRATIFIED = 0, 1, 2
 MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
 MP_PF_RECORD_HISTORY = 1
@@ -34,7 +35,7 @@ SYMBOLS = [
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
     "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_iterations", "mp_mh_destroy",
     # include/modppl_hip_probe.h
-    "mp_probe_math", "mp_probe_normal_sample", "mp_probe_u01",
+    "mp_probe_math", "mp_probe_normal_sample", "mp_probe_u01", "mp_probe_mfma_f64", "mp_probe_mvnormal",
 ]
 
 
@@ -141,6 +142,8 @@ def load():
     L.mp_probe_math.argtypes = [i32, dp, dp, dp, i64, dp, i32]
     L.mp_probe_normal_sample.argtypes = [u64, u32, u32, u32, u32, d, d, i64, dp, i32]
     L.mp_probe_u01.argtypes = [u64, u32, u32, u32, u32, u32, i64, dp, i32]
+    L.mp_probe_mfma_f64.argtypes = [dp, dp, dp, dp, i32]
+    L.mp_probe_mvnormal.argtypes = [i32, i32, dp, dp, dp, i64, dp, u64, u32, u32, u32, u32, dp, i32]
     _lib = L
     return L
 

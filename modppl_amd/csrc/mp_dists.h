@@ -109,6 +109,41 @@ MP_HD double mp_mvnormal_logpdf_pre(const double* x, const double* mu, const dou
     return -((double)K * MP_LN_2PI_CANON + ln_det + maha) / 2.;
 }
 
+// ---- dense K x K forms in the MATRIX CORE's accumulation order --------------------------------------------------------
+// v_mfma_f64_16x16x4_f64 computes D = fma(a_3, b_3, fma(a_2, b_2, fma(a_1, b_1, fma(a_0, b_0, C)))): a k-ascending fma chain
+// from C (pinned on the device by tests/test_gpu_math.py::test_mfma_f64_accumulation_order).  Models whose transition is a
+// dense matvec (mp_lgssm_dense) define their products as that chain, so the scalar form below, the MFMA kernel
+// (k_propagate_dense16) and the CPU checker's canonical arithmetic give the same bits; the literal checker keeps
+// nalgebra's multiply-then-add.
+template <int K>
+MP_HD double mp_dot_chain(const double* a, int stride_a, const double* b, int stride_b, double c0) {
+    double acc = c0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc = fma(a[k * stride_a], b[k * stride_b], acc);
+    return acc;
+}
+// mvnormal.rs:14-22, covariance constants hoisted (cov_inv row-major, ln_det): r_j = sum_i c_i inv[i][j]; maha = sum_j r_j c_j
+template <int K>
+MP_HD double mp_mvnormal_logpdf_chain(const double* x, const double* mu, const double* cov_inv, double ln_det) {
+    double c[K], r[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) c[i] = x[i] - mu[i];
+#pragma unroll
+    for (int j = 0; j < K; ++j) r[j] = mp_dot_chain<K>(c, 1, cov_inv + j, K, 0.);
+    const double maha = mp_dot_chain<K>(r, 1, c, 1, 0.);
+    return -((double)K * MP_LN_2PI_CANON + ln_det + maha) / 2.;
+}
+// mvnormal.rs:24-37: transform * z + mu with z_j ~ normal(0, 1) in index order from ONE site's stream (`transform` = lower
+// Cholesky factor, or the eigen form V sqrt(diag) when the covariance has no Cholesky factor: any K x K matrix here)
+template <int K>
+MP_HD void mp_mvnormal_sample_chain(mp_site& st, const double* mu, const double* transform, double* out) {
+    double z[K];
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) z[j] = mp_normal_sample(st, 0., 1.);
+#pragma unroll
+    for (int i = 0; i < K; ++i) out[i] = mp_dot_chain<K>(transform + i * K, 1, z, 1, 0.) + mu[i];
+}
+
 // categorical.rs:12-32 over a small probability table
 MP_HD double mp_categorical_logpdf(int x, const double* probs, int n) { return (x >= 0 && x < n) ? mp_log(probs[x]) : MP_NEG_INF; }
 MP_HD int mp_categorical_sample(mp_site& st, const double* probs, int n) {

@@ -74,3 +74,57 @@ inline bool mp_host_cholesky(const std::vector<double>& m, int n, std::vector<do
     }
     return true;
 }
+
+// mvnormal.rs:30-33: the fallback `transform` of a covariance without a Cholesky factor (positive semi-definite, singular):
+// eigenvectors * diag(sqrt(eigenvalues)).  nalgebra's symmetric_eigen is an un-vendored dependency; its result is defined only
+// up to the order and sign of the eigenvectors, which `transform * z` depends on, so the build fixes one: cyclic Jacobi
+// rotations (upper-triangle sweep order, at most 64 sweeps), eigenpairs in the order the diagonal ends up in.  A negative
+// eigenvalue gives NaN columns, as `.sqrt()` does in the reference — except round-off: an eigenvalue in [-64 eps lambda_max, 0)
+// (what a zero eigenvalue of a singular covariance comes out as) is taken as zero, where the reference's result depends on
+// the last bit of nalgebra's iteration.
+inline void mp_host_sym_eigen_transform(std::vector<double> a, int n, std::vector<double>& T) {
+    std::vector<double> v((size_t)n * n, 0.);
+    for (int i = 0; i < n; ++i) v[i * n + i] = 1.;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0.;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) off += a[p * n + q] * a[p * n + q];
+        if (off == 0.) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (apq == 0.) continue;
+                const double theta = (a[q * n + q] - a[p * n + p]) / (2. * apq);
+                const double t = (theta >= 0. ? 1. : -1.) / (std::fabs(theta) + std::sqrt(theta * theta + 1.));
+                const double c = 1. / std::sqrt(t * t + 1.), s_ = t * c;
+                for (int k = 0; k < n; ++k) {   // A <- J^T A J
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s_ * akq;
+                    a[k * n + q] = s_ * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s_ * aqk;
+                    a[q * n + k] = s_ * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c * vkp - s_ * vkq;
+                    v[k * n + q] = s_ * vkp + c * vkq;
+                }
+            }
+    }
+    double lmax = 0.;
+    for (int j = 0; j < n; ++j) lmax = std::fmax(lmax, std::fabs(a[j * n + j]));
+    T.assign((size_t)n * n, 0.);
+    for (int j = 0; j < n; ++j) {
+        double lam = a[j * n + j];
+        if (lam < 0. && lam >= -64. * 2.220446049250313e-16 * lmax) lam = 0.;
+        const double sq = std::sqrt(lam);
+        for (int i = 0; i < n; ++i) T[i * n + j] = v[i * n + j] * sq;
+    }
+}
+// mvnormal.rs:26-34: Cholesky factor if there is one, the eigen form otherwise
+inline void mp_host_mvnormal_transform(const std::vector<double>& cov, int n, std::vector<double>& T) {
+    if (!mp_host_cholesky(cov, n, T)) mp_host_sym_eigen_transform(cov, n, T);
+}

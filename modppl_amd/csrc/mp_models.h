@@ -75,6 +75,20 @@ struct mp_generate_handler {
         static_assert(k >= 0, "mvnormal_observed: the site must be constrained on this path");
         weight += mp_mvnormal_logpdf_pre<K>(obs + k, mu, cov_inv, ln_det);
     }
+    // mvnormal site of dimension K in the matrix core's accumulation order (mp_dists.h): constrained -> scored, free -> drawn
+    // (transform z + mu, the K normals one after the other from this site's stream).  x: the value (in: constraint slot / out: draw).
+    template <int SITE, int K>
+    MP_HD void mvnormal_chain(const double* mu, const double* transform, const double* cov_inv, double ln_det, double* x) {
+        constexpr int k = Model::obs_of(SITE);
+        if constexpr (k >= 0) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) x[i] = obs[k + i];
+            weight += mp_mvnormal_logpdf_chain<K>(x, mu, cov_inv, ln_det);
+        } else {
+            mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
+            mp_mvnormal_sample_chain<K>(st, mu, transform, x);
+        }
+    }
     // categorical over a small table; values travel as doubles in the constraint / state arrays
     template <int SITE>
     MP_HD int categorical(const double* probs, int n) {
@@ -142,6 +156,16 @@ struct mp_simulate_handler {
             double acc = 0.;
             for (int j = 0; j <= i; ++j) acc += chol[i * K + j] * z[j];
             obs_out[k + i] = acc + mu[i];
+        }
+    }
+    template <int SITE, int K>
+    MP_HD void mvnormal_chain(const double* mu, const double* transform, const double*, double, double* x) {
+        mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
+        mp_mvnormal_sample_chain<K>(st, mu, transform, x);
+        constexpr int k = Model::obs_of(SITE);
+        if constexpr (k >= 0) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) obs_out[k + i] = x[i];
         }
     }
     template <int SITE>
@@ -332,6 +356,42 @@ struct mp_lgssm_band {
     template <class H>
     MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
         site<H, 0>(g, t, prev, next);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Dense LGSSM, d = D: the state transition really is a dense matvec (BASELINE.json north star: "MFMA only where a state
+// transition really is a dense matvec").  Two mvnormal sites (mvnormal.rs:14-38), covariance constants hoisted to the host:
+//   t==0: x ~ mvnormal(0, sig0^2 I) %= "x";   t>0: x ~ mvnormal(A x_prev, Q) %= "x";   mvnormal(x, R) %= "y" observed
+// Every product is a k-ascending fma chain (mp_dists.h): the scalar interpretation below (any handler) and the MFMA kernel
+// k_propagate_dense16 (Generate mode, mp_pf_kernels.h) agree bit for bit.  The matrices live in device memory (4 x D x D
+// doubles do not fit kernel arguments): mats = [A | TQ | T0 | Rinv | TR], row-major; TQ / T0 / TR = mvnormal.random's
+// `transform` of Q, sig0^2 I and R (TR is only used by Simulate, which draws the observation too).
+// ---------------------------------------------------------------------------------------
+template <int D>
+struct mp_lgssm_dense {
+    static constexpr int DIM_STATE = D, DIM_OBS = D;
+    enum { X = 0, Y = 1 };
+    static constexpr int obs_of(int site) { return site == Y ? 0 : -1; }
+    static constexpr int MAX_NORMALS = 1;  // no independent normal sites: the D normals of "x" are ONE site's sequential stream
+    static constexpr int normal_index(int) { return 0; }
+    MP_HD int n_normals(int64_t) const { return 0; }
+    MP_HD uint32_t normal_site(int) const { return 0; }
+    const double* mats;   // [5][D][D]
+    double ln_det_R;
+    MP_HD const double* A() const { return mats; }
+    MP_HD const double* TQ() const { return mats + D * D; }
+    MP_HD const double* T0() const { return mats + 2 * D * D; }
+    MP_HD const double* Rinv() const { return mats + 3 * D * D; }
+    MP_HD const double* TR() const { return mats + 4 * D * D; }
+
+    template <class H>
+    MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
+        double mean[D], y[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) mean[i] = (t == 0) ? 0. : mp_dot_chain<D>(A() + i * D, 1, prev, 1, 0.);
+        g.template mvnormal_chain<X, D>(mean, t == 0 ? T0() : TQ(), nullptr, 0., next);
+        g.template mvnormal_chain<Y, D>(next, TR(), Rinv(), ln_det_R, y);
     }
 };
 

@@ -114,9 +114,10 @@ struct ResolveArgs {   // k_resolve_bins (+ the next step's deviates when zpre !
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
+    void* owned_device_mem = nullptr;   // model constants that do not fit kernel arguments (freed with the model)
     int max_normals = 0;
     bool coop = false;   // few normal sites per particle: deviates can be drawn cooperatively / one launch ahead
-    virtual ~ModelOps() {}
+    virtual ~ModelOps() { if (owned_device_mem) (void)hipFree(owned_device_mem); }
     virtual void propagate(const PropagateArgs& a) const = 0;
     virtual void resolve(const ResolveArgs& a) const = 0;
     virtual int n_normals(long long t) const = 0;
@@ -280,6 +281,42 @@ static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out
         for (int i = 0; i < 11; ++i) k.xs[i] = m->params[i];
         k.ln_noise = mp_log(0.1);
         out.reset(new ModelOpsT<mp_line<11>>(k));
+        return MP_OK;
+    }
+    case MP_MODEL_LGSSM_DENSE: {
+        if (!m->params || m->n_params < 2) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM_DENSE: params = {D, sig0, A[D*D], Q[D*D], R[D*D]}");
+        const int D = (int)m->params[0];
+        if (D != 16) return mp_fail(MP_ERR_UNSUPPORTED, "MP_MODEL_LGSSM_DENSE: D = 16 is compiled in (one matrix-core tile)");
+        if (m->n_params != 2 + 3 * D * D || m->dim_state != D || m->dim_obs != D)
+            return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM_DENSE: n_params = 2 + 3 D^2, dim_state = dim_obs = D");
+        const double sig0 = m->params[1];
+        if (!(sig0 > 0.)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM_DENSE: sig0 must be > 0");
+        const double* q = m->params + 2;
+        const std::vector<double> A(q, q + D * D), Q(q + D * D, q + 2 * D * D), R(q + 2 * D * D, q + 3 * D * D);
+        // the per-call nalgebra work of mvnormal.rs:17-18,27-33, once: transform of Q / sig0^2 I / R, inverse and ln det of R
+        std::vector<double> cov0((size_t)D * D, 0.), TQ, T0, TR, Rinv;
+        for (int i = 0; i < D; ++i) cov0[i * D + i] = sig0 * sig0;
+        mp_host_mvnormal_transform(Q, D, TQ);
+        mp_host_mvnormal_transform(cov0, D, T0);
+        mp_host_mvnormal_transform(R, D, TR);
+        const double detR = mp_host_det(R, D);
+        if (!mp_host_inverse(R, D, Rinv)) return mp_fail(MP_ERR_INVALID_ARG, "MP_MODEL_LGSSM_DENSE: R is not invertible (try_inverse().unwrap() panics, mvnormal.rs:18)");
+        std::vector<double> mats;
+        mats.insert(mats.end(), A.begin(), A.end());
+        mats.insert(mats.end(), TQ.begin(), TQ.end());
+        mats.insert(mats.end(), T0.begin(), T0.end());
+        mats.insert(mats.end(), Rinv.begin(), Rinv.end());
+        mats.insert(mats.end(), TR.begin(), TR.end());
+        double* d_mats = nullptr;
+        HIPCK(hipMalloc(&d_mats, sizeof(double) * mats.size()));
+        if (hipMemcpy(d_mats, mats.data(), sizeof(double) * mats.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_mats);
+            return mp_fail(MP_ERR_HIP, "MP_MODEL_LGSSM_DENSE: copying the model matrices failed");
+        }
+        mp_lgssm_dense<16> k{d_mats, mp_log(detR)};
+        auto* ops = new ModelOpsT<mp_lgssm_dense<16>>(k);
+        ops->owned_device_mem = d_mats;
+        out.reset(ops);
         return MP_OK;
     }
     default:

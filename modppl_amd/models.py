@@ -69,3 +69,13 @@ def line_model(xs=tuple(float(v) for v in range(-5, 6))):
     """`line_model` of modppl/tests/dyngenfns/simple.rs:9-24 (static): slope ~ normal(0,1), intercept ~ normal(0,2),
     ys/i ~ normal(slope x_i + intercept, 0.1) observed.  Default design: tests/importance.rs:62."""
     return UnfoldModel(capi.MP_MODEL_LINE, 2, len(xs), list(xs), "line")
+
+
+def lgssm_dense_model(A, Q, R, sig0=1.0):
+    """Dense LGSSM, d = 16: t==0: x ~ mvnormal(0, sig0^2 I); t>0: x ~ mvnormal(A x_prev, Q); mvnormal(x, R) observed
+    (two `mvnormal` sites, modppl/src/modeling/dists/mvnormal.rs:14-38; Q may be singular: the eigen `transform`, :30-33).
+    The three 16 x 16 products per particle-step run on the matrix cores (v_mfma_f64_16x16x4_f64)."""
+    A, Q, R = (np.ascontiguousarray(m, dtype=np.float64) for m in (A, Q, R))
+    D = A.shape[0]
+    assert A.shape == Q.shape == R.shape == (D, D)
+    return UnfoldModel(capi.MP_MODEL_LGSSM_DENSE, D, D, np.concatenate([[D, sig0], A.reshape(-1), Q.reshape(-1), R.reshape(-1)]), f"lgssm_dense{D}")

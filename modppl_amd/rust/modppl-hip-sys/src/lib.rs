@@ -18,6 +18,7 @@ pub const MP_MODEL_BEARINGS: i32 = 4;
 pub const MP_MODEL_LGSSM_BAND: i32 = 5;
 pub const MP_MODEL_POINTED_2D: i32 = 6;
 pub const MP_MODEL_LINE: i32 = 7;
+pub const MP_MODEL_LGSSM_DENSE: i32 = 8;
 pub const MP_RESAMPLE_MULTINOMIAL: i32 = 0;
 pub const MP_RESAMPLE_SYSTEMATIC: i32 = 1;
 pub const MP_RESAMPLE_STRATIFIED: i32 = 2;

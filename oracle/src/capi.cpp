@@ -201,6 +201,13 @@ int32_t oracle_pf_create(const mp_model_desc* m, uint64_t n, uint64_t seed, cons
                                                         Mat(2, std::vector<double>(m->params + 4, m->params + 8)));
             } else if (m->kind == MP_MODEL_LINE) {
                 e->model = std::make_unique<SoaLine>(Vec(m->params, m->params + m->n_params));
+            } else if (m->kind == MP_MODEL_LGSSM_DENSE) {
+                const int D = (int)m->params[0];
+                if (m->n_params != 2 + 3 * D * D) throw Panic("lgssm_dense: params = {D, sig0, A, Q, R}");
+                const double* q = m->params + 2;
+                e->model = std::make_unique<SoaLgssmDense>(D, m->params[1], Mat(D, std::vector<double>(q, q + D * D)),
+                                                           Mat(D, std::vector<double>(q + D * D, q + 2 * D * D)),
+                                                           Mat(D, std::vector<double>(q + 2 * D * D, q + 3 * D * D)));
             } else throw Panic("unsupported model kind for the SoA engine");
             e->pf = std::make_unique<SoaPf>(e->model.get(), (size_t)n, seed, canon, shard ? shard->n_global : 0, shard ? shard->slot_offset : 0);
             h->impl = std::move(e);
@@ -626,6 +633,18 @@ int64_t oracle_categorical_scan(double u, const double* probs, int64_t n) {
 void oracle_mvnormal_random(uint64_t seed, uint32_t slot, int32_t k, const double* mu, const double* cov, double* out) {
     Rng r; r.seed = seed; r.slot = slot; r.at(DOM_MODEL, 0);
     Vec v = mvnormal.random(r, MvNormalParams{Vec(mu, mu + k), Mat(k, Vec(cov, cov + k * k))});
+    for (int i = 0; i < k; ++i) out[i] = v[(size_t)i];
+}
+// the dense forms (dense_dot: multiply-then-add when canon == 0, the matrix cores' fma chain when 1), any slot / step / site
+double oracle_mvnormal_logpdf_dense(int32_t k, const double* x, const double* mu, const double* cov, int32_t canon) {
+    oracle_pf::Scope s(canon);
+    return mvnormal.logpdf_dense(Vec(x, x + k), MvNormalParams{Vec(mu, mu + k), Mat(k, Vec(cov, cov + k * k))});
+}
+void oracle_mvnormal_random_dense(uint64_t seed, uint32_t slot, uint32_t step, uint32_t domain, uint32_t site, int32_t k, const double* mu,
+                                  const double* cov, int32_t canon, double* out) {
+    oracle_pf::Scope s(canon);
+    Rng r; r.seed = seed; r.slot = slot; r.step = step; r.at(domain, site);
+    Vec v = mvnormal.random_dense(r, MvNormalParams{Vec(mu, mu + k), Mat(k, Vec(cov, cov + k * k))});
     for (int i = 0; i < k; ++i) out[i] = v[(size_t)i];
 }
 // canonical resampling spec, exposed piecewise

@@ -184,6 +184,55 @@ inline bool cholesky_l(const Mat& m, Mat& L) {
     }
     return true;
 }
+// mvnormal.rs:30-33 — `transform` of a covariance without a Cholesky factor: eigenvectors * diag(sqrt(eigenvalues)).
+// nalgebra's symmetric_eigen (un-vendored) fixes neither the order nor the sign of the eigenvectors, which
+// `transform * z` depends on; the build's definition (cyclic Jacobi, upper-triangle sweep order) is restated here.
+inline Mat symmetric_eigen_transform(Mat a) {
+    const int n = a.n;
+    Mat v(n, std::vector<double>((size_t)n * n, 0.));
+    for (int i = 0; i < n; ++i) v(i, i) = 1.;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0.;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) off += a(p, q) * a(p, q);
+        if (off == 0.) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a(p, q);
+                if (apq == 0.) continue;
+                const double theta = (a(q, q) - a(p, p)) / (2. * apq);
+                const double t = (theta >= 0. ? 1. : -1.) / (std::fabs(theta) + std::sqrt(theta * theta + 1.));
+                const double c = 1. / std::sqrt(t * t + 1.), s = t * c;
+                for (int k = 0; k < n; ++k) { const double x = a(k, p), y = a(k, q); a(k, p) = c * x - s * y; a(k, q) = s * x + c * y; }
+                for (int k = 0; k < n; ++k) { const double x = a(p, k), y = a(q, k); a(p, k) = c * x - s * y; a(q, k) = s * x + c * y; }
+                for (int k = 0; k < n; ++k) { const double x = v(k, p), y = v(k, q); v(k, p) = c * x - s * y; v(k, q) = s * x + c * y; }
+            }
+    }
+    double lmax = 0.;
+    for (int j = 0; j < n; ++j) lmax = std::fmax(lmax, std::fabs(a(j, j)));
+    Mat T(n, std::vector<double>((size_t)n * n, 0.));
+    for (int j = 0; j < n; ++j) {
+        double lam = a(j, j);
+        if (lam < 0. && lam >= -64. * 2.220446049250313e-16 * lmax) lam = 0.;   // round-off of a zero eigenvalue
+        const double sq = std::sqrt(lam);
+        for (int i = 0; i < n; ++i) T(i, j) = v(i, j) * sq;
+    }
+    return T;
+}
+// mvnormal.rs:26-34
+inline Mat mvnormal_transform(const Mat& cov) {
+    Mat L;
+    if (cholesky_l(cov, L)) return L;
+    return symmetric_eigen_transform(cov);
+}
+// sum_k a_k b_k: the reference's multiply-then-add, or (canonical mode) the k-ascending fma chain the matrix cores evaluate
+inline double dense_dot(const double* a, size_t sa, const double* b, size_t sb, int k) {
+    double acc = 0.;
+    if (canonical_mode()) { for (int i = 0; i < k; ++i) acc = std::fma(a[i * sa], b[i * sb], acc); }
+    else { for (int i = 0; i < k; ++i) acc += a[i * sa] * b[i * sb]; }
+    return acc;
+}
+
 struct MvNormalParams { std::vector<double> mu; Mat cov; };
 struct MvNormal {
     double logpdf(const std::vector<double>& x, const MvNormalParams& p) const {
@@ -201,10 +250,31 @@ struct MvNormal {
         }
         return -((double)k * o_ln(2. * M_PI) + o_ln(cov_det) + maha) / 2.;
     }
+    // the same two functions for models that define their dense products through dense_dot (mp_lgssm_dense): full k x k
+    // transform (Cholesky or eigen form), per-call determinant / inverse as in the reference
+    double logpdf_dense(const std::vector<double>& x, const MvNormalParams& p) const {
+        const int k = (int)p.mu.size();
+        const double cov_det = determinant(p.cov);
+        Mat cov_inv;
+        if (!try_inverse(p.cov, cov_inv)) throw Panic("mvnormal: covariance not invertible");
+        std::vector<double> c((size_t)k), r((size_t)k);
+        for (int i = 0; i < k; ++i) c[(size_t)i] = x[(size_t)i] - p.mu[(size_t)i];
+        for (int j = 0; j < k; ++j) r[(size_t)j] = dense_dot(c.data(), 1, &cov_inv.a[(size_t)j], (size_t)k, k);
+        const double maha = dense_dot(r.data(), 1, c.data(), 1, k);
+        return -((double)k * o_ln(2. * M_PI) + o_ln(cov_det) + maha) / 2.;
+    }
+    std::vector<double> random_dense(Rng& rng, const MvNormalParams& p) const {
+        const int k = (int)p.mu.size();
+        const Mat T = mvnormal_transform(p.cov);
+        std::vector<double> z((size_t)k), out((size_t)k);
+        for (int j = 0; j < k; ++j) z[(size_t)j] = normal.random(rng, {0., 1.});  // index order, one stream
+        for (int i = 0; i < k; ++i) out[(size_t)i] = dense_dot(&T.a[(size_t)i * k], 1, z.data(), 1, k) + p.mu[(size_t)i];
+        return out;
+    }
     std::vector<double> random(Rng& rng, const MvNormalParams& p) const {
         const int k = (int)p.mu.size();
         Mat L;
-        if (!cholesky_l(p.cov, L)) throw Panic("mvnormal: eigen fallback not restated (cov not PD)");
+        if (!cholesky_l(p.cov, L)) L = symmetric_eigen_transform(p.cov);   // mvnormal.rs:30-33
         std::vector<double> z((size_t)k), out((size_t)k);
         for (int j = 0; j < k; ++j) z[(size_t)j] = normal.random(rng, {0., 1.});  // index order
         for (int i = 0; i < k; ++i) {

@@ -125,6 +125,27 @@ struct SoaLgssmBand : SoaModel {
     }
 };
 
+// dense LGSSM (MP_MODEL_LGSSM_DENSE): two mvnormal sites per step, per-call determinant / inverse / transform as the
+// reference's mvnormal does (mvnormal.rs:14-38)
+struct SoaLgssmDense : SoaModel {
+    int D; double sig0; Mat A, Q, R;
+    SoaLgssmDense(int D_, double sig0_, Mat A_, Mat Q_, Mat R_) : D(D_), sig0(sig0_), A(std::move(A_)), Q(std::move(Q_)), R(std::move(R_)) { dim_state = D; dim_obs = D; }
+    double kernel(Rng& r, int64_t t, const double* prev, double* next, const double* obs) const override {
+        Vec mean((size_t)D, 0.);
+        Mat cov = Q;
+        if (t == 0) {
+            cov = Mat(D, std::vector<double>((size_t)D * D, 0.));
+            for (int i = 0; i < D; ++i) cov(i, i) = sig0 * sig0;
+        } else {
+            for (int i = 0; i < D; ++i) mean[(size_t)i] = dense_dot(&A.a[(size_t)i * D], 1, prev, 1, D);
+        }
+        r.at(DOM_MODEL, 0);
+        const Vec x = mvnormal.random_dense(r, MvNormalParams{mean, cov});
+        for (int i = 0; i < D; ++i) next[i] = x[(size_t)i];
+        return mvnormal.logpdf_dense(Vec(obs, obs + D), MvNormalParams{x, R});
+    }
+};
+
 struct SoaHmm : SoaModel {  // tests/hmm/model.rs:33-80
     HmmParams p;
     explicit SoaHmm(HmmParams p_) : p(std::move(p_)) { dim_state = 1; dim_obs = 1; }

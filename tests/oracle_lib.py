@@ -131,6 +131,10 @@ def load():
     L.oracle_mvnormal_logpdf.restype = d
     L.oracle_mvnormal_random.argtypes = [u64, u32, i32, dp, dp, dp]
     L.oracle_mvnormal_random.restype = None
+    L.oracle_mvnormal_logpdf_dense.argtypes = [i32, dp, dp, dp, i32]
+    L.oracle_mvnormal_logpdf_dense.restype = d
+    L.oracle_mvnormal_random_dense.argtypes = [u64, u32, u32, u32, u32, i32, dp, dp, i32, dp]
+    L.oracle_mvnormal_random_dense.restype = None
     L.oracle_categorical_scan.argtypes = [d, dp, i64]
     L.oracle_categorical_scan.restype = i64
     L.oracle_canonical_normalize.argtypes = [dp, i64, u64, dp, dp, C.POINTER(u64), C.POINTER(u64)]
