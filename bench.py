@@ -175,6 +175,14 @@ def sub_benches(steps, warmup, which):
     if "c5" in which:
         res["c5_shard"] = dict(pf_case(modppl_amd.lgssm_band_model(16), 1 << 21, rng.normal(0, 1.2, size=(T, 16)), 16),
                                workload="LGSSM d=16, 2^21 particles = one GPU's share of configs[4] (16M over 8 GPUs), unsharded code path")
+    if "c5" in which:
+        # the same shard with a DENSE transition (dense A, Q, R: two mvnormal sites): the 16 x 16 products on the matrix cores
+        r5 = np.random.default_rng(5)
+        A = 0.9 * np.eye(16) + 0.08 * r5.normal(size=(16, 16)) / 4.0
+        m = r5.normal(size=(16, 16)); Q = 0.25 * (m @ m.T / 16 + 0.5 * np.eye(16))
+        m = r5.normal(size=(16, 16)); R = 4.0 * (m @ m.T / 16 + 0.5 * np.eye(16))
+        res["c5_dense_shard"] = dict(pf_case(modppl_amd.lgssm_dense_model(A, Q, R, 1.0), 1 << 21, rng.normal(0, 1.5, size=(T, 16)), 16),
+                                     workload="dense-transition LGSSM d=16 (mvnormal(A x, Q), mvnormal(x, R)), 2^21 particles, v_mfma_f64_16x16x4_f64 kernel")
     if "c4" in which:
         xs = np.arange(-5, 6, dtype=np.float64)
         ys = 0.3 + 0.4 * xs + 0.5 * xs * xs + rng.normal(0, 0.1, xs.size)

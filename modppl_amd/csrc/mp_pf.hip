@@ -155,6 +155,16 @@ struct ModelOpsT : ModelOps {
                 return;
             }
         }
+        if constexpr (std::is_same<Model, mp_lgssm_dense<16>>::value) {
+            // the dense transition's products on the matrix cores (k_propagate_dense16); MP_DENSE_MFMA=0 keeps the scalar
+            // interpretation of the same functor (same bits), as does a sharded handle's exchange-row input
+            static const bool mfma = [] { const char* e = getenv("MP_DENSE_MFMA"); return !(e && e[0] == '0'); }();
+            if (mfma && a.inv == nullptr) {
+                hipLaunchKernelGGL(k_propagate_dense16, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
+                                   a.x_out, a.logw, a.obs, a.overwrite, a.perm, a.res_parent, a.nchunks, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
                            a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent, a.aux);

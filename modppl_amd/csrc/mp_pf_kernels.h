@@ -760,6 +760,138 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagat
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1 for the dense-transition model mp_lgssm_dense<16>: the four 16 x 16 products of a particle-step — A x, T z,
+// (y - x)^T R^-1 and its dot with (y - x) — on the matrix cores (v_mfma_f64_16x16x4_f64).  Same results as the scalar
+// interpretation of the model functor, bit for bit: every product there is the k-ascending fma chain the MFMA evaluates.
+//
+// Workgroup = one tile (2048 particles), 512 threads = 8 waves; a wave takes its 256 particles in 4 rounds of 64.  In a
+// round, lane = particle while the 16 normals of the "x" site are drawn (one sequential stream per particle: a lane-local
+// queue of ~20 Philox blocks), then the 64 particles go through the MFMAs in 4 groups of 16, TRANSPOSED: D[j][i] with the
+// state index j on the rows (lane >> 4, register) and the particle i on the columns (lane & 15).  In that orientation
+// every product's result is already laid out as the next product's operand: no cross-lane movement between them.
+//   A-operand lane l, k-step s = M[l & 15][(l >> 4) + 4 s]   (the constant matrix)
+//   B-operand lane l, k-step s = v[(l >> 4) + 4 s] of particle l & 15
+//   C / D     lane l, register r = [(l >> 4) + 4 r][l & 15]
+// ---------------------------------------------------------------------------------------------
+typedef double mp_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int DENSE_THREADS = 512;
+__global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_dense<16> model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, long long t,
+                                                                     const double* __restrict__ x_in, double* __restrict__ x_out, double* logw, mp_obs obs,
+                                                                     int overwrite, const unsigned short* __restrict__ perm,
+                                                                     const uint32_t* __restrict__ res_parent, int nchunks, mp_cx* __restrict__ cx,
+                                                                     unsigned short* __restrict__ guide, double* tile_m, u64* tile_W, u64* tile_W2,
+                                                                     mp_k1_aux aux) {
+    constexpr int D = 16, ZP = D + 1;   // z rows padded by one double: the transposed reads then spread over the LDS banks
+    __shared__ double s_z[DENSE_THREADS / 64][64][ZP];
+    __shared__ double s_lw[TILE], s_x0[TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const u64 tile0 = (u64)blockIdx.x * TILE;
+    // the constant operands of this lane
+    double amat[4], tmat[4], rmat[4], yv[4];
+    const double* T = t == 0 ? model.T0() : model.TQ();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        amat[s] = model.A()[li * D + lg + 4 * s];
+        tmat[s] = T[li * D + lg + 4 * s];
+        rmat[s] = model.Rinv()[(lg + 4 * s) * D + li];   // M[j][k] = Rinv[k][j]: r_j = sum_k c_k Rinv[k][j]
+        yv[s] = obs.v[lg + 4 * s];
+    }
+    const double lp_const = (double)D * MP_LN_2PI_CANON + model.ln_det_R;
+#pragma unroll 1
+    for (int rd = 0; rd < 4; ++rd) {
+        const int pl = wave * 256 + rd * 64 + lane;    // this lane's particle of the round, tile-local
+        const u64 p = tile0 + (u64)pl;
+        const bool live = p < n;
+        // ---- the 16 normals of site "x": one sequential stream per particle (mvnormal.rs:35) ----
+        {
+            mp_stream rng;
+            rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + p); rng.step = (uint32_t)t;
+            mp_site st(rng, MP_DOM_MODEL, (uint32_t)mp_lgssm_dense<16>::X);
+            int j = live ? 0 : D;
+            while (j < D && st.blk < MP_MAX_ATTEMPTS) {
+                const mp_u64x2 b = st.next_block();
+                double u, r;
+                if (mp_polar_attempt(b, &u, &r)) {
+                    s_z[wave][lane][j] = mp_normal_from_pair(u, r, 0., 1.);   // normal.random(rng, (0., 1.))
+                    ++j;
+                }
+            }
+            if (!live) {
+#pragma unroll
+                for (int q = 0; q < D; ++q) s_z[wave][lane][q] = 0.;
+            }
+        }
+        // where this particle's previous state lives (slot order, or the parent's row after a binned resample)
+        u64 myrow = p;
+        if (perm && live) {
+            const uint32_t pr_ = perm[p];
+            myrow = res_parent[MP_SEG_POS(pr_ >> 10, p >> 10, pr_ & 1023u, nchunks)];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            const int src = 16 * g + li;                       // the lane that owns this column's particle
+            const u64 row = ((u64)(uint32_t)__shfl((int)(myrow >> 32), src, 64) << 32) | (u64)(uint32_t)__shfl((int)myrow, src, 64);
+            const bool live_i = __shfl((int)live, src, 64) != 0;
+            const int pl_i = wave * 256 + rd * 64 + src;
+            const u64 p_i = tile0 + (u64)pl_i;
+            mp_f64x4 mean = {0., 0., 0., 0.};
+            if (t != 0) {   // uniform
+                double xk[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xk[s] = live_i ? x_in[row * D + lg + 4 * s] : 0.;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) mean = __builtin_amdgcn_mfma_f64_16x16x4f64(amat[s], xk[s], mean, 0, 0, 0);
+            }
+            mp_f64x4 tz = {0., 0., 0., 0.};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) tz = __builtin_amdgcn_mfma_f64_16x16x4f64(tmat[s], s_z[wave][src][lg + 4 * s], tz, 0, 0, 0);
+            mp_f64x4 xn, c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xn[r] = tz[r] + mean[r];        // transform * z + mu
+                c[r] = yv[r] - xn[r];           // centered_x of the observation site
+            }
+            mp_f64x4 rj = {0., 0., 0., 0.};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) rj = __builtin_amdgcn_mfma_f64_16x16x4f64(rmat[s], c[s], rj, 0, 0, 0);
+            mp_f64x4 pq = {0., 0., 0., 0.};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) pq = __builtin_amdgcn_mfma_f64_16x16x4f64(rj[s], c[s], pq, 0, 0, 0);
+            // diagonal of pq = the Mahalanobis terms: element [i][i] sits in lane (i & 3) * 16 + i, register i >> 2
+            if (live_i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x_out[p_i * D + lg + 4 * r] = xn[r];
+            }
+            if (lg == (li & 3)) {
+                const int rr = li >> 2;
+                const double maha = rr == 0 ? pq[0] : rr == 1 ? pq[1] : rr == 2 ? pq[2] : pq[3];
+                const double gw = 0. + (-(lp_const + maha) / 2.);
+                double w = MP_NEG_INF;
+                if (live_i) {
+                    w = overwrite == 1 ? gw : (overwrite == 2 ? 0. + gw : logw[p_i] + gw);
+                    logw[p_i] = w;
+                }
+                s_lw[pl_i] = w;
+            }
+            if (lg == 0) s_x0[pl_i] = live_i ? xn[0] : 0.;
+        }
+        __builtin_amdgcn_wave_barrier();   // the next round overwrites this wave's z
+    }
+    __syncthreads();
+    double lw[TILE / DENSE_THREADS], xv[TILE / DENSE_THREADS];
+#pragma unroll
+    for (int j = 0; j < TILE / DENSE_THREADS; ++j) {
+        lw[j] = s_lw[tid * (TILE / DENSE_THREADS) + j];
+        xv[j] = s_x0[tid * (TILE / DENSE_THREADS) + j];
+    }
+    normalize_tile<DENSE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2, aux.tab);
+}
+
+// ---------------------------------------------------------------------------------------------
 // level 1: the tile table of a workgroup.  T_b = rint((double)W_b * mp_exp(m_b - m) * 2^(S-51)), inclusive prefix in
 // s_incl[nt], W_b in s_W[nt]; returns the global max m (every thread).  s_red needs THREADS/64 doubles, s_wtot
 // THREADS/64 u64.
