@@ -256,7 +256,7 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
  *   is_linear ~ bernoulli(0.7); coeffs = linear() | quadratic() (a, b[, c] ~ normal(0,1));
  *   y_i ~ normal(a + b x_i [+ c x_i^2], 0.1) observed.
  * Static site ids (the stand-in for trie addresses): */
-enum mp_mh_site { MP_SITE_IS_LINEAR = 0, MP_SITE_A = 1, MP_SITE_B = 2, MP_SITE_C = 3 };
+enum mp_mh_site { MP_SITE_IS_LINEAR = 0, MP_SITE_A = 1, MP_SITE_B = 2, MP_SITE_C = 3, MP_SITE_Y0 = 4 /* "(y, k)" = MP_SITE_Y0 + k */ };
 enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1, MP_MH_MODEL_POINTED_2D = 2 };
 enum mp_mh_proposal_kind {
     MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1, /* hierarchical_drift_proposal(tr, drift_std): hierarchical.rs:62-70; args = {drift_std} */
@@ -284,14 +284,20 @@ int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args,
 /* n_iters x `regen_mh(model, trace, mask)` per chain (mh.rs:54-75; DynGenFn::regenerate dyngenfn.rs:563-583).
  * mask_sites: subset of {MP_SITE_A, MP_SITE_B, MP_SITE_C} ("coeffs/a" ...).  cycle = 0: every iteration
  * masks all listed sites at once; cycle = 1: iteration k masks only mask_sites[k % n_mask].
- * Masking is_linear or passing an empty mask is MP_ERR_UNSUPPORTED: the reference either panics on the
- * quadratic->linear structure change (dyngenfn.rs:425,526-529) or re-simulates the observed sites (:571). */
+ * n_mask = 0 (empty mask): as in the reference the mask is then the trace's whole schema (dyngenfn.rs:571): every site —
+ * is_linear, the coefficients and the "(y, i)" sites that were observations — is redrawn, the weight is 0 and every move is
+ * accepted; from then on a chain's observations are part of its state (mp_mh_read_observations).
+ * Masking is_linear with a non-empty mask is MP_ERR_UNSUPPORTED: the reference panics on the quadratic->linear structure
+ * change (dyngenfn.rs:425,526-529). */
 int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted);
 /* Chain states -> out[n_chains][4] = {is_linear (0/1), a, b, c}  (c = 0 when is_linear: such a trace has no coeffs/c);
  * pointed model: out[n_chains][2]. */
 int32_t mp_mh_read_state(mp_mh* h, double* out);
 /* trace.logjp per chain, summed in site order (the reference's value is the trie's running weight: same to ~1e-15 rel). */
 int32_t mp_mh_read_logjp(mp_mh* h, double* out);
+/* The "(y, i)" choices of every chain's trace -> out[n_chains][n_data]: the data passed to mp_mh_create until an empty-mask
+ * regenerate re-simulated them (hierarchical model only). */
+int32_t mp_mh_read_observations(mp_mh* h, double* out);
 /* MH iterations applied so far (the Philox step of the next iteration is this + 1). */
 int32_t mp_mh_iterations(mp_mh* h, uint64_t* out);
 int32_t mp_mh_destroy(mp_mh* h);

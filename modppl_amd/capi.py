@@ -17,7 +17,7 @@ MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC, MP_RESAMPLE_STRATIFIED = 0, 1, 
 MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
 MP_PF_RECORD_HISTORY = 1
 MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER, MP_K_BIN_DRAWS = 0, 1, 2, 3
-MP_SITE_IS_LINEAR, MP_SITE_A, MP_SITE_B, MP_SITE_C = 0, 1, 2, 3
+MP_SITE_IS_LINEAR, MP_SITE_A, MP_SITE_B, MP_SITE_C, MP_SITE_Y0 = 0, 1, 2, 3, 4
 MP_MH_MODEL_HIERARCHICAL = 1
 MP_MH_MODEL_POINTED_2D = 2
 MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1
@@ -33,7 +33,7 @@ SYMBOLS = [
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
     "mp_pf_shard_owned_count", "mp_pf_shard_owned_expand", "mp_pf_shard_owned_commit",
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
-    "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_iterations", "mp_mh_destroy",
+    "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_read_observations", "mp_mh_iterations", "mp_mh_destroy",
     # include/modppl_hip_probe.h
     "mp_probe_math", "mp_probe_normal_sample", "mp_probe_u01", "mp_probe_mfma_f64", "mp_probe_mvnormal",
 ]
@@ -137,6 +137,7 @@ def load():
     L.mp_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
     L.mp_mh_read_state.argtypes = [p, dp]
     L.mp_mh_read_logjp.argtypes = [p, dp]
+    L.mp_mh_read_observations.argtypes = [p, dp]
     L.mp_mh_iterations.argtypes = [p, C.POINTER(u64)]
     L.mp_mh_destroy.argtypes = [p]
     L.mp_probe_math.argtypes = [i32, dp, dp, dp, i64, dp, i32]

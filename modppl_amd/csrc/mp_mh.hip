@@ -73,11 +73,19 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_init(u64 n, uint32_t k0, uint
 }
 
 // trace.logjp: sum of all choice log-densities in site order
-__global__ __launch_bounds__(MH_THREADS) void k_mh_logjp(u64 n, mh_data data, double ln_noise, const int* __restrict__ is_lin_in,
+// The "(y, i)" choices of a chain's trace: the handle's data until a regenerate with an empty mask re-simulated them
+// (ys_chain[i][k], dyngenfn.rs:571), per chain afterwards.
+__device__ __forceinline__ void mh_load_ys(const mh_data& data, const double* ys_chain, u64 i, double (&y)[MH_MAX_DATA]) {
+#pragma unroll
+    for (int k = 0; k < MH_MAX_DATA; ++k) y[k] = (k < data.n) ? (ys_chain ? ys_chain[i * (u64)data.n + k] : data.ys[k]) : 0.;
+}
+__global__ __launch_bounds__(MH_THREADS) void k_mh_logjp(u64 n, mh_data data_, double ln_noise, const int* __restrict__ is_lin_in,
                                                          const double* __restrict__ a_in, const double* __restrict__ b_in,
-                                                         const double* __restrict__ c_in, double* __restrict__ out) {
+                                                         const double* __restrict__ c_in, double* __restrict__ out, const double* __restrict__ ys_chain) {
     const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
     if (i >= n) return;
+    mh_data data = data_;
+    mh_load_ys(data_, ys_chain, i, data.ys);
     const bool is_lin = is_lin_in[i] != 0;
     const double a = a_in[i], b = b_in[i], c = c_in[i];
     double lj = mp_bernoulli_logpdf(is_lin, 0.7);
@@ -95,14 +103,61 @@ struct mh_mask {
 };
 
 // KIND: 0 regenerative MH, 1 MH with hierarchical_drift_proposal, 2 MH with add_or_remove_param_proposal
+// regenerative_metropolis_hastings with an EMPTY mask (mh.rs:54-67 -> dyngenfn.rs:563-583): `mask.is_leaf()` makes the mask
+// the trace's whole schema, so every site is visited masked — is_linear, the coeffs sub-call's a, b (, c), and the
+// "(y, i)" sites that were observations — removed and redrawn from its distribution; nothing unmasked is revisited, so
+// the weight is 0 and `ln u < 0` accepts every move.  A branch switch is fine here: the sub-call's mask is the OLD
+// sub-trace's schema; a vanished c is collected by gc, a new c finds no previous value and is simulated (:253-257).
+// The chain's observations become part of its state from then on (ys_chain).  Sites: is_linear 0, a 1, b 2, c 3, (y, k) 4 + k.
+__global__ __launch_bounds__(MH_THREADS) void k_mh_regenerate_all(u64 n, uint32_t k0, uint32_t k1, uint32_t iter0, int n_iters, mh_data data,
+                                                                  int* __restrict__ is_lin_io, double* __restrict__ a_io, double* __restrict__ b_io,
+                                                                  double* __restrict__ c_io, double* __restrict__ ys_chain,
+                                                                  u64* __restrict__ accepted_total) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    u64 acc = 0;
+    if (i < n && n_iters > 0) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i;
+        bool is_lin = false;
+        double a = 0., b = 0., c = 0.;
+        for (int it = 0; it < n_iters; ++it) {
+            s.step = iter0 + (uint32_t)it;
+            const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
+            if (!(mp_log(mp_u01(ub.a)) < 0.)) continue;   // mh.rs:62 with weight 0: never taken (u01 < 1); the trace of the LAST accepted move stays
+            ++acc;
+            if (it != n_iters - 1) continue;              // every site is redrawn from scratch: only the last move's draws survive
+            mp_site sl(s, MP_DOM_MODEL, MP_SITE_IS_LINEAR), sa(s, MP_DOM_MODEL, MP_SITE_A), sb(s, MP_DOM_MODEL, MP_SITE_B), sc(s, MP_DOM_MODEL, MP_SITE_C);
+            is_lin = mp_bernoulli_sample(sl, 0.7);
+            a = mp_normal_sample(sa, 0., 1.);
+            b = mp_normal_sample(sb, 0., 1.);
+            c = is_lin ? 0. : mp_normal_sample(sc, 0., 1.);
+            for (int k = 0; k < data.n; ++k) {
+                mp_site sy(s, MP_DOM_MODEL, (uint32_t)(MP_SITE_Y0 + k));
+                ys_chain[i * (u64)data.n + k] = mp_normal_sample(sy, mh_mean(is_lin, a, b, c, data.xs[k]), MH_NOISE);
+            }
+            is_lin_io[i] = is_lin ? 1 : 0;
+            a_io[i] = a; b_io[i] = b; c_io[i] = c;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(accepted_total, acc);
+}
+__global__ __launch_bounds__(MH_THREADS) void k_mh_broadcast_ys(u64 n, mh_data data, double* __restrict__ ys_chain) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < data.n; ++k) ys_chain[i * (u64)data.n + k] = data.ys[k];
+}
+
 template <int KIND>
 __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, uint32_t k1, uint32_t iter0, int n_iters, mh_data data,
                                                            double ln_noise, mh_mask mask, double drift_std, double ln_drift_std,
                                                            int* __restrict__ is_lin_io, double* __restrict__ a_io, double* __restrict__ b_io,
-                                                           double* __restrict__ c_io, u64* __restrict__ accepted_total) {
+                                                           double* __restrict__ c_io, u64* __restrict__ accepted_total,
+                                                           const double* __restrict__ ys_chain) {
     const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
     u64 acc = 0;
     if (i < n) {
+        mh_load_ys(data, ys_chain, i, data.ys);
         bool is_lin = is_lin_io[i] != 0;
         double a = a_io[i], b = b_io[i], c = c_io[i];
         double ly[MH_MAX_DATA];
@@ -336,6 +391,7 @@ struct mp_mh {
     int kind = MP_MH_MODEL_HIERARCHICAL;
     pointed_params pointed{};
     double* lat = nullptr;   // pointed model: [n][2]
+    double* ys_chain = nullptr;   // [n][n_data]: per-chain "(y, i)" choices once an empty-mask regenerate re-simulated them
 };
 
 extern "C" {
@@ -385,13 +441,13 @@ static int32_t mh_run(mp_mh* h, int kind, const mh_mask& mask, double drift_std,
     const double ln_ds = kind ? mp_log(drift_std) : 0.;
     if (kind == 2)
         hipLaunchKernelGGL(k_mh_iterate<2>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
-                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc);
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
     else if (kind == 1)
         hipLaunchKernelGGL(k_mh_iterate<1>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
-                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc);
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
     else
         hipLaunchKernelGGL(k_mh_iterate<0>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
-                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc);
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
     MHCK(hipGetLastError());
     h->iters += (u64)n_iters;
     if (accepted) {
@@ -480,8 +536,27 @@ int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args,
 int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
     if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
     if (h->kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_UNSUPPORTED, "regen_mh is compiled for the hierarchical model only");
-    if (n_mask < 1 || !mask_sites)
-        return mp_set_error(MP_ERR_UNSUPPORTED, "empty mask: the reference regenerates every site including the observed ones (dyngenfn.rs:571)");
+    if (n_mask < 0 || (n_mask > 0 && !mask_sites)) return mp_set_error(MP_ERR_INVALID_ARG, "bad mask");
+    if (n_mask == 0) {
+        // empty mask = the trace's whole schema (dyngenfn.rs:571): every site, the observed ones included, is redrawn
+        if (n_iters < 0) return mp_set_error(MP_ERR_INVALID_ARG, "n_iters < 0");
+        MHCK(hipSetDevice(h->device));
+        const unsigned grid = (unsigned)((h->n + MH_THREADS - 1) / MH_THREADS);
+        if (!h->ys_chain) {
+            MHCK(hipMalloc(&h->ys_chain, sizeof(double) * h->n * (size_t)h->data.n));
+            hipLaunchKernelGGL(k_mh_broadcast_ys, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, h->data, h->ys_chain);
+        }
+        MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64), h->stream));
+        hipLaunchKernelGGL(k_mh_regenerate_all, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
+                           (uint32_t)(h->iters + 1), n_iters, h->data, h->is_lin, h->a, h->b, h->c, h->ys_chain, h->d_acc);
+        MHCK(hipGetLastError());
+        h->iters += (u64)n_iters;
+        if (accepted) {
+            MHCK(hipMemcpyAsync(accepted, h->d_acc, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+            MHCK(hipStreamSynchronize(h->stream));
+        }
+        return MP_OK;
+    }
     if (n_mask > 3) return mp_set_error(MP_ERR_INVALID_ARG, "at most 3 mask sites");
     mh_mask m{};
     m.n = n_mask; m.cycle = cycle ? 1 : 0;
@@ -521,10 +596,24 @@ int32_t mp_mh_read_logjp(mp_mh* h, double* out) {
                            h->tmp);
     else
     hipLaunchKernelGGL(k_mh_logjp, dim3((unsigned)((h->n + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n, h->data, h->ln_noise,
-                       h->is_lin, h->a, h->b, h->c, h->tmp);
+                       h->is_lin, h->a, h->b, h->c, h->tmp, (const double*)h->ys_chain);
     MHCK(hipGetLastError());
     MHCK(hipMemcpyAsync(out, h->tmp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
     MHCK(hipStreamSynchronize(h->stream));
+    return MP_OK;
+}
+
+int32_t mp_mh_read_observations(mp_mh* h, double* out) {
+    if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
+    if (h->kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_UNSUPPORTED, "the hierarchical model's (y, i) choices");
+    MHCK(hipSetDevice(h->device));
+    if (h->ys_chain) {
+        MHCK(hipMemcpyAsync(out, h->ys_chain, sizeof(double) * h->n * (size_t)h->data.n, hipMemcpyDeviceToHost, h->stream));
+        MHCK(hipStreamSynchronize(h->stream));
+    } else {
+        for (u64 i = 0; i < h->n; ++i)
+            for (int k = 0; k < h->data.n; ++k) out[i * (u64)h->data.n + k] = h->data.ys[k];
+    }
     return MP_OK;
 }
 
@@ -539,7 +628,7 @@ int32_t mp_mh_destroy(mp_mh* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->is_lin); (void)hipFree(h->a); (void)hipFree(h->b); (void)hipFree(h->c); (void)hipFree(h->tmp); (void)hipFree(h->d_acc);
-    (void)hipFree(h->lat);
+    (void)hipFree(h->lat); (void)hipFree(h->ys_chain);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;

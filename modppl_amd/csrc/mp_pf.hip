@@ -1055,6 +1055,7 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     HIPCK(hipMalloc(&h->sh_lt, sizeof(u64) * h->n));
     HIPCK(hipMalloc(&h->sh_tile, sizeof(uint32_t) * h->n));
     HIPCK(hipMalloc(&h->sh_req_slot, sizeof(uint32_t) * slots));
+    HIPCK(hipMemsetAsync(h->sh_req_slot, 0, sizeof(uint32_t) * slots, h->stream));   // never an out-of-range row index, whatever path leaves it unwritten
     HIPCK(hipMalloc(&h->sh_blockcount, sizeof(uint32_t) * (size_t)nblk * world));
     HIPCK(hipMalloc(&h->sh_blockoff, sizeof(uint32_t) * (size_t)nblk * world));
     HIPCK(hipMalloc(&h->sh_counts, sizeof(long long) * SH_MAX_KEYS));
@@ -1160,6 +1161,10 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
         HIPCK(hipMemcpyAsync(h->scal, h->scal_undo, sizeof(mp_dev_scalars), hipMemcpyDeviceToDevice, h->stream));  // un-fold the log-ML increment
         return mp_fail(MP_ERR_CAPACITY, "sharded exchange: a sub-segment needs more than `capacity` draws; repeat with the variable-size phases");
     }
+    // all weights -inf: no rank owns a draw, the request slots were never written — nothing may be committed (the next
+    // propagate would read rows[inv[i]] out of bounds); the reference panics here (categorical.rs:23)
+    if (h->h_pub->degenerate)
+        return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
     // traces[i] = traces[parents[i]].clone() (particle_filter.rs:109-113), lazily: the next propagate reads slot i's state
     // from row sh_req_slot[i] of the exchange buffer; anything else first copies states and parents into slot order.
     h->sh_rows = d_rows_in;
@@ -1256,6 +1261,8 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
     HIPCK(hipEventSynchronize(h->ev_resolved));   // the one host wait, for the plan only: the rows may still be written / travelling
     if (counts_out)
         for (int r = 0; r < h->ow_world; ++r) counts_out[r] = h->h_pub->counts[r];
+    if (h->h_pub->degenerate)   // before anything is committed: with Q == 0 no rank owns a draw and the donor never writes its request slots
+        return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
     if (h->h_pub->overflow) {
         // a pair of ranks exchanges more than `capacity` rows (every rank reaches this verdict from the same counts): nothing
         // is committed; the own draws stay queued, the caller repeats the expand with exact sizes (capacity 0)

@@ -221,6 +221,7 @@ class HierarchicalChains:
         if xs.shape != ys.shape or xs.ndim != 1:
             raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "xs and ys must be 1-D arrays of equal length")
         self.num_chains = int(num_chains)
+        self._n_data = len(xs)
         c = -1 if constrain_is_linear is None else int(bool(constrain_is_linear))
         h = C.c_void_p()
         capi.check(self._L.mp_mh_create(capi.MP_MH_MODEL_HIERARCHICAL, _dptr(xs), _dptr(ys), len(xs), c, self.num_chains, int(seed), int(device),
@@ -257,6 +258,13 @@ class HierarchicalChains:
     def logjp(self):
         out = np.empty(self.num_chains)
         capi.check(self._L.mp_mh_read_logjp(self._h, _dptr(out)))
+        return out
+
+    def observations(self):
+        """[num_chains, n_data]: the "(y, i)" choices of every chain's trace (the data, until regen_mh with an empty mask
+        — the trace's whole schema, dyngenfn.rs:571 — re-simulated them)."""
+        out = np.empty((self.num_chains, self._n_data))
+        capi.check(self._L.mp_mh_read_observations(self._h, _dptr(out)))
         return out
 
     @property

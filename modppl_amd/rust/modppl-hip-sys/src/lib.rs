@@ -29,6 +29,7 @@ pub const MP_SITE_IS_LINEAR: i32 = 0;
 pub const MP_SITE_A: i32 = 1;
 pub const MP_SITE_B: i32 = 2;
 pub const MP_SITE_C: i32 = 3;
+pub const MP_SITE_Y0: i32 = 4;
 pub const MP_MH_PROPOSAL_HIERARCHICAL_DRIFT: i32 = 1;
 pub const MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE: i32 = 2;
 pub const MP_ESS_REFERENCE: i32 = 0;
@@ -109,6 +110,7 @@ extern "C" {
     pub fn mp_regen_mh_step(h: *mut mp_mh, mask_sites: *const i32, n_mask: i32, cycle: i32, n_iters: i32, accepted: *mut u64) -> i32;
     pub fn mp_mh_read_state(h: *mut mp_mh, out: *mut f64) -> i32;
     pub fn mp_mh_read_logjp(h: *mut mp_mh, out: *mut f64) -> i32;
+    pub fn mp_mh_read_observations(h: *mut mp_mh, out: *mut f64) -> i32;
     pub fn mp_mh_iterations(h: *mut mp_mh, out: *mut u64) -> i32;
     pub fn mp_mh_destroy(h: *mut mp_mh) -> i32;
 }

@@ -546,6 +546,12 @@ int32_t oracle_mh_read_state(oracle_mh* h, double* out) {
         }
     })
 }
+int32_t oracle_mh_read_observations(oracle_mh* h, int32_t n_data, double* out) {
+    GUARD({
+        for (size_t i = 0; i < h->traces.size(); ++i)
+            for (int k = 0; k < n_data; ++k) out[i * (size_t)n_data + k] = h->traces[i].data.read<double>("(y, " + std::to_string(k) + ")");
+    })
+}
 int32_t oracle_mh_read_logjp(oracle_mh* h, double* out) { GUARD({ for (size_t i = 0; i < h->traces.size(); ++i) out[i] = h->traces[i].logjp; }) }
 int32_t oracle_mh_destroy(oracle_mh* h) { delete h; return MP_OK; }
 

@@ -229,7 +229,10 @@ struct Hierarchical {
         if (a == "a" || a == "coeffs/a") return 1u;
         if (a == "b" || a == "coeffs/b") return 2u;
         if (a == "c" || a == "coeffs/c") return 3u;
-        return 4u;  // "(y, i)" — always constrained on this path
+        // "(y, i)" -> 4 + i: constrained everywhere except under a regenerate with an empty mask (= the whole schema,
+        // dyngenfn.rs:571), which redraws the observed sites too: each needs a stream of its own
+        const size_t c = a.find(", ");
+        return 4u + (c == std::string::npos ? 0u : (uint32_t)std::stoul(a.substr(c + 2)));
     }
     DynGenFn<int, CoefL> linear;        // Args = unit -> int 0
     DynGenFn<int, CoefQ> quadratic;

@@ -101,6 +101,7 @@ def load():
     L.oracle_regen_mh_step.argtypes = [p, C.POINTER(i32), i32, i32, i32, C.POINTER(u64)]
     L.oracle_mh_read_state.argtypes = [p, dp]
     L.oracle_mh_read_logjp.argtypes = [p, dp]
+    L.oracle_mh_read_observations.argtypes = [p, i32, dp]
     L.oracle_mh_destroy.argtypes = [p]
     L.oracle_mp_exp.argtypes = [dp, i64, dp]
     L.oracle_mp_log.argtypes = [dp, i64, dp]
@@ -327,6 +328,11 @@ class OracleMH:
     def logjp(self):
         out = np.empty(self.n)
         self._ck(self.L.oracle_mh_read_logjp(self.h, dptr(out)))
+        return out
+
+    def observations(self, n_data):
+        out = np.empty((self.n, n_data))
+        self._ck(self.L.oracle_mh_read_observations(self.h, n_data, dptr(out)))
         return out
 
     def __del__(self):

@@ -321,3 +321,26 @@ def test_owner_keeps_million_particles(world, n, cap):
         ref.step(obs[t:t + 1])
         assert np.array_equal(hip.cat(lambda e: e.log_weights()), ref.log_weights())
     assert hip.fallbacks == 0
+
+
+@pytest.mark.parametrize("exchange", ["owned", "exact"])
+def test_sharded_parents_survive_a_step(exchange):
+    """the sharded filters leave the parents in the exchange rows; a step consumes the states from there and the parents must
+    still be readable afterwards (world of one: equal to the single filter's)."""
+    import modppl_amd
+    from modppl_amd.distributed import ShardedParticleSystem
+    n, seed, T = 1 << 14, 6, 5
+    ys = O.lgssm_observations(T)
+    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    a = modppl_amd.ParticleSystem(model, n, seed)
+    b = ShardedParticleSystem(model, n, seed, exchange=exchange)
+    a.init_step(None, ys[:1])
+    b.init_step(None, ys[:1])
+    for t in range(1, T):
+        a.resample()
+        b.resample(sync=False)
+        want = a.parents.copy()
+        a.step(ys[t:t + 1])
+        b.step(ys[t:t + 1])
+        assert np.array_equal(b.parents, want), f"{exchange}: parents went stale at t={t}"
+    assert np.array_equal(a.states(), b.states())

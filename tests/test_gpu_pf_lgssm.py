@@ -140,3 +140,32 @@ def test_error_statuses():
     with pytest.raises(ModpplError) as e:
         pf.resample()
     assert e.value.code == capi.MP_ERR_DEGENERATE
+
+
+@pytest.mark.parametrize("d", [1, 4])
+def test_parents_survive_a_step_after_a_lazy_resample(d):
+    """particle_filter.rs:73-96 keeps `parents` across `step`; here a binned resample leaves them in segment order and the
+    next propagate consumes the states from there — the parents must still be the last resample's when asked for later."""
+    import modppl_amd
+
+    n, seed, T = 5000, 4, 5
+    if d == 1:
+        model, obs, kind, params = modppl_amd.lgssm_model(*O.LGSSM_PARAMS), O.lgssm_observations(T).reshape(T, 1), 1, O.LGSSM_PARAMS
+    else:
+        model, obs = modppl_amd.lgssm_band_model(d), np.random.default_rng(3).normal(0, 1.2, size=(T, d))
+        kind, params = 5, np.array([d, 0.9, 0.05, 1.0, 0.5, 1.0])
+    pf = modppl_amd.ParticleSystem(model, n, seed)
+    ref = O.OraclePF(kind, d, d, params, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    pf.init_step(None, obs[:1])
+    ref.init_step(obs[:1])
+    for t in range(1, T):
+        pf.resample(sync=False)          # nothing materialised
+        ref.resample()
+        want = ref.parents().copy()
+        pf.step(obs[t:t + 1])            # consumes the segment-ordered states
+        ref.step(obs[t:t + 1])
+        if t % 2:
+            pf.step(obs[t:t + 1])        # and a second step without a resample in between
+            ref.step(obs[t:t + 1])
+        assert np.array_equal(pf.parents, want), f"parents went stale at t={t}"
+        assert np.array_equal(pf.states(), ref.state())
