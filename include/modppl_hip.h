@@ -126,6 +126,9 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out);
 /* traces[i].retv (Vec<State>) rebuilt from the recorded ancestry -> out[t_steps][dim_state].
  * Needs MP_PF_RECORD_HISTORY. */
 int32_t mp_pf_read_trajectory(mp_pf* h, uint64_t i, double* out, int32_t* t_steps);
+/* The same for the particles first .. first + count - 1 at once (one kernel walks the recorded ancestry of all of them):
+ * out[count][t][dim_state].  tests/smc.rs:67 reads `retv` of every particle. */
+int32_t mp_pf_read_trajectories(mp_pf* h, uint64_t first, uint64_t count, double* out, int32_t* t_steps);
 /* Number of Unfold steps taken so far (trace.args.0). */
 int32_t mp_pf_time(mp_pf* h, int64_t* out);
 /* Whole filter in one call: init_step on obs[0], then for t=1..T-1 {step; resample} with a

@@ -28,7 +28,7 @@ MP_MH_PROPOSAL_POINTED_DRIFT = 3
 SYMBOLS = [
     "mp_last_error", "mp_device_count", "mp_pf_create", "mp_pf_init_step", "mp_pf_step", "mp_pf_effective_sample_size",
     "mp_pf_resample", "mp_pf_resample_if_ess_below", "mp_pf_log_marginal_likelihood_estimate", "mp_pf_read_state", "mp_pf_read_log_weights",
-    "mp_pf_read_parents", "mp_pf_read_trajectory", "mp_pf_time", "mp_pf_run", "mp_pf_synchronize", "mp_pf_destroy",
+    "mp_pf_read_parents", "mp_pf_read_trajectory", "mp_pf_read_trajectories", "mp_pf_time", "mp_pf_run", "mp_pf_synchronize", "mp_pf_destroy",
     "mp_pf_set_timing", "mp_pf_get_timing", "mp_unfold_simulate", "mp_importance_resampling",
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
     "mp_pf_shard_owned_count", "mp_pf_shard_owned_expand", "mp_pf_shard_owned_commit",
@@ -109,6 +109,7 @@ def load():
     L.mp_pf_read_log_weights.argtypes = [p, dp]
     L.mp_pf_read_parents.argtypes = [p, C.POINTER(u32)]
     L.mp_pf_read_trajectory.argtypes = [p, u64, dp, C.POINTER(i32)]
+    L.mp_pf_read_trajectories.argtypes = [p, u64, u64, dp, C.POINTER(i32)]
     L.mp_pf_time.argtypes = [p, C.POINTER(i64)]
     L.mp_pf_run.argtypes = [p, dp, dp, i32, i32]
     L.mp_pf_synchronize.argtypes = [p]

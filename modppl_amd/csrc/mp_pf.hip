@@ -423,6 +423,12 @@ struct mp_pf {
     // ancestry record (MP_PF_RECORD_HISTORY): the event log from which `traces[i].retv` is rebuilt
     struct HistEvent { int kind; void* buf; };  // kind 0: states after an Unfold step ([n][d] f64); 1: parents of a resample ([n] u32)
     std::vector<HistEvent> hist;
+    // the event buffers come out of slabs that grow geometrically, so a step or a resample does not call hipMalloc
+    std::vector<void*> hist_slabs;
+    unsigned char* hist_slab_cur = nullptr;
+    size_t hist_slab_left = 0, hist_slab_next = 0;
+    mp_hist_event* d_hist_events = nullptr;   // device copy of the log for k_trajectories
+    size_t d_hist_events_cap = 0;
     // host-side filter state
     long long t = 0;  // Unfold steps taken (trace.args.0)
     uint32_t resample_count = 0;
@@ -537,6 +543,25 @@ static int32_t materialize(mp_pf* h) {
     return check_launch("k_unpermute");
 }
 
+// a buffer of `bytes` for one history event, out of the current slab (a new slab is twice the last one, at least 8 events)
+static int32_t hist_alloc(mp_pf* h, size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (h->hist_slab_left < bytes) {
+        size_t want = h->hist_slab_next ? h->hist_slab_next : 8 * bytes;
+        if (want < bytes) want = bytes;
+        void* slab = nullptr;
+        HIPCK(hipMalloc(&slab, want));
+        h->hist_slabs.push_back(slab);
+        h->hist_slab_cur = static_cast<unsigned char*>(slab);
+        h->hist_slab_left = want;
+        h->hist_slab_next = 2 * want;
+    }
+    *out = h->hist_slab_cur;
+    h->hist_slab_cur += bytes;
+    h->hist_slab_left -= bytes;
+    return MP_OK;
+}
+
 static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs, bool overwrite) {
     PropagateArgs a;
     a.n = h->n; a.slot_offset = h->slot_offset;
@@ -578,9 +603,10 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     int32_t rc_ = check_launch("k_propagate");
     if (rc_ != MP_OK) return rc_;
     if (h->flags & MP_PF_RECORD_HISTORY) {
-        double* buf = nullptr;
+        void* buf = nullptr;
         const size_t bytes = sizeof(double) * h->n * (size_t)h->ops->dim_state;
-        HIPCK(hipMalloc(&buf, bytes));
+        int32_t rch = hist_alloc(h, bytes, &buf);
+        if (rch != MP_OK) return rch;
         HIPCK(hipMemcpyAsync(buf, h->x[h->cur], bytes, hipMemcpyDeviceToDevice, h->stream));
         h->hist.push_back({0, buf});
     }
@@ -828,8 +854,9 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (h->flags & MP_PF_RECORD_HISTORY) {
         rc = materialize(h);
         if (rc != MP_OK) return rc;
-        uint32_t* buf = nullptr;
-        HIPCK(hipMalloc(&buf, sizeof(uint32_t) * h->n));
+        void* buf = nullptr;
+        rc = hist_alloc(h, sizeof(uint32_t) * h->n, &buf);
+        if (rc != MP_OK) return rc;
         HIPCK(hipMemcpyAsync(buf, h->parent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToDevice, h->stream));
         h->hist.push_back({1, buf});
     }
@@ -1304,31 +1331,41 @@ int32_t mp_pf_shard_query_packed(mp_pf* h, const uint64_t* d_tiles_all, int32_t 
     return MP_OK;
 }
 
-int32_t mp_pf_read_trajectory(mp_pf* h, uint64_t i, double* out, int32_t* t_steps) {
+int32_t mp_pf_read_trajectories(mp_pf* h, uint64_t first, uint64_t count, double* out, int32_t* t_steps) {
     if (!h || !out || !t_steps) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (!(h->flags & MP_PF_RECORD_HISTORY)) return mp_fail(MP_ERR_STATE, "read_trajectory needs a filter created with MP_PF_RECORD_HISTORY");
     if (h->sharded) return mp_fail(MP_ERR_UNSUPPORTED, "read_trajectory: ancestors of a sharded filter live on other ranks");
-    if (i >= h->n) return mp_fail(MP_ERR_INVALID_ARG, "particle index out of range");
+    if (count == 0 || first >= h->n || count > h->n - first) return mp_fail(MP_ERR_INVALID_ARG, "particle range out of bounds");
     HIPCK(hipSetDevice(h->device));
-    HIPCK(hipStreamSynchronize(h->stream));
-    // walk the event log backwards: a resample maps slot -> parent slot (traces[i] = traces[parents[i]].clone(),
-    // particle_filter.rs:109-113); a step contributes the state of the current ancestor slot (retv.push, dynunfold.rs:58,92)
     const int d = h->ops->dim_state;
-    int t = (int)h->t;
-    uint64_t a = i;
-    for (size_t e = h->hist.size(); e-- > 0;) {
-        const auto& ev = h->hist[e];
-        if (ev.kind == 1) {
-            uint32_t p = 0;
-            HIPCK(hipMemcpy(&p, (const uint32_t*)ev.buf + a, sizeof(uint32_t), hipMemcpyDeviceToHost));
-            a = p;
-        } else {
-            --t;
-            HIPCK(hipMemcpy(out + (size_t)t * d, (const double*)ev.buf + (size_t)a * d, sizeof(double) * d, hipMemcpyDeviceToHost));
-        }
-    }
+    const int T = (int)h->t;
     *t_steps = (int32_t)h->t;
+    if (T == 0) return MP_OK;
+    // the event log as the kernel reads it
+    std::vector<mp_hist_event> ev(h->hist.size());
+    for (size_t e = 0; e < h->hist.size(); ++e) { ev[e].buf = h->hist[e].buf; ev[e].kind = h->hist[e].kind; ev[e].pad = 0; }
+    if (h->d_hist_events_cap < ev.size()) {
+        (void)hipFree(h->d_hist_events);
+        h->d_hist_events = nullptr;
+        h->d_hist_events_cap = std::max<size_t>(64, 2 * ev.size());
+        HIPCK(hipMalloc(&h->d_hist_events, sizeof(mp_hist_event) * h->d_hist_events_cap));
+    }
+    HIPCK(hipMemcpyAsync(h->d_hist_events, ev.data(), sizeof(mp_hist_event) * ev.size(), hipMemcpyHostToDevice, h->stream));
+    double* d_out = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)count * (size_t)T * (size_t)d;
+    HIPCK(hipMalloc(&d_out, bytes));
+    hipLaunchKernelGGL(k_trajectories, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, (u64)first, (u64)count, d, T, (int)ev.size(),
+                       (const mp_hist_event*)h->d_hist_events, d_out);
+    hipError_t e1 = hipGetLastError();
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(h->stream);   // (ev / d_out stay alive until here)
+    (void)hipFree(d_out);
+    if (e1 != hipSuccess) return mp_fail(MP_ERR_HIP, std::string("mp_pf_read_trajectories: ") + hipGetErrorString(e1));
     return MP_OK;
+}
+
+int32_t mp_pf_read_trajectory(mp_pf* h, uint64_t i, double* out, int32_t* t_steps) {
+    return mp_pf_read_trajectories(h, i, 1, out, t_steps);
 }
 
 int32_t mp_pf_time(mp_pf* h, int64_t* out) {
@@ -1389,7 +1426,8 @@ int32_t mp_pf_destroy(mp_pf* h) {
         (void)hipEventDestroy(tl.stop);
     }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
-    for (auto& ev : h->hist) (void)hipFree(ev.buf);
+    for (void* slab : h->hist_slabs) (void)hipFree(slab);
+    (void)hipFree(h->d_hist_events);
     (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->guide);
     (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->scal);
     (void)hipFree(h->aos);

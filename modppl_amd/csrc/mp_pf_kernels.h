@@ -1464,6 +1464,31 @@ __global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __r
     logw[i] = 0.;
 }
 
+// `traces[i].retv` for a range of particles at once (particle_filter.rs:13; tests/smc.rs:67 walks every particle): thread =
+// particle, walking the event log backwards — a resample maps slot -> parent slot (traces[i] = traces[parents[i]].clone(),
+// :109-113), a step contributes the state of the current ancestor slot (retv.push, dynunfold.rs:58,92).
+struct mp_hist_event {
+    const void* buf;   // kind 0: [n][d] f64 states after an Unfold step; kind 1: [n] u32 parents of a resample
+    int kind;
+    int pad;
+};
+__global__ void k_trajectories(u64 first, u64 count, int D, int T, int n_events, const mp_hist_event* __restrict__ ev, double* __restrict__ out) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    u64 a = first + j;
+    int t = T;
+    for (int e = n_events - 1; e >= 0; --e) {
+        if (ev[e].kind == 1) {
+            a = static_cast<const uint32_t*>(ev[e].buf)[a];
+        } else {
+            --t;
+            const double* src = static_cast<const double*>(ev[e].buf) + a * (u64)D;
+            double* dst = out + (j * (u64)T + (u64)t) * (u64)D;
+            for (int d = 0; d < D; ++d) dst[d] = src[d];
+        }
+    }
+}
+
 // Level 1 on its own (one workgroup): mode 1 = query (log_marginal_likelihood_estimate / fresh ESS), mode 0 = fold a
 // sharded resample, mode 2 = importance sampling (L and log_ml = L - ln N, importance.rs:21-22).
 __global__ __launch_bounds__(K3_THREADS) void k_finalize_tiles(const double* __restrict__ tile_m, const u64* __restrict__ tile_W,

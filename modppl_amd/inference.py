@@ -132,6 +132,16 @@ class ParticleSystem:
         capi.check(self._L.mp_pf_read_trajectory(self._h, int(i), _dptr(out), C.byref(t)))
         return out[: t.value]
 
+    def trajectories(self, first=0, count=None):
+        """traces[first .. first + count).retv at once: [count, t, dim_state] (one kernel walks all the lineages;
+        modppl/tests/smc.rs:67 reads every particle's)."""
+        count = self.num_particles - first if count is None else int(count)
+        T = max(self.time, 1)
+        out = np.empty((count, T, self.model.dim_state))
+        t = C.c_int32()
+        capi.check(self._L.mp_pf_read_trajectories(self._h, int(first), count, _dptr(out), C.byref(t)))
+        return out[:, : t.value]
+
     def set_timing(self, enabled):
         capi.check(self._L.mp_pf_set_timing(self._h, int(enabled)))
 

@@ -70,6 +70,7 @@ extern "C" {
     pub fn mp_pf_read_log_weights(h: *mut mp_pf, out: *mut f64) -> i32;
     pub fn mp_pf_read_parents(h: *mut mp_pf, out: *mut u32) -> i32;
     pub fn mp_pf_read_trajectory(h: *mut mp_pf, i: u64, out: *mut f64, t_steps: *mut i32) -> i32;
+    pub fn mp_pf_read_trajectories(h: *mut mp_pf, first: u64, count: u64, out: *mut f64, t_steps: *mut i32) -> i32;
     pub fn mp_pf_time(h: *mut mp_pf, out: *mut i64) -> i32;
     pub fn mp_pf_run(h: *mut mp_pf, args0: *const f64, obs: *const f64, n_steps: i32, scheme: i32) -> i32;
     pub fn mp_pf_synchronize(h: *mut mp_pf) -> i32;

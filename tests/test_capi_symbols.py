@@ -81,3 +81,92 @@ def test_rust_sys_crate_declares_every_entry_point():
     declared = set(re.findall(r"pub fn (mp_\w+)\(", src))
     wanted = {s for s in capi.SYMBOLS if not s.startswith("mp_probe")}
     assert wanted <= declared, sorted(wanted - declared)
+
+
+# ---- signatures, not just names: header <-> Rust -sys crate <-> ctypes binding ---------------------------------------------
+_C2RUST = {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "double": "f64", "void": "c_void", "char": "c_char",
+           "mp_pf": "mp_pf", "mp_mh": "mp_mh", "mp_model_desc": "mp_model_desc", "mp_shard": "mp_shard"}
+
+
+def _c_type_to_rust(t):
+    """`const double*` -> `*const f64`, `mp_pf**` -> `*mut *mut mp_pf`, `uint64_t` -> `u64`."""
+    import re
+
+    t = t.strip()
+    const = t.startswith("const ")
+    base = re.sub(r"^const\s+", "", t)
+    stars = base.count("*")
+    base = base.replace("*", "").strip()
+    r = _C2RUST[base]
+    for k in range(stars):
+        r = ("*const " if (const and k == 0) else "*mut ") + r
+    return r
+
+
+def _header_functions():
+    import re
+
+    src = open(os.path.join(ROOT, "include", "modppl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for ret, name, args in re.findall(r"^\s*((?:const\s+)?\w+\s*\*?)\s*(mp_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.M):
+        args = " ".join(args.split())
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                m = re.match(r"^(.*?)(\w+)$", a)       # type, then the parameter name
+                params.append(m.group(1).strip())
+        out[name] = (ret.strip(), params)
+    return out
+
+
+def test_rust_sys_signatures_match_the_header():
+    """argument count, order, width, signedness and constness of every entry point: the -sys crate is source only (no rustc in
+    the image), so its declarations are checked against include/modppl_hip.h textually."""
+    import re
+
+    hdr = _header_functions()
+    assert len(hdr) >= 40
+    src = open(os.path.join(ROOT, "modppl_amd", "rust", "modppl-hip-sys", "src", "lib.rs")).read()
+    rust = {}
+    for name, args, ret in re.findall(r"pub fn (mp_\w+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", src):
+        params = [" ".join(a.split(":", 1)[1].split()) for a in args.split(",") if ":" in a]
+        rust[name] = ((ret or "").strip(), params)
+    for name, (ret, params) in hdr.items():
+        assert name in rust, name
+        rret, rparams = rust[name]
+        assert rret == _c_type_to_rust(ret), (name, ret, rret)
+        assert rparams == [_c_type_to_rust(p) for p in params], (name, params, rparams)
+    # repr(C) struct layouts
+    for struct, fields in (("mp_model_desc", ["kind: i32", "dim_state: i32", "dim_obs: i32", "n_params: i32", "params: *const f64"]),
+                           ("mp_shard", ["n_global: u64", "slot_offset: u64"])):
+        body = re.search(r"#\[repr\(C\)\]\s*pub struct %s \{(.*?)\}" % struct, src, flags=re.S).group(1)
+        got = [" ".join(f.replace("pub ", "").split()) for f in body.split(",") if f.strip()]
+        assert got == fields, (struct, got)
+        cbody = re.search(r"typedef struct %s \{(.*?)\}" % struct, re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "modppl_hip.h")).read(), flags=re.S), flags=re.S).group(1)
+        cfields = [f.strip() for f in cbody.split(";") if f.strip()]
+        assert len(cfields) == len(fields)
+        for cf, rf in zip(cfields, fields):
+            m = re.match(r"^(.*?)(\w+)$", cf)
+            assert rf == f"{m.group(2)}: {_c_type_to_rust(m.group(1))}", (cf, rf)
+
+
+def test_ctypes_binding_matches_the_header():
+    """the ctypes argtypes (what every GPU test calls through) have the header's argument counts and widths"""
+    import ctypes as C
+
+    from modppl_amd import capi
+
+    L = capi.load()
+    width = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "double": C.c_double}
+    for name, (ret, params) in _header_functions().items():
+        fn = getattr(L, name)
+        if not params:
+            continue
+        assert fn.argtypes is not None and len(fn.argtypes) == len(params), (name, len(params), fn.argtypes)
+        for p, a in zip(params, fn.argtypes):
+            if "*" in p:
+                assert a in (C.c_void_p,) or issubclass(a, C._Pointer), (name, p, a)
+            else:
+                assert a is width[p.strip()], (name, p, a)
