@@ -183,3 +183,65 @@ impl HierarchicalChains {
 impl Drop for HierarchicalChains {
     fn drop(&mut self) { unsafe { sys::mp_mh_destroy(self.h); } }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The GenFn surface (modppl/src/gfi.rs:49-92), batched.
+//
+// `trait GenFn<Args, Data, Ret>` is per trace: `generate(&self, args, constraints) -> (Trace, f64)`.  A device library cannot
+// sit behind it — `ParticleSystem` calls it once per particle (particle_filter.rs:65,76), i.e. one launch per particle — so the
+// drop-in sits one level up (ParticleSystem, importance_*, mh / regen_mh above).  What CAN keep the trait's shape is its
+// batched counterpart: the same five methods with the same argument meaning, over N traces that live on the device.
+// `DeviceTraces` plays `Trace<(i64, State), Vec<DynTrie>, Vec<State>>` for all N at once; `UnfoldModel` implements it the
+// way `DynUnfold` implements `GenFn` (dynunfold.rs:22-100): `update` accepts `ArgDiff::Extend` only, `regenerate` keeps the
+// trait's default panic (gfi.rs:66-73), `propose` / `assess` are the trait's provided methods.
+// ---------------------------------------------------------------------------------------------------------------------
+pub enum ArgDiff { NoChange, Unknown, Extend }   // gfi.rs:25-31
+
+/// N traces of an Unfold model on the device: `args.0` steps taken, choices = the states, `retv.last()` readable.
+pub struct DeviceTraces { pf: ParticleSystem, log_weights: Vec<f64> }
+
+impl DeviceTraces {
+    pub fn num_traces(&self) -> usize { self.pf.num_particles }
+    /// `traces[i].retv.last()` for every i, particle-major
+    pub fn last_states(&self) -> Vec<f64> { self.pf.states() }
+    /// hand the traces to the particle filter API (they ARE a `ParticleSystem`'s `traces` field)
+    pub fn into_particle_system(self) -> ParticleSystem { self.pf }
+}
+
+pub trait BatchedGenFn {
+    /// `simulate(args)`: N x `GenFn::simulate((t, state0))` — every site sampled, the observation sites too (dynunfold.rs:22-39).
+    /// Returns (states [n][t][dim_state], observations [n][t][dim_obs]).
+    fn simulate(&self, n: usize, seed: u64, t: usize, state0: &[f64]) -> (Vec<f64>, Vec<f64>);
+    /// `generate(args, constraints)`: N x `GenFn::generate((t, state0), constraints)` -> (traces, weights) (dynunfold.rs:41-64)
+    fn generate(&self, n: usize, seed: u64, state0: &[f64], constraints: &[f64]) -> (DeviceTraces, Vec<f64>);
+    /// `update(trace, args, ArgDiff::Extend, constraints)` -> (traces, discard = (), incremental weights) (dynunfold.rs:66-100)
+    fn update(&self, traces: DeviceTraces, diff: ArgDiff, constraints: &[f64]) -> (DeviceTraces, (), Vec<f64>);
+    /// gfi.rs:66-73: the default panics, and `DynUnfold` does not override it
+    fn regenerate(&self, _traces: DeviceTraces, _diff: ArgDiff, _mask: &[i32]) -> (DeviceTraces, Vec<f64>) {
+        panic!("regenerate: not implemented for Unfold models (gfi.rs:66-73 default)")
+    }
+    /// gfi.rs:81-84: `propose` = simulate -> (choices, logjp); an Unfold trace's logjp is 0 in the reference (dynunfold.rs:51,60)
+    fn propose(&self, n: usize, seed: u64, t: usize, state0: &[f64]) -> ((Vec<f64>, Vec<f64>), Vec<f64>) {
+        (self.simulate(n, seed, t, state0), vec![0.0; n])
+    }
+    /// gfi.rs:87-90: `assess` = generate(..).1
+    fn assess(&self, n: usize, seed: u64, state0: &[f64], constraints: &[f64]) -> Vec<f64> { self.generate(n, seed, state0, constraints).1 }
+}
+
+impl BatchedGenFn for UnfoldModel {
+    fn simulate(&self, n: usize, seed: u64, t: usize, state0: &[f64]) -> (Vec<f64>, Vec<f64>) { simulate(self, state0, t, n, seed) }
+    fn generate(&self, n: usize, seed: u64, state0: &[f64], constraints: &[f64]) -> (DeviceTraces, Vec<f64>) {
+        let mut pf = ParticleSystem::new(self.clone(), n, seed);
+        pf.init_step(state0, constraints);                    // N x generate over all the steps the constraints cover
+        let w = pf.log_weights();
+        (DeviceTraces { pf, log_weights: w.clone() }, w)
+    }
+    fn update(&self, traces: DeviceTraces, diff: ArgDiff, constraints: &[f64]) -> (DeviceTraces, (), Vec<f64>) {
+        match diff { ArgDiff::Extend => {}, _ => panic!("update: only ArgDiff::Extend is supported (dynunfold.rs:72)") }
+        let before = traces.log_weights;
+        let pf = traces.pf.step(constraints);
+        let after = pf.log_weights();
+        let inc: Vec<f64> = after.iter().zip(before.iter()).map(|(a, b)| a - b).collect();
+        (DeviceTraces { pf, log_weights: after }, (), inc)
+    }
+}
