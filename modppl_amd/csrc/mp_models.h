@@ -47,6 +47,13 @@ struct mp_generate_handler {
     MP_HD mp_generate_handler(const mp_stream& r, const double* o, const double* pz_ = nullptr)
         : rng(r), obs(o), pz(pz_), weight(0.) {}
 
+    // transcendental functions of a model body go through the handler, so that the CPU checker's interpretation of the same
+    // functor can apply its own arithmetic mode (oracle/src/functor_adapter.hpp)
+    MP_HD double exp_(double x) const { return mp_exp(x); }
+    MP_HD double log_(double x) const { return mp_log(x); }
+    MP_HD double sin_(double x) const { return mp_sin(x); }
+    MP_HD double cos_(double x) const { return mp_cos(x); }
+    MP_HD double atan2_(double y, double x) const { return mp_atan2(y, x); }
     // ln_sd: mp_log(sd) when the caller has it hoisted (a model constant), else NaN -> computed here
     template <int SITE>
     MP_HD double normal(double mu, double sd, double ln_sd) {
@@ -134,6 +141,11 @@ struct mp_simulate_handler {
     mp_stream rng;
     double* obs_out;
     MP_HD mp_simulate_handler(const mp_stream& r, double* o) : rng(r), obs_out(o) {}
+    MP_HD double exp_(double x) const { return mp_exp(x); }
+    MP_HD double log_(double x) const { return mp_log(x); }
+    MP_HD double sin_(double x) const { return mp_sin(x); }
+    MP_HD double cos_(double x) const { return mp_cos(x); }
+    MP_HD double atan2_(double y, double x) const { return mp_atan2(y, x); }
 
     template <int SITE>
     MP_HD double normal(double mu, double sd, double /*ln_sd*/) {
@@ -245,7 +257,7 @@ struct mp_spiral {
             pol0 = prev[0] + dr;
             pol1 = prev[1] + dtheta;
         }
-        const double pos[2] = {pol0 * mp_cos(pol1), pol0 * mp_sin(pol1)};
+        const double pos[2] = {pol0 * g.cos_(pol1), pol0 * g.sin_(pol1)};
         g.template mvnormal_observed<OBS, 2>(pos, cov_inv, ln_det, chol);
         next[0] = pol0;
         next[1] = pol1;
@@ -319,7 +331,7 @@ struct mp_bearings {
             vx = prev[2] + ax;
             vy = prev[3] + ay;
         }
-        g.template normal<THETA>(mp_atan2(py, px), sig_theta, ln_sig_theta);
+        g.template normal<THETA>(g.atan2_(py, px), sig_theta, ln_sig_theta);
         next[0] = px; next[1] = py; next[2] = vx; next[3] = vy;
     }
 };
@@ -453,3 +465,18 @@ struct mp_line {
         next[1] = intercept;
     }
 };
+
+// ---------------------------------------------------------------------------------------
+// Registration layer (f3: one model source).  A translation unit that wants the models registered defines
+// MP_MODEL_REGISTRAR to the name of a function template `template <class M> int R(int kind, bool (*parse)(const
+// mp_model_desc&, M&, std::string&))` before including this header: mp_pf.hip registers a device factory (ModelOpsT<M>),
+// the CPU checker its two interpretations of the same functor.  Everywhere else the macro expands to nothing.
+// ---------------------------------------------------------------------------------------
+// (active in the device pass too: the registrar's instantiation is what makes hipcc emit the model's kernels there)
+#include <string>
+#if defined(MP_MODEL_REGISTRAR)
+#define MP_REGISTER_UNFOLD_MODEL(KIND, TYPE, PARSE) static const int mp_registered_##TYPE = MP_MODEL_REGISTRAR<TYPE>(KIND, PARSE);
+#else
+#define MP_REGISTER_UNFOLD_MODEL(KIND, TYPE, PARSE)
+#endif
+#include "mp_models_extra.h"

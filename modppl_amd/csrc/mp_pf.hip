@@ -36,6 +36,10 @@
 
 #include "../../include/modppl_hip.h"
 #include "mp_linalg.h"
+// models register themselves (mp_models.h, MP_REGISTER_UNFOLD_MODEL): here a registration creates the device factory
+template <class M>
+int mp_register_model_hip(int kind, bool (*parse)(const mp_model_desc&, M&, std::string&));
+#define MP_MODEL_REGISTRAR mp_register_model_hip
 #include "mp_models.h"
 
 typedef unsigned long long u64;
@@ -191,6 +195,25 @@ struct ModelOpsT : ModelOps {
     }
 };
 
+// kind -> factory of the registered models
+#include <functional>
+#include <map>
+static std::map<int, std::function<int32_t(const mp_model_desc*, std::unique_ptr<ModelOps>&)>>& model_registry() {
+    static std::map<int, std::function<int32_t(const mp_model_desc*, std::unique_ptr<ModelOps>&)>> r;
+    return r;
+}
+template <class M>
+int mp_register_model_hip(int kind, bool (*parse)(const mp_model_desc&, M&, std::string&)) {
+    model_registry()[kind] = [parse](const mp_model_desc* m, std::unique_ptr<ModelOps>& out) -> int32_t {
+        M k{};
+        std::string err;
+        if (!parse(*m, k, err)) return mp_fail(MP_ERR_INVALID_ARG, err);
+        out.reset(new ModelOpsT<M>(k));   // instantiates k_propagate / k_simulate / the resample kernels for M
+        return MP_OK;
+    };
+    return kind;
+}
+
 static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out) {
     if (!m) return mp_fail(MP_ERR_INVALID_ARG, "model descriptor is null");
     switch (m->kind) {
@@ -329,8 +352,11 @@ static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out
         out.reset(ops);
         return MP_OK;
     }
-    default:
+    default: {
+        auto it = model_registry().find(m->kind);   // models added through MP_REGISTER_UNFOLD_MODEL (mp_models_extra.h)
+        if (it != model_registry().end()) return it->second(m, out);
         return mp_fail(MP_ERR_UNSUPPORTED, "model kind " + std::to_string(m->kind) + " is not compiled into this library");
+    }
     }
 }
 

@@ -79,3 +79,12 @@ def lgssm_dense_model(A, Q, R, sig0=1.0):
     D = A.shape[0]
     assert A.shape == Q.shape == R.shape == (D, D)
     return UnfoldModel(capi.MP_MODEL_LGSSM_DENSE, D, D, np.concatenate([[D, sig0], A.reshape(-1), Q.reshape(-1), R.reshape(-1)]), f"lgssm_dense{D}")
+
+
+MP_MODEL_STOCHVOL = 100   # registered through MP_REGISTER_UNFOLD_MODEL (modppl_amd/csrc/mp_models_extra.h)
+
+
+def stochastic_volatility_model(mu=-1.0, phi=0.95, sigma=0.25, sig0=0.8):
+    """Stochastic volatility: h_0 ~ normal(mu, sig0); h_t ~ normal(mu + phi (h_{t-1} - mu), sigma); y_t ~ normal(0, exp(h_t / 2))
+    observed.  The example model of the registration layer: its whole definition is one block of mp_models_extra.h."""
+    return UnfoldModel(MP_MODEL_STOCHVOL, 1, 1, [mu, phi, sigma, sig0], "stochvol")

@@ -245,3 +245,26 @@ impl BatchedGenFn for UnfoldModel {
         (DeviceTraces { pf, log_weights: after }, (), inc)
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// `dyngen!` on this path (sketch, source only).  modppl's proc-macro (modppl-macros/src/lib.rs:20-113) rewrites
+// `dist(args) %= addr` into `__g.sample_at(&dist, (args), addr)` inside a closure over the dynamic handler; a closure cannot
+// cross to the GPU, so here a model body lives ONCE as a C++ functor (`g.template normal<SITE>(mu, sd)`: the same rewrite,
+// with the address turned into a compile-time site id) in modppl_amd/csrc/mp_models_extra.h, where
+// `MP_REGISTER_UNFOLD_MODEL(kind, Type, parse)` makes it known to the device library AND to the CPU checker.  What the Rust
+// side needs per model is only its descriptor; this macro declares one, so that a new model is one block of C++ plus:
+//
+//     unfold_model!(stochastic_volatility, kind = 100, dim_state = 1, dim_obs = 1, params = [mu, phi, sigma, sig0]);
+//     let m = UnfoldModel::stochastic_volatility(-1.0, 0.95, 0.25, 0.8);
+// ---------------------------------------------------------------------------------------------------------------------
+#[macro_export]
+macro_rules! unfold_model {
+    ($name:ident, kind = $kind:expr, dim_state = $ds:expr, dim_obs = $dobs:expr, params = [$($p:ident),*]) => {
+        impl $crate::UnfoldModel {
+            pub fn $name($($p: f64),*) -> Self {
+                $crate::UnfoldModel { kind: $kind, dim_state: $ds, dim_obs: $dobs, params: vec![$($p),*] }
+            }
+        }
+    };
+}
+unfold_model!(stochastic_volatility, kind = 100, dim_state = 1, dim_obs = 1, params = [mu, phi, sigma, sig0]);

@@ -15,6 +15,7 @@
 
 #include "../../include/modppl_hip.h"
 #include "soa.hpp"
+#include "functor_adapter.hpp"
 
 using namespace oracle;
 
@@ -208,6 +209,8 @@ int32_t oracle_pf_create(const mp_model_desc* m, uint64_t n, uint64_t seed, cons
                 e->model = std::make_unique<SoaLgssmDense>(D, m->params[1], Mat(D, std::vector<double>(q, q + D * D)),
                                                            Mat(D, std::vector<double>(q + D * D, q + 2 * D * D)),
                                                            Mat(D, std::vector<double>(q + 2 * D * D, q + 3 * D * D)));
+            } else if (functor_registry().count(m->kind)) {
+                e->model = functor_registry()[m->kind].soa(*m);   // the product's model functor, the checker's handlers and distributions
             } else throw Panic("unsupported model kind for the SoA engine");
             e->pf = std::make_unique<SoaPf>(e->model.get(), (size_t)n, seed, canon, shard ? shard->n_global : 0, shard ? shard->slot_offset : 0);
             h->impl = std::move(e);
@@ -277,6 +280,19 @@ int32_t oracle_pf_create(const mp_model_desc* m, uint64_t n, uint64_t seed, cons
             } else if (m->kind == MP_MODEL_HMM) {
                 auto e = std::make_unique<HmmPf>(hmm_from_params(m->params, m->n_params));
                 e->ps = std::make_unique<HmmPf::PS>(e->model, (size_t)n, seed);
+                e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
+                h->impl = std::move(e);
+            } else if (functor_registry().count(m->kind)) {
+                // the product's model functor interpreted by the dynamic handler: one sample_at per site, tries and all
+                const FunctorEntry& fe = functor_registry()[m->kind];
+                auto e = std::make_unique<DynPf<Vec>>();
+                const int d = fe.dim_state, dobs = fe.dim_obs;
+                e->model = fe.dyn(*m);
+                e->dim_state = d; e->dim_obs = dobs;
+                e->mk_constraints = fe.constraints;
+                e->mk_state = [d](const double* a) { Vec v((size_t)d, 0.); if (a) for (int j = 0; j < d; ++j) v[(size_t)j] = a[j]; return v; };
+                e->put_state = [d](const Vec& s_, double* o) { for (int j = 0; j < d; ++j) o[j] = s_[(size_t)j]; };
+                e->ps = std::make_unique<DynPf<Vec>::PS>(e->model, (size_t)n, seed);
                 e->ps->canonical_resampling = canon; e->ps->fast_search = fast;
                 h->impl = std::move(e);
             } else throw Panic("unsupported model kind");
@@ -465,6 +481,22 @@ int32_t oracle_unfold_simulate(const mp_model_desc* m, const double* args0, int3
             auto model = make_line_unfold(Vec(m->params, m->params + dobs));
             run(model, vec_state(2), vec_put(2),
                 [dobs](const DynTrie& c, double* o) { for (int j = 0; j < dobs; ++j) o[j] = c.search("ys") ? c.read<double>("ys/" + std::to_string(j)) : 0.; }, 2, dobs);
+        } else if (functor_registry().count(m->kind)) {
+            // a registered functor model, Simulate mode of the dynamic handler; observed sites read back by their obs slot
+            const FunctorEntry& fe = functor_registry()[m->kind];
+            auto model = fe.dyn(*m);
+            const int d = fe.dim_state, dobs = fe.dim_obs;
+            const DynTrie probe = fe.constraints(std::vector<double>((size_t)dobs, 0.).data());   // the observed sites' addresses
+            std::vector<std::string> addr((size_t)dobs);
+            for (int site = 0; site < 64; ++site)
+                if (probe.search(functor_addr(site))) {
+                    // which slot: the site whose constraint carries y[k] — functor_constraints fills slots in obs_of order
+                    std::vector<double> mark((size_t)dobs);
+                    for (int k = 0; k < dobs; ++k) mark[(size_t)k] = (double)(k + 1);
+                    addr[(size_t)(fe.constraints(mark.data()).read<double>(functor_addr(site)) - 1.)] = functor_addr(site);
+                }
+            run(model, vec_state(d), vec_put(d),
+                [dobs, addr](const DynTrie& c, double* o) { for (int k = 0; k < dobs; ++k) o[k] = c.read<double>(addr[(size_t)k]); }, d, dobs);
         } else throw Panic("simulate: unsupported model kind");
     })
 }

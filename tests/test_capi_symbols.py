@@ -170,3 +170,39 @@ def test_ctypes_binding_matches_the_header():
                 assert a in (C.c_void_p,) or issubclass(a, C._Pointer), (name, p, a)
             else:
                 assert a is width[p.strip()], (name, p, a)
+
+
+def test_every_host_kernel_stub_has_device_code(tmp_path):
+    """each `__device_stub__<kernel>` the host side can launch has a gfx950 kernel of that name in the library's code objects
+    (a template instantiated only in the host pass links, loads, and aborts at its first launch with "Cannot find Symbol")"""
+    import subprocess
+
+    from modppl_amd import build
+
+    lib = build.build()
+    nm = subprocess.run(["nm", "-C", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    raw = subprocess.run(["nm", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    stubs = set()
+    for ln in raw.splitlines():
+        m = re.match(r"_Z(\d+)__device_stub__(.*)", ln.split()[-1])   # _Z<len>__device_stub__<name><args> -> _Z<len-15><name><args>
+        if m:
+            stubs.add("_Z%d%s" % (int(m.group(1)) - len("__device_stub__"), m.group(2)))
+    assert len(stubs) > 40 and nm
+    fat = tmp_path / "fat.bin"
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, str(fat)], check=True)
+    blob = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(magic, blob)]
+    assert starts
+    device = set()
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    for i, s in enumerate(starts):
+        part = tmp_path / ("bundle%d.bin" % i)
+        part.write_bytes(blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = tmp_path / ("dev%d.co" % i)
+        subprocess.run([bundler, "--unbundle", "--type=o", "--input=" + str(part), "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--output=" + str(co)], check=True)
+        syms = subprocess.run(["readelf", "-sW", str(co)], capture_output=True, text=True, check=True).stdout
+        device |= {ln.split()[-1] for ln in syms.splitlines() if " FUNC " in ln}
+    missing = sorted(stubs - device)
+    assert not missing, "host stubs without device code: %s" % missing[:5]
