@@ -196,6 +196,7 @@ struct ModelOpsT : ModelOps {
 };
 
 // kind -> factory of the registered models
+#include <atomic>
 #include <functional>
 #include <map>
 static std::map<int, std::function<int32_t(const mp_model_desc*, std::unique_ptr<ModelOps>&)>>& model_registry() {
@@ -438,13 +439,24 @@ struct mp_pf {
     u64 sh_rows_cap = 0;
     bool logw_zero = false;         // log-weights are all zero (after a sharded resample) and the buffer has not been cleared
     mp_dev_scalars* scal_undo = nullptr;  // the scalars before a fixed-capacity route folded this resample in
-    u64* ow_gq = nullptr;                 // "owner keeps" form: own targets of every k_shard_own_draws workgroup [ow_nblk][SHO_CHUNK]
-    uint32_t* ow_wgcnt = nullptr;         // own draws per workgroup, and their exclusive scan
+    // "owner keeps" form: per super-chunk of R * 1024 draws a window of entries (k_shard_own_bin), [ow_nsc][R * 1024]
+    u64* ow_seg_lt = nullptr;             // tile-local target
+    uint32_t* ow_seg_row = nullptr;       // start row of the forward scan
+    unsigned short* ow_seg_r = nullptr;   // draw-order rank inside the super-chunk
+    unsigned short* ow_permc = nullptr;   // draw-order rank -> place in the window
+    unsigned short* ow_seg_cnt = nullptr; // [ow_nsc][8] entries per bin
+    uint32_t* ow_sccnt = nullptr;         // own draws per super-chunk, and their exclusive scan
     uint32_t* ow_base = nullptr;
+    uint32_t* ow_cnt_r = nullptr;         // [ow_nsc][world] offspring per rank (multinomial)
     unsigned long long* ow_call = nullptr;   // offspring per rank [SH_MAX_WORLD]
     mp_owned_plan* ow_plan = nullptr;
-    int ow_nblk = 0;
+    mp_own_range* ow_range = nullptr;
+    unsigned int* ow_ticket = nullptr;
+    u64 ow_last_cap = 0;                  // capacity of the last mp_pf_shard_owned_expand (0 = exact sizes: nothing can overflow)
+    unsigned long long ow_seq = 0;        // owner-keeps resamples planned so far: the plan of number k writes pub->seq = k last
+    int ow_nsc = 0, ow_R = 0;
     int ow_world = 0;
+    int ow_scheme = 0;
     bool sharded = false;
     // ancestry record (MP_PF_RECORD_HISTORY): the event log from which `traces[i].retv` is rebuilt
     struct HistEvent { int kind; void* buf; };  // kind 0: states after an Unfold step ([n][d] f64); 1: parents of a resample ([n] u32)
@@ -1237,15 +1249,72 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
 }
 
 // ---- "owner keeps" form: offspring stay with the rank that owns their parent; only the surplus travels ----
-static int32_t owned_scratch(mp_pf* h) {
-    if (h->ow_gq) return MP_OK;
-    h->ow_nblk = (int)((h->n_global + SHO_CHUNK - 1) / SHO_CHUNK);
-    HIPCK(hipMalloc(&h->ow_gq, sizeof(u64) * (size_t)h->ow_nblk * SHO_CHUNK));
-    HIPCK(hipMalloc(&h->ow_wgcnt, sizeof(uint32_t) * (size_t)h->ow_nblk));
-    HIPCK(hipMalloc(&h->ow_base, sizeof(uint32_t) * (size_t)h->ow_nblk));
+static void owned_free(mp_pf* h) {
+    (void)hipFree(h->ow_seg_lt); (void)hipFree(h->ow_seg_row); (void)hipFree(h->ow_seg_r); (void)hipFree(h->ow_permc); (void)hipFree(h->ow_seg_cnt);
+    (void)hipFree(h->ow_sccnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_cnt_r); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
+    (void)hipFree(h->ow_range); (void)hipFree(h->ow_ticket);
+    h->ow_ticket = nullptr;
+    h->ow_seg_lt = nullptr; h->ow_seg_row = nullptr; h->ow_seg_r = nullptr; h->ow_permc = nullptr; h->ow_seg_cnt = nullptr;
+    h->ow_sccnt = nullptr; h->ow_base = nullptr; h->ow_cnt_r = nullptr; h->ow_call = nullptr; h->ow_plan = nullptr; h->ow_range = nullptr;
+}
+// super-chunk shape of one resample: the multinomial draws of a rank are spread over all N draws, so a workgroup takes
+// min(world, 4) rounds of 1024 to collect ~1024 own ones; under a lattice scheme a rank's own draws are one contiguous range
+static void owned_shape(mp_pf* h, int world, int scheme) {
+    h->ow_R = scheme ? 1 : mp_own_rounds(world);
+    const u64 Wd = (u64)h->ow_R * OWN_ROUND;
+    h->ow_nsc = (int)((h->n_global + Wd - 1) / Wd);
+}
+static int32_t owned_scratch(mp_pf* h, int world) {
+    if (h->ow_seg_lt && h->ow_world == world) return MP_OK;
+    if (h->ow_seg_lt) {
+        HIPCK(hipStreamSynchronize(h->stream));
+        owned_free(h);
+    }
+    // Windows cover every draw of the job (a rank may own any of them), touched only where this rank owns draws:
+    // 16 B x n_global of address space per rank, ~16 B x n_local of it used per resample.
+    // (sized for single-round super-chunks, the most there can be; owned_shape() picks the rounds per resampling scheme)
+    const int nsc1 = (int)((h->n_global + OWN_ROUND - 1) / OWN_ROUND);
+    const size_t ent = (size_t)nsc1 * OWN_ROUND;
+    h->ow_nsc = nsc1;
+    HIPCK(hipMalloc(&h->ow_seg_lt, sizeof(u64) * ent));
+    HIPCK(hipMalloc(&h->ow_seg_row, sizeof(uint32_t) * ent));
+    HIPCK(hipMalloc(&h->ow_seg_r, sizeof(unsigned short) * ent));
+    HIPCK(hipMalloc(&h->ow_permc, sizeof(unsigned short) * ent));
+    HIPCK(hipMalloc(&h->ow_seg_cnt, sizeof(unsigned short) * 8 * (size_t)h->ow_nsc));
+    HIPCK(hipMalloc(&h->ow_sccnt, sizeof(uint32_t) * (size_t)h->ow_nsc));
+    HIPCK(hipMalloc(&h->ow_base, sizeof(uint32_t) * (size_t)h->ow_nsc));
+    HIPCK(hipMalloc(&h->ow_cnt_r, sizeof(uint32_t) * (size_t)h->ow_nsc * world));
     HIPCK(hipMalloc(&h->ow_call, sizeof(unsigned long long) * SH_MAX_WORLD));
     HIPCK(hipMalloc(&h->ow_plan, sizeof(mp_owned_plan)));
+    HIPCK(hipMalloc(&h->ow_range, sizeof(mp_own_range)));
+    HIPCK(hipMalloc(&h->ow_ticket, sizeof(unsigned int)));
+    HIPCK(hipMemsetAsync(h->ow_ticket, 0, sizeof(unsigned int), h->stream));
+    // rows of entries never written are still read (masked) by idle lanes of k_shard_own_resolve: keep them valid row indices
+    HIPCK(hipMemsetAsync(h->ow_seg_row, 0, sizeof(uint32_t) * ent, h->stream));
+    HIPCK(hipMemsetAsync(h->ow_seg_r, 0, sizeof(unsigned short) * ent, h->stream));
+    HIPCK(hipMemsetAsync(h->ow_seg_lt, 0, sizeof(u64) * ent, h->stream));
+    HIPCK(hipMemsetAsync(h->ow_call, 0, sizeof(unsigned long long) * SH_MAX_WORLD, h->stream));
+    h->ow_world = world;
     return MP_OK;
+}
+
+// The host's one wait per owner-keeps resample: until the plan of resample number ow_seq has written its verdict word
+// (host-mapped memory, polled: no event, so no end-of-kernel cache write-back in the stream and no driver wake-up latency).
+static int32_t owned_wait_plan(mp_pf* h, unsigned* flags) {
+    volatile unsigned long long* v = &h->h_pub->verdict;
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long w = *v;
+        if ((w >> 8) == h->ow_seq) { *flags = (unsigned)(w & 0xFFu); return MP_OK; }
+        if ((spins & 1023u) == 1023u) {
+            const hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipSuccess) {   // everything has run: the verdict is there, or it never will be
+                const unsigned long long w2 = *v;
+                if ((w2 >> 8) == h->ow_seq) { *flags = (unsigned)(w2 & 0xFFu); return MP_OK; }
+                return mp_fail(MP_ERR_HIP, "owner-keeps plan: the stream drained without a verdict");
+            }
+            if (e != hipErrorNotReady) return mp_fail(MP_ERR_HIP, std::string("owner-keeps plan: ") + hipGetErrorString(e));
+        }
+    }
 }
 
 int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
@@ -1262,26 +1331,41 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     if (rc != MP_OK) return rc;
     rc = shard_scratch(h, world, h->sh_cap ? h->sh_cap : 1);
     if (rc != MP_OK) return rc;
-    rc = owned_scratch(h);
+    rc = owned_scratch(h, world);
     if (rc != MP_OK) return rc;
+    owned_shape(h, world, scheme);
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
-                           h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo,
-                           h->ow_call);
-        hipLaunchKernelGGL(k_shard_own_draws, dim3(h->ow_nblk), dim3(SH_THREADS), 0, h->stream, h->n_global, (uint32_t)h->seed,
-                           (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, h->nt, world, rank, h->ow_gq,
-                           h->ow_wgcnt, h->ow_call);
-        hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, h->n, world, (u64)capacity, h->ow_nblk,
-                           (const uint32_t*)h->ow_wgcnt, (const unsigned long long*)h->ow_call, (const mp_dev_scalars*)h->scal, h->ow_base, h->ow_plan,
-                           h->d_pub);
+        // A world of one: the job's tile table is the one the last workgroup of k_propagate / k_normalize_tiles built (as for
+        // the unsharded resample); otherwise one workgroup builds it from the gathered tiles.
+        const mp_tab tab = tab_of(h);
+        const bool solo_tab = world == 1 && tab.ticket && scheme == MP_RESAMPLE_MULTINOMIAL && (const void*)d_tiles_all == (const void*)h->tile_m;
+        if (!solo_tab)
+            hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
+                               h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo,
+                               h->ow_call, (int)scheme, rank, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->ow_range);
+        const u64* t_incl = solo_tab ? (const u64*)h->tab_incl : (const u64*)h->sh_incl_all;
+        const u64* t_W = solo_tab ? (const u64*)h->tile_W : (const u64*)h->sh_tW_all;
+        const double* t_ratio = solo_tab ? (const double*)h->tab_ratio : (const double*)h->sh_ratio_all;
+        mp_own_plan_args pa;
+        pa.n = h->n; pa.n_global = h->n_global; pa.cap = (u64)capacity;
+        pa.world = world; pa.nsc = h->ow_nsc; pa.lattice = scheme ? 1 : 0; pa.S = h->S;
+        pa.sccnt = h->ow_sccnt; pa.cnt_r = h->ow_cnt_r; pa.c_all = h->ow_call;
+        pa.scal = h->scal; pa.undo = h->scal_undo; pa.head = solo_tab ? (const mp_tab_head*)h->tab_head : nullptr;
+        pa.base = h->ow_base; pa.plan_out = h->ow_plan; pa.pub = h->d_pub; pa.seq = ++h->ow_seq;
+        const bool tab_lds = h->nt <= K1_TABLE_LDS_MAX_TILES;
+        const size_t lds = sizeof(u64) * (size_t)h->ow_R * OWN_ROUND + (tab_lds ? (size_t)h->nt * 24 : 0);
+        auto kern = tab_lds ? k_shard_own_bin<1> : k_shard_own_bin<2>;
+        hipLaunchKernelGGL(kern, dim3(h->ow_nsc), dim3(OWN_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
+                           h->resample_count, (int)scheme, h->ow_R, t_incl, t_W, t_ratio, h->nt, world, rank, (const unsigned short*)h->guide,
+                           (const mp_own_range*)h->ow_range, h->ow_seg_lt, h->ow_seg_row, h->ow_seg_r, h->ow_permc, h->ow_seg_cnt, pa);
+        hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, pa);
     }
-    h->ow_world = world;
+    h->ow_scheme = scheme;
     rc = check_launch("shard_owned_count kernels");
     if (rc != MP_OK) return rc;
-    HIPCK(hipEventRecord(h->ev_resolved, h->stream));   // mp_pf_shard_owned_commit waits for this: verdict, L and counts are out
-    if (counts_out) {
-        HIPCK(hipEventSynchronize(h->ev_resolved));
+    if (counts_out) {   // exact sizes: the caller sizes its buffers from the counts (the stream drains: every field of h_pub is out)
+        HIPCK(stream_wait(h->stream));
         if (h->h_pub->degenerate)
             return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
         for (int r = 0; r < world; ++r) counts_out[r] = h->h_pub->counts[r];
@@ -1291,35 +1375,48 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
 
 int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t capacity, double* d_send_out, double* d_rows, uint64_t recv_rows) {
     if (!h || !d_send_out || !d_rows) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    if (!h->ow_gq || h->ow_world != world) return mp_fail(MP_ERR_STATE, "shard_owned_expand before shard_owned_count");
+    if (!h->ow_seg_lt || h->ow_world != world) return mp_fail(MP_ERR_STATE, "shard_owned_expand before shard_owned_count");
     if (rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "0 <= rank < world");
     if (capacity && recv_rows != (uint64_t)world * capacity) return mp_fail(MP_ERR_INVALID_ARG, "fixed capacity: recv_rows must be world * capacity");
     if (recv_rows + h->n >= (1ull << 32)) return mp_fail(MP_ERR_INVALID_ARG, "exchange buffer rows must be < 2^32");
     HIPCK(hipSetDevice(h->device));
+    h->ow_last_cap = capacity;
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        hipLaunchKernelGGL(k_shard_own_place, dim3(h->ow_nblk), dim3(SH_THREADS), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank,
-                           h->nt * world, h->nt, (u64)capacity, (u64)recv_rows, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all,
-                           (const double*)h->sh_ratio_all, (const mp_cx*)h->cx, (const unsigned short*)h->guide, (const double*)h->x[h->cur],
-                           (const u64*)h->ow_gq, (const uint32_t*)h->ow_wgcnt, (const uint32_t*)h->ow_base, (const mp_owned_plan*)h->ow_plan,
-                           (const unsigned long long*)h->ow_call, d_rows, d_send_out, h->sh_req_slot);
+        const unsigned groups = (unsigned)((h->ow_nsc + OWB_GC - 1) / OWB_GC);
+        hipLaunchKernelGGL(k_shard_own_resolve, dim3(groups * 8), dim3(OWB_THREADS), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank,
+                           h->ow_R, h->ow_nsc, (u64)capacity, (u64)recv_rows, (const u64*)h->ow_seg_lt, (const uint32_t*)h->ow_seg_row,
+                           (const unsigned short*)h->ow_seg_r, (const unsigned short*)h->ow_permc, (const unsigned short*)h->ow_seg_cnt,
+                           (const uint32_t*)h->ow_sccnt, (const uint32_t*)h->ow_base, (const mp_cx*)h->cx, (const double*)h->x[h->cur],
+                           (const mp_owned_plan*)h->ow_plan, (const unsigned long long*)h->ow_call, d_rows, d_send_out, h->sh_req_slot);
     }
-    return check_launch("k_shard_own_place");
+    return check_launch("k_shard_own_resolve");
 }
 
 int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_total_weight, uint64_t* counts_out) {
     if (!h || !d_rows) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    if (!h->ow_gq || !h->h_pub) return mp_fail(MP_ERR_STATE, "shard_owned_commit before shard_owned_expand");
+    if (!h->ow_seg_lt || !h->h_pub) return mp_fail(MP_ERR_STATE, "shard_owned_commit before shard_owned_expand");
     HIPCK(hipSetDevice(h->device));
-    HIPCK(hipEventSynchronize(h->ev_resolved));   // the one host wait, for the plan only: the rows may still be written / travelling
+    // The one host wait of a resample, and only for the plan's verdict word: the rows may still be written / travelling.  A
+    // world of one exchanges nothing, so an asynchronous resample there has no verdict to wait for (degenerate weights
+    // surface at the next synchronising call, as for mp_pf_resample without a log_total_weight).
+    const bool slow = log_total_weight || counts_out;   // these read more than the verdict word: the stream drains first
+    unsigned flags = 0;
+    if (slow) {
+        HIPCK(stream_wait(h->stream));
+        flags = (unsigned)(h->h_pub->verdict & 0xFFu);
+        if ((h->h_pub->verdict >> 8) != h->ow_seq) return mp_fail(MP_ERR_HIP, "owner-keeps plan: the stream drained without a verdict");
+    } else if (h->ow_world > 1) {
+        int32_t rcw = owned_wait_plan(h, &flags);
+        if (rcw != MP_OK) return rcw;
+    }
     if (counts_out)
         for (int r = 0; r < h->ow_world; ++r) counts_out[r] = h->h_pub->counts[r];
-    if (h->h_pub->degenerate)   // before anything is committed: with Q == 0 no rank owns a draw and the donor never writes its request slots
+    if (flags & 2u)   // before anything is committed: with Q == 0 no rank owns a draw and the donor never writes its request slots
         return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
-    if (h->h_pub->overflow) {
+    if ((flags & 1u) && h->ow_last_cap) {
         // a pair of ranks exchanges more than `capacity` rows (every rank reaches this verdict from the same counts): nothing
-        // is committed; the own draws stay queued, the caller repeats the expand with exact sizes (capacity 0)
-        h->h_pub->overflow = 0;
+        // is committed; the entries stay queued, the caller repeats the expand with exact sizes (capacity 0)
         return mp_fail(MP_ERR_CAPACITY, "owner-keeps exchange: a pair of ranks needs more than `capacity` rows; repeat the expand with exact sizes");
     }
     h->sh_rows = d_rows;
@@ -1462,7 +1559,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all); (void)hipFree(h->sh_ratio_all);
     (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done); (void)hipFree(h->scal_undo);
-    (void)hipFree(h->ow_gq); (void)hipFree(h->ow_wgcnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
+    owned_free(h);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     if (h->h_pub) (void)hipHostFree(h->h_pub);
     if (h->ev_resolved) (void)hipEventDestroy(h->ev_resolved);

@@ -147,6 +147,8 @@ __device__ __forceinline__ void mp_st_agent(double* p, double v) {
     __hip_atomic_store(reinterpret_cast<u64*>(p), __builtin_bit_cast(u64, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void mp_st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t mp_ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mp_st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // by ONE workgroup of THREADS threads; thread t owns the `per` consecutive tiles t*per ..  (three short passes with O(1)
 // registers: this code sits in the tail of k_propagate and must not raise its register count)
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagat
     // the first hop of the state fetch goes out before anything else: its latency runs under phase 1
     uint32_t pm[LANE_ITEMS];
 #pragma unroll
-    for (int p = 0; p < LANE_ITEMS; ++p) pm[p] = (perm && !inv && base + p < n) ? (uint32_t)perm[base + p] : 0u;
+    for (int p = 0; p < LANE_ITEMS; ++p) pm[p] = base + p < n ? (inv ? inv[base + p] : (perm ? (uint32_t)perm[base + p] : 0u)) : 0u;
     // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
     if (aux.zpre) {
 #pragma unroll
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagat
             if (inv) {
                 // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row
                 // {x[0..D), parent id} is row inv[i] of the exchange buffer (res_x here)
-                const double* row = res_x + (u64)inv[i] * (u64)(D + 1);
+                const double* row = res_x + (u64)pm[p] * (u64)(D + 1);
 #pragma unroll
                 for (int d = 0; d < D; ++d) prev[d] = row[d];
             } else if (perm) {

@@ -174,6 +174,7 @@ struct mp_shard_pub {
     int degenerate;
     double L;
     unsigned long long counts[SH_MAX_WORLD];   // "owner keeps" form: offspring per rank of the last resample
+    unsigned long long verdict;                // owner-keeps resample number k: (k << 8) | degenerate << 1 | overflow, ONE 8-byte store the host polls
 };
 constexpr int SHF_ITEMS = 8;   // draws per thread: 4 / 8 / 16 measured 22.7 / 19.9 / 25.6 us at world 1 and 35.0 / 27.6 / 32.6 us at world 8
 constexpr int SH_BINS = 8;
@@ -259,20 +260,25 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
 // Before the route, one workgroup: unpack the gathered tiles, build the job's tile table ONCE (inclusive prefix of T_b to
 // global memory), zero the request counters, and fold this normalisation into the filter scalars (L, ESS, log-ML),
 // keeping a copy for the case that the fixed-capacity exchange overflows.
+struct mp_own_range {                        // lattice schemes: this rank's own draws are g_lo <= g < g_hi
+    u64 g_lo, g_hi;
+};
 constexpr int SHT_THREADS = 1024;
 constexpr int SHT_PER = MAX_TILES / SHT_THREADS;   // tiles per thread, held in registers (8)
 __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
                                                              double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
                                                              u64* __restrict__ incl_all, double* __restrict__ ratio_all,
                                                              long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
-                                                             unsigned long long* __restrict__ zero_call = nullptr) {
+                                                             unsigned long long* __restrict__ c_all = nullptr, int scheme = 0, int rank = 0,
+                                                             uint32_t k0 = 0, uint32_t k1 = 0, uint32_t rc = 0, mp_own_range* range = nullptr) {
     __shared__ double s_red[SHT_THREADS / 64];
     __shared__ u64 s_wtot[SHT_THREADS / 64];
     __shared__ u64 s_wtot2[SHT_THREADS / 64];
     const int nt = world * nt_local;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < SH_MAX_KEYS) zero_counts[tid] = 0;
-    if (zero_call && tid < SH_MAX_WORLD) zero_call[tid] = 0ull;
+    __shared__ u64 s_bound[SH_MAX_WORLD];
+    __shared__ u64 s_G[SH_MAX_WORLD];
     // thread t owns tiles t * per .. t * per + per - 1 (consecutive, so that a thread-local running sum is a prefix); each
     // tile is read once, kept in registers, and its unpacked copy written for the kernels that want plain arrays
     const int per = (nt + SHT_THREADS - 1) / SHT_THREADS;   // <= SHT_PER since nt <= MAX_TILES
@@ -342,6 +348,34 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
     if (tid == 0) {
         *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
         fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+    }
+    // Owner-keeps exchange under a lattice scheme: targets are non-decreasing in g, so the draws that land in rank r's rows
+    // are the range [G_{r-1}, G_r) with G_r = #{g : target(g) <= end of r's tiles}: one binary search per rank (the same target
+    // function as the draw kernels, so the ranges are exactly the draws those kernels will call their own).
+    if (c_all && scheme) {
+#pragma unroll
+        for (int j = 0; j < SHT_PER; ++j) {
+            const int i = b0 + j;
+            if (j < per && i < nt && (i + 1) % nt_local == 0) s_bound[i / nt_local] = off + pre[j];
+        }
+        __syncthreads();
+        if (tid < world) {
+            const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+            const u64 B = s_bound[tid];
+            u64 lo = 0, hi = n_global;
+            while (lo < hi) {   // at most 33 probes
+                const u64 mid = lo + ((hi - lo) >> 1);
+                if (mp_target_lattice(scheme, mid, k32, rc, k0, k1, Q, n_global) <= B) lo = mid + 1;
+                else hi = mid;
+            }
+            s_G[tid] = lo;
+        }
+        __syncthreads();
+        if (tid < world) {
+            const u64 g0 = tid ? s_G[tid - 1] : 0ull;
+            c_all[tid] = s_G[tid] - g0;
+            if (tid == rank) { range->g_lo = g0; range->g_hi = s_G[tid]; }
+        }
     }
 }
 // owner side: blockIdx.x & 7 = eighth of this shard's tiles (workgroups are dealt round-robin to the 8 XCDs, gridDim.x is
@@ -428,221 +462,472 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
     }
 }
 // ---------------------------------------------------------------------------------------------
-// "Owner keeps" form of the sharded resample.  Every rank enumerates ALL N draws of the job (the draws of the single
+// "Owner keeps" form of the sharded resample.  Every rank enumerates the N draws of the job (the draws of the single
 // filter: same Philox counters, same targets, hence the same parent for every draw g) and keeps those that land in its own
 // rows; offspring then stay on the rank that owns their parent, in the order of their draws, and only the surplus over n
 // slots travels (to the ranks that drew fewer than n): the xGMI traffic of a resample drops from ~40 B per particle to a
 // few thousand rows.  WHERE an offspring sits depends on the number of ranks (a world of one is the single filter).
-//   k_shard_own_draws : draws -> (mine?) -> this workgroup's own targets, compacted in draw order; offspring per rank (ballots)
-//   k_shard_own_plan  : one workgroup: first offspring position of every k_shard_own_draws workgroup (scan), the exchange
-//                       plan, the verdict "some pair needs more than cap rows", what the host reads
-//   k_shard_own_place : own target -> tile, guide, walk -> row {x, parent id} written at the offspring's position: lane q
-//                       of a workgroup handles its q-th own draw, so positions are consecutive and the writes coalesced.
-// No counting, no scattered writes: a first version counted offspring per row with one atomic per draw and expanded the
-// counts per tile (parent order); its 2^20 scattered 4-byte read-modify-writes alone cost 36 us of a 73 us count phase.
+//
+// Round 2: the same XCD-binned two-hop layout as the single filter's k_bin_draws / k_resolve_bins.
+//   k_shard_table       (one workgroup) the job's tile table; for the lattice schemes also every rank's own range of
+//                       draws [G_{r-1}, G_r) by binary search on the monotone target function: offspring counts in
+//                       closed form, and a rank only looks at its own draws — O(n_local), whatever the world size.
+//   k_shard_own_bin     workgroup = "super-chunk" of R x 1024 consecutive draws, R = min(world, 4): rounds of (Philox
+//                       pair -> targets -> mine?), own targets compacted to LDS in draw order (so that the lookups that
+//                       follow run on full waves even when a rank owns one draw in `world`); then, for the compacted own
+//                       draws: tile -> guide -> start row, split into 8 bins (eighths of this rank's share of the CDF),
+//                       entries {tile-local target, start row, draw-order rank} written bin by bin into the super-chunk's
+//                       window.  Multinomial: offspring of every rank counted with ballots against the rank boundaries.
+//   k_shard_own_plan    (one workgroup) first offspring position of every super-chunk (scan), offspring per rank, the
+//                       exchange plan, the verdict "some pair needs more than cap rows", what the host reads.
+//   k_shard_own_resolve workgroup (2 super-chunks, bin b), blockIdx % 8 == b: the row lookups of eighth b run on one XCD.
+//                       Offspring p = base + rank < n: row {x, parent id} written at the entry's own (bin-ordered)
+//                       position, inv[p] points there; p >= n: the row goes to the send buffer where the plan says.
+// No counting of offspring per row, no scattered 4-byte read-modify-writes (a first version spent 36 of 73 us there).
 // ---------------------------------------------------------------------------------------------
-constexpr int SHO_ITEMS = 8;
-constexpr int SHO_CHUNK = SH_THREADS * SHO_ITEMS;   // draws per k_shard_own_draws workgroup
-__global__ __launch_bounds__(SH_THREADS) void k_shard_own_draws(u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme,
-                                                                const u64* __restrict__ incl_all, int nt_local, int world, int rank,
-                                                                u64* __restrict__ gq, uint32_t* __restrict__ wgcnt,
-                                                                unsigned long long* __restrict__ c_all) {
-    __shared__ u64 s_bound[SH_MAX_WORLD];       // inclusive prefix of T_b at the end of every rank's tiles
-    __shared__ uint32_t s_above[SH_MAX_WORLD];  // draws of this workgroup whose target lies above s_bound[r]
-    __shared__ uint32_t s_wc[SHO_ITEMS][SH_THREADS / 64];   // own draws of (round k, wave w)
-    __shared__ uint32_t s_live;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int r = tid; r < world; r += SH_THREADS) {
-        s_bound[r] = incl_all[(u64)(r + 1) * nt_local - 1];
-        s_above[r] = 0u;
-    }
-    if (tid == 0) s_live = 0u;
-    __syncthreads();
-    const u64 Q = s_bound[world - 1];
-    const u64 lo = rank ? s_bound[rank - 1] : 0ull, hi = s_bound[rank];
-    const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
-    const u64 g0 = (u64)blockIdx.x * SHO_CHUNK + tid;
-    u64 target[SHO_ITEMS];
-    uint32_t before[SHO_ITEMS];   // own draws of the same round in lower lanes of this wave
-    bool mine[SHO_ITEMS];
-    uint32_t nlive = 0;
-#pragma unroll
-    for (int k = 0; k < SHO_ITEMS; ++k) {
-        const u64 g = g0 + (u64)k * SH_THREADS;
-        target[k] = 0ull;   // below every boundary, and never "mine" (targets are >= 1)
-        if (g < n_global) {
-            if (scheme) {
-                target[k] = mp_target_lattice(scheme, g, k32, rc, k0, k1, Q, n_global);
-            } else {
-                target[k] = mp_target(mp_resample_k52(g, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1), Q);
-            }
-            ++nlive;
-        }
-        mine[k] = target[k] > lo && target[k] <= hi;
-        const u64 bal = __ballot(mine[k]);
-        before[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (lane == 0) s_wc[k][wave] = (uint32_t)__popcll(bal);
-    }
-    // offspring per rank: (# above the previous boundary) - (# above this one), counted per wave with ballots
-    for (int r = 0; r + 1 < world; ++r) {
-        const u64 B = s_bound[r];
-        uint32_t a = 0;
-#pragma unroll
-        for (int k = 0; k < SHO_ITEMS; ++k) a += (uint32_t)__popcll(__ballot(target[k] > B));
-        if (lane == 0 && a) atomicAdd(&s_above[r], a);
-    }
-    {
-        uint32_t v = nlive;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0 && v) atomicAdd(&s_live, v);
-    }
-    __syncthreads();
-    for (int r = tid; r < world; r += SH_THREADS) {
-        const uint32_t above_prev = r ? s_above[r - 1] : s_live;
-        const uint32_t above = (r + 1 < world) ? s_above[r] : 0u;
-        if (above_prev > above) atomicAdd(&c_all[r], (unsigned long long)(above_prev - above));
-    }
-    // compaction in draw order: draw g = chunk + k * 256 + tid, so (round k, wave, lane) ascending IS g ascending
-    u64* q_out = gq + (u64)blockIdx.x * SHO_CHUNK;
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 0; k < SHO_ITEMS; ++k) {
-        uint32_t off = run;
-#pragma unroll
-        for (int w = 0; w < SH_THREADS / 64; ++w) {
-            const uint32_t c = s_wc[k][w];
-            if (w < wave) off += c;
-            run += c;
-        }
-        if (mine[k]) q_out[off + before[k]] = target[k];
-    }
-    if (tid == 0) wgcnt[blockIdx.x] = run;
+constexpr int OWN_THREADS = 512;             // a thread owns two ADJACENT draws of a round (one Philox block)
+constexpr int OWN_ROUND = 2 * OWN_THREADS;   // draws per round
+constexpr int OWN_RMAX = 4;                  // rounds per workgroup at most (LDS: 8 B per draw of the super-chunk)
+constexpr int OWN_NW = OWN_THREADS / 64;
+__host__ __device__ inline int mp_own_rounds(int world) { return world < OWN_RMAX ? world : OWN_RMAX; }
+
+// tile of a target inside ONE rank's tiles.  `incl` = the rank's entries of the job's inclusive prefix, either as they
+// are (tabs = target, excl0 = prefix below the rank's first tile) or rebased to the rank's share (tabs = trel, excl0 = 0)
+__device__ __forceinline__ void mp_locate_own(const u64* incl, const u64* W_, const double* ratio, uint32_t nt, u64 tabs, u64 trel, u64 excl0,
+                                              double nt_over_span, uint32_t* tile, u64* lt, uint32_t* gslot) {
+    int b = (int)((double)trel * nt_over_span);   // only a starting guess for the walk: no effect on the result
+    if (b > (int)nt - 1) b = (int)nt - 1;
+    if (b < 0) b = 0;
+    while (b > 0 && incl[b - 1] >= tabs) --b;
+    while (b < (int)nt - 1 && incl[b] < tabs) ++b;
+    const u64 excl = b ? incl[b - 1] : excl0;
+    const u64 W = W_[b];
+    const u64 x = mp_local_target_r(tabs - excl, W, ratio[b]);
+    uint32_t g = (uint32_t)(x >> mp_guide_shift(W));
+    if (g > GUIDE_N - 1) g = GUIDE_N - 1;
+    *tile = (uint32_t)b; *lt = x; *gslot = (uint32_t)b * (uint32_t)GUIDE_N + g;
 }
 
 // the exchange plan: unit u of the surplus (donors in rank order) fills unit u of the deficit (receivers in rank order)
 struct mp_owned_plan {
     u64 S[SH_MAX_WORLD], D[SH_MAX_WORLD], PS[SH_MAX_WORLD], PD[SH_MAX_WORLD];
 };
-constexpr int SHP_THREADS = 1024;
-__global__ __launch_bounds__(SHP_THREADS) void k_shard_own_plan(u64 n, int world, u64 cap, int nblk, const uint32_t* __restrict__ wgcnt,
-                                                                const unsigned long long* __restrict__ c_all, const mp_dev_scalars* scal,
-                                                                uint32_t* __restrict__ base, mp_owned_plan* __restrict__ plan_out, mp_shard_pub* pub) {
+// stores the host will read while the stream is still running: write-through to system scope (sc0 sc1), no cache write-back
+__device__ __forceinline__ void mp_st_sys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mp_st_sys(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mp_st_sys(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct mp_own_plan_args {
+    u64 n, n_global, cap;
+    int world, nsc, lattice, S;
+    uint32_t* sccnt;                 // [nsc] own draws per super-chunk (in), read with agent-scope loads
+    uint32_t* cnt_r;                 // [nsc][world] offspring per rank (multinomial)
+    unsigned long long* c_all;       // [world] in: lattice counts (k_shard_table); out: offspring per rank
+    mp_dev_scalars* scal;
+    mp_dev_scalars* undo;
+    const mp_tab_head* head;         // world of one: the table k_propagate's last workgroup built is the job's table; k_shard_own_bin folds it
+    uint32_t* base;                  // [nsc] out: first offspring position of every super-chunk
+    mp_owned_plan* plan_out;
+    mp_shard_pub* pub;               // host-mapped
+    unsigned long long seq;
+};
+// by ONE workgroup of THREADS threads
+template <int THREADS>
+__device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a) {
     __shared__ mp_owned_plan pl;
-    __shared__ u64 s_wtot[SHP_THREADS / 64];
+    __shared__ u64 s_ptot[THREADS / 64];
+    __shared__ uint32_t s_part[THREADS / 64][SH_MAX_WORLD];
+    __shared__ u64 s_c[SH_MAX_WORLD];
+    __shared__ int s_over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {
-        u64 ps = 0, pd = 0;
-        for (int r = 0; r < world; ++r) {
-            const u64 c = c_all[r];
-            pl.S[r] = c > n ? c - n : 0ull;
-            pl.D[r] = c < n ? n - c : 0ull;
-            pl.PS[r] = ps; pl.PD[r] = pd;
-            ps += pl.S[r]; pd += pl.D[r];
-            pub->counts[r] = c;
-        }
-        pub->L = scal->L;
-        pub->degenerate = scal->degenerate;
-    }
-    // exclusive scan of the workgroup counts: thread t owns entries [t * per, (t + 1) * per)
-    const int per = (nblk + SHP_THREADS - 1) / SHP_THREADS;
+    const int world = a.world, nsc = a.nsc;
+    // every load this workgroup depends on goes out now (one round trip instead of three in a kernel that is all latency)
+    const int per = (nsc + THREADS - 1) / THREADS;   // scan below: thread t owns entries [t * per, (t + 1) * per)
     const int b0 = tid * per;
     u64 run = 0;
     for (int j = 0; j < per; ++j)
-        if (b0 + j < nblk) run += wgcnt[b0 + j];
+        if (b0 + j < nsc) run += a.sccnt[b0 + j];
+    const double scal_L = a.scal->L;
+    const int scal_deg = a.scal->degenerate;
+    if (a.lattice) {   // k_shard_table found the counts in closed form
+        if (tid < world) s_c[tid] = a.c_all[tid];
+    } else {           // offspring per rank = column sums of the super-chunks' counts
+        for (int r = 0; r < world; ++r) {
+            uint32_t v = 0u;
+            for (int k = tid; k < nsc; k += THREADS) v += a.cnt_r[(u64)k * world + r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) s_part[wave][r] = v;
+        }
+        __syncthreads();
+        if (tid < world) {
+            u64 v = 0;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; ++w) v += s_part[w][tid];
+            s_c[tid] = v;
+            a.c_all[tid] = v;
+        }
+    }
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    if (tid == 0) {
+        u64 ps = 0, pd = 0;
+        for (int r = 0; r < world; ++r) {
+            const u64 c = s_c[r];
+            pl.S[r] = c > a.n ? c - a.n : 0ull;
+            pl.D[r] = c < a.n ? a.n - c : 0ull;
+            pl.PS[r] = ps; pl.PD[r] = pd;
+            ps += pl.S[r]; pd += pl.D[r];
+            mp_st_sys(&a.pub->counts[r], (unsigned long long)c);
+        }
+        mp_st_sys(&a.pub->L, scal_L);
+        mp_st_sys(&a.pub->degenerate, scal_deg);
+    }
+    // exclusive scan of the super-chunks' own counts: thread t owns entries [t * per, (t + 1) * per)
     const u64 incl = wave_incl_scan_u64(run, lane);
-    if (lane == 63) s_wtot[wave] = incl;
+    if (lane == 63) s_ptot[wave] = incl;
     __syncthreads();
     u64 woff = 0;
 #pragma unroll
-    for (int w = 0; w < SHP_THREADS / 64; ++w)
-        if (w < wave) woff += s_wtot[w];
+    for (int w = 0; w < THREADS / 64; ++w)
+        if (w < wave) woff += s_ptot[w];
     u64 off = woff + (incl - run);
     for (int j = 0; j < per; ++j) {
-        if (b0 + j < nblk) {
-            base[b0 + j] = (uint32_t)off;
-            off += wgcnt[b0 + j];
+        if (b0 + j < nsc) {
+            a.base[b0 + j] = (uint32_t)off;
+            off += a.sccnt[b0 + j];
         }
     }
     // every rank must reach the same verdict on "some pair needs more than cap rows" (the collective that follows is symmetric),
     // so every rank looks at every pair of the plan
     int over = 0;
-    if (cap) {
-        for (int pq = tid; pq < world * world; pq += SHP_THREADS) {
+    if (a.cap) {
+        for (int pq = tid; pq < world * world; pq += THREADS) {
             const int r = pq / world, s2 = pq - r * world;
             const u64 a0 = pl.PS[r] > pl.PD[s2] ? pl.PS[r] : pl.PD[s2];
             const u64 e0 = pl.PS[r] + pl.S[r], e1 = pl.PD[s2] + pl.D[s2];
             const u64 a1 = e0 < e1 ? e0 : e1;
-            if (a1 > a0 && a1 - a0 > cap) over = 1;
+            if (a1 > a0 && a1 - a0 > a.cap) over = 1;
         }
     }
-    over = __syncthreads_or(over);
-    if (tid == 0) pub->overflow = over;
-    for (int r = tid; r < world; r += SHP_THREADS) {
-        plan_out->S[r] = pl.S[r]; plan_out->D[r] = pl.D[r]; plan_out->PS[r] = pl.PS[r]; plan_out->PD[r] = pl.PD[r];
+    if (over) atomicOr(&s_over, 1);
+    for (int r = tid; r < world; r += THREADS) {
+        a.plan_out->S[r] = pl.S[r]; a.plan_out->D[r] = pl.D[r]; a.plan_out->PS[r] = pl.PS[r]; a.plan_out->PD[r] = pl.PD[r];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        mp_st_sys(&a.pub->overflow, s_over);
+        // what the host polls between resamples: one word, so it needs no ordering against the fields above (those are read
+        // after the stream has drained: log total weight of a synchronous resample, counts of the exact-size repeat)
+        mp_st_sys(&a.pub->verdict, (a.seq << 8) | (unsigned long long)((scal_deg ? 2 : 0) | (s_over ? 1 : 0)));
+    }
+}
+constexpr int SHP_THREADS = 1024;
+__global__ __launch_bounds__(SHP_THREADS) void k_shard_own_plan(mp_own_plan_args a) { mp_own_plan<SHP_THREADS>(a); }
+
+template <int TABMODE>   // 1: this rank's part of the tile table copied to LDS (rebased); 2: probed where it lies (more than 1024 tiles)
+__global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_shard_own_bin(
+    u64 n, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme, int R, const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
+    const double* __restrict__ ratio_all, int nt_local, int world, int rank, const unsigned short* __restrict__ guide,
+    const mp_own_range* __restrict__ range, u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row, unsigned short* __restrict__ seg_r,
+    unsigned short* __restrict__ permc, unsigned short* __restrict__ seg_cnt, mp_own_plan_args pa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nt_lds = TABMODE == 1 ? nt_local : 0;
+    u64* s_tgt = reinterpret_cast<u64*>(smem);                          // [R * 1024] own targets of the super-chunk, draw order
+    u64* s_incl_lds = s_tgt + (size_t)R * OWN_ROUND;                    // [nt_local]
+    u64* s_W_lds = s_incl_lds + nt_lds;
+    double* s_ratio_lds = reinterpret_cast<double*>(s_W_lds + nt_lds);
+    __shared__ u64 s_bound[SH_MAX_WORLD];                               // inclusive prefix of T_b at the end of every rank's tiles
+    __shared__ uint32_t s_above[OWN_NW][SH_MAX_WORLD];                  // per wave: draws whose target lies above s_bound[r]
+    __shared__ uint32_t s_wown[OWN_NW];
+    __shared__ uint32_t s_wcnt[OWN_NW * 8];
+    __shared__ uint32_t s_bincnt[8], s_binoff[8], s_binrun[8];
+    __shared__ uint32_t s_cntr[SH_MAX_WORLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sc = blockIdx.x;
+    const u64 Wd = (u64)R * OWN_ROUND;                                  // draws (and window entries) per super-chunk
+    const u64 g_base = (u64)sc * Wd;
+    const u64* my_incl = incl_all + (u64)rank * nt_local;
+    const u64* my_W = tW_all + (u64)rank * nt_local;
+    const double* my_ratio = ratio_all + (u64)rank * nt_local;
+    const u64 lo = rank ? incl_all[(u64)rank * nt_local - 1] : 0ull;    // uniform loads
+    const u64 hi = my_incl[nt_local - 1];
+    const u64 Q = incl_all[(u64)world * nt_local - 1];
+    if (pa.head && blockIdx.x == 0 && tid == 0) {   // fold this normalisation into the filter scalars (k_shard_table's part otherwise)
+        *pa.undo = *pa.scal;
+        fold_scalars(pa.scal, pa.head->Q, pa.head->Q2, pa.S, pa.head->m, n_global, 0);
+    }
+    auto publish = [&](uint32_t own_) {   // this super-chunk's counts, for k_shard_own_plan
+        if (tid == 0) pa.sccnt[sc] = own_;
+        if (scheme == 0 && tid < world) pa.cnt_r[(u64)sc * world + tid] = world > 1 ? s_cntr[tid] : own_;
+    };
+    if (scheme) {   // lattice: super-chunks without a draw of this rank leave at once
+        const u64 glo = range->g_lo, ghi = range->g_hi;
+        if (g_base >= ghi || g_base + Wd <= glo) {
+            if (tid < 8) seg_cnt[(u64)sc * 8 + tid] = 0;
+            publish(0u);
+            return;
+        }
+    }
+    if constexpr (TABMODE == 1) {
+        for (int b = tid; b < nt_local; b += OWN_THREADS) {
+            s_incl_lds[b] = my_incl[b] - lo;
+            s_W_lds[b] = my_W[b];
+            s_ratio_lds[b] = my_ratio[b];
+        }
+    }
+    for (int r = tid; r < world; r += OWN_THREADS) s_bound[r] = incl_all[(u64)(r + 1) * nt_local - 1];
+    if (tid < 8) { s_bincnt[tid] = 0u; s_binrun[tid] = 0u; }
+    __syncthreads();
+    const bool count_all = scheme == 0 && world > 1;
+    const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+    uint32_t above_acc = 0u;   // lane r: draws of this wave above boundary r (r < world - 1)
+    uint32_t run = 0u;         // own draws of the rounds so far (uniform)
+#pragma unroll 1
+    for (int rr = 0; rr < R; ++rr) {
+        const u64 i0 = g_base + (u64)rr * OWN_ROUND + 2u * (u64)tid;   // even
+        u64 t0, t1;
+        if (scheme) {
+            t0 = mp_target_lattice(scheme, i0, k32, rc, k0, k1, Q, n_global);
+            t1 = mp_target_lattice(scheme, i0 + 1, k32, rc, k0, k1, Q, n_global);
+        } else {
+            const mp_u64x2 blk = mp_resample_block(i0 >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
+            t0 = mp_target(mp_u52(blk.a), Q);
+            t1 = mp_target(mp_u52(blk.b), Q);
+        }
+        const bool live0 = i0 < n_global, live1 = i0 + 1 < n_global;
+        const bool mine0 = live0 && t0 > lo && t0 <= hi, mine1 = live1 && t1 > lo && t1 <= hi;
+        if (count_all) {
+            for (int r = 0; r + 1 < world; ++r) {
+                const u64 B = s_bound[r];
+                const uint32_t c = (uint32_t)__popcll(__ballot(live0 && t0 > B)) + (uint32_t)__popcll(__ballot(live1 && t1 > B));
+                above_acc += (lane == r) ? c : 0u;
+            }
+        }
+        // compaction in draw order: (round, wave, lane, slot of the pair) ascending IS g ascending
+        const u64 m0 = __ballot(mine0), m1 = __ballot(mine1);
+        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                             __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))));
+        if (lane == 0) s_wown[wave] = (uint32_t)(__popcll(m0) + __popcll(m1));
+        __syncthreads();
+        uint32_t woff = 0u, tot = 0u;
+#pragma unroll
+        for (int w = 0; w < OWN_NW; ++w) {
+            const uint32_t c = s_wown[w];
+            woff += (w < wave) ? c : 0u;
+            tot += c;
+        }
+        if (mine0) s_tgt[run + woff + pre] = t0;
+        if (mine1) s_tgt[run + woff + pre + (mine0 ? 1u : 0u)] = t1;
+        run += tot;
+        __syncthreads();
+    }
+    const uint32_t own = run;
+    if (count_all) {
+        if (lane < world) s_above[wave][lane] = above_acc;
+        __syncthreads();
+        if (tid < world) {
+            const u64 rest = n_global - g_base;
+            const uint32_t live_all = (uint32_t)(rest < Wd ? rest : Wd);
+            uint32_t a_prev = 0u, a_me = 0u;
+#pragma unroll
+            for (int w = 0; w < OWN_NW; ++w) {
+                a_prev += tid ? s_above[w][tid - 1] : 0u;
+                a_me += (tid + 1 < world) ? s_above[w][tid] : 0u;
+            }
+            if (tid == 0) a_prev = live_all;
+            s_cntr[tid] = a_prev - a_me;
+        }
+        __syncthreads();
+    }
+    publish(own);
+    // ---- the compacted own draws: bins first (their sizes fix where each bin's entries start in the window) ----
+    const u64 span = hi - lo;
+    const double eight_over_span = 8.0 / (double)span;           // own > 0 implies span > 0
+    auto bin_of = [&](u64 t) {                                   // eighth of this rank's share of the CDF (monotone in t)
+        uint32_t b = (uint32_t)((double)(t - lo - 1ull) * eight_over_span);
+        return b > 7u ? 7u : b;
+    };
+    {
+        uint32_t acc = 0u;   // lane bb < 8: entries of bin bb seen by this wave
+        for (uint32_t jb = 0; jb < own; jb += OWN_THREADS) {
+            const uint32_t j = jb + (uint32_t)tid;
+            const bool act = j < own;
+            const uint32_t bn = act ? bin_of(s_tgt[j]) : 8u;
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                const uint32_t c = (uint32_t)__popcll(__ballot(bn == (uint32_t)bb));
+                acc += (lane == bb) ? c : 0u;
+            }
+        }
+        if (lane < 8 && acc) atomicAdd(&s_bincnt[lane], acc);
+    }
+    __syncthreads();
+    if (tid < 8) {
+        uint32_t off = 0u;
+        for (int b = 0; b < tid; ++b) off += s_bincnt[b];
+        s_binoff[tid] = off;
+        seg_cnt[(u64)sc * 8 + tid] = (unsigned short)s_bincnt[tid];   // <= R * 1024 <= 4096
+    }
+    __syncthreads();
+    const u64* t_incl = TABMODE == 1 ? s_incl_lds : my_incl;
+    const u64* t_W = TABMODE == 1 ? s_W_lds : my_W;
+    const double* t_ratio = TABMODE == 1 ? s_ratio_lds : my_ratio;
+    const double nt_over_span = (double)nt_local / (double)span;
+    const u64 wbase = (u64)sc * Wd;
+    for (uint32_t jb = 0; jb < own; jb += OWN_ROUND) {   // uniform trip count
+        uint32_t j[2], bn[2], gslot[2], tile_of[2], j0[2], rank_[2];
+        u64 lt[2];
+        bool act[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            j[q] = jb + (uint32_t)q * OWN_THREADS + (uint32_t)tid;
+            act[q] = j[q] < own;
+            const u64 t = act[q] ? s_tgt[j[q]] : lo + 1ull;
+            bn[q] = act[q] ? bin_of(t) : 8u;
+            const u64 trel = t - lo;
+            mp_locate_own(t_incl, t_W, t_ratio, (uint32_t)nt_local, TABMODE == 1 ? trel : t, trel, TABMODE == 1 ? 0ull : lo, nt_over_span,
+                          &tile_of[q], &lt[q], &gslot[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];   // in flight while the places are worked out
+        rank_[0] = rank_[1] = 0u;
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const bool h0 = bn[0] == (uint32_t)bb, h1 = bn[1] == (uint32_t)bb;
+            const u64 m0 = __ballot(h0), m1 = __ballot(h1);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))));
+            if (h0) rank_[0] = below;
+            if (h1) rank_[1] = below + (h0 ? 1u : 0u);
+            if (lane == bb) s_wcnt[wave * 8 + bb] = (uint32_t)(__popcll(m0) + __popcll(m1));
+        }
+        __syncthreads();
+        if (tid < 8) {   // exclusive offsets of the waves per bin, on top of the bin's start and of the batches before
+            uint32_t at = s_binoff[tid] + s_binrun[tid];
+#pragma unroll
+            for (int w = 0; w < OWN_NW; ++w) {
+                const uint32_t cw = s_wcnt[w * 8 + tid];
+                s_wcnt[w * 8 + tid] = at;
+                at += cw;
+            }
+            s_binrun[tid] = at - s_binoff[tid];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (act[q]) {
+                const uint32_t s = s_wcnt[wave * 8 + bn[q]] + rank_[q];
+                const u64 tbase = (u64)tile_of[q] * TILE;
+                const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+                const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
+                seg_lt[wbase + s] = lt[q];
+                seg_row[wbase + s] = (uint32_t)tbase + jj;          // row where the forward scan starts
+                seg_r[wbase + s] = (unsigned short)j[q];            // draw-order rank inside the super-chunk
+                permc[wbase + j[q]] = (unsigned short)s;
+            }
+        }
+        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(SH_THREADS) void k_shard_own_place(u64 n, u64 slot_offset, int D, int world, int rank, int nt_all, int nt_local, u64 cap,
-                                                                u64 recv_rows, const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
-                                                                const double* __restrict__ ratio_all, const mp_cx* __restrict__ cx,
-                                                                const unsigned short* __restrict__ guide, const double* __restrict__ x,
-                                                                const u64* __restrict__ gq, const uint32_t* __restrict__ wgcnt,
-                                                                const uint32_t* __restrict__ base, const mp_owned_plan* __restrict__ plan,
-                                                                const unsigned long long* __restrict__ c_all, double* __restrict__ rows,
-                                                                double* __restrict__ send, uint32_t* __restrict__ inv) {
-    const int tid = threadIdx.x;
-    const uint32_t qn = wgcnt[blockIdx.x];
-    const u64 p0 = base[blockIdx.x];
-    const u64 Q = incl_all[nt_all - 1];
-    const double nt_over_Q = (double)nt_all / (double)Q;
+constexpr int OWB_THREADS = 256;
+constexpr int OWB_GC = 2;   // super-chunks per workgroup: (bin, 2 super-chunks) holds ~256 entries in a world of <= 4 ranks
+__global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_shard_own_resolve(
+    u64 n, u64 slot_offset, int D, int world, int rank, int R, int nsc, u64 cap, u64 recv_rows, const u64* __restrict__ seg_lt,
+    const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_r, const unsigned short* __restrict__ permc,
+    const unsigned short* __restrict__ seg_cnt, const uint32_t* __restrict__ sccnt, const uint32_t* __restrict__ base, const mp_cx* __restrict__ cx,
+    const double* __restrict__ x, const mp_owned_plan* __restrict__ plan, const unsigned long long* __restrict__ c_all, double* __restrict__ rows,
+    double* __restrict__ send, uint32_t* __restrict__ inv) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bin = blockIdx.x & 7, group = blockIdx.x >> 3;
+    const u64 Wd = (u64)R * OWN_ROUND;
+    // headers of this workgroup's super-chunks (uniform loads)
+    uint32_t cntb[OWB_GC], binoff[OWB_GC], base_k[OWB_GC], tot_k[OWB_GC];
+    int sck[OWB_GC];
+#pragma unroll
+    for (int k = 0; k < OWB_GC; ++k) {
+        const int s_ = group * OWB_GC + k;
+        const bool ok = s_ < nsc;
+        sck[k] = ok ? s_ : 0;
+        const uint4 c4 = *reinterpret_cast<const uint4*>(seg_cnt + (u64)sck[k] * 8);
+        const uint32_t c[8] = {c4.x & 0xFFFFu, c4.x >> 16, c4.y & 0xFFFFu, c4.y >> 16, c4.z & 0xFFFFu, c4.z >> 16, c4.w & 0xFFFFu, c4.w >> 16};
+        uint32_t off = 0u, mine = 0u;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            off += (b < bin) ? c[b] : 0u;
+            mine = (b == bin) ? c[b] : mine;
+        }
+        cntb[k] = ok ? mine : 0u;
+        binoff[k] = off;
+        base_k[k] = base[sck[k]];
+        tot_k[k] = ok ? sccnt[sck[k]] : 0u;
+    }
+    const uint32_t total = cntb[0] + cntb[1];
     const u64 PS_me = plan->PS[rank];
-    const u64* q_in = gq + (u64)blockIdx.x * SHO_CHUNK;
-    const int lane = tid & 63;
-    // lanes of a row group when states are wider than one double (as k_shard_resolve_binned): G lanes copy one parent's row
-    // together, a row is then one coalesced request instead of D scattered 8-byte ones
-    const int G = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : 16));
-    for (uint32_t q0 = 0; q0 < qn; q0 += SH_THREADS) {   // wave-uniform trip count
-        const uint32_t q = q0 + tid;
-        u64 i = 0;
+    uint32_t pc_first = 0u;   // first permc entry of this lane's share of inv[] (below): its load goes out with the entries'
+    {
+        const int k = tid >> 7;
+        const uint32_t tot = k ? tot_k[1] : tot_k[0];
+        const uint32_t r = (uint32_t)(((u64)tot * (u64)bin) >> 3) + (uint32_t)(tid & 127);
+        if (r < (uint32_t)(((u64)tot * (u64)(bin + 1)) >> 3)) pc_first = permc[(u64)(k ? sck[1] : sck[0]) * Wd + r];
+    }
+    const int G = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : 16));   // lanes of a row group when states are wider than one double
+    for (uint32_t idx0 = 0; idx0 < total; idx0 += OWB_THREADS) {   // uniform trip count
+        const uint32_t idx = idx0 + (uint32_t)tid;
+        const bool act = idx < total;
+        const int k = (act && idx >= cntb[0]) ? 1 : 0;
+        const uint32_t e = act ? idx - (k ? cntb[0] : 0u) : 0u;
+        const uint32_t s = (k ? binoff[1] : binoff[0]) + e;
+        const u64 wpos = (u64)(k ? sck[1] : sck[0]) * Wd + s;
+        // hop 1: the entry (three independent loads); hop 2: the start row and its successor, whole 16-byte rows
+        int a_ = act ? 1 : 0;
+        u64 lt = seg_lt[wpos];
+        uint32_t row0 = seg_row[wpos];
+        const uint32_t r = seg_r[wpos];
+        mp_pin3(a_, lt, row0);
+        if (!a_) row0 = 0u;
+        const u64 tend = (((u64)row0 / TILE) + 1) * TILE;
+        const u64 last = (tend < n ? tend : n) - 1;
+        mp_u64v2 r0 = mp_ld_row(cx + row0);
+        mp_u64v2 r1 = mp_ld_row(cx + (u64)row0 + ((u64)row0 < last ? 1 : 0));
+        mp_pin_rows(r0, r1);
+        u64 i = row0;
         double* dst = nullptr;
-        mp_cx cur;
-        cur.cum = 0; cur.x0 = 0.;
-        if (q < qn) {
-            uint32_t b, gs;
-            u64 lt;
-            mp_locate_r(incl_all, tW_all, ratio_all, (uint32_t)nt_all, q_in[q], nt_over_Q, &b, &lt, &gs);
-            const uint32_t tl = b - (uint32_t)rank * (uint32_t)nt_local;
-            const u64 tbase = (u64)tl * TILE;
-            const u64 tend = tbase + TILE;
-            const u64 last = (tend < n ? tend : n) - 1;
-            const u64 j = tbase + guide[(u64)tl * GUIDE_N + (gs - b * (uint32_t)GUIDE_N)];
-            i = j < last ? j : last;
-            cur = cx[i];
-            while (cur.cum < lt && i < last) {
+        double x0 = 0.;
+        if (act) {
+            const bool step1 = r0.x < lt && i < last;
+            i += step1 ? 1 : 0;
+            mp_u64v2 cur = step1 ? r1 : r0;
+            while (cur.x < lt && i < last) {   // rare: more than one row past the guide's start
                 ++i;
-                cur = cx[i];
+                cur = mp_ld_row(cx + i);
             }
-            const u64 p = p0 + q;
+            x0 = __builtin_bit_cast(double, (u64)cur.y);
+            const u64 bk = k ? base_k[1] : base_k[0];
+            const u64 p = bk + r;
             if (p < n) {
-                dst = rows + (recv_rows + p) * (u64)(D + 1);
-                inv[p] = (uint32_t)(recv_rows + p);
+                // kept: at the entry's own place (coalesced); the one super-chunk that straddles slot n keeps draw order, so
+                // that the kept rows stay within n rows
+                const bool straddle = bk + (k ? tot_k[1] : tot_k[0]) > n;
+                dst = rows + (recv_rows + (straddle ? p : bk + s)) * (u64)(D + 1);
             } else {
                 const u64 u = PS_me + (p - n);
-                int s = 0;
-                while (s + 1 < world && !(plan->D[s] && u < plan->PD[s] + plan->D[s])) ++s;
+                int s2 = 0;
+                while (s2 + 1 < world && !(plan->D[s2] && u < plan->PD[s2] + plan->D[s2])) ++s2;
                 if (cap) {
-                    const u64 first = PS_me > plan->PD[s] ? PS_me : plan->PD[s];
+                    const u64 first = PS_me > plan->PD[s2] ? PS_me : plan->PD[s2];
                     const u64 jj = u - first;
                     // jj >= cap: k_shard_own_plan has flagged it, nothing of this attempt is committed
-                    if (jj < cap) dst = send + ((u64)s * cap + jj) * (u64)(D + 1);
+                    if (jj < cap) dst = send + ((u64)s2 * cap + jj) * (u64)(D + 1);
                 } else {
                     dst = send + (u - PS_me) * (u64)(D + 1);
                 }
             }
         }
         if (D == 1) {
-            if (dst) *reinterpret_cast<double2*>(dst) = make_double2(cur.x0, (double)(slot_offset + i));
+            if (dst) *reinterpret_cast<double2*>(dst) = make_double2(x0, (double)(slot_offset + i));
         } else {
             if (dst) dst[D] = (double)(slot_offset + i);
             const u64 dbits = (u64)(uintptr_t)dst;
@@ -660,10 +945,27 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_own_place(u64 n, u64 slot_
             }
         }
     }
+    // where slot p finds its row (draw order, coalesced): the 8 workgroups of a group take an eighth of each super-chunk's range
+    {
+        const int k = tid >> 7;                                  // 128 lanes per super-chunk
+        const uint32_t tot = k ? tot_k[1] : tot_k[0];
+        const uint32_t r_lo = (uint32_t)(((u64)tot * (u64)bin) >> 3), r_hi = (uint32_t)(((u64)tot * (u64)(bin + 1)) >> 3);
+        const u64 bk = k ? base_k[1] : base_k[0];
+        const bool straddle = bk + tot > n;
+        const u64 pbase = (u64)(k ? sck[1] : sck[0]) * Wd;
+        uint32_t r = r_lo + (uint32_t)(tid & 127);
+        uint32_t pc = pc_first;
+        while (r < r_hi) {
+            const u64 p = bk + r;
+            if (p < n) inv[p] = (uint32_t)(recv_rows + (straddle ? p : bk + pc));
+            r += 128u;
+            if (r < r_hi) pc = permc[pbase + r];
+        }
+    }
     // slots this rank could not fill itself: where in the receive buffer their rows will arrive
     const u64 c_me = c_all[rank];
     const u64 PD_me = plan->PD[rank], D_me = plan->D[rank];
-    for (u64 k = (u64)blockIdx.x * SH_THREADS + tid; k < D_me; k += (u64)gridDim.x * SH_THREADS) {
+    for (u64 k = (u64)blockIdx.x * OWB_THREADS + tid; k < D_me; k += (u64)gridDim.x * OWB_THREADS) {
         u64 idx = k;
         if (cap) {
             const u64 u = PD_me + k;

@@ -114,15 +114,16 @@ class HipShardEngine:
     def shard_owned_expand(self, world, rank, cap, send_ptr, rows_ptr, recv_rows):
         capi.check(self._L.mp_pf_shard_owned_expand(self._h, world, rank, cap, send_ptr, rows_ptr, recv_rows))
 
-    def shard_owned_commit(self, rows_ptr, recv_rows, want_value):
-        """-> (committed, log total weight or None, offspring per rank)"""
+    def shard_owned_commit(self, rows_ptr, recv_rows, want_value, want_counts=True):
+        """-> (committed, log total weight or None, offspring per rank or None).  Without value and counts the call waits for
+        the plan's verdict word only (and not at all in a world of one); with either, for the stream."""
         out = C.c_double()
-        counts = (C.c_uint64 * 64)()   # SH_MAX_WORLD entries: the library writes the world's
+        counts = (C.c_uint64 * 64)() if want_counts else None   # SH_MAX_WORLD entries: the library writes the world's
         code = self._L.mp_pf_shard_owned_commit(self._h, rows_ptr, C.byref(out) if want_value else None, counts)
         if code == capi.MP_ERR_CAPACITY:
-            return False, None, list(counts)
+            return False, None, (list(counts) if want_counts else None)
         capi.check(code)
-        return True, (out.value if want_value else None), list(counts)
+        return True, (out.value if want_value else None), (list(counts) if want_counts else None)
 
     def shard_query_packed(self, tiles_all_ptr, world):
         lml, ess = C.c_double(), C.c_double()
@@ -379,10 +380,12 @@ class ShardedParticleSystem:
             e.shard_owned_expand(w, self.rank, cap, C.c_void_p(self._ow_send.data_ptr()), C.c_void_p(rows.data_ptr()), w * cap)
             if not solo:
                 dist.all_to_all_single(rows[: w * cap * (d + 1)], self._ow_send, group=self.group)
-            done, value, counts = e.shard_owned_commit(C.c_void_p(rows.data_ptr()), w * cap, sync)
+            p_rows = C.c_void_p(rows.data_ptr())
+            done, value, _ = e.shard_owned_commit(p_rows, w * cap, sync, want_counts=False)
             if done:
                 return value
             self.fallbacks += 1      # some pair of ranks exchanges more than cap rows: exact sizes this time
+            _, _, counts = e.shard_owned_commit(p_rows, w * cap, False, want_counts=True)   # same verdict, now with the counts
         else:
             counts = e.shard_owned_count(scheme, p_tiles_all, w, self.rank, 0, want_counts=True)
         amount = self.owned_plan(counts[:w], self.n)
@@ -398,7 +401,7 @@ class ShardedParticleSystem:
             recv = self._all_to_all(send, send_counts, recv_counts, d + 1)
         if n_recv:
             rows[: n_recv * (d + 1)].copy_(recv[: n_recv * (d + 1)])
-        done, value, _ = e.shard_owned_commit(C.c_void_p(rows.data_ptr()), n_recv, sync)
+        done, value, _ = e.shard_owned_commit(C.c_void_p(rows.data_ptr()), n_recv, sync, want_counts=False)
         self._ow_keep = (rows, send)   # the next propagate reads its parents' states from `rows`
         if self._ow_fixed and not self._ow_cap_forced and self._ow_cap < self.n:
             self.synchronize()

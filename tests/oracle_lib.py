@@ -417,7 +417,7 @@ class OracleShardEngine:
         self._ck(self.L.oracle_pf_shard_owned_expand(self.h, rank, send_ptr, C.byref(sent)))
         return sent.value
 
-    def shard_owned_commit(self, rows_ptr, recv_rows, want_value):
+    def shard_owned_commit(self, rows_ptr, recv_rows, want_value, want_counts=True):
         out = C.c_double()
         self._ck(self.L.oracle_pf_shard_owned_adopt(self.h, self._rank, rows_ptr, recv_rows, C.byref(out)))
         return True, (out.value if want_value else None), None

@@ -39,20 +39,23 @@ def main():
         r = eng.get_timing(capi.MP_K_BIN_DRAWS)
         g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
         print(f"world {world}: route (unpack + route + finalize) {r[0] / r[1] * 1e3:.1f} us, resolve + publish {g[0] / g[1] * 1e3:.1f} us", flush=True)
-        # the owner-keeps form: every rank enumerates all world * n draws, keeps its own
+        # the owner-keeps form: multinomial = every rank enumerates all world * n draws and keeps its own; lattice schemes = a
+        # rank's own draws are a range found by two searches
         ocap = max(4096, n // 128)
         send = torch.zeros(world * ocap * 2, dtype=torch.float64, device=dev)
         orow = torch.zeros((world * ocap + n) * 2, dtype=torch.float64, device=dev)
-        eng.synchronize()
-        eng.set_timing(False)
-        eng.set_timing(True)
-        for _ in range(12):
-            eng.shard_owned_count(0, C.c_void_p(tiles_all.data_ptr()), world, 0, ocap, want_counts=False)
-            eng.shard_owned_expand(world, 0, ocap, C.c_void_p(send.data_ptr()), C.c_void_p(orow.data_ptr()), world * ocap)
-        eng.synchronize()
-        r = eng.get_timing(capi.MP_K_BIN_DRAWS)
-        g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
-        print(f"world {world}: owner-keeps count (table + own draws + plan) {r[0] / r[1] * 1e3:.1f} us, place {g[0] / g[1] * 1e3:.1f} us", flush=True)
+        for scheme, name in ((0, "multinomial"), (1, "systematic"), (2, "stratified")):
+            eng.synchronize()
+            eng.set_timing(False)
+            eng.set_timing(True)
+            for _ in range(12):
+                eng.shard_owned_count(scheme, C.c_void_p(tiles_all.data_ptr()), world, 0, ocap, want_counts=False)
+                eng.shard_owned_expand(world, 0, ocap, C.c_void_p(send.data_ptr()), C.c_void_p(orow.data_ptr()), world * ocap)
+            eng.synchronize()
+            r = eng.get_timing(capi.MP_K_BIN_DRAWS)
+            g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
+            print(f"world {world}: owner-keeps {name}: count (table + own draws + plan) {r[0] / r[1] * 1e3:.1f} us, resolve {g[0] / g[1] * 1e3:.1f} us",
+                  flush=True)
         eng.close()
 
 
