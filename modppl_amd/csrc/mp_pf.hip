@@ -454,7 +454,7 @@ struct mp_pf {
     unsigned int* ow_ticket = nullptr;
     u64 ow_last_cap = 0;                  // capacity of the last mp_pf_shard_owned_expand (0 = exact sizes: nothing can overflow)
     unsigned long long ow_seq = 0;        // owner-keeps resamples planned so far: the plan of number k writes pub->seq = k last
-    int ow_nsc = 0, ow_R = 0;
+    int ow_nsc = 0, ow_R = 0, ow_wgs = 0;
     int ow_world = 0;
     int ow_scheme = 0;
     bool sharded = false;
@@ -1353,10 +1353,14 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         pa.sccnt = h->ow_sccnt; pa.cnt_r = h->ow_cnt_r; pa.c_all = h->ow_call;
         pa.scal = h->scal; pa.undo = h->scal_undo; pa.head = solo_tab ? (const mp_tab_head*)h->tab_head : nullptr;
         pa.base = h->ow_base; pa.plan_out = h->ow_plan; pa.pub = h->d_pub; pa.seq = ++h->ow_seq;
+        pa.range = h->ow_range; pa.Wd = (u64)h->ow_R * OWN_ROUND;
         const bool tab_lds = h->nt <= K1_TABLE_LDS_MAX_TILES;
         const size_t lds = sizeof(u64) * (size_t)h->ow_R * OWN_ROUND + (tab_lds ? (size_t)h->nt * 24 : 0);
-        auto kern = tab_lds ? k_shard_own_bin<1> : k_shard_own_bin<2>;
-        hipLaunchKernelGGL(kern, dim3(h->ow_nsc), dim3(OWN_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
+        auto kern = scheme ? (tab_lds ? k_shard_own_bin<1, true> : k_shard_own_bin<2, true>) : (tab_lds ? k_shard_own_bin<1, false> : k_shard_own_bin<2, false>);
+        // lattice: a rank's own draws are ~n consecutive ones, wherever they start: that many workgroups (a rank that owns more takes turns)
+        const int own_wgs = scheme ? (int)std::min<u64>((u64)h->ow_nsc, 2 * ((h->n + OWN_ROUND - 1) / OWN_ROUND) + 2) : h->ow_nsc;
+        h->ow_wgs = own_wgs;
+        hipLaunchKernelGGL(kern, dim3(own_wgs), dim3(OWN_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
                            h->resample_count, (int)scheme, h->ow_R, t_incl, t_W, t_ratio, h->nt, world, rank, (const unsigned short*)h->guide,
                            (const mp_own_range*)h->ow_range, h->ow_seg_lt, h->ow_seg_row, h->ow_seg_r, h->ow_permc, h->ow_seg_cnt, pa);
         hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, pa);
@@ -1383,12 +1387,14 @@ int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t
     h->ow_last_cap = capacity;
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        const unsigned groups = (unsigned)((h->ow_nsc + OWB_GC - 1) / OWB_GC);
-        hipLaunchKernelGGL(k_shard_own_resolve, dim3(groups * 8), dim3(OWB_THREADS), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank,
+        const unsigned groups = (unsigned)((h->ow_wgs + OWB_GC - 1) / OWB_GC);
+        auto kern = h->ow_scheme ? k_shard_own_resolve<true> : k_shard_own_resolve<false>;
+        hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(OWB_THREADS), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank,
                            h->ow_R, h->ow_nsc, (u64)capacity, (u64)recv_rows, (const u64*)h->ow_seg_lt, (const uint32_t*)h->ow_seg_row,
                            (const unsigned short*)h->ow_seg_r, (const unsigned short*)h->ow_permc, (const unsigned short*)h->ow_seg_cnt,
                            (const uint32_t*)h->ow_sccnt, (const uint32_t*)h->ow_base, (const mp_cx*)h->cx, (const double*)h->x[h->cur],
-                           (const mp_owned_plan*)h->ow_plan, (const unsigned long long*)h->ow_call, d_rows, d_send_out, h->sh_req_slot);
+                           (const mp_owned_plan*)h->ow_plan, (const unsigned long long*)h->ow_call, d_rows, d_send_out, h->sh_req_slot,
+                           h->ow_scheme ? (const mp_own_range*)h->ow_range : (const mp_own_range*)nullptr);
     }
     return check_launch("k_shard_own_resolve");
 }

@@ -491,6 +491,12 @@ constexpr int OWN_RMAX = 4;                  // rounds per workgroup at most (LD
 constexpr int OWN_NW = OWN_THREADS / 64;
 __host__ __device__ inline int mp_own_rounds(int world) { return world < OWN_RMAX ? world : OWN_RMAX; }
 
+// lattice schemes: first and last super-chunk (of Wd draws) that hold a draw of this rank (last < first: none)
+__device__ __forceinline__ void mp_own_span(const mp_own_range* range, u64 Wd, int* sc_first, int* sc_last) {
+    const u64 glo = range->g_lo, ghi = range->g_hi;
+    *sc_first = (int)(glo / Wd);
+    *sc_last = ghi > glo ? (int)((ghi - 1) / Wd) : *sc_first - 1;
+}
 // tile of a target inside ONE rank's tiles.  `incl` = the rank's entries of the job's inclusive prefix, either as they
 // are (tabs = target, excl0 = prefix below the rank's first tile) or rebased to the rank's share (tabs = trel, excl0 = 0)
 __device__ __forceinline__ void mp_locate_own(const u64* incl, const u64* W_, const double* ratio, uint32_t nt, u64 tabs, u64 trel, u64 excl0,
@@ -531,6 +537,8 @@ struct mp_own_plan_args {
     mp_owned_plan* plan_out;
     mp_shard_pub* pub;               // host-mapped
     unsigned long long seq;
+    const mp_own_range* range;       // lattice: only the super-chunks of the own range were written (and are scanned)
+    u64 Wd;
 };
 // by ONE workgroup of THREADS threads
 template <int THREADS>
@@ -541,13 +549,21 @@ __device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a) {
     __shared__ u64 s_c[SH_MAX_WORLD];
     __shared__ int s_over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int world = a.world, nsc = a.nsc;
+    const int world = a.world;
+    int nsc = a.nsc;
+    const uint32_t* sccnt = a.sccnt;
+    uint32_t* base = a.base;
+    if (a.lattice) {
+        int f, l;
+        mp_own_span(a.range, a.Wd, &f, &l);
+        sccnt += f; base += f; nsc = l - f + 1;
+    }
     // every load this workgroup depends on goes out now (one round trip instead of three in a kernel that is all latency)
     const int per = (nsc + THREADS - 1) / THREADS;   // scan below: thread t owns entries [t * per, (t + 1) * per)
     const int b0 = tid * per;
     u64 run = 0;
     for (int j = 0; j < per; ++j)
-        if (b0 + j < nsc) run += a.sccnt[b0 + j];
+        if (b0 + j < nsc) run += sccnt[b0 + j];
     const double scal_L = a.scal->L;
     const int scal_deg = a.scal->degenerate;
     if (a.lattice) {   // k_shard_table found the counts in closed form
@@ -595,8 +611,8 @@ __device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a) {
     u64 off = woff + (incl - run);
     for (int j = 0; j < per; ++j) {
         if (b0 + j < nsc) {
-            a.base[b0 + j] = (uint32_t)off;
-            off += a.sccnt[b0 + j];
+            base[b0 + j] = (uint32_t)off;
+            off += sccnt[b0 + j];
         }
     }
     // every rank must reach the same verdict on "some pair needs more than cap rows" (the collective that follows is symmetric),
@@ -626,7 +642,7 @@ __device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a) {
 constexpr int SHP_THREADS = 1024;
 __global__ __launch_bounds__(SHP_THREADS) void k_shard_own_plan(mp_own_plan_args a) { mp_own_plan<SHP_THREADS>(a); }
 
-template <int TABMODE>   // 1: this rank's part of the tile table copied to LDS (rebased); 2: probed where it lies (more than 1024 tiles)
+template <int TABMODE, bool LATTICE>   // TABMODE 1: this rank's part of the tile table copied to LDS (rebased); 2: probed where it lies (more than 1024 tiles)
 __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_shard_own_bin(
     u64 n, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme, int R, const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
     const double* __restrict__ ratio_all, int nt_local, int world, int rank, const unsigned short* __restrict__ guide,
@@ -645,9 +661,7 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     __shared__ uint32_t s_bincnt[8], s_binoff[8], s_binrun[8];
     __shared__ uint32_t s_cntr[SH_MAX_WORLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sc = blockIdx.x;
     const u64 Wd = (u64)R * OWN_ROUND;                                  // draws (and window entries) per super-chunk
-    const u64 g_base = (u64)sc * Wd;
     const u64* my_incl = incl_all + (u64)rank * nt_local;
     const u64* my_W = tW_all + (u64)rank * nt_local;
     const double* my_ratio = ratio_all + (u64)rank * nt_local;
@@ -658,18 +672,11 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         *pa.undo = *pa.scal;
         fold_scalars(pa.scal, pa.head->Q, pa.head->Q2, pa.S, pa.head->m, n_global, 0);
     }
-    auto publish = [&](uint32_t own_) {   // this super-chunk's counts, for k_shard_own_plan
-        if (tid == 0) pa.sccnt[sc] = own_;
-        if (scheme == 0 && tid < world) pa.cnt_r[(u64)sc * world + tid] = world > 1 ? s_cntr[tid] : own_;
-    };
-    if (scheme) {   // lattice: super-chunks without a draw of this rank leave at once
-        const u64 glo = range->g_lo, ghi = range->g_hi;
-        if (g_base >= ghi || g_base + Wd <= glo) {
-            if (tid < 8) seg_cnt[(u64)sc * 8 + tid] = 0;
-            publish(0u);
-            return;
-        }
-    }
+    // multinomial: workgroup = super-chunk; lattice: the super-chunks that hold this rank's own range of draws, dealt round-robin
+    // (LATTICE is a template parameter so that the multinomial form stays straight-line code: as a run-time loop it cost 15
+    // more registers and 2 us)
+    int sc_first = 0, sc_last = (int)gridDim.x - 1;
+    if constexpr (LATTICE) mp_own_span(range, Wd, &sc_first, &sc_last);
     if constexpr (TABMODE == 1) {
         for (int b = tid; b < nt_local; b += OWN_THREADS) {
             s_incl_lds[b] = my_incl[b] - lo;
@@ -678,10 +685,12 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         }
     }
     for (int r = tid; r < world; r += OWN_THREADS) s_bound[r] = incl_all[(u64)(r + 1) * nt_local - 1];
-    if (tid < 8) { s_bincnt[tid] = 0u; s_binrun[tid] = 0u; }
-    __syncthreads();
     const bool count_all = scheme == 0 && world > 1;
     const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+    for (int sc = sc_first + (int)blockIdx.x; sc <= sc_last; sc += (int)gridDim.x) {   // workgroup-uniform; one trip unless LATTICE
+    const u64 g_base = (u64)sc * Wd;
+    if (tid < 8) { s_bincnt[tid] = 0u; s_binrun[tid] = 0u; }
+    __syncthreads();
     uint32_t above_acc = 0u;   // lane r: draws of this wave above boundary r (r < world - 1)
     uint32_t run = 0u;         // own draws of the rounds so far (uniform)
 #pragma unroll 1
@@ -741,7 +750,8 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         }
         __syncthreads();
     }
-    publish(own);
+    if (tid == 0) pa.sccnt[sc] = own;   // this super-chunk's counts, for k_shard_own_plan
+    if (scheme == 0 && tid < world) pa.cnt_r[(u64)sc * world + tid] = world > 1 ? s_cntr[tid] : own;
     // ---- the compacted own draws: bins first (their sizes fix where each bin's entries start in the window) ----
     const u64 span = hi - lo;
     const double eight_over_span = 8.0 / (double)span;           // own > 0 implies span > 0
@@ -830,26 +840,35 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         }
         __syncthreads();
     }
+    if constexpr (!LATTICE) break;
+    __syncthreads();   // the next super-chunk of this workgroup reuses the LDS state
+    }
 }
 
 constexpr int OWB_THREADS = 256;
 constexpr int OWB_GC = 2;   // super-chunks per workgroup: (bin, 2 super-chunks) holds ~256 entries in a world of <= 4 ranks
+template <bool LATTICE>
 __global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_shard_own_resolve(
     u64 n, u64 slot_offset, int D, int world, int rank, int R, int nsc, u64 cap, u64 recv_rows, const u64* __restrict__ seg_lt,
     const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_r, const unsigned short* __restrict__ permc,
     const unsigned short* __restrict__ seg_cnt, const uint32_t* __restrict__ sccnt, const uint32_t* __restrict__ base, const mp_cx* __restrict__ cx,
     const double* __restrict__ x, const mp_owned_plan* __restrict__ plan, const unsigned long long* __restrict__ c_all, double* __restrict__ rows,
-    double* __restrict__ send, uint32_t* __restrict__ inv) {
+    double* __restrict__ send, uint32_t* __restrict__ inv, const mp_own_range* __restrict__ range) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int bin = blockIdx.x & 7, group = blockIdx.x >> 3;
+    const int bin = blockIdx.x & 7;
     const u64 Wd = (u64)R * OWN_ROUND;
+    int sc_first = 0, sc_last = nsc - 1;
+    if constexpr (LATTICE) mp_own_span(range, Wd, &sc_first, &sc_last);   // only the own range's super-chunks hold entries
+    const u64 PS_me = plan->PS[rank];
+    const int G = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : 16));   // lanes of a row group when states are wider than one double
+    for (int group = (int)(blockIdx.x >> 3); sc_first + group * OWB_GC <= sc_last; group += (int)(gridDim.x >> 3)) {   // uniform
     // headers of this workgroup's super-chunks (uniform loads)
     uint32_t cntb[OWB_GC], binoff[OWB_GC], base_k[OWB_GC], tot_k[OWB_GC];
     int sck[OWB_GC];
 #pragma unroll
     for (int k = 0; k < OWB_GC; ++k) {
-        const int s_ = group * OWB_GC + k;
-        const bool ok = s_ < nsc;
+        const int s_ = sc_first + group * OWB_GC + k;
+        const bool ok = s_ <= sc_last;
         sck[k] = ok ? s_ : 0;
         const uint4 c4 = *reinterpret_cast<const uint4*>(seg_cnt + (u64)sck[k] * 8);
         const uint32_t c[8] = {c4.x & 0xFFFFu, c4.x >> 16, c4.y & 0xFFFFu, c4.y >> 16, c4.z & 0xFFFFu, c4.z >> 16, c4.w & 0xFFFFu, c4.w >> 16};
@@ -865,7 +884,6 @@ __global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         tot_k[k] = ok ? sccnt[sck[k]] : 0u;
     }
     const uint32_t total = cntb[0] + cntb[1];
-    const u64 PS_me = plan->PS[rank];
     uint32_t pc_first = 0u;   // first permc entry of this lane's share of inv[] (below): its load goes out with the entries'
     {
         const int k = tid >> 7;
@@ -873,7 +891,6 @@ __global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         const uint32_t r = (uint32_t)(((u64)tot * (u64)bin) >> 3) + (uint32_t)(tid & 127);
         if (r < (uint32_t)(((u64)tot * (u64)(bin + 1)) >> 3)) pc_first = permc[(u64)(k ? sck[1] : sck[0]) * Wd + r];
     }
-    const int G = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : 16));   // lanes of a row group when states are wider than one double
     for (uint32_t idx0 = 0; idx0 < total; idx0 += OWB_THREADS) {   // uniform trip count
         const uint32_t idx = idx0 + (uint32_t)tid;
         const bool act = idx < total;
@@ -961,6 +978,8 @@ __global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
             r += 128u;
             if (r < r_hi) pc = permc[pbase + r];
         }
+    }
+    if constexpr (!LATTICE) break;   // multinomial: one group per workgroup, straight-line code
     }
     // slots this rank could not fill itself: where in the receive buffer their rows will arrive
     const u64 c_me = c_all[rank];
