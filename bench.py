@@ -260,10 +260,14 @@ def main():
         timer = pf.engine
 
     def barrier():
+        # the filter's own stream first, by polling (mp_pf_synchronize spins on hipStreamQuery: it returns within a microsecond of
+        # the last kernel, where a blocking synchronize wakes the host tens of microseconds late — 3-5 % of a 20-step region);
+        # then the device-wide synchronize the contract asks for, which finds nothing left to wait for
+        pf.synchronize()
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        pf.synchronize()
+            torch.cuda.synchronize()
 
     pf.init_step(None, ys[:1])
     pf.resample(sync=False)
@@ -359,7 +363,7 @@ def main():
         sharded_path = world > 1 or force_sharded
         if sharded_path:   # the sharded filter runs other kernels for the resample
             if getattr(pf, "exchange", "") == "owned":
-                KERNEL_OF.update({"bin_draws": "k_shard_table + k_shard_own_draws + k_shard_own_plan", "resample_gather": "k_shard_own_place"})
+                KERNEL_OF.update({"bin_draws": "k_shard_table + k_shard_own_bin + k_shard_own_plan", "resample_gather": "k_shard_own_resolve"})
             else:
                 KERNEL_OF.update({"bin_draws": "k_shard_route_fused", "resample_gather": "k_shard_resolve_binned"})
         roofline = None

@@ -13,9 +13,11 @@ import glob
 import json
 import sys
 
-FAM = {"k_propagate": "propagate", "k_normalize_tiles": "normalize_scan", "k_resample_gather": "resample_gather",
-       "k_bin_draws": "bin_draws", "k_resolve_bins": "resample_gather"}
-STREAMING = {"propagate", "normalize_scan", "bin_draws"}
+# one kernel per family: the kernels of the bench's multinomial step (the single-kernel resampler of the supplementary
+# systematic leg is listed on its own)
+FAM = {"k_propagate<mp_lgssm1": "propagate", "k_normalize_tiles": "normalize_scan", "k_bin_draws": "bin_draws",
+       "k_resolve_bins": "resample_gather", "k_resample_gather": "resample_single_kernel"}
+STREAMING = {"propagate", "normalize_scan", "bin_draws"}   # (k_bin_draws reads little: Philox in, segments out)
 
 
 NAMES = {}   # family -> kernel names seen (bench.py checks them against the kernels it times)
