@@ -216,9 +216,13 @@ int32_t mp_pf_shard_query_packed(mp_pf* h, const uint64_t* d_tiles_all, int32_t 
  *                             (= destination order), received rows in unit order (= source order).
  *   mp_pf_shard_owned_commit  waits for the plan of the count (not for the expand or the exchange: they are ordered before
  *                             the next step on the filter's stream) and commits as mp_pf_shard_commit_fixed does (the next
- *                             step reads states from d_rows).  MP_ERR_CAPACITY: the verdict above (all ranks reach the same
- *                             one); nothing was committed, counts_out holds the offspring per rank, repeat the expand with
- *                             capacity 0 and exact-size buffers, exchange, commit again. */
+ *                             step reads states from d_rows).  With log_total_weight and counts_out both NULL the wait is for
+ *                             one polled word of host-mapped memory (the verdict), and in a world of one — nothing to exchange,
+ *                             nothing to overflow — there is no wait at all (degenerate weights then surface at the next
+ *                             synchronising call, as for mp_pf_resample without a log_total_weight); with either, the call
+ *                             waits for the filter's stream.  MP_ERR_CAPACITY: the verdict above (all ranks reach the same
+ *                             one); nothing was committed; call again with counts_out to get the offspring per rank (same
+ *                             verdict), then repeat the expand with capacity 0 and exact-size buffers, exchange, commit. */
 int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
                                 uint64_t* counts_out);
 int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t capacity, double* d_send_out, double* d_rows, uint64_t recv_rows);

@@ -161,11 +161,12 @@ struct ModelOpsT : ModelOps {
         }
         if constexpr (std::is_same<Model, mp_lgssm_dense<16>>::value) {
             // the dense transition's products on the matrix cores (k_propagate_dense16); MP_DENSE_MFMA=0 keeps the scalar
-            // interpretation of the same functor (same bits), as does a sharded handle's exchange-row input
+            // interpretation of the same functor (same bits)
             static const bool mfma = [] { const char* e = getenv("MP_DENSE_MFMA"); return !(e && e[0] == '0'); }();
-            if (mfma && a.inv == nullptr) {
+            if (mfma) {
                 hipLaunchKernelGGL(k_propagate_dense16, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
-                                   a.x_out, a.logw, a.obs, a.overwrite, a.perm, a.res_parent, a.nchunks, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux);
+                                   a.x_out, a.logw, a.obs, a.overwrite, a.perm, a.res_parent, a.nchunks, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux,
+                                   a.inv, a.res_x);
                 return;
             }
         }
@@ -561,7 +562,7 @@ static int32_t fetch_scalars(mp_pf* h) {
 static int32_t materialize(mp_pf* h) {
     if (h->sh_lazy) {
         hipLaunchKernelGGL(k_shard_adopt_rows, dim3((unsigned)((h->n + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, h->stream, h->n,
-                           h->ops->dim_state, h->sh_rows, h->sh_req_slot, h->x[h->cur], h->parent);
+                           h->ops->dim_state, h->sh_rows, h->sh_req_slot, (const double*)h->x[h->cur ^ 1], h->slot_offset, h->x[h->cur], h->parent);
         h->sh_lazy = false;
         h->sh_parents_lazy = false;
         int32_t rc = check_launch("k_shard_adopt_rows");
@@ -608,7 +609,9 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     // after a binned resample of a filter with dim_state > 1 this propagate gathers the parents' states itself, from the
     // pre-resample buffer into the other one
     const bool gather_here = h->permuted && !h->sh_lazy && h->ops->dim_state > 1;
-    a.x_in = h->x[h->cur]; a.x_out = gather_here ? h->x[h->cur ^ 1] : h->x[h->cur];
+    // (after a sharded commit x[cur ^ 1] still holds the pre-resample states: kept offspring of the owner-keeps exchange read
+    // their parents there when states are wider than one double)
+    a.x_in = h->sh_lazy ? h->x[h->cur ^ 1] : h->x[h->cur]; a.x_out = gather_here ? h->x[h->cur ^ 1] : h->x[h->cur];
     a.res_parent = h->res_parent;
     a.logw = h->logw;
     for (int j = 0; j < MP_MAX_OBS; ++j) a.obs.v[j] = (j < h->ops->dim_obs) ? obs[j] : 0.;
@@ -991,7 +994,7 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
     }
     if (h->sh_parents_lazy) {
         hipLaunchKernelGGL(k_shard_adopt_parents, dim3((unsigned)((h->n + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, h->stream, h->n,
-                           h->ops->dim_state, h->sh_rows, h->sh_req_slot, h->parent);
+                           h->ops->dim_state, h->sh_rows, h->sh_req_slot, h->slot_offset, h->parent);
         h->sh_parents_lazy = false;
         int32_t rcp = check_launch("k_shard_adopt_parents");
         if (rcp != MP_OK) return rcp;
@@ -1175,6 +1178,7 @@ int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     if (world < 1 || world > SH_MAX_WORLD || rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, 0 <= rank < world");
     if ((u64)world * h->n != h->n_global) return mp_fail(MP_ERR_INVALID_ARG, "equal tile-aligned shards: world * n_particles must equal n_global");
     if (capacity == 0) return mp_fail(MP_ERR_INVALID_ARG, "capacity must be > 0");
+    if ((u64)world * SH_BINS * capacity >= (1ull << 31)) return mp_fail(MP_ERR_INVALID_ARG, "exchange buffer rows must be < 2^31 (row indices carry a flag bit)");
     HIPCK(hipSetDevice(h->device));
     int32_t rc = shard_scratch(h, world, capacity);
     if (rc != MP_OK) return rc;
@@ -1382,7 +1386,7 @@ int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t
     if (!h->ow_seg_lt || h->ow_world != world) return mp_fail(MP_ERR_STATE, "shard_owned_expand before shard_owned_count");
     if (rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "0 <= rank < world");
     if (capacity && recv_rows != (uint64_t)world * capacity) return mp_fail(MP_ERR_INVALID_ARG, "fixed capacity: recv_rows must be world * capacity");
-    if (recv_rows + h->n >= (1ull << 32)) return mp_fail(MP_ERR_INVALID_ARG, "exchange buffer rows must be < 2^32");
+    if (recv_rows + h->n >= (1ull << 31)) return mp_fail(MP_ERR_INVALID_ARG, "exchange buffer rows must be < 2^31 (row indices carry a flag bit)");
     HIPCK(hipSetDevice(h->device));
     h->ow_last_cap = capacity;
     {

@@ -720,7 +720,10 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagat
             if (inv) {
                 // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row
                 // {x[0..D), parent id} is row inv[i] of the exchange buffer (res_x here)
-                const double* row = res_x + (u64)pm[p] * (u64)(D + 1);
+                // (owner-keeps exchange, D > 1: a kept offspring has no row — its entry names the parent's local row of the
+                // pre-resample buffer x_in; mp_pf_shard_kernels.h MP_INV_LOCAL)
+                const bool local_parent = D > 1 && (pm[p] & 0x80000000u);
+                const double* row = local_parent ? x_in + (u64)(pm[p] & 0x7FFFFFFFu) * D : res_x + (u64)pm[p] * (u64)(D + 1);
 #pragma unroll
                 for (int d = 0; d < D; ++d) prev[d] = row[d];
             } else if (perm) {
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
                                                                      int overwrite, const unsigned short* __restrict__ perm,
                                                                      const uint32_t* __restrict__ res_parent, int nchunks, mp_cx* __restrict__ cx,
                                                                      unsigned short* __restrict__ guide, double* tile_m, u64* tile_W, u64* tile_W2,
-                                                                     mp_k1_aux aux) {
+                                                                     mp_k1_aux aux, const uint32_t* __restrict__ inv, const double* __restrict__ rows) {
     constexpr int D = 16, ZP = D + 1;   // z rows padded by one double: the transposed reads then spread over the LDS banks
     __shared__ double s_z[DENSE_THREADS / 64][64][ZP];
     __shared__ double s_lw[TILE], s_x0[TILE];
@@ -825,18 +828,25 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
             }
         }
         // where this particle's previous state lives (slot order, or the parent's row after a binned resample)
-        u64 myrow = p;
-        if (perm && live) {
+        // (as an address: after a sharded resample it is a row of the exchange buffer, or — kept offspring of the owner-keeps
+        // exchange — the parent's row of the pre-resample buffer x_in)
+        const double* myrow = x_in + p * D;
+        if (inv && live) {
+            const uint32_t v = inv[p];
+            myrow = (v & 0x80000000u) ? x_in + (u64)(v & 0x7FFFFFFFu) * D : rows + (u64)v * (u64)(D + 1);
+        } else if (perm && live) {
             const uint32_t pr_ = perm[p];
-            myrow = res_parent[MP_SEG_POS(pr_ >> 10, p >> 10, pr_ & 1023u, nchunks)];
+            myrow = x_in + (u64)res_parent[MP_SEG_POS(pr_ >> 10, p >> 10, pr_ & 1023u, nchunks)] * D;
         }
+        const u64 myaddr = (u64)(uintptr_t)myrow;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {
             const int src = 16 * g + li;                       // the lane that owns this column's particle
-            const u64 row = ((u64)(uint32_t)__shfl((int)(myrow >> 32), src, 64) << 32) | (u64)(uint32_t)__shfl((int)myrow, src, 64);
+            const double* xrow = reinterpret_cast<const double*>((uintptr_t)(((u64)(uint32_t)__shfl((int)(myaddr >> 32), src, 64) << 32) |
+                                                                              (u64)(uint32_t)__shfl((int)myaddr, src, 64)));
             const bool live_i = __shfl((int)live, src, 64) != 0;
             const int pl_i = wave * 256 + rd * 64 + src;
             const u64 p_i = tile0 + (u64)pl_i;
@@ -844,7 +854,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
             if (t != 0) {   // uniform
                 double xk[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) xk[s] = live_i ? x_in[row * D + lg + 4 * s] : 0.;
+                for (int s = 0; s < 4; ++s) xk[s] = live_i ? xrow[lg + 4 * s] : 0.;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) mean = __builtin_amdgcn_mfma_f64_16x16x4f64(amat[s], xk[s], mean, 0, 0, 0);
             }

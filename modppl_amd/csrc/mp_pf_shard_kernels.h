@@ -7,6 +7,7 @@
 // tiles of the job; every rank gathers all tiles' (m, W, W2) and builds the same table.
 // ---------------------------------------------------------------------------------------------
 constexpr int SH_THREADS = 256;
+constexpr uint32_t MP_INV_LOCAL = 0x80000000u;   // inv[] entry of a kept offspring with a wide state: | the parent's local row
 constexpr int SH_MAX_WORLD = 64;
 
 // pass 1: target of every local slot -> owner rank, tile inside the owner's shard, tile-local target; owner histogram
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     }
     const uint32_t total = cntb[0] + cntb[1];
     uint32_t pc_first = 0u;   // first permc entry of this lane's share of inv[] (below): its load goes out with the entries'
-    {
+    if (D == 1) {
         const int k = tid >> 7;
         const uint32_t tot = k ? tot_k[1] : tot_k[0];
         const uint32_t r = (uint32_t)(((u64)tot * (u64)bin) >> 3) + (uint32_t)(tid & 127);
@@ -925,10 +926,16 @@ __global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
             const u64 bk = k ? base_k[1] : base_k[0];
             const u64 p = bk + r;
             if (p < n) {
-                // kept: at the entry's own place (coalesced); the one super-chunk that straddles slot n keeps draw order, so
-                // that the kept rows stay within n rows
-                const bool straddle = bk + (k ? tot_k[1] : tot_k[0]) > n;
-                dst = rows + (recv_rows + (straddle ? p : bk + s)) * (u64)(D + 1);
+                if (D > 1) {
+                    // kept, wide state: nothing is copied — the offspring lives on its parent's rank, so the next propagate
+                    // gathers the parent's state from the pre-resample buffer, as the unsharded filter does
+                    inv[p] = MP_INV_LOCAL | (uint32_t)i;
+                } else {
+                    // kept: at the entry's own place (coalesced); the one super-chunk that straddles slot n keeps draw order,
+                    // so that the kept rows stay within n rows
+                    const bool straddle = bk + (k ? tot_k[1] : tot_k[0]) > n;
+                    dst = rows + (recv_rows + (straddle ? p : bk + s)) * (u64)(D + 1);
+                }
             } else {
                 const u64 u = PS_me + (p - n);
                 int s2 = 0;
@@ -963,7 +970,7 @@ __global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         }
     }
     // where slot p finds its row (draw order, coalesced): the 8 workgroups of a group take an eighth of each super-chunk's range
-    {
+    if (D == 1) {
         const int k = tid >> 7;                                  // 128 lanes per super-chunk
         const uint32_t tot = k ? tot_k[1] : tot_k[0];
         const uint32_t r_lo = (uint32_t)(((u64)tot * (u64)bin) >> 3), r_hi = (uint32_t)(((u64)tot * (u64)(bin + 1)) >> 3);
@@ -1005,22 +1012,33 @@ __global__ void k_shard_publish(int* overflow, const mp_dev_scalars* scal, mp_sh
     pub->degenerate = scal->degenerate;
     pub->overflow = atomicOr(overflow, 0);
 }
-// requester side, only when something other than the next propagate needs slot order: x[i], parent[i] from row inv[i]
+// requester side, only when something other than the next propagate needs slot order: x[i], parent[i] from row inv[i].
+// Owner-keeps exchange with states wider than one double: a kept offspring has no row — inv[i] = MP_INV_LOCAL | parent's
+// local row, its state is the parent's in the pre-resample buffer x_old.
 __global__ __launch_bounds__(SH_THREADS) void k_shard_adopt_rows(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ inv,
-                                                                 double* __restrict__ x_new, uint32_t* __restrict__ parent) {
+                                                                 const double* __restrict__ x_old, u64 slot_offset, double* __restrict__ x_new,
+                                                                 uint32_t* __restrict__ parent) {
     const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
     if (i >= n) return;
-    const double* in = rows + (u64)inv[i] * (u64)(D + 1);
+    const uint32_t v = inv[i];
+    if (D > 1 && (v & MP_INV_LOCAL)) {
+        const u64 pr = v & ~MP_INV_LOCAL;
+        for (int d = 0; d < D; ++d) x_new[i * D + d] = x_old[pr * D + d];
+        parent[i] = (uint32_t)(slot_offset + pr);
+        return;
+    }
+    const double* in = rows + (u64)v * (u64)(D + 1);
     for (int d = 0; d < D; ++d) x_new[i * D + d] = in[d];
     parent[i] = (uint32_t)in[D];
 }
 
 // parents alone (a step has already consumed the states of those rows)
 __global__ __launch_bounds__(SH_THREADS) void k_shard_adopt_parents(u64 n, int D, const double* __restrict__ rows, const uint32_t* __restrict__ inv,
-                                                                    uint32_t* __restrict__ parent) {
+                                                                    u64 slot_offset, uint32_t* __restrict__ parent) {
     const u64 i = (u64)blockIdx.x * SH_THREADS + threadIdx.x;
     if (i >= n) return;
-    parent[i] = (uint32_t)rows[(u64)inv[i] * (u64)(D + 1) + D];
+    const uint32_t v = inv[i];
+    parent[i] = (D > 1 && (v & MP_INV_LOCAL)) ? (uint32_t)(slot_offset + (v & ~MP_INV_LOCAL)) : (uint32_t)rows[(u64)v * (u64)(D + 1) + D];
 }
 
 // out[i] = a[i] - *b  (log_normalized_weights = w_i - log_total_weight, importance.rs:23-25)

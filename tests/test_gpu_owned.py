@@ -21,6 +21,9 @@ def _model(d, T):
     import modppl_amd
     if d == 1:
         return modppl_amd.lgssm_model(*O.LGSSM_PARAMS), O.lgssm_observations(T).reshape(T, 1)
+    if d == "dense16":   # the matrix-core kernel reads its inputs from the exchange rows / the parents' rows too
+        from tests.test_gpu_dense import dense_problem
+        return modppl_amd.lgssm_dense_model(*dense_problem(7), 1.0), np.random.default_rng(3).normal(0, 1.2, size=(T, 16))
     return modppl_amd.lgssm_band_model(d), np.random.default_rng(3).normal(0, 1.2, size=(T, d))
 
 
@@ -112,6 +115,8 @@ class _ByHand:
     (1, 2, 8192, 8192, True, 1, 6.0),      # systematic
     (1, 3, 4096, 64, True, 2, 6.0),        # stratified, odd world
     (16, 2, 2048, 2048, True, 0, 6.0),
+    ("dense16", 2, 2048, 64, False, 0, 6.0),
+    ("dense16", 3, 2048, 0, True, 0, 6.0),
     (1, 8, 2048, 256, True, 0, 6.0),       # eight ranks: several donors and receivers in the plan
     (2, 8, 2048, 0, False, 0, 14.0),
 ])
