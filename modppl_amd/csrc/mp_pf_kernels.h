@@ -71,24 +71,40 @@ constexpr int K1_TABLE_LDS_MAX_TILES = 1024;     // k_bin_draws copies the prebu
 template <class Model>
 constexpr int k1_items() { return Model::MAX_NORMALS >= 4 ? 1 : 4 / Model::MAX_NORMALS; }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+// Wave-wide reductions and scans on the DPP path (row_shr within the 16-lane rows, then row_bcast:15 / row_bcast:31 across
+// rows): register-to-register, where __shfl_up / __shfl_xor go through ds_bpermute — an LDS round trip per step of a serial
+// chain.  Integer sums and fmax: any order gives the same bits.
+template <int CTRL, int ROW_MASK, bool ZERO>
+__device__ __forceinline__ u64 mp_dpp_u64(u64 old, u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)old, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, ZERO);
+    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(old >> 32), (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, ZERO);
+    return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
+}
+__device__ __forceinline__ u64 mp_readlane_u64(u64 v, int l) {
+    return ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+// inclusive scan across the 64 lanes of a wave (lanes without a source add 0)
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int /*lane*/) {
+    v += mp_dpp_u64<0x111, 0xF, true>(0ull, v);   // row_shr:1
+    v += mp_dpp_u64<0x112, 0xF, true>(0ull, v);   // row_shr:2
+    v += mp_dpp_u64<0x114, 0xF, true>(0ull, v);   // row_shr:4
+    v += mp_dpp_u64<0x118, 0xF, true>(0ull, v);   // row_shr:8
+    v += mp_dpp_u64<0x142, 0xA, false>(0ull, v);  // row_bcast:15 into rows 1 and 3
+    v += mp_dpp_u64<0x143, 0xC, false>(0ull, v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// inclusive scan across the 64 lanes of a wave
-__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const u64 t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) { return mp_readlane_u64(wave_incl_scan_u64(v, 0), 63); }
+__device__ __forceinline__ double wave_max(double x) {   // lanes without a source keep their own value
+    u64 v = mp_f2u(x);
+#define MP_MAX_STEP(CTRL, MASK) v = mp_f2u(fmax(mp_u2f(v), mp_u2f(mp_dpp_u64<CTRL, MASK, false>(v, v))))
+    MP_MAX_STEP(0x111, 0xF);
+    MP_MAX_STEP(0x112, 0xF);
+    MP_MAX_STEP(0x114, 0xF);
+    MP_MAX_STEP(0x118, 0xF);
+    MP_MAX_STEP(0x142, 0xA);
+    MP_MAX_STEP(0x143, 0xC);
+#undef MP_MAX_STEP
+    return mp_u2f(mp_readlane_u64(v, 63));
 }
 __device__ __forceinline__ u64 mp_quantize(double e, double scale) {
     const double r = rint(e * scale);
@@ -160,6 +176,55 @@ __device__ __forceinline__ void build_tile_table_global(const double* tile_m, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (nt + THREADS - 1) / THREADS;
     const int b0 = tid * per;
+    if (per == 1) {
+        // At most one tile per thread (jobs of up to THREADS x 2048 particles: the bench's 2^20): ONE round of loads, everything
+        // in registers.  This workgroup runs after every other one has left, so its duration is added to the kernel's:
+        // the general form below (five dependent memory round trips) measured 4.8 us of a 27 us k_propagate.
+        const bool have = tid < nt;
+        const double mb = have ? mp_ld_agent(tile_m + tid) : MP_NEG_INF;
+        const u64 Wb = have ? mp_ld_agent(tile_W + tid) : 0ull;
+        const u64 W2b = have ? mp_ld_agent(tile_W2 + tid) : 0ull;
+        double m = wave_max(mb);
+        if (lane == 0) s_tred[wave] = m;
+        __syncthreads();
+        m = s_tred[0];
+#pragma unroll 1
+        for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_tred[w]);
+        const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+        const double sc = mp_u2f((u64)(1023 + tab.S - FIX_BITS) << 52);  // 2^(S-51)
+        const double d = mb - m;
+        u64 T = 0, T2 = 0;
+#pragma unroll 1
+        for (int j = 0; j < 2; ++j) {   // one mp_exp body for T_b and T2_b: the tail of k_propagate stays within its registers
+            const double f = ok ? mp_exp(j ? 2. * d : d) : 0.;
+            const u64 v = have ? mp_quantize((double)(j ? W2b : Wb) * f * sc, 1.0) : 0ull;
+            if (j) T2 = v;
+            else T = v;
+        }
+        const u64 incl = wave_incl_scan_u64(T, lane);
+        const u64 tot2 = wave_sum_u64(T2);
+        if (lane == 63) s_ttot[wave] = incl;
+        if (lane == 0) s_ttot2[wave] = tot2;
+        __syncthreads();
+        u64 woff = 0, Q = 0, Q2 = 0;
+#pragma unroll 1
+        for (int k = 0; k < THREADS / 64; ++k) {
+            const u64 tk = s_ttot[k];
+            if (k < wave) woff += tk;
+            Q += tk;
+            Q2 += s_ttot2[k];
+        }
+        if (have) {
+            tab.incl[tid] = woff + incl;
+            tab.ratio[tid] = (double)Wb / (double)T;
+        }
+        if (tid == 0) {
+            mp_tab_head h;
+            h.m = m; h.Q = Q; h.Q2 = Q2; h.S = tab.S; h.nt = nt;
+            *tab.head = h;
+        }
+        return;
+    }
     double m = MP_NEG_INF;
 #pragma unroll 1
     for (int j = 0; j < per; ++j)
