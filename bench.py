@@ -223,12 +223,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # MP_BENCH_REHEARSE=1 (never set by the driver): the N > 1 control flow on ONE GPU — all ranks share device 0 and the
+    # collectives go through gloo with host-staged buffers.  For checking this script's multi-rank legs, not for numbers.
+    rehearse = os.environ.get("MP_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    shard_kw = {"host_staging": True} if rehearse else {}
 
     import modppl_amd
     from modppl_amd import capi
@@ -256,7 +265,7 @@ def main():
         # default, moves only each rank's surplus, =exact keeps slot order and moves (G-1)/G of the particles)
         from modppl_amd.distributed import ShardedParticleSystem
 
-        pf = ShardedParticleSystem(model, n * world, 20241008, engine_kwargs={"device_index": local_rank})
+        pf = ShardedParticleSystem(model, n * world, 20241008, engine_kwargs={"device_index": local_rank}, **shard_kw)
         timer = pf.engine
 
     def barrier():
@@ -333,7 +342,7 @@ def main():
 
         n5 = 1 << 21
         obs5 = np.random.default_rng(20241008).normal(0, 1.2, size=(T, 16))
-        pf5 = ShardedParticleSystem(modppl_amd.lgssm_band_model(16), n5 * world, 20241008, engine_kwargs={"device_index": local_rank})
+        pf5 = ShardedParticleSystem(modppl_amd.lgssm_band_model(16), n5 * world, 20241008, engine_kwargs={"device_index": local_rank}, **shard_kw)
         pf5.init_step(None, obs5[:1])
         pf5.resample(sync=False)
         for t in range(1, 1 + W):
@@ -349,6 +358,8 @@ def main():
         tt = torch.tensor([dt5], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt5 = float(tt.item())
+        pf5.step(obs5[T - 1:T])
+        pf5.resample(sync=True)          # outside the timed region: a synchronous resample reports how many rows travelled
         surplus = getattr(pf5, "last_exchange_rows", None)
         c5 = {"workload": "LGSSM d=16 bootstrap SMC, 2^21 particles per GPU, one sharded filter (BASELINE.json configs[4] at 8 GPUs)",
               "particles_per_gpu": n5, "particles_total": n5 * world, "steps": K, "ms_per_step": dt5 / K * 1e3,

@@ -231,6 +231,8 @@ class ShardedParticleSystem:
             raise capi.ModpplError(capi.MP_ERR_UNSUPPORTED, "this engine has no owner-keeps exchange")
         self._host_staging = host_staging
         self._ow_keep = None
+        self.last_counts = None          # offspring per rank of the last synchronous owner-keeps resample
+        self.last_exchange_rows = None   # surplus rows it moved between ranks
         if self._owned:
             # surplus rows per pair of ranks in the equal-split all-to-all: the surplus of a rank is the spread of a
             # Binomial(N, ~1/world) count plus the imbalance of the shard masses, both O(sqrt) of n
@@ -240,6 +242,13 @@ class ShardedParticleSystem:
             ocap = max(4096, self.n // 128)
             self._ow_cap_forced = "MP_SHARD_OWNED_CAP" in os.environ   # tests: force the overflow path
             self._ow_cap = min(self.n, int(os.environ.get("MP_SHARD_OWNED_CAP", ocap)))
+            # The equal-split all-to-all moves `cap` rows to every peer whatever the surplus is: fine for 16-byte rows, not
+            # for wide states whose shard masses differ by percents (LGSSM d = 16: 3 % of 2^21 particles, 136-byte rows ->
+            # 125 MB of padding per rank and step at 8 ranks).  Beyond this many padded bytes per rank the exchange uses exact
+            # sizes (one host round trip per resample, a few percent of such a step).
+            self._ow_fixed_max_bytes = int(os.environ.get("MP_SHARD_OWNED_FIXED_MAX_BYTES", 4 << 20))
+            if self._ow_fixed and self._ow_padded_bytes(self._ow_cap) > self._ow_fixed_max_bytes and not self._ow_cap_forced:
+                self._ow_fixed = False
             if self._ow_fixed:
                 self._alloc_owned(self._ow_cap)
         if self._fixed:
@@ -265,6 +274,9 @@ class ShardedParticleSystem:
         self._fx_rows_in = self._fx_rows_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_rows_out)
         self._p_req_out, self._p_req_in = C.c_void_p(self._fx_req_out.data_ptr()), C.c_void_p(self._fx_req_in.data_ptr())
         self._p_rows_out, self._p_rows_in = C.c_void_p(self._fx_rows_out.data_ptr()), C.c_void_p(self._fx_rows_in.data_ptr())
+
+    def _ow_padded_bytes(self, cap):
+        return self.world * int(cap) * (self.model.dim_state + 1) * 8
 
     def _alloc_owned(self, cap):
         w, d = self.world, self.model.dim_state
@@ -381,13 +393,18 @@ class ShardedParticleSystem:
             if not solo:
                 dist.all_to_all_single(rows[: w * cap * (d + 1)], self._ow_send, group=self.group)
             p_rows = C.c_void_p(rows.data_ptr())
-            done, value, _ = e.shard_owned_commit(p_rows, w * cap, sync, want_counts=False)
+            done, value, cnts = e.shard_owned_commit(p_rows, w * cap, sync, want_counts=sync)   # a synchronous resample waits for the stream anyway
             if done:
+                if cnts is not None:
+                    self.last_counts = cnts[:w]
+                    self.last_exchange_rows = sum(max(int(c) - self.n, 0) for c in self.last_counts)   # rows that travelled, job-wide
                 return value
             self.fallbacks += 1      # some pair of ranks exchanges more than cap rows: exact sizes this time
             _, _, counts = e.shard_owned_commit(p_rows, w * cap, False, want_counts=True)   # same verdict, now with the counts
         else:
             counts = e.shard_owned_count(scheme, p_tiles_all, w, self.rank, 0, want_counts=True)
+        self.last_counts = [int(c) for c in counts[:w]]
+        self.last_exchange_rows = sum(max(c - self.n, 0) for c in self.last_counts)
         amount = self.owned_plan(counts[:w], self.n)
         send_counts = amount[self.rank]
         recv_counts = [amount[r][self.rank] for r in range(w)]
@@ -405,7 +422,11 @@ class ShardedParticleSystem:
         self._ow_keep = (rows, send)   # the next propagate reads its parents' states from `rows`
         if self._ow_fixed and not self._ow_cap_forced and self._ow_cap < self.n:
             self.synchronize()
-            self._alloc_owned(min(self.n, max(2 * self._ow_cap, 2 * max(max(a) for a in amount))))
+            grown = min(self.n, max(2 * self._ow_cap, 2 * max(max(a) for a in amount)))
+            if self._ow_padded_bytes(grown) > self._ow_fixed_max_bytes:
+                self._ow_fixed = False       # every rank sees the same counts, so every rank switches alike
+            else:
+                self._alloc_owned(grown)
         return value
 
     def _resample(self, scheme, sync):
