@@ -1298,6 +1298,15 @@ static int32_t owned_scratch(mp_pf* h, int world) {
     HIPCK(hipMemsetAsync(h->ow_seg_r, 0, sizeof(unsigned short) * ent, h->stream));
     HIPCK(hipMemsetAsync(h->ow_seg_lt, 0, sizeof(u64) * ent, h->stream));
     HIPCK(hipMemsetAsync(h->ow_call, 0, sizeof(unsigned long long) * SH_MAX_WORLD, h->stream));
+    HIPCK(hipMemsetAsync(h->ow_plan, 0, sizeof(mp_owned_plan), h->stream));
+    if (world == 1) {   // what k_shard_own_plan would find, every time (it is not launched in a world of one)
+        std::vector<uint32_t> base((size_t)nsc1);
+        for (int k = 0; k < nsc1; ++k) base[(size_t)k] = (uint32_t)((u64)k * OWN_ROUND);
+        HIPCK(hipMemcpyAsync(h->ow_base, base.data(), sizeof(uint32_t) * (size_t)nsc1, hipMemcpyHostToDevice, h->stream));
+        const unsigned long long c0 = h->n;
+        HIPCK(hipMemcpyAsync(h->ow_call, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));   // the host buffers above go out of scope
+    }
     h->ow_world = world;
     return MP_OK;
 }
@@ -1367,12 +1376,18 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         hipLaunchKernelGGL(kern, dim3(own_wgs), dim3(OWN_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
                            h->resample_count, (int)scheme, h->ow_R, t_incl, t_W, t_ratio, h->nt, world, rank, (const unsigned short*)h->guide,
                            (const mp_own_range*)h->ow_range, h->ow_seg_lt, h->ow_seg_row, h->ow_seg_r, h->ow_permc, h->ow_seg_cnt, pa);
-        hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, pa);
+        // A world of one has nothing to plan: every draw is this rank's own, super-chunk sc starts at offspring sc * 1024,
+        // nothing is sent or received (base[], the plan and c_all[0] = n were set when the scratch was allocated).
+        if (world > 1) hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, pa);
     }
     h->ow_scheme = scheme;
     rc = check_launch("shard_owned_count kernels");
     if (rc != MP_OK) return rc;
-    if (counts_out) {   // exact sizes: the caller sizes its buffers from the counts (the stream drains: every field of h_pub is out)
+    if (counts_out && world == 1) {
+        rc = fetch_scalars(h);   // degenerate weights are reported here, as by the plan's verdict in larger worlds
+        if (rc != MP_OK) return rc;
+        counts_out[0] = h->n;
+    } else if (counts_out) {   // exact sizes: the caller sizes its buffers from the counts (the stream drains: every field of h_pub is out)
         HIPCK(stream_wait(h->stream));
         if (h->h_pub->degenerate)
             return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
@@ -1412,7 +1427,15 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
     // surface at the next synchronising call, as for mp_pf_resample without a log_total_weight).
     const bool slow = log_total_weight || counts_out;   // these read more than the verdict word: the stream drains first
     unsigned flags = 0;
-    if (slow) {
+    double L_one = 0.;
+    if (h->ow_world == 1) {
+        if (slow) {   // no plan ran: the scalars themselves
+            int32_t rcs = fetch_scalars(h);
+            if (rcs != MP_OK) return rcs;
+            L_one = h->h_scal->L;
+            if (counts_out) counts_out[0] = h->n;
+        }
+    } else if (slow) {
         HIPCK(stream_wait(h->stream));
         flags = (unsigned)(h->h_pub->verdict & 0xFFu);
         if ((h->h_pub->verdict >> 8) != h->ow_seq) return mp_fail(MP_ERR_HIP, "owner-keeps plan: the stream drained without a verdict");
@@ -1420,7 +1443,7 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
         int32_t rcw = owned_wait_plan(h, &flags);
         if (rcw != MP_OK) return rcw;
     }
-    if (counts_out)
+    if (counts_out && h->ow_world > 1)
         for (int r = 0; r < h->ow_world; ++r) counts_out[r] = h->h_pub->counts[r];
     if (flags & 2u)   // before anything is committed: with Q == 0 no rank owns a draw and the donor never writes its request slots
         return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
@@ -1438,9 +1461,13 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
     h->rows_fresh = false;
     h->resample_count += 1;
     if (log_total_weight) {
-        if (h->h_pub->degenerate)
-            return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
-        *log_total_weight = h->h_pub->L;
+        if (h->ow_world == 1) {
+            *log_total_weight = L_one;
+        } else {
+            if (h->h_pub->degenerate)
+                return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
+            *log_total_weight = h->h_pub->L;
+        }
     }
     return MP_OK;
 }
