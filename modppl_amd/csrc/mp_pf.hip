@@ -452,6 +452,7 @@ struct mp_pf {
     unsigned long long* ow_call = nullptr;   // offspring per rank [SH_MAX_WORLD]
     mp_owned_plan* ow_plan = nullptr;
     mp_own_range* ow_range = nullptr;
+    u64* ow_kthr = nullptr;               // [SH_MAX_WORLD] rank boundaries as thresholds on the 52-bit uniforms (multinomial)
     unsigned int* ow_ticket = nullptr;
     u64 ow_last_cap = 0;                  // capacity of the last mp_pf_shard_owned_expand (0 = exact sizes: nothing can overflow)
     unsigned long long ow_seq = 0;        // owner-keeps resamples planned so far: the plan of number k writes pub->seq = k last
@@ -1256,7 +1257,8 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
 static void owned_free(mp_pf* h) {
     (void)hipFree(h->ow_seg_lt); (void)hipFree(h->ow_seg_row); (void)hipFree(h->ow_seg_r); (void)hipFree(h->ow_permc); (void)hipFree(h->ow_seg_cnt);
     (void)hipFree(h->ow_sccnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_cnt_r); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
-    (void)hipFree(h->ow_range); (void)hipFree(h->ow_ticket);
+    (void)hipFree(h->ow_range); (void)hipFree(h->ow_ticket); (void)hipFree(h->ow_kthr);
+    h->ow_kthr = nullptr;
     h->ow_ticket = nullptr;
     h->ow_seg_lt = nullptr; h->ow_seg_row = nullptr; h->ow_seg_r = nullptr; h->ow_permc = nullptr; h->ow_seg_cnt = nullptr;
     h->ow_sccnt = nullptr; h->ow_base = nullptr; h->ow_cnt_r = nullptr; h->ow_call = nullptr; h->ow_plan = nullptr; h->ow_range = nullptr;
@@ -1291,6 +1293,7 @@ static int32_t owned_scratch(mp_pf* h, int world) {
     HIPCK(hipMalloc(&h->ow_call, sizeof(unsigned long long) * SH_MAX_WORLD));
     HIPCK(hipMalloc(&h->ow_plan, sizeof(mp_owned_plan)));
     HIPCK(hipMalloc(&h->ow_range, sizeof(mp_own_range)));
+    HIPCK(hipMalloc(&h->ow_kthr, sizeof(u64) * SH_MAX_WORLD));
     HIPCK(hipMalloc(&h->ow_ticket, sizeof(unsigned int)));
     HIPCK(hipMemsetAsync(h->ow_ticket, 0, sizeof(unsigned int), h->stream));
     // rows of entries never written are still read (masked) by idle lanes of k_shard_own_resolve: keep them valid row indices
@@ -1356,7 +1359,7 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         if (!solo_tab)
             hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
                                h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo,
-                               h->ow_call, (int)scheme, rank, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->ow_range);
+                               h->ow_call, (int)scheme, rank, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->ow_range, h->ow_kthr);
         const u64* t_incl = solo_tab ? (const u64*)h->tab_incl : (const u64*)h->sh_incl_all;
         const u64* t_W = solo_tab ? (const u64*)h->tile_W : (const u64*)h->sh_tW_all;
         const double* t_ratio = solo_tab ? (const double*)h->tab_ratio : (const double*)h->sh_ratio_all;
@@ -1375,7 +1378,8 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         h->ow_wgs = own_wgs;
         hipLaunchKernelGGL(kern, dim3(own_wgs), dim3(OWN_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
                            h->resample_count, (int)scheme, h->ow_R, t_incl, t_W, t_ratio, h->nt, world, rank, (const unsigned short*)h->guide,
-                           (const mp_own_range*)h->ow_range, h->ow_seg_lt, h->ow_seg_row, h->ow_seg_r, h->ow_permc, h->ow_seg_cnt, pa);
+                           (const mp_own_range*)h->ow_range, h->ow_seg_lt, h->ow_seg_row, h->ow_seg_r, h->ow_permc, h->ow_seg_cnt, pa,
+                           (!solo_tab && scheme == MP_RESAMPLE_MULTINOMIAL && world > 1) ? (const u64*)h->ow_kthr : (const u64*)nullptr);
         // A world of one has nothing to plan: every draw is this rank's own, super-chunk sc starts at offspring sc * 1024,
         // nothing is sent or received (base[], the plan and c_all[0] = n were set when the scratch was allocated).
         if (world > 1) hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, pa);

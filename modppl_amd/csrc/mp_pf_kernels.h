@@ -641,8 +641,60 @@ struct mp_k1_aux {
     const double* zpre;     // [n][ns] standard deviates for THIS time step, or null
     mp_tab tab;
 };
+// The model kernel in Generate mode for ONE particle (slot i): previous state from wherever the last resample left it, the
+// functor with a Generate handler over the deviates zp[0..NS), new state and log-weight out.
+template <class Model>
+__device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, long long t,
+                                                const double* __restrict__ x_in, double* __restrict__ x_out, double* logw, const double* obs_v,
+                                                const double* s0_v, int overwrite, bool permuted, const double* __restrict__ res_x, int nchunks,
+                                                bool via_inv, const uint32_t* __restrict__ res_parent, uint32_t pmv, u64 i, const double* zp,
+                                                double* lw_out, double* x0_out) {
+    constexpr int D = Model::DIM_STATE;
+    if (i >= n) return;
+    double prev[D], next[D];
+    if (via_inv) {
+        // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row {x[0..D), parent
+        // id} is row inv[i] (= pmv) of the exchange buffer (res_x here); owner-keeps exchange, D > 1: a kept offspring has no row
+        // — its entry names the parent's local row of the pre-resample buffer x_in (mp_pf_shard_kernels.h MP_INV_LOCAL)
+        const bool local_parent = D > 1 && (pmv & 0x80000000u);
+        const double* row = local_parent ? x_in + (u64)(pmv & 0x7FFFFFFFu) * D : res_x + (u64)pmv * (u64)(D + 1);
+#pragma unroll
+        for (int d = 0; d < D; ++d) prev[d] = row[d];
+    } else if (permuted) {
+        // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at segment
+        // (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i] (= pmv)
+        const u64 pos = MP_SEG_POS(pmv >> 10, i >> 10, pmv & 1023u, nchunks);
+        if constexpr (D == 1) {
+            prev[0] = res_x[pos];              // k_resolve_bins had it in the table row it found
+        } else {
+            // wider states are gathered here, straight from the parent's (particle-major) row of the pre-resample buffer:
+            // one line per particle, hidden under this kernel's arithmetic
+            const double* src = x_in + (u64)res_parent[pos] * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) prev[d] = src[d];
+        }
+    } else if (t == 0) {   // (two branches, not a select between two loads: that form kept the by-value kernel argument in scratch)
+#pragma unroll
+        for (int d = 0; d < D; ++d) prev[d] = s0_v[d];
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) prev[d] = x_in[i * D + d];
+    }
+    mp_stream rng;
+    rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
+    mp_generate_handler<Model> g(rng, obs_v, zp);
+    model(g, t, prev, next);
+#pragma unroll
+    for (int d = 0; d < D; ++d) x_out[i * D + d] = next[d];
+    // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to be all zero
+    // after a resample (log_weights.fill(0.), :114) and are not re-read
+    const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
+    logw[i] = w;
+    *lw_out = w;
+    *x0_out = next[0];
+}
 template <class Model, int THREADS>
-__global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
                                                             mp_obs obs, mp_state0 s0, int overwrite,
                                                             const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
@@ -657,20 +709,66 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagat
     MP_STAMP(0, 0, 0); MP_STAMP(0, 1, 1); MP_STAMP(0, 6, 2);
     const u64 base = (u64)blockIdx.x * TILE + (u64)threadIdx.x * LANE_ITEMS;
     double lw[LANE_ITEMS], xv[LANE_ITEMS];
-    double z[LANE_ITEMS * NS];
+    // models with few normal sites draw every deviate of the lane first (z[]), then run the model; the others go particle by
+    // particle (QUEUE: 64 deviates per lane held across the phases lived in scratch memory — 640 B per thread at d = 16)
+    constexpr bool QUEUE = !(mp_coop_model<Model>() && LANE_ITEMS * Model::MAX_NORMALS <= 4);
+    double z[QUEUE ? 1 : LANE_ITEMS * NS];
 #pragma unroll
     for (int j = 0; j < LANE_ITEMS; ++j) { lw[j] = MP_NEG_INF; xv[j] = 0.; }
     // the first hop of the state fetch goes out before anything else: its latency runs under phase 1
     uint32_t pm[LANE_ITEMS];
 #pragma unroll
     for (int p = 0; p < LANE_ITEMS; ++p) pm[p] = base + p < n ? (inv ? inv[base + p] : (perm ? (uint32_t)perm[base + p] : 0u)) : 0u;
+    // phase 2 = mp_run_particle (above): the model kernel in Generate mode for one particle
+#define MP_RUN_PARTICLE(P, ZP)                                                                                                             \
+    mp_run_particle<Model>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, perm != nullptr, res_x, nchunks, inv != nullptr, \
+                           res_parent, pm[P], base + (u64)(P), ZP, &lw[P], &xv[P])
     // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
-    if (aux.zpre) {
+    if constexpr (QUEUE) {
+        // lane-local queue, rounds of ITEMS particles (ITEMS * NS accepted pairs in registers at a time); the model runs on a
+        // round's particles as soon as their deviates are there
+        constexpr int ITEMS = k1_items<Model>() < LANE_ITEMS ? k1_items<Model>() : LANE_ITEMS;
+        constexpr int ROUNDS = LANE_ITEMS / ITEMS;
+        constexpr int M = ITEMS * NS;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const u64 i0 = base + (u64)rd * ITEMS;
+            double pu[M], pr[M];
+#pragma unroll
+            for (int q = 0; q < M; ++q) { pu[q] = 0.; pr[q] = 1.; }
+            int p = 0, sidx = 0;  // current item: particle p of the round, normal site index sidx
+            uint32_t att = 0;
+            while (p < ITEMS && ns > 0 && att < MP_MAX_ATTEMPTS) {
+                const u64 i = i0 + (u64)p;
+                if (i >= n) break;
+                const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
+                                                    ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
+                double u, r;
+                if (!mp_polar_attempt(b, &u, &r)) {  // normal.rs:22
+                    ++att;
+                } else {
+                    const int q = p * NS + sidx;
+#pragma unroll
+                    for (int qq = 0; qq < M; ++qq) {
+                        pu[qq] = (qq == q) ? u : pu[qq];
+                        pr[qq] = (qq == q) ? r : pr[qq];
+                    }
+                    att = 0;
+                    if (++sidx == ns) { sidx = 0; ++p; }
+                }
+            }
+            double zr[M];
+#pragma unroll
+            for (int q = 0; q < M; ++q) zr[q] = mp_std_normal_from_pair(pu[q], pr[q]);
+#pragma unroll
+            for (int pp = 0; pp < ITEMS; ++pp) MP_RUN_PARTICLE(rd * ITEMS + pp, &zr[pp * NS]);
+        }
+    } else if (aux.zpre) {
 #pragma unroll
         for (int p = 0; p < LANE_ITEMS; ++p)
 #pragma unroll
             for (int s = 0; s < NS; ++s) z[p * NS + s] = (s < ns && base + p < n) ? aux.zpre[(base + p) * (u64)ns + s] : 0.;
-    } else if constexpr (mp_coop_model<Model>() && LANE_ITEMS * Model::MAX_NORMALS <= 4) {
+    } else {
         // few sites per particle: attempt 0 of every deviate in straight-line code (independent Philox chains, no
         // divergence; the state fetch's first hop lands meanwhile), then the rejected ones (21.5 %) are retried by the WAVE:
         // its 64 lanes share out the pending deviates and try several further attempts of each at once (attempts are
@@ -739,90 +837,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : 1)) void k_propagat
         }
 #pragma unroll
         for (int q = 0; q < M; ++q) z[q] = mp_std_normal_from_pair(pu[q], pr[q]);
-    } else {
-        // lane-local queue, rounds of ITEMS particles (ITEMS * NS accepted pairs in registers at a time)
-        constexpr int ITEMS = k1_items<Model>() < LANE_ITEMS ? k1_items<Model>() : LANE_ITEMS;
-        constexpr int ROUNDS = LANE_ITEMS / ITEMS;
-        constexpr int M = ITEMS * NS;
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; ++rd) {
-            const u64 i0 = base + (u64)rd * ITEMS;
-            double pu[M], pr[M];
-#pragma unroll
-            for (int q = 0; q < M; ++q) { pu[q] = 0.; pr[q] = 1.; }
-            int p = 0, sidx = 0;  // current item: particle p of the round, normal site index sidx
-            uint32_t att = 0;
-            while (p < ITEMS && ns > 0 && att < MP_MAX_ATTEMPTS) {
-                const u64 i = i0 + (u64)p;
-                if (i >= n) break;
-                const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
-                                                    ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
-                double u, r;
-                if (!mp_polar_attempt(b, &u, &r)) {  // normal.rs:22
-                    ++att;
-                } else {
-                    const int q = p * NS + sidx;
-#pragma unroll
-                    for (int qq = 0; qq < M; ++qq) {
-                        pu[qq] = (qq == q) ? u : pu[qq];
-                        pr[qq] = (qq == q) ? r : pr[qq];
-                    }
-                    att = 0;
-                    if (++sidx == ns) { sidx = 0; ++p; }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < M; ++q) z[rd * M + q] = mp_std_normal_from_pair(pu[q], pr[q]);
-        }
     }
     MP_STAMP(0, 2, 0);
-    // ---- phase 2: the model kernel in Generate mode --------------------------------------
+    if constexpr (!QUEUE) {
 #pragma unroll
-    for (int p = 0; p < LANE_ITEMS; ++p) {
-        const u64 i = base + (u64)p;
-        if (i < n) {
-            double prev[D], next[D];
-            if (inv) {
-                // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row
-                // {x[0..D), parent id} is row inv[i] of the exchange buffer (res_x here)
-                // (owner-keeps exchange, D > 1: a kept offspring has no row — its entry names the parent's local row of the
-                // pre-resample buffer x_in; mp_pf_shard_kernels.h MP_INV_LOCAL)
-                const bool local_parent = D > 1 && (pm[p] & 0x80000000u);
-                const double* row = local_parent ? x_in + (u64)(pm[p] & 0x7FFFFFFFu) * D : res_x + (u64)pm[p] * (u64)(D + 1);
-#pragma unroll
-                for (int d = 0; d < D; ++d) prev[d] = row[d];
-            } else if (perm) {
-                // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at
-                // segment (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i]
-                const uint32_t pr_ = pm[p];
-                const u64 pos = MP_SEG_POS(pr_ >> 10, i >> 10, pr_ & 1023u, nchunks);
-                if constexpr (D == 1) {
-                    prev[0] = res_x[pos];              // k_resolve_bins had it in the table row it found
-                } else {
-                    // wider states are gathered here, straight from the parent's (particle-major) row of the
-                    // pre-resample buffer: one line per particle, hidden under this kernel's arithmetic
-                    const double* src = x_in + (u64)res_parent[pos] * D;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) prev[d] = src[d];
-                }
-            } else {
-#pragma unroll
-                for (int d = 0; d < D; ++d) prev[d] = (t == 0) ? s0.v[d] : x_in[i * D + d];
-            }
-            mp_stream rng;
-            rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
-            mp_generate_handler<Model> g(rng, obs.v, &z[p * NS]);
-            model(g, t, prev, next);
-#pragma unroll
-            for (int d = 0; d < D; ++d) x_out[i * D + d] = next[d];
-            // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to
-            // be all zero after a resample (log_weights.fill(0.), :114) and are not re-read
-            const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
-            logw[i] = w;
-            lw[p] = w;
-            xv[p] = next[0];
-        }
+        for (int p = 0; p < LANE_ITEMS; ++p) MP_RUN_PARTICLE(p, &z[p * NS]);
     }
+#undef MP_RUN_PARTICLE
     MP_STAMP(0, 3, 0);
     // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----
     normalize_tile<THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2, aux.tab);

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
                                                              u64* __restrict__ incl_all, double* __restrict__ ratio_all,
                                                              long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
                                                              unsigned long long* __restrict__ c_all = nullptr, int scheme = 0, int rank = 0,
-                                                             uint32_t k0 = 0, uint32_t k1 = 0, uint32_t rc = 0, mp_own_range* range = nullptr) {
+                                                             uint32_t k0 = 0, uint32_t k1 = 0, uint32_t rc = 0, mp_own_range* range = nullptr,
+                                                             u64* __restrict__ kthr = nullptr) {
     __shared__ double s_red[SHT_THREADS / 64];
     __shared__ u64 s_wtot[SHT_THREADS / 64];
     __shared__ u64 s_wtot2[SHT_THREADS / 64];
@@ -353,13 +354,31 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
     // Owner-keeps exchange under a lattice scheme: targets are non-decreasing in g, so the draws that land in rank r's rows
     // are the range [G_{r-1}, G_r) with G_r = #{g : target(g) <= end of r's tiles}: one binary search per rank (the same target
     // function as the draw kernels, so the ranges are exactly the draws those kernels will call their own).
-    if (c_all && scheme) {
+    if (c_all) {
 #pragma unroll
         for (int j = 0; j < SHT_PER; ++j) {
             const int i = b0 + j;
             if (j < per && i < nt && (i + 1) % nt_local == 0) s_bound[i / nt_local] = off + pre[j];
         }
         __syncthreads();
+    }
+    // Owner-keeps exchange, multinomial: the rank boundaries as thresholds on the 52-bit uniforms themselves.  target(k) =
+    // max(1, ceil(k Q / 2^52)) is non-decreasing in k, so target(k) > B  <=>  k >= K(B) = the smallest such k (= floor(B 2^52 / Q)
+    // + 1, found from a double estimate and corrected with the target function itself): the draw kernel then tells whose a
+    // draw is with 64-bit compares and pays the 128-bit target only for its own.
+    if (c_all && kthr && scheme == 0) {
+        if (tid < world) {
+            const u64 B = s_bound[tid];
+            const u64 top = 1ull << 52;
+            double est = (double)B * 4503599627370496.0 / (double)Q;   // Q == 0: NaN / inf -> clamped below
+            u64 K = (est >= 4503599627370496.0) ? top : ((est >= 8.) ? (u64)est - 8ull : 0ull);
+            if (!(est == est)) K = 0ull;
+            while (K > 0ull && mp_target(K - 1ull, Q) > B) --K;          // (a few steps at most: the estimate is within a few units)
+            while (K < top && mp_target(K, Q) <= B) ++K;
+            kthr[tid] = K;
+        }
+    }
+    if (c_all && scheme) {
         if (tid < world) {
             const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
             const u64 B = s_bound[tid];
@@ -648,7 +667,7 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     u64 n, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme, int R, const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
     const double* __restrict__ ratio_all, int nt_local, int world, int rank, const unsigned short* __restrict__ guide,
     const mp_own_range* __restrict__ range, u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row, unsigned short* __restrict__ seg_r,
-    unsigned short* __restrict__ permc, unsigned short* __restrict__ seg_cnt, mp_own_plan_args pa) {
+    unsigned short* __restrict__ permc, unsigned short* __restrict__ seg_cnt, mp_own_plan_args pa, const u64* __restrict__ kthr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nt_lds = TABMODE == 1 ? nt_local : 0;
     u64* s_tgt = reinterpret_cast<u64*>(smem);                          // [R * 1024] own targets of the super-chunk, draw order
@@ -685,7 +704,10 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
             s_ratio_lds[b] = my_ratio[b];
         }
     }
-    for (int r = tid; r < world; r += OWN_THREADS) s_bound[r] = incl_all[(u64)(r + 1) * nt_local - 1];
+    // multinomial in a world of several ranks: s_bound holds the boundaries as thresholds on the uniforms (k_shard_table's kthr)
+    const bool by_k = !LATTICE && kthr != nullptr;
+    for (int r = tid; r < world; r += OWN_THREADS) s_bound[r] = by_k ? kthr[r] : incl_all[(u64)(r + 1) * nt_local - 1];
+    const u64 klo = (by_k && rank) ? kthr[rank - 1] : 0ull, khi = by_k ? kthr[rank] : (1ull << 52);
     const bool count_all = scheme == 0 && world > 1;
     const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
     for (int sc = sc_first + (int)blockIdx.x; sc <= sc_last; sc += (int)gridDim.x) {   // workgroup-uniform; one trip unless LATTICE
@@ -697,22 +719,28 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
 #pragma unroll 1
     for (int rr = 0; rr < R; ++rr) {
         const u64 i0 = g_base + (u64)rr * OWN_ROUND + 2u * (u64)tid;   // even
+        // t0, t1: what is compacted — the targets (lattice), or the 52-bit uniforms (multinomial: their targets are worked out
+        // after the compaction, by full waves, for this rank's own draws only)
         u64 t0, t1;
-        if (scheme) {
+        const bool live0 = i0 < n_global, live1 = i0 + 1 < n_global;
+        bool mine0, mine1;
+        if constexpr (LATTICE) {
             t0 = mp_target_lattice(scheme, i0, k32, rc, k0, k1, Q, n_global);
             t1 = mp_target_lattice(scheme, i0 + 1, k32, rc, k0, k1, Q, n_global);
+            mine0 = live0 && t0 > lo && t0 <= hi;
+            mine1 = live1 && t1 > lo && t1 <= hi;
         } else {
             const mp_u64x2 blk = mp_resample_block(i0 >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
-            t0 = mp_target(mp_u52(blk.a), Q);
-            t1 = mp_target(mp_u52(blk.b), Q);
-        }
-        const bool live0 = i0 < n_global, live1 = i0 + 1 < n_global;
-        const bool mine0 = live0 && t0 > lo && t0 <= hi, mine1 = live1 && t1 > lo && t1 <= hi;
-        if (count_all) {
-            for (int r = 0; r + 1 < world; ++r) {
-                const u64 B = s_bound[r];
-                const uint32_t c = (uint32_t)__popcll(__ballot(live0 && t0 > B)) + (uint32_t)__popcll(__ballot(live1 && t1 > B));
-                above_acc += (lane == r) ? c : 0u;
+            t0 = mp_u52(blk.a);
+            t1 = mp_u52(blk.b);
+            mine0 = live0 && t0 >= klo && t0 < khi;
+            mine1 = live1 && t1 >= klo && t1 < khi;
+            if (count_all) {
+                for (int r = 0; r + 1 < world; ++r) {
+                    const u64 Kr = s_bound[r];
+                    const uint32_t c = (uint32_t)__popcll(__ballot(live0 && t0 >= Kr)) + (uint32_t)__popcll(__ballot(live1 && t1 >= Kr));
+                    above_acc += (lane == r) ? c : 0u;
+                }
             }
         }
         // compaction in draw order: (round, wave, lane, slot of the pair) ascending IS g ascending
@@ -756,6 +784,7 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     // ---- the compacted own draws: bins first (their sizes fix where each bin's entries start in the window) ----
     const u64 span = hi - lo;
     const double eight_over_span = 8.0 / (double)span;           // own > 0 implies span > 0
+    auto tgt_of = [&](u64 v) { return LATTICE ? v : mp_target(v, Q); };   // compacted value -> target
     auto bin_of = [&](u64 t) {                                   // eighth of this rank's share of the CDF (monotone in t)
         uint32_t b = (uint32_t)((double)(t - lo - 1ull) * eight_over_span);
         return b > 7u ? 7u : b;
@@ -765,7 +794,7 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         for (uint32_t jb = 0; jb < own; jb += OWN_THREADS) {
             const uint32_t j = jb + (uint32_t)tid;
             const bool act = j < own;
-            const uint32_t bn = act ? bin_of(s_tgt[j]) : 8u;
+            const uint32_t bn = act ? bin_of(tgt_of(s_tgt[j])) : 8u;
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb) {
                 const uint32_t c = (uint32_t)__popcll(__ballot(bn == (uint32_t)bb));
@@ -795,7 +824,7 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         for (int q = 0; q < 2; ++q) {
             j[q] = jb + (uint32_t)q * OWN_THREADS + (uint32_t)tid;
             act[q] = j[q] < own;
-            const u64 t = act[q] ? s_tgt[j[q]] : lo + 1ull;
+            const u64 t = act[q] ? tgt_of(s_tgt[j[q]]) : lo + 1ull;
             bn[q] = act[q] ? bin_of(t) : 8u;
             const u64 trel = t - lo;
             mp_locate_own(t_incl, t_W, t_ratio, (uint32_t)nt_local, TABMODE == 1 ? trel : t, trel, TABMODE == 1 ? 0ull : lo, nt_over_span,

@@ -263,6 +263,8 @@ class ShardedParticleSystem:
             self._p_tiles_all = C.c_void_p(self._tiles.data_ptr() if (w == 1 and not self._always) else self._tiles_all.data_ptr())
             if not self._owned:
                 self._alloc_fixed(cap)
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)   # the buffers above were zero-filled on torch's current stream; the filter runs on its own
 
     def _alloc_fixed(self, cap):
         """exchange buffers for `cap` draws per (owner, eighth) sub-segment"""

@@ -59,6 +59,8 @@ class _ByHand:
         if cap:
             send = [z(w * cap) for _ in range(w)]
             rows = [z(w * cap + n) for _ in range(w)]
+        torch.cuda.synchronize()   # torch's stream made these; the engines' kernels run on streams of their own
+        if cap:
             for r, e in enumerate(self.eng):
                 e.shard_owned_count(scheme, ptr(tiles_all), w, r, cap, want_counts=False)
                 e.shard_owned_expand(w, r, cap, ptr(send[r]), ptr(rows[r]), w * cap)
@@ -85,6 +87,7 @@ class _ByHand:
         n_recv = [sum(amount[r][s] for r in range(w)) for s in range(w)]
         send = [z(sum(amount[r])) for r in range(w)]
         rows = [z(n_recv[s] + n) for s in range(w)]
+        torch.cuda.synchronize()
         for r, e in enumerate(self.eng):
             e.shard_owned_expand(w, r, 0, ptr(send[r]), ptr(rows[r]), n_recv[r])
         self.sync()

@@ -189,16 +189,19 @@ def test_fixed_capacity_exchange_two_shards_in_process(d, cap_frac, peek):
             e.shard_tiles_packed(ptr(tiles[r]))
         sync()
         tiles_all = torch.cat(tiles)                                   # all_gather_into_tensor
+        torch.cuda.synchronize()   # made on torch's stream, read by kernels on the engines' own streams
         for r, e in enumerate(eng):
             e.shard_route_fixed(0, ptr(tiles_all), world, r, cap, ptr(req_out[r]))
         sync()
         seg = 8 * (cap + 1) * 2                                        # all_to_all_single, equal splits
         req_in = [torch.cat([req_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
+        torch.cuda.synchronize()   # made on torch's stream, read by kernels on the engines' own streams
         for r, e in enumerate(eng):
             e.shard_resolve_fixed(ptr(req_in[r]), world, cap, ptr(rows_out[r]))
         sync()
         seg = 8 * cap * (d + 1)
         rows_in = [torch.cat([rows_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
+        torch.cuda.synchronize()   # made on torch's stream, read by kernels on the engines' own streams
         res = [e.shard_commit_fixed(ptr(rows_in[r]), True) for r, e in enumerate(eng)]
         L = one.resample()
         assert all(done for done, _ in res)
@@ -215,6 +218,7 @@ def test_fixed_capacity_exchange_two_shards_in_process(d, cap_frac, peek):
         e.shard_tiles_packed(ptr(tiles[r]))
     sync()
     tiles_all = torch.cat(tiles)
+    torch.cuda.synchronize()   # made on torch's stream, read by kernels on the engines' own streams
     assert eng[0].shard_query_packed(ptr(tiles_all), world)[0] == one.log_marginal_likelihood_estimate()
 
 
@@ -251,16 +255,19 @@ def test_fixed_capacity_overflow_commits_nothing():
         e.shard_tiles_packed(ptr(tiles[r]))
     sync()
     tiles_all = torch.cat(tiles)
+    torch.cuda.synchronize()   # made on torch's stream, read by kernels on the engines' own streams
     for r, e in enumerate(eng):
         e.shard_route_fixed(0, ptr(tiles_all), world, r, cap, ptr(req_out[r]))
     sync()
     seg = 8 * (cap + 1) * 2
     req_in = [torch.cat([req_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
+    torch.cuda.synchronize()   # made on torch's stream, read by kernels on the engines' own streams
     for r, e in enumerate(eng):
         e.shard_resolve_fixed(ptr(req_in[r]), world, cap, ptr(rows_out[r]))
     sync()
     seg = 8 * cap * 2
     rows_in = [torch.cat([rows_out[s][r * seg:(r + 1) * seg] for s in range(world)]) for r in range(world)]
+    torch.cuda.synchronize()   # made on torch's stream, read by kernels on the engines' own streams
     res = [e.shard_commit_fixed(ptr(rows_in[r]), True) for r, e in enumerate(eng)]
     assert all(not done for done, _ in res)
     for e, (x, w) in zip(eng, before):

@@ -28,6 +28,7 @@ def main():
         eng.shard_tiles_packed(C.c_void_p(tiles.data_ptr()))
         eng.synchronize()
         tiles_all = tiles.repeat(world).contiguous()
+        torch.cuda.synchronize()   # torch's stream made it; the engine's kernels run on a stream of their own
         cap = int(n // (8 * world) * 1.25) + 512
         req = torch.zeros(world * 8 * (cap + 1) * 2, dtype=torch.int64, device=dev)
         rows = torch.zeros(world * 8 * cap * 2, dtype=torch.float64, device=dev)
