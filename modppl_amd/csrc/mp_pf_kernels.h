@@ -730,36 +730,74 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
         constexpr int ITEMS = k1_items<Model>() < LANE_ITEMS ? k1_items<Model>() : LANE_ITEMS;
         constexpr int ROUNDS = LANE_ITEMS / ITEMS;
         constexpr int M = ITEMS * NS;
+        // the queue holds G accepted pairs at a time (an accepted pair is filed with a chain of 2 G selects, and G pairs are
+        // 4 G registers): a particle with more than 8 sites is drawn in groups of 8
+        constexpr int G = (ITEMS == 1 && NS > 8 && NS % 8 == 0) ? 8 : M;
+        constexpr int GROUPS = M / G;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             const u64 i0 = base + (u64)rd * ITEMS;
-            double pu[M], pr[M];
-#pragma unroll
-            for (int q = 0; q < M; ++q) { pu[q] = 0.; pr[q] = 1.; }
-            int p = 0, sidx = 0;  // current item: particle p of the round, normal site index sidx
-            uint32_t att = 0;
-            while (p < ITEMS && ns > 0 && att < MP_MAX_ATTEMPTS) {
-                const u64 i = i0 + (u64)p;
-                if (i >= n) break;
-                const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
-                                                    ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
-                double u, r;
-                if (!mp_polar_attempt(b, &u, &r)) {  // normal.rs:22
-                    ++att;
-                } else {
-                    const int q = p * NS + sidx;
-#pragma unroll
-                    for (int qq = 0; qq < M; ++qq) {
-                        pu[qq] = (qq == q) ? u : pu[qq];
-                        pr[qq] = (qq == q) ? r : pr[qq];
-                    }
-                    att = 0;
-                    if (++sidx == ns) { sidx = 0; ++p; }
-                }
-            }
             double zr[M];
 #pragma unroll
-            for (int q = 0; q < M; ++q) zr[q] = mp_std_normal_from_pair(pu[q], pr[q]);
+            for (int gr = 0; gr < GROUPS; ++gr) {
+                if constexpr (GROUPS > 1) {   // (no gain for 4-site models, measured on the bearings tracker)
+                    // many sites: accepted pairs are filed in LDS (slot-major, so that the lanes of a wave never share a bank
+                    // whatever slot each is at) instead of by a chain of selects over 4 G registers
+                    __shared__ double2 s_pair[G][THREADS];
+                    int q = 0;
+                    uint32_t att = 0;
+                    while (q < G && att < MP_MAX_ATTEMPTS) {
+                        const int slot = gr * G + q;
+                        const int p = slot / NS, sidx = slot % NS;
+                        const u64 i = i0 + (u64)p;
+                        if (sidx >= ns || i >= n) { s_pair[q][threadIdx.x] = make_double2(0., 1.); ++q; continue; }
+                        const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
+                                                            ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
+                        double u, r;
+                        if (!mp_polar_attempt(b, &u, &r)) {  // normal.rs:22
+                            ++att;
+                        } else {
+                            s_pair[q][threadIdx.x] = make_double2(u, r);
+                            att = 0;
+                            ++q;
+                        }
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < G; ++qq) {   // (a lane reads only what it wrote: no barrier)
+                        const double2 pr2 = s_pair[qq][threadIdx.x];
+                        zr[gr * G + qq] = mp_std_normal_from_pair(pr2.x, pr2.y);
+                    }
+                    continue;
+                }
+                double pu[G], pr[G];
+#pragma unroll
+                for (int q = 0; q < G; ++q) { pu[q] = 0.; pr[q] = 1.; }
+                int q = 0;            // next slot of the group: slot gr * G + q = (particle of the round) * NS + site
+                uint32_t att = 0;
+                while (q < G && att < MP_MAX_ATTEMPTS) {
+                    const int slot = gr * G + q;
+                    const int p = slot / NS, sidx = slot % NS;
+                    if (sidx >= ns) { ++q; continue; }   // a site this time step does not draw (uniform)
+                    const u64 i = i0 + (u64)p;
+                    if (i >= n) break;
+                    const mp_u64x2 b = mp_philox4x32_10((uint32_t)(slot_offset + i), (uint32_t)t,
+                                                        ((uint32_t)MP_DOM_MODEL << 16) | model.normal_site(sidx), att, k0, k1);
+                    double u, r;
+                    if (!mp_polar_attempt(b, &u, &r)) {  // normal.rs:22
+                        ++att;
+                    } else {
+#pragma unroll
+                        for (int qq = 0; qq < G; ++qq) {
+                            pu[qq] = (qq == q) ? u : pu[qq];
+                            pr[qq] = (qq == q) ? r : pr[qq];
+                        }
+                        att = 0;
+                        ++q;
+                    }
+                }
+#pragma unroll
+                for (int qq = 0; qq < G; ++qq) zr[gr * G + qq] = mp_std_normal_from_pair(pu[qq], pr[qq]);
+            }
 #pragma unroll
             for (int pp = 0; pp < ITEMS; ++pp) MP_RUN_PARTICLE(rd * ITEMS + pp, &zr[pp * NS]);
         }
