@@ -308,7 +308,8 @@ def test_owner_keeps_error_paths():
     e.close()
 
 
-@pytest.mark.parametrize("world,n,cap", [(4, 1 << 18, 4096), (2, 1 << 19, 0), (8, 1 << 17, 2048)])
+@pytest.mark.parametrize("world,n,cap", [(4, 1 << 18, 4096), (2, 1 << 19, 0), (8, 1 << 17, 2048),
+                                         (2, (1 << 21) + 4096, 16384)])   # 1026 tiles per rank: the tile table is probed in L2, not copied to LDS
 def test_owner_keeps_million_particles(world, n, cap):
     """2^20 particles over 2 / 4 / 8 shards: hundreds of workgroups per phase, several rounds per lane in the place kernel;
     the surplus stays a few hundred rows (O(sqrt n)), far below the capacity."""
