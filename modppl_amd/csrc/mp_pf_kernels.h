@@ -910,10 +910,14 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
                                                                      const uint32_t* __restrict__ res_parent, int nchunks, mp_cx* __restrict__ cx,
                                                                      unsigned short* __restrict__ guide, double* tile_m, u64* tile_W, u64* tile_W2,
                                                                      mp_k1_aux aux, const uint32_t* __restrict__ inv, const double* __restrict__ rows) {
-    constexpr int D = 16, ZP = D + 1;   // z rows padded by one double: the transposed reads then spread over the LDS banks
-    __shared__ double s_z[DENSE_THREADS / 64][64][ZP];
-    __shared__ double s_lw[TILE], s_x0[TILE];
+    constexpr int D = 16;
+    // z of the round's 64 particles per wave, column j of lane l at [l][j ^ (l & 15)]: the swizzle spreads both the per-lane
+    // writes and the transposed MFMA-operand reads over the banks without a padding column — with the two staging rows below
+    // the kernel needs 78 KB of LDS, so that TWO workgroups fit a CU (16 waves to hide the Philox chains instead of 8)
+    __shared__ double s_z[DENSE_THREADS / 64][64][D];
+    __shared__ double s_wst[DENSE_THREADS / 64][64], s_xst[DENSE_THREADS / 64][64];   // a round's log-weights / x0, by owning lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double lw[TILE / DENSE_THREADS], xv[TILE / DENSE_THREADS];
     const int li = lane & 15, lg = lane >> 4;
     const u64 tile0 = (u64)blockIdx.x * TILE;
     // the constant operands of this lane
@@ -929,7 +933,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
     const double lp_const = (double)D * MP_LN_2PI_CANON + model.ln_det_R;
 #pragma unroll 1
     for (int rd = 0; rd < 4; ++rd) {
-        const int pl = wave * 256 + rd * 64 + lane;    // this lane's particle of the round, tile-local
+        const int pl = tid * 4 + rd;                   // this lane's particle of the round, tile-local: thread t owns rows 4 t .. 4 t + 3,
+                                                       // the layout normalize_tile wants its inputs in (registers, no LDS re-map)
         const u64 p = tile0 + (u64)pl;
         const bool live = p < n;
         // ---- the 16 normals of site "x": one sequential stream per particle (mvnormal.rs:35) ----
@@ -942,13 +947,13 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
                 const mp_u64x2 b = st.next_block();
                 double u, r;
                 if (mp_polar_attempt(b, &u, &r)) {
-                    s_z[wave][lane][j] = mp_normal_from_pair(u, r, 0., 1.);   // normal.random(rng, (0., 1.))
+                    s_z[wave][lane][j ^ (lane & 15)] = mp_normal_from_pair(u, r, 0., 1.);   // normal.random(rng, (0., 1.))
                     ++j;
                 }
             }
             if (!live) {
 #pragma unroll
-                for (int q = 0; q < D; ++q) s_z[wave][lane][q] = 0.;
+                for (int q = 0; q < D; ++q) s_z[wave][lane][q] = 0.;   // (every column: the swizzle only permutes them)
             }
         }
         // where this particle's previous state lives (slot order, or the parent's row after a binned resample)
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
             const double* xrow = reinterpret_cast<const double*>((uintptr_t)(((u64)(uint32_t)__shfl((int)(myaddr >> 32), src, 64) << 32) |
                                                                               (u64)(uint32_t)__shfl((int)myaddr, src, 64)));
             const bool live_i = __shfl((int)live, src, 64) != 0;
-            const int pl_i = wave * 256 + rd * 64 + src;
+            const int pl_i = (wave * 64 + src) * 4 + rd;
             const u64 p_i = tile0 + (u64)pl_i;
             mp_f64x4 mean = {0., 0., 0., 0.};
             if (t != 0) {   // uniform
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
             }
             mp_f64x4 tz = {0., 0., 0., 0.};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) tz = __builtin_amdgcn_mfma_f64_16x16x4f64(tmat[s], s_z[wave][src][lg + 4 * s], tz, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) tz = __builtin_amdgcn_mfma_f64_16x16x4f64(tmat[s], s_z[wave][src][(lg + 4 * s) ^ li], tz, 0, 0, 0);   // src & 15 == li
             mp_f64x4 xn, c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1011,18 +1016,20 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
                     w = overwrite == 1 ? gw : (overwrite == 2 ? 0. + gw : logw[p_i] + gw);
                     logw[p_i] = w;
                 }
-                s_lw[pl_i] = w;
+                s_wst[wave][src] = w;
             }
-            if (lg == 0) s_x0[pl_i] = live_i ? xn[0] : 0.;
+            if (lg == 0) s_xst[wave][src] = live_i ? xn[0] : 0.;
         }
-        __builtin_amdgcn_wave_barrier();   // the next round overwrites this wave's z
-    }
-    __syncthreads();
-    double lw[TILE / DENSE_THREADS], xv[TILE / DENSE_THREADS];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the staged results are this wave's own; the next round overwrites its z
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double w_mine = s_wst[wave][lane], x_mine = s_xst[wave][lane];
 #pragma unroll
-    for (int j = 0; j < TILE / DENSE_THREADS; ++j) {
-        lw[j] = s_lw[tid * (TILE / DENSE_THREADS) + j];
-        xv[j] = s_x0[tid * (TILE / DENSE_THREADS) + j];
+        for (int j = 0; j < 4; ++j) {   // (static indices: lw / xv stay in registers)
+            lw[j] = j == rd ? w_mine : lw[j];
+            xv[j] = j == rd ? x_mine : xv[j];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     normalize_tile<DENSE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2, aux.tab);
 }
