@@ -65,7 +65,7 @@ constexpr int K3_THREADS = 256;
 constexpr int K3_ITEMS = 4;
 constexpr int K3_MAX_BLOCKS = 4096;
 constexpr int MAX_TILES = 8192;                  // LDS tile table: 16 B per tile
-constexpr int K1_TABLE_LDS_MAX_TILES = 1024;     // k_bin_draws copies the prebuilt tile table (24 B per tile) into LDS up to here, probes it in L2 beyond
+constexpr int K1_TABLE_LDS_MAX_TILES = 2048;     // k_bin_draws copies the prebuilt tile table (24 B per tile) into LDS up to here, probes it in L2 beyond
 
 // particles per predraw round in k_propagate: 4 pre-drawn (u, r) pairs per lane whatever the model's number of normal sites
 template <class Model>
