@@ -1370,7 +1370,7 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         pa.scal = h->scal; pa.undo = h->scal_undo; pa.head = solo_tab ? (const mp_tab_head*)h->tab_head : nullptr;
         pa.base = h->ow_base; pa.plan_out = h->ow_plan; pa.pub = h->d_pub; pa.seq = ++h->ow_seq;
         pa.range = h->ow_range; pa.Wd = (u64)h->ow_R * OWN_ROUND;
-        const bool tab_lds = h->nt <= K1_TABLE_LDS_MAX_TILES;
+        const bool tab_lds = h->nt <= 1024;   // (with the 32 KB of own targets at R = 4 this stays under the 64 KB a launch may ask for)
         const size_t lds = sizeof(u64) * (size_t)h->ow_R * OWN_ROUND + (tab_lds ? (size_t)h->nt * 24 : 0);
         auto kern = scheme ? (tab_lds ? k_shard_own_bin<1, true> : k_shard_own_bin<2, true>) : (tab_lds ? k_shard_own_bin<1, false> : k_shard_own_bin<2, false>);
         // lattice: a rank's own draws are ~n consecutive ones, wherever they start: that many workgroups (a rank that owns more takes turns)
