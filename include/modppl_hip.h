@@ -211,7 +211,9 @@ int32_t mp_pf_shard_query_packed(mp_pf* h, const uint64_t* d_tiles_all, int32_t 
  *                             return the offspring per rank (exact-size form).
  *   mp_pf_shard_owned_expand  own draws -> rows of d_rows ([recv_rows + n][dim_state + 1]: the first recv_rows rows are
  *                             where the received surplus arrives, the rest are this rank's own offspring), surplus rows ->
- *                             d_send_out.  capacity > 0: equal splits, d_send_out = [world][capacity] rows, recv_rows =
+ *                             d_send_out.  d_rows belongs to the handle until the next resample: with dim_state > 1 a kept
+ *                             offspring is NOT copied there (its parent is local: the next step gathers the parent's state
+ *                             itself), only received rows are read from it — read states through mp_pf_read_state.  capacity > 0: equal splits, d_send_out = [world][capacity] rows, recv_rows =
  *                             world * capacity, pair (r -> s) at [s][j]; capacity == 0: exact sizes, surplus in unit order
  *                             (= destination order), received rows in unit order (= source order).
  *   mp_pf_shard_owned_commit  waits for the plan of the count (not for the expand or the exchange: they are ordered before
