@@ -50,6 +50,8 @@ def test_owner_keeps_random_configurations(k, d, world, n, cap, scheme, tail):
             e.step(obs[t:t + 1])
         ref.step(obs[t:t + 1])
         assert np.array_equal(hip.cat(lambda e: e.log_weights()), ref.log_weights())
+        if (k + t) % 3 == 0:   # the parents of that resample, read only now: they come out of the exchange rows / the flagged entries
+            assert np.array_equal(hip.cat(lambda e: e.parents()), ref.parents())
     assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
 
 
