@@ -231,6 +231,7 @@ class ShardedParticleSystem:
             raise capi.ModpplError(capi.MP_ERR_UNSUPPORTED, "this engine has no owner-keeps exchange")
         self._host_staging = host_staging
         self._ow_keep = None
+        self._ox_cache, self._ox_flip = {}, 0   # exact-size exchange buffers
         self.last_counts = None          # offspring per rank of the last synchronous owner-keeps resample
         self.last_exchange_rows = None   # surplus rows it moved between ranks
         if self._owned:
@@ -276,6 +277,14 @@ class ShardedParticleSystem:
         self._fx_rows_in = self._fx_rows_out if (w == 1 and not self._always) else torch.zeros_like(self._fx_rows_out)
         self._p_req_out, self._p_req_in = C.c_void_p(self._fx_req_out.data_ptr()), C.c_void_p(self._fx_req_in.data_ptr())
         self._p_rows_out, self._p_rows_in = C.c_void_p(self._fx_rows_out.data_ptr()), C.c_void_p(self._fx_rows_in.data_ptr())
+
+    def _ox_buffer(self, name, numel):
+        key = (name, self._ox_flip)
+        buf = self._ox_cache.get(key)
+        if buf is None or buf.numel() < numel:
+            buf = torch.empty(int(numel * 1.25) + 64, dtype=torch.float64, device=self.dev)
+            self._ox_cache[key] = buf
+        return buf
 
     def _ow_padded_bytes(self, cap):
         return self.world * int(cap) * (self.model.dim_state + 1) * 8
@@ -411,8 +420,12 @@ class ShardedParticleSystem:
         send_counts = amount[self.rank]
         recv_counts = [amount[r][self.rank] for r in range(w)]
         n_send, n_recv = sum(send_counts), sum(recv_counts)
-        send = torch.empty(max(n_send, 1) * (d + 1), dtype=torch.float64, device=self.dev)
-        rows = torch.empty((n_recv + self.n) * (d + 1), dtype=torch.float64, device=self.dev)
+        # grow-only buffers, two sets used alternately (the rows of the previous resample are still read by the propagate in
+        # flight); with states wider than one double the library copies no kept offspring, so only the received rows need room
+        keep_rows = self.n if d == 1 else 0
+        send = self._ox_buffer("send", max(n_send, 1) * (d + 1))
+        rows = self._ox_buffer("rows", max(n_recv + keep_rows, 1) * (d + 1))
+        self._ox_flip ^= 1
         e.shard_owned_expand(w, self.rank, 0, C.c_void_p(send.data_ptr()), C.c_void_p(rows.data_ptr()), n_recv)
         if solo or sum(map(sum, amount)) == 0:
             recv = send          # nobody has a surplus (every rank sees the same counts, so every rank skips the collective)
