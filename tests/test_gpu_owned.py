@@ -175,6 +175,37 @@ def test_owner_keeps_world_of_one_and_its_law():
     assert abs(b.log_marginal_likelihood_estimate() - O.kalman_log_ml(ys)) < 0.05
 
 
+@pytest.mark.parametrize("d", [1, 16])
+@pytest.mark.parametrize("sync", [True, False])
+def test_owner_keeps_exact_size_policy_in_a_world_of_one(monkeypatch, d, sync):
+    """MP_SHARD_OWNED_FIXED_MAX_BYTES below the padded buffer size: the exchange takes the exact-size path (host-read counts,
+    grow-only cached buffers); in a world of one it still is the single filter, wide states included (kept offspring have no rows)."""
+    import modppl_amd
+    from modppl_amd.distributed import ShardedParticleSystem
+    monkeypatch.setenv("MP_SHARD_OWNED_FIXED_MAX_BYTES", "1")
+    n, seed, T = 3 * 2048 + 17 if d == 1 else 2 * 2048, 11, 6
+    model, obs = _model(d, T)
+    a = modppl_amd.ParticleSystem(model, n, seed)
+    b = ShardedParticleSystem(model, n, seed, exchange="owned")
+    assert not b._ow_fixed
+    a.init_step(None, obs[:1])
+    b.init_step(None, obs[:1])
+    for t in range(1, T):
+        if sync:
+            assert a.resample() == b.resample()
+            assert b.last_counts == [n] and b.last_exchange_rows == 0
+        else:
+            a.resample(sync=False)
+            b.resample(sync=False)
+        if t == 2:
+            assert np.array_equal(a.parents, b.parents)
+        a.step(obs[t:t + 1])
+        b.step(obs[t:t + 1])
+        assert np.array_equal(a.log_weights, b.log_weights)
+    assert np.array_equal(a.states(), b.states())
+    assert a.log_marginal_likelihood_estimate() == b.log_marginal_likelihood_estimate()
+
+
 NCCL_WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["MP_ROOT"])
