@@ -13,12 +13,16 @@
 //   scal        mp_dev_scalars   log_ml_estimate, last log total weight, ESS ... (device-resident so
 //                                that a whole filter run needs no host round trip)
 //
-// Kernels of one SMC time step (no inter-workgroup communication inside a launch, so nothing depends on
-// dispatch order or XCD placement; all cross-workgroup sums are integer):
+//   tab_incl/tab_ratio/tab_head  the job's tile table (level 1), built once per normalisation by the last level-0 workgroup
+//
+// Kernels of one SMC time step (results never depend on dispatch order or XCD placement: all cross-workgroup sums are
+// integer; the one hand-off inside a launch is the atomic ticket that lets the LAST workgroup of the level-0 launch build
+// the tile table from every workgroup's tile scalars — whichever workgroup that is):
 //   K1  k_propagate       ParticleSystem::init_step/step: one workgroup per 2048-row tile runs the model kernel in
 //                         Generate mode (logw (+)= weight) and, in the same pass, level 0 of normalize_weights
-//                         (:27-35): tile max, exp, 51-bit fixed point, tile-local scan, rows, guide
-//   K3a k_bin_draws       multinomial_resampling (:37-41), part 1: tile table (level 1), Philox draw, target,
+//                         (:27-35): tile max, exp, 51-bit fixed point, tile-local scan, rows, guide; level 1 (the tile
+//                         table) by the last workgroup
+//   K3a k_bin_draws       multinomial_resampling (:37-41), part 1: Philox draw (two adjacent draws per block), target,
 //                         tile + guide lookup, stable split of the draws into 8 CDF-eighth bins
 //   K3b k_resolve_bins    part 2 + the clone loop of resample (:109-114): row lookups per bin on one XCD
 //   (K3 k_resample_gather single-kernel form: importance_resampling's M draws and systematic resampling)

@@ -1,5 +1,6 @@
 // mp_pf_shard_kernels.h — device code of the sharded filter's resample phases (included by mp_pf.hip only, after
-// mp_pf_kernels.h): variable-size three-pass route, fixed-capacity single-pass route, owner-side resolve, adoption.
+// mp_pf_kernels.h): the owner-keeps exchange (k_shard_table, k_shard_own_bin, k_shard_own_plan, k_shard_own_resolve), the
+// slot-order exchange (variable-size three-pass route, fixed-capacity single-pass route, owner-side resolve), adoption.
 // Protocol: include/modppl_hip.h "sharded filter", DESIGN.md §8.
 #pragma once
 // ---------------------------------------------------------------------------------------------
