@@ -40,7 +40,14 @@ struct mp_dev_scalars {
     u64 Q, Q2;
     int degenerate;    // sticky: all log-weights were -inf (or +inf) at a normalisation
     int pad;
+    int* host_flag;    // host-mapped mirror of `degenerate` (set with a write-through store by whoever sets it): mp_pf_synchronize
+                       // then needs no copy of this struct to report it
 };
+// `degenerate` goes up, on the device and in the host's mirror
+__device__ __forceinline__ void mp_flag_degenerate(mp_dev_scalars* scal) {
+    scal->degenerate = 1;
+    if (scal->host_flag) __hip_atomic_store(scal->host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 constexpr int TILE_THREADS = 512;
 constexpr int TILE_ITEMS = 4;
@@ -1128,7 +1135,7 @@ __device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2
     double L, ess;
     finalize_scalars(Q, Q2, S, &L, &ess, m);
     scal->m = m;
-    if (!(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0) scal->degenerate = 1;
+    if (!(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0) mp_flag_degenerate(scal);
     if (mode == 0) {  // resample (particle_filter.rs:104-105)
         scal->L = L;
         scal->ess_stale = ess;
@@ -1651,7 +1658,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_finalize_tiles(const double* __r
             double L, ess;
             finalize_scalars(Q, Q2, S, &L, &ess, m);
             scal->m = m;
-            if (!(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0) scal->degenerate = 1;
+            if (!(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0) mp_flag_degenerate(scal);
             scal->L = L;
             scal->lml_fresh = L - mp_log((double)n_global);
         } else {
