@@ -1426,16 +1426,18 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     // place of a draw in its segment: draws of the same bin in lower waves, then in lower lanes of this wave (either slot of
     // the pair), then the lane's own first draw.  (One LDS atomic per draw instead costs ~10 cycles per LANE: 5 us per chunk.)
     const int lane = tid & 63, wave = tid >> 6;
-    uint32_t rank[2] = {0u, 0u};
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-        const bool h0 = live[0] && bin[0] == (uint32_t)bb, h1 = live[1] && bin[1] == (uint32_t)bb;
-        const u64 m0 = __ballot(h0), m1 = __ballot(h1);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
-                               __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))));
-        if (h0) rank[0] = below;
-        if (h1) rank[1] = below + (h0 ? 1u : 0u);
-        if (lane == bb) s_wcnt[wave * 8 + bb] = (uint32_t)(__popcll(m0) + __popcll(m1));
+    // One packed scan instead of eight ballot rounds: field b (8 bits) of a lane's word counts its draws in bin b (a wave has at
+    // most 128 draws, so no field overflows); the exclusive DPP prefix over the lanes is "draws of the same bin in lower lanes".
+    uint32_t rank[2];
+    {
+        const u64 p0 = live[0] ? 1ull << (8u * bin[0]) : 0ull, p1 = live[1] ? 1ull << (8u * bin[1]) : 0ull;
+        const u64 pk = p0 + p1;
+        const u64 inc = wave_incl_scan_u64(pk, lane);
+        const u64 exc = inc - pk;
+        rank[0] = (uint32_t)(exc >> (8u * bin[0])) & 0xFFu;
+        rank[1] = ((uint32_t)(exc >> (8u * bin[1])) & 0xFFu) + ((live[0] && bin[0] == bin[1]) ? 1u : 0u);
+        const u64 tot = mp_readlane_u64(inc, 63);
+        if (lane < 8) s_wcnt[wave * 8 + lane] = (uint32_t)(tot >> (8u * (uint32_t)lane)) & 0xFFu;
     }
     __syncthreads();
     if (tid < 8) {   // exclusive offsets of the waves, per bin; the chunk's segment lengths

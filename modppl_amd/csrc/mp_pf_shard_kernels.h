@@ -795,12 +795,9 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         for (uint32_t jb = 0; jb < own; jb += OWN_THREADS) {
             const uint32_t j = jb + (uint32_t)tid;
             const bool act = j < own;
-            const uint32_t bn = act ? bin_of(tgt_of(s_tgt[j])) : 8u;
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                const uint32_t c = (uint32_t)__popcll(__ballot(bn == (uint32_t)bb));
-                acc += (lane == bb) ? c : 0u;
-            }
+            const uint32_t bn = act ? bin_of(tgt_of(s_tgt[j])) : 0u;
+            const u64 tot = wave_sum_u64(act ? 1ull << (8u * bn) : 0ull);   // eight 8-bit counters in one word
+            acc += lane < 8 ? (uint32_t)(tot >> (8u * (uint32_t)lane)) & 0xFFu : 0u;
         }
         if (lane < 8 && acc) atomicAdd(&s_bincnt[lane], acc);
     }
@@ -833,16 +830,15 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];   // in flight while the places are worked out
-        rank_[0] = rank_[1] = 0u;
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            const bool h0 = bn[0] == (uint32_t)bb, h1 = bn[1] == (uint32_t)bb;
-            const u64 m0 = __ballot(h0), m1 = __ballot(h1);
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
-                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))));
-            if (h0) rank_[0] = below;
-            if (h1) rank_[1] = below + (h0 ? 1u : 0u);
-            if (lane == bb) s_wcnt[wave * 8 + bb] = (uint32_t)(__popcll(m0) + __popcll(m1));
+        {   // ranks inside the batch with one packed DPP scan (k_bin_draws): field b (8 bits) = this lane's entries of bin b
+            const u64 p0 = act[0] ? 1ull << (8u * bn[0]) : 0ull, p1 = act[1] ? 1ull << (8u * bn[1]) : 0ull;
+            const u64 pk = p0 + p1;
+            const u64 inc = wave_incl_scan_u64(pk, lane);
+            const u64 exc = inc - pk;
+            rank_[0] = act[0] ? (uint32_t)(exc >> (8u * bn[0])) & 0xFFu : 0u;
+            rank_[1] = act[1] ? ((uint32_t)(exc >> (8u * bn[1])) & 0xFFu) + ((act[0] && bn[0] == bn[1]) ? 1u : 0u) : 0u;
+            const u64 tot = mp_readlane_u64(inc, 63);
+            if (lane < 8) s_wcnt[wave * 8 + lane] = (uint32_t)(tot >> (8u * (uint32_t)lane)) & 0xFFu;
         }
         __syncthreads();
         if (tid < 8) {   // exclusive offsets of the waves per bin, on top of the bin's start and of the batches before
