@@ -101,6 +101,7 @@ struct PropagateArgs {
     u64* tile_W2;
     const uint32_t* inv;
     const uint32_t* res_parent;
+    const mp_k1_tail* tail;   // device copy of {cx, guide, tile_*, tab} (k_propagate reads them there)
     mp_k1_aux aux;
 };
 struct ResolveArgs {   // k_resolve_bins (+ the next step's deviates when zpre != null)
@@ -152,14 +153,14 @@ struct ModelOpsT : ModelOps {
         if constexpr (std::is_same<Model, mp_lgssm1>::value) {
             if (k1t == 256) {
                 hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
-                                   a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent, a.aux);
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.tail,
+                                   a.inv, a.res_parent, a.aux);
                 return;
             }
             if (k1t == 512) {
                 hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
-                                   a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent, a.aux);
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.tail,
+                                   a.inv, a.res_parent, a.aux);
                 return;
             }
         }
@@ -175,8 +176,8 @@ struct ModelOpsT : ModelOps {
             }
         }
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.cx, a.guide,
-                           a.tile_m, a.tile_W, a.tile_W2, a.inv, a.res_parent, a.aux);
+                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.tail,
+                           a.inv, a.res_parent, a.aux);
     }
     int n_normals(long long t) const override { return model.n_normals(t); }
     void resolve(const ResolveArgs& a) const override {
@@ -409,6 +410,7 @@ struct mp_pf {
     bool parents_lazy = false;          // parents of the last (binned) resample still sit in res_parent / perm (a step may have moved the states on)
     bool sh_parents_lazy = false;       // ... or in column D of the exchange rows sh_rows / sh_req_slot
     // level-1 table built by the last workgroup of the level-0 launch (mp_tab); deviates drawn one launch ahead
+    mp_k1_tail* k1_tail = nullptr;      // device copy of what k_propagate's last phase needs (update_k1_tail)
     unsigned int* tab_ticket = nullptr;
     u64* tab_incl = nullptr;
     double* tab_ratio = nullptr;
@@ -495,6 +497,15 @@ static mp_tab tab_of(const mp_pf* h) {
     t.head = h->tab_head;
     t.S = h->S;
     return t;
+}
+
+static int32_t update_k1_tail(mp_pf* h) {   // after anything that changes one of these pointers
+    mp_k1_tail t;
+    t.cx = h->cx; t.guide = h->guide; t.tile_m = h->tile_m; t.tile_W = h->tile_W; t.tile_W2 = h->tile_W2; t.tab = tab_of(h);
+    if (!h->k1_tail) HIPCK(hipMalloc(&h->k1_tail, sizeof(mp_k1_tail)));
+    HIPCK(hipMemcpyAsync(h->k1_tail, &t, sizeof(t), hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));   // `t` is a stack object
+    return MP_OK;
 }
 
 static hipEvent_t get_event(mp_pf* h) {
@@ -632,6 +643,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.stream = h->stream;
     a.aux.zpre = (h->zpre && h->zpre_t == h->t) ? h->zpre : nullptr;   // drawn for exactly this time step by the last resample's lookup kernel
     a.aux.tab = tab_of(h);
+    a.tail = h->k1_tail;
     {
         LaunchTimer lt(h, MP_K_PROPAGATE);
         h->ops->propagate(a);
@@ -792,6 +804,10 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     *h->h_scal = init;
     HIPCK(hipMemcpyAsync(h->scal, h->h_scal, sizeof(mp_dev_scalars), hipMemcpyHostToDevice, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
+    {
+        int32_t rct = update_k1_tail(h.get());
+        if (rct != MP_OK) return rct;
+    }
     *out = h.release();
     return MP_OK;
 }
@@ -1165,7 +1181,7 @@ int32_t mp_pf_shard_bind_tiles(mp_pf* h, uint64_t* d_tiles) {
     h->tile_m = reinterpret_cast<double*>(d_tiles);
     h->tile_W = (u64*)d_tiles + h->nt;
     h->tile_W2 = (u64*)d_tiles + 2 * (size_t)h->nt;
-    return MP_OK;
+    return update_k1_tail(h);
 }
 
 int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out) {
@@ -1607,6 +1623,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->guide);
     (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->scal);
     (void)hipFree(h->aos);
+    (void)hipFree(h->k1_tail);
     (void)hipFree(h->tab_ticket); (void)hipFree(h->tab_incl); (void)hipFree(h->tab_ratio); (void)hipFree(h->tab_head); (void)hipFree(h->zpre);
     (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);

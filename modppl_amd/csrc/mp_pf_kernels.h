@@ -648,6 +648,17 @@ struct mp_k1_aux {
     const double* zpre;     // [n][ns] standard deviates for THIS time step, or null
     mp_tab tab;
 };
+// What k_propagate needs only in its LAST phase (level 0 / level 1 of the normalisation), constant per handle: kept in
+// device memory and read there — as kernel arguments these 11 pointers sat in SGPRs through the whole VALU-bound part of the
+// kernel, which ran out of them (78 at 8 waves per SIMD) and spilled to VGPR lanes.
+struct mp_k1_tail {
+    mp_cx* cx;
+    unsigned short* guide;
+    double* tile_m;
+    u64* tile_W;
+    u64* tile_W2;
+    mp_tab tab;
+};
 // The model kernel in Generate mode for ONE particle (slot i): previous state from wherever the last resample left it, the
 // functor with a Generate handler over the deviates zp[0..NS), new state and log-weight out.
 template <class Model>
@@ -705,9 +716,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                                                             long long t, const double* x_in, double* x_out, double* logw,
                                                             mp_obs obs, mp_state0 s0, int overwrite,
                                                             const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
-                                                            int nchunks, mp_cx* __restrict__ cx,
-                                                            unsigned short* __restrict__ guide, double* tile_m,
-                                                            u64* tile_W, u64* tile_W2,
+                                                            int nchunks, const mp_k1_tail* tail,
                                                             const uint32_t* __restrict__ inv, const uint32_t* __restrict__ res_parent, mp_k1_aux aux) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
@@ -891,7 +900,10 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
 #undef MP_RUN_PARTICLE
     MP_STAMP(0, 3, 0);
     // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----
-    normalize_tile<THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2, aux.tab);
+    const mp_k1_tail* tp = tail;
+    asm volatile("" : "+s"(tp)::"memory");   // the loads of *tp stay here (hoisted to the kernel's entry they would be SGPR pressure again)
+    const mp_k1_tail tl = *tp;
+    normalize_tile<THREADS>(lw, xv, n, blockIdx.x, tl.cx, tl.guide, tl.tile_m, tl.tile_W, tl.tile_W2, tl.tab);
     MP_STAMP(0, 4, 0); MP_STAMP(0, 5, 1);
 }
 
