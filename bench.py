@@ -29,11 +29,13 @@ DIM = 1
 # algorithmic bytes per particle per kernel family (B(d) = 32d + 64 per particle-step):
 #   propagate       = propagate+weight (16d+16) and level 0 of the normalisation fused into it (LSE read 8 + normalise/scan 8+8)
 #   normalize_scan  = the standalone form of that level 0 (only launched when the weights changed without a propagate)
-#   resample_gather = search 8+4, gather 4+16d, weight reset 8   (K3a + K3b together)
-#   bin_draws       = the search half of the resample (8 + 4)
-#   resample_gather = the gather half: 4 + 16d, weight reset 8
+#   bin_draws       = the search half of the resample (8 + 4): k_draw_slots
+#   resample_gather = the gather half (4 + 16d, weight reset 8) where a kernel of its own does it (the single-kernel resampler,
+#                     the sharded path); in the unsharded multinomial step the next k_propagate looks its slots' parents up
+#                     itself, so that launch carries these bytes too (FUSED_GATHER below)
 BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "bin_draws": 8 + 4, "resample_gather": 4 + 16 * DIM + 8}
-KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_bin_draws<1>", "resample_gather": "k_resolve_bins<mp_lgssm1, false, 1>"}
+FUSED_GATHER = 4 + 16 * DIM + 8
+KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_draw_slots<1>", "resample_gather": "k_resample_gather<0>"}
 BYTES_STEP = 32 * DIM + 64
 
 
@@ -380,7 +382,10 @@ def main():
         roofline = None
         if timed:
             dom = max(fam, key=lambda k: fam[k][0])   # the kernel with the largest total time
-            achieved = BYTES_K[dom] * n / (avg_us[dom] * 1e-6) / 1e9
+            bytes_k = dict(BYTES_K)
+            if not sharded_path and fam["resample_gather"][1] == 0:
+                bytes_k["propagate"] += FUSED_GATHER   # the step's k_propagate also looked up / cloned the parents (no launch of its own did)
+            achieved = bytes_k[dom] * n / (avg_us[dom] * 1e-6) / 1e9
             # HBM-side bytes per launch of that kernel: PMC passes cannot run inside this process, so this is the committed
             # summary of the same single-GPU command — accepted only if it names this kernel AND was measured with this build
             # (content hash of the kernel sources), otherwise null with the reason
@@ -402,7 +407,7 @@ def main():
                     traffic_note = f"unreadable profiles summary: {e}"
             roofline = {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
-                        "bytes_per_launch": BYTES_K[dom] * n}
+                        "bytes_per_launch": bytes_k[dom] * n, "bytes_per_particle": bytes_k[dom]}
         out = {
             "metric": "particle-steps/sec, 1M-particle LGSSM SMC (step + multinomial resample per time step)",
             "value": n * world * K / dt,

@@ -236,8 +236,8 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
 enum mp_kernel_family {
     MP_K_PROPAGATE = 0,       /* k_propagate: model kernel + level 0 of the normalisation            */
     MP_K_NORMALIZE_SCAN = 1,  /* k_normalize_tiles: level 0 alone (weights changed without a propagate) */
-    MP_K_RESAMPLE_GATHER = 2, /* k_resolve_bins, or the single-kernel k_resample_gather / shard kernels */
-    MP_K_BIN_DRAWS = 3,       /* k_bin_draws, or the sharded route (k_shard_table / route_fused / headers) */
+    MP_K_RESAMPLE_GATHER = 2, /* the gather half of a resample where a kernel of its own does it: k_resample_gather, shard kernels */
+    MP_K_BIN_DRAWS = 3,       /* the draw half: k_draw_slots, or the sharded route (k_shard_table / own_bin / route_fused) */
     MP_K_COUNT = 4
 };
 int32_t mp_pf_set_timing(mp_pf* h, int32_t enabled);

@@ -6,9 +6,10 @@
 //   x[2][n][d]  f64   particle states (slot order, particle-major)
 //   logw[n]     f64   log-weights                              (particle_filter.rs:15)
 //   cx[n]       {u64,f64}  resampling table rows: tile-local inclusive prefix of the fixed-point weights + x[0]
+//               (+ cx_alt: a k_propagate that looks up the last resample's draws in cx writes the new table there)
 //   guide[nt][2048] u16  per-tile bucketed inverse CDF (first row of each bucket)
 //   tile_m/W/W2[nt]      per-tile max log-weight and fixed-point totals (level 0 of the normalisation)
-//   seg_lt/seg_row/perm/res_x/res_parent  the XCD-binned resampler's segments and segment-ordered results
+//   dfr_lt/dfr_row[n]  u64 / u32  draws of the last resample not looked up yet: tile-local target and start row per output slot
 //   parent[n]   u32   parents of the last resample             (particle_filter.rs:20)
 //   scal        mp_dev_scalars   log_ml_estimate, last log total weight, ESS ... (device-resident so
 //                                that a whole filter run needs no host round trip)
@@ -22,10 +23,11 @@
 //                         Generate mode (logw (+)= weight) and, in the same pass, level 0 of normalize_weights
 //                         (:27-35): tile max, exp, 51-bit fixed point, tile-local scan, rows, guide; level 1 (the tile
 //                         table) by the last workgroup
-//   K3a k_bin_draws       multinomial_resampling (:37-41), part 1: Philox draw (two adjacent draws per block), target,
-//                         tile + guide lookup, stable split of the draws into 8 CDF-eighth bins
-//   K3b k_resolve_bins    part 2 + the clone loop of resample (:109-114): row lookups per bin on one XCD
-//   (K3 k_resample_gather single-kernel form: importance_resampling's M draws and systematic resampling)
+//   K3a k_draw_slots      multinomial_resampling (:37-41), the draws: Philox (two adjacent draws per block), target, tile +
+//                         guide lookup -> {target, start row} per output slot
+//       the row lookups + the clone loop of resample (:109-114) run inside the NEXT k_propagate (each workgroup looks up
+//       the parents of its own slots, under its arithmetic), or in k_resolve_slots when the host asks for states / parents first
+//   (K3 k_resample_gather single-kernel form: importance_resampling's M draws, systematic / stratified resampling)
 // The normalisation spec (hierarchical fixed point) is stated in DESIGN.md §4 and restated on the CPU in
 // oracle/src/inference.hpp.
 #include <hip/hip_runtime.h>
@@ -91,44 +93,25 @@ struct PropagateArgs {
     int overwrite;
     int grid;
     hipStream_t stream;
-    const unsigned short* perm;
-    const double* res_x;
-    int nchunks;
+    const uint32_t* dfr_row;  // draws of the last resample not looked up yet: start rows / targets per slot, and the table they
+    const u64* dfr_lt;        // refer to (cx_old); `cx` below is then the OTHER table buffer
+    const mp_cx* cx_old;
+    const double* inv_rows;   // exchange rows of the last sharded resample (slot i reads row inv[i])
     mp_cx* cx;
     unsigned short* guide;
     double* tile_m;
     u64* tile_W;
     u64* tile_W2;
     const uint32_t* inv;
-    const uint32_t* res_parent;
     const mp_k1_tail* tail;   // device copy of {cx, guide, tile_*, tab} (k_propagate reads them there)
     mp_k1_aux aux;
-};
-struct ResolveArgs {   // k_resolve_bins (+ the next step's deviates when zpre != null)
-    u64 n;
-    int nchunks, grid;
-    const u64* seg_lt;
-    const uint32_t* seg_row;
-    const unsigned short* seg_cnt;
-    const mp_cx* cx;
-    double* res_x;
-    uint32_t* res_parent;
-    long long t_next;
-    u64 slot_offset;
-    uint32_t k0, k1;
-    double* zpre;
-    u64 pre_per;
-    int items;
-    hipStream_t stream;
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
     void* owned_device_mem = nullptr;   // model constants that do not fit kernel arguments (freed with the model)
     int max_normals = 0;
-    bool coop = false;   // few normal sites per particle: deviates can be drawn cooperatively / one launch ahead
     virtual ~ModelOps() { if (owned_device_mem) (void)hipFree(owned_device_mem); }
     virtual void propagate(const PropagateArgs& a) const = 0;
-    virtual void resolve(const ResolveArgs& a) const = 0;
     virtual int n_normals(long long t) const = 0;
     virtual void simulate(u64 n, uint32_t k0, uint32_t k1, int n_steps, const mp_state0& s0, double* states, double* obs, hipStream_t st) const = 0;
 };
@@ -139,7 +122,6 @@ struct ModelOpsT : ModelOps {
         dim_state = Model::DIM_STATE;
         dim_obs = Model::DIM_OBS;
         max_normals = Model::MAX_NORMALS;
-        coop = mp_coop_model<Model>();
         static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
         static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
     }
@@ -153,14 +135,14 @@ struct ModelOpsT : ModelOps {
         if constexpr (std::is_same<Model, mp_lgssm1>::value) {
             if (k1t == 256) {
                 hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.tail,
-                                   a.inv, a.res_parent, a.aux);
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                   a.inv, a.dfr_lt, a.aux);
                 return;
             }
             if (k1t == 512) {
                 hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.tail,
-                                   a.inv, a.res_parent, a.aux);
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                   a.inv, a.dfr_lt, a.aux);
                 return;
             }
         }
@@ -170,35 +152,16 @@ struct ModelOpsT : ModelOps {
             static const bool mfma = [] { const char* e = getenv("MP_DENSE_MFMA"); return !(e && e[0] == '0'); }();
             if (mfma) {
                 hipLaunchKernelGGL(k_propagate_dense16, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
-                                   a.x_out, a.logw, a.obs, a.overwrite, a.perm, a.res_parent, a.nchunks, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux,
-                                   a.inv, a.res_x);
+                                   a.x_out, a.logw, a.obs, a.overwrite, a.dfr_row, a.dfr_lt, a.cx_old, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux,
+                                   a.inv, a.inv_rows);
                 return;
             }
         }
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.perm, a.res_x, a.nchunks, a.tail,
-                           a.inv, a.res_parent, a.aux);
+                           a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                           a.inv, a.dfr_lt, a.aux);
     }
     int n_normals(long long t) const override { return model.n_normals(t); }
-    void resolve(const ResolveArgs& a) const override {
-        if constexpr (mp_coop_model<Model>()) {
-            if (a.zpre) {
-                hipLaunchKernelGGL((k_resolve_bins<Model, true, 1>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
-                                   a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, a.zpre, a.pre_per);
-                return;
-            }
-        }
-        // ITEMS segments per thread (a.items; the grid shrinks accordingly)
-        if (a.items == 4)
-            hipLaunchKernelGGL((k_resolve_bins<Model, false, 4>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
-                               a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, (double*)nullptr, (u64)0);
-        else if (a.items == 2)
-            hipLaunchKernelGGL((k_resolve_bins<Model, false, 2>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
-                               a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, (double*)nullptr, (u64)0);
-        else
-            hipLaunchKernelGGL((k_resolve_bins<Model, false, 1>), dim3(a.grid), dim3(K3B_THREADS), 0, a.stream, model, a.n, a.nchunks, a.seg_lt, a.seg_row,
-                               a.seg_cnt, a.cx, a.res_x, a.res_parent, a.t_next, a.slot_offset, a.k0, a.k1, (double*)nullptr, (u64)0);
-    }
 };
 
 // kind -> factory of the registered models
@@ -396,29 +359,23 @@ struct mp_pf {
     double* aos = nullptr;             // staging for read_state
     mp_dev_scalars* h_scal = nullptr;  // pinned
     int* h_flag = nullptr;             // host-mapped: the device-side sticky error (mp_dev_scalars::host_flag points here)
-    // binned resampling scratch: segments [bin][chunk][1024]
-    u64* seg_lt = nullptr;              // tile-local target of every binned draw
-    uint32_t* seg_row = nullptr;        // table row where the forward scan of every binned draw starts
-    unsigned short* perm = nullptr;     // [n]: (bin << 10 | position) of every slot's draw
-    unsigned short* seg_cnt = nullptr;
-    double* res_x = nullptr;            // [d][8 * nchunks * 1024]: resampled states in segment order
-    uint32_t* res_parent = nullptr;     // [8 * nchunks * 1024]
-    u64 res_stride = 0;
+    // the draws of a multinomial resample, per output slot (k_draw_slots)
+    u64* dfr_lt = nullptr;              // [n] tile-local target
+    uint32_t* dfr_row = nullptr;        // [n] table row where the forward scan starts
     int nchunks = 0;
-    int use_binned = 1;                 // MP_BINNED_RESAMPLE=0 selects the single-kernel path (A/B measurements)
-    bool permuted = false;              // the current states / parents / (zero) log-weights live in res_* (lazy slot order)
-    bool parents_lazy = false;          // parents of the last (binned) resample still sit in res_parent / perm (a step may have moved the states on)
+    int use_deferred = 1;               // MP_DEFERRED_LOOKUPS=0 selects the single-kernel resampler (A/B measurements)
     bool sh_parents_lazy = false;       // ... or in column D of the exchange rows sh_rows / sh_req_slot
-    // level-1 table built by the last workgroup of the level-0 launch (mp_tab); deviates drawn one launch ahead
+    // level-1 table built by the last workgroup of the level-0 launch (mp_tab)
     mp_k1_tail* k1_tail = nullptr;      // device copy of what k_propagate's last phase needs (update_k1_tail)
+    mp_k1_tail* k1_tail_alt = nullptr;  // the same with cx_alt for cx
+    mp_cx* cx_alt = nullptr;            // second row-table buffer: a k_propagate that looks up deferred draws in cx writes the new table here
+    bool deferred = false;              // the last resample only drew: {dfr_lt, dfr_row}[slot] against the table in cx; x[cur] is the pre-resample state
+    bool parents_deferred = false;      // ... and a step has consumed the draws since: its parents are still {dfr_lt, dfr_row} against cx_alt
     unsigned int* tab_ticket = nullptr;
     u64* tab_incl = nullptr;
     double* tab_ratio = nullptr;
     mp_tab_head* tab_head = nullptr;
-    int use_k1_table = 1;               // MP_K1_TABLE=0: every k_bin_draws workgroup builds the table itself (A/B measurements)
-    double* zpre = nullptr;             // [n][ns] standard deviates of time step zpre_t, drawn by k_resolve_bins
-    long long zpre_t = -1;
-    int use_predraw = 0;                // MP_PREDRAW=1: the resample's lookup launch also draws the next step's deviates (measured: a loss at 2^20 x d = 1)
+    int use_k1_table = 1;               // MP_K1_TABLE=0: every k_draw_slots workgroup builds the table itself (A/B measurements)
     bool rows_fresh = false;            // cx / guide / tile_* describe the current log-weights
     // sharded-resample scratch (allocated on first use)
     unsigned char* sh_dest = nullptr;
@@ -505,6 +462,12 @@ static int32_t update_k1_tail(mp_pf* h) {   // after anything that changes one o
     if (!h->k1_tail) HIPCK(hipMalloc(&h->k1_tail, sizeof(mp_k1_tail)));
     HIPCK(hipMemcpyAsync(h->k1_tail, &t, sizeof(t), hipMemcpyHostToDevice, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));   // `t` is a stack object
+    if (h->cx_alt) {
+        t.cx = h->cx_alt;
+        if (!h->k1_tail_alt) HIPCK(hipMalloc(&h->k1_tail_alt, sizeof(mp_k1_tail)));
+        HIPCK(hipMemcpyAsync(h->k1_tail_alt, &t, sizeof(t), hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
     return MP_OK;
 }
 
@@ -575,7 +538,7 @@ static int32_t fetch_scalars(mp_pf* h) {
     return MP_OK;
 }
 
-// Slot-order x / parent / logw after a binned resample (only when something other than the next step needs them).
+// Slot-order x / parent / logw after a resample that only drew (only when something other than the next step needs them).
 static int32_t materialize(mp_pf* h) {
     if (h->sh_lazy) {
         hipLaunchKernelGGL(k_shard_adopt_rows, dim3((unsigned)((h->n + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, h->stream, h->n,
@@ -589,14 +552,17 @@ static int32_t materialize(mp_pf* h) {
         HIPCK(hipMemsetAsync(h->logw, 0, sizeof(double) * h->n, h->stream));
         h->logw_zero = false;
     }
-    if (!h->permuted) return MP_OK;
-    hipLaunchKernelGGL(k_unpermute, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->ops->dim_state, h->nchunks, h->perm,
-                       h->res_x, h->res_parent, h->x[h->cur], h->ops->dim_state == 1 ? h->x[h->cur] : h->x[h->cur ^ 1], h->parent,
-                       h->logw);
-    if (h->ops->dim_state > 1) h->cur ^= 1;   // wider states were gathered from the pre-resample buffer into the other one
-    h->permuted = false;
-    h->parents_lazy = false;                  // k_unpermute wrote parent[] too
-    return check_launch("k_unpermute");
+    if (h->deferred) {
+        const int d = h->ops->dim_state;
+        hipLaunchKernelGGL(k_resolve_slots<true>, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, d, (const u64*)h->dfr_lt,
+                           (const uint32_t*)h->dfr_row, (const mp_cx*)h->cx, (const double*)h->x[h->cur], d == 1 ? h->x[h->cur] : h->x[h->cur ^ 1],
+                           h->parent, h->logw);
+        if (d > 1) h->cur ^= 1;   // wider states were gathered from the pre-resample buffer into the other one
+        h->deferred = false;
+        h->parents_deferred = false;   // k_resolve_slots wrote parent[] too
+        return check_launch("k_resolve_slots");
+    }
+    return MP_OK;
 }
 
 // a buffer of `bytes` for one history event, out of the current slab (a new slab is twice the last one, at least 8 events)
@@ -623,41 +589,45 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.n = h->n; a.slot_offset = h->slot_offset;
     a.k0 = (uint32_t)h->seed; a.k1 = (uint32_t)(h->seed >> 32);
     a.t = h->t;
-    // after a binned resample of a filter with dim_state > 1 this propagate gathers the parents' states itself, from the
-    // pre-resample buffer into the other one
-    const bool gather_here = h->permuted && !h->sh_lazy && h->ops->dim_state > 1;
+    // with deferred draws and dim_state > 1 this propagate gathers the parents' states itself, from the pre-resample buffer
+    // into the other one
+    const bool gather_here = h->deferred && !h->sh_lazy && h->ops->dim_state > 1;
     // (after a sharded commit x[cur ^ 1] still holds the pre-resample states: kept offspring of the owner-keeps exchange read
     // their parents there when states are wider than one double)
     a.x_in = h->sh_lazy ? h->x[h->cur ^ 1] : h->x[h->cur]; a.x_out = gather_here ? h->x[h->cur ^ 1] : h->x[h->cur];
-    a.res_parent = h->res_parent;
     a.logw = h->logw;
     for (int j = 0; j < MP_MAX_OBS; ++j) a.obs.v[j] = (j < h->ops->dim_obs) ? obs[j] : 0.;
     for (int j = 0; j < MP_MAX_STATE; ++j) a.s0.v[j] = (args0 && j < h->ops->dim_state) ? args0[j] : 0.;
-    a.overwrite = overwrite ? 1 : ((h->permuted || h->logw_zero) ? 2 : 0);
-    a.perm = h->permuted ? h->perm : nullptr;
-    a.res_x = h->sh_lazy ? h->sh_rows : h->res_x;
+    a.overwrite = overwrite ? 1 : ((h->deferred || h->logw_zero) ? 2 : 0);
+    // draws of the last resample are looked up by this launch, in the table they were drawn against (cx); the new table goes
+    // into the other buffer
+    a.dfr_row = h->deferred ? h->dfr_row : nullptr;
+    a.dfr_lt = h->deferred ? h->dfr_lt : nullptr;
+    a.cx_old = h->deferred ? h->cx : nullptr;
+    a.inv_rows = h->sh_lazy ? h->sh_rows : nullptr;
     a.inv = h->sh_lazy ? h->sh_req_slot : nullptr;
-    a.nchunks = h->nchunks;
-    a.cx = h->cx; a.guide = h->guide; a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
+    a.cx = h->deferred ? h->cx_alt : h->cx; a.guide = h->guide; a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
     a.grid = h->nt;
     a.stream = h->stream;
-    a.aux.zpre = (h->zpre && h->zpre_t == h->t) ? h->zpre : nullptr;   // drawn for exactly this time step by the last resample's lookup kernel
     a.aux.tab = tab_of(h);
-    a.tail = h->k1_tail;
+    a.tail = h->deferred ? h->k1_tail_alt : h->k1_tail;
     {
         LaunchTimer lt(h, MP_K_PROPAGATE);
         h->ops->propagate(a);
     }
-    h->zpre_t = -1;
+    if (h->deferred) {   // the fresh table is the current one from here on; the old one stays intact for mp_pf_read_parents
+        std::swap(h->cx, h->cx_alt);
+        std::swap(h->k1_tail, h->k1_tail_alt);
+        h->parents_deferred = true;
+        h->deferred = false;
+    }
     h->t += 1;
     if (gather_here) h->cur ^= 1;
     h->logw_zero = false;
-    // parents of that resample stay where they are (res_parent / perm, or the exchange rows) until somebody asks for them
-    // or the next resample replaces them: mp_pf_read_parents (particle_filter.rs:20 keeps `parents` across `step`)
-    if (h->permuted) h->parents_lazy = true;
+    // parents of that resample stay where they are (the draws + the old table, or the exchange rows) until somebody asks for
+    // them or the next resample replaces them: mp_pf_read_parents (particle_filter.rs:20 keeps `parents` across `step`)
     if (h->sh_lazy) h->sh_parents_lazy = true;
-    h->sh_lazy = false;
-    h->permuted = false;   // k_propagate wrote x[cur] and logw in slot order ...
+    h->sh_lazy = false;    // k_propagate wrote x[cur] and logw in slot order ...
     h->rows_fresh = true;  // ... and level 0 of their normalisation
     int32_t rc_ = check_launch("k_propagate");
     if (rc_ != MP_OK) return rc_;
@@ -740,14 +710,12 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     if ((h->n_global + TILE - 1) / TILE > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "at most 2^24 particles per job in this build (tile table in LDS)");
     h->k3_grid = (int)((n + KG_THREADS * KG_ITEMS - 1) / (KG_THREADS * KG_ITEMS));
     if (h->k3_grid > K3_MAX_BLOCKS) h->k3_grid = K3_MAX_BLOCKS;
-    h->nchunks = (int)((n + BIN_CHUNK - 1) / BIN_CHUNK);
+    h->nchunks = (int)((n + DRAW_CHUNK - 1) / DRAW_CHUNK);
     {
-        const char* env = getenv("MP_BINNED_RESAMPLE");
-        if (env && env[0] == '0') h->use_binned = 0;
+        const char* env = getenv("MP_DEFERRED_LOOKUPS");
+        if (env && env[0] == '0') h->use_deferred = 0;
         env = getenv("MP_K1_TABLE");
         if (env && env[0] == '0') h->use_k1_table = 0;
-        env = getenv("MP_PREDRAW");
-        if (env) h->use_predraw = env[0] == '1' ? 1 : 0;
     }
     HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
     HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
@@ -766,18 +734,13 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         HIPCK(hipMalloc(&h->tab_incl, sizeof(u64) * h->nt));
         HIPCK(hipMalloc(&h->tab_ratio, sizeof(double) * h->nt));
         HIPCK(hipMalloc(&h->tab_head, sizeof(mp_tab_head)));
-        if (h->use_predraw && h->use_binned && h->ops->coop && h->ops->max_normals > 0)
-            HIPCK(hipMalloc(&h->zpre, sizeof(double) * n * (size_t)h->ops->max_normals));
     }
     HIPCK(hipMalloc(&h->aos, sizeof(double) * n));   // scratch for importance sampling's normalised log-weights
     HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
-    h->res_stride = 8ull * (u64)h->nchunks * BIN_CHUNK;
-    HIPCK(hipMalloc(&h->seg_lt, sizeof(u64) * h->res_stride));
-    HIPCK(hipMalloc(&h->seg_row, sizeof(uint32_t) * h->res_stride));
-    HIPCK(hipMalloc(&h->perm, sizeof(unsigned short) * (size_t)h->nchunks * BIN_CHUNK));
-    HIPCK(hipMalloc(&h->seg_cnt, sizeof(unsigned short) * 8 * (size_t)h->nchunks));
-    HIPCK(hipMalloc(&h->res_x, sizeof(double) * h->res_stride));   // first state component only (dim_state == 1 needs nothing else)
-    HIPCK(hipMalloc(&h->res_parent, sizeof(uint32_t) * h->res_stride));
+    if (!h->sharded) {   // (sharded handles resample through the mp_pf_shard_* phases)
+        HIPCK(hipMalloc(&h->dfr_lt, sizeof(u64) * (size_t)h->nchunks * DRAW_CHUNK));
+        HIPCK(hipMalloc(&h->dfr_row, sizeof(uint32_t) * (size_t)h->nchunks * DRAW_CHUNK));
+    }
     // tile tables above 64 KiB of LDS need the limit raised once per kernel
     {
         const int nt_job = (int)((h->n_global + TILE - 1) / TILE);
@@ -786,7 +749,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_draws<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_draw_slots<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
         }
@@ -846,55 +809,42 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     HIPCK(hipSetDevice(h->device));
     int32_t rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
-    h->parents_lazy = false;   // this resample's parents replace whatever was still waiting to be read
+    h->parents_deferred = false;   // this resample's parents replace whatever was still waiting to be read
     h->sh_parents_lazy = false;
     const int d = h->ops->dim_state;
-    bool binned = false;
-    if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
+    bool drawn_only = false;
+    if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_deferred) {
+        // draws only (k_draw_slots): the lookups are done by whoever consumes the parents — the next k_propagate, under its
+        // arithmetic, or k_resolve_slots when the host asks first
+        if (!h->cx_alt) {
+            HIPCK(hipMalloc(&h->cx_alt, sizeof(mp_cx) * (size_t)h->nt * TILE));
+            int32_t rct = update_k1_tail(h);
+            if (rct != MP_OK) return rct;
+        }
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (BIN_THREADS / 64) + sizeof(uint32_t) * 8 * (BIN_THREADS / 64);
+        const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (DRAW_THREADS / 64);
         const mp_tab tab = tab_of(h);
         if (tab.ticket && h->nt <= K1_TABLE_LDS_MAX_TILES) {
             // the table was built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles): copy to LDS
-            hipLaunchKernelGGL(k_bin_draws<1>, dim3(h->nchunks), dim3(BIN_THREADS), 24 * (size_t)h->nt + lds_tail, h->stream, h->n, h->n_global,
-                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W,
-                               h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)h->tab_incl,
+            hipLaunchKernelGGL(k_draw_slots<1>, dim3(h->nchunks), dim3(DRAW_THREADS), 24 * (size_t)h->nt + lds_tail, h->stream, h->n, h->n_global,
+                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->tile_m, h->tile_W,
+                               h->tile_W2, h->nt, h->guide, h->dfr_lt, h->dfr_row, h->scal, (const u64*)h->tab_incl,
                                (const double*)h->tab_ratio, (const mp_tab_head*)h->tab_head);
         } else if (tab.ticket) {
-            hipLaunchKernelGGL(k_bin_draws<2>, dim3(h->nchunks), dim3(BIN_THREADS), lds_tail, h->stream, h->n, h->n_global,
-                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W,
-                               h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)h->tab_incl,
+            hipLaunchKernelGGL(k_draw_slots<2>, dim3(h->nchunks), dim3(DRAW_THREADS), lds_tail, h->stream, h->n, h->n_global,
+                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->tile_m, h->tile_W,
+                               h->tile_W2, h->nt, h->guide, h->dfr_lt, h->dfr_row, h->scal, (const u64*)h->tab_incl,
                                (const double*)h->tab_ratio, (const mp_tab_head*)h->tab_head);
         } else {
-            hipLaunchKernelGGL(k_bin_draws<0>, dim3(h->nchunks), dim3(BIN_THREADS), 16 * (size_t)h->nt + lds_tail, h->stream, h->n, h->n_global,
-                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->nchunks, h->tile_m, h->tile_W,
-                               h->tile_W2, h->nt, h->guide, h->seg_lt, h->seg_row, h->perm, h->seg_cnt, h->scal, (const u64*)nullptr,
+            hipLaunchKernelGGL(k_draw_slots<0>, dim3(h->nchunks), dim3(DRAW_THREADS), 16 * (size_t)h->nt + lds_tail, h->stream, h->n, h->n_global,
+                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->tile_m, h->tile_W,
+                               h->tile_W2, h->nt, h->guide, h->dfr_lt, h->dfr_row, h->scal, (const u64*)nullptr,
                                (const double*)nullptr, (const mp_tab_head*)nullptr);
         }
-    }
-    {
+        drawn_only = true;
+    } else {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_binned) {
-            static const int k3b_items = [] { const char* e = getenv("MP_K3B_ITEMS"); const int v = e ? atoi(e) : 1; return (v == 2 || v == 4) ? v : 1; }();
-            // the deviates of the NEXT time step (kernel time index h->t) are drawn by extra workgroups of the same launch
-            const bool pre = h->zpre && h->ops->n_normals(h->t) > 0;
-            ResolveArgs r;
-            r.items = pre ? 1 : k3b_items;
-            const int per_wg = BIN_GROUP * r.items;
-            const int ngroups = (h->nchunks + per_wg - 1) / per_wg;
-            r.n = h->n; r.nchunks = h->nchunks; r.grid = ngroups * 8;
-            r.seg_lt = h->seg_lt; r.seg_row = h->seg_row; r.seg_cnt = h->seg_cnt; r.cx = h->cx; r.res_x = h->res_x; r.res_parent = h->res_parent;
-            r.t_next = h->t; r.slot_offset = h->slot_offset; r.k0 = (uint32_t)h->seed; r.k1 = (uint32_t)(h->seed >> 32);
-            r.zpre = pre ? h->zpre : nullptr;
-            // with deviates: of every 16 workgroups 8 look up and 8 draw (k_resolve_bins); each drawing workgroup takes pre_per slots
-            const u64 unit = (u64)K3B_THREADS * PRE_ITEMS;
-            r.pre_per = unit * ((h->n + unit * (u64)r.grid - 1) / (unit * (u64)r.grid));
-            if (pre) r.grid *= 2;
-            r.stream = h->stream;
-            h->ops->resolve(r);
-            if (pre) h->zpre_t = h->t;
-            binned = true;
-        } else if (scheme == MP_RESAMPLE_STRATIFIED) {
+        if (scheme == MP_RESAMPLE_STRATIFIED) {
             hipLaunchKernelGGL(k_resample_gather<2>, dim3(h->k3_grid), dim3(KG_THREADS), table_lds(h->nt, KG_THREADS), h->stream, h->n, h->n,
                                h->n_global, h->slot_offset, (uint32_t)MP_DOM_RESAMPLE, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count,
                                h->S, d, h->cx, h->guide, h->tile_m, h->tile_W, h->tile_W2, h->nt, h->x[h->cur], h->x[h->cur ^ 1], h->parent, h->logw,
@@ -913,7 +863,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     }
     rc = check_launch("resample kernels");
     if (rc != MP_OK) return rc;
-    if (binned) h->permuted = true;   // results stay in segment order; x[cur] is the (stale) pre-resample state
+    if (drawn_only) h->deferred = true;   // x[cur] is the (stale) pre-resample state until the draws are looked up
     else h->cur ^= 1;
     h->rows_fresh = false;            // the log-weights are now all zero
     h->resample_count += 1;
@@ -1010,11 +960,12 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
     HIPCK(hipSetDevice(h->device));
     { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
     // a step after a lazy resample moved the states on but left the parents where the resample put them
-    if (h->parents_lazy) {
-        hipLaunchKernelGGL(k_parents_from_segments, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->nchunks, h->perm,
-                           h->res_parent, h->parent);
-        h->parents_lazy = false;
-        int32_t rcp = check_launch("k_parents_from_segments");
+    if (h->parents_deferred) {
+        hipLaunchKernelGGL(k_resolve_slots<false>, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->ops->dim_state,
+                           (const u64*)h->dfr_lt, (const uint32_t*)h->dfr_row, (const mp_cx*)h->cx_alt, (const double*)nullptr, (double*)nullptr, h->parent,
+                           (double*)nullptr);
+        h->parents_deferred = false;
+        int32_t rcp = check_launch("k_resolve_slots");
         if (rcp != MP_OK) return rcp;
     }
     if (h->sh_parents_lazy) {
@@ -1105,7 +1056,7 @@ int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total
     }
     int32_t rc = check_launch("k_shard_scatter");
     if (rc != MP_OK) return rc;
-    h->parents_lazy = false;   // k_shard_scatter wrote parent[]
+    h->parents_deferred = false;   // k_shard_scatter wrote parent[]
     h->sh_parents_lazy = false;
     h->cur ^= 1;
     h->rows_fresh = false;
@@ -1263,7 +1214,6 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
     // from row sh_req_slot[i] of the exchange buffer; anything else first copies states and parents into slot order.
     h->sh_rows = d_rows_in;
     h->sh_lazy = true;
-    h->parents_lazy = false;
     h->sh_parents_lazy = false;
     h->logw_zero = true;   // log_weights.fill(0.) (:114): the next propagate does not re-read them; anything else clears the buffer first
     h->cur ^= 1;
@@ -1482,7 +1432,6 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
     }
     h->sh_rows = d_rows;
     h->sh_lazy = true;     // the next propagate reads slot i's state from row sh_req_slot[i] of d_rows
-    h->parents_lazy = false;
     h->sh_parents_lazy = false;
     h->logw_zero = true;
     h->cur ^= 1;
@@ -1620,12 +1569,12 @@ int32_t mp_pf_destroy(mp_pf* h) {
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     for (void* slab : h->hist_slabs) (void)hipFree(slab);
     (void)hipFree(h->d_hist_events);
-    (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->guide);
+    (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->cx_alt); (void)hipFree(h->k1_tail_alt); (void)hipFree(h->guide);
     (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->scal);
     (void)hipFree(h->aos);
     (void)hipFree(h->k1_tail);
-    (void)hipFree(h->tab_ticket); (void)hipFree(h->tab_incl); (void)hipFree(h->tab_ratio); (void)hipFree(h->tab_head); (void)hipFree(h->zpre);
-    (void)hipFree(h->seg_lt); (void)hipFree(h->seg_row); (void)hipFree(h->perm); (void)hipFree(h->seg_cnt); (void)hipFree(h->res_x); (void)hipFree(h->res_parent);
+    (void)hipFree(h->tab_ticket); (void)hipFree(h->tab_incl); (void)hipFree(h->tab_ratio); (void)hipFree(h->tab_head);
+    (void)hipFree(h->dfr_lt); (void)hipFree(h->dfr_row);
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all); (void)hipFree(h->sh_ratio_all);
     (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done); (void)hipFree(h->scal_undo);

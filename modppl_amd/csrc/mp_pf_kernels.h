@@ -57,22 +57,15 @@ constexpr int GUIDE_N = 1 << GUIDE_BITS;
 static_assert(GUIDE_N == TILE, "normalize_tile zeroes/stores the guide with one (16 | 8 | 4)-byte word per thread");
 constexpr int GUIDE_DIRECT = 8;                  // bucket runs longer than this are filled by the whole wave
 constexpr int FIX_BITS = 51;                     // level-0 fixed point: q = rint(exp(lw - m_tile) * 2^51), 2048 * 2^51 < 2^63
-constexpr int BIN_CHUNK = 1024;                  // output slots per chunk of the binned resampler
-constexpr int BIN_THREADS = 512;                  // x 2 draws per thread (256 x 4: 20.4 us, 512 x 2: 18.4 us, 1024 x 1: 23.9 us at 2^20)
-constexpr int BIN_ITEMS = BIN_CHUNK / BIN_THREADS;   // = 2: a thread owns two ADJACENT output slots (one Philox block)
-static_assert(BIN_ITEMS == 2, "k_bin_draws: two adjacent draws per thread");
-constexpr int K3B_THREADS = 256;                  // k_resolve_bins: 128 lanes per quad of K3B_ITEMS chunks
-constexpr int K3B_ITEMS = 1;                      // segments per thread: 4 / 2 / 1 measured 19.0 / 17.5 / 16.2 us (more waves hide the two dependent hops better than 4 chains per lane)
-constexpr int BIN_GROUP = (K3B_THREADS / 128) * K3B_ITEMS;   // chunks per k_resolve_bins workgroup
-constexpr int PRE_ITEMS = 2;                      // slots per thread of a deviate-drawing workgroup of k_resolve_bins
-// Position of entry e of segment (bin, chunk) in the sparse segment arrays [bin][chunk][1024].  Only ~128 entries of
-// each 1024-entry window are used; the start is rotated by (chunk % 8) * 128 so the used parts spread over the address space.
-#define MP_SEG_POS(bin, c, e, nchunks) ((((u64)(bin) * (u64)(nchunks) + (u64)(c)) * BIN_CHUNK) + (u64)((((uint32_t)(e)) + (((uint32_t)(c)) & 7u) * 128u) & 1023u))
+constexpr int DRAW_CHUNK = 1024;                 // output slots per workgroup of k_draw_slots
+constexpr int DRAW_THREADS = 512;                // x 2 draws per thread (256 x 4: 20.4 us, 512 x 2: 18.4 us, 1024 x 1: 23.9 us at 2^20, round 1)
+constexpr int DRAW_ITEMS = DRAW_CHUNK / DRAW_THREADS;   // = 2: a thread owns two ADJACENT output slots (one Philox block)
+static_assert(DRAW_ITEMS == 2, "k_draw_slots: two adjacent draws per thread");
 constexpr int K3_THREADS = 256;
 constexpr int K3_ITEMS = 4;
 constexpr int K3_MAX_BLOCKS = 4096;
 constexpr int MAX_TILES = 8192;                  // LDS tile table: 16 B per tile
-constexpr int K1_TABLE_LDS_MAX_TILES = 2048;     // k_bin_draws copies the prebuilt tile table (24 B per tile) into LDS up to here, probes it in L2 beyond
+constexpr int K1_TABLE_LDS_MAX_TILES = 2048;     // k_draw_slots copies the prebuilt tile table (24 B per tile) into LDS up to here, probes it in L2 beyond
 
 // particles per predraw round in k_propagate: 4 pre-drawn (u, r) pairs per lane whatever the model's number of normal sites
 template <class Model>
@@ -508,131 +501,9 @@ __global__ __launch_bounds__(256) void k_simulate(Model model, u64 n, uint32_t k
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Standard deviates of the polar method for a block of particles, workgroup-cooperatively.
-// z[p * NS + s] = u * c (normal.rs:19-26) of particle (lane's p-th) and free normal site s, from the attempts
-// att = 0, 1, 2 ... of Philox stream (slot, t, MODEL | site): the first accepted one, exactly what the reference's
-// recursion returns.  A lane-local rejection loop makes a wave iterate max-over-lanes of the attempts (~2.7 Philox
-// blocks per deviate at 2 deviates per lane, more for the slowest wave of a workgroup, which the tile's barrier then
-// waits for); here every lane makes attempt 0 of its own deviates, the rejected ones (21.5 %) are queued in LDS and
-// retried by the workgroup's first lanes, one attempt per round (the attempt number is the round: wave-uniform),
-// until fewer than a wave's worth is left, which one wave finishes.  ~1.35 blocks per deviate, equal work per wave.
-// Results depend on nothing but the counters: which lane computes an attempt changes no bit.
-// ---------------------------------------------------------------------------------------------
 constexpr uint32_t MP_MAX_ATTEMPTS = 1u << 16;   // exit condition of every retry loop (acceptance pi/4: never reached)
-template <class Model, int THREADS, int LANE_ITEMS>
-struct mp_coop {
-    static constexpr int NS = Model::MAX_NORMALS;
-    static constexpr int M = LANE_ITEMS * NS;
-    static constexpr int NITEMS = THREADS * M;
-    // retry queue capacity: the expected load is 0.215 * NITEMS; an item that does not fit is retried by its own lane
-    static constexpr int CAP = NITEMS >= 4096 ? NITEMS / 3 : (NITEMS >= 512 ? NITEMS / 2 : NITEMS);
-};
-template <class Model, int THREADS, int LANE_ITEMS>
-__device__ __forceinline__ void mp_coop_std_normals(const Model& model, int ns, long long t, u64 wg_slot0 /* global slot of the block's first particle */,
-                                                    uint32_t n_live /* particles of the block that exist */, uint32_t k0, uint32_t k1,
-                                                    double (&z)[LANE_ITEMS * Model::MAX_NORMALS]) {
-    using C = mp_coop<Model, THREADS, LANE_ITEMS>;
-    constexpr int NS = C::NS, M = C::M, CAP = C::CAP;
-    __shared__ uint32_t s_q[2][CAP];           // (item | result index << 16) of the deviates still to be drawn
-    __shared__ double s_res[CAP][2];           // accepted (u, r) by result index
-    __shared__ uint32_t s_qn[3];               // queue lengths, rotating: read / push / zero
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t dom = (uint32_t)MP_DOM_MODEL << 16;
-    if (tid < 3) s_qn[tid] = 0u;
-    __syncthreads();
-    double pu[M], pr[M];
-    int res_idx[M];                            // -1: accepted at attempt 0; >= 0: result index; -2: retried by this lane
-    // ---- attempt 0 of every deviate of this lane --------------------------------------------
-#pragma unroll
-    for (int q = 0; q < M; ++q) {
-        const int p = q / NS, sidx = q % NS;
-        const uint32_t pl = (uint32_t)(tid * LANE_ITEMS + p);       // particle of the block
-        const bool live = sidx < ns && pl < n_live;
-        pu[q] = 0.; pr[q] = 1.; res_idx[q] = -1;
-        bool rej = false;
-        if (live) {
-            const mp_u64x2 b = mp_philox4x32_10((uint32_t)(wg_slot0 + pl), (uint32_t)t, dom | model.normal_site(sidx), 0u, k0, k1);
-            rej = !mp_polar_attempt(b, &pu[q], &pr[q]);
-        }
-        const u64 bal = __ballot(rej);
-        if (bal) {   // wave-uniform
-            const int leader = __ffsll((long long)bal) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&s_qn[0], (uint32_t)__popcll(bal));
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            if (rej) {
-                const uint32_t e = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (e < (uint32_t)CAP) {
-                    s_q[0][e] = (pl * NS + (uint32_t)sidx) | (e << 16);
-                    res_idx[q] = (int)e;
-                } else {
-                    res_idx[q] = -2;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- retry rounds: attempt number = round ------------------------------------------------
-    uint32_t nq = s_qn[0] < (uint32_t)CAP ? s_qn[0] : (uint32_t)CAP;
-    int cur = 0;
-    uint32_t att = 1;
-    while (nq > 64u && att < MP_MAX_ATTEMPTS) {   // workgroup-uniform
-        const int rd = (int)((att - 1) % 3), wr = (int)(att % 3), zr = (int)((att + 1) % 3);
-        (void)rd;
-        if (tid == 0) s_qn[zr] = 0u;              // next round's push counter: nobody touches it in this round
-        for (uint32_t e = (uint32_t)tid; e < nq; e += THREADS) {
-            const uint32_t ent = s_q[cur][e];
-            const uint32_t item = ent & 0xFFFFu, ri = ent >> 16;
-            const uint32_t pl = item / NS, sidx = item % NS;
-            const mp_u64x2 b = mp_philox4x32_10((uint32_t)(wg_slot0 + pl), (uint32_t)t, dom | model.normal_site((int)sidx), att, k0, k1);
-            double u, r;
-            const bool rej = !mp_polar_attempt(b, &u, &r);
-            if (!rej) { s_res[ri][0] = u; s_res[ri][1] = r; }
-            const u64 bal = __ballot(rej);
-            if (bal) {
-                const int leader = __ffsll((long long)bal) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&s_qn[wr], (uint32_t)__popcll(bal));
-                base = (uint32_t)__shfl((int)base, leader, 64);
-                if (rej) s_q[cur ^ 1][base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = ent;
-            }
-        }
-        __syncthreads();
-        nq = s_qn[wr];
-        cur ^= 1;
-        ++att;
-    }
-    if (tid < 64 && (uint32_t)tid < nq) {         // at most one wave's worth left: finished by lane-local loops
-        const uint32_t ent = s_q[cur][tid];
-        const uint32_t item = ent & 0xFFFFu, ri = ent >> 16;
-        const uint32_t pl = item / NS, sidx = item % NS;
-        double u = 0., r = 1.;
-        for (uint32_t a = att; a < MP_MAX_ATTEMPTS; ++a) {
-            const mp_u64x2 b = mp_philox4x32_10((uint32_t)(wg_slot0 + pl), (uint32_t)t, dom | model.normal_site((int)sidx), a, k0, k1);
-            if (mp_polar_attempt(b, &u, &r)) break;
-        }
-        s_res[ri][0] = u; s_res[ri][1] = r;
-    }
-    __syncthreads();
-    // ---- every lane: collect its retried deviates, then the parameter-free part of normal.rs:25-26 once per deviate ----
-#pragma unroll
-    for (int q = 0; q < M; ++q) {
-        const int p = q / NS, sidx = q % NS;
-        if (res_idx[q] >= 0) { pu[q] = s_res[res_idx[q]][0]; pr[q] = s_res[res_idx[q]][1]; }
-        if (res_idx[q] == -2) {   // did not fit the queue (never, in practice): own loop
-            const uint32_t pl = (uint32_t)(tid * LANE_ITEMS + p);
-            for (uint32_t a = 1; a < MP_MAX_ATTEMPTS; ++a) {
-                const mp_u64x2 b = mp_philox4x32_10((uint32_t)(wg_slot0 + pl), (uint32_t)t, dom | model.normal_site(sidx), a, k0, k1);
-                if (mp_polar_attempt(b, &pu[q], &pr[q])) break;
-            }
-        }
-        z[q] = mp_std_normal_from_pair(pu[q], pr[q]);
-    }
-}
-
-// whether a model's deviates are drawn cooperatively / ahead of the step (few sites per particle) or by the lane-local
-// queue of k_propagate (many sites per particle: the queue is long enough to even out the attempts, and the LDS is not)
+// whether the rejected attempts of a model's deviates are retried by the wave (few sites per particle) or by the lane-local
+// queue of k_propagate (many sites per particle: the queue is long enough to even out the attempts)
 template <class Model>
 constexpr bool mp_coop_model() { return Model::MAX_NORMALS <= 4; }
 
@@ -640,14 +511,52 @@ constexpr bool mp_coop_model() { return Model::MAX_NORMALS <= 4; }
 // K1: propagate + weight + level 0 of the normalisation, one workgroup per tile
 // ---------------------------------------------------------------------------------------------
 // A lane owns LANE_ITEMS consecutive particles of its tile.  Standard deviates of the free normal sites come
-//   (a) from zpre[slot][site] when the resample's lookup kernel drew them for this time step (k_resolve_bins), or
-//   (b) from mp_coop_std_normals (few sites per particle), or
-//   (c) from a lane-local work queue over the lane's (particle, site) items (many sites: ~1.6 blocks per item at 16).
+//   (a) few sites per particle: attempt 0 of every deviate in straight-line code, the rejected ones retried by the wave, or
+//   (b) many sites: from a lane-local work queue over the lane's (particle, site) items (~1.6 blocks per item at 16).
 // Then the model kernel runs per particle in Generate mode on them.
 struct mp_k1_aux {
-    const double* zpre;     // [n][ns] standard deviates for THIS time step, or null
     mp_tab tab;
 };
+// A draw of the last resample that has not been looked up yet (k_draw_slots left {tile-local target, start row} per output
+// slot): its parent is the first row of the start row's tile, at or after it, whose cumulative weight reaches the target
+// (categorical.rs:23-37 restricted to the tile).  Start row and successor go out together, whole 16-byte rows.
+typedef u64 mp_u64v2 __attribute__((ext_vector_type(2)));   // one table row as it is loaded: {cum, bits of x0}
+__device__ __forceinline__ mp_u64v2 mp_ld_row(const mp_cx* p) { return *reinterpret_cast<const mp_u64v2*>(p); }
+__device__ __forceinline__ void mp_pin_rows(mp_u64v2& a, mp_u64v2& b2) { asm volatile("" : "+v"(a), "+v"(b2)::"memory"); }
+__device__ __forceinline__ void mp_pin3(int& a, u64& b2, uint32_t& c) { asm volatile("" : "+v"(a), "+v"(b2), "+v"(c)::"memory"); }
+__device__ __forceinline__ u64 mp_tile_last(uint32_t row, u64 n) {
+    const u64 tend = (((u64)row / TILE) + 1) * TILE;
+    return (tend < n ? tend : n) - 1;      // last row of the tile
+}
+// N draws at a time: every load goes out before the first is used.
+template <int N>
+__device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u64 n, const u64* lt, const uint32_t* row, uint32_t* parent, double* x0) {
+    mp_u64v2 a[N], b2[N];
+    u64 last[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        last[k] = mp_tile_last(row[k], n);
+        a[k] = mp_ld_row(cx + row[k]);
+        b2[k] = mp_ld_row(cx + (u64)row[k] + ((u64)row[k] < last[k] ? 1 : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) mp_pin_rows(a[k], b2[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const bool step1 = a[k].x < lt[k] && (u64)row[k] < last[k];
+        u64 p = (u64)row[k] + (step1 ? 1 : 0);
+        mp_u64v2 cur = step1 ? b2[k] : a[k];
+        while (cur.x < lt[k] && p < last[k]) {   // rare: more than one row past the guide's start
+            ++p;
+            cur = mp_ld_row(cx + p);
+        }
+        parent[k] = (uint32_t)p;   // (may alias row[])
+        x0[k] = __builtin_bit_cast(double, (u64)cur.y);
+    }
+}
+__device__ __forceinline__ void mp_resolve_draw(const mp_cx* __restrict__ cx, u64 n, u64 lt, uint32_t row, uint32_t* parent, double* x0) {
+    mp_resolve_draws<1>(cx, n, &lt, &row, parent, x0);
+}
 // What k_propagate needs only in its LAST phase (level 0 / level 1 of the normalisation), constant per handle: kept in
 // device memory and read there — as kernel arguments these 11 pointers sat in SGPRs through the whole VALU-bound part of the
 // kernel, which ran out of them (78 at 8 waves per SIMD) and spilled to VGPR lanes.
@@ -661,33 +570,36 @@ struct mp_k1_tail {
 };
 // The model kernel in Generate mode for ONE particle (slot i): previous state from wherever the last resample left it, the
 // functor with a Generate handler over the deviates zp[0..NS), new state and log-weight out.
-template <class Model>
+template <class Model, bool LT_EARLY>
 __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, long long t,
                                                 const double* __restrict__ x_in, double* __restrict__ x_out, double* logw, const double* obs_v,
-                                                const double* s0_v, int overwrite, bool permuted, const double* __restrict__ res_x, int nchunks,
-                                                bool via_inv, const uint32_t* __restrict__ res_parent, uint32_t pmv, u64 i, const double* zp,
-                                                double* lw_out, double* x0_out) {
+                                                const double* s0_v, int overwrite, bool deferred, const double* __restrict__ inv_rows,
+                                                const mp_cx* __restrict__ cx_old, bool via_inv, const u64* __restrict__ dfr_lt, uint32_t pmv, u64 ltv,
+                                                double x0v, u64 i, const double* zp, double* lw_out, double* x0_out) {
     constexpr int D = Model::DIM_STATE;
     if (i >= n) return;
     double prev[D], next[D];
     if (via_inv) {
         // the last (sharded) resample left the parents' states where the all-to-all put them: slot i's row {x[0..D), parent
-        // id} is row inv[i] (= pmv) of the exchange buffer (res_x here); owner-keeps exchange, D > 1: a kept offspring has no row
+        // id} is row inv[i] (= pmv) of the exchange buffer (inv_rows here); owner-keeps exchange, D > 1: a kept offspring has no row
         // — its entry names the parent's local row of the pre-resample buffer x_in (mp_pf_shard_kernels.h MP_INV_LOCAL)
         const bool local_parent = D > 1 && (pmv & 0x80000000u);
-        const double* row = local_parent ? x_in + (u64)(pmv & 0x7FFFFFFFu) * D : res_x + (u64)pmv * (u64)(D + 1);
+        const double* row = local_parent ? x_in + (u64)(pmv & 0x7FFFFFFFu) * D : inv_rows + (u64)pmv * (u64)(D + 1);
 #pragma unroll
         for (int d = 0; d < D; ++d) prev[d] = row[d];
-    } else if (permuted) {
-        // the last resample left the states in bin-segment order (k_resolve_bins): slot i's state sits at segment
-        // (bin, chunk of i) position rank, (bin << 10 | rank) = perm[i] (= pmv)
-        const u64 pos = MP_SEG_POS(pmv >> 10, i >> 10, pmv & 1023u, nchunks);
+    } else if (deferred) {
+        // the last resample only DREW (k_draw_slots): slot i's parent is looked up here, in the row table of the generation
+        // that was resampled (cx_old; this launch writes the new table into the other buffer) — the clone loop of `resample`
+        // (particle_filter.rs:109-114), fused into the step that consumes it
+        // (LT_EARLY: the caller has looked the lane's draws up together — pmv = parent, x0v = its first state component)
+        uint32_t par = pmv;
+        double x0 = x0v;
+        if constexpr (!LT_EARLY) mp_resolve_draw(cx_old, n, dfr_lt[i], pmv, &par, &x0);
         if constexpr (D == 1) {
-            prev[0] = res_x[pos];              // k_resolve_bins had it in the table row it found
+            prev[0] = x0;                      // the row carries the first state component
         } else {
-            // wider states are gathered here, straight from the parent's (particle-major) row of the pre-resample buffer:
-            // one line per particle, hidden under this kernel's arithmetic
-            const double* src = x_in + (u64)res_parent[pos] * D;
+            // wider states: the parent's (particle-major) row of the pre-resample buffer
+            const double* src = x_in + (u64)par * D;
 #pragma unroll
             for (int d = 0; d < D; ++d) prev[d] = src[d];
         }
@@ -715,9 +627,9 @@ template <class Model, int THREADS>
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
                                                             mp_obs obs, mp_state0 s0, int overwrite,
-                                                            const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
-                                                            int nchunks, const mp_k1_tail* tail,
-                                                            const uint32_t* __restrict__ inv, const uint32_t* __restrict__ res_parent, mp_k1_aux aux) {
+                                                            const uint32_t* __restrict__ dfr_row, const double* __restrict__ inv_rows,
+                                                            const mp_cx* __restrict__ cx_old, const mp_k1_tail* tail,
+                                                            const uint32_t* __restrict__ inv, const u64* __restrict__ dfr_lt, mp_k1_aux aux) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int LANE_ITEMS = TILE / THREADS;
@@ -732,13 +644,23 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
 #pragma unroll
     for (int j = 0; j < LANE_ITEMS; ++j) { lw[j] = MP_NEG_INF; xv[j] = 0.; }
     // the first hop of the state fetch goes out before anything else: its latency runs under phase 1
+    // (a deferred draw = {start row, tile-local target}; the target rides along only where registers are plentiful)
+    constexpr bool LT_EARLY = !QUEUE;
     uint32_t pm[LANE_ITEMS];
+    u64 plt[LT_EARLY ? LANE_ITEMS : 1];
 #pragma unroll
-    for (int p = 0; p < LANE_ITEMS; ++p) pm[p] = base + p < n ? (inv ? inv[base + p] : (perm ? (uint32_t)perm[base + p] : 0u)) : 0u;
+    for (int p = 0; p < LANE_ITEMS; ++p) {
+        pm[p] = base + p < n ? (inv ? inv[base + p] : (dfr_row ? dfr_row[base + p] : 0u)) : 0u;
+        if constexpr (LT_EARLY) plt[p] = (dfr_lt && base + p < n) ? dfr_lt[base + p] : 0ull;
+        else plt[0] = 0ull;
+    }
     // phase 2 = mp_run_particle (above): the model kernel in Generate mode for one particle
 #define MP_RUN_PARTICLE(P, ZP)                                                                                                             \
-    mp_run_particle<Model>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, perm != nullptr, res_x, nchunks, inv != nullptr, \
-                           res_parent, pm[P], base + (u64)(P), ZP, &lw[P], &xv[P])
+    mp_run_particle<Model, LT_EARLY>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, dfr_row != nullptr, inv_rows, cx_old, \
+                                     inv != nullptr, dfr_lt, pm[P], plt[LT_EARLY ? (P) : 0], px0[LT_EARLY ? (P) : 0], base + (u64)(P), ZP, &lw[P],   \
+                                     &xv[P])
+    double px0[LT_EARLY ? LANE_ITEMS : 1];
+    px0[0] = 0.;
     // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
     if constexpr (QUEUE) {
         // lane-local queue, rounds of ITEMS particles (ITEMS * NS accepted pairs in registers at a time); the model runs on a
@@ -817,18 +739,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
 #pragma unroll
             for (int pp = 0; pp < ITEMS; ++pp) MP_RUN_PARTICLE(rd * ITEMS + pp, &zr[pp * NS]);
         }
-    } else if (aux.zpre) {
-#pragma unroll
-        for (int p = 0; p < LANE_ITEMS; ++p)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) z[p * NS + s] = (s < ns && base + p < n) ? aux.zpre[(base + p) * (u64)ns + s] : 0.;
     } else {
         // few sites per particle: attempt 0 of every deviate in straight-line code (independent Philox chains, no
         // divergence; the state fetch's first hop lands meanwhile), then the rejected ones (21.5 %) are retried by the WAVE:
         // its 64 lanes share out the pending deviates and try several further attempts of each at once (attempts are
         // independent counters; the lowest accepted one wins, which is what the reference's recursion returns).  Two rounds
         // nearly always, for every wave alike — a lane-local loop makes the tile's first barrier wait for the unluckiest of
-        // 1024 lanes (measured: 10 k cycles of a 43 k-cycle workgroup), and mp_coop_std_normals pays five workgroup barriers.
+        // 1024 lanes (measured: 10 k cycles of a 43 k-cycle workgroup), and a workgroup-wide queue pays five barriers.
         constexpr int M = LANE_ITEMS * NS;
         __shared__ uint32_t s_it[THREADS / 64][64];   // wave-private: identities of the pending deviates of a round
         const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
@@ -894,6 +811,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     }
     MP_STAMP(0, 2, 0);
     if constexpr (!QUEUE) {
+        // the lane's deferred draws, looked up together (their {start row, target} were loaded before the deviates: the rows
+        // are one more hop).  Where the row loads are placed — before the deviates, between attempt 0 and the retries, here —
+        // changes nothing measurable (39.9 / 38.6 / 38.3 us): the kernel pays for the lines these gathers pull through
+        // the fabric, not for their latency.
+        if (dfr_row) mp_resolve_draws<LANE_ITEMS>(cx_old, n, plt, pm, pm, px0);   // pm[] = the parents from here on
 #pragma unroll
         for (int p = 0; p < LANE_ITEMS; ++p) MP_RUN_PARTICLE(p, &z[p * NS]);
     }
@@ -925,8 +847,8 @@ typedef double mp_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int DENSE_THREADS = 512;
 __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_dense<16> model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, long long t,
                                                                      const double* __restrict__ x_in, double* __restrict__ x_out, double* logw, mp_obs obs,
-                                                                     int overwrite, const unsigned short* __restrict__ perm,
-                                                                     const uint32_t* __restrict__ res_parent, int nchunks, mp_cx* __restrict__ cx,
+                                                                     int overwrite, const uint32_t* __restrict__ dfr_row,
+                                                                     const u64* __restrict__ dfr_lt, const mp_cx* __restrict__ cx_old, mp_cx* __restrict__ cx,
                                                                      unsigned short* __restrict__ guide, double* tile_m, u64* tile_W, u64* tile_W2,
                                                                      mp_k1_aux aux, const uint32_t* __restrict__ inv, const double* __restrict__ rows) {
     constexpr int D = 16;
@@ -982,9 +904,11 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
         if (inv && live) {
             const uint32_t v = inv[p];
             myrow = (v & 0x80000000u) ? x_in + (u64)(v & 0x7FFFFFFFu) * D : rows + (u64)v * (u64)(D + 1);
-        } else if (perm && live) {
-            const uint32_t pr_ = perm[p];
-            myrow = x_in + (u64)res_parent[MP_SEG_POS(pr_ >> 10, p >> 10, pr_ & 1023u, nchunks)] * D;
+        } else if (dfr_row && live) {   // a draw of the last resample, looked up here (mp_resolve_draw)
+            uint32_t par;
+            double x0;
+            mp_resolve_draw(cx_old, n, dfr_lt[p], dfr_row[p], &par, &x0);
+            myrow = x_in + (u64)par * D;
         }
         const u64 myaddr = (u64)(uintptr_t)myrow;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1345,38 +1269,37 @@ __global__ __launch_bounds__(KG_THREADS) void k_resample_gather(u64 n, u64 n_out
 }
 
 // ---------------------------------------------------------------------------------------------
-// XCD-binned multinomial resampling (same parents per slot as k_resample_gather, bit for bit)
+// Multinomial resampling in two halves (same parents per slot as k_resample_gather, bit for bit)
 // ---------------------------------------------------------------------------------------------
-// The row table (16 B x N) does not fit one XCD's 4 MB L2, so random row reads cross the fabric a full line at a
-// time.  But the top 3 bits of a draw's uniform say which EIGHTH of the CDF it lands in.  So:
-//   K3a k_bin_draws     every chunk of 1024 output slots: tile table, Philox (one block per two adjacent slots), target,
-//                       tile + guide lookup (the 2 MB guide is L2-resident everywhere), split of the chunk's draws into
-//                       the 8 bins: segment [bin][chunk][<=1024] of (tile-local target, start row), perm[slot] = (bin << 10 | pos).
-//   K3b k_resolve_bins  workgroup (group of chunks, bin b) with blockIdx % 8 == b — workgroups are dealt
-//                       round-robin over the 8 XCDs, so the row lookups of bin b run on one XCD whose L2 then holds
-//                       that eighth of the table (speed only: any placement gives the same result).
-// Measured (profiles/r01): L2 hit rate 0.58 -> 0.86, fabric traffic 107 -> 52 MB per resample of 2^20, 46 -> 30 us.
+//   k_draw_slots    every chunk of 1024 output slots: tile table, Philox (one block per two adjacent slots), target, tile +
+//                   guide lookup (the 2 MB guide is L2-resident everywhere) -> {tile-local target, start row} per slot.
+//   the row lookups (start row, successor, rarely more: mp_resolve_draws) are left to the kernel that consumes the parents:
+//                   the next step's k_propagate, which looks its own slots' draws up under its arithmetic, or
+//                   k_resolve_slots when the host asks for slot-order states / parents first.
+// The row table (16 B x N) does not fit one XCD's 4 MB L2, so the random row reads pull whole lines through the fabric
+// whoever issues them.  Round 1 / early round 2 binned the draws by the top 3 bits of their uniform and resolved bin b on
+// XCD b in a kernel of its own (L2 hit rate 0.58 -> 0.86, 14 us at 2^20); fused into k_propagate the unbinned lookups cost
+// that kernel 10 us, the binning's scan, barriers and segment traffic disappear from this one (12.6 -> 9.9 us), and there
+// is no third kernel: 53.7 -> 47.5 us per step.
 // Tile table (TABMODE): 0 = every workgroup builds it in LDS from the tile scalars (handles without a k_propagate-built
 // table); 1 = built once by the last workgroup of the level-0 launch (build_tile_table_global) and copied to LDS here;
 // 2 = the same, probed where it lies in L2 (more tiles than fit LDS).
 template <int TABMODE>
-__global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_bin_draws(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S, int nchunks,
+__global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_draw_slots(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S,
                                                            const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
                                                            const u64* __restrict__ tile_W2, int nt,
                                                            const unsigned short* __restrict__ guide,
-                                                           u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row,
-                                                           unsigned short* __restrict__ perm, unsigned short* __restrict__ seg_cnt,
+                                                           u64* __restrict__ dfr_lt, uint32_t* __restrict__ dfr_row,
                                                            mp_dev_scalars* scal, const u64* __restrict__ incl_pre,
                                                            const double* __restrict__ ratio_pre, const mp_tab_head* __restrict__ head) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NW = BIN_THREADS / 64;
+    constexpr int NW = DRAW_THREADS / 64;
     const int nt_lds = TABMODE == 2 ? 0 : nt;
     u64* s_incl_lds = reinterpret_cast<u64*>(smem);                    // [nt]
     u64* s_W_lds = s_incl_lds + nt_lds;                                // [nt]
     double* s_ratio_lds = reinterpret_cast<double*>(s_W_lds + nt_lds); // [nt] (TABMODE 1)
     double* s_red = s_ratio_lds + (TABMODE == 1 ? nt_lds : 0);         // [NW]
     u64* s_wtot = reinterpret_cast<u64*>(s_red + NW);                  // [NW]
-    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(s_wtot + NW);       // [NW][8] draws per (wave, bin), then their exclusive offsets
     const u64* s_incl = TABMODE == 2 ? incl_pre : s_incl_lds;
     const u64* s_W = TABMODE == 2 ? tile_W : s_W_lds;
     const double* s_ratio = TABMODE == 2 ? ratio_pre : s_ratio_lds;
@@ -1384,23 +1307,23 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     const int tid = threadIdx.x;
     MP_STAMP(1, 0, 0); MP_STAMP(1, 1, 1); MP_STAMP(1, 6, 2);
     if constexpr (TABMODE == 0) {
-        const double m = block_tile_table<BIN_THREADS>(tile_m, tile_W, nt, S, s_incl_lds, s_W_lds, s_red, s_wtot);
+        const double m = block_tile_table<DRAW_THREADS>(tile_m, tile_W, nt, S, s_incl_lds, s_W_lds, s_red, s_wtot);
         if (blockIdx.x == 0) {  // fold this normalisation into the filter scalars
-            const u64 Q2 = block_sum_T2<BIN_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
+            const u64 Q2 = block_sum_T2<DRAW_THREADS>(tile_m, tile_W2, nt, S, m, s_wtot);
             if (threadIdx.x == 0) fold_scalars(scal, s_incl_lds[nt - 1], Q2, S, m, n_global, 0);
         }
     }
     // this thread's two adjacent output slots share one Philox block (it depends on no table: in TABMODE 1 it is computed
     // while the table's loads are in flight)
-    const u64 i0 = (u64)c * BIN_CHUNK + 2u * (u64)tid;
+    const u64 i0 = (u64)c * DRAW_CHUNK + 2u * (u64)tid;
     mp_u64x2 blk;
     if constexpr (TABMODE == 1) {
-        constexpr int TPT = (K1_TABLE_LDS_MAX_TILES + BIN_THREADS - 1) / BIN_THREADS;   // table entries per thread
+        constexpr int TPT = (K1_TABLE_LDS_MAX_TILES + DRAW_THREADS - 1) / DRAW_THREADS;   // table entries per thread
         u64 tI[TPT], tW[TPT];
         double tR[TPT];
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
-            const int b = tid + k * BIN_THREADS;
+            const int b = tid + k * DRAW_THREADS;
             tI[k] = b < nt ? incl_pre[b] : 0ull;
             tW[k] = b < nt ? tile_W[b] : 0ull;
             tR[k] = b < nt ? ratio_pre[b] : 0.;
@@ -1408,7 +1331,7 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
         blk = mp_resample_block((slot_offset + i0) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
-            const int b = tid + k * BIN_THREADS;
+            const int b = tid + k * DRAW_THREADS;
             if (b < nt) { s_incl_lds[b] = tI[k]; s_W_lds[b] = tW[k]; s_ratio_lds[b] = tR[k]; }
         }
     } else {
@@ -1422,210 +1345,58 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     MP_STAMP(1, 2, 0);
     const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
     u64 lt[2];
-    uint32_t gslot[2], tile_of[2], bin[2], pos[2], j0[2];
+    uint32_t gslot[2], tile_of[2], j0[2];
     bool live[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const u64 k52 = mp_u52(q ? blk.b : blk.a);
         if constexpr (TABMODE == 0) mp_locate(s_incl, s_W, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
         else mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
-        bin[q] = (uint32_t)(k52 >> 49);
         live[q] = i0 + q < n;
     }
-    // the guide lookups go out now (the guide is L2-resident on every XCD) and land while the places are worked out
+    // the guide lookups (the guide is L2-resident on every XCD)
 #pragma unroll
     for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];
-    // place of a draw in its segment: draws of the same bin in lower waves, then in lower lanes of this wave (either slot of
-    // the pair), then the lane's own first draw.  (One LDS atomic per draw instead costs ~10 cycles per LANE: 5 us per chunk.)
-    const int lane = tid & 63, wave = tid >> 6;
-    // One packed scan instead of eight ballot rounds: field b (8 bits) of a lane's word counts its draws in bin b (a wave has at
-    // most 128 draws, so no field overflows); the exclusive DPP prefix over the lanes is "draws of the same bin in lower lanes".
-    uint32_t rank[2];
-    {
-        const u64 p0 = live[0] ? 1ull << (8u * bin[0]) : 0ull, p1 = live[1] ? 1ull << (8u * bin[1]) : 0ull;
-        const u64 pk = p0 + p1;
-        const u64 inc = wave_incl_scan_u64(pk, lane);
-        const u64 exc = inc - pk;
-        rank[0] = (uint32_t)(exc >> (8u * bin[0])) & 0xFFu;
-        rank[1] = ((uint32_t)(exc >> (8u * bin[1])) & 0xFFu) + ((live[0] && bin[0] == bin[1]) ? 1u : 0u);
-        const u64 tot = mp_readlane_u64(inc, 63);
-        if (lane < 8) s_wcnt[wave * 8 + lane] = (uint32_t)(tot >> (8u * (uint32_t)lane)) & 0xFFu;
-    }
-    __syncthreads();
-    if (tid < 8) {   // exclusive offsets of the waves, per bin; the chunk's segment lengths
-        uint32_t run = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const uint32_t cw = s_wcnt[w * 8 + tid];
-            s_wcnt[w * 8 + tid] = run;
-            run += cw;
-        }
-        seg_cnt[(u64)tid * nchunks + c] = (unsigned short)run;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 2; ++q) pos[q] = live[q] ? s_wcnt[wave * 8 + bin[q]] + rank[q] : 0u;
-    MP_STAMP(1, 3, 0);
+    // {target, start row} of the two draws in SLOT order: one 16-byte and one 8-byte store per lane
+    uint32_t srow[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        if (live[q]) {
-            const u64 sp = MP_SEG_POS(bin[q], c, pos[q], nchunks);
-            const u64 tbase = (u64)tile_of[q] * TILE;
-            const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
-            const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
-            seg_lt[sp] = lt[q];
-            seg_row[sp] = (uint32_t)tbase + jj;   // row where the forward scan starts
-        }
+        const u64 tbase = (u64)tile_of[q] * TILE;
+        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+        const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
+        srow[q] = (uint32_t)tbase + jj;   // row where the forward scan starts
     }
-    const uint32_t pw0 = (bin[0] << 10) | pos[0], pw1 = (bin[1] << 10) | pos[1];
-    if (live[1]) reinterpret_cast<uint32_t*>(perm)[i0 >> 1] = pw0 | (pw1 << 16);   // i0 is even: one aligned 4-byte store
-    else if (live[0]) perm[i0] = (unsigned short)pw0;
-    MP_STAMP(1, 4, 0); MP_STAMP(1, 5, 1);
+    if (live[1]) {
+        mp_u64v2 v2; v2.x = lt[0]; v2.y = lt[1];
+        *reinterpret_cast<mp_u64v2*>(dfr_lt + i0) = v2;                                      // i0 is even: aligned
+        *reinterpret_cast<uint2*>(dfr_row + i0) = make_uint2(srow[0], srow[1]);
+    } else if (live[0]) {
+        dfr_lt[i0] = lt[0];
+        dfr_row[i0] = srow[0];
+    }
+    MP_STAMP(1, 3, 0); MP_STAMP(1, 4, 0); MP_STAMP(1, 5, 1);
 }
 
-// K3b: pure lookup, two dependent hops (segment entry -> table rows), all inside the bin's eighth of the table.
-// Thread (quad, e) = (tid >> 7, tid & 127) owns entry e of the segment of chunk group*2 + quad; a segment holds
-// 128 +- 11 entries, so nearly every lane is live.  Results stay in SEGMENT order (res_x[bin][chunk][pos], res_parent
-// likewise: coalesced stores); the next k_propagate reads its inputs through perm[], k_unpermute materialises slot
-// order when the host asks.
-// PREDRAW: this kernel is bound by the latency of its lookups and leaves the vector ALUs idle, so the same launch also
-// carries workgroups of a second ROLE that draw the standard deviates the NEXT time step's k_propagate will need
-// (zpre[slot][site], mp_coop_std_normals: they depend on nothing but (slot, t_next, site)) — which takes the rejection
-// loops and their log / divide / sqrt out of the kernel that is bound by vector issue.  Roles go by block: of every 16
-// consecutive workgroups the first 8 are lookups of bins 0..7 (blockIdx % 8 == bin keeps the XCD affinity), the other
-// 8 draw deviates for 8 blocks of K3B_THREADS slots; the hardware overlaps the two kinds on every CU.
-__device__ __forceinline__ void mp_pin3(int& a, u64& b2, uint32_t& c) { asm volatile("" : "+v"(a), "+v"(b2), "+v"(c)::"memory"); }
-typedef u64 mp_u64v2 __attribute__((ext_vector_type(2)));   // one table row as it is loaded: {cum, bits of x0}
-__device__ __forceinline__ mp_u64v2 mp_ld_row(const mp_cx* p) { return *reinterpret_cast<const mp_u64v2*>(p); }
-__device__ __forceinline__ void mp_pin_rows(mp_u64v2& a, mp_u64v2& b2) { asm volatile("" : "+v"(a), "+v"(b2)::"memory"); }
-template <class Model, bool PREDRAW, int ITEMS>
-__global__ __launch_bounds__(K3B_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_resolve_bins(Model model, u64 n, int nchunks, const u64* __restrict__ seg_lt,
-                                                             const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_cnt,
-                                                             const mp_cx* __restrict__ cx, double* __restrict__ res_x,
-                                                             uint32_t* __restrict__ res_parent, long long t_next, u64 slot_offset,
-                                                             uint32_t k0, uint32_t k1, double* __restrict__ zpre, u64 pre_per) {
-    const int role_blk = PREDRAW ? (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;   // index within its role
-    if constexpr (PREDRAW) {
-        if (blockIdx.x & 8) {   // ---- role 2: deviates of the next time step for the slots [lo, hi) ----
-            constexpr int NS = Model::MAX_NORMALS;
-            const int ns = model.n_normals(t_next);   // uniform
-            const u64 lo = (u64)role_blk * pre_per;
-            const u64 hi = (lo + pre_per < n) ? lo + pre_per : n;
-            if (ns > 0) {
-                for (u64 s0 = lo; s0 < hi; s0 += (u64)K3B_THREADS * PRE_ITEMS) {   // workgroup-uniform trip count (barriers inside)
-                    double z[PRE_ITEMS * NS];
-                    const uint32_t n_live = (uint32_t)((hi - s0) < (u64)K3B_THREADS * PRE_ITEMS ? (hi - s0) : (u64)K3B_THREADS * PRE_ITEMS);
-                    mp_coop_std_normals<Model, K3B_THREADS, PRE_ITEMS>(model, ns, t_next, slot_offset + s0, n_live, k0, k1, z);
-#pragma unroll
-                    for (int p = 0; p < PRE_ITEMS; ++p) {
-                        const uint32_t pl = threadIdx.x * PRE_ITEMS + p;
-                        if (pl < n_live) {
-#pragma unroll
-                            for (int s = 0; s < NS; ++s)
-                                if (s < ns) zpre[(s0 + pl) * (u64)ns + s] = z[p * NS + s];
-                        }
-                    }
-                }
-            }
-            return;
-        }
-    }
-    // ---- role 1: lookups of (bin, 2 * ITEMS chunks): thread (quad, e) owns entry e of ITEMS segments ----
-    const int bin = role_blk & 7;
-    const int group = role_blk >> 3;
-    const int e0 = threadIdx.x & 127, quad = threadIdx.x >> 7;
-    MP_STAMP(2, 0, 0); MP_STAMP(2, 1, 1); MP_STAMP(2, 6, 2);
-    auto tile_last = [&](uint32_t row) {
-        const u64 tend = (((u64)row / TILE) + 1) * TILE;
-        return (tend < n ? tend : n) - 1;      // last row of the tile
-    };
-    // first row >= lt, walking forward from `row` inside its tile; a, b2 = that row and the next one, already loaded
-    auto finish = [&](u64 ltx, uint32_t row, u64 last, u64 sp, mp_u64v2 a, mp_u64v2 b2) {
-        const bool step1 = a.x < ltx && (u64)row < last;
-        u64 p = (u64)row + (step1 ? 1 : 0);
-        mp_u64v2 cur = step1 ? b2 : a;
-        while (cur.x < ltx && p < last) {   // rare: more than one row past the guide's start
-            ++p;
-            cur = mp_ld_row(cx + p);
-        }
-        res_parent[sp] = (uint32_t)p;
-        res_x[sp] = __builtin_bit_cast(double, (u64)cur.y);
-        // D > 1: the rest of the state is gathered by the next k_propagate (or k_unpermute) from res_parent
-    };
-    // hop 1: three independent loads per owned segment, by every thread (the segment windows are allocated in full; `cnt`
-    // masks afterwards).  The pins keep the compiler from sinking loads under the `live` test or fetching a row's halves in
-    // separate hops (it did both to an earlier form of this kernel: five dependent hops instead of two, +3.6 us).
-    int cnt[ITEMS], chunk[ITEMS];
-    u64 lt[ITEMS], spos[ITEMS];
-    uint32_t row0[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        const int cq = (group * 2 + quad) * ITEMS + k;
-        const bool okc = cq < nchunks;
-        chunk[k] = okc ? cq : 0;
-        cnt[k] = okc ? (int)seg_cnt[(u64)bin * nchunks + chunk[k]] : 0;
-        spos[k] = MP_SEG_POS(bin, chunk[k], e0, nchunks);
-        lt[k] = seg_lt[spos[k]];
-        row0[k] = seg_row[spos[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) mp_pin3(cnt[k], lt[k], row0[k]);
-    // hop 2: the start row and its successor, whole 16-byte rows (idle lanes read row 0)
-    mp_u64v2 r0[ITEMS], r1[ITEMS];
-    u64 last0[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        if (!(e0 < cnt[k])) row0[k] = 0u;
-        last0[k] = tile_last(row0[k]);
-        r0[k] = mp_ld_row(cx + row0[k]);
-        r1[k] = mp_ld_row(cx + (u64)row0[k] + ((u64)row0[k] < last0[k] ? 1 : 0));
-    }
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) mp_pin_rows(r0[k], r1[k]);
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k)
-        if (e0 < cnt[k]) finish(lt[k], row0[k], last0[k], spos[k], r0[k], r1[k]);
-    // entries 128.. of a segment (about 5 % of the entries: the upper tail of Binomial(1024, 1/8))
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        for (int e = 128 + e0; e < cnt[k]; e += 128) {
-            const u64 sp = MP_SEG_POS(bin, chunk[k], e, nchunks);
-            const uint32_t row = seg_row[sp];
-            const u64 last = tile_last(row);
-            mp_u64v2 a = mp_ld_row(cx + row);
-            mp_u64v2 bq = mp_ld_row(cx + (u64)row + ((u64)row < last ? 1 : 0));
-            mp_pin_rows(a, bq);
-            finish(seg_lt[sp], row, last, sp, a, bq);
-        }
-    }
-    MP_STAMP(2, 4, 0); MP_STAMP(2, 5, 1);
-}
-
-// parents in slot order from the segment-ordered results of the last binned resample (the states may have moved on)
-__global__ void k_parents_from_segments(u64 n, int nchunks, const unsigned short* __restrict__ perm, const uint32_t* __restrict__ res_parent,
-                                        uint32_t* __restrict__ parent) {
+// The lookups of a resample that only drew (k_draw_slots), for whoever needs slot-order results before — or instead of — the
+// next k_propagate: traces[i] = traces[parents[i]].clone(); log_weights.fill(0.) (particle_filter.rs:109-114).
+// STATES = false: parents only (a step has already consumed the draws and moved the states on).
+template <bool STATES>
+__global__ void k_resolve_slots(u64 n, int D, const u64* __restrict__ dfr_lt, const uint32_t* __restrict__ dfr_row, const mp_cx* __restrict__ cx,
+                                const double* __restrict__ x_old, double* __restrict__ x_new, uint32_t* __restrict__ parent, double* __restrict__ logw) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t pr = perm[i];
-    parent[i] = res_parent[MP_SEG_POS(pr >> 10, i >> 10, pr & 1023u, nchunks)];
-}
-
-// slot order from segment order: traces[i] = traces[parents[i]].clone(); log_weights.fill(0.) (particle_filter.rs:109-114)
-__global__ void k_unpermute(u64 n, int D, int nchunks, const unsigned short* __restrict__ perm, const double* __restrict__ res_x,
-                            const uint32_t* __restrict__ res_parent, const double* __restrict__ x_old, double* __restrict__ x_new,
-                            uint32_t* __restrict__ parent, double* __restrict__ logw) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t pr = perm[i];
-    const u64 pos = MP_SEG_POS(pr >> 10, i >> 10, pr & 1023u, nchunks);
-    const uint32_t p = res_parent[pos];
-    if (D == 1) {
-        x_new[i] = res_x[pos];
-    } else {
-        for (int d = 0; d < D; ++d) x_new[i * D + d] = x_old[(u64)p * D + d];
-    }
+    uint32_t p;
+    double x0;
+    mp_resolve_draw(cx, n, dfr_lt[i], dfr_row[i], &p, &x0);
     parent[i] = p;
-    logw[i] = 0.;
+    if constexpr (STATES) {
+        if (D == 1) {
+            x_new[i] = x0;
+        } else {
+            for (int d = 0; d < D; ++d) x_new[i * D + d] = x_old[(u64)p * D + d];
+        }
+        logw[i] = 0.;
+    }
 }
 
 // `traces[i].retv` for a range of particles at once (particle_filter.rs:13; tests/smc.rs:67 walks every particle): thread =

@@ -144,7 +144,7 @@ def test_error_statuses():
 
 @pytest.mark.parametrize("d", [1, 4])
 def test_parents_survive_a_step_after_a_lazy_resample(d):
-    """particle_filter.rs:73-96 keeps `parents` across `step`; here a binned resample leaves them in segment order and the
+    """particle_filter.rs:73-96 keeps `parents` across `step`; here a resample that only drew leaves them as {target, start row} per slot and the
     next propagate consumes the states from there — the parents must still be the last resample's when asked for later."""
     import modppl_amd
 

@@ -15,9 +15,11 @@ import sys
 
 # one kernel per family: the kernels of the bench's multinomial step (the single-kernel resampler of the supplementary
 # systematic leg is listed on its own)
-FAM = {"k_propagate<mp_lgssm1": "propagate", "k_normalize_tiles": "normalize_scan", "k_bin_draws": "bin_draws",
-       "k_resolve_bins": "resample_gather", "k_resample_gather": "resample_single_kernel"}
-STREAMING = {"propagate", "normalize_scan", "bin_draws"}   # (k_bin_draws reads little: Philox in, segments out)
+FAM = {"k_propagate<mp_lgssm1": "propagate", "k_normalize_tiles": "normalize_scan", "k_draw_slots": "bin_draws",
+       "k_resample_gather": "resample_gather"}
+# (k_draw_slots reads little: Philox in, draws out.  k_propagate streams its own inputs/outputs AND gathers random 16-byte
+# rows for the deferred draws; the x2 correction applied to its whole FETCH_SIZE is therefore an upper bound.)
+STREAMING = {"propagate", "normalize_scan", "bin_draws"}
 
 
 NAMES = {}   # family -> kernel names seen (bench.py checks them against the kernels it times)

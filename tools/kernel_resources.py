@@ -1,5 +1,6 @@
 """VGPR / SGPR / scratch / LDS of every gfx950 kernel in the built library (from the code objects' metadata notes).
-usage: python tools/kernel_resources.py [substring]"""
+usage: python tools/kernel_resources.py [substring]        (MODPPL_HIP_LIB=path: that library instead of the tree's)"""
+import os
 import re
 import subprocess
 import sys
@@ -11,7 +12,7 @@ from modppl_amd import build  # noqa: E402
 
 
 def main():
-    lib = build.lib_path() if hasattr(build, "lib_path") else build.build()
+    lib = os.environ.get("MODPPL_HIP_LIB") or build.build()
     want = sys.argv[1] if len(sys.argv) > 1 else ""
     with tempfile.TemporaryDirectory() as td:
         td = Path(td)

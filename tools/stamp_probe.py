@@ -53,7 +53,7 @@ def main():
     if args.raw:
         np.save(args.raw, buf)
     out = {"particles": n}
-    names = {0: "k_propagate", 1: "k_bin_draws", 2: "k_resolve_bins"}
+    names = {0: "k_propagate", 1: "k_draw_slots"}
     for k, name in names.items():
         b = buf[k]
         live = b[:, 1] != 0

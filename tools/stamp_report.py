@@ -7,7 +7,7 @@ import numpy as np
 b = np.load(sys.argv[1])
 x = b[0]
 x = x[x[:, 1] != 0].astype(np.int64)
-names = [(0, 2, "deviates (load / draw)"), (2, 3, "state fetch + model"), (3, 8, "wave max"), (8, 9, "barrier 1"), (9, 10, "exp + quantise"),
+names = [(0, 2, "deviates (load / draw)"), (2, 3, "parent lookup + model"), (3, 8, "wave max"), (8, 9, "barrier 1"), (9, 10, "exp + quantise"),
          (10, 11, "wave scan"), (11, 12, "LDS atomic + barrier 2"), (12, 7, "cross-wave offsets"), (7, 13, "scalars/ticket + row stores"),
          (13, 14, "guide build"), (14, 15, "barrier 3"), (15, 4, "guide store (+ table)")]
 tot = (x[:, 4] - x[:, 0]).mean()
@@ -15,7 +15,7 @@ print("k_propagate: %d workgroups, wave 0 lifetime %.0f cycles = %.2f us real ti
 for a, c, nm in names:
     d = (x[:, c] - x[:, a])
     print("  %-32s %8.0f cycles  %5.1f %%   (p10 %.0f, p90 %.0f)" % (nm, d.mean(), 100 * d.mean() / tot, np.percentile(d, 10), np.percentile(d, 90)))
-for k, nm in ((1, "k_bin_draws"), (2, "k_resolve_bins")):
+for k, nm in ((1, "k_draw_slots"),):
     y = b[k]
     y = y[y[:, 1] != 0].astype(np.int64)
     if len(y):
