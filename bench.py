@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record hipEvents around each launch in the timed region")
     ap.add_argument("--no-sub-benches", action="store_true", help="skip the c3 / c4 / c5 sub-objects")
+    ap.add_argument("--no-systematic-leg", action="store_true", help="skip the supplementary systematic-resampling leg (profiles: only the headline step's kernels)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -300,7 +301,7 @@ def main():
     lml = pf.log_marginal_likelihood_estimate()
     # ---- supplementary: the same K steps with systematic resampling (named next to multinomial in the north star; not `value`)
     dt_sys = None
-    if world == 1 and not force_sharded:
+    if world == 1 and not force_sharded and not args.no_systematic_leg:
         barrier()
         t0 = time.perf_counter()
         for t in range(1 + W, T):
@@ -402,7 +403,9 @@ def main():
                         traffic_note = f"profiles summary names {meta.get('kernels', {}).get(dom)!r}, the dominant kernel is {KERNEL_OF.get(dom)!r}"
                     else:
                         traffic = tj[dom]["traffic_bytes"]
-                        traffic_note = f"rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, commit {meta.get('commit')}"
+                        traffic_note = f"rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, commit {meta.get('commit')}; fetch correction: {tj[dom].get('fetch_correction')}"
+                        if tj[dom].get("traffic_bytes_lower") is not None:
+                            traffic_note += f"; lower bound {tj[dom]['traffic_bytes_lower']:.0f} B"
                 except Exception as e:   # noqa: BLE001
                     traffic_note = f"unreadable profiles summary: {e}"
             roofline = {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -52,8 +52,12 @@ def main(root):
         f_raw = fetch.get(fam, 0.0) * 1024.0
         w = write.get(fam, 0.0) * 1024.0
         f_corr = f_raw * 2.0 if fam in STREAMING else f_raw
+        note = "x2 (wide coalesced stream)" if fam in STREAMING else "none (random 16-B rows: uncalibrated width; true value in [1x, 2x] of raw)"
+        if fam == "propagate":
+            note = ("x2 on the whole FETCH_SIZE: exact for the kernel's streaming reads, an UPPER bound for the row gathers of the deferred "
+                    "draws it looks up (one 64- or 128-byte fetch per miss: uncalibrated); traffic_bytes_lower takes the counter as it is")
         res[fam] = {"fetch_bytes_raw": f_raw, "fetch_bytes_corrected": f_corr, "write_bytes": w, "traffic_bytes": f_corr + w,
-                    "fetch_correction": "x2 (wide coalesced stream)" if fam in STREAMING else "none (random 16-B rows: uncalibrated width; true value in [1x, 2x] of raw)",
+                    "traffic_bytes_lower": f_raw + w, "fetch_correction": note,
                     "launches_sampled": [nf.get(fam, 0), nw.get(fam, 0)]}
     import os
     import subprocess
