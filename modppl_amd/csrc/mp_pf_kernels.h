@@ -570,12 +570,11 @@ struct mp_k1_tail {
 };
 // The model kernel in Generate mode for ONE particle (slot i): previous state from wherever the last resample left it, the
 // functor with a Generate handler over the deviates zp[0..NS), new state and log-weight out.
-template <class Model, bool LT_EARLY>
+template <class Model>
 __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, long long t,
                                                 const double* __restrict__ x_in, double* __restrict__ x_out, double* logw, const double* obs_v,
                                                 const double* s0_v, int overwrite, bool deferred, const double* __restrict__ inv_rows,
-                                                const mp_cx* __restrict__ cx_old, bool via_inv, const u64* __restrict__ dfr_lt, uint32_t pmv, u64 ltv,
-                                                double x0v, u64 i, const double* zp, double* lw_out, double* x0_out) {
+                                                bool via_inv, uint32_t pmv, const double* x0p, u64 i, const double* zp, double* lw_out, double* x0_out) {
     constexpr int D = Model::DIM_STATE;
     if (i >= n) return;
     double prev[D], next[D];
@@ -588,18 +587,14 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
 #pragma unroll
         for (int d = 0; d < D; ++d) prev[d] = row[d];
     } else if (deferred) {
-        // the last resample only DREW (k_draw_slots): slot i's parent is looked up here, in the row table of the generation
-        // that was resampled (cx_old; this launch writes the new table into the other buffer) — the clone loop of `resample`
-        // (particle_filter.rs:109-114), fused into the step that consumes it
-        // (LT_EARLY: the caller has looked the lane's draws up together — pmv = parent, x0v = its first state component)
-        uint32_t par = pmv;
-        double x0 = x0v;
-        if constexpr (!LT_EARLY) mp_resolve_draw(cx_old, n, dfr_lt[i], pmv, &par, &x0);
+        // the last resample only DREW (k_draw_slots) and the caller has looked this lane's draws up (mp_resolve_draws): pmv = the
+        // parent, *x0p = its first state component — the clone loop of `resample` (particle_filter.rs:109-114), fused into the
+        // step that consumes it
         if constexpr (D == 1) {
-            prev[0] = x0;                      // the row carries the first state component
+            prev[0] = *x0p;                    // the row carries the first state component
         } else {
             // wider states: the parent's (particle-major) row of the pre-resample buffer
-            const double* src = x_in + (u64)par * D;
+            const double* src = x_in + (u64)pmv * D;
 #pragma unroll
             for (int d = 0; d < D; ++d) prev[d] = src[d];
         }
@@ -644,23 +639,32 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
 #pragma unroll
     for (int j = 0; j < LANE_ITEMS; ++j) { lw[j] = MP_NEG_INF; xv[j] = 0.; }
     // the first hop of the state fetch goes out before anything else: its latency runs under phase 1
-    // (a deferred draw = {start row, tile-local target}; the target rides along only where registers are plentiful)
-    constexpr bool LT_EARLY = !QUEUE;
+    // (a deferred draw = {start row, tile-local target}; kernels of wider states have no registers to carry the targets
+    // through the deviates and read them where they look the draw up)
+    constexpr bool LT_LATE = D > 1;
     uint32_t pm[LANE_ITEMS];
-    u64 plt[LT_EARLY ? LANE_ITEMS : 1];
+    u64 plt[LANE_ITEMS];
 #pragma unroll
     for (int p = 0; p < LANE_ITEMS; ++p) {
         pm[p] = base + p < n ? (inv ? inv[base + p] : (dfr_row ? dfr_row[base + p] : 0u)) : 0u;
-        if constexpr (LT_EARLY) plt[p] = (dfr_lt && base + p < n) ? dfr_lt[base + p] : 0ull;
-        else plt[0] = 0ull;
+        if constexpr (!LT_LATE) plt[p] = (dfr_lt && base + p < n) ? dfr_lt[base + p] : 0ull;
     }
     // phase 2 = mp_run_particle (above): the model kernel in Generate mode for one particle
 #define MP_RUN_PARTICLE(P, ZP)                                                                                                             \
-    mp_run_particle<Model, LT_EARLY>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, dfr_row != nullptr, inv_rows, cx_old, \
-                                     inv != nullptr, dfr_lt, pm[P], plt[LT_EARLY ? (P) : 0], px0[LT_EARLY ? (P) : 0], base + (u64)(P), ZP, &lw[P],   \
-                                     &xv[P])
-    double px0[LT_EARLY ? LANE_ITEMS : 1];
-    px0[0] = 0.;
+    mp_run_particle<Model>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, dfr_row != nullptr, inv_rows, inv != nullptr, \
+                           pm[P], &px0[P], base + (u64)(P), ZP, &lw[P], &xv[P])
+    double px0[LANE_ITEMS];   // (written and read only with deferred draws)
+    // Where a lane's deferred draws are looked up (every form gives the same parents; what differs is when a CU's 4096 row
+    // gathers hit its vector-memory path, and bursts are what this kernel pays for):
+    //   two particles per lane, d = 1 (the headline kernel): the first particle's draw BEFORE the deviates, the second's after
+    //     (37.1 us; both after 37.6, both before 39.3, half of the waves before and half after 40.2 .. 40.6)
+    //   many sites per particle (lane-local queue below): each round's particles just before the model runs on them (all of
+    //     a lane's draws in one batch up front: the bearings tracker 314 -> 327 us per step, the banded d = 16 model 440 -> 434 / 442)
+    //   otherwise: after the deviates, one draw at a time (four rows in flight on top of a wider model's registers spill)
+    constexpr bool SPLIT2 = !QUEUE && D == 1 && LANE_ITEMS == 2;
+    if constexpr (SPLIT2) {
+        if (dfr_row) mp_resolve_draw(cx_old, n, plt[0], pm[0], &pm[0], &px0[0]);   // pm[] = the parent from here on
+    }
     // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
     if constexpr (QUEUE) {
         // lane-local queue, rounds of ITEMS particles (ITEMS * NS accepted pairs in registers at a time); the model runs on a
@@ -735,6 +739,12 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 }
 #pragma unroll
                 for (int qq = 0; qq < G; ++qq) zr[gr * G + qq] = mp_std_normal_from_pair(pu[qq], pr[qq]);
+            }
+            if (dfr_row) {
+                u64 ltr[ITEMS];
+#pragma unroll
+                for (int pp = 0; pp < ITEMS; ++pp) ltr[pp] = LT_LATE ? (i0 + pp < n ? dfr_lt[i0 + pp] : 0ull) : plt[rd * ITEMS + pp];
+                mp_resolve_draws<ITEMS>(cx_old, n, ltr, &pm[rd * ITEMS], &pm[rd * ITEMS], &px0[rd * ITEMS]);
             }
 #pragma unroll
             for (int pp = 0; pp < ITEMS; ++pp) MP_RUN_PARTICLE(rd * ITEMS + pp, &zr[pp * NS]);
@@ -811,11 +821,19 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     }
     MP_STAMP(0, 2, 0);
     if constexpr (!QUEUE) {
-        // the lane's deferred draws, looked up together (their {start row, target} were loaded before the deviates: the rows
-        // are one more hop).  Where the row loads are placed — before the deviates, between attempt 0 and the retries, here —
-        // changes nothing measurable (39.9 / 38.6 / 38.3 us): the kernel pays for the lines these gathers pull through
-        // the fabric, not for their latency.
-        if (dfr_row) mp_resolve_draws<LANE_ITEMS>(cx_old, n, plt, pm, pm, px0);   // pm[] = the parents from here on
+        if (dfr_row) {   // pm[] = the parents from here on
+            if constexpr (SPLIT2) {
+                // (an empty statement that makes the target "depend" on the last deviate: the compiler would otherwise run this
+                // lookup ahead of the deviates as well)
+                asm volatile("" : "+v"(plt[1]) : "v"(z[NS + NS - 1]));
+                mp_resolve_draw(cx_old, n, plt[1], pm[1], &pm[1], &px0[1]);
+            } else if constexpr (D == 1) {
+                mp_resolve_draws<LANE_ITEMS>(cx_old, n, plt, pm, pm, px0);
+            } else {
+#pragma unroll
+                for (int p = 0; p < LANE_ITEMS; ++p) mp_resolve_draw(cx_old, n, base + p < n ? dfr_lt[base + p] : 0ull, pm[p], &pm[p], &px0[p]);
+            }
+        }
 #pragma unroll
         for (int p = 0; p < LANE_ITEMS; ++p) MP_RUN_PARTICLE(p, &z[p * NS]);
     }
