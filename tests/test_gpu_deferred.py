@@ -1,0 +1,98 @@
+"""GPU parity of the resample whose row lookups are deferred (k_draw_slots leaves {target, start row} per slot; the next
+k_propagate, or k_resolve_slots when the host asks first, looks the parents up — mp_pf.hip `deferred` / `parents_deferred`).
+Every order in which a caller can interleave resample / step / reads must give the checker's values, bit for bit:
+particle_filter.rs:103-116 (`resample`), :73-96 (`step` keeps `parents`)."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(d, n, seed, T):
+    import modppl_amd
+
+    if d == 1:
+        model, obs, kind, params = modppl_amd.lgssm_model(*O.LGSSM_PARAMS), O.lgssm_observations(T).reshape(T, 1), 1, O.LGSSM_PARAMS
+    else:
+        model, obs = modppl_amd.lgssm_band_model(d), np.random.default_rng(11).normal(0, 1.2, size=(T, d))
+        kind, params = 5, np.array([d, 0.9, 0.05, 1.0, 0.5, 1.0])
+    pf = modppl_amd.ParticleSystem(model, n, seed)
+    ref = O.OraclePF(kind, d, d, params, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    pf.init_step(None, obs[:1])
+    ref.init_step(obs[:1])
+    return pf, ref, obs
+
+
+@pytest.mark.parametrize("d,n", [(1, 6001), (1, 2048), (4, 5000), (16, 3000)])
+def test_two_resamples_in_a_row_then_step(d, n):
+    """resample; resample (the second one needs level 0 of the zero weights: the first one's draws are looked up by
+    k_resolve_slots, not by a propagate); then a step consumes the second one's draws."""
+    pf, ref, obs = _pair(d, n, 21, 4)
+    for t in range(1, 4):
+        pf.resample(sync=False)
+        ref.resample()
+        pf.resample(sync=False)
+        ref.resample()
+        assert np.array_equal(pf.parents, ref.parents())
+        pf.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(pf.states(), ref.state())
+        assert np.array_equal(pf.log_weights, ref.log_weights())
+    assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+
+
+@pytest.mark.parametrize("d", [1, 4])
+def test_schemes_alternate_without_a_read_in_between(d):
+    """multinomial (deferred lookups) and systematic / stratified (single kernel) resamples alternate; nothing is read until the end
+    of each round, so every hand-over between the two forms goes through the library's own bookkeeping."""
+    pf, ref, obs = _pair(d, 7000, 5, 7)
+    schemes = [0, 1, 0, 2, 0, 0]
+    for t, sc in zip(range(1, 7), schemes):
+        pf.resample(scheme=sc, sync=False)
+        ref.resample(sc)
+        pf.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(pf.parents, ref.parents()), f"t={t} scheme={sc}"
+    assert np.array_equal(pf.states(), ref.state())
+    assert np.array_equal(pf.log_weights, ref.log_weights())
+    assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+
+
+@pytest.mark.parametrize("d", [1, 4])
+def test_several_steps_in_one_call_after_a_resample(d):
+    """step(obs of 3 time steps) after a resample: only the first of the three launches looks draws up; the row tables swap once."""
+    pf, ref, obs = _pair(d, 4500, 9, 8)
+    pf.resample(sync=False)
+    ref.resample()
+    pf.step(obs[1:4])
+    ref.step(obs[1:4])
+    want = ref.parents().copy()
+    pf.resample(sync=False)
+    ref.resample()
+    pf.step(obs[4:6])
+    ref.step(obs[4:6])
+    assert np.array_equal(pf.states(), ref.state())
+    assert np.array_equal(pf.log_weights, ref.log_weights())
+    assert np.array_equal(pf.parents, ref.parents())
+    assert not np.array_equal(ref.parents(), want)   # (the second resample's parents, not the first's)
+
+
+def test_reads_between_resample_and_step_do_not_disturb_the_step():
+    """states / log-weights / ESS / log-ML read right after a resample materialise slot order (k_resolve_slots); the step that
+    follows must then run as a plain step on those states."""
+    pf, ref, obs = _pair(1, 9000, 2, 6)
+    for t in range(1, 6):
+        pf.resample(sync=False)
+        ref.resample()
+        if t % 2:
+            assert np.array_equal(pf.states(), ref.state())
+            assert np.all(pf.log_weights == 0.0)
+        else:
+            assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+        pf.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(pf.parents, ref.parents())
+    assert np.array_equal(pf.states(), ref.state())
+    assert np.array_equal(pf.log_weights, ref.log_weights())
