@@ -281,6 +281,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # what a plain device-to-device copy reaches on this box (read + write bytes), for scale next to the 8 TB/s spec peak
+    # (measured first: 2.7 GB of copies also bring the card out of its idle clocks before anything is timed)
+    copy_gbps = None
+    if True:   # (every rank: each card is its own)
+        a_ = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+        b_ = torch.empty_like(a_)
+        b_.copy_(a_)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b_.copy_(a_)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * a_.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a_, b_
     pf.init_step(None, ys[:1])
     pf.resample(sync=False)
     for t in range(1, 1 + W):
@@ -322,21 +338,6 @@ def main():
                "bin_draws": timer.get_timing(capi.MP_K_BIN_DRAWS), "resample_gather": timer.get_timing(capi.MP_K_RESAMPLE_GATHER)}
         timer.set_timing(False)
 
-    # what a plain device-to-device copy reaches on this box (read + write bytes), for scale next to the 8 TB/s spec peak
-    copy_gbps = None
-    if rank == 0:
-        a_ = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
-        b_ = torch.empty_like(a_)
-        b_.copy_(a_)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            b_.copy_(a_)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbps = 2 * a_.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del a_, b_
     # ---- N > 1: the workload that CAN scale (BASELINE.json configs[4]): LGSSM d = 16, 2^21 particles per GPU, same K steps,
     # through the same sharded filter (every rank runs it; rank 0 reports).  Not `value`.
     c5 = None
