@@ -749,7 +749,9 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_draw_slots<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_draw_slots<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_draw_slots<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_draw_slots<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
             HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shard_targets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
         }
@@ -813,7 +815,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     h->sh_parents_lazy = false;
     const int d = h->ops->dim_state;
     bool drawn_only = false;
-    if (scheme == MP_RESAMPLE_MULTINOMIAL && h->use_deferred) {
+    if (h->use_deferred) {
         // draws only (k_draw_slots): the lookups are done by whoever consumes the parents — the next k_propagate, under its
         // arithmetic, or k_resolve_slots when the host asks first
         if (!h->cx_alt) {
@@ -824,23 +826,28 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
         const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (DRAW_THREADS / 64);
         const mp_tab tab = tab_of(h);
-        if (tab.ticket && h->nt <= K1_TABLE_LDS_MAX_TILES) {
-            // the table was built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles): copy to LDS
-            hipLaunchKernelGGL(k_draw_slots<1>, dim3(h->nchunks), dim3(DRAW_THREADS), 24 * (size_t)h->nt + lds_tail, h->stream, h->n, h->n_global,
-                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->tile_m, h->tile_W,
-                               h->tile_W2, h->nt, h->guide, h->dfr_lt, h->dfr_row, h->scal, (const u64*)h->tab_incl,
-                               (const double*)h->tab_ratio, (const mp_tab_head*)h->tab_head);
-        } else if (tab.ticket) {
-            hipLaunchKernelGGL(k_draw_slots<2>, dim3(h->nchunks), dim3(DRAW_THREADS), lds_tail, h->stream, h->n, h->n_global,
-                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->tile_m, h->tile_W,
-                               h->tile_W2, h->nt, h->guide, h->dfr_lt, h->dfr_row, h->scal, (const u64*)h->tab_incl,
-                               (const double*)h->tab_ratio, (const mp_tab_head*)h->tab_head);
-        } else {
-            hipLaunchKernelGGL(k_draw_slots<0>, dim3(h->nchunks), dim3(DRAW_THREADS), 16 * (size_t)h->nt + lds_tail, h->stream, h->n, h->n_global,
-                               h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->tile_m, h->tile_W,
-                               h->tile_W2, h->nt, h->guide, h->dfr_lt, h->dfr_row, h->scal, (const u64*)nullptr,
-                               (const double*)nullptr, (const mp_tab_head*)nullptr);
-        }
+        // tile table: built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles) and copied to LDS (1) or,
+        // beyond K1_TABLE_LDS_MAX_TILES, probed in L2 (2); handles without such a table build it per workgroup (0)
+        const int tabmode = tab.ticket ? (h->nt <= K1_TABLE_LDS_MAX_TILES ? 1 : 2) : 0;
+        const size_t lds = (tabmode == 1 ? 24 * (size_t)h->nt : tabmode == 0 ? 16 * (size_t)h->nt : 0) + lds_tail;
+        const u64* incl = tabmode ? (const u64*)h->tab_incl : nullptr;
+        const double* ratio = tabmode ? (const double*)h->tab_ratio : nullptr;
+        const mp_tab_head* head = tabmode ? (const mp_tab_head*)h->tab_head : nullptr;
+#define MP_LAUNCH_DRAW(TM, SC)                                                                                                              \
+        hipLaunchKernelGGL((k_draw_slots<TM, SC>), dim3(h->nchunks), dim3(DRAW_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,      \
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->tile_m, h->tile_W, h->tile_W2, h->nt,    \
+                           h->guide, h->dfr_lt, h->dfr_row, h->scal, incl, ratio, head)
+#define MP_LAUNCH_DRAW_SCHEME(TM)                                                                                                           \
+        do {                                                                                                                                \
+            if (scheme == MP_RESAMPLE_MULTINOMIAL) MP_LAUNCH_DRAW(TM, 0);                                                                   \
+            else if (scheme == MP_RESAMPLE_SYSTEMATIC) MP_LAUNCH_DRAW(TM, 1);                                                               \
+            else MP_LAUNCH_DRAW(TM, 2);                                                                                                     \
+        } while (0)
+        if (tabmode == 1) MP_LAUNCH_DRAW_SCHEME(1);
+        else if (tabmode == 2) MP_LAUNCH_DRAW_SCHEME(2);
+        else MP_LAUNCH_DRAW_SCHEME(0);
+#undef MP_LAUNCH_DRAW_SCHEME
+#undef MP_LAUNCH_DRAW
         drawn_only = true;
     } else {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);

@@ -1302,7 +1302,9 @@ __global__ __launch_bounds__(KG_THREADS) void k_resample_gather(u64 n, u64 n_out
 // Tile table (TABMODE): 0 = every workgroup builds it in LDS from the tile scalars (handles without a k_propagate-built
 // table); 1 = built once by the last workgroup of the level-0 launch (build_tile_table_global) and copied to LDS here;
 // 2 = the same, probed where it lies in L2 (more tiles than fit LDS).
-template <int TABMODE>
+// SCHEME: 0 multinomial (one Philox block per two adjacent slots), 1 systematic, 2 stratified (mp_target_lattice: the draws
+// are sorted, so the lookups the consumer makes are nearly sequential).
+template <int TABMODE, int SCHEME>
 __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_draw_slots(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int S,
                                                            const double* __restrict__ tile_m, const u64* __restrict__ tile_W,
                                                            const u64* __restrict__ tile_W2, int nt,
@@ -1335,6 +1337,7 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
     // while the table's loads are in flight)
     const u64 i0 = (u64)c * DRAW_CHUNK + 2u * (u64)tid;
     mp_u64x2 blk;
+    blk.a = 0ull; blk.b = 0ull;
     if constexpr (TABMODE == 1) {
         constexpr int TPT = (K1_TABLE_LDS_MAX_TILES + DRAW_THREADS - 1) / DRAW_THREADS;   // table entries per thread
         u64 tI[TPT], tW[TPT];
@@ -1346,14 +1349,14 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
             tW[k] = b < nt ? tile_W[b] : 0ull;
             tR[k] = b < nt ? ratio_pre[b] : 0.;
         }
-        blk = mp_resample_block((slot_offset + i0) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
+        if constexpr (SCHEME == 0) blk = mp_resample_block((slot_offset + i0) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const int b = tid + k * DRAW_THREADS;
             if (b < nt) { s_incl_lds[b] = tI[k]; s_W_lds[b] = tW[k]; s_ratio_lds[b] = tR[k]; }
         }
     } else {
-        blk = mp_resample_block((slot_offset + i0) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
+        if constexpr (SCHEME == 0) blk = mp_resample_block((slot_offset + i0) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
     }
     if constexpr (TABMODE != 0) {
         if (blockIdx.x == 0 && tid == 0) fold_scalars(scal, head->Q, head->Q2, S, head->m, n_global, 0);
@@ -1365,12 +1368,15 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
     u64 lt[2];
     uint32_t gslot[2], tile_of[2], j0[2];
     bool live[2];
+    const uint32_t sys_k32 = SCHEME == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const u64 k52 = mp_u52(q ? blk.b : blk.a);
-        if constexpr (TABMODE == 0) mp_locate(s_incl, s_W, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
-        else mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)nt, mp_target(k52, Q), nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
         live[q] = i0 + q < n;
+        u64 target;
+        if constexpr (SCHEME == 0) target = mp_target(mp_u52(q ? blk.b : blk.a), Q);
+        else target = mp_target_lattice(SCHEME, slot_offset + (live[q] ? i0 + q : 0), sys_k32, rc, k0, k1, Q, n_global);
+        if constexpr (TABMODE == 0) mp_locate(s_incl, s_W, (uint32_t)nt, target, nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
+        else mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)nt, target, nt_over_Q, &tile_of[q], &lt[q], &gslot[q]);
     }
     // the guide lookups (the guide is L2-resident on every XCD)
 #pragma unroll
