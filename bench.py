@@ -387,6 +387,8 @@ def main():
             bytes_k = dict(BYTES_K)
             if not sharded_path and fam["resample_gather"][1] == 0:
                 bytes_k["propagate"] += FUSED_GATHER   # the step's k_propagate also looked up / cloned the parents (no launch of its own did)
+                if fam["bin_draws"][1] == 0:
+                    bytes_k["propagate"] += BYTES_K["bin_draws"]   # ... and made the draws: the whole step is that one launch
             achieved = bytes_k[dom] * n / (avg_us[dom] * 1e-6) / 1e9
             # HBM-side bytes per launch of that kernel: PMC passes cannot run inside this process, so this is the committed
             # summary of the same single-GPU command — accepted only if it names this kernel AND was measured with this build

@@ -103,6 +103,9 @@ struct PropagateArgs {
     u64* tile_W;
     u64* tile_W2;
     const uint32_t* inv;
+    const mp_k1_draw* drw;    // non-null: this launch also MAKES the previous resample's draws (resample counter rc), into dfr_row / dfr_lt
+    uint32_t rc;
+    size_t dyn_lds;           // LDS for that phase's copy of the tile table
     const mp_k1_tail* tail;   // device copy of {cx, guide, tile_*, tab} (k_propagate reads them there)
     mp_k1_aux aux;
 };
@@ -110,6 +113,7 @@ struct ModelOps {
     int dim_state = 0, dim_obs = 0;
     void* owned_device_mem = nullptr;   // model constants that do not fit kernel arguments (freed with the model)
     int max_normals = 0;
+    bool can_draw = false;   // its k_propagate can make the previous resample's draws itself (lanes of two adjacent slots, d = 1)
     virtual ~ModelOps() { if (owned_device_mem) (void)hipFree(owned_device_mem); }
     virtual void propagate(const PropagateArgs& a) const = 0;
     virtual int n_normals(long long t) const = 0;
@@ -122,6 +126,9 @@ struct ModelOpsT : ModelOps {
         dim_state = Model::DIM_STATE;
         dim_obs = Model::DIM_OBS;
         max_normals = Model::MAX_NORMALS;
+        // (the conditions of CAN_DRAW in k_propagate, for the launch configuration `propagate` below picks)
+        can_draw = Model::MAX_NORMALS <= 4 && Model::DIM_STATE == 1 && mp_coop_model<Model>() && 2 * Model::MAX_NORMALS <= 4 &&
+                   !std::is_same<Model, mp_lgssm_dense<16>>::value;
         static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
         static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
     }
@@ -134,15 +141,15 @@ struct ModelOpsT : ModelOps {
         static const int k1t = [] { const char* e = getenv("MP_K1_THREADS"); return e ? atoi(e) : 0; }();   // A/B measurements
         if constexpr (std::is_same<Model, mp_lgssm1>::value) {
             if (k1t == 256) {
-                hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux);
+                                   a.inv, a.dfr_lt, a.aux, a.drw, a.rc);
                 return;
             }
             if (k1t == 512) {
-                hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux);
+                                   a.inv, a.dfr_lt, a.aux, a.drw, a.rc);
                 return;
             }
         }
@@ -157,9 +164,9 @@ struct ModelOpsT : ModelOps {
                 return;
             }
         }
-        hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+        hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                           a.inv, a.dfr_lt, a.aux);
+                           a.inv, a.dfr_lt, a.aux, a.drw, a.rc);
     }
     int n_normals(long long t) const override { return model.n_normals(t); }
 };
@@ -367,7 +374,14 @@ struct mp_pf {
     bool sh_parents_lazy = false;       // ... or in column D of the exchange rows sh_rows / sh_req_slot
     // level-1 table built by the last workgroup of the level-0 launch (mp_tab)
     mp_k1_tail* k1_tail = nullptr;      // device copy of what k_propagate's last phase needs (update_k1_tail)
-    mp_k1_tail* k1_tail_alt = nullptr;  // the same with cx_alt for cx
+    mp_k1_tail* k1_tail_alt = nullptr;  // the same with cx_alt / guide_alt for cx / guide
+    unsigned short* guide_alt = nullptr; // second guide buffer (swaps with guide together with the row tables)
+    u64* tab_W = nullptr;               // the tile table's copy of tile_W (mp_tab::W)
+    mp_k1_draw* k1_draw = nullptr;      // device copies of what a drawing k_propagate reads: guide_old = guide ...
+    mp_k1_draw* k1_draw_alt = nullptr;  // ... / guide_alt
+    bool draw_pending = false;          // with `deferred`: not even the draws of the last resample have been made (counter pending_rc);
+    uint32_t pending_rc = 0;            // the next k_propagate makes them, or flush_draws() when anything else needs them first
+    int use_fused_draws = 1;            // MP_FUSED_DRAWS=0: a resample always launches k_draw_slots (A/B measurements)
     mp_cx* cx_alt = nullptr;            // second row-table buffer: a k_propagate that looks up deferred draws in cx writes the new table here
     bool deferred = false;              // the last resample only drew: {dfr_lt, dfr_row}[slot] against the table in cx; x[cur] is the pre-resample state
     bool parents_deferred = false;      // ... and a step has consumed the draws since: its parents are still {dfr_lt, dfr_row} against cx_alt
@@ -453,6 +467,7 @@ static mp_tab tab_of(const mp_pf* h) {
     t.ratio = h->tab_ratio;
     t.head = h->tab_head;
     t.S = h->S;
+    t.W = h->tab_W;
     return t;
 }
 
@@ -464,8 +479,20 @@ static int32_t update_k1_tail(mp_pf* h) {   // after anything that changes one o
     HIPCK(hipStreamSynchronize(h->stream));   // `t` is a stack object
     if (h->cx_alt) {
         t.cx = h->cx_alt;
+        t.guide = h->guide_alt;
         if (!h->k1_tail_alt) HIPCK(hipMalloc(&h->k1_tail_alt, sizeof(mp_k1_tail)));
         HIPCK(hipMemcpyAsync(h->k1_tail_alt, &t, sizeof(t), hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+        mp_k1_draw d;
+        d.tab_incl = h->tab_incl; d.tab_ratio = h->tab_ratio; d.tab_W = h->tab_W; d.head = h->tab_head; d.scal = h->scal;
+        d.n_global = h->n_global; d.nt = h->nt; d.S = h->S; d.dfr_lt = h->dfr_lt; d.dfr_row = h->dfr_row;
+        d.guide_old = h->guide;
+        if (!h->k1_draw) HIPCK(hipMalloc(&h->k1_draw, sizeof(mp_k1_draw)));
+        HIPCK(hipMemcpyAsync(h->k1_draw, &d, sizeof(d), hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+        d.guide_old = h->guide_alt;
+        if (!h->k1_draw_alt) HIPCK(hipMalloc(&h->k1_draw_alt, sizeof(mp_k1_draw)));
+        HIPCK(hipMemcpyAsync(h->k1_draw_alt, &d, sizeof(d), hipMemcpyHostToDevice, h->stream));
         HIPCK(hipStreamSynchronize(h->stream));
     }
     return MP_OK;
@@ -530,7 +557,12 @@ static hipError_t stream_wait(hipStream_t s) {
         if (e != hipErrorNotReady) return e;
     }
 }
+static int32_t flush_draws(mp_pf* h);
 static int32_t fetch_scalars(mp_pf* h) {
+    {   // (the scalars of a resample are folded by whoever makes its draws)
+        int32_t rcf = flush_draws(h);
+        if (rcf != MP_OK) return rcf;
+    }
     HIPCK(hipMemcpyAsync(h->h_scal, h->scal, sizeof(mp_dev_scalars), hipMemcpyDeviceToHost, h->stream));
     HIPCK(stream_wait(h->stream));
     if (h->h_scal->degenerate)
@@ -553,6 +585,10 @@ static int32_t materialize(mp_pf* h) {
         h->logw_zero = false;
     }
     if (h->deferred) {
+        {
+            int32_t rcf = flush_draws(h);
+            if (rcf != MP_OK) return rcf;
+        }
         const int d = h->ops->dim_state;
         hipLaunchKernelGGL(k_resolve_slots<true>, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, d, (const u64*)h->dfr_lt,
                            (const uint32_t*)h->dfr_row, (const mp_cx*)h->cx, (const double*)h->x[h->cur], d == 1 ? h->x[h->cur] : h->x[h->cur ^ 1],
@@ -606,7 +642,13 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.cx_old = h->deferred ? h->cx : nullptr;
     a.inv_rows = h->sh_lazy ? h->sh_rows : nullptr;
     a.inv = h->sh_lazy ? h->sh_req_slot : nullptr;
-    a.cx = h->deferred ? h->cx_alt : h->cx; a.guide = h->guide; a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
+    a.cx = h->deferred ? h->cx_alt : h->cx; a.guide = h->deferred ? h->guide_alt : h->guide;
+    a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
+    // ... and made by it too, when the resample left them pending (kernels of two-slot lanes)
+    a.drw = (h->deferred && h->draw_pending) ? h->k1_draw : nullptr;
+    if (a.drw) { a.dfr_row = nullptr; a.dfr_lt = nullptr; }   // (not read: the kernel writes them through the struct's pointers)
+    a.rc = h->pending_rc;
+    a.dyn_lds = a.drw ? 24 * (size_t)h->nt : 0;
     a.grid = h->nt;
     a.stream = h->stream;
     a.aux.tab = tab_of(h);
@@ -617,7 +659,10 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     }
     if (h->deferred) {   // the fresh table is the current one from here on; the old one stays intact for mp_pf_read_parents
         std::swap(h->cx, h->cx_alt);
+        std::swap(h->guide, h->guide_alt);
         std::swap(h->k1_tail, h->k1_tail_alt);
+        std::swap(h->k1_draw, h->k1_draw_alt);
+        h->draw_pending = false;
         h->parents_deferred = true;
         h->deferred = false;
     }
@@ -716,6 +761,8 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (env && env[0] == '0') h->use_deferred = 0;
         env = getenv("MP_K1_TABLE");
         if (env && env[0] == '0') h->use_k1_table = 0;
+        env = getenv("MP_FUSED_DRAWS");
+        if (env && env[0] == '0') h->use_fused_draws = 0;
     }
     HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
     HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
@@ -734,6 +781,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         HIPCK(hipMalloc(&h->tab_incl, sizeof(u64) * h->nt));
         HIPCK(hipMalloc(&h->tab_ratio, sizeof(double) * h->nt));
         HIPCK(hipMalloc(&h->tab_head, sizeof(mp_tab_head)));
+        HIPCK(hipMalloc(&h->tab_W, sizeof(u64) * h->nt));
     }
     HIPCK(hipMalloc(&h->aos, sizeof(double) * n));   // scratch for importance sampling's normalised log-weights
     HIPCK(hipHostMalloc(&h->h_scal, sizeof(mp_dev_scalars)));
@@ -802,6 +850,45 @@ int32_t mp_pf_step(mp_pf* h, const double* obs, int32_t n_steps) {
     return MP_OK;
 }
 
+// k_draw_slots for resample number `rc` of scheme `scheme`: {target, start row} per output slot
+static int32_t launch_draws(mp_pf* h, int32_t scheme, uint32_t rc) {
+    {
+        LaunchTimer lt(h, MP_K_BIN_DRAWS);
+        const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (DRAW_THREADS / 64);
+        const mp_tab tab = tab_of(h);
+        // tile table: built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles) and copied to LDS (1) or,
+        // beyond K1_TABLE_LDS_MAX_TILES, probed in L2 (2); handles without such a table build it per workgroup (0)
+        const int tabmode = tab.ticket ? (h->nt <= K1_TABLE_LDS_MAX_TILES ? 1 : 2) : 0;
+        const size_t lds = (tabmode == 1 ? 24 * (size_t)h->nt : tabmode == 0 ? 16 * (size_t)h->nt : 0) + lds_tail;
+        const u64* incl = tabmode ? (const u64*)h->tab_incl : nullptr;
+        const double* ratio = tabmode ? (const double*)h->tab_ratio : nullptr;
+        const mp_tab_head* head = tabmode ? (const mp_tab_head*)h->tab_head : nullptr;
+#define MP_LAUNCH_DRAW(TM, SC)                                                                                                              \
+        hipLaunchKernelGGL((k_draw_slots<TM, SC>), dim3(h->nchunks), dim3(DRAW_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,      \
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), rc, h->S, h->tile_m, h->tile_W, h->tile_W2, h->nt,    \
+                           h->guide, h->dfr_lt, h->dfr_row, h->scal, incl, ratio, head)
+#define MP_LAUNCH_DRAW_SCHEME(TM)                                                                                                           \
+        do {                                                                                                                                \
+            if (scheme == MP_RESAMPLE_MULTINOMIAL) MP_LAUNCH_DRAW(TM, 0);                                                                   \
+            else if (scheme == MP_RESAMPLE_SYSTEMATIC) MP_LAUNCH_DRAW(TM, 1);                                                               \
+            else MP_LAUNCH_DRAW(TM, 2);                                                                                                     \
+        } while (0)
+        if (tabmode == 1) MP_LAUNCH_DRAW_SCHEME(1);
+        else if (tabmode == 2) MP_LAUNCH_DRAW_SCHEME(2);
+        else MP_LAUNCH_DRAW_SCHEME(0);
+#undef MP_LAUNCH_DRAW_SCHEME
+#undef MP_LAUNCH_DRAW
+    }
+    return check_launch("k_draw_slots");
+}
+
+// the draws a resample left to the next k_propagate, made now because something else needs them first
+static int32_t flush_draws(mp_pf* h) {
+    if (!h->draw_pending) return MP_OK;
+    h->draw_pending = false;
+    return launch_draws(h, MP_RESAMPLE_MULTINOMIAL, h->pending_rc);
+}
+
 int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
@@ -816,38 +903,25 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     const int d = h->ops->dim_state;
     bool drawn_only = false;
     if (h->use_deferred) {
-        // draws only (k_draw_slots): the lookups are done by whoever consumes the parents — the next k_propagate, under its
-        // arithmetic, or k_resolve_slots when the host asks first
+        // draws only: the lookups are done by whoever consumes the parents — the next k_propagate, under its arithmetic, or
+        // k_resolve_slots when the host asks first
         if (!h->cx_alt) {
             HIPCK(hipMalloc(&h->cx_alt, sizeof(mp_cx) * (size_t)h->nt * TILE));
+            HIPCK(hipMalloc(&h->guide_alt, sizeof(unsigned short) * (size_t)h->nt * GUIDE_N));
             int32_t rct = update_k1_tail(h);
             if (rct != MP_OK) return rct;
         }
-        LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (DRAW_THREADS / 64);
         const mp_tab tab = tab_of(h);
-        // tile table: built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles) and copied to LDS (1) or,
-        // beyond K1_TABLE_LDS_MAX_TILES, probed in L2 (2); handles without such a table build it per workgroup (0)
-        const int tabmode = tab.ticket ? (h->nt <= K1_TABLE_LDS_MAX_TILES ? 1 : 2) : 0;
-        const size_t lds = (tabmode == 1 ? 24 * (size_t)h->nt : tabmode == 0 ? 16 * (size_t)h->nt : 0) + lds_tail;
-        const u64* incl = tabmode ? (const u64*)h->tab_incl : nullptr;
-        const double* ratio = tabmode ? (const double*)h->tab_ratio : nullptr;
-        const mp_tab_head* head = tabmode ? (const mp_tab_head*)h->tab_head : nullptr;
-#define MP_LAUNCH_DRAW(TM, SC)                                                                                                              \
-        hipLaunchKernelGGL((k_draw_slots<TM, SC>), dim3(h->nchunks), dim3(DRAW_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,      \
-                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->S, h->tile_m, h->tile_W, h->tile_W2, h->nt,    \
-                           h->guide, h->dfr_lt, h->dfr_row, h->scal, incl, ratio, head)
-#define MP_LAUNCH_DRAW_SCHEME(TM)                                                                                                           \
-        do {                                                                                                                                \
-            if (scheme == MP_RESAMPLE_MULTINOMIAL) MP_LAUNCH_DRAW(TM, 0);                                                                   \
-            else if (scheme == MP_RESAMPLE_SYSTEMATIC) MP_LAUNCH_DRAW(TM, 1);                                                               \
-            else MP_LAUNCH_DRAW(TM, 2);                                                                                                     \
-        } while (0)
-        if (tabmode == 1) MP_LAUNCH_DRAW_SCHEME(1);
-        else if (tabmode == 2) MP_LAUNCH_DRAW_SCHEME(2);
-        else MP_LAUNCH_DRAW_SCHEME(0);
-#undef MP_LAUNCH_DRAW_SCHEME
-#undef MP_LAUNCH_DRAW
+        // ... and for kernels whose lanes own one Philox block's two slots, not even the draws are made here: an asynchronous
+        // multinomial resample enqueues NOTHING, the next k_propagate draws for its own slots (flush_draws() otherwise)
+        if (scheme == MP_RESAMPLE_MULTINOMIAL && !log_total_weight && h->use_fused_draws && h->ops->can_draw && tab.ticket &&
+            h->nt <= K1_TABLE_LDS_MAX_TILES && !(h->flags & MP_PF_RECORD_HISTORY)) {
+            h->draw_pending = true;
+            h->pending_rc = h->resample_count;
+        } else {
+            rc = launch_draws(h, scheme, h->resample_count);
+            if (rc != MP_OK) return rc;
+        }
         drawn_only = true;
     } else {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
@@ -1577,6 +1651,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     for (void* slab : h->hist_slabs) (void)hipFree(slab);
     (void)hipFree(h->d_hist_events);
     (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->cx_alt); (void)hipFree(h->k1_tail_alt); (void)hipFree(h->guide);
+    (void)hipFree(h->guide_alt); (void)hipFree(h->tab_W); (void)hipFree(h->k1_draw); (void)hipFree(h->k1_draw_alt);
     (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->scal);
     (void)hipFree(h->aos);
     (void)hipFree(h->k1_tail);

@@ -154,6 +154,7 @@ struct mp_tab {               // null ticket = no table is built (sharded handle
     double* ratio;
     mp_tab_head* head;
     int S;
+    u64* W;                   // copy of tile_W as of the build (a k_propagate that DRAWS reads the table while the next generation's tile_W is being written)
 };
 __device__ __forceinline__ double mp_ld_agent(const double* p) {
     return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -217,6 +218,7 @@ __device__ __forceinline__ void build_tile_table_global(const double* tile_m, co
         if (have) {
             tab.incl[tid] = woff + incl;
             tab.ratio[tid] = (double)Wb / (double)T;
+            tab.W[tid] = Wb;
         }
         if (tid == 0) {
             mp_tab_head h;
@@ -273,7 +275,9 @@ __device__ __forceinline__ void build_tile_table_global(const double* tile_m, co
             const u64 T = tab.incl[b0 + j];
             cum += T;
             tab.incl[b0 + j] = cum;
-            tab.ratio[b0 + j] = (double)mp_ld_agent(tile_W + b0 + j) / (double)T;
+            const u64 Wb = mp_ld_agent(tile_W + b0 + j);
+            tab.ratio[b0 + j] = (double)Wb / (double)T;
+            tab.W[b0 + j] = Wb;
         }
     }
     if (tid == 0) {
@@ -568,6 +572,27 @@ struct mp_k1_tail {
     u64* tile_W2;
     mp_tab tab;
 };
+// What a k_propagate that makes the previous resample's DRAWS itself reads (kernels whose lanes own two adjacent slots = one
+// Philox block: k_draw_slots' work, without its launch, its lockstep round and the round trip of its output through memory).
+// Everything here belongs to the generation that was resampled and is not written by this launch before its last workgroup
+// runs (the table, tab.W) or at all (guide_old: the launch writes the other guide buffer).
+struct mp_k1_draw {
+    const u64* tab_incl;
+    const double* tab_ratio;
+    const u64* tab_W;
+    const mp_tab_head* head;
+    const unsigned short* guide_old;
+    mp_dev_scalars* scal;
+    u64* dfr_lt;              // the draws are also written out: mp_pf_read_parents after the step recomputes the parents from them
+    uint32_t* dfr_row;
+    u64 n_global;
+    int nt, S;
+};
+__device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2, int S, double m, u64 n_global, int mode);
+__device__ __forceinline__ u64 mp_target(u64 k52, u64 Q);
+__device__ __forceinline__ mp_u64x2 mp_resample_block(u64 g_pair, uint32_t rc, uint32_t domain, uint32_t k0, uint32_t k1);
+__device__ __forceinline__ void mp_locate_r(const u64* s_incl, const u64* s_W, const double* s_ratio, uint32_t nt, u64 target, double nt_over_Q,
+                                            uint32_t* tile, u64* lt, uint32_t* gslot);
 // The model kernel in Generate mode for ONE particle (slot i): previous state from wherever the last resample left it, the
 // functor with a Generate handler over the deviates zp[0..NS), new state and log-weight out.
 template <class Model>
@@ -624,7 +649,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                                                             mp_obs obs, mp_state0 s0, int overwrite,
                                                             const uint32_t* __restrict__ dfr_row, const double* __restrict__ inv_rows,
                                                             const mp_cx* __restrict__ cx_old, const mp_k1_tail* tail,
-                                                            const uint32_t* __restrict__ inv, const u64* __restrict__ dfr_lt, mp_k1_aux aux) {
+                                                            const uint32_t* __restrict__ inv, const u64* __restrict__ dfr_lt, mp_k1_aux aux,
+                                                            const mp_k1_draw* drw, uint32_t rc) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int LANE_ITEMS = TILE / THREADS;
@@ -642,16 +668,68 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     // (a deferred draw = {start row, tile-local target}; kernels of wider states have no registers to carry the targets
     // through the deviates and read them where they look the draw up)
     constexpr bool LT_LATE = D > 1;
+    constexpr bool CAN_DRAW = !QUEUE && D == 1 && LANE_ITEMS == 2;   // (the host passes `drw` to these kernels only)
     uint32_t pm[LANE_ITEMS];
     u64 plt[LANE_ITEMS];
+    bool drew = false;
+    if constexpr (CAN_DRAW) {
+        if (drw) {
+            // ---- phase 0: the draws of the previous resample for this lane's two adjacent slots (k_draw_slots<1, 0>'s body:
+            // same Philox block, same target, same tile walk, same guide cell -> bit-identical {target, start row}) ----
+            drew = true;
+            const mp_k1_draw* dp = drw;
+            asm volatile("" : "+s"(dp)::"memory");
+            const mp_k1_draw dw = *dp;
+            extern __shared__ __attribute__((aligned(16))) unsigned char k1_dyn[];
+            u64* s_incl = reinterpret_cast<u64*>(k1_dyn);              // [nt]
+            u64* s_W = s_incl + dw.nt;                                  // [nt]
+            double* s_ratio = reinterpret_cast<double*>(s_W + dw.nt);  // [nt]
+            for (int b = (int)threadIdx.x; b < dw.nt; b += THREADS) {
+                s_incl[b] = dw.tab_incl[b];
+                s_W[b] = dw.tab_W[b];
+                s_ratio[b] = dw.tab_ratio[b];
+            }
+            const mp_u64x2 blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
+            if (blockIdx.x == 0 && threadIdx.x == 0) fold_scalars(dw.scal, dw.head->Q, dw.head->Q2, dw.S, dw.head->m, dw.n_global, 0);
+            __syncthreads();
+            const u64 Q = s_incl[dw.nt - 1];
+            const double nt_over_Q = (double)dw.nt / (double)Q;   // only a starting guess for the tile walk: no effect on results
+            uint32_t gslot[2], tile_of[2];
 #pragma unroll
-    for (int p = 0; p < LANE_ITEMS; ++p) {
-        pm[p] = base + p < n ? (inv ? inv[base + p] : (dfr_row ? dfr_row[base + p] : 0u)) : 0u;
-        if constexpr (!LT_LATE) plt[p] = (dfr_lt && base + p < n) ? dfr_lt[base + p] : 0ull;
+            for (int q = 0; q < 2; ++q)
+                mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)dw.nt, mp_target(mp_u52(q ? blk.b : blk.a), Q), nt_over_Q, &tile_of[q], &plt[q], &gslot[q]);
+            uint32_t j0[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) j0[q] = dw.guide_old[gslot[q]];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u64 tbase = (u64)tile_of[q] * TILE;
+                const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+                pm[q] = (uint32_t)tbase + (j0[q] > tlen - 1 ? tlen - 1 : j0[q]);   // row where the forward scan starts
+            }
+            // kept for mp_pf_read_parents after this step (the draws + the old table are what the parents are recomputed from)
+            u64* wl = dw.dfr_lt;
+            uint32_t* wr = dw.dfr_row;
+            if (base + 1 < n) {
+                mp_u64v2 v2; v2.x = plt[0]; v2.y = plt[1];
+                *reinterpret_cast<mp_u64v2*>(wl + base) = v2;
+                *reinterpret_cast<uint2*>(wr + base) = make_uint2(pm[0], pm[1]);
+            } else if (base < n) {
+                wl[base] = plt[0];
+                wr[base] = pm[0];
+            }
+        }
+    }
+    if (!drew) {
+#pragma unroll
+        for (int p = 0; p < LANE_ITEMS; ++p) {
+            pm[p] = base + p < n ? (inv ? inv[base + p] : (dfr_row ? dfr_row[base + p] : 0u)) : 0u;
+            if constexpr (!LT_LATE) plt[p] = (dfr_lt && base + p < n) ? dfr_lt[base + p] : 0ull;
+        }
     }
     // phase 2 = mp_run_particle (above): the model kernel in Generate mode for one particle
 #define MP_RUN_PARTICLE(P, ZP)                                                                                                             \
-    mp_run_particle<Model>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, dfr_row != nullptr, inv_rows, inv != nullptr, \
+    mp_run_particle<Model>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, cx_old != nullptr, inv_rows, inv != nullptr, \
                            pm[P], &px0[P], base + (u64)(P), ZP, &lw[P], &xv[P])
     double px0[LANE_ITEMS];   // (written and read only with deferred draws)
     // Where a lane's deferred draws are looked up (every form gives the same parents; what differs is when a CU's 4096 row
@@ -663,7 +741,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     //   otherwise: after the deviates, one draw at a time (four rows in flight on top of a wider model's registers spill)
     constexpr bool SPLIT2 = !QUEUE && D == 1 && LANE_ITEMS == 2;
     if constexpr (SPLIT2) {
-        if (dfr_row) mp_resolve_draw(cx_old, n, plt[0], pm[0], &pm[0], &px0[0]);   // pm[] = the parent from here on
+        if (cx_old) mp_resolve_draw(cx_old, n, plt[0], pm[0], &pm[0], &px0[0]);   // pm[] = the parent from here on
     }
     // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
     if constexpr (QUEUE) {
@@ -740,7 +818,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
 #pragma unroll
                 for (int qq = 0; qq < G; ++qq) zr[gr * G + qq] = mp_std_normal_from_pair(pu[qq], pr[qq]);
             }
-            if (dfr_row) {
+            if (cx_old) {
                 u64 ltr[ITEMS];
 #pragma unroll
                 for (int pp = 0; pp < ITEMS; ++pp) ltr[pp] = LT_LATE ? (i0 + pp < n ? dfr_lt[i0 + pp] : 0ull) : plt[rd * ITEMS + pp];
@@ -821,7 +899,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     }
     MP_STAMP(0, 2, 0);
     if constexpr (!QUEUE) {
-        if (dfr_row) {   // pm[] = the parents from here on
+        if (cx_old) {   // pm[] = the parents from here on
             if constexpr (SPLIT2) {
                 // (an empty statement that makes the target "depend" on the last deviate: the compiler would otherwise run this
                 // lookup ahead of the deviates as well)

@@ -96,3 +96,33 @@ def test_reads_between_resample_and_step_do_not_disturb_the_step():
         assert np.array_equal(pf.parents, ref.parents())
     assert np.array_equal(pf.states(), ref.state())
     assert np.array_equal(pf.log_weights, ref.log_weights())
+
+
+def test_draws_made_by_the_step_equal_draws_made_by_the_resample(monkeypatch):
+    """An asynchronous multinomial resample of a filter whose k_propagate can draw (two adjacent slots per lane, d = 1) enqueues
+    nothing: the next step makes the draws for its own slots.  MP_FUSED_DRAWS=0 (read at creation) keeps the k_draw_slots
+    launch.  Same Philox blocks, same targets, same walk: every value must agree, bit for bit, and with the checker."""
+    import modppl_amd
+
+    n, seed, T = 70001, 31, 6
+    obs = O.lgssm_observations(T).reshape(T, 1)
+    fused = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    monkeypatch.setenv("MP_FUSED_DRAWS", "0")
+    plain = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    monkeypatch.delenv("MP_FUSED_DRAWS")
+    ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    for pf in (fused, plain):
+        pf.init_step(None, obs[:1])
+    ref.init_step(obs[:1])
+    for t in range(1, T):
+        for pf in (fused, plain):
+            pf.resample(sync=False)
+            pf.step(obs[t:t + 1])
+        ref.resample()
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(fused.parents, plain.parents)
+        assert np.array_equal(fused.parents, ref.parents())
+    assert np.array_equal(fused.states(), plain.states())
+    assert np.array_equal(fused.log_weights, ref.log_weights())
+    assert fused.effective_sample_size() == plain.effective_sample_size() == ref.effective_sample_size(0)
+    assert fused.log_marginal_likelihood_estimate() == plain.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
