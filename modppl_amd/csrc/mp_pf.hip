@@ -128,7 +128,7 @@ struct ModelOpsT : ModelOps {
         max_normals = Model::MAX_NORMALS;
         // (the conditions of CAN_DRAW in k_propagate, for the launch configuration `propagate` below picks)
         can_draw = Model::MAX_NORMALS <= 4 && Model::DIM_STATE == 1 && mp_coop_model<Model>() && 2 * Model::MAX_NORMALS <= 4 &&
-                   !std::is_same<Model, mp_lgssm_dense<16>>::value;
+                   !std::is_same<Model, mp_lgssm_dense<16>>::value && !getenv("MP_K1_THREADS");   // (that override launches other lane shapes)
         static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
         static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
     }
@@ -914,8 +914,9 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         const mp_tab tab = tab_of(h);
         // ... and for kernels whose lanes own one Philox block's two slots, not even the draws are made here: an asynchronous
         // multinomial resample enqueues NOTHING, the next k_propagate draws for its own slots (flush_draws() otherwise)
+        // (up to 1024 tiles: the kernel's copy of the tile table, 24 B per tile, stays within the default dynamic-LDS limit)
         if (scheme == MP_RESAMPLE_MULTINOMIAL && !log_total_weight && h->use_fused_draws && h->ops->can_draw && tab.ticket &&
-            h->nt <= K1_TABLE_LDS_MAX_TILES && !(h->flags & MP_PF_RECORD_HISTORY)) {
+            h->nt <= 1024 && !(h->flags & MP_PF_RECORD_HISTORY)) {
             h->draw_pending = true;
             h->pending_rc = h->resample_count;
         } else {
