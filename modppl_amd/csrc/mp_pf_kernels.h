@@ -7,7 +7,7 @@
 // product library): wave 0 of every workgroup records shader-clock / 100 MHz real-time stamps into a buffer of its own.
 // ---------------------------------------------------------------------------------------------
 #ifdef MP_STAMPS
-constexpr int MP_STAMP_MAX_WG = 16384, MP_STAMP_SLOTS = 16, MP_STAMP_KERNELS = 4;
+constexpr int MP_STAMP_MAX_WG = 16384, MP_STAMP_SLOTS = 32, MP_STAMP_KERNELS = 4;
 __device__ unsigned long long* g_mp_stamp_buf = nullptr;
 __device__ __forceinline__ void mp_stamp(int kernel, int slot, int what /*0 shader clock, 1 real time, 2 hw id*/) {
     if (threadIdx.x == 0 && g_mp_stamp_buf && blockIdx.x < MP_STAMP_MAX_WG) {
@@ -47,6 +47,24 @@ struct mp_dev_scalars {
 __device__ __forceinline__ void mp_flag_degenerate(mp_dev_scalars* scal) {
     scal->degenerate = 1;
     if (scal->host_flag) __hip_atomic_store(scal->host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Address spaces.  A pointer that the kernel READS FROM MEMORY (a field of mp_k1_tail / mp_k1_draw) is a generic pointer to
+// the compiler: every access through it becomes a flat_* instruction, which ticks BOTH vmcnt and lgkmcnt, completes out of
+// order and must be waited for with vmcnt(0) lgkmcnt(0) before the next LDS operation — the table copy of a drawing
+// k_propagate was four serialised round trips that way.  mp_as_global says what is true anyway (these are hipMalloc'ed
+// buffers): the round trip through address space 1 lets the address-space inference turn the accesses into global_* (vmcnt
+// only, in order).  mp_ld_const reads a launch-constant struct at a wave-uniform address through the scalar cache (s_load)
+// instead of one vector load per lane.
+template <class T>
+__device__ __forceinline__ T* mp_as_global(T* p) {
+    return (T*)(__attribute__((address_space(1))) T*)p;
+}
+template <class T>
+__device__ __forceinline__ T mp_ld_const(const T* p) {
+    T v;
+    __builtin_memcpy(&v, (const __attribute__((address_space(4))) T*)p, sizeof(T));
+    return v;
 }
 
 constexpr int TILE_THREADS = 512;
@@ -679,19 +697,32 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             drew = true;
             const mp_k1_draw* dp = drw;
             asm volatile("" : "+s"(dp)::"memory");
-            const mp_k1_draw dw = *dp;
+            mp_k1_draw dw = mp_ld_const(dp);
+            dw.tab_incl = mp_as_global(dw.tab_incl); dw.tab_ratio = mp_as_global(dw.tab_ratio); dw.tab_W = mp_as_global(dw.tab_W);
+            dw.head = mp_as_global(dw.head); dw.guide_old = mp_as_global(dw.guide_old); dw.scal = mp_as_global(dw.scal);
+            dw.dfr_lt = mp_as_global(dw.dfr_lt); dw.dfr_row = mp_as_global(dw.dfr_row);
             extern __shared__ __attribute__((aligned(16))) unsigned char k1_dyn[];
             u64* s_incl = reinterpret_cast<u64*>(k1_dyn);              // [nt]
             u64* s_W = s_incl + dw.nt;                                  // [nt]
             double* s_ratio = reinterpret_cast<double*>(s_W + dw.nt);  // [nt]
-            for (int b = (int)threadIdx.x; b < dw.nt; b += THREADS) {
+            // (the host lets a launch draw only for jobs of at most THREADS tiles: one table entry per thread, its three loads
+            // in flight together and the Philox block computed under them)
+            const int tb = (int)threadIdx.x;
+            const bool have_tb = tb < dw.nt;
+            const u64 t_incl = have_tb ? dw.tab_incl[tb] : 0ull;
+            const u64 t_W = have_tb ? dw.tab_W[tb] : 0ull;
+            const double t_ratio = have_tb ? dw.tab_ratio[tb] : 0.;
+            const mp_u64x2 blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
+            if (have_tb) { s_incl[tb] = t_incl; s_W[tb] = t_W; s_ratio[tb] = t_ratio; }
+            for (int b = tb + THREADS; b < dw.nt; b += THREADS) {   // (never taken: see above)
                 s_incl[b] = dw.tab_incl[b];
                 s_W[b] = dw.tab_W[b];
                 s_ratio[b] = dw.tab_ratio[b];
             }
-            const mp_u64x2 blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
             if (blockIdx.x == 0 && threadIdx.x == 0) fold_scalars(dw.scal, dw.head->Q, dw.head->Q2, dw.S, dw.head->m, dw.n_global, 0);
+            MP_STAMP(0, 16, 0);
             __syncthreads();
+            MP_STAMP(0, 17, 0);
             const u64 Q = s_incl[dw.nt - 1];
             const double nt_over_Q = (double)dw.nt / (double)Q;   // only a starting guess for the tile walk: no effect on results
             uint32_t gslot[2], tile_of[2];
@@ -699,6 +730,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             for (int q = 0; q < 2; ++q)
                 mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)dw.nt, mp_target(mp_u52(q ? blk.b : blk.a), Q), nt_over_Q, &tile_of[q], &plt[q], &gslot[q]);
             uint32_t j0[2];
+            MP_STAMP(0, 18, 0);
 #pragma unroll
             for (int q = 0; q < 2; ++q) j0[q] = dw.guide_old[gslot[q]];
 #pragma unroll
@@ -718,6 +750,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 wl[base] = plt[0];
                 wr[base] = pm[0];
             }
+            MP_STAMP(0, 19, 0);
         }
     }
     if (!drew) {
@@ -743,6 +776,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     if constexpr (SPLIT2) {
         if (cx_old) mp_resolve_draw(cx_old, n, plt[0], pm[0], &pm[0], &px0[0]);   // pm[] = the parent from here on
     }
+    MP_STAMP(0, 20, 0);
     // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
     if constexpr (QUEUE) {
         // lane-local queue, rounds of ITEMS particles (ITEMS * NS accepted pairs in registers at a time); the model runs on a
@@ -851,6 +885,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             }
         }
         const u64 wave_slot0 = slot_offset + (u64)blockIdx.x * TILE + (u64)wave_ * 64 * LANE_ITEMS;   // first slot of this wave's lanes
+        MP_STAMP(0, 21, 0);
         for (uint32_t guard = 0; guard < MP_MAX_ATTEMPTS; ++guard) {
             // number the pending deviates of the wave: (q-major, lane) order
             uint32_t idx[M];
@@ -894,6 +929,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 else if (mine) att[q] += 64u >> lg;
             }
         }
+        MP_STAMP(0, 22, 0);
 #pragma unroll
         for (int q = 0; q < M; ++q) z[q] = mp_std_normal_from_pair(pu[q], pr[q]);
     }
@@ -905,6 +941,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 // lookup ahead of the deviates as well)
                 asm volatile("" : "+v"(plt[1]) : "v"(z[NS + NS - 1]));
                 mp_resolve_draw(cx_old, n, plt[1], pm[1], &pm[1], &px0[1]);
+                MP_STAMP(0, 24, 0);
             } else if constexpr (D == 1) {
                 mp_resolve_draws<LANE_ITEMS>(cx_old, n, plt, pm, pm, px0);
             } else {
@@ -920,8 +957,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----
     const mp_k1_tail* tp = tail;
     asm volatile("" : "+s"(tp)::"memory");   // the loads of *tp stay here (hoisted to the kernel's entry they would be SGPR pressure again)
-    const mp_k1_tail tl = *tp;
-    normalize_tile<THREADS>(lw, xv, n, blockIdx.x, tl.cx, tl.guide, tl.tile_m, tl.tile_W, tl.tile_W2, tl.tab);
+    mp_k1_tail tl = mp_ld_const(tp);
+    tl.tab.ticket = mp_as_global(tl.tab.ticket); tl.tab.incl = mp_as_global(tl.tab.incl); tl.tab.ratio = mp_as_global(tl.tab.ratio);
+    tl.tab.head = mp_as_global(tl.tab.head); tl.tab.W = mp_as_global(tl.tab.W);
+    normalize_tile<THREADS>(lw, xv, n, blockIdx.x, mp_as_global(tl.cx), mp_as_global(tl.guide), mp_as_global(tl.tile_m), mp_as_global(tl.tile_W),
+                            mp_as_global(tl.tile_W2), tl.tab);
     MP_STAMP(0, 4, 0); MP_STAMP(0, 5, 1);
 }
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
-KERNELS, MAX_WG, SLOTS = 4, 16384, 16
+KERNELS, MAX_WG, SLOTS = 4, 16384, 32
 
 
 def main():

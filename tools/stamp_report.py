@@ -7,7 +7,10 @@ import numpy as np
 b = np.load(sys.argv[1])
 x = b[0]
 x = x[x[:, 1] != 0].astype(np.int64)
-names = [(0, 2, "deviates (load / draw)"), (2, 3, "parent lookup + model"), (3, 8, "wave max"), (8, 9, "barrier 1"), (9, 10, "exp + quantise"),
+# (slots 16..24 exist only in launches that make their draws themselves)
+names = [(0, 16, "entry, table loads issued, resample Philox"), (16, 17, "table copy landed + barrier 0"), (17, 18, "targets + tile walks (LDS)"),
+         (18, 19, "guide cells -> start rows, draw stores"), (19, 20, "lookup of particle 0 (row pair)"), (20, 21, "attempt 0 of both deviates"),
+         (21, 22, "retry rounds (wave-cooperative)"), (22, 2, "log / divide / sqrt -> z"), (2, 24, "lookup of particle 1 (row pair)"), (24, 3, "model x 2"), (3, 8, "wave max"), (8, 9, "barrier 1"), (9, 10, "exp + quantise"),
          (10, 11, "wave scan"), (11, 12, "LDS atomic + barrier 2"), (12, 7, "cross-wave offsets"), (7, 13, "scalars/ticket + row stores"),
          (13, 14, "guide build"), (14, 15, "barrier 3"), (15, 4, "guide store (+ table)")]
 tot = (x[:, 4] - x[:, 0]).mean()
