@@ -390,6 +390,12 @@ struct mp_pf {
     double* tab_ratio = nullptr;
     mp_tab_head* tab_head = nullptr;
     int use_k1_table = 1;               // MP_K1_TABLE=0: every k_draw_slots workgroup builds the table itself (A/B measurements)
+    // local_table: the level-0 launches of this handle build NO job table (no ticket, no workgroup left behind at the end of every
+    // step); a drawing k_propagate builds it per workgroup in LDS from the previous generation's tile scalars, which are therefore
+    // double-buffered like the row table (tiles_alt), and k_build_table makes the global one when something else asks for it
+    bool local_table = false;
+    bool table_fresh = false;           // (local_table) tab_* describe the current tile scalars
+    u64* tiles_alt = nullptr;           // second [3][nt] tile-scalar buffer
     bool rows_fresh = false;            // cx / guide / tile_* describe the current log-weights
     // sharded-resample scratch (allocated on first use)
     unsigned char* sh_dest = nullptr;
@@ -461,7 +467,7 @@ struct mp_pf {
 
 static mp_tab tab_of(const mp_pf* h) {
     mp_tab t;
-    const bool on = h->use_k1_table && !h->sharded && h->tab_ticket;
+    const bool on = h->use_k1_table && !h->sharded && h->tab_ticket && !h->local_table;
     t.ticket = on ? h->tab_ticket : nullptr;
     t.incl = h->tab_incl;
     t.ratio = h->tab_ratio;
@@ -480,17 +486,24 @@ static int32_t update_k1_tail(mp_pf* h) {   // after anything that changes one o
     if (h->cx_alt) {
         t.cx = h->cx_alt;
         t.guide = h->guide_alt;
+        if (h->local_table) {   // (the launch that draws reads the old generation's tile scalars while it writes the new one's)
+            t.tile_m = reinterpret_cast<double*>(h->tiles_alt); t.tile_W = h->tiles_alt + h->nt; t.tile_W2 = h->tiles_alt + 2 * (size_t)h->nt;
+        }
         if (!h->k1_tail_alt) HIPCK(hipMalloc(&h->k1_tail_alt, sizeof(mp_k1_tail)));
         HIPCK(hipMemcpyAsync(h->k1_tail_alt, &t, sizeof(t), hipMemcpyHostToDevice, h->stream));
         HIPCK(hipStreamSynchronize(h->stream));
         mp_k1_draw d;
-        d.tab_incl = h->tab_incl; d.tab_ratio = h->tab_ratio; d.tab_W = h->tab_W; d.head = h->tab_head; d.scal = h->scal;
+        d.scal = h->scal;
         d.n_global = h->n_global; d.nt = h->nt; d.S = h->S; d.dfr_lt = h->dfr_lt; d.dfr_row = h->dfr_row;
         d.guide_old = h->guide;
+        d.tile_m_old = h->tile_m; d.tile_W_old = h->tile_W; d.tile_W2_old = h->tile_W2;
         if (!h->k1_draw) HIPCK(hipMalloc(&h->k1_draw, sizeof(mp_k1_draw)));
         HIPCK(hipMemcpyAsync(h->k1_draw, &d, sizeof(d), hipMemcpyHostToDevice, h->stream));
         HIPCK(hipStreamSynchronize(h->stream));
         d.guide_old = h->guide_alt;
+        if (h->local_table) {
+            d.tile_m_old = reinterpret_cast<double*>(h->tiles_alt); d.tile_W_old = h->tiles_alt + h->nt; d.tile_W2_old = h->tiles_alt + 2 * (size_t)h->nt;
+        }
         if (!h->k1_draw_alt) HIPCK(hipMalloc(&h->k1_draw_alt, sizeof(mp_k1_draw)));
         HIPCK(hipMemcpyAsync(h->k1_draw_alt, &d, sizeof(d), hipMemcpyHostToDevice, h->stream));
         HIPCK(hipStreamSynchronize(h->stream));
@@ -662,6 +675,10 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         std::swap(h->guide, h->guide_alt);
         std::swap(h->k1_tail, h->k1_tail_alt);
         std::swap(h->k1_draw, h->k1_draw_alt);
+        if (h->local_table) {
+            std::swap(h->tiles_own, h->tiles_alt);
+            h->tile_m = reinterpret_cast<double*>(h->tiles_own); h->tile_W = h->tiles_own + h->nt; h->tile_W2 = h->tiles_own + 2 * (size_t)h->nt;
+        }
         h->draw_pending = false;
         h->parents_deferred = true;
         h->deferred = false;
@@ -674,6 +691,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     if (h->sh_lazy) h->sh_parents_lazy = true;
     h->sh_lazy = false;    // k_propagate wrote x[cur] and logw in slot order ...
     h->rows_fresh = true;  // ... and level 0 of their normalisation
+    h->table_fresh = false;
     int32_t rc_ = check_launch("k_propagate");
     if (rc_ != MP_OK) return rc_;
     if (h->flags & MP_PF_RECORD_HISTORY) {
@@ -697,6 +715,7 @@ static int32_t ensure_rows(mp_pf* h) {
         hipLaunchKernelGGL(k_normalize_tiles, dim3(h->nt), dim3(TILE_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->ops->dim_state, h->n, h->cx, h->guide,
                            h->tile_m, h->tile_W, h->tile_W2, tab_of(h));
     }
+    h->table_fresh = false;
     h->rows_fresh = true;
     return check_launch("k_normalize_tiles");
 }
@@ -763,6 +782,11 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (env && env[0] == '0') h->use_k1_table = 0;
         env = getenv("MP_FUSED_DRAWS");
         if (env && env[0] == '0') h->use_fused_draws = 0;
+        // kernels that make their draws themselves build the job's tile table themselves too (MP_K1_LOCAL_TABLE=0: the last
+        // workgroup of every level-0 launch builds it, as for every other kernel)
+        env = getenv("MP_K1_LOCAL_TABLE");
+        h->local_table = !h->sharded && h->use_k1_table && h->use_fused_draws && h->use_deferred && h->ops->can_draw && h->nt <= 1024 &&
+                         !(h->flags & MP_PF_RECORD_HISTORY) && !(env && env[0] == '0');
     }
     HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
     HIPCK(hipMalloc(&h->x[1], sizeof(double) * n * d));
@@ -856,9 +880,15 @@ static int32_t launch_draws(mp_pf* h, int32_t scheme, uint32_t rc) {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
         const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (DRAW_THREADS / 64);
         const mp_tab tab = tab_of(h);
+        if (h->local_table && !h->table_fresh) {   // this handle's level-0 launches build no job table: one workgroup does it now
+            mp_tab tb = tab;
+            tb.ticket = nullptr;
+            hipLaunchKernelGGL(k_build_table, dim3(1), dim3(1024), 0, h->stream, (const double*)h->tile_m, (const u64*)h->tile_W, (const u64*)h->tile_W2, h->nt, tb);
+            h->table_fresh = true;
+        }
         // tile table: built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles) and copied to LDS (1) or,
         // beyond K1_TABLE_LDS_MAX_TILES, probed in L2 (2); handles without such a table build it per workgroup (0)
-        const int tabmode = tab.ticket ? (h->nt <= K1_TABLE_LDS_MAX_TILES ? 1 : 2) : 0;
+        const int tabmode = (tab.ticket || h->local_table) ? (h->nt <= K1_TABLE_LDS_MAX_TILES ? 1 : 2) : 0;
         const size_t lds = (tabmode == 1 ? 24 * (size_t)h->nt : tabmode == 0 ? 16 * (size_t)h->nt : 0) + lds_tail;
         const u64* incl = tabmode ? (const u64*)h->tab_incl : nullptr;
         const double* ratio = tabmode ? (const double*)h->tab_ratio : nullptr;
@@ -908,6 +938,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         if (!h->cx_alt) {
             HIPCK(hipMalloc(&h->cx_alt, sizeof(mp_cx) * (size_t)h->nt * TILE));
             HIPCK(hipMalloc(&h->guide_alt, sizeof(unsigned short) * (size_t)h->nt * GUIDE_N));
+            if (h->local_table) HIPCK(hipMalloc(&h->tiles_alt, sizeof(u64) * 3 * h->nt));
             int32_t rct = update_k1_tail(h);
             if (rct != MP_OK) return rct;
         }
@@ -915,7 +946,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         // ... and for kernels whose lanes own one Philox block's two slots, not even the draws are made here: an asynchronous
         // multinomial resample enqueues NOTHING, the next k_propagate draws for its own slots (flush_draws() otherwise)
         // (up to 1024 tiles: the kernel's copy of the tile table, 24 B per tile, stays within the default dynamic-LDS limit)
-        if (scheme == MP_RESAMPLE_MULTINOMIAL && !log_total_weight && h->use_fused_draws && h->ops->can_draw && tab.ticket &&
+        if (scheme == MP_RESAMPLE_MULTINOMIAL && !log_total_weight && h->use_fused_draws && h->ops->can_draw && h->local_table &&
             h->nt <= 1024 && !(h->flags & MP_PF_RECORD_HISTORY)) {
             h->draw_pending = true;
             h->pending_rc = h->resample_count;
@@ -1653,7 +1684,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     (void)hipFree(h->d_hist_events);
     (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->cx_alt); (void)hipFree(h->k1_tail_alt); (void)hipFree(h->guide);
     (void)hipFree(h->guide_alt); (void)hipFree(h->tab_W); (void)hipFree(h->k1_draw); (void)hipFree(h->k1_draw_alt);
-    (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->scal);
+    (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->tiles_alt); (void)hipFree(h->scal);
     (void)hipFree(h->aos);
     (void)hipFree(h->k1_tail);
     (void)hipFree(h->tab_ticket); (void)hipFree(h->tab_incl); (void)hipFree(h->tab_ratio); (void)hipFree(h->tab_head);

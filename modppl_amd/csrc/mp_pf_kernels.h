@@ -67,6 +67,45 @@ __device__ __forceinline__ T mp_ld_const(const T* p) {
     return v;
 }
 
+// Streaming outputs of a step (states, log-weights, table rows, guide, draws) as WRITE-THROUGH stores (sc1): the bytes leave
+// the XCD's L2 while the kernel still computes, instead of sitting there dirty until the end-of-kernel release writes all of
+// them back at once (the next launch cannot start before that: MI355X_MICROARCH.md, "dependent kernel boundary ... + B / 6 TB/s
+// when the predecessor leaves B bytes dirty").  MP_WT_STORES=0 builds the plain stores (A/B).
+#ifndef MP_WT_STORES
+#define MP_WT_STORES 0   // measured: 44.4 -> 46.5 us per step with write-through stores (the write traffic competes with the gathers)
+#endif
+__device__ __forceinline__ void mp_st_stream(double* p, double v) {
+#if MP_WT_STORES
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void mp_st_stream(uint32_t* p, uint32_t v) {
+#if MP_WT_STORES
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+typedef u64 mp_u64v2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mp_st_stream16(void* p, mp_u64v2_ v) {
+#if MP_WT_STORES
+    // (s_nop: a store of more than 64 bits must not be followed at once by a write of its data registers — a hazard the
+    // compiler pads for its own stores and cannot see inside inline assembly)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<mp_u64v2_*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void mp_st_stream8(void* p, u64 v) {
+#if MP_WT_STORES
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<u64*>(p) = v;
+#endif
+}
+
 constexpr int TILE_THREADS = 512;
 constexpr int TILE_ITEMS = 4;
 constexpr int TILE = TILE_THREADS * TILE_ITEMS;  // 2048 rows per tile: a constant of the normalisation spec
@@ -420,10 +459,10 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
 #pragma unroll
     for (int j = 0; j < ITEMS_; ++j) {
         if (base + j < n) {
-            mp_cx row;
-            row.cum = off + c[j];
-            row.x0 = xv[j];
-            cx[base + j] = row;
+            mp_u64v2_ row;
+            row.x = off + c[j];
+            row.y = mp_f2u(xv[j]);
+            mp_st_stream16(cx + base + j, row);
         }
     }
 
@@ -461,7 +500,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     MP_STAMP(0, 15, 0);
     if constexpr (THREADS == 256) reinterpret_cast<uint4*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint4*>(s_guide)[tid];
     else if constexpr (THREADS == 512) reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
-    else reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint32_t*>(s_guide)[tid];
+    else mp_st_stream(reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N) + tid, reinterpret_cast<const uint32_t*>(s_guide)[tid]);
     if (s_last) {   // workgroup-uniform: every other workgroup's scalars are out (their tickets precede ours)
 #ifndef MP_TEST_NOTABLE
         build_tile_table_global<THREADS>(tile_m, tile_W, tile_W2, (int)gridDim.x, tab);
@@ -497,6 +536,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* 
         }
     }
     normalize_tile<TILE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2, tab);
+}
+
+// The job's tile table as a launch of its own: for handles whose level-0 launches build none (drawing k_propagates build it
+// per workgroup in LDS) when something else wants it — k_draw_slots of a synchronous or lattice resample.
+__global__ __launch_bounds__(1024) void k_build_table(const double* tile_m, const u64* tile_W, const u64* tile_W2, int nt, mp_tab tab) {
+    build_tile_table_global<1024>(tile_m, tile_W, tile_W2, nt, tab);
 }
 
 // GenFn::simulate over an Unfold model (dynunfold.rs:22-39): one lane = one trace of n_steps kernel calls, every site
@@ -595,10 +640,12 @@ struct mp_k1_tail {
 // Everything here belongs to the generation that was resampled and is not written by this launch before its last workgroup
 // runs (the table, tab.W) or at all (guide_old: the launch writes the other guide buffer).
 struct mp_k1_draw {
-    const u64* tab_incl;
-    const double* tab_ratio;
-    const u64* tab_W;
-    const mp_tab_head* head;
+    // the tile scalars of the generation that was resampled: no workgroup of the level-0 launch that wrote them built the job's
+    // tile table (mp_tab::ticket was null), every drawing workgroup builds it in LDS from these (buffers this launch does not
+    // write: its own tile scalars go to the other set)
+    const double* tile_m_old;
+    const u64* tile_W_old;
+    const u64* tile_W2_old;
     const unsigned short* guide_old;
     mp_dev_scalars* scal;
     u64* dfr_lt;              // the draws are also written out: mp_pf_read_parents after the step recomputes the parents from them
@@ -653,11 +700,14 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
     mp_generate_handler<Model> g(rng, obs_v, zp);
     model(g, t, prev, next);
 #pragma unroll
-    for (int d = 0; d < D; ++d) x_out[i * D + d] = next[d];
+    for (int d = 0; d < D; ++d) {
+        if constexpr (D == 1) mp_st_stream(x_out + i * D + d, next[d]);   // (wider states: a lane's 8-byte pieces of its own row are partial-line writes when they bypass L2)
+        else x_out[i * D + d] = next[d];
+    }
     // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to be all zero
     // after a resample (log_weights.fill(0.), :114) and are not re-read
     const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
-    logw[i] = w;
+    mp_st_stream(logw + i, w);
     *lw_out = w;
     *x0_out = next[0];
 }
@@ -698,28 +748,65 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             const mp_k1_draw* dp = drw;
             asm volatile("" : "+s"(dp)::"memory");
             mp_k1_draw dw = mp_ld_const(dp);
-            dw.tab_incl = mp_as_global(dw.tab_incl); dw.tab_ratio = mp_as_global(dw.tab_ratio); dw.tab_W = mp_as_global(dw.tab_W);
-            dw.head = mp_as_global(dw.head); dw.guide_old = mp_as_global(dw.guide_old); dw.scal = mp_as_global(dw.scal);
+            dw.guide_old = mp_as_global(dw.guide_old); dw.scal = mp_as_global(dw.scal);
             dw.dfr_lt = mp_as_global(dw.dfr_lt); dw.dfr_row = mp_as_global(dw.dfr_row);
             extern __shared__ __attribute__((aligned(16))) unsigned char k1_dyn[];
             u64* s_incl = reinterpret_cast<u64*>(k1_dyn);              // [nt]
             u64* s_W = s_incl + dw.nt;                                  // [nt]
             double* s_ratio = reinterpret_cast<double*>(s_W + dw.nt);  // [nt]
-            // (the host lets a launch draw only for jobs of at most THREADS tiles: one table entry per thread, its three loads
-            // in flight together and the Philox block computed under them)
+            // (the host lets a launch draw only for jobs of at most THREADS tiles: one table entry per thread, its loads in flight
+            // together and the Philox block computed under them)
             const int tb = (int)threadIdx.x;
             const bool have_tb = tb < dw.nt;
-            const u64 t_incl = have_tb ? dw.tab_incl[tb] : 0ull;
-            const u64 t_W = have_tb ? dw.tab_W[tb] : 0ull;
-            const double t_ratio = have_tb ? dw.tab_ratio[tb] : 0.;
-            const mp_u64x2 blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
-            if (have_tb) { s_incl[tb] = t_incl; s_W[tb] = t_W; s_ratio[tb] = t_ratio; }
-            for (int b = tb + THREADS; b < dw.nt; b += THREADS) {   // (never taken: see above)
-                s_incl[b] = dw.tab_incl[b];
-                s_W[b] = dw.tab_W[b];
-                s_ratio[b] = dw.tab_ratio[b];
+            mp_u64x2 blk;
+            {
+                // Level 1 of the normalisation by THIS workgroup, in LDS (build_tile_table_global's arithmetic, entry by entry):
+                // no workgroup of the previous launch stayed behind to build the job's table after everybody else had left — that
+                // serial tail (a round of remote loads, two barriers, the stores) was 3 - 4 us of every step's kernel.  Here the
+                // same work costs each workgroup one mp_exp and one division per THREAD, under the start-up latencies.
+                __shared__ double s_l1_red[THREADS / 64];
+                __shared__ u64 s_l1_tot[THREADS / 64], s_l1_tot2[THREADS / 64];
+                const int lane1 = tb & 63, wave1 = tb >> 6;
+                const double mb = have_tb ? mp_as_global(dw.tile_m_old)[tb] : MP_NEG_INF;
+                const u64 Wb = have_tb ? mp_as_global(dw.tile_W_old)[tb] : 0ull;
+                const u64 W2b = (have_tb && blockIdx.x == 0) ? mp_as_global(dw.tile_W2_old)[tb] : 0ull;
+                blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
+                double m = wave_max(mb);
+                if (lane1 == 0) s_l1_red[wave1] = m;
+                __syncthreads();
+                m = s_l1_red[0];
+#pragma unroll
+                for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_l1_red[w]);
+                const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+                const double sc = mp_u2f((u64)(1023 + dw.S - FIX_BITS) << 52);  // 2^(S-51)
+                const double dm = mb - m;
+                const u64 T = have_tb ? mp_quantize((double)Wb * (ok ? mp_exp(dm) : 0.) * sc, 1.0) : 0ull;
+                const u64 incl = wave_incl_scan_u64(T, lane1);
+                if (lane1 == 63) s_l1_tot[wave1] = incl;
+                if (blockIdx.x == 0) {   // (workgroup-uniform) the scalars of this normalisation: Q2 as well
+                    const u64 T2 = have_tb ? mp_quantize((double)W2b * (ok ? mp_exp(2. * dm) : 0.) * sc, 1.0) : 0ull;
+                    const u64 tot2 = wave_sum_u64(T2);
+                    if (lane1 == 0) s_l1_tot2[wave1] = tot2;
+                }
+                __syncthreads();
+                u64 woff = 0, Qall = 0;
+#pragma unroll
+                for (int k = 0; k < THREADS / 64; ++k) {
+                    const u64 tk = s_l1_tot[k];
+                    if (k < wave1) woff += tk;
+                    Qall += tk;
+                }
+                if (have_tb) {
+                    s_incl[tb] = woff + incl;
+                    s_W[tb] = Wb;
+                    s_ratio[tb] = (double)Wb / (double)T;
+                }
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    u64 Q2all = 0;
+                    for (int k = 0; k < THREADS / 64; ++k) Q2all += s_l1_tot2[k];
+                    fold_scalars(dw.scal, Qall, Q2all, dw.S, m, dw.n_global, 0);
+                }
             }
-            if (blockIdx.x == 0 && threadIdx.x == 0) fold_scalars(dw.scal, dw.head->Q, dw.head->Q2, dw.S, dw.head->m, dw.n_global, 0);
             MP_STAMP(0, 16, 0);
             __syncthreads();
             MP_STAMP(0, 17, 0);
@@ -744,8 +831,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             uint32_t* wr = dw.dfr_row;
             if (base + 1 < n) {
                 mp_u64v2 v2; v2.x = plt[0]; v2.y = plt[1];
-                *reinterpret_cast<mp_u64v2*>(wl + base) = v2;
-                *reinterpret_cast<uint2*>(wr + base) = make_uint2(pm[0], pm[1]);
+                mp_st_stream16(wl + base, v2);
+                mp_st_stream8(wr + base, ((u64)pm[1] << 32) | (u64)pm[0]);
             } else if (base < n) {
                 wl[base] = plt[0];
                 wr[base] = pm[0];
@@ -954,6 +1041,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     }
 #undef MP_RUN_PARTICLE
     MP_STAMP(0, 3, 0);
+
     // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----
     const mp_k1_tail* tp = tail;
     asm volatile("" : "+s"(tp)::"memory");   // the loads of *tp stay here (hoisted to the kernel's entry they would be SGPR pressure again)
