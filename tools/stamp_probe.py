@@ -44,9 +44,12 @@ def main():
         pf.resample(sync=False)
     pf.synchronize()
     capi.check(L.mp_debug_stamps(None))   # arm
-    t = args.steps
-    pf.step(ys[t:t + 1])
-    pf.resample(sync=False)
+    # several steps back to back: every launch overwrites the stamps, the last one's remain — a launch in the middle of a busy
+    # queue, as in the bench (a launch behind an idle queue starts its workgroups up to 3 us apart, XCD by XCD)
+    ys2 = lgssm_observations(args.steps + 8)
+    for t in range(args.steps, args.steps + 5):
+        pf.step(ys2[t:t + 1])
+        pf.resample(sync=False)
     pf.synchronize()
     buf = np.zeros((KERNELS, MAX_WG, SLOTS), dtype=np.uint64)
     capi.check(L.mp_debug_stamps(buf.ctypes.data_as(C.c_void_p)))

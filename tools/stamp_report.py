@@ -24,3 +24,11 @@ for k, nm in ((1, "k_draw_slots"),):
     if len(y):
         print("%s: %d workgroups, span %.2f us, mean lifetime %.2f us, clock %.0f MHz" % (nm, len(y), (y[:, 5].max() - y[:, 1].min()) / 100.0, (y[:, 5] - y[:, 1]).mean() / 100.0,
                                                                                       np.median((y[:, 4] - y[:, 0]) / np.maximum(y[:, 5] - y[:, 1], 1) * 100)))
+# who finishes when: the kernel ends with its slowest workgroup
+rt0, rt1 = x[:, 1], x[:, 5]
+t0 = rt0.min()
+start, end = (rt0 - t0) / 100.0, (rt1 - t0) / 100.0
+print("workgroup starts  p0 %.2f p50 %.2f p100 %.2f us;  ends  p0 %.2f p50 %.2f p90 %.2f p100 %.2f us" % (
+    start.min(), np.median(start), start.max(), end.min(), np.median(end), np.percentile(end, 90), end.max()))
+nb = len(x)
+print("first half of the grid (first workgroup of each CU): mean end %.2f us; second half: %.2f us" % (end[:nb // 2].mean(), end[nb // 2:].mean()))
