@@ -767,39 +767,60 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 __shared__ double s_l1_red[THREADS / 64];
                 __shared__ u64 s_l1_tot[THREADS / 64], s_l1_tot2[THREADS / 64];
                 const int lane1 = tb & 63, wave1 = tb >> 6;
-                const double mb = have_tb ? mp_as_global(dw.tile_m_old)[tb] : MP_NEG_INF;
-                const u64 Wb = have_tb ? mp_as_global(dw.tile_W_old)[tb] : 0ull;
-                const u64 W2b = (have_tb && blockIdx.x == 0) ? mp_as_global(dw.tile_W2_old)[tb] : 0ull;
+                // (only the waves that own table entries do the arithmetic — at 512 tiles half of the workgroup's; the others
+                // go straight to the barriers: everything in front of the first gather is on the step's critical path, twice,
+                // because the CU's other workgroup is doing the same)
+                const bool wave_has = wave1 * 64 < dw.nt;   // wave-uniform
+                double mb = MP_NEG_INF;
+                u64 Wb = 0ull, W2b = 0ull;
+                if (wave_has) {
+                    mb = have_tb ? mp_as_global(dw.tile_m_old)[tb] : MP_NEG_INF;
+                    Wb = have_tb ? mp_as_global(dw.tile_W_old)[tb] : 0ull;
+                    W2b = (have_tb && blockIdx.x == 0) ? mp_as_global(dw.tile_W2_old)[tb] : 0ull;
+                }
                 blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
-                double m = wave_max(mb);
-                if (lane1 == 0) s_l1_red[wave1] = m;
+                if (wave_has) {
+                    const double mw = wave_max(mb);
+                    if (lane1 == 0) s_l1_red[wave1] = mw;
+                } else if (lane1 == 0) {
+                    s_l1_red[wave1] = MP_NEG_INF;
+                    s_l1_tot[wave1] = 0ull;
+                    s_l1_tot2[wave1] = 0ull;
+                }
                 __syncthreads();
-                m = s_l1_red[0];
+                double m = s_l1_red[0];
 #pragma unroll
                 for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_l1_red[w]);
-                const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
-                const double sc = mp_u2f((u64)(1023 + dw.S - FIX_BITS) << 52);  // 2^(S-51)
-                const double dm = mb - m;
-                const u64 T = have_tb ? mp_quantize((double)Wb * (ok ? mp_exp(dm) : 0.) * sc, 1.0) : 0ull;
-                const u64 incl = wave_incl_scan_u64(T, lane1);
-                if (lane1 == 63) s_l1_tot[wave1] = incl;
-                if (blockIdx.x == 0) {   // (workgroup-uniform) the scalars of this normalisation: Q2 as well
-                    const u64 T2 = have_tb ? mp_quantize((double)W2b * (ok ? mp_exp(2. * dm) : 0.) * sc, 1.0) : 0ull;
-                    const u64 tot2 = wave_sum_u64(T2);
-                    if (lane1 == 0) s_l1_tot2[wave1] = tot2;
+                u64 incl = 0ull;
+                u64 T = 0ull;
+                if (wave_has) {
+                    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+                    const double sc = mp_u2f((u64)(1023 + dw.S - FIX_BITS) << 52);  // 2^(S-51)
+                    const double dm = mb - m;
+                    T = have_tb ? mp_quantize((double)Wb * (ok ? mp_exp(dm) : 0.) * sc, 1.0) : 0ull;
+                    incl = wave_incl_scan_u64(T, lane1);
+                    if (lane1 == 63) s_l1_tot[wave1] = incl;
+                    if (blockIdx.x == 0) {   // (workgroup-uniform) the scalars of this normalisation: Q2 as well
+                        const u64 T2 = have_tb ? mp_quantize((double)W2b * (ok ? mp_exp(2. * dm) : 0.) * sc, 1.0) : 0ull;
+                        const u64 tot2 = wave_sum_u64(T2);
+                        if (lane1 == 0) s_l1_tot2[wave1] = tot2;
+                    }
                 }
                 __syncthreads();
-                u64 woff = 0, Qall = 0;
+                u64 Qall = 0;
+                if (wave_has || (blockIdx.x == 0 && threadIdx.x == 0)) {
+                    u64 woff = 0;
 #pragma unroll
-                for (int k = 0; k < THREADS / 64; ++k) {
-                    const u64 tk = s_l1_tot[k];
-                    if (k < wave1) woff += tk;
-                    Qall += tk;
-                }
-                if (have_tb) {
-                    s_incl[tb] = woff + incl;
-                    s_W[tb] = Wb;
-                    s_ratio[tb] = (double)Wb / (double)T;
+                    for (int k = 0; k < THREADS / 64; ++k) {
+                        const u64 tk = s_l1_tot[k];
+                        if (k < wave1) woff += tk;
+                        Qall += tk;
+                    }
+                    if (have_tb) {
+                        s_incl[tb] = woff + incl;
+                        s_W[tb] = Wb;
+                        s_ratio[tb] = (double)Wb / (double)T;
+                    }
                 }
                 if (blockIdx.x == 0 && threadIdx.x == 0) {
                     u64 Q2all = 0;
