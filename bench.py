@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command;
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command;
 # it carries the content hash of the kernel sources it was measured with: a summary of another build is refused
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 N_PER_GPU = 1 << 20
@@ -127,15 +127,25 @@ def cpu_baseline_parity(model_fn, seed=20241008):
         pf.init_step(None, ys[:1])
         ref.init_step(ys[:1])
         m = 0
+        # the 2^20 slice runs the TIMED path: resample(sync=False); step back to back, parents read after the step that consumed
+        # the draws (k_propagate makes them itself there); the C1 shape keeps the synchronous resample (k_draw_slots makes them)
+        timed_path = n >= (1 << 20)
         for t in range(1, T):
-            pf.resample()
             ref.resample()
-            m += int((pf.parents != ref.parents()).sum())
-            pf.step(ys[t:t + 1])
+            want = ref.parents().copy()
+            if timed_path:
+                pf.resample(sync=False)
+                pf.step(ys[t:t + 1])
+                m += int((pf.parents != want).sum())
+            else:
+                pf.resample()
+                m += int((pf.parents != want).sum())
+                pf.step(ys[t:t + 1])
             ref.step(ys[t:t + 1])
         a, b = pf.log_marginal_likelihood_estimate(), ref.log_marginal_likelihood_estimate()
         rel = abs(a - b) / abs(b)
-        out[tag] = {"log_ml_gpu": a, "log_ml_cpu": b, "log_ml_rel_err": rel, "index_mismatches": m, "draws": n * (T - 1)}
+        out[tag] = {"log_ml_gpu": a, "log_ml_cpu": b, "log_ml_rel_err": rel, "index_mismatches": m, "draws": n * (T - 1),
+                    "draws_made_by": "k_propagate (asynchronous resample: the timed path)" if timed_path else "k_draw_slots (synchronous resample)"}
         worst_rel = max(worst_rel, rel)
         mism += m
         draws += n * (T - 1)
@@ -194,9 +204,55 @@ def sub_benches(steps, warmup, which):
         t0 = time.perf_counter()
         ch.regen_mh([1, 2, 3], n_iters=3 * sweeps, cycle=True)
         dt = time.perf_counter() - t0
+        rate = (1 << 20) * 3 * sweeps / dt
+        # this kernel is bound by fp64 vector arithmetic, not by HBM — both figures.  Arithmetic per chain-iteration
+        # (quadratic branch, 11 observations; counted on k_mh_iterate<0>): one polar normal (1.27 attempts of
+        # 9 operations, then ln, divide, sqrt: 71), eleven normal log-densities with their means (20 each) and weight updates (2 each),
+        # the accept test's ln (37): ~350 fp64 instructions, ~400 flop with their fused multiply-adds counted twice; a division
+        # or a square root counts as the ~10 instructions it expands to.  State: (a, b, c, is_linear) = 8 k + 8 bytes with k = 3,
+        # read and written once per LAUNCH of 3 * sweeps iterations (it lives in registers in between).
+        flop_per_it = 400.0
         res["c4"] = {"workload": "regen-MH on the hierarchical model, 2^20 chains, masks cycling a, b, c (BASELINE.json configs[3])",
-                     "chains": 1 << 20, "chain_iterations": 3 * sweeps, "chain_iterations_per_s": (1 << 20) * 3 * sweeps / dt}
+                     "chains": 1 << 20, "chain_iterations": 3 * sweeps, "chain_iterations_per_s": rate,
+                     "roofline": {"bound": "fp64 vector arithmetic", "flop_per_chain_iteration": flop_per_it, "achieved": rate * flop_per_it / 1e12,
+                                  "peak": 78.6, "unit": "TFLOP/s", "frac": rate * flop_per_it / 1e12 / 78.6,
+                                  "hbm_bytes_per_chain_per_launch": 2 * (8 * 3 + 8), "iterations_per_launch": 3 * sweeps,
+                                  "hbm_GBps": rate / (3 * sweeps) * 2 * (8 * 3 + 8) / 1e9, "hbm_frac": rate / (3 * sweeps) * 2 * (8 * 3 + 8) / 1e9 / HBM_PEAK_GBPS}}
     return res
+
+
+def _finite(obj, path="", bad=None):
+    """JSON has no NaN / inf: a non-finite number anywhere (a degenerate sub-bench's log-ML, a 0 / 0 ratio) becomes null and its
+    path is listed under "non_finite", so that one bad leg cannot cost the driver the whole line."""
+    if bad is None:
+        bad = []
+    if isinstance(obj, dict):
+        return {k: _finite(v, f"{path}.{k}" if path else str(k), bad) for k, v in obj.items()}, bad
+    if isinstance(obj, (list, tuple)):
+        return [_finite(v, f"{path}[{i}]", bad)[0] for i, v in enumerate(obj)], bad
+    if isinstance(obj, (float, np.floating)) and not np.isfinite(obj):
+        bad.append(path)
+        return None, bad
+    if isinstance(obj, np.generic):
+        return obj.item(), bad
+    return obj, bad
+
+
+def _library_identity():
+    """Which libmodppl_hip.so this process runs: the tree's own build (content hash checked at load) or an override
+    (MODPPL_HIP_LIB: A/B and diagnostics builds — a line measured with one is marked, and takes no traffic summary)."""
+    from modppl_amd import build as _b
+
+    override = os.environ.get("MODPPL_HIP_LIB")
+    path = override or _b.SO
+    stamp = None
+    try:
+        with open(path + ".srchash") as f:
+            stamp = f.read().strip()
+    except OSError:
+        pass
+    return {"path": os.path.relpath(path, ROOT) if path.startswith(ROOT) else path, "srchash": stamp, "tree_source_hash": _b.source_hash(),
+            "override": bool(override), "product_build": (not override) and stamp == _b.source_hash()}
 
 
 def main():
@@ -394,7 +450,10 @@ def main():
             # summary of the same single-GPU command — accepted only if it names this kernel AND was measured with this build
             # (content hash of the kernel sources), otherwise null with the reason
             traffic, traffic_note = None, None
-            if n == N_PER_GPU and os.path.exists(TRAFFIC_JSON) and not sharded_path:
+            lib_id = _library_identity()
+            if not lib_id["product_build"]:
+                traffic_note = "no traffic summary for a library that is not this tree's own build (MODPPL_HIP_LIB override)"
+            elif n == N_PER_GPU and os.path.exists(TRAFFIC_JSON) and not sharded_path:
                 try:
                     from modppl_amd import build as _b
 
@@ -407,13 +466,13 @@ def main():
                     else:
                         traffic = tj[dom]["traffic_bytes"]
                         traffic_note = f"rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, commit {meta.get('commit')}; fetch correction: {tj[dom].get('fetch_correction')}"
-                        if tj[dom].get("traffic_bytes_lower") is not None:
-                            traffic_note += f"; lower bound {tj[dom]['traffic_bytes_lower']:.0f} B"
                 except Exception as e:   # noqa: BLE001
                     traffic_note = f"unreadable profiles summary: {e}"
             roofline = {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
-                        "bytes_per_launch": bytes_k[dom] * n, "bytes_per_particle": bytes_k[dom]}
+                        "bytes_per_launch": bytes_k[dom] * n, "bytes_per_particle": bytes_k[dom],
+                        "bytes_are": "ALGORITHMIC bytes of the reference step this launch stands for (SURVEY.md 8d: 96 B per particle-step at d = 1), "
+                                     "not measured traffic: `traffic` is the measured figure"}
         out = {
             "metric": "particle-steps/sec, 1M-particle LGSSM SMC (step + multinomial resample per time step)",
             "value": n * world * K / dt,
@@ -444,9 +503,14 @@ def main():
             out["roofline"] = roofline
         if c5 is not None:
             out["c5"] = c5
+        out["library"] = _library_identity()
         if world == 1 and not force_sharded and not args.no_sub_benches:
             del pf
-            out.update(sub_benches(max(10, min(K, 40)), min(W, 5), ("c3", "c5", "c4")))
+            for leg in ("c3", "c5", "c4"):   # (one leg's failure is that leg's, not the headline's)
+                try:
+                    out.update(sub_benches(max(10, min(K, 40)), min(W, 5), (leg,)))
+                except Exception as e:   # noqa: BLE001
+                    out[leg + "_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ys, n)
             # parity beside the CPU restatement: relative log-ML difference, resample-index mismatches
@@ -457,6 +521,9 @@ def main():
                                         cpu="literal arithmetic (libm, sequential fp64 sums, linear `while t < u` scan at N=1000; binary search over the same running sum at 2^20)")
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
+        out, bad = _finite(out)
+        if bad:
+            out["non_finite"] = bad
         print(json.dumps(out, allow_nan=False), flush=True)
         os.dup2(2, 1)
     if dist is not None:

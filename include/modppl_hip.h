@@ -109,7 +109,12 @@ int32_t mp_pf_step(mp_pf* h, const double* obs, int32_t n_steps);
 /* ParticleSystem::effective_sample_size — :98-100. */
 int32_t mp_pf_effective_sample_size(mp_pf* h, int32_t ess_mode, double* out);
 /* ParticleSystem::resample — :103-116.  Returns the log total weight through `log_total_weight`;
- * pass NULL to enqueue without synchronising (the value still feeds the log-ML estimate). */
+ * pass NULL to enqueue without synchronising (the value still feeds the log-ML estimate).
+ * Degenerate weights (all -inf / NaN: where the reference's categorical asserts, categorical.rs:23) are MP_ERR_DEGENERATE from
+ * this call when it synchronises; from an asynchronous one the error is sticky and surfaces at the next synchronising call
+ * AFTER the work that normalises has run — for filters whose next mp_pf_step makes the resample's draws itself (two-slot
+ * lanes, dim_state 1, at most 2^21 particles) that is the first synchronising call after that step, not an
+ * mp_pf_synchronize directly behind the resample: nothing of the resample has been enqueued by then. */
 int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight);
 /* ESS-triggered resampling (extension named by the north star): resample with `scheme` iff the effective sample size of the
  * CURRENT weights is below ess_fraction * n_particles.  *resampled = 0 / 1; ess_out and log_total_weight may be NULL. */

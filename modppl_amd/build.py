@@ -52,18 +52,40 @@ def is_stale(so=SO, extra_flags=()):
 
 
 def build(force=False, verbose=False, so=SO, extra_flags=()):
+    """Builds `so` unless its stamp matches the tree.  Safe when several processes (one rank per GPU) find the same stale
+    library at import: the compile runs under an exclusive lock next to the library, the staleness test is repeated inside
+    the lock (the ranks that waited find a fresh library and return), and both the library and its stamp appear atomically
+    (compiled / written to temporary names, then os.replace) — a reader never maps a half-written file, and a kill between
+    the two leaves a library without a matching stamp, i.e. stale, not a stale library that looks fresh."""
     if not force and not is_stale(so, extra_flags):
         return so
     if shutil.which("hipcc") is None:
         raise RuntimeError(f"{so} does not correspond to the sources in this tree (content hash differs) and hipcc is not available to rebuild it")
-    cmd = ["hipcc"] + FLAGS + list(extra_flags) + ["-o", so] + [os.path.join(CSRC, s) for s in SOURCES]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    with open(_stamp_path(so), "w") as f:
-        f.write(source_hash(extra_flags) + "\n")
-    if verbose:
-        print(res.stderr)
+    import fcntl
+
+    with open(so + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale(so, extra_flags):
+                return so   # another process built it while this one waited
+            tmp = f"{so}.tmp.{os.getpid()}"
+            cmd = ["hipcc"] + FLAGS + list(extra_flags) + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+                raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+            if os.path.exists(_stamp_path(so)):
+                os.unlink(_stamp_path(so))   # (first the old stamp goes: from here until the new one lands the library counts as stale)
+            os.replace(tmp, so)
+            stmp = f"{_stamp_path(so)}.tmp.{os.getpid()}"
+            with open(stmp, "w") as f:
+                f.write(source_hash(extra_flags) + "\n")
+            os.replace(stmp, _stamp_path(so))
+            if verbose:
+                print(res.stderr)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return so
 
 

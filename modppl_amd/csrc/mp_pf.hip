@@ -81,6 +81,14 @@ static size_t table_lds(int nt, int threads) {  // s_incl[nt] + s_W[nt] + s_red 
     return sizeof(u64) * 2 * (size_t)nt + (sizeof(double) + sizeof(u64)) * (size_t)(threads / 64);
 }
 
+// MP_K1_THREADS (A/B measurements: other lane shapes of k_propagate<mp_lgssm1>), read ONCE per process: what a model may do
+// (can_draw) and the launch shape come from this one value — read at two different times they could disagree, and a kernel
+// that cannot draw would be handed draws to make
+static int k1_threads_override() {
+    static const int v = [] { const char* e = getenv("MP_K1_THREADS"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 struct PropagateArgs {
     u64 n, slot_offset;
     uint32_t k0, k1;
@@ -128,7 +136,7 @@ struct ModelOpsT : ModelOps {
         max_normals = Model::MAX_NORMALS;
         // (the conditions of CAN_DRAW in k_propagate, for the launch configuration `propagate` below picks)
         can_draw = Model::MAX_NORMALS <= 4 && Model::DIM_STATE == 1 && mp_coop_model<Model>() && 2 * Model::MAX_NORMALS <= 4 &&
-                   !std::is_same<Model, mp_lgssm_dense<16>>::value && !getenv("MP_K1_THREADS");   // (that override launches other lane shapes)
+                   !std::is_same<Model, mp_lgssm_dense<16>>::value && k1_threads_override() == 0;   // (that override launches other lane shapes)
         static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
         static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
     }
@@ -138,7 +146,7 @@ struct ModelOpsT : ModelOps {
     void propagate(const PropagateArgs& a) const override {
         // light kernels (few registers) run 1024 threads x 2 particles per tile: twice the waves in flight for the same 2048-slot tile
         constexpr int THREADS = (Model::MAX_NORMALS <= 4 && Model::DIM_STATE <= 4) ? 1024 : TILE_THREADS;
-        static const int k1t = [] { const char* e = getenv("MP_K1_THREADS"); return e ? atoi(e) : 0; }();   // A/B measurements
+        const int k1t = k1_threads_override();   // A/B measurements
         if constexpr (std::is_same<Model, mp_lgssm1>::value) {
             if (k1t == 256) {
                 hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,

@@ -126,3 +126,51 @@ def test_draws_made_by_the_step_equal_draws_made_by_the_resample(monkeypatch):
     assert np.array_equal(fused.log_weights, ref.log_weights())
     assert fused.effective_sample_size() == plain.effective_sample_size() == ref.effective_sample_size(0)
     assert fused.log_marginal_likelihood_estimate() == plain.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+
+
+@pytest.mark.parametrize("n", [1 << 20, 1 << 21, (1 << 21) + 2048])
+def test_timed_path_at_the_timed_size(n):
+    """The path bench.py TIMES — step; resample(sync=False) back to back, nothing read in between — against the canonical checker
+    at the bench's population (2^20: 512 tiles) and on both sides of the switch-over at 1024 tiles: up to 2^21 particles an
+    asynchronous multinomial resample enqueues nothing and the next k_propagate makes the draws for its own slots from a tile
+    table it builds in LDS; beyond, k_draw_slots makes them against the table one workgroup builds (mp_pf.hip: local_table,
+    launch_draws).  Parents and states are read only after the step that consumed the draws."""
+    pf, ref, obs = _pair(1, n, 20241008, 4)
+    for t in range(1, 4):
+        pf.resample(sync=False)
+        pf.step(obs[t:t + 1])
+        ref.resample()
+        want = ref.parents().copy()
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(pf.parents, want), f"t={t}"
+    assert np.array_equal(pf.states(), ref.state())
+    assert np.array_equal(pf.log_weights, ref.log_weights())
+    assert pf.effective_sample_size() == ref.effective_sample_size(0)
+    assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+
+
+def test_degenerate_population_on_the_fused_path():
+    """All log-weights -inf (an observation no particle can explain): the synchronous resample raises where the reference's
+    categorical asserts (categorical.rs:23); an ASYNCHRONOUS resample of a filter that makes its draws inside the next step has
+    enqueued nothing yet, so `synchronize()` right after it has nothing to report — the step that consumes the draws does
+    (include/modppl_hip.h, mp_pf_resample)."""
+    import modppl_amd
+    from modppl_amd import capi
+
+    obs = O.lgssm_observations(3).reshape(3, 1)
+    bad = np.array([[1e200]])   # (y - x)^2 overflows: every log-weight is -inf
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), 70001, 3)
+    pf.init_step(None, obs[:1])
+    pf.resample(sync=False)
+    pf.step(bad)
+    pf.resample(sync=False)
+    pf.synchronize()                 # nothing of that resample has run
+    pf.step(obs[1:2])                # its draws are made here
+    with pytest.raises(capi.ModpplError):
+        pf.synchronize()
+    pf2 = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), 70001, 3)
+    pf2.init_step(None, obs[:1])
+    pf2.resample(sync=False)
+    pf2.step(bad)
+    with pytest.raises(capi.ModpplError):
+        pf2.resample()               # synchronous: reported at once

@@ -5,8 +5,9 @@ requires) of `bench.py --no-kernel-timing` into per-launch HBM-side traffic per 
     python tools/collect_traffic.py gpurun_out/r1 > profiles/r01/traffic.json
 
 Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction (guide §HBM): FETCH_SIZE reports half of the
-bytes of a wide coalesced streaming read, so the streaming kernels (propagate, normalize_scan) are doubled; the resample
-kernel's reads are random 16-byte rows, a width the guide leaves uncalibrated, so its raw value is kept and flagged."""
+bytes of a wide coalesced streaming read, so the streaming kernels (normalize_scan, bin_draws) are doubled.  Random 16-byte
+row reads are counted exactly — one 64-byte fabric read per miss, calibrated with tools/gather_probe.hip
+(profiles/r03/gather_probe_fetch.txt) — so the drawing k_propagate, whose fetches are its gathers, is taken as it is."""
 import collections
 import csv
 import glob
@@ -17,9 +18,8 @@ import sys
 # systematic leg is listed on its own)
 FAM = {"k_propagate<mp_lgssm1": "propagate", "k_normalize_tiles": "normalize_scan", "k_draw_slots": "bin_draws",
        "k_resample_gather": "resample_gather"}
-# (k_draw_slots reads little: Philox in, draws out.  k_propagate streams its own inputs/outputs AND gathers random 16-byte
-# rows for the deferred draws; the x2 correction applied to its whole FETCH_SIZE is therefore an upper bound.)
-STREAMING = {"propagate", "normalize_scan", "bin_draws"}
+# (k_draw_slots reads little: Philox in, draws out)
+STREAMING = {"normalize_scan", "bin_draws"}
 
 
 NAMES = {}   # family -> kernel names seen (bench.py checks them against the kernels it times)
@@ -54,10 +54,15 @@ def main(root):
         f_corr = f_raw * 2.0 if fam in STREAMING else f_raw
         note = "x2 (wide coalesced stream)" if fam in STREAMING else "none (random 16-B rows: uncalibrated width; true value in [1x, 2x] of raw)"
         if fam == "propagate":
-            note = ("x2 on the whole FETCH_SIZE: exact for the kernel's streaming reads, an UPPER bound for the row gathers of the deferred "
-                    "draws it looks up (one 64- or 128-byte fetch per miss: uncalibrated); traffic_bytes_lower takes the counter as it is")
+            # calibrated (tools/gather_probe.hip under rocprofv3 --pmc FETCH_SIZE, profiles/r03/gather_probe_fetch.txt): a random
+            # 16-byte row read that misses L2 is ONE 64-byte fabric read and FETCH_SIZE counts it in full (63.6 B per request from
+            # a 1 GB table, 47.5 B from a 16 MB one of which a quarter hits L2) — the x2 correction applies to wide coalesced
+            # streams only.  The drawing k_propagate's fetches are its gathers (guide cells, table rows); what it streams in
+            # (2 x 8 B x tiles of tile scalars per workgroup) hits L2 after each XCD's first touch.
+            f_corr = f_raw
+            note = "x1: the launch's fetches are random guide-cell / table-row reads, which FETCH_SIZE counts exactly (calibrated with tools/gather_probe.hip)"
         res[fam] = {"fetch_bytes_raw": f_raw, "fetch_bytes_corrected": f_corr, "write_bytes": w, "traffic_bytes": f_corr + w,
-                    "traffic_bytes_lower": f_raw + w, "fetch_correction": note,
+                    "fetch_correction": note,
                     "launches_sampled": [nf.get(fam, 0), nw.get(fam, 0)]}
     import os
     import subprocess
