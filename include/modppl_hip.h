@@ -235,6 +235,46 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
 int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t capacity, double* d_send_out, double* d_rows, uint64_t recv_rows);
 int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_total_weight, uint64_t* counts_out);
 
+/* ---- the sharded resample as ONE call: the library runs the collectives itself ----------------------------------------
+ * ParticleSystem::resample (particle_filter.rs:103-116) of a filter sharded over `world` devices, owner-keeps exchange: tiles
+ * packed -> all-gather -> mp_pf_shard_owned_count / _expand -> all-to-all of the surplus rows -> mp_pf_shard_owned_commit, with
+ * the fallback to exact sizes when a pair of ranks exceeds the equal-split capacity, all buffers owned by the handle and every
+ * collective enqueued on the filter's stream.  A C, C++, Rust or Python host calls this (or the _rccl form) once per
+ * resample; nothing else of the protocol lives outside the library.
+ *
+ * mp_transport: the two collectives, as plain C function pointers (device pointers, byte counts, the filter's hipStream_t):
+ *   all_gather(ctx, d_send, d_recv, bytes_per_rank, stream)              rank-major result
+ *   all_to_all(ctx, d_send, send_off[world], send_bytes[world], d_recv, recv_off[world], recv_bytes[world], world, stream)
+ * Both return 0 or an MP_ERR_* code.  mp_transport_rccl fills one over an ncclComm_t: ncclAllGather, and ONE group of
+ * ncclSend / ncclRecv per exchange (xGMI is point-to-point).  librccl.so.1 is resolved at first use, by SONAME — a process
+ * that has one mapped already (PyTorch) gets that copy — and never for a single-GPU filter.
+ * force_collectives != 0: issue them even in a world of one (exercises the transport on one GPU).
+ * log_total_weight NULL: asynchronous (one polled word per resample in a world > 1, nothing in a world of one). */
+typedef struct mp_transport {
+    void* ctx;
+    int32_t (*all_gather)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream);
+    int32_t (*all_to_all)(void* ctx, const void* d_send, const uint64_t* send_off, const uint64_t* send_bytes, void* d_recv,
+                          const uint64_t* recv_off, const uint64_t* recv_bytes, int32_t world, void* stream);
+} mp_transport;
+int32_t mp_pf_shard_resample(mp_pf* h, const mp_transport* t, int32_t world, int32_t rank, int32_t scheme, int32_t force_collectives,
+                             double* log_total_weight);
+int32_t mp_pf_shard_resample_rccl(mp_pf* h, void* nccl_comm, int32_t world, int32_t rank, int32_t scheme, int32_t force_collectives,
+                                  double* log_total_weight);
+/* log_marginal_likelihood_estimate (:119-121) / fresh ESS of the whole job: level 0 of this shard, all-gather, level 1 */
+int32_t mp_pf_shard_query_native(mp_pf* h, const mp_transport* t, int32_t world, int32_t force_collectives, double* log_ml, double* ess);
+/* what the last native resamples did: fallbacks to exact sizes so far, surplus rows moved job-wide and offspring per rank of the
+ * last resample whose counts reached the host (a synchronous one, or one that fell back), the current equal-split capacity
+ * (0: exact sizes).  Any pointer may be NULL. */
+int32_t mp_pf_shard_resample_stats(mp_pf* h, uint64_t* fallbacks, uint64_t* exchange_rows, uint64_t* counts_out, uint64_t* capacity);
+int32_t mp_transport_rccl(void* nccl_comm, mp_transport* out);
+/* a communicator of the library's own: rank 0 makes the 128-byte id and hands it to the other ranks by whatever channel the
+ * host has (MPI, a file, torch.distributed's store); every rank then creates its communicator on its device */
+int32_t mp_rccl_unique_id(void* out128);
+int32_t mp_rccl_comm_create(int32_t world, int32_t rank, const void* id128, int32_t device, void** comm_out);
+int32_t mp_rccl_comm_destroy(void* comm);
+/* device <-> host copy on the filter's stream, waited for: for transports that stage through the host */
+int32_t mp_pf_stream_copy(mp_pf* h, void* dst, const void* src, uint64_t bytes, int32_t to_host);
+
 /* ---- profiling hooks (bench.py: HIP-event timing on the stream the kernels run on) ------ */
 /* Accumulated GPU time (ms) and launch count of kernel family `which` since the last reset,
  * measured with hipEvents recorded around each launch when timing is enabled. */

@@ -32,6 +32,8 @@ SYMBOLS = [
     "mp_pf_set_timing", "mp_pf_get_timing", "mp_unfold_simulate", "mp_importance_resampling",
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
     "mp_pf_shard_owned_count", "mp_pf_shard_owned_expand", "mp_pf_shard_owned_commit",
+    "mp_pf_shard_resample", "mp_pf_shard_resample_rccl", "mp_pf_shard_query_native", "mp_pf_shard_resample_stats", "mp_transport_rccl",
+    "mp_rccl_unique_id", "mp_rccl_comm_create", "mp_rccl_comm_destroy", "mp_pf_stream_copy",
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
     "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_read_observations", "mp_mh_iterations", "mp_mh_destroy",
     # include/modppl_hip_probe.h
@@ -57,6 +59,16 @@ class ModpplError(RuntimeError):
 
 
 _lib = None
+
+
+# mp_transport (include/modppl_hip.h): the two collectives of the sharded resample as C function pointers
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                            C.POINTER(C.c_uint64), C.c_int32, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("all_to_all", ALL_TO_ALL_FN)]
 
 
 def _preload_hip_runtime():
@@ -127,6 +139,15 @@ def load():
     L.mp_pf_shard_owned_count.argtypes = [p, i32, p, i32, i32, u64, C.POINTER(u64)]
     L.mp_pf_shard_owned_expand.argtypes = [p, i32, i32, u64, p, p, u64]
     L.mp_pf_shard_owned_commit.argtypes = [p, p, dp, C.POINTER(u64)]
+    L.mp_pf_shard_resample.argtypes = [p, C.POINTER(Transport), i32, i32, i32, i32, dp]
+    L.mp_pf_shard_resample_rccl.argtypes = [p, p, i32, i32, i32, i32, dp]
+    L.mp_pf_shard_query_native.argtypes = [p, C.POINTER(Transport), i32, i32, dp, dp]
+    L.mp_pf_shard_resample_stats.argtypes = [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.mp_transport_rccl.argtypes = [p, C.POINTER(Transport)]
+    L.mp_rccl_unique_id.argtypes = [p]
+    L.mp_rccl_comm_create.argtypes = [i32, i32, p, i32, C.POINTER(p)]
+    L.mp_rccl_comm_destroy.argtypes = [p]
+    L.mp_pf_stream_copy.argtypes = [p, p, p, u64, i32]
     L.mp_pf_shard_tiles.argtypes = [p, p, p, p]
     L.mp_pf_shard_route.argtypes = [p, i32, p, p, p, i32, i32, p, C.POINTER(i64)]
     L.mp_pf_shard_resolve.argtypes = [p, p, u64, p]

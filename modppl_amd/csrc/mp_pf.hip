@@ -66,6 +66,8 @@ int32_t mp_set_error(int32_t code, const std::string& msg) { return mp_fail(code
             return mp_fail(MP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes for mp_shard_native.h (resolved with dlsym at first use: no link-time dependency)
 #include "mp_pf_kernels.h"
 #include "mp_pf_shard_kernels.h"
 
@@ -350,8 +352,10 @@ struct TimedLaunch {
     int family;
 };
 
+struct mp_shard_native_state;   // mp_shard_native.h
 struct mp_pf {
     std::unique_ptr<ModelOps> ops;
+    mp_shard_native_state* native = nullptr;   // buffers and bookkeeping of mp_pf_shard_resample
     u64 n = 0, n_global = 0, slot_offset = 0, seed = 0;
     uint32_t flags = 0;
     int device = 0;
@@ -402,7 +406,7 @@ struct mp_pf {
     // step); a drawing k_propagate builds it per workgroup in LDS from the previous generation's tile scalars, which are therefore
     // double-buffered like the row table (tiles_alt), and k_build_table makes the global one when something else asks for it
     bool local_table = false;
-    bool table_fresh = false;           // (local_table) tab_* describe the current tile scalars
+    bool table_fresh = false;           // tab_* (the job's tile table in global memory) describe the current tile scalars
     u64* tiles_alt = nullptr;           // second [3][nt] tile-scalar buffer
     bool rows_fresh = false;            // cx / guide / tile_* describe the current log-weights
     // sharded-resample scratch (allocated on first use)
@@ -699,7 +703,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     if (h->sh_lazy) h->sh_parents_lazy = true;
     h->sh_lazy = false;    // k_propagate wrote x[cur] and logw in slot order ...
     h->rows_fresh = true;  // ... and level 0 of their normalisation
-    h->table_fresh = false;
+    h->table_fresh = a.aux.tab.ticket != nullptr;   // (built by that launch's last workgroup, or not at all)
     int32_t rc_ = check_launch("k_propagate");
     if (rc_ != MP_OK) return rc_;
     if (h->flags & MP_PF_RECORD_HISTORY) {
@@ -723,7 +727,7 @@ static int32_t ensure_rows(mp_pf* h) {
         hipLaunchKernelGGL(k_normalize_tiles, dim3(h->nt), dim3(TILE_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->ops->dim_state, h->n, h->cx, h->guide,
                            h->tile_m, h->tile_W, h->tile_W2, tab_of(h));
     }
-    h->table_fresh = false;
+    h->table_fresh = tab_of(h).ticket != nullptr;
     h->rows_fresh = true;
     return check_launch("k_normalize_tiles");
 }
@@ -882,21 +886,28 @@ int32_t mp_pf_step(mp_pf* h, const double* obs, int32_t n_steps) {
     return MP_OK;
 }
 
+// The job's tile table in global memory (tab_*), for the kernels that read it there: built by the last workgroup of the level-0
+// launch when that launch was given the ticket, by one workgroup of its own otherwise (handles whose drawing k_propagates
+// build the table per workgroup in LDS; a handle that changed modes).  false: this handle has no such buffers (sharded).
+static bool ensure_table(mp_pf* h) {
+    if (!h->tab_incl || h->sharded || !h->use_k1_table) return false;
+    if (!h->table_fresh) {
+        mp_tab tb = tab_of(h);
+        tb.ticket = nullptr;
+        hipLaunchKernelGGL(k_build_table, dim3(1), dim3(1024), 0, h->stream, (const double*)h->tile_m, (const u64*)h->tile_W, (const u64*)h->tile_W2, h->nt, tb);
+        h->table_fresh = true;
+    }
+    return true;
+}
+
 // k_draw_slots for resample number `rc` of scheme `scheme`: {target, start row} per output slot
 static int32_t launch_draws(mp_pf* h, int32_t scheme, uint32_t rc) {
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
         const size_t lds_tail = (sizeof(double) + sizeof(u64)) * (DRAW_THREADS / 64);
-        const mp_tab tab = tab_of(h);
-        if (h->local_table && !h->table_fresh) {   // this handle's level-0 launches build no job table: one workgroup does it now
-            mp_tab tb = tab;
-            tb.ticket = nullptr;
-            hipLaunchKernelGGL(k_build_table, dim3(1), dim3(1024), 0, h->stream, (const double*)h->tile_m, (const u64*)h->tile_W, (const u64*)h->tile_W2, h->nt, tb);
-            h->table_fresh = true;
-        }
-        // tile table: built by the last workgroup of the level-0 launch (k_propagate / k_normalize_tiles) and copied to LDS (1) or,
-        // beyond K1_TABLE_LDS_MAX_TILES, probed in L2 (2); handles without such a table build it per workgroup (0)
-        const int tabmode = (tab.ticket || h->local_table) ? (h->nt <= K1_TABLE_LDS_MAX_TILES ? 1 : 2) : 0;
+        // tile table: in global memory (ensure_table) and copied to LDS (1) or, beyond K1_TABLE_LDS_MAX_TILES, probed in L2 (2);
+        // handles without such a table build it per workgroup (0)
+        const int tabmode = ensure_table(h) ? (h->nt <= K1_TABLE_LDS_MAX_TILES ? 1 : 2) : 0;
         const size_t lds = (tabmode == 1 ? 24 * (size_t)h->nt : tabmode == 0 ? 16 * (size_t)h->nt : 0) + lds_tail;
         const u64* incl = tabmode ? (const u64*)h->tab_incl : nullptr;
         const double* ratio = tabmode ? (const double*)h->tab_ratio : nullptr;
@@ -1250,6 +1261,7 @@ int32_t mp_pf_shard_bind_tiles(mp_pf* h, uint64_t* d_tiles) {
     if (!h || !d_tiles) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
     HIPCK(hipMemcpyAsync(d_tiles, h->tile_m, sizeof(u64) * 3 * h->nt, hipMemcpyDeviceToDevice, h->stream));
+    h->local_table = false;   // (a handle driven through the shard phases: its tile scalars live in the caller's buffer, not in a pair of the library's)
     h->tile_m = reinterpret_cast<double*>(d_tiles);
     h->tile_W = (u64*)d_tiles + h->nt;
     h->tile_W2 = (u64*)d_tiles + 2 * (size_t)h->nt;
@@ -1449,8 +1461,7 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
         // A world of one: the job's tile table is the one the last workgroup of k_propagate / k_normalize_tiles built (as for
         // the unsharded resample); otherwise one workgroup builds it from the gathered tiles.
-        const mp_tab tab = tab_of(h);
-        const bool solo_tab = world == 1 && tab.ticket && scheme == MP_RESAMPLE_MULTINOMIAL && (const void*)d_tiles_all == (const void*)h->tile_m;
+        const bool solo_tab = world == 1 && scheme == MP_RESAMPLE_MULTINOMIAL && (const void*)d_tiles_all == (const void*)h->tile_m && ensure_table(h);
         if (!solo_tab)
             hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
                                h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo,
@@ -1679,10 +1690,12 @@ int32_t mp_pf_get_timing(mp_pf* h, int32_t which, double* total_ms, uint64_t* la
     return MP_OK;
 }
 
+static void shard_native_free(mp_shard_native_state* s);   // mp_shard_native.h
 int32_t mp_pf_destroy(mp_pf* h) {
     if (!h) return MP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    shard_native_free(h->native);
     for (auto& tl : h->timed) {
         (void)hipEventDestroy(tl.start);
         (void)hipEventDestroy(tl.stop);
@@ -1796,6 +1809,8 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
     }
     return MP_OK;
 }
+
+#include "mp_shard_native.h"
 
 #ifdef MP_STAMPS
 // diagnostics only (libmodppl_hip_stamps.so, tools/stamp_probe.py): enable / read the per-workgroup stamps

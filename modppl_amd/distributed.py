@@ -105,6 +105,29 @@ class HipShardEngine:
 
     # "owner keeps" form
     supports_owned = True
+    # ... and the whole resample as ONE library call that issues the collectives itself (mp_pf_shard_resample, include/modppl_hip.h)
+    supports_native = True
+
+    def shard_resample_native(self, transport, world, rank, scheme, force, want_value):
+        out = C.c_double()
+        capi.check(self._L.mp_pf_shard_resample(self._h, C.byref(transport) if transport is not None else None, world, rank, scheme, int(force),
+                                                C.byref(out) if want_value else None))
+        return out.value if want_value else None
+
+    def shard_query_native(self, transport, world, force):
+        lml, ess = C.c_double(), C.c_double()
+        capi.check(self._L.mp_pf_shard_query_native(self._h, C.byref(transport) if transport is not None else None, world, int(force),
+                                                    C.byref(lml), C.byref(ess)))
+        return lml.value, ess.value
+
+    def shard_native_stats(self, world):
+        fb, rows, cap = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        counts = (C.c_uint64 * 64)()
+        capi.check(self._L.mp_pf_shard_resample_stats(self._h, C.byref(fb), C.byref(rows), counts, C.byref(cap)))
+        return fb.value, (None if rows.value == 2 ** 64 - 1 else rows.value), list(counts)[:world], cap.value
+
+    def stream_copy(self, dst_ptr, src_ptr, nbytes, to_host):
+        capi.check(self._L.mp_pf_stream_copy(self._h, dst_ptr, src_ptr, nbytes, int(to_host)))
 
     def shard_owned_count(self, scheme, tiles_all_ptr, world, rank, cap=0, want_counts=True):
         counts = (C.c_uint64 * world)()
@@ -182,6 +205,82 @@ class HipShardEngine:
             pass
 
 
+def rccl_transport(L, group, world, rank, device_index):
+    """A communicator of the LIBRARY's own over the ranks of `group` (mp_rccl_*): rank 0 makes the id, torch.distributed only
+    carries its 128 bytes to the others.  -> (Transport, comm handle)"""
+    ident = (C.c_ubyte * 128)()
+    if rank == 0:
+        capi.check(L.mp_rccl_unique_id(ident))
+    box = [bytes(ident)]
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    comm = C.c_void_p()
+    capi.check(L.mp_rccl_comm_create(world, rank, ident, device_index, C.byref(comm)))
+    t = capi.Transport()
+    capi.check(L.mp_transport_rccl(comm, C.byref(t)))
+    return t, comm
+
+
+class HostStagedTransport:
+    """mp_transport over a process group that cannot take device buffers (gloo; ranks sharing one GPU in tests): the library
+    calls back with device pointers, the callbacks stage through host memory (mp_pf_stream_copy) and run the collective on CPU
+    tensors.  Only for tests: every collective costs two copies and a stream wait."""
+
+    def __init__(self, engine, group, world):
+        self.engine, self.group, self.world = engine, group, world
+        self._ag = capi.ALL_GATHER_FN(self._all_gather)
+        self._aa = capi.ALL_TO_ALL_FN(self._all_to_all)
+        self.struct = capi.Transport(None, self._ag, self._aa)
+        self.calls = {"all_gather": 0, "all_to_all": 0}
+
+    def _all_gather(self, ctx, d_send, d_recv, nbytes, stream):
+        try:
+            self.calls["all_gather"] += 1
+            mine = torch.empty(nbytes, dtype=torch.uint8)
+            self.engine.stream_copy(C.c_void_p(mine.data_ptr()), C.c_void_p(d_send), nbytes, True)
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+            allp = torch.cat(parts)
+            self.engine.stream_copy(C.c_void_p(d_recv), C.c_void_p(allp.data_ptr()), nbytes * self.world, False)
+            return 0
+        except Exception:   # noqa: BLE001 (an exception must not unwind through the C frames)
+            return capi.MP_ERR_HIP
+
+    def _all_to_all(self, ctx, d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes, world, stream):
+        try:
+            self.calls["all_to_all"] += 1
+            outs, ins = [], []
+            for q in range(world):
+                o = torch.empty(int(send_bytes[q]), dtype=torch.uint8)
+                if send_bytes[q]:
+                    self.engine.stream_copy(C.c_void_p(o.data_ptr()), C.c_void_p(d_send + int(send_off[q])), int(send_bytes[q]), True)
+                outs.append(o)
+                ins.append(torch.empty(int(recv_bytes[q]), dtype=torch.uint8))
+            dist.all_to_all(ins, outs, group=self.group) if dist.get_backend(self.group) != "gloo" else self._gloo_all_to_all(ins, outs)
+            for q in range(world):
+                if recv_bytes[q]:
+                    self.engine.stream_copy(C.c_void_p(d_recv + int(recv_off[q])), C.c_void_p(ins[q].data_ptr()), int(recv_bytes[q]), False)
+            return 0
+        except Exception:   # noqa: BLE001
+            return capi.MP_ERR_HIP
+
+    def _gloo_all_to_all(self, ins, outs):
+        # gloo has no all_to_all: pairwise send / recv, lower rank first
+        me = dist.get_rank(self.group)
+        ins[me].copy_(outs[me])
+        for q in range(self.world):
+            if q == me:
+                continue
+            peer = dist.get_global_rank(self.group, q) if self.group is not None else q
+            first, second = ("send", "recv") if me < q else ("recv", "send")
+            for op in (first, second):   # (empty pieces are skipped on both sides alike: the sizes come from the same plan)
+                if op == "send" and outs[q].numel():
+                    dist.send(outs[q], peer, group=self.group)
+                if op == "recv" and ins[q].numel():
+                    dist.recv(ins[q], peer, group=self.group)
+
+
 class ShardedParticleSystem:
     """`ParticleSystem` (modppl/src/inference/particle_filter.rs) over a process group: same methods, same results
     as one filter with `num_particles` particles, whatever the world size.
@@ -229,12 +328,23 @@ class ShardedParticleSystem:
         self._owned = self.exchange == "owned"
         if self._owned and not getattr(self.engine, "supports_owned", False):
             raise capi.ModpplError(capi.MP_ERR_UNSUPPORTED, "this engine has no owner-keeps exchange")
+        # The owner-keeps resample of the product's engine is ONE library call (mp_pf_shard_resample): buffers, phases, fallback
+        # and collectives live in the library; this class only names the transport.  MP_SHARD_NATIVE=0, or an engine without the
+        # entry point (the CPU checker in tests/test_distributed_cpu.py), runs the same protocol from _resample_owned below.
+        self._native = self._owned and getattr(self.engine, "supports_native", False) and os.environ.get("MP_SHARD_NATIVE", "1") == "1"
+        self._transport, self._rccl_comm, self._staged = None, None, None
+        if self._native and (self.world > 1 or self._always):
+            if host_staging or dist.get_backend(group) == "gloo":
+                self._staged = HostStagedTransport(self.engine, group, self.world)
+                self._transport = self._staged.struct
+            else:
+                self._transport, self._rccl_comm = rccl_transport(self.engine._L, group, self.world, self.rank, self.dev.index or 0)
         self._host_staging = host_staging
         self._ow_keep = None
         self._ox_cache, self._ox_flip = {}, 0   # exact-size exchange buffers
         self.last_counts = None          # offspring per rank of the last synchronous owner-keeps resample
         self.last_exchange_rows = None   # surplus rows it moved between ranks
-        if self._owned:
+        if self._owned and not self._native:
             # surplus rows per pair of ranks in the equal-split all-to-all: the surplus of a rank is the spread of a
             # Binomial(N, ~1/world) count plus the imbalance of the shard masses, both O(sqrt) of n
             self._ow_fixed = self._fixed
@@ -252,7 +362,7 @@ class ShardedParticleSystem:
                 self._ow_fixed = False
             if self._ow_fixed:
                 self._alloc_owned(self._ow_cap)
-        if self._fixed:
+        if self._fixed and not self._native:
             slack = float(os.environ.get("MP_SHARD_SLACK", "1.25"))
             per = self.n // (min(8, self.nt) * self.world)   # draws per (owner, eighth of the owner's tiles) sub-segment, on average
             cap = min(self.n, int(per * slack) + 512)
@@ -384,6 +494,12 @@ class ShardedParticleSystem:
         return [[max(0, min(PS[r] + S[r], PD[s] + D[s]) - max(PS[r], PD[s])) for s in range(w)] for r in range(w)]
 
     def _resample_owned(self, scheme, sync):
+        if self._native:
+            value = self.engine.shard_resample_native(self._transport, self.world, self.rank, scheme, self._always, sync)
+            self.fallbacks, rows, counts, _ = self.engine.shard_native_stats(self.world)
+            if rows is not None:
+                self.last_counts, self.last_exchange_rows = counts, rows
+            return value
         e, w, d = self.engine, self.world, self.model.dim_state
         p_tiles = C.c_void_p(self._tiles.data_ptr())
         e.shard_tiles_packed(p_tiles)
@@ -483,6 +599,8 @@ class ShardedParticleSystem:
         return self.engine.shard_scatter(C.c_void_p(self._rows.data_ptr()), sync)
 
     def _query(self):
+        if self._native:
+            return self.engine.shard_query_native(self._transport, self.world, self._always)
         with self._ctx():
             if self._fixed:
                 self._gather_tiles_packed()
@@ -520,3 +638,18 @@ class ShardedParticleSystem:
 
     def synchronize(self):
         self.engine.synchronize()
+
+    def close(self):
+        """the library's own RCCL communicator goes before the filter whose stream it was used on"""
+        if getattr(self, "_rccl_comm", None):
+            self.engine.synchronize()
+            self.engine._L.mp_rccl_comm_destroy(self._rccl_comm)
+            self._rccl_comm = None
+        if getattr(self, "engine", None) is not None and hasattr(self.engine, "close"):
+            self.engine.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass

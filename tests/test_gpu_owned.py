@@ -187,12 +187,12 @@ def test_owner_keeps_exact_size_policy_in_a_world_of_one(monkeypatch, d, sync):
     model, obs = _model(d, T)
     a = modppl_amd.ParticleSystem(model, n, seed)
     b = ShardedParticleSystem(model, n, seed, exchange="owned")
-    assert not b._ow_fixed
     a.init_step(None, obs[:1])
     b.init_step(None, obs[:1])
     for t in range(1, T):
         if sync:
             assert a.resample() == b.resample()
+            assert b.engine.shard_native_stats(1)[3] == 0          # (mp_pf_shard_resample took the exact-size policy: no equal-split capacity)
             assert b.last_counts == [n] and b.last_exchange_rows == 0
         else:
             a.resample(sync=False)
@@ -244,7 +244,7 @@ from modppl_amd.distributed import ShardedParticleSystem
 from tests import oracle_lib as O
 from tests.owned_ref import OwnedReference
 rank, world = dist.get_rank(), dist.get_world_size()
-N, T, seed = 16384, 7, 5
+N, T, seed = 2048 * 2 * world * 2, 7, 5
 model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
 obs = O.lgssm_observations(T).reshape(T, 1)
 pf = ShardedParticleSystem(model, N, seed, host_staging=True, exchange="owned")   # both ranks on cuda:0, exact-size exchange
@@ -267,7 +267,9 @@ for t in range(1, T):
 lw = gather(pf.log_weights)
 if ref:
     ok &= bool(np.array_equal(lw, ref.log_weights()))
-    print("RESULT ok" if ok else "RESULT mismatch")
+    print("RESULT ok" if ok else "RESULT mismatch", "fallbacks", pf.fallbacks, "native", pf._native, pf._staged.calls if pf._staged else None)
+    if os.environ.get("MP_SHARD_OWNED_CAP") == "8":
+        assert pf.fallbacks > 0
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -281,13 +283,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("which,nproc", [("nccl", 1), ("gloo", 2)])
-def test_owner_keeps_through_process_groups(tmp_path, which, nproc):
-    """RCCL with every collective forced in a world of one (the bench's transport, equal-split all-to-all); two ranks sharing
-    the GPU over gloo with host staging (exact-size all-to-all)."""
+@pytest.mark.parametrize("which,nproc,extra", [("nccl", 1, {}), ("gloo", 2, {}), ("gloo", 2, {"MP_SHARD_OWNED_CAP": "8"}), ("gloo", 2, {"MP_SHARD_FIXED": "0"}),
+                                               ("gloo", 3, {})])
+def test_owner_keeps_through_process_groups(tmp_path, which, nproc, extra):
+    """The whole resample as ONE library call (mp_pf_shard_resample) with the library issuing the collectives: over its own RCCL
+    communicator with every collective forced in a world of one (the bench's transport: ncclAllGather + one group of ncclSend /
+    ncclRecv); and over a callback transport staged through the host, two and three ranks sharing the GPU over gloo — equal
+    splits, a capacity of 8 rows per pair (every resample overflows and falls back to exact sizes), exact sizes by policy."""
     script = tmp_path / "worker.py"
     script.write_text(NCCL_WORKER if which == "nccl" else GLOO_WORKER)
-    env = dict(os.environ, MP_ROOT=ROOT, OMP_NUM_THREADS="2")
+    env = dict(os.environ, MP_ROOT=ROOT, OMP_NUM_THREADS="2", **extra)
     if which == "nccl":
         env["MP_SHARD_ALWAYS_COLLECTIVE"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
