@@ -221,21 +221,24 @@ def sub_benches(steps, warmup, which):
     return res
 
 
-def _finite(obj, path="", bad=None):
+def _finite(obj):
     """JSON has no NaN / inf: a non-finite number anywhere (a degenerate sub-bench's log-ML, a 0 / 0 ratio) becomes null and its
-    path is listed under "non_finite", so that one bad leg cannot cost the driver the whole line."""
-    if bad is None:
-        bad = []
-    if isinstance(obj, dict):
-        return {k: _finite(v, f"{path}.{k}" if path else str(k), bad) for k, v in obj.items()}, bad
-    if isinstance(obj, (list, tuple)):
-        return [_finite(v, f"{path}[{i}]", bad)[0] for i, v in enumerate(obj)], bad
-    if isinstance(obj, (float, np.floating)) and not np.isfinite(obj):
-        bad.append(path)
-        return None, bad
-    if isinstance(obj, np.generic):
-        return obj.item(), bad
-    return obj, bad
+    path is listed under "non_finite", so that one bad leg cannot cost the driver the whole line.  -> (clean object, paths)"""
+    bad = []
+
+    def walk(o, path):
+        if isinstance(o, dict):
+            return {k: walk(v, f"{path}.{k}" if path else str(k)) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [walk(v, f"{path}[{i}]") for i, v in enumerate(o)]
+        if isinstance(o, (float, np.floating)) and not np.isfinite(o):
+            bad.append(path)
+            return None
+        if isinstance(o, np.generic):
+            return o.item()
+        return o
+
+    return walk(obj, ""), bad
 
 
 def _library_identity():
