@@ -912,10 +912,14 @@ static int32_t launch_draws(mp_pf* h, int32_t scheme, uint32_t rc) {
         const u64* incl = tabmode ? (const u64*)h->tab_incl : nullptr;
         const double* ratio = tabmode ? (const double*)h->tab_ratio : nullptr;
         const mp_tab_head* head = tabmode ? (const mp_tab_head*)h->tab_head : nullptr;
+        // (two workgroups per CU when the table is copied to LDS; the L2-probing form has no table to amortise)
+        static const int draw_wgs = [] { const char* e = getenv("MP_DRAW_WGS"); return e ? atoi(e) : 512; }();
+        // (measured: 2^22 particles / 2048 tiles 55 -> 45 us; at 1024 tiles one workgroup per chunk is the faster form, 26 against 29 us)
+        const int draw_grid = (tabmode == 2 || h->nt <= 1024) ? h->nchunks : std::min(h->nchunks, std::max(1, draw_wgs));
 #define MP_LAUNCH_DRAW(TM, SC)                                                                                                              \
-        hipLaunchKernelGGL((k_draw_slots<TM, SC>), dim3(h->nchunks), dim3(DRAW_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,      \
+        hipLaunchKernelGGL((k_draw_slots<TM, SC>), dim3(draw_grid), dim3(DRAW_THREADS), lds, h->stream, h->n, h->n_global, h->slot_offset,       \
                            (uint32_t)h->seed, (uint32_t)(h->seed >> 32), rc, h->S, h->tile_m, h->tile_W, h->tile_W2, h->nt,    \
-                           h->guide, h->dfr_lt, h->dfr_row, h->scal, incl, ratio, head)
+                           h->guide, h->dfr_lt, h->dfr_row, h->scal, incl, ratio, head, h->nchunks)
 #define MP_LAUNCH_DRAW_SCHEME(TM)                                                                                                           \
         do {                                                                                                                                \
             if (scheme == MP_RESAMPLE_MULTINOMIAL) MP_LAUNCH_DRAW(TM, 0);                                                                   \

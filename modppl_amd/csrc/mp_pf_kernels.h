@@ -1538,7 +1538,7 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
                                                            const unsigned short* __restrict__ guide,
                                                            u64* __restrict__ dfr_lt, uint32_t* __restrict__ dfr_row,
                                                            mp_dev_scalars* scal, const u64* __restrict__ incl_pre,
-                                                           const double* __restrict__ ratio_pre, const mp_tab_head* __restrict__ head) {
+                                                           const double* __restrict__ ratio_pre, const mp_tab_head* __restrict__ head, int n_chunks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = DRAW_THREADS / 64;
     const int nt_lds = TABMODE == 2 ? 0 : nt;
@@ -1550,7 +1550,10 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
     const u64* s_incl = TABMODE == 2 ? incl_pre : s_incl_lds;
     const u64* s_W = TABMODE == 2 ? tile_W : s_W_lds;
     const double* s_ratio = TABMODE == 2 ? ratio_pre : s_ratio_lds;
-    const int c = blockIdx.x;
+    // A workgroup takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ... (n_chunks of them in all): its LDS copy of the tile
+    // table serves every one of them — one workgroup per chunk copied 24 B x tiles from L2 for every 1024 draws: 200 MB per
+    // launch at 2^22 particles (2048 tiles, 4096 chunks), most of that kernel's 55 us
+    int c = blockIdx.x;
     const int tid = threadIdx.x;
     MP_STAMP(1, 0, 0); MP_STAMP(1, 1, 1); MP_STAMP(1, 6, 2);
     if constexpr (TABMODE == 0) {
@@ -1562,7 +1565,7 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
     }
     // this thread's two adjacent output slots share one Philox block (it depends on no table: in TABMODE 1 it is computed
     // while the table's loads are in flight)
-    const u64 i0 = (u64)c * DRAW_CHUNK + 2u * (u64)tid;
+    u64 i0 = (u64)c * DRAW_CHUNK + 2u * (u64)tid;
     mp_u64x2 blk;
     blk.a = 0ull; blk.b = 0ull;
     if constexpr (TABMODE == 1) {
@@ -1592,10 +1595,11 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
     const u64 Q = s_incl[nt - 1];
     MP_STAMP(1, 2, 0);
     const double nt_over_Q = (double)nt / (double)Q;  // only a starting guess for the tile walk: no effect on results
+    const uint32_t sys_k32 = SCHEME == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+    for (;;) {
     u64 lt[2];
     uint32_t gslot[2], tile_of[2], j0[2];
     bool live[2];
-    const uint32_t sys_k32 = SCHEME == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         live[q] = i0 + q < n;
@@ -1624,6 +1628,11 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
     } else if (live[0]) {
         dfr_lt[i0] = lt[0];
         dfr_row[i0] = srow[0];
+    }
+    c += (int)gridDim.x;
+    if (c >= n_chunks) break;
+    i0 = (u64)c * DRAW_CHUNK + 2u * (u64)tid;
+    if constexpr (SCHEME == 0) blk = mp_resample_block((slot_offset + i0) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
     }
     MP_STAMP(1, 3, 0); MP_STAMP(1, 4, 0); MP_STAMP(1, 5, 1);
 }
