@@ -433,15 +433,13 @@ struct mp_pf {
     hipEvent_t ev_resolved = nullptr;
     bool sh_lazy = false;           // the states of the last sharded resample still sit in the exchange buffer sh_rows, slot i at row sh_req_slot[i]
     const double* sh_rows = nullptr;
+    bool sh_recv = false;           // (owner-keeps) the draws of the last resample hold MP_DRAW_RECV entries: rows of sh_rows
     u64 sh_rows_cap = 0;
     bool logw_zero = false;         // log-weights are all zero (after a sharded resample) and the buffer has not been cleared
     mp_dev_scalars* scal_undo = nullptr;  // the scalars before a fixed-capacity route folded this resample in
     // "owner keeps" form: per super-chunk of R * 1024 draws a window of entries (k_shard_own_bin), [ow_nsc][R * 1024]
     u64* ow_seg_lt = nullptr;             // tile-local target
     uint32_t* ow_seg_row = nullptr;       // start row of the forward scan
-    unsigned short* ow_seg_r = nullptr;   // draw-order rank inside the super-chunk
-    unsigned short* ow_permc = nullptr;   // draw-order rank -> place in the window
-    unsigned short* ow_seg_cnt = nullptr; // [ow_nsc][8] entries per bin
     uint32_t* ow_sccnt = nullptr;         // own draws per super-chunk, and their exclusive scan
     uint32_t* ow_base = nullptr;
     uint32_t* ow_cnt_r = nullptr;         // [ow_nsc][world] offspring per rank (multinomial)
@@ -617,7 +615,7 @@ static int32_t materialize(mp_pf* h) {
         const int d = h->ops->dim_state;
         hipLaunchKernelGGL(k_resolve_slots<true>, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, d, (const u64*)h->dfr_lt,
                            (const uint32_t*)h->dfr_row, (const mp_cx*)h->cx, (const double*)h->x[h->cur], d == 1 ? h->x[h->cur] : h->x[h->cur ^ 1],
-                           h->parent, h->logw);
+                           h->parent, h->logw, h->sh_recv ? h->sh_rows : (const double*)nullptr, h->slot_offset);
         if (d > 1) h->cur ^= 1;   // wider states were gathered from the pre-resample buffer into the other one
         h->deferred = false;
         h->parents_deferred = false;   // k_resolve_slots wrote parent[] too
@@ -665,7 +663,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.dfr_row = h->deferred ? h->dfr_row : nullptr;
     a.dfr_lt = h->deferred ? h->dfr_lt : nullptr;
     a.cx_old = h->deferred ? h->cx : nullptr;
-    a.inv_rows = h->sh_lazy ? h->sh_rows : nullptr;
+    a.inv_rows = h->sh_lazy ? h->sh_rows : ((h->deferred && h->sh_recv) ? h->sh_rows : nullptr);
     a.inv = h->sh_lazy ? h->sh_req_slot : nullptr;
     a.cx = h->deferred ? h->cx_alt : h->cx; a.guide = h->deferred ? h->guide_alt : h->guide;
     a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
@@ -953,6 +951,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (rc != MP_OK) return rc;
     h->parents_deferred = false;   // this resample's parents replace whatever was still waiting to be read
     h->sh_parents_lazy = false;
+    h->sh_recv = false;
     const int d = h->ops->dim_state;
     bool drawn_only = false;
     if (h->use_deferred) {
@@ -1099,7 +1098,7 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
     if (h->parents_deferred) {
         hipLaunchKernelGGL(k_resolve_slots<false>, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->ops->dim_state,
                            (const u64*)h->dfr_lt, (const uint32_t*)h->dfr_row, (const mp_cx*)h->cx_alt, (const double*)nullptr, (double*)nullptr, h->parent,
-                           (double*)nullptr);
+                           (double*)nullptr, h->sh_recv ? h->sh_rows : (const double*)nullptr, h->slot_offset);
         h->parents_deferred = false;
         int32_t rcp = check_launch("k_resolve_slots");
         if (rcp != MP_OK) return rcp;
@@ -1351,6 +1350,7 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
     // from row sh_req_slot[i] of the exchange buffer; anything else first copies states and parents into slot order.
     h->sh_rows = d_rows_in;
     h->sh_lazy = true;
+    h->sh_recv = false;
     h->sh_parents_lazy = false;
     h->logw_zero = true;   // log_weights.fill(0.) (:114): the next propagate does not re-read them; anything else clears the buffer first
     h->cur ^= 1;
@@ -1366,12 +1366,12 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
 
 // ---- "owner keeps" form: offspring stay with the rank that owns their parent; only the surplus travels ----
 static void owned_free(mp_pf* h) {
-    (void)hipFree(h->ow_seg_lt); (void)hipFree(h->ow_seg_row); (void)hipFree(h->ow_seg_r); (void)hipFree(h->ow_permc); (void)hipFree(h->ow_seg_cnt);
+    (void)hipFree(h->ow_seg_lt); (void)hipFree(h->ow_seg_row);
     (void)hipFree(h->ow_sccnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_cnt_r); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
     (void)hipFree(h->ow_range); (void)hipFree(h->ow_ticket); (void)hipFree(h->ow_kthr);
     h->ow_kthr = nullptr;
     h->ow_ticket = nullptr;
-    h->ow_seg_lt = nullptr; h->ow_seg_row = nullptr; h->ow_seg_r = nullptr; h->ow_permc = nullptr; h->ow_seg_cnt = nullptr;
+    h->ow_seg_lt = nullptr; h->ow_seg_row = nullptr;
     h->ow_sccnt = nullptr; h->ow_base = nullptr; h->ow_cnt_r = nullptr; h->ow_call = nullptr; h->ow_plan = nullptr; h->ow_range = nullptr;
 }
 // super-chunk shape of one resample: the multinomial draws of a rank are spread over all N draws, so a workgroup takes
@@ -1393,11 +1393,21 @@ static int32_t owned_scratch(mp_pf* h, int world) {
     const int nsc1 = (int)((h->n_global + OWN_ROUND - 1) / OWN_ROUND);
     const size_t ent = (size_t)nsc1 * OWN_ROUND;
     h->ow_nsc = nsc1;
-    HIPCK(hipMalloc(&h->ow_seg_lt, sizeof(u64) * ent));
-    HIPCK(hipMalloc(&h->ow_seg_row, sizeof(uint32_t) * ent));
-    HIPCK(hipMalloc(&h->ow_seg_r, sizeof(unsigned short) * ent));
-    HIPCK(hipMalloc(&h->ow_permc, sizeof(unsigned short) * ent));
-    HIPCK(hipMalloc(&h->ow_seg_cnt, sizeof(unsigned short) * 8 * (size_t)h->ow_nsc));
+    HIPCK(hipMalloc(&h->ow_seg_lt, sizeof(u64) * (world == 1 ? 2 : ent)));        // (a world of one writes its draws straight into the slot-order arrays)
+    HIPCK(hipMalloc(&h->ow_seg_row, sizeof(uint32_t) * (world == 1 ? 2 : ent)));
+    // what the next k_propagate (or k_resolve_slots) looks the kept offspring up from, and the second table it writes meanwhile:
+    // the deferred-lookup machinery of the unsharded resample
+    if (!h->dfr_lt) {
+        HIPCK(hipMalloc(&h->dfr_lt, sizeof(u64) * (size_t)h->nchunks * DRAW_CHUNK));
+        HIPCK(hipMalloc(&h->dfr_row, sizeof(uint32_t) * (size_t)h->nchunks * DRAW_CHUNK));
+    }
+    if (!h->cx_alt) {
+        HIPCK(hipMalloc(&h->cx_alt, sizeof(mp_cx) * (size_t)h->nt * TILE));
+        HIPCK(hipMalloc(&h->guide_alt, sizeof(unsigned short) * (size_t)h->nt * GUIDE_N));
+        if (h->local_table) HIPCK(hipMalloc(&h->tiles_alt, sizeof(u64) * 3 * h->nt));
+        int32_t rct = update_k1_tail(h);
+        if (rct != MP_OK) return rct;
+    }
     HIPCK(hipMalloc(&h->ow_sccnt, sizeof(uint32_t) * (size_t)h->ow_nsc));
     HIPCK(hipMalloc(&h->ow_base, sizeof(uint32_t) * (size_t)h->ow_nsc));
     HIPCK(hipMalloc(&h->ow_cnt_r, sizeof(uint32_t) * (size_t)h->ow_nsc * world));
@@ -1407,10 +1417,6 @@ static int32_t owned_scratch(mp_pf* h, int world) {
     HIPCK(hipMalloc(&h->ow_kthr, sizeof(u64) * SH_MAX_WORLD));
     HIPCK(hipMalloc(&h->ow_ticket, sizeof(unsigned int)));
     HIPCK(hipMemsetAsync(h->ow_ticket, 0, sizeof(unsigned int), h->stream));
-    // rows of entries never written are still read (masked) by idle lanes of k_shard_own_resolve: keep them valid row indices
-    HIPCK(hipMemsetAsync(h->ow_seg_row, 0, sizeof(uint32_t) * ent, h->stream));
-    HIPCK(hipMemsetAsync(h->ow_seg_r, 0, sizeof(unsigned short) * ent, h->stream));
-    HIPCK(hipMemsetAsync(h->ow_seg_lt, 0, sizeof(u64) * ent, h->stream));
     HIPCK(hipMemsetAsync(h->ow_call, 0, sizeof(unsigned long long) * SH_MAX_WORLD, h->stream));
     HIPCK(hipMemsetAsync(h->ow_plan, 0, sizeof(mp_owned_plan), h->stream));
     if (world == 1) {   // what k_shard_own_plan would find, every time (it is not launched in a world of one)
@@ -1482,13 +1488,16 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         pa.range = h->ow_range; pa.Wd = (u64)h->ow_R * OWN_ROUND;
         const bool tab_lds = h->nt <= 1024;   // (with the 32 KB of own targets at R = 4 this stays under the 64 KB a launch may ask for)
         const size_t lds = sizeof(u64) * (size_t)h->ow_R * OWN_ROUND + (tab_lds ? (size_t)h->nt * 24 : 0);
-        auto kern = scheme ? (tab_lds ? k_shard_own_bin<1, true> : k_shard_own_bin<2, true>) : (tab_lds ? k_shard_own_bin<1, false> : k_shard_own_bin<2, false>);
+        auto kern = scheme ? (tab_lds ? k_shard_own_draw<1, true> : k_shard_own_draw<2, true>) : (tab_lds ? k_shard_own_draw<1, false> : k_shard_own_draw<2, false>);
+        // a world of one: every draw is this rank's own, super-chunks are 1024 consecutive slots — the window IS slot order
+        u64* win_lt = world == 1 ? h->dfr_lt : h->ow_seg_lt;
+        uint32_t* win_row = world == 1 ? h->dfr_row : h->ow_seg_row;
         // lattice: a rank's own draws are ~n consecutive ones, wherever they start: that many workgroups (a rank that owns more takes turns)
         const int own_wgs = scheme ? (int)std::min<u64>((u64)h->ow_nsc, 2 * ((h->n + OWN_ROUND - 1) / OWN_ROUND) + 2) : h->ow_nsc;
         h->ow_wgs = own_wgs;
         hipLaunchKernelGGL(kern, dim3(own_wgs), dim3(OWN_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
                            h->resample_count, (int)scheme, h->ow_R, t_incl, t_W, t_ratio, h->nt, world, rank, (const unsigned short*)h->guide,
-                           (const mp_own_range*)h->ow_range, h->ow_seg_lt, h->ow_seg_row, h->ow_seg_r, h->ow_permc, h->ow_seg_cnt, pa,
+                           (const mp_own_range*)h->ow_range, win_lt, win_row, pa,
                            (!solo_tab && scheme == MP_RESAMPLE_MULTINOMIAL && world > 1) ? (const u64*)h->ow_kthr : (const u64*)nullptr);
         // A world of one has nothing to plan: every draw is this rank's own, super-chunk sc starts at offspring sc * 1024,
         // nothing is sent or received (base[], the plan and c_all[0] = n were set when the scratch was allocated).
@@ -1518,18 +1527,17 @@ int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t
     if (recv_rows + h->n >= (1ull << 31)) return mp_fail(MP_ERR_INVALID_ARG, "exchange buffer rows must be < 2^31 (row indices carry a flag bit)");
     HIPCK(hipSetDevice(h->device));
     h->ow_last_cap = capacity;
-    {
+    if (world > 1) {   // (a world of one: k_shard_own_draw wrote the slot-order arrays itself; nothing is sent or received)
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        const unsigned groups = (unsigned)((h->ow_wgs + OWB_GC - 1) / OWB_GC);
-        auto kern = h->ow_scheme ? k_shard_own_resolve<true> : k_shard_own_resolve<false>;
-        hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(OWB_THREADS), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank,
-                           h->ow_R, h->ow_nsc, (u64)capacity, (u64)recv_rows, (const u64*)h->ow_seg_lt, (const uint32_t*)h->ow_seg_row,
-                           (const unsigned short*)h->ow_seg_r, (const unsigned short*)h->ow_permc, (const unsigned short*)h->ow_seg_cnt,
-                           (const uint32_t*)h->ow_sccnt, (const uint32_t*)h->ow_base, (const mp_cx*)h->cx, (const double*)h->x[h->cur],
-                           (const mp_owned_plan*)h->ow_plan, (const unsigned long long*)h->ow_call, d_rows, d_send_out, h->sh_req_slot,
+        const unsigned grid = (unsigned)std::max(1, std::min(h->ow_wgs, 2048));
+        auto kern = h->ow_scheme ? k_shard_own_place<true> : k_shard_own_place<false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank, h->ow_R, h->ow_nsc,
+                           (u64)capacity, (const u64*)h->ow_seg_lt, (const uint32_t*)h->ow_seg_row, (const uint32_t*)h->ow_sccnt,
+                           (const uint32_t*)h->ow_base, (const mp_cx*)h->cx, (const double*)h->x[h->cur], (const mp_owned_plan*)h->ow_plan,
+                           (const unsigned long long*)h->ow_call, d_send_out, h->dfr_lt, h->dfr_row,
                            h->ow_scheme ? (const mp_own_range*)h->ow_range : (const mp_own_range*)nullptr);
     }
-    return check_launch("k_shard_own_resolve");
+    return check_launch("k_shard_own_place");
 }
 
 int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_total_weight, uint64_t* counts_out) {
@@ -1566,11 +1574,16 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
         // is committed; the entries stay queued, the caller repeats the expand with exact sizes (capacity 0)
         return mp_fail(MP_ERR_CAPACITY, "owner-keeps exchange: a pair of ranks needs more than `capacity` rows; repeat the expand with exact sizes");
     }
+    // from here on the filter is in the state an unsharded resample that only DREW leaves it in: slot i's draw {target, start row}
+    // in dfr_lt / dfr_row against the table cx, x[cur] the pre-resample states — the next k_propagate (or k_resolve_slots, if the
+    // host reads first) looks the kept offspring up; the slots filled from other ranks read their rows of d_rows (MP_DRAW_RECV)
     h->sh_rows = d_rows;
-    h->sh_lazy = true;     // the next propagate reads slot i's state from row sh_req_slot[i] of d_rows
+    h->sh_recv = h->ow_world > 1;
+    h->sh_lazy = false;
     h->sh_parents_lazy = false;
-    h->logw_zero = true;
-    h->cur ^= 1;
+    h->deferred = true;
+    h->draw_pending = false;
+    h->parents_deferred = false;
     h->rows_fresh = false;
     h->resample_count += 1;
     if (log_total_weight) {

@@ -595,23 +595,35 @@ __device__ __forceinline__ u64 mp_tile_last(uint32_t row, u64 n) {
     const u64 tend = (((u64)row / TILE) + 1) * TILE;
     return (tend < n ? tend : n) - 1;      // last row of the tile
 }
+// A slot of a SHARDED filter whose offspring arrives from another rank has no draw to look up: its entry in the start-row array
+// is MP_DRAW_RECV | the index of its row {state[dim], parent's global slot id} in the exchange buffer (`rows`, rows of `rw`
+// doubles); the "parent" handed on keeps the flag, so that the consumer knows where the state is.
+constexpr uint32_t MP_DRAW_RECV = 0x80000000u;
 // N draws at a time: every load goes out before the first is used.
 template <int N>
-__device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u64 n, const u64* lt, const uint32_t* row, uint32_t* parent, double* x0) {
+__device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u64 n, const u64* lt, const uint32_t* row, uint32_t* parent, double* x0,
+                                                 const double* __restrict__ rows = nullptr, int rw = 0) {
     mp_u64v2 a[N], b2[N];
     u64 last[N];
+    uint32_t r0[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        last[k] = mp_tile_last(row[k], n);
-        a[k] = mp_ld_row(cx + row[k]);
-        b2[k] = mp_ld_row(cx + (u64)row[k] + ((u64)row[k] < last[k] ? 1 : 0));
+        r0[k] = (rows && (row[k] & MP_DRAW_RECV)) ? 0u : row[k];
+        last[k] = mp_tile_last(r0[k], n);
+        a[k] = mp_ld_row(cx + r0[k]);
+        b2[k] = mp_ld_row(cx + (u64)r0[k] + ((u64)r0[k] < last[k] ? 1 : 0));
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) mp_pin_rows(a[k], b2[k]);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const bool step1 = a[k].x < lt[k] && (u64)row[k] < last[k];
-        u64 p = (u64)row[k] + (step1 ? 1 : 0);
+        if (rows && (row[k] & MP_DRAW_RECV)) {   // (sharded filters only)
+            x0[k] = rows[(u64)(row[k] & ~MP_DRAW_RECV) * (u64)rw];
+            parent[k] = row[k];
+            continue;
+        }
+        const bool step1 = a[k].x < lt[k] && (u64)r0[k] < last[k];
+        u64 p = (u64)r0[k] + (step1 ? 1 : 0);
         mp_u64v2 cur = step1 ? b2[k] : a[k];
         while (cur.x < lt[k] && p < last[k]) {   // rare: more than one row past the guide's start
             ++p;
@@ -621,8 +633,9 @@ __device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u
         x0[k] = __builtin_bit_cast(double, (u64)cur.y);
     }
 }
-__device__ __forceinline__ void mp_resolve_draw(const mp_cx* __restrict__ cx, u64 n, u64 lt, uint32_t row, uint32_t* parent, double* x0) {
-    mp_resolve_draws<1>(cx, n, &lt, &row, parent, x0);
+__device__ __forceinline__ void mp_resolve_draw(const mp_cx* __restrict__ cx, u64 n, u64 lt, uint32_t row, uint32_t* parent, double* x0,
+                                                const double* __restrict__ rows = nullptr, int rw = 0) {
+    mp_resolve_draws<1>(cx, n, &lt, &row, parent, x0, rows, rw);
 }
 // What k_propagate needs only in its LAST phase (level 0 / level 1 of the normalisation), constant per handle: kept in
 // device memory and read there — as kernel arguments these 11 pointers sat in SGPRs through the whole VALU-bound part of the
@@ -683,8 +696,9 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
         if constexpr (D == 1) {
             prev[0] = *x0p;                    // the row carries the first state component
         } else {
-            // wider states: the parent's (particle-major) row of the pre-resample buffer
-            const double* src = x_in + (u64)pmv * D;
+            // wider states: the parent's (particle-major) row of the pre-resample buffer — or, for a slot of a sharded filter whose
+            // offspring came from another rank, its row of the exchange buffer
+            const double* src = (inv_rows && (pmv & MP_DRAW_RECV)) ? inv_rows + (u64)(pmv & ~MP_DRAW_RECV) * (u64)(D + 1) : x_in + (u64)pmv * D;
 #pragma unroll
             for (int d = 0; d < D; ++d) prev[d] = src[d];
         }
@@ -882,7 +896,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     //   otherwise: after the deviates, one draw at a time (four rows in flight on top of a wider model's registers spill)
     constexpr bool SPLIT2 = !QUEUE && D == 1 && LANE_ITEMS == 2;
     if constexpr (SPLIT2) {
-        if (cx_old) mp_resolve_draw(cx_old, n, plt[0], pm[0], &pm[0], &px0[0]);   // pm[] = the parent from here on
+        if (cx_old) mp_resolve_draw(cx_old, n, plt[0], pm[0], &pm[0], &px0[0], inv ? nullptr : inv_rows, D + 1);   // pm[] = the parent from here on
     }
     MP_STAMP(0, 20, 0);
     // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
@@ -964,7 +978,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 u64 ltr[ITEMS];
 #pragma unroll
                 for (int pp = 0; pp < ITEMS; ++pp) ltr[pp] = LT_LATE ? (i0 + pp < n ? dfr_lt[i0 + pp] : 0ull) : plt[rd * ITEMS + pp];
-                mp_resolve_draws<ITEMS>(cx_old, n, ltr, &pm[rd * ITEMS], &pm[rd * ITEMS], &px0[rd * ITEMS]);
+                mp_resolve_draws<ITEMS>(cx_old, n, ltr, &pm[rd * ITEMS], &pm[rd * ITEMS], &px0[rd * ITEMS], inv ? nullptr : inv_rows, D + 1);
             }
 #pragma unroll
             for (int pp = 0; pp < ITEMS; ++pp) MP_RUN_PARTICLE(rd * ITEMS + pp, &zr[pp * NS]);
@@ -1048,13 +1062,14 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 // (an empty statement that makes the target "depend" on the last deviate: the compiler would otherwise run this
                 // lookup ahead of the deviates as well)
                 asm volatile("" : "+v"(plt[1]) : "v"(z[NS + NS - 1]));
-                mp_resolve_draw(cx_old, n, plt[1], pm[1], &pm[1], &px0[1]);
+                mp_resolve_draw(cx_old, n, plt[1], pm[1], &pm[1], &px0[1], inv ? nullptr : inv_rows, D + 1);
                 MP_STAMP(0, 24, 0);
             } else if constexpr (D == 1) {
-                mp_resolve_draws<LANE_ITEMS>(cx_old, n, plt, pm, pm, px0);
+                mp_resolve_draws<LANE_ITEMS>(cx_old, n, plt, pm, pm, px0, inv ? nullptr : inv_rows, D + 1);
             } else {
 #pragma unroll
-                for (int p = 0; p < LANE_ITEMS; ++p) mp_resolve_draw(cx_old, n, base + p < n ? dfr_lt[base + p] : 0ull, pm[p], &pm[p], &px0[p]);
+                for (int p = 0; p < LANE_ITEMS; ++p)
+                    mp_resolve_draw(cx_old, n, base + p < n ? dfr_lt[base + p] : 0ull, pm[p], &pm[p], &px0[p], inv ? nullptr : inv_rows, D + 1);
             }
         }
 #pragma unroll
@@ -1152,8 +1167,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
         } else if (dfr_row && live) {   // a draw of the last resample, looked up here (mp_resolve_draw)
             uint32_t par;
             double x0;
-            mp_resolve_draw(cx_old, n, dfr_lt[p], dfr_row[p], &par, &x0);
-            myrow = x_in + (u64)par * D;
+            mp_resolve_draw(cx_old, n, dfr_lt[p], dfr_row[p], &par, &x0, rows, D + 1);
+            myrow = (rows && (par & MP_DRAW_RECV)) ? rows + (u64)(par & ~MP_DRAW_RECV) * (u64)(D + 1) : x_in + (u64)par * D;
         }
         const u64 myaddr = (u64)(uintptr_t)myrow;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1640,20 +1655,25 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
 // The lookups of a resample that only drew (k_draw_slots), for whoever needs slot-order results before — or instead of — the
 // next k_propagate: traces[i] = traces[parents[i]].clone(); log_weights.fill(0.) (particle_filter.rs:109-114).
 // STATES = false: parents only (a step has already consumed the draws and moved the states on).
+// (sharded filters: `parent` holds GLOBAL slot ids — slot_offset + the local row, or what the exchange row says for a slot
+// whose offspring came from another rank: `rows`, MP_DRAW_RECV)
 template <bool STATES>
 __global__ void k_resolve_slots(u64 n, int D, const u64* __restrict__ dfr_lt, const uint32_t* __restrict__ dfr_row, const mp_cx* __restrict__ cx,
-                                const double* __restrict__ x_old, double* __restrict__ x_new, uint32_t* __restrict__ parent, double* __restrict__ logw) {
+                                const double* __restrict__ x_old, double* __restrict__ x_new, uint32_t* __restrict__ parent, double* __restrict__ logw,
+                                const double* __restrict__ rows, u64 slot_offset) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t p;
     double x0;
-    mp_resolve_draw(cx, n, dfr_lt[i], dfr_row[i], &p, &x0);
-    parent[i] = p;
+    mp_resolve_draw(cx, n, dfr_lt[i], dfr_row[i], &p, &x0, rows, D + 1);
+    const bool recv = rows && (p & MP_DRAW_RECV);
+    const double* rrow = recv ? rows + (u64)(p & ~MP_DRAW_RECV) * (u64)(D + 1) : nullptr;
+    parent[i] = recv ? (uint32_t)rrow[D] : (uint32_t)(slot_offset + p);
     if constexpr (STATES) {
         if (D == 1) {
             x_new[i] = x0;
         } else {
-            for (int d = 0; d < D; ++d) x_new[i * D + d] = x_old[(u64)p * D + d];
+            for (int d = 0; d < D; ++d) x_new[i * D + d] = recv ? rrow[d] : x_old[(u64)p * D + d];
         }
         logw[i] = 0.;
     }

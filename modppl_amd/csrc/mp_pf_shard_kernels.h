@@ -664,11 +664,11 @@ constexpr int SHP_THREADS = 1024;
 __global__ __launch_bounds__(SHP_THREADS) void k_shard_own_plan(mp_own_plan_args a) { mp_own_plan<SHP_THREADS>(a); }
 
 template <int TABMODE, bool LATTICE>   // TABMODE 1: this rank's part of the tile table copied to LDS (rebased); 2: probed where it lies (more than 1024 tiles)
-__global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_shard_own_bin(
+__global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_shard_own_draw(
     u64 n, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme, int R, const u64* __restrict__ incl_all, const u64* __restrict__ tW_all,
     const double* __restrict__ ratio_all, int nt_local, int world, int rank, const unsigned short* __restrict__ guide,
-    const mp_own_range* __restrict__ range, u64* __restrict__ seg_lt, uint32_t* __restrict__ seg_row, unsigned short* __restrict__ seg_r,
-    unsigned short* __restrict__ permc, unsigned short* __restrict__ seg_cnt, mp_own_plan_args pa, const u64* __restrict__ kthr) {
+    const mp_own_range* __restrict__ range, u64* __restrict__ win_lt, uint32_t* __restrict__ win_row, mp_own_plan_args pa,
+    const u64* __restrict__ kthr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nt_lds = TABMODE == 1 ? nt_local : 0;
     u64* s_tgt = reinterpret_cast<u64*>(smem);                          // [R * 1024] own targets of the super-chunk, draw order
@@ -678,8 +678,6 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     __shared__ u64 s_bound[SH_MAX_WORLD];                               // inclusive prefix of T_b at the end of every rank's tiles
     __shared__ uint32_t s_above[OWN_NW][SH_MAX_WORLD];                  // per wave: draws whose target lies above s_bound[r]
     __shared__ uint32_t s_wown[OWN_NW];
-    __shared__ uint32_t s_wcnt[OWN_NW * 8];
-    __shared__ uint32_t s_bincnt[8], s_binoff[8], s_binrun[8];
     __shared__ uint32_t s_cntr[SH_MAX_WORLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 Wd = (u64)R * OWN_ROUND;                                  // draws (and window entries) per super-chunk
@@ -713,8 +711,7 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
     for (int sc = sc_first + (int)blockIdx.x; sc <= sc_last; sc += (int)gridDim.x) {   // workgroup-uniform; one trip unless LATTICE
     const u64 g_base = (u64)sc * Wd;
-    if (tid < 8) { s_bincnt[tid] = 0u; s_binrun[tid] = 0u; }
-    __syncthreads();
+    __syncthreads();   // s_bound and the LDS table are there (first trip); the previous super-chunk's LDS state is free (lattice)
     uint32_t above_acc = 0u;   // lane r: draws of this wave above boundary r (r < world - 1)
     uint32_t run = 0u;         // own draws of the rounds so far (uniform)
 #pragma unroll 1
@@ -782,242 +779,115 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     }
     if (tid == 0) pa.sccnt[sc] = own;   // this super-chunk's counts, for k_shard_own_plan
     if (scheme == 0 && tid < world) pa.cnt_r[(u64)sc * world + tid] = world > 1 ? s_cntr[tid] : own;
-    // ---- the compacted own draws: bins first (their sizes fix where each bin's entries start in the window) ----
+    // ---- the compacted own draws, in draw order: target -> tile -> guide cell -> {tile-local target, start row}, written at the
+    // draw's rank inside the super-chunk (k_shard_own_place, or in a world of one the next k_propagate itself, takes it from
+    // there: the row lookups run under that kernel's arithmetic, as in the single filter) ----
     const u64 span = hi - lo;
-    const double eight_over_span = 8.0 / (double)span;           // own > 0 implies span > 0
     auto tgt_of = [&](u64 v) { return LATTICE ? v : mp_target(v, Q); };   // compacted value -> target
-    auto bin_of = [&](u64 t) {                                   // eighth of this rank's share of the CDF (monotone in t)
-        uint32_t b = (uint32_t)((double)(t - lo - 1ull) * eight_over_span);
-        return b > 7u ? 7u : b;
-    };
-    {
-        uint32_t acc = 0u;   // lane bb < 8: entries of bin bb seen by this wave
-        for (uint32_t jb = 0; jb < own; jb += OWN_THREADS) {
-            const uint32_t j = jb + (uint32_t)tid;
-            const bool act = j < own;
-            const uint32_t bn = act ? bin_of(tgt_of(s_tgt[j])) : 0u;
-            const u64 tot = wave_sum_u64(act ? 1ull << (8u * bn) : 0ull);   // eight 8-bit counters in one word
-            acc += lane < 8 ? (uint32_t)(tot >> (8u * (uint32_t)lane)) & 0xFFu : 0u;
-        }
-        if (lane < 8 && acc) atomicAdd(&s_bincnt[lane], acc);
-    }
-    __syncthreads();
-    if (tid < 8) {
-        uint32_t off = 0u;
-        for (int b = 0; b < tid; ++b) off += s_bincnt[b];
-        s_binoff[tid] = off;
-        seg_cnt[(u64)sc * 8 + tid] = (unsigned short)s_bincnt[tid];   // <= R * 1024 <= 4096
-    }
-    __syncthreads();
     const u64* t_incl = TABMODE == 1 ? s_incl_lds : my_incl;
     const u64* t_W = TABMODE == 1 ? s_W_lds : my_W;
     const double* t_ratio = TABMODE == 1 ? s_ratio_lds : my_ratio;
-    const double nt_over_span = (double)nt_local / (double)span;
+    const double nt_over_span = (double)nt_local / (double)span;   // own > 0 implies span > 0
     const u64 wbase = (u64)sc * Wd;
     for (uint32_t jb = 0; jb < own; jb += OWN_ROUND) {   // uniform trip count
-        uint32_t j[2], bn[2], gslot[2], tile_of[2], j0[2], rank_[2];
+        uint32_t j[2], gslot[2], tile_of[2], j0[2];
         u64 lt[2];
         bool act[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            j[q] = jb + (uint32_t)q * OWN_THREADS + (uint32_t)tid;
+            j[q] = jb + 2u * (uint32_t)tid + (uint32_t)q;   // a thread's two entries are adjacent: one 16-byte and one 8-byte store
             act[q] = j[q] < own;
             const u64 t = act[q] ? tgt_of(s_tgt[j[q]]) : lo + 1ull;
-            bn[q] = act[q] ? bin_of(t) : 8u;
             const u64 trel = t - lo;
             mp_locate_own(t_incl, t_W, t_ratio, (uint32_t)nt_local, TABMODE == 1 ? trel : t, trel, TABMODE == 1 ? 0ull : lo, nt_over_span,
                           &tile_of[q], &lt[q], &gslot[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];   // in flight while the places are worked out
-        {   // ranks inside the batch with one packed DPP scan (k_bin_draws): field b (8 bits) = this lane's entries of bin b
-            const u64 p0 = act[0] ? 1ull << (8u * bn[0]) : 0ull, p1 = act[1] ? 1ull << (8u * bn[1]) : 0ull;
-            const u64 pk = p0 + p1;
-            const u64 inc = wave_incl_scan_u64(pk, lane);
-            const u64 exc = inc - pk;
-            rank_[0] = act[0] ? (uint32_t)(exc >> (8u * bn[0])) & 0xFFu : 0u;
-            rank_[1] = act[1] ? ((uint32_t)(exc >> (8u * bn[1])) & 0xFFu) + ((act[0] && bn[0] == bn[1]) ? 1u : 0u) : 0u;
-            const u64 tot = mp_readlane_u64(inc, 63);
-            if (lane < 8) s_wcnt[wave * 8 + lane] = (uint32_t)(tot >> (8u * (uint32_t)lane)) & 0xFFu;
-        }
-        __syncthreads();
-        if (tid < 8) {   // exclusive offsets of the waves per bin, on top of the bin's start and of the batches before
-            uint32_t at = s_binoff[tid] + s_binrun[tid];
-#pragma unroll
-            for (int w = 0; w < OWN_NW; ++w) {
-                const uint32_t cw = s_wcnt[w * 8 + tid];
-                s_wcnt[w * 8 + tid] = at;
-                at += cw;
-            }
-            s_binrun[tid] = at - s_binoff[tid];
-        }
-        __syncthreads();
+        for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];
+        uint32_t srow[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            if (act[q]) {
-                const uint32_t s = s_wcnt[wave * 8 + bn[q]] + rank_[q];
-                const u64 tbase = (u64)tile_of[q] * TILE;
-                const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
-                const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
-                seg_lt[wbase + s] = lt[q];
-                seg_row[wbase + s] = (uint32_t)tbase + jj;          // row where the forward scan starts
-                seg_r[wbase + s] = (unsigned short)j[q];            // draw-order rank inside the super-chunk
-                permc[wbase + j[q]] = (unsigned short)s;
-            }
+            const u64 tbase = (u64)tile_of[q] * TILE;
+            const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+            const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
+            srow[q] = (uint32_t)tbase + jj;          // row where the forward scan starts
         }
-        __syncthreads();
+        if (act[1]) {
+            mp_u64v2 v2; v2.x = lt[0]; v2.y = lt[1];
+            *reinterpret_cast<mp_u64v2*>(win_lt + wbase + j[0]) = v2;      // wbase and j[0] are even: aligned
+            *reinterpret_cast<uint2*>(win_row + wbase + j[0]) = make_uint2(srow[0], srow[1]);
+        } else if (act[0]) {
+            win_lt[wbase + j[0]] = lt[0];
+            win_row[wbase + j[0]] = srow[0];
+        }
     }
     if constexpr (!LATTICE) break;
     __syncthreads();   // the next super-chunk of this workgroup reuses the LDS state
     }
 }
 
-constexpr int OWB_THREADS = 256;
-constexpr int OWB_GC = 2;   // super-chunks per workgroup: (bin, 2 super-chunks) holds ~256 entries in a world of <= 4 ranks
+
+// After the plan (worlds of more than one rank): the own draws of every super-chunk go where their offspring's place says —
+// offspring p = base[super-chunk] + rank in draw order:
+//   p < n   kept: {target, start row} into the draws' slot-order arrays at p — the next k_propagate (or k_resolve_slots) looks
+//           the parent up, exactly as after an unsharded resample;
+//   p >= n  surplus: looked up HERE (O(sqrt N) of them) and its row {state, parent's global id} written into the send buffer
+//           where the plan says;
+// and the slots this rank could not fill itself, [c_me, n), get MP_DRAW_RECV | the index of the row that will arrive for them.
 template <bool LATTICE>
-__global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_shard_own_resolve(
-    u64 n, u64 slot_offset, int D, int world, int rank, int R, int nsc, u64 cap, u64 recv_rows, const u64* __restrict__ seg_lt,
-    const uint32_t* __restrict__ seg_row, const unsigned short* __restrict__ seg_r, const unsigned short* __restrict__ permc,
-    const unsigned short* __restrict__ seg_cnt, const uint32_t* __restrict__ sccnt, const uint32_t* __restrict__ base, const mp_cx* __restrict__ cx,
-    const double* __restrict__ x, const mp_owned_plan* __restrict__ plan, const unsigned long long* __restrict__ c_all, double* __restrict__ rows,
-    double* __restrict__ send, uint32_t* __restrict__ inv, const mp_own_range* __restrict__ range) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int bin = blockIdx.x & 7;
+__global__ __launch_bounds__(256) void k_shard_own_place(u64 n, u64 slot_offset, int D, int world, int rank, int R, int nsc, u64 cap,
+                                                         const u64* __restrict__ win_lt, const uint32_t* __restrict__ win_row,
+                                                         const uint32_t* __restrict__ sccnt, const uint32_t* __restrict__ base, const mp_cx* __restrict__ cx,
+                                                         const double* __restrict__ x, const mp_owned_plan* __restrict__ plan,
+                                                         const unsigned long long* __restrict__ c_all, double* __restrict__ send,
+                                                         u64* __restrict__ dfr_lt, uint32_t* __restrict__ dfr_row, const mp_own_range* __restrict__ range) {
+    const int tid = threadIdx.x;
     const u64 Wd = (u64)R * OWN_ROUND;
     int sc_first = 0, sc_last = nsc - 1;
     if constexpr (LATTICE) mp_own_span(range, Wd, &sc_first, &sc_last);   // only the own range's super-chunks hold entries
     const u64 PS_me = plan->PS[rank];
-    const int G = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : 16));   // lanes of a row group when states are wider than one double
-    for (int group = (int)(blockIdx.x >> 3); sc_first + group * OWB_GC <= sc_last; group += (int)(gridDim.x >> 3)) {   // uniform
-    // headers of this workgroup's super-chunks (uniform loads)
-    uint32_t cntb[OWB_GC], binoff[OWB_GC], base_k[OWB_GC], tot_k[OWB_GC];
-    int sck[OWB_GC];
-#pragma unroll
-    for (int k = 0; k < OWB_GC; ++k) {
-        const int s_ = sc_first + group * OWB_GC + k;
-        const bool ok = s_ <= sc_last;
-        sck[k] = ok ? s_ : 0;
-        const uint4 c4 = *reinterpret_cast<const uint4*>(seg_cnt + (u64)sck[k] * 8);
-        const uint32_t c[8] = {c4.x & 0xFFFFu, c4.x >> 16, c4.y & 0xFFFFu, c4.y >> 16, c4.z & 0xFFFFu, c4.z >> 16, c4.w & 0xFFFFu, c4.w >> 16};
-        uint32_t off = 0u, mine = 0u;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            off += (b < bin) ? c[b] : 0u;
-            mine = (b == bin) ? c[b] : mine;
-        }
-        cntb[k] = ok ? mine : 0u;
-        binoff[k] = off;
-        base_k[k] = base[sck[k]];
-        tot_k[k] = ok ? sccnt[sck[k]] : 0u;
-    }
-    const uint32_t total = cntb[0] + cntb[1];
-    uint32_t pc_first = 0u;   // first permc entry of this lane's share of inv[] (below): its load goes out with the entries'
-    if (D == 1) {
-        const int k = tid >> 7;
-        const uint32_t tot = k ? tot_k[1] : tot_k[0];
-        const uint32_t r = (uint32_t)(((u64)tot * (u64)bin) >> 3) + (uint32_t)(tid & 127);
-        if (r < (uint32_t)(((u64)tot * (u64)(bin + 1)) >> 3)) pc_first = permc[(u64)(k ? sck[1] : sck[0]) * Wd + r];
-    }
-    for (uint32_t idx0 = 0; idx0 < total; idx0 += OWB_THREADS) {   // uniform trip count
-        const uint32_t idx = idx0 + (uint32_t)tid;
-        const bool act = idx < total;
-        const int k = (act && idx >= cntb[0]) ? 1 : 0;
-        const uint32_t e = act ? idx - (k ? cntb[0] : 0u) : 0u;
-        const uint32_t s = (k ? binoff[1] : binoff[0]) + e;
-        const u64 wpos = (u64)(k ? sck[1] : sck[0]) * Wd + s;
-        // hop 1: the entry (three independent loads); hop 2: the start row and its successor, whole 16-byte rows
-        int a_ = act ? 1 : 0;
-        u64 lt = seg_lt[wpos];
-        uint32_t row0 = seg_row[wpos];
-        const uint32_t r = seg_r[wpos];
-        mp_pin3(a_, lt, row0);
-        if (!a_) row0 = 0u;
-        const u64 tend = (((u64)row0 / TILE) + 1) * TILE;
-        const u64 last = (tend < n ? tend : n) - 1;
-        mp_u64v2 r0 = mp_ld_row(cx + row0);
-        mp_u64v2 r1 = mp_ld_row(cx + (u64)row0 + ((u64)row0 < last ? 1 : 0));
-        mp_pin_rows(r0, r1);
-        u64 i = row0;
-        double* dst = nullptr;
-        double x0 = 0.;
-        if (act) {
-            const bool step1 = r0.x < lt && i < last;
-            i += step1 ? 1 : 0;
-            mp_u64v2 cur = step1 ? r1 : r0;
-            while (cur.x < lt && i < last) {   // rare: more than one row past the guide's start
-                ++i;
-                cur = mp_ld_row(cx + i);
-            }
-            x0 = __builtin_bit_cast(double, (u64)cur.y);
-            const u64 bk = k ? base_k[1] : base_k[0];
-            const u64 p = bk + r;
+    for (int sc = sc_first + (int)blockIdx.x; sc <= sc_last; sc += (int)gridDim.x) {   // workgroup-uniform
+        const uint32_t cnt = sccnt[sc];
+        const u64 bk = base[sc];
+        const u64 wbase = (u64)sc * Wd;
+        for (uint32_t j = (uint32_t)tid; j < cnt; j += 256u) {
+            const u64 p = bk + j;
+            const u64 lt = win_lt[wbase + j];
+            const uint32_t row0 = win_row[wbase + j];
             if (p < n) {
-                if (D > 1) {
-                    // kept, wide state: nothing is copied — the offspring lives on its parent's rank, so the next propagate
-                    // gathers the parent's state from the pre-resample buffer, as the unsharded filter does
-                    inv[p] = MP_INV_LOCAL | (uint32_t)i;
-                } else {
-                    // kept: at the entry's own place (coalesced); the one super-chunk that straddles slot n keeps draw order,
-                    // so that the kept rows stay within n rows
-                    const bool straddle = bk + (k ? tot_k[1] : tot_k[0]) > n;
-                    dst = rows + (recv_rows + (straddle ? p : bk + s)) * (u64)(D + 1);
-                }
+                dfr_lt[p] = lt;
+                dfr_row[p] = row0;
+                continue;
+            }
+            uint32_t par;
+            double x0;
+            mp_resolve_draw(cx, n, lt, row0, &par, &x0);
+            const u64 u = PS_me + (p - n);
+            int s2 = 0;
+            while (s2 + 1 < world && !(plan->D[s2] && u < plan->PD[s2] + plan->D[s2])) ++s2;
+            double* dst = nullptr;
+            if (cap) {
+                const u64 first = PS_me > plan->PD[s2] ? PS_me : plan->PD[s2];
+                const u64 jj = u - first;
+                // jj >= cap: k_shard_own_plan has flagged it, nothing of this attempt is committed
+                if (jj < cap) dst = send + ((u64)s2 * cap + jj) * (u64)(D + 1);
             } else {
-                const u64 u = PS_me + (p - n);
-                int s2 = 0;
-                while (s2 + 1 < world && !(plan->D[s2] && u < plan->PD[s2] + plan->D[s2])) ++s2;
-                if (cap) {
-                    const u64 first = PS_me > plan->PD[s2] ? PS_me : plan->PD[s2];
-                    const u64 jj = u - first;
-                    // jj >= cap: k_shard_own_plan has flagged it, nothing of this attempt is committed
-                    if (jj < cap) dst = send + ((u64)s2 * cap + jj) * (u64)(D + 1);
+                dst = send + (u - PS_me) * (u64)(D + 1);
+            }
+            if (dst) {
+                if (D == 1) {
+                    dst[0] = x0;
                 } else {
-                    dst = send + (u - PS_me) * (u64)(D + 1);
+                    for (int d = 0; d < D; ++d) dst[d] = x[(u64)par * D + d];
                 }
+                dst[D] = (double)(slot_offset + par);
             }
         }
-        if (D == 1) {
-            if (dst) *reinterpret_cast<double2*>(dst) = make_double2(x0, (double)(slot_offset + i));
-        } else {
-            if (dst) dst[D] = (double)(slot_offset + i);
-            const u64 dbits = (u64)(uintptr_t)dst;
-            const uint32_t d_lo = (uint32_t)dbits, d_hi = (uint32_t)(dbits >> 32);
-            const uint32_t i_lo = (uint32_t)i, i_hi = (uint32_t)(i >> 32);
-            const int comp = lane % G;
-            for (int base_l = 0; base_l < 64; base_l += 64 / G) {
-                const int src = base_l + lane / G;
-                const u64 sd = ((u64)(uint32_t)__shfl((int)d_hi, src, 64) << 32) | (u64)(uint32_t)__shfl((int)d_lo, src, 64);
-                const u64 si = ((u64)(uint32_t)__shfl((int)i_hi, src, 64) << 32) | (u64)(uint32_t)__shfl((int)i_lo, src, 64);
-                if (sd) {
-                    double* out = reinterpret_cast<double*>((uintptr_t)sd);
-                    for (int d = comp; d < D; d += G) out[d] = x[si * D + d];
-                }
-            }
-        }
-    }
-    // where slot p finds its row (draw order, coalesced): the 8 workgroups of a group take an eighth of each super-chunk's range
-    if (D == 1) {
-        const int k = tid >> 7;                                  // 128 lanes per super-chunk
-        const uint32_t tot = k ? tot_k[1] : tot_k[0];
-        const uint32_t r_lo = (uint32_t)(((u64)tot * (u64)bin) >> 3), r_hi = (uint32_t)(((u64)tot * (u64)(bin + 1)) >> 3);
-        const u64 bk = k ? base_k[1] : base_k[0];
-        const bool straddle = bk + tot > n;
-        const u64 pbase = (u64)(k ? sck[1] : sck[0]) * Wd;
-        uint32_t r = r_lo + (uint32_t)(tid & 127);
-        uint32_t pc = pc_first;
-        while (r < r_hi) {
-            const u64 p = bk + r;
-            if (p < n) inv[p] = (uint32_t)(recv_rows + (straddle ? p : bk + pc));
-            r += 128u;
-            if (r < r_hi) pc = permc[pbase + r];
-        }
-    }
-    if constexpr (!LATTICE) break;   // multinomial: one group per workgroup, straight-line code
     }
     // slots this rank could not fill itself: where in the receive buffer their rows will arrive
     const u64 c_me = c_all[rank];
     const u64 PD_me = plan->PD[rank], D_me = plan->D[rank];
-    for (u64 k = (u64)blockIdx.x * OWB_THREADS + tid; k < D_me; k += (u64)gridDim.x * OWB_THREADS) {
+    for (u64 k = (u64)blockIdx.x * 256u + tid; k < D_me; k += (u64)gridDim.x * 256u) {
         u64 idx = k;
         if (cap) {
             const u64 u = PD_me + k;
@@ -1027,7 +897,8 @@ __global__ __launch_bounds__(OWB_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
             const u64 jj = u - first;
             idx = jj >= cap ? 0ull : (u64)r * cap + jj;
         }
-        inv[c_me + k] = (uint32_t)idx;
+        dfr_lt[c_me + k] = 0ull;
+        dfr_row[c_me + k] = MP_DRAW_RECV | (uint32_t)idx;
     }
 }
 // After the resolve: "somebody overflowed" (flags are only ever OR-ed atomically) and the scalars of this normalisation,
