@@ -55,7 +55,8 @@ def main():
             eng.synchronize()
             r = eng.get_timing(capi.MP_K_BIN_DRAWS)
             g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
-            print(f"world {world}: owner-keeps {name}: count (table + own draws + plan) {r[0] / r[1] * 1e3:.1f} us, resolve {g[0] / g[1] * 1e3:.1f} us",
+            place = g[0] / g[1] * 1e3 if g[1] else 0.0   # (a world of one launches nothing there: the next k_propagate looks its draws up)
+            print(f"world {world}: owner-keeps {name}: count (table + own draws + plan) {r[0] / r[1] * 1e3:.1f} us, place + surplus lookups {place:.1f} us",
                   flush=True)
         eng.close()
 
