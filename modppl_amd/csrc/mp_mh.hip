@@ -505,7 +505,11 @@ int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args,
         if (n_iters < 0) return mp_set_error(MP_ERR_INVALID_ARG, "n_iters < 0");
         const std::vector<double> cov(proposal_args, proposal_args + 4);
         std::vector<double> L, inv;
-        if (!mp_host_cholesky(cov, 2, L)) return mp_set_error(MP_ERR_UNSUPPORTED, "noise covariance is not positive definite (the reference's eigen fallback, mvnormal.rs:30-33, is not built)");
+        // A covariance without a Cholesky factor takes mvnormal.random's eigen fallback in the reference (mvnormal.rs:30-33; built for
+        // filter sites, mp_linalg.h) — but mh also ASSESSES the proposal (mh.rs:27-34 -> mvnormal.logpdf, :17-18): a singular
+        // covariance panics there in try_inverse().unwrap(), an indefinite one gives NaN through sqrt of a negative eigenvalue.
+        // No such proposal has a defined acceptance ratio, so the status replaces that panic.
+        if (!mp_host_cholesky(cov, 2, L)) return mp_set_error(MP_ERR_INVALID_ARG, "noise covariance is not positive definite: the reference's mh panics on it (mvnormal.logpdf: try_inverse / sqrt of a negative eigenvalue, mvnormal.rs:17-18,30-33)");
         if (!mp_host_inverse(cov, 2, inv)) return mp_set_error(MP_ERR_INVALID_ARG, "noise covariance is not invertible");
         pointed_noise N;
         N.l00 = L[0]; N.l10 = L[2]; N.l11 = L[3];

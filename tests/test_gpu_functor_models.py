@@ -60,3 +60,44 @@ def test_registered_model_full_size_sanity():
     assert np.isfinite(pf.log_marginal_likelihood_estimate())
     ess = pf.effective_sample_size(fresh=True)
     assert 0.05 * n < ess <= n
+
+
+def test_stochastic_volatility_against_a_grid_filter():
+    """An EXTERNAL check of the registered example: the checker interprets the product's own functor, so a wrong line inside
+    mp_stochvol::operator() (the AR(1) mean, exp(h / 2) as the observation's standard deviation) would pass every test above.
+    Here the model is written down independently — numpy, straight from its definition — as a deterministic grid filter
+    (the latent h on 3001 points, trapezoid weights): its log marginal likelihood must agree with the particle estimate at
+    2^20 particles within Monte Carlo error."""
+    import modppl_amd
+
+    mu, phi, sigma, sig0 = SV
+    T = 8
+    obs = sv_observations(T)
+    # the grid filter
+    sd_stat = max(sig0, sigma / np.sqrt(max(1e-12, 1.0 - phi * phi)))
+    hs = np.linspace(mu - 9.0 * sd_stat, mu + 9.0 * sd_stat, 3001)
+    dh = hs[1] - hs[0]
+    wq = np.full(hs.size, dh); wq[0] = wq[-1] = dh / 2
+
+    def npdf(x, m, s):
+        return np.exp(-0.5 * ((x - m) / s) ** 2) / (s * np.sqrt(2.0 * np.pi))
+
+    trans = npdf(hs[None, :], mu + phi * (hs[:, None] - mu), sigma)     # p(h' | h), rows = h
+    pred = npdf(hs, mu, sig0)
+    log_ml = 0.0
+    for t in range(T):
+        if t > 0:
+            pred = (post * wq) @ trans
+        like = npdf(obs[t, 0], 0.0, np.exp(hs / 2.0))
+        z = float(np.sum(pred * like * wq))
+        log_ml += np.log(z)
+        post = pred * like / z
+    # the particle filter
+    n = 1 << 20
+    pf = modppl_amd.ParticleSystem(modppl_amd.stochastic_volatility_model(*SV), n, 20241008)
+    pf.init_step(None, obs[:1])
+    for t in range(1, T):
+        pf.resample(sync=False)
+        pf.step(obs[t:t + 1])
+    est = pf.log_marginal_likelihood_estimate()
+    assert abs(est - log_ml) < 0.01, (est, log_ml)
