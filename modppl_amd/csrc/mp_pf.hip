@@ -113,7 +113,8 @@ struct PropagateArgs {
     u64* tile_W;
     u64* tile_W2;
     const uint32_t* inv;
-    const mp_k1_draw* drw;    // non-null: this launch also MAKES the previous resample's draws (resample counter rc), into dfr_row / dfr_lt
+    mp_k1_draw drw_v;         // ... what it reads for that (by value: kernel arguments)
+    int drw;                  // non-zero: this launch also MAKES the previous resample's draws (resample counter rc), into dfr_row / dfr_lt
     uint32_t rc;
     size_t dyn_lds;           // LDS for that phase's copy of the tile table
     const mp_k1_tail* tail;   // device copy of {cx, guide, tile_*, tab} (k_propagate reads them there)
@@ -153,13 +154,13 @@ struct ModelOpsT : ModelOps {
             if (k1t == 256) {
                 hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux, a.drw, a.rc);
+                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.drw, a.rc);
                 return;
             }
             if (k1t == 512) {
                 hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux, a.drw, a.rc);
+                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.drw, a.rc);
                 return;
             }
         }
@@ -176,7 +177,7 @@ struct ModelOpsT : ModelOps {
         }
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                           a.inv, a.dfr_lt, a.aux, a.drw, a.rc);
+                           a.inv, a.dfr_lt, a.aux, a.drw_v, a.drw, a.rc);
     }
     int n_normals(long long t) const override { return model.n_normals(t); }
 };
@@ -389,8 +390,6 @@ struct mp_pf {
     mp_k1_tail* k1_tail_alt = nullptr;  // the same with cx_alt / guide_alt for cx / guide
     unsigned short* guide_alt = nullptr; // second guide buffer (swaps with guide together with the row tables)
     u64* tab_W = nullptr;               // the tile table's copy of tile_W (mp_tab::W)
-    mp_k1_draw* k1_draw = nullptr;      // device copies of what a drawing k_propagate reads: guide_old = guide ...
-    mp_k1_draw* k1_draw_alt = nullptr;  // ... / guide_alt
     bool draw_pending = false;          // with `deferred`: not even the draws of the last resample have been made (counter pending_rc);
     uint32_t pending_rc = 0;            // the next k_propagate makes them, or flush_draws() when anything else needs them first
     int use_fused_draws = 1;            // MP_FUSED_DRAWS=0: a resample always launches k_draw_slots (A/B measurements)
@@ -501,21 +500,6 @@ static int32_t update_k1_tail(mp_pf* h) {   // after anything that changes one o
         }
         if (!h->k1_tail_alt) HIPCK(hipMalloc(&h->k1_tail_alt, sizeof(mp_k1_tail)));
         HIPCK(hipMemcpyAsync(h->k1_tail_alt, &t, sizeof(t), hipMemcpyHostToDevice, h->stream));
-        HIPCK(hipStreamSynchronize(h->stream));
-        mp_k1_draw d;
-        d.scal = h->scal;
-        d.n_global = h->n_global; d.nt = h->nt; d.S = h->S; d.dfr_lt = h->dfr_lt; d.dfr_row = h->dfr_row;
-        d.guide_old = h->guide;
-        d.tile_m_old = h->tile_m; d.tile_W_old = h->tile_W; d.tile_W2_old = h->tile_W2;
-        if (!h->k1_draw) HIPCK(hipMalloc(&h->k1_draw, sizeof(mp_k1_draw)));
-        HIPCK(hipMemcpyAsync(h->k1_draw, &d, sizeof(d), hipMemcpyHostToDevice, h->stream));
-        HIPCK(hipStreamSynchronize(h->stream));
-        d.guide_old = h->guide_alt;
-        if (h->local_table) {
-            d.tile_m_old = reinterpret_cast<double*>(h->tiles_alt); d.tile_W_old = h->tiles_alt + h->nt; d.tile_W2_old = h->tiles_alt + 2 * (size_t)h->nt;
-        }
-        if (!h->k1_draw_alt) HIPCK(hipMalloc(&h->k1_draw_alt, sizeof(mp_k1_draw)));
-        HIPCK(hipMemcpyAsync(h->k1_draw_alt, &d, sizeof(d), hipMemcpyHostToDevice, h->stream));
         HIPCK(hipStreamSynchronize(h->stream));
     }
     return MP_OK;
@@ -668,7 +652,14 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.cx = h->deferred ? h->cx_alt : h->cx; a.guide = h->deferred ? h->guide_alt : h->guide;
     a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
     // ... and made by it too, when the resample left them pending (kernels of two-slot lanes)
-    a.drw = (h->deferred && h->draw_pending) ? h->k1_draw : nullptr;
+    a.drw = (h->deferred && h->draw_pending) ? 1 : 0;
+    a.drw_v = mp_k1_draw{};
+    if (a.drw) {
+        mp_k1_draw& d = a.drw_v;
+        d.tile_m_old = h->tile_m; d.tile_W_old = h->tile_W; d.tile_W2_old = h->tile_W2;   // (this launch writes the other set: k1_tail_alt)
+        d.guide_old = h->guide; d.scal = h->scal; d.dfr_lt = h->dfr_lt; d.dfr_row = h->dfr_row;
+        d.n_global = h->n_global; d.nt = h->nt; d.S = h->S;
+    }
     if (a.drw) { a.dfr_row = nullptr; a.dfr_lt = nullptr; }   // (not read: the kernel writes them through the struct's pointers)
     a.rc = h->pending_rc;
     a.dyn_lds = a.drw ? 24 * (size_t)h->nt : 0;
@@ -684,7 +675,6 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         std::swap(h->cx, h->cx_alt);
         std::swap(h->guide, h->guide_alt);
         std::swap(h->k1_tail, h->k1_tail_alt);
-        std::swap(h->k1_draw, h->k1_draw_alt);
         if (h->local_table) {
             std::swap(h->tiles_own, h->tiles_alt);
             h->tile_m = reinterpret_cast<double*>(h->tiles_own); h->tile_W = h->tiles_own + h->nt; h->tile_W2 = h->tiles_own + 2 * (size_t)h->nt;
@@ -1721,7 +1711,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     for (void* slab : h->hist_slabs) (void)hipFree(slab);
     (void)hipFree(h->d_hist_events);
     (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->cx_alt); (void)hipFree(h->k1_tail_alt); (void)hipFree(h->guide);
-    (void)hipFree(h->guide_alt); (void)hipFree(h->tab_W); (void)hipFree(h->k1_draw); (void)hipFree(h->k1_draw_alt);
+    (void)hipFree(h->guide_alt); (void)hipFree(h->tab_W);
     (void)hipFree(h->parent); (void)hipFree(h->tiles_own); (void)hipFree(h->tiles_alt); (void)hipFree(h->scal);
     (void)hipFree(h->aos);
     (void)hipFree(h->k1_tail);

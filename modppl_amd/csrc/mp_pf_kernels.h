@@ -732,7 +732,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                                                             const uint32_t* __restrict__ dfr_row, const double* __restrict__ inv_rows,
                                                             const mp_cx* __restrict__ cx_old, const mp_k1_tail* tail,
                                                             const uint32_t* __restrict__ inv, const u64* __restrict__ dfr_lt, mp_k1_aux aux,
-                                                            const mp_k1_draw* drw, uint32_t rc) {
+                                                            mp_k1_draw drw_v, int drw, uint32_t rc) {
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int LANE_ITEMS = TILE / THREADS;
@@ -759,9 +759,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             // ---- phase 0: the draws of the previous resample for this lane's two adjacent slots (k_draw_slots<1, 0>'s body:
             // same Philox block, same target, same tile walk, same guide cell -> bit-identical {target, start row}) ----
             drew = true;
-            const mp_k1_draw* dp = drw;
-            asm volatile("" : "+s"(dp)::"memory");
-            mp_k1_draw dw = mp_ld_const(dp);
+            // (the struct travels BY VALUE in the kernel arguments: read from device memory it was a second, dependent scalar-load
+            // miss — 1.2 k cycles — in front of everything this launch does)
+            mp_k1_draw dw = drw_v;
             dw.guide_old = mp_as_global(dw.guide_old); dw.scal = mp_as_global(dw.scal);
             dw.dfr_lt = mp_as_global(dw.dfr_lt); dw.dfr_row = mp_as_global(dw.dfr_row);
             extern __shared__ __attribute__((aligned(16))) unsigned char k1_dyn[];
@@ -785,6 +785,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 // go straight to the barriers: everything in front of the first gather is on the step's critical path, twice,
                 // because the CU's other workgroup is doing the same)
                 const bool wave_has = wave1 * 64 < dw.nt;   // wave-uniform
+                MP_STAMP(0, 25, 0);
                 double mb = MP_NEG_INF;
                 u64 Wb = 0ull, W2b = 0ull;
                 if (wave_has) {
@@ -792,9 +793,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                     Wb = have_tb ? mp_as_global(dw.tile_W_old)[tb] : 0ull;
                     W2b = (have_tb && blockIdx.x == 0) ? mp_as_global(dw.tile_W2_old)[tb] : 0ull;
                 }
+                MP_STAMP(0, 26, 0);
                 blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
+                asm volatile("" : "+v"(blk.a), "+v"(blk.b));
+                MP_STAMP(0, 27, 0);
                 if (wave_has) {
                     const double mw = wave_max(mb);
+                    MP_STAMP(0, 28, 0);
                     if (lane1 == 0) s_l1_red[wave1] = mw;
                 } else if (lane1 == 0) {
                     s_l1_red[wave1] = MP_NEG_INF;
@@ -802,6 +807,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                     s_l1_tot2[wave1] = 0ull;
                 }
                 __syncthreads();
+                MP_STAMP(0, 29, 0);
                 double m = s_l1_red[0];
 #pragma unroll
                 for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_l1_red[w]);
@@ -811,11 +817,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                     const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
                     const double sc = mp_u2f((u64)(1023 + dw.S - FIX_BITS) << 52);  // 2^(S-51)
                     const double dm = mb - m;
-                    T = have_tb ? mp_quantize((double)Wb * (ok ? mp_exp(dm) : 0.) * sc, 1.0) : 0ull;
+                    T = have_tb ? mp_quantize((double)Wb * (ok ? mp_exp_nonpos(dm) : 0.) * sc, 1.0) : 0ull;   // (dm <= 0: mp_exp's bits)
                     incl = wave_incl_scan_u64(T, lane1);
                     if (lane1 == 63) s_l1_tot[wave1] = incl;
                     if (blockIdx.x == 0) {   // (workgroup-uniform) the scalars of this normalisation: Q2 as well
-                        const u64 T2 = have_tb ? mp_quantize((double)W2b * (ok ? mp_exp(2. * dm) : 0.) * sc, 1.0) : 0ull;
+                        const u64 T2 = have_tb ? mp_quantize((double)W2b * (ok ? mp_exp_nonpos(2. * dm) : 0.) * sc, 1.0) : 0ull;
                         const u64 tot2 = wave_sum_u64(T2);
                         if (lane1 == 0) s_l1_tot2[wave1] = tot2;
                     }

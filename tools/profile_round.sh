@@ -5,7 +5,7 @@
 # tools/collect_profiles.sh on the build side.
 set -u
 R=$PWD
-OUT=$R/gpurun_out/${1:-r02_prof}
+OUT=$R/gpurun_out/${1:-r03_prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-kernel-timing --no-sub-benches --no-systematic-leg"
@@ -17,9 +17,15 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_IN
   timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -o p -- $B --steps 10 --warmup 3 > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed ($grp)"; tail -n 3 $OUT/pmc$i.log; continue; }
   echo "pmc pass $i done ($grp)"
 done
+# stamps of one launch in a busy queue (diagnostics build)
+cd $R && timeout -k 10 200 python3 tools/stamp_probe.py --raw $OUT/stamps.npy > $OUT/stamps.json 2> $OUT/stamps.err && python3 tools/stamp_report.py $OUT/stamps.npy > $OUT/stamp_report.txt || echo "stamp probe failed"
+cd /tmp
 # the sharded code path in a world of one (owner-keeps exchange), kernel stats only
 MP_BENCH_FORCE_SHARDED=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sharded -o bench -- $B --steps 50 --warmup 10 > $OUT/trace_sharded.log 2>&1 || echo "sharded trace pass failed"
-cd $R && MP_BENCH_FORCE_SHARDED=1 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-sub-benches > $OUT/bench_forced_sharded.json 2> $OUT/bench_forced_sharded.err || echo "forced-sharded bench failed"
+cd $R && MP_BENCH_FORCE_SHARDED=1 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline > $OUT/bench_forced_sharded.json 2> $OUT/bench_forced_sharded.err || echo "forced-sharded bench failed"
+cd $R && MP_BENCH_FORCE_SHARDED=1 MP_SHARD_ALWAYS_COLLECTIVE=1 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline > $OUT/bench_forced_sharded_rccl.json 2> $OUT/bench_forced_sharded_rccl.err || echo "forced-sharded RCCL bench failed"
+cd $R && timeout -k 10 300 python3 tools/route_scale.py > $OUT/route_scale.txt 2>&1 || echo "route_scale failed"
+cd $R && timeout -k 10 300 python3 tools/model_bench.py --which c3,c5,c4 > $OUT/model_bench.jsonl 2> $OUT/model_bench.err || echo "model_bench failed"
 cd $R && timeout -k 10 600 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { echo "bench failed"; tail -n 5 $OUT/bench_n1.err; exit 1; }
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1_k20.json 2>> $OUT/bench_n1.err || { echo "bench k20 failed"; exit 1; }
 echo "bench done"

@@ -32,3 +32,13 @@ print("workgroup starts  p0 %.2f p50 %.2f p100 %.2f us;  ends  p0 %.2f p50 %.2f 
     start.min(), np.median(start), start.max(), end.min(), np.median(end), np.percentile(end, 90), end.max()))
 nb = len(x)
 print("first half of the grid (first workgroup of each CU): mean end %.2f us; second half: %.2f us" % (end[:nb // 2].mean(), end[nb // 2:].mean()))
+
+# the start-up of a drawing launch, first against second workgroup of a CU (first / second half of the grid)
+if x[:, 25].any():
+    half = nb // 2
+    seq = [(0, 25, "kernel arguments, struct (scalar loads)"), (25, 26, "tile-scalar loads issued"), (26, 27, "resample Philox block"),
+           (27, 28, "tile scalars landed, wave max"), (28, 29, "barrier"), (29, 16, "exp, scan, barrier, offsets, LDS table"), (16, 17, "barrier 0")]
+    print("start-up, mean cycles: first workgroup of a CU | second")
+    for a, c, nm in seq:
+        d = x[:, c] - x[:, a]
+        print("  %-44s %8.0f | %8.0f" % (nm, d[:half].mean(), d[half:].mean()))
