@@ -599,6 +599,9 @@ __device__ __forceinline__ u64 mp_tile_last(uint32_t row, u64 n) {
 // is MP_DRAW_RECV | the index of its row {state[dim], parent's global slot id} in the exchange buffer (`rows`, rows of `rw`
 // doubles); the "parent" handed on keeps the flag, so that the consumer knows where the state is.
 constexpr uint32_t MP_DRAW_RECV = 0x80000000u;
+#ifndef MP_PAIR_SAME_LINE
+#define MP_PAIR_SAME_LINE 1
+#endif
 // N draws at a time: every load goes out before the first is used.
 template <int N>
 __device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u64 n, const u64* lt, const uint32_t* row, uint32_t* parent, double* x0,
@@ -606,12 +609,17 @@ __device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u
     mp_u64v2 a[N], b2[N];
     u64 last[N];
     uint32_t r0[N];
+    bool hb[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         r0[k] = (rows && (row[k] & MP_DRAW_RECV)) ? 0u : row[k];
         last[k] = mp_tile_last(r0[k], n);
         a[k] = mp_ld_row(cx + r0[k]);
-        b2[k] = mp_ld_row(cx + (u64)r0[k] + ((u64)r0[k] < last[k] ? 1 : 0));
+        // the successor goes out with the start row only where it lies in the SAME 64-byte line (four rows): a successor in the
+        // next line is needed by 37 % of the draws only, and fetching it for all of them was a quarter-line-miss per draw for
+        // nothing — the lookups are bound by the fabric's miss rate (tools/gather_probe.hip); the few that need it walk on below
+        hb[k] = (u64)r0[k] < last[k] && (MP_PAIR_SAME_LINE ? (r0[k] & 3u) != 3u : true);
+        b2[k] = mp_ld_row(cx + (u64)r0[k] + (hb[k] ? 1 : 0));
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) mp_pin_rows(a[k], b2[k]);
@@ -622,7 +630,7 @@ __device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u
             parent[k] = row[k];
             continue;
         }
-        const bool step1 = a[k].x < lt[k] && (u64)r0[k] < last[k];
+        const bool step1 = a[k].x < lt[k] && hb[k];
         u64 p = (u64)r0[k] + (step1 ? 1 : 0);
         mp_u64v2 cur = step1 ? b2[k] : a[k];
         while (cur.x < lt[k] && p < last[k]) {   // rare: more than one row past the guide's start
