@@ -657,7 +657,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     if (a.drw) {
         mp_k1_draw& d = a.drw_v;
         d.tile_m_old = h->tile_m; d.tile_W_old = h->tile_W; d.tile_W2_old = h->tile_W2;   // (this launch writes the other set: k1_tail_alt)
-        d.guide_old = h->guide; d.scal = h->scal; d.dfr_lt = h->dfr_lt; d.dfr_row = h->dfr_row;
+        d.guide_old = h->guide; d.scal = h->scal; d.parent = h->parent;
         d.n_global = h->n_global; d.nt = h->nt; d.S = h->S;
     }
     if (a.drw) { a.dfr_row = nullptr; a.dfr_lt = nullptr; }   // (not read: the kernel writes them through the struct's pointers)
@@ -680,7 +680,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
             h->tile_m = reinterpret_cast<double*>(h->tiles_own); h->tile_W = h->tiles_own + h->nt; h->tile_W2 = h->tiles_own + 2 * (size_t)h->nt;
         }
         h->draw_pending = false;
-        h->parents_deferred = true;
+        h->parents_deferred = !a.drw;   // (a launch that made the draws itself wrote parent[] as well)
         h->deferred = false;
     }
     h->t += 1;

@@ -669,8 +669,9 @@ struct mp_k1_draw {
     const u64* tile_W2_old;
     const unsigned short* guide_old;
     mp_dev_scalars* scal;
-    u64* dfr_lt;              // the draws are also written out: mp_pf_read_parents after the step recomputes the parents from them
-    uint32_t* dfr_row;
+    uint32_t* parent;         // the parents are written out once the lookups have resolved them (particle_filter.rs:20 keeps `parents`): 4 B per
+                              // slot at the end of the lookups, where {target, start row} written during the draws were 12 B per slot of
+                              // store traffic in the middle of the phase that is bound by the memory fabric
     u64 n_global;
     int nt, S;
 };
@@ -771,7 +772,6 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             // miss — 1.2 k cycles — in front of everything this launch does)
             mp_k1_draw dw = drw_v;
             dw.guide_old = mp_as_global(dw.guide_old); dw.scal = mp_as_global(dw.scal);
-            dw.dfr_lt = mp_as_global(dw.dfr_lt); dw.dfr_row = mp_as_global(dw.dfr_row);
             extern __shared__ __attribute__((aligned(16))) unsigned char k1_dyn[];
             u64* s_incl = reinterpret_cast<u64*>(k1_dyn);              // [nt]
             u64* s_W = s_incl + dw.nt;                                  // [nt]
@@ -874,17 +874,6 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 const u64 tbase = (u64)tile_of[q] * TILE;
                 const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
                 pm[q] = (uint32_t)tbase + (j0[q] > tlen - 1 ? tlen - 1 : j0[q]);   // row where the forward scan starts
-            }
-            // kept for mp_pf_read_parents after this step (the draws + the old table are what the parents are recomputed from)
-            u64* wl = dw.dfr_lt;
-            uint32_t* wr = dw.dfr_row;
-            if (base + 1 < n) {
-                mp_u64v2 v2; v2.x = plt[0]; v2.y = plt[1];
-                mp_st_stream16(wl + base, v2);
-                mp_st_stream8(wr + base, ((u64)pm[1] << 32) | (u64)pm[0]);
-            } else if (base < n) {
-                wl[base] = plt[0];
-                wr[base] = pm[0];
             }
             MP_STAMP(0, 19, 0);
         }
@@ -1077,6 +1066,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 // lookup ahead of the deviates as well)
                 asm volatile("" : "+v"(plt[1]) : "v"(z[NS + NS - 1]));
                 mp_resolve_draw(cx_old, n, plt[1], pm[1], &pm[1], &px0[1], inv ? nullptr : inv_rows, D + 1);
+                if constexpr (CAN_DRAW) {
+                    if (drew) {   // this lane's two parents, slot order: one 8-byte store
+                        uint32_t* pp = mp_as_global(drw_v.parent);
+                        if (base + 1 < n) *reinterpret_cast<uint2*>(pp + base) = make_uint2(pm[0], pm[1]);
+                        else if (base < n) pp[base] = pm[0];
+                    }
+                }
                 MP_STAMP(0, 24, 0);
             } else if constexpr (D == 1) {
                 mp_resolve_draws<LANE_ITEMS>(cx_old, n, plt, pm, pm, px0, inv ? nullptr : inv_rows, D + 1);
