@@ -408,6 +408,7 @@ struct mp_pf {
     bool table_fresh = false;           // tab_* (the job's tile table in global memory) describe the current tile scalars
     u64* tiles_alt = nullptr;           // second [3][nt] tile-scalar buffer
     bool rows_fresh = false;            // cx / guide / tile_* describe the current log-weights
+    bool x_in_rows = false;             // (dim_state 1) the current states are the x0 of the rows of cx; x[cur] is stale (ensure_x)
     // sharded-resample scratch (allocated on first use)
     unsigned char* sh_dest = nullptr;
     u64* sh_lt = nullptr;
@@ -577,6 +578,14 @@ static int32_t fetch_scalars(mp_pf* h) {
     return MP_OK;
 }
 
+// dim_state 1: k_propagate leaves the new states in the row table only; whoever wants x[cur] gets it here
+static int32_t ensure_x(mp_pf* h) {
+    if (!h->x_in_rows) return MP_OK;
+    hipLaunchKernelGGL(k_rows_to_x, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, (const mp_cx*)h->cx, h->x[h->cur]);
+    h->x_in_rows = false;
+    return check_launch("k_rows_to_x");
+}
+
 // Slot-order x / parent / logw after a resample that only drew (only when something other than the next step needs them).
 static int32_t materialize(mp_pf* h) {
     if (h->sh_lazy) {
@@ -584,6 +593,7 @@ static int32_t materialize(mp_pf* h) {
                            h->ops->dim_state, h->sh_rows, h->sh_req_slot, (const double*)h->x[h->cur ^ 1], h->slot_offset, h->x[h->cur], h->parent);
         h->sh_lazy = false;
         h->sh_parents_lazy = false;
+        h->x_in_rows = false;   // (every slot's state was just written)
         int32_t rc = check_launch("k_shard_adopt_rows");
         if (rc != MP_OK) return rc;
     }
@@ -603,9 +613,10 @@ static int32_t materialize(mp_pf* h) {
         if (d > 1) h->cur ^= 1;   // wider states were gathered from the pre-resample buffer into the other one
         h->deferred = false;
         h->parents_deferred = false;   // k_resolve_slots wrote parent[] too
+        h->x_in_rows = false;          // ... and every slot's state
         return check_launch("k_resolve_slots");
     }
-    return MP_OK;
+    return MP_OK;   // (x[cur] itself: ensure_x, for the callers that read it)
 }
 
 // a buffer of `bytes` for one history event, out of the current slab (a new slab is twice the last one, at least 8 events)
@@ -666,6 +677,11 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.grid = h->nt;
     a.stream = h->stream;
     a.aux.tab = tab_of(h);
+    a.aux.x_rows = 0;
+    if (h->ops->dim_state == 1 && h->x_in_rows && !h->deferred && !h->sh_lazy) {   // a plain step: the previous states are the x0 of the current rows
+        a.x_in = reinterpret_cast<const double*>(h->cx);
+        a.aux.x_rows = 1;
+    }
     a.tail = h->deferred ? h->k1_tail_alt : h->k1_tail;
     {
         LaunchTimer lt(h, MP_K_PROPAGATE);
@@ -685,6 +701,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     }
     h->t += 1;
     if (gather_here) h->cur ^= 1;
+    if (h->ops->dim_state == 1) h->x_in_rows = true;   // k_propagate left the new states in the row table only
     h->logw_zero = false;
     // parents of that resample stay where they are (the draws + the old table, or the exchange rows) until somebody asks for
     // them or the next resample replaces them: mp_pf_read_parents (particle_filter.rs:20 keeps `parents` across `step`)
@@ -699,6 +716,10 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         const size_t bytes = sizeof(double) * h->n * (size_t)h->ops->dim_state;
         int32_t rch = hist_alloc(h, bytes, &buf);
         if (rch != MP_OK) return rch;
+        {
+            int32_t rcx = ensure_x(h);
+            if (rcx != MP_OK) return rcx;
+        }
         HIPCK(hipMemcpyAsync(buf, h->x[h->cur], bytes, hipMemcpyDeviceToDevice, h->stream));
         h->hist.push_back({0, buf});
     }
@@ -710,6 +731,8 @@ static int32_t ensure_rows(mp_pf* h) {
     int32_t rc = materialize(h);
     if (rc != MP_OK) return rc;
     if (h->rows_fresh) return MP_OK;
+    rc = ensure_x(h);
+    if (rc != MP_OK) return rc;
     {
         LaunchTimer lt(h, MP_K_NORMALIZE_SCAN);
         hipLaunchKernelGGL(k_normalize_tiles, dim3(h->nt), dim3(TILE_THREADS), 0, h->stream, h->logw, h->x[h->cur], h->ops->dim_state, h->n, h->cx, h->guide,
@@ -1065,6 +1088,7 @@ int32_t mp_pf_read_state(mp_pf* h, double* x_out) {
     if (!h || !x_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
     { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
+    { int32_t rcx = ensure_x(h); if (rcx != MP_OK) return rcx; }
     const int d = h->ops->dim_state;   // device layout = host layout: particle-major x[i][d]
     HIPCK(hipMemcpyAsync(x_out, h->x[h->cur], sizeof(double) * h->n * d, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
@@ -1161,6 +1185,7 @@ int32_t mp_pf_shard_resolve(mp_pf* h, const uint64_t* d_req_in, uint64_t n_req, 
     if (n_req == 0) return MP_OK;
     if (!d_req_in || !d_rows_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
+    { int32_t rcx = ensure_x(h); if (rcx != MP_OK) return rcx; }
     int grid = (int)std::min<u64>((n_req + K3_THREADS - 1) / K3_THREADS, (u64)K3_MAX_BLOCKS);
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
@@ -1303,6 +1328,7 @@ int32_t mp_pf_shard_resolve_fixed(mp_pf* h, const uint64_t* d_req_in, int32_t wo
     if (world < 1 || world > SH_MAX_WORLD || capacity == 0) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, capacity > 0");
     if (!h->h_pub) return mp_fail(MP_ERR_STATE, "shard_resolve_fixed before shard_route_fixed");
     HIPCK(hipSetDevice(h->device));
+    { int32_t rcx = ensure_x(h); if (rcx != MP_OK) return rcx; }
     // workgroups per (asking rank, eighth): enough to fill the chip, each takes K3_THREADS * K3_ITEMS requests per round
     const u64 per = (u64)K3_THREADS * SHR_ITEMS;
     const unsigned groups = (unsigned)std::max<u64>(1, std::min<u64>((capacity + per - 1) / per, std::max<u64>(1, 512 / (u64)world)));

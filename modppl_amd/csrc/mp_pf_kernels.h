@@ -72,38 +72,26 @@ __device__ __forceinline__ T mp_ld_const(const T* p) {
 // them back at once (the next launch cannot start before that: MI355X_MICROARCH.md, "dependent kernel boundary ... + B / 6 TB/s
 // when the predecessor leaves B bytes dirty").  MP_WT_STORES=0 builds the plain stores (A/B).
 #ifndef MP_WT_STORES
-#define MP_WT_STORES 0   // measured: 44.4 -> 46.5 us per step with write-through stores (the write traffic competes with the gathers)
+#define MP_WT_STORES 0   // bit mask (A/B builds): 1 log-weights, 2 states, 4 table rows, 8 guide.  Measured with all of them (and the
+                         // draws' stores, since removed): 44.4 -> 46.5 us per step — the write traffic competes with the gathers
 #endif
+template <int BIT>
 __device__ __forceinline__ void mp_st_stream(double* p, double v) {
-#if MP_WT_STORES
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
+    if constexpr ((MP_WT_STORES & BIT) != 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
 }
+template <int BIT>
 __device__ __forceinline__ void mp_st_stream(uint32_t* p, uint32_t v) {
-#if MP_WT_STORES
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
+    if constexpr ((MP_WT_STORES & BIT) != 0) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
 }
 typedef u64 mp_u64v2_ __attribute__((ext_vector_type(2)));
+template <int BIT>
 __device__ __forceinline__ void mp_st_stream16(void* p, mp_u64v2_ v) {
-#if MP_WT_STORES
     // (s_nop: a store of more than 64 bits must not be followed at once by a write of its data registers — a hazard the
     // compiler pads for its own stores and cannot see inside inline assembly)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
-#else
-    *reinterpret_cast<mp_u64v2_*>(p) = v;
-#endif
-}
-__device__ __forceinline__ void mp_st_stream8(void* p, u64 v) {
-#if MP_WT_STORES
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    *reinterpret_cast<u64*>(p) = v;
-#endif
+    if constexpr ((MP_WT_STORES & BIT) != 0) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<mp_u64v2_*>(p) = v;
 }
 
 constexpr int TILE_THREADS = 512;
@@ -462,7 +450,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
             mp_u64v2_ row;
             row.x = off + c[j];
             row.y = mp_f2u(xv[j]);
-            mp_st_stream16(cx + base + j, row);
+            mp_st_stream16<4>(cx + base + j, row);
         }
     }
 
@@ -500,7 +488,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     MP_STAMP(0, 15, 0);
     if constexpr (THREADS == 256) reinterpret_cast<uint4*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint4*>(s_guide)[tid];
     else if constexpr (THREADS == 512) reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
-    else mp_st_stream(reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N) + tid, reinterpret_cast<const uint32_t*>(s_guide)[tid]);
+    else mp_st_stream<8>(reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N) + tid, reinterpret_cast<const uint32_t*>(s_guide)[tid]);
     if (s_last) {   // workgroup-uniform: every other workgroup's scalars are out (their tickets precede ours)
 #ifndef MP_TEST_NOTABLE
         build_tile_table_global<THREADS>(tile_m, tile_W, tile_W2, (int)gridDim.x, tab);
@@ -536,6 +524,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_normalize_tiles(const double* 
         }
     }
     normalize_tile<TILE_THREADS>(lw, xv, n, blockIdx.x, cx, guide, tile_m, tile_W, tile_W2, tab);
+}
+
+// Slot-order states of a filter with dim_state 1 out of its row table (k_propagate does not store them separately)
+__global__ void k_rows_to_x(u64 n, const mp_cx* __restrict__ cx, double* __restrict__ x) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = cx[i].x0;
 }
 
 // The job's tile table as a launch of its own: for handles whose level-0 launches build none (drawing k_propagates build it
@@ -583,6 +577,7 @@ constexpr bool mp_coop_model() { return Model::MAX_NORMALS <= 4; }
 // Then the model kernel runs per particle in Generate mode on them.
 struct mp_k1_aux {
     mp_tab tab;
+    int x_rows;   // (dim_state 1, a plain step) x_in is the current row table: slot i's state is the x0 of row i
 };
 // A draw of the last resample that has not been looked up yet (k_draw_slots left {tile-local target, start row} per output
 // slot): its parent is the first row of the start row's tile, at or after it, whose cumulative weight reaches the target
@@ -686,7 +681,8 @@ template <class Model>
 __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, long long t,
                                                 const double* __restrict__ x_in, double* __restrict__ x_out, double* logw, const double* obs_v,
                                                 const double* s0_v, int overwrite, bool deferred, const double* __restrict__ inv_rows,
-                                                bool via_inv, uint32_t pmv, const double* x0p, u64 i, const double* zp, double* lw_out, double* x0_out) {
+                                                bool via_inv, uint32_t pmv, const double* x0p, u64 i, const double* zp, double* lw_out, double* x0_out,
+                                                bool x_rows = false) {
     constexpr int D = Model::DIM_STATE;
     if (i >= n) return;
     double prev[D], next[D];
@@ -715,22 +711,28 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
 #pragma unroll
         for (int d = 0; d < D; ++d) prev[d] = s0_v[d];
     } else {
+        // (d = 1: x_in may be the current row table itself — {cum, x0} pairs: the states of such filters live there, below)
+        if constexpr (D == 1) prev[0] = x_rows ? x_in[2 * i + 1] : x_in[i];
+        else {
 #pragma unroll
-        for (int d = 0; d < D; ++d) prev[d] = x_in[i * D + d];
+            for (int d = 0; d < D; ++d) prev[d] = x_in[i * D + d];
+        }
     }
     mp_stream rng;
     rng.k0 = k0; rng.k1 = k1; rng.slot = (uint32_t)(slot_offset + i); rng.step = (uint32_t)t;
     mp_generate_handler<Model> g(rng, obs_v, zp);
     model(g, t, prev, next);
+    // d = 1: the state is not stored on its own — it is the x0 of this particle's row of the table that the level-0 pass below
+    // writes anyway; who wants slot-order states afterwards copies them out of the rows (mp_pf.hip ensure_x).  8 MB less written
+    // per step at 2^20 particles, in a kernel whose lookups are bound by what the L2s can hold and the fabric can move.
+    if constexpr (D > 1) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if constexpr (D == 1) mp_st_stream(x_out + i * D + d, next[d]);   // (wider states: a lane's 8-byte pieces of its own row are partial-line writes when they bypass L2)
-        else x_out[i * D + d] = next[d];
+        for (int d = 0; d < D; ++d) x_out[i * D + d] = next[d];
     }
     // particle_filter.rs:68 (init: overwrite) / :81 (accumulate); overwrite == 2: the log-weights are known to be all zero
     // after a resample (log_weights.fill(0.), :114) and are not re-read
     const double w = overwrite == 1 ? g.weight : (overwrite == 2 ? 0. + g.weight : logw[i] + g.weight);
-    mp_st_stream(logw + i, w);
+    mp_st_stream<1>(logw + i, w);
     *lw_out = w;
     *x0_out = next[0];
 }
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     // phase 2 = mp_run_particle (above): the model kernel in Generate mode for one particle
 #define MP_RUN_PARTICLE(P, ZP)                                                                                                             \
     mp_run_particle<Model>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, cx_old != nullptr, inv_rows, inv != nullptr, \
-                           pm[P], &px0[P], base + (u64)(P), ZP, &lw[P], &xv[P])
+                           pm[P], &px0[P], base + (u64)(P), ZP, &lw[P], &xv[P], aux.x_rows != 0)
     double px0[LANE_ITEMS];   // (written and read only with deferred draws)
     // Where a lane's deferred draws are looked up (every form gives the same parents; what differs is when a CU's 4096 row
     // gathers hit its vector-memory path, and bursts are what this kernel pays for):
