@@ -75,14 +75,19 @@ __device__ __forceinline__ T mp_ld_const(const T* p) {
 #define MP_WT_STORES 0   // bit mask (A/B builds): 1 log-weights, 2 states, 4 table rows, 8 guide.  Measured with all of them (and the
                          // draws' stores, since removed): 44.4 -> 46.5 us per step — the write traffic competes with the gathers
 #endif
+#ifndef MP_NT_STORES
+#define MP_NT_STORES 0   // same bit mask: non-temporal stores (streamed through the L2, first in line for eviction)
+#endif
 template <int BIT>
 __device__ __forceinline__ void mp_st_stream(double* p, double v) {
     if constexpr ((MP_WT_STORES & BIT) != 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr ((MP_NT_STORES & BIT) != 0) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 template <int BIT>
 __device__ __forceinline__ void mp_st_stream(uint32_t* p, uint32_t v) {
     if constexpr ((MP_WT_STORES & BIT) != 0) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr ((MP_NT_STORES & BIT) != 0) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 typedef u64 mp_u64v2_ __attribute__((ext_vector_type(2)));
@@ -91,15 +96,21 @@ __device__ __forceinline__ void mp_st_stream16(void* p, mp_u64v2_ v) {
     // (s_nop: a store of more than 64 bits must not be followed at once by a write of its data registers — a hazard the
     // compiler pads for its own stores and cannot see inside inline assembly)
     if constexpr ((MP_WT_STORES & BIT) != 0) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+    else if constexpr ((MP_NT_STORES & BIT) != 0) __builtin_nontemporal_store(v, reinterpret_cast<mp_u64v2_*>(p));
     else *reinterpret_cast<mp_u64v2_*>(p) = v;
 }
 
 constexpr int TILE_THREADS = 512;
 constexpr int TILE_ITEMS = 4;
 constexpr int TILE = TILE_THREADS * TILE_ITEMS;  // 2048 rows per tile: a constant of the normalisation spec
-constexpr int GUIDE_BITS = 11;                   // one guide bucket per table row (GUIDE_N == TILE): 2 B per particle
+#ifndef MP_GUIDE_BITS
+#define MP_GUIDE_BITS 11
+#endif
+constexpr int GUIDE_BITS = MP_GUIDE_BITS;        // 11: one guide bucket per table row (GUIDE_N == TILE), 2 B per particle
 constexpr int GUIDE_N = 1 << GUIDE_BITS;
-static_assert(GUIDE_N == TILE, "normalize_tile zeroes/stores the guide with one (16 | 8 | 4)-byte word per thread");
+static_assert(GUIDE_N <= TILE && GUIDE_N >= 1024, "normalize_tile zeroes / stores the guide with one word of >= 2 bytes per thread");
+// (measured at 2^20 particles: 1024 cells per tile 40.2 us per step against 39.1 with 2048 — the guide's smaller footprint in the
+// L2s does not pay for the longer walks)
 constexpr int GUIDE_DIRECT = 8;                  // bucket runs longer than this are filled by the whole wave
 constexpr int FIX_BITS = 51;                     // level-0 fixed point: q = rint(exp(lw - m_tile) * 2^51), 2048 * 2^51 < 2^63
 constexpr int DRAW_CHUNK = 1024;                 // output slots per workgroup of k_draw_slots
@@ -386,9 +397,12 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     MP_STAMP(0, 8, 0);
     if (lane == 0) s_red[wave] = m;
     // THREADS x (16 | 8 | 4) B = the whole guide
-    if constexpr (THREADS == 256) reinterpret_cast<uint4*>(s_guide)[tid] = make_uint4(0u, 0u, 0u, 0u);
-    else if constexpr (THREADS == 512) reinterpret_cast<u64*>(s_guide)[tid] = 0ull;
-    else reinterpret_cast<uint32_t*>(s_guide)[tid] = 0u;
+    // THREADS words of GUIDE_N * 2 / THREADS bytes each = the whole guide
+    constexpr int GW = GUIDE_N * 2 / THREADS;   // bytes per thread: 16 | 8 | 4 | 2
+    if constexpr (GW == 16) reinterpret_cast<uint4*>(s_guide)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    else if constexpr (GW == 8) reinterpret_cast<u64*>(s_guide)[tid] = 0ull;
+    else if constexpr (GW == 4) reinterpret_cast<uint32_t*>(s_guide)[tid] = 0u;
+    else s_guide[tid] = 0;
     __syncthreads();
     MP_STAMP(0, 9, 0);
     m = s_red[0];
@@ -486,9 +500,10 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     if (tid == 0) s_last = (tab.ticket != nullptr && my_ticket == gridDim.x - 1u) ? 1 : 0;
     __syncthreads();
     MP_STAMP(0, 15, 0);
-    if constexpr (THREADS == 256) reinterpret_cast<uint4*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint4*>(s_guide)[tid];
-    else if constexpr (THREADS == 512) reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
-    else mp_st_stream<8>(reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N) + tid, reinterpret_cast<const uint32_t*>(s_guide)[tid]);
+    if constexpr (GW == 16) reinterpret_cast<uint4*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint4*>(s_guide)[tid];
+    else if constexpr (GW == 8) reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];
+    else if constexpr (GW == 4) mp_st_stream<8>(reinterpret_cast<uint32_t*>(guide + tile * GUIDE_N) + tid, reinterpret_cast<const uint32_t*>(s_guide)[tid]);
+    else guide[tile * GUIDE_N + tid] = s_guide[tid];
     if (s_last) {   // workgroup-uniform: every other workgroup's scalars are out (their tickets precede ours)
 #ifndef MP_TEST_NOTABLE
         build_tile_table_global<THREADS>(tile_m, tile_W, tile_W2, (int)gridDim.x, tab);
