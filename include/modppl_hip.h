@@ -311,7 +311,7 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
  *   y_i ~ normal(a + b x_i [+ c x_i^2], 0.1) observed.
  * Static site ids (the stand-in for trie addresses): */
 enum mp_mh_site { MP_SITE_IS_LINEAR = 0, MP_SITE_A = 1, MP_SITE_B = 2, MP_SITE_C = 3, MP_SITE_Y0 = 4 /* "(y, k)" = MP_SITE_Y0 + k */ };
-enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1, MP_MH_MODEL_POINTED_2D = 2 };
+enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1, MP_MH_MODEL_POINTED_2D = 2, MP_MH_MODEL_HIERARCHICAL_FN = 101 /* mp_mh_create_fn */ };
 enum mp_mh_proposal_kind {
     MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1, /* hierarchical_drift_proposal(tr, drift_std): hierarchical.rs:62-70; args = {drift_std} */
     MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE = 2, /* add_or_remove_param_proposal(tr): hierarchical.rs:48-61, the structure-changing move of
@@ -352,6 +352,25 @@ int32_t mp_mh_read_logjp(mp_mh* h, double* out);
 /* The "(y, i)" choices of every chain's trace -> out[n_chains][n_data]: the data passed to mp_mh_create until an empty-mask
  * regenerate re-simulated them (hierarchical model only). */
 int32_t mp_mh_read_observations(mp_mh* h, double* out);
+/* ---- mh / regen_mh for REGISTERED generative functions (modppl_amd/csrc/mp_mh_models.h) ----
+ * The reference's mh / regen_mh take ANY model and proposal written with `dyngen!` (mh.rs:9-75 over DynGenFn::update /
+ * regenerate / propose / assess, dyngenfn.rs:143-273, 321-446, 453-483, 523-583).  The static counterpart: a model or proposal is one
+ * functor over the handler of mp_genfn.h (sites = compile-time ids, sub-calls = `call<SITES>`), registered with
+ * MP_REGISTER_MH_MODEL / MP_REGISTER_MH_PROPOSAL; the library instantiates the Simulate / Generate / Update / Regenerate
+ * kernels for it.  Kind 101 is the hierarchical model again, written that way (params = xs[0 .. n_data); proposal kinds 1, 2 as
+ * above): it must and does reproduce the hand-written kernels bit for bit (tests/test_gpu_mh.py).
+ * Initial traces: model.generate(args, constraints) per chain, constraints = (site id, value) pairs, Philox step 0.
+ * A constraint on a site the model does not visit is the reference's panic: MP_ERR_STATE (also from the step functions when
+ * a move reaches such a case; the chains keep whatever the kernel left). */
+int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                        int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out);
+/* Number of site ids of the model (the row width of mp_mh_read_trace). */
+int32_t mp_mh_n_sites(mp_mh* h, int32_t* out);
+/* Every chain's trace: values[n_chains][n_sites] (0 where the site is absent) and present[n_chains] (bit k = site k is in the
+ * trace).  mp_mh_step (proposal kinds registered for the model), mp_regen_mh_step (mask_sites = any site ids; cycle and the
+ * empty mask as above), mp_mh_read_logjp, mp_mh_iterations and mp_mh_destroy apply to these handles; mp_mh_read_state and
+ * mp_mh_read_observations do not. */
+int32_t mp_mh_read_trace(mp_mh* h, double* values, uint32_t* present);
 /* MH iterations applied so far (the Philox step of the next iteration is this + 1). */
 int32_t mp_mh_iterations(mp_mh* h, uint64_t* out);
 int32_t mp_mh_destroy(mp_mh* h);

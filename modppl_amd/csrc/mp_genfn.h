@@ -1,0 +1,219 @@
+// mp_genfn.h — static generative functions for the MH kernels: ONE functor over a handler type, four interpretations.
+//
+// In modppl a model or proposal is a closure over `DynGenFnHandler` and `simulate / generate / update / regenerate` are
+// four interpretations of it (modppl/src/modeling/dyngenfn.rs:39-93).  Here it is a functor
+//
+//     template <class H> MP_HD void operator()(H& g) const                      (a model)
+//     template <class H, class T> MP_HD void operator()(H& g, const T& tr) const (a proposal: `tr` is the trace it reads)
+//
+// whose addresses are compile-time site ids 0 .. NS-1 (NS <= 32) and whose choices are doubles (a bool is 0 / 1):
+//     g.template normal<SITE>(mu, sd, ln_sd)     `normal(mu, sd) %= addr`    -> sample_at (dyngenfn.rs:100-273)
+//     g.template bernoulli<SITE>(p)              `bernoulli(p) %= addr`
+//     g.template call<SITES>(body)               `gen_fn(args) /= addr`      -> trace_at  (dyngenfn.rs:283-449);
+//                                                SITES = bit set of the sites of the sub-trace, body = [&](H& g) { ...; return retv; }
+// A trace is the dense row mp_fn_trace<NS> (value, log-density and a presence bit per site) kept in registers: every site id
+// is a template argument, so after inlining each slot is a scalar and the slots a model never touches do not exist.
+//
+// The handler restates the weight rules of sample_at / trace_at / gc, in the reference's order of operations:
+//   SIMULATE   x ~ dist; the trace's score (`propose`'s weight, trace.logjp) += logp                       (:106-114)
+//   GENERATE   constrained: x = constraint, weight += logp; free: x ~ dist                                 (:116-141)
+//   UPDATE     constrained: weight -= prev.logp (the old choice goes to the discard), weight += logp, diff = Unknown;
+//              free with a previous value: diff NoChange -> kept as it is; diff Unknown -> weight += logp - prev.logp;
+//              free without one: x ~ dist, diff = Unknown.  gc: unvisited previous sites leave, weight - their logp  (:143-211, 453-470)
+//   REGENERATE masked: x ~ dist, diff = Unknown, no weight; unmasked: as a free site of UPDATE; gc without weight   (:213-273)
+//   call       the sub-call's weight is accumulated from 0, closed by its own gc, and added to the caller's as ONE term;
+//              a constrained / masked / new sub-call sets the caller's diff to Unknown; an untouched one under NoChange is
+//              replayed (its body runs, every site returns its previous value: the static form of `return retv`)     (:321-446)
+// What is NOT restated: `Regenerate` through an unmasked sub-call after an upstream change (generate(args, sub) against the
+// sub-trie's running weight, :424-428) and leftover constraints — both raise `panic`, which the kernels report as an error.
+#pragma once
+#include "mp_dists.h"
+
+#define MP_FN_MAX_SITES 32
+
+template <int NS>
+struct mp_fn_trace {
+    double val[NS];
+    double lp[NS];
+    uint32_t present;
+    MP_HD bool has(int site) const { return (present >> site) & 1u; }
+    // tr.data.read(addr) of a proposal body; `dflt` when the address is absent (hierarchical.rs:54-58 `search`)
+    MP_HD double get(int site, double dflt) const { return has(site) ? val[site] : dflt; }
+};
+template <int NS>
+MP_HD void mp_fn_clear(mp_fn_trace<NS>& t) {
+    t.present = 0u;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { t.val[k] = 0.; t.lp[k] = 0.; }
+}
+// trace.logjp: the choices' log-densities in site order
+template <int NS>
+MP_HD double mp_fn_logjp(const mp_fn_trace<NS>& t) {
+    double s = 0.;
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+        if (t.has(k)) { s = first ? t.lp[k] : s + t.lp[k]; first = false; }
+    return s;
+}
+
+struct mp_fn_normal {
+    double mu, sd, ln_sd;
+    MP_HD double sample(mp_site& st) const { return mp_normal_sample(st, mu, sd); }
+    MP_HD double logpdf(double x) const { return mp_normal_logpdf_ln(x, mu, sd, ln_sd); }
+};
+struct mp_fn_bernoulli {
+    double p;
+    MP_HD double sample(mp_site& st) const { return mp_bernoulli_sample(st, p) ? 1. : 0.; }
+    MP_HD double logpdf(double x) const { return mp_bernoulli_logpdf(x != 0., p); }
+};
+
+enum mp_fn_mode { MP_FN_SIMULATE = 0, MP_FN_GENERATE = 1, MP_FN_UPDATE = 2, MP_FN_REGENERATE = 3 };
+
+template <int NS, int MODE>
+struct mp_fn_handler {
+    static_assert(NS <= MP_FN_MAX_SITES, "site ids are bits of a 32-bit word");
+    const mp_stream& rng;
+    uint32_t dom;                     // Philox domain of this function's draws (MP_DOM_MODEL / MP_DOM_PROPOSAL); site id = site
+    const mp_fn_trace<NS>* prev;      // UPDATE / REGENERATE: the previous trace
+    const mp_fn_trace<NS>* cons;      // GENERATE / UPDATE: the constraints (presence bits + values)
+    uint32_t mask;                    // REGENERATE: the masked sites
+    mp_fn_trace<NS> tr;               // the trace being built
+    double weight;                    // SIMULATE: the trace's score
+    bool changed;                     // diff == ArgDiff::Unknown
+    uint32_t visited, consumed, discarded;
+    bool panic;
+
+    MP_HD mp_fn_handler(const mp_stream& r, uint32_t dom_, const mp_fn_trace<NS>* prev_, const mp_fn_trace<NS>* cons_, uint32_t mask_ = 0u)
+        : rng(r), dom(dom_), prev(prev_), cons(cons_), mask(mask_), weight(0.), changed(false), visited(0u), consumed(0u), discarded(0u),
+          panic(false) {
+        mp_fn_clear(tr);
+    }
+    MP_HD double exp_(double x) const { return mp_exp(x); }
+    MP_HD double log_(double x) const { return mp_log(x); }
+
+    template <int SITE, class Dist>
+    MP_HD double at(const Dist& d) {
+        static_assert(SITE >= 0 && SITE < NS, "site id out of range");
+        constexpr uint32_t bit = 1u << SITE;
+        visited |= bit;
+        double x, lp;
+        if constexpr (MODE == MP_FN_SIMULATE) {
+            mp_site st(rng, dom, (uint32_t)SITE);
+            x = d.sample(st);
+            lp = d.logpdf(x);
+            weight += lp;
+        } else if constexpr (MODE == MP_FN_GENERATE) {
+            if (cons->present & bit) {
+                consumed |= bit;
+                x = cons->val[SITE];
+                lp = d.logpdf(x);
+                weight += lp;
+            } else {
+                mp_site st(rng, dom, (uint32_t)SITE);
+                x = d.sample(st);
+                lp = d.logpdf(x);
+            }
+        } else {
+            const bool had = (prev->present & bit) != 0u;
+            bool fresh = false;   // drawn from the distribution
+            if constexpr (MODE == MP_FN_UPDATE) {
+                if (cons->present & bit) {
+                    consumed |= bit;
+                    if (had) { weight -= prev->lp[SITE]; discarded |= bit; }
+                    x = cons->val[SITE];
+                    lp = d.logpdf(x);
+                    changed = true;
+                    weight += lp;
+                    tr.val[SITE] = x; tr.lp[SITE] = lp; tr.present |= bit;
+                    return x;
+                }
+            } else {
+                fresh = (mask & bit) != 0u;
+            }
+            if (!fresh && had) {
+                x = prev->val[SITE];
+                if (!changed) {
+                    lp = prev->lp[SITE];   // NoChange: the call goes back into the trace as it was
+                } else {
+                    lp = d.logpdf(x);
+                    weight += lp - prev->lp[SITE];
+                }
+            } else {
+                mp_site st(rng, dom, (uint32_t)SITE);
+                x = d.sample(st);
+                lp = d.logpdf(x);
+                changed = true;
+            }
+        }
+        tr.val[SITE] = x; tr.lp[SITE] = lp; tr.present |= bit;
+        return x;
+    }
+    template <int SITE>
+    MP_HD double normal(double mu, double sd, double ln_sd) { return at<SITE>(mp_fn_normal{mu, sd, ln_sd}); }
+    template <int SITE>
+    MP_HD double normal(double mu, double sd) { return at<SITE>(mp_fn_normal{mu, sd, mp_log(sd)}); }
+    template <int SITE>
+    MP_HD bool bernoulli(double p) { return at<SITE>(mp_fn_bernoulli{p}) != 0.; }
+
+    // previous choices of `sites` that this visit did not reach: they leave the trace; their log-densities in site order
+    MP_HD double collect(uint32_t sites) {
+        const uint32_t un = prev->present & sites & ~visited;
+        double c = 0.;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if ((un >> k) & 1u) c += prev->lp[k];
+        discarded |= un;
+        return c;
+    }
+
+    template <uint32_t SITES, class Body>
+    MP_HD auto call(Body&& body) {
+        if constexpr (MODE == MP_FN_SIMULATE) {
+            return body(*this);   // the sub-trace's choices are the caller's; `propose`'s weight is the whole trie's
+        } else if constexpr (MODE == MP_FN_GENERATE) {
+            // generate(args, choices): weight += d_weight as one term (:316-319); simulate when nothing is constrained
+            const double w_out = weight;
+            const bool any = (cons->present & SITES) != 0u;
+            weight = 0.;
+            auto r = body(*this);
+            weight = any ? w_out + weight : w_out;
+            return r;
+        } else {
+            const uint32_t had = prev->present & SITES;
+            uint32_t touched;
+            if constexpr (MODE == MP_FN_UPDATE) touched = cons->present & SITES;
+            else touched = mask & SITES;
+            const double w_out = weight;
+            if (!touched && had && !changed) {
+                auto r = body(*this);   // replay: every site returns its previous value and log-density
+                weight = w_out;
+                changed = false;
+                return r;
+            }
+            if (MODE == MP_FN_REGENERATE && !touched && had) panic = true;   // generate(args, sub) - sub.weight(): not restated
+            weight = 0.;
+            auto r = body(*this);
+            if (had) {
+                const double c = collect(SITES);
+                if constexpr (MODE == MP_FN_UPDATE) weight = weight - c;
+            }
+            weight = (touched || had) ? w_out + weight : w_out;
+            changed = true;
+            return r;
+        }
+    }
+
+    // the outer gc of update / regenerate (dyngenfn.rs:453-483); constraints nobody consumed are the reference's panic
+    MP_HD void finish() {
+        if constexpr (MODE == MP_FN_UPDATE) {
+            const double c = collect(0xFFFFFFFFu);
+            weight = weight - c;
+            if (cons->present & ~consumed) panic = true;
+        } else if constexpr (MODE == MP_FN_REGENERATE) {
+            (void)collect(0xFFFFFFFFu);
+        } else if constexpr (MODE == MP_FN_GENERATE) {
+            if (cons->present & ~consumed) panic = true;
+        }
+    }
+};

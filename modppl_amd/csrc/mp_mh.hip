@@ -377,6 +377,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_pointed_logjp(u64 n, pointed_par
     out[i] = pointed_prior(P, x) + mp_mvnormal_logpdf_pre<2>(P.obs, x, P.cov_inv, P.ln_det_cov);
 }
 
+struct mh_fn_ops;   // mp_mh_fn.h: chains of a registered generative function
 struct mp_mh {
     u64 n = 0, seed = 0;
     int device = 0;
@@ -392,7 +393,24 @@ struct mp_mh {
     pointed_params pointed{};
     double* lat = nullptr;   // pointed model: [n][2]
     double* ys_chain = nullptr;   // [n][n_data]: per-chain "(y, i)" choices once an empty-mask regenerate re-simulated them
+    std::shared_ptr<mh_fn_ops> fn;   // registered function: the trace table below replaces the fields above
+    double* fvals = nullptr;         // [n_sites][n]
+    uint32_t* fpresent = nullptr;    // [n]
 };
+#include "mp_mh_fn.h"
+
+// acceptance count (and, for registered functions, the count of chains that reached a state the reference panics on)
+static int32_t mh_finish(mp_mh* h, uint64_t* accepted) {
+    if (!accepted && !h->fn) return MP_OK;
+    u64 tot[2] = {0, 0};
+    MHCK(hipMemcpyAsync(tot, h->d_acc, sizeof(u64) * (h->fn ? 2 : 1), hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipStreamSynchronize(h->stream));
+    if (accepted) *accepted = tot[0];
+    if (tot[1])
+        return mp_set_error(MP_ERR_STATE, std::to_string(tot[1]) + " chain-moves reached a case the reference panics on or this layer does not restate "
+                            "(constraints nobody consumed, or regenerate through an unmasked sub-call after an upstream change: mp_genfn.h)");
+    return MP_OK;
+}
 
 extern "C" {
 
@@ -496,8 +514,104 @@ int32_t mp_mh_create_pointed(const double* bounds, const double* obs_cov, const 
     return MP_OK;
 }
 
+int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                        int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out) {
+    if (!out) return mp_set_error(MP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    auto it = mh_fn_models().find(model_kind);
+    if (it == mh_fn_models().end()) return mp_set_error(MP_ERR_UNSUPPORTED, "no generative function of this kind is registered (MP_REGISTER_MH_MODEL, mp_mh_models.h)");
+    if (n_params < 0 || (n_params > 0 && !params)) return mp_set_error(MP_ERR_INVALID_ARG, "bad params");
+    if (n_constraints < 0 || (n_constraints > 0 && (!constraint_sites || !constraint_values))) return mp_set_error(MP_ERR_INVALID_ARG, "bad constraints");
+    if (n_chains == 0 || n_chains > 0xFFFFFFFFull) return mp_set_error(MP_ERR_INVALID_ARG, "n_chains must be in [1, 2^32)");
+    std::string err;
+    std::shared_ptr<mh_fn_ops> ops = it->second(params, n_params, err);
+    if (!ops) return mp_set_error(MP_ERR_INVALID_ARG, err);
+    mp_fn_consspec cs{};
+    for (int q = 0; q < n_constraints; ++q) {
+        const int s = constraint_sites[q];
+        if (s < 0 || s >= ops->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "constraint site out of range");
+        if (cs.bits & (1u << s)) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
+        cs.bits |= 1u << s;
+        cs.val[s] = constraint_values[q];
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return mp_set_error(MP_ERR_HIP, "no HIP device visible: the gfx950 path has no CPU fallback");
+    }
+    struct Cleanup { void operator()(mp_mh* p) const { (void)mp_mh_destroy(p); } };
+    std::unique_ptr<mp_mh, Cleanup> h(new mp_mh());
+    h->kind = model_kind;
+    h->fn = ops;
+    h->n = n_chains; h->seed = seed; h->device = device;
+    MHCK(hipSetDevice(device));
+    if (stream) h->stream = (hipStream_t)stream;
+    else { MHCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    MHCK(hipMalloc(&h->fvals, sizeof(double) * n_chains * (size_t)ops->ns()));
+    MHCK(hipMalloc(&h->fpresent, sizeof(uint32_t) * n_chains));
+    MHCK(hipMalloc(&h->tmp, sizeof(double) * n_chains));
+    MHCK(hipMalloc(&h->d_acc, sizeof(u64) * 2));
+    MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64) * 2, h->stream));
+    const int32_t rc = ops->init(h.get(), cs);
+    if (rc != MP_OK) return rc;
+    const int32_t rf = mh_finish(h.get(), nullptr);   // a constraint on a site the model never visits is the reference's panic
+    if (rf != MP_OK) return rf;
+    *out = h.release();
+    return MP_OK;
+}
+
+int32_t mp_mh_n_sites(mp_mh* h, int32_t* out) {
+    if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
+    if (!h->fn) return mp_set_error(MP_ERR_UNSUPPORTED, "chains of a registered generative function only (mp_mh_create_fn)");
+    *out = h->fn->ns();
+    return MP_OK;
+}
+
+int32_t mp_mh_read_trace(mp_mh* h, double* values, uint32_t* present) {
+    if (!h || !values || !present) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
+    if (!h->fn) return mp_set_error(MP_ERR_UNSUPPORTED, "chains of a registered generative function only (mp_mh_create_fn)");
+    MHCK(hipSetDevice(h->device));
+    const int ns = h->fn->ns();
+    std::vector<double> v((size_t)ns * h->n);
+    MHCK(hipMemcpyAsync(v.data(), h->fvals, sizeof(double) * v.size(), hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipMemcpyAsync(present, h->fpresent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipStreamSynchronize(h->stream));
+    for (u64 i = 0; i < h->n; ++i)
+        for (int k = 0; k < ns; ++k) values[i * (u64)ns + k] = v[(size_t)k * h->n + i];
+    return MP_OK;
+}
+
+static int32_t mh_fn_step(mp_mh* h, int32_t proposal_kind, const double* args, int32_t n_args, int32_t n_iters, uint64_t* accepted) {
+    if (n_iters < 0) return mp_set_error(MP_ERR_INVALID_ARG, "n_iters < 0");
+    if (n_args < 0 || (n_args > 0 && !args)) return mp_set_error(MP_ERR_INVALID_ARG, "bad proposal_args");
+    MHCK(hipSetDevice(h->device));
+    MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64) * 2, h->stream));
+    const int32_t rc = h->fn->mh(h, proposal_kind, args, n_args, n_iters);
+    if (rc != MP_OK) return rc;
+    h->iters += (u64)n_iters;
+    return mh_finish(h, accepted);
+}
+static int32_t mh_fn_regen(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
+    if (n_iters < 0) return mp_set_error(MP_ERR_INVALID_ARG, "n_iters < 0");
+    if (n_mask < 0 || n_mask > MP_FN_MAX_SITES || (n_mask > 0 && !mask_sites)) return mp_set_error(MP_ERR_INVALID_ARG, "bad mask");
+    mp_fn_maskspec m{};
+    for (int q = 0; q < n_mask; ++q) {
+        if (mask_sites[q] < 0 || mask_sites[q] >= h->fn->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "mask site out of range");
+        m.bits |= 1u << mask_sites[q];
+        m.cycle[q] = (unsigned char)mask_sites[q];
+    }
+    m.n_cycle = (cycle && n_mask > 0) ? n_mask : 0;
+    MHCK(hipSetDevice(h->device));
+    MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64) * 2, h->stream));
+    const int32_t rc = h->fn->regen(h, m, n_iters);
+    if (rc != MP_OK) return rc;
+    h->iters += (u64)n_iters;
+    return mh_finish(h, accepted);
+}
+
 int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, int32_t n_iters, uint64_t* accepted) {
     if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
+    if (h->fn) return mh_fn_step(h, proposal_kind, proposal_args, n_proposal_args, n_iters, accepted);
     mh_mask none{};
     if (proposal_kind == MP_MH_PROPOSAL_POINTED_DRIFT) {
         if (h->kind != MP_MH_MODEL_POINTED_2D) return mp_set_error(MP_ERR_INVALID_ARG, "pointed_2d_drift_proposal needs chains of the pointed 2-D model");
@@ -539,7 +653,8 @@ int32_t mp_mh_step(mp_mh* h, int32_t proposal_kind, const double* proposal_args,
 
 int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
     if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
-    if (h->kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_UNSUPPORTED, "regen_mh is compiled for the hierarchical model only");
+    if (h->fn) return mh_fn_regen(h, mask_sites, n_mask, cycle, n_iters, accepted);
+    if (h->kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_UNSUPPORTED, "regen_mh: the hierarchical model's hand-written kernels, or chains of a registered function (mp_mh_create_fn)");
     if (n_mask < 0 || (n_mask > 0 && !mask_sites)) return mp_set_error(MP_ERR_INVALID_ARG, "bad mask");
     if (n_mask == 0) {
         // empty mask = the trace's whole schema (dyngenfn.rs:571): every site, the observed ones included, is redrawn
@@ -575,6 +690,7 @@ int32_t mp_regen_mh_step(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, in
 
 int32_t mp_mh_read_state(mp_mh* h, double* out) {
     if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
+    if (h->fn) return mp_set_error(MP_ERR_UNSUPPORTED, "chains of a registered generative function: mp_mh_read_trace");
     MHCK(hipSetDevice(h->device));
     if (h->kind == MP_MH_MODEL_POINTED_2D) {
         MHCK(hipMemcpyAsync(out, h->lat, sizeof(double) * 2 * h->n, hipMemcpyDeviceToHost, h->stream));
@@ -595,7 +711,10 @@ int32_t mp_mh_read_state(mp_mh* h, double* out) {
 int32_t mp_mh_read_logjp(mp_mh* h, double* out) {
     if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
     MHCK(hipSetDevice(h->device));
-    if (h->kind == MP_MH_MODEL_POINTED_2D)
+    if (h->fn) {
+        const int32_t rc = h->fn->logjp(h);
+        if (rc != MP_OK) return rc;
+    } else if (h->kind == MP_MH_MODEL_POINTED_2D)
         hipLaunchKernelGGL(k_pointed_logjp, dim3((unsigned)((h->n + MH_THREADS - 1) / MH_THREADS)), dim3(MH_THREADS), 0, h->stream, h->n, h->pointed, h->lat,
                            h->tmp);
     else
@@ -609,7 +728,7 @@ int32_t mp_mh_read_logjp(mp_mh* h, double* out) {
 
 int32_t mp_mh_read_observations(mp_mh* h, double* out) {
     if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
-    if (h->kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_UNSUPPORTED, "the hierarchical model's (y, i) choices");
+    if (h->fn || h->kind != MP_MH_MODEL_HIERARCHICAL) return mp_set_error(MP_ERR_UNSUPPORTED, "the hierarchical model's (y, i) choices (registered functions: mp_mh_read_trace)");
     MHCK(hipSetDevice(h->device));
     if (h->ys_chain) {
         MHCK(hipMemcpyAsync(out, h->ys_chain, sizeof(double) * h->n * (size_t)h->data.n, hipMemcpyDeviceToHost, h->stream));
@@ -632,7 +751,7 @@ int32_t mp_mh_destroy(mp_mh* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->is_lin); (void)hipFree(h->a); (void)hipFree(h->b); (void)hipFree(h->c); (void)hipFree(h->tmp); (void)hipFree(h->d_acc);
-    (void)hipFree(h->lat); (void)hipFree(h->ys_chain);
+    (void)hipFree(h->lat); (void)hipFree(h->ys_chain); (void)hipFree(h->fvals); (void)hipFree(h->fpresent);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;

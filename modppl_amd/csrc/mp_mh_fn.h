@@ -1,0 +1,244 @@
+// mp_mh_fn.h — mh / regen_mh for REGISTERED generative functions (mp_mh_models.h): the kernels below are the four GFI
+// interpretations of mp_genfn.h applied to whatever functor a registration names, so a new model or proposal needs no kernel.
+// Included by mp_mh.hip (after struct mp_mh); not a public header.
+//
+//   K7g k_fn_mh<Model, Proposal>   metropolis_hastings (modppl/src/inference/mh.rs:9-40):
+//         (fwd_choices, fwd) = proposal.propose(trace)          -> SIMULATE, Philox domain MP_DOM_PROPOSAL
+//         (trace', discard, w) = model.update(trace, NoChange, fwd_choices) -> UPDATE (+ gc)
+//         bwd = proposal.assess(trace', discard)                -> GENERATE with the discard as constraints
+//         accept iff ln u < w - fwd + bwd                       -> MP_DOM_ACCEPT site 0
+//   K7h k_fn_regen<Model>          regenerative_metropolis_hastings (mh.rs:54-67): REGENERATE, accept iff ln u < w; an empty
+//         mask is the trace's whole schema (dyngenfn.rs:571)
+// One lane = one chain; the trace lives in registers for all n_iters iterations of a launch and in a site-major table
+// vals[site][chain] + present[chain] between launches (log-densities are recomputed on load: GENERATE with every choice
+// constrained).  Philox: chain = slot, iteration (1-based) = step, site id = site — the addressing of the hand-written kernels.
+#pragma once
+#include <functional>
+#include <map>
+
+#include "mp_genfn.h"
+
+struct mp_fn_maskspec {
+    uint32_t bits;      // cycle == 0: the masked sites (0 = empty mask = whole schema)
+    int n_cycle;        // > 0: iteration k masks only cycle[k % n_cycle]
+    unsigned char cycle[MP_FN_MAX_SITES];
+};
+struct mp_fn_consspec {
+    uint32_t bits;
+    double val[MP_FN_MAX_SITES];
+};
+
+template <class M>
+__device__ __forceinline__ void fn_load(const M& model, const mp_stream& s, u64 i, u64 n, const double* __restrict__ vals,
+                                        const uint32_t* __restrict__ present, mp_fn_trace<M::NS>& out) {
+    mp_fn_trace<M::NS> c;
+    c.present = present[i];
+#pragma unroll
+    for (int k = 0; k < M::NS; ++k) {
+        c.val[k] = ((c.present >> k) & 1u) ? vals[(u64)k * n + i] : 0.;
+        c.lp[k] = 0.;
+    }
+    mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+    model(g);
+    out = g.tr;
+}
+template <int NS>
+__device__ __forceinline__ void fn_store(const mp_fn_trace<NS>& t, u64 i, u64 n, double* __restrict__ vals, uint32_t* __restrict__ present) {
+    present[i] = t.present;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) vals[(u64)k * n + i] = t.has(k) ? t.val[k] : 0.;
+}
+__device__ __forceinline__ void fn_count(u64 acc, bool panic, u64* __restrict__ totals) {
+    u64 p = panic ? 1ull : 0ull;
+    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); p += __shfl_xor(p, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (acc) atomicAdd(totals, acc);
+        if (p) atomicAdd(totals + 1, p);
+    }
+}
+
+// model.generate(args, constraints) per chain (tests/mh.rs:91), Philox step 0
+template <class M>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_init(u64 n, uint32_t k0, uint32_t k1, M model, mp_fn_consspec cs, double* __restrict__ vals,
+                                                        uint32_t* __restrict__ present, u64* __restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    bool panic = false;
+    if (i < n) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = 0;
+        mp_fn_trace<M::NS> c;
+        c.present = cs.bits;
+#pragma unroll
+        for (int k = 0; k < M::NS; ++k) { c.val[k] = cs.val[k]; c.lp[k] = 0.; }
+        mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+        model(g);
+        g.finish();
+        panic = g.panic;
+        fn_store(g.tr, i, n, vals, present);
+    }
+    fn_count(0, panic, totals);
+}
+
+template <class M>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_logjp(u64 n, M model, const double* __restrict__ vals, const uint32_t* __restrict__ present,
+                                                         double* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    mp_stream s;
+    s.k0 = 0; s.k1 = 0; s.slot = 0; s.step = 0;   // nothing is drawn: every choice is constrained
+    mp_fn_trace<M::NS> cur;
+    fn_load(model, s, i, n, vals, present, cur);
+    out[i] = mp_fn_logjp(cur);
+}
+
+template <class M>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_regen(u64 n, uint32_t k0, uint32_t k1, uint32_t iter0, int n_iters, M model, mp_fn_maskspec mask,
+                                                         double* __restrict__ vals, uint32_t* __restrict__ present, u64* __restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    u64 acc = 0;
+    bool panic = false;
+    if (i < n) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = 0;
+        mp_fn_trace<M::NS> cur;
+        fn_load(model, s, i, n, vals, present, cur);
+        for (int it = 0; it < n_iters; ++it) {
+            s.step = iter0 + (uint32_t)it;
+            uint32_t m = mask.bits;
+            if (mask.n_cycle > 0) m = 1u << mask.cycle[(iter0 - 1u + (uint32_t)it) % (uint32_t)mask.n_cycle];
+            if (m == 0u) m = cur.present;   // mask.is_leaf(): the whole schema (dyngenfn.rs:571)
+            mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
+            model(g);
+            g.finish();
+            panic |= g.panic;
+            const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
+            if (mp_log(mp_u01(ub.a)) < g.weight) {   // mh.rs:62
+                cur = g.tr;
+                ++acc;
+            }
+        }
+        fn_store(cur, i, n, vals, present);
+    }
+    fn_count(acc, panic, totals);
+}
+
+template <class M, class P>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_mh(u64 n, uint32_t k0, uint32_t k1, uint32_t iter0, int n_iters, M model, P proposal,
+                                                      double* __restrict__ vals, uint32_t* __restrict__ present, u64* __restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    u64 acc = 0;
+    bool panic = false;
+    if (i < n) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = 0;
+        mp_fn_trace<M::NS> cur;
+        fn_load(model, s, i, n, vals, present, cur);
+        for (int it = 0; it < n_iters; ++it) {
+            s.step = iter0 + (uint32_t)it;
+            mp_fn_handler<M::NS, MP_FN_SIMULATE> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
+            proposal(p, cur);
+            const double fwd = p.weight;
+            mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &cur, &p.tr);
+            model(g);
+            g.finish();
+            // the discard: the previous values of what update replaced or collected
+            mp_fn_trace<M::NS> disc = cur;
+            disc.present = g.discarded;
+            mp_fn_handler<M::NS, MP_FN_GENERATE> q(s, MP_DOM_PROPOSAL, nullptr, &disc);
+            proposal(q, g.tr);
+            q.finish();
+            panic |= g.panic | q.panic;
+            const double alpha = g.weight - fwd + q.weight;   // mh.rs:34
+            const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
+            if (mp_log(mp_u01(ub.a)) < alpha) {
+                cur = g.tr;
+                ++acc;
+            }
+        }
+        fn_store(cur, i, n, vals, present);
+    }
+    fn_count(acc, panic, totals);
+}
+
+// ---------------------------------------------------------------------------------------
+// registry: model kind -> factory; (model type, proposal kind) -> launcher
+// ---------------------------------------------------------------------------------------
+struct mh_fn_ops {
+    virtual ~mh_fn_ops() {}
+    virtual int ns() const = 0;
+    virtual int32_t init(mp_mh* h, const mp_fn_consspec& cs) = 0;
+    virtual int32_t regen(mp_mh* h, const mp_fn_maskspec& m, int n_iters) = 0;
+    virtual int32_t mh(mp_mh* h, int proposal_kind, const double* args, int n_args, int n_iters) = 0;
+    virtual int32_t logjp(mp_mh* h) = 0;
+};
+static inline unsigned fn_grid(const mp_mh* h) { return (unsigned)((h->n + MH_THREADS - 1) / MH_THREADS); }
+
+template <class M>
+using mh_fn_launcher = std::function<int32_t(mp_mh*, const M&, const double*, int, int)>;
+template <class M>
+static std::map<int, mh_fn_launcher<M>>& mh_fn_proposals() {
+    static std::map<int, mh_fn_launcher<M>> r;
+    return r;
+}
+template <class M>
+struct mh_fn_ops_t : mh_fn_ops {
+    M model;
+    int ns() const override { return M::NS; }
+    int32_t init(mp_mh* h, const mp_fn_consspec& cs) override {
+        hipLaunchKernelGGL(k_fn_init<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), model, cs,
+                           h->fvals, h->fpresent, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    }
+    int32_t regen(mp_mh* h, const mp_fn_maskspec& m, int n_iters) override {
+        hipLaunchKernelGGL(k_fn_regen<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
+                           (uint32_t)(h->iters + 1), n_iters, model, m, h->fvals, h->fpresent, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    }
+    int32_t mh(mp_mh* h, int proposal_kind, const double* args, int n_args, int n_iters) override {
+        auto& reg = mh_fn_proposals<M>();
+        auto it = reg.find(proposal_kind);
+        if (it == reg.end()) return mp_set_error(MP_ERR_UNSUPPORTED, "no proposal of this kind is registered for the model (MP_REGISTER_MH_PROPOSAL)");
+        return it->second(h, model, args, n_args, n_iters);
+    }
+    int32_t logjp(mp_mh* h) override {
+        hipLaunchKernelGGL(k_fn_logjp<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, model, (const double*)h->fvals,
+                           (const uint32_t*)h->fpresent, h->tmp);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    }
+};
+
+typedef std::function<std::shared_ptr<mh_fn_ops>(const double*, int, std::string&)> mh_fn_factory;
+static std::map<int, mh_fn_factory>& mh_fn_models() {
+    static std::map<int, mh_fn_factory> r;
+    return r;
+}
+template <class M>
+static int mp_mh_register_model(int kind, bool (*parse)(const double*, int, M&, std::string&)) {
+    static_assert(std::is_trivially_copyable<M>::value, "a model functor travels to the kernels by value");
+    mh_fn_models()[kind] = [parse](const double* params, int n, std::string& err) -> std::shared_ptr<mh_fn_ops> {
+        auto ops = std::make_shared<mh_fn_ops_t<M>>();
+        if (!parse(params, n, ops->model, err)) return nullptr;
+        return ops;
+    };
+    return kind;
+}
+template <class M, class P>
+static int mp_mh_register_proposal(int kind, bool (*parse)(const double*, int, P&, std::string&)) {
+    static_assert(std::is_trivially_copyable<P>::value, "a proposal functor travels to the kernels by value");
+    mh_fn_proposals<M>()[kind] = [parse](mp_mh* h, const M& model, const double* args, int n_args, int n_iters) -> int32_t {
+        P prop;
+        std::string err;
+        if (!parse(args, n_args, prop, err)) return mp_set_error(MP_ERR_INVALID_ARG, err);
+        hipLaunchKernelGGL((k_fn_mh<M, P>), dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
+                           (uint32_t)(h->iters + 1), n_iters, model, prop, h->fvals, h->fpresent, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    };
+    return kind;
+}
+#define MP_REGISTER_MH_MODEL(KIND, TYPE, PARSE) static const int mp_mh_registered_##TYPE = mp_mh_register_model<TYPE>(KIND, PARSE);
+#define MP_REGISTER_MH_PROPOSAL(KIND, MODEL, TYPE, PARSE) static const int mp_mh_registered_##TYPE = mp_mh_register_proposal<MODEL, TYPE>(KIND, PARSE);
+#include "mp_mh_models.h"

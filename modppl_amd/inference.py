@@ -224,7 +224,9 @@ class HierarchicalChains:
     _ADDR = {"coeffs/a": capi.MP_SITE_A, "coeffs / a": capi.MP_SITE_A, "coeffs/b": capi.MP_SITE_B, "coeffs / b": capi.MP_SITE_B,
              "coeffs/c": capi.MP_SITE_C, "coeffs / c": capi.MP_SITE_C, "is_linear": capi.MP_SITE_IS_LINEAR}
 
-    def __init__(self, xs, ys, num_chains, seed, *, constrain_is_linear=None, device=0, stream=None):
+    def __init__(self, xs, ys, num_chains, seed, *, constrain_is_linear=None, device=0, stream=None, functor=False):
+        """functor=True: the same model as a REGISTERED generative function (csrc/mp_mh_models.h, kind 101) run by the
+        generic Update / Regenerate handlers instead of the hand-written kernels — same calls, same results bit for bit."""
         self._L = capi.load()
         xs = np.ascontiguousarray(xs, dtype=np.float64)
         ys = np.ascontiguousarray(ys, dtype=np.float64)
@@ -232,6 +234,14 @@ class HierarchicalChains:
             raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "xs and ys must be 1-D arrays of equal length")
         self.num_chains = int(num_chains)
         self._n_data = len(xs)
+        self._fn = None
+        if functor:
+            cons = {capi.MP_SITE_Y0 + k: float(y) for k, y in enumerate(ys)}
+            if constrain_is_linear is not None:
+                cons[capi.MP_SITE_IS_LINEAR] = float(bool(constrain_is_linear))
+            self._fn = FunctionChains(capi.MP_MH_MODEL_HIERARCHICAL_FN, xs, cons, num_chains, seed, device=device, stream=stream)
+            self._h = self._fn._h
+            return
         c = -1 if constrain_is_linear is None else int(bool(constrain_is_linear))
         h = C.c_void_p()
         capi.check(self._L.mp_mh_create(capi.MP_MH_MODEL_HIERARCHICAL, _dptr(xs), _dptr(ys), len(xs), c, self.num_chains, int(seed), int(device),
@@ -261,6 +271,11 @@ class HierarchicalChains:
 
     def states(self):
         """[num_chains, 4] = is_linear, a, b, c  (read_coeffs of hierarchical.rs:5-16)."""
+        if self._fn is not None:
+            vals, present = self._fn.trace()
+            out = vals[:, :4].copy()
+            assert np.all(present & 0b111 == 0b111) and np.all(((present >> 3) & 1) == (vals[:, 0] == 0.0))   # c is there iff quadratic
+            return out
         out = np.empty((self.num_chains, 4))
         capi.check(self._L.mp_mh_read_state(self._h, _dptr(out)))
         return out
@@ -273,8 +288,78 @@ class HierarchicalChains:
     def observations(self):
         """[num_chains, n_data]: the "(y, i)" choices of every chain's trace (the data, until regen_mh with an empty mask
         — the trace's whole schema, dyngenfn.rs:571 — re-simulated them)."""
+        if self._fn is not None:
+            return self._fn.trace()[0][:, capi.MP_SITE_Y0:capi.MP_SITE_Y0 + self._n_data].copy()
         out = np.empty((self.num_chains, self._n_data))
         capi.check(self._L.mp_mh_read_observations(self._h, _dptr(out)))
+        return out
+
+    @property
+    def iterations(self):
+        it = C.c_uint64()
+        capi.check(self._L.mp_mh_iterations(self._h, C.byref(it)))
+        return it.value
+
+    def close(self):
+        if getattr(self, "_fn", None) is not None:
+            self._fn.close()
+            self._h = None
+        if getattr(self, "_h", None):
+            self._L.mp_mh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FunctionChains:
+    """N independent MH chains over a REGISTERED generative function (csrc/mp_mh_models.h: a functor over the static
+    handler of csrc/mp_genfn.h, `MP_REGISTER_MH_MODEL`), the counterpart of calling the reference's `mh` / `regen_mh`
+    (modppl/src/inference/mh.rs:9-75) with a model and proposal of one's own.  Sites are integer ids.
+
+        constraints = {site: value}: creation runs model.generate(params, constraints) per chain."""
+
+    def __init__(self, model_kind, params, constraints, num_chains, seed, *, device=0, stream=None):
+        self._L = capi.load()
+        params = np.ascontiguousarray(params, dtype=np.float64).ravel()
+        sites = np.array(sorted(constraints), dtype=np.int32)
+        vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
+        self.num_chains = int(num_chains)
+        h = C.c_void_p()
+        capi.check(self._L.mp_mh_create_fn(int(model_kind), _dptr(params) if params.size else None, int(params.size),
+                                           sites.ctypes.data_as(C.POINTER(C.c_int32)) if sites.size else None, _dptr(vals) if sites.size else None,
+                                           int(sites.size), self.num_chains, int(seed), int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        ns = C.c_int32()
+        capi.check(self._L.mp_mh_n_sites(self._h, C.byref(ns)))
+        self.num_sites = ns.value
+
+    def mh(self, proposal_kind, proposal_args=(), n_iters=1):
+        a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
+        acc = C.c_uint64()
+        capi.check(self._L.mp_mh_step(self._h, int(proposal_kind), _dptr(a) if a.size else None, int(a.size), int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def regen_mh(self, mask, n_iters=1, cycle=False):
+        sites = [int(m) for m in mask]
+        m = (C.c_int32 * max(len(sites), 1))(*sites)
+        acc = C.c_uint64()
+        capi.check(self._L.mp_regen_mh_step(self._h, m if sites else None, len(sites), int(cycle), int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def trace(self):
+        """(values [num_chains, num_sites], present [num_chains] uint32: bit k = site k is in the chain's trace)"""
+        vals = np.empty((self.num_chains, self.num_sites))
+        present = np.empty(self.num_chains, dtype=np.uint32)
+        capi.check(self._L.mp_mh_read_trace(self._h, _dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return vals, present
+
+    def logjp(self):
+        out = np.empty(self.num_chains)
+        capi.check(self._L.mp_mh_read_logjp(self._h, _dptr(out)))
         return out
 
     @property

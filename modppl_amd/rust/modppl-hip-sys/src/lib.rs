@@ -49,6 +49,16 @@ pub struct mp_shard {
     pub n_global: u64,
     pub slot_offset: u64,
 }
+/// The two collectives of the sharded resample as plain C function pointers (include/modppl_hip.h: `mp_transport`).
+#[repr(C)]
+pub struct mp_transport {
+    pub ctx: *mut c_void,
+    pub all_gather: Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64,
+                                               stream: *mut c_void) -> i32>,
+    pub all_to_all: Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, send_off: *const u64, send_bytes: *const u64,
+                                               d_recv: *mut c_void, recv_off: *const u64, recv_bytes: *const u64, world: i32,
+                                               stream: *mut c_void) -> i32>,
+}
 #[repr(C)]
 pub struct mp_pf { _private: [u8; 0] }
 #[repr(C)]
@@ -93,6 +103,20 @@ extern "C" {
     pub fn mp_pf_shard_owned_count(h: *mut mp_pf, scheme: i32, d_tiles_all: *const u64, world: i32, rank: i32, capacity: u64, counts_out: *mut u64) -> i32;
     pub fn mp_pf_shard_owned_expand(h: *mut mp_pf, world: i32, rank: i32, capacity: u64, d_send_out: *mut f64, d_rows: *mut f64, recv_rows: u64) -> i32;
     pub fn mp_pf_shard_owned_commit(h: *mut mp_pf, d_rows: *const f64, log_total_weight: *mut f64, counts_out: *mut u64) -> i32;
+    // the whole sharded resample behind one call (the collectives go through `mp_transport`, or RCCL directly)
+    pub fn mp_pf_shard_resample(h: *mut mp_pf, t: *const mp_transport, world: i32, rank: i32, scheme: i32, force_collectives: i32,
+                                log_total_weight: *mut f64) -> i32;
+    pub fn mp_pf_shard_resample_rccl(h: *mut mp_pf, nccl_comm: *mut c_void, world: i32, rank: i32, scheme: i32, force_collectives: i32,
+                                     log_total_weight: *mut f64) -> i32;
+    pub fn mp_pf_shard_query_native(h: *mut mp_pf, t: *const mp_transport, world: i32, force_collectives: i32, log_ml: *mut f64,
+                                    ess: *mut f64) -> i32;
+    pub fn mp_pf_shard_resample_stats(h: *mut mp_pf, fallbacks: *mut u64, exchange_rows: *mut u64, counts_out: *mut u64,
+                                      capacity: *mut u64) -> i32;
+    pub fn mp_transport_rccl(nccl_comm: *mut c_void, out: *mut mp_transport) -> i32;
+    pub fn mp_rccl_unique_id(out128: *mut c_void) -> i32;
+    pub fn mp_rccl_comm_create(world: i32, rank: i32, id128: *const c_void, device: i32, comm_out: *mut *mut c_void) -> i32;
+    pub fn mp_rccl_comm_destroy(comm: *mut c_void) -> i32;
+    pub fn mp_pf_stream_copy(h: *mut mp_pf, dst: *mut c_void, src: *const c_void, bytes: u64, to_host: i32) -> i32;
     // per-kernel-family hipEvent timing (bench)
     pub fn mp_pf_set_timing(h: *mut mp_pf, enabled: i32) -> i32;
     pub fn mp_pf_get_timing(h: *mut mp_pf, family: i32, total_ms: *mut f64, launches: *mut u64) -> i32;
@@ -112,6 +136,11 @@ extern "C" {
     pub fn mp_mh_read_state(h: *mut mp_mh, out: *mut f64) -> i32;
     pub fn mp_mh_read_logjp(h: *mut mp_mh, out: *mut f64) -> i32;
     pub fn mp_mh_read_observations(h: *mut mp_mh, out: *mut f64) -> i32;
+    // chains of a registered generative function (csrc/mp_mh_models.h)
+    pub fn mp_mh_create_fn(model_kind: i32, params: *const f64, n_params: i32, constraint_sites: *const i32, constraint_values: *const f64,
+                           n_constraints: i32, n_chains: u64, seed: u64, device: i32, stream: *mut c_void, out: *mut *mut mp_mh) -> i32;
+    pub fn mp_mh_n_sites(h: *mut mp_mh, out: *mut i32) -> i32;
+    pub fn mp_mh_read_trace(h: *mut mp_mh, values: *mut f64, present: *mut u32) -> i32;
     pub fn mp_mh_iterations(h: *mut mp_mh, out: *mut u64) -> i32;
     pub fn mp_mh_destroy(h: *mut mp_mh) -> i32;
 }

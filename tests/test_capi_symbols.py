@@ -85,7 +85,7 @@ def test_rust_sys_crate_declares_every_entry_point():
 
 # ---- signatures, not just names: header <-> Rust -sys crate <-> ctypes binding ---------------------------------------------
 _C2RUST = {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "double": "f64", "void": "c_void", "char": "c_char",
-           "mp_pf": "mp_pf", "mp_mh": "mp_mh", "mp_model_desc": "mp_model_desc", "mp_shard": "mp_shard"}
+           "mp_pf": "mp_pf", "mp_mh": "mp_mh", "mp_model_desc": "mp_model_desc", "mp_shard": "mp_shard", "mp_transport": "mp_transport"}
 
 
 def _c_type_to_rust(t):

@@ -16,11 +16,26 @@ def make_ys(seed=0):
     return 0.3 + 0.4 * XS + 0.5 * XS * XS + 0.1 * rng.normal(size=XS.size)  # tests/mh.rs:84-87
 
 
+# Every test below runs twice: over the hand-written kernels (k_mh_iterate) and over the SAME model and proposals written as
+# registered functors (csrc/mp_mh_models.h) and run by the generic Update / Regenerate / Simulate / Generate handlers of
+# csrc/mp_genfn.h (k_fn_mh, k_fn_regen) — both against the oracle's dynamic-trie engine, bit for bit.
+@pytest.fixture(params=[False, True], ids=["handwritten", "functor"], autouse=True)
+def engine(request):
+    global FUNCTOR
+    if request.param and "pointed" in request.node.name:
+        pytest.skip("the pointed model has hand-written kernels only")
+    FUNCTOR = request.param
+    yield request.param
+
+
+FUNCTOR = False
+
+
 def pair(n, seed, constrain):
     import modppl_amd
 
     ys = make_ys()
-    g = modppl_amd.HierarchicalChains(XS, ys, n, seed, constrain_is_linear=constrain)
+    g = modppl_amd.HierarchicalChains(XS, ys, n, seed, constrain_is_linear=constrain, functor=FUNCTOR)
     o = O.OracleMH(XS, ys, n, seed, -1 if constrain is None else int(constrain), canonical=True)
     assert np.array_equal(g.states(), o.state())
     return g, o
@@ -97,10 +112,12 @@ def test_unsupported_masks():
     import modppl_amd
     from modppl_amd import capi
 
-    g = modppl_amd.HierarchicalChains(XS, make_ys(), 16, 1)
+    g = modppl_amd.HierarchicalChains(XS, make_ys(), 16, 1, functor=FUNCTOR)
     with pytest.raises(modppl_amd.ModpplError) as e:
         g.regen_mh(["is_linear"])
-    assert e.value.code == capi.MP_ERR_UNSUPPORTED
+    # hand-written kernels: refused up front; generic handlers: the move runs into regenerate through the unmasked `coeffs`
+    # sub-call after an upstream change (generate(args, sub), where quadratic -> linear panics in the reference): reported
+    assert e.value.code == (capi.MP_ERR_STATE if FUNCTOR else capi.MP_ERR_UNSUPPORTED)
 
 
 def test_regen_mh_empty_mask_regenerates_every_site():
@@ -131,7 +148,7 @@ def test_c4_full_size_posterior():
 
     ys = make_ys()
     n = 1 << 20
-    g = modppl_amd.HierarchicalChains(XS, ys, n, 3, constrain_is_linear=False)
+    g = modppl_amd.HierarchicalChains(XS, ys, n, 3, constrain_is_linear=False, functor=FUNCTOR)
     g.regen_mh(["coeffs/a", "coeffs/b", "coeffs/c"], 30, cycle=True)
     acc = 0
     for std in (0.5, 0.1, 0.02):
@@ -182,3 +199,32 @@ def test_pointed_2d_posterior_full_size():
     cov = np.cov(st.T)
     assert np.allclose(st.mean(axis=0), 0.0, atol=0.01)
     assert np.allclose(cov, np.array(OBS_COV), atol=0.03)
+
+
+def test_function_chains_argument_checks():
+    """mp_mh_create_fn / registered proposals: unknown kinds, bad constraints and a constraint the model never visits."""
+    import modppl_amd
+    from modppl_amd import capi
+
+    ys = make_ys()
+    cons = {capi.MP_SITE_Y0 + k: y for k, y in enumerate(ys)}
+    with pytest.raises(modppl_amd.ModpplError) as e:
+        modppl_amd.FunctionChains(999, XS, cons, 8, 1)
+    assert e.value.code == capi.MP_ERR_UNSUPPORTED
+    with pytest.raises(modppl_amd.ModpplError) as e:
+        modppl_amd.FunctionChains(capi.MP_MH_MODEL_HIERARCHICAL_FN, XS, {25: 0.0}, 8, 1)
+    assert e.value.code == capi.MP_ERR_INVALID_ARG
+    with pytest.raises(modppl_amd.ModpplError) as e:   # "(y, 12)" with 11 data points: generate leaves the constraint unconsumed
+        modppl_amd.FunctionChains(capi.MP_MH_MODEL_HIERARCHICAL_FN, XS, {**cons, capi.MP_SITE_Y0 + 12: 1.0}, 8, 1)
+    assert e.value.code == capi.MP_ERR_STATE
+    g = modppl_amd.FunctionChains(capi.MP_MH_MODEL_HIERARCHICAL_FN, XS, cons, 64, 1)
+    assert g.num_sites == 20
+    with pytest.raises(modppl_amd.ModpplError) as e:
+        g.mh(77)
+    assert e.value.code == capi.MP_ERR_UNSUPPORTED
+    with pytest.raises(modppl_amd.ModpplError) as e:
+        g.mh(capi.MP_MH_PROPOSAL_HIERARCHICAL_DRIFT, [-1.0])
+    assert e.value.code == capi.MP_ERR_INVALID_ARG
+    vals, present = g.trace()
+    assert np.array_equal(vals[:, capi.MP_SITE_Y0:capi.MP_SITE_Y0 + 11], np.tile(ys, (64, 1)))
+    assert np.all((present >> capi.MP_SITE_Y0) == (1 << 11) - 1)
