@@ -417,6 +417,9 @@ struct mp_pf {
     uint32_t* sh_blockcount = nullptr;
     uint32_t* sh_blockoff = nullptr;
     long long* sh_counts = nullptr;
+    mp_tab_part* sh_tab_part = nullptr;   // [SH_MAX_WORLD] k_shard_table_mw: every rank's {sum T, sum T2}
+    unsigned int* sh_tab_ticket = nullptr;   // counts up by `world` per launch
+    unsigned int sh_tab_seq = 0;
     long long* h_counts = nullptr;  // pinned
     int sh_world = 0;
     u64 sh_cap = 0;                 // fixed-capacity exchange: request slots per (src, dst) pair
@@ -442,7 +445,6 @@ struct mp_pf {
     uint32_t* ow_seg_row = nullptr;       // start row of the forward scan
     uint32_t* ow_sccnt = nullptr;         // own draws per super-chunk, and their exclusive scan
     uint32_t* ow_base = nullptr;
-    uint32_t* ow_cnt_r = nullptr;         // [ow_nsc][world] offspring per rank (multinomial)
     unsigned long long* ow_call = nullptr;   // offspring per rank [SH_MAX_WORLD]
     mp_owned_plan* ow_plan = nullptr;
     mp_own_range* ow_range = nullptr;
@@ -1242,7 +1244,7 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     if (h->sh_dest && h->sh_world >= world && h->sh_cap >= cap && h->sh_tm_all) return MP_OK;
     (void)hipFree(h->sh_dest); (void)hipFree(h->sh_lt); (void)hipFree(h->sh_tile); (void)hipFree(h->sh_req_slot); (void)hipFree(h->sh_blockcount);
     (void)hipFree(h->sh_blockoff); (void)hipFree(h->sh_counts); (void)hipFree(h->sh_tm_all); (void)hipFree(h->sh_tW_all); (void)hipFree(h->sh_tW2_all); (void)hipFree(h->sh_incl_all); (void)hipFree(h->sh_ratio_all);
-    (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done);
+    (void)hipFree(h->sh_overflow); (void)hipFree(h->sh_done); (void)hipFree(h->sh_tab_part); (void)hipFree(h->sh_tab_ticket);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     const u64 slots = std::max<u64>(h->n, (u64)world * SH_BINS * cap);
     HIPCK(hipMalloc(&h->sh_dest, h->n));
@@ -1260,6 +1262,10 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     HIPCK(hipMalloc(&h->sh_ratio_all, sizeof(double) * (size_t)h->nt * world));
     HIPCK(hipMalloc(&h->sh_overflow, sizeof(int)));
     HIPCK(hipMalloc(&h->sh_done, 2 * sizeof(unsigned int)));
+    HIPCK(hipMalloc(&h->sh_tab_part, sizeof(mp_tab_part) * SH_MAX_WORLD));
+    HIPCK(hipMalloc(&h->sh_tab_ticket, sizeof(unsigned int)));
+    HIPCK(hipMemsetAsync(h->sh_tab_ticket, 0, sizeof(unsigned int), h->stream));
+    h->sh_tab_seq = 0;
     HIPCK(hipMemsetAsync(h->sh_done, 0, 2 * sizeof(unsigned int), h->stream));
     if (!h->scal_undo) HIPCK(hipMalloc(&h->scal_undo, sizeof(mp_dev_scalars)));
     HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
@@ -1297,6 +1303,23 @@ int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out) {
     return MP_OK;
 }
 
+// the job's tile table from the gathered tiles: one workgroup per rank in a world of several (k_shard_table_mw), one in all otherwise
+static void launch_shard_table(mp_pf* h, const u64* d_tiles_all, int world, unsigned long long* c_all, int scheme, int rank, mp_own_range* range,
+                               u64* kthr) {
+    static const bool one_wg = getenv("MP_SHARD_TABLE_ONE_WG") && atoi(getenv("MP_SHARD_TABLE_ONE_WG")) != 0;   // A/B
+    // (measured, 512 tiles per rank: one workgroup 8.3 us up to 4 ranks and 16.9 us at 8; one per rank 9.8 - 10.8 us at 2 .. 8)
+    if (world > 1 && !one_wg && (size_t)world * (size_t)h->nt > 2048) {
+        h->sh_tab_seq += (unsigned)world;
+        hipLaunchKernelGGL(k_shard_table_mw, dim3(world), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
+                           h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, c_all, scheme, rank,
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, range, kthr, h->sh_tab_part, h->sh_tab_ticket, h->sh_tab_seq);
+    } else {
+        hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
+                           h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, c_all, scheme, rank,
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, range, kthr);
+    }
+}
+
 int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
                                 uint64_t* d_req_out) {
     if (!h || !d_tiles_all || !d_req_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
@@ -1312,8 +1335,7 @@ int32_t mp_pf_shard_route_fixed(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     const int nt_all = h->nt * world;
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
-        hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
-                           h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo);
+        launch_shard_table(h, (const u64*)d_tiles_all, world, nullptr, 0, 0, nullptr, nullptr);
         const int nblk_f = (int)((h->n + SH_THREADS * SHF_ITEMS - 1) / (SH_THREADS * SHF_ITEMS));
         hipLaunchKernelGGL(k_shard_route_fused, dim3(nblk_f), dim3(SH_THREADS), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed,
                            (uint32_t)(h->seed >> 32), h->resample_count, (int)scheme, (const u64*)h->sh_incl_all, (const u64*)h->sh_tW_all, (const double*)h->sh_ratio_all,
@@ -1383,17 +1405,18 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
 // ---- "owner keeps" form: offspring stay with the rank that owns their parent; only the surplus travels ----
 static void owned_free(mp_pf* h) {
     (void)hipFree(h->ow_seg_lt); (void)hipFree(h->ow_seg_row);
-    (void)hipFree(h->ow_sccnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_cnt_r); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
+    (void)hipFree(h->ow_sccnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
     (void)hipFree(h->ow_range); (void)hipFree(h->ow_ticket); (void)hipFree(h->ow_kthr);
     h->ow_kthr = nullptr;
     h->ow_ticket = nullptr;
     h->ow_seg_lt = nullptr; h->ow_seg_row = nullptr;
-    h->ow_sccnt = nullptr; h->ow_base = nullptr; h->ow_cnt_r = nullptr; h->ow_call = nullptr; h->ow_plan = nullptr; h->ow_range = nullptr;
+    h->ow_sccnt = nullptr; h->ow_base = nullptr; h->ow_call = nullptr; h->ow_plan = nullptr; h->ow_range = nullptr;
 }
 // super-chunk shape of one resample: the multinomial draws of a rank are spread over all N draws, so a workgroup takes
 // min(world, 4) rounds of 1024 to collect ~1024 own ones; under a lattice scheme a rank's own draws are one contiguous range
 static void owned_shape(mp_pf* h, int world, int scheme) {
-    h->ow_R = scheme ? 1 : mp_own_rounds(world);
+    static const int r_env = getenv("MP_OWN_ROUNDS") ? atoi(getenv("MP_OWN_ROUNDS")) : 0;   // A/B
+    h->ow_R = scheme ? 1 : (r_env > 0 ? std::min(r_env, mp_own_rounds(world)) : mp_own_rounds(world));
     const u64 Wd = (u64)h->ow_R * OWN_ROUND;
     h->ow_nsc = (int)((h->n_global + Wd - 1) / Wd);
 }
@@ -1426,7 +1449,6 @@ static int32_t owned_scratch(mp_pf* h, int world) {
     }
     HIPCK(hipMalloc(&h->ow_sccnt, sizeof(uint32_t) * (size_t)h->ow_nsc));
     HIPCK(hipMalloc(&h->ow_base, sizeof(uint32_t) * (size_t)h->ow_nsc));
-    HIPCK(hipMalloc(&h->ow_cnt_r, sizeof(uint32_t) * (size_t)h->ow_nsc * world));
     HIPCK(hipMalloc(&h->ow_call, sizeof(unsigned long long) * SH_MAX_WORLD));
     HIPCK(hipMalloc(&h->ow_plan, sizeof(mp_owned_plan)));
     HIPCK(hipMalloc(&h->ow_range, sizeof(mp_own_range)));
@@ -1488,17 +1510,14 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         // A world of one: the job's tile table is the one the last workgroup of k_propagate / k_normalize_tiles built (as for
         // the unsharded resample); otherwise one workgroup builds it from the gathered tiles.
         const bool solo_tab = world == 1 && scheme == MP_RESAMPLE_MULTINOMIAL && (const void*)d_tiles_all == (const void*)h->tile_m && ensure_table(h);
-        if (!solo_tab)
-            hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, (const u64*)d_tiles_all, world, h->nt, h->S,
-                               h->n_global, h->sh_tm_all, h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo,
-                               h->ow_call, (int)scheme, rank, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, h->ow_range, h->ow_kthr);
+        if (!solo_tab) launch_shard_table(h, (const u64*)d_tiles_all, world, h->ow_call, (int)scheme, rank, h->ow_range, h->ow_kthr);
         const u64* t_incl = solo_tab ? (const u64*)h->tab_incl : (const u64*)h->sh_incl_all;
         const u64* t_W = solo_tab ? (const u64*)h->tile_W : (const u64*)h->sh_tW_all;
         const double* t_ratio = solo_tab ? (const double*)h->tab_ratio : (const double*)h->sh_ratio_all;
         mp_own_plan_args pa;
         pa.n = h->n; pa.n_global = h->n_global; pa.cap = (u64)capacity;
         pa.world = world; pa.nsc = h->ow_nsc; pa.lattice = scheme ? 1 : 0; pa.S = h->S;
-        pa.sccnt = h->ow_sccnt; pa.cnt_r = h->ow_cnt_r; pa.c_all = h->ow_call;
+        pa.sccnt = h->ow_sccnt; pa.c_all = h->ow_call;
         pa.scal = h->scal; pa.undo = h->scal_undo; pa.head = solo_tab ? (const mp_tab_head*)h->tab_head : nullptr;
         pa.base = h->ow_base; pa.plan_out = h->ow_plan; pa.pub = h->d_pub; pa.seq = ++h->ow_seq;
         pa.range = h->ow_range; pa.Wd = (u64)h->ow_R * OWN_ROUND;
@@ -1509,7 +1528,10 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         u64* win_lt = world == 1 ? h->dfr_lt : h->ow_seg_lt;
         uint32_t* win_row = world == 1 ? h->dfr_row : h->ow_seg_row;
         // lattice: a rank's own draws are ~n consecutive ones, wherever they start: that many workgroups (a rank that owns more takes turns)
-        const int own_wgs = scheme ? (int)std::min<u64>((u64)h->ow_nsc, 2 * ((h->n + OWN_ROUND - 1) / OWN_ROUND) + 2) : h->ow_nsc;
+        // multinomial: resident workgroups (3 per CU with the 44 KB of LDS at R = 4) take turns over the super-chunks, so the LDS table is
+        // filled once per workgroup and the per-rank counts leave as `world` atomics per workgroup
+        static const int mn_wgs = getenv("MP_OWN_WGS") ? atoi(getenv("MP_OWN_WGS")) : 768;
+        const int own_wgs = scheme ? (int)std::min<u64>((u64)h->ow_nsc, 2 * ((h->n + OWN_ROUND - 1) / OWN_ROUND) + 2) : std::min(h->ow_nsc, mn_wgs);
         h->ow_wgs = own_wgs;
         hipLaunchKernelGGL(kern, dim3(own_wgs), dim3(OWN_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
                            h->resample_count, (int)scheme, h->ow_R, t_incl, t_W, t_ratio, h->nt, world, rank, (const unsigned short*)h->guide,
@@ -1545,7 +1567,7 @@ int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t
     h->ow_last_cap = capacity;
     if (world > 1) {   // (a world of one: k_shard_own_draw wrote the slot-order arrays itself; nothing is sent or received)
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
-        const unsigned grid = (unsigned)std::max(1, std::min(h->ow_wgs, 2048));
+        const unsigned grid = (unsigned)std::max(1, std::min(h->ow_scheme ? h->ow_wgs : h->ow_nsc, 2048));
         auto kern = h->ow_scheme ? k_shard_own_place<true> : k_shard_own_place<false>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, h->stream, h->n, h->slot_offset, h->ops->dim_state, world, rank, h->ow_R, h->ow_nsc,
                            (u64)capacity, (const u64*)h->ow_seg_lt, (const uint32_t*)h->ow_seg_row, (const uint32_t*)h->ow_sccnt,

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
             while (K > 0ull && mp_target(K - 1ull, Q) > B) --K;          // (a few steps at most: the estimate is within a few units)
             while (K < top && mp_target(K, Q) <= B) ++K;
             kthr[tid] = K;
+            if (world > 1) c_all[tid] = 0ull;   // the draw kernel's workgroups add the offspring per rank up
         }
     }
     if (c_all && scheme) {
@@ -385,6 +386,158 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
             const u64 B = s_bound[tid];
             u64 lo = 0, hi = n_global;
             while (lo < hi) {   // at most 33 probes
+                const u64 mid = lo + ((hi - lo) >> 1);
+                if (mp_target_lattice(scheme, mid, k32, rc, k0, k1, Q, n_global) <= B) lo = mid + 1;
+                else hi = mid;
+            }
+            s_G[tid] = lo;
+        }
+        __syncthreads();
+        if (tid < world) {
+            const u64 g0 = tid ? s_G[tid - 1] : 0ull;
+            c_all[tid] = s_G[tid] - g0;
+            if (tid == rank) { range->g_lo = g0; range->g_hi = s_G[tid]; }
+        }
+    }
+}
+// The same table by `world` workgroups (worlds of more than one rank): workgroup r takes rank r's nt_local tiles, so the
+// serial part no longer grows with the job (16.9 us for 8 x 512 tiles by one workgroup, profiles/r03/route_scale.txt).
+// Every workgroup finds the job's maximum itself (world x nt_local loads), quantises its own tiles, publishes its two sums
+// {sum T, sum T2} and a ticket (agent scope), waits until all `world` tickets of this launch are there — the workgroups are
+// co-resident: world <= 64 of them on 256 CUs — and adds the sums of the ranks before it to its local prefix.  Workgroup 0
+// then folds the scalars and works out the per-rank boundaries (thresholds / lattice ranges) exactly as the one-workgroup
+// form does.  `ticket` counts up by `world` per launch (never reset): this launch waits for `ticket_target`.
+struct mp_tab_part {
+    u64 Q, Q2;
+};
+__global__ __launch_bounds__(SHT_THREADS) void k_shard_table_mw(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
+                                                                double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
+                                                                u64* __restrict__ incl_all, double* __restrict__ ratio_all,
+                                                                long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
+                                                                unsigned long long* __restrict__ c_all, int scheme, int rank, uint32_t k0, uint32_t k1,
+                                                                uint32_t rc, mp_own_range* range, u64* __restrict__ kthr, mp_tab_part* __restrict__ part,
+                                                                unsigned int* __restrict__ ticket, unsigned int ticket_target) {
+    __shared__ double s_red[SHT_THREADS / 64];
+    __shared__ u64 s_wtot[SHT_THREADS / 64];
+    __shared__ u64 s_wtot2[SHT_THREADS / 64];
+    __shared__ u64 s_bound[SH_MAX_WORLD];
+    __shared__ u64 s_G[SH_MAX_WORLD];
+    __shared__ u64 s_off, s_Q, s_Q2;
+    const int nt = world * nt_local;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int me = (int)blockIdx.x;   // the rank whose tiles this workgroup quantises
+    if (me == 0 && tid < SH_MAX_KEYS) zero_counts[tid] = 0;
+    // the job's maximum: every tile maximum of the gathered buffer
+    double m = MP_NEG_INF;
+    for (int i = tid; i < nt; i += SHT_THREADS) {
+        const int r = i / nt_local, b = i - r * nt_local;
+        m = fmax(m, mp_u2f(packed[(u64)r * 3 * nt_local + b]));
+    }
+    // this rank's tiles: thread t owns tiles t * per .. t * per + per - 1 of them
+    const int per = (nt_local + SHT_THREADS - 1) / SHT_THREADS;   // <= SHT_PER
+    const int b0 = tid * per;
+    const u64* base = packed + (u64)me * 3 * nt_local;
+    double mb[SHT_PER];
+    u64 Wb[SHT_PER], W2b[SHT_PER];
+#pragma unroll
+    for (int j = 0; j < SHT_PER; ++j) {
+        const int b = b0 + j;
+        mb[j] = MP_NEG_INF; Wb[j] = 0; W2b[j] = 0;
+        if (j < per && b < nt_local) {
+            mb[j] = mp_u2f(base[b]);
+            Wb[j] = base[nt_local + b];
+            W2b[j] = base[2 * nt_local + b];
+            const int i = me * nt_local + b;
+            tm[i] = mb[j]; tW[i] = Wb[j]; tW2[i] = W2b[j];
+        }
+    }
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < SHT_THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
+    u64 pre[SHT_PER];
+    double ratio[SHT_PER];
+    u64 run = 0, run2 = 0;
+#pragma unroll
+    for (int j = 0; j < SHT_PER; ++j) {
+        const int b = b0 + j;
+        pre[j] = 0;
+        if (j < per && b < nt_local) {
+            const double f = ok ? mp_exp(mb[j] - m) : 0.;
+            const double f2 = ok ? mp_exp(2. * (mb[j] - m)) : 0.;
+            const u64 T = mp_quantize((double)Wb[j] * f * sc, 1.0);
+            run += T;
+            run2 += mp_quantize((double)W2b[j] * f2 * sc, 1.0);
+            pre[j] = run;
+            ratio[j] = (double)Wb[j] / (double)T;
+        }
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    const u64 tot2 = wave_sum_u64(run2);
+    if (lane == 63) s_wtot[wave] = incl;
+    if (lane == 0) s_wtot2[wave] = tot2;
+    __syncthreads();
+    u64 woff = 0, Qr = 0, Q2r = 0;
+#pragma unroll
+    for (int w = 0; w < SHT_THREADS / 64; ++w) {
+        if (w < wave) woff += s_wtot[w];
+        Qr += s_wtot[w];
+        Q2r += s_wtot2[w];
+    }
+    // publish this rank's sums, then wait for everybody's
+    if (tid == 0) {
+        mp_st_agent(&part[me].Q, Qr);
+        mp_st_agent(&part[me].Q2, Q2r);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sums are out before the ticket says so
+        (void)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_target) < 0) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    if (tid < world) {
+        const u64 q = mp_ld_agent(&part[tid].Q), q2 = mp_ld_agent(&part[tid].Q2);
+        // inclusive prefix over the ranks (world <= 64: one wave)
+        const u64 inc = wave_incl_scan_u64(q, lane);
+        const u64 t2 = wave_sum_u64(q2);
+        s_bound[tid] = inc;
+        if (tid == me) s_off = inc - q;
+        if (tid == world - 1) { s_Q = inc; s_Q2 = t2; }
+    }
+    __syncthreads();
+    const u64 off = s_off + woff + (incl - run);
+    const u64 Q = s_Q, Q2 = s_Q2;
+#pragma unroll
+    for (int j = 0; j < SHT_PER; ++j) {
+        const int b = b0 + j;
+        if (j < per && b < nt_local) { incl_all[me * nt_local + b] = off + pre[j]; ratio_all[me * nt_local + b] = ratio[j]; }
+    }
+    if (me != 0) return;
+    if (tid == 0) {
+        *undo = *scal;
+        fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+    }
+    if (c_all && kthr && scheme == 0) {
+        if (tid < world) {
+            const u64 B = s_bound[tid];
+            const u64 top = 1ull << 52;
+            double est = (double)B * 4503599627370496.0 / (double)Q;
+            u64 K = (est >= 4503599627370496.0) ? top : ((est >= 8.) ? (u64)est - 8ull : 0ull);
+            if (!(est == est)) K = 0ull;
+            while (K > 0ull && mp_target(K - 1ull, Q) > B) --K;
+            while (K < top && mp_target(K, Q) <= B) ++K;
+            kthr[tid] = K;
+            c_all[tid] = 0ull;   // the draw kernel's workgroups add the offspring per rank up
+        }
+    }
+    if (c_all && scheme) {
+        if (tid < world) {
+            const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+            const u64 B = s_bound[tid];
+            u64 lo = 0, hi = n_global;
+            while (lo < hi) {
                 const u64 mid = lo + ((hi - lo) >> 1);
                 if (mp_target_lattice(scheme, mid, k32, rc, k0, k1, Q, n_global) <= B) lo = mid + 1;
                 else hi = mid;
@@ -549,8 +702,7 @@ struct mp_own_plan_args {
     u64 n, n_global, cap;
     int world, nsc, lattice, S;
     uint32_t* sccnt;                 // [nsc] own draws per super-chunk (in), read with agent-scope loads
-    uint32_t* cnt_r;                 // [nsc][world] offspring per rank (multinomial)
-    unsigned long long* c_all;       // [world] in: lattice counts (k_shard_table); out: offspring per rank
+    unsigned long long* c_all;       // [world] offspring per rank: k_shard_table (lattice: closed form; multinomial: zeroed) + the draw kernel's atomics
     mp_dev_scalars* scal;
     mp_dev_scalars* undo;
     const mp_tab_head* head;         // world of one: the table k_propagate's last workgroup built is the job's table; k_shard_own_bin folds it
@@ -566,7 +718,6 @@ template <int THREADS>
 __device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a) {
     __shared__ mp_owned_plan pl;
     __shared__ u64 s_ptot[THREADS / 64];
-    __shared__ uint32_t s_part[THREADS / 64][SH_MAX_WORLD];
     __shared__ u64 s_c[SH_MAX_WORLD];
     __shared__ int s_over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -587,25 +738,8 @@ __device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a) {
         if (b0 + j < nsc) run += sccnt[b0 + j];
     const double scal_L = a.scal->L;
     const int scal_deg = a.scal->degenerate;
-    if (a.lattice) {   // k_shard_table found the counts in closed form
-        if (tid < world) s_c[tid] = a.c_all[tid];
-    } else {           // offspring per rank = column sums of the super-chunks' counts
-        for (int r = 0; r < world; ++r) {
-            uint32_t v = 0u;
-            for (int k = tid; k < nsc; k += THREADS) v += a.cnt_r[(u64)k * world + r];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) s_part[wave][r] = v;
-        }
-        __syncthreads();
-        if (tid < world) {
-            u64 v = 0;
-#pragma unroll
-            for (int w = 0; w < THREADS / 64; ++w) v += s_part[w][tid];
-            s_c[tid] = v;
-            a.c_all[tid] = v;
-        }
-    }
+    // offspring per rank: k_shard_table found them in closed form (lattice), or the draw kernel's workgroups added them up
+    if (tid < world) s_c[tid] = mp_ld_agent(reinterpret_cast<const u64*>(a.c_all) + tid);
     if (tid == 0) s_over = 0;
     __syncthreads();
     if (tid == 0) {
@@ -678,7 +812,6 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     __shared__ u64 s_bound[SH_MAX_WORLD];                               // inclusive prefix of T_b at the end of every rank's tiles
     __shared__ uint32_t s_above[OWN_NW][SH_MAX_WORLD];                  // per wave: draws whose target lies above s_bound[r]
     __shared__ uint32_t s_wown[OWN_NW];
-    __shared__ uint32_t s_cntr[SH_MAX_WORLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 Wd = (u64)R * OWN_ROUND;                                  // draws (and window entries) per super-chunk
     const u64* my_incl = incl_all + (u64)rank * nt_local;
@@ -694,7 +827,8 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     // multinomial: workgroup = super-chunk; lattice: the super-chunks that hold this rank's own range of draws, dealt round-robin
     // (LATTICE is a template parameter so that the multinomial form stays straight-line code: as a run-time loop it cost 15
     // more registers and 2 us)
-    int sc_first = 0, sc_last = (int)gridDim.x - 1;
+    // multinomial: every super-chunk of the job, dealt round-robin over the (resident) workgroups
+    int sc_first = 0, sc_last = pa.nsc - 1;
     if constexpr (LATTICE) mp_own_span(range, Wd, &sc_first, &sc_last);
     if constexpr (TABMODE == 1) {
         for (int b = tid; b < nt_local; b += OWN_THREADS) {
@@ -709,76 +843,86 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     const u64 klo = (by_k && rank) ? kthr[rank - 1] : 0ull, khi = by_k ? kthr[rank] : (1ull << 52);
     const bool count_all = scheme == 0 && world > 1;
     const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
-    for (int sc = sc_first + (int)blockIdx.x; sc <= sc_last; sc += (int)gridDim.x) {   // workgroup-uniform; one trip unless LATTICE
+    uint32_t above_acc = 0u;   // lane r: draws of this wave above boundary r (r < world - 1), over all super-chunks of this workgroup
+    u64 live_tot = 0;          // draws this workgroup enumerated (uniform)
+    for (int sc = sc_first + (int)blockIdx.x; sc <= sc_last; sc += (int)gridDim.x) {   // workgroup-uniform
     const u64 g_base = (u64)sc * Wd;
-    __syncthreads();   // s_bound and the LDS table are there (first trip); the previous super-chunk's LDS state is free (lattice)
-    uint32_t above_acc = 0u;   // lane r: draws of this wave above boundary r (r < world - 1)
-    uint32_t run = 0u;         // own draws of the rounds so far (uniform)
+    __syncthreads();   // s_bound and the LDS table are there (first trip); the previous super-chunk's LDS state is free
+    {
+        const u64 rest = n_global - g_base;
+        live_tot += rest < Wd ? rest : Wd;
+    }
+    uint32_t run = 0u;         // own draws of the rounds so far (lattice: of the workgroup; multinomial: of this wave)
+    uint32_t woff = 0u;        // multinomial: own draws of the waves before this one
+    uint32_t own_sc = 0u;
+    if constexpr (LATTICE) {
 #pragma unroll 1
     for (int rr = 0; rr < R; ++rr) {
         const u64 i0 = g_base + (u64)rr * OWN_ROUND + 2u * (u64)tid;   // even
-        // t0, t1: what is compacted — the targets (lattice), or the 52-bit uniforms (multinomial: their targets are worked out
-        // after the compaction, by full waves, for this rank's own draws only)
-        u64 t0, t1;
         const bool live0 = i0 < n_global, live1 = i0 + 1 < n_global;
-        bool mine0, mine1;
-        if constexpr (LATTICE) {
-            t0 = mp_target_lattice(scheme, i0, k32, rc, k0, k1, Q, n_global);
-            t1 = mp_target_lattice(scheme, i0 + 1, k32, rc, k0, k1, Q, n_global);
-            mine0 = live0 && t0 > lo && t0 <= hi;
-            mine1 = live1 && t1 > lo && t1 <= hi;
-        } else {
-            const mp_u64x2 blk = mp_resample_block(i0 >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
-            t0 = mp_u52(blk.a);
-            t1 = mp_u52(blk.b);
-            mine0 = live0 && t0 >= klo && t0 < khi;
-            mine1 = live1 && t1 >= klo && t1 < khi;
-            if (count_all) {
-                for (int r = 0; r + 1 < world; ++r) {
-                    const u64 Kr = s_bound[r];
-                    const uint32_t c = (uint32_t)__popcll(__ballot(live0 && t0 >= Kr)) + (uint32_t)__popcll(__ballot(live1 && t1 >= Kr));
-                    above_acc += (lane == r) ? c : 0u;
-                }
-            }
-        }
+        const u64 t0 = mp_target_lattice(scheme, i0, k32, rc, k0, k1, Q, n_global);
+        const u64 t1 = mp_target_lattice(scheme, i0 + 1, k32, rc, k0, k1, Q, n_global);
+        const bool mine0 = live0 && t0 > lo && t0 <= hi;
+        const bool mine1 = live1 && t1 > lo && t1 <= hi;
         // compaction in draw order: (round, wave, lane, slot of the pair) ascending IS g ascending
         const u64 m0 = __ballot(mine0), m1 = __ballot(mine1);
         const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
                              __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))));
         if (lane == 0) s_wown[wave] = (uint32_t)(__popcll(m0) + __popcll(m1));
         __syncthreads();
-        uint32_t woff = 0u, tot = 0u;
+        uint32_t wo = 0u, tot = 0u;
 #pragma unroll
         for (int w = 0; w < OWN_NW; ++w) {
             const uint32_t c = s_wown[w];
-            woff += (w < wave) ? c : 0u;
+            wo += (w < wave) ? c : 0u;
             tot += c;
         }
-        if (mine0) s_tgt[run + woff + pre] = t0;
-        if (mine1) s_tgt[run + woff + pre + (mine0 ? 1u : 0u)] = t1;
+        if (mine0) s_tgt[run + wo + pre] = t0;
+        if (mine1) s_tgt[run + wo + pre + (mine0 ? 1u : 0u)] = t1;
         run += tot;
         __syncthreads();
     }
-    const uint32_t own = run;
-    if (count_all) {
-        if (lane < world) s_above[wave][lane] = above_acc;
-        __syncthreads();
-        if (tid < world) {
-            const u64 rest = n_global - g_base;
-            const uint32_t live_all = (uint32_t)(rest < Wd ? rest : Wd);
-            uint32_t a_prev = 0u, a_me = 0u;
-#pragma unroll
-            for (int w = 0; w < OWN_NW; ++w) {
-                a_prev += tid ? s_above[w][tid - 1] : 0u;
-                a_me += (tid + 1 < world) ? s_above[w][tid] : 0u;
+    } else {
+    // multinomial: a WAVE takes R * 128 consecutive draws of the super-chunk and compacts its own ones — the 52-bit uniforms; their
+    // targets are worked out afterwards, for this rank's own draws only — into its segment of s_tgt: no barrier inside the
+    // enumeration, which is all a rank does for the (world - 1) / world of the draws that are not its own
+    u64* seg = s_tgt + (size_t)wave * ((size_t)R * 128u);
+    const u64 w_base = g_base + (u64)wave * ((u64)R * 128u);
+#pragma unroll 1
+    for (int rr = 0; rr < R; ++rr) {
+        const u64 i0 = w_base + (u64)rr * 128u + 2u * (u64)lane;   // even
+        const bool live0 = i0 < n_global, live1 = i0 + 1 < n_global;
+        const mp_u64x2 blk = mp_resample_block(i0 >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);
+        const u64 t0 = mp_u52(blk.a), t1 = mp_u52(blk.b);
+        const bool mine0 = live0 && t0 >= klo && t0 < khi;
+        const bool mine1 = live1 && t1 >= klo && t1 < khi;
+        if (count_all) {
+            for (int r = 0; r + 1 < world; ++r) {
+                const u64 Kr = s_bound[r];
+                const uint32_t c = (uint32_t)__popcll(__ballot(live0 && t0 >= Kr)) + (uint32_t)__popcll(__ballot(live1 && t1 >= Kr));
+                above_acc += (lane == r) ? c : 0u;
             }
-            if (tid == 0) a_prev = live_all;
-            s_cntr[tid] = a_prev - a_me;
         }
-        __syncthreads();
+        const u64 m0 = __ballot(mine0), m1 = __ballot(mine1);
+        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                             __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))));
+        if (mine0) seg[run + pre] = t0;
+        if (mine1) seg[run + pre + (mine0 ? 1u : 0u)] = t1;
+        run += (uint32_t)(__popcll(m0) + __popcll(m1));
     }
+    if (lane == 0) s_wown[wave] = run;
+    __syncthreads();
+    uint32_t tot = 0u;
+#pragma unroll
+    for (int w = 0; w < OWN_NW; ++w) {
+        const uint32_t c = s_wown[w];
+        woff += (w < wave) ? c : 0u;
+        tot += c;
+    }
+    own_sc = tot;
+    }
+    const uint32_t own = LATTICE ? run : own_sc;   // the super-chunk's count (`run`: the workgroup's under a lattice scheme, this wave's otherwise)
     if (tid == 0) pa.sccnt[sc] = own;   // this super-chunk's counts, for k_shard_own_plan
-    if (scheme == 0 && tid < world) pa.cnt_r[(u64)sc * world + tid] = world > 1 ? s_cntr[tid] : own;
     // ---- the compacted own draws, in draw order: target -> tile -> guide cell -> {tile-local target, start row}, written at the
     // draw's rank inside the super-chunk (k_shard_own_place, or in a world of one the next k_propagate itself, takes it from
     // there: the row lookups run under that kernel's arithmetic, as in the single filter) ----
@@ -788,16 +932,22 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
     const u64* t_W = TABMODE == 1 ? s_W_lds : my_W;
     const double* t_ratio = TABMODE == 1 ? s_ratio_lds : my_ratio;
     const double nt_over_span = (double)nt_local / (double)span;   // own > 0 implies span > 0
-    const u64 wbase = (u64)sc * Wd;
-    for (uint32_t jb = 0; jb < own; jb += OWN_ROUND) {   // uniform trip count
+    // lattice: the workgroup's entries dealt over all threads; multinomial: a wave's own entries over its lanes, placed behind
+    // those of the waves before it (draw order: the waves' sub-ranges ascend)
+    const u64 wbase = (u64)sc * Wd + (LATTICE ? 0u : woff);
+    const u64* ent = LATTICE ? s_tgt : s_tgt + (size_t)wave * ((size_t)R * 128u);
+    const uint32_t n_ent = LATTICE ? own : run;
+    const uint32_t stride = LATTICE ? (uint32_t)OWN_ROUND : 128u;
+    const uint32_t me = LATTICE ? (uint32_t)tid : (uint32_t)lane;
+    for (uint32_t jb = 0; jb < n_ent; jb += stride) {   // trip count uniform over the workgroup (lattice) / the wave (multinomial)
         uint32_t j[2], gslot[2], tile_of[2], j0[2];
         u64 lt[2];
         bool act[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            j[q] = jb + 2u * (uint32_t)tid + (uint32_t)q;   // a thread's two entries are adjacent: one 16-byte and one 8-byte store
-            act[q] = j[q] < own;
-            const u64 t = act[q] ? tgt_of(s_tgt[j[q]]) : lo + 1ull;
+            j[q] = jb + 2u * me + (uint32_t)q;
+            act[q] = j[q] < n_ent;
+            const u64 t = act[q] ? tgt_of(ent[j[q]]) : lo + 1ull;
             const u64 trel = t - lo;
             mp_locate_own(t_incl, t_W, t_ratio, (uint32_t)nt_local, TABMODE == 1 ? trel : t, trel, TABMODE == 1 ? 0ull : lo, nt_over_span,
                           &tile_of[q], &lt[q], &gslot[q]);
@@ -812,17 +962,36 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
             const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
             srow[q] = (uint32_t)tbase + jj;          // row where the forward scan starts
         }
-        if (act[1]) {
+        // a thread's two entries are adjacent: one 16-byte and one 8-byte store where the pair is aligned (lattice: wbase and j[0]
+        // are even; multinomial: the waves before may have left an odd count)
+        if (act[1] && (((wbase + j[0]) & 1ull) == 0ull)) {
             mp_u64v2 v2; v2.x = lt[0]; v2.y = lt[1];
-            *reinterpret_cast<mp_u64v2*>(win_lt + wbase + j[0]) = v2;      // wbase and j[0] are even: aligned
+            *reinterpret_cast<mp_u64v2*>(win_lt + wbase + j[0]) = v2;
             *reinterpret_cast<uint2*>(win_row + wbase + j[0]) = make_uint2(srow[0], srow[1]);
-        } else if (act[0]) {
-            win_lt[wbase + j[0]] = lt[0];
-            win_row[wbase + j[0]] = srow[0];
+        } else {
+            if (act[0]) { win_lt[wbase + j[0]] = lt[0]; win_row[wbase + j[0]] = srow[0]; }
+            if (act[1]) { win_lt[wbase + j[1]] = lt[1]; win_row[wbase + j[1]] = srow[1]; }
         }
     }
-    if constexpr (!LATTICE) break;
     __syncthreads();   // the next super-chunk of this workgroup reuses the LDS state
+    }
+    // multinomial in a world of several ranks: offspring per rank over this workgroup's super-chunks -> the job's counts
+    // (k_shard_table zeroed them; k_shard_own_plan reads them): world atomics per workgroup instead of a [super-chunk][rank]
+    // table for the plan to sum
+    if (count_all) {
+        if (lane < world) s_above[wave][lane] = above_acc;
+        __syncthreads();
+        if (tid < world) {
+            u64 a_prev = 0, a_me = 0;
+#pragma unroll
+            for (int w = 0; w < OWN_NW; ++w) {
+                a_prev += tid ? s_above[w][tid - 1] : 0u;
+                a_me += (tid + 1 < world) ? s_above[w][tid] : 0u;
+            }
+            if (tid == 0) a_prev = live_tot;
+            const u64 c = a_prev - a_me;
+            if (c) __hip_atomic_fetch_add(pa.c_all + tid, (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
