@@ -10,7 +10,11 @@
 //     g.template normal<SITE>(mu, sd, ln_sd)     `normal(mu, sd) %= addr`    -> sample_at (dyngenfn.rs:100-273)
 //     g.template bernoulli<SITE>(p)              `bernoulli(p) %= addr`
 //     g.template call<SITES>(body)               `gen_fn(args) /= addr`      -> trace_at  (dyngenfn.rs:283-449);
-//                                                SITES = bit set of the sites of the sub-trace, body = [&](H& g) { ...; return retv; }
+//                                                SITES = bit set of the sites of the sub-trace, body = [&](H& q) { ...; return mp_fn_ret{...}; }
+//                                                What the caller needs from the sub-call travels in that RETURN VALUE, never in
+//                                                captured variables: an untouched sub-call under diff NoChange is not executed by
+//                                                a dynamic interpreter (trace_at returns the stored retv, dyngenfn.rs:362-366), so a
+//                                                body's side effects would be lost there (here the body is replayed: same result).
 // A trace is the dense row mp_fn_trace<NS> (value, log-density and a presence bit per site) kept in registers: every site id
 // is a template argument, so after inlining each slot is a scalar and the slots a model never touches do not exist.
 //
@@ -30,6 +34,11 @@
 #include "mp_dists.h"
 
 #define MP_FN_MAX_SITES 32
+
+// the return value of a sub-call body (and of a model): up to four doubles
+struct mp_fn_ret {
+    double v[4];
+};
 
 template <int NS>
 struct mp_fn_trace {

@@ -1,7 +1,8 @@
 // mp_mh_models.h — models and proposals for mh / regen_mh written ONCE against the handler interface of mp_genfn.h
 // (the static stand-in for `dyngen!` bodies) and registered by one line each; nothing else to touch.
 //
-// A model is a functor `template <class H> void operator()(H& g) const` with `static constexpr int NS` sites; a proposal is
+// A model is a functor `template <class H> void operator()(H& g) const` with `static constexpr int NS` sites (plus `sub_of(site)` and
+// `is_bool(site)`, which only the checker's dynamic interpretation reads); a proposal is
 // `template <class H, class T> void operator()(H& g, const T& tr) const` over the SAME site ids (a proposal's addresses are the
 // model's: mh.rs:17-23 feeds its choices to model.update as constraints).  Both are trivially copyable (they travel to the
 // kernels by value) and are filled from the C ABI's double arrays by a parse function.
@@ -24,6 +25,10 @@ struct mp_hier_fn {
     static constexpr int NS = 4 + MAX_DATA;
     enum { IS_LINEAR = 0, A = 1, B = 2, C = 3, Y0 = 4 };   // = enum mp_mh_site
     static constexpr uint32_t COEFFS = (1u << A) | (1u << B) | (1u << C);   // the sub-trace at "coeffs"
+    // what a DYNAMIC interpretation of the functor needs to know about its sites (the CPU checker runs the same source through
+    // tries: oracle/src/mh_functor_adapter.hpp): the sub-call a site lives in (0: top level), and whether its value is a bool
+    static constexpr uint32_t sub_of(int site) { return (site >= A && site <= C) ? COEFFS : 0u; }
+    static constexpr bool is_bool(int site) { return site == IS_LINEAR; }
     int n;
     double xs[MAX_DATA];
     double ln_noise;   // mp_log(0.1)
@@ -39,15 +44,15 @@ struct mp_hier_fn {
     template <class H>
     MP_HD void operator()(H& g) const {
         const bool lin = g.template bernoulli<IS_LINEAR>(0.7);
-        double a = 0., b = 0., c = 0.;
-        // linear() / quadratic() /= "coeffs" (:17-30, :37, :42)
-        g.template call<COEFFS>([&](H& q) {
-            a = q.template normal<A>(0., 1., 0.);
-            b = q.template normal<B>(0., 1., 0.);
-            if (!lin) c = q.template normal<C>(0., 1., 0.);
-            return 0;
+        // let coeffs = linear() / quadratic() /= "coeffs" (:17-30, :37, :42): the coefficients are the sub-call's return value
+        const mp_fn_ret co = g.template call<COEFFS>([&](H& q) {
+            mp_fn_ret r{};
+            r.v[0] = q.template normal<A>(0., 1., 0.);
+            r.v[1] = q.template normal<B>(0., 1., 0.);
+            if (!lin) r.v[2] = q.template normal<C>(0., 1., 0.);
+            return r;
         });
-        ys<H, 0>(g, lin, a, b, c);
+        ys<H, 0>(g, lin, co.v[0], co.v[1], co.v[2]);
     }
 };
 inline bool mp_parse_hier_fn(const double* params, int n_params, mp_hier_fn& m, std::string& err) {
@@ -97,3 +102,87 @@ inline bool mp_parse_hier_add_or_remove_fn(const double*, int n_args, mp_hier_ad
     return true;
 }
 MP_REGISTER_MH_PROPOSAL(2, mp_hier_fn, mp_hier_add_or_remove_fn, mp_parse_hier_add_or_remove_fn)
+
+// ---------------------------------------------------------------------------------------
+// Robust regression with outlier indicators, kind 102 — a model that exists ONLY here (no hand-written kernel, no hand-written
+// restatement in the checker): the test of the generic layer proper.  The shape of Gen's MCMC tutorial model:
+//   line() /= "line":  slope ~ normal(0, 2) %= "slope";  intercept ~ normal(0, 2) %= "intercept"
+//   for k:  is_outlier_k ~ bernoulli(0.1) %= ("outlier", k);  y_k ~ normal(slope x_k + intercept, is_outlier_k ? 5 : 0.5) %= ("y", k)
+//   params = xs[0 .. n_data), n_data <= 12; the observations are constraints on the sites Y0 + k.
+// Moves: proposal 1 = drift of the line {std}; proposal 2 = flip of one indicator {k} (proposes the other value with
+// probability 0.95); regen_mh over any sites (block resimulation of indicators, of the line, or both).
+// ---------------------------------------------------------------------------------------
+struct mp_robust_line_fn {
+    static constexpr int MAX_DATA = 12;
+    static constexpr int NS = 2 + 2 * MAX_DATA;
+    enum { SLOPE = 0, INTERCEPT = 1, OUT0 = 2, Y0 = 2 + MAX_DATA };
+    static constexpr uint32_t LINE = (1u << SLOPE) | (1u << INTERCEPT);
+    static constexpr uint32_t sub_of(int site) { return site <= INTERCEPT ? LINE : 0u; }
+    static constexpr bool is_bool(int site) { return site >= OUT0 && site < Y0; }
+    int n;
+    double xs[MAX_DATA];
+    double ln_prior_sd, ln_sd_in, ln_sd_out;   // mp_log(2), mp_log(0.5), mp_log(5)
+
+    template <class H, int J>
+    MP_HD void points(H& g, double slope, double intercept) const {
+        if (J < n) {
+            const bool out = g.template bernoulli<OUT0 + J>(0.1);
+            g.template normal<Y0 + J>(slope * xs[J] + intercept, out ? 5. : 0.5, out ? ln_sd_out : ln_sd_in);
+        }
+        if constexpr (J + 1 < MAX_DATA) points<H, J + 1>(g, slope, intercept);
+    }
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        const mp_fn_ret line = g.template call<LINE>([&](H& q) {
+            mp_fn_ret r{};
+            r.v[0] = q.template normal<SLOPE>(0., 2., ln_prior_sd);
+            r.v[1] = q.template normal<INTERCEPT>(0., 2., ln_prior_sd);
+            return r;
+        });
+        points<H, 0>(g, line.v[0], line.v[1]);
+    }
+};
+inline bool mp_parse_robust_line_fn(const double* params, int n_params, mp_robust_line_fn& m, std::string& err) {
+    if (!params || n_params < 1 || n_params > mp_robust_line_fn::MAX_DATA) { err = "robust line: params = xs[0 .. n_data), 1 <= n_data <= 12"; return false; }
+    m.n = n_params;
+    for (int k = 0; k < mp_robust_line_fn::MAX_DATA; ++k) m.xs[k] = k < n_params ? params[k] : 0.;
+    m.ln_prior_sd = mp_log(2.); m.ln_sd_in = mp_log(0.5); m.ln_sd_out = mp_log(5.);
+    return true;
+}
+MP_REGISTER_MH_MODEL(102, mp_robust_line_fn, mp_parse_robust_line_fn)
+
+struct mp_robust_line_drift_fn {
+    double sd, ln_sd;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        g.template normal<mp_robust_line_fn::SLOPE>(tr.val[mp_robust_line_fn::SLOPE], sd, ln_sd);
+        g.template normal<mp_robust_line_fn::INTERCEPT>(tr.val[mp_robust_line_fn::INTERCEPT], sd, ln_sd);
+    }
+};
+inline bool mp_parse_robust_line_drift_fn(const double* args, int n_args, mp_robust_line_drift_fn& p, std::string& err) {
+    if (!args || n_args != 1 || !(args[0] > 0.)) { err = "line drift proposal takes {std > 0}"; return false; }
+    p.sd = args[0];
+    p.ln_sd = mp_log(args[0]);
+    return true;
+}
+MP_REGISTER_MH_PROPOSAL(1, mp_robust_line_fn, mp_robust_line_drift_fn, mp_parse_robust_line_drift_fn)
+
+struct mp_robust_line_flip_fn {
+    int k;
+    template <class H, class T, int J>
+    MP_HD void flip(H& g, const T& tr) const {
+        if (J == k) g.template bernoulli<mp_robust_line_fn::OUT0 + J>(tr.val[mp_robust_line_fn::OUT0 + J] != 0. ? 0.05 : 0.95);
+        if constexpr (J + 1 < mp_robust_line_fn::MAX_DATA) flip<H, T, J + 1>(g, tr);
+    }
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const { flip<H, T, 0>(g, tr); }
+};
+inline bool mp_parse_robust_line_flip_fn(const double* args, int n_args, mp_robust_line_flip_fn& p, std::string& err) {
+    if (!args || n_args != 1 || !(args[0] >= 0.) || !(args[0] < mp_robust_line_fn::MAX_DATA) || args[0] != (double)(int)args[0]) {
+        err = "flip proposal takes {k}: the index of the data point whose indicator is re-proposed";
+        return false;
+    }
+    p.k = (int)args[0];
+    return true;
+}
+MP_REGISTER_MH_PROPOSAL(2, mp_robust_line_fn, mp_robust_line_flip_fn, mp_parse_robust_line_flip_fn)

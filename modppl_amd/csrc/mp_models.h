@@ -77,7 +77,8 @@ struct mp_generate_handler {
     }
     // constrained mvnormal site with hoisted covariance constants (dim K = Model::DIM_OBS slots k..k+K-1)
     template <int SITE, int K>
-    MP_HD void mvnormal_observed(const double* mu, const double* cov_inv, double ln_det, const double* /*chol: Simulate only*/) {
+    MP_HD void mvnormal_observed(const double* mu, const double* cov_inv, double ln_det, const double* /*chol: Simulate only*/,
+                                 const double* /*cov: for interpreters that work from the covariance itself (the CPU checker)*/ = nullptr) {
         constexpr int k = Model::obs_of(SITE);
         static_assert(k >= 0, "mvnormal_observed: the site must be constrained on this path");
         weight += mp_mvnormal_logpdf_pre<K>(obs + k, mu, cov_inv, ln_det);
@@ -159,7 +160,7 @@ struct mp_simulate_handler {
     MP_HD double normal(double mu, double sd) { return normal<SITE>(mu, sd, 0.); }
     // mvnormal.random (mvnormal.rs:24-37): L z + mu, z_j ~ normal(0, 1) in index order from the site's stream
     template <int SITE, int K>
-    MP_HD void mvnormal_observed(const double* mu, const double*, double, const double* chol) {
+    MP_HD void mvnormal_observed(const double* mu, const double*, double, const double* chol, const double* = nullptr) {
         constexpr int k = Model::obs_of(SITE);
         mp_site st(rng, MP_DOM_MODEL, (uint32_t)SITE);
         double z[K];
@@ -237,6 +238,7 @@ struct mp_spiral {
     static constexpr int DIM_STATE = 2, DIM_OBS = 2;
     enum { R = 0, THETA = 1, OBS = 2 };
     static constexpr int obs_of(int site) { return site == OBS ? 0 : -1; }
+    static constexpr int obs_dim(int site) { return site == OBS ? 2 : 1; }   // a vector-valued site owns obs slots obs_of .. obs_of + obs_dim - 1
     static constexpr int MAX_NORMALS = 2;
     static constexpr int normal_index(int site) { return site; }  // dr -> 0, dtheta -> 1
     MP_HD int n_normals(int64_t t) const { return t == 0 ? 0 : 2; }
@@ -244,6 +246,7 @@ struct mp_spiral {
     double cov_inv[4];
     double ln_det;
     double chol[4];   // lower Cholesky factor of the covariance, row-major (mvnormal.random in Simulate mode)
+    double cov[4];    // the covariance itself, row-major: what the reference's mvnormal is called with (mvnormal.rs:12-37 derives the rest per call)
 
     template <class H>
     MP_HD void operator()(H& g, int64_t t, const double* prev, double* next) const {
@@ -258,7 +261,7 @@ struct mp_spiral {
             pol1 = prev[1] + dtheta;
         }
         const double pos[2] = {pol0 * g.cos_(pol1), pol0 * g.sin_(pol1)};
-        g.template mvnormal_observed<OBS, 2>(pos, cov_inv, ln_det, chol);
+        g.template mvnormal_observed<OBS, 2>(pos, cov_inv, ln_det, chol, cov);
         next[0] = pol0;
         next[1] = pol1;
     }

@@ -224,7 +224,7 @@ static int32_t make_model(const mp_model_desc* m, std::unique_ptr<ModelOps>& out
         k.ln_det = mp_log(mp_host_det(cov, 2));
         std::vector<double> L;
         if (!mp_host_cholesky(cov, 2, L)) return mp_fail(MP_ERR_INVALID_ARG, "covariance not positive definite");
-        for (int i = 0; i < 4; ++i) k.chol[i] = L[i];
+        for (int i = 0; i < 4; ++i) { k.chol[i] = L[i]; k.cov[i] = cov[i]; }
         out.reset(new ModelOpsT<mp_spiral>(k));
         return MP_OK;
     }

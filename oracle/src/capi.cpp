@@ -16,6 +16,7 @@
 #include "../../include/modppl_hip.h"
 #include "soa.hpp"
 #include "functor_adapter.hpp"
+#include "mh_functor_adapter.hpp"
 
 using namespace oracle;
 
@@ -500,6 +501,75 @@ int32_t oracle_unfold_simulate(const mp_model_desc* m, const double* args0, int3
         } else throw Panic("simulate: unsupported model kind");
     })
 }
+
+// ---- mh.rs over N independent chains of a REGISTERED functor model (mh_functor_adapter.hpp) ----------------------------
+struct oracle_mhfn {
+    std::shared_ptr<MhFnModel> m;
+    std::vector<MhFnTrace> traces;
+    uint64_t seed = 0, iters = 0;
+    bool canonical = false;
+};
+int32_t oracle_mhfn_create(int32_t kind, const double* params, int32_t n_params, const int32_t* cons_sites, const double* cons_vals, int32_t n_cons,
+                           uint64_t n_chains, uint64_t seed, int32_t canon, oracle_mhfn** out) {
+    GUARD({
+        auto it = mhfn_models().find(kind);
+        if (it == mhfn_models().end()) throw Panic("no MH functor model of this kind");
+        auto h = std::make_unique<oracle_mhfn>();
+        h->seed = seed; h->canonical = canon != 0;
+        oracle_pf::Scope scope(h->canonical);
+        h->m = it->second(params, n_params);
+        for (uint64_t i = 0; i < n_chains; ++i) {
+            Rng r; r.seed = seed; r.slot = (uint32_t)i; r.step = 0;
+            h->traces.push_back(h->m->model().generate(r, 0, h->m->constraints(cons_sites, cons_vals, n_cons)).first);
+        }
+        *out = h.release();
+    })
+}
+int32_t oracle_mhfn_n_sites(oracle_mhfn* h, int32_t* out) { GUARD({ *out = h->m->ns(); }) }
+int32_t oracle_mhfn_step(oracle_mhfn* h, int32_t proposal_kind, const double* args, int32_t n_args, int32_t n_iters, uint64_t* accepted) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        const MhFnProposal proposal = h->m->proposal(proposal_kind, args, n_args);
+        uint64_t acc = 0;
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            for (int k = 0; k < n_iters; ++k) {
+                Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = (uint32_t)(h->iters + 1 + (uint64_t)k);
+                auto [tr, ok] = metropolis_hastings<int, mp_fn_ret, int>(r, h->m->model(), std::move(h->traces[i]), proposal, 0);
+                h->traces[i] = std::move(tr);
+                acc += ok;
+            }
+        }
+        h->iters += (uint64_t)n_iters;
+        if (accepted) *accepted = acc;
+    })
+}
+int32_t oracle_mhfn_regen(oracle_mhfn* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        uint64_t acc = 0;
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            for (int k = 0; k < n_iters; ++k) {
+                AddrMap mask;   // empty: the trace's whole schema (dyngenfn.rs:571)
+                if (cycle && n_mask > 0) mask.visit(h->m->flat_addr(mask_sites[(h->iters + (uint64_t)k) % (uint64_t)n_mask]));
+                else for (int q = 0; q < n_mask; ++q) mask.visit(h->m->flat_addr(mask_sites[q]));
+                Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = (uint32_t)(h->iters + 1 + (uint64_t)k);
+                auto [tr, ok] = regenerative_metropolis_hastings<int, mp_fn_ret>(r, h->m->model(), std::move(h->traces[i]), mask);
+                h->traces[i] = std::move(tr);
+                acc += ok;
+            }
+        }
+        h->iters += (uint64_t)n_iters;
+        if (accepted) *accepted = acc;
+    })
+}
+int32_t oracle_mhfn_read_trace(oracle_mhfn* h, double* values, uint32_t* present) {
+    GUARD({
+        const int ns = h->m->ns();
+        for (size_t i = 0; i < h->traces.size(); ++i) h->m->view(h->traces[i].data, values + i * (size_t)ns, present + i);
+    })
+}
+int32_t oracle_mhfn_read_logjp(oracle_mhfn* h, double* out) { GUARD({ for (size_t i = 0; i < h->traces.size(); ++i) out[i] = h->traces[i].logjp; }) }
+int32_t oracle_mhfn_destroy(oracle_mhfn* h) { delete h; return MP_OK; }
 
 // ---- mh.rs over N independent chains of hierarchical_model ------------------------------------
 struct oracle_mh {

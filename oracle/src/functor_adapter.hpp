@@ -55,6 +55,15 @@ struct SoaFunctorHandler {
         if constexpr (k >= 0) { weight += oracle::categorical.logpdf((int64_t)obs[k], p); return (int)obs[k]; }
         else { r.at(DOM_MODEL, (uint32_t)SITE); return (int)oracle::categorical.random(r, p); }
     }
+    // mvnormal site of dimension K (mvnormal.rs:12-37): the checker works from the covariance itself — determinant, inverse and
+    // Cholesky / eigen transform per call, as the reference does — and ignores the constants the device form hoists
+    template <int SITE, int K>
+    void mvnormal_observed(const double* mu, const double*, double, const double*, const double* cov) {
+        constexpr int k = M::obs_of(SITE);
+        static_assert(k >= 0, "mvnormal_observed: constrained on the Generate path");
+        if (!cov) throw Panic("functor adapter: the functor must pass the covariance of its mvnormal site");
+        weight += oracle::mvnormal.logpdf(Vec(obs + k, obs + k + K), MvNormalParams{Vec(mu, mu + K), Mat(K, Vec(cov, cov + K * K))});
+    }
 };
 template <class M>
 struct SoaFunctorModel : SoaModel {
@@ -88,6 +97,11 @@ struct DynFunctorHandler {
     double uniform(double a, double b) { return g.template sample_at<double>(oracle::uniform, UniformParams{a, b}, functor_addr(SITE)); }
     template <int SITE>
     int categorical(const double* probs, int n) { return (int)g.template sample_at<int64_t>(oracle::categorical, Vec(probs, probs + n), functor_addr(SITE)); }
+    template <int SITE, int K>
+    void mvnormal_observed(const double* mu, const double*, double, const double*, const double* cov) {
+        if (!cov) throw Panic("functor adapter: the functor must pass the covariance of its mvnormal site");
+        (void)g.template sample_at<Vec>(oracle::mvnormal, MvNormalParams{Vec(mu, mu + K), Mat(K, Vec(cov, cov + K * K))}, functor_addr(SITE));
+    }
 };
 template <class M>
 DynUnfold<Vec> make_functor_unfold(const M& m) {
@@ -105,12 +119,19 @@ DynUnfold<Vec> make_functor_unfold(const M& m) {
     return DynUnfold<Vec>(std::move(k));
 }
 // constraints of one time step for the functor's observed sites: obs slot k belongs to the site with obs_of(site) == k
+template <class M, class = void>
+struct functor_obs_dim { static constexpr int of(int) { return 1; } };
+template <class M>
+struct functor_obs_dim<M, std::void_t<decltype(M::obs_dim(0))>> { static constexpr int of(int site) { return M::obs_dim(site); } };
 template <class M>
 DynTrie functor_constraints(const double* y) {
     DynTrie c;
     for (int site = 0; site < 64; ++site) {
         const int k = M::obs_of(site);
-        if (k >= 0 && k < M::DIM_OBS) c.observe(functor_addr(site), arc(y[k]));
+        if (k < 0 || k >= M::DIM_OBS) continue;
+        const int dim = functor_obs_dim<M>::of(site);   // a vector-valued site (mvnormal) is constrained with a Vec
+        if (dim == 1) c.observe(functor_addr(site), arc(y[k]));
+        else c.observe(functor_addr(site), arc(Vec(y + k, y + k + dim)));
     }
     return c;
 }
@@ -167,6 +188,13 @@ inline bool parse_band4_functor(const mp_model_desc& m, mp_lgssm_band<4>& k, std
     k = mp_lgssm_band<4>{m.params[1], m.params[2], m.params[3], m.params[4], m.params[5], 0.};
     return true;
 }
+inline bool parse_spiral_functor(const mp_model_desc&, mp_spiral& k, std::string&) {
+    // only the covariance matters here (unfold.rs:29): the checker's mvnormal derives everything else per call
+    k = mp_spiral{};
+    k.cov[0] = 0.001; k.cov[1] = 0.; k.cov[2] = 0.; k.cov[3] = 0.001;
+    return true;
+}
+static const int functor_check_2 = register_functor_model<mp_spiral>(1000 + MP_MODEL_SPIRAL, parse_spiral_functor);
 static const int functor_check_1 = register_functor_model<mp_lgssm1>(1000 + MP_MODEL_LGSSM1, parse_lgssm1_functor);
 static const int functor_check_4 = register_functor_model<mp_bearings>(1000 + MP_MODEL_BEARINGS, parse_bearings_functor);
 static const int functor_check_5 = register_functor_model<mp_lgssm_band<4>>(1000 + MP_MODEL_LGSSM_BAND, parse_band4_functor);

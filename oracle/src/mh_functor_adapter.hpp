@@ -1,0 +1,203 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see rng.hpp).
+//
+// mh_functor_adapter.hpp — runs the model and proposal functors of modppl_amd/csrc/mp_mh_models.h (the ONE source of an MH
+// model added through MP_REGISTER_MH_MODEL / MP_REGISTER_MH_PROPOSAL) against the checker's OWN dynamic machinery: tries,
+// DynGenFnHandler::sample_at / trace_at / gc (dyngenfn.hpp: the restated dyngenfn.rs:100-483 with its weight and discard
+// bookkeeping), metropolis_hastings / regenerative_metropolis_hastings (inference.hpp: mh.rs:9-67), dists.hpp's
+// distributions and rng.hpp's Philox.  What the `dyngen!` macro would have expanded a body to (modppl-macros/src/lib.rs:20-113):
+//   g.template normal<SITE>(mu, sd, ln_sd)   ->  g.sample_at(normal, {mu, sd}, "s<SITE>")
+//   g.template bernoulli<SITE>(p)            ->  g.sample_at(bernoulli, p, "s<SITE>")
+//   g.template call<SITES>(body)             ->  g.trace_at(DynGenFn{body}, (), "c<SITES>")   a real sub-trace with its own trie
+// A proposal addresses the model's sites by their full paths ("c<SITES>/s<SITE>" for a site inside a sub-call:
+// M::sub_of(site) tells) and reads the trace it is given through a dense view (val[], has(), get()).
+// Shared with the product: the functor BODIES (which sites, in which order, with which parameters).  Not shared: everything
+// that interprets them — in particular none of mp_genfn.h's handler rules, which are what the GPU tests check against this.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+
+#include "inference.hpp"
+#include "../../modppl_amd/csrc/mp_genfn.h"   // mp_fn_ret (the functor contract); none of its handlers is used here
+
+namespace oracle {
+
+inline std::string mhfn_local_addr(int site) { return "s" + std::to_string(site); }
+inline std::string mhfn_sub_addr(uint32_t sites) { return "c" + std::to_string(sites); }
+template <class M>
+std::string mhfn_flat_addr(int site) {
+    const uint32_t sub = M::sub_of(site);
+    return sub ? mhfn_sub_addr(sub) + "/" + mhfn_local_addr(site) : mhfn_local_addr(site);
+}
+inline uint32_t mhfn_site_of(const std::string& a) {   // the Philox site of an address: the id after the last 's'
+    return (uint32_t)std::stoul(a.substr(a.rfind('s') + 1));
+}
+
+using MhFnGen = DynGenFn<int, mp_fn_ret>;      // args = () as an int; retv = the body's mp_fn_ret (mp_genfn.h)
+using MhFnH = DynGenFnHandler<int, mp_fn_ret>;
+using MhFnTrace = Trace<int, DynTrie, mp_fn_ret>;
+
+// the handler a functor body sees: top level (a proposal, or the model's own frame) or inside one sub-call
+template <class M>
+struct DynMhHandler {
+    MhFnH& g;
+    bool inside;      // in a sub-call the addresses are local to its trie
+    bool flat;        // (unused for models: their top-level sites are local to the model's own trie)
+    double exp_(double x) const { return o_exp(x); }
+    double log_(double x) const { return o_ln(x); }
+    template <int SITE>
+    std::string addr() const { return (flat && !inside) ? mhfn_flat_addr<M>(SITE) : mhfn_local_addr(SITE); }
+    template <int SITE>
+    double normal(double mu, double sd, double /*ln_sd hoisted by the device form*/) {
+        return g.template sample_at<double>(oracle::normal, NormalParams{mu, sd}, addr<SITE>());
+    }
+    template <int SITE>
+    double normal(double mu, double sd) { return normal<SITE>(mu, sd, 0.); }
+    template <int SITE>
+    bool bernoulli(double p) { return g.template sample_at<bool>(oracle::bernoulli, p, addr<SITE>()); }
+    // trace_at: under Update / Regenerate with nothing touched and diff NoChange the body is NOT run and the stored retv comes
+    // back (dyngenfn.rs:362-366, 415-419) — which is why a functor may take a sub-call's results from its return value only
+    template <uint32_t SITES, class Body>
+    mp_fn_ret call(Body&& body) {
+        const uint32_t dom = g.domain;
+        MhFnGen sub([&body](MhFnH& g2, int) -> mp_fn_ret {
+            DynMhHandler<M> h2{g2, true, false};
+            return body(h2);
+        }, mhfn_site_of, dom);
+        return g.template trace_at<int, mp_fn_ret>(sub, 0, mhfn_sub_addr(SITES));
+    }
+};
+
+// dense view of a trie trace for proposal bodies (tr.val[SITE], tr.has(SITE), tr.get(SITE, dflt)) and for the test's reads
+template <class M>
+struct MhFnView {
+    double val[M::NS];
+    uint32_t present = 0;
+    bool has(int site) const { return (present >> site) & 1u; }
+    double get(int site, double dflt) const { return has(site) ? val[site] : dflt; }
+    explicit MhFnView(const DynTrie& data) {
+        for (int s = 0; s < M::NS; ++s) {
+            val[s] = 0.;
+            const uint32_t sub = M::sub_of(s);
+            const Trie* node = nullptr;
+            if (sub) {
+                const Trie* st = data.search(mhfn_sub_addr(sub));
+                node = st ? st->search(mhfn_local_addr(s)) : nullptr;
+            } else {
+                node = data.search(mhfn_local_addr(s));
+            }
+            if (!node || !node->value) continue;
+            present |= 1u << s;
+            if (const double* d = std::any_cast<double>(node->value->get())) val[s] = *d;
+            else if (const bool* b = std::any_cast<bool>(node->value->get())) val[s] = *b ? 1. : 0.;
+            else throw Panic("mh functor adapter: a choice that is neither f64 nor bool at site " + std::to_string(s));
+        }
+    }
+};
+
+using MhFnPArgs = std::pair<const MhFnTrace*, int>;
+using MhFnProposal = DynGenFn<MhFnPArgs, int>;
+// a proposal's frame: full paths, no sub-calls (a proposal addresses the model's sites directly, hierarchical.rs:48-70)
+template <class M>
+struct MhFnFlatHandler {
+    DynGenFnHandler<MhFnPArgs, int>& g;
+    template <int SITE>
+    double normal(double mu, double sd, double) { return g.template sample_at<double>(oracle::normal, NormalParams{mu, sd}, mhfn_flat_addr<M>(SITE)); }
+    template <int SITE>
+    double normal(double mu, double sd) { return normal<SITE>(mu, sd, 0.); }
+    template <int SITE>
+    bool bernoulli(double q) { return g.template sample_at<bool>(oracle::bernoulli, q, mhfn_flat_addr<M>(SITE)); }
+    double exp_(double x) const { return o_exp(x); }
+    double log_(double x) const { return o_ln(x); }
+};
+
+struct MhFnModel {
+    virtual ~MhFnModel() {}
+    virtual int ns() const = 0;
+    virtual const MhFnGen& model() const = 0;
+    virtual DynTrie constraints(const int32_t* sites, const double* vals, int n) const = 0;
+    virtual std::string flat_addr(int site) const = 0;
+    virtual MhFnProposal proposal(int kind, const double* args, int n_args) const = 0;
+    virtual void view(const DynTrie& data, double* vals, uint32_t* present) const = 0;
+};
+template <class M>
+using MhFnProposalFactory = std::function<MhFnProposal(const double*, int)>;
+template <class M>
+std::map<int, MhFnProposalFactory<M>>& mhfn_proposals() {
+    static std::map<int, MhFnProposalFactory<M>> r;
+    return r;
+}
+template <class M>
+struct MhFnModelT : MhFnModel {
+    M m;
+    MhFnGen gen;
+    explicit MhFnModelT(const M& m_) : m(m_) {
+        const M mm = m;
+        gen = MhFnGen([mm](MhFnH& g, int) -> mp_fn_ret {
+            DynMhHandler<M> h{g, false, false};
+            mm(h);
+            return mp_fn_ret{};
+        }, mhfn_site_of, DOM_MODEL);
+    }
+    int ns() const override { return M::NS; }
+    const MhFnGen& model() const override { return gen; }
+    std::string flat_addr(int site) const override { return mhfn_flat_addr<M>(site); }
+    DynTrie constraints(const int32_t* sites, const double* vals, int n) const override {
+        DynTrie c;
+        for (int q = 0; q < n; ++q) {
+            const int s = sites[q];
+            if (s < 0 || s >= M::NS) throw Panic("constraint site out of range");
+            if (M::is_bool(s)) c.observe(mhfn_flat_addr<M>(s), arc(vals[q] != 0.));
+            else c.observe(mhfn_flat_addr<M>(s), arc(vals[q]));
+        }
+        return c;
+    }
+    MhFnProposal proposal(int kind, const double* args, int n_args) const override {
+        auto it = mhfn_proposals<M>().find(kind);
+        if (it == mhfn_proposals<M>().end()) throw Panic("no proposal of this kind is registered for the model");
+        return it->second(args, n_args);
+    }
+    void view(const DynTrie& data, double* vals, uint32_t* present) const override {
+        const MhFnView<M> v(data);
+        for (int s = 0; s < M::NS; ++s) vals[s] = v.val[s];
+        *present = v.present;
+    }
+};
+
+using MhFnFactory = std::function<std::shared_ptr<MhFnModel>(const double*, int)>;
+inline std::map<int, MhFnFactory>& mhfn_models() {
+    static std::map<int, MhFnFactory> r;
+    return r;
+}
+template <class M>
+int mhfn_register_model(int kind, bool (*parse)(const double*, int, M&, std::string&)) {
+    mhfn_models()[kind] = [parse](const double* params, int n) -> std::shared_ptr<MhFnModel> {
+        M m{};
+        std::string err;
+        if (!parse(params, n, m, err)) throw Panic(err);
+        return std::make_shared<MhFnModelT<M>>(m);
+    };
+    return kind;
+}
+template <class M, class P>
+int mhfn_register_proposal(int kind, bool (*parse)(const double*, int, P&, std::string&)) {
+    mhfn_proposals<M>()[kind] = [parse](const double* args, int n_args) -> MhFnProposal {
+        P p{};
+        std::string err;
+        if (!parse(args, n_args, p, err)) throw Panic(err);
+        return MhFnProposal([p](DynGenFnHandler<MhFnPArgs, int>& g, MhFnPArgs pa) -> int {
+            MhFnFlatHandler<M> h{g};
+            const MhFnView<M> tr(pa.first->data);
+            p(h, tr);
+            return 0;
+        }, mhfn_site_of, DOM_PROPOSAL);
+    };
+    return kind;
+}
+
+}  // namespace oracle
+
+// the product's MH model sources, interpreted by the registrars above
+#define MP_REGISTER_MH_MODEL(KIND, TYPE, PARSE) static const int oracle_mh_registered_##TYPE = oracle::mhfn_register_model<TYPE>(KIND, PARSE);
+#define MP_REGISTER_MH_PROPOSAL(KIND, MODEL, TYPE, PARSE) static const int oracle_mh_registered_##TYPE = oracle::mhfn_register_proposal<MODEL, TYPE>(KIND, PARSE);
+#include "../../modppl_amd/csrc/mp_mh_models.h"

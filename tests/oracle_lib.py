@@ -482,3 +482,57 @@ class OraclePointedMH:
             self.L.oracle_mh_pointed_destroy(self.h)
         except Exception:
             pass
+
+
+class OracleFunctionChains:
+    """N chains of a REGISTERED MH functor model (modppl_amd/csrc/mp_mh_models.h) run by the checker's dynamic machinery — tries,
+    sample_at / trace_at / gc, mh / regen_mh — through oracle/src/mh_functor_adapter.hpp: no hand-written restatement."""
+
+    def __init__(self, kind, params, constraints, n_chains, seed, canonical=True):
+        self.L = load()
+        self.n = n_chains
+        params = np.ascontiguousarray(params, dtype=np.float64).ravel()
+        sites = np.array(sorted(constraints), dtype=np.int32)
+        vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
+        h = C.c_void_p()
+        self._ck(self.L.oracle_mhfn_create(int(kind), dptr(params), int(params.size), sites.ctypes.data_as(C.POINTER(C.c_int32)), dptr(vals), int(sites.size),
+                                           C.c_uint64(n_chains), C.c_uint64(seed), int(canonical), C.byref(h)))
+        self.h = h
+        ns = C.c_int32()
+        self._ck(self.L.oracle_mhfn_n_sites(self.h, C.byref(ns)))
+        self.num_sites = ns.value
+
+    def _ck(self, code):
+        if code != 0:
+            raise OracleError(code, self.L.oracle_last_error().decode())
+
+    def mh(self, proposal_kind, proposal_args=(), n_iters=1):
+        a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
+        acc = C.c_uint64()
+        self._ck(self.L.oracle_mhfn_step(self.h, int(proposal_kind), dptr(a), int(a.size), int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def regen_mh(self, mask_sites, n_iters=1, cycle=False):
+        m = (C.c_int32 * max(len(mask_sites), 1))(*mask_sites)
+        acc = C.c_uint64()
+        self._ck(self.L.oracle_mhfn_regen(self.h, m, len(mask_sites), int(cycle), int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def trace(self):
+        vals = np.empty((self.n, self.num_sites))
+        present = np.empty(self.n, dtype=np.uint32)
+        self._ck(self.L.oracle_mhfn_read_trace(self.h, dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return vals, present
+
+    def logjp(self):
+        out = np.empty(self.n)
+        self._ck(self.L.oracle_mhfn_read_logjp(self.h, dptr(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.oracle_mhfn_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

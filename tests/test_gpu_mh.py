@@ -228,3 +228,80 @@ def test_function_chains_argument_checks():
     vals, present = g.trace()
     assert np.array_equal(vals[:, capi.MP_SITE_Y0:capi.MP_SITE_Y0 + 11], np.tile(ys, (64, 1)))
     assert np.all((present >> capi.MP_SITE_Y0) == (1 << 11) - 1)
+
+
+# ---- a model that exists ONLY as a registered functor (kind 102, robust regression with outlier indicators): the device's
+# generic handlers (mp_genfn.h) against the checker's dynamic interpretation of the SAME functor bodies (tries, sample_at /
+# trace_at / gc: oracle/src/mh_functor_adapter.hpp) ---------------------------------------------------------------------------
+RL_OUT0, RL_Y0 = 2, 14
+
+
+def robust_line_pair(n, seed, n_data=10):
+    import modppl_amd
+
+    xs = np.linspace(-3, 3, n_data)
+    rng = np.random.default_rng(1)
+    ys = 0.7 * xs - 0.4 + 0.3 * rng.normal(size=n_data)
+    ys[2] += 9.0
+    ys[n_data - 3] -= 8.0
+    cons = {RL_Y0 + k: y for k, y in enumerate(ys)}
+    g = modppl_amd.FunctionChains(102, xs, cons, n, seed)
+    o = O.OracleFunctionChains(102, xs, cons, n, seed)
+    return g, o, n_data
+
+
+def check_fn(g, o):
+    gv, gp = g.trace()
+    ov, op = o.trace()
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gv, ov)
+    assert np.allclose(g.logjp(), o.logjp(), rtol=1e-12, atol=1e-9)
+
+
+def test_registered_only_model_against_the_dynamic_interpretation():
+    if FUNCTOR:
+        pytest.skip("one engine: the model has no hand-written kernel")
+    g, o, nd = robust_line_pair(1500, 17)
+    check_fn(g, o)
+    for sweep in range(3):
+        assert g.mh(1, [0.3], 2) == o.mh(1, [0.3], 2)                       # drift of the line (a sub-call's sites, constrained)
+        check_fn(g, o)
+        for k in (0, 2, nd - 3, nd - 1):
+            assert g.mh(2, [k], 1) == o.mh(2, [k], 1)                       # flip of one indicator: a bernoulli site constrained
+            check_fn(g, o)
+        assert g.regen_mh([RL_OUT0 + k for k in range(nd)], nd, cycle=True) == o.regen_mh([RL_OUT0 + k for k in range(nd)], nd, cycle=True)
+        check_fn(g, o)
+        assert g.regen_mh([0], 2) == o.regen_mh([0], 2)                     # slope alone: masked site inside the sub-call
+        check_fn(g, o)
+        assert g.regen_mh([1, RL_OUT0 + 1, RL_OUT0 + 4], 2) == o.regen_mh([1, RL_OUT0 + 1, RL_OUT0 + 4], 2)   # sub-call and top-level sites at once
+        check_fn(g, o)
+    assert g.regen_mh([RL_OUT0 + 3], 3) == o.regen_mh([RL_OUT0 + 3], 3)     # masked top-level site AFTER the untouched sub-call: replayed
+    check_fn(g, o)
+    assert g.regen_mh([], 2) == o.regen_mh([], 2) == 3000                   # empty mask: the whole schema, observed sites included
+    check_fn(g, o)
+    assert g.mh(1, [0.2], 3) == o.mh(1, [0.2], 3)
+    check_fn(g, o)
+    assert g.iterations == 3 * (2 + 4 + nd + 2 + 2) + 3 + 2 + 3
+
+
+def test_registered_only_model_full_size():
+    """2^20 chains of the functor-only model: planted outliers are found by the flip moves"""
+    if FUNCTOR:
+        pytest.skip("one engine: the model has no hand-written kernel")
+    import modppl_amd
+
+    n_data = 10
+    xs = np.linspace(-3, 3, n_data)
+    rng = np.random.default_rng(1)
+    ys = 0.7 * xs - 0.4 + 0.3 * rng.normal(size=n_data)
+    ys[2] += 9.0
+    ys[7] -= 8.0
+    g = modppl_amd.FunctionChains(102, xs, {RL_Y0 + k: y for k, y in enumerate(ys)}, 1 << 20, 5)
+    for sweep in range(40):
+        g.mh(1, [0.4 if sweep < 20 else 0.1], 2)
+        for k in range(n_data):
+            g.mh(2, [k], 1)
+    vals, present = g.trace()
+    out = vals[:, RL_OUT0:RL_OUT0 + n_data].mean(axis=0)
+    assert out[2] > 0.9 and out[7] > 0.9 and out[3:7].max() < 0.5, out
+    assert np.isfinite(g.logjp()).all()

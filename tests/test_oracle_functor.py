@@ -7,8 +7,16 @@ import pytest
 
 from tests import oracle_lib as O
 
+def _spiral_obs(T):
+    t = np.arange(T)
+    r, th = 0.5 + 0.02 * t, 0.3 + 0.4 * t
+    return np.stack([r * np.cos(th), r * np.sin(th)], axis=1) + 0.01 * np.random.default_rng(2).normal(size=(T, 2))
+
+
 CASES = [
     ("lgssm1", 1, 1, 1, O.LGSSM_PARAMS, lambda T: O.lgssm_observations(T).reshape(T, 1)),
+    # uniform sites at t = 0, normal sites after, and a vector-valued mvnormal site (mvnormal.rs:12-37) constrained with a Vec
+    ("spiral", 2, 2, 2, np.zeros(0), _spiral_obs),
     ("bearings", 4, 4, 1, np.array([1.0, 1.0, 1.0, 0.1, 0.05, 0.02]),
      lambda T: (np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + 0.01 * np.sin(np.arange(T))).reshape(T, 1)),
     ("band4", 5, 4, 4, np.array([4, 0.9, 0.05, 1.0, 0.5, 1.0]), lambda T: np.random.default_rng(3).normal(0, 1.2, size=(T, 4))),

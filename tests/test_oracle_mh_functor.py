@@ -1,0 +1,86 @@
+"""One source for MH models: a model / proposal functor of modppl_amd/csrc/mp_mh_models.h is run by the CPU
+checker through its OWN dynamic machinery (oracle/src/mh_functor_adapter.hpp: tries, sample_at / trace_at / gc, mh / regen_mh).
+The adapter is itself cross-checked here: the hierarchical model's functor (kind 101) through the adapter against the checker's
+hand-written restatement of the reference's hierarchical_model and proposals (models.hpp), chain by chain, bit for bit."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+XS = np.arange(-5.0, 6.0)  # tests/mh.rs:81
+Y0 = 4
+
+
+def make_ys(seed=0):
+    rng = np.random.default_rng(seed)
+    return 0.3 + 0.4 * XS + 0.5 * XS * XS + 0.1 * rng.normal(size=XS.size)
+
+
+def pair(n, seed, constrain, canonical):
+    ys = make_ys()
+    cons = {Y0 + k: y for k, y in enumerate(ys)}
+    if constrain is not None:
+        cons[0] = float(constrain)
+    f = O.OracleFunctionChains(101, XS, cons, n, seed, canonical=canonical)
+    o = O.OracleMH(XS, ys, n, seed, -1 if constrain is None else int(constrain), canonical=canonical)
+    return f, o
+
+
+def check(f, o):
+    vals, present = f.trace()
+    st = o.state()
+    assert np.array_equal(vals[:, :4], st)
+    assert np.array_equal((present >> 3) & 1, (st[:, 0] == 0.0).astype(np.uint32))   # coeffs/c is in the trace iff quadratic
+    assert np.array_equal(f.logjp(), o.logjp())   # both are the trie's running weight: identical bookkeeping
+
+
+@pytest.mark.parametrize("canonical", [True, False])
+@pytest.mark.parametrize("constrain", [None, False])
+def test_hierarchical_functor_through_the_adapter_equals_the_restatement(constrain, canonical):
+    f, o = pair(60, 21, constrain, canonical)
+    check(f, o)
+    for _ in range(3):
+        assert f.mh(2, [], 1) == o.mh_add_or_remove(1)      # structure-changing move: c appears / is collected by gc
+        check(f, o)
+        assert f.mh(1, [0.1], 3) == o.mh(0.1, 3)
+        check(f, o)
+        assert f.regen_mh([1, 2, 3], 4, cycle=True) == o.regen_mh([1, 2, 3], 4, cycle=True)
+        check(f, o)
+        assert f.regen_mh([1, 2], 2) == o.regen_mh([1, 2], 2)
+        check(f, o)
+
+
+def test_empty_mask_and_observed_sites():
+    f, o = pair(40, 5, None, True)
+    assert f.regen_mh([], 2) == o.regen_mh([], 2) == 80
+    check(f, o)
+    vals, _ = f.trace()
+    assert np.array_equal(vals[:, Y0:Y0 + len(XS)], o.observations(len(XS)))
+    assert f.mh(1, [0.1], 2) == o.mh(0.1, 2)
+    check(f, o)
+
+
+def test_robust_line_model_runs_and_mixes():
+    """kind 102 exists in ONE place (mp_mh_models.h); here the checker's interpretation of it is exercised on its own: flips of
+    the indicators find the planted outliers, the line settles near the inliers' least-squares fit"""
+    xs = np.linspace(-3, 3, 10)
+    rng = np.random.default_rng(1)
+    ys = 0.7 * xs - 0.4 + 0.3 * rng.normal(size=xs.size)
+    ys[2] += 9.0
+    ys[7] -= 8.0
+    OUT0, YS = 2, 14
+    f = O.OracleFunctionChains(102, xs, {YS + k: y for k, y in enumerate(ys)}, 30, 3)
+    assert f.num_sites == 26
+    for sweep in range(80):
+        f.mh(1, [0.4 if sweep < 40 else 0.1], 2)
+        for k in range(len(xs)):
+            f.mh(2, [k], 1)
+        f.regen_mh([OUT0 + (sweep % len(xs))], 1)
+    vals, present = f.trace()
+    assert np.all(present == (1 << 2) - 1 | ((1 << 10) - 1) << OUT0 | ((1 << 10) - 1) << YS)
+    out = vals[:, OUT0:OUT0 + 10].mean(axis=0)
+    assert out[2] > 0.9 and out[7] > 0.9 and out[3:7].max() < 0.5, out   # (the end points stay flagged in some chains: a local mode)
+    inl = np.delete(np.arange(10), [2, 7])
+    slope, icpt = np.polyfit(xs[inl], ys[inl], 1)
+    assert abs(np.median(vals[:, 0]) - slope) < 0.4 and abs(np.median(vals[:, 1]) - icpt) < 0.5
+    assert np.isfinite(f.logjp()).all()
