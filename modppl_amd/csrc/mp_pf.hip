@@ -440,7 +440,7 @@ struct mp_pf {
     u64 sh_rows_cap = 0;
     bool logw_zero = false;         // log-weights are all zero (after a sharded resample) and the buffer has not been cleared
     mp_dev_scalars* scal_undo = nullptr;  // the scalars before a fixed-capacity route folded this resample in
-    // "owner keeps" form: per super-chunk of R * 1024 draws a window of entries (k_shard_own_bin), [ow_nsc][R * 1024]
+    // "owner keeps" form: per super-chunk of R * 1024 draws a window of entries (k_shard_own_draw), [ow_nsc][R * 1024]
     u64* ow_seg_lt = nullptr;             // tile-local target
     uint32_t* ow_seg_row = nullptr;       // start row of the forward scan
     uint32_t* ow_sccnt = nullptr;         // own draws per super-chunk, and their exclusive scan

@@ -1,5 +1,5 @@
 // mp_pf_shard_kernels.h — device code of the sharded filter's resample phases (included by mp_pf.hip only, after
-// mp_pf_kernels.h): the owner-keeps exchange (k_shard_table, k_shard_own_bin, k_shard_own_plan, k_shard_own_resolve), the
+// mp_pf_kernels.h): the owner-keeps exchange (k_shard_table / k_shard_table_mw, k_shard_own_draw, k_shard_own_plan, k_shard_own_place), the
 // slot-order exchange (variable-size three-pass route, fixed-capacity single-pass route, owner-side resolve), adoption.
 // Protocol: include/modppl_hip.h "sharded filter", DESIGN.md §8.
 #pragma once
@@ -642,21 +642,21 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
 // slots travels (to the ranks that drew fewer than n): the xGMI traffic of a resample drops from ~40 B per particle to a
 // few thousand rows.  WHERE an offspring sits depends on the number of ranks (a world of one is the single filter).
 //
-// Round 2: the same XCD-binned two-hop layout as the single filter's k_bin_draws / k_resolve_bins.
-//   k_shard_table       (one workgroup) the job's tile table; for the lattice schemes also every rank's own range of
-//                       draws [G_{r-1}, G_r) by binary search on the monotone target function: offspring counts in
-//                       closed form, and a rank only looks at its own draws — O(n_local), whatever the world size.
-//   k_shard_own_bin     workgroup = "super-chunk" of R x 1024 consecutive draws, R = min(world, 4): rounds of (Philox
-//                       pair -> targets -> mine?), own targets compacted to LDS in draw order (so that the lookups that
-//                       follow run on full waves even when a rank owns one draw in `world`); then, for the compacted own
-//                       draws: tile -> guide -> start row, split into 8 bins (eighths of this rank's share of the CDF),
-//                       entries {tile-local target, start row, draw-order rank} written bin by bin into the super-chunk's
-//                       window.  Multinomial: offspring of every rank counted with ballots against the rank boundaries.
-//   k_shard_own_plan    (one workgroup) first offspring position of every super-chunk (scan), offspring per rank, the
-//                       exchange plan, the verdict "some pair needs more than cap rows", what the host reads.
-//   k_shard_own_resolve workgroup (2 super-chunks, bin b), blockIdx % 8 == b: the row lookups of eighth b run on one XCD.
-//                       Offspring p = base + rank < n: row {x, parent id} written at the entry's own (bin-ordered)
-//                       position, inv[p] points there; p >= n: the row goes to the send buffer where the plan says.
+// Round 3: a kept offspring is a {tile-local target, start row} pair in the slot-order arrays the NEXT k_propagate consumes,
+// exactly as after an unsharded resample (the parent is local by construction); only the surplus is looked up early.
+//   k_shard_table[_mw]  the job's tile table (one workgroup, or one per rank beyond 2048 tiles); the rank boundaries as
+//                       thresholds on the uniforms (multinomial); for the lattice schemes every rank's own range of draws
+//                       [G_{r-1}, G_r) by binary search on the monotone target function: offspring counts in closed form,
+//                       and a rank only looks at its own draws — O(n_local), whatever the world size.
+//   k_shard_own_draw    super-chunk = R x 1024 consecutive draws, R = min(world, 4) (multinomial: resident workgroups take
+//                       turns; a WAVE enumerates 128 R of them and compacts its own ones in LDS without a workgroup barrier;
+//                       offspring of every rank counted with ballots against the boundaries, added to the job's counts with
+//                       `world` atomics per workgroup) or 1 (lattice); then for the own draws: target -> tile -> guide ->
+//                       start row, written in draw order into the super-chunk's window.
+//   k_shard_own_plan    (one workgroup) first offspring position of every super-chunk (scan), the exchange plan, the
+//                       verdict "some pair needs more than cap rows", what the host reads.
+//   k_shard_own_place   offspring p = base + rank: p < n -> the pair goes to slot p; p >= n -> looked up here, its row goes
+//                       to the send buffer where the plan says; deficit slots get MP_DRAW_RECV | the arriving row's index.
 // No counting of offspring per row, no scattered 4-byte read-modify-writes (a first version spent 36 of 73 us there).
 // ---------------------------------------------------------------------------------------------
 constexpr int OWN_THREADS = 512;             // a thread owns two ADJACENT draws of a round (one Philox block)
@@ -705,7 +705,7 @@ struct mp_own_plan_args {
     unsigned long long* c_all;       // [world] offspring per rank: k_shard_table (lattice: closed form; multinomial: zeroed) + the draw kernel's atomics
     mp_dev_scalars* scal;
     mp_dev_scalars* undo;
-    const mp_tab_head* head;         // world of one: the table k_propagate's last workgroup built is the job's table; k_shard_own_bin folds it
+    const mp_tab_head* head;         // world of one: the single filter's table (ensure_table) is the job's table; k_shard_own_draw folds it
     uint32_t* base;                  // [nsc] out: first offspring position of every super-chunk
     mp_owned_plan* plan_out;
     mp_shard_pub* pub;               // host-mapped

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build side, after `gpurun -- bash tools/profile_round.sh rNN_prof`: copy the summaries to be judged from gpurun_out/ (scratch)
+# into profiles/rNN (tracked).    tools/collect_profiles.sh r03
+set -eu
+R=${1:-r03}
+SRC=gpurun_out/${R}_prof
+DST=profiles/$R
+mkdir -p $DST
+python3 tools/collect_traffic.py $SRC > $DST/traffic.json
+python3 tools/pmc_summary.py $SRC > $DST/counters_summary.txt
+for f in stamp_report.txt stamps.json bench_n1.json bench_n1_k20.json bench_forced_sharded.json bench_forced_sharded_rccl.json route_scale.txt model_bench.jsonl mh_functor_vs_handwritten.json; do
+  [ -f $SRC/$f ] && cp $SRC/$f $DST/$f
+done
+cp $SRC/trace/bench_kernel_stats.csv $DST/kernel_stats.csv
+cp $SRC/trace_sharded/bench_kernel_stats.csv $DST/kernel_stats_forced_sharded.csv
+for i in 1 2 3 4 5 6 7; do cp $SRC/pmc$i/p_counter_collection.csv $DST/pmc${i}_counter_collection.csv; done
+echo "collected into $DST"
