@@ -437,7 +437,7 @@ def main():
         sharded_path = world > 1 or force_sharded
         if sharded_path:   # the sharded filter runs other kernels for the resample
             if getattr(pf, "exchange", "") == "owned":
-                KERNEL_OF.update({"bin_draws": "k_shard_table + k_shard_own_bin + k_shard_own_plan", "resample_gather": "k_shard_own_resolve"})
+                KERNEL_OF.update({"bin_draws": "k_shard_table + k_shard_own_draw + k_shard_own_plan", "resample_gather": "k_shard_own_place"})
             else:
                 KERNEL_OF.update({"bin_draws": "k_shard_route_fused", "resample_gather": "k_shard_resolve_binned"})
         roofline = None

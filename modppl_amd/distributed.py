@@ -338,7 +338,28 @@ class ShardedParticleSystem:
                 self._staged = HostStagedTransport(self.engine, group, self.world)
                 self._transport = self._staged.struct
             else:
-                self._transport, self._rccl_comm = rccl_transport(self.engine._L, group, self.world, self.rank, self.dev.index or 0)
+                # A communicator of the library's own.  If ANY rank cannot make one (no librccl.so.1 to resolve, an RCCL that
+                # refuses a second communicator), EVERY rank takes the round-2 protocol below over torch.distributed instead:
+                # the decision is a collective one, so that no rank waits in a collective the others never enter.
+                ok, why = 1, None
+                try:
+                    self._transport, self._rccl_comm = rccl_transport(self.engine._L, group, self.world, self.rank, self.dev.index or 0)
+                except Exception as e:   # noqa: BLE001
+                    ok, why = 0, e
+                if self.world > 1:
+                    flag = torch.tensor([ok], dtype=torch.int32, device=self.dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                    ok = int(flag.item())
+                if not ok:
+                    if self._rccl_comm is not None:
+                        self.engine._L.mp_rccl_comm_destroy(self._rccl_comm)
+                    self._transport, self._rccl_comm, self._native = None, None, False
+                    if self.rank == 0:
+                        import warnings
+                        warnings.warn(f"native RCCL transport unavailable ({why!r} on this or another rank): the sharded resample runs its "
+                                      "collectives through torch.distributed")
+                elif why is not None:
+                    raise why
         self._host_staging = host_staging
         self._ow_keep = None
         self._ox_cache, self._ox_flip = {}, 0   # exact-size exchange buffers
