@@ -20,7 +20,10 @@ SO_STAMPS = os.path.join(CSRC, "libmodppl_hip_stamps.so")   # diagnostics build 
 SOURCES = ["mp_pf.hip", "mp_mh.hip", "mp_probe.hip"]
 # -ffp-contract=off: the only fused multiply-adds are the explicit fma() calls in mp_math.h, so the
 # device evaluates exp/log with exactly the operations the CPU checker uses (bit-exact indices).
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
+# -amdgpu-kernarg-preload-count=8: the first 8 dwords of a kernel's arguments (scalars and pointers only; the run stops at the
+# first aggregate) arrive in SGPRs at wave launch instead of through the kernel-argument fetch — k_propagate's tile-scalar
+# pointers sit there so that a drawing launch's first loads do not wait ~1 us for that fetch (-0.3 us per step, measured).
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-amdgpu-kernarg-preload-count=8"]
 
 
 def _dep_files():

@@ -152,15 +152,17 @@ struct ModelOpsT : ModelOps {
         const int k1t = k1_threads_override();   // A/B measurements
         if constexpr (std::is_same<Model, mp_lgssm1>::value) {
             if (k1t == 256) {
-                hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                hipLaunchKernelGGL((k_propagate<Model, 256>), dim3(a.grid), dim3(256), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old, a.drw_v.tile_W2_old,
+                                   a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.drw, a.rc);
+                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
                 return;
             }
             if (k1t == 512) {
-                hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old, a.drw_v.tile_W2_old,
+                                   a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.drw, a.rc);
+                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
                 return;
             }
         }
@@ -175,9 +177,10 @@ struct ModelOpsT : ModelOps {
                 return;
             }
         }
-        hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+        hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old, a.drw_v.tile_W2_old,
+                                   a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                           a.inv, a.dfr_lt, a.aux, a.drw_v, a.drw, a.rc);
+                           a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
     }
     int n_normals(long long t) const override { return model.n_normals(t); }
 };

@@ -752,13 +752,18 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
     *x0_out = next[0];
 }
 template <class Model, int THREADS>
-__global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(const double* __restrict__ pre_tm, const u64* __restrict__ pre_tW, const u64* __restrict__ pre_tW2, int pre_nt, int drw,
+                                                            Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
                                                             mp_obs obs, mp_state0 s0, int overwrite,
                                                             const uint32_t* __restrict__ dfr_row, const double* __restrict__ inv_rows,
                                                             const mp_cx* __restrict__ cx_old, const mp_k1_tail* tail,
                                                             const uint32_t* __restrict__ inv, const u64* __restrict__ dfr_lt, mp_k1_aux aux,
-                                                            mp_k1_draw drw_v, int drw, uint32_t rc) {
+                                                            mp_k1_draw drw_v, uint32_t rc) {
+    // (the first five arguments are what a drawing launch needs to get its tile-scalar loads out — preloading the Philox inputs as
+    // well, 15 dwords, measured no better —: scalars and pointers at the head of
+    // the argument list are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count), so those loads do not wait for
+    // the kernel-argument fetch — ~1 us from device memory — that everything else starts with)
     constexpr int D = Model::DIM_STATE;
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int LANE_ITEMS = TILE / THREADS;
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             // (the host lets a launch draw only for jobs of at most THREADS tiles: one table entry per thread, its loads in flight
             // together and the Philox block computed under them)
             const int tb = (int)threadIdx.x;
-            const bool have_tb = tb < dw.nt;
+            const bool have_tb = tb < pre_nt;
             mp_u64x2 blk;
             {
                 // Level 1 of the normalisation by THIS workgroup, in LDS (build_tile_table_global's arithmetic, entry by entry):
@@ -809,14 +814,14 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 // (only the waves that own table entries do the arithmetic — at 512 tiles half of the workgroup's; the others
                 // go straight to the barriers: everything in front of the first gather is on the step's critical path, twice,
                 // because the CU's other workgroup is doing the same)
-                const bool wave_has = wave1 * 64 < dw.nt;   // wave-uniform
+                const bool wave_has = wave1 * 64 < pre_nt;   // wave-uniform
                 MP_STAMP(0, 25, 0);
                 double mb = MP_NEG_INF;
                 u64 Wb = 0ull, W2b = 0ull;
                 if (wave_has) {
-                    mb = have_tb ? mp_as_global(dw.tile_m_old)[tb] : MP_NEG_INF;
-                    Wb = have_tb ? mp_as_global(dw.tile_W_old)[tb] : 0ull;
-                    W2b = (have_tb && blockIdx.x == 0) ? mp_as_global(dw.tile_W2_old)[tb] : 0ull;
+                    mb = have_tb ? pre_tm[tb] : MP_NEG_INF;
+                    Wb = have_tb ? pre_tW[tb] : 0ull;
+                    W2b = (have_tb && blockIdx.x == 0) ? pre_tW2[tb] : 0ull;
                 }
                 MP_STAMP(0, 26, 0);
                 blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
