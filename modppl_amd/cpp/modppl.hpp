@@ -152,4 +152,104 @@ public:
     }
 };
 
+// mh / regen_mh over a REGISTERED generative function (csrc/mp_mh_models.h: MP_REGISTER_MH_MODEL / _PROPOSAL) — what calling the
+// reference's mh(&model, trace, &proposal, args) / regen_mh(&model, trace, &mask) with functions of one's own becomes.
+class FunctionChains {
+    mp_mh* h_ = nullptr;
+    uint64_t n_;
+    int32_t ns_ = 0;
+
+public:
+    // constraints = (site id, value) pairs: creation runs model.generate(params, constraints) per chain
+    FunctionChains(int32_t model_kind, const std::vector<double>& params, const std::vector<std::pair<int32_t, double>>& constraints, uint64_t num_chains,
+                   uint64_t seed, int device = 0, void* stream = nullptr)
+        : n_(num_chains) {
+        std::vector<int32_t> sites;
+        std::vector<double> vals;
+        for (const auto& c : constraints) { sites.push_back(c.first); vals.push_back(c.second); }
+        check(mp_mh_create_fn(model_kind, params.empty() ? nullptr : params.data(), (int32_t)params.size(), sites.empty() ? nullptr : sites.data(),
+                              vals.empty() ? nullptr : vals.data(), (int32_t)sites.size(), num_chains, seed, device, stream, &h_));
+        check(mp_mh_n_sites(h_, &ns_));
+    }
+    FunctionChains(const FunctionChains&) = delete;
+    ~FunctionChains() { mp_mh_destroy(h_); }
+    int32_t num_sites() const { return ns_; }
+    uint64_t mh(int32_t proposal_kind, const std::vector<double>& args = {}, int32_t n_iters = 1) {
+        uint64_t acc;
+        check(mp_mh_step(h_, proposal_kind, args.empty() ? nullptr : args.data(), (int32_t)args.size(), n_iters, &acc));
+        return acc;
+    }
+    uint64_t regen_mh(const std::vector<int32_t>& mask_sites, int32_t n_iters = 1, bool cycle = false) {
+        uint64_t acc;
+        check(mp_regen_mh_step(h_, mask_sites.empty() ? nullptr : mask_sites.data(), (int32_t)mask_sites.size(), cycle ? 1 : 0, n_iters, &acc));
+        return acc;
+    }
+    // values[chain][site] (0 where absent), present[chain] (bit k = site k is in the trace)
+    void trace(std::vector<double>& values, std::vector<uint32_t>& present) {
+        values.resize(n_ * (size_t)ns_);
+        present.resize(n_);
+        check(mp_mh_read_trace(h_, values.data(), present.data()));
+    }
+};
+
+// One rank of a filter sharded over `world` GPUs (one process per GPU): same calls as ParticleSystem, and resample() is ONE
+// library call that issues its RCCL collectives itself (mp_pf_shard_resample_rccl).  `comm`: the host's ncclComm_t, or null to
+// let the library make a communicator of its own from `id128` (mp_rccl_unique_id on rank 0, handed to the others by the host).
+class ShardedParticleSystem {
+    mp_pf* h_ = nullptr;
+    UnfoldModel model_;
+    uint64_t n_;
+    int32_t world_, rank_;
+    void* comm_ = nullptr;
+    bool own_comm_ = false;
+    bool force_;
+
+public:
+    ShardedParticleSystem(UnfoldModel model, uint64_t particles_per_rank, uint64_t seed, int32_t world, int32_t rank, void* comm, const void* id128 = nullptr,
+                          int device = 0, bool force_collectives = false)
+        : model_(std::move(model)), n_(particles_per_rank), world_(world), rank_(rank), comm_(comm), force_(force_collectives) {
+        const mp_model_desc d = model_.desc();
+        const mp_shard sh{particles_per_rank * (uint64_t)world, particles_per_rank * (uint64_t)rank};
+        check(mp_pf_create(&d, particles_per_rank, seed, &sh, 0, device, nullptr, &h_));
+        if (!comm_ && (world > 1 || force_collectives)) {
+            unsigned char id[128];
+            if (!id128) { check(mp_rccl_unique_id(id)); id128 = id; }   // (a world of one: its own id)
+            check(mp_rccl_comm_create(world, rank, id128, device, &comm_));
+            own_comm_ = true;
+        }
+    }
+    ShardedParticleSystem(const ShardedParticleSystem&) = delete;
+    ~ShardedParticleSystem() {
+        mp_pf_destroy(h_);
+        if (own_comm_) mp_rccl_comm_destroy(comm_);
+    }
+    void init_step(const std::vector<double>& args, const std::vector<double>& constraints) {
+        check(mp_pf_init_step(h_, args.empty() ? nullptr : args.data(), constraints.data(), (int32_t)(constraints.size() / model_.dim_obs)));
+    }
+    ShardedParticleSystem& step(const std::vector<double>& constraints) {
+        check(mp_pf_step(h_, constraints.data(), (int32_t)(constraints.size() / model_.dim_obs)));
+        return *this;
+    }
+    // log total weight of the whole job
+    double resample(int32_t scheme = MP_RESAMPLE_MULTINOMIAL) {
+        double v;
+        check(mp_pf_shard_resample_rccl(h_, comm_, world_, rank_, scheme, force_ ? 1 : 0, &v));
+        return v;
+    }
+    void resample_async(int32_t scheme = MP_RESAMPLE_MULTINOMIAL) { check(mp_pf_shard_resample_rccl(h_, comm_, world_, rank_, scheme, force_ ? 1 : 0, nullptr)); }
+    double log_marginal_likelihood_estimate() {
+        mp_transport t{};
+        double lml, ess;
+        if (comm_) check(mp_transport_rccl(comm_, &t));
+        check(mp_pf_shard_query_native(h_, comm_ ? &t : nullptr, world_, force_ ? 1 : 0, &lml, &ess));
+        return lml;
+    }
+    std::vector<double> states() {   // this rank's slots
+        std::vector<double> x(n_ * (size_t)model_.dim_state);
+        check(mp_pf_read_state(h_, x.data()));
+        return x;
+    }
+    mp_pf* raw() { return h_; }
+};
+
 }  // namespace modppl

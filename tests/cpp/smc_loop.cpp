@@ -28,6 +28,22 @@ int main(int argc, char** argv) {
         const uint64_t a1 = chains.mh_add_or_remove(2);
         const uint64_t a2 = chains.mh(0.1, 3);
         std::printf("accepted=%llu,%llu\n", (unsigned long long)a1, (unsigned long long)a2);
+        // a registered functor model (kind 101 = the hierarchical model again) through the generic entry points: same moves, same counts
+        modppl::FunctionChains fchains(MP_MH_MODEL_HIERARCHICAL_FN, {-1., 0., 1.}, {{MP_SITE_Y0, 0.2}, {MP_SITE_Y0 + 1, 0.9}, {MP_SITE_Y0 + 2, 2.2}}, 256, seed);
+        const uint64_t f1 = fchains.mh(MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE, {}, 2);
+        const uint64_t f2 = fchains.mh(MP_MH_PROPOSAL_HIERARCHICAL_DRIFT, {0.1}, 3);
+        std::printf("accepted_fn=%llu,%llu sites=%d\n", (unsigned long long)f1, (unsigned long long)f2, fchains.num_sites());
+        // the sharded filter in a world of one with both RCCL collectives forced: one library call per resample
+        if (argc > 3 && std::atoi(argv[3])) {
+            modppl::ShardedParticleSystem sf(modppl::UnfoldModel::lgssm(), n, seed, 1, 0, nullptr, nullptr, 0, true);
+            sf.init_step({}, {ys[0]});
+            sf.resample();
+            for (size_t t = 1; t < ys.size(); ++t) {
+                sf.step({ys[t]});
+                sf.resample();
+            }
+            std::printf("sharded lml=%.17g\n", sf.log_marginal_likelihood_estimate());
+        }
     } catch (const modppl::Panic& p) {
         std::fprintf(stderr, "panic %d: %s\n", p.code, p.what());
         return 2;

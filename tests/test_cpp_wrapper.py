@@ -35,7 +35,7 @@ def test_cpp_wrapper_runs_the_smc_loop(tmp_path):
     exe = build_exe(tmp_path)
     n, seed = 4096, 7
     env = dict(os.environ)
-    res = subprocess.run([exe, str(n), str(seed)], capture_output=True, text=True, env=env, timeout=300)
+    res = subprocess.run([exe, str(n), str(seed), "1"], capture_output=True, text=True, env=env, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     ys = [0.31, -0.12, 0.58, 1.02, 0.44, -0.27]
     pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(0.0, 1.0, 0.9, 0.5, 1.0), n, seed)
@@ -49,3 +49,8 @@ def test_cpp_wrapper_runs_the_smc_loop(tmp_path):
     want2 = "accepted=%d,%d" % (ch.mh_add_or_remove(2), ch.mh(0.1, 3))
     lines = res.stdout.strip().splitlines()
     assert lines[0] == want and lines[1] == want2, (lines, want, want2)
+    # the same chains as a registered functor model through the generic entry points, and the sharded filter's native resample
+    # (world of one, RCCL collectives forced): a world of one IS the single filter
+    assert lines[2] == want2.replace("accepted=", "accepted_fn=") + " sites=20", lines
+    sharded = [l for l in lines if l.startswith("sharded ")]   # (RCCL prints its version banner to stdout in between)
+    assert sharded == ["sharded " + want.split()[0]], (lines, want)
