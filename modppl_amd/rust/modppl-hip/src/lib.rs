@@ -4,7 +4,7 @@
 //! `step(self) -> Self` consumes the filter, `resample(&mut self) -> f64`; a non-zero status from the library is
 //! re-raised as a panic, the reference's only error convention.
 use modppl_hip_sys as sys;
-use std::ffi::CStr;
+use std::ffi::{c_void, CStr};
 use std::ptr;
 
 fn check(rc: i32) {
@@ -182,6 +182,93 @@ impl HierarchicalChains {
 
 impl Drop for HierarchicalChains {
     fn drop(&mut self) { unsafe { sys::mp_mh_destroy(self.h); } }
+}
+
+/// N chains of a REGISTERED generative function (csrc/mp_mh_models.h: `MP_REGISTER_MH_MODEL` / `MP_REGISTER_MH_PROPOSAL`) —
+/// what `mh(&model, trace, &proposal, args)` / `regen_mh(&model, trace, &mask)` (mh.rs:9-75) become for a model and proposal
+/// of one's own: sites are integer ids, `constraints` the `(site, value)` pairs of the initial `model.generate`.
+pub struct FunctionChains { h: *mut sys::mp_mh, n_chains: usize, n_sites: usize }
+
+impl FunctionChains {
+    pub fn new(model_kind: i32, params: &[f64], constraints: &[(i32, f64)], n_chains: usize, seed: u64) -> Self {
+        let sites: Vec<i32> = constraints.iter().map(|c| c.0).collect();
+        let vals: Vec<f64> = constraints.iter().map(|c| c.1).collect();
+        let mut h = ptr::null_mut();
+        check(unsafe {
+            sys::mp_mh_create_fn(model_kind, params.as_ptr(), params.len() as i32, sites.as_ptr(), vals.as_ptr(), sites.len() as i32,
+                                 n_chains as u64, seed, 0, ptr::null_mut(), &mut h)
+        });
+        let mut ns = 0i32;
+        check(unsafe { sys::mp_mh_n_sites(h, &mut ns) });
+        FunctionChains { h, n_chains, n_sites: ns as usize }
+    }
+    /// `mh(model, trace, proposal, args)` x n_iters per chain -> accepted moves
+    pub fn mh(&mut self, proposal_kind: i32, args: &[f64], n_iters: i32) -> u64 {
+        let mut acc = 0u64;
+        check(unsafe { sys::mp_mh_step(self.h, proposal_kind, args.as_ptr(), args.len() as i32, n_iters, &mut acc) });
+        acc
+    }
+    /// `regen_mh(model, trace, mask)` x n_iters per chain; an empty mask is the trace's whole schema (dyngenfn.rs:571)
+    pub fn regen_mh(&mut self, mask: &[i32], cycle: bool, n_iters: i32) -> u64 {
+        let mut acc = 0u64;
+        check(unsafe { sys::mp_regen_mh_step(self.h, mask.as_ptr(), mask.len() as i32, cycle as i32, n_iters, &mut acc) });
+        acc
+    }
+    /// `(values[chain][site], present[chain])`: bit k of `present` = site k is in the chain's trace
+    pub fn trace(&self) -> (Vec<f64>, Vec<u32>) {
+        let mut v = vec![0.0; self.n_chains * self.n_sites];
+        let mut p = vec![0u32; self.n_chains];
+        check(unsafe { sys::mp_mh_read_trace(self.h, v.as_mut_ptr(), p.as_mut_ptr()) });
+        (v, p)
+    }
+}
+
+impl Drop for FunctionChains {
+    fn drop(&mut self) { unsafe { sys::mp_mh_destroy(self.h); } }
+}
+
+/// One rank of a filter sharded over `world` GPUs (one process per GPU).  `resample` is ONE library call: the library issues
+/// its RCCL all-gather and grouped send/recv exchange itself, on the filter's stream (include/modppl_hip.h:
+/// `mp_pf_shard_resample_rccl`).  `comm` is the host's `ncclComm_t` (e.g. from an `rccl-sys` binding).
+pub struct ShardedParticleSystem { h: *mut sys::mp_pf, model: UnfoldModel, num_particles: usize, world: i32, rank: i32, comm: *mut c_void }
+
+impl ShardedParticleSystem {
+    pub fn new(model: UnfoldModel, particles_per_rank: usize, seed: u64, world: i32, rank: i32, comm: *mut c_void, device: i32) -> Self {
+        let d = sys::mp_model_desc { kind: model.kind, dim_state: model.dim_state, dim_obs: model.dim_obs, n_params: model.params.len() as i32,
+                                     params: model.params.as_ptr() };
+        let sh = sys::mp_shard { n_global: (particles_per_rank * world as usize) as u64, slot_offset: (particles_per_rank * rank as usize) as u64 };
+        let mut h = ptr::null_mut();
+        check(unsafe { sys::mp_pf_create(&d, particles_per_rank as u64, seed, &sh, 0, device, ptr::null_mut(), &mut h) });
+        ShardedParticleSystem { h, model, num_particles: particles_per_rank, world, rank, comm }
+    }
+    pub fn init_step(&mut self, args: &[f64], constraints: &[f64]) {
+        check(unsafe { sys::mp_pf_init_step(self.h, if args.is_empty() { ptr::null() } else { args.as_ptr() }, constraints.as_ptr(),
+                                            (constraints.len() / self.model.dim_obs as usize) as i32) });
+    }
+    pub fn step(self, constraints: &[f64]) -> Self {
+        check(unsafe { sys::mp_pf_step(self.h, constraints.as_ptr(), (constraints.len() / self.model.dim_obs as usize) as i32) });
+        self
+    }
+    /// log total weight of the whole job
+    pub fn resample(&mut self, scheme: i32) -> f64 {
+        let mut v = 0.0;
+        check(unsafe { sys::mp_pf_shard_resample_rccl(self.h, self.comm, self.world, self.rank, scheme, 0, &mut v) });
+        v
+    }
+    /// asynchronous: nothing is waited for but one polled word
+    pub fn resample_async(&mut self, scheme: i32) {
+        check(unsafe { sys::mp_pf_shard_resample_rccl(self.h, self.comm, self.world, self.rank, scheme, 0, ptr::null_mut()) });
+    }
+    /// this rank's slots (offspring stay on the rank that owns their parent: slot numbers carry no meaning across ranks)
+    pub fn states(&self) -> Vec<f64> {
+        let mut x = vec![0.0; self.num_particles * self.model.dim_state as usize];
+        check(unsafe { sys::mp_pf_read_state(self.h, x.as_mut_ptr()) });
+        x
+    }
+}
+
+impl Drop for ShardedParticleSystem {
+    fn drop(&mut self) { unsafe { sys::mp_pf_destroy(self.h); } }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
