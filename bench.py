@@ -35,7 +35,7 @@ DIM = 1
 #                     itself, so that launch carries these bytes too (FUSED_GATHER below)
 BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "bin_draws": 8 + 4, "resample_gather": 4 + 16 * DIM + 8}
 FUSED_GATHER = 4 + 16 * DIM + 8
-KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_draw_slots<1, 0>", "resample_gather": "k_resample_gather<0>"}
+KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024, false>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_draw_slots<1, 0>", "resample_gather": "k_resample_gather<0>"}
 BYTES_STEP = 32 * DIM + 64
 
 

@@ -138,7 +138,7 @@ struct ModelOpsT : ModelOps {
         dim_obs = Model::DIM_OBS;
         max_normals = Model::MAX_NORMALS;
         // (the conditions of CAN_DRAW in k_propagate, for the launch configuration `propagate` below picks)
-        can_draw = Model::MAX_NORMALS <= 4 && Model::DIM_STATE == 1 && mp_coop_model<Model>() && 2 * Model::MAX_NORMALS <= 4 &&
+        can_draw = Model::MAX_NORMALS <= 4 && Model::DIM_STATE <= 4 &&   // = the 1024-thread, two-slot-lane launch shape of `propagate` below
                    !std::is_same<Model, mp_lgssm_dense<16>>::value && k1_threads_override() == 0;   // (that override launches other lane shapes)
         static_assert(Model::DIM_STATE <= MP_MAX_STATE && Model::DIM_OBS <= MP_MAX_OBS, "model too wide for mp_obs / mp_state0");
         static_assert(TILE_ITEMS % k1_items<Model>() == 0, "rounds of k_propagate");
@@ -174,6 +174,15 @@ struct ModelOpsT : ModelOps {
                 hipLaunchKernelGGL(k_propagate_dense16, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
                                    a.x_out, a.logw, a.obs, a.overwrite, a.dfr_row, a.dfr_lt, a.cx_old, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux,
                                    a.inv, a.inv_rows);
+                return;
+            }
+        }
+        if constexpr (THREADS == 1024) {
+            if (a.drw && a.drw_v.nt > THREADS) {   // a drawing launch of a job with more tiles than threads: two table entries per thread
+                hipLaunchKernelGGL((k_propagate<Model, THREADS, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
+                                   a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
                 return;
             }
         }
@@ -813,7 +822,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         // kernels that make their draws themselves build the job's tile table themselves too (MP_K1_LOCAL_TABLE=0: the last
         // workgroup of every level-0 launch builds it, as for every other kernel)
         env = getenv("MP_K1_LOCAL_TABLE");
-        h->local_table = !h->sharded && h->use_k1_table && h->use_fused_draws && h->use_deferred && h->ops->can_draw && h->nt <= 1024 &&
+        h->local_table = !h->sharded && h->use_k1_table && h->use_fused_draws && h->use_deferred && h->ops->can_draw && h->nt <= 2048 &&
                          !(h->flags & MP_PF_RECORD_HISTORY) && !(env && env[0] == '0');
     }
     HIPCK(hipMalloc(&h->x[0], sizeof(double) * n * d));
@@ -985,9 +994,9 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         const mp_tab tab = tab_of(h);
         // ... and for kernels whose lanes own one Philox block's two slots, not even the draws are made here: an asynchronous
         // multinomial resample enqueues NOTHING, the next k_propagate draws for its own slots (flush_draws() otherwise)
-        // (up to 1024 tiles: the kernel's copy of the tile table, 24 B per tile, stays within the default dynamic-LDS limit)
+        // (up to 2048 tiles = 2^22 particles: the kernel's table, 24 B per tile, stays within the default dynamic-LDS limit)
         if (scheme == MP_RESAMPLE_MULTINOMIAL && !log_total_weight && h->use_fused_draws && h->ops->can_draw && h->local_table &&
-            h->nt <= 1024 && !(h->flags & MP_PF_RECORD_HISTORY)) {
+            h->nt <= 2048 && !(h->flags & MP_PF_RECORD_HISTORY)) {
             h->draw_pending = true;
             h->pending_rc = h->resample_count;
         } else {

@@ -751,7 +751,9 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
     *lw_out = w;
     *x0_out = next[0];
 }
-template <class Model, int THREADS>
+// TAB2: the drawing launch's job has more tiles than the workgroup has threads (two table entries per thread): an instantiation
+// of its own, so that the headline kernel — 62 of its 64 registers in use — does not carry a second form of the table build
+template <class Model, int THREADS, bool TAB2 = false>
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(const double* __restrict__ pre_tm, const u64* __restrict__ pre_tW, const u64* __restrict__ pre_tW2, int pre_nt, int drw,
                                                             Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
@@ -781,7 +783,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     // (a deferred draw = {start row, tile-local target}; kernels of wider states have no registers to carry the targets
     // through the deviates and read them where they look the draw up)
     constexpr bool LT_LATE = D > 1;
-    constexpr bool CAN_DRAW = !QUEUE && D == 1 && LANE_ITEMS == 2;   // (the host passes `drw` to these kernels only)
+    // a lane of two adjacent slots owns exactly the two draws of one Philox block (the host passes `drw` to these kernels only: jobs of
+    // at most 2 * THREADS tiles, whose table — 24 B per tile — fits the launch's dynamic LDS)
+    constexpr bool CAN_DRAW = LANE_ITEMS == 2 && THREADS == 1024;
     uint32_t pm[LANE_ITEMS];
     u64 plt[LANE_ITEMS];
     bool drew = false;
@@ -803,13 +807,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             const int tb = (int)threadIdx.x;
             const bool have_tb = tb < pre_nt;
             mp_u64x2 blk;
-            {
+            __shared__ double s_l1_red[THREADS / 64];
+            __shared__ u64 s_l1_tot[THREADS / 64], s_l1_tot2[THREADS / 64];
+            if constexpr (!TAB2) {
                 // Level 1 of the normalisation by THIS workgroup, in LDS (build_tile_table_global's arithmetic, entry by entry):
                 // no workgroup of the previous launch stayed behind to build the job's table after everybody else had left — that
                 // serial tail (a round of remote loads, two barriers, the stores) was 3 - 4 us of every step's kernel.  Here the
                 // same work costs each workgroup one mp_exp and one division per THREAD, under the start-up latencies.
-                __shared__ double s_l1_red[THREADS / 64];
-                __shared__ u64 s_l1_tot[THREADS / 64], s_l1_tot2[THREADS / 64];
                 const int lane1 = tb & 63, wave1 = tb >> 6;
                 // (only the waves that own table entries do the arithmetic — at 512 tiles half of the workgroup's; the others
                 // go straight to the barriers: everything in front of the first gather is on the step's critical path, twice,
@@ -872,6 +876,53 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                         s_ratio[tb] = (double)Wb / (double)T;
                     }
                 }
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    u64 Q2all = 0;
+                    for (int k = 0; k < THREADS / 64; ++k) Q2all += s_l1_tot2[k];
+                    fold_scalars(dw.scal, Qall, Q2all, dw.S, m, dw.n_global, 0);
+                }
+            } else {
+                // THREADS < tiles <= 2 THREADS (2^22 particles): thread t owns the ADJACENT entries 2t, 2t + 1 — same arithmetic entry by
+                // entry, a thread-local running sum under the wave scan
+                const int lane1 = tb & 63, wave1 = tb >> 6;
+                const int e0 = 2 * tb, e1 = 2 * tb + 1;
+                const bool h0 = e0 < pre_nt, h1 = e1 < pre_nt;
+                const double mb0 = h0 ? pre_tm[e0] : MP_NEG_INF, mb1 = h1 ? pre_tm[e1] : MP_NEG_INF;
+                const u64 Wb0 = h0 ? pre_tW[e0] : 0ull, Wb1 = h1 ? pre_tW[e1] : 0ull;
+                u64 W2b0 = 0ull, W2b1 = 0ull;
+                if (blockIdx.x == 0) { W2b0 = h0 ? pre_tW2[e0] : 0ull; W2b1 = h1 ? pre_tW2[e1] : 0ull; }
+                blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
+                asm volatile("" : "+v"(blk.a), "+v"(blk.b));
+                const double mw = wave_max(fmax(mb0, mb1));
+                if (lane1 == 0) s_l1_red[wave1] = mw;
+                __syncthreads();
+                double m = s_l1_red[0];
+#pragma unroll
+                for (int w = 1; w < THREADS / 64; ++w) m = fmax(m, s_l1_red[w]);
+                const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+                const double sc = mp_u2f((u64)(1023 + dw.S - FIX_BITS) << 52);  // 2^(S-51)
+                const u64 T0 = h0 ? mp_quantize((double)Wb0 * (ok ? mp_exp_nonpos(mb0 - m) : 0.) * sc, 1.0) : 0ull;
+                const u64 T1 = h1 ? mp_quantize((double)Wb1 * (ok ? mp_exp_nonpos(mb1 - m) : 0.) * sc, 1.0) : 0ull;
+                const u64 run = T0 + T1;
+                const u64 incl = wave_incl_scan_u64(run, lane1);
+                if (lane1 == 63) s_l1_tot[wave1] = incl;
+                if (blockIdx.x == 0) {   // (workgroup-uniform) the scalars of this normalisation: Q2 as well
+                    const u64 T20 = h0 ? mp_quantize((double)W2b0 * (ok ? mp_exp_nonpos(2. * (mb0 - m)) : 0.) * sc, 1.0) : 0ull;
+                    const u64 T21 = h1 ? mp_quantize((double)W2b1 * (ok ? mp_exp_nonpos(2. * (mb1 - m)) : 0.) * sc, 1.0) : 0ull;
+                    const u64 tot2 = wave_sum_u64(T20 + T21);
+                    if (lane1 == 0) s_l1_tot2[wave1] = tot2;
+                }
+                __syncthreads();
+                u64 woff = 0, Qall = 0;
+#pragma unroll
+                for (int k = 0; k < THREADS / 64; ++k) {
+                    const u64 tk = s_l1_tot[k];
+                    if (k < wave1) woff += tk;
+                    Qall += tk;
+                }
+                const u64 before = woff + (incl - run);
+                if (h0) { s_incl[e0] = before + T0; s_W[e0] = Wb0; s_ratio[e0] = (double)Wb0 / (double)T0; }
+                if (h1) { s_incl[e1] = before + run; s_W[e1] = Wb1; s_ratio[e1] = (double)Wb1 / (double)T1; }
                 if (blockIdx.x == 0 && threadIdx.x == 0) {
                     u64 Q2all = 0;
                     for (int k = 0; k < THREADS / 64; ++k) Q2all += s_l1_tot2[k];
@@ -1002,11 +1053,18 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             if (cx_old) {
                 u64 ltr[ITEMS];
 #pragma unroll
-                for (int pp = 0; pp < ITEMS; ++pp) ltr[pp] = LT_LATE ? (i0 + pp < n ? dfr_lt[i0 + pp] : 0ull) : plt[rd * ITEMS + pp];
+                for (int pp = 0; pp < ITEMS; ++pp) ltr[pp] = (LT_LATE && !drew) ? (i0 + pp < n ? dfr_lt[i0 + pp] : 0ull) : plt[rd * ITEMS + pp];
                 mp_resolve_draws<ITEMS>(cx_old, n, ltr, &pm[rd * ITEMS], &pm[rd * ITEMS], &px0[rd * ITEMS], inv ? nullptr : inv_rows, D + 1);
             }
 #pragma unroll
             for (int pp = 0; pp < ITEMS; ++pp) MP_RUN_PARTICLE(rd * ITEMS + pp, &zr[pp * NS]);
+        }
+        if constexpr (CAN_DRAW) {
+            if (drew) {   // this lane's two parents, slot order (particle_filter.rs:20 keeps `parents`): one 8-byte store
+                uint32_t* pp2 = mp_as_global(drw_v.parent);
+                if (base + 1 < n) *reinterpret_cast<uint2*>(pp2 + base) = make_uint2(pm[0], pm[1]);
+                else if (base < n) pp2[base] = pm[0];
+            }
         }
     } else {
         // few sites per particle: attempt 0 of every deviate in straight-line code (independent Philox chains, no
@@ -1101,7 +1159,14 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             } else {
 #pragma unroll
                 for (int p = 0; p < LANE_ITEMS; ++p)
-                    mp_resolve_draw(cx_old, n, base + p < n ? dfr_lt[base + p] : 0ull, pm[p], &pm[p], &px0[p], inv ? nullptr : inv_rows, D + 1);
+                    mp_resolve_draw(cx_old, n, drew ? plt[p] : (base + p < n ? dfr_lt[base + p] : 0ull), pm[p], &pm[p], &px0[p], inv ? nullptr : inv_rows, D + 1);
+                if constexpr (CAN_DRAW) {
+                    if (drew) {
+                        uint32_t* pp2 = mp_as_global(drw_v.parent);
+                        if (base + 1 < n) *reinterpret_cast<uint2*>(pp2 + base) = make_uint2(pm[0], pm[1]);
+                        else if (base < n) pp2[base] = pm[0];
+                    }
+                }
             }
         }
 #pragma unroll

@@ -128,10 +128,58 @@ def test_draws_made_by_the_step_equal_draws_made_by_the_resample(monkeypatch):
     assert fused.log_marginal_likelihood_estimate() == plain.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
 
 
-@pytest.mark.parametrize("n", [1 << 20, 1 << 21, (1 << 21) + 2048])
+def _wide_case(name, T):
+    """(model, observations) of the two-slot-lane kernels with wider states / more sites: fused draws since round 3"""
+    import modppl_amd
+    from tests.test_gpu_pf_models import bearings_obs, spiral_obs
+
+    if name == "bearings":      # d = 4, four normal sites at t = 0: the lane-local queue path of k_propagate
+        return modppl_amd.bearings_model(), bearings_obs(T).reshape(T, 1)
+    if name == "band4":         # d = 4, wave-cooperative deviates... four sites: the queue path again, dense-ish weights
+        return modppl_amd.lgssm_band_model(4), np.random.default_rng(11).normal(0, 1.2, size=(T, 4))
+    if name == "band2":         # d = 2, two sites: the straight-line path with a gathered parent state
+        return modppl_amd.lgssm_band_model(2), np.random.default_rng(12).normal(0, 1.2, size=(T, 2))
+    if name == "spiral":        # d = 2, uniform sites at t = 0, an mvnormal observation
+        return modppl_amd.spiral_model(), spiral_obs(T)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name,n", [("bearings", 70001), ("band4", 70001), ("band2", 70001), ("spiral", 70001),
+                                    ("bearings", (1 << 21) + 4096 + 7), ("band2", (1 << 22))])
+def test_wide_models_draw_for_themselves_too(name, n, monkeypatch):
+    """Every kernel whose lanes own two adjacent slots (1024 threads per 2048-slot tile: d <= 4, at most four normal sites) makes
+    the previous resample's draws itself, up to 2048 tiles (two table entries per thread beyond 1024: the TAB2 instantiation).
+    Against MP_FUSED_DRAWS=0 (k_draw_slots + the deferred lookups): same Philox blocks, same targets, same walk — parents, states,
+    log-weights, ESS and log-ML bit for bit; a read between resample and step (flush_draws) included."""
+    import modppl_amd
+
+    T, seed = 5, 17
+    model, obs = _wide_case(name, T)
+    fused = modppl_amd.ParticleSystem(model, n, seed)
+    monkeypatch.setenv("MP_FUSED_DRAWS", "0")
+    plain = modppl_amd.ParticleSystem(model, n, seed)
+    monkeypatch.delenv("MP_FUSED_DRAWS")
+    args0 = [0.0, 0.0] if name == "spiral" else None
+    for pf in (fused, plain):
+        pf.init_step(args0, obs[:1])
+    for t in range(1, T):
+        for pf in (fused, plain):
+            pf.resample(sync=False)
+            if t == 3:
+                pf.parents   # something other than a step comes first: the draws are flushed into k_draw_slots
+            pf.step(obs[t:t + 1])
+        assert np.array_equal(fused.parents, plain.parents), (name, t)
+    assert np.array_equal(fused.states(), plain.states())
+    assert np.array_equal(fused.log_weights, plain.log_weights)
+    assert fused.effective_sample_size(fresh=True) == plain.effective_sample_size(fresh=True)
+    assert fused.log_marginal_likelihood_estimate() == plain.log_marginal_likelihood_estimate()
+
+
+@pytest.mark.parametrize("n", [1 << 20, 1 << 21, (1 << 21) + 2048, (1 << 22), (1 << 22) + 2048])
 def test_timed_path_at_the_timed_size(n):
     """The path bench.py TIMES — step; resample(sync=False) back to back, nothing read in between — against the canonical checker
-    at the bench's population (2^20: 512 tiles) and on both sides of the switch-over at 1024 tiles: up to 2^21 particles an
+    at the bench's population (2^20: 512 tiles), on both sides of 1024 tiles (up to there one table entry per thread of the
+    drawing k_propagate, beyond it two: the TAB2 instantiation) and on both sides of 2048 tiles: up to 2^22 particles an
     asynchronous multinomial resample enqueues nothing and the next k_propagate makes the draws for its own slots from a tile
     table it builds in LDS; beyond, k_draw_slots makes them against the table one workgroup builds (mp_pf.hip: local_table,
     launch_draws).  Parents and states are read only after the step that consumed the draws."""

@@ -85,6 +85,13 @@ def main():
     if "c3" in which:
         th = np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + rng.normal(0, 0.02, T)
         out.append(pf_case("C3 bearings d=4", modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), args.steps, args.warmup, 192, args.sharded, args.scheme))
+    if "mid" in which:   # the two-slot-lane kernels of wider states at 2^20 particles (512 tiles: the guide and the tile table sit in L2 / LDS)
+        th = np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + rng.normal(0, 0.02, T)
+        out.append(pf_case("bearings d=4, 2^20", modppl_amd.bearings_model(), 1 << 20, th.reshape(T, 1), args.steps, args.warmup, 192, args.sharded, args.scheme))
+        out.append(pf_case("LGSSM band d=4, 2^20", modppl_amd.lgssm_band_model(4), 1 << 20, rng.normal(0, 1.2, size=(T, 4)), args.steps, args.warmup,
+                           192, args.sharded, args.scheme))
+        out.append(pf_case("LGSSM band d=2, 2^21", modppl_amd.lgssm_band_model(2), 1 << 21, rng.normal(0, 1.2, size=(T, 2)), args.steps, args.warmup,
+                           128, args.sharded, args.scheme))
     if "c5" in which:
         out.append(pf_case("C5 LGSSM band d=16 (one GPU's shard of 2^24 / 8)", modppl_amd.lgssm_band_model(16), 1 << 21,
                            rng.normal(0, 1.2, size=(T, 16)), args.steps, args.warmup, 576, args.sharded, args.scheme))
