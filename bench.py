@@ -35,6 +35,7 @@ DIM = 1
 #                     itself, so that launch carries these bytes too (FUSED_GATHER below)
 BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "bin_draws": 8 + 4, "resample_gather": 4 + 16 * DIM + 8}
 FUSED_GATHER = 4 + 16 * DIM + 8
+SHARD_NOTE = {}   # how the sharded filter's collectives were issued (N > 1)
 KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024, false>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_draw_slots<1, 0>", "resample_gather": "k_resample_gather<0>"}
 BYTES_STEP = 32 * DIM + 64
 
@@ -327,6 +328,25 @@ def main():
         # default, moves only each rank's surplus, =exact keeps slot order and moves (G-1)/G of the particles)
         from modppl_amd.distributed import ShardedParticleSystem
 
+        # A trial resample on a throw-away filter first: if the library's own RCCL path raises on ANY rank (it has run on one GPU
+        # only: no multi-GPU node was ever available to the builder), every rank switches to the round-2 protocol over
+        # torch.distributed (MP_SHARD_NATIVE=0) and the line says so — rather than no line at all.
+        if world > 1 and os.environ.get("MP_SHARD_NATIVE", "1") == "1":
+            ok, why = 1, ""
+            try:
+                trial = ShardedParticleSystem(model, 2048 * 4 * world, 1, engine_kwargs={"device_index": local_rank}, **shard_kw)
+                trial.init_step(None, ys[:1])
+                trial.resample(sync=True)
+                trial.step(ys[1:2])
+                trial.log_marginal_likelihood_estimate()
+                trial.close()
+            except Exception as e:   # noqa: BLE001
+                ok, why = 0, repr(e)[:200]
+            flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                os.environ["MP_SHARD_NATIVE"] = "0"
+                SHARD_NOTE["transport"] = "torch.distributed collectives from Python (the native RCCL path failed its trial%s)" % (": " + why if why else " on another rank")
         pf = ShardedParticleSystem(model, n * world, 20241008, engine_kwargs={"device_index": local_rank}, **shard_kw)
         timer = pf.engine
 
@@ -492,7 +512,11 @@ def main():
             "config": {"workload": "LGSSM d=1 bootstrap SMC, resample every step (BASELINE.json configs[1])",
                        "particles_per_gpu": n, "time_steps_timed": K, "particles_total": n * world,
                        "parallelism": "1 GPU" if world == 1 else f"one filter sharded over {world} GPUs (RCCL all-gather of tile totals + all-to-all particle exchange)",
-                       "exchange": getattr(pf, "exchange", None)},
+                       "exchange": getattr(pf, "exchange", None),
+                       "collectives": None if world == 1 and not force_sharded else SHARD_NOTE.get(
+                           "transport", ("through the library's mp_transport callbacks, staged on the host (rehearsal / gloo)" if getattr(pf, "_staged", None) is not None
+                                         else "issued by the library on the filter's stream (mp_pf_shard_resample_rccl)") if getattr(pf, "_native", False)
+                           else "torch.distributed collectives from Python (MP_SHARD_NATIVE=0)")},
             "log_ml": lml,
             "systematic_resampling_particle_steps_per_s": (n * K / dt_sys) if dt_sys else None,
             "log_ml_abs_err_vs_kalman": abs(lml - kalman),
