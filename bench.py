@@ -36,7 +36,7 @@ DIM = 1
 BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "bin_draws": 8 + 4, "resample_gather": 4 + 16 * DIM + 8}
 FUSED_GATHER = 4 + 16 * DIM + 8
 SHARD_NOTE = {}   # how the sharded filter's collectives were issued (N > 1)
-KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024, false>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_draw_slots<1, 0>", "resample_gather": "k_resample_gather<0>"}
+KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024, false, false>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_draw_slots<1, 0>", "resample_gather": "k_resample_gather<0>"}
 BYTES_STEP = 32 * DIM + 64
 
 
@@ -519,6 +519,10 @@ def main():
                            else "torch.distributed collectives from Python (MP_SHARD_NATIVE=0)")},
             "log_ml": lml,
             "systematic_resampling_particle_steps_per_s": (n * K / dt_sys) if dt_sys else None,
+            # (supplementary, not `value`: the same K steps with the systematic lattice — the reference has multinomial only; its draws
+            # are made by the step's k_propagate as well, and its sorted parents make the row lookups nearly sequential)
+            "systematic_resampling": ({"us_per_step": dt_sys / K * 1e6, "step_hbm_frac": BYTES_STEP * n * K / dt_sys / 1e9 / HBM_PEAK_GBPS}
+                                      if dt_sys else None),
             "log_ml_abs_err_vs_kalman": abs(lml - kalman),
             "step_bytes_per_particle": BYTES_STEP,
             "step_hbm_frac": BYTES_STEP * n * K / dt / 1e9 / HBM_PEAK_GBPS,

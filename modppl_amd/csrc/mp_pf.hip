@@ -178,6 +178,13 @@ struct ModelOpsT : ModelOps {
             }
         }
         if constexpr (THREADS == 1024) {
+            if ((a.drw >> 1) != 0) {   // the pending draws are a lattice's (systematic / stratified; jobs of at most THREADS tiles)
+                hipLaunchKernelGGL((k_propagate<Model, THREADS, false, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
+                                   a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
+                return;
+            }
             if (a.drw && a.drw_v.nt > THREADS) {   // a drawing launch of a job with more tiles than threads: two table entries per thread
                 hipLaunchKernelGGL((k_propagate<Model, THREADS, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
                                    a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
@@ -404,6 +411,7 @@ struct mp_pf {
     u64* tab_W = nullptr;               // the tile table's copy of tile_W (mp_tab::W)
     bool draw_pending = false;          // with `deferred`: not even the draws of the last resample have been made (counter pending_rc);
     uint32_t pending_rc = 0;            // the next k_propagate makes them, or flush_draws() when anything else needs them first
+    int pending_scheme = 0;             // (their resampling scheme)
     int use_fused_draws = 1;            // MP_FUSED_DRAWS=0: a resample always launches k_draw_slots (A/B measurements)
     mp_cx* cx_alt = nullptr;            // second row-table buffer: a k_propagate that looks up deferred draws in cx writes the new table here
     bool deferred = false;              // the last resample only drew: {dfr_lt, dfr_row}[slot] against the table in cx; x[cur] is the pre-resample state
@@ -677,7 +685,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.cx = h->deferred ? h->cx_alt : h->cx; a.guide = h->deferred ? h->guide_alt : h->guide;
     a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
     // ... and made by it too, when the resample left them pending (kernels of two-slot lanes)
-    a.drw = (h->deferred && h->draw_pending) ? 1 : 0;
+    a.drw = (h->deferred && h->draw_pending) ? (1 | (h->pending_scheme << 1)) : 0;   // bit 0: draw; bits 1..2: the scheme
     a.drw_v = mp_k1_draw{};
     if (a.drw) {
         mp_k1_draw& d = a.drw_v;
@@ -964,7 +972,7 @@ static int32_t launch_draws(mp_pf* h, int32_t scheme, uint32_t rc) {
 static int32_t flush_draws(mp_pf* h) {
     if (!h->draw_pending) return MP_OK;
     h->draw_pending = false;
-    return launch_draws(h, MP_RESAMPLE_MULTINOMIAL, h->pending_rc);
+    return launch_draws(h, h->pending_scheme, h->pending_rc);
 }
 
 int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
@@ -995,10 +1003,12 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         // ... and for kernels whose lanes own one Philox block's two slots, not even the draws are made here: an asynchronous
         // multinomial resample enqueues NOTHING, the next k_propagate draws for its own slots (flush_draws() otherwise)
         // (up to 2048 tiles = 2^22 particles: the kernel's table, 24 B per tile, stays within the default dynamic-LDS limit)
-        if (scheme == MP_RESAMPLE_MULTINOMIAL && !log_total_weight && h->use_fused_draws && h->ops->can_draw && h->local_table &&
-            h->nt <= 2048 && !(h->flags & MP_PF_RECORD_HISTORY)) {
+        // (the lattice schemes too, up to 1024 tiles: their targets need no Philox block per lane at all)
+        if ((scheme == MP_RESAMPLE_MULTINOMIAL ? h->nt <= 2048 : h->nt <= 1024) && !log_total_weight && h->use_fused_draws && h->ops->can_draw &&
+            h->local_table && !(h->flags & MP_PF_RECORD_HISTORY)) {
             h->draw_pending = true;
             h->pending_rc = h->resample_count;
+            h->pending_scheme = scheme;
         } else {
             rc = launch_draws(h, scheme, h->resample_count);
             if (rc != MP_OK) return rc;

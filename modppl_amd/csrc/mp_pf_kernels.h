@@ -687,6 +687,8 @@ struct mp_k1_draw {
 };
 __device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2, int S, double m, u64 n_global, int mode);
 __device__ __forceinline__ u64 mp_target(u64 k52, u64 Q);
+__device__ __forceinline__ uint32_t mp_systematic_k32(uint32_t rc, uint32_t k0, uint32_t k1);
+__device__ __forceinline__ u64 mp_target_lattice(int scheme, u64 g, uint32_t shared_k32, uint32_t rc, uint32_t k0, uint32_t k1, u64 Q, u64 n_global);
 __device__ __forceinline__ mp_u64x2 mp_resample_block(u64 g_pair, uint32_t rc, uint32_t domain, uint32_t k0, uint32_t k1);
 __device__ __forceinline__ void mp_locate_r(const u64* s_incl, const u64* s_W, const double* s_ratio, uint32_t nt, u64 target, double nt_over_Q,
                                             uint32_t* tile, u64* lt, uint32_t* gslot);
@@ -753,7 +755,9 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
 }
 // TAB2: the drawing launch's job has more tiles than the workgroup has threads (two table entries per thread): an instantiation
 // of its own, so that the headline kernel — 62 of its 64 registers in use — does not carry a second form of the table build
-template <class Model, int THREADS, bool TAB2 = false>
+// LAT: the pending draws are a lattice's (systematic / stratified, scheme = drw >> 1): targets from mp_target_lattice instead of a
+// Philox block per lane — again an instantiation of its own (its 64-bit divisions would cost the multinomial form registers)
+template <class Model, int THREADS, bool TAB2 = false, bool LAT = false>
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(const double* __restrict__ pre_tm, const u64* __restrict__ pre_tW, const u64* __restrict__ pre_tW2, int pre_nt, int drw,
                                                             Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
@@ -807,6 +811,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             const int tb = (int)threadIdx.x;
             const bool have_tb = tb < pre_nt;
             mp_u64x2 blk;
+            uint32_t lat_k32 = 0u;
             __shared__ double s_l1_red[THREADS / 64];
             __shared__ u64 s_l1_tot[THREADS / 64], s_l1_tot2[THREADS / 64];
             if constexpr (!TAB2) {
@@ -828,8 +833,12 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                     W2b = (have_tb && blockIdx.x == 0) ? pre_tW2[tb] : 0ull;
                 }
                 MP_STAMP(0, 26, 0);
-                blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
-                asm volatile("" : "+v"(blk.a), "+v"(blk.b));
+                if constexpr (LAT) {   // the resample's one shared uniform (systematic); stratified draws one per slot below
+                    lat_k32 = (drw >> 1) == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+                } else {
+                    blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
+                    asm volatile("" : "+v"(blk.a), "+v"(blk.b));
+                }
                 MP_STAMP(0, 27, 0);
                 if (wave_has) {
                     const double mw = wave_max(mb);
@@ -891,8 +900,12 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 const u64 Wb0 = h0 ? pre_tW[e0] : 0ull, Wb1 = h1 ? pre_tW[e1] : 0ull;
                 u64 W2b0 = 0ull, W2b1 = 0ull;
                 if (blockIdx.x == 0) { W2b0 = h0 ? pre_tW2[e0] : 0ull; W2b1 = h1 ? pre_tW2[e1] : 0ull; }
-                blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
-                asm volatile("" : "+v"(blk.a), "+v"(blk.b));
+                if constexpr (LAT) {   // the resample's one shared uniform (systematic); stratified draws one per slot below
+                    lat_k32 = (drw >> 1) == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+                } else {
+                    blk = mp_resample_block((slot_offset + base) >> 1, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1);   // base is even
+                    asm volatile("" : "+v"(blk.a), "+v"(blk.b));
+                }
                 const double mw = wave_max(fmax(mb0, mb1));
                 if (lane1 == 0) s_l1_red[wave1] = mw;
                 __syncthreads();
@@ -937,7 +950,12 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             uint32_t gslot[2], tile_of[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)dw.nt, mp_target(mp_u52(q ? blk.b : blk.a), Q), nt_over_Q, &tile_of[q], &plt[q], &gslot[q]);
+            {
+                u64 tg;
+                if constexpr (LAT) tg = mp_target_lattice(drw >> 1, slot_offset + (base + q < n ? base + q : 0ull), lat_k32, rc, k0, k1, Q, dw.n_global);
+                else tg = mp_target(mp_u52(q ? blk.b : blk.a), Q);
+                mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)dw.nt, tg, nt_over_Q, &tile_of[q], &plt[q], &gslot[q]);
+            }
             uint32_t j0[2];
             MP_STAMP(0, 18, 0);
 #pragma unroll

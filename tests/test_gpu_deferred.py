@@ -175,6 +175,48 @@ def test_wide_models_draw_for_themselves_too(name, n, monkeypatch):
     assert fused.log_marginal_likelihood_estimate() == plain.log_marginal_likelihood_estimate()
 
 
+@pytest.mark.parametrize("scheme", [1, 2])
+@pytest.mark.parametrize("name,n", [("lgssm1", 70001), ("lgssm1", 1 << 20), ("bearings", 70001), ("band2", 40000)])
+def test_lattice_draws_made_by_the_step(name, n, scheme, monkeypatch):
+    """Systematic (1) and stratified (2) resampling, asynchronous: the next k_propagate makes these draws too (its LAT
+    instantiation: targets from the lattice function, no Philox block per lane; jobs of up to 1024 tiles).  Against
+    MP_FUSED_DRAWS=0 (k_draw_slots<., scheme>) bit for bit, and for the LGSSM against the canonical checker; schemes alternate
+    with multinomial in one run."""
+    import modppl_amd
+
+    T, seed = 6, 23
+    if name == "lgssm1":
+        model, obs = modppl_amd.lgssm_model(*O.LGSSM_PARAMS), O.lgssm_observations(T).reshape(T, 1)
+    else:
+        model, obs = _wide_case(name, T)
+    fused = modppl_amd.ParticleSystem(model, n, seed)
+    monkeypatch.setenv("MP_FUSED_DRAWS", "0")
+    plain = modppl_amd.ParticleSystem(model, n, seed)
+    monkeypatch.delenv("MP_FUSED_DRAWS")
+    ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA) if name == "lgssm1" else None
+    for pf in (fused, plain):
+        pf.init_step(None, obs[:1])
+    if ref:
+        ref.init_step(obs[:1])
+    for t in range(1, T):
+        sch = scheme if t != 3 else 0   # a multinomial resample in between: the same handle switches kernels
+        for pf in (fused, plain):
+            pf.resample(sch, sync=False)
+            pf.step(obs[t:t + 1])
+        assert np.array_equal(fused.parents, plain.parents), (name, t)
+        if ref:
+            ref.resample(sch)
+            want = ref.parents().copy()
+            ref.step(obs[t:t + 1])
+            assert np.array_equal(fused.parents, want), (name, t)
+    assert np.array_equal(fused.states(), plain.states())
+    assert np.array_equal(fused.log_weights, plain.log_weights)
+    assert fused.log_marginal_likelihood_estimate() == plain.log_marginal_likelihood_estimate()
+    if ref:
+        assert np.array_equal(fused.states(), ref.state())
+        assert fused.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+
+
 @pytest.mark.parametrize("n", [1 << 20, 1 << 21, (1 << 21) + 2048, (1 << 22), (1 << 22) + 2048])
 def test_timed_path_at_the_timed_size(n):
     """The path bench.py TIMES — step; resample(sync=False) back to back, nothing read in between — against the canonical checker
