@@ -73,3 +73,77 @@ def test_unsharded_filter_edges(n, seed, scheme):
         ref.step(ys[t:t + 1].reshape(1, 1))
         assert np.array_equal(pf.log_weights, ref.log_weights())
     assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+
+
+def _random_program(rng, length):
+    """a random sequence of filter operations: what may follow what in the reference's API"""
+    ops = []
+    for _ in range(length):
+        r = rng.random()
+        if r < 0.45:
+            ops.append(("resample_async", int(rng.choice([0, 0, 1, 2]))))
+        elif r < 0.55:
+            ops.append(("resample_sync", int(rng.choice([0, 1, 2]))))
+        elif r < 0.65:
+            ops.append(("read", str(rng.choice(["parents", "states", "log_weights", "ess", "lml"]))))
+        ops.append(("step", None))
+    return ops
+
+
+@pytest.mark.parametrize("rep", [0, 1, 2])
+@pytest.mark.parametrize("name,n,seed", [("lgssm1", 70001, 1), ("lgssm1", (1 << 20) + 4096 + 5, 2), ("lgssm1", (1 << 21) + 2048, 3),
+                                         ("bearings", 50001, 4), ("band2", 2 * 2048 * 1024 + 2048, 5), ("spiral", 9000, 6)])
+def test_random_programs_fused_against_unfused(name, n, seed, rep, monkeypatch):
+    """The state machine around the draws a step may make for itself (pending scheme, flush on a read, synchronous resamples in
+    between, both table forms, the lattice instantiation): a random program of steps, asynchronous / synchronous resamples of
+    all three schemes and reads, run on a handle whose k_propagate draws and on one that always launches k_draw_slots
+    (MP_FUSED_DRAWS=0).  Every read and the final state must agree bit for bit."""
+    import modppl_amd
+    from tests.test_gpu_deferred import _wide_case
+
+    rng = np.random.default_rng(900 + seed + 100 * rep)
+    prog = _random_program(rng, 14)
+    T = 1 + sum(1 for op, _ in prog if op == "step")
+    if name == "lgssm1":
+        model, obs = modppl_amd.lgssm_model(*O.LGSSM_PARAMS), O.lgssm_observations(T).reshape(T, 1)
+    else:
+        model, obs = _wide_case(name, T)
+    fused = modppl_amd.ParticleSystem(model, n, 40 + seed)
+    monkeypatch.setenv("MP_FUSED_DRAWS", "0")
+    plain = modppl_amd.ParticleSystem(model, n, 40 + seed)
+    monkeypatch.delenv("MP_FUSED_DRAWS")
+    args0 = [0.0, 0.0] if name == "spiral" else None
+    for pf in (fused, plain):
+        pf.init_step(args0, obs[:1])
+    t = 1
+    resampled = False
+    for op, arg in prog:
+        got = []
+        for pf in (fused, plain):
+            if op == "step":
+                pf.step(obs[t:t + 1])
+            elif op == "resample_async":
+                pf.resample(arg, sync=False)
+            elif op == "resample_sync":
+                got.append(pf.resample(arg, sync=True))
+            elif arg == "parents":
+                got.append(pf.parents.copy() if resampled else None)
+            elif arg == "states":
+                got.append(pf.states())
+            elif arg == "log_weights":
+                got.append(pf.log_weights.copy())
+            elif arg == "ess":
+                got.append(pf.effective_sample_size(fresh=True))
+            else:
+                got.append(pf.log_marginal_likelihood_estimate())
+        if op == "step":
+            t += 1
+        if op.startswith("resample"):
+            resampled = True
+        if got and got[0] is not None:
+            assert np.array_equal(np.asarray(got[0]), np.asarray(got[1])), (name, op, arg, t)
+    assert np.array_equal(fused.states(), plain.states())
+    assert np.array_equal(fused.log_weights, plain.log_weights)
+    if resampled:
+        assert np.array_equal(fused.parents, plain.parents)
+    assert fused.log_marginal_likelihood_estimate() == plain.log_marginal_likelihood_estimate()
