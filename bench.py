@@ -162,29 +162,36 @@ def sub_benches(steps, warmup, which):
     rng = np.random.default_rng(20241008)
     T = 1 + warmup + steps
     res = {}
+    capi_MULTINOMIAL, capi_SYSTEMATIC = 0, 1   # MP_RESAMPLE_*
 
-    def pf_case(model, n, obs, d):
-        pf = modppl_amd.ParticleSystem(model, n, 20241008)
-        pf.init_step(None, obs[:1])
-        pf.resample(sync=False)
-        for t in range(1, 1 + warmup):
-            pf.step(obs[t:t + 1])
-            pf.resample(sync=False)
-        pf.synchronize()
-        t0 = time.perf_counter()
-        for t in range(1 + warmup, T):
-            pf.step(obs[t:t + 1])
-            pf.resample(sync=False)
-        pf.synchronize()
-        dt = time.perf_counter() - t0
+    def pf_case(model, n, obs, d, also_systematic=False):
+        def run(scheme):
+            pf = modppl_amd.ParticleSystem(model, n, 20241008)
+            pf.init_step(None, obs[:1])
+            pf.resample(scheme, sync=False)
+            for t in range(1, 1 + warmup):
+                pf.step(obs[t:t + 1])
+                pf.resample(scheme, sync=False)
+            pf.synchronize()
+            t0 = time.perf_counter()
+            for t in range(1 + warmup, T):
+                pf.step(obs[t:t + 1])
+                pf.resample(scheme, sync=False)
+            pf.synchronize()
+            return time.perf_counter() - t0, pf.log_marginal_likelihood_estimate()
+
+        dt, lml = run(capi_MULTINOMIAL)
         b = 32 * d + 64
-        return {"particles": n, "dim_state": d, "steps": steps, "us_per_step": dt / steps * 1e6, "particle_steps_per_s": n * steps / dt,
-                "step_bytes_per_particle": b, "step_hbm_frac": b * n * steps / dt / 1e9 / HBM_PEAK_GBPS,
-                "log_ml": pf.log_marginal_likelihood_estimate()}
+        out = {"particles": n, "dim_state": d, "steps": steps, "us_per_step": dt / steps * 1e6, "particle_steps_per_s": n * steps / dt,
+               "step_bytes_per_particle": b, "step_hbm_frac": b * n * steps / dt / 1e9 / HBM_PEAK_GBPS, "log_ml": lml}
+        if also_systematic:   # supplementary (the reference has multinomial only): the same steps with the systematic lattice
+            dts, _ = run(capi_SYSTEMATIC)
+            out["systematic_resampling"] = {"us_per_step": dts / steps * 1e6, "step_hbm_frac": b * n * steps / dts / 1e9 / HBM_PEAK_GBPS}
+        return out
 
     if "c3" in which:
         th = np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + rng.normal(0, 0.02, T)
-        res["c3"] = dict(pf_case(modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), 4), workload="bearings-only tracker d=4, 2^22 particles (BASELINE.json configs[2])")
+        res["c3"] = dict(pf_case(modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), 4, also_systematic=True), workload="bearings-only tracker d=4, 2^22 particles (BASELINE.json configs[2])")
     if "c5" in which:
         res["c5_shard"] = dict(pf_case(modppl_amd.lgssm_band_model(16), 1 << 21, rng.normal(0, 1.2, size=(T, 16)), 16),
                                workload="LGSSM d=16, 2^21 particles = one GPU's share of configs[4] (16M over 8 GPUs), unsharded code path")

@@ -22,7 +22,7 @@ int32_t mp_probe_normal_sample(uint64_t seed, uint32_t slot0, uint32_t step, uin
 int32_t mp_probe_u01(uint64_t seed, uint32_t slot0, uint32_t step, uint32_t domain, uint32_t site, uint32_t attempt, int64_t n,
                      double* out, int32_t device);
 
-/* mvnormal of dimension k <= 16 (modppl/src/modeling/dists/mvnormal.rs:14-38), determinant / inverse / transform hoisted to the
+/* mvnormal of dimension k <= 64 (modppl/src/modeling/dists/mvnormal.rs:14-38; model sites are compiled for k <= 16), determinant / inverse / transform hoisted to the
  * host once: logpdf_out[i] = logpdf(x[i][0..k); mu, cov) when logpdf_out != NULL; sample_out[i][0..k) = random with the Philox
  * stream (seed, slot0 + i, step, domain, site) when sample_out != NULL (covariances without a Cholesky factor take the
  * eigen transform, :30-33).  chain = 0: the reference's multiply-then-add order; 1: the matrix cores' fma chain. */

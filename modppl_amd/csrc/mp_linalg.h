@@ -1,4 +1,4 @@
-// mp_linalg.h — host-side dense helpers for model constants (k <= 16): determinant and inverse of a
+// mp_linalg.h — host-side dense helpers for model constants (any k; model sites use k <= 16): determinant and inverse of a
 // covariance, evaluated ONCE per model instead of once per logpdf call as modppl does
 // (modppl/src/modeling/dists/mvnormal.rs:17-18 calls nalgebra's determinant() and try_inverse() inside
 // every logpdf).  LU / Gauss-Jordan with partial pivoting, row-major.

@@ -178,11 +178,17 @@ struct ModelOpsT : ModelOps {
             }
         }
         if constexpr (THREADS == 1024) {
-            if ((a.drw >> 1) != 0) {   // the pending draws are a lattice's (systematic / stratified; jobs of at most THREADS tiles)
-                hipLaunchKernelGGL((k_propagate<Model, THREADS, false, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
-                                   a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
+            if ((a.drw >> 1) != 0) {   // the pending draws are a lattice's (systematic / stratified)
+                if (a.drw_v.nt > THREADS)
+                    hipLaunchKernelGGL((k_propagate<Model, THREADS, true, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
+                                       a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                       a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                       a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
+                else
+                    hipLaunchKernelGGL((k_propagate<Model, THREADS, false, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
+                                       a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                       a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                       a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
                 return;
             }
             if (a.drw && a.drw_v.nt > THREADS) {   // a drawing launch of a job with more tiles than threads: two table entries per thread
@@ -1003,8 +1009,8 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         // ... and for kernels whose lanes own one Philox block's two slots, not even the draws are made here: an asynchronous
         // multinomial resample enqueues NOTHING, the next k_propagate draws for its own slots (flush_draws() otherwise)
         // (up to 2048 tiles = 2^22 particles: the kernel's table, 24 B per tile, stays within the default dynamic-LDS limit)
-        // (the lattice schemes too, up to 1024 tiles: their targets need no Philox block per lane at all)
-        if ((scheme == MP_RESAMPLE_MULTINOMIAL ? h->nt <= 2048 : h->nt <= 1024) && !log_total_weight && h->use_fused_draws && h->ops->can_draw &&
+        // (the lattice schemes too: their targets need no Philox block per lane at all)
+        if (h->nt <= 2048 && !log_total_weight && h->use_fused_draws && h->ops->can_draw &&
             h->local_table && !(h->flags & MP_PF_RECORD_HISTORY)) {
             h->draw_pending = true;
             h->pending_rc = h->resample_count;

@@ -41,12 +41,14 @@ __global__ void k_probe_u01(uint32_t k0, uint32_t k1, uint32_t slot0, uint32_t s
     out[2 * i + 1] = mp_u01(b.b);
 }
 
-// mvnormal (mvnormal.rs:14-38) of dimension k <= 16 with the covariance constants hoisted by the host (mp_linalg.h):
+// mvnormal (mvnormal.rs:14-38) of dimension k <= MP_PROBE_MAX_K with the covariance constants hoisted by the host (mp_linalg.h;
+// the reference takes any k; model sites are compiled for k <= 16, this general-k form serves the distribution on its own):
+#define MP_PROBE_MAX_K 64
 // out[i] = logpdf(x_i; mu, cov) in the reference's operation order (chain = 0) or as the matrix cores' fma chain (chain = 1)
 __global__ void k_probe_mvnormal_logpdf(int k, int chain, const double* x, const double* mu, const double* cov_inv, double ln_det, long long n, double* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double c[16];
+    double c[MP_PROBE_MAX_K];
     for (int a = 0; a < k; ++a) c[a] = x[i * k + a] - mu[a];
     double maha = 0.;
     for (int j = 0; j < k; ++j) {
@@ -64,7 +66,7 @@ __global__ void k_probe_mvnormal_sample(int k, int chain, uint32_t k0, uint32_t 
     mp_stream s;
     s.k0 = k0; s.k1 = k1; s.slot = slot0 + (uint32_t)i; s.step = step;
     mp_site st(s, domain, site);
-    double z[16];
+    double z[MP_PROBE_MAX_K];
     for (int j = 0; j < k; ++j) z[j] = mp_normal_sample(st, 0., 1.);
     for (int a = 0; a < k; ++a) {
         double acc = 0.;
@@ -146,7 +148,7 @@ done:
 
 int32_t mp_probe_mvnormal(int32_t k, int32_t chain, const double* x, const double* mu, const double* cov, int64_t n, double* logpdf_out,
                           uint64_t seed, uint32_t slot0, uint32_t step, uint32_t domain, uint32_t site, double* sample_out, int32_t device) {
-    if (k < 1 || k > 16 || !mu || !cov || n < 1) return MP_ERR_INVALID_ARG;
+    if (k < 1 || k > MP_PROBE_MAX_K || !mu || !cov || n < 1) return MP_ERR_INVALID_ARG;
     int32_t rc = MP_OK;
     const std::vector<double> c(cov, cov + (size_t)k * k);
     std::vector<double> inv, T;

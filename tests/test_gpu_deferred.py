@@ -176,10 +176,11 @@ def test_wide_models_draw_for_themselves_too(name, n, monkeypatch):
 
 
 @pytest.mark.parametrize("scheme", [1, 2])
-@pytest.mark.parametrize("name,n", [("lgssm1", 70001), ("lgssm1", 1 << 20), ("bearings", 70001), ("band2", 40000)])
+@pytest.mark.parametrize("name,n", [("lgssm1", 70001), ("lgssm1", 1 << 20), ("lgssm1", (1 << 21) + 2048), ("bearings", 70001), ("band2", 40000),
+                                    ("bearings", (1 << 21) + 6144)])
 def test_lattice_draws_made_by_the_step(name, n, scheme, monkeypatch):
     """Systematic (1) and stratified (2) resampling, asynchronous: the next k_propagate makes these draws too (its LAT
-    instantiation: targets from the lattice function, no Philox block per lane; jobs of up to 1024 tiles).  Against
+    instantiation: targets from the lattice function, no Philox block per lane; both table forms).  Against
     MP_FUSED_DRAWS=0 (k_draw_slots<., scheme>) bit for bit, and for the LGSSM against the canonical checker; schemes alternate
     with multinomial in one run."""
     import modppl_amd

@@ -55,10 +55,11 @@ def spd(k, rng, scale=1.0):
 
 
 def test_general_k_logpdf_and_random_vs_checker(hiplib, oracle):
-    """k = 3 .. 16: the device (constants hoisted once) against the checker's per-call determinant / inverse / Cholesky —
-    bit for bit in both operation orders (the hoisted routines restate the same eliminations)."""
+    """k = 3 .. 64 (the reference's mvnormal takes any k; model sites are compiled for k <= 16, the general-k form is the probe's):
+    the device (constants hoisted once) against the checker's per-call determinant / inverse / Cholesky — bit for bit in both
+    operation orders (the hoisted routines restate the same eliminations)."""
     rng = np.random.default_rng(7)
-    for k in (3, 5, 8, 16):
+    for k in (3, 5, 8, 16, 24, 40, 64):
         mu, cov = rng.normal(size=k), spd(k, rng)
         xs = rng.normal(size=(64, k)) * 1.5
         for chain in (0, 1):
