@@ -112,8 +112,8 @@ int32_t mp_pf_effective_sample_size(mp_pf* h, int32_t ess_mode, double* out);
  * pass NULL to enqueue without synchronising (the value still feeds the log-ML estimate).
  * Degenerate weights (all -inf / NaN: where the reference's categorical asserts, categorical.rs:23) are MP_ERR_DEGENERATE from
  * this call when it synchronises; from an asynchronous one the error is sticky and surfaces at the next synchronising call
- * AFTER the work that normalises has run — for filters whose next mp_pf_step makes the resample's draws itself (two-slot
- * lanes, dim_state 1, at most 2^21 particles) that is the first synchronising call after that step, not an
+ * AFTER the work that normalises has run — for filters whose next mp_pf_step makes the resample's draws itself (dim_state <= 4
+ * and at most four normal sites, at most 2^22 particles; any of the three schemes) that is the first synchronising call after that step, not an
  * mp_pf_synchronize directly behind the resample: nothing of the resample has been enqueued by then. */
 int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight);
 /* ESS-triggered resampling (extension named by the north star): resample with `scheme` iff the effective sample size of the

@@ -124,7 +124,7 @@ struct ModelOps {
     int dim_state = 0, dim_obs = 0;
     void* owned_device_mem = nullptr;   // model constants that do not fit kernel arguments (freed with the model)
     int max_normals = 0;
-    bool can_draw = false;   // its k_propagate can make the previous resample's draws itself (lanes of two adjacent slots, d = 1)
+    bool can_draw = false;   // its k_propagate can make the previous resample's draws itself (lanes of two adjacent slots: the 1024-thread launch shape)
     virtual ~ModelOps() { if (owned_device_mem) (void)hipFree(owned_device_mem); }
     virtual void propagate(const PropagateArgs& a) const = 0;
     virtual int n_normals(long long t) const = 0;
