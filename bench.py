@@ -403,7 +403,7 @@ def main():
     lml = pf.log_marginal_likelihood_estimate()
     # ---- supplementary: the same K steps with systematic resampling (named next to multinomial in the north star; not `value`)
     dt_sys = None
-    if world == 1 and not force_sharded and not args.no_systematic_leg:
+    if not force_sharded and not args.no_systematic_leg:   # (at N > 1 too: the sharded filter's lattice schemes need no enumeration of all N draws)
         barrier()
         t0 = time.perf_counter()
         for t in range(1 + W, T):
@@ -411,6 +411,10 @@ def main():
             pf.resample(scheme=1, sync=False)
         barrier()
         dt_sys = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt_sys], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_sys = float(tt.item())
     # ---- per-kernel durations: the same K steps again with a hipEvent pair around every launch, recorded on the
     # stream the kernels run on (the pairs cost ~20 us per step, so they stay out of the region `value` is taken from)
     fam = {"propagate": (0.0, 0), "normalize_scan": (0.0, 0), "bin_draws": (0.0, 0), "resample_gather": (0.0, 0)}
@@ -525,10 +529,10 @@ def main():
                                          else "issued by the library on the filter's stream (mp_pf_shard_resample_rccl)") if getattr(pf, "_native", False)
                            else "torch.distributed collectives from Python (MP_SHARD_NATIVE=0)")},
             "log_ml": lml,
-            "systematic_resampling_particle_steps_per_s": (n * K / dt_sys) if dt_sys else None,
+            "systematic_resampling_particle_steps_per_s": (n * world * K / dt_sys) if dt_sys else None,
             # (supplementary, not `value`: the same K steps with the systematic lattice — the reference has multinomial only; its draws
             # are made by the step's k_propagate as well, and its sorted parents make the row lookups nearly sequential)
-            "systematic_resampling": ({"us_per_step": dt_sys / K * 1e6, "step_hbm_frac": BYTES_STEP * n * K / dt_sys / 1e9 / HBM_PEAK_GBPS}
+            "systematic_resampling": ({"us_per_step": dt_sys / K * 1e6, "step_hbm_frac": BYTES_STEP * n * K / dt_sys / 1e9 / HBM_PEAK_GBPS}   # (per GPU)
                                       if dt_sys else None),
             "log_ml_abs_err_vs_kalman": abs(lml - kalman),
             "step_bytes_per_particle": BYTES_STEP,
