@@ -28,8 +28,11 @@
 //   call       the sub-call's weight is accumulated from 0, closed by its own gc, and added to the caller's as ONE term;
 //              a constrained / masked / new sub-call sets the caller's diff to Unknown; an untouched one under NoChange is
 //              replayed (its body runs, every site returns its previous value: the static form of `return retv`)     (:321-446)
-// What is NOT restated: `Regenerate` through an unmasked sub-call after an upstream change (generate(args, sub) against the
-// sub-trie's running weight, :424-428) and leftover constraints — both raise `panic`, which the kernels report as an error.
+//              `Regenerate` through an UNMASKED sub-call after an upstream change is generate(args, sub) with the old sub-trace as
+//              constraints, weight += new_weight - sub.weight() (:424-428): sub.weight() is the sub-trie's RUNNING weight — the
+//              history of its inserts and removes, not a fresh sum — so a trace carries it per sub-call (`subw`, indexed by the
+//              sub-call's lowest site) and the handler applies the trie's own += / -= to it, in the trie's order (trie.rs:118-184).
+// What is NOT restated: leftover constraints (the reference's panic): `panic`, which the kernels report as an error.
 #pragma once
 #include "mp_dists.h"
 
@@ -44,6 +47,7 @@ template <int NS>
 struct mp_fn_trace {
     double val[NS];
     double lp[NS];
+    double subw[NS];   // [lowest site of a sub-call] the running weight of that sub-trie
     uint32_t present;
     MP_HD bool has(int site) const { return (present >> site) & 1u; }
     // tr.data.read(addr) of a proposal body; `dflt` when the address is absent (hierarchical.rs:54-58 `search`)
@@ -53,7 +57,7 @@ template <int NS>
 MP_HD void mp_fn_clear(mp_fn_trace<NS>& t) {
     t.present = 0u;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) { t.val[k] = 0.; t.lp[k] = 0.; }
+    for (int k = 0; k < NS; ++k) { t.val[k] = 0.; t.lp[k] = 0.; t.subw[k] = 0.; }
 }
 // trace.logjp: the choices' log-densities in site order
 template <int NS>
@@ -92,10 +96,13 @@ struct mp_fn_handler {
     bool changed;                     // diff == ArgDiff::Unknown
     uint32_t visited, consumed, discarded;
     bool panic;
+    double sw;            // inside a sub-call: the running weight of its trie
+    bool in_sub;          // the sites visited belong to a sub-trie whose weight is being kept
+    bool from_prev;       // REGENERATE through an unmasked sub-call after an upstream change: generate with the old choices as constraints
 
     MP_HD mp_fn_handler(const mp_stream& r, uint32_t dom_, const mp_fn_trace<NS>* prev_, const mp_fn_trace<NS>* cons_, uint32_t mask_ = 0u)
         : rng(r), dom(dom_), prev(prev_), cons(cons_), mask(mask_), weight(0.), changed(false), visited(0u), consumed(0u), discarded(0u),
-          panic(false) {
+          panic(false), sw(0.), in_sub(false), from_prev(false) {
         mp_fn_clear(tr);
     }
     MP_HD double exp_(double x) const { return mp_exp(x); }
@@ -107,11 +114,14 @@ struct mp_fn_handler {
         constexpr uint32_t bit = 1u << SITE;
         visited |= bit;
         double x, lp;
+        // (`sw`: what the trie does to the weight of the sub-trie this site lives in — remove: -= the old choice's, w_observe / insert:
+        // += the new one's, trie.rs:118-184 — in the order sample_at does them)
         if constexpr (MODE == MP_FN_SIMULATE) {
             mp_site st(rng, dom, (uint32_t)SITE);
             x = d.sample(st);
             lp = d.logpdf(x);
             weight += lp;
+            if (in_sub) sw += lp;
         } else if constexpr (MODE == MP_FN_GENERATE) {
             if (cons->present & bit) {
                 consumed |= bit;
@@ -123,23 +133,43 @@ struct mp_fn_handler {
                 x = d.sample(st);
                 lp = d.logpdf(x);
             }
+            if (in_sub) sw += lp;
         } else {
             const bool had = (prev->present & bit) != 0u;
+            if (from_prev) {   // generate(args, sub): the old choice is the constraint (:116-131); a site the old sub-trace lacks is drawn
+                if (had) {
+                    x = prev->val[SITE];
+                    lp = d.logpdf(x);
+                    weight += lp;
+                } else {
+                    mp_site st(rng, dom, (uint32_t)SITE);
+                    x = d.sample(st);
+                    lp = d.logpdf(x);
+                }
+                sw += lp;
+                tr.val[SITE] = x; tr.lp[SITE] = lp; tr.present |= bit;
+                return x;
+            }
             bool fresh = false;   // drawn from the distribution
             if constexpr (MODE == MP_FN_UPDATE) {
                 if (cons->present & bit) {
                     consumed |= bit;
-                    if (had) { weight -= prev->lp[SITE]; discarded |= bit; }
+                    if (had) {
+                        weight -= prev->lp[SITE]; discarded |= bit;
+                        if (in_sub) sw -= prev->lp[SITE];
+                    }
                     x = cons->val[SITE];
                     lp = d.logpdf(x);
                     changed = true;
                     weight += lp;
+                    if (in_sub) sw += lp;
                     tr.val[SITE] = x; tr.lp[SITE] = lp; tr.present |= bit;
                     return x;
                 }
             } else {
                 fresh = (mask & bit) != 0u;
             }
+            if (in_sub && had) sw -= prev->lp[SITE];   // trace.data.remove(addr) comes first in every arm
             if (!fresh && had) {
                 x = prev->val[SITE];
                 if (!changed) {
@@ -154,6 +184,7 @@ struct mp_fn_handler {
                 lp = d.logpdf(x);
                 changed = true;
             }
+            if (in_sub) sw += lp;
         }
         tr.val[SITE] = x; tr.lp[SITE] = lp; tr.present |= bit;
         return x;
@@ -171,21 +202,32 @@ struct mp_fn_handler {
         double c = 0.;
 #pragma unroll
         for (int k = 0; k < NS; ++k)
-            if ((un >> k) & 1u) c += prev->lp[k];
+            if ((un >> k) & 1u) {
+                c += prev->lp[k];
+                if (in_sub) sw -= prev->lp[k];   // collect removes them from the (sub-)trie
+            }
         discarded |= un;
         return c;
     }
 
     template <uint32_t SITES, class Body>
     MP_HD auto call(Body&& body) {
+        static_assert(SITES != 0u, "a sub-call names the set of its sites");
+        constexpr int ID = __builtin_ctz(SITES);   // where the trace keeps this sub-trie's running weight
         if constexpr (MODE == MP_FN_SIMULATE) {
-            return body(*this);   // the sub-trace's choices are the caller's; `propose`'s weight is the whole trie's
+            // the sub-trace's choices are the caller's; `propose`'s weight is the whole trie's
+            in_sub = true; sw = 0.;
+            auto r = body(*this);
+            in_sub = false; tr.subw[ID] = sw;
+            return r;
         } else if constexpr (MODE == MP_FN_GENERATE) {
             // generate(args, choices): weight += d_weight as one term (:316-319); simulate when nothing is constrained
             const double w_out = weight;
             const bool any = (cons->present & SITES) != 0u;
             weight = 0.;
+            in_sub = true; sw = 0.;
             auto r = body(*this);
+            in_sub = false; tr.subw[ID] = sw;
             weight = any ? w_out + weight : w_out;
             return r;
         } else {
@@ -195,18 +237,32 @@ struct mp_fn_handler {
             else touched = mask & SITES;
             const double w_out = weight;
             if (!touched && had && !changed) {
-                auto r = body(*this);   // replay: every site returns its previous value and log-density
+                auto r = body(*this);   // replay: every site returns its previous value and log-density; the sub-trie is not touched
                 weight = w_out;
                 changed = false;
+                tr.subw[ID] = prev->subw[ID];
                 return r;
             }
-            if (MODE == MP_FN_REGENERATE && !touched && had) panic = true;   // generate(args, sub) - sub.weight(): not restated
+            if (MODE == MP_FN_REGENERATE && !touched && had) {
+                // generate(args, sub): new_weight from 0 over the old choices, a fresh sub-trie; weight += new_weight - sub.weight()
+                weight = 0.;
+                from_prev = true; sw = 0.;
+                auto r = body(*this);
+                from_prev = false;
+                if (had & ~visited) panic = true;   // "not all constraints were consumed" (:526-529)
+                weight = w_out + (weight - prev->subw[ID]);
+                tr.subw[ID] = sw;
+                changed = true;
+                return r;
+            }
             weight = 0.;
+            in_sub = true; sw = had ? prev->subw[ID] : 0.;
             auto r = body(*this);
             if (had) {
                 const double c = collect(SITES);
                 if constexpr (MODE == MP_FN_UPDATE) weight = weight - c;
             }
+            in_sub = false; tr.subw[ID] = sw;
             weight = (touched || had) ? w_out + weight : w_out;
             changed = true;
             return r;

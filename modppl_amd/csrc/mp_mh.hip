@@ -394,7 +394,7 @@ struct mp_mh {
     double* lat = nullptr;   // pointed model: [n][2]
     double* ys_chain = nullptr;   // [n][n_data]: per-chain "(y, i)" choices once an empty-mask regenerate re-simulated them
     std::shared_ptr<mh_fn_ops> fn;   // registered function: the trace table below replaces the fields above
-    double* fvals = nullptr;         // [n_sites][n]
+    double* fvals = nullptr;         // [2 n_sites][n]: values, then the sub-tries' running weights
     uint32_t* fpresent = nullptr;    // [n]
 };
 #include "mp_mh_fn.h"
@@ -407,8 +407,9 @@ static int32_t mh_finish(mp_mh* h, uint64_t* accepted) {
     MHCK(hipStreamSynchronize(h->stream));
     if (accepted) *accepted = tot[0];
     if (tot[1])
-        return mp_set_error(MP_ERR_STATE, std::to_string(tot[1]) + " chain-moves reached a case the reference panics on or this layer does not restate "
-                            "(constraints nobody consumed, or regenerate through an unmasked sub-call after an upstream change: mp_genfn.h)");
+        return mp_set_error(MP_ERR_STATE, std::to_string(tot[1]) + " chain-moves reached a case the reference panics on: constraints nobody consumed "
+                            "(generate / update / assess, or generate(args, sub) of an unmasked sub-call whose old choices the new branch does not visit: "
+                            "dyngenfn.rs:526-529)");
     return MP_OK;
 }
 
@@ -547,7 +548,7 @@ int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_para
     MHCK(hipSetDevice(device));
     if (stream) h->stream = (hipStream_t)stream;
     else { MHCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
-    MHCK(hipMalloc(&h->fvals, sizeof(double) * n_chains * (size_t)ops->ns()));
+    MHCK(hipMalloc(&h->fvals, sizeof(double) * n_chains * 2 * (size_t)ops->ns()));   // [n_sites] values + [n_sites] sub-trie running weights (rows of sub-call ids)
     MHCK(hipMalloc(&h->fpresent, sizeof(uint32_t) * n_chains));
     MHCK(hipMalloc(&h->tmp, sizeof(double) * n_chains));
     MHCK(hipMalloc(&h->d_acc, sizeof(u64) * 2));

@@ -28,6 +28,13 @@ struct mp_fn_consspec {
     double val[MP_FN_MAX_SITES];
 };
 
+// site k is where a sub-call of the model keeps its sub-trie's running weight (the lowest site of the sub-call): rows NS + k of
+// the chain table hold it between launches — unlike the log-densities it cannot be recomputed from the values (it is the
+// history of the trie's inserts and removes, mp_genfn.h)
+template <class M>
+__host__ __device__ constexpr bool fn_is_sub_id(int k) {
+    return M::sub_of(k) != 0u && (M::sub_of(k) & ((1u << k) - 1u)) == 0u;
+}
 template <class M>
 __device__ __forceinline__ void fn_load(const M& model, const mp_stream& s, u64 i, u64 n, const double* __restrict__ vals,
                                         const uint32_t* __restrict__ present, mp_fn_trace<M::NS>& out) {
@@ -37,16 +44,23 @@ __device__ __forceinline__ void fn_load(const M& model, const mp_stream& s, u64 
     for (int k = 0; k < M::NS; ++k) {
         c.val[k] = ((c.present >> k) & 1u) ? vals[(u64)k * n + i] : 0.;
         c.lp[k] = 0.;
+        c.subw[k] = 0.;
     }
     mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
     model(g);
     out = g.tr;
+#pragma unroll
+    for (int k = 0; k < M::NS; ++k)
+        if (fn_is_sub_id<M>(k)) out.subw[k] = vals[(u64)(M::NS + k) * n + i];
 }
-template <int NS>
-__device__ __forceinline__ void fn_store(const mp_fn_trace<NS>& t, u64 i, u64 n, double* __restrict__ vals, uint32_t* __restrict__ present) {
+template <class M>
+__device__ __forceinline__ void fn_store(const mp_fn_trace<M::NS>& t, u64 i, u64 n, double* __restrict__ vals, uint32_t* __restrict__ present) {
     present[i] = t.present;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) vals[(u64)k * n + i] = t.has(k) ? t.val[k] : 0.;
+    for (int k = 0; k < M::NS; ++k) {
+        vals[(u64)k * n + i] = t.has(k) ? t.val[k] : 0.;
+        if (fn_is_sub_id<M>(k)) vals[(u64)(M::NS + k) * n + i] = t.subw[k];
+    }
 }
 __device__ __forceinline__ void fn_count(u64 acc, bool panic, u64* __restrict__ totals) {
     u64 p = panic ? 1ull : 0ull;
@@ -74,7 +88,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_init(u64 n, uint32_t k0, uint
         model(g);
         g.finish();
         panic = g.panic;
-        fn_store(g.tr, i, n, vals, present);
+        fn_store<M>(g.tr, i, n, vals, present);
     }
     fn_count(0, panic, totals);
 }
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_regen(u64 n, uint32_t k0, uin
                 ++acc;
             }
         }
-        fn_store(cur, i, n, vals, present);
+        fn_store<M>(cur, i, n, vals, present);
     }
     fn_count(acc, panic, totals);
 }
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_mh(u64 n, uint32_t k0, uint32
                 ++acc;
             }
         }
-        fn_store(cur, i, n, vals, present);
+        fn_store<M>(cur, i, n, vals, present);
     }
     fn_count(acc, panic, totals);
 }

@@ -186,3 +186,79 @@ inline bool mp_parse_robust_line_flip_fn(const double* args, int n_args, mp_robu
     return true;
 }
 MP_REGISTER_MH_PROPOSAL(2, mp_robust_line_fn, mp_robust_line_flip_fn, mp_parse_robust_line_flip_fn)
+
+// ---------------------------------------------------------------------------------------
+// A line whose noise regime is chosen BEFORE the line's sub-call, kind 103 (functor only):
+//   big ~ bernoulli(0.3) %= "big";  (slope, intercept) = line() /= "line";  y_k ~ normal(slope x_k + intercept, big ? 2 : 0.5)
+//   params = xs[0 .. n_data), n_data <= 10; the observations are constraints on the sites Y0 + k.
+// What it is for: a change upstream of an UNTOUCHED sub-call — regen_mh with mask {big} takes trace_at's
+// `generate(args, sub)` arm (weight += new_weight - sub.weight(), dyngenfn.rs:424-428), mh with the toggle proposal the
+// `update(sub, args, Unknown, {})` arm (:371-381): both work on the sub-trie's running weight.
+// Moves: proposal 1 = toggle of `big` (proposes the other value with probability 0.9); proposal 2 = drift of the line {std}.
+// ---------------------------------------------------------------------------------------
+struct mp_scaled_line_fn {
+    static constexpr int MAX_DATA = 10;
+    static constexpr int NS = 3 + MAX_DATA;
+    enum { BIG = 0, SLOPE = 1, INTERCEPT = 2, Y0 = 3 };
+    static constexpr uint32_t LINE = (1u << SLOPE) | (1u << INTERCEPT);
+    static constexpr uint32_t sub_of(int site) { return (site == SLOPE || site == INTERCEPT) ? LINE : 0u; }
+    static constexpr bool is_bool(int site) { return site == BIG; }
+    int n;
+    double xs[MAX_DATA];
+    double ln_prior_sd, ln_sd_small, ln_sd_big;   // mp_log(2), mp_log(0.5), mp_log(2)
+
+    template <class H, int J>
+    MP_HD void points(H& g, bool big, double slope, double intercept) const {
+        if (J < n) g.template normal<Y0 + J>(slope * xs[J] + intercept, big ? 2. : 0.5, big ? ln_sd_big : ln_sd_small);
+        if constexpr (J + 1 < MAX_DATA) points<H, J + 1>(g, big, slope, intercept);
+    }
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        const bool big = g.template bernoulli<BIG>(0.3);
+        const mp_fn_ret line = g.template call<LINE>([&](H& q) {
+            mp_fn_ret r{};
+            r.v[0] = q.template normal<SLOPE>(0., 2., ln_prior_sd);
+            r.v[1] = q.template normal<INTERCEPT>(0., 2., ln_prior_sd);
+            return r;
+        });
+        points<H, 0>(g, big, line.v[0], line.v[1]);
+    }
+};
+inline bool mp_parse_scaled_line_fn(const double* params, int n_params, mp_scaled_line_fn& m, std::string& err) {
+    if (!params || n_params < 1 || n_params > mp_scaled_line_fn::MAX_DATA) { err = "scaled line: params = xs[0 .. n_data), 1 <= n_data <= 10"; return false; }
+    m.n = n_params;
+    for (int k = 0; k < mp_scaled_line_fn::MAX_DATA; ++k) m.xs[k] = k < n_params ? params[k] : 0.;
+    m.ln_prior_sd = mp_log(2.); m.ln_sd_small = mp_log(0.5); m.ln_sd_big = mp_log(2.);
+    return true;
+}
+MP_REGISTER_MH_MODEL(103, mp_scaled_line_fn, mp_parse_scaled_line_fn)
+
+struct mp_scaled_line_toggle_fn {
+    int unused;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        g.template bernoulli<mp_scaled_line_fn::BIG>(tr.val[mp_scaled_line_fn::BIG] != 0. ? 0.1 : 0.9);
+    }
+};
+inline bool mp_parse_scaled_line_toggle_fn(const double*, int n_args, mp_scaled_line_toggle_fn& p, std::string& err) {
+    if (n_args != 0) { err = "toggle proposal takes no arguments"; return false; }
+    p.unused = 0;
+    return true;
+}
+MP_REGISTER_MH_PROPOSAL(1, mp_scaled_line_fn, mp_scaled_line_toggle_fn, mp_parse_scaled_line_toggle_fn)
+
+struct mp_scaled_line_drift_fn {
+    double sd, ln_sd;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        g.template normal<mp_scaled_line_fn::SLOPE>(tr.val[mp_scaled_line_fn::SLOPE], sd, ln_sd);
+        g.template normal<mp_scaled_line_fn::INTERCEPT>(tr.val[mp_scaled_line_fn::INTERCEPT], sd, ln_sd);
+    }
+};
+inline bool mp_parse_scaled_line_drift_fn(const double* args, int n_args, mp_scaled_line_drift_fn& p, std::string& err) {
+    if (!args || n_args != 1 || !(args[0] > 0.)) { err = "line drift proposal takes {std > 0}"; return false; }
+    p.sd = args[0];
+    p.ln_sd = mp_log(args[0]);
+    return true;
+}
+MP_REGISTER_MH_PROPOSAL(2, mp_scaled_line_fn, mp_scaled_line_drift_fn, mp_parse_scaled_line_drift_fn)

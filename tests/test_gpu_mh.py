@@ -115,8 +115,8 @@ def test_unsupported_masks():
     g = modppl_amd.HierarchicalChains(XS, make_ys(), 16, 1, functor=FUNCTOR)
     with pytest.raises(modppl_amd.ModpplError) as e:
         g.regen_mh(["is_linear"])
-    # hand-written kernels: refused up front; generic handlers: the move runs into regenerate through the unmasked `coeffs`
-    # sub-call after an upstream change (generate(args, sub), where quadratic -> linear panics in the reference): reported
+    # hand-written kernels: refused up front; generic handlers: the move runs generate(args, sub) on the old `coeffs` sub-trace,
+    # and a quadratic chain that redraws linear leaves its c unconsumed — the reference's panic (dyngenfn.rs:526-529): reported
     assert e.value.code == (capi.MP_ERR_STATE if FUNCTOR else capi.MP_ERR_UNSUPPORTED)
 
 
@@ -305,3 +305,56 @@ def test_registered_only_model_full_size():
     out = vals[:, RL_OUT0:RL_OUT0 + n_data].mean(axis=0)
     assert out[2] > 0.9 and out[7] > 0.9 and out[3:7].max() < 0.5, out
     assert np.isfinite(g.logjp()).all()
+
+
+# ---- a change UPSTREAM of an untouched sub-call (kind 103: `big` is drawn before the line's sub-call): regenerate takes
+# trace_at's generate(args, sub) arm — weight += new_weight - sub.weight(), the sub-trie's RUNNING weight (dyngenfn.rs:424-428) —
+# and update its update(sub, args, Unknown, {}) arm (:371-381).  Device (mp_genfn.h: `subw`) against the dynamic interpretation. --
+SL_BIG, SL_SLOPE, SL_ICPT, SL_Y0 = 0, 1, 2, 3
+
+
+def test_change_upstream_of_an_untouched_sub_call():
+    if FUNCTOR:
+        pytest.skip("one engine: the model has no hand-written kernel")
+    import modppl_amd
+
+    n, nd = 2000, 9
+    xs = np.linspace(-2, 2, nd)
+    ys = -0.6 * xs + 0.8 + 0.7 * np.random.default_rng(4).normal(size=nd)
+    cons = {SL_Y0 + k: y for k, y in enumerate(ys)}
+    g = modppl_amd.FunctionChains(103, xs, cons, n, 29)
+    o = O.OracleFunctionChains(103, xs, cons, n, 29)
+    check_fn(g, o)
+    for sweep in range(3):
+        assert g.regen_mh([SL_BIG], 2) == o.regen_mh([SL_BIG], 2)            # masked upstream site, the sub-call unmasked: generate(args, sub)
+        check_fn(g, o)
+        assert g.mh(2, [0.2], 2) == o.mh(2, [0.2], 2)                        # drift inside the sub-call: its running weight moves (remove / observe)
+        check_fn(g, o)
+        assert g.mh(1, [], 2) == o.mh(1, [], 2)                              # toggle upstream: update(sub, Unknown, {}) rescoring inside the sub-call
+        check_fn(g, o)
+        assert g.regen_mh([SL_BIG, SL_SLOPE], 2) == o.regen_mh([SL_BIG, SL_SLOPE], 2)   # both: the inner regenerate arm
+        check_fn(g, o)
+        assert g.regen_mh([SL_BIG, SL_ICPT, SL_SLOPE], 3, cycle=True) == o.regen_mh([SL_BIG, SL_ICPT, SL_SLOPE], 3, cycle=True)
+        check_fn(g, o)
+    assert g.regen_mh([], 1) == o.regen_mh([], 1) == n
+    check_fn(g, o)
+    assert g.regen_mh([SL_BIG], 3) == o.regen_mh([SL_BIG], 3)
+    check_fn(g, o)
+
+
+def test_masking_is_linear_where_the_reference_does_not_panic():
+    """hierarchical model as a functor, all chains linear, ONE regen move with mask {is_linear}: linear -> linear and linear ->
+    quadratic go through generate(args, sub) on the old `coeffs` sub-trace (c is drawn when the new branch wants it); only
+    quadratic -> linear leaves a constraint behind and panics (dyngenfn.rs:526-529) — there is no such chain yet."""
+    if not FUNCTOR:
+        pytest.skip("the hand-written kernels refuse the mask up front")
+    g, o = pair(1500, 33, True)
+    assert g.regen_mh(["is_linear"], 1) == o.regen_mh([0], 1)
+    check(g, o)
+    assert 0.02 < (g.states()[:, 0] == 0.0).mean() < 0.4    # some chains moved to the quadratic branch (30 % proposed it)
+    import modppl_amd
+    from modppl_amd import capi
+
+    with pytest.raises(modppl_amd.ModpplError) as e:          # now some chains are quadratic: quadratic -> linear is the reference's panic
+        g.regen_mh(["is_linear"], 1)
+    assert e.value.code == capi.MP_ERR_STATE

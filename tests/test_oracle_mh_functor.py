@@ -84,3 +84,24 @@ def test_robust_line_model_runs_and_mixes():
     slope, icpt = np.polyfit(xs[inl], ys[inl], 1)
     assert abs(np.median(vals[:, 0]) - slope) < 0.4 and abs(np.median(vals[:, 1]) - icpt) < 0.5
     assert np.isfinite(f.logjp()).all()
+
+
+def test_scaled_line_model_exercises_the_generate_from_sub_arm():
+    """kind 103 (mp_mh_models.h): a masked site upstream of an unmasked sub-call — trace_at's generate(args, sub) arm of
+    Regenerate.  The move resimulates `big` from its prior and keeps the line: accepted with probability min(1, likelihood
+    ratio), so chains end up in the regime the data's noise supports."""
+    xs = np.linspace(-2, 2, 9)
+    rng = np.random.default_rng(4)
+    ys = -0.6 * xs + 0.8 + 0.3 * rng.normal(size=9)        # small noise: `big` should lose against the prior's 0.3 once the line fits
+    f = O.OracleFunctionChains(103, xs, {3 + k: y for k, y in enumerate(ys)}, 60, 2)
+    assert f.num_sites == 13
+    acc = 0
+    for _ in range(60):
+        f.mh(2, [0.3 if _ < 30 else 0.1], 2)
+        acc += f.regen_mh([0], 1)
+        f.mh(1, [], 1)
+    vals, present = f.trace()
+    assert np.all(present == (1 << 12) - 1)
+    assert 0 < acc < 60 * 60                         # the move is neither always nor never accepted
+    assert vals[:, 0].mean() < 0.3                   # below the prior: the data speak for the small noise
+    assert np.isfinite(f.logjp()).all()
