@@ -571,6 +571,31 @@ int32_t oracle_mhfn_read_trace(oracle_mhfn* h, double* values, uint32_t* present
 int32_t oracle_mhfn_read_logjp(oracle_mhfn* h, double* out) { GUARD({ for (size_t i = 0; i < h->traces.size(); ++i) out[i] = h->traces[i].logjp; }) }
 int32_t oracle_mhfn_destroy(oracle_mhfn* h) { delete h; return MP_OK; }
 
+// ---- the product's static MH handlers (mp_genfn.h) on the host, chain by chain: a checkee for the suite without a GPU ----
+struct oracle_mhfn_static { std::shared_ptr<MhFnStatic> r; uint64_t n = 0; };
+int32_t oracle_mhfn_static_create(int32_t kind, const double* params, int32_t n_params, const int32_t* cons_sites, const double* cons_vals, int32_t n_cons,
+                                  uint64_t n_chains, uint64_t seed, oracle_mhfn_static** out) {
+    GUARD({
+        auto it = mhfn_static_models().find(kind);
+        if (it == mhfn_static_models().end()) throw Panic("no MH functor model of this kind");
+        auto h = std::make_unique<oracle_mhfn_static>();
+        h->r = it->second(params, n_params);
+        h->n = n_chains;
+        h->r->create(n_chains, seed, cons_sites, cons_vals, n_cons);
+        *out = h.release();
+    })
+}
+int32_t oracle_mhfn_static_step(oracle_mhfn_static* h, int32_t proposal_kind, const double* args, int32_t n_args, int32_t n_iters, uint64_t* accepted) {
+    GUARD({ const uint64_t a = h->r->mh(proposal_kind, args, n_args, n_iters); if (accepted) *accepted = a; })
+}
+int32_t oracle_mhfn_static_regen(oracle_mhfn_static* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
+    GUARD({ const uint64_t a = h->r->regen(mask_sites, n_mask, cycle, n_iters); if (accepted) *accepted = a; })
+}
+int32_t oracle_mhfn_static_read(oracle_mhfn_static* h, double* values, uint32_t* present, uint64_t* panics) {
+    GUARD({ h->r->read(values, present); if (panics) *panics = h->r->panics(); })
+}
+int32_t oracle_mhfn_static_destroy(oracle_mhfn_static* h) { delete h; return MP_OK; }
+
 // ---- mh.rs over N independent chains of hierarchical_model ------------------------------------
 struct oracle_mh {
     Hierarchical hm;

@@ -164,6 +164,123 @@ struct MhFnModelT : MhFnModel {
     }
 };
 
+// ---- the PRODUCT's static handlers (mp_genfn.h: mp_fn_handler<NS, MODE>) compiled for the host and run chain by chain — not a
+// checker but a checkee: the same code the k_fn_* kernels run per lane, so that the suite without a GPU can hold the handler rules
+// against the dynamic machinery above as well (tests/test_oracle_mh_functor.py).  Canonical arithmetic by construction (mp_math.h).
+struct MhFnStatic {
+    virtual ~MhFnStatic() {}
+    virtual int ns() const = 0;
+    virtual void create(uint64_t n_chains, uint64_t seed, const int32_t* sites, const double* vals, int n_cons) = 0;
+    virtual uint64_t mh(int kind, const double* args, int n_args, int n_iters) = 0;
+    virtual uint64_t regen(const int32_t* mask_sites, int n_mask, int cycle, int n_iters) = 0;
+    virtual void read(double* vals, uint32_t* present) const = 0;
+    virtual uint64_t panics() const = 0;
+};
+template <class M>
+struct MhFnStaticT;
+template <class M>
+using MhFnStaticProposal = std::function<uint64_t(MhFnStaticT<M>&, const double*, int, int)>;
+template <class M>
+std::map<int, MhFnStaticProposal<M>>& mhfn_static_proposals() {
+    static std::map<int, MhFnStaticProposal<M>> r;
+    return r;
+}
+template <class M>
+struct MhFnStaticT : MhFnStatic {
+    M model;
+    std::vector<mp_fn_trace<M::NS>> tr;
+    uint64_t seed = 0, iters = 0, n_panic = 0;
+    explicit MhFnStaticT(const M& m) : model(m) {}
+    int ns() const override { return M::NS; }
+    uint64_t panics() const override { return n_panic; }
+    mp_stream stream(size_t i, uint32_t step) const {
+        mp_stream s;
+        s.k0 = (uint32_t)seed; s.k1 = (uint32_t)(seed >> 32); s.slot = (uint32_t)i; s.step = step;
+        return s;
+    }
+    void create(uint64_t n_chains, uint64_t seed_, const int32_t* sites, const double* vals, int n_cons) override {
+        seed = seed_; iters = 0;
+        mp_fn_trace<M::NS> c;
+        mp_fn_clear(c);
+        for (int q = 0; q < n_cons; ++q) { c.present |= 1u << sites[q]; c.val[sites[q]] = vals[q]; }
+        tr.resize(n_chains);
+        for (size_t i = 0; i < tr.size(); ++i) {   // k_fn_init
+            const mp_stream s = stream(i, 0);
+            mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+            model(g);
+            g.finish();
+            n_panic += g.panic;
+            tr[i] = g.tr;
+        }
+    }
+    uint64_t regen(const int32_t* mask_sites, int n_mask, int cycle, int n_iters) override {   // k_fn_regen
+        uint64_t acc = 0;
+        uint32_t bits = 0;
+        for (int q = 0; q < n_mask; ++q) bits |= 1u << mask_sites[q];
+        for (size_t i = 0; i < tr.size(); ++i) {
+            mp_fn_trace<M::NS> cur = tr[i];
+            for (int it = 0; it < n_iters; ++it) {
+                const mp_stream s = stream(i, (uint32_t)(iters + 1 + (uint64_t)it));
+                uint32_t m = (cycle && n_mask > 0) ? 1u << mask_sites[(iters + (uint64_t)it) % (uint64_t)n_mask] : bits;
+                if (m == 0u) m = cur.present;
+                mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
+                model(g);
+                g.finish();
+                n_panic += g.panic;
+                const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
+                if (mp_log(mp_u01(ub.a)) < g.weight) { cur = g.tr; ++acc; }
+            }
+            tr[i] = cur;
+        }
+        iters += (uint64_t)n_iters;
+        return acc;
+    }
+    template <class P>
+    uint64_t mh_with(const P& proposal, int n_iters) {   // k_fn_mh
+        uint64_t acc = 0;
+        for (size_t i = 0; i < tr.size(); ++i) {
+            mp_fn_trace<M::NS> cur = tr[i];
+            for (int it = 0; it < n_iters; ++it) {
+                const mp_stream s = stream(i, (uint32_t)(iters + 1 + (uint64_t)it));
+                mp_fn_handler<M::NS, MP_FN_SIMULATE> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
+                proposal(p, cur);
+                const double fwd = p.weight;
+                mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &cur, &p.tr);
+                model(g);
+                g.finish();
+                mp_fn_trace<M::NS> disc = cur;
+                disc.present = g.discarded;
+                mp_fn_handler<M::NS, MP_FN_GENERATE> q(s, MP_DOM_PROPOSAL, nullptr, &disc);
+                proposal(q, g.tr);
+                q.finish();
+                n_panic += (g.panic || q.panic);
+                const double alpha = g.weight - fwd + q.weight;
+                const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
+                if (mp_log(mp_u01(ub.a)) < alpha) { cur = g.tr; ++acc; }
+            }
+            tr[i] = cur;
+        }
+        iters += (uint64_t)n_iters;
+        return acc;
+    }
+    uint64_t mh(int kind, const double* args, int n_args, int n_iters) override {
+        auto it = mhfn_static_proposals<M>().find(kind);
+        if (it == mhfn_static_proposals<M>().end()) throw Panic("no proposal of this kind is registered for the model");
+        return it->second(*this, args, n_args, n_iters);
+    }
+    void read(double* vals, uint32_t* present) const override {
+        for (size_t i = 0; i < tr.size(); ++i) {
+            present[i] = tr[i].present;
+            for (int k = 0; k < M::NS; ++k) vals[i * (size_t)M::NS + k] = tr[i].has(k) ? tr[i].val[k] : 0.;
+        }
+    }
+};
+using MhFnStaticFactory = std::function<std::shared_ptr<MhFnStatic>(const double*, int)>;
+inline std::map<int, MhFnStaticFactory>& mhfn_static_models() {
+    static std::map<int, MhFnStaticFactory> r;
+    return r;
+}
+
 using MhFnFactory = std::function<std::shared_ptr<MhFnModel>(const double*, int)>;
 inline std::map<int, MhFnFactory>& mhfn_models() {
     static std::map<int, MhFnFactory> r;
@@ -176,6 +293,12 @@ int mhfn_register_model(int kind, bool (*parse)(const double*, int, M&, std::str
         std::string err;
         if (!parse(params, n, m, err)) throw Panic(err);
         return std::make_shared<MhFnModelT<M>>(m);
+    };
+    mhfn_static_models()[kind] = [parse](const double* params, int n) -> std::shared_ptr<MhFnStatic> {
+        M m{};
+        std::string err;
+        if (!parse(params, n, m, err)) throw Panic(err);
+        return std::make_shared<MhFnStaticT<M>>(m);
     };
     return kind;
 }
@@ -191,6 +314,12 @@ int mhfn_register_proposal(int kind, bool (*parse)(const double*, int, P&, std::
             p(h, tr);
             return 0;
         }, mhfn_site_of, DOM_PROPOSAL);
+    };
+    mhfn_static_proposals<M>()[kind] = [parse](MhFnStaticT<M>& r, const double* args, int n_args, int n_iters) -> uint64_t {
+        P p{};
+        std::string err;
+        if (!parse(args, n_args, p, err)) throw Panic(err);
+        return r.mh_with(p, n_iters);
     };
     return kind;
 }

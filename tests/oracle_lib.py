@@ -536,3 +536,53 @@ class OracleFunctionChains:
                 self.h = None
         except Exception:
             pass
+
+
+class HostStaticFunctionChains:
+    """The PRODUCT's static MH handlers (modppl_amd/csrc/mp_genfn.h) compiled for the host inside the test library and run chain
+    by chain — a checkee, not a checker: what the k_fn_* kernels execute per lane, available without a GPU so that the CPU
+    suite holds the handler rules against the dynamic machinery (OracleFunctionChains) too."""
+
+    def __init__(self, kind, params, constraints, n_chains, seed):
+        self.L = load()
+        self.n = n_chains
+        params = np.ascontiguousarray(params, dtype=np.float64).ravel()
+        sites = np.array(sorted(constraints), dtype=np.int32)
+        vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
+        h = C.c_void_p()
+        self._ck(self.L.oracle_mhfn_static_create(int(kind), dptr(params), int(params.size), sites.ctypes.data_as(C.POINTER(C.c_int32)), dptr(vals),
+                                                  int(sites.size), C.c_uint64(n_chains), C.c_uint64(seed), C.byref(h)))
+        self.h = h
+        self.num_sites = None
+
+    def _ck(self, code):
+        if code != 0:
+            raise OracleError(code, self.L.oracle_last_error().decode())
+
+    def mh(self, proposal_kind, proposal_args=(), n_iters=1):
+        a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
+        acc = C.c_uint64()
+        self._ck(self.L.oracle_mhfn_static_step(self.h, int(proposal_kind), dptr(a), int(a.size), int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def regen_mh(self, mask_sites, n_iters=1, cycle=False):
+        m = (C.c_int32 * max(len(mask_sites), 1))(*mask_sites)
+        acc = C.c_uint64()
+        self._ck(self.L.oracle_mhfn_static_regen(self.h, m, len(mask_sites), int(cycle), int(n_iters), C.byref(acc)))
+        return acc.value
+
+    def trace(self, num_sites):
+        vals = np.empty((self.n, num_sites))
+        present = np.empty(self.n, dtype=np.uint32)
+        pan = C.c_uint64()
+        self._ck(self.L.oracle_mhfn_static_read(self.h, dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pan)))
+        self.panics = pan.value
+        return vals, present
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.oracle_mhfn_static_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

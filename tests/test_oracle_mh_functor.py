@@ -105,3 +105,74 @@ def test_scaled_line_model_exercises_the_generate_from_sub_arm():
     assert 0 < acc < 60 * 60                         # the move is neither always nor never accepted
     assert vals[:, 0].mean() < 0.3                   # below the prior: the data speak for the small noise
     assert np.isfinite(f.logjp()).all()
+
+
+# ---- the product's static handlers (mp_genfn.h) on the host against the dynamic machinery: the handler rules without a GPU -------
+def _both(kind, params, cons, n, seed):
+    return O.HostStaticFunctionChains(kind, params, cons, n, seed), O.OracleFunctionChains(kind, params, cons, n, seed, canonical=True)
+
+
+def _same(s, d):
+    dv, dp = d.trace()
+    sv, sp = s.trace(d.num_sites)
+    assert np.array_equal(sp, dp)
+    assert np.array_equal(sv, dv)
+    assert s.panics == 0
+
+
+def test_static_handlers_hierarchical_model():
+    ys = make_ys()
+    cons = {Y0 + k: y for k, y in enumerate(ys)}
+    s, d = _both(101, XS, cons, 300, 21)
+    _same(s, d)
+    for _ in range(3):
+        assert s.mh(2, [], 1) == d.mh(2, [], 1)
+        _same(s, d)
+        assert s.mh(1, [0.1], 3) == d.mh(1, [0.1], 3)
+        _same(s, d)
+        assert s.regen_mh([1, 2, 3], 4, cycle=True) == d.regen_mh([1, 2, 3], 4, cycle=True)
+        _same(s, d)
+        assert s.regen_mh([1, 2], 2) == d.regen_mh([1, 2], 2)
+        _same(s, d)
+    assert s.regen_mh([], 2) == d.regen_mh([], 2) == 600
+    _same(s, d)
+    assert s.mh(1, [0.1], 2) == d.mh(1, [0.1], 2)
+    _same(s, d)
+
+
+def test_static_handlers_robust_line_and_scaled_line():
+    xs = np.linspace(-3, 3, 10)
+    rng = np.random.default_rng(1)
+    ys = 0.7 * xs - 0.4 + 0.3 * rng.normal(size=10)
+    ys[2] += 9.0
+    s, d = _both(102, xs, {14 + k: y for k, y in enumerate(ys)}, 200, 17)
+    _same(s, d)
+    for sweep in range(2):
+        assert s.mh(1, [0.3], 2) == d.mh(1, [0.3], 2)
+        for k in (0, 2, 9):
+            assert s.mh(2, [k], 1) == d.mh(2, [k], 1)
+        _same(s, d)
+        assert s.regen_mh([2 + k for k in range(10)], 10, cycle=True) == d.regen_mh([2 + k for k in range(10)], 10, cycle=True)
+        assert s.regen_mh([0], 2) == d.regen_mh([0], 2)
+        assert s.regen_mh([1, 3, 6], 2) == d.regen_mh([1, 3, 6], 2)
+        _same(s, d)
+    assert s.regen_mh([5], 3) == d.regen_mh([5], 3)          # masked top-level site after the untouched sub-call: replayed
+    _same(s, d)
+    # a change upstream of an untouched sub-call (kind 103): generate(args, sub) against the sub-trie's running weight
+    xs = np.linspace(-2, 2, 9)
+    ys = -0.6 * xs + 0.8 + 0.7 * np.random.default_rng(4).normal(size=9)
+    s, d = _both(103, xs, {3 + k: y for k, y in enumerate(ys)}, 300, 29)
+    _same(s, d)
+    for sweep in range(3):
+        assert s.regen_mh([0], 2) == d.regen_mh([0], 2)
+        _same(s, d)
+        assert s.mh(2, [0.2], 2) == d.mh(2, [0.2], 2)
+        assert s.mh(1, [], 2) == d.mh(1, [], 2)
+        _same(s, d)
+        assert s.regen_mh([0, 1], 2) == d.regen_mh([0, 1], 2)
+        assert s.regen_mh([0, 2, 1], 3, cycle=True) == d.regen_mh([0, 2, 1], 3, cycle=True)
+        _same(s, d)
+    assert s.regen_mh([], 1) == d.regen_mh([], 1) == 300
+    _same(s, d)
+    assert s.regen_mh([0], 3) == d.regen_mh([0], 3)
+    _same(s, d)
