@@ -167,6 +167,59 @@ def main_paths():
     print("paths_small.npz:", sorted(out)[:6], "...", len(out), "arrays")
 
 
+# ---- third fixture: mh / regen_mh over the registered functor models (kinds 101, 102, 103 of modppl_amd/csrc/mp_mh_models.h), as the
+# checker's dynamic interpretation of those functors runs them (tries, sample_at / trace_at / gc): tests/golden/mh_functor.npz ---------
+def functor_inputs():
+    rng = np.random.default_rng(20241009)
+    xs2 = np.linspace(-3, 3, 10)
+    ys2 = 0.7 * xs2 - 0.4 + 0.3 * rng.normal(size=10)
+    ys2[2] += 9.0
+    ys2[7] -= 8.0
+    xs3 = np.linspace(-2, 2, 9)
+    return dict(hier_ys=0.3 + 0.4 * XS + 0.5 * XS * XS + 0.1 * rng.normal(size=XS.size), rl_xs=xs2, rl_ys=ys2, sl_xs=xs3,
+                sl_ys=-0.6 * xs3 + 0.8 + 0.7 * rng.normal(size=9))
+
+
+def functor_outputs(mk, inp):
+    """mk(kind, params, constraints, n_chains, seed) -> an object with mh / regen_mh / trace (FunctionChains' surface)"""
+    out = {}
+    h = mk(101, XS, {4 + k: y for k, y in enumerate(inp["hier_ys"])}, 96, 41)
+    acc = []
+    for _ in range(2):
+        acc += [h.mh(2, [], 1), h.mh(1, [0.1], 3), h.regen_mh([1, 2, 3], 6, True), h.regen_mh([1, 2], 2, False)]
+    acc += [h.regen_mh([], 1, False), h.mh(1, [0.05], 2)]
+    out["hier_vals"], out["hier_present"] = h.trace()
+    out["hier_acc"] = np.array(acc, dtype=np.int64)
+    r = mk(102, inp["rl_xs"], {14 + k: y for k, y in enumerate(inp["rl_ys"])}, 96, 42)
+    acc = []
+    for _ in range(2):
+        acc += [r.mh(1, [0.3], 2)] + [r.mh(2, [k], 1) for k in (0, 2, 7, 9)] + [r.regen_mh([2 + k for k in range(10)], 10, True), r.regen_mh([0], 2, False),
+                                                                                 r.regen_mh([1, 3, 6], 2, False)]
+    acc += [r.regen_mh([5], 2, False), r.regen_mh([], 1, False), r.mh(1, [0.2], 2)]
+    out["rl_vals"], out["rl_present"] = r.trace()
+    out["rl_acc"] = np.array(acc, dtype=np.int64)
+    s = mk(103, inp["sl_xs"], {3 + k: y for k, y in enumerate(inp["sl_ys"])}, 96, 43)
+    acc = []
+    for _ in range(3):
+        acc += [s.regen_mh([0], 2, False), s.mh(2, [0.2], 2), s.mh(1, [], 2), s.regen_mh([0, 1], 2, False), s.regen_mh([0, 2, 1], 3, True)]
+    acc += [s.regen_mh([], 1, False), s.regen_mh([0], 3, False)]
+    out["sl_vals"], out["sl_present"] = s.trace()
+    out["sl_acc"] = np.array(acc, dtype=np.int64)
+    return out
+
+
+def oracle_functor(inp):
+    return functor_outputs(lambda kind, params, cons, n, seed: O.OracleFunctionChains(kind, params, cons, n, seed, canonical=True), inp)
+
+
+def main_functor():
+    inp = functor_inputs()
+    out = oracle_functor(inp)
+    np.savez_compressed(os.path.join(HERE, "mh_functor.npz"), **{"in_" + k: v for k, v in inp.items()}, **out)
+    print("mh_functor.npz:", sorted(out), {k: int(v.sum()) for k, v in out.items() if k.endswith("_acc")})
+
+
 if __name__ == "__main__":
     main()
     main_paths()
+    main_functor()

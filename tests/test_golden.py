@@ -138,3 +138,61 @@ def test_hip_reproduces_paths_golden():
     got = M.paths_outputs(lambda ys, n, seed, constrain=None: Mh(ys, n, seed, constrain),
                           lambda n, seed: modppl_amd.PointedChains(M.BOUNDS, M.COV, [0.0, 0.0], n, seed), importance, Pf, inp)
     _compare(got, exp)
+
+
+# mh / regen_mh over the registered functor models (tests/golden/mh_functor.npz) -------------------------------------------------
+def _functor():
+    z = np.load(os.path.join(G, "mh_functor.npz"))
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    exp = {k: z[k] for k in z.files if not k.startswith("in_")}
+    return inp, exp
+
+
+def test_oracle_reproduces_functor_golden():
+    """the dynamic interpretation (tries) AND the product's static handlers compiled for the host, against the committed vectors"""
+    from tests.golden import make_golden as M
+
+    inp, exp = _functor()
+    for k, v in M.functor_inputs().items():
+        assert np.array_equal(v, inp[k]), k
+    _compare(M.oracle_functor(inp), exp)
+
+    class Static:
+        def __init__(self, kind, params, cons, n, seed):
+            self.s = O.HostStaticFunctionChains(kind, params, cons, n, seed)
+            self.ns = {101: 20, 102: 26, 103: 13}[kind]
+
+        def mh(self, kind, args, it):
+            return self.s.mh(kind, args, it)
+
+        def regen_mh(self, sites, it, cycle):
+            return self.s.regen_mh(sites, it, cycle)
+
+        def trace(self):
+            return self.s.trace(self.ns)
+
+    _compare(M.functor_outputs(Static, inp), exp)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_functor_golden():
+    """The device's generic MH kernels against the committed vectors alone (no checker in the loop)."""
+    import modppl_amd
+    from tests.golden import make_golden as M
+
+    inp, exp = _functor()
+
+    class Dev:
+        def __init__(self, kind, params, cons, n, seed):
+            self.c = modppl_amd.FunctionChains(kind, params, cons, n, seed)
+
+        def mh(self, kind, args, it):
+            return self.c.mh(kind, args, it)
+
+        def regen_mh(self, sites, it, cycle):
+            return self.c.regen_mh(sites, it, cycle)
+
+        def trace(self):
+            return self.c.trace()
+
+    _compare(M.functor_outputs(Dev, inp), exp)
