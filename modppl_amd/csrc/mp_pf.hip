@@ -1042,7 +1042,10 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     rc = check_launch("resample kernels");
     if (rc != MP_OK) return rc;
     if (drawn_only) h->deferred = true;   // x[cur] is the (stale) pre-resample state until the draws are looked up
-    else h->cur ^= 1;
+    else {
+        h->cur ^= 1;
+        h->x_in_rows = false;   // k_resample_gather wrote every slot's state into x[cur] (slot order): the rows are the OLD generation's
+    }
     h->rows_fresh = false;            // the log-weights are now all zero
     h->resample_count += 1;
     if (h->flags & MP_PF_RECORD_HISTORY) {
@@ -1212,10 +1215,12 @@ int32_t mp_pf_shard_route(mp_pf* h, int32_t scheme, const double* d_tm_all, cons
 
 int32_t mp_pf_shard_resolve(mp_pf* h, const uint64_t* d_req_in, uint64_t n_req, double* d_rows_out) {
     if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
+    HIPCK(hipSetDevice(h->device));
+    // (before the early return: mp_pf_shard_scatter flips `cur` whether or not this rank was asked for rows, and a dim_state-1
+    // handle's current states may live in the row table only)
+    { int32_t rcx = ensure_x(h); if (rcx != MP_OK) return rcx; }
     if (n_req == 0) return MP_OK;
     if (!d_req_in || !d_rows_out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
-    HIPCK(hipSetDevice(h->device));
-    { int32_t rcx = ensure_x(h); if (rcx != MP_OK) return rcx; }
     int grid = (int)std::min<u64>((n_req + K3_THREADS - 1) / K3_THREADS, (u64)K3_MAX_BLOCKS);
     {
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
@@ -1239,6 +1244,7 @@ int32_t mp_pf_shard_scatter(mp_pf* h, const double* d_rows_in, double* log_total
     h->parents_deferred = false;   // k_shard_scatter wrote parent[]
     h->sh_parents_lazy = false;
     h->cur ^= 1;
+    h->x_in_rows = false;          // ... and every slot's state into x[cur]
     h->rows_fresh = false;
     h->resample_count += 1;
     if (log_total_weight) {
@@ -1336,7 +1342,11 @@ static void launch_shard_table(mp_pf* h, const u64* d_tiles_all, int world, unsi
                                u64* kthr) {
     static const bool one_wg = getenv("MP_SHARD_TABLE_ONE_WG") && atoi(getenv("MP_SHARD_TABLE_ONE_WG")) != 0;   // A/B
     // (measured, 512 tiles per rank: one workgroup 8.3 us up to 4 ranks and 16.9 us at 8; one per rank 9.8 - 10.8 us at 2 .. 8)
-    if (world > 1 && !one_wg && (size_t)world * (size_t)h->nt > 2048) {
+    // (MP_SHARD_TABLE_MW_TILES: the job size from which one workgroup per rank builds the table — tests lower it to reach that
+    // kernel with a few thousand particles)
+    const char* mw_env = getenv("MP_SHARD_TABLE_MW_TILES");   // (read per call: a resample, not a hot loop)
+    const size_t mw_tiles = mw_env ? (size_t)atoll(mw_env) : (size_t)2048;
+    if (world > 1 && !one_wg && (size_t)world * (size_t)h->nt > mw_tiles) {
         h->sh_tab_seq += (unsigned)world;
         hipLaunchKernelGGL(k_shard_table_mw, dim3(world), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
                            h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, c_all, scheme, rank,

@@ -497,12 +497,14 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table_mw(const u64* __res
         while ((int)(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_target) < 0) __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
-    if (tid < world) {
-        const u64 q = mp_ld_agent(&part[tid].Q), q2 = mp_ld_agent(&part[tid].Q2);
-        // inclusive prefix over the ranks (world <= 64: one wave)
+    if (tid < 64) {
+        // inclusive prefix over the ranks (world <= 64: one wave).  The WHOLE of wave 0 takes part, lanes beyond `world` with
+        // zeros: wave_sum_u64 reads lane 63 of the scan, which an inactive lane would never have written
+        const bool have = tid < world;
+        const u64 q = have ? mp_ld_agent(&part[tid].Q) : 0ull, q2 = have ? mp_ld_agent(&part[tid].Q2) : 0ull;
         const u64 inc = wave_incl_scan_u64(q, lane);
         const u64 t2 = wave_sum_u64(q2);
-        s_bound[tid] = inc;
+        if (have) s_bound[tid] = inc;
         if (tid == me) s_off = inc - q;
         if (tid == world - 1) { s_Q = inc; s_Q2 = t2; }
     }

@@ -153,6 +153,33 @@ def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme, tail):
         assert hip.fallbacks > 0
 
 
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_table_by_one_workgroup_per_rank_at_small_sizes(monkeypatch, world):
+    """k_shard_table_mw (one workgroup per rank; the library picks it beyond 2048 tiles per job) forced at a few thousand
+    particles: L, counts, parents and the STALE ESS — i.e. Q2, summed over the ranks' partial sums by wave 0 with fewer than 64
+    ranks active — against the checker (the sum read an inactive lane)."""
+    monkeypatch.setenv("MP_SHARD_TABLE_MW_TILES", "0")
+    n, seed = 4096, 19
+    model, obs = _model(1, 6)
+    obs = obs.copy()
+    obs[2] = 9.0
+    hip = _ByHand(model, n, world, seed)
+    ref = OwnedReference(model, n * world, seed, world)
+    for e in hip.eng:
+        e.init_step(None, obs[:1])
+    ref.init_step(None, obs[:1])
+    for t in range(1, len(obs)):
+        assert hip.resample(512 if t % 2 else 0, 0) == ref.resample(0)
+        assert list(hip.counts) == list(ref.counts)
+        ess = [e.ess_reference() for e in hip.eng]
+        assert all(v == ref.eng[0].ess_reference() for v in ess), (ess, ref.eng[0].ess_reference())
+        assert np.array_equal(hip.cat(lambda e: e.parents()), ref.parents())
+        for e in hip.eng:
+            e.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+    assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
+
+
 def test_owner_keeps_world_of_one_and_its_law():
     """One shard (n not a multiple of the tile): draw order IS slot order, so a world of one is the single filter bit for bit."""
     import modppl_amd

@@ -40,6 +40,36 @@ def test_lockstep_bit_exact_vs_canonical(n):
     assert pf.time == len(ys)
 
 
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_single_kernel_resampler_mode_lockstep(monkeypatch, scheme):
+    """MP_DEFERRED_LOOKUPS=0 (a supported A/B mode: k_resample_gather draws, looks up and clones in one launch) with dim_state 1,
+    whose states otherwise live in the row table only (the flag saying so survived that resample, and the next
+    step read the PRE-resample rows).  step, resample, step, read_state against the checker, with and without reads in between."""
+    monkeypatch.setenv("MP_DEFERRED_LOOKUPS", "0")
+    ys = O.lgssm_observations(9)
+    n, seed = 5000, 77
+    for peek in (False, True):
+        pf = _mk(n, seed)
+        ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+        pf.init_step(None, ys[:1])
+        ref.init_step(ys[:1])
+        for t in range(1, len(ys)):
+            if peek:
+                assert pf.resample(scheme) == ref.resample(scheme)
+                assert np.array_equal(pf.states(), ref.state())
+                assert np.array_equal(pf.parents, ref.parents())
+            else:
+                pf.resample(scheme, sync=False)
+                ref.resample(scheme)
+            pf.step(ys[t:t + 1])
+            ref.step(ys[t:t + 1])
+            if peek or t % 3 == 0:
+                assert np.array_equal(pf.states(), ref.state())
+                assert np.array_equal(pf.log_weights, ref.log_weights())
+        assert np.array_equal(pf.states(), ref.state())
+        assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+
+
 def test_weights_accumulate_without_resample():
     ys = O.lgssm_observations(6)
     n, seed = 2000, 5

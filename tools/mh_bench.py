@@ -3,12 +3,13 @@
 hand-written kernels and over the same model as a registered functor run by the generic handlers (mp_genfn.h).
     python tools/mh_bench.py [chains] [iters]"""
 import json
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import modppl_amd  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
