@@ -69,6 +69,7 @@ int32_t mp_set_error(int32_t code, const std::string& msg) { return mp_fail(code
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes for mp_shard_native.h (resolved with dlsym at first use: no link-time dependency)
 #include "mp_pf_kernels.h"
+#include "mp_pf_k1mt.h"
 #include "mp_pf_shard_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -112,6 +113,9 @@ struct PropagateArgs {
     double* tile_m;
     u64* tile_W;
     u64* tile_W2;
+    double* tile_m_new;       // (drawing launches of local_table handles) the tile scalars this launch WRITES: the other buffer pair (= what `tail` names)
+    u64* tile_W_new;
+    u64* tile_W2_new;
     const uint32_t* inv;
     mp_k1_draw drw_v;         // ... what it reads for that (by value: kernel arguments)
     int drw;                  // non-zero: this launch also MAKES the previous resample's draws (resample counter rc), into dfr_row / dfr_lt
@@ -119,6 +123,8 @@ struct PropagateArgs {
     size_t dyn_lds;           // LDS for that phase's copy of the tile table
     const mp_k1_tail* tail;   // device copy of {cx, guide, tile_*, tab} (k_propagate reads them there)
     mp_k1_aux aux;
+    int mt_grid;              // > 0: a drawing launch may run as k_propagate_mt with this many workgroups (one per CU, several tiles each)
+    int mt_flags;             // MP_MT_SKIP_* (mp_pf_k1mt.h)
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
@@ -174,6 +180,26 @@ struct ModelOpsT : ModelOps {
                 hipLaunchKernelGGL(k_propagate_dense16, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
                                    a.x_out, a.logw, a.obs, a.overwrite, a.dfr_row, a.dfr_lt, a.cx_old, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux,
                                    a.inv, a.inv_rows);
+                return;
+            }
+        }
+        if constexpr (THREADS == 1024 && Model::DIM_STATE == 1 && 2 * Model::MAX_NORMALS <= 4) {
+            // one workgroup per CU walking several tiles (mp_pf_k1mt.h): drawing launches of unsharded filters with at most one table
+            // entry per thread
+            if (a.drw == 1 && a.mt_grid > 0 && a.drw_v.nt <= 1024 && a.drw_v.nt >= 2 * a.mt_grid && a.cx_old && !a.inv && !a.inv_rows) {
+                // (multinomial draws, jobs of at least two tiles per CU: below that one workgroup per tile spreads over more CUs —
+                // 2^17 particles 23 against 32 us —, and a lattice's sorted lookups leave nothing to hide: 30.0 against 31.5 us;
+                // 2^20: 38.6 against 38.9, 2^21: 80.9 against 85.9, profiles/r04/k1_scaling.txt)
+                mp_k1mt m;
+                m.n = a.n; m.slot_offset = a.slot_offset; m.n_global = a.drw_v.n_global; m.t = a.t; m.k0 = a.k0; m.k1 = a.k1; m.rc = a.rc;
+                m.S = a.drw_v.S; m.flags = a.mt_flags; m.logw = a.logw; m.cx_old = a.cx_old; m.guide_old = a.drw_v.guide_old;
+                m.cx_new = a.cx; m.guide_new = a.guide; m.tm_new = a.tile_m_new; m.tW_new = a.tile_W_new; m.tW2_new = a.tile_W2_new;
+                m.parent = a.drw_v.parent; m.scal = a.drw_v.scal;
+                mp_obs_n<Model::DIM_OBS> ob;
+                for (int j = 0; j < Model::DIM_OBS; ++j) ob.v[j] = a.obs.v[j];
+                const int grid = (a.drw_v.nt + 1) / 2;   // two tiles per workgroup: b and b + grid
+                hipLaunchKernelGGL((k_propagate_mt<Model>), dim3(grid), dim3(1024), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
+                                   a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, m, ob);
                 return;
             }
         }
@@ -419,6 +445,9 @@ struct mp_pf {
     uint32_t pending_rc = 0;            // the next k_propagate makes them, or flush_draws() when anything else needs them first
     int pending_scheme = 0;             // (their resampling scheme)
     int use_fused_draws = 1;            // MP_FUSED_DRAWS=0: a resample always launches k_draw_slots (A/B measurements)
+    int use_k1_mt = 1;                  // MP_K1_MT=0: drawing launches stay one workgroup per tile (k_propagate) instead of k_propagate_mt (A/B measurements)
+    int cus = 0;                        // compute units of the device (= workgroups of a k_propagate_mt launch)
+    int mt_flags = 0;                   // MP_MT_SKIP_* for the next k_propagate_mt (set by mp_pf_run, which knows what follows a step)
     mp_cx* cx_alt = nullptr;            // second row-table buffer: a k_propagate that looks up deferred draws in cx writes the new table here
     bool deferred = false;              // the last resample only drew: {dfr_lt, dfr_row}[slot] against the table in cx; x[cur] is the pre-resample state
     bool parents_deferred = false;      // ... and a step has consumed the draws since: its parents are still {dfr_lt, dfr_row} against cx_alt
@@ -690,6 +719,12 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.inv = h->sh_lazy ? h->sh_req_slot : nullptr;
     a.cx = h->deferred ? h->cx_alt : h->cx; a.guide = h->deferred ? h->guide_alt : h->guide;
     a.tile_m = h->tile_m; a.tile_W = h->tile_W; a.tile_W2 = h->tile_W2;
+    a.tile_m_new = h->tile_m; a.tile_W_new = h->tile_W; a.tile_W2_new = h->tile_W2;
+    if (h->deferred && h->local_table && h->tiles_alt) {   // (what k1_tail_alt says: update_k1_tail)
+        a.tile_m_new = reinterpret_cast<double*>(h->tiles_alt); a.tile_W_new = h->tiles_alt + h->nt; a.tile_W2_new = h->tiles_alt + 2 * (size_t)h->nt;
+    }
+    a.mt_grid = (h->use_k1_mt && !h->sharded) ? h->cus : 0;
+    a.mt_flags = h->mt_flags;
     // ... and made by it too, when the resample left them pending (kernels of two-slot lanes)
     a.drw = (h->deferred && h->draw_pending) ? (1 | (h->pending_scheme << 1)) : 0;   // bit 0: draw; bits 1..2: the scheme
     a.drw_v = mp_k1_draw{};
@@ -833,6 +868,13 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (env && env[0] == '0') h->use_k1_table = 0;
         env = getenv("MP_FUSED_DRAWS");
         if (env && env[0] == '0') h->use_fused_draws = 0;
+        env = getenv("MP_K1_MT");
+        if (env && env[0] == '0') h->use_k1_mt = 0;
+        HIPCK(hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device));
+        env = getenv("MP_K1_MT_GRID");   // (A/B measurements: another number of workgroups)
+        if (env && atoi(env) > 0) h->cus = atoi(env);
+        env = getenv("MP_K1_MT_FLAGS");  // (A/B measurements: MP_MT_SKIP_* for every launch — results of reads are then undefined)
+        if (env) h->mt_flags = atoi(env);
         // kernels that make their draws themselves build the job's tile table themselves too (MP_K1_LOCAL_TABLE=0: the last
         // workgroup of every level-0 launch builds it, as for every other kernel)
         env = getenv("MP_K1_LOCAL_TABLE");
@@ -1743,13 +1785,18 @@ int32_t mp_pf_run(mp_pf* h, const double* args0, const double* obs, int32_t n_st
     if (rc != MP_OK) return rc;
     rc = mp_pf_resample(h, scheme, nullptr);
     if (rc != MP_OK) return rc;
-    for (int t = 1; t < n_steps; ++t) {
+    // Here the library owns the loop and knows what follows every step: a resample.  The log-weights a step would store are dead
+    // (`resample` zeroes them, particle_filter.rs:114: whoever reads them afterwards gets the zeros materialize() writes) and so
+    // are the parents of every resample but the last, which is still pending when this function returns and is drawn on demand
+    // (flush_draws + k_resolve_slots).  k_propagate_mt skips both stores (12 B per particle-step, -1.1 us per step at 2^20).
+    const int saved_flags = h->mt_flags;
+    h->mt_flags |= MP_MT_SKIP_LOGW | MP_MT_SKIP_PARENT;
+    for (int t = 1; t < n_steps && rc == MP_OK; ++t) {
         rc = mp_pf_step(h, obs + (size_t)t * h->ops->dim_obs, 1);
-        if (rc != MP_OK) return rc;
-        rc = mp_pf_resample(h, scheme, nullptr);
-        if (rc != MP_OK) return rc;
+        if (rc == MP_OK) rc = mp_pf_resample(h, scheme, nullptr);
     }
-    return MP_OK;
+    h->mt_flags = saved_flags;
+    return rc;
 }
 
 int32_t mp_pf_synchronize(mp_pf* h) {

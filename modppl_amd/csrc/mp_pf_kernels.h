@@ -23,8 +23,33 @@ __device__ __forceinline__ void mp_stamp(int kernel, int slot, int what /*0 shad
     }
 }
 #define MP_STAMP(k, s, w) mp_stamp(k, s, w)
+// The same stamps parked in LDS and written out at the kernel's end (k_propagate_mt): a stamp that is a global store queues
+// behind whatever the CU's vector-memory path is busy with — 4096 row gathers, in that kernel — and measures that queue, not the phase.
+__device__ __forceinline__ void mp_stamp_lds(unsigned long long* s, int slot, int what) {
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        if (what == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        else if (what == 1) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        else {
+            unsigned int a, b;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(a), "=s"(b));
+            t = ((unsigned long long)b << 32) | a;
+        }
+        s[slot] = t;
+    }
+}
+__device__ __forceinline__ void mp_stamp_flush(int kernel, const unsigned long long* s) {
+    if (threadIdx.x == 0 && g_mp_stamp_buf && blockIdx.x < MP_STAMP_MAX_WG)
+        for (int i = 0; i < MP_STAMP_SLOTS; ++i) g_mp_stamp_buf[((size_t)kernel * MP_STAMP_MAX_WG + blockIdx.x) * MP_STAMP_SLOTS + i] = s[i];
+}
+#define MP_STAMP_L(s, w) mp_stamp_lds(s_stamps, s, w)
+#define MP_STAMP_L_DECL __shared__ unsigned long long s_stamps[MP_STAMP_SLOTS]; if (threadIdx.x < MP_STAMP_SLOTS) s_stamps[threadIdx.x] = 0ull
+#define MP_STAMP_L_FLUSH(k) mp_stamp_flush(k, s_stamps)
 #else
 #define MP_STAMP(k, s, w) do { } while (0)
+#define MP_STAMP_L(s, w) do { } while (0)
+#define MP_STAMP_L_DECL do { } while (0)
+#define MP_STAMP_L_FLUSH(k) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -376,6 +401,16 @@ __device__ __forceinline__ double mp_exp_nonpos(double x) {
     return y * mp_u2f((uint64_t)(k + 1023) << 52);
 }
 
+// A barrier for data exchanged through LDS only: __syncthreads() is also a workgroup-scope fence for global memory, i.e. an
+// s_waitcnt vmcnt(0) in front of the s_barrier — every barrier of level 0 then waits for the log-weight / state / parent stores
+// the workgroup has just issued (and for whatever gathers are still in flight) before a single LDS word changes hands.
+#ifndef MP_NORM_LDS_BARRIER
+#define MP_NORM_LDS_BARRIER 0
+#endif
+__device__ __forceinline__ void mp_lds_barrier() {
+    if constexpr (MP_NORM_LDS_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
 template <int THREADS>
 __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS], const double (&xv)[TILE / THREADS], u64 n, u64 tile,
                                                mp_cx* __restrict__ cx, unsigned short* __restrict__ guide,
@@ -403,7 +438,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     else if constexpr (GW == 8) reinterpret_cast<u64*>(s_guide)[tid] = 0ull;
     else if constexpr (GW == 4) reinterpret_cast<uint32_t*>(s_guide)[tid] = 0u;
     else s_guide[tid] = 0;
-    __syncthreads();
+    mp_lds_barrier();
     MP_STAMP(0, 9, 0);
     m = s_red[0];
 #pragma unroll
@@ -426,7 +461,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     const u64 wtot2 = wave_sum_u64(run2);   // (an LDS atomic per lane instead costs ~10 cycles per LANE: measured 12 k cycles for this tile)
     if (lane == 63) s_wsum[wave] = incl;
     if (lane == 0) s_wsum2[wave] = wtot2;
-    __syncthreads();
+    mp_lds_barrier();
     MP_STAMP(0, 12, 0);
     // cross-wave offsets on the scalar unit: the per-wave totals and `wave` are wave-uniform, so the sums need no VALU issue
     u64 woff = 0, W = 0;
@@ -498,7 +533,7 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
     }
     MP_STAMP(0, 14, 0);
     if (tid == 0) s_last = (tab.ticket != nullptr && my_ticket == gridDim.x - 1u) ? 1 : 0;
-    __syncthreads();
+    mp_lds_barrier();
     MP_STAMP(0, 15, 0);
     if constexpr (GW == 16) reinterpret_cast<uint4*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const uint4*>(s_guide)[tid];
     else if constexpr (GW == 8) reinterpret_cast<u64*>(guide + tile * GUIDE_N)[tid] = reinterpret_cast<const u64*>(s_guide)[tid];

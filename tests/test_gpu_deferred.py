@@ -265,3 +265,73 @@ def test_degenerate_population_on_the_fused_path():
     pf2.step(bad)
     with pytest.raises(capi.ModpplError):
         pf2.resample()               # synchronous: reported at once
+
+
+@pytest.mark.parametrize("n", [4097, 6143, 2048 * 5, 2048 * 6 + 1, 70001])
+def test_two_tiles_per_workgroup_kernel_at_small_sizes(monkeypatch, n):
+    """k_propagate_mt (mp_pf_k1mt.h: one workgroup walks two tiles, row gathers under the other tile's arithmetic) is picked for
+    jobs of at least two tiles per CU; MP_K1_MT_GRID=1 (read at creation) lowers that bar to two tiles, so that odd tile counts
+    — a last workgroup without a second tile —, ragged last tiles and reads in every position meet it at sizes the checker
+    walks in milliseconds.  Same Philox blocks, targets and walks as k_propagate: every value against the one-workgroup-per-tile
+    kernel (MP_K1_MT=0) and against the checker, bit for bit."""
+    import modppl_amd
+
+    seed, T = 97, 7
+    obs = O.lgssm_observations(T).reshape(T, 1)
+    monkeypatch.setenv("MP_K1_MT_GRID", "1")
+    mt = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    monkeypatch.delenv("MP_K1_MT_GRID")
+    monkeypatch.setenv("MP_K1_MT", "0")
+    one = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    monkeypatch.delenv("MP_K1_MT")
+    ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    for pf in (mt, one):
+        pf.init_step(None, obs[:1])
+    ref.init_step(obs[:1])
+    for t in range(1, T):
+        for pf in (mt, one):
+            pf.resample(sync=False)
+            pf.step(obs[t:t + 1])
+        ref.resample()
+        ref.step(obs[t:t + 1])
+        if t % 2:   # (reads only every other round: the rounds in between hand over from one launch to the next untouched)
+            assert np.array_equal(mt.parents, ref.parents())
+            assert np.array_equal(mt.parents, one.parents)
+            assert np.array_equal(mt.log_weights, ref.log_weights())
+            assert np.array_equal(mt.states(), ref.state())
+    assert np.array_equal(mt.states(), one.states())
+    assert np.array_equal(mt.states(), ref.state())
+    assert np.array_equal(mt.log_weights, ref.log_weights())
+    assert mt.effective_sample_size(fresh=True) == ref.effective_sample_size(1)
+    assert mt.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate() == one.log_marginal_likelihood_estimate()
+
+
+@pytest.mark.parametrize("n", [2048 * 4 + 77, 1 << 20])
+def test_run_owns_the_loop_and_skips_the_dead_stores(monkeypatch, n):
+    """mp_pf_run knows that a resample follows every step: its k_propagate_mt launches store neither the log-weights (zeroed by
+    `resample`, particle_filter.rs:114) nor the parents of any resample but the last, which is still pending when it returns.
+    Whatever is read afterwards — parents, states, (zero) log-weights, ESS, log-ML, a further step — equals the checker's loop."""
+    import modppl_amd
+
+    seed, T = 5, 6
+    obs = O.lgssm_observations(T + 1).reshape(T + 1, 1)
+    if n < (1 << 20):
+        monkeypatch.setenv("MP_K1_MT_GRID", "1")
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    monkeypatch.delenv("MP_K1_MT_GRID", raising=False)
+    ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    pf.run(None, obs[:T])
+    ref.init_step(obs[:1])
+    ref.resample()
+    for t in range(1, T):
+        ref.step(obs[t:t + 1])
+        ref.resample()
+    assert np.array_equal(pf.parents, ref.parents())
+    assert np.array_equal(pf.states(), ref.state())
+    assert np.all(pf.log_weights == 0.0)
+    assert pf.effective_sample_size() == ref.effective_sample_size(0)
+    assert pf.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate()
+    pf.step(obs[T:T + 1])
+    ref.step(obs[T:T + 1])
+    assert np.array_equal(pf.log_weights, ref.log_weights())
+    assert np.array_equal(pf.states(), ref.state())

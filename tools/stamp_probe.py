@@ -27,7 +27,8 @@ def main():
     args = ap.parse_args()
     from modppl_amd import build as B
 
-    os.environ["MODPPL_HIP_LIB"] = B.build_stamps()
+    # (MP_STAMPS_LIB: another -DMP_STAMPS build, e.g. one of tools/build_variant.py's)
+    os.environ["MODPPL_HIP_LIB"] = os.environ.get("MP_STAMPS_LIB") or B.build_stamps()
     import modppl_amd
     from modppl_amd import capi
     from bench import LGSSM_PARAMS, lgssm_observations
