@@ -239,6 +239,62 @@ def sub_benches(steps, warmup, which):
     return res
 
 
+def reference_shaped_loop(model, n, ys, steps, warmup):
+    """The loop a drop-in caller of the reference writes (modppl/tests/smc.rs:64-90 over particle_filter.rs:73-116): every call
+    SYNCHRONOUS — `step`; `effective_sample_size()` (the reference's stale value, a host f64); `L = resample()` (a host f64) —
+    against bench.py's own loop, whose resample only enqueues.  The synchronous resample asks one small workgroup for L
+    (k_peek_level1 -> host-mapped memory) and leaves draws and lookups to the next step's k_propagate, the ESS comes out of
+    host-mapped memory written by that launch's first workgroup: one host round trip per step, no launch of k_draw_slots /
+    k_resolve_slots.  Also: the same loop with every particle's state copied to the host after each resample, as the reference's
+    test does (PCIe-inclusive: 8 MB per step; never `value`), and the per-kernel durations of an instrumented repeat."""
+    import modppl_amd
+    from modppl_amd import capi
+
+    pf = modppl_amd.ParticleSystem(model, n, 20241008)
+    T = len(ys)
+    pf.init_step(None, ys[:1])
+    pf.resample()
+    for t in range(1, 1 + warmup):
+        pf.step(ys[t:t + 1])
+        pf.effective_sample_size()
+        pf.resample()
+    pf.synchronize()
+    t0 = time.perf_counter()
+    Ls = 0.0
+    for t in range(1 + warmup, 1 + warmup + steps):
+        pf.step(ys[t % T:t % T + 1])
+        pf.effective_sample_size()
+        Ls += pf.resample()
+    pf.synchronize()
+    dt = time.perf_counter() - t0
+    pf.set_timing(True)
+    for t in range(1 + warmup, 1 + warmup + steps):
+        pf.step(ys[t % T:t % T + 1])
+        pf.effective_sample_size()
+        pf.resample()
+    pf.synchronize()
+    fam = {k: pf.get_timing(v) for k, v in (("propagate", capi.MP_K_PROPAGATE), ("normalize_scan", capi.MP_K_NORMALIZE_SCAN),
+                                            ("bin_draws", capi.MP_K_BIN_DRAWS), ("resample_gather", capi.MP_K_RESAMPLE_GATHER))}
+    pf.set_timing(False)
+    k_states = max(3, min(steps, 10))
+    t0 = time.perf_counter()
+    for t in range(1, 1 + k_states):
+        pf.step(ys[t:t + 1])
+        pf.effective_sample_size()
+        pf.resample()
+        pf.states()
+    dts = time.perf_counter() - t0
+    return {"what": "step; effective_sample_size() -> f64; resample() -> f64 (every call synchronous, as in particle_filter.rs:73-116)",
+            "steps": steps, "us_per_step": dt / steps * 1e6, "particle_steps_per_s": n * steps / dt,
+            "step_hbm_frac": BYTES_STEP * n * steps / dt / 1e9 / HBM_PEAK_GBPS,
+            "kernel_launches_per_step": {k: v[1] / steps for k, v in fam.items()},
+            "kernel_avg_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in fam.items()},
+            "k_peek_level1": "one 1024-thread workgroup per synchronous resample (not in a timing family: the difference between us_per_step and the kernels above is that launch plus one host round trip)",
+            "with_states_copied_to_host_each_step": {"steps": k_states, "us_per_step": dts / k_states * 1e6,
+                                                     "note": "PCIe-inclusive: k_draw_slots + k_resolve_slots + 8 MB device-to-host per step (tests/smc.rs:64-90 writes every state to disk)"},
+            "sum_of_log_total_weights": Ls}
+
+
 def _finite(obj):
     """JSON has no NaN / inf: a non-finite number anywhere (a degenerate sub-bench's log-ML, a 0 / 0 ratio) becomes null and its
     path is listed under "non_finite", so that one bad leg cannot cost the driver the whole line.  -> (clean object, paths)"""
@@ -282,6 +338,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
+    ap.add_argument("--repeats", type=int, default=9, help="the timed region of --steps steps is repeated this many times; `value` is the median region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record hipEvents around each launch in the timed region")
     ap.add_argument("--no-sub-benches", action="store_true", help="skip the c3 / c4 / c5 sub-objects")
@@ -399,32 +456,56 @@ def main():
         pf.step(ys[t:t + 1])
         pf.resample(sync=False)
     barrier()
-    # ---- timed region: EXACTLY K steps, nothing but the hot path enqueued ----
-    t0 = time.perf_counter()
-    for t in range(1 + W, T):
-        pf.step(ys[t:t + 1])
+
+    # ---- timed region: EXACTLY K steps, nothing but the hot path enqueued; one hipEvent pair on the kernels' stream around the
+    # whole region (mp_pf_region_begin / _end: no per-launch instrumentation), max over ranks ----
+    def timed_region():
+        barrier()
+        t0 = time.perf_counter()
+        if hasattr(timer, "region_begin"):
+            timer.region_begin()
+        for t in range(1 + W, T):
+            pf.step(ys[t:t + 1])
+            pf.resample(sync=False)
+        ev = timer.region_end() if hasattr(timer, "region_end") else (None, 0)
+        barrier()
+        d = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([d], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d, ev
+
+    dts, evs = [], []
+    d0, ev0 = timed_region()
+    dts.append(d0); evs.append(ev0)
+    lml = pf.log_marginal_likelihood_estimate()   # of the first region: y_0 .. y_{T-1}, the run the Kalman value below belongs to
+    # the same K steps again, R - 1 times (the filter simply goes on; the query above made the pending draws, so one untimed step
+    # first puts the loop back into its steady state): `value` is the MEDIAN region, min / max beside it
+    for _ in range(max(0, args.repeats - 1)):
+        pf.step(ys[1 + W:2 + W])
         pf.resample(sync=False)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    lml = pf.log_marginal_likelihood_estimate()
+        d, ev = timed_region()
+        dts.append(d); evs.append(ev)
+    dt = float(np.median(dts))
     # ---- supplementary: the same K steps with systematic resampling (named next to multinomial in the north star; not `value`)
     dt_sys = None
     if not force_sharded and not args.no_systematic_leg:   # (at N > 1 too: the sharded filter's lattice schemes need no enumeration of all N draws)
-        barrier()
-        t0 = time.perf_counter()
-        for t in range(1 + W, T):
-            pf.step(ys[t:t + 1])
-            pf.resample(scheme=1, sync=False)
-        barrier()
-        dt_sys = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([dt_sys], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_sys = float(tt.item())
+        sys_dts = []
+        for rep in range(1 + min(4, max(0, args.repeats - 1))):   # (a first, untimed-in-effect region switches the scheme; median of the rest)
+            barrier()
+            t0 = time.perf_counter()
+            for t in range(1 + W, T):
+                pf.step(ys[t:t + 1])
+                pf.resample(scheme=1, sync=False)
+            barrier()
+            d = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([d], device="cuda", dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                d = float(tt.item())
+            sys_dts.append(d)
+        dt_sys = float(np.median(sys_dts[1:])) if len(sys_dts) > 1 else sys_dts[0]
     # ---- per-kernel durations: the same K steps again with a hipEvent pair around every launch, recorded on the
     # stream the kernels run on (the pairs cost ~20 us per step, so they stay out of the region `value` is taken from)
     fam = {"propagate": (0.0, 0), "normalize_scan": (0.0, 0), "bin_draws": (0.0, 0), "resample_gather": (0.0, 0)}
@@ -476,6 +557,8 @@ def main():
         timed = any(v[1] for v in fam.values())
         avg_us = {k: ((v[0] / v[1]) * 1e3 if v[1] else 0.0) for k, v in fam.items()} if timed else None
         sharded_path = world > 1 or force_sharded
+        if hasattr(timer, "last_propagate_form") and timer.last_propagate_form() == 1:   # (the library says which form of K1 its steps launched)
+            KERNEL_OF["propagate"] = "k_propagate_mt<mp_lgssm1>"
         if sharded_path:   # the sharded filter runs other kernels for the resample
             if getattr(pf, "exchange", "") == "owned":
                 KERNEL_OF.update({"bin_draws": "k_shard_table + k_shard_own_draw + k_shard_own_plan", "resample_gather": "k_shard_own_place"})
@@ -489,7 +572,15 @@ def main():
                 bytes_k["propagate"] += FUSED_GATHER   # the step's k_propagate also looked up / cloned the parents (no launch of its own did)
                 if fam["bin_draws"][1] == 0:
                     bytes_k["propagate"] += BYTES_K["bin_draws"]   # ... and made the draws: the whole step is that one launch
-            achieved = bytes_k[dom] * n / (avg_us[dom] * 1e-6) / 1e9
+            # the dominant kernel's mean launch duration: from the ONE event pair around each timed region (elapsed / launches of that
+            # region, median over the regions) where every step is one launch of it — un-perturbed, and including the gaps between
+            # launches, i.e. an upper bound; the per-launch event pairs of the instrumented repeat (kernel_avg_us) cost each launch
+            # ~0.5 us and are kept for the breakdown by kernel
+            dom_us, dom_src = avg_us[dom], "hipEvent pair around every launch (instrumented repeat)"
+            reg = [e[0] / e[1] * 1e3 for e in evs if e[0] is not None and e[1] == K]
+            if dom == "propagate" and reg and fam["bin_draws"][1] == 0 and fam["resample_gather"][1] == 0 and fam["normalize_scan"][1] == 0:
+                dom_us, dom_src = float(np.median(reg)), f"one hipEvent pair around each timed region of {K} launches, median of {len(reg)} regions (no per-launch instrumentation)"
+            achieved = bytes_k[dom] * n / (dom_us * 1e-6) / 1e9
             # HBM-side bytes per launch of that kernel: PMC passes cannot run inside this process, so this is the committed
             # summary of the same single-GPU command — accepted only if it names this kernel AND was measured with this build
             # (content hash of the kernel sources), otherwise null with the reason
@@ -512,7 +603,8 @@ def main():
                         traffic_note = f"rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, commit {meta.get('commit')}; fetch correction: {tj[dom].get('fetch_correction')}"
                 except Exception as e:   # noqa: BLE001
                     traffic_note = f"unreadable profiles summary: {e}"
-            roofline = {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            roofline = {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "kernel_us": dom_us, "kernel_us_source": dom_src,
+                        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
                         "bytes_per_launch": bytes_k[dom] * n, "bytes_per_particle": bytes_k[dom],
                         "bytes_are": "ALGORITHMIC bytes of the reference step this launch stands for (SURVEY.md 8d: 96 B per particle-step at d = 1), "
@@ -525,6 +617,9 @@ def main():
             "steps": K,
             "warmup": W,
             "ms_per_step": dt / K * 1e3,
+            "repeats": len(dts),
+            "ms_per_step_min": min(dts) / K * 1e3, "ms_per_step_max": max(dts) / K * 1e3,
+            "value_is": f"median of {len(dts)} timed regions of {K} steps each (min / max: ms_per_step_min / _max)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -556,6 +651,11 @@ def main():
         if c5 is not None:
             out["c5"] = c5
         out["library"] = _library_identity()
+        if world == 1 and not force_sharded and not args.no_sub_benches:
+            try:
+                out["reference_shaped_loop"] = reference_shaped_loop(model, n, ys, max(10, min(K, 50)), min(W, 5))
+            except Exception as e:   # noqa: BLE001
+                out["reference_shaped_loop_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not force_sharded and not args.no_sub_benches:
             del pf
             for leg in ("c3", "c5", "c4"):   # (one leg's failure is that leg's, not the headline's)

@@ -287,6 +287,19 @@ enum mp_kernel_family {
 };
 int32_t mp_pf_set_timing(mp_pf* h, int32_t enabled);
 int32_t mp_pf_get_timing(mp_pf* h, int32_t which, double* total_ms, uint64_t* launches);
+/* ONE hipEvent pair around a whole region of launches on the handle's stream (begin ... end): the elapsed device time and the
+ * k_propagate-family launches enqueued in between.  Unlike the per-launch pairs above this costs the region nothing per step, so
+ * elapsed / launches is the un-perturbed mean duration of a launch (including the gaps between launches) — what bench.py's
+ * roofline uses.  mp_pf_region_end waits for the stream. */
+/* which form of K1 the handle's last step launched (profiles name kernels; a bench line should name the one it measured) */
+enum mp_k1_form {
+    MP_K1_FORM_TILE = 0,       /* k_propagate<Model, ...>: one workgroup per 2048-slot tile                         */
+    MP_K1_FORM_TWO_TILES = 1,  /* k_propagate_mt<Model>: one workgroup per CU over two tiles (mp_pf_k1mt.h)         */
+    MP_K1_FORM_DENSE16 = 2     /* k_propagate_dense16: the dense d = 16 model on the matrix cores                   */
+};
+int32_t mp_pf_last_propagate_form(mp_pf* h, int32_t* out);   /* -1 before the first step */
+int32_t mp_pf_region_begin(mp_pf* h);
+int32_t mp_pf_region_end(mp_pf* h, double* elapsed_ms, uint64_t* propagate_launches);
 
 /* ---- GenFn::simulate over an Unfold model — DynUnfold::simulate, modppl/src/modeling/dynunfold.rs:22-39 ---- */
 /* n independent traces of n_steps kernel calls with EVERY site sampled (the sites that are observations on the filtering

@@ -132,7 +132,7 @@ struct ModelOps {
     int max_normals = 0;
     bool can_draw = false;   // its k_propagate can make the previous resample's draws itself (lanes of two adjacent slots: the 1024-thread launch shape)
     virtual ~ModelOps() { if (owned_device_mem) (void)hipFree(owned_device_mem); }
-    virtual void propagate(const PropagateArgs& a) const = 0;
+    virtual int propagate(const PropagateArgs& a) const = 0;   // -> MP_K1_FORM_* of the kernel it launched
     virtual int n_normals(long long t) const = 0;
     virtual void simulate(u64 n, uint32_t k0, uint32_t k1, int n_steps, const mp_state0& s0, double* states, double* obs, hipStream_t st) const = 0;
 };
@@ -152,7 +152,7 @@ struct ModelOpsT : ModelOps {
     void simulate(u64 n, uint32_t k0, uint32_t k1, int n_steps, const mp_state0& s0, double* states, double* obs, hipStream_t st) const override {
         hipLaunchKernelGGL(k_simulate<Model>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, model, n, k0, k1, n_steps, s0, states, obs);
     }
-    void propagate(const PropagateArgs& a) const override {
+    int propagate(const PropagateArgs& a) const override {
         // light kernels (few registers) run 1024 threads x 2 particles per tile: twice the waves in flight for the same 2048-slot tile
         constexpr int THREADS = (Model::MAX_NORMALS <= 4 && Model::DIM_STATE <= 4) ? 1024 : TILE_THREADS;
         const int k1t = k1_threads_override();   // A/B measurements
@@ -162,14 +162,14 @@ struct ModelOpsT : ModelOps {
                                    a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
                                    a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                return;
+                return MP_K1_FORM_TILE;
             }
             if (k1t == 512) {
                 hipLaunchKernelGGL((k_propagate<Model, 512>), dim3(a.grid), dim3(512), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old, a.drw_v.tile_W2_old,
                                    a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
                                    a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                return;
+                return MP_K1_FORM_TILE;
             }
         }
         if constexpr (std::is_same<Model, mp_lgssm_dense<16>>::value) {
@@ -180,7 +180,7 @@ struct ModelOpsT : ModelOps {
                 hipLaunchKernelGGL(k_propagate_dense16, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
                                    a.x_out, a.logw, a.obs, a.overwrite, a.dfr_row, a.dfr_lt, a.cx_old, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux,
                                    a.inv, a.inv_rows);
-                return;
+                return MP_K1_FORM_DENSE16;
             }
         }
         if constexpr (THREADS == 1024 && Model::DIM_STATE == 1 && 2 * Model::MAX_NORMALS <= 4) {
@@ -200,7 +200,7 @@ struct ModelOpsT : ModelOps {
                 const int grid = (a.drw_v.nt + 1) / 2;   // two tiles per workgroup: b and b + grid
                 hipLaunchKernelGGL((k_propagate_mt<Model>), dim3(grid), dim3(1024), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
                                    a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, m, ob);
-                return;
+                return MP_K1_FORM_TWO_TILES;
             }
         }
         if constexpr (THREADS == 1024) {
@@ -215,20 +215,21 @@ struct ModelOpsT : ModelOps {
                                        a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                        a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
                                        a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                return;
+                return MP_K1_FORM_TILE;
             }
             if (a.drw && a.drw_v.nt > THREADS) {   // a drawing launch of a job with more tiles than threads: two table entries per thread
                 hipLaunchKernelGGL((k_propagate<Model, THREADS, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
                                    a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
                                    a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                return;
+                return MP_K1_FORM_TILE;
             }
         }
         hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old, a.drw_v.tile_W2_old,
                                    a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
                            a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
+        return MP_K1_FORM_TILE;
     }
     int n_normals(long long t) const override { return model.n_normals(t); }
 };
@@ -430,6 +431,10 @@ struct mp_pf {
     double* aos = nullptr;             // staging for read_state
     mp_dev_scalars* h_scal = nullptr;  // pinned
     int* h_flag = nullptr;             // host-mapped: the device-side sticky error (mp_dev_scalars::host_flag points here)
+    mp_host_mirror* h_mirror = nullptr;   // host-mapped: L / ESS / log-ML of every fold, and k_peek_level1's answers (mp_pf_kernels.h)
+    mp_host_mirror* d_mirror = nullptr;   // its device address
+    unsigned long long peek_seq = 0;      // k_peek_level1 launches so far
+    int use_mirror = 1;                   // MP_HOST_MIRROR=0: synchronous calls copy mp_dev_scalars back as before (A/B measurements)
     // the draws of a multinomial resample, per output slot (k_draw_slots)
     u64* dfr_lt = nullptr;              // [n] tile-local target
     uint32_t* dfr_row = nullptr;        // [n] table row where the forward scan starts
@@ -528,6 +533,10 @@ struct mp_pf {
     bool timing = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
+    int last_k1_form = -1;                          // MP_K1_FORM_* of the last k_propagate-family launch
+    hipEvent_t region_ev[2] = {nullptr, nullptr};   // mp_pf_region_begin / _end
+    bool region_open = false;
+    uint64_t region_launches = 0;
     double fam_ms[MP_K_COUNT] = {0, 0, 0, 0};
     uint64_t fam_launches[MP_K_COUNT] = {0, 0, 0, 0};
 };
@@ -621,6 +630,24 @@ static hipError_t stream_wait(hipStream_t s) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
     }
+}
+// Poll one host-mapped sequence word until the device has written `want` (data words are written before it, release order).
+// If the stream drains without it, whoever was to write it never ran: an error of the library, reported rather than spun on.
+static int32_t wait_seq(mp_pf* h, const volatile unsigned long long* word, unsigned long long want, const char* what) {
+    for (unsigned spins = 1;; ++spins) {
+        if (*word == want) break;
+        if ((spins & 255u) == 0u) {
+            const hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipErrorNotReady) continue;
+            if (e != hipSuccess) return mp_fail(MP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+            if (*word == want) break;
+            return mp_fail(MP_ERR_STATE, std::string(what) + ": the stream drained without the value (sequence " + std::to_string(*word) + ", expected " + std::to_string(want) + ")");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*(volatile int*)h->h_flag)
+        return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
+    return MP_OK;
 }
 static int32_t flush_draws(mp_pf* h);
 static int32_t fetch_scalars(mp_pf* h) {
@@ -748,8 +775,9 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.tail = h->deferred ? h->k1_tail_alt : h->k1_tail;
     {
         LaunchTimer lt(h, MP_K_PROPAGATE);
-        h->ops->propagate(a);
+        h->last_k1_form = h->ops->propagate(a);
     }
+    h->region_launches += 1;
     if (h->deferred) {   // the fresh table is the current one from here on; the old one stays intact for mp_pf_read_parents
         std::swap(h->cx, h->cx_alt);
         std::swap(h->guide, h->guide_alt);
@@ -931,6 +959,17 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     mp_dev_scalars init{};
     init.ess_stale = 1.0 / (double)h->n_global;  // exp(-logsumexp(zeros)) before any resample
     HIPCK(hipHostGetDevicePointer((void**)&init.host_flag, h->h_flag, 0));
+    {
+        const char* env = getenv("MP_HOST_MIRROR");
+        if (env && env[0] == '0') h->use_mirror = 0;
+    }
+    if (!h->sharded && h->use_mirror) {   // (sharded handles fold, undo and re-fold through mp_pf_shard_*: they keep the copy)
+        HIPCK(hipHostMalloc(&h->h_mirror, sizeof(mp_host_mirror), hipHostMallocMapped));
+        std::memset(h->h_mirror, 0, sizeof(mp_host_mirror));
+        h->h_mirror->ess_stale = init.ess_stale;
+        HIPCK(hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0));
+        init.mirror = h->d_mirror;
+    }
     *h->h_scal = init;
     HIPCK(hipMemcpyAsync(h->scal, h->h_scal, sizeof(mp_dev_scalars), hipMemcpyHostToDevice, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
@@ -1037,6 +1076,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     h->sh_recv = false;
     const int d = h->ops->dim_state;
     bool drawn_only = false;
+    bool peek_L = false;   // the return value from k_peek_level1 (the draws stay pending)
     if (h->use_deferred) {
         // draws only: the lookups are done by whoever consumes the parents — the next k_propagate, under its arithmetic, or
         // k_resolve_slots when the host asks first
@@ -1052,11 +1092,13 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         // multinomial resample enqueues NOTHING, the next k_propagate draws for its own slots (flush_draws() otherwise)
         // (up to 2048 tiles = 2^22 particles: the kernel's table, 24 B per tile, stays within the default dynamic-LDS limit)
         // (the lattice schemes too: their targets need no Philox block per lane at all)
-        if (h->nt <= 2048 && !log_total_weight && h->use_fused_draws && h->ops->can_draw &&
+        // (a SYNCHRONOUS resample too, when the handle has the host-mapped mirror: its return value comes from k_peek_level1 below)
+        if (h->nt <= 2048 && (!log_total_weight || h->h_mirror) && h->use_fused_draws && h->ops->can_draw &&
             h->local_table && !(h->flags & MP_PF_RECORD_HISTORY)) {
             h->draw_pending = true;
             h->pending_rc = h->resample_count;
             h->pending_scheme = scheme;
+            peek_L = log_total_weight != nullptr;
         } else {
             rc = launch_draws(h, scheme, h->resample_count);
             if (rc != MP_OK) return rc;
@@ -1099,7 +1141,21 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         HIPCK(hipMemcpyAsync(buf, h->parent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToDevice, h->stream));
         h->hist.push_back({1, buf});
     }
-    if (log_total_weight) {
+    if (log_total_weight && peek_L) {
+        // `resample() -> f64` without making the draws now: level 1 of the normalisation that is being resampled by one small
+        // workgroup, its result in host-mapped memory; the draws, the lookups and the fold into log_ml happen inside the next
+        // step's k_propagate as after an asynchronous resample (k_draw_slots + k_resolve_slots + a copy of the scalars before)
+        h->peek_seq += 1;
+        hipLaunchKernelGGL(k_peek_level1, dim3(1), dim3(1024), 0, h->stream, (const double*)h->tile_m, (const u64*)h->tile_W, (const u64*)h->tile_W2, h->nt, h->S,
+                           h->scal, h->d_mirror, h->peek_seq);
+        rc = check_launch("k_peek_level1");
+        if (rc != MP_OK) return rc;
+        rc = wait_seq(h, &h->h_mirror->peek_seq, h->peek_seq, "resample");
+        if (rc != MP_OK) return rc;
+        if (h->h_mirror->peek_degenerate)
+            return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
+        *log_total_weight = h->h_mirror->peek_L;
+    } else if (log_total_weight) {
         rc = fetch_scalars(h);
         if (rc != MP_OK) return rc;
         *log_total_weight = h->h_scal->L;
@@ -1122,6 +1178,17 @@ int32_t mp_pf_effective_sample_size(mp_pf* h, int32_t ess_mode, double* out) {
     if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
     if (ess_mode == MP_ESS_REFERENCE) {
+        if (h->h_mirror) {
+            // the value of the last resample's normalisation (particle_filter.rs:98-100 reads buffers only `resample` refreshes): in
+            // host-mapped memory as soon as whoever makes that resample's draws has folded it — the first workgroup of the step
+            // that follows an asynchronous resample does so in its first microseconds, so this does not wait for the step to end
+            int32_t rc = flush_draws(h);
+            if (rc != MP_OK) return rc;
+            rc = wait_seq(h, &h->h_mirror->fold_seq, h->resample_count, "effective_sample_size");
+            if (rc != MP_OK) return rc;
+            *out = h->h_mirror->ess_stale;
+            return MP_OK;
+        }
         int32_t rc = fetch_scalars(h);
         if (rc != MP_OK) return rc;
         *out = h->h_scal->ess_stale;
@@ -1830,6 +1897,39 @@ int32_t mp_pf_get_timing(mp_pf* h, int32_t which, double* total_ms, uint64_t* la
     return MP_OK;
 }
 
+int32_t mp_pf_last_propagate_form(mp_pf* h, int32_t* out) {
+    if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    *out = h->last_k1_form;
+    return MP_OK;
+}
+
+int32_t mp_pf_region_begin(mp_pf* h) {
+    if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
+    HIPCK(hipSetDevice(h->device));
+    if (!h->region_ev[0]) {
+        HIPCK(hipEventCreate(&h->region_ev[0]));
+        HIPCK(hipEventCreate(&h->region_ev[1]));
+    }
+    h->region_launches = 0;
+    HIPCK(hipEventRecord(h->region_ev[0], h->stream));
+    h->region_open = true;
+    return MP_OK;
+}
+
+int32_t mp_pf_region_end(mp_pf* h, double* elapsed_ms, uint64_t* propagate_launches) {
+    if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
+    if (!h->region_open) return mp_fail(MP_ERR_STATE, "region_end without region_begin");
+    HIPCK(hipSetDevice(h->device));
+    HIPCK(hipEventRecord(h->region_ev[1], h->stream));
+    HIPCK(stream_wait(h->stream));
+    float ms = 0.f;
+    HIPCK(hipEventElapsedTime(&ms, h->region_ev[0], h->region_ev[1]));
+    h->region_open = false;
+    if (elapsed_ms) *elapsed_ms = (double)ms;
+    if (propagate_launches) *propagate_launches = h->region_launches;
+    return MP_OK;
+}
+
 static void shard_native_free(mp_shard_native_state* s);   // mp_shard_native.h
 int32_t mp_pf_destroy(mp_pf* h) {
     if (!h) return MP_OK;
@@ -1841,6 +1941,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
         (void)hipEventDestroy(tl.stop);
     }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    for (auto e : h->region_ev) if (e) (void)hipEventDestroy(e);
     for (void* slab : h->hist_slabs) (void)hipFree(slab);
     (void)hipFree(h->d_hist_events);
     (void)hipFree(h->x[0]); (void)hipFree(h->x[1]); (void)hipFree(h->logw); (void)hipFree(h->cx); (void)hipFree(h->cx_alt); (void)hipFree(h->k1_tail_alt); (void)hipFree(h->guide);
@@ -1859,6 +1960,7 @@ int32_t mp_pf_destroy(mp_pf* h) {
     if (h->ev_resolved) (void)hipEventDestroy(h->ev_resolved);
     (void)hipHostFree(h->h_scal);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    if (h->h_mirror) (void)hipHostFree(h->h_mirror);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;

@@ -67,6 +67,19 @@ struct mp_dev_scalars {
     int pad;
     int* host_flag;    // host-mapped mirror of `degenerate` (set with a write-through store by whoever sets it): mp_pf_synchronize
                        // then needs no copy of this struct to report it
+    struct mp_host_mirror* mirror;   // host-mapped: what a synchronous caller asks for after every resample (below); null = none
+    u64 folds;         // resamples folded into these scalars so far (mode-0 folds)
+};
+// What `resample() -> f64` and `effective_sample_size()` (particle_filter.rs:98-116) hand back to the host, in host-mapped memory
+// written with system-scope stores by the thread that computes it: the host polls a sequence word instead of enqueueing a copy
+// of mp_dev_scalars and waiting for the stream to drain (16 us per call, and a resample whose draws the next step would have
+// made had to be drawn by a launch of its own first).  Data first, sequence word last (release).
+struct mp_host_mirror {
+    unsigned long long fold_seq;    // == mp_dev_scalars::folds once the values below belong to that resample
+    double L, ess_stale, log_ml;
+    unsigned long long peek_seq;    // k_peek_level1: the number the host passed, once peek_* are valid
+    double peek_L, peek_ess;
+    int peek_degenerate, pad;
 };
 // `degenerate` goes up, on the device and in the host's mirror
 __device__ __forceinline__ void mp_flag_degenerate(mp_dev_scalars* scal) {
@@ -1487,7 +1500,17 @@ __device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2
         scal->ess_stale = ess;
         scal->Q = Q;
         scal->Q2 = Q2;
-        scal->log_ml += L - mp_log((double)n_global);
+        const double lml = scal->log_ml + (L - mp_log((double)n_global));
+        scal->log_ml = lml;
+        const u64 folds = scal->folds + 1;
+        scal->folds = folds;
+        if (scal->mirror) {
+            mp_host_mirror* hm = scal->mirror;
+            __hip_atomic_store(reinterpret_cast<u64*>(&hm->L), mp_f2u(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<u64*>(&hm->ess_stale), mp_f2u(ess), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<u64*>(&hm->log_ml), mp_f2u(lml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&hm->fold_seq, folds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     } else {          // query (particle_filter.rs:119-121; fresh ESS)
         scal->L = L;
         scal->ess_fresh = ess;
@@ -1851,6 +1874,49 @@ __global__ void k_trajectories(u64 first, u64 count, int D, int T, int n_events,
             double* dst = out + (j * (u64)T + (u64)t) * (u64)D;
             for (int d = 0; d < D; ++d) dst[d] = src[d];
         }
+    }
+}
+
+// Level 1 of the CURRENT tile scalars for a synchronous `resample() -> f64` (particle_filter.rs:103-105, 116): the log total
+// weight (and the ESS of these weights) straight into host-mapped memory, nothing folded — the resample's draws, and with them
+// the fold into log_ml, are still left to the next step's k_propagate exactly as after an asynchronous resample.  Same
+// arithmetic as block_tile_table / block_sum_T2 (T_b, T2_b entry by entry, integer sums), one workgroup, no table.
+__global__ __launch_bounds__(1024) void k_peek_level1(const double* __restrict__ tile_m, const u64* __restrict__ tile_W, const u64* __restrict__ tile_W2,
+                                                      int nt, int S, mp_dev_scalars* scal, mp_host_mirror* hm, unsigned long long seq) {
+    __shared__ double s_red[16];
+    __shared__ u64 s_q[16], s_q2[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double m = MP_NEG_INF;
+    for (int b = tid; b < nt; b += 1024) m = fmax(m, tile_m[b]);
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);  // 2^(S-51)
+    u64 q = 0, q2 = 0;
+    for (int b = tid; b < nt; b += 1024) {
+        const double d = tile_m[b] - m;
+        q += mp_quantize((double)tile_W[b] * (ok ? mp_exp(d) : 0.) * sc, 1.0);
+        q2 += mp_quantize((double)tile_W2[b] * (ok ? mp_exp(2. * d) : 0.) * sc, 1.0);
+    }
+    q = wave_sum_u64(q);
+    q2 = wave_sum_u64(q2);
+    if (lane == 0) { s_q[wave] = q; s_q2[wave] = q2; }
+    __syncthreads();
+    if (tid == 0) {
+        u64 Q = 0, Q2 = 0;
+        for (int w = 0; w < 16; ++w) { Q += s_q[w]; Q2 += s_q2[w]; }
+        double L, ess;
+        finalize_scalars(Q, Q2, S, &L, &ess, m);
+        const int degenerate = (!ok || Q == 0) ? 1 : 0;
+        if (degenerate) mp_flag_degenerate(scal);
+        __hip_atomic_store(reinterpret_cast<u64*>(&hm->peek_L), mp_f2u(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<u64*>(&hm->peek_ess), mp_f2u(ess), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->peek_degenerate, degenerate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->peek_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -193,6 +193,19 @@ class HipShardEngine:
         capi.check(self._L.mp_pf_get_timing(self._h, family, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def region_begin(self):
+        capi.check(self._L.mp_pf_region_begin(self._h))
+
+    def region_end(self):
+        ms, n = C.c_double(), C.c_uint64()
+        capi.check(self._L.mp_pf_region_end(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_propagate_form(self):
+        out = C.c_int32()
+        capi.check(self._L.mp_pf_last_propagate_form(self._h, C.byref(out)))
+        return out.value
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.mp_pf_destroy(self._h)

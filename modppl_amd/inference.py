@@ -145,6 +145,22 @@ class ParticleSystem:
     def set_timing(self, enabled):
         capi.check(self._L.mp_pf_set_timing(self._h, int(enabled)))
 
+    def last_propagate_form(self):
+        """0 one workgroup per tile (k_propagate), 1 two tiles per workgroup (k_propagate_mt), 2 the dense d = 16 MFMA kernel; -1 before any step"""
+        out = C.c_int32()
+        capi.check(self._L.mp_pf_last_propagate_form(self._h, C.byref(out)))
+        return out.value
+
+    def region_begin(self):
+        """ONE hipEvent pair around a region of launches (un-perturbed device time): region_begin(); ...; region_end()."""
+        capi.check(self._L.mp_pf_region_begin(self._h))
+
+    def region_end(self):
+        """-> (elapsed ms on the handle's stream, k_propagate-family launches enqueued since region_begin); waits for the stream"""
+        ms, n = C.c_double(), C.c_uint64()
+        capi.check(self._L.mp_pf_region_end(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def get_timing(self, family):
         ms, n = C.c_double(), C.c_uint64()
         capi.check(self._L.mp_pf_get_timing(self._h, family, C.byref(ms), C.byref(n)))

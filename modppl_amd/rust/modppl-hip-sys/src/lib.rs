@@ -121,6 +121,9 @@ extern "C" {
     // per-kernel-family hipEvent timing (bench)
     pub fn mp_pf_set_timing(h: *mut mp_pf, enabled: i32) -> i32;
     pub fn mp_pf_get_timing(h: *mut mp_pf, family: i32, total_ms: *mut f64, launches: *mut u64) -> i32;
+    pub fn mp_pf_last_propagate_form(h: *mut mp_pf, out: *mut i32) -> i32;
+    pub fn mp_pf_region_begin(h: *mut mp_pf) -> i32;
+    pub fn mp_pf_region_end(h: *mut mp_pf, elapsed_ms: *mut f64, propagate_launches: *mut u64) -> i32;
     pub fn mp_unfold_simulate(model: *const mp_model_desc, args0: *const f64, n_steps: i32, n: u64, seed: u64, device: i32,
                               states_out: *mut f64, obs_out: *mut f64) -> i32;
     pub fn mp_importance_resampling(model: *const mp_model_desc, args0: *const f64, obs: *const f64, n_steps: i32,
