@@ -384,6 +384,42 @@ int32_t mp_mh_n_sites(mp_mh* h, int32_t* out);
  * empty mask as above), mp_mh_read_logjp, mp_mh_iterations and mp_mh_destroy apply to these handles; mp_mh_read_state and
  * mp_mh_read_observations do not. */
 int32_t mp_mh_read_trace(mp_mh* h, double* values, uint32_t* present);
+
+/* ---- The GFI operations ONE AT A TIME, batched over the chains of a registered generative function ---------------------------
+ * `GenFn::update / regenerate / propose / assess` are public in the reference (modppl/src/gfi.rs:57-90) and its tests call them
+ * directly (modppl/tests/dyngenfn.rs:55-114, 303-388); mp_mh_step / mp_regen_mh_step above fuse them into whole MH moves, the
+ * calls below expose the pieces so that a caller can compose inference moves of its own.  One call = the operation on EVERY
+ * chain of the handle (each chain's trace is the `trace` argument; args = the model's parameters).
+ *   constraints  shared by all chains: sites[n_constraints] + values[n_constraints]; or per chain: chain_values[n_chains][n_sites]
+ *                + chain_present[n_chains] (the layout of mp_mh_read_trace — what mp_fn_propose and a discard come out as), with
+ *                sites = values = NULL, n_constraints = 0
+ *   argdiff      ArgDiff::NoChange / ::Unknown (gfi.rs:94-111): under Unknown every revisited choice is re-scored
+ *   rng_step     the Philox step of whatever the call draws (free sites); 0 = the next MH iteration's, which the call then
+ *                consumes (mp_mh_iterations advances by one).  A caller composing `mh` by hand passes the same step to
+ *                propose / update / assess, as mh.rs:9-40 uses one rng for all three.
+ *   weights_out  [n_chains] (host), or NULL
+ * Errors: MP_ERR_STATE when a chain reaches a case the reference panics on (constraints nobody consumed, dyngenfn.rs:526-529). */
+enum mp_argdiff { MP_ARGDIFF_NOCHANGE = 0, MP_ARGDIFF_UNKNOWN = 1 };
+/* (new_trace, discard, weight) = model.update(trace, args, argdiff, constraints) — gfi.rs:57-64, dyngenfn.rs:536-560.  Every
+ * chain's trace is REPLACED by its new trace; the discard (previous values of the choices that were replaced or dropped) comes back
+ * as discard_values_out[n_chains][n_sites] + discard_present_out[n_chains] (either may be NULL). */
+int32_t mp_fn_update(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int32_t* sites, const double* values, int32_t n_constraints,
+                     const double* chain_values, const uint32_t* chain_present, double* weights_out, double* discard_values_out,
+                     uint32_t* discard_present_out);
+/* (new_trace, weight) = model.regenerate(trace, args, argdiff, mask) — gfi.rs:66-73, dyngenfn.rs:562-583; mask_sites = the
+ * masked sites (n_mask = 0: the trace's whole schema, :571).  Every chain's trace is replaced. */
+int32_t mp_fn_regenerate(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int32_t* mask_sites, int32_t n_mask, double* weights_out);
+/* weight = f.assess(args, constraints) = f.generate(args, constraints).1 — gfi.rs:85-90.  proposal_kind < 0: f = the model (the
+ * chains' traces play no part); otherwise f = that registered proposal applied to each chain's CURRENT trace, as in mh.rs:25-27
+ * (`proposal.assess((new_trace, args), discard)` after an update).  Traces are not modified. */
+int32_t mp_fn_assess(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, uint32_t rng_step, const int32_t* sites,
+                     const double* values, int32_t n_constraints, const double* chain_values, const uint32_t* chain_present, double* weights_out);
+/* (choices, weight) = proposal.propose((trace, args)) — gfi.rs:78-83, mh.rs:17-19: the registered proposal simulated on each
+ * chain's current trace; choice_values_out[n_chains][n_sites] + choice_present_out[n_chains], weights_out = the choices' logjp.
+ * Traces are not modified. */
+int32_t mp_fn_propose(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, uint32_t rng_step,
+                      double* choice_values_out, uint32_t* choice_present_out, double* weights_out);
+
 /* MH iterations applied so far (the Philox step of the next iteration is this + 1). */
 int32_t mp_mh_iterations(mp_mh* h, uint64_t* out);
 int32_t mp_mh_destroy(mp_mh* h);

@@ -20,6 +20,7 @@ MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER, MP_K_BIN_DRAWS = 0, 1
 MP_SITE_IS_LINEAR, MP_SITE_A, MP_SITE_B, MP_SITE_C, MP_SITE_Y0 = 0, 1, 2, 3, 4
 MP_MH_MODEL_HIERARCHICAL = 1
 MP_MH_MODEL_POINTED_2D = 2
+MP_ARGDIFF_NOCHANGE, MP_ARGDIFF_UNKNOWN = 0, 1   # gfi.rs:94-111
 MP_MH_MODEL_HIERARCHICAL_FN = 101   # the hierarchical model as a registered functor (mp_mh_create_fn)
 MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1
 MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE = 2
@@ -37,7 +38,7 @@ SYMBOLS = [
     "mp_rccl_unique_id", "mp_rccl_comm_create", "mp_rccl_comm_destroy", "mp_pf_stream_copy",
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
     "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_read_observations", "mp_mh_iterations", "mp_mh_destroy",
-    "mp_mh_create_fn", "mp_mh_n_sites", "mp_mh_read_trace",
+    "mp_mh_create_fn", "mp_mh_n_sites", "mp_mh_read_trace", "mp_fn_update", "mp_fn_regenerate", "mp_fn_assess", "mp_fn_propose",
     # include/modppl_hip_probe.h
     "mp_probe_math", "mp_probe_normal_sample", "mp_probe_u01", "mp_probe_mfma_f64", "mp_probe_mvnormal",
 ]
@@ -170,6 +171,10 @@ def load():
     L.mp_mh_create_fn.argtypes = [i32, dp, i32, C.POINTER(i32), dp, i32, u64, u64, i32, p, C.POINTER(p)]
     L.mp_mh_n_sites.argtypes = [p, C.POINTER(i32)]
     L.mp_mh_read_trace.argtypes = [p, dp, C.POINTER(u32)]
+    L.mp_fn_update.argtypes = [p, i32, u32, C.POINTER(i32), dp, i32, dp, C.POINTER(u32), dp, dp, C.POINTER(u32)]
+    L.mp_fn_regenerate.argtypes = [p, i32, u32, C.POINTER(i32), i32, dp]
+    L.mp_fn_assess.argtypes = [p, i32, dp, i32, u32, C.POINTER(i32), dp, i32, dp, C.POINTER(u32), dp]
+    L.mp_fn_propose.argtypes = [p, i32, dp, i32, u32, dp, C.POINTER(u32), dp]
     L.mp_probe_math.argtypes = [i32, dp, dp, dp, i64, dp, i32]
     L.mp_probe_normal_sample.argtypes = [u64, u32, u32, u32, u32, d, d, i64, dp, i32]
     L.mp_probe_u01.argtypes = [u64, u32, u32, u32, u32, u32, i64, dp, i32]

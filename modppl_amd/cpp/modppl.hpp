@@ -169,7 +169,11 @@ public:
         for (const auto& c : constraints) { sites.push_back(c.first); vals.push_back(c.second); }
         check(mp_mh_create_fn(model_kind, params.empty() ? nullptr : params.data(), (int32_t)params.size(), sites.empty() ? nullptr : sites.data(),
                               vals.empty() ? nullptr : vals.data(), (int32_t)sites.size(), num_chains, seed, device, stream, &h_));
-        check(mp_mh_n_sites(h_, &ns_));
+        if (mp_mh_n_sites(h_, &ns_) != MP_OK) {   // (the destructor does not run for a half-constructed object)
+            const std::string why = mp_last_error();
+            mp_mh_destroy(h_);
+            throw std::runtime_error(why);
+        }
     }
     FunctionChains(const FunctionChains&) = delete;
     ~FunctionChains() { mp_mh_destroy(h_); }
@@ -189,6 +193,51 @@ public:
         values.resize(n_ * (size_t)ns_);
         present.resize(n_);
         check(mp_mh_read_trace(h_, values.data(), present.data()));
+    }
+    // ---- GenFn::update / regenerate / assess / propose one at a time, every chain per call (gfi.rs:57-90; mp_fn_* of the C ABI) ----
+    // A per-chain table of choices: values[chain][site], present[chain] — what propose() and update()'s discard return.
+    struct Choices {
+        std::vector<double> values;
+        std::vector<uint32_t> present;
+    };
+    // shared constraints {(site, value)}; the chains' traces are replaced; -> weights (the discard into *discard when asked for)
+    std::vector<double> update(const std::vector<std::pair<int32_t, double>>& constraints, int32_t argdiff = MP_ARGDIFF_NOCHANGE, uint32_t rng_step = 0,
+                               Choices* discard = nullptr) {
+        std::vector<int32_t> sites;
+        std::vector<double> vals, w(n_);
+        for (const auto& c : constraints) { sites.push_back(c.first); vals.push_back(c.second); }
+        if (discard) { discard->values.resize(n_ * (size_t)ns_); discard->present.resize(n_); }
+        check(mp_fn_update(h_, argdiff, rng_step, sites.empty() ? nullptr : sites.data(), vals.empty() ? nullptr : vals.data(), (int32_t)sites.size(), nullptr,
+                           nullptr, w.data(), discard ? discard->values.data() : nullptr, discard ? discard->present.data() : nullptr));
+        return w;
+    }
+    // per-chain constraints (e.g. the choices of propose())
+    std::vector<double> update(const Choices& constraints, int32_t argdiff = MP_ARGDIFF_NOCHANGE, uint32_t rng_step = 0, Choices* discard = nullptr) {
+        std::vector<double> w(n_);
+        if (discard) { discard->values.resize(n_ * (size_t)ns_); discard->present.resize(n_); }
+        check(mp_fn_update(h_, argdiff, rng_step, nullptr, nullptr, 0, constraints.values.data(), constraints.present.data(), w.data(),
+                           discard ? discard->values.data() : nullptr, discard ? discard->present.data() : nullptr));
+        return w;
+    }
+    std::vector<double> regenerate(const std::vector<int32_t>& mask_sites, int32_t argdiff = MP_ARGDIFF_NOCHANGE, uint32_t rng_step = 0) {
+        std::vector<double> w(n_);
+        check(mp_fn_regenerate(h_, argdiff, rng_step, mask_sites.empty() ? nullptr : mask_sites.data(), (int32_t)mask_sites.size(), w.data()));
+        return w;
+    }
+    // proposal_kind < 0: the model's assess; otherwise the registered proposal's on each chain's current trace (mh.rs:25-27)
+    std::vector<double> assess(const Choices& constraints, int32_t proposal_kind = -1, const std::vector<double>& args = {}, uint32_t rng_step = 0) {
+        std::vector<double> w(n_);
+        check(mp_fn_assess(h_, proposal_kind, args.empty() ? nullptr : args.data(), (int32_t)args.size(), rng_step, nullptr, nullptr, 0, constraints.values.data(),
+                           constraints.present.data(), w.data()));
+        return w;
+    }
+    std::vector<double> propose(int32_t proposal_kind, const std::vector<double>& args, Choices& choices, uint32_t rng_step = 0) {
+        std::vector<double> w(n_);
+        choices.values.resize(n_ * (size_t)ns_);
+        choices.present.resize(n_);
+        check(mp_fn_propose(h_, proposal_kind, args.empty() ? nullptr : args.data(), (int32_t)args.size(), rng_step, choices.values.data(), choices.present.data(),
+                            w.data()));
+        return w;
     }
 };
 
@@ -213,6 +262,11 @@ public:
         check(mp_pf_create(&d, particles_per_rank, seed, &sh, 0, device, nullptr, &h_));
         if (!comm_ && (world > 1 || force_collectives)) {
             unsigned char id[128];
+            if (!id128 && world > 1) {
+                // (every rank would make an id of its own and wait in ncclCommInitRank for peers that never come)
+                mp_pf_destroy(h_);
+                throw std::invalid_argument("ShardedParticleSystem: a world of several ranks needs the host's communicator or the id128 rank 0 made (mp_rccl_unique_id)");
+            }
             if (!id128) { check(mp_rccl_unique_id(id)); id128 = id; }   // (a world of one: its own id)
             check(mp_rccl_comm_create(world, rank, id128, device, &comm_));
             own_comm_ = true;

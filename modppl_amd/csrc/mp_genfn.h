@@ -9,6 +9,7 @@
 // whose addresses are compile-time site ids 0 .. NS-1 (NS <= 32) and whose choices are doubles (a bool is 0 / 1):
 //     g.template normal<SITE>(mu, sd, ln_sd)     `normal(mu, sd) %= addr`    -> sample_at (dyngenfn.rs:100-273)
 //     g.template bernoulli<SITE>(p)              `bernoulli(p) %= addr`
+//     g.template uniform<SITE>(a, b)             `uniform(a, b) %= addr`
 //     g.template call<SITES>(body)               `gen_fn(args) /= addr`      -> trace_at  (dyngenfn.rs:283-449);
 //                                                SITES = bit set of the sites of the sub-trace, body = [&](H& q) { ...; return mp_fn_ret{...}; }
 //                                                What the caller needs from the sub-call travels in that RETURN VALUE, never in
@@ -79,6 +80,12 @@ struct mp_fn_bernoulli {
     double p;
     MP_HD double sample(mp_site& st) const { return mp_bernoulli_sample(st, p) ? 1. : 0.; }
     MP_HD double logpdf(double x) const { return mp_bernoulli_logpdf(x != 0., p); }
+};
+
+struct mp_fn_uniform {
+    double a, b;
+    MP_HD double sample(mp_site& st) const { return mp_uniform_sample(st, a, b); }
+    MP_HD double logpdf(double x) const { return mp_uniform_logpdf(x, a, b); }
 };
 
 enum mp_fn_mode { MP_FN_SIMULATE = 0, MP_FN_GENERATE = 1, MP_FN_UPDATE = 2, MP_FN_REGENERATE = 3 };
@@ -195,6 +202,8 @@ struct mp_fn_handler {
     MP_HD double normal(double mu, double sd) { return at<SITE>(mp_fn_normal{mu, sd, mp_log(sd)}); }
     template <int SITE>
     MP_HD bool bernoulli(double p) { return at<SITE>(mp_fn_bernoulli{p}) != 0.; }
+    template <int SITE>
+    MP_HD double uniform(double a, double b) { return at<SITE>(mp_fn_uniform{a, b}); }
 
     // previous choices of `sites` that this visit did not reach: they leave the trace; their log-densities in site order
     MP_HD double collect(uint32_t sites) {
@@ -207,6 +216,10 @@ struct mp_fn_handler {
                 if (in_sub) sw -= prev->lp[k];   // collect removes them from the (sub-)trie
             }
         discarded |= un;
+        visited |= un;   // they have left: the caller's own gc (finish, or an enclosing collect) must not take them a second time — a sub-call's
+                         // gc removes them from the SUB-trie, and the outer gc walks the outer trie only (dyngenfn.rs:453-483).  (Until round 4
+                         // update() subtracted the log-density of a choice dropped inside a sub-call twice: found by the standalone
+                         // mp_fn_update test against the trie engine; the fused mh tests only ever rejected such moves.)
         return c;
     }
 

@@ -396,6 +396,11 @@ struct mp_mh {
     std::shared_ptr<mh_fn_ops> fn;   // registered function: the trace table below replaces the fields above
     double* fvals = nullptr;         // [2 n_sites][n]: values, then the sub-tries' running weights
     uint32_t* fpresent = nullptr;    // [n]
+    // scratch of the standalone GFI calls (mp_fn_*), allocated on first use
+    double* gfi_vals = nullptr;      // [n_sites][n]: the discard of an update / the choices of a proposal
+    uint32_t* gfi_present = nullptr; // [n]
+    double* gfi_cons = nullptr;      // [n_sites][n]: per-chain constraint values
+    uint32_t* gfi_cpresent = nullptr; // [n]: per-chain constraint presence
 };
 #include "mp_mh_fn.h"
 
@@ -741,6 +746,146 @@ int32_t mp_mh_read_observations(mp_mh* h, double* out) {
     return MP_OK;
 }
 
+// ---- the GFI operations one at a time, for chains of a registered generative function (gfi.rs:57-90) -------------------------
+// constraints of one call: shared {sites, values} or a per-chain table {chain_values[n][n_sites], chain_present[n]} -> device
+struct gfi_cons {
+    mp_fn_consspec cs{};
+    const double* d_vals = nullptr;
+    const uint32_t* d_present = nullptr;
+};
+static int32_t gfi_scratch(mp_mh* h) {
+    const size_t ns = (size_t)h->fn->ns();
+    if (!h->gfi_vals) {
+        MHCK(hipMalloc(&h->gfi_vals, sizeof(double) * ns * h->n));
+        MHCK(hipMalloc(&h->gfi_present, sizeof(uint32_t) * h->n));
+        MHCK(hipMalloc(&h->gfi_cons, sizeof(double) * ns * h->n));
+        MHCK(hipMalloc(&h->gfi_cpresent, sizeof(uint32_t) * h->n));
+    }
+    return MP_OK;
+}
+static int32_t gfi_constraints(mp_mh* h, const int32_t* sites, const double* values, int32_t n_cons, const double* chain_values, const uint32_t* chain_present,
+                               gfi_cons& out) {
+    const int ns = h->fn->ns();
+    if (chain_values || chain_present) {
+        if (!chain_values || !chain_present) return mp_set_error(MP_ERR_INVALID_ARG, "per-chain constraints need both chain_values[n][n_sites] and chain_present[n]");
+        if (sites || values || n_cons) return mp_set_error(MP_ERR_INVALID_ARG, "constraints are either shared (sites, values) or per chain, not both");
+        std::vector<double> t((size_t)ns * h->n);   // [chain][site] -> [site][chain]
+        for (u64 i = 0; i < h->n; ++i) {
+            if (ns < 32 && (chain_present[i] >> ns)) return mp_set_error(MP_ERR_INVALID_ARG, "chain_present names a site the model does not have");
+            for (int k = 0; k < ns; ++k) t[(size_t)k * h->n + i] = chain_values[i * (u64)ns + k];
+        }
+        MHCK(hipMemcpyAsync(h->gfi_cons, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, h->stream));
+        MHCK(hipMemcpyAsync(h->gfi_cpresent, chain_present, sizeof(uint32_t) * h->n, hipMemcpyHostToDevice, h->stream));
+        MHCK(hipStreamSynchronize(h->stream));   // `t` is a local
+        out.d_vals = h->gfi_cons;
+        out.d_present = h->gfi_cpresent;
+        return MP_OK;
+    }
+    if (n_cons < 0 || (n_cons > 0 && (!sites || !values))) return mp_set_error(MP_ERR_INVALID_ARG, "bad constraints");
+    for (int q = 0; q < n_cons; ++q) {
+        const int sidx = sites[q];
+        if (sidx < 0 || sidx >= ns) return mp_set_error(MP_ERR_INVALID_ARG, "constraint site out of range");
+        if (out.cs.bits & (1u << sidx)) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
+        out.cs.bits |= 1u << sidx;
+        out.cs.val[sidx] = values[q];
+    }
+    return MP_OK;
+}
+static int32_t gfi_begin(mp_mh* h, uint32_t rng_step, uint32_t* step) {
+    if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
+    if (!h->fn) return mp_set_error(MP_ERR_UNSUPPORTED, "chains of a registered generative function only (mp_mh_create_fn)");
+    MHCK(hipSetDevice(h->device));
+    int32_t rc = gfi_scratch(h);
+    if (rc != MP_OK) return rc;
+    MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64) * 2, h->stream));
+    // the Philox step of what this call draws: the caller's, or the next MH iteration's (which it then consumes)
+    *step = rng_step ? rng_step : (uint32_t)(++h->iters);
+    return MP_OK;
+}
+static int32_t gfi_weights(mp_mh* h, double* weights_out) {
+    if (weights_out) MHCK(hipMemcpyAsync(weights_out, h->tmp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    return mh_finish(h, nullptr);   // (waits for the stream; chains that reached a case the reference panics on are an error)
+}
+static int32_t gfi_table(mp_mh* h, double* values_out, uint32_t* present_out) {   // the discard / the choices: [site][chain] -> [chain][site]
+    if (!values_out && !present_out) return MP_OK;
+    const int ns = h->fn->ns();
+    std::vector<double> v((size_t)ns * h->n);
+    std::vector<uint32_t> pr(h->n);
+    MHCK(hipMemcpyAsync(v.data(), h->gfi_vals, sizeof(double) * v.size(), hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipMemcpyAsync(pr.data(), h->gfi_present, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipStreamSynchronize(h->stream));
+    for (u64 i = 0; i < h->n; ++i) {
+        if (present_out) present_out[i] = pr[i];
+        if (values_out)
+            for (int k = 0; k < ns; ++k) values_out[i * (u64)ns + k] = v[(size_t)k * h->n + i];
+    }
+    return MP_OK;
+}
+
+int32_t mp_fn_update(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int32_t* sites, const double* values, int32_t n_constraints,
+                     const double* chain_values, const uint32_t* chain_present, double* weights_out, double* discard_values_out,
+                     uint32_t* discard_present_out) {
+    uint32_t step = 0;
+    int32_t rc = gfi_begin(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
+    if (argdiff != MP_ARGDIFF_NOCHANGE && argdiff != MP_ARGDIFF_UNKNOWN) return mp_set_error(MP_ERR_INVALID_ARG, "argdiff: MP_ARGDIFF_NOCHANGE or MP_ARGDIFF_UNKNOWN");
+    gfi_cons c;
+    rc = gfi_constraints(h, sites, values, n_constraints, chain_values, chain_present, c);
+    if (rc != MP_OK) return rc;
+    const bool want = discard_values_out || discard_present_out;
+    rc = h->fn->update(h, c.cs, c.d_vals, c.d_present, argdiff == MP_ARGDIFF_UNKNOWN, step, want);
+    if (rc != MP_OK) return rc;
+    rc = gfi_weights(h, weights_out);
+    if (rc != MP_OK) return rc;
+    return want ? gfi_table(h, discard_values_out, discard_present_out) : MP_OK;
+}
+
+int32_t mp_fn_regenerate(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int32_t* mask_sites, int32_t n_mask, double* weights_out) {
+    uint32_t step = 0;
+    int32_t rc = gfi_begin(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
+    if (argdiff != MP_ARGDIFF_NOCHANGE && argdiff != MP_ARGDIFF_UNKNOWN) return mp_set_error(MP_ERR_INVALID_ARG, "argdiff: MP_ARGDIFF_NOCHANGE or MP_ARGDIFF_UNKNOWN");
+    if (n_mask < 0 || (n_mask > 0 && !mask_sites)) return mp_set_error(MP_ERR_INVALID_ARG, "bad mask");
+    uint32_t bits = 0;
+    for (int q = 0; q < n_mask; ++q) {
+        if (mask_sites[q] < 0 || mask_sites[q] >= h->fn->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "mask site out of range");
+        bits |= 1u << mask_sites[q];
+    }
+    rc = h->fn->regenerate(h, bits, argdiff == MP_ARGDIFF_UNKNOWN, step);
+    if (rc != MP_OK) return rc;
+    return gfi_weights(h, weights_out);
+}
+
+int32_t mp_fn_assess(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, uint32_t rng_step, const int32_t* sites,
+                     const double* values, int32_t n_constraints, const double* chain_values, const uint32_t* chain_present, double* weights_out) {
+    uint32_t step = 0;
+    int32_t rc = gfi_begin(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
+    gfi_cons c;
+    rc = gfi_constraints(h, sites, values, n_constraints, chain_values, chain_present, c);
+    if (rc != MP_OK) return rc;
+    if (proposal_kind < 0) rc = h->fn->assess(h, c.cs, c.d_vals, c.d_present, step);
+    else {
+        if (n_proposal_args < 0 || (n_proposal_args > 0 && !proposal_args)) return mp_set_error(MP_ERR_INVALID_ARG, "bad proposal_args");
+        rc = h->fn->assess_proposal(h, proposal_kind, proposal_args, n_proposal_args, c.cs, c.d_vals, c.d_present, step);
+    }
+    if (rc != MP_OK) return rc;
+    return gfi_weights(h, weights_out);
+}
+
+int32_t mp_fn_propose(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, uint32_t rng_step,
+                      double* choice_values_out, uint32_t* choice_present_out, double* weights_out) {
+    uint32_t step = 0;
+    int32_t rc = gfi_begin(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
+    if (n_proposal_args < 0 || (n_proposal_args > 0 && !proposal_args)) return mp_set_error(MP_ERR_INVALID_ARG, "bad proposal_args");
+    rc = h->fn->propose(h, proposal_kind, proposal_args, n_proposal_args, step);
+    if (rc != MP_OK) return rc;
+    rc = gfi_weights(h, weights_out);
+    if (rc != MP_OK) return rc;
+    return gfi_table(h, choice_values_out, choice_present_out);
+}
+
 int32_t mp_mh_iterations(mp_mh* h, uint64_t* out) {
     if (!h || !out) return mp_set_error(MP_ERR_INVALID_ARG, "null argument");
     *out = h->iters;
@@ -753,6 +898,7 @@ int32_t mp_mh_destroy(mp_mh* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->is_lin); (void)hipFree(h->a); (void)hipFree(h->b); (void)hipFree(h->c); (void)hipFree(h->tmp); (void)hipFree(h->d_acc);
     (void)hipFree(h->lat); (void)hipFree(h->ys_chain); (void)hipFree(h->fvals); (void)hipFree(h->fpresent);
+    (void)hipFree(h->gfi_vals); (void)hipFree(h->gfi_present); (void)hipFree(h->gfi_cons); (void)hipFree(h->gfi_cpresent);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;

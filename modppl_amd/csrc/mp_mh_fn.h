@@ -175,6 +175,139 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_mh(u64 n, uint32_t k0, uint32
 }
 
 // ---------------------------------------------------------------------------------------
+// The GFI operations ONE AT A TIME (gfi.rs:57-90: update / regenerate / assess / propose), for callers that compose their own
+// inference moves: what k_fn_mh / k_fn_regen fuse, exposed per call (include/modppl_hip.h mp_fn_*).  Every chain, one launch.
+// Constraints: shared by every chain (cs.bits, cs.val) or per chain (a table cvals[site][chain] + cpresent[chain]).  `step` is the
+// Philox step of whatever the call draws.
+// ---------------------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void fn_cons(const mp_fn_consspec& cs, const double* __restrict__ cvals, const uint32_t* __restrict__ cpresent, u64 i, u64 n,
+                                        mp_fn_trace<NS>& c) {
+    // shared: the sites cs.bits with the values cs.val; per chain: the table cvals[site][chain] + cpresent[chain] (what fn_emit writes:
+    // the choices of a propose, the discard of an update — a proposal's choices differ in their SITES from chain to chain)
+    c.present = cpresent ? cpresent[i] : cs.bits;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const bool on = (c.present >> k) & 1u;
+        c.val[k] = on ? (cvals ? cvals[(u64)k * n + i] : cs.val[k]) : 0.;
+        c.lp[k] = 0.;
+        c.subw[k] = 0.;
+    }
+}
+template <int NS>
+__device__ __forceinline__ void fn_emit(const mp_fn_trace<NS>& t, uint32_t bits, u64 i, u64 n, double* __restrict__ vals, uint32_t* __restrict__ present) {
+    present[i] = bits;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) vals[(u64)k * n + i] = ((bits >> k) & 1u) ? t.val[k] : 0.;
+}
+// (new_trace, discard, weight) = model.update(trace, args, diff, constraints)   gfi.rs:57-64, dyngenfn.rs:536-560; the trace is replaced
+template <class M>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_update(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, mp_fn_consspec cs,
+                                                          const double* __restrict__ cvals, const uint32_t* __restrict__ cpresent, int unknown, double* __restrict__ vals,
+                                                          uint32_t* __restrict__ present, double* __restrict__ w_out, double* __restrict__ dvals,
+                                                          uint32_t* __restrict__ dpresent, u64* __restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    bool panic = false;
+    if (i < n) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
+        mp_fn_trace<M::NS> cur, c;
+        fn_load(model, s, i, n, vals, present, cur);
+        fn_cons<M::NS>(cs, cvals, cpresent, i, n, c);
+        mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &cur, &c);
+        g.changed = unknown != 0;   // ArgDiff::Unknown: every revisited choice is re-scored (dyngenfn.rs:180-190)
+        model(g);
+        g.finish();
+        panic = g.panic;
+        fn_store<M>(g.tr, i, n, vals, present);
+        w_out[i] = g.weight;
+        if (dvals) fn_emit<M::NS>(cur, g.discarded, i, n, dvals, dpresent);   // the discard: the previous values of what was replaced or collected
+    }
+    fn_count(0, panic, totals);
+}
+// (new_trace, weight) = model.regenerate(trace, args, diff, mask)   gfi.rs:66-73, dyngenfn.rs:562-583; the trace is replaced
+template <class M>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_regenerate(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, uint32_t mask, int unknown,
+                                                              double* __restrict__ vals, uint32_t* __restrict__ present, double* __restrict__ w_out,
+                                                              u64* __restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    bool panic = false;
+    if (i < n) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
+        mp_fn_trace<M::NS> cur;
+        fn_load(model, s, i, n, vals, present, cur);
+        const uint32_t m = mask ? mask : cur.present;   // mask.is_leaf(): the whole schema (dyngenfn.rs:571)
+        mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
+        g.changed = unknown != 0;
+        model(g);
+        g.finish();
+        panic = g.panic;
+        fn_store<M>(g.tr, i, n, vals, present);
+        w_out[i] = g.weight;
+    }
+    fn_count(0, panic, totals);
+}
+// weight = model.assess(args, constraints) = generate(args, constraints).1   gfi.rs:85-90; the chains' traces are not touched
+template <class M>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_assess(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, mp_fn_consspec cs,
+                                                          const double* __restrict__ cvals, const uint32_t* __restrict__ cpresent, double* __restrict__ w_out,
+                                                          u64* __restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    bool panic = false;
+    if (i < n) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
+        mp_fn_trace<M::NS> c;
+        fn_cons<M::NS>(cs, cvals, cpresent, i, n, c);
+        mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+        model(g);
+        g.finish();
+        panic = g.panic;
+        w_out[i] = g.weight;
+    }
+    fn_count(0, panic, totals);
+}
+// (choices, weight) = proposal.propose((trace, args)) = simulate -> (data, logjp)   gfi.rs:78-83, mh.rs:17-19
+template <class M, class P>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_propose(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, P proposal,
+                                                           const double* __restrict__ vals, const uint32_t* __restrict__ present,
+                                                           double* __restrict__ w_out, double* __restrict__ cvals_out, uint32_t* __restrict__ cpresent_out) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    mp_stream s;
+    s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
+    mp_fn_trace<M::NS> cur;
+    fn_load(model, s, i, n, vals, present, cur);
+    mp_fn_handler<M::NS, MP_FN_SIMULATE> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
+    proposal(p, cur);
+    w_out[i] = p.weight;
+    fn_emit<M::NS>(p.tr, p.tr.present, i, n, cvals_out, cpresent_out);
+}
+// weight = proposal.assess((trace, args), constraints)   mh.rs:25-27 (the backward weight: constraints = the discard of an update)
+template <class M, class P>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_assess_proposal(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, P proposal, mp_fn_consspec cs,
+                                                                   const double* __restrict__ cvals, const uint32_t* __restrict__ cpresent,
+                                                                   const double* __restrict__ vals, const uint32_t* __restrict__ present,
+                                                                   double* __restrict__ w_out, u64* __restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    bool panic = false;
+    if (i < n) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
+        mp_fn_trace<M::NS> cur, c;
+        fn_load(model, s, i, n, vals, present, cur);
+        fn_cons<M::NS>(cs, cvals, cpresent, i, n, c);
+        mp_fn_handler<M::NS, MP_FN_GENERATE> q(s, MP_DOM_PROPOSAL, nullptr, &c);
+        proposal(q, cur);
+        q.finish();
+        panic = q.panic;
+        w_out[i] = q.weight;
+    }
+    fn_count(0, panic, totals);
+}
+
+// ---------------------------------------------------------------------------------------
 // registry: model kind -> factory; (model type, proposal kind) -> launcher
 // ---------------------------------------------------------------------------------------
 struct mh_fn_ops {
@@ -184,11 +317,22 @@ struct mh_fn_ops {
     virtual int32_t regen(mp_mh* h, const mp_fn_maskspec& m, int n_iters) = 0;
     virtual int32_t mh(mp_mh* h, int proposal_kind, const double* args, int n_args, int n_iters) = 0;
     virtual int32_t logjp(mp_mh* h) = 0;
+    // the GFI operations one at a time (mp_fn_*): weights into h->tmp, discard / choices into h->gfi_vals / h->gfi_present
+    virtual int32_t update(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, int unknown, uint32_t step, bool want_discard) = 0;
+    virtual int32_t regenerate(mp_mh* h, uint32_t mask, int unknown, uint32_t step) = 0;
+    virtual int32_t assess(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, uint32_t step) = 0;
+    virtual int32_t propose(mp_mh* h, int proposal_kind, const double* args, int n_args, uint32_t step) = 0;
+    virtual int32_t assess_proposal(mp_mh* h, int proposal_kind, const double* args, int n_args, const mp_fn_consspec& cs, const double* d_cvals,
+                                    const uint32_t* d_cpresent, uint32_t step) = 0;
 };
 static inline unsigned fn_grid(const mp_mh* h) { return (unsigned)((h->n + MH_THREADS - 1) / MH_THREADS); }
 
 template <class M>
-using mh_fn_launcher = std::function<int32_t(mp_mh*, const M&, const double*, int, int)>;
+struct mh_fn_launcher {   // what a registered proposal can be launched as
+    std::function<int32_t(mp_mh*, const M&, const double*, int, int)> mh;   // (args, n_args, n_iters)
+    std::function<int32_t(mp_mh*, const M&, const double*, int, uint32_t)> propose;   // (args, n_args, step)
+    std::function<int32_t(mp_mh*, const M&, const double*, int, const mp_fn_consspec&, const double*, const uint32_t*, uint32_t)> assess;
+};
 template <class M>
 static std::map<int, mh_fn_launcher<M>>& mh_fn_proposals() {
     static std::map<int, mh_fn_launcher<M>> r;
@@ -214,7 +358,39 @@ struct mh_fn_ops_t : mh_fn_ops {
         auto& reg = mh_fn_proposals<M>();
         auto it = reg.find(proposal_kind);
         if (it == reg.end()) return mp_set_error(MP_ERR_UNSUPPORTED, "no proposal of this kind is registered for the model (MP_REGISTER_MH_PROPOSAL)");
-        return it->second(h, model, args, n_args, n_iters);
+        return it->second.mh(h, model, args, n_args, n_iters);
+    }
+    int32_t update(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, int unknown, uint32_t step, bool want_discard) override {
+        hipLaunchKernelGGL(k_fn_update<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), step, model, cs,
+                           d_cvals, d_cpresent, unknown, h->fvals, h->fpresent, h->tmp, want_discard ? h->gfi_vals : (double*)nullptr,
+                           want_discard ? h->gfi_present : (uint32_t*)nullptr, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    }
+    int32_t regenerate(mp_mh* h, uint32_t mask, int unknown, uint32_t step) override {
+        hipLaunchKernelGGL(k_fn_regenerate<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), step, model,
+                           mask, unknown, h->fvals, h->fpresent, h->tmp, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    }
+    int32_t assess(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, uint32_t step) override {
+        hipLaunchKernelGGL(k_fn_assess<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), step, model, cs,
+                           d_cvals, d_cpresent, h->tmp, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    }
+    int32_t propose(mp_mh* h, int proposal_kind, const double* args, int n_args, uint32_t step) override {
+        auto& reg = mh_fn_proposals<M>();
+        auto it = reg.find(proposal_kind);
+        if (it == reg.end()) return mp_set_error(MP_ERR_UNSUPPORTED, "no proposal of this kind is registered for the model (MP_REGISTER_MH_PROPOSAL)");
+        return it->second.propose(h, model, args, n_args, step);
+    }
+    int32_t assess_proposal(mp_mh* h, int proposal_kind, const double* args, int n_args, const mp_fn_consspec& cs, const double* d_cvals,
+                            const uint32_t* d_cpresent, uint32_t step) override {
+        auto& reg = mh_fn_proposals<M>();
+        auto it = reg.find(proposal_kind);
+        if (it == reg.end()) return mp_set_error(MP_ERR_UNSUPPORTED, "no proposal of this kind is registered for the model (MP_REGISTER_MH_PROPOSAL)");
+        return it->second.assess(h, model, args, n_args, cs, d_cvals, d_cpresent, step);
     }
     int32_t logjp(mp_mh* h) override {
         hipLaunchKernelGGL(k_fn_logjp<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, model, (const double*)h->fvals,
@@ -242,7 +418,8 @@ static int mp_mh_register_model(int kind, bool (*parse)(const double*, int, M&, 
 template <class M, class P>
 static int mp_mh_register_proposal(int kind, bool (*parse)(const double*, int, P&, std::string&)) {
     static_assert(std::is_trivially_copyable<P>::value, "a proposal functor travels to the kernels by value");
-    mh_fn_proposals<M>()[kind] = [parse](mp_mh* h, const M& model, const double* args, int n_args, int n_iters) -> int32_t {
+    mh_fn_launcher<M> L;
+    L.mh = [parse](mp_mh* h, const M& model, const double* args, int n_args, int n_iters) -> int32_t {
         P prop;
         std::string err;
         if (!parse(args, n_args, prop, err)) return mp_set_error(MP_ERR_INVALID_ARG, err);
@@ -251,6 +428,26 @@ static int mp_mh_register_proposal(int kind, bool (*parse)(const double*, int, P
         MHCK(hipGetLastError());
         return MP_OK;
     };
+    L.propose = [parse](mp_mh* h, const M& model, const double* args, int n_args, uint32_t step) -> int32_t {
+        P prop;
+        std::string err;
+        if (!parse(args, n_args, prop, err)) return mp_set_error(MP_ERR_INVALID_ARG, err);
+        hipLaunchKernelGGL((k_fn_propose<M, P>), dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), step,
+                           model, prop, (const double*)h->fvals, (const uint32_t*)h->fpresent, h->tmp, h->gfi_vals, h->gfi_present);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    };
+    L.assess = [parse](mp_mh* h, const M& model, const double* args, int n_args, const mp_fn_consspec& cs, const double* d_cvals,
+                       const uint32_t* d_cpresent, uint32_t step) -> int32_t {
+        P prop;
+        std::string err;
+        if (!parse(args, n_args, prop, err)) return mp_set_error(MP_ERR_INVALID_ARG, err);
+        hipLaunchKernelGGL((k_fn_assess_proposal<M, P>), dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
+                           step, model, prop, cs, d_cvals, d_cpresent, (const double*)h->fvals, (const uint32_t*)h->fpresent, h->tmp, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    };
+    mh_fn_proposals<M>()[kind] = L;
     return kind;
 }
 #define MP_REGISTER_MH_MODEL(KIND, TYPE, PARSE) static const int mp_mh_registered_##TYPE = mp_mh_register_model<TYPE>(KIND, PARSE);

@@ -262,3 +262,64 @@ inline bool mp_parse_scaled_line_drift_fn(const double* args, int n_args, mp_sca
     return true;
 }
 MP_REGISTER_MH_PROPOSAL(2, mp_scaled_line_fn, mp_scaled_line_drift_fn, mp_parse_scaled_line_drift_fn)
+
+// ---------------------------------------------------------------------------------------
+// The reference's own Update regression functions (modppl/tests/dyngenfn.rs:30-53), kinds 110 - 112: what its known-answer
+// tests for `update` run (:55-114: -0.5, -2.517551, 0.4, -1.098612 twice) — here so that the same calls can be made on the
+// device through mp_fn_update (tests/test_gpu_gfi.py).  No params, no proposals.
+//   110  b ~ bernoulli(0.25) %= "b"; if b { normal(0, 1) %= "x" }
+//   111  m ~ uniform(0, 1) %= "m"; normal(m, 1) %= "x"; normal(m, 1) %= "y"
+//   112  b ~ bernoulli(0.25) %= "b"; if b { prototype(1.0) /= "sub" }   with prototype = normal(1, noise) at three addresses (the
+//        reference's has 2999: the sub-call is new and unconstrained in the test, so its size does not enter the weight)
+// ---------------------------------------------------------------------------------------
+struct mp_kat_bx_fn {
+    static constexpr int NS = 2;
+    enum { B = 0, X = 1 };
+    static constexpr uint32_t sub_of(int) { return 0u; }
+    static constexpr bool is_bool(int site) { return site == B; }
+    int unused;
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        if (g.template bernoulli<B>(0.25)) g.template normal<X>(0., 1., 0.);
+    }
+};
+struct mp_kat_mxy_fn {
+    static constexpr int NS = 3;
+    enum { M = 0, X = 1, Y = 2 };
+    static constexpr uint32_t sub_of(int) { return 0u; }
+    static constexpr bool is_bool(int) { return false; }
+    int unused;
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        const double m = g.template uniform<M>(0., 1.);
+        g.template normal<X>(m, 1., 0.);
+        g.template normal<Y>(m, 1., 0.);
+    }
+};
+struct mp_kat_bsub_fn {
+    static constexpr int NS = 4;
+    enum { B = 0, S1 = 1, S2 = 2, S3 = 3 };
+    static constexpr uint32_t SUB = (1u << S1) | (1u << S2) | (1u << S3);
+    static constexpr uint32_t sub_of(int site) { return site >= S1 ? SUB : 0u; }
+    static constexpr bool is_bool(int site) { return site == B; }
+    int unused;
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        if (g.template bernoulli<B>(0.25)) {
+            (void)g.template call<SUB>([&](H& q) {
+                mp_fn_ret r{};
+                r.v[0] = q.template normal<S1>(1., 1., 0.) + q.template normal<S2>(1., 1., 0.) + q.template normal<S3>(1., 1., 0.);
+                return r;
+            });
+        }
+    }
+};
+template <class M>
+inline bool mp_parse_kat_fn(const double*, int n_params, M& m, std::string& err) {
+    if (n_params != 0) { err = "the reference's regression functions take no parameters"; return false; }
+    m.unused = 0;
+    return true;
+}
+MP_REGISTER_MH_MODEL(110, mp_kat_bx_fn, mp_parse_kat_fn<mp_kat_bx_fn>)
+MP_REGISTER_MH_MODEL(111, mp_kat_mxy_fn, mp_parse_kat_fn<mp_kat_mxy_fn>)
+MP_REGISTER_MH_MODEL(112, mp_kat_bsub_fn, mp_parse_kat_fn<mp_kat_bsub_fn>)

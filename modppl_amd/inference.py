@@ -373,6 +373,60 @@ class FunctionChains:
         capi.check(self._L.mp_mh_read_trace(self._h, _dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint32))))
         return vals, present
 
+    # ---- the GFI operations one at a time (modppl/src/gfi.rs:57-90), every chain per call ------------------------------------
+    # constraints: {site: value} shared by all chains, or a (values [num_chains, num_sites], present [num_chains]) pair per chain
+    # (what propose() and update()'s discard return).  rng_step = 0: the next MH iteration's Philox step, which the call consumes.
+    def _constraints(self, constraints):
+        none_i, none_d, none_u = None, None, None
+        if isinstance(constraints, dict):
+            sites = np.array(sorted(constraints), dtype=np.int32)
+            vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
+            keep = (sites, vals)
+            return keep, (sites.ctypes.data_as(C.POINTER(C.c_int32)) if sites.size else none_i, _dptr(vals) if sites.size else none_d, int(sites.size), none_d, none_u)
+        cv, cp = constraints
+        cv = np.ascontiguousarray(cv, dtype=np.float64).reshape(self.num_chains, self.num_sites)
+        cp = np.ascontiguousarray(cp, dtype=np.uint32).reshape(self.num_chains)
+        return (cv, cp), (none_i, none_d, 0, _dptr(cv), cp.ctypes.data_as(C.POINTER(C.c_uint32)))
+
+    def update(self, constraints, argdiff=capi.MP_ARGDIFF_NOCHANGE, rng_step=0, want_discard=True):
+        """(new_trace, discard, weight) = model.update(trace, args, argdiff, constraints) on every chain (gfi.rs:57-64); the chains'
+        traces are replaced.  -> (weights [num_chains], (discard_values, discard_present) or None)"""
+        keep, c = self._constraints(constraints)
+        w = np.empty(self.num_chains)
+        dv = np.empty((self.num_chains, self.num_sites)) if want_discard else None
+        dp_ = np.empty(self.num_chains, dtype=np.uint32) if want_discard else None
+        capi.check(self._L.mp_fn_update(self._h, int(argdiff), int(rng_step), c[0], c[1], c[2], c[3], c[4], _dptr(w), _dptr(dv) if want_discard else None,
+                                        dp_.ctypes.data_as(C.POINTER(C.c_uint32)) if want_discard else None))
+        return w, ((dv, dp_) if want_discard else None)
+
+    def regenerate(self, mask, argdiff=capi.MP_ARGDIFF_NOCHANGE, rng_step=0):
+        """(new_trace, weight) = model.regenerate(trace, args, argdiff, mask) on every chain (gfi.rs:66-73); -> weights"""
+        sites = [int(m) for m in mask]
+        m = (C.c_int32 * max(len(sites), 1))(*sites)
+        w = np.empty(self.num_chains)
+        capi.check(self._L.mp_fn_regenerate(self._h, int(argdiff), int(rng_step), m if sites else None, len(sites), _dptr(w)))
+        return w
+
+    def assess(self, constraints, proposal_kind=-1, proposal_args=(), rng_step=0):
+        """weight = f.assess(args, constraints) (gfi.rs:85-90): f = the model (proposal_kind < 0) or a registered proposal applied to
+        each chain's current trace (mh.rs:25-27); -> weights.  Traces are not modified."""
+        keep, c = self._constraints(constraints)
+        a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
+        w = np.empty(self.num_chains)
+        capi.check(self._L.mp_fn_assess(self._h, int(proposal_kind), _dptr(a) if a.size else None, int(a.size), int(rng_step), c[0], c[1], c[2], c[3], c[4], _dptr(w)))
+        return w
+
+    def propose(self, proposal_kind, proposal_args=(), rng_step=0):
+        """(choices, weight) = proposal.propose((trace, args)) on every chain (gfi.rs:78-83, mh.rs:17-19);
+        -> ((choice_values, choice_present), weights).  Traces are not modified."""
+        a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
+        cv = np.empty((self.num_chains, self.num_sites))
+        cp = np.empty(self.num_chains, dtype=np.uint32)
+        w = np.empty(self.num_chains)
+        capi.check(self._L.mp_fn_propose(self._h, int(proposal_kind), _dptr(a) if a.size else None, int(a.size), int(rng_step), _dptr(cv),
+                                         cp.ctypes.data_as(C.POINTER(C.c_uint32)), _dptr(w)))
+        return (cv, cp), w
+
     def logjp(self):
         out = np.empty(self.num_chains)
         capi.check(self._L.mp_mh_read_logjp(self._h, _dptr(out)))

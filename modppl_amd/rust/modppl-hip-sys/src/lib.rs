@@ -145,6 +145,14 @@ extern "C" {
                            n_constraints: i32, n_chains: u64, seed: u64, device: i32, stream: *mut c_void, out: *mut *mut mp_mh) -> i32;
     pub fn mp_mh_n_sites(h: *mut mp_mh, out: *mut i32) -> i32;
     pub fn mp_mh_read_trace(h: *mut mp_mh, values: *mut f64, present: *mut u32) -> i32;
+    pub fn mp_fn_update(h: *mut mp_mh, argdiff: i32, rng_step: u32, sites: *const i32, values: *const f64, n_constraints: i32,
+                        chain_values: *const f64, chain_present: *const u32, weights_out: *mut f64, discard_values_out: *mut f64,
+                        discard_present_out: *mut u32) -> i32;
+    pub fn mp_fn_regenerate(h: *mut mp_mh, argdiff: i32, rng_step: u32, mask_sites: *const i32, n_mask: i32, weights_out: *mut f64) -> i32;
+    pub fn mp_fn_assess(h: *mut mp_mh, proposal_kind: i32, proposal_args: *const f64, n_proposal_args: i32, rng_step: u32, sites: *const i32,
+                        values: *const f64, n_constraints: i32, chain_values: *const f64, chain_present: *const u32, weights_out: *mut f64) -> i32;
+    pub fn mp_fn_propose(h: *mut mp_mh, proposal_kind: i32, proposal_args: *const f64, n_proposal_args: i32, rng_step: u32,
+                         choice_values_out: *mut f64, choice_present_out: *mut u32, weights_out: *mut f64) -> i32;
     pub fn mp_mh_iterations(h: *mut mp_mh, out: *mut u64) -> i32;
     pub fn mp_mh_destroy(h: *mut mp_mh) -> i32;
 }

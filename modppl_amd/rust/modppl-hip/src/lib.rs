@@ -221,6 +221,41 @@ impl FunctionChains {
         check(unsafe { sys::mp_mh_read_trace(self.h, v.as_mut_ptr(), p.as_mut_ptr()) });
         (v, p)
     }
+    // ---- `GenFn::update / regenerate / assess / propose` (gfi.rs:57-90) one at a time, every chain per call ----
+    /// `(new_trace, discard, weight) = model.update(trace, args, diff, constraints)` with per-chain constraints
+    /// `(values[chain][site], present[chain])`; the chains' traces are replaced.  -> (weights, discard)
+    pub fn update(&mut self, constraints: &(Vec<f64>, Vec<u32>), diff: &ArgDiff, rng_step: u32) -> (Vec<f64>, (Vec<f64>, Vec<u32>)) {
+        let mut w = vec![0.0; self.n_chains];
+        let mut dv = vec![0.0; self.n_chains * self.n_sites];
+        let mut dp = vec![0u32; self.n_chains];
+        let d = match diff { ArgDiff::NoChange => 0, ArgDiff::Unknown => 1, ArgDiff::Extend => panic!("a DynGenFn's update takes NoChange or Unknown") };
+        check(unsafe { sys::mp_fn_update(self.h, d, rng_step, ptr::null(), ptr::null(), 0, constraints.0.as_ptr(), constraints.1.as_ptr(), w.as_mut_ptr(),
+                                         dv.as_mut_ptr(), dp.as_mut_ptr()) });
+        (w, (dv, dp))
+    }
+    /// `(new_trace, weight) = model.regenerate(trace, args, diff, mask)`; an empty mask is the trace's whole schema
+    pub fn regenerate(&mut self, mask: &[i32], diff: &ArgDiff, rng_step: u32) -> Vec<f64> {
+        let mut w = vec![0.0; self.n_chains];
+        let d = match diff { ArgDiff::NoChange => 0, ArgDiff::Unknown => 1, ArgDiff::Extend => panic!("a DynGenFn's regenerate takes NoChange or Unknown") };
+        check(unsafe { sys::mp_fn_regenerate(self.h, d, rng_step, mask.as_ptr(), mask.len() as i32, w.as_mut_ptr()) });
+        w
+    }
+    /// `weight = f.assess(args, constraints)`: `proposal = None` -> the model; `Some((kind, args))` -> that proposal on each chain's trace
+    pub fn assess(&mut self, constraints: &(Vec<f64>, Vec<u32>), proposal: Option<(i32, &[f64])>, rng_step: u32) -> Vec<f64> {
+        let mut w = vec![0.0; self.n_chains];
+        let (kind, args): (i32, &[f64]) = proposal.unwrap_or((-1, &[]));
+        check(unsafe { sys::mp_fn_assess(self.h, kind, args.as_ptr(), args.len() as i32, rng_step, ptr::null(), ptr::null(), 0, constraints.0.as_ptr(),
+                                         constraints.1.as_ptr(), w.as_mut_ptr()) });
+        w
+    }
+    /// `(choices, weight) = proposal.propose((trace, args))`
+    pub fn propose(&mut self, proposal_kind: i32, args: &[f64], rng_step: u32) -> ((Vec<f64>, Vec<u32>), Vec<f64>) {
+        let mut w = vec![0.0; self.n_chains];
+        let mut cv = vec![0.0; self.n_chains * self.n_sites];
+        let mut cp = vec![0u32; self.n_chains];
+        check(unsafe { sys::mp_fn_propose(self.h, proposal_kind, args.as_ptr(), args.len() as i32, rng_step, cv.as_mut_ptr(), cp.as_mut_ptr(), w.as_mut_ptr()) });
+        ((cv, cp), w)
+    }
 }
 
 impl Drop for FunctionChains {
@@ -258,6 +293,14 @@ impl ShardedParticleSystem {
     /// asynchronous: nothing is waited for but one polled word
     pub fn resample_async(&mut self, scheme: i32) {
         check(unsafe { sys::mp_pf_shard_resample_rccl(self.h, self.comm, self.world, self.rank, scheme, 0, ptr::null_mut()) });
+    }
+    /// `log_marginal_likelihood_estimate` of the whole job (one small all-gather of the ranks' tile scalars)
+    pub fn log_marginal_likelihood_estimate(&mut self) -> f64 {
+        let mut t = sys::mp_transport { ctx: ptr::null_mut(), all_gather: None, all_to_all: None };
+        let (mut lml, mut ess) = (0.0, 0.0);
+        if !self.comm.is_null() { check(unsafe { sys::mp_transport_rccl(self.comm, &mut t) }); }
+        check(unsafe { sys::mp_pf_shard_query_native(self.h, if self.comm.is_null() { ptr::null() } else { &t }, self.world, 0, &mut lml, &mut ess) });
+        lml
     }
     /// this rank's slots (offspring stay on the rank that owns their parent: slot numbers carry no meaning across ranks)
     pub fn states(&self) -> Vec<f64> {

@@ -562,6 +562,79 @@ int32_t oracle_mhfn_regen(oracle_mhfn* h, const int32_t* mask_sites, int32_t n_m
         if (accepted) *accepted = acc;
     })
 }
+// ---- the GFI operations one at a time (gfi.rs:57-90), chain by chain through the dynamic machinery: the checker of mp_fn_* ----
+static DynTrie mhfn_chain_constraints(oracle_mhfn* h, const int32_t* sites, const double* vals, int32_t n_cons, const double* chain_values,
+                                      const uint32_t* chain_present, size_t i) {
+    if (!chain_values) return h->m->constraints(sites, vals, n_cons);
+    const int ns = h->m->ns();
+    std::vector<int32_t> s2;
+    std::vector<double> v2;
+    for (int k = 0; k < ns; ++k)
+        if ((chain_present[i] >> k) & 1u) { s2.push_back(k); v2.push_back(chain_values[i * (size_t)ns + k]); }
+    return h->m->constraints(s2.data(), v2.data(), (int)s2.size());
+}
+static uint32_t mhfn_step(oracle_mhfn* h, uint32_t rng_step) { return rng_step ? rng_step : (uint32_t)(++h->iters); }
+int32_t oracle_mhfn_update(oracle_mhfn* h, int32_t argdiff, uint32_t rng_step, const int32_t* sites, const double* vals, int32_t n_cons,
+                           const double* chain_values, const uint32_t* chain_present, double* weights, double* discard_values, uint32_t* discard_present) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        const uint32_t step = mhfn_step(h, rng_step);
+        const int ns = h->m->ns();
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = step;
+            auto [tr, discard, w] = h->m->model().update(r, std::move(h->traces[i]), 0, argdiff ? ArgDiff::Unknown : ArgDiff::NoChange,
+                                                        mhfn_chain_constraints(h, sites, vals, n_cons, chain_values, chain_present, i));
+            h->traces[i] = std::move(tr);
+            if (weights) weights[i] = w;
+            if (discard_values && discard_present) h->m->view(discard, discard_values + i * (size_t)ns, discard_present + i);
+        }
+    })
+}
+int32_t oracle_mhfn_regenerate(oracle_mhfn* h, int32_t argdiff, uint32_t rng_step, const int32_t* mask_sites, int32_t n_mask, double* weights) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        const uint32_t step = mhfn_step(h, rng_step);
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            AddrMap mask;
+            for (int q = 0; q < n_mask; ++q) mask.visit(h->m->flat_addr(mask_sites[q]));
+            Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = step;
+            auto [tr, w] = h->m->model().regenerate(r, std::move(h->traces[i]), 0, argdiff ? ArgDiff::Unknown : ArgDiff::NoChange, mask);
+            h->traces[i] = std::move(tr);
+            if (weights) weights[i] = w;
+        }
+    })
+}
+int32_t oracle_mhfn_assess(oracle_mhfn* h, int32_t proposal_kind, const double* args, int32_t n_args, uint32_t rng_step, const int32_t* sites,
+                           const double* vals, int32_t n_cons, const double* chain_values, const uint32_t* chain_present, double* weights) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        const uint32_t step = mhfn_step(h, rng_step);
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = step;
+            DynTrie c = mhfn_chain_constraints(h, sites, vals, n_cons, chain_values, chain_present, i);
+            if (proposal_kind < 0) weights[i] = h->m->model().assess(r, 0, std::move(c));
+            else {
+                const MhFnProposal proposal = h->m->proposal(proposal_kind, args, n_args);
+                weights[i] = proposal.assess(r, {&h->traces[i], 0}, std::move(c));
+            }
+        }
+    })
+}
+int32_t oracle_mhfn_propose(oracle_mhfn* h, int32_t proposal_kind, const double* args, int32_t n_args, uint32_t rng_step, double* choice_values,
+                            uint32_t* choice_present, double* weights) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        const uint32_t step = mhfn_step(h, rng_step);
+        const int ns = h->m->ns();
+        const MhFnProposal proposal = h->m->proposal(proposal_kind, args, n_args);
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = step;
+            auto [choices, w] = proposal.propose(r, {&h->traces[i], 0});
+            if (weights) weights[i] = w;
+            h->m->view(choices, choice_values + i * (size_t)ns, choice_present + i);
+        }
+    })
+}
 int32_t oracle_mhfn_read_trace(oracle_mhfn* h, double* values, uint32_t* present) {
     GUARD({
         const int ns = h->m->ns();
@@ -590,6 +663,10 @@ int32_t oracle_mhfn_static_step(oracle_mhfn_static* h, int32_t proposal_kind, co
 }
 int32_t oracle_mhfn_static_regen(oracle_mhfn_static* h, const int32_t* mask_sites, int32_t n_mask, int32_t cycle, int32_t n_iters, uint64_t* accepted) {
     GUARD({ const uint64_t a = h->r->regen(mask_sites, n_mask, cycle, n_iters); if (accepted) *accepted = a; })
+}
+int32_t oracle_mhfn_static_update(oracle_mhfn_static* h, const int32_t* sites, const double* vals, int32_t n_cons, int32_t unknown, uint32_t step,
+                                  double* weights, uint32_t* disc_present) {
+    GUARD({ h->r->update(sites, vals, n_cons, unknown, step, weights, disc_present); })
 }
 int32_t oracle_mhfn_static_read(oracle_mhfn_static* h, double* values, uint32_t* present, uint64_t* panics) {
     GUARD({ h->r->read(values, present); if (panics) *panics = h->r->panics(); })

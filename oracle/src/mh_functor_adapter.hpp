@@ -55,6 +55,8 @@ struct DynMhHandler {
     double normal(double mu, double sd) { return normal<SITE>(mu, sd, 0.); }
     template <int SITE>
     bool bernoulli(double p) { return g.template sample_at<bool>(oracle::bernoulli, p, addr<SITE>()); }
+    template <int SITE>
+    double uniform(double a, double b) { return g.template sample_at<double>(oracle::uniform, UniformParams{a, b}, addr<SITE>()); }
     // trace_at: under Update / Regenerate with nothing touched and diff NoChange the body is NOT run and the stored retv comes
     // back (dyngenfn.rs:362-366, 415-419) — which is why a functor may take a sub-call's results from its return value only
     template <uint32_t SITES, class Body>
@@ -107,6 +109,8 @@ struct MhFnFlatHandler {
     double normal(double mu, double sd) { return normal<SITE>(mu, sd, 0.); }
     template <int SITE>
     bool bernoulli(double q) { return g.template sample_at<bool>(oracle::bernoulli, q, mhfn_flat_addr<M>(SITE)); }
+    template <int SITE>
+    double uniform(double a, double b) { return g.template sample_at<double>(oracle::uniform, UniformParams{a, b}, mhfn_flat_addr<M>(SITE)); }
     double exp_(double x) const { return o_exp(x); }
     double log_(double x) const { return o_ln(x); }
 };
@@ -175,6 +179,8 @@ struct MhFnStatic {
     virtual uint64_t regen(const int32_t* mask_sites, int n_mask, int cycle, int n_iters) = 0;
     virtual void read(double* vals, uint32_t* present) const = 0;
     virtual uint64_t panics() const = 0;
+    // mp_fn_update's per-lane work (k_fn_update) with constraints shared by all chains: weights and discard presence out
+    virtual void update(const int32_t* sites, const double* vals, int n_cons, int unknown, uint32_t step, double* weights, uint32_t* disc_present) = 0;
 };
 template <class M>
 struct MhFnStaticT;
@@ -267,6 +273,22 @@ struct MhFnStaticT : MhFnStatic {
         auto it = mhfn_static_proposals<M>().find(kind);
         if (it == mhfn_static_proposals<M>().end()) throw Panic("no proposal of this kind is registered for the model");
         return it->second(*this, args, n_args, n_iters);
+    }
+    void update(const int32_t* sites, const double* vals, int n_cons, int unknown, uint32_t step, double* weights, uint32_t* disc_present) override {
+        mp_fn_trace<M::NS> c;
+        mp_fn_clear(c);
+        for (int q = 0; q < n_cons; ++q) { c.present |= 1u << sites[q]; c.val[sites[q]] = vals[q]; }
+        for (size_t i = 0; i < tr.size(); ++i) {
+            const mp_stream s = stream(i, step);
+            mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &tr[i], &c);
+            g.changed = unknown != 0;
+            model(g);
+            g.finish();
+            n_panic += g.panic;
+            weights[i] = g.weight;
+            disc_present[i] = g.discarded;
+            tr[i] = g.tr;
+        }
     }
     void read(double* vals, uint32_t* present) const override {
         for (size_t i = 0; i < tr.size(); ++i) {

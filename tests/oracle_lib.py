@@ -524,6 +524,44 @@ class OracleFunctionChains:
         self._ck(self.L.oracle_mhfn_read_trace(self.h, dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint32))))
         return vals, present
 
+    # ---- GenFn::update / regenerate / assess / propose one at a time (gfi.rs:57-90): the checker of mp_fn_* ----
+    def _cons(self, constraints):
+        ip, up = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+        if isinstance(constraints, dict):
+            sites = np.array(sorted(constraints), dtype=np.int32)
+            vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
+            return (sites, vals), (sites.ctypes.data_as(ip), dptr(vals), int(sites.size), None, None)
+        cv = np.ascontiguousarray(constraints[0], dtype=np.float64).reshape(self.n, self.num_sites)
+        cp = np.ascontiguousarray(constraints[1], dtype=np.uint32).reshape(self.n)
+        return (cv, cp), (None, None, 0, dptr(cv), cp.ctypes.data_as(up))
+
+    def update(self, constraints, argdiff=0, rng_step=0):
+        keep, c = self._cons(constraints)
+        w, dv, dp_ = np.empty(self.n), np.zeros((self.n, self.num_sites)), np.zeros(self.n, dtype=np.uint32)
+        self._ck(self.L.oracle_mhfn_update(self.h, int(argdiff), C.c_uint32(rng_step), c[0], c[1], c[2], c[3], c[4], dptr(w), dptr(dv),
+                                           dp_.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return w, (dv, dp_)
+
+    def regenerate(self, mask_sites, argdiff=0, rng_step=0):
+        m = (C.c_int32 * max(len(mask_sites), 1))(*mask_sites)
+        w = np.empty(self.n)
+        self._ck(self.L.oracle_mhfn_regenerate(self.h, int(argdiff), C.c_uint32(rng_step), m, len(mask_sites), dptr(w)))
+        return w
+
+    def assess(self, constraints, proposal_kind=-1, proposal_args=(), rng_step=0):
+        keep, c = self._cons(constraints)
+        a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
+        w = np.empty(self.n)
+        self._ck(self.L.oracle_mhfn_assess(self.h, int(proposal_kind), dptr(a), int(a.size), C.c_uint32(rng_step), c[0], c[1], c[2], c[3], c[4], dptr(w)))
+        return w
+
+    def propose(self, proposal_kind, proposal_args=(), rng_step=0):
+        a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
+        cv, cp, w = np.zeros((self.n, self.num_sites)), np.zeros(self.n, dtype=np.uint32), np.empty(self.n)
+        self._ck(self.L.oracle_mhfn_propose(self.h, int(proposal_kind), dptr(a), int(a.size), C.c_uint32(rng_step), dptr(cv),
+                                            cp.ctypes.data_as(C.POINTER(C.c_uint32)), dptr(w)))
+        return (cv, cp), w
+
     def logjp(self):
         out = np.empty(self.n)
         self._ck(self.L.oracle_mhfn_read_logjp(self.h, dptr(out)))
@@ -570,6 +608,15 @@ class HostStaticFunctionChains:
         acc = C.c_uint64()
         self._ck(self.L.oracle_mhfn_static_regen(self.h, m, len(mask_sites), int(cycle), int(n_iters), C.byref(acc)))
         return acc.value
+
+    def update(self, constraints, argdiff=0, rng_step=1):
+        """k_fn_update's per-lane work with constraints shared by all chains -> (weights, discard presence)"""
+        sites = np.array(sorted(constraints), dtype=np.int32)
+        vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
+        w, dp_ = np.empty(self.n), np.zeros(self.n, dtype=np.uint32)
+        self._ck(self.L.oracle_mhfn_static_update(self.h, sites.ctypes.data_as(C.POINTER(C.c_int32)), dptr(vals), int(sites.size), int(argdiff),
+                                                  C.c_uint32(rng_step), dptr(w), dp_.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return w, dp_
 
     def trace(self, num_sites):
         vals = np.empty((self.n, num_sites))
