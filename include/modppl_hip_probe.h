@@ -12,7 +12,9 @@
 extern "C" {
 #endif
 
-enum mp_probe_op { MP_PROBE_EXP = 0, MP_PROBE_LOG = 1, MP_PROBE_SQRT = 2, MP_PROBE_DIV = 3, MP_PROBE_NORMAL_LOGPDF = 4 };
+enum mp_probe_op { MP_PROBE_EXP = 0, MP_PROBE_LOG = 1, MP_PROBE_SQRT = 2, MP_PROBE_DIV = 3, MP_PROBE_NORMAL_LOGPDF = 4,
+                   MP_PROBE_DIV_HOISTED = 5 /* mp_div_hoisted(a, b, RN(1 / b)): the division by a hoisted constant, mp_math.h */,
+                   MP_PROBE_NORMAL_LOGPDF_H = 6 /* mp_normal_logpdf_h(a, b, c, mp_log(c), mp_rcp_hoist(c)): no division inside */ };
 /* out[i] = op(a[i], b[i], c[i]) on the device; b, c may be NULL for unary ops (host pointers). */
 int32_t mp_probe_math(int32_t op, const double* a, const double* b, const double* c, int64_t n, double* out, int32_t device);
 /* out[i] = normal.random with Philox (seed, slot = slot0 + i, step, domain, site) and params (mu, sd). */

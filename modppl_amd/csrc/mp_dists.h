@@ -29,6 +29,15 @@ MP_HD double mp_normal_logpdf_ln(double x, double mu, double sd, double ln_sd) {
     return -(az * az + MP_LN_2PI_CANON) / 2. - ln_sd;
 }
 MP_HD double mp_normal_logpdf(double x, double mu, double sd) { return mp_normal_logpdf_ln(x, mu, sd, mp_log(sd)); }
+// ... with the reciprocal of sd hoisted as well (mp_rcp_hoist; 0 = not hoisted): same bits, no division (mp_div_hoisted)
+MP_HD double mp_normal_logpdf_h(double x, double mu, double sd, double ln_sd, double rcp_sd) {
+    // (the branch-free core: outside its exact range — |x - mu| < 2^-960, or a quotient that overflows — z * z is 0 or infinite
+    // whichever of the two quotients it is computed from, and an infinite x - mu stays infinite: the same log-density bits for every
+    // input, without the division's code in every site of a model.  mp_probe op MP_PROBE_NORMAL_LOGPDF_H holds it to that.)
+    const double z = rcp_sd != 0. ? mp_div_hoisted_core(x - mu, sd, rcp_sd) : (x - mu) / sd;
+    const double az = fabs(z);
+    return -(az * az + MP_LN_2PI_CANON) / 2. - ln_sd;
+}
 
 // The accepted pair (u, r = u*u + v*v) of the polar method does not depend on (mu, sd), so the
 // rejection loop can run ahead of the model (mp_pf.hip, k_propagate) and the model consumes it here.

@@ -48,6 +48,7 @@ __device__ __forceinline__ double mh_mean(bool is_lin, double a, double b, doubl
     return is_lin ? a + b * x : a + b * x + c * x * x;
 }
 #define MH_NOISE 0.1
+#define MH_RCP_NOISE (1.0 / MH_NOISE)   // RN(1 / 0.1) = 10.0, folded by the compiler: the observations are scored without a division (mp_div_hoisted)
 // mp_log(0.1), hoisted: computed on the host with the same mp_log and passed in
 
 __global__ __launch_bounds__(MH_THREADS) void k_mh_init(u64 n, uint32_t k0, uint32_t k1, int constrain,
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_logjp(u64 n, mh_data data_, d
     lj += mp_normal_logpdf_ln(a, 0., 1., 0.);
     lj += mp_normal_logpdf_ln(b, 0., 1., 0.);
     if (!is_lin) lj += mp_normal_logpdf_ln(c, 0., 1., 0.);
-    for (int k = 0; k < data.n; ++k) lj += mp_normal_logpdf_ln(data.ys[k], mh_mean(is_lin, a, b, c, data.xs[k]), MH_NOISE, ln_noise);
+    for (int k = 0; k < data.n; ++k) lj += mp_normal_logpdf_h(data.ys[k], mh_mean(is_lin, a, b, c, data.xs[k]), MH_NOISE, ln_noise, MH_RCP_NOISE);
     out[i] = lj;
 }
 
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_broadcast_ys(u64 n, mh_data d
 
 template <int KIND>
 __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, uint32_t k1, uint32_t iter0, int n_iters, mh_data data,
-                                                           double ln_noise, mh_mask mask, double drift_std, double ln_drift_std,
+                                                           double ln_noise, mh_mask mask, double drift_std, double ln_drift_std, double rcp_drift_std,
                                                            int* __restrict__ is_lin_io, double* __restrict__ a_io, double* __restrict__ b_io,
                                                            double* __restrict__ c_io, u64* __restrict__ accepted_total,
                                                            const double* __restrict__ ys_chain) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
         double ly[MH_MAX_DATA];
 #pragma unroll
         for (int k = 0; k < MH_MAX_DATA; ++k)
-            ly[k] = (k < data.n) ? mp_normal_logpdf_ln(data.ys[k], mh_mean(is_lin, a, b, c, data.xs[k]), MH_NOISE, ln_noise) : 0.;
+            ly[k] = (k < data.n) ? mp_normal_logpdf_h(data.ys[k], mh_mean(is_lin, a, b, c, data.xs[k]), MH_NOISE, ln_noise, MH_RCP_NOISE) : 0.;
         mp_stream s;
         s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i;
         for (int it = 0; it < n_iters; ++it) {
@@ -176,12 +177,12 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
                 // ---- proposal.propose: simulate hierarchical_drift_proposal (hierarchical.rs:62-70) ----
                 mp_site pa(s, MP_DOM_PROPOSAL, MP_SITE_A), pb(s, MP_DOM_PROPOSAL, MP_SITE_B), pc(s, MP_DOM_PROPOSAL, MP_SITE_C);
                 na = mp_normal_sample(pa, a, drift_std);
-                fwd += mp_normal_logpdf_ln(na, a, drift_std, ln_drift_std);
+                fwd += mp_normal_logpdf_h(na, a, drift_std, ln_drift_std, rcp_drift_std);
                 nb = mp_normal_sample(pb, b, drift_std);
-                fwd += mp_normal_logpdf_ln(nb, b, drift_std, ln_drift_std);
+                fwd += mp_normal_logpdf_h(nb, b, drift_std, ln_drift_std, rcp_drift_std);
                 if (!is_lin) {
                     nc = mp_normal_sample(pc, c, drift_std);
-                    fwd += mp_normal_logpdf_ln(nc, c, drift_std, ln_drift_std);
+                    fwd += mp_normal_logpdf_h(nc, c, drift_std, ln_drift_std, rcp_drift_std);
                 }
                 // ---- model.update(trace, args, NoChange, fwd_choices): inner update of `coeffs` ----
                 double dw = 0.;
@@ -201,15 +202,15 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
                 mp_site pa(s, MP_DOM_PROPOSAL, MP_SITE_A), pb(s, MP_DOM_PROPOSAL, MP_SITE_B), pl(s, MP_DOM_PROPOSAL, MP_SITE_IS_LINEAR),
                     pc(s, MP_DOM_PROPOSAL, MP_SITE_C);
                 na = mp_normal_sample(pa, a, drift_std);
-                fwd += mp_normal_logpdf_ln(na, a, drift_std, ln_drift_std);
+                fwd += mp_normal_logpdf_h(na, a, drift_std, ln_drift_std, rcp_drift_std);
                 nb = mp_normal_sample(pb, b, drift_std);
-                fwd += mp_normal_logpdf_ln(nb, b, drift_std, ln_drift_std);
+                fwd += mp_normal_logpdf_h(nb, b, drift_std, ln_drift_std, rcp_drift_std);
                 nl = mp_bernoulli_sample(pl, 0.5);
                 fwd += mp_bernoulli_logpdf(nl, 0.5);
                 if (!nl) {
                     const double prev_c = is_lin ? 0. : c;   // tr.data.search("coeffs/c") (:54-58)
                     nc = mp_normal_sample(pc, prev_c, drift_std);
-                    fwd += mp_normal_logpdf_ln(nc, prev_c, drift_std, ln_drift_std);
+                    fwd += mp_normal_logpdf_h(nc, prev_c, drift_std, ln_drift_std, rcp_drift_std);
                 }
                 // ---- model.update(trace, args, NoChange, fwd_choices) (dyngenfn.rs:143-211, 321-391): is_linear is a
                 // constrained site with a previous value; `coeffs` is updated by linear() or quadratic() as the NEW
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
 #pragma unroll
             for (int k = 0; k < MH_MAX_DATA; ++k) {
                 if (k < data.n) {
-                    lnew[k] = mp_normal_logpdf_ln(data.ys[k], mh_mean(nl, na, nb, nc, data.xs[k]), MH_NOISE, ln_noise);
+                    lnew[k] = mp_normal_logpdf_h(data.ys[k], mh_mean(nl, na, nb, nc, data.xs[k]), MH_NOISE, ln_noise, MH_RCP_NOISE);
                     w += lnew[k] - ly[k];
                 } else {
                     lnew[k] = 0.;
@@ -268,18 +269,18 @@ __global__ __launch_bounds__(MH_THREADS) void k_mh_iterate(u64 n, uint32_t k0, u
                 w = w - 0.;  // gc of the outer update
                 // ---- proposal.assess((new trace, ()), discard): the backward proposal scores the old values; its c site
                 // exists iff the OLD is_linear was false, centred on the new c if the new trace has one ----
-                bwd += mp_normal_logpdf_ln(a, na, drift_std, ln_drift_std);
-                bwd += mp_normal_logpdf_ln(b, nb, drift_std, ln_drift_std);
+                bwd += mp_normal_logpdf_h(a, na, drift_std, ln_drift_std, rcp_drift_std);
+                bwd += mp_normal_logpdf_h(b, nb, drift_std, ln_drift_std, rcp_drift_std);
                 bwd += mp_bernoulli_logpdf(is_lin, 0.5);
-                if (!is_lin) bwd += mp_normal_logpdf_ln(c, nl ? 0. : nc, drift_std, ln_drift_std);
+                if (!is_lin) bwd += mp_normal_logpdf_h(c, nl ? 0. : nc, drift_std, ln_drift_std, rcp_drift_std);
                 alpha = w - fwd + bwd;  // mh.rs:34
             }
             if (KIND == 1) {
                 w = w - 0.;  // gc of the outer update
                 // ---- proposal.assess((new trace, args), discard): generate with the old values constrained ----
-                bwd += mp_normal_logpdf_ln(a, na, drift_std, ln_drift_std);
-                bwd += mp_normal_logpdf_ln(b, nb, drift_std, ln_drift_std);
-                if (!is_lin) bwd += mp_normal_logpdf_ln(c, nc, drift_std, ln_drift_std);
+                bwd += mp_normal_logpdf_h(a, na, drift_std, ln_drift_std, rcp_drift_std);
+                bwd += mp_normal_logpdf_h(b, nb, drift_std, ln_drift_std, rcp_drift_std);
+                if (!is_lin) bwd += mp_normal_logpdf_h(c, nc, drift_std, ln_drift_std, rcp_drift_std);
                 alpha = w - fwd + bwd;  // mh.rs:34
             }
             const mp_u64x2 ub = s.draw(MP_DOM_ACCEPT, 0u, 0u);
@@ -465,13 +466,13 @@ static int32_t mh_run(mp_mh* h, int kind, const mh_mask& mask, double drift_std,
     const double ln_ds = kind ? mp_log(drift_std) : 0.;
     if (kind == 2)
         hipLaunchKernelGGL(k_mh_iterate<2>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
-                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, mp_rcp_hoist(drift_std), h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
     else if (kind == 1)
         hipLaunchKernelGGL(k_mh_iterate<1>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
-                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, mp_rcp_hoist(drift_std), h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
     else
         hipLaunchKernelGGL(k_mh_iterate<0>, dim3(grid), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), iter0,
-                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
+                           n_iters, h->data, h->ln_noise, mask, drift_std, ln_ds, mp_rcp_hoist(drift_std), h->is_lin, h->a, h->b, h->c, h->d_acc, (const double*)h->ys_chain);
     MHCK(hipGetLastError());
     h->iters += (u64)n_iters;
     if (accepted) {

@@ -20,6 +20,8 @@ __global__ void k_probe_math(int op, const double* a, const double* b, const dou
     case MP_PROBE_SQRT: r = mp_sqrt(a[i]); break;
     case MP_PROBE_DIV: r = a[i] / b[i]; break;
     case MP_PROBE_NORMAL_LOGPDF: r = mp_normal_logpdf(a[i], b[i], c[i]); break;
+    case MP_PROBE_NORMAL_LOGPDF_H: r = mp_normal_logpdf_h(a[i], b[i], c[i], mp_log(c[i]), mp_rcp_hoist(c[i])); break;
+    case MP_PROBE_DIV_HOISTED: r = mp_rcp_hoistable(b[i]) ? mp_div_hoisted(a[i], b[i], 1.0 / b[i]) : a[i] / b[i]; break;
     }
     out[i] = r;
 }

@@ -813,6 +813,18 @@ int32_t oracle_mh_pointed_destroy(oracle_mh_pointed* h) { delete h; return MP_OK
 
 // ---- math / rng / distribution probes ---------------------------------------------------------
 void oracle_mp_exp(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_exp(x[i]); }
+// mp_div_hoisted (mp_math.h) on the host: the product's division by a hoisted constant, for the bit-for-bit check against `/`
+void oracle_mp_div_hoisted(const double* x, const double* d, int64_t n, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = mp_rcp_hoistable(d[i]) ? mp_div_hoisted(x[i], d[i], 1.0 / d[i]) : x[i] / d[i];
+}
+// out[0][i] = mp_normal_logpdf_h (hoisted reciprocal, no division), out[1][i] = mp_normal_logpdf_ln (the division): must be equal bits
+void oracle_mp_normal_logpdf_both(const double* x, const double* mu, const double* sd, int64_t n, double* out_h, double* out_div) {
+    for (int64_t i = 0; i < n; ++i) {
+        const double ln = mp_log(sd[i]);
+        out_h[i] = mp_normal_logpdf_h(x[i], mu[i], sd[i], ln, mp_rcp_hoist(sd[i]));
+        out_div[i] = mp_normal_logpdf_ln(x[i], mu[i], sd[i], ln);
+    }
+}
 void oracle_mp_log(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_log(x[i]); }
 void oracle_mp_sin(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_sin(x[i]); }
 void oracle_mp_cos(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_cos(x[i]); }

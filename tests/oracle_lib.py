@@ -105,6 +105,10 @@ def load():
     L.oracle_mh_destroy.argtypes = [p]
     L.oracle_mp_exp.argtypes = [dp, i64, dp]
     L.oracle_mp_log.argtypes = [dp, i64, dp]
+    L.oracle_mp_div_hoisted.argtypes = [dp, dp, i64, dp]
+    L.oracle_mp_div_hoisted.restype = None
+    L.oracle_mp_normal_logpdf_both.argtypes = [dp, dp, dp, i64, dp, dp]
+    L.oracle_mp_normal_logpdf_both.restype = None
     L.oracle_mp_exp.restype = None
     for f in (L.oracle_mp_sin, L.oracle_mp_cos):
         f.argtypes = [dp, i64, dp]

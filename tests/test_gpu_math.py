@@ -51,6 +51,33 @@ def test_sqrt_div_ieee(hiplib):
         assert np.array_equal(_bits(_probe(hiplib, 3, x, y)), _bits(x / y))
 
 
+def test_division_by_a_hoisted_constant_is_the_ieee_division_on_device(hiplib):
+    """mp_div_hoisted (mp_math.h) == x / d, bit for bit, on the device: what the observation log-densities of lgssm1 / bearings /
+    the banded models and of the MH kernels are divided with"""
+    from tests.test_math import _div_cases
+
+    x, d = _div_cases(np.random.default_rng(8), 1 << 18)
+    got = _probe(hiplib, 5, x, d)
+    with np.errstate(all="ignore"):
+        want = x / d
+    ok = ~np.isnan(want)
+    assert np.array_equal(_bits(got[ok]), _bits(want[ok]))
+    assert np.all(np.isnan(got[~ok]))
+
+
+def test_logpdf_with_a_hoisted_reciprocal_on_device(hiplib):
+    """mp_normal_logpdf_h == mp_normal_logpdf (the dividing form) on the device for every input, extremes included"""
+    from tests.test_math import _div_cases
+
+    x, d = _div_cases(np.random.default_rng(11), 1 << 17)
+    d = np.abs(d)
+    mu = np.where(np.arange(x.size) % 3 == 0, 0.0, np.random.default_rng(12).normal(0, 1, x.size))
+    a, b = _probe(hiplib, 6, x, mu, d), _probe(hiplib, 4, x, mu, d)
+    nan = np.isnan(b)
+    assert np.array_equal(_bits(a[~nan]), _bits(b[~nan]))
+    assert np.all(np.isnan(a[nan]))
+
+
 def test_normal_logpdf_kats_on_device(hiplib):
     # modppl/tests/dists.rs:120-136 (epsilon there: f32::EPSILON)
     x = np.array([1.4, 2.8, -3.14])

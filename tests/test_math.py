@@ -80,3 +80,41 @@ def test_normal_sampler_moments(oracle):
     # modppl/tests/dists.rs:107-118
     s = np.array([oracle.oracle_normal_random(1, i, 0, 0, 0, 1.64, 0.025, 0) for i in range(50000)])
     assert abs(s.mean() - 1.64) < 0.001 and abs(s.std(ddof=1) - 0.025) < 0.001
+
+
+def _div_cases(rng, n):
+    """numerators x divisors for mp_div_hoisted: model constants (noise levels, drift widths), awkward significands, and the
+    numerator ranges a log-density sees — plus the ranges that must take the real division (tiny, huge, zero, inf, NaN)"""
+    ds = [0.1, 0.5, 5.0, 2.0, 1.0, 0.02, 0.05, 0.025, 0.3, 1.0 / 3.0, 7.0, 1e-3, 123.456, np.pi, 1.0 + 2.0 ** -52, 2.0 - 2.0 ** -52,
+          0.9999999999999999, 1.5, 0.15, 0.2, 0.25, 0.4, 20.0, 1e10, 1e-10, -0.1, -3.7]
+    xs, dd = [], []
+    for d in ds:
+        x = np.concatenate([rng.normal(0, 1, n), rng.normal(0, 1, n) * np.exp(rng.uniform(-60, 60, n)), rng.uniform(-1, 1, n // 4) * 2.0 ** rng.integers(-1000, 1000, n // 4),
+                            [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-310, -1e-310, 2.0 ** -900, 2.0 ** 900, 1.7976931348623157e308, 5e-324]])
+        xs.append(x)
+        dd.append(np.full(x.size, d))
+    return np.concatenate(xs), np.concatenate(dd)
+
+
+def test_division_by_a_hoisted_constant_is_the_ieee_division(oracle):
+    """mp_div_hoisted(x, d, RN(1 / d)) == x / d, bit for bit (mp_math.h: Markstein's correction twice), on the host build"""
+    x, d = _div_cases(np.random.default_rng(7), 1 << 18)
+    out = np.empty_like(x)
+    oracle.oracle_mp_div_hoisted(O.dptr(x), O.dptr(d), x.size, O.dptr(out))
+    with np.errstate(all="ignore"):
+        want = x / d
+    assert np.array_equal(out.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])
+    assert np.all(np.isnan(out[np.isnan(want)]))
+
+
+def test_logpdf_with_a_hoisted_reciprocal_has_the_bits_of_the_dividing_one(oracle):
+    """mp_normal_logpdf_h (branch-free corrected quotient) == mp_normal_logpdf_ln (IEEE division) for EVERY input: the ranges where
+    the quotient itself may differ are exactly those where its square underflows or overflows"""
+    x, d = _div_cases(np.random.default_rng(9), 1 << 17)
+    d = np.abs(d)
+    mu = np.where(np.arange(x.size) % 3 == 0, 0.0, np.random.default_rng(10).normal(0, 1, x.size))
+    a, b = np.empty_like(x), np.empty_like(x)
+    oracle.oracle_mp_normal_logpdf_both(O.dptr(x), O.dptr(mu), O.dptr(d), x.size, O.dptr(a), O.dptr(b))
+    nan = np.isnan(b)
+    assert np.array_equal(a.view(np.uint64)[~nan], b.view(np.uint64)[~nan])
+    assert np.all(np.isnan(a[nan]))
