@@ -317,6 +317,12 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
                                  double* log_ml_estimate, double* log_normalized_weights, uint64_t* resampled_indices,
                                  double* final_states);
 
+/* importance_sampling(model, args, constraints, num_samples) — importance.rs:12-31 — with what it returns first: ALL N traces.
+ * A trace of an Unfold model is its states at every step: trajectories_out[num_samples][n_steps][dim_state] (host; may be NULL),
+ * next to the log normalised weights [num_samples] and the log marginal likelihood estimate.  Sample i = Philox slot i. */
+int32_t mp_importance_sampling(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples, uint64_t seed,
+                               int32_t device, double* log_ml_estimate, double* log_normalized_weights, double* trajectories_out);
+
 /* ---- Metropolis-Hastings — modppl/src/inference/mh.rs:9-75 -------------------------------- */
 /* N independent chains advanced in lockstep (chains never communicate: replicas only).  The model
  * is the reference's `hierarchical_model` (modppl/tests/dyngenfns/hierarchical.rs:33-47):

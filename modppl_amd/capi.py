@@ -31,7 +31,7 @@ SYMBOLS = [
     "mp_last_error", "mp_device_count", "mp_pf_create", "mp_pf_init_step", "mp_pf_step", "mp_pf_effective_sample_size",
     "mp_pf_resample", "mp_pf_resample_if_ess_below", "mp_pf_log_marginal_likelihood_estimate", "mp_pf_read_state", "mp_pf_read_log_weights",
     "mp_pf_read_parents", "mp_pf_read_trajectory", "mp_pf_read_trajectories", "mp_pf_time", "mp_pf_run", "mp_pf_synchronize", "mp_pf_destroy",
-    "mp_pf_set_timing", "mp_pf_get_timing", "mp_pf_region_begin", "mp_pf_region_end", "mp_pf_last_propagate_form", "mp_unfold_simulate", "mp_importance_resampling",
+    "mp_pf_set_timing", "mp_pf_get_timing", "mp_pf_region_begin", "mp_pf_region_end", "mp_pf_last_propagate_form", "mp_unfold_simulate", "mp_importance_resampling", "mp_importance_sampling",
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
     "mp_pf_shard_owned_count", "mp_pf_shard_owned_expand", "mp_pf_shard_owned_commit",
     "mp_pf_shard_resample", "mp_pf_shard_resample_rccl", "mp_pf_shard_query_native", "mp_pf_shard_resample_stats", "mp_transport_rccl",
@@ -136,6 +136,7 @@ def load():
     L.mp_pf_region_end.argtypes = [p, dp, C.POINTER(u64)]
     L.mp_unfold_simulate.argtypes = [C.POINTER(ModelDesc), dp, i32, u64, u64, i32, dp, dp]
     L.mp_importance_resampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), dp]
+    L.mp_importance_sampling.argtypes = [C.POINTER(ModelDesc), dp, dp, i32, u64, u64, i32, dp, dp, dp]
     L.mp_pf_shard_bind_tiles.argtypes = [p, p]
     L.mp_pf_shard_tiles_packed.argtypes = [p, p]
     L.mp_pf_shard_route_fixed.argtypes = [p, i32, p, i32, i32, u64, p]

@@ -1998,13 +1998,28 @@ int32_t mp_unfold_simulate(const mp_model_desc* model, const double* args0, int3
     return MP_OK;
 }
 
+static int32_t importance_run(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples,
+                              uint64_t num_ret_samples, uint64_t seed, int32_t device, double* log_ml_estimate, double* log_normalized_weights,
+                              uint64_t* resampled_indices, double* final_states, double* trajectories);
 int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples,
                                  uint64_t num_ret_samples, uint64_t seed, int32_t device, double* log_ml_estimate,
                                  double* log_normalized_weights, uint64_t* resampled_indices, double* final_states) {
+    return importance_run(model, args0, obs, n_steps, num_samples, num_ret_samples, seed, device, log_ml_estimate, log_normalized_weights,
+                          resampled_indices, final_states, nullptr);
+}
+int32_t mp_importance_sampling(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples, uint64_t seed,
+                               int32_t device, double* log_ml_estimate, double* log_normalized_weights, double* trajectories_out) {
+    return importance_run(model, args0, obs, n_steps, num_samples, 0, seed, device, log_ml_estimate, log_normalized_weights, nullptr, nullptr, trajectories_out);
+}
+static int32_t importance_run(const mp_model_desc* model, const double* args0, const double* obs, int32_t n_steps, uint64_t num_samples,
+                              uint64_t num_ret_samples, uint64_t seed, int32_t device, double* log_ml_estimate, double* log_normalized_weights,
+                              uint64_t* resampled_indices, double* final_states, double* trajectories) {
     if (!model || !obs) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (num_ret_samples > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "num_ret_samples must fit u32");
     mp_pf* h = nullptr;
-    int32_t rc = mp_pf_create(model, num_samples, seed, nullptr, 0, device, nullptr, &h);
+    // (the traces themselves — importance.rs:26-27 returns all N of them — are every sample's states at every step: the ancestry
+    // record, which without a resample is each slot's own history)
+    int32_t rc = mp_pf_create(model, num_samples, seed, nullptr, trajectories ? MP_PF_RECORD_HISTORY : 0, device, nullptr, &h);
     if (rc != MP_OK) return rc;
     struct Guard { mp_pf* h; ~Guard() { mp_pf_destroy(h); } } guard{h};
     // importance_sampling: N x generate(model_args, constraints) over all n_steps constraints (importance.rs:18-20)
@@ -2029,6 +2044,11 @@ int32_t mp_importance_resampling(const mp_model_desc* model, const double* args0
     }
     if (final_states) {
         rc = mp_pf_read_state(h, final_states);
+        if (rc != MP_OK) return rc;
+    }
+    if (trajectories) {
+        int32_t t_steps = 0;
+        rc = mp_pf_read_trajectories(h, 0, num_samples, trajectories, &t_steps);
         if (rc != MP_OK) return rc;
     }
     if (resampled_indices && num_ret_samples > 0) {

@@ -178,11 +178,26 @@ class ParticleSystem:
             pass
 
 
-def importance_sampling(model, model_args, constraints, num_samples, seed, *, device=0):
+def importance_sampling(model, model_args, constraints, num_samples, seed, *, device=0, full_traces=False):
     """`importance_sampling(model, model_args, constraints, num_samples)` — modppl/src/inference/importance.rs:12-28.
 
     Returns (traces, log_normalized_weights, log_ml_estimate); `traces` is the array of final states
-    (`traces[i].retv.last()`), since choices live in dense per-particle rows on the device."""
+    (`traces[i].retv.last()`) or, with full_traces=True, every sample's states at every step — `traces[i].retv`,
+    [num_samples, n_steps, dim_state] — which is what the reference's `Vec<Trace>` holds."""
+    if full_traces:
+        L = capi.load()
+        obs = np.ascontiguousarray(constraints, dtype=np.float64)
+        if obs.size == 0 or obs.size % model.dim_obs:
+            raise capi.ModpplError(capi.MP_ERR_CONSTRAINTS, "constraints must hold dim_obs values per time step")
+        obs = obs.reshape(-1, model.dim_obs)
+        a = None if model_args is None else np.ascontiguousarray(model_args, dtype=np.float64).reshape(-1)
+        desc = model.desc()
+        lml = C.c_double()
+        lnw = np.empty(int(num_samples))
+        traj = np.empty((int(num_samples), obs.shape[0], model.dim_state))
+        capi.check(L.mp_importance_sampling(C.byref(desc), _dptr(a) if a is not None else None, _dptr(obs), obs.shape[0], int(num_samples), int(seed),
+                                            int(device), C.byref(lml), _dptr(lnw), _dptr(traj)))
+        return traj, lnw, lml.value
     states, lnw, lml, _ = _importance(model, model_args, constraints, num_samples, 0, seed, device)
     return states, lnw, lml
 

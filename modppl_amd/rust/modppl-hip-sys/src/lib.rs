@@ -126,6 +126,8 @@ extern "C" {
     pub fn mp_pf_region_end(h: *mut mp_pf, elapsed_ms: *mut f64, propagate_launches: *mut u64) -> i32;
     pub fn mp_unfold_simulate(model: *const mp_model_desc, args0: *const f64, n_steps: i32, n: u64, seed: u64, device: i32,
                               states_out: *mut f64, obs_out: *mut f64) -> i32;
+    pub fn mp_importance_sampling(model: *const mp_model_desc, args0: *const f64, obs: *const f64, n_steps: i32, num_samples: u64, seed: u64,
+                                  device: i32, log_ml_estimate: *mut f64, log_normalized_weights: *mut f64, trajectories_out: *mut f64) -> i32;
     pub fn mp_importance_resampling(model: *const mp_model_desc, args0: *const f64, obs: *const f64, n_steps: i32,
                                     num_samples: u64, num_ret_samples: u64, seed: u64, device: i32,
                                     log_ml_estimate: *mut f64, log_normalized_weights: *mut f64,

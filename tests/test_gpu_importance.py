@@ -86,3 +86,28 @@ def test_importance_reference_models():
     d_lml, d_lnw, d_idx, d_xs = O.importance_resampling(7, 2, 11, xs, ys, 1500, 40, seed, O.VARIANT_CANONICAL, args0=[0.0, 0.0])
     s3, i3, l3 = modppl_amd.importance_resampling(modppl_amd.line_model(xs), [0.0, 0.0], ys, 1500, 40, seed)
     assert l3 == d_lml and np.array_equal(i3, d_idx) and np.array_equal(s3, d_xs)
+
+
+def test_importance_sampling_returns_every_trace():
+    """importance_sampling returns ALL N traces (importance.rs:26-27): every sample's choices at every step, against the checker's
+    per-particle trajectories (the structure-faithful engine keeps each trace's `retv`), for a scalar and a wider model."""
+    import modppl_amd
+    from tests.test_gpu_pf_models import spiral_obs
+
+    ys = O.lgssm_observations(6)
+    n, seed = 5000, 5
+    traj, lnw, lml = modppl_amd.importance_sampling(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), None, ys, n, seed, full_traces=True)
+    st, lnw2, lml2 = modppl_amd.importance_sampling(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), None, ys, n, seed)
+    assert traj.shape == (n, 6, 1)
+    assert lml == lml2 and np.array_equal(lnw, lnw2)
+    assert np.array_equal(traj[:, -1, :], st)          # retv.last()
+    ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL)   # structure-faithful: traces with their retv
+    ref.init_step(ys)
+    for i in (0, 1, 777, n - 1):
+        assert np.array_equal(traj[i], np.asarray(ref.trajectory(i)).reshape(6, 1))
+    obs = spiral_obs(20)[:4]
+    traj, lnw, lml = modppl_amd.importance_sampling(modppl_amd.spiral_model(), [0.0, 0.0], obs, 3000, 9, full_traces=True)
+    ref = O.OraclePF(2, 2, 2, np.zeros(0), 3000, 9, O.VARIANT_CANONICAL)
+    ref.init_step(obs, args0=[0.0, 0.0])
+    for i in (0, 2999, 1234):
+        assert np.array_equal(traj[i], np.asarray(ref.trajectory(i)).reshape(4, 2))
