@@ -330,7 +330,8 @@ int32_t mp_importance_sampling(const mp_model_desc* model, const double* args0, 
  *   y_i ~ normal(a + b x_i [+ c x_i^2], 0.1) observed.
  * Static site ids (the stand-in for trie addresses): */
 enum mp_mh_site { MP_SITE_IS_LINEAR = 0, MP_SITE_A = 1, MP_SITE_B = 2, MP_SITE_C = 3, MP_SITE_Y0 = 4 /* "(y, k)" = MP_SITE_Y0 + k */ };
-enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1, MP_MH_MODEL_POINTED_2D = 2, MP_MH_MODEL_HIERARCHICAL_FN = 101 /* mp_mh_create_fn */ };
+enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1, MP_MH_MODEL_POINTED_2D = 2, MP_MH_MODEL_HIERARCHICAL_FN = 101 /* mp_mh_create_fn */,
+                       MP_MH_MODEL_POINTED_FN = 120 /* mp_mh_create_fn: pointed_2d_model as a registered functor (vector-valued sites: latent = slots 1, 2; obs = 3, 4) */ };
 enum mp_mh_proposal_kind {
     MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1, /* hierarchical_drift_proposal(tr, drift_std): hierarchical.rs:62-70; args = {drift_std} */
     MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE = 2, /* add_or_remove_param_proposal(tr): hierarchical.rs:48-61, the structure-changing move of

@@ -10,6 +10,8 @@
 //     g.template normal<SITE>(mu, sd, ln_sd)     `normal(mu, sd) %= addr`    -> sample_at (dyngenfn.rs:100-273)
 //     g.template bernoulli<SITE>(p)              `bernoulli(p) %= addr`
 //     g.template uniform<SITE>(a, b)             `uniform(a, b) %= addr`
+//     g.template uniform_2d<SITE>(.., out), g.template mvnormal2<SITE>(mu, cov, .., out)   vector-valued sites: K = 2 consecutive slots
+//                                                SITE, SITE + 1 hold the value, SITE is the address (at_k)
 //     g.template call<SITES>(body)               `gen_fn(args) /= addr`      -> trace_at  (dyngenfn.rs:283-449);
 //                                                SITES = bit set of the sites of the sub-trace, body = [&](H& q) { ...; return mp_fn_ret{...}; }
 //                                                What the caller needs from the sub-call travels in that RETURN VALUE, never in
@@ -88,6 +90,39 @@ struct mp_fn_uniform {
     MP_HD double logpdf(double x) const { return mp_uniform_logpdf(x, a, b); }
 };
 
+// a scalar distribution as a one-value site
+template <class D>
+struct mp_fn_scalar {
+    D d;
+    MP_HD void sample(mp_site& st, double* x) const { x[0] = d.sample(st); }
+    MP_HD double logpdf(const double* x) const { return d.logpdf(x[0]); }
+};
+// uniform_2d (modppl/tests/pointed_model/types_2d.rs:14-32): both coordinates from ONE site = the two halves of one Philox block
+struct mp_fn_uniform_2d {
+    double xmin, xmax, ymin, ymax, neg_ln_area;   // neg_ln_area = -mp_log((xmax - xmin) * (ymax - ymin)), hoisted
+    MP_HD void sample(mp_site& st, double* x) const {
+        const mp_u64x2 b = st.next_block();
+        x[0] = mp_u01(b.a) * (xmax - xmin) + xmin;
+        x[1] = mp_u01(b.b) * (ymax - ymin) + ymin;
+    }
+    MP_HD double logpdf(const double* p) const { return (xmin <= p[0] && p[0] <= xmax && ymin <= p[1] && p[1] <= ymax) ? neg_ln_area : MP_NEG_INF; }
+};
+// mvnormal of dimension 2 (mvnormal.rs:12-37) with the per-call nalgebra work hoisted: cov_inv (row-major), ln_det, and the lower
+// Cholesky factor {l00, l10, l11} for `random` = L z + mu with z_0, z_1 ~ normal(0, 1) one after the other from the site's stream
+struct mp_fn_mvnormal2 {
+    double mu[2];
+    double cov_inv[4];
+    double ln_det;
+    double l00, l10, l11;
+    MP_HD void sample(mp_site& st, double* x) const {
+        const double z0 = mp_normal_sample(st, 0., 1.);
+        const double z1 = mp_normal_sample(st, 0., 1.);
+        x[0] = (0. + l00 * z0) + mu[0];
+        x[1] = ((0. + l10 * z0) + l11 * z1) + mu[1];
+    }
+    MP_HD double logpdf(const double* x) const { return mp_mvnormal_logpdf_pre<2>(x, mu, cov_inv, ln_det); }
+};
+
 enum mp_fn_mode { MP_FN_SIMULATE = 0, MP_FN_GENERATE = 1, MP_FN_UPDATE = 2, MP_FN_REGENERATE = 3 };
 
 template <int NS, int MODE>
@@ -115,29 +150,36 @@ struct mp_fn_handler {
     MP_HD double exp_(double x) const { return mp_exp(x); }
     MP_HD double log_(double x) const { return mp_log(x); }
 
-    template <int SITE, class Dist>
-    MP_HD double at(const Dist& d) {
-        static_assert(SITE >= 0 && SITE < NS, "site id out of range");
+    // One site of K values (K = 1: a scalar choice; K > 1: a vector-valued one, e.g. uniform_2d or a 2-d mvnormal — the value
+    // occupies the slots SITE .. SITE + K - 1 of the trace, its log-density sits in lp[SITE], its address is SITE: constraints, masks
+    // and the Philox site id name the FIRST slot).  Dist: sample(mp_site&, double* x), logpdf(const double* x).
+    template <int SITE, int K, class Dist>
+    MP_HD void at_k(const Dist& d, double* x) {
+        static_assert(SITE >= 0 && SITE + K <= NS && K >= 1, "site id out of range");
         constexpr uint32_t bit = 1u << SITE;
-        visited |= bit;
-        double x, lp;
+        constexpr uint32_t vbits = ((K >= 32 ? 0u : (1u << K)) - 1u) << SITE;
+        visited |= vbits;
+        double lp;
+#define MP_FN_PUT_() do { _Pragma("unroll") for (int j_ = 0; j_ < K; ++j_) { tr.val[SITE + j_] = x[j_]; tr.lp[SITE + j_] = 0.; } tr.lp[SITE] = lp; tr.present |= vbits; } while (0)
+#define MP_FN_PREV_() do { _Pragma("unroll") for (int j_ = 0; j_ < K; ++j_) x[j_] = prev->val[SITE + j_]; } while (0)
         // (`sw`: what the trie does to the weight of the sub-trie this site lives in — remove: -= the old choice's, w_observe / insert:
         // += the new one's, trie.rs:118-184 — in the order sample_at does them)
         if constexpr (MODE == MP_FN_SIMULATE) {
             mp_site st(rng, dom, (uint32_t)SITE);
-            x = d.sample(st);
+            d.sample(st, x);
             lp = d.logpdf(x);
             weight += lp;
             if (in_sub) sw += lp;
         } else if constexpr (MODE == MP_FN_GENERATE) {
             if (cons->present & bit) {
-                consumed |= bit;
-                x = cons->val[SITE];
+                consumed |= vbits;
+#pragma unroll
+                for (int j_ = 0; j_ < K; ++j_) x[j_] = cons->val[SITE + j_];
                 lp = d.logpdf(x);
                 weight += lp;
             } else {
                 mp_site st(rng, dom, (uint32_t)SITE);
-                x = d.sample(st);
+                d.sample(st, x);
                 lp = d.logpdf(x);
             }
             if (in_sub) sw += lp;
@@ -145,40 +187,41 @@ struct mp_fn_handler {
             const bool had = (prev->present & bit) != 0u;
             if (from_prev) {   // generate(args, sub): the old choice is the constraint (:116-131); a site the old sub-trace lacks is drawn
                 if (had) {
-                    x = prev->val[SITE];
+                    MP_FN_PREV_();
                     lp = d.logpdf(x);
                     weight += lp;
                 } else {
                     mp_site st(rng, dom, (uint32_t)SITE);
-                    x = d.sample(st);
+                    d.sample(st, x);
                     lp = d.logpdf(x);
                 }
                 sw += lp;
-                tr.val[SITE] = x; tr.lp[SITE] = lp; tr.present |= bit;
-                return x;
+                MP_FN_PUT_();
+                return;
             }
             bool fresh = false;   // drawn from the distribution
             if constexpr (MODE == MP_FN_UPDATE) {
                 if (cons->present & bit) {
-                    consumed |= bit;
+                    consumed |= vbits;
                     if (had) {
-                        weight -= prev->lp[SITE]; discarded |= bit;
+                        weight -= prev->lp[SITE]; discarded |= vbits;
                         if (in_sub) sw -= prev->lp[SITE];
                     }
-                    x = cons->val[SITE];
+#pragma unroll
+                    for (int j_ = 0; j_ < K; ++j_) x[j_] = cons->val[SITE + j_];
                     lp = d.logpdf(x);
                     changed = true;
                     weight += lp;
                     if (in_sub) sw += lp;
-                    tr.val[SITE] = x; tr.lp[SITE] = lp; tr.present |= bit;
-                    return x;
+                    MP_FN_PUT_();
+                    return;
                 }
             } else {
                 fresh = (mask & bit) != 0u;
             }
             if (in_sub && had) sw -= prev->lp[SITE];   // trace.data.remove(addr) comes first in every arm
             if (!fresh && had) {
-                x = prev->val[SITE];
+                MP_FN_PREV_();
                 if (!changed) {
                     lp = prev->lp[SITE];   // NoChange: the call goes back into the trace as it was
                 } else {
@@ -187,14 +230,21 @@ struct mp_fn_handler {
                 }
             } else {
                 mp_site st(rng, dom, (uint32_t)SITE);
-                x = d.sample(st);
+                d.sample(st, x);
                 lp = d.logpdf(x);
                 changed = true;
             }
             if (in_sub) sw += lp;
         }
-        tr.val[SITE] = x; tr.lp[SITE] = lp; tr.present |= bit;
-        return x;
+        MP_FN_PUT_();
+#undef MP_FN_PUT_
+#undef MP_FN_PREV_
+    }
+    template <int SITE, class Dist>
+    MP_HD double at(const Dist& d) {
+        double x[1];
+        at_k<SITE, 1>(mp_fn_scalar<Dist>{d}, x);
+        return x[0];
     }
     template <int SITE>
     MP_HD double normal(double mu, double sd, double ln_sd) { return at<SITE>(mp_fn_normal{mu, sd, ln_sd}); }
@@ -204,6 +254,16 @@ struct mp_fn_handler {
     MP_HD bool bernoulli(double p) { return at<SITE>(mp_fn_bernoulli{p}) != 0.; }
     template <int SITE>
     MP_HD double uniform(double a, double b) { return at<SITE>(mp_fn_uniform{a, b}); }
+    // vector-valued sites (two slots each): `uniform_2d(bounds) %= addr`, `mvnormal(mu, cov) %= addr` with the covariance constants
+    // hoisted by the functor (cov itself, row-major, is what a dynamic interpretation hands its own mvnormal)
+    template <int SITE>
+    MP_HD void uniform_2d(double xmin, double xmax, double ymin, double ymax, double neg_ln_area, double* out) {
+        at_k<SITE, 2>(mp_fn_uniform_2d{xmin, xmax, ymin, ymax, neg_ln_area}, out);
+    }
+    template <int SITE>
+    MP_HD void mvnormal2(const double* mu, const double* /*cov*/, const double* cov_inv, double ln_det, const double* chol, double* out) {
+        at_k<SITE, 2>(mp_fn_mvnormal2{{mu[0], mu[1]}, {cov_inv[0], cov_inv[1], cov_inv[2], cov_inv[3]}, ln_det, chol[0], chol[2], chol[3]}, out);
+    }
 
     // previous choices of `sites` that this visit did not reach: they leave the trace; their log-densities in site order
     MP_HD double collect(uint32_t sites) {

@@ -12,8 +12,10 @@
 // mp_mh_create_fn and driven by the same mp_mh_step / mp_regen_mh_step as the hand-written kernels.
 #pragma once
 #include <string>
+#include <vector>
 
 #include "mp_genfn.h"
+#include "mp_linalg.h"
 
 // ---------------------------------------------------------------------------------------
 // hierarchical_model (modppl/tests/dyngenfns/hierarchical.rs:17-47), kind 101 — the functor form of the model the
@@ -323,3 +325,62 @@ inline bool mp_parse_kat_fn(const double*, int n_params, M& m, std::string& err)
 MP_REGISTER_MH_MODEL(110, mp_kat_bx_fn, mp_parse_kat_fn<mp_kat_bx_fn>)
 MP_REGISTER_MH_MODEL(111, mp_kat_mxy_fn, mp_parse_kat_fn<mp_kat_mxy_fn>)
 MP_REGISTER_MH_MODEL(112, mp_kat_bsub_fn, mp_parse_kat_fn<mp_kat_bsub_fn>)
+
+// ---------------------------------------------------------------------------------------
+// pointed_2d_model + pointed_2d_drift_proposal (modppl/tests/dyngenfns/simple.rs:27-41; driven by tests/mh.rs:50-68), kind 120 —
+// vector-valued sites through the generic layer: the functor form of the model the hand-written k_pointed_iterate restates
+// (tests/test_gpu_mh.py holds the two, and the checker's own restatement, to the same bits).
+//   latent ~ uniform_2d(bounds) %= "latent";  obs ~ mvnormal(latent, cov) %= "obs"
+//   params = {xmin, xmax, ymin, ymax, cov row-major[4]}; the observation is a constraint on OBS (two values: slots OBS, OBS + 1).
+//   proposal 1 (args = noise covariance row-major[4]):  mvnormal(tr["latent"], noise) %= "latent"
+// Site ids: LATENT = 1 as in the hand-written kernel and the checker's restatement (slots 1, 2), OBS = 3 (slots 3, 4).
+// ---------------------------------------------------------------------------------------
+struct mp_pointed_fn {
+    static constexpr int NS = 5;
+    enum { LATENT = 1, OBS = 3 };
+    static constexpr uint32_t sub_of(int) { return 0u; }
+    static constexpr bool is_bool(int) { return false; }
+    static constexpr int dim_of(int site) { return (site == LATENT || site == OBS) ? 2 : ((site == LATENT + 1 || site == OBS + 1) ? 0 : 1); }   // 0: a vector's further slot
+    double xmin, xmax, ymin, ymax, neg_ln_area;
+    double cov[4], cov_inv[4], chol[4], ln_det;
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        double latent[2], obs[2];
+        g.template uniform_2d<LATENT>(xmin, xmax, ymin, ymax, neg_ln_area, latent);
+        g.template mvnormal2<OBS>(latent, cov, cov_inv, ln_det, chol, obs);
+    }
+};
+// the hoisted constants of a 2 x 2 covariance: inverse, ln det, lower Cholesky factor (zeros where there is none)
+inline bool mp_pointed_cov(const double* c4, double* cov, double* inv, double* chol, double* ln_det, std::string& err) {
+    const std::vector<double> c(c4, c4 + 4);
+    std::vector<double> iv, L;
+    const double det = mp_host_det(c, 2);
+    if (!(det > 0.) || !mp_host_inverse(c, 2, iv)) { err = "covariance must be invertible with a positive determinant"; return false; }
+    if (!mp_host_cholesky(c, 2, L)) { err = "covariance without a Cholesky factor"; return false; }
+    for (int q = 0; q < 4; ++q) { cov[q] = c[q]; inv[q] = iv[q]; chol[q] = L[q]; }
+    *ln_det = mp_log(det);
+    return true;
+}
+inline bool mp_parse_pointed_fn(const double* params, int n_params, mp_pointed_fn& m, std::string& err) {
+    if (!params || n_params != 8) { err = "pointed model: params = {xmin, xmax, ymin, ymax, cov row-major[4]}"; return false; }
+    if (!(params[1] > params[0]) || !(params[3] > params[2])) { err = "pointed model: xmax > xmin and ymax > ymin"; return false; }
+    m.xmin = params[0]; m.xmax = params[1]; m.ymin = params[2]; m.ymax = params[3];
+    m.neg_ln_area = -mp_log((m.xmax - m.xmin) * (m.ymax - m.ymin));
+    return mp_pointed_cov(params + 4, m.cov, m.cov_inv, m.chol, &m.ln_det, err);
+}
+MP_REGISTER_MH_MODEL(120, mp_pointed_fn, mp_parse_pointed_fn)
+
+struct mp_pointed_drift_fn {
+    double cov[4], cov_inv[4], chol[4], ln_det;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        const double prev[2] = {tr.val[mp_pointed_fn::LATENT], tr.val[mp_pointed_fn::LATENT + 1]};
+        double out[2];
+        g.template mvnormal2<mp_pointed_fn::LATENT>(prev, cov, cov_inv, ln_det, chol, out);
+    }
+};
+inline bool mp_parse_pointed_drift_fn(const double* args, int n_args, mp_pointed_drift_fn& p, std::string& err) {
+    if (!args || n_args != 4) { err = "pointed drift proposal takes the noise covariance, row-major[4]"; return false; }
+    return mp_pointed_cov(args, p.cov, p.cov_inv, p.chol, &p.ln_det, err);
+}
+MP_REGISTER_MH_PROPOSAL(1, mp_pointed_fn, mp_pointed_drift_fn, mp_parse_pointed_drift_fn)

@@ -470,12 +470,19 @@ class PointedChains:
     latent ~ uniform_2d(bounds), obs ~ mvnormal(latent, obs_cov) observed — the model of `test_metropolis_hastings_dyngenfn`
     (tests/mh.rs:50-68).  `mh(noise)` = mh(&pointed_2d_model, trace, &pointed_2d_drift_proposal, noise)."""
 
-    def __init__(self, bounds, obs_cov, obs, num_chains, seed, *, device=0, stream=None):
+    def __init__(self, bounds, obs_cov, obs, num_chains, seed, *, device=0, stream=None, functor=False):
         self._L = capi.load()
         b = np.ascontiguousarray(bounds, dtype=np.float64).reshape(4)
         c = np.ascontiguousarray(obs_cov, dtype=np.float64).reshape(4)
         o = np.ascontiguousarray(obs, dtype=np.float64).reshape(2)
         self.num_chains = int(num_chains)
+        self._fn = None
+        if functor:
+            # the same model and proposal as a REGISTERED functor with vector-valued sites (csrc/mp_mh_models.h kind 120: latent = slots
+            # 1, 2; obs = slots 3, 4), run by the generic handlers of csrc/mp_genfn.h: same results, bit for bit
+            self._fn = FunctionChains(capi.MP_MH_MODEL_POINTED_FN, np.concatenate([b, c]), {3: o[0], 4: o[1]}, num_chains, seed, device=device, stream=stream)
+            self._h = None
+            return
         h = C.c_void_p()
         capi.check(self._L.mp_mh_create_pointed(_dptr(b), _dptr(c), _dptr(o), self.num_chains, int(seed), int(device),
                                                 C.c_void_p(stream) if stream else None, C.byref(h)))
@@ -483,22 +490,31 @@ class PointedChains:
 
     def mh(self, noise, n_iters=1):
         nz = np.ascontiguousarray(noise, dtype=np.float64).reshape(4)
+        if self._fn is not None:
+            return self._fn.mh(1, nz, n_iters)
         acc = C.c_uint64()
         capi.check(self._L.mp_mh_step(self._h, capi.MP_MH_PROPOSAL_POINTED_DRIFT, _dptr(nz), 4, int(n_iters), C.byref(acc)))
         return acc.value
 
     def states(self):
         """[num_chains, 2] = latent."""
+        if self._fn is not None:
+            return np.ascontiguousarray(self._fn.trace()[0][:, 1:3])
         out = np.empty((self.num_chains, 2))
         capi.check(self._L.mp_mh_read_state(self._h, _dptr(out)))
         return out
 
     def logjp(self):
+        if self._fn is not None:
+            return self._fn.logjp()
         out = np.empty(self.num_chains)
         capi.check(self._L.mp_mh_read_logjp(self._h, _dptr(out)))
         return out
 
     def close(self):
+        if getattr(self, "_fn", None) is not None:
+            self._fn.close()
+            self._fn = None
         if getattr(self, "_h", None):
             self._L.mp_mh_destroy(self._h)
             self._h = None

@@ -33,6 +33,18 @@ inline uint32_t mhfn_site_of(const std::string& a) {   // the Philox site of an 
     return (uint32_t)std::stoul(a.substr(a.rfind('s') + 1));
 }
 
+// how many slots a site's value takes: models with vector-valued sites say so (M::dim_of: 2 for the head of a 2-vector, 0 for
+// its second slot), every other model's sites are scalars
+template <class M, class = void>
+struct mhfn_has_dim : std::false_type {};
+template <class M>
+struct mhfn_has_dim<M, std::void_t<decltype(M::dim_of(0))>> : std::true_type {};
+template <class M>
+int mhfn_dim(int s) {
+    if constexpr (mhfn_has_dim<M>::value) return M::dim_of(s);
+    else return 1;
+}
+
 using MhFnGen = DynGenFn<int, mp_fn_ret>;      // args = () as an int; retv = the body's mp_fn_ret (mp_genfn.h)
 using MhFnH = DynGenFnHandler<int, mp_fn_ret>;
 using MhFnTrace = Trace<int, DynTrie, mp_fn_ret>;
@@ -57,6 +69,18 @@ struct DynMhHandler {
     bool bernoulli(double p) { return g.template sample_at<bool>(oracle::bernoulli, p, addr<SITE>()); }
     template <int SITE>
     double uniform(double a, double b) { return g.template sample_at<double>(oracle::uniform, UniformParams{a, b}, addr<SITE>()); }
+    // vector-valued sites: one address, a Vec value (the checker's own uniform_2d / mvnormal, the latter from the covariance itself)
+    template <int SITE>
+    void uniform_2d(double xmin, double xmax, double ymin, double ymax, double /*neg_ln_area: hoisted by the device form*/, double* out) {
+        const Vec v = g.template sample_at<Vec>(oracle::uniform_2d, Bounds{xmin, xmax, ymin, ymax}, addr<SITE>());
+        out[0] = v[0]; out[1] = v[1];
+    }
+    template <int SITE>
+    void mvnormal2(const double* mu, const double* cov, const double* /*cov_inv*/, double /*ln_det*/, const double* /*chol*/, double* out) {
+        const Vec v = g.template sample_at<Vec>(oracle::mvnormal, MvNormalParams{Vec{mu[0], mu[1]}, Mat(2, {cov[0], cov[1], cov[2], cov[3]})}, addr<SITE>());
+        out[0] = v[0]; out[1] = v[1];
+    }
+
     // trace_at: under Update / Regenerate with nothing touched and diff NoChange the body is NOT run and the stored retv comes
     // back (dyngenfn.rs:362-366, 415-419) — which is why a functor may take a sub-call's results from its return value only
     template <uint32_t SITES, class Body>
@@ -78,8 +102,8 @@ struct MhFnView {
     bool has(int site) const { return (present >> site) & 1u; }
     double get(int site, double dflt) const { return has(site) ? val[site] : dflt; }
     explicit MhFnView(const DynTrie& data) {
+        for (int s = 0; s < M::NS; ++s) val[s] = 0.;
         for (int s = 0; s < M::NS; ++s) {
-            val[s] = 0.;
             const uint32_t sub = M::sub_of(s);
             const Trie* node = nullptr;
             if (sub) {
@@ -89,10 +113,14 @@ struct MhFnView {
                 node = data.search(mhfn_local_addr(s));
             }
             if (!node || !node->value) continue;
+            if (mhfn_dim<M>(s) == 0) continue;   // (a vector's further slot: filled with its head)
             present |= 1u << s;
             if (const double* d = std::any_cast<double>(node->value->get())) val[s] = *d;
             else if (const bool* b = std::any_cast<bool>(node->value->get())) val[s] = *b ? 1. : 0.;
-            else throw Panic("mh functor adapter: a choice that is neither f64 nor bool at site " + std::to_string(s));
+            else if (const Vec* v = std::any_cast<Vec>(node->value->get())) {
+                if ((int)v->size() != mhfn_dim<M>(s)) throw Panic("mh functor adapter: a vector choice of the wrong length at site " + std::to_string(s));
+                for (size_t j = 0; j < v->size(); ++j) { val[s + (int)j] = (*v)[j]; present |= 1u << (s + (int)j); }
+            } else throw Panic("mh functor adapter: a choice that is neither f64, bool nor Vec at site " + std::to_string(s));
         }
     }
 };
@@ -111,6 +139,18 @@ struct MhFnFlatHandler {
     bool bernoulli(double q) { return g.template sample_at<bool>(oracle::bernoulli, q, mhfn_flat_addr<M>(SITE)); }
     template <int SITE>
     double uniform(double a, double b) { return g.template sample_at<double>(oracle::uniform, UniformParams{a, b}, mhfn_flat_addr<M>(SITE)); }
+    // vector-valued sites: one address, a Vec value (the checker's own uniform_2d / mvnormal, the latter from the covariance itself)
+    template <int SITE>
+    void uniform_2d(double xmin, double xmax, double ymin, double ymax, double /*neg_ln_area: hoisted by the device form*/, double* out) {
+        const Vec v = g.template sample_at<Vec>(oracle::uniform_2d, Bounds{xmin, xmax, ymin, ymax}, mhfn_flat_addr<M>(SITE));
+        out[0] = v[0]; out[1] = v[1];
+    }
+    template <int SITE>
+    void mvnormal2(const double* mu, const double* cov, const double* /*cov_inv*/, double /*ln_det*/, const double* /*chol*/, double* out) {
+        const Vec v = g.template sample_at<Vec>(oracle::mvnormal, MvNormalParams{Vec{mu[0], mu[1]}, Mat(2, {cov[0], cov[1], cov[2], cov[3]})}, mhfn_flat_addr<M>(SITE));
+        out[0] = v[0]; out[1] = v[1];
+    }
+
     double exp_(double x) const { return o_exp(x); }
     double log_(double x) const { return o_ln(x); }
 };
@@ -151,7 +191,18 @@ struct MhFnModelT : MhFnModel {
         for (int q = 0; q < n; ++q) {
             const int s = sites[q];
             if (s < 0 || s >= M::NS) throw Panic("constraint site out of range");
-            if (M::is_bool(s)) c.observe(mhfn_flat_addr<M>(s), arc(vals[q] != 0.));
+            const int d = mhfn_dim<M>(s);
+            if (d == 0) continue;   // a vector's further slot: taken with its head below
+            if (d > 1) {            // a vector-valued site: its d slots make ONE choice at the head's address
+                Vec v((size_t)d);
+                for (int j = 0; j < d; ++j) {
+                    int at = -1;
+                    for (int q2 = 0; q2 < n; ++q2) if (sites[q2] == s + j) at = q2;
+                    if (at < 0) throw Panic("constraint on a vector-valued site must name all of its slots");
+                    v[(size_t)j] = vals[at];
+                }
+                c.observe(mhfn_flat_addr<M>(s), arc(v));
+            } else if (M::is_bool(s)) c.observe(mhfn_flat_addr<M>(s), arc(vals[q] != 0.));
             else c.observe(mhfn_flat_addr<M>(s), arc(vals[q]));
         }
         return c;

@@ -22,8 +22,6 @@ def make_ys(seed=0):
 @pytest.fixture(params=[False, True], ids=["handwritten", "functor"], autouse=True)
 def engine(request):
     global FUNCTOR
-    if request.param and "pointed" in request.node.name:
-        pytest.skip("the pointed model has hand-written kernels only")
     FUNCTOR = request.param
     yield request.param
 
@@ -176,7 +174,7 @@ def test_pointed_2d_mh_reference_loop(noise):
     import modppl_amd
 
     n, seed = 3000, 4
-    g = modppl_amd.PointedChains(BOUNDS, OBS_COV, [0.0, 0.0], n, seed)
+    g = modppl_amd.PointedChains(BOUNDS, OBS_COV, [0.0, 0.0], n, seed, functor=FUNCTOR)
     o = O.OraclePointedMH(BOUNDS, OBS_COV, [0.0, 0.0], n, seed, canonical=True)
     assert np.array_equal(g.states(), o.state())
     for it in (1, 4, 20):
@@ -192,7 +190,7 @@ def test_pointed_2d_posterior_full_size():
     mvnormal(0, obs_cov) likelihood itself."""
     import modppl_amd
 
-    g = modppl_amd.PointedChains(BOUNDS, OBS_COV, [0.0, 0.0], 1 << 20, 9)
+    g = modppl_amd.PointedChains(BOUNDS, OBS_COV, [0.0, 0.0], 1 << 20, 9, functor=FUNCTOR)
     acc = g.mh(NOISE, 200)
     assert 0.3 < acc / (200 * (1 << 20)) < 0.95
     st = g.states()

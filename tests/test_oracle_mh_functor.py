@@ -176,3 +176,36 @@ def test_static_handlers_robust_line_and_scaled_line():
     _same(s, d)
     assert s.regen_mh([0], 3) == d.regen_mh([0], 3)
     _same(s, d)
+
+
+BOUNDS = [-5.0, 5.0, -5.0, 5.0]            # tests/mh.rs:55
+OBS_COV = [1.0, -0.6, -0.6, 2.0]           # :61
+
+
+@pytest.mark.parametrize("noise", [[0.25, 0.0, 0.0, 0.25], [0.3, 0.1, 0.1, 0.2], [9.0, 0.0, 0.0, 9.0]])
+def test_vector_valued_sites_pointed_model_three_ways(noise):
+    """pointed_2d_model + pointed_2d_drift_proposal (tests/dyngenfns/simple.rs:27-41) as a REGISTERED functor (kind 120: uniform_2d
+    and mvnormal sites of two slots each): the product's static handlers on the host, the checker's dynamic interpretation of the
+    same functor, and the checker's independent hand restatement of the model (OraclePointedMH, models.hpp Pointed2D) — chain
+    states and accept counts equal, bit for bit, through the reference's test loop (tests/mh.rs:50-68) and masked regenerates."""
+    n, seed = 400, 4
+    params = BOUNDS + OBS_COV
+    cons = {3: 0.0, 4: 0.0}
+    s, d = _both(120, params, cons, n, seed)
+    hand = O.OraclePointedMH(BOUNDS, OBS_COV, [0.0, 0.0], n, seed, canonical=True)
+    _same(s, d)
+    assert np.array_equal(d.trace()[0][:, 1:3], hand.state())
+    for it in (1, 4, 12):
+        a = s.mh(1, noise, it)
+        assert a == d.mh(1, noise, it) == hand.mh(noise, it)
+        _same(s, d)
+        assert np.array_equal(d.trace()[0][:, 1:3], hand.state())
+        assert np.allclose(d.logjp(), hand.logjp(), rtol=1e-12, atol=1e-12)
+    # regenerate of the vector site (mask = its head slot), then of everything
+    assert s.regen_mh([1], 3) == d.regen_mh([1], 3)
+    _same(s, d)
+    assert s.regen_mh([], 1) == d.regen_mh([], 1) == n
+    _same(s, d)
+    v, p = d.trace()
+    assert np.all(p == 0b11110)
+    assert np.all(np.abs(v[:, 1:3]) <= 5.0)
