@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command;
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command;
 # it carries the content hash of the kernel sources it was measured with: a summary of another build is refused
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 N_PER_GPU = 1 << 20
@@ -219,10 +219,24 @@ def sub_benches(steps, warmup, which):
         # the accept test's ln (37): ~350 fp64 instructions, ~400 flop with their fused multiply-adds counted twice; a division
         # or a square root counts as the ~10 instructions it expands to.  State: (a, b, c, is_linear) = 8 k + 8 bytes with k = 3,
         # read and written once per LAUNCH of 3 * sweeps iterations (it lives in registers in between).
-        flop_per_it = 400.0
+        # MEASURED where profiles/r04/c4_flops.json belongs to this build (tools/collect_c4_flops.py over the SQ_INSTS_VALU_*_F64 counters of
+        # k_mh_iterate<0>: 64 lanes x (ADD + MUL + TRANS + 2 FMA) per chain-iteration); the hand count (400) otherwise, and the line says which
+        flop_per_it, flop_source = 400.0, "hand count of k_mh_iterate<0> (no PMC summary for this build)"
+        try:
+            from modppl_amd import build as _b
+
+            fj = json.load(open(os.path.join(ROOT, "profiles", "r04", "c4_flops.json")))
+            if fj.get("_measured", {}).get("source_hash") == _b.source_hash() and "k_mh_iterate<0>" in fj:
+                flop_per_it = float(fj["k_mh_iterate<0>"]["flop_per_chain_iteration"])
+                flop_source = "profiles/r04/c4_flops.json: " + fj["_measured"]["formula"] + " (rocprofv3 --pmc passes of tools/mh_bench.py: profiles/r04/pmc_mh_summary.txt)"
+            else:
+                flop_source += "; profiles/r04/c4_flops.json is from another build"
+        except Exception as e:   # noqa: BLE001
+            flop_source += f" ({type(e).__name__})"
         res["c4"] = {"workload": "regen-MH on the hierarchical model, 2^20 chains, masks cycling a, b, c (BASELINE.json configs[3])",
                      "chains": 1 << 20, "chain_iterations": 3 * sweeps, "chain_iterations_per_s": rate,
-                     "roofline": {"bound": "fp64 vector arithmetic", "flop_per_chain_iteration": flop_per_it, "achieved": rate * flop_per_it / 1e12,
+                     "roofline": {"bound": "fp64 vector arithmetic", "flop_per_chain_iteration": flop_per_it, "flop_source": flop_source,
+                                  "achieved": rate * flop_per_it / 1e12,
                                   "peak": 78.6, "unit": "TFLOP/s", "frac": rate * flop_per_it / 1e12 / 78.6,
                                   "hbm_bytes_per_chain_per_launch": 2 * (8 * 3 + 8), "iterations_per_launch": 3 * sweeps,
                                   "hbm_GBps": rate / (3 * sweeps) * 2 * (8 * 3 + 8) / 1e9, "hbm_frac": rate / (3 * sweeps) * 2 * (8 * 3 + 8) / 1e9 / HBM_PEAK_GBPS}}

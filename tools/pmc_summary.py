@@ -8,7 +8,7 @@ import csv
 import glob
 import sys
 
-KERNELS = ["k_propagate<mp_lgssm1", "k_draw_slots", "k_resolve_slots", "k_shard_own_draw", "k_shard_own_place", "k_shard_own_plan", "k_shard_table", "k_build_table"]
+KERNELS = ["k_propagate_mt<mp_lgssm1", "k_propagate<mp_lgssm1", "k_draw_slots", "k_resolve_slots", "k_shard_own_draw", "k_shard_own_place", "k_shard_own_plan", "k_shard_table", "k_build_table"]
 UNITS = 1 << 20   # particles (draws) per launch of the bench workload
 
 
