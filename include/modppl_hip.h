@@ -84,6 +84,12 @@ enum mp_resample_scheme {
                                   * u_g = (g + u0) / N; parents come out sorted, so the gather is coalesced and the multi-GPU
                                   * exchange near-neighbour */
     MP_RESAMPLE_STRATIFIED = 2,  /* extension: the same lattice with one uniform per output slot, u_g = (g + u_g') / N; sorted parents too */
+    MP_RESAMPLE_MULTINOMIAL_SPLIT = 3, /* particle_filter.rs:37-41's law for SHARDED filters at O(n) work per rank (opt-in): the offspring
+                                  * per rank are drawn first — Multinomial(N; rank masses), by binary splitting with one binomial variate
+                                  * per node (csrc/mp_binomial.h) — then every rank draws its own c_r parents i.i.d. from its own weights.
+                                  * Same law as MP_RESAMPLE_MULTINOMIAL, another seeded stream: the parents differ from the single
+                                  * filter's unless the world is one rank (then they are the same, bit for bit; an unsharded filter
+                                  * takes this value as MP_RESAMPLE_MULTINOMIAL).  DESIGN.md §8.3 */
 };
 enum mp_ess_mode {
     MP_ESS_REFERENCE = 0, /* particle_filter.rs:98-100: from the weights normalised by the LAST resample() (1/N before any) */
@@ -269,6 +275,7 @@ int32_t mp_pf_shard_resample_stats(mp_pf* h, uint64_t* fallbacks, uint64_t* exch
 int32_t mp_transport_rccl(void* nccl_comm, mp_transport* out);
 /* a communicator of the library's own: rank 0 makes the 128-byte id and hands it to the other ranks by whatever channel the
  * host has (MPI, a file, torch.distributed's store); every rank then creates its communicator on its device */
+int32_t mp_rccl_available(void);   /* 1 if this process can resolve an RCCL; local, no collective: agree on it before any rendezvous */
 int32_t mp_rccl_unique_id(void* out128);
 int32_t mp_rccl_comm_create(int32_t world, int32_t rank, const void* id128, int32_t device, void** comm_out);
 int32_t mp_rccl_comm_destroy(void* comm);

@@ -13,7 +13,7 @@ MP_ERR_INVALID_ARG, MP_ERR_STATE, MP_ERR_CONSTRAINTS, MP_ERR_DEGENERATE, MP_ERR_
 
 MP_MODEL_LGSSM1, MP_MODEL_SPIRAL, MP_MODEL_HMM, MP_MODEL_BEARINGS, MP_MODEL_LGSSM_BAND, MP_MODEL_POINTED_2D, MP_MODEL_LINE = 1, 2, 3, 4, 5, 6, 7
 MP_MODEL_LGSSM_DENSE = 8
-MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC, MP_RESAMPLE_STRATIFIED = 0, 1, 2
+MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC, MP_RESAMPLE_STRATIFIED, MP_RESAMPLE_MULTINOMIAL_SPLIT = 0, 1, 2, 3
 MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
 MP_PF_RECORD_HISTORY = 1
 MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER, MP_K_BIN_DRAWS = 0, 1, 2, 3
@@ -36,7 +36,7 @@ SYMBOLS = [
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
     "mp_pf_shard_owned_count", "mp_pf_shard_owned_expand", "mp_pf_shard_owned_commit",
     "mp_pf_shard_resample", "mp_pf_shard_resample_rccl", "mp_pf_shard_query_native", "mp_pf_shard_resample_stats", "mp_transport_rccl",
-    "mp_rccl_unique_id", "mp_rccl_comm_create", "mp_rccl_comm_destroy", "mp_pf_stream_copy",
+    "mp_rccl_available", "mp_rccl_unique_id", "mp_rccl_comm_create", "mp_rccl_comm_destroy", "mp_pf_stream_copy",
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
     "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_read_observations", "mp_mh_iterations", "mp_mh_destroy",
     "mp_mh_create_fn", "mp_mh_n_sites", "mp_mh_read_trace", "mp_fn_update", "mp_fn_regenerate", "mp_fn_assess", "mp_fn_propose",
@@ -152,6 +152,7 @@ def load():
     L.mp_pf_shard_query_native.argtypes = [p, C.POINTER(Transport), i32, i32, dp, dp]
     L.mp_pf_shard_resample_stats.argtypes = [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mp_transport_rccl.argtypes = [p, C.POINTER(Transport)]
+    L.mp_rccl_available.argtypes = []
     L.mp_rccl_unique_id.argtypes = [p]
     L.mp_rccl_comm_create.argtypes = [i32, i32, p, i32, C.POINTER(p)]
     L.mp_rccl_comm_destroy.argtypes = [p]

@@ -1,0 +1,102 @@
+// mp_binomial.h — Binomial(n, a / b) variates for the rank counts of the split multinomial resample (mp_pf_shard_kernels.h).
+//
+// particle_filter.rs:37-41 draws N i.i.d. parents from the job's normalised weights.  The number of those that land on the G
+// ranks is Multinomial(N; M_0 / Q .. M_{G-1} / Q) (M_r = rank r's share of the fixed-point mass Q), and given the counts the
+// parents of a rank are i.i.d. from that rank's own weights: drawing the counts first and then c_r parents per rank IS that
+// law, at O(n) work per rank instead of the O(N) enumeration the single filter's uniform stream needs (exchange = "owned").
+// The counts come from a binary splitting of the ranks (mp_split_counts below); each split is ONE binomial variate:
+//     n * p >= 10   BTRS, the transformed rejection sampler with squeeze of W. Hoermann, "The generation of binomial random
+//                   variates", J. Stat. Comput. Simul. 46 (1993), Algorithm BTRS — restated here from the published steps
+//     n * p <  10   sequential search from 0 on the probability recurrence (the same paper's inversion fallback, BINV)
+// with p <= 1/2 always (the smaller of the two masses is the one sampled).  Every uniform is named by a Philox counter
+// ( node , resample count , RESAMPLE << 16 | 3 , attempt ): attempt a of the sampler at tree node `node` takes block a as its
+// pair (U, V), so the variate is a pure function of (seed, resample count, node, n, a, b) — every rank computes the same counts
+// without talking to the others.  The arithmetic is single IEEE operations, mp_log and mp_exp (mp_math.h): host and device
+// agree bit for bit (oracle/src/inference.hpp restates it; tests/test_split_binomial.py checks both the bits and the law).
+#pragma once
+#include <stdint.h>
+
+#include "mp_math.h"
+#include "mp_philox.h"
+
+constexpr uint32_t MP_SITE_SPLIT_COUNTS = 3u;   // site word of the counts' uniforms in domain RESAMPLE (0: the draws, 1 / 2: lattices)
+constexpr uint32_t MP_BINOMIAL_MAX_ATTEMPTS = 1u << 16;
+
+// log(k!) - [ log(sqrt(2 pi)) + (k + 1/2) log(k + 1) - (k + 1) ]: tabulated below 10, the Stirling series beyond (Hoermann §3)
+MP_HD double mp_stirling_tail(double k) {
+    if (k <= 9.) {
+        const int i = (int)k;
+        // (a chain of selects, not a table: no constant-address-space array in a device function)
+        return i == 0 ? 0.0810614667953272 : i == 1 ? 0.0413406959554092 : i == 2 ? 0.0276779256849983 : i == 3 ? 0.02079067210376509
+             : i == 4 ? 0.0166446911898211 : i == 5 ? 0.0138761288230707 : i == 6 ? 0.0118967099458917 : i == 7 ? 0.0104112652619720
+             : i == 8 ? 0.00925546218271273 : 0.00833056343336287;
+    }
+    const double kp1 = k + 1.;
+    const double kp1sq = kp1 * kp1;
+    return (1.0 / 12. - (1.0 / 360. - 1.0 / 1260. / kp1sq) / kp1sq) / kp1;
+}
+
+// X ~ Binomial(n, p), 0 < p <= 1/2, n >= 1; uniforms: blocks 0, 1, ... of (node, rc, RESAMPLE << 16 | 3, .)
+MP_HD uint64_t mp_binomial_small_p(uint64_t n_u, double p, uint32_t node, uint32_t rc, uint32_t k0, uint32_t k1) {
+    const double n = (double)n_u;
+    const double q = 1. - p;
+    const uint32_t c2 = ((uint32_t)MP_DOM_RESAMPLE << 16) | MP_SITE_SPLIT_COUNTS;
+    if (n * p < 10.) {
+        // P(X = 0) = q^n; P(X = k) = P(X = k - 1) (n - k + 1) / k * p / q; walk up from 0 until the uniform is used up
+        const double s = p / q;
+        const double f0 = mp_exp(n * mp_log(q));
+        for (uint32_t att = 0; att < MP_BINOMIAL_MAX_ATTEMPTS; ++att) {
+            double u = mp_u01(mp_philox4x32_10(node, rc, c2, att, k0, k1).a);
+            double f = f0;
+            double k = 0.;
+            bool ok = true;
+            while (u >= f) {
+                u -= f;
+                k += 1.;
+                if (k > n || k > 512.) { ok = false; break; }   // rounding left a sliver of u beyond the last term: next attempt
+                f *= (n - k + 1.) / k * s;
+            }
+            if (ok) return (uint64_t)k;
+        }
+        return 0ull;
+    }
+    const double spq = mp_sqrt(n * p * q);
+    const double b = 1.15 + 2.53 * spq;
+    const double a = -0.0873 + 0.0248 * b + 0.01 * p;
+    const double c = n * p + 0.5;
+    const double v_r = 0.92 - 4.2 / b;
+    const double r = p / q;
+    const double alpha = (2.83 + 5.1 / b) * spq;
+    const double m = floor((n + 1.) * p);
+    for (uint32_t att = 0; att < MP_BINOMIAL_MAX_ATTEMPTS; ++att) {
+        const mp_u64x2 blk = mp_philox4x32_10(node, rc, c2, att, k0, k1);
+        const double u = mp_u01(blk.a) - 0.5;
+        double v = mp_u01(blk.b);
+        const double us = 0.5 - fabs(u);
+        const double k = floor((2. * a / us + b) * u + c);
+        if (!(k >= 0. && k <= n)) continue;             // (also what an infinite or NaN k from us == 0 falls into)
+        if (us >= 0.07 && v <= v_r) return (uint64_t)k;   // inside the squeeze: ~ 86 % of the accepted pairs
+        v = mp_log(v * alpha / (a / (us * us) + b));
+        const double ub = (m + 0.5) * mp_log((m + 1.) / (r * (n - m + 1.))) + (n + 1.) * mp_log((n - m + 1.) / (n - k + 1.)) +
+                          (k + 0.5) * mp_log(r * (n - k + 1.) / (k + 1.)) + mp_stirling_tail(m) + mp_stirling_tail(n - m) - mp_stirling_tail(k) -
+                          mp_stirling_tail(n - k);
+        if (v <= ub) return (uint64_t)k;
+    }
+    return (uint64_t)m;
+}
+
+// X ~ Binomial(n, a / b) for integer masses 0 <= a <= b, b > 0 (the left child's share of a node's mass)
+MP_HD uint64_t mp_binomial_ratio(uint64_t n, uint64_t a, uint64_t b, uint32_t node, uint32_t rc, uint32_t k0, uint32_t k1) {
+    if (n == 0ull || a == 0ull) return 0ull;
+    if (a >= b) return n;
+    const uint64_t other = b - a;
+    if (a <= other) return mp_binomial_small_p(n, (double)a / (double)b, node, rc, k0, k1);
+    return n - mp_binomial_small_p(n, (double)other / (double)b, node, rc, k0, k1);
+}
+
+// Levels of the splitting tree over `world` ranks: its leaves are the ranks padded with empty ones to a power of two
+MP_HD int mp_split_levels(int world) {
+    int L = 0;
+    while ((1 << L) < world) ++L;
+    return L;
+}

@@ -204,6 +204,20 @@ struct ModelOpsT : ModelOps {
             }
         }
         if constexpr (THREADS == 1024) {
+            if (a.drw && a.drw_v.shd_range) {   // a sharded filter's self-drawn resample (lattice range / split multinomial)
+                const int sch = a.drw >> 1;
+                if (sch == 1 || sch == 2)
+                    hipLaunchKernelGGL((k_propagate<Model, THREADS, false, true, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
+                                       a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                       a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                       a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
+                else
+                    hipLaunchKernelGGL((k_propagate<Model, THREADS, false, false, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
+                                       a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                       a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                       a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
+                return MP_K1_FORM_TILE;
+            }
             if ((a.drw >> 1) != 0) {   // the pending draws are a lattice's (systematic / stratified)
                 if (a.drw_v.nt > THREADS)
                     hipLaunchKernelGGL((k_propagate<Model, THREADS, true, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
@@ -515,6 +529,14 @@ struct mp_pf {
     int ow_nsc = 0, ow_R = 0, ow_wgs = 0;
     int ow_world = 0;
     int ow_scheme = 0;
+    // self-drawn form (lattice schemes, split multinomial; mp_pf_shard_kernels.h): own offspring have their targets in closed form
+    int use_shard_self = 1;               // MP_SHARD_SELF=0: the lattice schemes keep the window form (k_shard_own_draw / _place) — A/B and tests
+    bool ow_self = false;                 // the resample being run (count .. commit) is self-drawn
+    bool ow_solo_folded = false;          // (world of one) its scalars have been folded already (a synchronous commit): the next k_propagate must not
+    int ow_rank = 0;
+    mp_own_range* ow_range_solo = nullptr;   // {0, n}: a world of one owns every draw
+    bool pending_shard = false;           // with draw_pending: the pending draws are a sharded filter's self-drawn ones (world ps_world, rank ps_rank)
+    int ps_world = 1, ps_rank = 0;
     bool sharded = false;
     // ancestry record (MP_PF_RECORD_HISTORY): the event log from which `traces[i].retv` is rebuilt
     struct HistEvent { int kind; void* buf; };  // kind 0: states after an Unfold step ([n][d] f64); 1: parents of a resample ([n] u32)
@@ -761,7 +783,20 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         d.guide_old = h->guide; d.scal = h->scal; d.parent = h->parent;
         d.n_global = h->n_global; d.nt = h->nt; d.S = h->S;
     }
-    if (a.drw) { a.dfr_row = nullptr; a.dfr_lt = nullptr; }   // (not read: the kernel writes them through the struct's pointers)
+    if (a.drw && h->pending_shard) {
+        // a sharded filter's self-drawn resample: the table is this rank's slice of the job's (k_shard_table's arrays; in a world of one
+        // the table the last level-0 launch left), own offspring [0, c_me) of ow_range, the slots beyond read their received rows
+        mp_k1_draw& d = a.drw_v;
+        const bool solo = h->ps_world == 1;
+        const size_t off = (size_t)h->ps_rank * (size_t)h->nt;
+        d.tile_m_old = solo ? (const double*)h->tab_ratio : (const double*)h->sh_ratio_all + off;
+        d.tile_W_old = solo ? (const u64*)h->tab_W : (const u64*)h->sh_tW_all + off;
+        d.tile_W2_old = solo ? (const u64*)h->tab_incl : (const u64*)h->sh_incl_all + off;
+        d.shd_range = solo ? h->ow_range_solo : h->ow_range;
+        d.shd_head = (solo && !h->ow_solo_folded) ? (const mp_tab_head*)h->tab_head : nullptr;
+        d.shd_rank = h->ps_rank; d.shd_world = h->ps_world;
+        a.dfr_lt = nullptr;   // (dfr_row: the flags of the slots other ranks fill)
+    } else if (a.drw) { a.dfr_row = nullptr; a.dfr_lt = nullptr; }   // (not read: the kernel writes them through the struct's pointers)
     a.rc = h->pending_rc;
     a.dyn_lds = a.drw ? 24 * (size_t)h->nt : 0;
     a.grid = h->nt;
@@ -787,6 +822,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
             h->tile_m = reinterpret_cast<double*>(h->tiles_own); h->tile_W = h->tiles_own + h->nt; h->tile_W2 = h->tiles_own + 2 * (size_t)h->nt;
         }
         h->draw_pending = false;
+        h->pending_shard = false;
         h->parents_deferred = !a.drw;   // (a launch that made the draws itself wrote parent[] as well)
         h->deferred = false;
     }
@@ -896,6 +932,8 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (env && env[0] == '0') h->use_k1_table = 0;
         env = getenv("MP_FUSED_DRAWS");
         if (env && env[0] == '0') h->use_fused_draws = 0;
+        env = getenv("MP_SHARD_SELF");
+        if (env && env[0] == '0') h->use_shard_self = 0;
         env = getenv("MP_K1_MT");
         if (env && env[0] == '0') h->use_k1_mt = 0;
         HIPCK(hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device));
@@ -1056,15 +1094,25 @@ static int32_t launch_draws(mp_pf* h, int32_t scheme, uint32_t rc) {
 }
 
 // the draws a resample left to the next k_propagate, made now because something else needs them first
+static int32_t launch_self_draws(mp_pf* h, int scheme, uint32_t rc, int world, int rank);
 static int32_t flush_draws(mp_pf* h) {
     if (!h->draw_pending) return MP_OK;
     h->draw_pending = false;
+    if (h->pending_shard) {
+        h->pending_shard = false;
+        if (h->ps_world == 1 && !h->ow_solo_folded) {   // (what the next k_propagate would have done on the way)
+            hipLaunchKernelGGL(k_shard_solo_fold, dim3(1), dim3(1), 0, h->stream, (const mp_tab_head*)h->tab_head, h->scal, h->S, h->n_global);
+            h->ow_solo_folded = true;
+        }
+        return launch_self_draws(h, h->pending_scheme, h->pending_rc, h->ps_world, h->ps_rank);
+    }
     return launch_draws(h, h->pending_scheme, h->pending_rc);
 }
 
 int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (!h) return mp_fail(MP_ERR_INVALID_ARG, "null handle");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
+    if (scheme == MP_RESAMPLE_MULTINOMIAL_SPLIT) scheme = MP_RESAMPLE_MULTINOMIAL;   // (one rank: the same draws, include/modppl_hip.h)
     if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC && scheme != MP_RESAMPLE_STRATIFIED)
         return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: resample runs through the mp_pf_shard_* phases");
@@ -1553,7 +1601,8 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
 static void owned_free(mp_pf* h) {
     (void)hipFree(h->ow_seg_lt); (void)hipFree(h->ow_seg_row);
     (void)hipFree(h->ow_sccnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
-    (void)hipFree(h->ow_range); (void)hipFree(h->ow_ticket); (void)hipFree(h->ow_kthr);
+    (void)hipFree(h->ow_range); (void)hipFree(h->ow_ticket); (void)hipFree(h->ow_kthr); (void)hipFree(h->ow_range_solo);
+    h->ow_range_solo = nullptr;
     h->ow_kthr = nullptr;
     h->ow_ticket = nullptr;
     h->ow_seg_lt = nullptr; h->ow_seg_row = nullptr;
@@ -1605,6 +1654,9 @@ static int32_t owned_scratch(mp_pf* h, int world) {
     HIPCK(hipMemsetAsync(h->ow_call, 0, sizeof(unsigned long long) * SH_MAX_WORLD, h->stream));
     HIPCK(hipMemsetAsync(h->ow_plan, 0, sizeof(mp_owned_plan), h->stream));
     if (world == 1) {   // what k_shard_own_plan would find, every time (it is not launched in a world of one)
+        const mp_own_range all{0ull, h->n};
+        HIPCK(hipMalloc(&h->ow_range_solo, sizeof(mp_own_range)));
+        HIPCK(hipMemcpyAsync(h->ow_range_solo, &all, sizeof(all), hipMemcpyHostToDevice, h->stream));
         std::vector<uint32_t> base((size_t)nsc1);
         for (int k = 0; k < nsc1; ++k) base[(size_t)k] = (uint32_t)((u64)k * OWN_ROUND);
         HIPCK(hipMemcpyAsync(h->ow_base, base.data(), sizeof(uint32_t) * (size_t)nsc1, hipMemcpyHostToDevice, h->stream));
@@ -1635,11 +1687,34 @@ static int32_t owned_wait_plan(mp_pf* h, unsigned* flags) {
     }
 }
 
+// the next k_propagate can make a self-drawn resample's kept draws itself (its SHD form: lanes of two adjacent slots, one table
+// entry per thread); MP_FUSED_DRAWS=0 keeps them in a launch of their own
+static bool self_k1_draws(const mp_pf* h) {
+    return h->use_fused_draws && h->ops->can_draw && h->nt <= 1024 && !(h->flags & MP_PF_RECORD_HISTORY);
+}
+// the kept draws of a self-drawn resample (number rc) into the slot-order arrays: {tile-local target, start row} for slots [0, min(c_me, n))
+static int32_t launch_self_draws(mp_pf* h, int scheme, uint32_t rc, int world, int rank) {
+    const bool solo = world == 1;
+    const size_t off = (size_t)rank * (size_t)h->nt;
+    const u64* incl = solo ? (const u64*)h->tab_incl : (const u64*)h->sh_incl_all + off;
+    const u64* W = solo ? (const u64*)h->tab_W : (const u64*)h->sh_tW_all + off;
+    const double* ratio = solo ? (const double*)h->tab_ratio : (const double*)h->sh_ratio_all + off;
+    const mp_own_range* range = solo ? h->ow_range_solo : h->ow_range;
+    const bool tab_lds = h->nt <= 2048;
+    const size_t lds = tab_lds ? (size_t)h->nt * 24 : 0;
+    const bool lat = scheme != MP_RESAMPLE_MULTINOMIAL_SPLIT;
+    auto kern = lat ? (tab_lds ? k_shard_self_draw<1, true> : k_shard_self_draw<2, true>) : (tab_lds ? k_shard_self_draw<1, false> : k_shard_self_draw<2, false>);
+    const int grid = (int)std::min<u64>((h->n + 2 * SELF_THREADS - 1) / (2 * SELF_THREADS), 1024);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SELF_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), rc, scheme,
+                       incl, W, ratio, h->nt, world, rank, (const unsigned short*)h->guide, range, h->dfr_lt, h->dfr_row);
+    return check_launch("k_shard_self_draw");
+}
+
 int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
                                 uint64_t* counts_out) {
     if (!h || !d_tiles_all) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
-    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC && scheme != MP_RESAMPLE_STRATIFIED)
+    if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC && scheme != MP_RESAMPLE_STRATIFIED && scheme != MP_RESAMPLE_MULTINOMIAL_SPLIT)
         return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (world < 1 || world > SH_MAX_WORLD || rank < 0 || rank >= world) return mp_fail(MP_ERR_INVALID_ARG, "1 <= world <= 64, 0 <= rank < world");
     if ((u64)world * h->n != h->n_global) return mp_fail(MP_ERR_INVALID_ARG, "equal tile-aligned shards: world * n_particles must equal n_global");
@@ -1651,6 +1726,47 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     if (rc != MP_OK) return rc;
     rc = owned_scratch(h, world);
     if (rc != MP_OK) return rc;
+    h->ow_rank = rank;
+    h->ow_self = false;
+    h->ow_solo_folded = false;
+    // Self-drawn form (mp_pf_shard_kernels.h): the lattice schemes (unless MP_SHARD_SELF=0) and the split multinomial.  A world of
+    // one needs the table the last level-0 launch left (ensure_table); without it the lattice schemes keep the window form and
+    // the split multinomial runs as the plain one (in a world of one the two make the same draws, bit for bit).
+    bool self = (scheme == MP_RESAMPLE_MULTINOMIAL_SPLIT) || (scheme != MP_RESAMPLE_MULTINOMIAL && h->use_shard_self);
+    if (self && world == 1 && !((const void*)d_tiles_all == (const void*)h->tile_m && ensure_table(h))) self = false;
+    if (!self && scheme == MP_RESAMPLE_MULTINOMIAL_SPLIT) {
+        if (world > 1) return mp_fail(MP_ERR_STATE, "split multinomial resample: the self-drawn form is not available on this handle");
+        scheme = MP_RESAMPLE_MULTINOMIAL;
+    }
+    if (self) {
+        LaunchTimer lt(h, MP_K_BIN_DRAWS);
+        h->ow_self = true;
+        h->ow_scheme = scheme;
+        if (world > 1) {
+            // the job's table, the offspring per rank (lattice: closed form; split: the binomial tree) and this rank's own range; then
+            // the exchange plan from the counts alone
+            launch_shard_table(h, (const u64*)d_tiles_all, world, h->ow_call, (int)scheme, rank, h->ow_range, h->ow_kthr);
+            mp_own_plan_args pa;
+            pa.n = h->n; pa.n_global = h->n_global; pa.cap = (u64)capacity;
+            pa.world = world; pa.nsc = 0; pa.lattice = 0; pa.S = h->S;
+            pa.sccnt = h->ow_sccnt; pa.c_all = h->ow_call;
+            pa.scal = h->scal; pa.undo = h->scal_undo; pa.head = nullptr;
+            pa.base = h->ow_base; pa.plan_out = h->ow_plan; pa.pub = h->d_pub; pa.seq = ++h->ow_seq;
+            pa.range = h->ow_range; pa.Wd = (u64)OWN_ROUND;
+            hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, pa);
+        }
+        rc = check_launch("self-drawn resample: table / plan");
+        if (rc != MP_OK) return rc;
+        if (counts_out && world == 1) {
+            counts_out[0] = h->n;
+        } else if (counts_out) {
+            HIPCK(stream_wait(h->stream));
+            if (h->h_pub->degenerate)
+                return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
+            for (int r = 0; r < world; ++r) counts_out[r] = h->h_pub->counts[r];
+        }
+        return MP_OK;
+    }
     owned_shape(h, world, scheme);
     {
         LaunchTimer lt(h, MP_K_BIN_DRAWS);
@@ -1712,6 +1828,25 @@ int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t
     if (recv_rows + h->n >= (1ull << 31)) return mp_fail(MP_ERR_INVALID_ARG, "exchange buffer rows must be < 2^31 (row indices carry a flag bit)");
     HIPCK(hipSetDevice(h->device));
     h->ow_last_cap = capacity;
+    if (h->ow_self) {
+        // the kept offspring are drawn by the next k_propagate itself where its kernel can (self_k1_draws), here otherwise; the
+        // surplus is looked up now (it travels), the deficit slots are flagged with the rows that will arrive
+        LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
+        if (!self_k1_draws(h)) {
+            int32_t rcs = launch_self_draws(h, h->ow_scheme, h->resample_count, world, rank);
+            if (rcs != MP_OK) return rcs;
+        }
+        if (world > 1) {
+            const size_t off = (size_t)rank * (size_t)h->nt;
+            auto kern = (h->ow_scheme == MP_RESAMPLE_MULTINOMIAL_SPLIT) ? k_shard_self_place<false> : k_shard_self_place<true>;
+            hipLaunchKernelGGL(kern, dim3(64), dim3(256), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
+                               h->resample_count, h->ow_scheme, h->ops->dim_state, world, rank, (u64)capacity, (const u64*)h->sh_incl_all + off,
+                               (const u64*)h->sh_tW_all + off, (const double*)h->sh_ratio_all + off, h->nt, (const unsigned short*)h->guide,
+                               (const mp_own_range*)h->ow_range, (const mp_cx*)h->cx, (const double*)h->x[h->cur], (const mp_owned_plan*)h->ow_plan,
+                               d_send_out, h->dfr_lt, h->dfr_row);
+        }
+        return check_launch("k_shard_self_place");
+    }
     if (world > 1) {   // (a world of one: k_shard_own_draw wrote the slot-order arrays itself; nothing is sent or received)
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         const unsigned grid = (unsigned)std::max(1, std::min(h->ow_scheme ? h->ow_wgs : h->ow_nsc, 2048));
@@ -1736,6 +1871,10 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
     unsigned flags = 0;
     double L_one = 0.;
     if (h->ow_world == 1) {
+        if (slow && h->ow_self && !h->ow_solo_folded) {   // nobody has folded this normalisation yet (the next k_propagate would have)
+            hipLaunchKernelGGL(k_shard_solo_fold, dim3(1), dim3(1), 0, h->stream, (const mp_tab_head*)h->tab_head, h->scal, h->S, h->n_global);
+            h->ow_solo_folded = true;
+        }
         if (slow) {   // no plan ran: the scalars themselves
             int32_t rcs = fetch_scalars(h);
             if (rcs != MP_OK) return rcs;
@@ -1768,6 +1907,14 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
     h->sh_parents_lazy = false;
     h->deferred = true;
     h->draw_pending = false;
+    h->pending_shard = false;
+    if (h->ow_self && self_k1_draws(h)) {   // the kept draws are left to the next k_propagate (flush_draws() when something else needs them first)
+        h->draw_pending = true;
+        h->pending_shard = true;
+        h->pending_rc = h->resample_count;
+        h->pending_scheme = h->ow_scheme;
+        h->ps_world = h->ow_world; h->ps_rank = h->ow_rank;
+    }
     h->parents_deferred = false;
     h->rows_fresh = false;
     h->resample_count += 1;

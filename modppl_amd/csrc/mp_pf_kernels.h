@@ -718,6 +718,9 @@ struct mp_k1_tail {
 // Philox block: k_draw_slots' work, without its launch, its lockstep round and the round trip of its output through memory).
 // Everything here belongs to the generation that was resampled and is not written by this launch before its last workgroup
 // runs (the table, tab.W) or at all (guide_old: the launch writes the other guide buffer).
+struct mp_own_range {   // a sharded filter's own draws of a resample — lattice schemes: g_lo <= g < g_hi of the job's lattice; split multinomial: its c_r draws, [0, c_r)
+    u64 g_lo, g_hi;
+};
 struct mp_k1_draw {
     // the tile scalars of the generation that was resampled: no workgroup of the level-0 launch that wrote them built the job's
     // tile table (mp_tab::ticket was null), every drawing workgroup builds it in LDS from these (buffers this launch does not
@@ -732,6 +735,12 @@ struct mp_k1_draw {
                               // store traffic in the middle of the phase that is bound by the memory fabric
     u64 n_global;
     int nt, S;
+    // SHD launches (a sharded filter's self-drawn resample, mp_pf_shard_kernels.h): this rank's own offspring are [0, g_hi - g_lo) of
+    // `shd_range` (device memory: k_shard_table wrote it); the kernel's first three arguments are then this rank's SLICE of the job's
+    // tile table {ratio, W, inclusive prefix} instead of tile scalars; shd_head: a world of one folds the scalars here (nobody else did)
+    const mp_own_range* shd_range;
+    const mp_tab_head* shd_head;
+    int shd_rank, shd_world;
 };
 __device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2, int S, double m, u64 n_global, int mode);
 __device__ __forceinline__ u64 mp_target(u64 k52, u64 Q);
@@ -805,7 +814,10 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
 // of its own, so that the headline kernel — 62 of its 64 registers in use — does not carry a second form of the table build
 // LAT: the pending draws are a lattice's (systematic / stratified, scheme = drw >> 1): targets from mp_target_lattice instead of a
 // Philox block per lane — again an instantiation of its own (its 64-bit divisions would cost the multinomial form registers)
-template <class Model, int THREADS, bool TAB2 = false, bool LAT = false>
+// SHD: the pending draws are a SHARDED filter's self-drawn ones (lattice range or split multinomial, mp_pf_shard_kernels.h): the table
+// is this rank's slice of the job's, own offspring p < c_me have their target in closed form, the slots beyond read the row that
+// arrived for them (dfr_row: MP_DRAW_RECV | index)
+template <class Model, int THREADS, bool TAB2 = false, bool LAT = false, bool SHD = false>
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(const double* __restrict__ pre_tm, const u64* __restrict__ pre_tW, const u64* __restrict__ pre_tW2, int pre_nt, int drw,
                                                             Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
@@ -862,7 +874,32 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             uint32_t lat_k32 = 0u;
             __shared__ double s_l1_red[THREADS / 64];
             __shared__ u64 s_l1_tot[THREADS / 64], s_l1_tot2[THREADS / 64];
-            if constexpr (!TAB2) {
+            u64 shd_lo = 0ull, shd_glo = 0ull, shd_cme = 0ull, shd_Q = 0ull;
+            if constexpr (SHD) {
+                static_assert(!TAB2, "SHD launches: at most one table entry per thread");
+                // this rank's slice of the job's table as k_shard_table left it (pre_tm = ratio, pre_tW = W, pre_tW2 = inclusive prefix),
+                // rebased to the rank's own share (lo, hi] of the fixed-point mass
+                const int nt_sl = dw.nt;
+                const mp_own_range* rgp = mp_as_global(dw.shd_range);
+                shd_glo = rgp->g_lo;
+                shd_cme = rgp->g_hi - shd_glo;
+                shd_lo = dw.shd_rank ? pre_tW2[-1] : 0ull;
+                shd_Q = pre_tW2[(u64)(dw.shd_world - dw.shd_rank) * (u64)nt_sl - 1];
+                if (have_tb) {
+                    s_incl[tb] = pre_tW2[tb] - shd_lo;
+                    s_W[tb] = pre_tW[tb];
+                    s_ratio[tb] = pre_tm[tb];
+                }
+                if constexpr (LAT) {
+                    lat_k32 = (drw >> 1) == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+                } else {   // the rank's own stream: block (p >> 1), word 3 = the rank (rank 0: the single filter's)
+                    blk = mp_philox4x32_10((uint32_t)(base >> 1), rc, (uint32_t)MP_DOM_RESAMPLE << 16, (uint32_t)dw.shd_rank, k0, k1);
+                }
+                if (dw.shd_head && blockIdx.x == 0 && threadIdx.x == 0) {
+                    const mp_tab_head* hd = mp_as_global(dw.shd_head);
+                    fold_scalars(dw.scal, hd->Q, hd->Q2, dw.S, hd->m, dw.n_global, 0);
+                }
+            } else if constexpr (!TAB2) {
                 // Level 1 of the normalisation by THIS workgroup, in LDS (build_tile_table_global's arithmetic, entry by entry):
                 // no workgroup of the previous launch stayed behind to build the job's table after everybody else had left — that
                 // serial tail (a round of remote loads, two barriers, the stores) was 3 - 4 us of every step's kernel.  Here the
@@ -993,14 +1030,19 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             MP_STAMP(0, 16, 0);
             __syncthreads();
             MP_STAMP(0, 17, 0);
-            const u64 Q = s_incl[dw.nt - 1];
+            const u64 Q = s_incl[dw.nt - 1];   // (SHD: the rank's own share, hi - lo)
             const double nt_over_Q = (double)dw.nt / (double)Q;   // only a starting guess for the tile walk: no effect on results
             uint32_t gslot[2], tile_of[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
             {
                 u64 tg;
-                if constexpr (LAT) tg = mp_target_lattice(drw >> 1, slot_offset + (base + q < n ? base + q : 0ull), lat_k32, rc, k0, k1, Q, dw.n_global);
+                if constexpr (SHD) {
+                    const bool own = base + q < shd_cme;   // (a slot beyond the rank's own offspring: any in-range target; overwritten below)
+                    if constexpr (LAT) tg = mp_target_lattice(drw >> 1, shd_glo + (own ? base + q : 0ull), lat_k32, rc, k0, k1, shd_Q, dw.n_global) - shd_lo;
+                    else tg = mp_target(mp_u52(q ? blk.b : blk.a), Q);
+                    if (!own) tg = 1ull;
+                } else if constexpr (LAT) tg = mp_target_lattice(drw >> 1, slot_offset + (base + q < n ? base + q : 0ull), lat_k32, rc, k0, k1, Q, dw.n_global);
                 else tg = mp_target(mp_u52(q ? blk.b : blk.a), Q);
                 mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)dw.nt, tg, nt_over_Q, &tile_of[q], &plt[q], &gslot[q]);
             }
@@ -1013,6 +1055,15 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 const u64 tbase = (u64)tile_of[q] * TILE;
                 const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
                 pm[q] = (uint32_t)tbase + (j0[q] > tlen - 1 ? tlen - 1 : j0[q]);   // row where the forward scan starts
+            }
+            if constexpr (SHD) {   // the slots this rank could not fill itself: the row that arrived for them (k_shard_self_place flagged them)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (base + q >= shd_cme) {
+                        pm[q] = base + q < n ? dfr_row[base + q] : 0u;
+                        plt[q] = 0ull;
+                    }
+                }
             }
             MP_STAMP(0, 19, 0);
         }
@@ -1028,6 +1079,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
 #define MP_RUN_PARTICLE(P, ZP)                                                                                                             \
     mp_run_particle<Model>(model, n, slot_offset, k0, k1, t, x_in, x_out, logw, obs.v, s0.v, overwrite, cx_old != nullptr, inv_rows, inv != nullptr, \
                            pm[P], &px0[P], base + (u64)(P), ZP, &lw[P], &xv[P], aux.x_rows != 0)
+    // what a drawing launch stores as a slot's parent: the local row — or, for a sharded filter's self-drawn resample, the GLOBAL slot
+    // id: slot_offset + the row, or what the exchange row says for a slot whose offspring came from another rank
+    auto parent_id = [&](uint32_t v) -> uint32_t {
+        if constexpr (SHD) return (v & MP_DRAW_RECV) ? (uint32_t)inv_rows[(u64)(v & ~MP_DRAW_RECV) * (u64)(D + 1) + D] : (uint32_t)slot_offset + v;
+        else return v;
+    };
+#define MP_PARENT_ID(V) parent_id(V)
     double px0[LANE_ITEMS];   // (written and read only with deferred draws)
     // Where a lane's deferred draws are looked up (every form gives the same parents; what differs is when a CU's 4096 row
     // gathers hit its vector-memory path, and bursts are what this kernel pays for):
@@ -1128,8 +1186,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
         if constexpr (CAN_DRAW) {
             if (drew) {   // this lane's two parents, slot order (particle_filter.rs:20 keeps `parents`): one 8-byte store
                 uint32_t* pp2 = mp_as_global(drw_v.parent);
-                if (base + 1 < n) *reinterpret_cast<uint2*>(pp2 + base) = make_uint2(pm[0], pm[1]);
-                else if (base < n) pp2[base] = pm[0];
+                if (base + 1 < n) *reinterpret_cast<uint2*>(pp2 + base) = make_uint2(MP_PARENT_ID(pm[0]), MP_PARENT_ID(pm[1]));
+                else if (base < n) pp2[base] = MP_PARENT_ID(pm[0]);
             }
         }
     } else {
@@ -1215,8 +1273,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 if constexpr (CAN_DRAW) {
                     if (drew) {   // this lane's two parents, slot order: one 8-byte store
                         uint32_t* pp = mp_as_global(drw_v.parent);
-                        if (base + 1 < n) *reinterpret_cast<uint2*>(pp + base) = make_uint2(pm[0], pm[1]);
-                        else if (base < n) pp[base] = pm[0];
+                        if (base + 1 < n) *reinterpret_cast<uint2*>(pp + base) = make_uint2(MP_PARENT_ID(pm[0]), MP_PARENT_ID(pm[1]));
+                        else if (base < n) pp[base] = MP_PARENT_ID(pm[0]);
                     }
                 }
                 MP_STAMP(0, 24, 0);
@@ -1229,8 +1287,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 if constexpr (CAN_DRAW) {
                     if (drew) {
                         uint32_t* pp2 = mp_as_global(drw_v.parent);
-                        if (base + 1 < n) *reinterpret_cast<uint2*>(pp2 + base) = make_uint2(pm[0], pm[1]);
-                        else if (base < n) pp2[base] = pm[0];
+                        if (base + 1 < n) *reinterpret_cast<uint2*>(pp2 + base) = make_uint2(MP_PARENT_ID(pm[0]), MP_PARENT_ID(pm[1]));
+                        else if (base < n) pp2[base] = MP_PARENT_ID(pm[0]);
                     }
                 }
             }
@@ -1239,6 +1297,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
         for (int p = 0; p < LANE_ITEMS; ++p) MP_RUN_PARTICLE(p, &z[p * NS]);
     }
 #undef MP_RUN_PARTICLE
+#undef MP_PARENT_ID
     MP_STAMP(0, 3, 0);
 
     // ---- level 0 of normalize_weights for this tile, while everything is still in registers ----

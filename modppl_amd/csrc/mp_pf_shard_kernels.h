@@ -3,6 +3,7 @@
 // slot-order exchange (variable-size three-pass route, fixed-capacity single-pass route, owner-side resolve), adoption.
 // Protocol: include/modppl_hip.h "sharded filter", DESIGN.md §8.
 #pragma once
+#include "mp_binomial.h"
 // ---------------------------------------------------------------------------------------------
 // sharded filter phases (include/modppl_hip.h "sharded filter").  Shards are tile-aligned, so a shard's tiles are
 // tiles of the job; every rank gathers all tiles' (m, W, W2) and builds the same table.
@@ -262,9 +263,34 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
 // Before the route, one workgroup: unpack the gathered tiles, build the job's tile table ONCE (inclusive prefix of T_b to
 // global memory), zero the request counters, and fold this normalisation into the filter scalars (L, ESS, log-ML),
 // keeping a copy for the case that the fixed-capacity exchange overflows.
-struct mp_own_range {                        // lattice schemes: this rank's own draws are g_lo <= g < g_hi
-    u64 g_lo, g_hi;
-};
+// (mp_own_range — this rank's own draws of a resample — is declared in mp_pf_kernels.h: k_propagate's SHD form reads it too)
+constexpr int MP_SCHEME_SPLIT = 3;           // MP_RESAMPLE_MULTINOMIAL_SPLIT (include/modppl_hip.h): sharded resamples only
+// Offspring per rank of the split multinomial resample (mp_binomial.h): binary splitting of the N draws over the ranks, one binomial
+// variate per tree node, the nodes of a level by different lanes.  s_bound[r] = the job's inclusive prefix of T_b at the end of rank
+// r's tiles; s_n = [2 * 64] heap of draw counts (node k: children 2k, 2k + 1; leaf of rank r: P + r).  Called by EVERY thread of the
+// workgroup (barriers); the counts are s_n[P + r] afterwards, P = 1 << mp_split_levels(world).
+__device__ __forceinline__ void mp_split_counts(const u64* s_bound, int world, u64 n_global, uint32_t rc, uint32_t k0, uint32_t k1, u64* s_n) {
+    const int tid = threadIdx.x;
+    const int L = mp_split_levels(world), P = 1 << L;
+    if (tid == 0) s_n[1] = n_global;
+    __syncthreads();
+    for (int l = 0; l < L; ++l) {
+        if (tid < (1 << l)) {
+            const int node = (1 << l) + tid;
+            const int width = P >> l;   // leaves under this node: [a, a + width), split at a + width / 2
+            const int a = tid * width, mid = a + width / 2, b = a + width;
+            // mass of the leaves [0, r): ranks beyond `world` are empty
+            const u64 pa = a <= 0 ? 0ull : s_bound[(a < world ? a : world) - 1];
+            const u64 pm = s_bound[(mid < world ? mid : world) - 1];   // (mid >= 1)
+            const u64 pb = s_bound[(b < world ? b : world) - 1];
+            const u64 nk = s_n[node];
+            const u64 left = mp_binomial_ratio(nk, pm - pa, pb - pa, (uint32_t)node, rc, k0, k1);
+            s_n[2 * node] = left;
+            s_n[2 * node + 1] = nk - left;
+        }
+        __syncthreads();
+    }
+}
 constexpr int SHT_THREADS = 1024;
 constexpr int SHT_PER = MAX_TILES / SHT_THREADS;   // tiles per thread, held in registers (8)
 __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
@@ -380,7 +406,16 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
             if (world > 1) c_all[tid] = 0ull;   // the draw kernel's workgroups add the offspring per rank up
         }
     }
-    if (c_all && scheme) {
+    if (c_all && scheme == MP_SCHEME_SPLIT) {   // (workgroup-uniform)
+        __shared__ u64 s_heap[2 * SH_MAX_WORLD];
+        mp_split_counts(s_bound, world, n_global, rc, k0, k1, s_heap);
+        if (tid < world) {
+            const u64 c = s_heap[(1 << mp_split_levels(world)) + tid];
+            c_all[tid] = c;
+            if (tid == rank) { range->g_lo = 0ull; range->g_hi = c; }
+        }
+    }
+    if (c_all && (scheme == 1 || scheme == 2)) {
         if (tid < world) {
             const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
             const u64 B = s_bound[tid];
@@ -534,7 +569,16 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table_mw(const u64* __res
             c_all[tid] = 0ull;   // the draw kernel's workgroups add the offspring per rank up
         }
     }
-    if (c_all && scheme) {
+    if (c_all && scheme == MP_SCHEME_SPLIT) {   // (workgroup-uniform)
+        __shared__ u64 s_heap[2 * SH_MAX_WORLD];
+        mp_split_counts(s_bound, world, n_global, rc, k0, k1, s_heap);
+        if (tid < world) {
+            const u64 c = s_heap[(1 << mp_split_levels(world)) + tid];
+            c_all[tid] = c;
+            if (tid == rank) { range->g_lo = 0ull; range->g_hi = c; }
+        }
+    }
+    if (c_all && (scheme == 1 || scheme == 2)) {
         if (tid < world) {
             const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
             const u64 B = s_bound[tid];
@@ -1071,6 +1115,159 @@ __global__ __launch_bounds__(256) void k_shard_own_place(u64 n, u64 slot_offset,
         dfr_lt[c_me + k] = 0ull;
         dfr_row[c_me + k] = MP_DRAW_RECV | (uint32_t)idx;
     }
+}
+// ---------------------------------------------------------------------------------------------
+// Self-drawn owner-keeps resample (lattice schemes; split multinomial).  Offspring p of this rank — p = 0 .. c_me - 1, in the order
+// of its draws — has its target in CLOSED FORM:
+//   lattice             draw g = g_lo + p of the job's lattice (k_shard_table found the rank's range [g_lo, g_hi) by binary search)
+//   split multinomial   uniform p of the rank's own stream (Philox block p >> 1, word 3 = the rank) scaled to the rank's own share
+//                       (lo, hi] of the job's fixed-point mass (mp_binomial.h; k_shard_table drew the counts c_r)
+// so nothing is enumerated, compacted or scanned: kept offspring p < min(c_me, n) IS slot p.  The kept draws are made by the next
+// k_propagate itself (its SHD form, mp_pf_kernels.h) or, for models whose propagate kernel cannot draw and for readers that come
+// before the next step, by k_shard_self_draw below; k_shard_self_place looks up the O(sqrt N) surplus offspring p >= n for the send
+// buffer and flags the deficit slots [c_me, n) with the rows that will arrive for them.  Same offspring, same slots, same rows as
+// k_shard_own_draw / _plan / _place produce for the lattice schemes (tests/test_gpu_owned.py runs both).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ mp_u64x2 mp_split_block(u64 j_pair, uint32_t rc, int rank, uint32_t k0, uint32_t k1) {
+    return mp_philox4x32_10((uint32_t)j_pair, rc, (uint32_t)MP_DOM_RESAMPLE << 16, (uint32_t)rank, k0, k1);
+}
+// target of own offspring p relative to the rank's share: in [1, hi - lo]
+template <bool LATTICE>
+__device__ __forceinline__ u64 mp_self_trel(int scheme, u64 p, u64 g_lo, u64 lo, u64 span, u64 Q, u64 n_global, uint32_t k32, int rank, uint32_t rc,
+                                            uint32_t k0, uint32_t k1) {
+    if constexpr (LATTICE) {
+        return mp_target_lattice(scheme, g_lo + p, k32, rc, k0, k1, Q, n_global) - lo;
+    } else {
+        const mp_u64x2 blk = mp_split_block(p >> 1, rc, rank, k0, k1);
+        return mp_target(mp_u52((p & 1ull) ? blk.b : blk.a), span);
+    }
+}
+constexpr int SELF_THREADS = 512;   // a thread owns two ADJACENT slots of a trip
+template <int TABMODE, bool LATTICE>   // TABMODE 1: the rank's slice of the tile table copied to LDS (rebased); 2: probed where it lies
+__global__ __launch_bounds__(SELF_THREADS) void k_shard_self_draw(u64 n, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme,
+                                                                  const u64* __restrict__ incl_sl, const u64* __restrict__ W_sl,
+                                                                  const double* __restrict__ ratio_sl, int nt_local, int world, int rank,
+                                                                  const unsigned short* __restrict__ guide, const mp_own_range* __restrict__ range,
+                                                                  u64* __restrict__ dfr_lt, uint32_t* __restrict__ dfr_row) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_incl_lds = reinterpret_cast<u64*>(smem);
+    u64* s_W_lds = s_incl_lds + (TABMODE == 1 ? nt_local : 0);
+    double* s_ratio_lds = reinterpret_cast<double*>(s_W_lds + (TABMODE == 1 ? nt_local : 0));
+    const int tid = threadIdx.x;
+    const u64 lo = rank ? incl_sl[-1] : 0ull;   // uniform loads
+    const u64 hi = incl_sl[nt_local - 1];
+    const u64 Q = incl_sl[(u64)(world - rank) * nt_local - 1];
+    const u64 g_lo = range->g_lo, c_me = range->g_hi - range->g_lo;
+    const u64 keep = c_me < n ? c_me : n;
+    if constexpr (TABMODE == 1) {
+        for (int b = tid; b < nt_local; b += SELF_THREADS) {
+            s_incl_lds[b] = incl_sl[b] - lo;
+            s_W_lds[b] = W_sl[b];
+            s_ratio_lds[b] = ratio_sl[b];
+        }
+        __syncthreads();
+    }
+    const u64* t_incl = TABMODE == 1 ? s_incl_lds : incl_sl;
+    const u64* t_W = TABMODE == 1 ? s_W_lds : W_sl;
+    const double* t_ratio = TABMODE == 1 ? s_ratio_lds : ratio_sl;
+    const u64 span = hi - lo;
+    const double nt_over_span = (double)nt_local / (double)span;   // keep > 0 implies span > 0
+    const uint32_t k32 = (LATTICE && scheme == 1) ? mp_systematic_k32(rc, k0, k1) : 0u;
+    for (u64 p0 = ((u64)blockIdx.x * SELF_THREADS + tid) * 2ull; p0 < keep; p0 += (u64)gridDim.x * SELF_THREADS * 2ull) {
+        uint32_t gslot[2], tile_of[2], j0[2], srow[2];
+        u64 lt[2];
+        bool act[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            act[q] = p0 + q < keep;
+            const u64 trel = act[q] ? mp_self_trel<LATTICE>(scheme, p0 + q, g_lo, lo, span, Q, n_global, k32, rank, rc, k0, k1) : 1ull;
+            mp_locate_own(t_incl, t_W, t_ratio, (uint32_t)nt_local, TABMODE == 1 ? trel : trel + lo, trel, TABMODE == 1 ? 0ull : lo, nt_over_span,
+                          &tile_of[q], &lt[q], &gslot[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u64 tbase = (u64)tile_of[q] * TILE;
+            const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+            srow[q] = (uint32_t)tbase + (j0[q] > tlen - 1 ? tlen - 1 : j0[q]);
+        }
+        if (act[1]) {   // (p0 is even: aligned pair)
+            mp_u64v2 v2; v2.x = lt[0]; v2.y = lt[1];
+            *reinterpret_cast<mp_u64v2*>(dfr_lt + p0) = v2;
+            *reinterpret_cast<uint2*>(dfr_row + p0) = make_uint2(srow[0], srow[1]);
+        } else {
+            dfr_lt[p0] = lt[0]; dfr_row[p0] = srow[0];
+        }
+    }
+}
+// the surplus offspring p = n .. c_me - 1 (looked up here: row {state, parent's global id} into the send buffer where the plan says)
+// and the deficit slots [c_me, n) (MP_DRAW_RECV | the index of the row that will arrive); a handful of workgroups, grid-stride
+template <bool LATTICE>
+__global__ __launch_bounds__(256) void k_shard_self_place(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int scheme, int D,
+                                                          int world, int rank, u64 cap, const u64* __restrict__ incl_sl, const u64* __restrict__ W_sl,
+                                                          const double* __restrict__ ratio_sl, int nt_local, const unsigned short* __restrict__ guide,
+                                                          const mp_own_range* __restrict__ range, const mp_cx* __restrict__ cx,
+                                                          const double* __restrict__ x, const mp_owned_plan* __restrict__ plan, double* __restrict__ send,
+                                                          u64* __restrict__ dfr_lt, uint32_t* __restrict__ dfr_row) {
+    const u64 lo = rank ? incl_sl[-1] : 0ull;
+    const u64 hi = incl_sl[nt_local - 1];
+    const u64 Q = incl_sl[(u64)(world - rank) * nt_local - 1];
+    const u64 g_lo = range->g_lo, c_me = range->g_hi - range->g_lo;
+    const u64 span = hi - lo;
+    const double nt_over_span = (double)nt_local / (double)span;
+    const uint32_t k32 = (LATTICE && scheme == 1) ? mp_systematic_k32(rc, k0, k1) : 0u;
+    const u64 PS_me = plan->PS[rank];
+    const u64 stride = (u64)gridDim.x * blockDim.x, t0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 p = n + t0; p < c_me; p += stride) {
+        const u64 trel = mp_self_trel<LATTICE>(scheme, p, g_lo, lo, span, Q, n_global, k32, rank, rc, k0, k1);
+        uint32_t tile, gslot;
+        u64 lt;
+        mp_locate_own(incl_sl, W_sl, ratio_sl, (uint32_t)nt_local, trel + lo, trel, lo, nt_over_span, &tile, &lt, &gslot);
+        const uint32_t j0 = guide[gslot];
+        const u64 tbase = (u64)tile * TILE;
+        const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
+        const uint32_t row0 = (uint32_t)tbase + (j0 > tlen - 1 ? tlen - 1 : j0);
+        uint32_t par;
+        double x0;
+        mp_resolve_draw(cx, n, lt, row0, &par, &x0);
+        const u64 u = PS_me + (p - n);
+        int s2 = 0;
+        while (s2 + 1 < world && !(plan->D[s2] && u < plan->PD[s2] + plan->D[s2])) ++s2;
+        double* dst = nullptr;
+        if (cap) {
+            const u64 first = PS_me > plan->PD[s2] ? PS_me : plan->PD[s2];
+            const u64 jj = u - first;
+            if (jj < cap) dst = send + ((u64)s2 * cap + jj) * (u64)(D + 1);   // (jj >= cap: the plan has flagged it, nothing of this attempt is committed)
+        } else {
+            dst = send + (u - PS_me) * (u64)(D + 1);
+        }
+        if (dst) {
+            if (D == 1) dst[0] = x0;
+            else
+                for (int d = 0; d < D; ++d) dst[d] = x[(u64)par * D + d];
+            dst[D] = (double)(slot_offset + par);
+        }
+    }
+    const u64 PD_me = plan->PD[rank], D_me = plan->D[rank];
+    for (u64 k = t0; k < D_me; k += stride) {
+        u64 idx = k;
+        if (cap) {
+            const u64 u = PD_me + k;
+            int r = 0;
+            while (r + 1 < world && !(plan->S[r] && u < plan->PS[r] + plan->S[r])) ++r;
+            const u64 first = plan->PS[r] > PD_me ? plan->PS[r] : PD_me;
+            const u64 jj = u - first;
+            idx = jj >= cap ? 0ull : (u64)r * cap + jj;
+        }
+        dfr_lt[c_me + k] = 0ull;
+        dfr_row[c_me + k] = MP_DRAW_RECV | (uint32_t)idx;
+    }
+}
+// a world of one: the job's table is the one the last level-0 launch left; nobody has folded this normalisation into the filter
+// scalars yet (the next k_propagate does on the way, unless the host wants the resample's value first)
+__global__ void k_shard_solo_fold(const mp_tab_head* __restrict__ head, mp_dev_scalars* scal, int S, u64 n_global) {
+    fold_scalars(scal, head->Q, head->Q2, S, head->m, n_global, 0);
 }
 // After the resolve: "somebody overflowed" (flags are only ever OR-ed atomically) and the scalars of this normalisation,
 // where the host reads them after waiting for ev_resolved (host-mapped memory: no copy command, no stream sync).  A kernel of

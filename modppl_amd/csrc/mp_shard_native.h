@@ -152,8 +152,10 @@ int32_t mp_pf_shard_resample(mp_pf* h, const mp_transport* t, int32_t world, int
         }
         rc = mp_pf_shard_owned_commit(h, rows, log_total_weight, log_total_weight ? counts : nullptr);   // (a synchronous resample waits for the stream anyway)
         if (rc == MP_OK) {
+            // (an asynchronous resample never reads the counts back: the statistics then say "none" rather than repeat an
+            //  earlier resample's)
+            s->have_counts = log_total_weight != nullptr;
             if (log_total_weight) {
-                s->have_counts = true;
                 s->last_exchange_rows = 0;
                 for (int r = 0; r < world; ++r) { s->last_counts[r] = counts[r]; s->last_exchange_rows += counts[r] > h->n ? counts[r] - h->n : 0; }
             }
@@ -262,22 +264,24 @@ struct mp_rccl_api {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
-static mp_rccl_api* rccl_api() {
-    static mp_rccl_api api;
-    static bool tried = false;
-    if (tried) return api.lib ? &api : nullptr;
-    tried = true;
+static bool rccl_resolve(mp_rccl_api& api) {
     // by SONAME first: a process that already has an RCCL mapped (PyTorch's bundled one) gets THAT copy, not a second one
     for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
         api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (api.lib) break;
     }
-    if (!api.lib) return nullptr;
-#define MP_RCCL_SYM(F) api.F = reinterpret_cast<decltype(api.F)>(dlsym(api.lib, "nccl" #F)); if (!api.F) { api.lib = nullptr; return nullptr; }
+    if (!api.lib) return false;
+#define MP_RCCL_SYM(F) api.F = reinterpret_cast<decltype(api.F)>(dlsym(api.lib, "nccl" #F)); if (!api.F) { api.lib = nullptr; return false; }
     MP_RCCL_SYM(GetUniqueId) MP_RCCL_SYM(CommInitRank) MP_RCCL_SYM(CommDestroy) MP_RCCL_SYM(AllGather) MP_RCCL_SYM(GroupStart)
     MP_RCCL_SYM(GroupEnd) MP_RCCL_SYM(Send) MP_RCCL_SYM(Recv) MP_RCCL_SYM(GetErrorString)
 #undef MP_RCCL_SYM
-    return &api;
+    return true;
+}
+static mp_rccl_api* rccl_api() {
+    // resolved once, whichever host thread asks first (initialisation of a function-local static is synchronised)
+    static mp_rccl_api api;
+    static const bool ok = rccl_resolve(api);
+    return ok ? &api : nullptr;
 }
 #define RCCLCK(call)                                                                                                         \
     do {                                                                                                                     \
@@ -295,13 +299,27 @@ static int32_t rccl_all_to_all(void* ctx, const void* d_send, const uint64_t* se
                                const uint64_t* recv_off, const uint64_t* recv_bytes, int32_t world, void* stream) {
     mp_rccl_api* a = rccl_api();
     RCCLCK(a->GroupStart());
-    for (int q = 0; q < world; ++q) {
-        if (send_bytes[q]) RCCLCK(a->Send(static_cast<const char*>(d_send) + send_off[q], send_bytes[q], ncclUint8, q, (ncclComm_t)ctx, (hipStream_t)stream));
-        if (recv_bytes[q]) RCCLCK(a->Recv(static_cast<char*>(d_recv) + recv_off[q], recv_bytes[q], ncclUint8, q, (ncclComm_t)ctx, (hipStream_t)stream));
+    // an error inside the group still closes it (an open group would swallow every later RCCL call of this thread); the FIRST
+    // error is the one reported
+    ncclResult_t first = ncclSuccess;
+    const char* where = "";
+    for (int q = 0; q < world && first == ncclSuccess; ++q) {
+        if (send_bytes[q]) {
+            first = a->Send(static_cast<const char*>(d_send) + send_off[q], send_bytes[q], ncclUint8, q, (ncclComm_t)ctx, (hipStream_t)stream);
+            if (first != ncclSuccess) { where = "ncclSend"; break; }
+        }
+        if (recv_bytes[q]) {
+            first = a->Recv(static_cast<char*>(d_recv) + recv_off[q], recv_bytes[q], ncclUint8, q, (ncclComm_t)ctx, (hipStream_t)stream);
+            if (first != ncclSuccess) where = "ncclRecv";
+        }
     }
-    RCCLCK(a->GroupEnd());
+    const ncclResult_t end = a->GroupEnd();
+    if (first != ncclSuccess) return mp_fail(MP_ERR_HIP, std::string(where) + " failed: " + a->GetErrorString(first));
+    if (end != ncclSuccess) return mp_fail(MP_ERR_HIP, std::string("ncclGroupEnd failed: ") + a->GetErrorString(end));
     return MP_OK;
 }
+// local, non-collective: can this process resolve an RCCL at all?  (hosts agree on the answer BEFORE any rendezvous)
+int32_t mp_rccl_available(void) { return rccl_api() ? 1 : 0; }
 int32_t mp_rccl_unique_id(void* out128) {
     mp_rccl_api* a = rccl_api();
     if (!a) return mp_fail(MP_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");

@@ -222,11 +222,18 @@ def rccl_transport(L, group, world, rank, device_index):
     """A communicator of the LIBRARY's own over the ranks of `group` (mp_rccl_*): rank 0 makes the id, torch.distributed only
     carries its 128 bytes to the others.  -> (Transport, comm handle)"""
     ident = (C.c_ubyte * 128)()
+    err = None
     if rank == 0:
-        capi.check(L.mp_rccl_unique_id(ident))
-    box = [bytes(ident)]
+        try:
+            capi.check(L.mp_rccl_unique_id(ident))
+        except capi.ModpplError as e:
+            err = e
+    # rank 0 ALWAYS broadcasts (None = "no id"), so every rank runs the same sequence of collectives whatever failed where
+    box = [bytes(ident) if err is None else None]
     if world > 1:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if box[0] is None:
+        raise err or capi.ModpplError(capi.MP_ERR_UNSUPPORTED, "rank 0 could not make an RCCL id")
     ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
     comm = C.c_void_p()
     capi.check(L.mp_rccl_comm_create(world, rank, ident, device_index, C.byref(comm)))
@@ -305,8 +312,8 @@ class ShardedParticleSystem:
                  exchange=None):
         self.group = group
         self.exchange = exchange or os.environ.get("MP_SHARD_EXCHANGE", "owned")
-        if self.exchange not in ("owned", "exact"):
-            raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "exchange must be 'owned' or 'exact'")
+        if self.exchange not in ("owned", "exact", "split"):
+            raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "exchange must be 'owned', 'split' or 'exact'")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # MP_SHARD_ALWAYS_COLLECTIVE=1: issue the collectives even in a world of one (exercises the backend's API path)
@@ -338,7 +345,9 @@ class ShardedParticleSystem:
         self._fixed = bool(getattr(self.engine, "supports_fixed", False)) and not host_staging \
             and os.environ.get("MP_SHARD_FIXED", "1") == "1"
         self.fallbacks = 0
-        self._owned = self.exchange == "owned"
+        # "split": the owner-keeps exchange with the multinomial draws made rank by rank (MP_RESAMPLE_MULTINOMIAL_SPLIT: counts per
+        # rank first, then every rank its own — O(n) per rank, the same law, another seeded stream than the single filter's)
+        self._owned = self.exchange in ("owned", "split")
         if self._owned and not getattr(self.engine, "supports_owned", False):
             raise capi.ModpplError(capi.MP_ERR_UNSUPPORTED, "this engine has no owner-keeps exchange")
         # The owner-keeps resample of the product's engine is ONE library call (mp_pf_shard_resample): buffers, phases, fallback
@@ -351,28 +360,24 @@ class ShardedParticleSystem:
                 self._staged = HostStagedTransport(self.engine, group, self.world)
                 self._transport = self._staged.struct
             else:
-                # A communicator of the library's own.  If ANY rank cannot make one (no librccl.so.1 to resolve, an RCCL that
-                # refuses a second communicator), EVERY rank takes the round-2 protocol below over torch.distributed instead:
-                # the decision is a collective one, so that no rank waits in a collective the others never enter.
-                ok, why = 1, None
-                try:
-                    self._transport, self._rccl_comm = rccl_transport(self.engine._L, group, self.world, self.rank, self.dev.index or 0)
-                except Exception as e:   # noqa: BLE001
-                    ok, why = 0, e
+                # A communicator of the library's own.  If ANY rank cannot resolve an RCCL (no librccl.so.1), EVERY rank takes the
+                # round-2 protocol below over torch.distributed instead.  The ranks agree on that from a LOCAL probe
+                # (mp_rccl_available: no collective, no rendezvous inside it) before any of them enters the id broadcast or
+                # ncclCommInitRank, so every rank runs the same sequence of collectives.  A failure after that agreement (rank 0
+                # cannot make an id: every rank learns it from the broadcast; a communicator that does not come up) is an error.
+                ok = int(self.engine._L.mp_rccl_available()) if os.environ.get("MP_SHARD_RCCL", "1") == "1" else 0
                 if self.world > 1:
                     flag = torch.tensor([ok], dtype=torch.int32, device=self.dev)
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                     ok = int(flag.item())
-                if not ok:
-                    if self._rccl_comm is not None:
-                        self.engine._L.mp_rccl_comm_destroy(self._rccl_comm)
-                    self._transport, self._rccl_comm, self._native = None, None, False
+                if ok:
+                    self._transport, self._rccl_comm = rccl_transport(self.engine._L, group, self.world, self.rank, self.dev.index or 0)
+                else:
+                    self._native = False
                     if self.rank == 0:
                         import warnings
-                        warnings.warn(f"native RCCL transport unavailable ({why!r} on this or another rank): the sharded resample runs its "
-                                      "collectives through torch.distributed")
-                elif why is not None:
-                    raise why
+                        warnings.warn("native RCCL transport unavailable (librccl.so.1 does not resolve on this or another rank): the "
+                                      "sharded resample runs its collectives through torch.distributed")
         self._host_staging = host_staging
         self._ow_keep = None
         self._ox_cache, self._ox_flip = {}, 0   # exact-size exchange buffers
@@ -496,6 +501,8 @@ class ShardedParticleSystem:
 
     def resample(self, scheme=capi.MP_RESAMPLE_MULTINOMIAL, sync=True):
         """resample() -> log total weight (particle_filter.rs:103-116), multinomial over ALL shards."""
+        if self.exchange == "split" and scheme == capi.MP_RESAMPLE_MULTINOMIAL:
+            scheme = capi.MP_RESAMPLE_MULTINOMIAL_SPLIT
         with self._ctx():
             return self._resample(scheme, sync)
 
@@ -531,8 +538,8 @@ class ShardedParticleSystem:
         if self._native:
             value = self.engine.shard_resample_native(self._transport, self.world, self.rank, scheme, self._always, sync)
             self.fallbacks, rows, counts, _ = self.engine.shard_native_stats(self.world)
-            if rows is not None:
-                self.last_counts, self.last_exchange_rows = counts, rows
+            # (an asynchronous resample that kept to its capacity never reads its counts back: None, not an earlier resample's)
+            self.last_counts, self.last_exchange_rows = (counts, rows) if rows is not None else (None, None)
             return value
         e, w, d = self.engine, self.world, self.model.dim_state
         p_tiles = C.c_void_p(self._tiles.data_ptr())

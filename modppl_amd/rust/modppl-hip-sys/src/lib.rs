@@ -22,6 +22,7 @@ pub const MP_MODEL_LGSSM_DENSE: i32 = 8;
 pub const MP_RESAMPLE_MULTINOMIAL: i32 = 0;
 pub const MP_RESAMPLE_SYSTEMATIC: i32 = 1;
 pub const MP_RESAMPLE_STRATIFIED: i32 = 2;
+pub const MP_RESAMPLE_MULTINOMIAL_SPLIT: i32 = 3;
 pub const MP_MH_MODEL_HIERARCHICAL: i32 = 1;
 pub const MP_MH_MODEL_POINTED_2D: i32 = 2;
 pub const MP_MH_MODEL_HIERARCHICAL_FN: i32 = 101;   // the hierarchical model as a registered functor (mp_mh_create_fn)
@@ -114,6 +115,7 @@ extern "C" {
     pub fn mp_pf_shard_resample_stats(h: *mut mp_pf, fallbacks: *mut u64, exchange_rows: *mut u64, counts_out: *mut u64,
                                       capacity: *mut u64) -> i32;
     pub fn mp_transport_rccl(nccl_comm: *mut c_void, out: *mut mp_transport) -> i32;
+    pub fn mp_rccl_available() -> i32;
     pub fn mp_rccl_unique_id(out128: *mut c_void) -> i32;
     pub fn mp_rccl_comm_create(world: i32, rank: i32, id128: *const c_void, device: i32, comm_out: *mut *mut c_void) -> i32;
     pub fn mp_rccl_comm_destroy(comm: *mut c_void) -> i32;

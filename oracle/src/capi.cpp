@@ -17,6 +17,7 @@
 #include "soa.hpp"
 #include "functor_adapter.hpp"
 #include "mh_functor_adapter.hpp"
+#include "../../modppl_amd/csrc/mp_binomial.h"
 
 using namespace oracle;
 
@@ -825,6 +826,20 @@ void oracle_mp_normal_logpdf_both(const double* x, const double* mu, const doubl
         out_div[i] = mp_normal_logpdf_ln(x[i], mu[i], sd[i], ln);
     }
 }
+// Binomial(n, a / b) of the split multinomial's rank counts: the restatement (inference.hpp) and the product's own header
+// (mp_binomial.h) compiled for the host, case by case — must be the same integers
+void oracle_binomial_both(const uint64_t* n, const uint64_t* a, const uint64_t* b, const uint32_t* node, int64_t cases, uint64_t seed, uint32_t rc,
+                          uint64_t* out_restated, uint64_t* out_product) {
+    for (int64_t i = 0; i < cases; ++i) {
+        out_restated[i] = oracle::canonical_binomial(n[i], a[i], b[i], seed, rc, node[i]);
+        out_product[i] = mp_binomial_ratio(n[i], a[i], b[i], node[i], rc, (uint32_t)seed, (uint32_t)(seed >> 32));
+    }
+}
+void oracle_split_counts(const uint64_t* mass, int32_t world, uint64_t n_global, uint64_t seed, uint32_t rc, uint64_t* out) {
+    const std::vector<uint64_t> c = oracle::canonical_split_counts(std::vector<uint64_t>(mass, mass + world), n_global, seed, rc);
+    for (int32_t r = 0; r < world; ++r) out[r] = c[(size_t)r];
+}
+double oracle_stirling_tail(double k) { return oracle::canonical_stirling_tail(k); }
 void oracle_mp_log(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_log(x[i]); }
 void oracle_mp_sin(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_sin(x[i]); }
 void oracle_mp_cos(const double* x, int64_t n, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = mp_cos(x[i]); }

@@ -239,6 +239,100 @@ inline uint64_t canonical_target_lattice(int scheme, uint64_t seed, uint32_t rc,
     return canonical_target_systematic(g, scheme == 2 ? canonical_stratified_k32(seed, rc, g) : canonical_systematic_k32(seed, rc), Q, n_global);
 }
 
+// ---- split multinomial resample (sharded filters, opt-in) -----------------------------------------------
+// particle_filter.rs:37-41 draws N i.i.d. parents from the normalised weights.  Over G ranks the number landing on each rank is
+// Multinomial(N; M_r / Q) and, given the counts, a rank's parents are i.i.d. from its own weights.  The counts are drawn by
+// binary splitting of the ranks (padded with empty ranks to a power of two): node k of the heap (root 1) with n_k draws and
+// mass S_k gives its left child Binomial(n_k, S_left / S_k) of them.  One binomial variate (Hoermann 1993): BTRS for
+// n p >= 10, search from 0 on the probability recurrence below; the smaller of the two masses is the one sampled (p <= 1/2).
+// Uniforms: stream (slot = node, step = resample count, domain RESAMPLE, site 3); attempt a of the sampler takes uniforms
+// 2a (U) and 2a + 1 (V).  Restated independently of modppl_amd/csrc/mp_binomial.h; tests compare the two bit for bit.
+inline double canonical_stirling_tail(double k) {
+    static const double tab[10] = {0.0810614667953272,  0.0413406959554092, 0.0276779256849983, 0.02079067210376509, 0.0166446911898211,
+                                   0.0138761288230707,  0.0118967099458917, 0.0104112652619720, 0.00925546218271273, 0.00833056343336287};
+    if (k <= 9.) return tab[(int)k];
+    const double kp1 = k + 1., kp1sq = kp1 * kp1;
+    return (1.0 / 12. - (1.0 / 360. - 1.0 / 1260. / kp1sq) / kp1sq) / kp1;
+}
+inline uint64_t canonical_binomial_small_p(uint64_t n_u, double p, uint64_t seed, uint32_t rc, uint32_t node) {
+    Rng rng; rng.seed = seed; rng.slot = node; rng.step = rc; rng.at(DOM_RESAMPLE, 3);
+    const double n = (double)n_u, q = 1. - p;
+    if (n * p < 10.) {
+        const double s = p / q, f0 = mp_exp(n * mp_log(q));
+        for (uint32_t att = 0; att < (1u << 16); ++att) {
+            rng.n = 2 * att;
+            double u = rng.u01(), f = f0, k = 0.;
+            bool ok = true;
+            while (u >= f) {
+                u -= f;
+                k += 1.;
+                if (k > n || k > 512.) { ok = false; break; }
+                f *= (n - k + 1.) / k * s;
+            }
+            if (ok) return (uint64_t)k;
+        }
+        return 0;
+    }
+    const double spq = std::sqrt(n * p * q);
+    const double b = 1.15 + 2.53 * spq;
+    const double a = -0.0873 + 0.0248 * b + 0.01 * p;
+    const double c = n * p + 0.5;
+    const double v_r = 0.92 - 4.2 / b;
+    const double r = p / q;
+    const double alpha = (2.83 + 5.1 / b) * spq;
+    const double m = std::floor((n + 1.) * p);
+    for (uint32_t att = 0; att < (1u << 16); ++att) {
+        rng.n = 2 * att;
+        const double u = rng.u01() - 0.5;
+        double v = rng.u01();
+        const double us = 0.5 - std::fabs(u);
+        const double k = std::floor((2. * a / us + b) * u + c);
+        if (!(k >= 0. && k <= n)) continue;
+        if (us >= 0.07 && v <= v_r) return (uint64_t)k;
+        v = mp_log(v * alpha / (a / (us * us) + b));
+        const double ub = (m + 0.5) * mp_log((m + 1.) / (r * (n - m + 1.))) + (n + 1.) * mp_log((n - m + 1.) / (n - k + 1.)) +
+                          (k + 0.5) * mp_log(r * (n - k + 1.) / (k + 1.)) + canonical_stirling_tail(m) + canonical_stirling_tail(n - m) -
+                          canonical_stirling_tail(k) - canonical_stirling_tail(n - k);
+        if (v <= ub) return (uint64_t)k;
+    }
+    return (uint64_t)m;
+}
+inline uint64_t canonical_binomial(uint64_t n, uint64_t a, uint64_t b, uint64_t seed, uint32_t rc, uint32_t node) {
+    if (n == 0 || a == 0) return 0;
+    if (a >= b) return n;
+    const uint64_t other = b - a;
+    if (a <= other) return canonical_binomial_small_p(n, (double)a / (double)b, seed, rc, node);
+    return n - canonical_binomial_small_p(n, (double)other / (double)b, seed, rc, node);
+}
+// offspring per rank: mass[r] = rank r's share of Q
+inline void canonical_split_node(const std::vector<uint64_t>& mass, size_t a, size_t b, uint64_t n, uint32_t node, uint64_t seed, uint32_t rc,
+                                 std::vector<uint64_t>& out) {
+    if (b - a == 1) { if (a < out.size()) out[a] = n; return; }
+    const size_t mid = a + (b - a) / 2;
+    uint64_t S = 0, Sl = 0;
+    for (size_t r = a; r < b && r < mass.size(); ++r) { S += mass[r]; if (r < mid) Sl += mass[r]; }
+    const uint64_t left = canonical_binomial(n, Sl, S, seed, rc, node);
+    canonical_split_node(mass, a, mid, left, 2 * node, seed, rc, out);
+    canonical_split_node(mass, mid, b, n - left, 2 * node + 1, seed, rc, out);
+}
+inline std::vector<uint64_t> canonical_split_counts(const std::vector<uint64_t>& mass, uint64_t n_global, uint64_t seed, uint32_t rc) {
+    size_t P = 1;
+    while (P < mass.size()) P *= 2;
+    std::vector<uint64_t> out(mass.size(), 0);
+    canonical_split_node(mass, 0, P, n_global, 1, seed, rc, out);
+    return out;
+}
+// draw j of rank `rank` (its own stream: uniform j of (slot = j >> 1 block, step = resample count, domain RESAMPLE, site 0), block
+// word 3 = the rank — rank 0's stream IS the single filter's, so a world of one draws the single filter's parents)
+inline uint64_t canonical_split_u52(uint64_t seed, uint32_t rc, int rank, uint64_t j) {
+    const uint32_t ctr[4] = {(uint32_t)(j >> 1), rc, (uint32_t)DOM_RESAMPLE << 16, (uint32_t)rank};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    philox4x32_10(ctr, key, o);
+    const uint64_t bits = (j & 1) ? (((uint64_t)o[3] << 32) | o[2]) : (((uint64_t)o[1] << 32) | o[0]);
+    return bits >> 12;
+}
+
 // ---- particle_filter.rs ---------------------------------------------------------------
 template <class Args, class Data, class Ret>
 struct ParticleSystem {

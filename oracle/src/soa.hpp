@@ -386,6 +386,26 @@ struct SoaPf {
         const size_t nt_local = nt_all / (size_t)world;
         sh_own.clear();
         sh_call.assign((size_t)world, 0);
+        if (scheme == 3) {
+            // split multinomial (inference.hpp: canonical_split_counts): the counts from the rank masses, then this rank's own
+            // c_r draws inside its own share (lo, lo + M_r] of the job's fixed-point mass
+            std::vector<uint64_t> mass((size_t)world);
+            for (int r = 0; r < world; ++r)
+                mass[(size_t)r] = sh_c.inclT[(size_t)(r + 1) * nt_local - 1] - (r ? sh_c.inclT[(size_t)r * nt_local - 1] : 0);
+            sh_call = canonical_split_counts(mass, n_global, seed, resample_count);
+            const uint64_t lo = rank ? sh_c.inclT[(size_t)rank * nt_local - 1] : 0;
+            for (uint64_t j = 0; j < sh_call[(size_t)rank]; ++j) {
+                const uint64_t target = lo + canonical_target(canonical_split_u52(seed, resample_count, rank, j), mass[(size_t)rank]);
+                size_t tile; uint64_t lt;
+                canonical_locate(sh_c, target, &tile, &lt);
+                if ((int)(tile / nt_local) != rank) throw Panic("split multinomial: a rank's own draw left its tiles");
+                sh_own.push_back((uint32_t)canonical_row(sh_t.cum, tile % nt_local, lt));
+            }
+            for (int r = 0; r < world; ++r) c_all[r] = sh_call[(size_t)r];
+            ess_stale = sh_c.ess;
+            log_ml += sh_c.L - o_ln((double)n_global);
+            return;
+        }
         for (uint64_t g = 0; g < n_global; ++g) {
             Rng r = resample_rng(seed, DOM_RESAMPLE, resample_count, g);
             const uint64_t target = scheme != 0 ? canonical_target_lattice(scheme, seed, resample_count, g, sh_c.Q, n_global)

@@ -105,6 +105,12 @@ def load():
     L.oracle_mh_destroy.argtypes = [p]
     L.oracle_mp_exp.argtypes = [dp, i64, dp]
     L.oracle_mp_log.argtypes = [dp, i64, dp]
+    L.oracle_binomial_both.argtypes = [C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), i64, u64, u32, C.POINTER(u64), C.POINTER(u64)]
+    L.oracle_binomial_both.restype = None
+    L.oracle_split_counts.argtypes = [C.POINTER(u64), i32, u64, u64, u32, C.POINTER(u64)]
+    L.oracle_split_counts.restype = None
+    L.oracle_stirling_tail.argtypes = [C.c_double]
+    L.oracle_stirling_tail.restype = C.c_double
     L.oracle_mp_div_hoisted.argtypes = [dp, dp, i64, dp]
     L.oracle_mp_div_hoisted.restype = None
     L.oracle_mp_normal_logpdf_both.argtypes = [dp, dp, dp, i64, dp, dp]

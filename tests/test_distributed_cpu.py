@@ -105,7 +105,7 @@ if os.environ["MP_MODEL"] == "lgssm":
 else:
     model = modppl_amd.lgssm_band_model(4)
     obs = np.random.default_rng(1).normal(0, 1.2, size=(T, 4))
-pf = ShardedParticleSystem(model, N, seed, engine_cls=O.OracleShardEngine, exchange="owned")
+pf = ShardedParticleSystem(model, N, seed, engine_cls=O.OracleShardEngine, exchange=os.environ.get("MP_EXCHANGE", "owned"))
 ref = OwnedReference(model, N, seed, world) if rank == 0 else None
 def gather(a):
     out = [None] * world
@@ -118,7 +118,7 @@ for t in range(1, T):
     L = pf.resample(scheme)
     par, x = gather(pf.parents), gather(pf.states())
     if ref:
-        ok &= L == ref.resample(scheme)
+        ok &= L == ref.resample(int(os.environ.get("MP_REF_SCHEME", scheme)))
         ok &= bool(np.array_equal(par, ref.parents())) and bool(np.array_equal(x, ref.states()))
         moved += sum(max(c - N // world, 0) for c in ref.counts)
     pf.step(obs[t:t + 1])
@@ -133,13 +133,17 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("model,n,t,scheme", [("lgssm", 8192, 8, 0), ("band", 4096, 5, 0), ("lgssm", 4096, 5, 1)])
-def test_two_rank_owner_keeps_exchange(tmp_path, model, n, t, scheme):
-    """gloo, 2 ranks, exact-size all-to-all of the surplus == the same protocol with all shards in one process"""
+@pytest.mark.parametrize("model,n,t,scheme,nproc", [("lgssm", 8192, 8, 0, 2), ("band", 4096, 5, 0, 2), ("lgssm", 4096, 5, 1, 2),
+                                                     ("lgssm", 8192, 8, 3, 2), ("band", 6144, 5, 3, 3)])
+def test_two_rank_owner_keeps_exchange(tmp_path, model, n, t, scheme, nproc):
+    """gloo, 2 (3) ranks, exact-size all-to-all of the surplus == the same protocol with all shards in one process; scheme 3 = the
+    split multinomial (exchange="split" with the default scheme)"""
     script = tmp_path / "worker.py"
     script.write_text(OWNED_WORKER)
     env = dict(os.environ, MP_ROOT=ROOT, MP_MODEL=model, MP_N=str(n), MP_T=str(t), MP_SCHEME=str(scheme), OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    if scheme == 3:   # the worker calls resample(scheme) with the plain multinomial; the exchange turns it into the split one
+        env.update(MP_EXCHANGE="split", MP_SCHEME="0", MP_REF_SCHEME="3")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
@@ -215,3 +219,65 @@ def test_sharded_maybe_resample_follows_the_fresh_ess(exchange):
         one.step(obs[t:t + 1])
     assert 0 < n_res < T - 1
     assert pf.log_marginal_likelihood_estimate() == one.log_marginal_likelihood_estimate()
+
+
+# ---- the split multinomial (MP_RESAMPLE_MULTINOMIAL_SPLIT): counts per rank first, then every rank its own draws ------------
+def test_split_multinomial_in_a_world_of_one_is_the_single_filters_resample():
+    """rank 0's stream is the single filter's and its share of the mass is all of it: same parents, bit for bit"""
+    import modppl_amd
+    from tests import oracle_lib as O
+    from tests.owned_ref import OwnedReference
+    N, T, seed = 6144, 5, 21
+    obs = O.lgssm_observations(T).reshape(T, 1)
+    one = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, N, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    ref = OwnedReference(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), N, seed, 1)
+    one.init_step(obs[:1])
+    ref.init_step(None, obs[:1])
+    for t in range(1, T):
+        assert ref.resample(3) == one.resample(0)
+        assert np.array_equal(ref.parents(), one.parents()) and np.array_equal(ref.states().reshape(-1), one.state().reshape(-1))
+        ref.step(obs[t:t + 1])
+        one.step(obs[t:t + 1])
+    assert np.array_equal(ref.log_weights(), one.log_weights())
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_split_multinomial_structure_and_law(world):
+    """Counts = the splitting tree's over the rank masses; a rank's kept offspring have parents on that rank; L, ESS and log-ML are
+    the single filter's (they do not depend on the draws); and over many seeds the offspring per TILE follow the weights
+    (chi-square against N x tile mass, the masses restated in numpy from the log-weights)."""
+    import modppl_amd
+    from scipy import stats
+    from tests import oracle_lib as O
+    from tests.owned_ref import OwnedReference
+    n, T = 2048, 3
+    N = n * world
+    obs = O.lgssm_observations(T).reshape(T, 1).copy()
+    obs[1] = 4.0                       # uneven shard masses
+    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    chi2, dof = 0.0, 0
+    for seed in range(30):
+        one = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, N, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+        ref = OwnedReference(model, N, seed, world)
+        for f in (lambda: (one.init_step(obs[:1]), ref.init_step(None, obs[:1])), lambda: (one.step(obs[1:2]), ref.step(obs[1:2]))):
+            f()
+        lw = one.log_weights()
+        L1 = one.resample(0)
+        assert ref.resample(3) == L1                     # the normalisation is the job's, whatever the sampler
+        assert ref.eng[0].ess_reference() == one.effective_sample_size(0)
+        counts = np.array(ref.counts, dtype=np.int64)
+        assert counts.sum() == N
+        par = ref.parents().astype(np.int64).reshape(world, n)
+        for r in range(world):
+            keep = min(counts[r], n)
+            assert (par[r, :keep] // n == r).all()       # kept offspring: parents on the owner
+        # every offspring's parent, wherever it was placed: counts per rank as drawn
+        assert np.array_equal(np.bincount(par.reshape(-1) // n, minlength=world), counts)
+        w = np.exp(lw - lw.max())
+        p_tile = w.reshape(-1, 2048).sum(1) / w.sum()
+        got = np.bincount(par.reshape(-1) // 2048, minlength=world)
+        exp = N * p_tile
+        chi2 += ((got - exp) ** 2 / exp).sum()
+        dof += world - 1
+    assert chi2 < stats.chi2.ppf(1 - 1e-6, dof), (chi2, dof)
+    assert chi2 > stats.chi2.ppf(1e-6, dof), (chi2, dof)   # (and not suspiciously regular either)

@@ -122,6 +122,23 @@ class _ByHand:
     ("dense16", 3, 2048, 0, True, 0, 6.0),
     (1, 8, 2048, 256, True, 0, 6.0),       # eight ranks: several donors and receivers in the plan
     (2, 8, 2048, 0, False, 0, 14.0),
+    # self-drawn forms (mp_pf_shard_kernels.h): the lattice schemes' kept draws made by the next k_propagate itself (peek False: nothing
+    # else ever makes them) or by k_shard_self_draw (wide states; readers before the step), the surplus by k_shard_self_place
+    (1, 4, 4096, 512, False, 1, 14.0),
+    (1, 2, 8192, 0, False, 2, 6.0),
+    (4, 4, 2048, 8, False, 1, 6.0),
+    (4, 3, 2048, 2048, True, 2, 6.0),
+    (16, 2, 2048, 0, True, 1, 6.0),
+    ("dense16", 2, 2048, 64, False, 2, 6.0),
+    # the split multinomial: counts per rank from the binomial tree, then every rank its own draws
+    (1, 2, 8192, 8192, True, 3, 6.0),
+    (1, 2, 8192, 8192, False, 3, 6.0),
+    (1, 4, 4096, 0, True, 3, 14.0),
+    (1, 4, 4096, 16, False, 3, 14.0),      # capacity too small: the repeat with exact sizes
+    (4, 3, 2048, 2048, False, 3, 6.0),
+    (16, 2, 2048, 2048, True, 3, 6.0),
+    (1, 8, 2048, 256, False, 3, 6.0),
+    (1, 5, 2048, 0, True, 3, 6.0),         # odd world: the splitting tree's padded leaves
 ])
 def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme, tail):
     model, obs = _model(d, 7)
@@ -153,8 +170,30 @@ def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme, tail):
         assert hip.fallbacks > 0
 
 
-@pytest.mark.parametrize("world", [2, 5, 8])
-def test_table_by_one_workgroup_per_rank_at_small_sizes(monkeypatch, world):
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_lattice_schemes_window_form_still_agrees(monkeypatch, scheme):
+    """MP_SHARD_SELF=0: the lattice schemes through k_shard_own_draw / _plan / _place (round 3's form, kept for A/B) — the same
+    offspring in the same slots as the self-drawn form and the checker"""
+    monkeypatch.setenv("MP_SHARD_SELF", "0")
+    n, world, seed = 4096, 3, 23
+    model, obs = _model(1, 5)
+    hip = _ByHand(model, n, world, seed)
+    ref = OwnedReference(model, n * world, seed, world)
+    for e in hip.eng:
+        e.init_step(None, obs[:1])
+    ref.init_step(None, obs[:1])
+    for t in range(1, len(obs)):
+        assert hip.resample(256 if t % 2 else 0, scheme) == ref.resample(scheme)
+        if t % 2:
+            assert np.array_equal(hip.cat(lambda e: e.parents()), ref.parents())
+        for e in hip.eng:
+            e.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+    assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
+
+
+@pytest.mark.parametrize("world,scheme", [(2, 0), (5, 0), (8, 0), (5, 3), (8, 1)])
+def test_table_by_one_workgroup_per_rank_at_small_sizes(monkeypatch, world, scheme):
     """k_shard_table_mw (one workgroup per rank; the library picks it beyond 2048 tiles per job) forced at a few thousand
     particles: L, counts, parents and the STALE ESS — i.e. Q2, summed over the ranks' partial sums by wave 0 with fewer than 64
     ranks active — against the checker (the sum read an inactive lane)."""
@@ -169,7 +208,7 @@ def test_table_by_one_workgroup_per_rank_at_small_sizes(monkeypatch, world):
         e.init_step(None, obs[:1])
     ref.init_step(None, obs[:1])
     for t in range(1, len(obs)):
-        assert hip.resample(512 if t % 2 else 0, 0) == ref.resample(0)
+        assert hip.resample(512 if t % 2 else 0, scheme) == ref.resample(scheme)
         assert list(hip.counts) == list(ref.counts)
         ess = [e.ess_reference() for e in hip.eng]
         assert all(v == ref.eng[0].ess_reference() for v in ess), (ess, ref.eng[0].ess_reference())
@@ -200,6 +239,35 @@ def test_owner_keeps_world_of_one_and_its_law():
     assert np.array_equal(a.states(), b.states())
     assert a.log_marginal_likelihood_estimate() == b.log_marginal_likelihood_estimate()
     assert abs(b.log_marginal_likelihood_estimate() - O.kalman_log_ml(ys)) < 0.05
+
+
+@pytest.mark.parametrize("scheme,exchange", [(1, "owned"), (2, "owned"), (0, "split")])
+@pytest.mark.parametrize("sync", [True, False])
+def test_self_drawn_resample_in_a_world_of_one_is_the_single_filter(scheme, exchange, sync):
+    """One shard through the sharded entry points: the kept range is every draw, the next k_propagate makes them itself from the
+    table the last level-0 launch left (SHD form) — the single filter's parents, states, L, ESS and log-ML, bit for bit; a
+    synchronous resample reads its value before that step, an asynchronous one never touches the host"""
+    import modppl_amd
+    from modppl_amd.distributed import ShardedParticleSystem
+    n, seed, T = 300000, 8, 10
+    ys = O.lgssm_observations(T)
+    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    a = modppl_amd.ParticleSystem(model, n, seed)
+    b = ShardedParticleSystem(model, n, seed, exchange=exchange)
+    a.init_step(None, ys[:1])
+    b.init_step(None, ys[:1])
+    for t in range(1, T):
+        la, lb = a.resample(scheme, sync=sync), b.resample(scheme, sync=sync)
+        assert la == lb
+        if t == 3:   # a reader before the step: the draws are made by k_shard_self_draw instead
+            assert np.array_equal(a.parents, b.parents) and np.array_equal(a.states(), b.states())
+        a.step(ys[t:t + 1])
+        b.step(ys[t:t + 1])
+        if t == 5:   # ... and after it: the parents the drawing launch stored
+            assert np.array_equal(a.parents, b.parents)
+        assert a.effective_sample_size() == b.effective_sample_size()
+    assert np.array_equal(a.states(), b.states()) and np.array_equal(a.log_weights, b.log_weights)
+    assert a.log_marginal_likelihood_estimate() == b.log_marginal_likelihood_estimate()
 
 
 @pytest.mark.parametrize("d", [1, 16])
