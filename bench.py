@@ -504,7 +504,7 @@ def main():
     dt = float(np.median(dts))
     # ---- supplementary: the same K steps with systematic resampling (named next to multinomial in the north star; not `value`)
     dt_sys = None
-    if not force_sharded and not args.no_systematic_leg:   # (at N > 1 too: the sharded filter's lattice schemes need no enumeration of all N draws)
+    if not args.no_systematic_leg:   # (at N > 1 too: the sharded filter's lattice schemes need no enumeration of all N draws)
         sys_dts = []
         for rep in range(1 + min(4, max(0, args.repeats - 1))):   # (a first, untimed-in-effect region switches the scheme; median of the rest)
             barrier()

@@ -1739,10 +1739,10 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         scheme = MP_RESAMPLE_MULTINOMIAL;
     }
     if (self) {
-        LaunchTimer lt(h, MP_K_BIN_DRAWS);
         h->ow_self = true;
         h->ow_scheme = scheme;
         if (world > 1) {
+            LaunchTimer lt(h, MP_K_BIN_DRAWS);
             // the job's table, the offspring per rank (lattice: closed form; split: the binomial tree) and this rank's own range; then
             // the exchange plan from the counts alone
             launch_shard_table(h, (const u64*)d_tiles_all, world, h->ow_call, (int)scheme, rank, h->ow_range, h->ow_kthr);
@@ -1831,6 +1831,7 @@ int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t
     if (h->ow_self) {
         // the kept offspring are drawn by the next k_propagate itself where its kernel can (self_k1_draws), here otherwise; the
         // surplus is looked up now (it travels), the deficit slots are flagged with the rows that will arrive
+        if (world == 1 && self_k1_draws(h)) return MP_OK;   // (nothing to launch: no surplus, no deficit, the draws are the next step's)
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (!self_k1_draws(h)) {
             int32_t rcs = launch_self_draws(h, h->ow_scheme, h->resample_count, world, rank);

@@ -314,12 +314,13 @@ from tests.owned_ref import OwnedReference
 ys = O.lgssm_observations(6).reshape(6, 1)
 n, seed = 1 << 16, 9
 model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
-b = ShardedParticleSystem(model, n, seed, exchange="owned")   # device tensors through RCCL, every collective issued
+EX, SCH = os.environ.get("MP_T_EXCHANGE", "owned"), int(os.environ.get("MP_T_SCHEME", "0"))
+b = ShardedParticleSystem(model, n, seed, exchange=EX)   # device tensors through RCCL, every collective issued
 ref = OwnedReference(model, n, seed, 1)
 b.init_step(None, ys[:1]); ref.init_step(None, ys[:1])
 ok = True
 for t in range(1, 6):
-    ok &= b.resample() == ref.resample()
+    ok &= b.resample(SCH) == ref.resample(3 if EX == "split" else SCH)
     if t % 2:
         ok &= bool(np.array_equal(b.parents, ref.parents())) and bool(np.array_equal(b.states(), ref.states()))
     b.step(ys[t:t + 1]); ref.step(ys[t:t + 1])
@@ -342,7 +343,8 @@ rank, world = dist.get_rank(), dist.get_world_size()
 N, T, seed = 2048 * 2 * world * 2, 7, 5
 model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
 obs = O.lgssm_observations(T).reshape(T, 1)
-pf = ShardedParticleSystem(model, N, seed, host_staging=True, exchange="owned")   # both ranks on cuda:0, exact-size exchange
+EX, SCH = os.environ.get("MP_T_EXCHANGE", "owned"), int(os.environ.get("MP_T_SCHEME", "0"))
+pf = ShardedParticleSystem(model, N, seed, host_staging=True, exchange=EX)   # both ranks on cuda:0, exact-size exchange
 ref = OwnedReference(model, N, seed, world) if rank == 0 else None
 def gather(a):
     out = [None] * world
@@ -352,11 +354,14 @@ pf.init_step(None, obs[:1])
 if ref: ref.init_step(None, obs[:1])
 ok = True
 for t in range(1, T):
-    L = pf.resample()
-    par, x = gather(pf.parents), gather(pf.states())
+    L = pf.resample(SCH, sync=(t != 4))      # (one asynchronous resample: nothing read until after the next step)
+    if t != 4:
+        par, x = gather(pf.parents), gather(pf.states())
     if ref:
-        ok &= L == ref.resample()
-        ok &= bool(np.array_equal(par, ref.parents())) and bool(np.array_equal(x, ref.states()))
+        Lr = ref.resample(3 if EX == "split" else SCH)
+        if t != 4:
+            ok &= L == Lr
+            ok &= bool(np.array_equal(par, ref.parents())) and bool(np.array_equal(x, ref.states()))
     pf.step(obs[t:t + 1])
     if ref: ref.step(obs[t:t + 1])
 lw = gather(pf.log_weights)
@@ -379,7 +384,10 @@ def _free_port():
 
 
 @pytest.mark.parametrize("which,nproc,extra", [("nccl", 1, {}), ("gloo", 2, {}), ("gloo", 2, {"MP_SHARD_OWNED_CAP": "8"}), ("gloo", 2, {"MP_SHARD_FIXED": "0"}),
-                                               ("gloo", 3, {})])
+                                               ("gloo", 3, {}),
+                                               # the self-drawn forms through the same entry point: split multinomial, a lattice scheme
+                                               ("nccl", 1, {"MP_T_EXCHANGE": "split"}), ("gloo", 2, {"MP_T_EXCHANGE": "split"}),
+                                               ("gloo", 3, {"MP_T_EXCHANGE": "split", "MP_SHARD_OWNED_CAP": "8"}), ("gloo", 2, {"MP_T_SCHEME": "1"})])
 def test_owner_keeps_through_process_groups(tmp_path, which, nproc, extra):
     """The whole resample as ONE library call (mp_pf_shard_resample) with the library issuing the collectives: over its own RCCL
     communicator with every collective forced in a world of one (the bench's transport: ncclAllGather + one group of ncclSend /

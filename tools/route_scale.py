@@ -27,7 +27,7 @@ def main():
         eng.init_step(None, ys[:1])
         eng.shard_tiles_packed(C.c_void_p(tiles.data_ptr()))
         eng.synchronize()
-        tiles_all = tiles.repeat(world).contiguous()
+        tiles_all = tiles if world == 1 else tiles.repeat(world).contiguous()   # (a world of one gathers nothing: its own, bound buffer)
         torch.cuda.synchronize()   # torch's stream made it; the engine's kernels run on a stream of their own
         cap = int(n // (8 * world) * 1.25) + 512
         req = torch.zeros(world * 8 * (cap + 1) * 2, dtype=torch.int64, device=dev)
@@ -45,7 +45,7 @@ def main():
         ocap = max(4096, n // 128)
         send = torch.zeros(world * ocap * 2, dtype=torch.float64, device=dev)
         orow = torch.zeros((world * ocap + n) * 2, dtype=torch.float64, device=dev)
-        for scheme, name in ((0, "multinomial"), (1, "systematic"), (2, "stratified")):
+        for scheme, name in ((0, "multinomial"), (1, "systematic"), (2, "stratified"), (3, "split multinomial")):
             eng.synchronize()
             eng.set_timing(False)
             eng.set_timing(True)
@@ -58,6 +58,32 @@ def main():
             place = g[0] / g[1] * 1e3 if g[1] else 0.0   # (a world of one launches nothing there: the next k_propagate looks its draws up)
             print(f"world {world}: owner-keeps {name}: count (table + own draws + plan) {r[0] / r[1] * 1e3:.1f} us, place + surplus lookups {place:.1f} us",
                   flush=True)
+        # a whole step of this rank, kernel by kernel (HIP events around every launch): count + expand + commit (asynchronous) + the
+        # next propagate, which makes the kept draws of a self-drawn resample itself (the rows "received" for the deficit slots are
+        # whatever the buffer holds: timing only)
+        ys2 = B.lgssm_observations(64).reshape(64, 1)
+        for scheme, name in ((0, "multinomial"), (1, "systematic"), (2, "stratified"), (3, "split multinomial")):
+            K = 30
+            for rep in range(2):
+                eng.synchronize()
+                eng.set_timing(False)
+                eng.set_timing(True)      # (the first pass warms up)
+                for t in range(K):
+                    eng.shard_owned_count(scheme, C.c_void_p(tiles_all.data_ptr()), world, 0, ocap, want_counts=False)
+                    eng.shard_owned_expand(world, 0, ocap, C.c_void_p(send.data_ptr()), C.c_void_p(orow.data_ptr()), world * ocap)
+                    eng.shard_owned_commit(C.c_void_p(orow.data_ptr()), world * ocap, False, want_counts=False)
+                    eng.step(ys2[1 + t % 60:2 + t % 60])
+                    if world > 1:   # the tiles this rank would contribute to the next all-gather (its own, `world` times over)
+                        eng.synchronize()
+                        tiles_all.copy_(tiles.repeat(world))
+                        torch.cuda.synchronize()
+                eng.synchronize()
+            k1 = eng.get_timing(capi.MP_K_PROPAGATE)
+            r = eng.get_timing(capi.MP_K_BIN_DRAWS)
+            g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
+            us = lambda v: v[0] / v[1] * 1e3 if v[1] else 0.0   # noqa: E731
+            print(f"world {world}: {name}: kernels of one resample + step: propagate {us(k1):.1f} + count {us(r):.1f} + place {us(g):.1f} "
+                  f"= {us(k1) + us(r) + us(g):.1f} us", flush=True)
         eng.close()
 
 
