@@ -283,15 +283,24 @@ struct mp_fn_handler {
         return c;
     }
 
+    // Sub-calls nest: a body may itself `call` (SITES of the outer call then includes the inner call's sites, and the outer call owns
+    // at least one site below them: its lowest site names where the trace keeps its running weight).  Every call is a frame — its own
+    // weight from 0, its own trie weight `sw` — and on the way out it does to the ENCLOSING frame's trie what trace_at does to
+    // `trace.data`: remove(addr) took the old sub-trie's weight off when the call began (:207, :221, :252-), insert(addr, sub) puts the
+    // new one on (:186, :200, :244).
     template <uint32_t SITES, class Body>
     MP_HD auto call(Body&& body) {
         static_assert(SITES != 0u, "a sub-call names the set of its sites");
         constexpr int ID = __builtin_ctz(SITES);   // where the trace keeps this sub-trie's running weight
+        const bool o_in = in_sub;                  // the enclosing frame: is it a sub-trie whose weight is being kept, and that weight so far
+        const double o_sw = sw;
         if constexpr (MODE == MP_FN_SIMULATE) {
             // the sub-trace's choices are the caller's; `propose`'s weight is the whole trie's
             in_sub = true; sw = 0.;
             auto r = body(*this);
-            in_sub = false; tr.subw[ID] = sw;
+            const double w_new = sw;
+            tr.subw[ID] = w_new;
+            in_sub = o_in; sw = o_in ? o_sw + w_new : o_sw;
             return r;
         } else if constexpr (MODE == MP_FN_GENERATE) {
             // generate(args, choices): weight += d_weight as one term (:316-319); simulate when nothing is constrained
@@ -300,20 +309,37 @@ struct mp_fn_handler {
             weight = 0.;
             in_sub = true; sw = 0.;
             auto r = body(*this);
-            in_sub = false; tr.subw[ID] = sw;
+            const double w_new = sw;
+            tr.subw[ID] = w_new;
+            in_sub = o_in; sw = o_in ? o_sw + w_new : o_sw;
             weight = any ? w_out + weight : w_out;
             return r;
         } else {
             const uint32_t had = prev->present & SITES;
+            const double w_out = weight;
+            if (from_prev) {
+                // inside an enclosing generate(args, old sub-trace): this call is that generate's own trace_at — the old choices of
+                // its sites are its constraints, the enclosing trie is a fresh one (nothing to remove from it)
+                weight = 0.;
+                sw = 0.;
+                auto r = body(*this);
+                const double w_new = sw;
+                tr.subw[ID] = w_new;
+                sw = o_sw + w_new;
+                weight = had ? w_out + weight : w_out;
+                return r;
+            }
             uint32_t touched;
             if constexpr (MODE == MP_FN_UPDATE) touched = cons->present & SITES;
             else touched = mask & SITES;
-            const double w_out = weight;
+            const double e_sw = (o_in && had) ? o_sw - prev->subw[ID] : o_sw;   // the enclosing trie after trace.data.remove(addr)
             if (!touched && had && !changed) {
-                auto r = body(*this);   // replay: every site returns its previous value and log-density; the sub-trie is not touched
+                in_sub = false;         // replay: every site returns its previous value and log-density; no trie is touched but the
+                auto r = body(*this);   // enclosing one, which gets the sub-trie back as it was
                 weight = w_out;
                 changed = false;
                 tr.subw[ID] = prev->subw[ID];
+                in_sub = o_in; sw = o_in ? e_sw + prev->subw[ID] : o_sw;
                 return r;
             }
             if (MODE == MP_FN_REGENERATE && !touched && had) {
@@ -324,7 +350,9 @@ struct mp_fn_handler {
                 from_prev = false;
                 if (had & ~visited) panic = true;   // "not all constraints were consumed" (:526-529)
                 weight = w_out + (weight - prev->subw[ID]);
-                tr.subw[ID] = sw;
+                const double w_new = sw;
+                tr.subw[ID] = w_new;
+                in_sub = o_in; sw = o_in ? e_sw + w_new : o_sw;
                 changed = true;
                 return r;
             }
@@ -335,7 +363,9 @@ struct mp_fn_handler {
                 const double c = collect(SITES);
                 if constexpr (MODE == MP_FN_UPDATE) weight = weight - c;
             }
-            in_sub = false; tr.subw[ID] = sw;
+            const double w_new = sw;
+            tr.subw[ID] = w_new;
+            in_sub = o_in; sw = o_in ? e_sw + w_new : o_sw;
             weight = (touched || had) ? w_out + weight : w_out;
             changed = true;
             return r;

@@ -266,6 +266,108 @@ inline bool mp_parse_scaled_line_drift_fn(const double* args, int n_args, mp_sca
 MP_REGISTER_MH_PROPOSAL(2, mp_scaled_line_fn, mp_scaled_line_drift_fn, mp_parse_scaled_line_drift_fn)
 
 // ---------------------------------------------------------------------------------------
+// Two LEVELS of sub-calls (kind 113): trace_at inside trace_at (dyngenfn.rs:283-449 is recursive through GenFn::update /
+// regenerate / generate of the callee, which is a DynGenFn with a handler of its own).  No reference test nests calls; the model is
+// built so that every arm is reached at depth two — constraints that land in the inner call only, a structure change in the middle
+// one (gc there), a change upstream of both (update(sub, Unknown, {}) twice over; generate(args, sub) twice over under regenerate).
+//   a ~ normal(0, 2) %= "a"
+//   e = mid(a) /= "mid":     b ~ normal(a, 1) %= "b"
+//                            (c, f) = inner(b) /= "inner":   c ~ normal(b, 0.5) %= "c";  f ~ bernoulli(0.3) %= "f"
+//                            if f { d ~ normal(c, 1) %= "d" }
+//                            e ~ normal(c + b + (f ? d : 0), 0.7) %= "e"
+//   y_j ~ normal(e x_j, 0.3) %= "y_j",  j < n_data   (constraints);  params = xs[0 .. n_data), n_data <= 4
+// Moves: proposal 1 = drift of b and c {std}; proposal 2 = flip of f (proposes the other value with probability 0.8, and d ~ normal(c, 1) with a true f);
+// proposal 3 = drift of a {std}.
+// ---------------------------------------------------------------------------------------
+struct mp_nested_fn {
+    static constexpr int MAX_DATA = 4;
+    static constexpr int NS = 6 + MAX_DATA;
+    enum { A = 0, B = 1, C = 2, F = 3, D = 4, E = 5, Y0 = 6 };
+    static constexpr uint32_t INNER = (1u << C) | (1u << F);
+    static constexpr uint32_t MID = (1u << B) | INNER | (1u << D) | (1u << E);   // (an outer call's sites include the inner call's)
+    static constexpr uint32_t sub_of(int site) { return (site == C || site == F) ? INNER : ((site == B || site == D || site == E) ? MID : 0u); }
+    static constexpr uint32_t outer_of(int site) { return (site == C || site == F) ? MID : 0u; }
+    static constexpr bool is_bool(int site) { return site == F; }
+    int n;
+    double xs[MAX_DATA];
+    double ln2, ln_half, ln_07, ln_03;
+
+    template <class H, int J>
+    MP_HD void points(H& g, double e) const {
+        if (J < n) g.template normal<Y0 + J>(e * xs[J], 0.3, ln_03);
+        if constexpr (J + 1 < MAX_DATA) points<H, J + 1>(g, e);
+    }
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        const double a = g.template normal<A>(0., 2., ln2);
+        const mp_fn_ret mid = g.template call<MID>([&](H& q) {
+            const double b = q.template normal<B>(a, 1., 0.);
+            const mp_fn_ret in = q.template call<INNER>([&](H& q2) {
+                mp_fn_ret r{};
+                r.v[0] = q2.template normal<C>(b, 0.5, ln_half);
+                r.v[1] = q2.template bernoulli<F>(0.3) ? 1. : 0.;
+                return r;
+            });
+            double d = 0.;
+            if (in.v[1] != 0.) d = q.template normal<D>(in.v[0], 1., 0.);
+            mp_fn_ret r{};
+            r.v[0] = q.template normal<E>(in.v[0] + b + d, 0.7, ln_07);
+            return r;
+        });
+        points<H, 0>(g, mid.v[0]);
+    }
+};
+inline bool mp_parse_nested_fn(const double* params, int n_params, mp_nested_fn& m, std::string& err) {
+    if (!params || n_params < 1 || n_params > mp_nested_fn::MAX_DATA) { err = "nested calls: params = xs[0 .. n_data), 1 <= n_data <= 4"; return false; }
+    m.n = n_params;
+    for (int k = 0; k < mp_nested_fn::MAX_DATA; ++k) m.xs[k] = k < n_params ? params[k] : 0.;
+    m.ln2 = mp_log(2.); m.ln_half = mp_log(0.5); m.ln_07 = mp_log(0.7); m.ln_03 = mp_log(0.3);
+    return true;
+}
+MP_REGISTER_MH_MODEL(113, mp_nested_fn, mp_parse_nested_fn)
+
+struct mp_nested_drift_bc_fn {
+    double sd, ln_sd;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        g.template normal<mp_nested_fn::B>(tr.val[mp_nested_fn::B], sd, ln_sd);
+        g.template normal<mp_nested_fn::C>(tr.val[mp_nested_fn::C], sd, ln_sd);
+    }
+};
+struct mp_nested_flip_fn {
+    int unused;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        // (a move that switches `d` on proposes it as well — and its reverse then finds the dropped `d` in the discard it assesses: a
+        // proposal that left it out would be the reference's "not all constraints were consumed" panic, as for hierarchical.rs:60-70)
+        if (g.template bernoulli<mp_nested_fn::F>(tr.val[mp_nested_fn::F] != 0. ? 0.2 : 0.8))
+            g.template normal<mp_nested_fn::D>(tr.val[mp_nested_fn::C], 1., 0.);
+    }
+};
+struct mp_nested_drift_a_fn {
+    double sd, ln_sd;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        g.template normal<mp_nested_fn::A>(tr.val[mp_nested_fn::A], sd, ln_sd);
+    }
+};
+template <class P>
+inline bool mp_parse_nested_drift(const double* args, int n_args, P& p, std::string& err) {
+    if (!args || n_args != 1 || !(args[0] > 0.)) { err = "drift proposal takes {std > 0}"; return false; }
+    p.sd = args[0];
+    p.ln_sd = mp_log(args[0]);
+    return true;
+}
+inline bool mp_parse_nested_flip(const double*, int n_args, mp_nested_flip_fn& p, std::string& err) {
+    if (n_args != 0) { err = "flip proposal takes no arguments"; return false; }
+    p.unused = 0;
+    return true;
+}
+MP_REGISTER_MH_PROPOSAL(1, mp_nested_fn, mp_nested_drift_bc_fn, mp_parse_nested_drift<mp_nested_drift_bc_fn>)
+MP_REGISTER_MH_PROPOSAL(2, mp_nested_fn, mp_nested_flip_fn, mp_parse_nested_flip)
+MP_REGISTER_MH_PROPOSAL(3, mp_nested_fn, mp_nested_drift_a_fn, mp_parse_nested_drift<mp_nested_drift_a_fn>)
+
+// ---------------------------------------------------------------------------------------
 // The reference's own Update regression functions (modppl/tests/dyngenfn.rs:30-53), kinds 110 - 112: what its known-answer
 // tests for `update` run (:55-114: -0.5, -2.517551, 0.4, -1.098612 twice) — here so that the same calls can be made on the
 // device through mp_fn_update (tests/test_gpu_gfi.py).  No params, no proposals.

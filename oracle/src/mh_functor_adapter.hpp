@@ -24,10 +24,22 @@ namespace oracle {
 
 inline std::string mhfn_local_addr(int site) { return "s" + std::to_string(site); }
 inline std::string mhfn_sub_addr(uint32_t sites) { return "c" + std::to_string(sites); }
+// models with two levels of sub-calls also say which call encloses a site's innermost one (M::outer_of: its SITES, or 0)
+template <class M, class = void>
+struct mhfn_has_outer : std::false_type {};
+template <class M>
+struct mhfn_has_outer<M, std::void_t<decltype(M::outer_of(0))>> : std::true_type {};
+template <class M>
+uint32_t mhfn_outer(int s) {
+    if constexpr (mhfn_has_outer<M>::value) return M::outer_of(s);
+    else return 0u;
+}
 template <class M>
 std::string mhfn_flat_addr(int site) {
-    const uint32_t sub = M::sub_of(site);
-    return sub ? mhfn_sub_addr(sub) + "/" + mhfn_local_addr(site) : mhfn_local_addr(site);
+    const uint32_t sub = M::sub_of(site), outer = mhfn_outer<M>(site);
+    std::string a = outer ? mhfn_sub_addr(outer) + "/" : std::string();
+    if (sub) a += mhfn_sub_addr(sub) + "/";
+    return a + mhfn_local_addr(site);
 }
 inline uint32_t mhfn_site_of(const std::string& a) {   // the Philox site of an address: the id after the last 's'
     return (uint32_t)std::stoul(a.substr(a.rfind('s') + 1));
@@ -104,14 +116,12 @@ struct MhFnView {
     explicit MhFnView(const DynTrie& data) {
         for (int s = 0; s < M::NS; ++s) val[s] = 0.;
         for (int s = 0; s < M::NS; ++s) {
-            const uint32_t sub = M::sub_of(s);
+            const uint32_t sub = M::sub_of(s), outer = mhfn_outer<M>(s);
             const Trie* node = nullptr;
-            if (sub) {
-                const Trie* st = data.search(mhfn_sub_addr(sub));
-                node = st ? st->search(mhfn_local_addr(s)) : nullptr;
-            } else {
-                node = data.search(mhfn_local_addr(s));
-            }
+            const Trie* at = &data;
+            if (outer) at = at->search(mhfn_sub_addr(outer));   // (term searches: a missing sub-trie is "absent", not a panic)
+            if (at && sub) at = at->search(mhfn_sub_addr(sub));
+            node = at ? at->search(mhfn_local_addr(s)) : nullptr;
             if (!node || !node->value) continue;
             if (mhfn_dim<M>(s) == 0) continue;   // (a vector's further slot: filled with its head)
             present |= 1u << s;

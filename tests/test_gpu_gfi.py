@@ -57,7 +57,7 @@ def test_residual_constraints_are_an_error_on_the_device():
         g.update({X: 0.3})
 
 
-@pytest.mark.parametrize("kind", [101, 102, 103])
+@pytest.mark.parametrize("kind", [101, 102, 103, 113])
 def test_gfi_calls_against_the_dynamic_interpretation(kind):
     """A scripted sequence of update (shared and per-chain constraints, both ArgDiffs), regenerate (masks inside and outside
     sub-calls, the empty mask), propose and assess on three registered models: weights, discards, choices, traces."""
@@ -72,6 +72,10 @@ def test_gfi_calls_against_the_dynamic_interpretation(kind):
         ys = 0.7 * xs - 0.2 + rng.normal(0, 0.4, xs.size); ys[3] += 6.0
         cons = {y0 + k: v for k, v in enumerate(ys)}
         free, props = [0, 1, 2, 5], [(1, [0.2]), (2, [3.0])]
+    elif kind == 113:   # two levels of sub-calls: a | mid { b | inner { c, f } | d if f | e } | y
+        xs = np.array([0.5, -1.0, 1.5, 2.0]); y0 = 6
+        cons = {y0 + k: v for k, v in enumerate(1.3 * xs + rng.normal(0, 0.2, xs.size))}
+        free, props = [0, 2, 1, 5], [(1, [0.2]), (2, []), (3, [0.4])]
     else:
         xs = np.linspace(-1, 3, 6); y0 = 3
         cons = {y0 + k: v for k, v in enumerate(1.1 * xs + 0.3 + rng.normal(0, 0.6, xs.size))}

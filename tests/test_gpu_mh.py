@@ -340,6 +340,24 @@ def test_change_upstream_of_an_untouched_sub_call():
     check_fn(g, o)
 
 
+def test_two_levels_of_sub_calls():
+    """kind 113: a sub-call inside a sub-call — constraints that land in the inner call, a structure change in the middle one, a
+    change upstream of both, and every mask placement — the device's static handlers (mp_genfn.h: `call` as a frame) against the
+    checker's recursive trace_at over real nested tries, through mh and regen_mh"""
+    if FUNCTOR:
+        pytest.skip("one engine: the model has no hand-written kernel")
+    import modppl_amd
+    from tests.test_oracle_mh_functor import nested_moves, nested_problem
+
+    xs, cons = nested_problem()
+    n = 3000
+    g = modppl_amd.FunctionChains(113, xs, cons, n, 13)
+    o = O.OracleFunctionChains(113, xs, cons, n, 13)
+    nested_moves(g, o, check_fn, sweeps=2)
+    vals, present = g.trace()
+    assert 0 < ((present >> 4) & 1).sum() < n
+
+
 def test_masking_is_linear_where_the_reference_does_not_panic():
     """hierarchical model as a functor, all chains linear, ONE regen move with mask {is_linear}: linear -> linear and linear ->
     quadratic go through generate(args, sub) on the old `coeffs` sub-trace (c is drawn when the new branch wants it); only

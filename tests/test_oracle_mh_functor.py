@@ -178,6 +178,54 @@ def test_static_handlers_robust_line_and_scaled_line():
     _same(s, d)
 
 
+NF_A, NF_B, NF_C, NF_F, NF_D, NF_E, NF_Y0 = 0, 1, 2, 3, 4, 5, 6
+
+
+def nested_moves(s, d, same, sweeps=3):
+    """kind 113 (two levels of sub-calls, mp_mh_models.h): every arm of trace_at at depth two, engine `s` against engine `d`"""
+    same(s, d)
+    for sweep in range(sweeps):
+        assert s.mh(1, [0.3], 2) == d.mh(1, [0.3], 2)                 # constraints in the middle call AND the inner one
+        same(s, d)
+        assert s.mh(2, [], 2) == d.mh(2, [], 2)                       # the inner call's flag flips: `d` comes or goes (gc in the middle call)
+        same(s, d)
+        assert s.mh(3, [0.5], 2) == d.mh(3, [0.5], 2)                 # upstream of both calls: update(sub, Unknown, {}) at both depths
+        same(s, d)
+        assert s.regen_mh([NF_A], 2) == d.regen_mh([NF_A], 2)         # masked upstream, both calls unmasked: generate(args, sub) nested
+        same(s, d)
+        assert s.regen_mh([NF_C], 2) == d.regen_mh([NF_C], 2)         # masked inside the inner call only
+        same(s, d)
+        assert s.regen_mh([NF_F], 2) == d.regen_mh([NF_F], 2)         # the flag redrawn: structure change through regenerate
+        same(s, d)
+        assert s.regen_mh([NF_B], 2) == d.regen_mh([NF_B], 2)         # masked in the middle call, upstream of the inner one
+        same(s, d)
+        assert s.regen_mh([NF_E, NF_D], 2) == d.regen_mh([NF_E, NF_D], 2)   # masked in the middle call after the (replayed) inner one
+        same(s, d)
+        assert s.regen_mh([NF_A, NF_C, NF_F, NF_B, NF_E], 5, cycle=True) == d.regen_mh([NF_A, NF_C, NF_F, NF_B, NF_E], 5, cycle=True)
+        same(s, d)
+    assert s.regen_mh([], 1) == d.regen_mh([], 1)
+    same(s, d)
+
+
+def nested_problem():
+    xs = np.array([0.5, -1.0, 1.5, 2.0])
+    ys = 1.3 * xs + 0.2 * np.random.default_rng(8).normal(size=4)
+    return xs, {NF_Y0 + k: y for k, y in enumerate(ys)}
+
+
+def test_two_levels_of_sub_calls_static_handlers_against_the_trie_engine():
+    """the product's handler rules for NESTED calls (mp_genfn.h `call` as a frame: its own weight, its own trie weight, remove /
+    insert on the enclosing trie) on the host against the checker's recursive trace_at over real nested tries"""
+    xs, cons = nested_problem()
+    s, d = _both(113, xs, cons, 400, 13)
+    nested_moves(s, d, _same)
+    vals, present = d.trace()
+    has_d = (present >> NF_D) & 1
+    assert 0 < has_d.sum() < len(has_d)                      # both structures present at the end
+    assert np.array_equal(has_d, (vals[:, NF_F] != 0).astype(has_d.dtype))
+    assert np.isfinite(d.logjp()).all()
+
+
 BOUNDS = [-5.0, 5.0, -5.0, 5.0]            # tests/mh.rs:55
 OBS_COV = [1.0, -0.6, -0.6, 2.0]           # :61
 
