@@ -389,6 +389,12 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     shard_kw = {"host_staging": True} if rehearse else {}
+    # Several GPUs: the multinomial resample runs as the SPLIT form unless MP_SHARD_EXCHANGE says otherwise — the same law (offspring per
+    # GPU drawn first, then every GPU its own parents: O(n) per GPU), another seeded stream than the single filter's; the form whose
+    # parents are the single filter's multiset ("owned") enumerates all N draws on every GPU (52.6 against 20.6 us
+    # of count phase at 8 ranks).  A world of one (MP_BENCH_FORCE_SHARDED) keeps "owned" unless told otherwise.
+    if world > 1 and "MP_SHARD_EXCHANGE" not in os.environ:
+        shard_kw["exchange"] = "split"
 
     import modppl_amd
     from modppl_amd import capi
