@@ -1496,7 +1496,9 @@ int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out) {
 
 // the job's tile table from the gathered tiles: one workgroup per rank in a world of several (k_shard_table_mw), one in all otherwise
 static void launch_shard_table(mp_pf* h, const u64* d_tiles_all, int world, unsigned long long* c_all, int scheme, int rank, mp_own_range* range,
-                               u64* kthr) {
+                               u64* kthr, const mp_own_plan_args* plan = nullptr) {
+    const mp_own_plan_args pa = plan ? *plan : mp_own_plan_args{};
+    const int do_plan = plan ? 1 : 0;
     static const bool one_wg = getenv("MP_SHARD_TABLE_ONE_WG") && atoi(getenv("MP_SHARD_TABLE_ONE_WG")) != 0;   // A/B
     // (measured, 512 tiles per rank: one workgroup 8.3 us up to 4 ranks and 16.9 us at 8; one per rank 9.8 - 10.8 us at 2 .. 8)
     // (MP_SHARD_TABLE_MW_TILES: the job size from which one workgroup per rank builds the table — tests lower it to reach that
@@ -1507,11 +1509,12 @@ static void launch_shard_table(mp_pf* h, const u64* d_tiles_all, int world, unsi
         h->sh_tab_seq += (unsigned)world;
         hipLaunchKernelGGL(k_shard_table_mw, dim3(world), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
                            h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, c_all, scheme, rank,
-                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, range, kthr, h->sh_tab_part, h->sh_tab_ticket, h->sh_tab_seq);
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, range, kthr, h->sh_tab_part, h->sh_tab_ticket, h->sh_tab_seq,
+                           pa, do_plan);
     } else {
         hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
                            h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, c_all, scheme, rank,
-                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, range, kthr);
+                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, range, kthr, pa, do_plan);
     }
 }
 
@@ -1745,7 +1748,6 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
             LaunchTimer lt(h, MP_K_BIN_DRAWS);
             // the job's table, the offspring per rank (lattice: closed form; split: the binomial tree) and this rank's own range; then
             // the exchange plan from the counts alone
-            launch_shard_table(h, (const u64*)d_tiles_all, world, h->ow_call, (int)scheme, rank, h->ow_range, h->ow_kthr);
             mp_own_plan_args pa;
             pa.n = h->n; pa.n_global = h->n_global; pa.cap = (u64)capacity;
             pa.world = world; pa.nsc = 0; pa.lattice = 0; pa.S = h->S;
@@ -1753,7 +1755,8 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
             pa.scal = h->scal; pa.undo = h->scal_undo; pa.head = nullptr;
             pa.base = h->ow_base; pa.plan_out = h->ow_plan; pa.pub = h->d_pub; pa.seq = ++h->ow_seq;
             pa.range = h->ow_range; pa.Wd = (u64)OWN_ROUND;
-            hipLaunchKernelGGL(k_shard_own_plan, dim3(1), dim3(SHP_THREADS), 0, h->stream, pa);
+            // (the plan needs nothing but the counts: the table kernel's first workgroup makes it on its way out — no launch of its own)
+            launch_shard_table(h, (const u64*)d_tiles_all, world, h->ow_call, (int)scheme, rank, h->ow_range, h->ow_kthr, &pa);
         }
         rc = check_launch("self-drawn resample: table / plan");
         if (rc != MP_OK) return rc;

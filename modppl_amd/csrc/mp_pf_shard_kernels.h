@@ -291,15 +291,49 @@ __device__ __forceinline__ void mp_split_counts(const u64* s_bound, int world, u
         __syncthreads();
     }
 }
+// the exchange plan: unit u of the surplus (donors in rank order) fills unit u of the deficit (receivers in rank order)
+struct mp_owned_plan {
+    u64 S[SH_MAX_WORLD], D[SH_MAX_WORLD], PS[SH_MAX_WORLD], PD[SH_MAX_WORLD];
+};
+// stores the host will read while the stream is still running: write-through to system scope (sc0 sc1), no cache write-back
+__device__ __forceinline__ void mp_st_sys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mp_st_sys(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mp_st_sys(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct mp_own_plan_args {
+    u64 n, n_global, cap;
+    int world, nsc, lattice, S;
+    uint32_t* sccnt;                 // [nsc] own draws per super-chunk (in), read with agent-scope loads
+    unsigned long long* c_all;       // [world] offspring per rank: k_shard_table (lattice: closed form; multinomial: zeroed) + the draw kernel's atomics
+    mp_dev_scalars* scal;
+    mp_dev_scalars* undo;
+    const mp_tab_head* head;         // world of one: the single filter's table (ensure_table) is the job's table; k_shard_own_draw folds it
+    uint32_t* base;                  // [nsc] out: first offspring position of every super-chunk
+    mp_owned_plan* plan_out;
+    mp_shard_pub* pub;               // host-mapped
+    unsigned long long seq;
+    const mp_own_range* range;       // lattice: only the super-chunks of the own range were written (and are scanned)
+    u64 Wd;
+};
+template <int THREADS>
+__device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a);
 constexpr int SHT_THREADS = 1024;
 constexpr int SHT_PER = MAX_TILES / SHT_THREADS;   // tiles per thread, held in registers (8)
+// the exchange plan of a self-drawn resample needs nothing but the counts: the table kernel's (first) workgroup makes it on its way out
+// instead of a launch of its own (do_plan 0: the window form, whose plan also scans the draw kernel's counts)
+__device__ __forceinline__ void mp_table_then_plan(const mp_own_plan_args& plan, int do_plan) {
+    if (!do_plan) return;       // (uniform)
+    __syncthreads();            // the counts and the scalars this workgroup just stored are out (a workgroup barrier waits for its stores)
+    mp_own_plan<SHT_THREADS>(plan);
+}
 __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
                                                              double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
                                                              u64* __restrict__ incl_all, double* __restrict__ ratio_all,
                                                              long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
                                                              unsigned long long* __restrict__ c_all = nullptr, int scheme = 0, int rank = 0,
                                                              uint32_t k0 = 0, uint32_t k1 = 0, uint32_t rc = 0, mp_own_range* range = nullptr,
-                                                             u64* __restrict__ kthr = nullptr) {
+                                                             u64* __restrict__ kthr = nullptr, mp_own_plan_args plan = mp_own_plan_args{}, int do_plan = 0) {
     __shared__ double s_red[SHT_THREADS / 64];
     __shared__ u64 s_wtot[SHT_THREADS / 64];
     __shared__ u64 s_wtot2[SHT_THREADS / 64];
@@ -434,6 +468,7 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restri
             if (tid == rank) { range->g_lo = g0; range->g_hi = s_G[tid]; }
         }
     }
+    mp_table_then_plan(plan, do_plan);
 }
 // The same table by `world` workgroups (worlds of more than one rank): workgroup r takes rank r's nt_local tiles, so the
 // serial part no longer grows with the job (16.9 us for 8 x 512 tiles by one workgroup, profiles/r03/route_scale.txt).
@@ -451,7 +486,8 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table_mw(const u64* __res
                                                                 long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
                                                                 unsigned long long* __restrict__ c_all, int scheme, int rank, uint32_t k0, uint32_t k1,
                                                                 uint32_t rc, mp_own_range* range, u64* __restrict__ kthr, mp_tab_part* __restrict__ part,
-                                                                unsigned int* __restrict__ ticket, unsigned int ticket_target) {
+                                                                unsigned int* __restrict__ ticket, unsigned int ticket_target,
+                                                                mp_own_plan_args plan = mp_own_plan_args{}, int do_plan = 0) {
     __shared__ double s_red[SHT_THREADS / 64];
     __shared__ u64 s_wtot[SHT_THREADS / 64];
     __shared__ u64 s_wtot2[SHT_THREADS / 64];
@@ -597,6 +633,7 @@ __global__ __launch_bounds__(SHT_THREADS) void k_shard_table_mw(const u64* __res
             if (tid == rank) { range->g_lo = g0; range->g_hi = s_G[tid]; }
         }
     }
+    mp_table_then_plan(plan, do_plan);
 }
 // owner side: blockIdx.x & 7 = eighth of this shard's tiles (workgroups are dealt round-robin to the 8 XCDs, gridDim.x is
 // a multiple of 8), blockIdx.y = asking rank.  Per request: guide cell -> first row -> short forward walk, all inside
@@ -734,31 +771,6 @@ __device__ __forceinline__ void mp_locate_own(const u64* incl, const u64* W_, co
     *tile = (uint32_t)b; *lt = x; *gslot = (uint32_t)b * (uint32_t)GUIDE_N + g;
 }
 
-// the exchange plan: unit u of the surplus (donors in rank order) fills unit u of the deficit (receivers in rank order)
-struct mp_owned_plan {
-    u64 S[SH_MAX_WORLD], D[SH_MAX_WORLD], PS[SH_MAX_WORLD], PD[SH_MAX_WORLD];
-};
-// stores the host will read while the stream is still running: write-through to system scope (sc0 sc1), no cache write-back
-__device__ __forceinline__ void mp_st_sys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void mp_st_sys(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void mp_st_sys(double* p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-struct mp_own_plan_args {
-    u64 n, n_global, cap;
-    int world, nsc, lattice, S;
-    uint32_t* sccnt;                 // [nsc] own draws per super-chunk (in), read with agent-scope loads
-    unsigned long long* c_all;       // [world] offspring per rank: k_shard_table (lattice: closed form; multinomial: zeroed) + the draw kernel's atomics
-    mp_dev_scalars* scal;
-    mp_dev_scalars* undo;
-    const mp_tab_head* head;         // world of one: the single filter's table (ensure_table) is the job's table; k_shard_own_draw folds it
-    uint32_t* base;                  // [nsc] out: first offspring position of every super-chunk
-    mp_owned_plan* plan_out;
-    mp_shard_pub* pub;               // host-mapped
-    unsigned long long seq;
-    const mp_own_range* range;       // lattice: only the super-chunks of the own range were written (and are scanned)
-    u64 Wd;
-};
 // by ONE workgroup of THREADS threads
 template <int THREADS>
 __device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a) {

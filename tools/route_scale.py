@@ -56,7 +56,8 @@ def main():
             r = eng.get_timing(capi.MP_K_BIN_DRAWS)
             g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
             place = g[0] / g[1] * 1e3 if g[1] else 0.0   # (a world of one launches nothing there: the next k_propagate looks its draws up)
-            print(f"world {world}: owner-keeps {name}: count (table + own draws + plan) {r[0] / r[1] * 1e3:.1f} us, place + surplus lookups {place:.1f} us",
+            count = r[0] / r[1] * 1e3 if r[1] else 0.0   # (a self-drawn resample in a world of one launches nothing at all)
+            print(f"world {world}: owner-keeps {name}: count (table + own draws + plan) {count:.1f} us, place + surplus lookups {place:.1f} us",
                   flush=True)
         # a whole step of this rank, kernel by kernel (HIP events around every launch): count + expand + commit (asynchronous) + the
         # next propagate, which makes the kept draws of a self-drawn resample itself (the rows "received" for the deficit slots are
