@@ -37,6 +37,7 @@ print(json.dumps(r))"; done > $OUT/reference_shaped_loop.jsonl 2>/dev/null || ec
 cd /tmp
 # the sharded code path in a world of one (owner-keeps exchange), kernel stats only
 MP_BENCH_FORCE_SHARDED=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sharded -o bench -- $B --steps 50 --warmup 10 > $OUT/trace_sharded.log 2>&1 || echo "sharded trace pass failed"
+MP_BENCH_FORCE_SHARDED=1 MP_SHARD_EXCHANGE=split timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sharded_split -o bench -- $B --steps 50 --warmup 10 > $OUT/trace_sharded_split.log 2>&1 || echo "sharded split trace pass failed"
 cd $R && MP_BENCH_FORCE_SHARDED=1 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline > $OUT/bench_forced_sharded.json 2> $OUT/bench_forced_sharded.err || echo "forced-sharded bench failed"
 cd $R && MP_BENCH_FORCE_SHARDED=1 MP_SHARD_ALWAYS_COLLECTIVE=1 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline > $OUT/bench_forced_sharded_rccl.json 2> $OUT/bench_forced_sharded_rccl.err || echo "forced-sharded RCCL bench failed"
 cd $R && MP_BENCH_FORCE_SHARDED=1 MP_SHARD_EXCHANGE=split timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline --no-systematic-leg > $OUT/bench_forced_sharded_split.json 2> $OUT/bench_forced_sharded_split.err || echo "forced-sharded split bench failed"
