@@ -393,8 +393,10 @@ int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_para
                         int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out);
 /* Number of site ids of the model (the row width of mp_mh_read_trace). */
 int32_t mp_mh_n_sites(mp_mh* h, int32_t* out);
-/* Every chain's trace: values[n_chains][n_sites] (0 where the site is absent) and present[n_chains] (bit k = site k is in the
- * trace).  mp_mh_step (proposal kinds registered for the model), mp_regen_mh_step (mask_sites = any site ids; cycle and the
+/* Every chain's trace: values[n_chains][n_sites] (0 where the site is absent) and present[n_chains][W] — 32-bit words, W =
+ * (n_sites + 31) / 32: ONE word per chain for models of up to 32 sites (every model the reference's tests need), two up to the
+ * 64 sites a model may have; bit k of a chain's words = site k is in the trace.  Every `*present*` array of the mp_fn_* calls
+ * below has this layout.  mp_mh_step (proposal kinds registered for the model), mp_regen_mh_step (mask_sites = any site ids; cycle and the
  * empty mask as above), mp_mh_read_logjp, mp_mh_iterations and mp_mh_destroy apply to these handles; mp_mh_read_state and
  * mp_mh_read_observations do not. */
 int32_t mp_mh_read_trace(mp_mh* h, double* values, uint32_t* present);
@@ -405,7 +407,7 @@ int32_t mp_mh_read_trace(mp_mh* h, double* values, uint32_t* present);
  * calls below expose the pieces so that a caller can compose inference moves of its own.  One call = the operation on EVERY
  * chain of the handle (each chain's trace is the `trace` argument; args = the model's parameters).
  *   constraints  shared by all chains: sites[n_constraints] + values[n_constraints]; or per chain: chain_values[n_chains][n_sites]
- *                + chain_present[n_chains] (the layout of mp_mh_read_trace — what mp_fn_propose and a discard come out as), with
+ *                + chain_present[n_chains][W] (the layout of mp_mh_read_trace — what mp_fn_propose and a discard come out as), with
  *                sites = values = NULL, n_constraints = 0
  *   argdiff      ArgDiff::NoChange / ::Unknown (gfi.rs:94-111): under Unknown every revisited choice is re-scored
  *   rng_step     the Philox step of whatever the call draws (free sites); 0 = the next MH iteration's, which the call then

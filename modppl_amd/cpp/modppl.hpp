@@ -188,14 +188,16 @@ public:
         check(mp_regen_mh_step(h_, mask_sites.empty() ? nullptr : mask_sites.data(), (int32_t)mask_sites.size(), cycle ? 1 : 0, n_iters, &acc));
         return acc;
     }
-    // values[chain][site] (0 where absent), present[chain] (bit k = site k is in the trace)
+    // values[chain][site] (0 where absent), present[chain][words()] (32-bit words, bit k of the chain's words = site k is in the trace;
+    // ONE word per chain for models of up to 32 sites)
+    size_t words() const { return ((size_t)ns_ + 31) / 32; }
     void trace(std::vector<double>& values, std::vector<uint32_t>& present) {
         values.resize(n_ * (size_t)ns_);
-        present.resize(n_);
+        present.resize(n_ * words());
         check(mp_mh_read_trace(h_, values.data(), present.data()));
     }
     // ---- GenFn::update / regenerate / assess / propose one at a time, every chain per call (gfi.rs:57-90; mp_fn_* of the C ABI) ----
-    // A per-chain table of choices: values[chain][site], present[chain] — what propose() and update()'s discard return.
+    // A per-chain table of choices: values[chain][site], present[chain][words()] — what propose() and update()'s discard return.
     struct Choices {
         std::vector<double> values;
         std::vector<uint32_t> present;
@@ -206,7 +208,7 @@ public:
         std::vector<int32_t> sites;
         std::vector<double> vals, w(n_);
         for (const auto& c : constraints) { sites.push_back(c.first); vals.push_back(c.second); }
-        if (discard) { discard->values.resize(n_ * (size_t)ns_); discard->present.resize(n_); }
+        if (discard) { discard->values.resize(n_ * (size_t)ns_); discard->present.resize(n_ * words()); }
         check(mp_fn_update(h_, argdiff, rng_step, sites.empty() ? nullptr : sites.data(), vals.empty() ? nullptr : vals.data(), (int32_t)sites.size(), nullptr,
                            nullptr, w.data(), discard ? discard->values.data() : nullptr, discard ? discard->present.data() : nullptr));
         return w;
@@ -214,7 +216,7 @@ public:
     // per-chain constraints (e.g. the choices of propose())
     std::vector<double> update(const Choices& constraints, int32_t argdiff = MP_ARGDIFF_NOCHANGE, uint32_t rng_step = 0, Choices* discard = nullptr) {
         std::vector<double> w(n_);
-        if (discard) { discard->values.resize(n_ * (size_t)ns_); discard->present.resize(n_); }
+        if (discard) { discard->values.resize(n_ * (size_t)ns_); discard->present.resize(n_ * words()); }
         check(mp_fn_update(h_, argdiff, rng_step, nullptr, nullptr, 0, constraints.values.data(), constraints.present.data(), w.data(),
                            discard ? discard->values.data() : nullptr, discard ? discard->present.data() : nullptr));
         return w;
@@ -234,7 +236,7 @@ public:
     std::vector<double> propose(int32_t proposal_kind, const std::vector<double>& args, Choices& choices, uint32_t rng_step = 0) {
         std::vector<double> w(n_);
         choices.values.resize(n_ * (size_t)ns_);
-        choices.present.resize(n_);
+        choices.present.resize(n_ * words());
         check(mp_fn_propose(h_, proposal_kind, args.empty() ? nullptr : args.data(), (int32_t)args.size(), rng_step, choices.values.data(), choices.present.data(),
                             w.data()));
         return w;

@@ -6,7 +6,8 @@
 //     template <class H> MP_HD void operator()(H& g) const                      (a model)
 //     template <class H, class T> MP_HD void operator()(H& g, const T& tr) const (a proposal: `tr` is the trace it reads)
 //
-// whose addresses are compile-time site ids 0 .. NS-1 (NS <= 32) and whose choices are doubles (a bool is 0 / 1):
+// whose addresses are compile-time site ids 0 .. NS-1 (NS <= 64: the presence / mask words are 32 bits wide up to 32 sites, 64 beyond)
+// and whose choices are doubles (a bool is 0 / 1):
 //     g.template normal<SITE>(mu, sd, ln_sd)     `normal(mu, sd) %= addr`    -> sample_at (dyngenfn.rs:100-273)
 //     g.template bernoulli<SITE>(p)              `bernoulli(p) %= addr`
 //     g.template uniform<SITE>(a, b)             `uniform(a, b) %= addr`
@@ -39,7 +40,12 @@
 #pragma once
 #include "mp_dists.h"
 
-#define MP_FN_MAX_SITES 32
+#include <type_traits>
+
+#define MP_FN_MAX_SITES 64
+// one bit per site: a 32-bit word for models of up to 32 sites (everything the reference's tests need), 64 bits beyond
+template <int NS>
+using mp_fn_bits_t = typename std::conditional<(NS > 32), uint64_t, uint32_t>::type;
 
 // the return value of a sub-call body (and of a model): up to four doubles
 struct mp_fn_ret {
@@ -51,14 +57,14 @@ struct mp_fn_trace {
     double val[NS];
     double lp[NS];
     double subw[NS];   // [lowest site of a sub-call] the running weight of that sub-trie
-    uint32_t present;
-    MP_HD bool has(int site) const { return (present >> site) & 1u; }
+    mp_fn_bits_t<NS> present;
+    MP_HD bool has(int site) const { return ((present >> site) & 1u) != 0u; }
     // tr.data.read(addr) of a proposal body; `dflt` when the address is absent (hierarchical.rs:54-58 `search`)
     MP_HD double get(int site, double dflt) const { return has(site) ? val[site] : dflt; }
 };
 template <int NS>
 MP_HD void mp_fn_clear(mp_fn_trace<NS>& t) {
-    t.present = 0u;
+    t.present = 0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) { t.val[k] = 0.; t.lp[k] = 0.; t.subw[k] = 0.; }
 }
@@ -127,23 +133,24 @@ enum mp_fn_mode { MP_FN_SIMULATE = 0, MP_FN_GENERATE = 1, MP_FN_UPDATE = 2, MP_F
 
 template <int NS, int MODE>
 struct mp_fn_handler {
-    static_assert(NS <= MP_FN_MAX_SITES, "site ids are bits of a 32-bit word");
+    static_assert(NS <= MP_FN_MAX_SITES, "site ids are bits of a 64-bit word at most");
+    using bits_t = mp_fn_bits_t<NS>;
     const mp_stream& rng;
     uint32_t dom;                     // Philox domain of this function's draws (MP_DOM_MODEL / MP_DOM_PROPOSAL); site id = site
     const mp_fn_trace<NS>* prev;      // UPDATE / REGENERATE: the previous trace
     const mp_fn_trace<NS>* cons;      // GENERATE / UPDATE: the constraints (presence bits + values)
-    uint32_t mask;                    // REGENERATE: the masked sites
+    bits_t mask;                      // REGENERATE: the masked sites
     mp_fn_trace<NS> tr;               // the trace being built
     double weight;                    // SIMULATE: the trace's score
     bool changed;                     // diff == ArgDiff::Unknown
-    uint32_t visited, consumed, discarded;
+    bits_t visited, consumed, discarded;
     bool panic;
     double sw;            // inside a sub-call: the running weight of its trie
     bool in_sub;          // the sites visited belong to a sub-trie whose weight is being kept
     bool from_prev;       // REGENERATE through an unmasked sub-call after an upstream change: generate with the old choices as constraints
 
-    MP_HD mp_fn_handler(const mp_stream& r, uint32_t dom_, const mp_fn_trace<NS>* prev_, const mp_fn_trace<NS>* cons_, uint32_t mask_ = 0u)
-        : rng(r), dom(dom_), prev(prev_), cons(cons_), mask(mask_), weight(0.), changed(false), visited(0u), consumed(0u), discarded(0u),
+    MP_HD mp_fn_handler(const mp_stream& r, uint32_t dom_, const mp_fn_trace<NS>* prev_, const mp_fn_trace<NS>* cons_, bits_t mask_ = 0)
+        : rng(r), dom(dom_), prev(prev_), cons(cons_), mask(mask_), weight(0.), changed(false), visited(0), consumed(0), discarded(0),
           panic(false), sw(0.), in_sub(false), from_prev(false) {
         mp_fn_clear(tr);
     }
@@ -156,8 +163,8 @@ struct mp_fn_handler {
     template <int SITE, int K, class Dist>
     MP_HD void at_k(const Dist& d, double* x) {
         static_assert(SITE >= 0 && SITE + K <= NS && K >= 1, "site id out of range");
-        constexpr uint32_t bit = 1u << SITE;
-        constexpr uint32_t vbits = ((K >= 32 ? 0u : (1u << K)) - 1u) << SITE;
+        constexpr bits_t bit = bits_t(1) << SITE;
+        constexpr bits_t vbits = (bits_t)((K >= 32 ? uint64_t(0) : (uint64_t(1) << K)) - 1u) << SITE;
         visited |= vbits;
         double lp;
 #define MP_FN_PUT_() do { _Pragma("unroll") for (int j_ = 0; j_ < K; ++j_) { tr.val[SITE + j_] = x[j_]; tr.lp[SITE + j_] = 0.; } tr.lp[SITE] = lp; tr.present |= vbits; } while (0)
@@ -184,7 +191,7 @@ struct mp_fn_handler {
             }
             if (in_sub) sw += lp;
         } else {
-            const bool had = (prev->present & bit) != 0u;
+            const bool had = (prev->present & bit) != 0;
             if (from_prev) {   // generate(args, sub): the old choice is the constraint (:116-131); a site the old sub-trace lacks is drawn
                 if (had) {
                     MP_FN_PREV_();
@@ -217,7 +224,7 @@ struct mp_fn_handler {
                     return;
                 }
             } else {
-                fresh = (mask & bit) != 0u;
+                fresh = (mask & bit) != 0;
             }
             if (in_sub && had) sw -= prev->lp[SITE];   // trace.data.remove(addr) comes first in every arm
             if (!fresh && had) {
@@ -266,8 +273,8 @@ struct mp_fn_handler {
     }
 
     // previous choices of `sites` that this visit did not reach: they leave the trace; their log-densities in site order
-    MP_HD double collect(uint32_t sites) {
-        const uint32_t un = prev->present & sites & ~visited;
+    MP_HD double collect(bits_t sites) {
+        const bits_t un = prev->present & sites & ~visited;
         double c = 0.;
 #pragma unroll
         for (int k = 0; k < NS; ++k)
@@ -288,10 +295,12 @@ struct mp_fn_handler {
     // weight from 0, its own trie weight `sw` — and on the way out it does to the ENCLOSING frame's trie what trace_at does to
     // `trace.data`: remove(addr) took the old sub-trie's weight off when the call began (:207, :221, :252-), insert(addr, sub) puts the
     // new one on (:186, :200, :244).
-    template <uint32_t SITES, class Body>
+    template <uint64_t SITES64, class Body>
     MP_HD auto call(Body&& body) {
-        static_assert(SITES != 0u, "a sub-call names the set of its sites");
-        constexpr int ID = __builtin_ctz(SITES);   // where the trace keeps this sub-trie's running weight
+        static_assert(SITES64 != 0u, "a sub-call names the set of its sites");
+        static_assert(NS > 32 || (SITES64 >> 32) == 0u, "a sub-call's sites are sites of the model");
+        constexpr bits_t SITES = (bits_t)SITES64;
+        constexpr int ID = __builtin_ctzll(SITES64);   // where the trace keeps this sub-trie's running weight
         const bool o_in = in_sub;                  // the enclosing frame: is it a sub-trie whose weight is being kept, and that weight so far
         const double o_sw = sw;
         if constexpr (MODE == MP_FN_SIMULATE) {
@@ -305,7 +314,7 @@ struct mp_fn_handler {
         } else if constexpr (MODE == MP_FN_GENERATE) {
             // generate(args, choices): weight += d_weight as one term (:316-319); simulate when nothing is constrained
             const double w_out = weight;
-            const bool any = (cons->present & SITES) != 0u;
+            const bool any = (cons->present & SITES) != 0;
             weight = 0.;
             in_sub = true; sw = 0.;
             auto r = body(*this);
@@ -315,7 +324,7 @@ struct mp_fn_handler {
             weight = any ? w_out + weight : w_out;
             return r;
         } else {
-            const uint32_t had = prev->present & SITES;
+            const bits_t had = prev->present & SITES;
             const double w_out = weight;
             if (from_prev) {
                 // inside an enclosing generate(args, old sub-trace): this call is that generate's own trace_at — the old choices of
@@ -329,7 +338,7 @@ struct mp_fn_handler {
                 weight = had ? w_out + weight : w_out;
                 return r;
             }
-            uint32_t touched;
+            bits_t touched;
             if constexpr (MODE == MP_FN_UPDATE) touched = cons->present & SITES;
             else touched = mask & SITES;
             const double e_sw = (o_in && had) ? o_sw - prev->subw[ID] : o_sw;   // the enclosing trie after trace.data.remove(addr)
@@ -375,11 +384,11 @@ struct mp_fn_handler {
     // the outer gc of update / regenerate (dyngenfn.rs:453-483); constraints nobody consumed are the reference's panic
     MP_HD void finish() {
         if constexpr (MODE == MP_FN_UPDATE) {
-            const double c = collect(0xFFFFFFFFu);
+            const double c = collect(~bits_t(0));
             weight = weight - c;
             if (cons->present & ~consumed) panic = true;
         } else if constexpr (MODE == MP_FN_REGENERATE) {
-            (void)collect(0xFFFFFFFFu);
+            (void)collect(~bits_t(0));
         } else if constexpr (MODE == MP_FN_GENERATE) {
             if (cons->present & ~consumed) panic = true;
         }

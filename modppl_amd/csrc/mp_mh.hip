@@ -537,8 +537,8 @@ int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_para
     for (int q = 0; q < n_constraints; ++q) {
         const int s = constraint_sites[q];
         if (s < 0 || s >= ops->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "constraint site out of range");
-        if (cs.bits & (1u << s)) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
-        cs.bits |= 1u << s;
+        if (cs.bits & (1ull << s)) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
+        cs.bits |= 1ull << s;
         cs.val[s] = constraint_values[q];
     }
     int ndev = 0;
@@ -555,7 +555,7 @@ int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_para
     if (stream) h->stream = (hipStream_t)stream;
     else { MHCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     MHCK(hipMalloc(&h->fvals, sizeof(double) * n_chains * 2 * (size_t)ops->ns()));   // [n_sites] values + [n_sites] sub-trie running weights (rows of sub-call ids)
-    MHCK(hipMalloc(&h->fpresent, sizeof(uint32_t) * n_chains));
+    MHCK(hipMalloc(&h->fpresent, sizeof(uint32_t) * n_chains * (size_t)fn_words(ops->ns())));
     MHCK(hipMalloc(&h->tmp, sizeof(double) * n_chains));
     MHCK(hipMalloc(&h->d_acc, sizeof(u64) * 2));
     MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64) * 2, h->stream));
@@ -564,6 +564,38 @@ int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_para
     const int32_t rf = mh_finish(h.get(), nullptr);   // a constraint on a site the model never visits is the reference's panic
     if (rf != MP_OK) return rf;
     *out = h.release();
+    return MP_OK;
+}
+
+// Presence words across the C ABI: [chain][W] 32-bit words on the host side, W = (n_sites + 31) / 32 (one word up to 32 sites);
+// [word][chain] on the device (mp_mh_fn.h fn_bits_load).  For W = 1 the two are the same array.
+static int fn_words_of(const mp_mh* h) { return fn_words(h->fn->ns()); }
+static int32_t present_to_host(mp_mh* h, const uint32_t* d_present, uint32_t* host_out) {
+    const int W = fn_words_of(h);
+    if (W == 1) {
+        MHCK(hipMemcpyAsync(host_out, d_present, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+        MHCK(hipStreamSynchronize(h->stream));
+        return MP_OK;
+    }
+    std::vector<uint32_t> t((size_t)W * h->n);
+    MHCK(hipMemcpyAsync(t.data(), d_present, sizeof(uint32_t) * t.size(), hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipStreamSynchronize(h->stream));
+    for (u64 i = 0; i < h->n; ++i)
+        for (int w = 0; w < W; ++w) host_out[i * (u64)W + w] = t[(size_t)w * h->n + i];
+    return MP_OK;
+}
+static int32_t present_to_device(mp_mh* h, const uint32_t* host_in, uint32_t* d_present) {
+    const int W = fn_words_of(h);
+    if (W == 1) {
+        MHCK(hipMemcpyAsync(d_present, host_in, sizeof(uint32_t) * h->n, hipMemcpyHostToDevice, h->stream));
+        MHCK(hipStreamSynchronize(h->stream));
+        return MP_OK;
+    }
+    std::vector<uint32_t> t((size_t)W * h->n);
+    for (u64 i = 0; i < h->n; ++i)
+        for (int w = 0; w < W; ++w) t[(size_t)w * h->n + i] = host_in[i * (u64)W + w];
+    MHCK(hipMemcpyAsync(d_present, t.data(), sizeof(uint32_t) * t.size(), hipMemcpyHostToDevice, h->stream));
+    MHCK(hipStreamSynchronize(h->stream));   // `t` is a local
     return MP_OK;
 }
 
@@ -581,8 +613,7 @@ int32_t mp_mh_read_trace(mp_mh* h, double* values, uint32_t* present) {
     const int ns = h->fn->ns();
     std::vector<double> v((size_t)ns * h->n);
     MHCK(hipMemcpyAsync(v.data(), h->fvals, sizeof(double) * v.size(), hipMemcpyDeviceToHost, h->stream));
-    MHCK(hipMemcpyAsync(present, h->fpresent, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
-    MHCK(hipStreamSynchronize(h->stream));
+    { const int32_t rcp = present_to_host(h, h->fpresent, present); if (rcp != MP_OK) return rcp; }   // (waits for the stream)
     for (u64 i = 0; i < h->n; ++i)
         for (int k = 0; k < ns; ++k) values[i * (u64)ns + k] = v[(size_t)k * h->n + i];
     return MP_OK;
@@ -604,7 +635,7 @@ static int32_t mh_fn_regen(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, 
     mp_fn_maskspec m{};
     for (int q = 0; q < n_mask; ++q) {
         if (mask_sites[q] < 0 || mask_sites[q] >= h->fn->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "mask site out of range");
-        m.bits |= 1u << mask_sites[q];
+        m.bits |= 1ull << mask_sites[q];
         m.cycle[q] = (unsigned char)mask_sites[q];
     }
     m.n_cycle = (cycle && n_mask > 0) ? n_mask : 0;
@@ -758,9 +789,9 @@ static int32_t gfi_scratch(mp_mh* h) {
     const size_t ns = (size_t)h->fn->ns();
     if (!h->gfi_vals) {
         MHCK(hipMalloc(&h->gfi_vals, sizeof(double) * ns * h->n));
-        MHCK(hipMalloc(&h->gfi_present, sizeof(uint32_t) * h->n));
+        MHCK(hipMalloc(&h->gfi_present, sizeof(uint32_t) * h->n * (size_t)fn_words_of(h)));
         MHCK(hipMalloc(&h->gfi_cons, sizeof(double) * ns * h->n));
-        MHCK(hipMalloc(&h->gfi_cpresent, sizeof(uint32_t) * h->n));
+        MHCK(hipMalloc(&h->gfi_cpresent, sizeof(uint32_t) * h->n * (size_t)fn_words_of(h)));
     }
     return MP_OK;
 }
@@ -772,12 +803,13 @@ static int32_t gfi_constraints(mp_mh* h, const int32_t* sites, const double* val
         if (sites || values || n_cons) return mp_set_error(MP_ERR_INVALID_ARG, "constraints are either shared (sites, values) or per chain, not both");
         std::vector<double> t((size_t)ns * h->n);   // [chain][site] -> [site][chain]
         for (u64 i = 0; i < h->n; ++i) {
-            if (ns < 32 && (chain_present[i] >> ns)) return mp_set_error(MP_ERR_INVALID_ARG, "chain_present names a site the model does not have");
+            const int W = fn_words(ns);
+            const uint32_t top = chain_present[i * (u64)W + (W - 1)];   // the last word: bits beyond the model's sites
+            if ((ns & 31) && (top >> (ns & 31))) return mp_set_error(MP_ERR_INVALID_ARG, "chain_present names a site the model does not have");
             for (int k = 0; k < ns; ++k) t[(size_t)k * h->n + i] = chain_values[i * (u64)ns + k];
         }
         MHCK(hipMemcpyAsync(h->gfi_cons, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, h->stream));
-        MHCK(hipMemcpyAsync(h->gfi_cpresent, chain_present, sizeof(uint32_t) * h->n, hipMemcpyHostToDevice, h->stream));
-        MHCK(hipStreamSynchronize(h->stream));   // `t` is a local
+        { const int32_t rcp = present_to_device(h, chain_present, h->gfi_cpresent); if (rcp != MP_OK) return rcp; }   // (waits for the stream: `t` is a local)
         out.d_vals = h->gfi_cons;
         out.d_present = h->gfi_cpresent;
         return MP_OK;
@@ -786,8 +818,8 @@ static int32_t gfi_constraints(mp_mh* h, const int32_t* sites, const double* val
     for (int q = 0; q < n_cons; ++q) {
         const int sidx = sites[q];
         if (sidx < 0 || sidx >= ns) return mp_set_error(MP_ERR_INVALID_ARG, "constraint site out of range");
-        if (out.cs.bits & (1u << sidx)) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
-        out.cs.bits |= 1u << sidx;
+        if (out.cs.bits & (1ull << sidx)) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
+        out.cs.bits |= 1ull << sidx;
         out.cs.val[sidx] = values[q];
     }
     return MP_OK;
@@ -811,15 +843,12 @@ static int32_t gfi_table(mp_mh* h, double* values_out, uint32_t* present_out) { 
     if (!values_out && !present_out) return MP_OK;
     const int ns = h->fn->ns();
     std::vector<double> v((size_t)ns * h->n);
-    std::vector<uint32_t> pr(h->n);
     MHCK(hipMemcpyAsync(v.data(), h->gfi_vals, sizeof(double) * v.size(), hipMemcpyDeviceToHost, h->stream));
-    MHCK(hipMemcpyAsync(pr.data(), h->gfi_present, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (present_out) { const int32_t rcp = present_to_host(h, h->gfi_present, present_out); if (rcp != MP_OK) return rcp; }
     MHCK(hipStreamSynchronize(h->stream));
-    for (u64 i = 0; i < h->n; ++i) {
-        if (present_out) present_out[i] = pr[i];
-        if (values_out)
+    if (values_out)
+        for (u64 i = 0; i < h->n; ++i)
             for (int k = 0; k < ns; ++k) values_out[i * (u64)ns + k] = v[(size_t)k * h->n + i];
-    }
     return MP_OK;
 }
 
@@ -847,10 +876,10 @@ int32_t mp_fn_regenerate(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int
     if (rc != MP_OK) return rc;
     if (argdiff != MP_ARGDIFF_NOCHANGE && argdiff != MP_ARGDIFF_UNKNOWN) return mp_set_error(MP_ERR_INVALID_ARG, "argdiff: MP_ARGDIFF_NOCHANGE or MP_ARGDIFF_UNKNOWN");
     if (n_mask < 0 || (n_mask > 0 && !mask_sites)) return mp_set_error(MP_ERR_INVALID_ARG, "bad mask");
-    uint32_t bits = 0;
+    uint64_t bits = 0;
     for (int q = 0; q < n_mask; ++q) {
         if (mask_sites[q] < 0 || mask_sites[q] >= h->fn->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "mask site out of range");
-        bits |= 1u << mask_sites[q];
+        bits |= 1ull << mask_sites[q];
     }
     rc = h->fn->regenerate(h, bits, argdiff == MP_ARGDIFF_UNKNOWN, step);
     if (rc != MP_OK) return rc;

@@ -19,12 +19,12 @@
 #include "mp_genfn.h"
 
 struct mp_fn_maskspec {
-    uint32_t bits;      // cycle == 0: the masked sites (0 = empty mask = whole schema)
+    uint64_t bits;      // cycle == 0: the masked sites (0 = empty mask = whole schema)
     int n_cycle;        // > 0: iteration k masks only cycle[k % n_cycle]
     unsigned char cycle[MP_FN_MAX_SITES];
 };
 struct mp_fn_consspec {
-    uint32_t bits;
+    uint64_t bits;
     double val[MP_FN_MAX_SITES];
 };
 
@@ -33,13 +33,27 @@ struct mp_fn_consspec {
 // history of the trie's inserts and removes, mp_genfn.h)
 template <class M>
 __host__ __device__ constexpr bool fn_is_sub_id(int k) {
-    return M::sub_of(k) != 0u && (M::sub_of(k) & ((1u << k) - 1u)) == 0u;
+    return M::sub_of(k) != 0u && ((uint64_t)M::sub_of(k) & ((uint64_t(1) << k) - 1u)) == 0u;
+}
+// Presence words between launches and across the C ABI: 32-bit words, one per chain up to 32 sites, two beyond — word w of chain i at
+// present[w * n + i] on the device ([chain][word] on the host side of the ABI: the same thing for one word)
+__host__ __device__ constexpr int fn_words(int ns) { return (ns + 31) / 32; }
+template <int NS>
+__device__ __forceinline__ mp_fn_bits_t<NS> fn_bits_load(const uint32_t* __restrict__ present, u64 i, u64 n) {
+    mp_fn_bits_t<NS> b = present[i];
+    if constexpr (NS > 32) b |= (mp_fn_bits_t<NS>)present[n + i] << 32;
+    return b;
+}
+template <int NS>
+__device__ __forceinline__ void fn_bits_store(uint32_t* __restrict__ present, u64 i, u64 n, mp_fn_bits_t<NS> b) {
+    present[i] = (uint32_t)b;
+    if constexpr (NS > 32) present[n + i] = (uint32_t)((uint64_t)b >> 32);
 }
 template <class M>
 __device__ __forceinline__ void fn_load(const M& model, const mp_stream& s, u64 i, u64 n, const double* __restrict__ vals,
                                         const uint32_t* __restrict__ present, mp_fn_trace<M::NS>& out) {
     mp_fn_trace<M::NS> c;
-    c.present = present[i];
+    c.present = fn_bits_load<M::NS>(present, i, n);
 #pragma unroll
     for (int k = 0; k < M::NS; ++k) {
         c.val[k] = ((c.present >> k) & 1u) ? vals[(u64)k * n + i] : 0.;
@@ -55,7 +69,7 @@ __device__ __forceinline__ void fn_load(const M& model, const mp_stream& s, u64 
 }
 template <class M>
 __device__ __forceinline__ void fn_store(const mp_fn_trace<M::NS>& t, u64 i, u64 n, double* __restrict__ vals, uint32_t* __restrict__ present) {
-    present[i] = t.present;
+    fn_bits_store<M::NS>(present, i, n, t.present);
 #pragma unroll
     for (int k = 0; k < M::NS; ++k) {
         vals[(u64)k * n + i] = t.has(k) ? t.val[k] : 0.;
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_init(u64 n, uint32_t k0, uint
         mp_stream s;
         s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = 0;
         mp_fn_trace<M::NS> c;
-        c.present = cs.bits;
+        c.present = (mp_fn_bits_t<M::NS>)cs.bits;
 #pragma unroll
         for (int k = 0; k < M::NS; ++k) { c.val[k] = cs.val[k]; c.lp[k] = 0.; }
         mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
@@ -118,8 +132,8 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_regen(u64 n, uint32_t k0, uin
         fn_load(model, s, i, n, vals, present, cur);
         for (int it = 0; it < n_iters; ++it) {
             s.step = iter0 + (uint32_t)it;
-            uint32_t m = mask.bits;
-            if (mask.n_cycle > 0) m = 1u << mask.cycle[(iter0 - 1u + (uint32_t)it) % (uint32_t)mask.n_cycle];
+            mp_fn_bits_t<M::NS> m = (mp_fn_bits_t<M::NS>)mask.bits;
+            if (mask.n_cycle > 0) m = mp_fn_bits_t<M::NS>(1) << mask.cycle[(iter0 - 1u + (uint32_t)it) % (uint32_t)mask.n_cycle];
             if (m == 0u) m = cur.present;   // mask.is_leaf(): the whole schema (dyngenfn.rs:571)
             mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
             model(g);
@@ -185,7 +199,7 @@ __device__ __forceinline__ void fn_cons(const mp_fn_consspec& cs, const double* 
                                         mp_fn_trace<NS>& c) {
     // shared: the sites cs.bits with the values cs.val; per chain: the table cvals[site][chain] + cpresent[chain] (what fn_emit writes:
     // the choices of a propose, the discard of an update — a proposal's choices differ in their SITES from chain to chain)
-    c.present = cpresent ? cpresent[i] : cs.bits;
+    c.present = cpresent ? fn_bits_load<NS>(cpresent, i, n) : (mp_fn_bits_t<NS>)cs.bits;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const bool on = (c.present >> k) & 1u;
@@ -195,8 +209,8 @@ __device__ __forceinline__ void fn_cons(const mp_fn_consspec& cs, const double* 
     }
 }
 template <int NS>
-__device__ __forceinline__ void fn_emit(const mp_fn_trace<NS>& t, uint32_t bits, u64 i, u64 n, double* __restrict__ vals, uint32_t* __restrict__ present) {
-    present[i] = bits;
+__device__ __forceinline__ void fn_emit(const mp_fn_trace<NS>& t, mp_fn_bits_t<NS> bits, u64 i, u64 n, double* __restrict__ vals, uint32_t* __restrict__ present) {
+    fn_bits_store<NS>(present, i, n, bits);
 #pragma unroll
     for (int k = 0; k < NS; ++k) vals[(u64)k * n + i] = ((bits >> k) & 1u) ? t.val[k] : 0.;
 }
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_update(u64 n, uint32_t k0, ui
 }
 // (new_trace, weight) = model.regenerate(trace, args, diff, mask)   gfi.rs:66-73, dyngenfn.rs:562-583; the trace is replaced
 template <class M>
-__global__ __launch_bounds__(MH_THREADS) void k_fn_regenerate(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, uint32_t mask, int unknown,
+__global__ __launch_bounds__(MH_THREADS) void k_fn_regenerate(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, uint64_t mask, int unknown,
                                                               double* __restrict__ vals, uint32_t* __restrict__ present, double* __restrict__ w_out,
                                                               u64* __restrict__ totals) {
     const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_regenerate(u64 n, uint32_t k0
         s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
         mp_fn_trace<M::NS> cur;
         fn_load(model, s, i, n, vals, present, cur);
-        const uint32_t m = mask ? mask : cur.present;   // mask.is_leaf(): the whole schema (dyngenfn.rs:571)
+        const mp_fn_bits_t<M::NS> m = mask ? (mp_fn_bits_t<M::NS>)mask : cur.present;   // mask.is_leaf(): the whole schema (dyngenfn.rs:571)
         mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
         g.changed = unknown != 0;
         model(g);
@@ -319,7 +333,7 @@ struct mh_fn_ops {
     virtual int32_t logjp(mp_mh* h) = 0;
     // the GFI operations one at a time (mp_fn_*): weights into h->tmp, discard / choices into h->gfi_vals / h->gfi_present
     virtual int32_t update(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, int unknown, uint32_t step, bool want_discard) = 0;
-    virtual int32_t regenerate(mp_mh* h, uint32_t mask, int unknown, uint32_t step) = 0;
+    virtual int32_t regenerate(mp_mh* h, uint64_t mask, int unknown, uint32_t step) = 0;
     virtual int32_t assess(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, uint32_t step) = 0;
     virtual int32_t propose(mp_mh* h, int proposal_kind, const double* args, int n_args, uint32_t step) = 0;
     virtual int32_t assess_proposal(mp_mh* h, int proposal_kind, const double* args, int n_args, const mp_fn_consspec& cs, const double* d_cvals,
@@ -367,7 +381,7 @@ struct mh_fn_ops_t : mh_fn_ops {
         MHCK(hipGetLastError());
         return MP_OK;
     }
-    int32_t regenerate(mp_mh* h, uint32_t mask, int unknown, uint32_t step) override {
+    int32_t regenerate(mp_mh* h, uint64_t mask, int unknown, uint32_t step) override {
         hipLaunchKernelGGL(k_fn_regenerate<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), step, model,
                            mask, unknown, h->fvals, h->fpresent, h->tmp, h->d_acc);
         MHCK(hipGetLastError());

@@ -368,6 +368,94 @@ MP_REGISTER_MH_PROPOSAL(2, mp_nested_fn, mp_nested_flip_fn, mp_parse_nested_flip
 MP_REGISTER_MH_PROPOSAL(3, mp_nested_fn, mp_nested_drift_a_fn, mp_parse_nested_drift<mp_nested_drift_a_fn>)
 
 // ---------------------------------------------------------------------------------------
+// More than 32 sites (kind 114): the reference's traces are tries and have no size limit; here a trace is a dense row with one
+// presence bit per site, 32 bits wide up to 32 sites and 64 beyond (mp_genfn.h mp_fn_bits_t; two 32-bit words per chain through
+// the C ABI).  A line with 30 observations, then — at site ids ABOVE 32 — a sub-call whose second choice comes and goes and six more
+// observations that depend on it: constraints, masks, proposals, the discard, gc and a sub-trie's running weight all live in the high word.
+//   slope ~ normal(0, 2) %= "slope";  intercept ~ normal(0, 2) %= "intercept";  big ~ bernoulli(0.3) %= "big"
+//   y_j ~ normal(slope x_j + intercept, big ? 2 : 0.5) %= ("y", j),  j < 30
+//   off = offsets() /= "off":   o1 ~ normal(0, 1) %= "o1";  if big { o2 ~ normal(o1, 1) %= "o2" };  return o1 + o2
+//   z_k ~ normal(off + 0.1 k, 0.5) %= ("z", k),  k < 6
+//   params = xs[0 .. 30); the observations are constraints on Y0 + j and Z0 + k.
+// Moves: proposal 1 = drift of slope, intercept and o1 {std}; proposal 2 = toggle of `big` (proposes the other value with
+// probability 0.8, and o2 ~ normal(o1, 1) with a true `big`: its reverse finds the dropped o2 in the discard it assesses).
+// ---------------------------------------------------------------------------------------
+struct mp_wide_fn {
+    static constexpr int N_Y = 30, N_Z = 6;
+    enum { SLOPE = 0, INTERCEPT = 1, BIG = 2, Y0 = 3, O1 = Y0 + N_Y, O2 = O1 + 1, Z0 = O2 + 1 };
+    static constexpr int NS = Z0 + N_Z;   // 41
+    static constexpr uint64_t OFF = (uint64_t(1) << O1) | (uint64_t(1) << O2);
+    static constexpr uint64_t sub_of(int site) { return (site == O1 || site == O2) ? OFF : uint64_t(0); }
+    static constexpr bool is_bool(int site) { return site == BIG; }
+    double xs[N_Y];
+    double ln2, ln_half;
+
+    template <class H, int J>
+    MP_HD void ys(H& g, bool big, double slope, double intercept) const {
+        g.template normal<Y0 + J>(slope * xs[J] + intercept, big ? 2. : 0.5, big ? ln2 : ln_half);
+        if constexpr (J + 1 < N_Y) ys<H, J + 1>(g, big, slope, intercept);
+    }
+    template <class H, int K>
+    MP_HD void zs(H& g, double off) const {
+        g.template normal<Z0 + K>(off + 0.1 * (double)K, 0.5, ln_half);
+        if constexpr (K + 1 < N_Z) zs<H, K + 1>(g, off);
+    }
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        const double slope = g.template normal<SLOPE>(0., 2., ln2);
+        const double intercept = g.template normal<INTERCEPT>(0., 2., ln2);
+        const bool big = g.template bernoulli<BIG>(0.3);
+        ys<H, 0>(g, big, slope, intercept);
+        const mp_fn_ret off = g.template call<OFF>([&](H& q) {
+            mp_fn_ret r{};
+            const double o1 = q.template normal<O1>(0., 1., 0.);
+            r.v[0] = o1;
+            if (big) r.v[0] = o1 + q.template normal<O2>(o1, 1., 0.);
+            return r;
+        });
+        zs<H, 0>(g, off.v[0]);
+    }
+};
+inline bool mp_parse_wide_fn(const double* params, int n_params, mp_wide_fn& m, std::string& err) {
+    if (!params || n_params != mp_wide_fn::N_Y) { err = "wide model: params = xs[0 .. 30)"; return false; }
+    for (int k = 0; k < mp_wide_fn::N_Y; ++k) m.xs[k] = params[k];
+    m.ln2 = mp_log(2.); m.ln_half = mp_log(0.5);
+    return true;
+}
+MP_REGISTER_MH_MODEL(114, mp_wide_fn, mp_parse_wide_fn)
+
+struct mp_wide_drift_fn {
+    double sd, ln_sd;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        g.template normal<mp_wide_fn::SLOPE>(tr.val[mp_wide_fn::SLOPE], sd, ln_sd);
+        g.template normal<mp_wide_fn::INTERCEPT>(tr.val[mp_wide_fn::INTERCEPT], sd, ln_sd);
+        g.template normal<mp_wide_fn::O1>(tr.val[mp_wide_fn::O1], sd, ln_sd);
+    }
+};
+struct mp_wide_toggle_fn {
+    int unused;
+    template <class H, class T>
+    MP_HD void operator()(H& g, const T& tr) const {
+        if (g.template bernoulli<mp_wide_fn::BIG>(tr.val[mp_wide_fn::BIG] != 0. ? 0.2 : 0.8))
+            g.template normal<mp_wide_fn::O2>(tr.val[mp_wide_fn::O1], 1., 0.);
+    }
+};
+inline bool mp_parse_wide_drift_fn(const double* args, int n_args, mp_wide_drift_fn& p, std::string& err) {
+    if (!args || n_args != 1 || !(args[0] > 0.)) { err = "drift proposal takes {std > 0}"; return false; }
+    p.sd = args[0];
+    p.ln_sd = mp_log(args[0]);
+    return true;
+}
+inline bool mp_parse_wide_toggle_fn(const double*, int n_args, mp_wide_toggle_fn& p, std::string& err) {
+    if (n_args != 0) { err = "toggle proposal takes no arguments"; return false; }
+    p.unused = 0;
+    return true;
+}
+MP_REGISTER_MH_PROPOSAL(1, mp_wide_fn, mp_wide_drift_fn, mp_parse_wide_drift_fn)
+MP_REGISTER_MH_PROPOSAL(2, mp_wide_fn, mp_wide_toggle_fn, mp_parse_wide_toggle_fn)
+
+// ---------------------------------------------------------------------------------------
 // The reference's own Update regression functions (modppl/tests/dyngenfn.rs:30-53), kinds 110 - 112: what its known-answer
 // tests for `update` run (:55-114: -0.5, -2.517551, 0.4, -1.098612 twice) — here so that the same calls can be made on the
 // device through mp_fn_update (tests/test_gpu_gfi.py).  No params, no proposals.

@@ -381,12 +381,35 @@ class FunctionChains:
         capi.check(self._L.mp_regen_mh_step(self._h, m if sites else None, len(sites), int(cycle), int(n_iters), C.byref(acc)))
         return acc.value
 
+    # Presence words: the C ABI carries [num_chains][W] 32-bit words, W = (num_sites + 31) // 32.  Here: one integer per chain, bit k =
+    # site k — uint32 for models of up to 32 sites, uint64 beyond.
+    def _words(self):
+        return (self.num_sites + 31) // 32
+
+    def _present_buf(self):
+        return np.empty((self.num_chains, self._words()), dtype=np.uint32)
+
+    def _present_out(self, words):
+        if words.shape[1] == 1:
+            return words.reshape(self.num_chains)
+        return words[:, 0].astype(np.uint64) | (words[:, 1].astype(np.uint64) << np.uint64(32))
+
+    def _present_in(self, present):
+        p = np.asarray(present).reshape(self.num_chains).astype(np.uint64)
+        w = np.empty((self.num_chains, self._words()), dtype=np.uint32)
+        w[:, 0] = (p & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        if w.shape[1] > 1:
+            w[:, 1] = (p >> np.uint64(32)).astype(np.uint32)
+        elif np.any(p >> np.uint64(32)):
+            raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "present names a site the model does not have")
+        return np.ascontiguousarray(w)
+
     def trace(self):
-        """(values [num_chains, num_sites], present [num_chains] uint32: bit k = site k is in the chain's trace)"""
+        """(values [num_chains, num_sites], present [num_chains]: bit k = site k is in the chain's trace)"""
         vals = np.empty((self.num_chains, self.num_sites))
-        present = np.empty(self.num_chains, dtype=np.uint32)
+        present = self._present_buf()
         capi.check(self._L.mp_mh_read_trace(self._h, _dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint32))))
-        return vals, present
+        return vals, self._present_out(present)
 
     # ---- the GFI operations one at a time (modppl/src/gfi.rs:57-90), every chain per call ------------------------------------
     # constraints: {site: value} shared by all chains, or a (values [num_chains, num_sites], present [num_chains]) pair per chain
@@ -400,7 +423,7 @@ class FunctionChains:
             return keep, (sites.ctypes.data_as(C.POINTER(C.c_int32)) if sites.size else none_i, _dptr(vals) if sites.size else none_d, int(sites.size), none_d, none_u)
         cv, cp = constraints
         cv = np.ascontiguousarray(cv, dtype=np.float64).reshape(self.num_chains, self.num_sites)
-        cp = np.ascontiguousarray(cp, dtype=np.uint32).reshape(self.num_chains)
+        cp = self._present_in(cp)
         return (cv, cp), (none_i, none_d, 0, _dptr(cv), cp.ctypes.data_as(C.POINTER(C.c_uint32)))
 
     def update(self, constraints, argdiff=capi.MP_ARGDIFF_NOCHANGE, rng_step=0, want_discard=True):
@@ -409,10 +432,10 @@ class FunctionChains:
         keep, c = self._constraints(constraints)
         w = np.empty(self.num_chains)
         dv = np.empty((self.num_chains, self.num_sites)) if want_discard else None
-        dp_ = np.empty(self.num_chains, dtype=np.uint32) if want_discard else None
+        dp_ = self._present_buf() if want_discard else None
         capi.check(self._L.mp_fn_update(self._h, int(argdiff), int(rng_step), c[0], c[1], c[2], c[3], c[4], _dptr(w), _dptr(dv) if want_discard else None,
                                         dp_.ctypes.data_as(C.POINTER(C.c_uint32)) if want_discard else None))
-        return w, ((dv, dp_) if want_discard else None)
+        return w, ((dv, self._present_out(dp_)) if want_discard else None)
 
     def regenerate(self, mask, argdiff=capi.MP_ARGDIFF_NOCHANGE, rng_step=0):
         """(new_trace, weight) = model.regenerate(trace, args, argdiff, mask) on every chain (gfi.rs:66-73); -> weights"""
@@ -436,11 +459,11 @@ class FunctionChains:
         -> ((choice_values, choice_present), weights).  Traces are not modified."""
         a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
         cv = np.empty((self.num_chains, self.num_sites))
-        cp = np.empty(self.num_chains, dtype=np.uint32)
+        cp = self._present_buf()
         w = np.empty(self.num_chains)
         capi.check(self._L.mp_fn_propose(self._h, int(proposal_kind), _dptr(a) if a.size else None, int(a.size), int(rng_step), _dptr(cv),
                                          cp.ctypes.data_as(C.POINTER(C.c_uint32)), _dptr(w)))
-        return (cv, cp), w
+        return (cv, self._present_out(cp)), w
 
     def logjp(self):
         out = np.empty(self.num_chains)

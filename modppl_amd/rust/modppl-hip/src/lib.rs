@@ -214,10 +214,12 @@ impl FunctionChains {
         check(unsafe { sys::mp_regen_mh_step(self.h, mask.as_ptr(), mask.len() as i32, cycle as i32, n_iters, &mut acc) });
         acc
     }
-    /// `(values[chain][site], present[chain])`: bit k of `present` = site k is in the chain's trace
+    /// 32-bit presence words per chain: one up to 32 sites, two beyond (`present[chain * words() + w]`)
+    pub fn words(&self) -> usize { (self.n_sites + 31) / 32 }
+    /// `(values[chain][site], present[chain][words()])`: bit k of a chain's words = site k is in the chain's trace
     pub fn trace(&self) -> (Vec<f64>, Vec<u32>) {
         let mut v = vec![0.0; self.n_chains * self.n_sites];
-        let mut p = vec![0u32; self.n_chains];
+        let mut p = vec![0u32; self.n_chains * self.words()];
         check(unsafe { sys::mp_mh_read_trace(self.h, v.as_mut_ptr(), p.as_mut_ptr()) });
         (v, p)
     }
@@ -227,7 +229,7 @@ impl FunctionChains {
     pub fn update(&mut self, constraints: &(Vec<f64>, Vec<u32>), diff: &ArgDiff, rng_step: u32) -> (Vec<f64>, (Vec<f64>, Vec<u32>)) {
         let mut w = vec![0.0; self.n_chains];
         let mut dv = vec![0.0; self.n_chains * self.n_sites];
-        let mut dp = vec![0u32; self.n_chains];
+        let mut dp = vec![0u32; self.n_chains * self.words()];
         let d = match diff { ArgDiff::NoChange => 0, ArgDiff::Unknown => 1, ArgDiff::Extend => panic!("a DynGenFn's update takes NoChange or Unknown") };
         check(unsafe { sys::mp_fn_update(self.h, d, rng_step, ptr::null(), ptr::null(), 0, constraints.0.as_ptr(), constraints.1.as_ptr(), w.as_mut_ptr(),
                                          dv.as_mut_ptr(), dp.as_mut_ptr()) });
@@ -252,7 +254,7 @@ impl FunctionChains {
     pub fn propose(&mut self, proposal_kind: i32, args: &[f64], rng_step: u32) -> ((Vec<f64>, Vec<u32>), Vec<f64>) {
         let mut w = vec![0.0; self.n_chains];
         let mut cv = vec![0.0; self.n_chains * self.n_sites];
-        let mut cp = vec![0u32; self.n_chains];
+        let mut cp = vec![0u32; self.n_chains * self.words()];
         check(unsafe { sys::mp_fn_propose(self.h, proposal_kind, args.as_ptr(), args.len() as i32, rng_step, cv.as_mut_ptr(), cp.as_mut_ptr(), w.as_mut_ptr()) });
         ((cv, cp), w)
     }

@@ -565,7 +565,7 @@ int32_t oracle_mhfn_regen(oracle_mhfn* h, const int32_t* mask_sites, int32_t n_m
 }
 // ---- the GFI operations one at a time (gfi.rs:57-90), chain by chain through the dynamic machinery: the checker of mp_fn_* ----
 static DynTrie mhfn_chain_constraints(oracle_mhfn* h, const int32_t* sites, const double* vals, int32_t n_cons, const double* chain_values,
-                                      const uint32_t* chain_present, size_t i) {
+                                      const uint64_t* chain_present, size_t i) {
     if (!chain_values) return h->m->constraints(sites, vals, n_cons);
     const int ns = h->m->ns();
     std::vector<int32_t> s2;
@@ -576,7 +576,7 @@ static DynTrie mhfn_chain_constraints(oracle_mhfn* h, const int32_t* sites, cons
 }
 static uint32_t mhfn_step(oracle_mhfn* h, uint32_t rng_step) { return rng_step ? rng_step : (uint32_t)(++h->iters); }
 int32_t oracle_mhfn_update(oracle_mhfn* h, int32_t argdiff, uint32_t rng_step, const int32_t* sites, const double* vals, int32_t n_cons,
-                           const double* chain_values, const uint32_t* chain_present, double* weights, double* discard_values, uint32_t* discard_present) {
+                           const double* chain_values, const uint64_t* chain_present, double* weights, double* discard_values, uint64_t* discard_present) {
     GUARD({
         oracle_pf::Scope scope(h->canonical);
         const uint32_t step = mhfn_step(h, rng_step);
@@ -606,7 +606,7 @@ int32_t oracle_mhfn_regenerate(oracle_mhfn* h, int32_t argdiff, uint32_t rng_ste
     })
 }
 int32_t oracle_mhfn_assess(oracle_mhfn* h, int32_t proposal_kind, const double* args, int32_t n_args, uint32_t rng_step, const int32_t* sites,
-                           const double* vals, int32_t n_cons, const double* chain_values, const uint32_t* chain_present, double* weights) {
+                           const double* vals, int32_t n_cons, const double* chain_values, const uint64_t* chain_present, double* weights) {
     GUARD({
         oracle_pf::Scope scope(h->canonical);
         const uint32_t step = mhfn_step(h, rng_step);
@@ -622,7 +622,7 @@ int32_t oracle_mhfn_assess(oracle_mhfn* h, int32_t proposal_kind, const double* 
     })
 }
 int32_t oracle_mhfn_propose(oracle_mhfn* h, int32_t proposal_kind, const double* args, int32_t n_args, uint32_t rng_step, double* choice_values,
-                            uint32_t* choice_present, double* weights) {
+                            uint64_t* choice_present, double* weights) {
     GUARD({
         oracle_pf::Scope scope(h->canonical);
         const uint32_t step = mhfn_step(h, rng_step);
@@ -636,7 +636,7 @@ int32_t oracle_mhfn_propose(oracle_mhfn* h, int32_t proposal_kind, const double*
         }
     })
 }
-int32_t oracle_mhfn_read_trace(oracle_mhfn* h, double* values, uint32_t* present) {
+int32_t oracle_mhfn_read_trace(oracle_mhfn* h, double* values, uint64_t* present) {
     GUARD({
         const int ns = h->m->ns();
         for (size_t i = 0; i < h->traces.size(); ++i) h->m->view(h->traces[i].data, values + i * (size_t)ns, present + i);
@@ -666,10 +666,10 @@ int32_t oracle_mhfn_static_regen(oracle_mhfn_static* h, const int32_t* mask_site
     GUARD({ const uint64_t a = h->r->regen(mask_sites, n_mask, cycle, n_iters); if (accepted) *accepted = a; })
 }
 int32_t oracle_mhfn_static_update(oracle_mhfn_static* h, const int32_t* sites, const double* vals, int32_t n_cons, int32_t unknown, uint32_t step,
-                                  double* weights, uint32_t* disc_present) {
+                                  double* weights, uint64_t* disc_present) {
     GUARD({ h->r->update(sites, vals, n_cons, unknown, step, weights, disc_present); })
 }
-int32_t oracle_mhfn_static_read(oracle_mhfn_static* h, double* values, uint32_t* present, uint64_t* panics) {
+int32_t oracle_mhfn_static_read(oracle_mhfn_static* h, double* values, uint64_t* present, uint64_t* panics) {
     GUARD({ h->r->read(values, present); if (panics) *panics = h->r->panics(); })
 }
 int32_t oracle_mhfn_static_destroy(oracle_mhfn_static* h) { delete h; return MP_OK; }

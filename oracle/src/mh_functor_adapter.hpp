@@ -23,20 +23,20 @@
 namespace oracle {
 
 inline std::string mhfn_local_addr(int site) { return "s" + std::to_string(site); }
-inline std::string mhfn_sub_addr(uint32_t sites) { return "c" + std::to_string(sites); }
+inline std::string mhfn_sub_addr(uint64_t sites) { return "c" + std::to_string(sites); }
 // models with two levels of sub-calls also say which call encloses a site's innermost one (M::outer_of: its SITES, or 0)
 template <class M, class = void>
 struct mhfn_has_outer : std::false_type {};
 template <class M>
 struct mhfn_has_outer<M, std::void_t<decltype(M::outer_of(0))>> : std::true_type {};
 template <class M>
-uint32_t mhfn_outer(int s) {
+uint64_t mhfn_outer(int s) {
     if constexpr (mhfn_has_outer<M>::value) return M::outer_of(s);
     else return 0u;
 }
 template <class M>
 std::string mhfn_flat_addr(int site) {
-    const uint32_t sub = M::sub_of(site), outer = mhfn_outer<M>(site);
+    const uint64_t sub = M::sub_of(site), outer = mhfn_outer<M>(site);
     std::string a = outer ? mhfn_sub_addr(outer) + "/" : std::string();
     if (sub) a += mhfn_sub_addr(sub) + "/";
     return a + mhfn_local_addr(site);
@@ -95,7 +95,7 @@ struct DynMhHandler {
 
     // trace_at: under Update / Regenerate with nothing touched and diff NoChange the body is NOT run and the stored retv comes
     // back (dyngenfn.rs:362-366, 415-419) — which is why a functor may take a sub-call's results from its return value only
-    template <uint32_t SITES, class Body>
+    template <uint64_t SITES, class Body>
     mp_fn_ret call(Body&& body) {
         const uint32_t dom = g.domain;
         MhFnGen sub([&body](MhFnH& g2, int) -> mp_fn_ret {
@@ -110,13 +110,13 @@ struct DynMhHandler {
 template <class M>
 struct MhFnView {
     double val[M::NS];
-    uint32_t present = 0;
+    uint64_t present = 0;   // one bit per site (up to 64 sites)
     bool has(int site) const { return (present >> site) & 1u; }
     double get(int site, double dflt) const { return has(site) ? val[site] : dflt; }
     explicit MhFnView(const DynTrie& data) {
         for (int s = 0; s < M::NS; ++s) val[s] = 0.;
         for (int s = 0; s < M::NS; ++s) {
-            const uint32_t sub = M::sub_of(s), outer = mhfn_outer<M>(s);
+            const uint64_t sub = M::sub_of(s), outer = mhfn_outer<M>(s);
             const Trie* node = nullptr;
             const Trie* at = &data;
             if (outer) at = at->search(mhfn_sub_addr(outer));   // (term searches: a missing sub-trie is "absent", not a panic)
@@ -124,12 +124,12 @@ struct MhFnView {
             node = at ? at->search(mhfn_local_addr(s)) : nullptr;
             if (!node || !node->value) continue;
             if (mhfn_dim<M>(s) == 0) continue;   // (a vector's further slot: filled with its head)
-            present |= 1u << s;
+            present |= 1ull << s;
             if (const double* d = std::any_cast<double>(node->value->get())) val[s] = *d;
             else if (const bool* b = std::any_cast<bool>(node->value->get())) val[s] = *b ? 1. : 0.;
             else if (const Vec* v = std::any_cast<Vec>(node->value->get())) {
                 if ((int)v->size() != mhfn_dim<M>(s)) throw Panic("mh functor adapter: a vector choice of the wrong length at site " + std::to_string(s));
-                for (size_t j = 0; j < v->size(); ++j) { val[s + (int)j] = (*v)[j]; present |= 1u << (s + (int)j); }
+                for (size_t j = 0; j < v->size(); ++j) { val[s + (int)j] = (*v)[j]; present |= 1ull << (s + (int)j); }
             } else throw Panic("mh functor adapter: a choice that is neither f64, bool nor Vec at site " + std::to_string(s));
         }
     }
@@ -172,7 +172,7 @@ struct MhFnModel {
     virtual DynTrie constraints(const int32_t* sites, const double* vals, int n) const = 0;
     virtual std::string flat_addr(int site) const = 0;
     virtual MhFnProposal proposal(int kind, const double* args, int n_args) const = 0;
-    virtual void view(const DynTrie& data, double* vals, uint32_t* present) const = 0;
+    virtual void view(const DynTrie& data, double* vals, uint64_t* present) const = 0;
 };
 template <class M>
 using MhFnProposalFactory = std::function<MhFnProposal(const double*, int)>;
@@ -222,7 +222,7 @@ struct MhFnModelT : MhFnModel {
         if (it == mhfn_proposals<M>().end()) throw Panic("no proposal of this kind is registered for the model");
         return it->second(args, n_args);
     }
-    void view(const DynTrie& data, double* vals, uint32_t* present) const override {
+    void view(const DynTrie& data, double* vals, uint64_t* present) const override {
         const MhFnView<M> v(data);
         for (int s = 0; s < M::NS; ++s) vals[s] = v.val[s];
         *present = v.present;
@@ -238,10 +238,10 @@ struct MhFnStatic {
     virtual void create(uint64_t n_chains, uint64_t seed, const int32_t* sites, const double* vals, int n_cons) = 0;
     virtual uint64_t mh(int kind, const double* args, int n_args, int n_iters) = 0;
     virtual uint64_t regen(const int32_t* mask_sites, int n_mask, int cycle, int n_iters) = 0;
-    virtual void read(double* vals, uint32_t* present) const = 0;
+    virtual void read(double* vals, uint64_t* present) const = 0;
     virtual uint64_t panics() const = 0;
     // mp_fn_update's per-lane work (k_fn_update) with constraints shared by all chains: weights and discard presence out
-    virtual void update(const int32_t* sites, const double* vals, int n_cons, int unknown, uint32_t step, double* weights, uint32_t* disc_present) = 0;
+    virtual void update(const int32_t* sites, const double* vals, int n_cons, int unknown, uint32_t step, double* weights, uint64_t* disc_present) = 0;
 };
 template <class M>
 struct MhFnStaticT;
@@ -269,7 +269,7 @@ struct MhFnStaticT : MhFnStatic {
         seed = seed_; iters = 0;
         mp_fn_trace<M::NS> c;
         mp_fn_clear(c);
-        for (int q = 0; q < n_cons; ++q) { c.present |= 1u << sites[q]; c.val[sites[q]] = vals[q]; }
+        for (int q = 0; q < n_cons; ++q) { c.present |= mp_fn_bits_t<M::NS>(1) << sites[q]; c.val[sites[q]] = vals[q]; }
         tr.resize(n_chains);
         for (size_t i = 0; i < tr.size(); ++i) {   // k_fn_init
             const mp_stream s = stream(i, 0);
@@ -282,13 +282,14 @@ struct MhFnStaticT : MhFnStatic {
     }
     uint64_t regen(const int32_t* mask_sites, int n_mask, int cycle, int n_iters) override {   // k_fn_regen
         uint64_t acc = 0;
-        uint32_t bits = 0;
-        for (int q = 0; q < n_mask; ++q) bits |= 1u << mask_sites[q];
+        using bits_t = mp_fn_bits_t<M::NS>;
+        bits_t bits = 0;
+        for (int q = 0; q < n_mask; ++q) bits |= bits_t(1) << mask_sites[q];
         for (size_t i = 0; i < tr.size(); ++i) {
             mp_fn_trace<M::NS> cur = tr[i];
             for (int it = 0; it < n_iters; ++it) {
                 const mp_stream s = stream(i, (uint32_t)(iters + 1 + (uint64_t)it));
-                uint32_t m = (cycle && n_mask > 0) ? 1u << mask_sites[(iters + (uint64_t)it) % (uint64_t)n_mask] : bits;
+                bits_t m = (cycle && n_mask > 0) ? bits_t(1) << mask_sites[(iters + (uint64_t)it) % (uint64_t)n_mask] : bits;
                 if (m == 0u) m = cur.present;
                 mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
                 model(g);
@@ -335,10 +336,10 @@ struct MhFnStaticT : MhFnStatic {
         if (it == mhfn_static_proposals<M>().end()) throw Panic("no proposal of this kind is registered for the model");
         return it->second(*this, args, n_args, n_iters);
     }
-    void update(const int32_t* sites, const double* vals, int n_cons, int unknown, uint32_t step, double* weights, uint32_t* disc_present) override {
+    void update(const int32_t* sites, const double* vals, int n_cons, int unknown, uint32_t step, double* weights, uint64_t* disc_present) override {
         mp_fn_trace<M::NS> c;
         mp_fn_clear(c);
-        for (int q = 0; q < n_cons; ++q) { c.present |= 1u << sites[q]; c.val[sites[q]] = vals[q]; }
+        for (int q = 0; q < n_cons; ++q) { c.present |= mp_fn_bits_t<M::NS>(1) << sites[q]; c.val[sites[q]] = vals[q]; }
         for (size_t i = 0; i < tr.size(); ++i) {
             const mp_stream s = stream(i, step);
             mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &tr[i], &c);
@@ -351,7 +352,7 @@ struct MhFnStaticT : MhFnStatic {
             tr[i] = g.tr;
         }
     }
-    void read(double* vals, uint32_t* present) const override {
+    void read(double* vals, uint64_t* present) const override {
         for (size_t i = 0; i < tr.size(); ++i) {
             present[i] = tr[i].present;
             for (int k = 0; k < M::NS; ++k) vals[i * (size_t)M::NS + k] = tr[i].has(k) ? tr[i].val[k] : 0.;

@@ -530,26 +530,26 @@ class OracleFunctionChains:
 
     def trace(self):
         vals = np.empty((self.n, self.num_sites))
-        present = np.empty(self.n, dtype=np.uint32)
-        self._ck(self.L.oracle_mhfn_read_trace(self.h, dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint32))))
+        present = np.empty(self.n, dtype=np.uint64)
+        self._ck(self.L.oracle_mhfn_read_trace(self.h, dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint64))))
         return vals, present
 
     # ---- GenFn::update / regenerate / assess / propose one at a time (gfi.rs:57-90): the checker of mp_fn_* ----
     def _cons(self, constraints):
-        ip, up = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+        ip, up = C.POINTER(C.c_int32), C.POINTER(C.c_uint64)
         if isinstance(constraints, dict):
             sites = np.array(sorted(constraints), dtype=np.int32)
             vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
             return (sites, vals), (sites.ctypes.data_as(ip), dptr(vals), int(sites.size), None, None)
         cv = np.ascontiguousarray(constraints[0], dtype=np.float64).reshape(self.n, self.num_sites)
-        cp = np.ascontiguousarray(constraints[1], dtype=np.uint32).reshape(self.n)
+        cp = np.ascontiguousarray(constraints[1], dtype=np.uint64).reshape(self.n)   # (one 64-bit presence word per chain, whatever the product's table uses)
         return (cv, cp), (None, None, 0, dptr(cv), cp.ctypes.data_as(up))
 
     def update(self, constraints, argdiff=0, rng_step=0):
         keep, c = self._cons(constraints)
-        w, dv, dp_ = np.empty(self.n), np.zeros((self.n, self.num_sites)), np.zeros(self.n, dtype=np.uint32)
+        w, dv, dp_ = np.empty(self.n), np.zeros((self.n, self.num_sites)), np.zeros(self.n, dtype=np.uint64)
         self._ck(self.L.oracle_mhfn_update(self.h, int(argdiff), C.c_uint32(rng_step), c[0], c[1], c[2], c[3], c[4], dptr(w), dptr(dv),
-                                           dp_.ctypes.data_as(C.POINTER(C.c_uint32))))
+                                           dp_.ctypes.data_as(C.POINTER(C.c_uint64))))
         return w, (dv, dp_)
 
     def regenerate(self, mask_sites, argdiff=0, rng_step=0):
@@ -567,9 +567,9 @@ class OracleFunctionChains:
 
     def propose(self, proposal_kind, proposal_args=(), rng_step=0):
         a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()
-        cv, cp, w = np.zeros((self.n, self.num_sites)), np.zeros(self.n, dtype=np.uint32), np.empty(self.n)
+        cv, cp, w = np.zeros((self.n, self.num_sites)), np.zeros(self.n, dtype=np.uint64), np.empty(self.n)
         self._ck(self.L.oracle_mhfn_propose(self.h, int(proposal_kind), dptr(a), int(a.size), C.c_uint32(rng_step), dptr(cv),
-                                            cp.ctypes.data_as(C.POINTER(C.c_uint32)), dptr(w)))
+                                            cp.ctypes.data_as(C.POINTER(C.c_uint64)), dptr(w)))
         return (cv, cp), w
 
     def logjp(self):
@@ -623,16 +623,16 @@ class HostStaticFunctionChains:
         """k_fn_update's per-lane work with constraints shared by all chains -> (weights, discard presence)"""
         sites = np.array(sorted(constraints), dtype=np.int32)
         vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
-        w, dp_ = np.empty(self.n), np.zeros(self.n, dtype=np.uint32)
+        w, dp_ = np.empty(self.n), np.zeros(self.n, dtype=np.uint64)
         self._ck(self.L.oracle_mhfn_static_update(self.h, sites.ctypes.data_as(C.POINTER(C.c_int32)), dptr(vals), int(sites.size), int(argdiff),
-                                                  C.c_uint32(rng_step), dptr(w), dp_.ctypes.data_as(C.POINTER(C.c_uint32))))
+                                                  C.c_uint32(rng_step), dptr(w), dp_.ctypes.data_as(C.POINTER(C.c_uint64))))
         return w, dp_
 
     def trace(self, num_sites):
         vals = np.empty((self.n, num_sites))
-        present = np.empty(self.n, dtype=np.uint32)
+        present = np.empty(self.n, dtype=np.uint64)
         pan = C.c_uint64()
-        self._ck(self.L.oracle_mhfn_static_read(self.h, dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pan)))
+        self._ck(self.L.oracle_mhfn_static_read(self.h, dptr(vals), present.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(pan)))
         self.panics = pan.value
         return vals, present
 

@@ -358,6 +358,33 @@ def test_two_levels_of_sub_calls():
     assert 0 < ((present >> 4) & 1).sum() < n
 
 
+def test_more_than_32_sites():
+    """kind 114: 41 sites — presence, masks, constraints and the discard are 64-bit words inside the kernels and two 32-bit words per
+    chain through the C ABI; the sub-call, its optional choice and six observations live above bit 32"""
+    if FUNCTOR:
+        pytest.skip("one engine: the model has no hand-written kernel")
+    import modppl_amd
+    from tests.test_oracle_mh_functor import WF_NS, WF_O1, WF_O2, wide_moves, wide_problem
+
+    xs, cons = wide_problem()
+    n = 1500
+    g = modppl_amd.FunctionChains(114, xs, cons, n, 5)
+    o = O.OracleFunctionChains(114, xs, cons, n, 5)
+    assert g.num_sites == WF_NS
+    wide_moves(g, o, check_fn)
+    # the GFI calls one at a time with per-chain tables: choices, discard and constraints above bit 32 through the two-word layout
+    (gcv, gcp), gf = g.propose(2, [], rng_step=77)
+    (ocv, ocp), of = o.propose(2, [], rng_step=77)
+    assert gcp.dtype == np.uint64 and np.array_equal(gcp, ocp) and np.array_equal(gcv, ocv) and np.array_equal(gf, of)
+    gw, gd = g.update((gcv, gcp), rng_step=77)
+    ow, od = o.update((ocv, ocp), rng_step=77)
+    assert np.array_equal(gw, ow) and np.array_equal(gd[1], od[1]) and np.array_equal(gd[0], od[0])
+    assert ((gd[1] >> np.uint64(WF_O2)) & np.uint64(1)).any()              # some chains dropped o2: a discard bit in the high word
+    assert np.array_equal(g.assess(gd, proposal_kind=2, rng_step=77), o.assess(od, proposal_kind=2, rng_step=77))
+    assert np.array_equal(g.regenerate([WF_O1, 0], rng_step=78), o.regenerate([WF_O1, 0], rng_step=78))
+    check_fn(g, o)
+
+
 def test_masking_is_linear_where_the_reference_does_not_panic():
     """hierarchical model as a functor, all chains linear, ONE regen move with mask {is_linear}: linear -> linear and linear ->
     quadratic go through generate(args, sub) on the old `coeffs` sub-trace (c is drawn when the new branch wants it); only

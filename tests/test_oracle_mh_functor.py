@@ -226,6 +226,51 @@ def test_two_levels_of_sub_calls_static_handlers_against_the_trie_engine():
     assert np.isfinite(d.logjp()).all()
 
 
+WF_SLOPE, WF_ICPT, WF_BIG, WF_Y0, WF_O1, WF_O2, WF_Z0, WF_NS = 0, 1, 2, 3, 33, 34, 35, 41
+
+
+def wide_problem():
+    xs = np.linspace(-2, 2, 30)
+    rng = np.random.default_rng(12)
+    ys = 0.8 * xs - 0.3 + 0.5 * rng.normal(size=30)
+    zs = 0.7 + 0.1 * np.arange(6) + 0.5 * rng.normal(size=6)
+    cons = {WF_Y0 + k: y for k, y in enumerate(ys)}
+    cons.update({WF_Z0 + k: z for k, z in enumerate(zs)})
+    return xs, cons
+
+
+def wide_moves(s, d, same, sweeps=2):
+    """kind 114 (41 sites: a 64-bit presence word; the sub-call, its optional choice and six observations sit ABOVE bit 32)"""
+    same(s, d)
+    for sweep in range(sweeps):
+        assert s.mh(1, [0.15], 2) == d.mh(1, [0.15], 2)                         # constraints below and above bit 32 in one move
+        same(s, d)
+        assert s.mh(2, [], 2) == d.mh(2, [], 2)                                 # o2 (site 34) comes or goes: discard and gc in the high word
+        same(s, d)
+        assert s.regen_mh([WF_O1], 2) == d.regen_mh([WF_O1], 2)                 # a mask bit above 32, inside the sub-call
+        same(s, d)
+        # (a mask of `big` alone is the reference's panic when big turns false: generate(args, sub) finds the old o2 unconsumed)
+        assert s.regen_mh([WF_BIG, WF_O2], 2) == d.regen_mh([WF_BIG, WF_O2], 2) # upstream and inside: o2 redrawn, created or collected; the
+        same(s, d)                                                              # sub-trie's running weight is kept at index 33
+        assert s.regen_mh([WF_SLOPE], 2) == d.regen_mh([WF_SLOPE], 2)           # upstream of the UNTOUCHED sub-call: replayed, weight kept
+        same(s, d)
+        assert s.regen_mh([WF_SLOPE, WF_O2, WF_ICPT, WF_O1], 4, cycle=True) == d.regen_mh([WF_SLOPE, WF_O2, WF_ICPT, WF_O1], 4, cycle=True)
+        same(s, d)
+    assert s.regen_mh([], 1) == d.regen_mh([], 1)                               # the whole schema: every one of the 40 / 41 bits
+    same(s, d)
+
+
+def test_more_than_32_sites_static_handlers_against_the_trie_engine():
+    xs, cons = wide_problem()
+    s, d = _both(114, xs, cons, 200, 5)
+    assert d.num_sites == WF_NS
+    wide_moves(s, d, _same)
+    vals, present = d.trace()
+    assert present.dtype == np.uint64 and (present >> np.uint64(WF_Z0 + 5)).all()          # the last site is bit 40
+    has_o2 = (present >> np.uint64(WF_O2)) & np.uint64(1)
+    assert 0 < has_o2.sum() < len(has_o2)
+
+
 BOUNDS = [-5.0, 5.0, -5.0, 5.0]            # tests/mh.rs:55
 OBS_COV = [1.0, -0.6, -0.6, 2.0]           # :61
 
