@@ -15,6 +15,6 @@ cp $SRC/trace/bench_kernel_stats.csv $DST/kernel_stats.csv
 cp $SRC/trace_sharded/bench_kernel_stats.csv $DST/kernel_stats_forced_sharded.csv
 [ -f $SRC/trace_sharded_split/bench_kernel_stats.csv ] && cp $SRC/trace_sharded_split/bench_kernel_stats.csv $DST/kernel_stats_forced_sharded_split.csv
 for i in 1 2 3 4 5 6 7; do cp $SRC/pmc$i/p_counter_collection.csv $DST/pmc${i}_counter_collection.csv; done
-for d in pmc_models pmc_mh pmc_dense; do [ -f $SRC/$d/summary.txt ] && cp $SRC/$d/summary.txt $DST/${d}_summary.txt; done
+for d in pmc_models pmc_mh pmc_dense pmc_sharded; do [ -f $SRC/$d/summary.txt ] && cp $SRC/$d/summary.txt $DST/${d}_summary.txt; done
 python3 tools/collect_c4_flops.py $SRC/pmc_mh 30 > $DST/c4_flops.json || echo "no C4 flop summary"
 echo "collected into $DST"

@@ -47,6 +47,8 @@ cd $R && timeout -k 10 300 python3 tools/model_bench.py --which c3,mid,c5,c4 > $
 # counters, fp64 operation counts and durations of the other configurations' kernels (C3 / C5 propagate kernels, the MH kernels)
 cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_models "inst busy f64 tcc fetch write tcp" "k_propagate|k_draw_slots" tools/model_bench.py --steps 8 --which c3,mid,c5 > $OUT/pmc_models.log 2>&1 || echo "pmc_models failed"
 cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_mh "inst busy f64" "k_mh|k_fn" tools/mh_bench.py 1048576 30 > $OUT/pmc_mh.log 2>&1 || echo "pmc_mh failed"
+# the sharded resample's kernels (one rank of emulated worlds of 1 .. 8): table + counts + plan, placement, the propagate kernel's SHD form
+cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_sharded "inst busy tcc" "k_shard_table|k_shard_self|k_shard_own|k_propagate" tools/route_scale.py > $OUT/pmc_sharded.log 2>&1 || echo "pmc_sharded failed"
 cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_dense "inst busy f64 tcc" "k_propagate|k_draw" tools/dense_bench.py > $OUT/pmc_dense.log 2>&1 || echo "pmc_dense failed"
 cd $R && timeout -k 10 600 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { echo "bench failed"; tail -n 5 $OUT/bench_n1.err; exit 1; }
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1_k20.json 2>> $OUT/bench_n1.err || { echo "bench k20 failed"; exit 1; }
