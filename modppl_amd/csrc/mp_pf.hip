@@ -123,6 +123,8 @@ struct PropagateArgs {
     size_t dyn_lds;           // LDS for that phase's copy of the tile table
     const mp_k1_tail* tail;   // device copy of {cx, guide, tile_*, tab} (k_propagate reads them there)
     mp_k1_aux aux;
+    bool walk_bisect;         // the draws this launch looks up are a lattice's (consecutive slots, consecutive targets): wide-state kernels then
+                              // finish long walks by bisection (the WALKB instantiation)
     int mt_grid;              // > 0: a drawing launch may run as k_propagate_mt with this many workgroups (one per CU, several tiles each)
     int mt_flags;             // MP_MT_SKIP_* (mp_pf_k1mt.h)
 };
@@ -177,7 +179,7 @@ struct ModelOpsT : ModelOps {
             // interpretation of the same functor (same bits)
             static const bool mfma = [] { const char* e = getenv("MP_DENSE_MFMA"); return !(e && e[0] == '0'); }();
             if (mfma) {
-                hipLaunchKernelGGL(k_propagate_dense16, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
+                hipLaunchKernelGGL(a.walk_bisect ? k_propagate_dense16<true> : k_propagate_dense16<false>, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
                                    a.x_out, a.logw, a.obs, a.overwrite, a.dfr_row, a.dfr_lt, a.cx_old, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux,
                                    a.inv, a.inv_rows);
                 return MP_K1_FORM_DENSE16;
@@ -234,6 +236,15 @@ struct ModelOpsT : ModelOps {
             if (a.drw && a.drw_v.nt > THREADS) {   // a drawing launch of a job with more tiles than threads: two table entries per thread
                 hipLaunchKernelGGL((k_propagate<Model, THREADS, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
                                    a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
+                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
+                return MP_K1_FORM_TILE;
+            }
+        }
+        if constexpr (THREADS != 1024) {   // the wide models: a lattice's draws are looked up by the instantiation whose long walks bisect
+            if (a.walk_bisect) {
+                hipLaunchKernelGGL((k_propagate<Model, THREADS, false, false, false, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
+                                   a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                                    a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
                                    a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
                 return MP_K1_FORM_TILE;
@@ -535,6 +546,7 @@ struct mp_pf {
     bool ow_solo_folded = false;          // (world of one) its scalars have been folded already (a synchronous commit): the next k_propagate must not
     int ow_rank = 0;
     mp_own_range* ow_range_solo = nullptr;   // {0, n}: a world of one owns every draw
+    bool draws_lattice = false;           // the draws of the last resample are a lattice's (systematic / stratified)
     bool pending_shard = false;           // with draw_pending: the pending draws are a sharded filter's self-drawn ones (world ps_world, rank ps_rank)
     int ps_world = 1, ps_rank = 0;
     bool sharded = false;
@@ -772,6 +784,7 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     if (h->deferred && h->local_table && h->tiles_alt) {   // (what k1_tail_alt says: update_k1_tail)
         a.tile_m_new = reinterpret_cast<double*>(h->tiles_alt); a.tile_W_new = h->tiles_alt + h->nt; a.tile_W2_new = h->tiles_alt + 2 * (size_t)h->nt;
     }
+    a.walk_bisect = h->deferred && h->draws_lattice;
     a.mt_grid = (h->use_k1_mt && !h->sharded) ? h->cus : 0;
     a.mt_flags = h->mt_flags;
     // ... and made by it too, when the resample left them pending (kernels of two-slot lanes)
@@ -1173,6 +1186,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     }
     rc = check_launch("resample kernels");
     if (rc != MP_OK) return rc;
+    h->draws_lattice = scheme != MP_RESAMPLE_MULTINOMIAL;
     if (drawn_only) h->deferred = true;   // x[cur] is the (stale) pre-resample state until the draws are looked up
     else {
         h->cur ^= 1;
@@ -1910,6 +1924,7 @@ int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_tot
     h->sh_lazy = false;
     h->sh_parents_lazy = false;
     h->deferred = true;
+    h->draws_lattice = h->ow_scheme == MP_RESAMPLE_SYSTEMATIC || h->ow_scheme == MP_RESAMPLE_STRATIFIED;
     h->draw_pending = false;
     h->pending_shard = false;
     if (h->ow_self && self_k1_draws(h)) {   // the kept draws are left to the next k_propagate (flush_draws() when something else needs them first)

@@ -661,7 +661,21 @@ constexpr uint32_t MP_DRAW_RECV = 0x80000000u;
 #define MP_PAIR_SAME_LINE 1
 #endif
 // N draws at a time: every load goes out before the first is used.
-template <int N>
+// BISECT: a walk that is still going after MP_WALK_LINEAR rows finishes by bisection over the rest of the tile (the rows' cumulative
+// weights ascend: "first row at or after the start row whose cumulative weight reaches the target" is a lower bound, the same row
+// either way).  Walks are 0 - 2 rows long when a tile's weights are of one order of magnitude; when a few particles carry a tile
+// (d = 16: an ESS of a few hundred out of 2^21) the guide cell that holds the light rows in front of a heavy one holds hundreds of
+// them, 1 / 1024 of the tile's draws start there, and under a lattice scheme those draws are CONSECUTIVE slots — the four slots of
+// one lane walk a thousand dependent loads each, one after the other, and their workgroup ends 100 - 180 us after everybody else
+// (C5 under systematic resampling: 565 us per step against 410 with flat weights -> 435 with the bisection).
+// The bisection is not free where walks are short (same box: C3 + 5 %, C5 under multinomial draws + 1 %: registers), so the
+// propagate kernels carry it in an instantiation of their own (WALKB) that the host launches when the draws being looked up are a
+// lattice's and the model is a wide one; the one-double headline kernels keep the plain walk.
+#ifndef MP_WALK_LINEAR
+#define MP_WALK_LINEAR 3
+#endif
+
+template <int N, bool BISECT = false>
 __device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u64 n, const u64* lt, const uint32_t* row, uint32_t* parent, double* x0,
                                                  const double* __restrict__ rows = nullptr, int rw = 0) {
     mp_u64v2 a[N], b2[N];
@@ -691,17 +705,37 @@ __device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u
         const bool step1 = a[k].x < lt[k] && hb[k];
         u64 p = (u64)r0[k] + (step1 ? 1 : 0);
         mp_u64v2 cur = step1 ? b2[k] : a[k];
-        while (cur.x < lt[k] && p < last[k]) {   // rare: more than one row past the guide's start
-            ++p;
-            cur = mp_ld_row(cx + p);
+        if constexpr (BISECT) {
+            int steps = 0;
+            while (cur.x < lt[k] && p < last[k]) {   // rare: more than one row past the guide's start
+                if (++steps > MP_WALK_LINEAR) {      // very rare: the first row of (p, last] whose cumulative weight reaches the target, or `last`
+                    u64 lo = p + 1, hi = last[k];
+                    while (lo < hi) {
+                        const u64 mid = lo + ((hi - lo) >> 1);
+                        if (mp_ld_row(cx + mid).x >= lt[k]) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    p = lo;
+                    cur = mp_ld_row(cx + p);
+                    break;
+                }
+                ++p;
+                cur = mp_ld_row(cx + p);
+            }
+        } else {
+            while (cur.x < lt[k] && p < last[k]) {   // rare: more than one row past the guide's start
+                ++p;
+                cur = mp_ld_row(cx + p);
+            }
         }
         parent[k] = (uint32_t)p;   // (may alias row[])
         x0[k] = __builtin_bit_cast(double, (u64)cur.y);
     }
 }
+template <bool BISECT = false>
 __device__ __forceinline__ void mp_resolve_draw(const mp_cx* __restrict__ cx, u64 n, u64 lt, uint32_t row, uint32_t* parent, double* x0,
                                                 const double* __restrict__ rows = nullptr, int rw = 0) {
-    mp_resolve_draws<1>(cx, n, &lt, &row, parent, x0, rows, rw);
+    mp_resolve_draws<1, BISECT>(cx, n, &lt, &row, parent, x0, rows, rw);
 }
 // What k_propagate needs only in its LAST phase (level 0 / level 1 of the normalisation), constant per handle: kept in
 // device memory and read there — as kernel arguments these 11 pointers sat in SGPRs through the whole VALU-bound part of the
@@ -817,7 +851,8 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
 // SHD: the pending draws are a SHARDED filter's self-drawn ones (lattice range or split multinomial, mp_pf_shard_kernels.h): the table
 // is this rank's slice of the job's, own offspring p < c_me have their target in closed form, the slots beyond read the row that
 // arrived for them (dfr_row: MP_DRAW_RECV | index)
-template <class Model, int THREADS, bool TAB2 = false, bool LAT = false, bool SHD = false>
+// WALKB: long walks finish by bisection (mp_resolve_draws' BISECT): wide-state kernels looking up a lattice's draws
+template <class Model, int THREADS, bool TAB2 = false, bool LAT = false, bool SHD = false, bool WALKB = false>
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(const double* __restrict__ pre_tm, const u64* __restrict__ pre_tW, const u64* __restrict__ pre_tW2, int pre_nt, int drw,
                                                             Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
@@ -1178,7 +1213,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 u64 ltr[ITEMS];
 #pragma unroll
                 for (int pp = 0; pp < ITEMS; ++pp) ltr[pp] = (LT_LATE && !drew) ? (i0 + pp < n ? dfr_lt[i0 + pp] : 0ull) : plt[rd * ITEMS + pp];
-                mp_resolve_draws<ITEMS>(cx_old, n, ltr, &pm[rd * ITEMS], &pm[rd * ITEMS], &px0[rd * ITEMS], inv ? nullptr : inv_rows, D + 1);
+                mp_resolve_draws<ITEMS, WALKB>(cx_old, n, ltr, &pm[rd * ITEMS], &pm[rd * ITEMS], &px0[rd * ITEMS], inv ? nullptr : inv_rows, D + 1);
             }
 #pragma unroll
             for (int pp = 0; pp < ITEMS; ++pp) MP_RUN_PARTICLE(rd * ITEMS + pp, &zr[pp * NS]);
@@ -1283,7 +1318,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             } else {
 #pragma unroll
                 for (int p = 0; p < LANE_ITEMS; ++p)
-                    mp_resolve_draw(cx_old, n, drew ? plt[p] : (base + p < n ? dfr_lt[base + p] : 0ull), pm[p], &pm[p], &px0[p], inv ? nullptr : inv_rows, D + 1);
+                    mp_resolve_draw<WALKB>(cx_old, n, drew ? plt[p] : (base + p < n ? dfr_lt[base + p] : 0ull), pm[p], &pm[p], &px0[p], inv ? nullptr : inv_rows, D + 1);
                 if constexpr (CAN_DRAW) {
                     if (drew) {
                         uint32_t* pp2 = mp_as_global(drw_v.parent);
@@ -1327,6 +1362,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
 // ---------------------------------------------------------------------------------------------
 typedef double mp_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int DENSE_THREADS = 512;
+template <bool WALKB>
 __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_dense<16> model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1, long long t,
                                                                      const double* __restrict__ x_in, double* __restrict__ x_out, double* logw, mp_obs obs,
                                                                      int overwrite, const uint32_t* __restrict__ dfr_row,
@@ -1389,7 +1425,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
         } else if (dfr_row && live) {   // a draw of the last resample, looked up here (mp_resolve_draw)
             uint32_t par;
             double x0;
-            mp_resolve_draw(cx_old, n, dfr_lt[p], dfr_row[p], &par, &x0, rows, D + 1);
+            mp_resolve_draw<WALKB>(cx_old, n, dfr_lt[p], dfr_row[p], &par, &x0, rows, D + 1);
             myrow = (rows && (par & MP_DRAW_RECV)) ? rows + (u64)(par & ~MP_DRAW_RECV) * (u64)(D + 1) : x_in + (u64)par * D;
         }
         const u64 myaddr = (u64)(uintptr_t)myrow;
@@ -1897,7 +1933,7 @@ __global__ void k_resolve_slots(u64 n, int D, const u64* __restrict__ dfr_lt, co
     if (i >= n) return;
     uint32_t p;
     double x0;
-    mp_resolve_draw(cx, n, dfr_lt[i], dfr_row[i], &p, &x0, rows, D + 1);
+    mp_resolve_draw<true>(cx, n, dfr_lt[i], dfr_row[i], &p, &x0, rows, D + 1);
     const bool recv = rows && (p & MP_DRAW_RECV);
     const double* rrow = recv ? rows + (u64)(p & ~MP_DRAW_RECV) * (u64)(D + 1) : nullptr;
     parent[i] = recv ? (uint32_t)rrow[D] : (uint32_t)(slot_offset + p);

@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_shard_own_place(u64 n, u64 slot_offset,
             }
             uint32_t par;
             double x0;
-            mp_resolve_draw(cx, n, lt, row0, &par, &x0);
+            mp_resolve_draw<true>(cx, n, lt, row0, &par, &x0);
             const u64 u = PS_me + (p - n);
             int s2 = 0;
             while (s2 + 1 < world && !(plan->D[s2] && u < plan->PD[s2] + plan->D[s2])) ++s2;
@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_shard_self_place(u64 n, u64 n_global, u
         const uint32_t row0 = (uint32_t)tbase + (j0 > tlen - 1 ? tlen - 1 : j0);
         uint32_t par;
         double x0;
-        mp_resolve_draw(cx, n, lt, row0, &par, &x0);
+        mp_resolve_draw<true>(cx, n, lt, row0, &par, &x0);
         const u64 u = PS_me + (p - n);
         int s2 = 0;
         while (s2 + 1 < world && !(plan->D[s2] && u < plan->PD[s2] + plan->D[s2])) ++s2;

@@ -102,3 +102,46 @@ def test_lattice_schemes_beyond_48k_lds(scheme):
     p = np.exp(w - np.logaddexp.reduce(w))
     counts = np.bincount(par, minlength=n)
     assert np.all(np.abs(counts - n * p) < (1.0 if scheme == SYS else 2.0) + 1e-6 * n)
+
+
+@pytest.mark.parametrize("scheme", [0, SYS, STRAT])
+@pytest.mark.parametrize("kind", ["band16", "dense16"])
+def test_collapsed_weights_long_walks_wide_states(kind, scheme):
+    """d = 16 with informative observations: a few hundred particles carry the population, so a guide cell in front of a heavy row holds
+    hundreds of light rows and 1 / 1024 of a tile's draws start a walk there.  Under a lattice scheme the wide-state propagate kernels
+    finish such walks by bisection (their WALKB instantiation, chosen by the host); the parents must be the checker's — which finds
+    them by binary search — for every scheme, and the walks must really have been long."""
+    import modppl_amd
+
+    n, T, seed = 3 * 2048 + 77, 7, 6
+    if kind == "band16":
+        model, okind, params = modppl_amd.lgssm_band_model(16), 5, np.array([16, 0.9, 0.05, 1.0, 0.5, 1.0])
+        ref = O.OraclePF(okind, 16, 16, params, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, threads=4)
+    else:
+        from tests.test_gpu_dense import MP_MODEL_LGSSM_DENSE, dense_params, dense_problem
+        A, Q, R = dense_problem(7)
+        model = modppl_amd.lgssm_dense_model(A, Q, R, 1.0)
+        ref = O.OraclePF(MP_MODEL_LGSSM_DENSE, 16, 16, dense_params(A, Q, R, 1.0), n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, threads=4)
+    obs = np.random.default_rng(3).normal(0, 1.2, size=(T, 16))
+    pf = modppl_amd.ParticleSystem(model, n, seed)
+    pf.init_step(None, obs[:1])
+    ref.init_step(obs[:1])
+    longest = 0
+    for t in range(1, T):
+        lw = pf.log_weights
+        assert np.array_equal(lw, ref.log_weights())
+        assert pf.resample(scheme) == ref.resample(scheme)
+        par = pf.parents.astype(np.int64)
+        assert np.array_equal(par, ref.parents())
+        # how far a walk from the start of a guide cell could be: the longest run of rows of one tile whose weights together are
+        # below 1 / 1024 of the tile's (what one cell spans)
+        w = np.exp(lw - lw.max())
+        for b in range(0, n, 2048):
+            wt = w[b:b + 2048]
+            c = np.cumsum(wt) / wt.sum()
+            cell = np.floor(c * 1024).astype(np.int64)
+            longest = max(longest, int(np.bincount(cell).max()))
+        pf.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+    assert np.array_equal(pf.states(), ref.state())
+    assert longest > 100, longest      # some guide cell held a hundred rows and more: the long-walk case was there

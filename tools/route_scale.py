@@ -11,15 +11,28 @@ import torch  # noqa: E402
 
 
 def main():
+    import argparse
+    import numpy as np
     import modppl_amd
     from modppl_amd import capi
     from modppl_amd.distributed import HipShardEngine
     import bench as B   # observations only; nothing under oracle/ is used by the tools
 
-    n = 1 << 20
-    ys = B.lgssm_observations(3).reshape(3, 1)
-    for world in (1, 2, 4, 8):
-        eng = HipShardEngine(modppl_amd.lgssm_model(*B.LGSSM_PARAMS), n, n * world, 0, 7)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="lgssm1", choices=["lgssm1", "band16"], help="band16: the C5 model (its propagate kernel cannot make the draws: k_shard_self_draw does)")
+    ap.add_argument("--particles", type=int, default=1 << 20, help="per rank")
+    ap.add_argument("--worlds", default="1,2,4,8")
+    args = ap.parse_args()
+    n = args.particles
+    if args.model == "band16":
+        model, dim = modppl_amd.lgssm_band_model(16), 16
+        obs_of = lambda T: np.random.default_rng(3).normal(0, 1.2, size=(T, 16))   # noqa: E731
+    else:
+        model, dim = modppl_amd.lgssm_model(*B.LGSSM_PARAMS), 1
+        obs_of = lambda T: B.lgssm_observations(T).reshape(T, 1)   # noqa: E731
+    ys = obs_of(3)
+    for world in [int(w) for w in args.worlds.split(",")]:
+        eng = HipShardEngine(model, n, n * world, 0, 7)
         nt = n // 2048
         dev = eng.device
         tiles = torch.zeros(3 * nt, dtype=torch.int64, device=dev)
@@ -31,7 +44,7 @@ def main():
         torch.cuda.synchronize()   # torch's stream made it; the engine's kernels run on a stream of their own
         cap = int(n // (8 * world) * 1.25) + 512
         req = torch.zeros(world * 8 * (cap + 1) * 2, dtype=torch.int64, device=dev)
-        rows = torch.zeros(world * 8 * cap * 2, dtype=torch.float64, device=dev)
+        rows = torch.zeros(world * 8 * cap * (dim + 1), dtype=torch.float64, device=dev)
         eng.set_timing(True)
         for _ in range(12):
             eng.shard_route_fixed(0, C.c_void_p(tiles_all.data_ptr()), world, 0, cap, C.c_void_p(req.data_ptr()))
@@ -43,8 +56,8 @@ def main():
         # the owner-keeps form: multinomial = every rank enumerates all world * n draws and keeps its own; lattice schemes = a
         # rank's own draws are a range found by two searches
         ocap = max(4096, n // 128)
-        send = torch.zeros(world * ocap * 2, dtype=torch.float64, device=dev)
-        orow = torch.zeros((world * ocap + n) * 2, dtype=torch.float64, device=dev)
+        send = torch.zeros(world * ocap * (dim + 1), dtype=torch.float64, device=dev)
+        orow = torch.zeros((world * ocap + n) * (dim + 1), dtype=torch.float64, device=dev)
         for scheme, name in ((0, "multinomial"), (1, "systematic"), (2, "stratified"), (3, "split multinomial")):
             eng.synchronize()
             eng.set_timing(False)
@@ -62,7 +75,7 @@ def main():
         # a whole step of this rank, kernel by kernel (HIP events around every launch): count + expand + commit (asynchronous) + the
         # next propagate, which makes the kept draws of a self-drawn resample itself (the rows "received" for the deficit slots are
         # whatever the buffer holds: timing only)
-        ys2 = B.lgssm_observations(64).reshape(64, 1)
+        ys2 = obs_of(64)
         for scheme, name in ((0, "multinomial"), (1, "systematic"), (2, "stratified"), (3, "split multinomial")):
             K = 30
             for rep in range(2):
