@@ -6,6 +6,13 @@ R=${1:-r04}
 SRC=gpurun_out/${R}_prof
 DST=profiles/$R
 mkdir -p $DST
+# the run must be of THIS tree (traffic.json / c4_flops.json are stamped with the local content hash)
+if [ -f $SRC/source_hash.txt ]; then
+  HERE=$(python3 -c "from modppl_amd import build as B; print(B.source_hash())")
+  [ "$(cat $SRC/source_hash.txt)" = "$HERE" ] || { echo "profile run is of another build ($(cut -c1-8 $SRC/source_hash.txt) vs $(echo $HERE | cut -c1-8)): not collected"; exit 1; }
+else
+  echo "warning: $SRC/source_hash.txt missing (a run that did not travel back?)"; exit 1
+fi
 python3 tools/collect_traffic.py $SRC > $DST/traffic.json
 python3 tools/pmc_summary.py $SRC > $DST/counters_summary.txt
 for f in stamp_report.txt stamp_report_tile_kernel.txt k1_scaling.txt k1_forms_ab.txt reference_shaped_loop.jsonl stamps.json bench_n1.json bench_n1_k20.json bench_forced_sharded.json bench_forced_sharded_rccl.json bench_forced_sharded_split.json route_scale.txt model_bench.jsonl mh_functor_vs_handwritten.json; do

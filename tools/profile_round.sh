@@ -7,6 +7,8 @@ set -u
 R=$PWD
 OUT=$R/gpurun_out/${1:-r04_prof}
 mkdir -p $OUT
+# the content hash of the sources the library on THIS box was built from: tools/collect_profiles.sh refuses a run of another tree
+(cd $R && python3 -c "from modppl_amd import build as B; print(B.source_hash())") > $OUT/source_hash.txt
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-kernel-timing --no-sub-benches --no-systematic-leg"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $B --steps 50 --warmup 10 > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -n 5 $OUT/trace.log; exit 1; }
@@ -52,4 +54,7 @@ cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_sharded "inst busy tcc" 
 cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_dense "inst busy f64 tcc" "k_propagate|k_draw" tools/dense_bench.py > $OUT/pmc_dense.log 2>&1 || echo "pmc_dense failed"
 cd $R && timeout -k 10 600 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { echo "bench failed"; tail -n 5 $OUT/bench_n1.err; exit 1; }
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1_k20.json 2>> $OUT/bench_n1.err || { echo "bench k20 failed"; exit 1; }
+# what travels back is limited to 64 MiB: the raw per-launch traces and the stamp dumps have been summarised above
+find $OUT -name '*_kernel_trace.csv' -delete; find $OUT -name '*.npy' -delete; find $OUT -name '*_agent_info.csv' -delete
+rm -rf $OUT/pmc_sharded/pmc_* $OUT/pmc_sharded/trace $OUT/pmc_models/pmc_* $OUT/pmc_models/trace $OUT/pmc_dense/pmc_* $OUT/pmc_dense/trace
 echo "bench done"
