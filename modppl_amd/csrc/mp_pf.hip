@@ -200,58 +200,34 @@ struct ModelOpsT : ModelOps {
                 mp_obs_n<Model::DIM_OBS> ob;
                 for (int j = 0; j < Model::DIM_OBS; ++j) ob.v[j] = a.obs.v[j];
                 const int grid = (a.drw_v.nt + 1) / 2;   // two tiles per workgroup: b and b + grid
-                hipLaunchKernelGGL((k_propagate_mt<Model>), dim3(grid), dim3(1024), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
-                                   a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, m, ob);
+                if (a.walk_bisect)
+                    hipLaunchKernelGGL((k_propagate_mt<Model, true>), dim3(grid), dim3(1024), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
+                                       a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, m, ob);
+                else
+                    hipLaunchKernelGGL((k_propagate_mt<Model, false>), dim3(grid), dim3(1024), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
+                                       a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, m, ob);
                 return MP_K1_FORM_TWO_TILES;
             }
         }
+        // the form of k_propagate: TAB2 (more tiles than threads in a drawing launch), LAT (the pending draws are a lattice's), SHD (a
+        // sharded filter's self-drawn resample); WALKB (long row walks finish by bisection) for the forms that have such an instantiation
+        const int sch = a.drw >> 1;
+        const bool shd = a.drw && a.drw_v.shd_range;
+        const bool lat = a.drw && (sch == 1 || sch == 2);
+        const bool tab2 = a.drw && !shd && a.drw_v.nt > THREADS;
         if constexpr (THREADS == 1024) {
-            if (a.drw && a.drw_v.shd_range) {   // a sharded filter's self-drawn resample (lattice range / split multinomial)
-                const int sch = a.drw >> 1;
-                if (sch == 1 || sch == 2)
-                    hipLaunchKernelGGL((k_propagate<Model, THREADS, false, true, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
-                                       a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                       a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                       a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                else
-                    hipLaunchKernelGGL((k_propagate<Model, THREADS, false, false, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
-                                       a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                       a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                       a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                return MP_K1_FORM_TILE;
-            }
-            if ((a.drw >> 1) != 0) {   // the pending draws are a lattice's (systematic / stratified)
-                if (a.drw_v.nt > THREADS)
-                    hipLaunchKernelGGL((k_propagate<Model, THREADS, true, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
-                                       a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                       a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                       a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                else
-                    hipLaunchKernelGGL((k_propagate<Model, THREADS, false, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
-                                       a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                       a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                       a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                return MP_K1_FORM_TILE;
-            }
-            if (a.drw && a.drw_v.nt > THREADS) {   // a drawing launch of a job with more tiles than threads: two table entries per thread
-                hipLaunchKernelGGL((k_propagate<Model, THREADS, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old,
-                                   a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                return MP_K1_FORM_TILE;
-            }
+            if (shd) return lat ? (a.walk_bisect ? k1<false, true, true, true>(a) : k1<false, true, true, false>(a))
+                                : (a.walk_bisect ? k1<false, false, true, true>(a) : k1<false, false, true, false>(a));
+            if (tab2) return lat ? k1<true, true, false, false>(a) : k1<true, false, false, false>(a);
+            if (lat) return a.walk_bisect ? k1<false, true, false, true>(a) : k1<false, true, false, false>(a);
         }
-        if constexpr (THREADS != 1024) {   // the wide models: a lattice's draws are looked up by the instantiation whose long walks bisect
-            if (a.walk_bisect) {
-                hipLaunchKernelGGL((k_propagate<Model, THREADS, false, false, false, true>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
-                                   a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
-                                   a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
-                                   a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
-                return MP_K1_FORM_TILE;
-            }
-        }
-        hipLaunchKernelGGL((k_propagate<Model, THREADS>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old, a.drw_v.tile_W_old, a.drw_v.tile_W2_old,
-                                   a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
+        return a.walk_bisect ? k1<false, false, false, true>(a) : k1<false, false, false, false>(a);
+    }
+    template <bool TAB2, bool LAT, bool SHD, bool WALKB>
+    int k1(const PropagateArgs& a) const {
+        constexpr int THREADS = (Model::MAX_NORMALS <= 4 && Model::DIM_STATE <= 4) ? 1024 : TILE_THREADS;
+        hipLaunchKernelGGL((k_propagate<Model, THREADS, TAB2, LAT, SHD, WALKB>), dim3(a.grid), dim3(THREADS), a.dyn_lds, a.stream, a.drw_v.tile_m_old,
+                           a.drw_v.tile_W_old, a.drw_v.tile_W2_old, a.drw_v.nt, a.drw, model, a.n, a.slot_offset, a.k0, a.k1, a.t,
                            a.x_in, a.x_out, a.logw, a.obs, a.s0, a.overwrite, a.dfr_row, a.inv_rows, a.cx_old, a.tail,
                            a.inv, a.dfr_lt, a.aux, a.drw_v, a.rc);
         return MP_K1_FORM_TILE;
@@ -547,6 +523,7 @@ struct mp_pf {
     int ow_rank = 0;
     mp_own_range* ow_range_solo = nullptr;   // {0, n}: a world of one owns every draw
     bool draws_lattice = false;           // the draws of the last resample are a lattice's (systematic / stratified)
+    int walk_bisect_force = -1;           // MP_WALK_BISECT: 0 = the plain-walk kernels always, 1 = the bisecting ones always, unset = by the rule in launch_propagate
     bool pending_shard = false;           // with draw_pending: the pending draws are a sharded filter's self-drawn ones (world ps_world, rank ps_rank)
     int ps_world = 1, ps_rank = 0;
     bool sharded = false;
@@ -784,7 +761,21 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     if (h->deferred && h->local_table && h->tiles_alt) {   // (what k1_tail_alt says: update_k1_tail)
         a.tile_m_new = reinterpret_cast<double*>(h->tiles_alt); a.tile_W_new = h->tiles_alt + h->nt; a.tile_W2_new = h->tiles_alt + 2 * (size_t)h->nt;
     }
-    a.walk_bisect = h->deferred && h->draws_lattice;
+    // Long row walks (collapsed weights: mp_resolve_draws' BISECT) — which instantiation looks the draws up.  Wide models: when the
+    // draws are a lattice's (consecutive slots share the long walks of a tile: the 40 % tail of DESIGN.md section 5).  One-double models: when
+    // the weights HAVE collapsed — the ESS of the last normalisation that reached the host-mapped mirror (a step old in an
+    // asynchronous loop; read without waiting) below 1 / 16 of the population; with healthy weights the plain walk is 5 - 10 % faster.
+    // Both instantiations find the same parents: the choice changes time only.
+    {
+        const bool wide = !(h->ops->max_normals <= 4 && h->ops->dim_state <= 4);
+        bool collapsed = false;
+        if (h->h_mirror && h->use_mirror) {
+            const double ess = *(volatile double*)&h->h_mirror->ess_stale;
+            collapsed = ess > 0. && ess * 16. < (double)h->n_global;
+        }
+        a.walk_bisect = h->deferred && (wide ? h->draws_lattice : collapsed);
+        if (h->walk_bisect_force >= 0) a.walk_bisect = h->walk_bisect_force != 0;   // MP_WALK_BISECT=0 / 1 (tests, A/B): never / always
+    }
     a.mt_grid = (h->use_k1_mt && !h->sharded) ? h->cus : 0;
     a.mt_flags = h->mt_flags;
     // ... and made by it too, when the resample left them pending (kernels of two-slot lanes)
@@ -945,6 +936,8 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (env && env[0] == '0') h->use_k1_table = 0;
         env = getenv("MP_FUSED_DRAWS");
         if (env && env[0] == '0') h->use_fused_draws = 0;
+        env = getenv("MP_WALK_BISECT");
+        if (env && (env[0] == '0' || env[0] == '1')) h->walk_bisect_force = env[0] - '0';
         env = getenv("MP_SHARD_SELF");
         if (env && env[0] == '0') h->use_shard_self = 0;
         env = getenv("MP_K1_MT");

@@ -115,6 +115,7 @@ __device__ __forceinline__ void mt_resolve_first(mp_mt_tile& T, const mp_k1mt& a
         }
     }
 }
+template <bool WALKB>
 __device__ __forceinline__ void mt_resolve_rest(const mp_mt_tile& T, const mp_k1mt& a, mp_mt_walk& W, uint32_t* parent, double* x0) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -126,9 +127,22 @@ __device__ __forceinline__ void mt_resolve_rest(const mp_mt_tile& T, const mp_k1
             for (int k = 0; k < MP_MT_WALK_ROWS; ++k) {
                 if (cur.x < T.plt[q] && p < last) { ++p; cur = W.nx[q][k]; }
             }
-            while (cur.x < T.plt[q] && p < last) {   // rare
-                ++p;
-                cur = mp_ld_row(a.cx_old + p);
+            if (cur.x < T.plt[q] && p < last) {   // rare: the walk is longer than the rows asked for in advance — the rest by bisection (the first
+                u64 lo = p + 1, hi = last;        // row of (p, last] whose cumulative weight reaches the target, or `last`: mp_resolve_draws' BISECT)
+                if constexpr (WALKB) {
+                    while (lo < hi) {
+                        const u64 mid = lo + ((hi - lo) >> 1);
+                        if (mp_ld_row(a.cx_old + mid).x >= T.plt[q]) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    p = lo;
+                    cur = mp_ld_row(a.cx_old + p);
+                } else {
+                    while (cur.x < T.plt[q] && p < last) {
+                        ++p;
+                        cur = mp_ld_row(a.cx_old + p);
+                    }
+                }
             }
         }
         parent[q] = (uint32_t)p;
@@ -358,7 +372,8 @@ __device__ __forceinline__ void mt_store_guide(const mp_k1mt& a, u64 tile, const
     reinterpret_cast<uint32_t*>(mp_as_global(a.guide_new) + tile * GUIDE_N)[threadIdx.x] = reinterpret_cast<const uint32_t*>(s_guide)[threadIdx.x];
 }
 
-template <class Model>
+// WALKB: walks beyond the rows asked for in advance finish by bisection (collapsed weights: the host picks, mp_pf.hip launch_propagate)
+template <class Model, bool WALKB = false>
 __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict__ pre_tm, const u64* __restrict__ pre_tW, const u64* __restrict__ pre_tW2,
                                                        int pre_nt, int /*drw: multinomial draws only*/, Model model, mp_k1mt a, mp_obs_n<Model::DIM_OBS> obs) {
     constexpr int THREADS = 1024, NWV = THREADS / 64;
@@ -482,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict_
     // every wave's walks of A are over before any wave asks for B's rows: the CU serves vector-memory operations in order, ACROSS
     // waves, so a late wave's walk loads would otherwise wait behind the early waves' 64-lane gathers for B (and A's normalisation,
     // behind its first barrier, for that wave)
-    mt_resolve_rest(A, a, WK, oA.par, px0);
+    mt_resolve_rest<WALKB>(A, a, WK, oA.par, px0);
     MP_STAMP_L(23, 0);
     mt_lds_barrier();
     asm volatile("" : "+v"(B.g[0]), "+v"(B.g[1]));
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict_
     asm volatile("" : "+v"(B.g[0]), "+v"(B.g[1]));   // (B's start rows are computed here, not hoisted to where its guide cells were asked for)
     mt_rows(B, a);                        // B's row pairs go out behind them
     MP_STAMP_L(23, 0);
-    mt_resolve_rest(A, a, WK, oA.par, px0);
+    mt_resolve_rest<WALKB>(A, a, WK, oA.par, px0);
 #endif
     MP_STAMP_L(25, 0);
     mt_model<Model>(model, a, obs, A.base, px0, zA, oA.lw, oA.xv);
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict_
     mt_norm_compute(oA.lw, a.n, tileA, s_norm, s_guideA, oA.cum, oA.m, oA.W, oA.W2);   // LDS and registers only: under B's row gathers
     MP_STAMP_L(20, 0);
     mt_resolve_first(B, a, WK);
-    mt_resolve_rest(B, a, WK, oB.par, px0);
+    mt_resolve_rest<WALKB>(B, a, WK, oB.par, px0);
     if (hasB) {
         MP_STAMP_L(27, 0);
         mt_store_tile(a, tileA, oA);      // the vector-memory path is free again: A's stores under B's arithmetic

@@ -670,7 +670,8 @@ constexpr uint32_t MP_DRAW_RECV = 0x80000000u;
 // (C5 under systematic resampling: 565 us per step against 410 with flat weights -> 435 with the bisection).
 // The bisection is not free where walks are short (same box: C3 + 5 %, C5 under multinomial draws + 1 %: registers), so the
 // propagate kernels carry it in an instantiation of their own (WALKB) that the host launches when the draws being looked up are a
-// lattice's and the model is a wide one; the one-double headline kernels keep the plain walk.
+// lattice's and the model is a wide one; the one-double kernels have the same two instantiations and the host picks the bisecting one
+// when the weights have collapsed (the last normalisation's ESS below 1 / 16 of the population: mp_pf.hip launch_propagate).
 #ifndef MP_WALK_LINEAR
 #define MP_WALK_LINEAR 3
 #endif
@@ -1131,7 +1132,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
     //   otherwise: after the deviates, one draw at a time (four rows in flight on top of a wider model's registers spill)
     constexpr bool SPLIT2 = !QUEUE && D == 1 && LANE_ITEMS == 2;
     if constexpr (SPLIT2) {
-        if (cx_old) mp_resolve_draw(cx_old, n, plt[0], pm[0], &pm[0], &px0[0], inv ? nullptr : inv_rows, D + 1);   // pm[] = the parent from here on
+        if (cx_old) mp_resolve_draw<WALKB>(cx_old, n, plt[0], pm[0], &pm[0], &px0[0], inv ? nullptr : inv_rows, D + 1);   // pm[] = the parent from here on
     }
     MP_STAMP(0, 20, 0);
     // ---- phase 1: standard deviates of every (particle, free normal site) of this lane ----
@@ -1304,7 +1305,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 // (an empty statement that makes the target "depend" on the last deviate: the compiler would otherwise run this
                 // lookup ahead of the deviates as well)
                 asm volatile("" : "+v"(plt[1]) : "v"(z[NS + NS - 1]));
-                mp_resolve_draw(cx_old, n, plt[1], pm[1], &pm[1], &px0[1], inv ? nullptr : inv_rows, D + 1);
+                mp_resolve_draw<WALKB>(cx_old, n, plt[1], pm[1], &pm[1], &px0[1], inv ? nullptr : inv_rows, D + 1);
                 if constexpr (CAN_DRAW) {
                     if (drew) {   // this lane's two parents, slot order: one 8-byte store
                         uint32_t* pp = mp_as_global(drw_v.parent);
@@ -1314,7 +1315,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                 }
                 MP_STAMP(0, 24, 0);
             } else if constexpr (D == 1) {
-                mp_resolve_draws<LANE_ITEMS>(cx_old, n, plt, pm, pm, px0, inv ? nullptr : inv_rows, D + 1);
+                mp_resolve_draws<LANE_ITEMS, WALKB>(cx_old, n, plt, pm, pm, px0, inv ? nullptr : inv_rows, D + 1);
             } else {
 #pragma unroll
                 for (int p = 0; p < LANE_ITEMS; ++p)

@@ -335,3 +335,40 @@ def test_run_owns_the_loop_and_skips_the_dead_stores(monkeypatch, n):
     ref.step(obs[T:T + 1])
     assert np.array_equal(pf.log_weights, ref.log_weights())
     assert np.array_equal(pf.states(), ref.state())
+
+
+@pytest.mark.parametrize("force", [None, "0", "1"])
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_collapsed_weights_one_double_state(monkeypatch, scheme, force):
+    """An observation noise of 1e-4 leaves ONE particle with all the weight: every draw lands in one tile, a thousand of them start in
+    the guide cell that holds the light rows in front of the heavy one and walk up to two thousand rows.  The propagate kernels have
+    an instantiation whose long walks finish by bisection (k_propagate<…, WALKB>, k_propagate_mt<…, true>); the host launches it when
+    the last normalisation's ESS is below 1 / 16 of the population (MP_WALK_BISECT = 0 / 1 forces never / always).  Same parents
+    either way — the checker finds them by binary search — at a size where both the one-workgroup-per-tile kernel and the two-tile
+    kernel run."""
+    import modppl_amd
+
+    if force is not None:
+        monkeypatch.setenv("MP_WALK_BISECT", force)
+    for n in (40000, 1 << 20):
+        T, seed = 6, 3
+        params = (0.0, 1.0, 0.9, 0.5, 1e-4)
+        obs = np.random.default_rng(3).normal(0, 1.0, size=(T, 1))
+        pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*params), n, seed)
+        ref = O.OraclePF(1, 1, 1, params, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, threads=8)
+        pf.init_step(None, obs[:1])
+        ref.init_step(obs[:1])
+        for t in range(1, T):
+            if t % 2:
+                assert pf.resample(scheme) == ref.resample(scheme)
+                assert np.array_equal(pf.parents, ref.parents())
+            else:   # asynchronous: the draws and their lookups inside the next step's kernel
+                pf.resample(scheme, sync=False)
+                ref.resample(scheme)
+            pf.step(obs[t:t + 1])
+            ref.step(obs[t:t + 1])
+            assert np.array_equal(pf.log_weights, ref.log_weights())
+            if t % 2 == 0:
+                assert np.array_equal(pf.parents, ref.parents())
+        assert pf.effective_sample_size(fresh=True) < n / 64        # collapsed indeed (the rule's threshold is n / 16)
+        assert np.array_equal(pf.states(), ref.state())
