@@ -51,6 +51,7 @@ struct mp_mt_tile {
 };
 
 // stage 1: the two draws of the lane's slots of tile `tile`: targets, tile walk in the LDS table, guide cells requested
+template <bool WALKB>
 __device__ __forceinline__ void mt_draw(mp_mt_tile& T, u64 tile, const mp_u64x2& blk, const mp_k1mt& a, int nt,
                                         const u64* s_incl, const u64* s_W, const double* s_ratio, u64 Q, double nt_over_Q) {
     T.base = tile * TILE + (u64)threadIdx.x * 2;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void mt_draw(mp_mt_tile& T, u64 tile, const mp_u64x2&
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const u64 tg = mp_target(mp_u52(q ? blk.b : blk.a), Q);
-        mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)nt, tg, nt_over_Q, &T.tile_of[q], &T.plt[q], &gslot[q]);
+        mp_locate_r<WALKB>(s_incl, s_W, s_ratio, (uint32_t)nt, tg, nt_over_Q, &T.tile_of[q], &T.plt[q], &gslot[q]);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) T.g[q] = a.guide_old[gslot[q]];
@@ -474,10 +475,10 @@ __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict_
     // (a workgroup without a second tile — the last one of an odd number of tiles — draws and gathers tile A's slots twice and
     // drops the copy: every memory operation up to B's parents is then straight-line code, whose waits the compiler counts exactly)
     const u64 tileBe = hasB ? tileB : tileA;
-    mt_draw(A, tileA, blk, a, pre_nt, s_incl, s_W, s_ratio, Q, nt_over_Q);
+    mt_draw<WALKB>(A, tileA, blk, a, pre_nt, s_incl, s_W, s_ratio, Q, nt_over_Q);
     if constexpr (MP_MT_ORDER <= 1) {
         blk = mp_resample_block((a.slot_offset + tileBe * TILE + (u64)tb * 2) >> 1, a.rc, (uint32_t)MP_DOM_RESAMPLE, a.k0, a.k1);
-        mt_draw(B, tileBe, blk, a, pre_nt, s_incl, s_W, s_ratio, Q, nt_over_Q);
+        mt_draw<WALKB>(B, tileBe, blk, a, pre_nt, s_incl, s_W, s_ratio, Q, nt_over_Q);
     }
     MP_STAMP_L(18, 0);
     if constexpr (MP_MT_ORDER == 0 || MP_MT_ORDER == 3) mt_deviates<Model>(model, ns, a, A.base, tileA, s_it[wave1], zA);   // under the guide gathers
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict_
     MP_STAMP_L(2, 0);
     if constexpr (MP_MT_ORDER >= 2) {   // B's draws (and its guide gathers) only now: A's row gathers are asked for as early as they can be
         blk = mp_resample_block((a.slot_offset + tileBe * TILE + (u64)tb * 2) >> 1, a.rc, (uint32_t)MP_DOM_RESAMPLE, a.k0, a.k1);
-        mt_draw(B, tileBe, blk, a, pre_nt, s_incl, s_W, s_ratio, Q, nt_over_Q);
+        mt_draw<WALKB>(B, tileBe, blk, a, pre_nt, s_incl, s_W, s_ratio, Q, nt_over_Q);
     }
     if constexpr (MP_MT_ORDER == 1 || MP_MT_ORDER == 2) mt_deviates<Model>(model, ns, a, A.base, tileA, s_it[wave1], zA);
     mt_deviates<Model>(model, ns, a, B.base, tileBe, s_it[wave1], zB);                                  // under A's row gathers

@@ -782,6 +782,7 @@ __device__ __forceinline__ u64 mp_target(u64 k52, u64 Q);
 __device__ __forceinline__ uint32_t mp_systematic_k32(uint32_t rc, uint32_t k0, uint32_t k1);
 __device__ __forceinline__ u64 mp_target_lattice(int scheme, u64 g, uint32_t shared_k32, uint32_t rc, uint32_t k0, uint32_t k1, u64 Q, u64 n_global);
 __device__ __forceinline__ mp_u64x2 mp_resample_block(u64 g_pair, uint32_t rc, uint32_t domain, uint32_t k0, uint32_t k1);
+template <bool BS = false>
 __device__ __forceinline__ void mp_locate_r(const u64* s_incl, const u64* s_W, const double* s_ratio, uint32_t nt, u64 target, double nt_over_Q,
                                             uint32_t* tile, u64* lt, uint32_t* gslot);
 // The model kernel in Generate mode for ONE particle (slot i): previous state from wherever the last resample left it, the
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
                     if (!own) tg = 1ull;
                 } else if constexpr (LAT) tg = mp_target_lattice(drw >> 1, slot_offset + (base + q < n ? base + q : 0ull), lat_k32, rc, k0, k1, Q, dw.n_global);
                 else tg = mp_target(mp_u52(q ? blk.b : blk.a), Q);
-                mp_locate_r(s_incl, s_W, s_ratio, (uint32_t)dw.nt, tg, nt_over_Q, &tile_of[q], &plt[q], &gslot[q]);
+                mp_locate_r<WALKB>(s_incl, s_W, s_ratio, (uint32_t)dw.nt, tg, nt_over_Q, &tile_of[q], &plt[q], &gslot[q]);
             }
             uint32_t j0[2];
             MP_STAMP(0, 18, 0);
@@ -1685,7 +1686,37 @@ __device__ __forceinline__ u64 mp_target_lattice(int scheme, u64 g, uint32_t sha
 
 // Tile of a global target: tile totals are nearly equal (each sums 2048 weights), so target * nt / Q lands within a
 // tile or two of the answer; walk from there.  Same result as a lower_bound over s_incl, fewer LDS reads.
+// BS: a plain lower bound by bisection instead — when the weights have collapsed most tiles carry no mass, the guess lands anywhere and
+// the walk crosses hundreds of flat entries (the WALKB kernels: same tile either way)
+template <bool BS = false>
 __device__ __forceinline__ uint32_t tile_of_target(const u64* s_incl, uint32_t nt, u64 target, double nt_over_Q) {
+#ifndef MP_TILE_BS
+#define MP_TILE_BS 1
+#endif
+    if constexpr (BS && MP_TILE_BS) {
+        // the same guess and up to three steps of the same walk; what is left of the table by bisection (first b with incl[b] >= target, or nt - 1)
+        int g = (int)((double)target * nt_over_Q);
+        if (g > (int)nt - 1) g = (int)nt - 1;
+        if (g < 0) g = 0;
+        uint32_t lo, hi;
+        if (g > 0 && s_incl[g - 1] >= target) {          // the answer is below g
+            int k = 0;
+            while (g > 0 && s_incl[g - 1] >= target && k < 3) { --g; ++k; }
+            if (!(g > 0 && s_incl[g - 1] >= target)) return (uint32_t)g;
+            lo = 0u; hi = (uint32_t)g - 1u;              // incl[g - 1] >= target: the answer is in [0, g - 1]
+        } else {                                          // incl[g - 1] < target (or g == 0): the answer is g or above
+            int k = 0;
+            while (g < (int)nt - 1 && s_incl[g] < target && k < 3) { ++g; ++k; }
+            if (!(g < (int)nt - 1 && s_incl[g] < target)) return (uint32_t)g;
+            lo = (uint32_t)g + 1u; hi = nt - 1u;         // incl[g] < target: the answer is in [g + 1, nt - 1]
+        }
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_incl[mid] >= target) hi = mid;
+            else lo = mid + 1u;
+        }
+        return lo;
+    }
     int b = (int)((double)target * nt_over_Q);
     if (b > (int)nt - 1) b = (int)nt - 1;
     if (b < 0) b = 0;
@@ -1694,9 +1725,10 @@ __device__ __forceinline__ uint32_t tile_of_target(const u64* s_incl, uint32_t n
     return (uint32_t)b;
 }
 // the same with the per-tile ratios (double)W_b / (double)T_b precomputed (k_shard_table)
+template <bool BS>
 __device__ __forceinline__ void mp_locate_r(const u64* s_incl, const u64* s_W, const double* s_ratio, uint32_t nt, u64 target, double nt_over_Q,
                                             uint32_t* tile, u64* lt, uint32_t* gslot) {
-    const uint32_t b = tile_of_target(s_incl, nt, target, nt_over_Q);
+    const uint32_t b = tile_of_target<BS>(s_incl, nt, target, nt_over_Q);
     const u64 excl = b ? s_incl[b - 1] : 0ull;
     const u64 W = s_W[b];
     const u64 x = mp_local_target_r(target - excl, W, s_ratio[b]);
