@@ -36,7 +36,7 @@ DIM = 1
 BYTES_K = {"propagate": 16 * DIM + 16 + 24, "normalize_scan": 8 + 8 + 8, "bin_draws": 8 + 4, "resample_gather": 4 + 16 * DIM + 8}
 FUSED_GATHER = 4 + 16 * DIM + 8
 SHARD_NOTE = {}   # how the sharded filter's collectives were issued (N > 1)
-KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024, false, false, false, false>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_draw_slots<1, 0>", "resample_gather": "k_resample_gather<0>"}
+KERNEL_OF = {"propagate": "k_propagate<mp_lgssm1, 1024, false, false, false, true>", "normalize_scan": "k_normalize_tiles", "bin_draws": "k_draw_slots<1, 0>", "resample_gather": "k_resample_gather<0>"}
 BYTES_STEP = 32 * DIM + 64
 
 
@@ -578,7 +578,7 @@ def main():
         avg_us = {k: ((v[0] / v[1]) * 1e3 if v[1] else 0.0) for k, v in fam.items()} if timed else None
         sharded_path = world > 1 or force_sharded
         if hasattr(timer, "last_propagate_form") and timer.last_propagate_form() == 1:   # (the library says which form of K1 its steps launched)
-            KERNEL_OF["propagate"] = "k_propagate_mt<mp_lgssm1, false>"   # (<…, true>: its long-walk form, launched when the weights have collapsed)
+            KERNEL_OF["propagate"] = "k_propagate_mt<mp_lgssm1, %s>" % ("false" if os.environ.get("MP_WALK_BISECT") == "0" else "true")   # (true: long walks finish by bisection)
         if sharded_path:   # the sharded filter runs other kernels for the resample
             if getattr(pf, "exchange", "") == "owned":
                 KERNEL_OF.update({"bin_draws": "k_shard_table + k_shard_own_draw + k_shard_own_plan", "resample_gather": "k_shard_own_place"})

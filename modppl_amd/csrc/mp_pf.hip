@@ -761,19 +761,15 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     if (h->deferred && h->local_table && h->tiles_alt) {   // (what k1_tail_alt says: update_k1_tail)
         a.tile_m_new = reinterpret_cast<double*>(h->tiles_alt); a.tile_W_new = h->tiles_alt + h->nt; a.tile_W2_new = h->tiles_alt + 2 * (size_t)h->nt;
     }
-    // Long row walks (collapsed weights: mp_resolve_draws' BISECT) — which instantiation looks the draws up.  Wide models: when the
-    // draws are a lattice's (consecutive slots share the long walks of a tile: the 40 % tail of DESIGN.md section 5).  One-double models: when
-    // the weights HAVE collapsed — the ESS of the last normalisation that reached the host-mapped mirror (a step old in an
-    // asynchronous loop; read without waiting) below 1 / 16 of the population; with healthy weights the plain walk is 5 - 10 % faster.
-    // Both instantiations find the same parents: the choice changes time only.
+    // Long row walks (collapsed weights: mp_resolve_draws' BISECT) — which instantiation looks the draws up.  One-double models: always
+    // the long-walk one (with MP_WALK_LINEAR = 12 it measures the same as the plain walk on healthy weights — 37.3 us either way,
+    // six alternations on one box — and an ESS that drops from 5 x 10^5 to 9 within one step no longer costs a 490 us step; a rule on
+    // the LAST normalisation's ESS, tried first, is a step late for exactly that case).  Wide models: when the draws are a lattice's
+    // (consecutive slots share a tile's long walks: the 40 % tail of DESIGN.md section 5; under multinomial draws the bisecting instantiation
+    // is 4 % slower on C5 and buys nothing).  Both find the same parents: the choice changes time only.
     {
         const bool wide = !(h->ops->max_normals <= 4 && h->ops->dim_state <= 4);
-        bool collapsed = false;
-        if (h->h_mirror && h->use_mirror) {
-            const double ess = *(volatile double*)&h->h_mirror->ess_stale;
-            collapsed = ess > 0. && ess * 16. < (double)h->n_global;
-        }
-        a.walk_bisect = h->deferred && (wide ? h->draws_lattice : collapsed);
+        a.walk_bisect = h->deferred && (wide ? h->draws_lattice : true);
         if (h->walk_bisect_force >= 0) a.walk_bisect = h->walk_bisect_force != 0;   // MP_WALK_BISECT=0 / 1 (tests, A/B): never / always
     }
     a.mt_grid = (h->use_k1_mt && !h->sharded) ? h->cus : 0;

@@ -131,6 +131,14 @@ __device__ __forceinline__ void mt_resolve_rest(const mp_mt_tile& T, const mp_k1
             if (cur.x < T.plt[q] && p < last) {   // rare: the walk is longer than the rows asked for in advance — the rest by bisection (the first
                 u64 lo = p + 1, hi = last;        // row of (p, last] whose cumulative weight reaches the target, or `last`: mp_resolve_draws' BISECT)
                 if constexpr (WALKB) {
+                    // (a few more rows one at a time first: a bisection is 11 dependent loads, a 5 - 8 row walk fewer)
+                    int steps = 0;
+                    while (cur.x < T.plt[q] && p < last && steps < MP_WALK_LINEAR - MP_MT_WALK_ROWS) {
+                        ++p; ++steps;
+                        cur = mp_ld_row(a.cx_old + p);
+                    }
+                    if (!(cur.x < T.plt[q] && p < last)) { lo = p; hi = p; }
+                    else lo = p + 1;
                     while (lo < hi) {
                         const u64 mid = lo + ((hi - lo) >> 1);
                         if (mp_ld_row(a.cx_old + mid).x >= T.plt[q]) hi = mid;

@@ -670,10 +670,11 @@ constexpr uint32_t MP_DRAW_RECV = 0x80000000u;
 // (C5 under systematic resampling: 565 us per step against 410 with flat weights -> 435 with the bisection).
 // The bisection is not free where walks are short (same box: C3 + 5 %, C5 under multinomial draws + 1 %: registers), so the
 // propagate kernels carry it in an instantiation of their own (WALKB) that the host launches when the draws being looked up are a
-// lattice's and the model is a wide one; the one-double kernels have the same two instantiations and the host picks the bisecting one
-// when the weights have collapsed (the last normalisation's ESS below 1 / 16 of the population: mp_pf.hip launch_propagate).
+// lattice's and the model is a wide one; the 1024-thread kernels have the same two instantiations and always look deferred draws up
+// with the bisecting one (mp_pf.hip launch_propagate says why).
 #ifndef MP_WALK_LINEAR
-#define MP_WALK_LINEAR 3
+#define MP_WALK_LINEAR 12   // (a bisection is 11 dependent loads: switching to it after 3 rows made every 5 - 8 row walk — one lane in a few
+                            //  waves even with healthy weights — cost more than walking on, and the waves of a workgroup wait for it: + 7 - 11 %)
 #endif
 
 template <int N, bool BISECT = false>

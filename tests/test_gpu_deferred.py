@@ -342,8 +342,8 @@ def test_run_owns_the_loop_and_skips_the_dead_stores(monkeypatch, n):
 def test_collapsed_weights_one_double_state(monkeypatch, scheme, force):
     """An observation noise of 1e-4 leaves ONE particle with all the weight: every draw lands in one tile, a thousand of them start in
     the guide cell that holds the light rows in front of the heavy one and walk up to two thousand rows.  The propagate kernels have
-    an instantiation whose long walks finish by bisection (k_propagate<…, WALKB>, k_propagate_mt<…, true>); the host launches it when
-    the last normalisation's ESS is below 1 / 16 of the population (MP_WALK_BISECT = 0 / 1 forces never / always).  Same parents
+    an instantiation whose long walks finish by bisection (k_propagate<…, WALKB>, k_propagate_mt<…, true>): the default for these
+    kernels (MP_WALK_BISECT = 0 / 1 forces never / always).  Same parents
     either way — the checker finds them by binary search — at a size where both the one-workgroup-per-tile kernel and the two-tile
     kernel run."""
     import modppl_amd
@@ -370,5 +370,5 @@ def test_collapsed_weights_one_double_state(monkeypatch, scheme, force):
             assert np.array_equal(pf.log_weights, ref.log_weights())
             if t % 2 == 0:
                 assert np.array_equal(pf.parents, ref.parents())
-        assert pf.effective_sample_size(fresh=True) < n / 64        # collapsed indeed (the rule's threshold is n / 16)
+        assert pf.effective_sample_size(fresh=True) < n / 64        # collapsed indeed
         assert np.array_equal(pf.states(), ref.state())
