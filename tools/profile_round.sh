@@ -36,6 +36,9 @@ ys = bench.lgssm_observations(80)
 r = bench.reference_shaped_loop(modppl_amd.lgssm_model(*bench.LGSSM_PARAMS), 1 << 20, ys, 50, 5)
 r['MP_HOST_MIRROR'] = $v
 print(json.dumps(r))"; done > $OUT/reference_shaped_loop.jsonl 2>/dev/null || echo "reference-shaped loop failed"
+# ... and the same loop from compiled host code (tools/sync_loop.cpp over the C++ wrapper): without the interpreter's share
+cd $R && g++ -std=c++17 -O2 tools/sync_loop.cpp -o $OUT/sync_loop -Lmodppl_amd/csrc -lmodppl_hip -Wl,-rpath,$R/modppl_amd/csrc 2> $OUT/sync_loop.err && { timeout -k 10 120 $OUT/sync_loop; MP_HOST_MIRROR=0 timeout -k 10 120 $OUT/sync_loop 1048576 100 | sed 's/^/MP_HOST_MIRROR=0: /'; } > $OUT/reference_shaped_loop_cpp.txt 2>&1 || echo "sync_loop (C++) failed"
+rm -f $OUT/sync_loop
 cd /tmp
 # the sharded code path in a world of one (owner-keeps exchange), kernel stats only
 MP_BENCH_FORCE_SHARDED=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sharded -o bench -- $B --steps 50 --warmup 10 > $OUT/trace_sharded.log 2>&1 || echo "sharded trace pass failed"
