@@ -499,3 +499,40 @@ def test_sharded_parents_survive_a_step(exchange):
         b.step(ys[t:t + 1])
         assert np.array_equal(b.parents, want), f"{exchange}: parents went stale at t={t}"
     assert np.array_equal(a.states(), b.states())
+
+
+def test_self_drawn_resample_randomised():
+    """Seeded random configurations of the self-drawn forms (world, state width, scheme, capacity, how uneven the weights are, whether
+    states are read between steps): parents, states, counts and log-weights against the checker's run of the same protocol."""
+    rng = np.random.default_rng(2024)
+    for trial in range(14):
+        world = int(rng.integers(2, 9))
+        d = int(rng.choice([1, 1, 4]))
+        scheme = int(rng.choice([1, 2, 3, 3]))
+        cap = int(rng.choice([0, 16, 512, 4096]))
+        tail = float(rng.choice([6.0, 14.0]))
+        peek = bool(rng.integers(0, 2))
+        n = 2048 * int(rng.integers(1, 3))
+        seed = int(rng.integers(1, 1 << 30))
+        model, obs = _model(d, 5)
+        if d == 1:
+            obs = obs.copy()
+            obs[2] = tail
+        hip = _ByHand(model, n, world, seed)
+        ref = OwnedReference(model, n * world, seed, world)
+        for e in hip.eng:
+            e.init_step(None, obs[:1])
+        ref.init_step(None, obs[:1])
+        what = (trial, world, d, scheme, cap, tail, peek, n, seed)
+        for t in range(1, len(obs)):
+            assert hip.resample(cap, scheme) == ref.resample(scheme), what
+            assert list(hip.counts) == list(ref.counts), what
+            if peek:
+                assert np.array_equal(hip.cat(lambda e: e.parents()), ref.parents()), what
+            for e in hip.eng:
+                e.step(obs[t:t + 1])
+            ref.step(obs[t:t + 1])
+            assert np.array_equal(hip.cat(lambda e: e.log_weights()), ref.log_weights()), what
+        assert np.array_equal(hip.cat(lambda e: e.states()), ref.states()), what
+        for e in hip.eng:
+            e.close()
