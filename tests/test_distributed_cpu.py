@@ -193,7 +193,7 @@ def test_owned_plan_conserves_rows():
             assert (np.diag(a) == 0).all()
 
 
-@pytest.mark.parametrize("exchange", ["owned", "exact"])
+@pytest.mark.parametrize("exchange", ["owned", "exact", "split"])
 def test_sharded_maybe_resample_follows_the_fresh_ess(exchange):
     """ESS-triggered resampling over shards (a world of one here, the checker as local engine): the decisions and results of
     one filter that is resampled whenever its fresh ESS drops below the threshold."""
