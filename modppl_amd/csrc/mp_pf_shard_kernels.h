@@ -38,7 +38,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_targets(u64 n, u64 n_globa
         }
         uint32_t b, gs;
         u64 lt;
-        mp_locate(s_incl, s_W, (uint32_t)nt_all, target, nt_over_Q, &b, &lt, &gs);
+        mp_locate<true>(s_incl, s_W, (uint32_t)nt_all, target, nt_over_Q, &b, &lt, &gs);
         const int s = (int)(b / (uint32_t)nt_local);
         dest[i] = (unsigned char)s;
         lt_out[i] = lt;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
                 target = mp_target(mp_resample_k52(slot_offset + i, rc, (uint32_t)MP_DOM_RESAMPLE, k0, k1), Q);
             }
             uint32_t b, gs;
-            mp_locate_r(s_incl, s_W, ratio_all, (uint32_t)nt_all, target, nt_over_Q, &b, &lt[k], &gs);
+            mp_locate_r<true>(s_incl, s_W, ratio_all, (uint32_t)nt_all, target, nt_over_Q, &b, &lt[k], &gs);
             const uint32_t own = b / (uint32_t)nt_local;
             tl[k] = b - own * (uint32_t)nt_local;
             key[k] = (int)(own * SH_BINS + (tl[k] * SH_BINS) / (uint32_t)nt_local);
@@ -761,8 +761,18 @@ __device__ __forceinline__ void mp_locate_own(const u64* incl, const u64* W_, co
     int b = (int)((double)trel * nt_over_span);   // only a starting guess for the walk: no effect on the result
     if (b > (int)nt - 1) b = (int)nt - 1;
     if (b < 0) b = 0;
-    while (b > 0 && incl[b - 1] >= tabs) --b;
-    while (b < (int)nt - 1 && incl[b] < tabs) ++b;
+    int budget = 4;                               // (a walk that uses its budget up — collapsed weights — is settled by bisection)
+    while (b > 0 && incl[b - 1] >= tabs && budget > 0) { --b; --budget; }
+    while (b < (int)nt - 1 && incl[b] < tabs && budget > 0) { ++b; --budget; }
+    if (budget == 0) {
+        uint32_t lo = 0u, hi = nt - 1u;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (incl[mid] >= tabs) hi = mid;
+            else lo = mid + 1u;
+        }
+        b = (int)lo;
+    }
     const u64 excl = b ? incl[b - 1] : excl0;
     const u64 W = W_[b];
     const u64 x = mp_local_target_r(tabs - excl, W, ratio[b]);
