@@ -372,3 +372,27 @@ def test_collapsed_weights_one_double_state(monkeypatch, scheme, force):
                 assert np.array_equal(pf.parents, ref.parents())
         assert pf.effective_sample_size(fresh=True) < n / 64        # collapsed indeed
         assert np.array_equal(pf.states(), ref.state())
+
+
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_collapsed_weights_single_kernel_resampler(monkeypatch, scheme):
+    """MP_DEFERRED_LOOKUPS=0: k_resample_gather (also the kernel behind importance_resampling) with ONE particle carrying the weight —
+    its long row walks finish by bisection and its tile walk is budgeted; same parents as the checker's binary searches."""
+    import modppl_amd
+
+    monkeypatch.setenv("MP_DEFERRED_LOOKUPS", "0")
+    n, T, seed = 50000, 6, 4
+    params = (0.0, 1.0, 0.9, 0.5, 1e-4)
+    obs = np.random.default_rng(3).normal(0, 1.0, size=(T, 1))
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*params), n, seed)
+    ref = O.OraclePF(1, 1, 1, params, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA, threads=8)
+    pf.init_step(None, obs[:1])
+    ref.init_step(obs[:1])
+    for t in range(1, T):
+        assert pf.resample(scheme) == ref.resample(scheme)
+        assert np.array_equal(pf.parents, ref.parents())
+        assert np.array_equal(pf.states(), ref.state())
+        pf.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(pf.log_weights, ref.log_weights())
+    assert pf.effective_sample_size(fresh=True) < n / 64
