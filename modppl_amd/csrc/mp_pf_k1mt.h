@@ -47,6 +47,7 @@ struct mp_mt_tile {
     u64 plt[2];             // tile-local targets of its two draws
     uint32_t tile_of[2];    // the draws' tiles, then (mt_rows) their start rows
     uint32_t g[2];          // guide cells (in flight after mt_draw)
+    uint32_t sp[2];         // the 32nd of its guide cell each target lies in (mp_guide_sub): with the cell's position bits it says which rows to ask for
     mp_u64v2 a[2], b2[2];   // start row and successor (in flight after mt_rows)
 };
 
@@ -59,25 +60,46 @@ __device__ __forceinline__ void mt_draw(mp_mt_tile& T, u64 tile, const mp_u64x2&
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const u64 tg = mp_target(mp_u52(q ? blk.b : blk.a), Q);
-        mp_locate_r<WALKB>(s_incl, s_W, s_ratio, (uint32_t)nt, tg, nt_over_Q, &T.tile_of[q], &T.plt[q], &gslot[q]);
+        mp_locate_r<WALKB>(s_incl, s_W, s_ratio, (uint32_t)nt, tg, nt_over_Q, &T.tile_of[q], &T.plt[q], &gslot[q], &T.sp[q]);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) T.g[q] = a.guide_old[gslot[q]];
 }
-// stage 2: start rows from the guide cells; the row pairs requested
+// stage 2: start rows from the guide cells; the rows requested.  MP_MT_Q5 (default): the cell's position bits against the target's own
+// 32nd of the cell (mp_guide_q5 / mp_guide_sub, mp_pf_kernels.h) say which rows — r0 ALONE when the target lies below cum[r0] (39 % of
+// the draws: the parent is r0, only its state is wanted), r0 + 1 and r0 + 2 when it lies above (r0's row is not fetched; the pair ends all
+// but 1.2 % of the walks), r0 and r0 + 1 when the two fall into the same 32nd (3 %).  Before: r0 and its successor for every draw, and a
+// third hop (three more rows) for the quarter of the lanes whose walk went past the pair — which every wave of the workgroup waited for.
+#ifndef MP_MT_Q5
+#define MP_MT_Q5 1
+#endif
 __device__ __forceinline__ void mt_rows(mp_mt_tile& T, const mp_k1mt& a) {
+    bool hbv[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const u64 tbase = (u64)T.tile_of[q] * TILE;
         const uint32_t tlen = (uint32_t)((a.n - tbase) < (u64)TILE ? (a.n - tbase) : (u64)TILE);
-        T.tile_of[q] = (uint32_t)tbase + (T.g[q] > tlen - 1 ? tlen - 1 : T.g[q]);   // row where the forward scan starts
+        const uint32_t j0 = mp_guide_row(T.g[q]);
+        uint32_t r0 = (uint32_t)tbase + (j0 > tlen - 1 ? tlen - 1 : j0);   // row where the forward scan starts
+        const uint32_t last = (uint32_t)tbase + tlen - 1;
+        if constexpr (MP_MT_Q5 != 0) {
+            const uint32_t q5 = mp_guide_q5(T.g[q]);
+            const bool below = T.sp[q] < q5, above = T.sp[q] > q5;
+            if (above && r0 < last) ++r0;                            // cum[r0] < target: the scan may start one row on
+            hbv[q] = !below && r0 < last;
+        } else {
+            hbv[q] = r0 < last && (MP_PAIR_SAME_LINE ? (r0 & 3u) != 3u : true);
+        }
+        T.tile_of[q] = r0;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t r0 = T.tile_of[q];
-        const bool hb = (u64)r0 < mp_tile_last(r0, a.n) && (MP_PAIR_SAME_LINE ? (r0 & 3u) != 3u : true);
         T.a[q] = mp_ld_row(a.cx_old + r0);
-        T.b2[q] = mp_ld_row(a.cx_old + (u64)r0 + (hb ? 1 : 0));
+        // (a lane that wants no second row reads row 0 of the table with every other such lane of the chip — or, without the position bits,
+        // its own row again, as before)
+        T.b2[q] = mp_ld_row(a.cx_old + (hbv[q] ? (u64)r0 + 1 : (MP_MT_Q5 != 0 ? 0ull : (u64)r0)));
+        T.sp[q] = hbv[q] ? 1u : 0u;                                  // (from here on: whether b2 is the successor)
     }
 }
 // stage 3: the parents (mp_resolve_draws' walk on the rows that have arrived) and their states — in two halves, because a CU's
@@ -101,7 +123,7 @@ __device__ __forceinline__ void mt_resolve_first(mp_mt_tile& T, const mp_k1mt& a
     for (int q = 0; q < 2; ++q) {
         const uint32_t r0 = T.tile_of[q];
         const u64 last = mp_tile_last(r0, a.n);
-        const bool hb = (u64)r0 < last && (MP_PAIR_SAME_LINE ? (r0 & 3u) != 3u : true);
+        const bool hb = T.sp[q] != 0u;                          // (mt_rows: the successor was asked for)
         const bool step1 = T.a[q].x < T.plt[q] && hb;
         W.p[q] = r0 + (step1 ? 1u : 0u);
         W.cur[q] = step1 ? T.b2[q] : T.a[q];
@@ -325,11 +347,14 @@ __device__ __forceinline__ void mt_norm_compute(const double (&lw)[2], u64 n, u6
         if (cur > prev) {
             const int g_lo = prev ? (int)(prev >> shift) + 1 : 0;
             const int g_hi = (int)(cur >> shift);
-            const unsigned short idx = (unsigned short)(tid * 2 + j);
+            const unsigned short idx = (unsigned short)((tid * 2 + j) | (31 << MP_GUIDE_Q_SHIFT));                            // (mp_guide_q5, mp_pf_kernels.h)
+            const unsigned short idx_hi = (unsigned short)((tid * 2 + j) | (mp_guide_sub(cur, shift) << MP_GUIDE_Q_SHIFT));
             if (g_hi - g_lo < GUIDE_DIRECT || long_hi >= long_lo) {
-                for (int g = g_lo; g <= g_hi; ++g) s_guide[g] = idx;
-            } else {
-                long_lo = g_lo; long_hi = g_hi; long_j = idx;
+                for (int g = g_lo; g < g_hi; ++g) s_guide[g] = idx;
+                if (g_hi >= g_lo) s_guide[g_hi] = idx_hi;
+            } else {   // (the run's last cell now, the cells in front of it by the wave below)
+                s_guide[g_hi] = idx_hi;
+                long_lo = g_lo; long_hi = g_hi - 1; long_j = idx;
             }
         }
         prev = cur;

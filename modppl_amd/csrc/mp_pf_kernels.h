@@ -227,6 +227,20 @@ __device__ __forceinline__ int mp_guide_shift(u64 W) {
     const int bits = 64 - __clzll((long long)W);  // W == 0 -> clz = 64 -> bits = 0
     return bits > GUIDE_BITS ? bits - GUIDE_BITS : 0;
 }
+// A guide cell is 16 bits and a row index needs 11: bits 11..15 carry WHERE in the cell the start row's cumulative weight lies, in
+// 32nds of the cell (round 5).  Cell g covers targets [g << shift, (g + 1) << shift); r0 = its start row; q5 = mp_guide_sub(cum[r0])
+// when cum[r0] lies inside the cell and 31 when it lies beyond.  A draw with target t in that cell compares its own 32nd,
+// sp = mp_guide_sub(t), with q5:  sp < q5 -> t < cum[r0]: the parent IS r0 (its row is fetched for the state only);  sp > q5 ->
+// t > cum[r0]: the walk starts at r0 + 1, r0's row is not fetched at all;  sp == q5 (one draw in ~ 30) -> undecided: r0 and its successor
+// as before.  Nothing changes in WHICH row a draw finds — the first row at or after r0 whose cumulative weight reaches the target —,
+// only in which rows are asked for on the way.  Readers that do not use the bits take mp_guide_row() of the cell.
+constexpr int MP_GUIDE_Q_SHIFT = 11;
+static_assert((TILE - 1) < (1 << MP_GUIDE_Q_SHIFT), "a tile-local row index fits below the position bits of a guide cell");
+__device__ __forceinline__ uint32_t mp_guide_row(uint32_t cell) { return cell & (uint32_t)(TILE - 1); }
+__device__ __forceinline__ uint32_t mp_guide_q5(uint32_t cell) { return cell >> MP_GUIDE_Q_SHIFT; }
+__device__ __forceinline__ uint32_t mp_guide_sub(u64 v, int shift) {   // the 32nd of its cell that tile-local value v lies in (cells narrower than 32: the offset itself)
+    return shift >= 5 ? (uint32_t)(v >> (shift - 5)) & 31u : (uint32_t)v & ((1u << shift) - 1u);
+}
 
 // ---------------------------------------------------------------------------------------------
 // level 1 built ONCE per normalisation, by the last workgroup of the level-0 launch to finish (atomic ticket): the
@@ -527,11 +541,15 @@ __device__ __forceinline__ void normalize_tile(const double (&lw)[TILE / THREADS
         if (cur > prev) {
             const int g_lo = prev ? (int)(prev >> shift) + 1 : 0;
             const int g_hi = (int)(cur >> shift);
-            const unsigned short idx = (unsigned short)(tid * ITEMS_ + j);
+            // (mp_guide_q5: the row ends inside cell g_hi, at 32nd mp_guide_sub(cur), and beyond every earlier cell it covers)
+            const unsigned short idx = (unsigned short)((tid * ITEMS_ + j) | (31 << MP_GUIDE_Q_SHIFT));
+            const unsigned short idx_hi = (unsigned short)((tid * ITEMS_ + j) | (mp_guide_sub(cur, shift) << MP_GUIDE_Q_SHIFT));
             if (g_hi - g_lo < GUIDE_DIRECT || long_hi >= long_lo) {
-                for (int g = g_lo; g <= g_hi; ++g) s_guide[g] = idx;
-            } else {
-                long_lo = g_lo; long_hi = g_hi; long_j = idx;
+                for (int g = g_lo; g < g_hi; ++g) s_guide[g] = idx;
+                if (g_hi >= g_lo) s_guide[g_hi] = idx_hi;
+            } else {   // (the run's last cell now, the cells in front of it by the wave below)
+                s_guide[g_hi] = idx_hi;
+                long_lo = g_lo; long_hi = g_hi - 1; long_j = idx;
             }
         }
         prev = cur;
@@ -785,7 +803,7 @@ __device__ __forceinline__ u64 mp_target_lattice(int scheme, u64 g, uint32_t sha
 __device__ __forceinline__ mp_u64x2 mp_resample_block(u64 g_pair, uint32_t rc, uint32_t domain, uint32_t k0, uint32_t k1);
 template <bool BS = false>
 __device__ __forceinline__ void mp_locate_r(const u64* s_incl, const u64* s_W, const double* s_ratio, uint32_t nt, u64 target, double nt_over_Q,
-                                            uint32_t* tile, u64* lt, uint32_t* gslot);
+                                            uint32_t* tile, u64* lt, uint32_t* gslot, uint32_t* sub = nullptr);
 // The model kernel in Generate mode for ONE particle (slot i): previous state from wherever the last resample left it, the
 // functor with a Generate handler over the deviates zp[0..NS), new state and log-weight out.
 template <class Model>
@@ -1087,7 +1105,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4
             uint32_t j0[2];
             MP_STAMP(0, 18, 0);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) j0[q] = dw.guide_old[gslot[q]];
+            for (int q = 0; q < 2; ++q) j0[q] = mp_guide_row(dw.guide_old[gslot[q]]);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const u64 tbase = (u64)tile_of[q] * TILE;
@@ -1720,16 +1738,19 @@ __device__ __forceinline__ uint32_t tile_of_target(const u64* s_incl, uint32_t n
     return (uint32_t)b;
 }
 // the same with the per-tile ratios (double)W_b / (double)T_b precomputed (k_shard_table)
+// (sub: the 32nd of its guide cell the tile-local target lies in, mp_guide_sub — for the readers that use the cell's position bits)
 template <bool BS>
 __device__ __forceinline__ void mp_locate_r(const u64* s_incl, const u64* s_W, const double* s_ratio, uint32_t nt, u64 target, double nt_over_Q,
-                                            uint32_t* tile, u64* lt, uint32_t* gslot) {
+                                            uint32_t* tile, u64* lt, uint32_t* gslot, uint32_t* sub) {
     const uint32_t b = tile_of_target<BS>(s_incl, nt, target, nt_over_Q);
     const u64 excl = b ? s_incl[b - 1] : 0ull;
     const u64 W = s_W[b];
     const u64 x = mp_local_target_r(target - excl, W, s_ratio[b]);
-    uint32_t g = (uint32_t)(x >> mp_guide_shift(W));
+    const int shift = mp_guide_shift(W);
+    uint32_t g = (uint32_t)(x >> shift);
     if (g > GUIDE_N - 1) g = GUIDE_N - 1;
     *tile = b; *lt = x; *gslot = b * (uint32_t)GUIDE_N + g;
+    if (sub) *sub = mp_guide_sub(x, shift);
 }
 // global target -> (tile, tile-local target, guide slot)
 template <bool BS = false>
@@ -1790,7 +1811,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_resample_gather(u64 n, u64 n_out
             tlen[k] = (uint32_t)((n - tbase[k]) < (u64)TILE ? (n - tbase[k]) : (u64)TILE);
         }
 #pragma unroll
-        for (int k = 0; k < KG_ITEMS; ++k) j[k] = guide[gslot[k]];
+        for (int k = 0; k < KG_ITEMS; ++k) j[k] = mp_guide_row(guide[gslot[k]]);
         mp_cx r0[KG_ITEMS], r1[KG_ITEMS];
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k) {
@@ -1936,7 +1957,7 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
     }
     // the guide lookups (the guide is L2-resident on every XCD)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];
+    for (int q = 0; q < 2; ++q) j0[q] = mp_guide_row(guide[gslot[q]]);
     // {target, start row} of the two draws in SLOT order: one 16-byte and one 8-byte store per lane
     uint32_t srow[2];
 #pragma unroll

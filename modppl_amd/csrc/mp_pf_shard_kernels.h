@@ -121,7 +121,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve(u64 n, u64 n_req, 
         const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
         uint32_t g = (uint32_t)(lt >> shift);
         if (g > GUIDE_N - 1) g = GUIDE_N - 1;
-        uint32_t j = guide[b * GUIDE_N + g];
+        uint32_t j = mp_guide_row(guide[b * GUIDE_N + g]);
         if (j > tlen - 1) j = tlen - 1;
         mp_cx row = load_row_nt(cx + tbase + j);
         while (row.cum < lt && j + 1 < tlen) {
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
         u64 p[SHR_ITEMS];
 #pragma unroll
         for (int k = 0; k < SHR_ITEMS; ++k) {   // hop 1: guide cells
-            u64 j = tbase[k] + guide[gi[k]];
+            u64 j = tbase[k] + mp_guide_row(guide[gi[k]]);
             p[k] = j < last[k] ? j : last[k];
         }
         mp_cx r0[SHR_ITEMS], r1[SHR_ITEMS];
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_num_sgpr(80))) v
                           &tile_of[q], &lt[q], &gslot[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];
+        for (int q = 0; q < 2; ++q) j0[q] = mp_guide_row(guide[gslot[q]]);
         uint32_t srow[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(SELF_THREADS) void k_shard_self_draw(u64 n, u64 n_g
                           &tile_of[q], &lt[q], &gslot[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];
+        for (int q = 0; q < 2; ++q) j0[q] = mp_guide_row(guide[gslot[q]]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const u64 tbase = (u64)tile_of[q] * TILE;
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_shard_self_place(u64 n, u64 n_global, u
         uint32_t tile, gslot;
         u64 lt;
         mp_locate_own(incl_sl, W_sl, ratio_sl, (uint32_t)nt_local, trel + lo, trel, lo, nt_over_span, &tile, &lt, &gslot);
-        const uint32_t j0 = guide[gslot];
+        const uint32_t j0 = mp_guide_row(guide[gslot]);
         const u64 tbase = (u64)tile * TILE;
         const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
         const uint32_t row0 = (uint32_t)tbase + (j0 > tlen - 1 ? tlen - 1 : j0);
