@@ -17,6 +17,7 @@ MP_RESAMPLE_MULTINOMIAL, MP_RESAMPLE_SYSTEMATIC, MP_RESAMPLE_STRATIFIED, MP_RESA
 MP_ESS_REFERENCE, MP_ESS_FRESH = 0, 1
 MP_PF_RECORD_HISTORY = 1
 MP_K_PROPAGATE, MP_K_NORMALIZE_SCAN, MP_K_RESAMPLE_GATHER, MP_K_BIN_DRAWS = 0, 1, 2, 3
+MP_K1_FORM_TILE, MP_K1_FORM_TWO_TILES, MP_K1_FORM_DENSE16 = 0, 1, 2   # mp_pf_last_propagate_form
 MP_SITE_IS_LINEAR, MP_SITE_A, MP_SITE_B, MP_SITE_C, MP_SITE_Y0 = 0, 1, 2, 3, 4
 MP_MH_MODEL_HIERARCHICAL = 1
 MP_MH_MODEL_POINTED_2D = 2

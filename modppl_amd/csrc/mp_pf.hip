@@ -453,7 +453,16 @@ struct mp_pf {
     int use_fused_draws = 1;            // MP_FUSED_DRAWS=0: a resample always launches k_draw_slots (A/B measurements)
     int use_k1_mt = 1;                  // MP_K1_MT=0: drawing launches stay one workgroup per tile (k_propagate) instead of k_propagate_mt (A/B measurements)
     int cus = 0;                        // compute units of the device (= workgroups of a k_propagate_mt launch)
-    int mt_flags = 0;                   // MP_MT_SKIP_* for the next k_propagate_mt (set by mp_pf_run, which knows what follows a step)
+    int mt_flags = 0;                   // (diagnostics) MP_MT_SKIP_* forced for every k_propagate_mt launch
+    // Lazy log-weights and parents (round 5).  A drawing k_propagate_mt launch stores neither: `resample` zeroes the one and replaces the
+    // other (particle_filter.rs:109-114), so in a step / resample loop they are dead stores — 12 B per particle-step of fabric writes in a
+    // kernel that is bound by its fabric transactions (-1.1 us per step at 2^20).  Whoever does read them before the next resample
+    // (mp_pf_read_log_weights, mp_pf_read_parents, a further step without a resample) first REPLAYS that launch with the same arguments
+    // and MP_MT_REPLAY: same Philox blocks, tables of the resampled generation (cx_alt, guide_alt, tiles_alt: untouched until the next
+    // drawing launch), same parents and log-weights, nothing else stored (ensure_lazy).
+    int use_lazy = 1;                   // MP_K1_LAZY=0 (diagnostics): every launch stores them
+    bool lazy_pending = false;          // logw[] and parent[] are those of an EARLIER launch: lazy_args reproduces the current ones
+    PropagateArgs lazy_args;
     mp_cx* cx_alt = nullptr;            // second row-table buffer: a k_propagate that looks up deferred draws in cx writes the new table here
     bool deferred = false;              // the last resample only drew: {dfr_lt, dfr_row}[slot] against the table in cx; x[cur] is the pre-resample state
     bool parents_deferred = false;      // ... and a step has consumed the draws since: its parents are still {dfr_lt, dfr_row} against cx_alt
@@ -661,6 +670,15 @@ static int32_t wait_seq(mp_pf* h, const volatile unsigned long long* word, unsig
     return MP_OK;
 }
 static int32_t flush_draws(mp_pf* h);
+// the log-weights and parents a drawing k_propagate_mt launch did not store (mp_pf::lazy_pending), now
+static int32_t ensure_lazy(mp_pf* h) {
+    if (!h->lazy_pending) return MP_OK;
+    h->lazy_pending = false;
+    PropagateArgs a = h->lazy_args;
+    a.mt_flags = MP_MT_REPLAY;
+    (void)h->ops->propagate(a);
+    return check_launch("k_propagate_mt (replay for the log-weights and parents)");
+}
 static int32_t fetch_scalars(mp_pf* h) {
     {   // (the scalars of a resample are folded by whoever makes its draws)
         int32_t rcf = flush_draws(h);
@@ -734,6 +752,8 @@ static int32_t hist_alloc(mp_pf* h, size_t bytes, void** out) {
 }
 
 static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs, bool overwrite) {
+    // (still pending here = no resample since: this is a further step of the same generation, which accumulates onto the log-weights)
+    { int32_t rcl = ensure_lazy(h); if (rcl != MP_OK) return rcl; }
     PropagateArgs a;
     a.n = h->n; a.slot_offset = h->slot_offset;
     a.k0 = (uint32_t)h->seed; a.k1 = (uint32_t)(h->seed >> 32);
@@ -774,6 +794,8 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     }
     a.mt_grid = (h->use_k1_mt && !h->sharded) ? h->cus : 0;
     a.mt_flags = h->mt_flags;
+    const bool lazy = h->use_lazy && h->deferred && h->draw_pending && !h->pending_shard && h->pending_scheme == MP_RESAMPLE_MULTINOMIAL;
+    if (lazy) a.mt_flags |= MP_MT_SKIP_LOGW | MP_MT_SKIP_PARENT;   // (read by k_propagate_mt only; below: whether that is what ran)
     // ... and made by it too, when the resample left them pending (kernels of two-slot lanes)
     a.drw = (h->deferred && h->draw_pending) ? (1 | (h->pending_scheme << 1)) : 0;   // bit 0: draw; bits 1..2: the scheme
     a.drw_v = mp_k1_draw{};
@@ -813,6 +835,10 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         h->last_k1_form = h->ops->propagate(a);
     }
     h->region_launches += 1;
+    if (lazy && h->last_k1_form == MP_K1_FORM_TWO_TILES) {
+        h->lazy_pending = true;
+        h->lazy_args = a;
+    }
     if (h->deferred) {   // the fresh table is the current one from here on; the old one stays intact for mp_pf_read_parents
         std::swap(h->cx, h->cx_alt);
         std::swap(h->guide, h->guide_alt);
@@ -939,6 +965,8 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         env = getenv("MP_K1_MT");
         if (env && env[0] == '0') h->use_k1_mt = 0;
         HIPCK(hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device));
+        env = getenv("MP_K1_LAZY");
+        if (env && env[0] == '0') h->use_lazy = 0;
         env = getenv("MP_K1_MT_GRID");   // (A/B measurements: another number of workgroups)
         if (env && atoi(env) > 0) h->cus = atoi(env);
         env = getenv("MP_K1_MT_FLAGS");  // (A/B measurements: MP_MT_SKIP_* for every launch — results of reads are then undefined)
@@ -1119,6 +1147,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         return mp_fail(MP_ERR_INVALID_ARG, "unknown resampling scheme");
     if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: resample runs through the mp_pf_shard_* phases");
     HIPCK(hipSetDevice(h->device));
+    h->lazy_pending = false;   // log_weights.fill(0.) and new parents (particle_filter.rs:109-114): what the last step did not store is dead
     int32_t rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
     h->parents_deferred = false;   // this resample's parents replace whatever was still waiting to be read
@@ -1292,6 +1321,7 @@ int32_t mp_pf_read_log_weights(mp_pf* h, double* out) {
     if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
     { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
+    { int32_t rcl = ensure_lazy(h); if (rcl != MP_OK) return rcl; }
     HIPCK(hipMemcpyAsync(out, h->logw, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
     return MP_OK;
@@ -1301,6 +1331,7 @@ int32_t mp_pf_read_parents(mp_pf* h, uint32_t* out) {
     if (!h || !out) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     HIPCK(hipSetDevice(h->device));
     { int32_t rcm = materialize(h); if (rcm != MP_OK) return rcm; }
+    { int32_t rcl = ensure_lazy(h); if (rcl != MP_OK) return rcl; }
     // a step after a lazy resample moved the states on but left the parents where the resample put them
     if (h->parents_deferred) {
         hipLaunchKernelGGL(k_resolve_slots<false>, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->ops->dim_state,
@@ -2007,17 +2038,13 @@ int32_t mp_pf_run(mp_pf* h, const double* args0, const double* obs, int32_t n_st
     if (rc != MP_OK) return rc;
     rc = mp_pf_resample(h, scheme, nullptr);
     if (rc != MP_OK) return rc;
-    // Here the library owns the loop and knows what follows every step: a resample.  The log-weights a step would store are dead
-    // (`resample` zeroes them, particle_filter.rs:114: whoever reads them afterwards gets the zeros materialize() writes) and so
-    // are the parents of every resample but the last, which is still pending when this function returns and is drawn on demand
-    // (flush_draws + k_resolve_slots).  k_propagate_mt skips both stores (12 B per particle-step, -1.1 us per step at 2^20).
-    const int saved_flags = h->mt_flags;
-    h->mt_flags |= MP_MT_SKIP_LOGW | MP_MT_SKIP_PARENT;
+    // (the log-weights a step would store are dead here — `resample` zeroes them, particle_filter.rs:114 — and so are the parents of
+    // every resample but the last: k_propagate_mt launches leave both out and reproduce them on demand, mp_pf::lazy_pending; round 4 did
+    // that for this loop only, by flags that a failing resample left behind)
     for (int t = 1; t < n_steps && rc == MP_OK; ++t) {
         rc = mp_pf_step(h, obs + (size_t)t * h->ops->dim_obs, 1);
         if (rc == MP_OK) rc = mp_pf_resample(h, scheme, nullptr);
     }
-    h->mt_flags = saved_flags;
     return rc;
 }
 

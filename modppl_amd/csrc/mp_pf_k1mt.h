@@ -27,7 +27,9 @@ struct mp_k1mt {            // by value (kernel arguments)
     long long t;
     uint32_t k0, k1, rc;
     int S;
-    int flags;              // bit 0: the log-weights are not stored (the caller resamples next: mp_pf_run); bit 1: parent[] is not stored (recomputed on demand)
+    int flags;              // MP_MT_SKIP_LOGW: the log-weights are not stored, MP_MT_SKIP_PARENT: parent[] is not stored (both produced on demand by a
+                            // launch with MP_MT_REPLAY: `resample` zeroes the one and replaces the other, particle_filter.rs:109-114, so in a
+                            // step / resample loop nobody ever reads them)
     double* logw;
     const mp_cx* cx_old;                 // the generation that was resampled: its rows and guide (read) ...
     const unsigned short* guide_old;
@@ -40,6 +42,9 @@ struct mp_k1mt {            // by value (kernel arguments)
     mp_dev_scalars* scal;
 };
 constexpr int MP_MT_SKIP_LOGW = 1, MP_MT_SKIP_PARENT = 2;
+// MP_MT_REPLAY: the launch repeats an earlier one of the same arguments ONLY to produce what that one skipped — the log-weights and the
+// parents (mp_pf.hip ensure_lazy): nothing else is stored, nothing folded, no normalisation
+constexpr int MP_MT_REPLAY = 4;
 
 // what a lane carries for one of its tiles between the stages of the pipeline
 struct mp_mt_tile {
@@ -402,6 +407,17 @@ __device__ __forceinline__ void mt_store_tile(const mp_k1mt& a, u64 tile, const 
         mp_as_global(a.tW2_new)[tile] = o.W2;
     }
 }
+// (MP_MT_REPLAY) only what the first launch of these arguments left out
+__device__ __forceinline__ void mt_store_replay(const mp_k1mt& a, u64 tile, const mp_mt_out& o) {
+    const u64 base = tile * TILE + (u64)threadIdx.x * 2;
+    if (base + 1 < a.n) {
+        *reinterpret_cast<uint2*>(a.parent + base) = make_uint2(o.par[0], o.par[1]);
+        *reinterpret_cast<double2*>(a.logw + base) = make_double2(o.lw[0], o.lw[1]);
+    } else if (base < a.n) {
+        a.parent[base] = o.par[0];
+        a.logw[base] = o.lw[0];
+    }
+}
 __device__ __forceinline__ void mt_store_guide(const mp_k1mt& a, u64 tile, const unsigned short* s_guide) {
     reinterpret_cast<uint32_t*>(mp_as_global(a.guide_new) + tile * GUIDE_N)[threadIdx.x] = reinterpret_cast<const uint32_t*>(s_guide)[threadIdx.x];
 }
@@ -489,7 +505,7 @@ __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict_
                 s_ratio[tb] = (double)Wb / (double)Tq;
             }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !(a.flags & MP_MT_REPLAY)) {
             u64 Q2all = 0;
             for (int k = 0; k < NWV; ++k) Q2all += s_l1_tot2[k];
             fold_scalars(mp_as_global(a.scal), Qall, Q2all, a.S, m, a.n_global, 0);
@@ -545,11 +561,18 @@ __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict_
     MP_STAMP_L(25, 0);
     mt_model<Model>(model, a, obs, A.base, px0, zA, oA.lw, oA.xv);
     MP_STAMP_L(26, 0);
-    mt_norm_compute(oA.lw, a.n, tileA, s_norm, s_guideA, oA.cum, oA.m, oA.W, oA.W2);   // LDS and registers only: under B's row gathers
+    const bool replay = (a.flags & MP_MT_REPLAY) != 0;   // workgroup-uniform
+    if (!replay) mt_norm_compute(oA.lw, a.n, tileA, s_norm, s_guideA, oA.cum, oA.m, oA.W, oA.W2);   // LDS and registers only: under B's row gathers
     MP_STAMP_L(20, 0);
     mt_resolve_first(B, a, WK);
     mt_resolve_rest<WALKB>(B, a, WK, oB.par, px0);
-    if (hasB) {
+    if (replay) {
+        mt_store_replay(a, tileA, oA);
+        if (hasB) {
+            mt_model<Model>(model, a, obs, B.base, px0, zB, oB.lw, oB.xv);
+            mt_store_replay(a, tileB, oB);
+        }
+    } else if (hasB) {
         MP_STAMP_L(27, 0);
         mt_store_tile(a, tileA, oA);      // the vector-memory path is free again: A's stores under B's arithmetic
         mt_model<Model>(model, a, obs, B.base, px0, zB, oB.lw, oB.xv);

@@ -5,6 +5,7 @@ particle_filter.rs:103-116 (`resample`), :73-96 (`step` keeps `parents`)."""
 import numpy as np
 import pytest
 
+from modppl_amd import capi
 from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -304,6 +305,56 @@ def test_two_tiles_per_workgroup_kernel_at_small_sizes(monkeypatch, n):
     assert np.array_equal(mt.log_weights, ref.log_weights())
     assert mt.effective_sample_size(fresh=True) == ref.effective_sample_size(1)
     assert mt.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate() == one.log_marginal_likelihood_estimate()
+
+
+@pytest.mark.parametrize("n", [2048 * 4 + 77, 2048 * 7])
+def test_log_weights_and_parents_left_out_by_the_step_are_reproduced_on_demand(monkeypatch, n):
+    """A drawing k_propagate_mt launch stores neither the log-weights nor the parents (round 5: `resample` zeroes the one and replaces
+    the other, particle_filter.rs:109-114; 12 B per particle-step of dead stores in a step / resample loop).  Whoever reads them
+    before the next resample gets them from a replay of that launch (mp_pf.hip ensure_lazy, MP_MT_REPLAY): every way of reaching that —
+    a read of either, a FURTHER step without a resample in between (it accumulates onto the log-weights, :81), nothing at all — must
+    leave the checker's values, and a filter that stores eagerly (MP_K1_LAZY=0) must agree."""
+    import modppl_amd
+
+    seed, T = 31, 12
+    obs = O.lgssm_observations(T).reshape(T, 1)
+    monkeypatch.setenv("MP_K1_MT_GRID", "1")
+    lazy = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    monkeypatch.setenv("MP_K1_LAZY", "0")
+    eager = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, seed)
+    monkeypatch.delenv("MP_K1_LAZY")
+    monkeypatch.delenv("MP_K1_MT_GRID")
+    ref = O.OraclePF(1, 1, 1, O.LGSSM_PARAMS, n, seed, O.VARIANT_CANONICAL | O.VARIANT_SOA)
+    for pf in (lazy, eager):
+        pf.init_step(None, obs[:1])
+    ref.init_step(obs[:1])
+    # what happens between a step and the next resample, round by round
+    plan = ["none", "logw", "parents", "step", "none", "both", "step+logw", "states", "none", "step", "parents"]
+    for t, what in zip(range(1, T), plan):
+        for pf in (lazy, eager):
+            pf.resample(sync=False)
+            pf.step(obs[t:t + 1])
+            assert pf.last_propagate_form() == capi.MP_K1_FORM_TWO_TILES
+        ref.resample()
+        ref.step(obs[t:t + 1])
+        if what in ("logw", "both"):
+            assert np.array_equal(lazy.log_weights, ref.log_weights())
+        if what in ("parents", "both"):
+            assert np.array_equal(lazy.parents, ref.parents())
+        if what == "states":
+            assert np.array_equal(lazy.states(), ref.state())
+        if what.startswith("step"):   # a second observation of the same generation: no resample, the log-weights accumulate
+            for pf in (lazy, eager):
+                pf.step(obs[t:t + 1])
+            ref.step(obs[t:t + 1])
+            if what == "step+logw":
+                assert np.array_equal(lazy.log_weights, ref.log_weights())
+                assert np.array_equal(lazy.parents, ref.parents())
+    assert np.array_equal(lazy.log_weights, ref.log_weights())
+    assert np.array_equal(lazy.log_weights, eager.log_weights)
+    assert np.array_equal(lazy.parents, eager.parents)
+    assert np.array_equal(lazy.states(), ref.state())
+    assert lazy.log_marginal_likelihood_estimate() == ref.log_marginal_likelihood_estimate() == eager.log_marginal_likelihood_estimate()
 
 
 @pytest.mark.parametrize("n", [2048 * 4 + 77, 1 << 20])
