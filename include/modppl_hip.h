@@ -436,6 +436,39 @@ int32_t mp_fn_assess(mp_mh* h, int32_t proposal_kind, const double* proposal_arg
 int32_t mp_fn_propose(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, uint32_t rng_step,
                       double* choice_values_out, uint32_t* choice_present_out, double* weights_out);
 
+/* (trace, weight) = model.generate(args, constraints) — gfi.rs:53-55, dyngenfn.rs:513-521: constrained sites take their constraint
+ * and score into the weight, every other site is drawn from its prior (the internal proposal importance sampling is made of).
+ * Every chain's trace is REPLACED by its new trace; constraints shared or per chain as above. */
+int32_t mp_fn_generate(mp_mh* h, uint32_t rng_step, const int32_t* sites, const double* values, int32_t n_constraints, const double* chain_values,
+                       const uint32_t* chain_present, double* weights_out);
+/* trace = model.simulate(args) — gfi.rs:51, dyngenfn.rs:503-511: every site drawn, the observed ones included; every chain's trace
+ * is replaced; logjp_out[n_chains] = trace.logjp (nullable). */
+int32_t mp_fn_simulate(mp_mh* h, uint32_t rng_step, double* logjp_out);
+/* The same two as constructors: n_chains traces of a registered function from nothing, Philox step 0.  mp_fn_generate_create with
+ * weights_out = NULL is mp_mh_create_fn. */
+int32_t mp_fn_generate_create(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                              int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, double* weights_out, mp_mh** out);
+int32_t mp_fn_simulate_create(int32_t model_kind, const double* params, int32_t n_params, uint64_t n_chains, uint64_t seed, int32_t device, void* stream,
+                              double* logjp_out, mp_mh** out);
+
+/* ---- importance sampling over a REGISTERED generative function — modppl/src/inference/importance.rs:12-50 -------------------
+ * `importance_sampling(model, model_args, constraints, num_samples)` is generic over `impl GenFn`; the reference's third test runs it
+ * on `hierarchical_model` (modppl/tests/importance.rs:89-139: 11 observations, 10 000 samples, "works with ~1,000,000 particles").
+ * mp_importance_sampling above takes Unfold-style model descriptors only; these take any registered function:
+ *   num_samples x model.generate(args, constraints) (Philox slot = sample, step 0)             importance.rs:18-20
+ *   log_total_weight = logsumexp(weights); log_ml_estimate = log_total_weight - ln N;  lnw_i = w_i - log_total_weight   :21-25
+ *   importance_resampling: num_ret_samples categorical draws over exp(lnw) (one sequential stream, Philox domain IS)      :44-47
+ * The normalisation is the filters' canonical one, so log_ml and the indices are bit-equal to the checker's.
+ * log_normalized_weights[num_samples], resampled_indices[num_ret_samples] (host; the former nullable).  traces_out (nullable): the
+ * num_samples traces as a handle — mp_mh_read_trace returns them, and every mp_mh_* / mp_fn_* call applies (sample i = chain i);
+ * the caller destroys it. */
+int32_t mp_fn_importance_sampling(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                                  int32_t n_constraints, uint64_t num_samples, uint64_t seed, int32_t device, double* log_ml_estimate,
+                                  double* log_normalized_weights, mp_mh** traces_out);
+int32_t mp_fn_importance_resampling(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                                    int32_t n_constraints, uint64_t num_samples, uint64_t num_ret_samples, uint64_t seed, int32_t device,
+                                    double* log_ml_estimate, double* log_normalized_weights, uint64_t* resampled_indices, mp_mh** traces_out);
+
 /* MH iterations applied so far (the Philox step of the next iteration is this + 1). */
 int32_t mp_mh_iterations(mp_mh* h, uint64_t* out);
 int32_t mp_mh_destroy(mp_mh* h);

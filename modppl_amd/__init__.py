@@ -4,6 +4,7 @@ Only what the path needs: csrc/ (HIP kernels + the C ABI of include/modppl_hip.h
 mirror of the reference's inference entry points.
 """
 from .capi import ModpplError  # noqa: F401
-from .inference import FunctionChains, HierarchicalChains, ParticleSystem, PointedChains, importance_resampling, importance_sampling, simulate  # noqa: F401
+from .inference import (FunctionChains, HierarchicalChains, ParticleSystem, PointedChains, fn_importance_resampling, fn_importance_sampling,  # noqa: F401
+                        importance_resampling, importance_sampling, simulate)
 from .models import (UnfoldModel, bearings_model, hmm_model, lgssm_band_model, lgssm_dense_model, lgssm_model, line_model,  # noqa: F401
                      pointed_2d_model, spiral_model, stochastic_volatility_model)

@@ -41,6 +41,7 @@ SYMBOLS = [
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
     "mp_mh_create", "mp_mh_create_pointed", "mp_mh_step", "mp_regen_mh_step", "mp_mh_read_state", "mp_mh_read_logjp", "mp_mh_read_observations", "mp_mh_iterations", "mp_mh_destroy",
     "mp_mh_create_fn", "mp_mh_n_sites", "mp_mh_read_trace", "mp_fn_update", "mp_fn_regenerate", "mp_fn_assess", "mp_fn_propose",
+    "mp_fn_generate", "mp_fn_simulate", "mp_fn_generate_create", "mp_fn_simulate_create", "mp_fn_importance_sampling", "mp_fn_importance_resampling",
     # include/modppl_hip_probe.h
     "mp_probe_math", "mp_probe_normal_sample", "mp_probe_u01", "mp_probe_mfma_f64", "mp_probe_mvnormal",
 ]
@@ -179,6 +180,12 @@ def load():
     L.mp_fn_regenerate.argtypes = [p, i32, u32, C.POINTER(i32), i32, dp]
     L.mp_fn_assess.argtypes = [p, i32, dp, i32, u32, C.POINTER(i32), dp, i32, dp, C.POINTER(u32), dp]
     L.mp_fn_propose.argtypes = [p, i32, dp, i32, u32, dp, C.POINTER(u32), dp]
+    L.mp_fn_generate.argtypes = [p, u32, C.POINTER(i32), dp, i32, dp, C.POINTER(u32), dp]
+    L.mp_fn_simulate.argtypes = [p, u32, dp]
+    L.mp_fn_generate_create.argtypes = [i32, dp, i32, C.POINTER(i32), dp, i32, u64, u64, i32, p, dp, C.POINTER(p)]
+    L.mp_fn_simulate_create.argtypes = [i32, dp, i32, u64, u64, i32, p, dp, C.POINTER(p)]
+    L.mp_fn_importance_sampling.argtypes = [i32, dp, i32, C.POINTER(i32), dp, i32, u64, u64, i32, dp, dp, C.POINTER(p)]
+    L.mp_fn_importance_resampling.argtypes = [i32, dp, i32, C.POINTER(i32), dp, i32, u64, u64, u64, i32, dp, dp, C.POINTER(u64), C.POINTER(p)]
     L.mp_probe_math.argtypes = [i32, dp, dp, dp, i64, dp, i32]
     L.mp_probe_normal_sample.argtypes = [u64, u32, u32, u32, u32, d, d, i64, dp, i32]
     L.mp_probe_u01.argtypes = [u64, u32, u32, u32, u32, u32, i64, dp, i32]

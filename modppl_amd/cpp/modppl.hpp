@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <memory>
 #include <vector>
 
 #include "../../include/modppl_hip.h"
@@ -175,9 +176,32 @@ public:
             throw std::runtime_error(why);
         }
     }
+    // a handle the library returned (the traces of fn_importance_*): sample i = chain i
+    FunctionChains(mp_mh* adopted, uint64_t num_chains) : h_(adopted), n_(num_chains) {
+        if (mp_mh_n_sites(h_, &ns_) != MP_OK) {
+            const std::string why = mp_last_error();
+            mp_mh_destroy(h_);
+            throw std::runtime_error(why);
+        }
+    }
     FunctionChains(const FunctionChains&) = delete;
     ~FunctionChains() { mp_mh_destroy(h_); }
     int32_t num_sites() const { return ns_; }
+    // (trace, weight) = model.generate(args, constraints) on every chain, shared constraints (gfi.rs:53-55); the traces are replaced
+    std::vector<double> generate(const std::vector<std::pair<int32_t, double>>& constraints, uint32_t rng_step = 0) {
+        std::vector<int32_t> sites;
+        std::vector<double> vals, w(n_);
+        for (const auto& c : constraints) { sites.push_back(c.first); vals.push_back(c.second); }
+        check(mp_fn_generate(h_, rng_step, sites.empty() ? nullptr : sites.data(), vals.empty() ? nullptr : vals.data(), (int32_t)sites.size(), nullptr, nullptr,
+                             w.data()));
+        return w;
+    }
+    // trace = model.simulate(args) on every chain (gfi.rs:51) -> each new trace's logjp
+    std::vector<double> simulate(uint32_t rng_step = 0) {
+        std::vector<double> lj(n_);
+        check(mp_fn_simulate(h_, rng_step, lj.data()));
+        return lj;
+    }
     uint64_t mh(int32_t proposal_kind, const std::vector<double>& args = {}, int32_t n_iters = 1) {
         uint64_t acc;
         check(mp_mh_step(h_, proposal_kind, args.empty() ? nullptr : args.data(), (int32_t)args.size(), n_iters, &acc));
@@ -246,6 +270,33 @@ public:
 // One rank of a filter sharded over `world` GPUs (one process per GPU): same calls as ParticleSystem, and resample() is ONE
 // library call that issues its RCCL collectives itself (mp_pf_shard_resample_rccl).  `comm`: the host's ncclComm_t, or null to
 // let the library make a communicator of its own from `id128` (mp_rccl_unique_id on rank 0, handed to the others by the host).
+// importance_sampling / importance_resampling over a registered generative function (importance.rs:12-50; mp_fn_importance_* of the C ABI)
+struct FnImportance {
+    std::unique_ptr<FunctionChains> traces;       // sample i = chain i
+    std::vector<double> log_normalized_weights;   // [num_samples]
+    std::vector<uint64_t> resampled_indices;      // [num_ret_samples]
+    double log_ml_estimate = 0.;
+};
+inline FnImportance fn_importance_resampling(int32_t model_kind, const std::vector<double>& params, const std::vector<std::pair<int32_t, double>>& constraints,
+                                             uint64_t num_samples, uint64_t num_ret_samples, uint64_t seed, int device = 0) {
+    std::vector<int32_t> sites;
+    std::vector<double> vals;
+    for (const auto& c : constraints) { sites.push_back(c.first); vals.push_back(c.second); }
+    FnImportance out;
+    out.log_normalized_weights.resize(num_samples);
+    out.resampled_indices.resize(num_ret_samples);
+    mp_mh* h = nullptr;
+    check(mp_fn_importance_resampling(model_kind, params.empty() ? nullptr : params.data(), (int32_t)params.size(), sites.empty() ? nullptr : sites.data(),
+                                      vals.empty() ? nullptr : vals.data(), (int32_t)sites.size(), num_samples, num_ret_samples, seed, device, &out.log_ml_estimate,
+                                      out.log_normalized_weights.data(), num_ret_samples ? out.resampled_indices.data() : nullptr, &h));
+    out.traces.reset(new FunctionChains(h, num_samples));
+    return out;
+}
+inline FnImportance fn_importance_sampling(int32_t model_kind, const std::vector<double>& params, const std::vector<std::pair<int32_t, double>>& constraints,
+                                           uint64_t num_samples, uint64_t seed, int device = 0) {
+    return fn_importance_resampling(model_kind, params, constraints, num_samples, 0, seed, device);
+}
+
 class ShardedParticleSystem {
     mp_pf* h_ = nullptr;
     UnfoldModel model_;

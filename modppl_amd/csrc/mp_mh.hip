@@ -32,6 +32,9 @@ typedef unsigned long long u64;
 static thread_local std::string g_mh_err;
 extern "C" const char* mp_last_error(void);
 int32_t mp_set_error(int32_t code, const std::string& msg);  // mp_pf.hip
+// mp_pf.hip: L, log-ML, lnw[n] and M categorical draws from a device array of log-weights (importance.rs:21-27, 44-47)
+int32_t mp_is_finish_device(const double* d_logw, uint64_t n, uint64_t num_ret, uint64_t seed, int32_t device, void* stream, double* log_ml_estimate,
+                            double* log_normalized_weights, uint64_t* resampled_indices);
 #define MHCK(call)                                                                                   \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \
@@ -521,33 +524,23 @@ int32_t mp_mh_create_pointed(const double* bounds, const double* obs_cov, const 
     return MP_OK;
 }
 
-int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
-                        int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out) {
-    if (!out) return mp_set_error(MP_ERR_INVALID_ARG, "out is null");
-    *out = nullptr;
+// chains of a registered generative function with EMPTY traces (the callers below fill them by generate or simulate)
+struct mh_cleanup { void operator()(mp_mh* p) const { (void)mp_mh_destroy(p); } };
+static int32_t fn_alloc(int32_t model_kind, const double* params, int32_t n_params, uint64_t n_chains, uint64_t seed, int32_t device, void* stream,
+                        std::unique_ptr<mp_mh, mh_cleanup>& out) {
     auto it = mh_fn_models().find(model_kind);
     if (it == mh_fn_models().end()) return mp_set_error(MP_ERR_UNSUPPORTED, "no generative function of this kind is registered (MP_REGISTER_MH_MODEL, mp_mh_models.h)");
     if (n_params < 0 || (n_params > 0 && !params)) return mp_set_error(MP_ERR_INVALID_ARG, "bad params");
-    if (n_constraints < 0 || (n_constraints > 0 && (!constraint_sites || !constraint_values))) return mp_set_error(MP_ERR_INVALID_ARG, "bad constraints");
     if (n_chains == 0 || n_chains > 0xFFFFFFFFull) return mp_set_error(MP_ERR_INVALID_ARG, "n_chains must be in [1, 2^32)");
     std::string err;
     std::shared_ptr<mh_fn_ops> ops = it->second(params, n_params, err);
     if (!ops) return mp_set_error(MP_ERR_INVALID_ARG, err);
-    mp_fn_consspec cs{};
-    for (int q = 0; q < n_constraints; ++q) {
-        const int s = constraint_sites[q];
-        if (s < 0 || s >= ops->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "constraint site out of range");
-        if (cs.bits & (1ull << s)) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
-        cs.bits |= 1ull << s;
-        cs.val[s] = constraint_values[q];
-    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         (void)hipGetLastError();
         return mp_set_error(MP_ERR_HIP, "no HIP device visible: the gfx950 path has no CPU fallback");
     }
-    struct Cleanup { void operator()(mp_mh* p) const { (void)mp_mh_destroy(p); } };
-    std::unique_ptr<mp_mh, Cleanup> h(new mp_mh());
+    std::unique_ptr<mp_mh, mh_cleanup> h(new mp_mh());
     h->kind = model_kind;
     h->fn = ops;
     h->n = n_chains; h->seed = seed; h->device = device;
@@ -559,12 +552,91 @@ int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_para
     MHCK(hipMalloc(&h->tmp, sizeof(double) * n_chains));
     MHCK(hipMalloc(&h->d_acc, sizeof(u64) * 2));
     MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64) * 2, h->stream));
-    const int32_t rc = ops->init(h.get(), cs);
+    MHCK(hipMemsetAsync(h->fpresent, 0, sizeof(uint32_t) * n_chains * (size_t)fn_words(ops->ns()), h->stream));
+    out = std::move(h);
+    return MP_OK;
+}
+static int32_t fn_shared_constraints(int ns, const int32_t* sites, const double* values, int32_t n_cons, mp_fn_consspec& cs) {
+    if (n_cons < 0 || (n_cons > 0 && (!sites || !values))) return mp_set_error(MP_ERR_INVALID_ARG, "bad constraints");
+    for (int q = 0; q < n_cons; ++q) {
+        const int s = sites[q];
+        if (s < 0 || s >= ns) return mp_set_error(MP_ERR_INVALID_ARG, "constraint site out of range");
+        if (cs.bits & (1ull << s)) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
+        cs.bits |= 1ull << s;
+        cs.val[s] = values[q];
+    }
+    return MP_OK;
+}
+// N x model.generate(args, constraints) at Philox step 0 (tests/mh.rs:91, importance.rs:18-20): the weights stay in h->tmp
+static int32_t fn_create_generate(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                                  int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, std::unique_ptr<mp_mh, mh_cleanup>& h) {
+    int32_t rc = fn_alloc(model_kind, params, n_params, n_chains, seed, device, stream, h);
     if (rc != MP_OK) return rc;
-    const int32_t rf = mh_finish(h.get(), nullptr);   // a constraint on a site the model never visits is the reference's panic
-    if (rf != MP_OK) return rf;
+    mp_fn_consspec cs{};
+    rc = fn_shared_constraints(h->fn->ns(), constraint_sites, constraint_values, n_constraints, cs);
+    if (rc != MP_OK) return rc;
+    rc = h->fn->generate(h.get(), cs, nullptr, nullptr, 0u);
+    if (rc != MP_OK) return rc;
+    return mh_finish(h.get(), nullptr);   // a constraint on a site the model never visits is the reference's panic
+}
+int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                        int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out) {
+    return mp_fn_generate_create(model_kind, params, n_params, constraint_sites, constraint_values, n_constraints, n_chains, seed, device, stream, nullptr, out);
+}
+int32_t mp_fn_generate_create(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                              int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, double* weights_out, mp_mh** out) {
+    if (!out) return mp_set_error(MP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    std::unique_ptr<mp_mh, mh_cleanup> h;
+    int32_t rc = fn_create_generate(model_kind, params, n_params, constraint_sites, constraint_values, n_constraints, n_chains, seed, device, stream, h);
+    if (rc != MP_OK) return rc;
+    if (weights_out) {
+        MHCK(hipMemcpyAsync(weights_out, h->tmp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+        MHCK(hipStreamSynchronize(h->stream));
+    }
     *out = h.release();
     return MP_OK;
+}
+int32_t mp_fn_simulate_create(int32_t model_kind, const double* params, int32_t n_params, uint64_t n_chains, uint64_t seed, int32_t device, void* stream,
+                              double* logjp_out, mp_mh** out) {
+    if (!out) return mp_set_error(MP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    std::unique_ptr<mp_mh, mh_cleanup> h;
+    int32_t rc = fn_alloc(model_kind, params, n_params, n_chains, seed, device, stream, h);
+    if (rc != MP_OK) return rc;
+    rc = h->fn->simulate(h.get(), 0u);
+    if (rc != MP_OK) return rc;
+    if (logjp_out) MHCK(hipMemcpyAsync(logjp_out, h->tmp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    MHCK(hipStreamSynchronize(h->stream));
+    *out = h.release();
+    return MP_OK;
+}
+// importance_sampling / importance_resampling over a registered generative function (importance.rs:12-50): N x generate, then the
+// canonical normalisation and the M categorical draws of the filters' importance path (mp_is_finish_device, mp_pf.hip)
+static int32_t fn_importance(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                             int32_t n_constraints, uint64_t num_samples, uint64_t num_ret_samples, uint64_t seed, int32_t device, double* log_ml_estimate,
+                             double* log_normalized_weights, uint64_t* resampled_indices, mp_mh** traces_out) {
+    if (traces_out) *traces_out = nullptr;
+    std::unique_ptr<mp_mh, mh_cleanup> h;
+    int32_t rc = fn_create_generate(model_kind, params, n_params, constraint_sites, constraint_values, n_constraints, num_samples, seed, device, nullptr, h);
+    if (rc != MP_OK) return rc;
+    rc = mp_is_finish_device(h->tmp, h->n, num_ret_samples, seed, device, h->stream, log_ml_estimate, log_normalized_weights, resampled_indices);
+    if (rc != MP_OK) return rc;
+    if (traces_out) *traces_out = h.release();
+    return MP_OK;
+}
+int32_t mp_fn_importance_sampling(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                                  int32_t n_constraints, uint64_t num_samples, uint64_t seed, int32_t device, double* log_ml_estimate,
+                                  double* log_normalized_weights, mp_mh** traces_out) {
+    return fn_importance(model_kind, params, n_params, constraint_sites, constraint_values, n_constraints, num_samples, 0, seed, device, log_ml_estimate,
+                         log_normalized_weights, nullptr, traces_out);
+}
+int32_t mp_fn_importance_resampling(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
+                                    int32_t n_constraints, uint64_t num_samples, uint64_t num_ret_samples, uint64_t seed, int32_t device,
+                                    double* log_ml_estimate, double* log_normalized_weights, uint64_t* resampled_indices, mp_mh** traces_out) {
+    if (num_ret_samples > 0 && !resampled_indices) return mp_set_error(MP_ERR_INVALID_ARG, "resampled_indices is null");
+    return fn_importance(model_kind, params, n_params, constraint_sites, constraint_values, n_constraints, num_samples, num_ret_samples, seed, device,
+                         log_ml_estimate, log_normalized_weights, resampled_indices, traces_out);
 }
 
 // Presence words across the C ABI: [chain][W] 32-bit words on the host side, W = (n_sites + 31) / 32 (one word up to 32 sites);
@@ -824,14 +896,17 @@ static int32_t gfi_constraints(mp_mh* h, const int32_t* sites, const double* val
     }
     return MP_OK;
 }
-static int32_t gfi_begin(mp_mh* h, uint32_t rng_step, uint32_t* step) {
+// A standalone GFI call in two halves: gfi_check validates the handle and prepares scratch WITHOUT touching the chains'
+// state; gfi_take_step, called once every argument has been accepted and the kernel is about to be launched, clears the counters and
+// takes the Philox step (the caller's, or the next MH iteration's, which the call then consumes) — a rejected call leaves `iters` alone.
+static int32_t gfi_check(mp_mh* h) {
     if (!h) return mp_set_error(MP_ERR_INVALID_ARG, "null handle");
     if (!h->fn) return mp_set_error(MP_ERR_UNSUPPORTED, "chains of a registered generative function only (mp_mh_create_fn)");
     MHCK(hipSetDevice(h->device));
-    int32_t rc = gfi_scratch(h);
-    if (rc != MP_OK) return rc;
+    return gfi_scratch(h);
+}
+static int32_t gfi_take_step(mp_mh* h, uint32_t rng_step, uint32_t* step) {
     MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64) * 2, h->stream));
-    // the Philox step of what this call draws: the caller's, or the next MH iteration's (which it then consumes)
     *step = rng_step ? rng_step : (uint32_t)(++h->iters);
     return MP_OK;
 }
@@ -855,14 +930,16 @@ static int32_t gfi_table(mp_mh* h, double* values_out, uint32_t* present_out) { 
 int32_t mp_fn_update(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int32_t* sites, const double* values, int32_t n_constraints,
                      const double* chain_values, const uint32_t* chain_present, double* weights_out, double* discard_values_out,
                      uint32_t* discard_present_out) {
-    uint32_t step = 0;
-    int32_t rc = gfi_begin(h, rng_step, &step);
+    int32_t rc = gfi_check(h);
     if (rc != MP_OK) return rc;
     if (argdiff != MP_ARGDIFF_NOCHANGE && argdiff != MP_ARGDIFF_UNKNOWN) return mp_set_error(MP_ERR_INVALID_ARG, "argdiff: MP_ARGDIFF_NOCHANGE or MP_ARGDIFF_UNKNOWN");
     gfi_cons c;
     rc = gfi_constraints(h, sites, values, n_constraints, chain_values, chain_present, c);
     if (rc != MP_OK) return rc;
     const bool want = discard_values_out || discard_present_out;
+    uint32_t step = 0;
+    rc = gfi_take_step(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
     rc = h->fn->update(h, c.cs, c.d_vals, c.d_present, argdiff == MP_ARGDIFF_UNKNOWN, step, want);
     if (rc != MP_OK) return rc;
     rc = gfi_weights(h, weights_out);
@@ -871,8 +948,7 @@ int32_t mp_fn_update(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int32_t
 }
 
 int32_t mp_fn_regenerate(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int32_t* mask_sites, int32_t n_mask, double* weights_out) {
-    uint32_t step = 0;
-    int32_t rc = gfi_begin(h, rng_step, &step);
+    int32_t rc = gfi_check(h);
     if (rc != MP_OK) return rc;
     if (argdiff != MP_ARGDIFF_NOCHANGE && argdiff != MP_ARGDIFF_UNKNOWN) return mp_set_error(MP_ERR_INVALID_ARG, "argdiff: MP_ARGDIFF_NOCHANGE or MP_ARGDIFF_UNKNOWN");
     if (n_mask < 0 || (n_mask > 0 && !mask_sites)) return mp_set_error(MP_ERR_INVALID_ARG, "bad mask");
@@ -881,6 +957,9 @@ int32_t mp_fn_regenerate(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int
         if (mask_sites[q] < 0 || mask_sites[q] >= h->fn->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "mask site out of range");
         bits |= 1ull << mask_sites[q];
     }
+    uint32_t step = 0;
+    rc = gfi_take_step(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
     rc = h->fn->regenerate(h, bits, argdiff == MP_ARGDIFF_UNKNOWN, step);
     if (rc != MP_OK) return rc;
     return gfi_weights(h, weights_out);
@@ -888,32 +967,60 @@ int32_t mp_fn_regenerate(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int
 
 int32_t mp_fn_assess(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, uint32_t rng_step, const int32_t* sites,
                      const double* values, int32_t n_constraints, const double* chain_values, const uint32_t* chain_present, double* weights_out) {
-    uint32_t step = 0;
-    int32_t rc = gfi_begin(h, rng_step, &step);
+    int32_t rc = gfi_check(h);
     if (rc != MP_OK) return rc;
     gfi_cons c;
     rc = gfi_constraints(h, sites, values, n_constraints, chain_values, chain_present, c);
     if (rc != MP_OK) return rc;
+    if (proposal_kind >= 0 && (n_proposal_args < 0 || (n_proposal_args > 0 && !proposal_args))) return mp_set_error(MP_ERR_INVALID_ARG, "bad proposal_args");
+    uint32_t step = 0;
+    rc = gfi_take_step(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
     if (proposal_kind < 0) rc = h->fn->assess(h, c.cs, c.d_vals, c.d_present, step);
-    else {
-        if (n_proposal_args < 0 || (n_proposal_args > 0 && !proposal_args)) return mp_set_error(MP_ERR_INVALID_ARG, "bad proposal_args");
-        rc = h->fn->assess_proposal(h, proposal_kind, proposal_args, n_proposal_args, c.cs, c.d_vals, c.d_present, step);
-    }
+    else rc = h->fn->assess_proposal(h, proposal_kind, proposal_args, n_proposal_args, c.cs, c.d_vals, c.d_present, step);
     if (rc != MP_OK) return rc;
     return gfi_weights(h, weights_out);
 }
 
 int32_t mp_fn_propose(mp_mh* h, int32_t proposal_kind, const double* proposal_args, int32_t n_proposal_args, uint32_t rng_step,
                       double* choice_values_out, uint32_t* choice_present_out, double* weights_out) {
-    uint32_t step = 0;
-    int32_t rc = gfi_begin(h, rng_step, &step);
+    int32_t rc = gfi_check(h);
     if (rc != MP_OK) return rc;
     if (n_proposal_args < 0 || (n_proposal_args > 0 && !proposal_args)) return mp_set_error(MP_ERR_INVALID_ARG, "bad proposal_args");
+    uint32_t step = 0;
+    rc = gfi_take_step(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
     rc = h->fn->propose(h, proposal_kind, proposal_args, n_proposal_args, step);
     if (rc != MP_OK) return rc;
     rc = gfi_weights(h, weights_out);
     if (rc != MP_OK) return rc;
     return gfi_table(h, choice_values_out, choice_present_out);
+}
+
+int32_t mp_fn_generate(mp_mh* h, uint32_t rng_step, const int32_t* sites, const double* values, int32_t n_constraints, const double* chain_values,
+                       const uint32_t* chain_present, double* weights_out) {
+    int32_t rc = gfi_check(h);
+    if (rc != MP_OK) return rc;
+    gfi_cons c;
+    rc = gfi_constraints(h, sites, values, n_constraints, chain_values, chain_present, c);
+    if (rc != MP_OK) return rc;
+    uint32_t step = 0;
+    rc = gfi_take_step(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
+    rc = h->fn->generate(h, c.cs, c.d_vals, c.d_present, step);
+    if (rc != MP_OK) return rc;
+    return gfi_weights(h, weights_out);
+}
+
+int32_t mp_fn_simulate(mp_mh* h, uint32_t rng_step, double* logjp_out) {
+    int32_t rc = gfi_check(h);
+    if (rc != MP_OK) return rc;
+    uint32_t step = 0;
+    rc = gfi_take_step(h, rng_step, &step);
+    if (rc != MP_OK) return rc;
+    rc = h->fn->simulate(h, step);
+    if (rc != MP_OK) return rc;
+    return gfi_weights(h, logjp_out);
 }
 
 int32_t mp_mh_iterations(mp_mh* h, uint64_t* out) {

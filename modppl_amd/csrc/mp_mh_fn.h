@@ -85,28 +85,6 @@ __device__ __forceinline__ void fn_count(u64 acc, bool panic, u64* __restrict__ 
     }
 }
 
-// model.generate(args, constraints) per chain (tests/mh.rs:91), Philox step 0
-template <class M>
-__global__ __launch_bounds__(MH_THREADS) void k_fn_init(u64 n, uint32_t k0, uint32_t k1, M model, mp_fn_consspec cs, double* __restrict__ vals,
-                                                        uint32_t* __restrict__ present, u64* __restrict__ totals) {
-    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
-    bool panic = false;
-    if (i < n) {
-        mp_stream s;
-        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = 0;
-        mp_fn_trace<M::NS> c;
-        c.present = (mp_fn_bits_t<M::NS>)cs.bits;
-#pragma unroll
-        for (int k = 0; k < M::NS; ++k) { c.val[k] = cs.val[k]; c.lp[k] = 0.; }
-        mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
-        model(g);
-        g.finish();
-        panic = g.panic;
-        fn_store<M>(g.tr, i, n, vals, present);
-    }
-    fn_count(0, panic, totals);
-}
-
 template <class M>
 __global__ __launch_bounds__(MH_THREADS) void k_fn_logjp(u64 n, M model, const double* __restrict__ vals, const uint32_t* __restrict__ present,
                                                          double* __restrict__ out) {
@@ -233,7 +211,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_update(u64 n, uint32_t k0, ui
         model(g);
         g.finish();
         panic = g.panic;
-        fn_store<M>(g.tr, i, n, vals, present);
+        if (!panic) fn_store<M>(g.tr, i, n, vals, present);   // (a chain that reached the reference's panic keeps the trace it had: ADVICE round 4)
         w_out[i] = g.weight;
         if (dvals) fn_emit<M::NS>(cur, g.discarded, i, n, dvals, dpresent);   // the discard: the previous values of what was replaced or collected
     }
@@ -257,7 +235,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_regenerate(u64 n, uint32_t k0
         model(g);
         g.finish();
         panic = g.panic;
-        fn_store<M>(g.tr, i, n, vals, present);
+        if (!panic) fn_store<M>(g.tr, i, n, vals, present);
         w_out[i] = g.weight;
     }
     fn_count(0, panic, totals);
@@ -281,6 +259,42 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_assess(u64 n, uint32_t k0, ui
         w_out[i] = g.weight;
     }
     fn_count(0, panic, totals);
+}
+// (trace, weight) = model.generate(args, constraints)   gfi.rs:53-55, dyngenfn.rs:513-521: every chain's trace is REPLACED by the new one
+// (constrained sites take their constraint and score into the weight, the others are drawn from their priors: the internal proposal of
+// importance_sampling, importance.rs:18-20)
+template <class M>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_generate(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, mp_fn_consspec cs,
+                                                            const double* __restrict__ cvals, const uint32_t* __restrict__ cpresent, double* __restrict__ vals,
+                                                            uint32_t* __restrict__ present, double* __restrict__ w_out, u64* __restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    bool panic = false;
+    if (i < n) {
+        mp_stream s;
+        s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
+        mp_fn_trace<M::NS> c;
+        fn_cons<M::NS>(cs, cvals, cpresent, i, n, c);
+        mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+        model(g);
+        g.finish();
+        panic = g.panic;
+        if (!panic) fn_store<M>(g.tr, i, n, vals, present);   // (a chain that reached the reference's panic keeps the trace it had)
+        w_out[i] = g.weight;
+    }
+    fn_count(0, panic, totals);
+}
+// trace = model.simulate(args)   gfi.rs:51, dyngenfn.rs:503-511: every site drawn, the observed ones too; out: trace.logjp
+template <class M>
+__global__ __launch_bounds__(MH_THREADS) void k_fn_simulate(u64 n, uint32_t k0, uint32_t k1, uint32_t step, M model, double* __restrict__ vals,
+                                                            uint32_t* __restrict__ present, double* __restrict__ w_out) {
+    const u64 i = (u64)blockIdx.x * MH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    mp_stream s;
+    s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
+    mp_fn_handler<M::NS, MP_FN_SIMULATE> g(s, MP_DOM_MODEL, nullptr, nullptr);
+    model(g);
+    fn_store<M>(g.tr, i, n, vals, present);
+    w_out[i] = g.weight;
 }
 // (choices, weight) = proposal.propose((trace, args)) = simulate -> (data, logjp)   gfi.rs:78-83, mh.rs:17-19
 template <class M, class P>
@@ -327,7 +341,6 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_assess_proposal(u64 n, uint32
 struct mh_fn_ops {
     virtual ~mh_fn_ops() {}
     virtual int ns() const = 0;
-    virtual int32_t init(mp_mh* h, const mp_fn_consspec& cs) = 0;
     virtual int32_t regen(mp_mh* h, const mp_fn_maskspec& m, int n_iters) = 0;
     virtual int32_t mh(mp_mh* h, int proposal_kind, const double* args, int n_args, int n_iters) = 0;
     virtual int32_t logjp(mp_mh* h) = 0;
@@ -335,6 +348,8 @@ struct mh_fn_ops {
     virtual int32_t update(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, int unknown, uint32_t step, bool want_discard) = 0;
     virtual int32_t regenerate(mp_mh* h, uint64_t mask, int unknown, uint32_t step) = 0;
     virtual int32_t assess(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, uint32_t step) = 0;
+    virtual int32_t generate(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, uint32_t step) = 0;
+    virtual int32_t simulate(mp_mh* h, uint32_t step) = 0;
     virtual int32_t propose(mp_mh* h, int proposal_kind, const double* args, int n_args, uint32_t step) = 0;
     virtual int32_t assess_proposal(mp_mh* h, int proposal_kind, const double* args, int n_args, const mp_fn_consspec& cs, const double* d_cvals,
                                     const uint32_t* d_cpresent, uint32_t step) = 0;
@@ -356,12 +371,6 @@ template <class M>
 struct mh_fn_ops_t : mh_fn_ops {
     M model;
     int ns() const override { return M::NS; }
-    int32_t init(mp_mh* h, const mp_fn_consspec& cs) override {
-        hipLaunchKernelGGL(k_fn_init<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), model, cs,
-                           h->fvals, h->fpresent, h->d_acc);
-        MHCK(hipGetLastError());
-        return MP_OK;
-    }
     int32_t regen(mp_mh* h, const mp_fn_maskspec& m, int n_iters) override {
         hipLaunchKernelGGL(k_fn_regen<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
                            (uint32_t)(h->iters + 1), n_iters, model, m, h->fvals, h->fpresent, h->d_acc);
@@ -390,6 +399,18 @@ struct mh_fn_ops_t : mh_fn_ops {
     int32_t assess(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, uint32_t step) override {
         hipLaunchKernelGGL(k_fn_assess<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), step, model, cs,
                            d_cvals, d_cpresent, h->tmp, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    }
+    int32_t generate(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, uint32_t step) override {
+        hipLaunchKernelGGL(k_fn_generate<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), step, model, cs,
+                           d_cvals, d_cpresent, h->fvals, h->fpresent, h->tmp, h->d_acc);
+        MHCK(hipGetLastError());
+        return MP_OK;
+    }
+    int32_t simulate(mp_mh* h, uint32_t step) override {
+        hipLaunchKernelGGL(k_fn_simulate<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), step, model,
+                           h->fvals, h->fpresent, h->tmp);
         MHCK(hipGetLastError());
         return MP_OK;
     }

@@ -2273,3 +2273,68 @@ int32_t mp_debug_stamps(unsigned long long* host_out /* [KERNELS][MAX_WG][SLOTS]
 #endif
 
 }  // extern "C"
+
+// The tail of importance_sampling / importance_resampling (importance.rs:21-27, 44-47) over ANY device array of log-weights — for
+// callers inside the library whose samples are not an Unfold model's (mp_mh.hip: importance sampling over a registered generative
+// function).  The same canonical normalisation and the same M categorical draws (Philox domain IS) as importance_run above: level 0 by
+// k_normalize_tiles, level 1 by k_finalize_tiles (mode 2: L and log_ml = L - ln N), lnw = lw - L, draws by k_resample_gather<0>.
+int32_t mp_is_finish_device(const double* d_logw, uint64_t n, uint64_t num_ret, uint64_t seed, int32_t device, void* stream, double* log_ml_estimate,
+                            double* log_normalized_weights, uint64_t* resampled_indices) {
+    if (!d_logw || n == 0 || n > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "importance sampling: num_samples must be in [1, 2^32)");
+    if (num_ret > 0xFFFFFFFFull) return mp_fail(MP_ERR_INVALID_ARG, "num_ret_samples must fit u32");
+    const int nt = (int)((n + TILE - 1) / TILE);
+    if (nt > MAX_TILES) return mp_fail(MP_ERR_UNSUPPORTED, "at most 2^24 samples in this build (tile table in LDS)");
+    HIPCK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const int S = 62 - ceil_log2_u64(n);
+    struct Bufs {
+        mp_cx* cx = nullptr; unsigned short* guide = nullptr; u64* tiles = nullptr; mp_dev_scalars* scal = nullptr; double* tmp = nullptr; uint32_t* idx = nullptr;
+        ~Bufs() { (void)hipFree(cx); (void)hipFree(guide); (void)hipFree(tiles); (void)hipFree(scal); (void)hipFree(tmp); (void)hipFree(idx); }
+    } b;
+    HIPCK(hipMalloc(&b.cx, sizeof(mp_cx) * (size_t)nt * TILE));
+    HIPCK(hipMalloc(&b.guide, sizeof(unsigned short) * (size_t)nt * GUIDE_N));
+    HIPCK(hipMalloc(&b.tiles, sizeof(u64) * 3 * (size_t)nt));
+    HIPCK(hipMalloc(&b.scal, sizeof(mp_dev_scalars)));
+    HIPCK(hipMemsetAsync(b.scal, 0, sizeof(mp_dev_scalars), st));
+    double* tile_m = reinterpret_cast<double*>(b.tiles);
+    u64 *tile_W = b.tiles + nt, *tile_W2 = b.tiles + 2 * (size_t)nt;
+    const size_t lds = table_lds(nt, K3_THREADS);
+    if (lds > 48 * 1024) {
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_finalize_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    mp_tab tab{};
+    tab.S = S;
+    hipLaunchKernelGGL(k_normalize_tiles, dim3(nt), dim3(TILE_THREADS), 0, st, d_logw, d_logw /* x0: the rows' second halves are not read here */, 1, (u64)n, b.cx,
+                       b.guide, tile_m, tile_W, tile_W2, tab);
+    hipLaunchKernelGGL(k_finalize_tiles, dim3(1), dim3(K3_THREADS), lds, st, tile_m, tile_W, tile_W2, nt, S, (u64)n, 2, b.scal);
+    int32_t rc = check_launch("importance sampling: normalisation");
+    if (rc != MP_OK) return rc;
+    mp_dev_scalars hs;
+    HIPCK(hipMemcpyAsync(&hs, b.scal, sizeof(hs), hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if (hs.degenerate) return mp_fail(MP_ERR_DEGENERATE, "all log-weights are -inf: normalized weights are NaN (categorical.rs:23 assert in the reference)");
+    if (log_ml_estimate) *log_ml_estimate = hs.lml_fresh;
+    if (log_normalized_weights) {
+        HIPCK(hipMalloc(&b.tmp, sizeof(double) * n));
+        hipLaunchKernelGGL(k_sub_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_logw, &b.scal->L, (u64)n, b.tmp);
+        rc = check_launch("k_sub_scalar");
+        if (rc != MP_OK) return rc;
+        HIPCK(hipMemcpyAsync(log_normalized_weights, b.tmp, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+    }
+    if (resampled_indices && num_ret > 0) {
+        HIPCK(hipMalloc(&b.idx, sizeof(uint32_t) * num_ret));
+        const int grid = (int)std::min<u64>((num_ret + KG_THREADS * KG_ITEMS - 1) / (KG_THREADS * KG_ITEMS), (u64)K3_MAX_BLOCKS);
+        hipLaunchKernelGGL(k_resample_gather<0>, dim3(grid), dim3(KG_THREADS), lds, st, (u64)n, (u64)num_ret, (u64)n, (u64)0, (uint32_t)MP_DOM_IS, (uint32_t)seed,
+                           (uint32_t)(seed >> 32), 0u, S, 1, b.cx, b.guide, tile_m, tile_W, tile_W2, nt, (const double*)nullptr, (double*)nullptr, b.idx,
+                           (double*)nullptr, (mp_dev_scalars*)nullptr);
+        rc = check_launch("k_resample_gather(IS)");
+        if (rc != MP_OK) return rc;
+        std::vector<uint32_t> idx(num_ret);
+        HIPCK(hipMemcpyAsync(idx.data(), b.idx, sizeof(uint32_t) * num_ret, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        for (uint64_t j = 0; j < num_ret; ++j) resampled_indices[j] = idx[j];
+    }
+    return MP_OK;
+}

@@ -346,6 +346,46 @@ class HierarchicalChains:
             pass
 
 
+def _fn_constraints(constraints):
+    sites = np.array(sorted(constraints), dtype=np.int32)
+    vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
+    return sites, vals
+
+
+def fn_importance_sampling(model_kind, params, constraints, num_samples, seed, *, device=0, traces=True):
+    """`importance_sampling(model, model_args, constraints, num_samples)` (modppl/src/inference/importance.rs:12-28) for a REGISTERED
+    generative function (any model written for csrc/mp_genfn.h — the reference's call is generic over `impl GenFn`, and its third test
+    runs it on `hierarchical_model`, tests/importance.rs:89-139).  -> (traces: FunctionChains whose chain i is sample i (or None),
+    log_normalized_weights [num_samples], log_ml_estimate)."""
+    return _fn_importance(model_kind, params, constraints, num_samples, 0, seed, device, traces)[:3]
+
+
+def fn_importance_resampling(model_kind, params, constraints, num_samples, num_ret_samples, seed, *, device=0, traces=True):
+    """`importance_resampling(...)` (importance.rs:37-50) for a registered generative function.
+    -> (traces, resampled_indices [num_ret_samples], log_ml_estimate)   — the reference's return triple."""
+    tr, lnw, lml, idx = _fn_importance(model_kind, params, constraints, num_samples, num_ret_samples, seed, device, traces)
+    return tr, idx, lml
+
+
+def _fn_importance(model_kind, params, constraints, num_samples, num_ret, seed, device, traces):
+    L = capi.load()
+    params = np.ascontiguousarray(params, dtype=np.float64).ravel()
+    sites, vals = _fn_constraints(constraints)
+    lnw = np.empty(int(num_samples))
+    lml = C.c_double()
+    idx = np.empty(max(int(num_ret), 1), dtype=np.uint64)
+    h = C.c_void_p()
+    common = (int(model_kind), _dptr(params) if params.size else None, int(params.size), sites.ctypes.data_as(C.POINTER(C.c_int32)) if sites.size else None,
+              _dptr(vals) if sites.size else None, int(sites.size), int(num_samples))
+    if num_ret:
+        capi.check(L.mp_fn_importance_resampling(*common, int(num_ret), int(seed), int(device), C.byref(lml), _dptr(lnw),
+                                                 idx.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(h) if traces else None))
+    else:
+        capi.check(L.mp_fn_importance_sampling(*common, int(seed), int(device), C.byref(lml), _dptr(lnw), C.byref(h) if traces else None))
+    tr = FunctionChains(model_kind, params, {}, num_samples, seed, _handle=h) if traces else None
+    return tr, lnw, lml.value, idx[:int(num_ret)]
+
+
 class FunctionChains:
     """N independent MH chains over a REGISTERED generative function (csrc/mp_mh_models.h: a functor over the static
     handler of csrc/mp_genfn.h, `MP_REGISTER_MH_MODEL`), the counterpart of calling the reference's `mh` / `regen_mh`
@@ -353,20 +393,45 @@ class FunctionChains:
 
         constraints = {site: value}: creation runs model.generate(params, constraints) per chain."""
 
-    def __init__(self, model_kind, params, constraints, num_chains, seed, *, device=0, stream=None):
+    def __init__(self, model_kind, params, constraints, num_chains, seed, *, device=0, stream=None, simulate=False, _handle=None):
+        """constraints = {site: value}: the chains start as `model.generate(params, constraints)` (gfi.rs:53-55; `initial_weights` keeps
+        that call's weights); simulate=True: as `model.simulate(params)` instead (gfi.rs:51; `initial_weights` = each trace's logjp)."""
         self._L = capi.load()
-        params = np.ascontiguousarray(params, dtype=np.float64).ravel()
-        sites = np.array(sorted(constraints), dtype=np.int32)
-        vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
         self.num_chains = int(num_chains)
-        h = C.c_void_p()
-        capi.check(self._L.mp_mh_create_fn(int(model_kind), _dptr(params) if params.size else None, int(params.size),
-                                           sites.ctypes.data_as(C.POINTER(C.c_int32)) if sites.size else None, _dptr(vals) if sites.size else None,
-                                           int(sites.size), self.num_chains, int(seed), int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
-        self._h = h
+        self.initial_weights = None
+        if _handle is not None:   # (a handle the library returned: the traces of mp_fn_importance_*)
+            self._h = _handle
+        else:
+            params = np.ascontiguousarray(params, dtype=np.float64).ravel()
+            w = np.empty(self.num_chains)
+            h = C.c_void_p()
+            if simulate:
+                capi.check(self._L.mp_fn_simulate_create(int(model_kind), _dptr(params) if params.size else None, int(params.size), self.num_chains, int(seed),
+                                                         int(device), C.c_void_p(stream) if stream else None, _dptr(w), C.byref(h)))
+            else:
+                sites, vals = _fn_constraints(constraints)
+                capi.check(self._L.mp_fn_generate_create(int(model_kind), _dptr(params) if params.size else None, int(params.size),
+                                                         sites.ctypes.data_as(C.POINTER(C.c_int32)) if sites.size else None, _dptr(vals) if sites.size else None,
+                                                         int(sites.size), self.num_chains, int(seed), int(device), C.c_void_p(stream) if stream else None,
+                                                         _dptr(w), C.byref(h)))
+            self._h = h
+            self.initial_weights = w
         ns = C.c_int32()
         capi.check(self._L.mp_mh_n_sites(self._h, C.byref(ns)))
         self.num_sites = ns.value
+
+    def generate(self, constraints, rng_step=0):
+        """(trace, weight) = model.generate(args, constraints) on every chain (gfi.rs:53-55): the chains' traces are replaced; -> weights"""
+        keep, c = self._constraints(constraints)
+        w = np.empty(self.num_chains)
+        capi.check(self._L.mp_fn_generate(self._h, int(rng_step), c[0], c[1], c[2], c[3], c[4], _dptr(w)))
+        return w
+
+    def simulate(self, rng_step=0):
+        """trace = model.simulate(args) on every chain (gfi.rs:51): every site drawn; -> each new trace's logjp"""
+        w = np.empty(self.num_chains)
+        capi.check(self._L.mp_fn_simulate(self._h, int(rng_step), _dptr(w)))
+        return w
 
     def mh(self, proposal_kind, proposal_args=(), n_iters=1):
         a = np.ascontiguousarray(proposal_args, dtype=np.float64).ravel()

@@ -157,6 +157,21 @@ extern "C" {
                         values: *const f64, n_constraints: i32, chain_values: *const f64, chain_present: *const u32, weights_out: *mut f64) -> i32;
     pub fn mp_fn_propose(h: *mut mp_mh, proposal_kind: i32, proposal_args: *const f64, n_proposal_args: i32, rng_step: u32,
                          choice_values_out: *mut f64, choice_present_out: *mut u32, weights_out: *mut f64) -> i32;
+    pub fn mp_fn_generate(h: *mut mp_mh, rng_step: u32, sites: *const i32, values: *const f64, n_constraints: i32, chain_values: *const f64,
+                          chain_present: *const u32, weights_out: *mut f64) -> i32;
+    pub fn mp_fn_simulate(h: *mut mp_mh, rng_step: u32, logjp_out: *mut f64) -> i32;
+    pub fn mp_fn_generate_create(model_kind: i32, params: *const f64, n_params: i32, constraint_sites: *const i32, constraint_values: *const f64,
+                                 n_constraints: i32, n_chains: u64, seed: u64, device: i32, stream: *mut c_void, weights_out: *mut f64,
+                                 out: *mut *mut mp_mh) -> i32;
+    pub fn mp_fn_simulate_create(model_kind: i32, params: *const f64, n_params: i32, n_chains: u64, seed: u64, device: i32, stream: *mut c_void,
+                                 logjp_out: *mut f64, out: *mut *mut mp_mh) -> i32;
+    // importance sampling over a registered generative function (importance.rs:12-50)
+    pub fn mp_fn_importance_sampling(model_kind: i32, params: *const f64, n_params: i32, constraint_sites: *const i32, constraint_values: *const f64,
+                                     n_constraints: i32, num_samples: u64, seed: u64, device: i32, log_ml_estimate: *mut f64,
+                                     log_normalized_weights: *mut f64, traces_out: *mut *mut mp_mh) -> i32;
+    pub fn mp_fn_importance_resampling(model_kind: i32, params: *const f64, n_params: i32, constraint_sites: *const i32, constraint_values: *const f64,
+                                       n_constraints: i32, num_samples: u64, num_ret_samples: u64, seed: u64, device: i32, log_ml_estimate: *mut f64,
+                                       log_normalized_weights: *mut f64, resampled_indices: *mut u64, traces_out: *mut *mut mp_mh) -> i32;
     pub fn mp_mh_iterations(h: *mut mp_mh, out: *mut u64) -> i32;
     pub fn mp_mh_destroy(h: *mut mp_mh) -> i32;
 }

@@ -185,6 +185,32 @@ impl Drop for HierarchicalChains {
 }
 
 /// N chains of a REGISTERED generative function (csrc/mp_mh_models.h: `MP_REGISTER_MH_MODEL` / `MP_REGISTER_MH_PROPOSAL`) —
+/// `importance_sampling(model, model_args, constraints, num_samples)` (importance.rs:12-28) for a registered generative function:
+/// -> (traces: chain i = sample i, log_normalized_weights, log_ml_estimate)
+pub fn fn_importance_sampling(model_kind: i32, params: &[f64], constraints: &[(i32, f64)], num_samples: usize, seed: u64) -> (FunctionChains, Vec<f64>, f64) {
+    let sites: Vec<i32> = constraints.iter().map(|c| c.0).collect();
+    let vals: Vec<f64> = constraints.iter().map(|c| c.1).collect();
+    let (mut h, mut lml, mut lnw) = (ptr::null_mut(), 0.0f64, vec![0.0; num_samples]);
+    check(unsafe {
+        sys::mp_fn_importance_sampling(model_kind, params.as_ptr(), params.len() as i32, sites.as_ptr(), vals.as_ptr(), sites.len() as i32, num_samples as u64, seed, 0,
+                                       &mut lml, lnw.as_mut_ptr(), &mut h)
+    });
+    (FunctionChains::adopt(h, num_samples), lnw, lml)
+}
+/// `importance_resampling(model, model_args, constraints, num_samples, num_ret_samples)` (importance.rs:37-50)
+/// -> (traces, resampled_indices, log_ml_estimate)
+pub fn fn_importance_resampling(model_kind: i32, params: &[f64], constraints: &[(i32, f64)], num_samples: usize, num_ret_samples: usize,
+                                seed: u64) -> (FunctionChains, Vec<usize>, f64) {
+    let sites: Vec<i32> = constraints.iter().map(|c| c.0).collect();
+    let vals: Vec<f64> = constraints.iter().map(|c| c.1).collect();
+    let (mut h, mut lml, mut idx) = (ptr::null_mut(), 0.0f64, vec![0u64; num_ret_samples]);
+    check(unsafe {
+        sys::mp_fn_importance_resampling(model_kind, params.as_ptr(), params.len() as i32, sites.as_ptr(), vals.as_ptr(), sites.len() as i32, num_samples as u64,
+                                         num_ret_samples as u64, seed, 0, &mut lml, ptr::null_mut(), idx.as_mut_ptr(), &mut h)
+    });
+    (FunctionChains::adopt(h, num_samples), idx.into_iter().map(|i| i as usize).collect(), lml)
+}
+
 /// what `mh(&model, trace, &proposal, args)` / `regen_mh(&model, trace, &mask)` (mh.rs:9-75) become for a model and proposal
 /// of one's own: sites are integer ids, `constraints` the `(site, value)` pairs of the initial `model.generate`.
 pub struct FunctionChains { h: *mut sys::mp_mh, n_chains: usize, n_sites: usize }
@@ -201,6 +227,44 @@ impl FunctionChains {
         let mut ns = 0i32;
         check(unsafe { sys::mp_mh_n_sites(h, &mut ns) });
         FunctionChains { h, n_chains, n_sites: ns as usize }
+    }
+    /// `model.simulate(args)` per chain (gfi.rs:51) -> (chains, each trace's logjp)
+    pub fn simulate_new(model_kind: i32, params: &[f64], n_chains: usize, seed: u64) -> (Self, Vec<f64>) {
+        let mut h = ptr::null_mut();
+        let mut lj = vec![0.0; n_chains];
+        check(unsafe { sys::mp_fn_simulate_create(model_kind, params.as_ptr(), params.len() as i32, n_chains as u64, seed, 0, ptr::null_mut(), lj.as_mut_ptr(), &mut h) });
+        (Self::adopt(h, n_chains), lj)
+    }
+    /// `model.generate(args, constraints)` per chain (gfi.rs:53-55) -> (chains, weights)
+    pub fn generate_new(model_kind: i32, params: &[f64], constraints: &[(i32, f64)], n_chains: usize, seed: u64) -> (Self, Vec<f64>) {
+        let sites: Vec<i32> = constraints.iter().map(|c| c.0).collect();
+        let vals: Vec<f64> = constraints.iter().map(|c| c.1).collect();
+        let mut h = ptr::null_mut();
+        let mut w = vec![0.0; n_chains];
+        check(unsafe {
+            sys::mp_fn_generate_create(model_kind, params.as_ptr(), params.len() as i32, sites.as_ptr(), vals.as_ptr(), sites.len() as i32, n_chains as u64, seed, 0,
+                                       ptr::null_mut(), w.as_mut_ptr(), &mut h)
+        });
+        (Self::adopt(h, n_chains), w)
+    }
+    fn adopt(h: *mut sys::mp_mh, n_chains: usize) -> Self {
+        let mut ns = 0i32;
+        check(unsafe { sys::mp_mh_n_sites(h, &mut ns) });
+        FunctionChains { h, n_chains, n_sites: ns as usize }
+    }
+    /// `(trace, weight) = model.generate(args, constraints)` on every chain, shared constraints; the traces are replaced -> weights
+    pub fn generate(&mut self, constraints: &[(i32, f64)], rng_step: u32) -> Vec<f64> {
+        let sites: Vec<i32> = constraints.iter().map(|c| c.0).collect();
+        let vals: Vec<f64> = constraints.iter().map(|c| c.1).collect();
+        let mut w = vec![0.0; self.n_chains];
+        check(unsafe { sys::mp_fn_generate(self.h, rng_step, sites.as_ptr(), vals.as_ptr(), sites.len() as i32, ptr::null(), ptr::null(), w.as_mut_ptr()) });
+        w
+    }
+    /// `trace = model.simulate(args)` on every chain; the traces are replaced -> each new trace's logjp
+    pub fn simulate(&mut self, rng_step: u32) -> Vec<f64> {
+        let mut lj = vec![0.0; self.n_chains];
+        check(unsafe { sys::mp_fn_simulate(self.h, rng_step, lj.as_mut_ptr()) });
+        lj
     }
     /// `mh(model, trace, proposal, args)` x n_iters per chain -> accepted moves
     pub fn mh(&mut self, proposal_kind: i32, args: &[f64], n_iters: i32) -> u64 {

@@ -636,6 +636,53 @@ int32_t oracle_mhfn_propose(oracle_mhfn* h, int32_t proposal_kind, const double*
         }
     })
 }
+// (trace, weight) = model.generate(args, constraints) / trace = model.simulate(args) on every chain (gfi.rs:51-55): the checker of
+// mp_fn_generate / mp_fn_simulate; the traces are replaced
+int32_t oracle_mhfn_generate(oracle_mhfn* h, uint32_t rng_step, const int32_t* sites, const double* vals, int32_t n_cons, const double* chain_values,
+                             const uint64_t* chain_present, double* weights) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        const uint32_t step = mhfn_step(h, rng_step);
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = step;
+            auto [tr, w] = h->m->model().generate(r, 0, mhfn_chain_constraints(h, sites, vals, n_cons, chain_values, chain_present, i));
+            h->traces[i] = std::move(tr);
+            if (weights) weights[i] = w;
+        }
+    })
+}
+int32_t oracle_mhfn_simulate(oracle_mhfn* h, uint32_t rng_step, double* logjp) {
+    GUARD({
+        oracle_pf::Scope scope(h->canonical);
+        const uint32_t step = mhfn_step(h, rng_step);
+        for (size_t i = 0; i < h->traces.size(); ++i) {
+            Rng r; r.seed = h->seed; r.slot = (uint32_t)i; r.step = step;
+            h->traces[i] = h->m->model().simulate(r, 0);
+            if (logjp) logjp[i] = h->traces[i].logjp;
+        }
+    })
+}
+// importance_sampling / importance_resampling (importance.rs:12-50) over a registered functor model through the GENERIC functions of
+// inference.hpp (the ones the Unfold checker uses): the N traces come back as a chain handle
+int32_t oracle_mhfn_importance(int32_t kind, const double* params, int32_t n_params, const int32_t* cons_sites, const double* cons_vals, int32_t n_cons,
+                               uint64_t num_samples, uint64_t num_ret, uint64_t seed, int32_t canon, double* log_ml, double* lnw, uint64_t* idx,
+                               oracle_mhfn** traces_out) {
+    GUARD({
+        auto it = mhfn_models().find(kind);
+        if (it == mhfn_models().end()) throw Panic("no MH functor model of this kind");
+        auto h = std::make_unique<oracle_mhfn>();
+        h->seed = seed; h->canonical = canon != 0;
+        oracle_pf::Scope scope(h->canonical);
+        h->m = it->second(params, n_params);
+        auto res = importance_resampling<int, DynTrie, mp_fn_ret>(seed, h->m->model(), 0, h->m->constraints(cons_sites, cons_vals, n_cons), (uint32_t)num_samples,
+                                                                  (uint32_t)num_ret, h->canonical);
+        if (log_ml) *log_ml = res.log_ml_estimate;
+        if (lnw) for (size_t i = 0; i < res.log_normalized_weights.size(); ++i) lnw[i] = res.log_normalized_weights[i];
+        if (idx) for (size_t j = 0; j < res.resampled_indices.size(); ++j) idx[j] = (uint64_t)res.resampled_indices[j];
+        h->traces = std::move(res.traces);
+        if (traces_out) *traces_out = h.release();
+    })
+}
 int32_t oracle_mhfn_read_trace(oracle_mhfn* h, double* values, uint64_t* present) {
     GUARD({
         const int ns = h->m->ns();

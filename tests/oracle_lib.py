@@ -572,6 +572,38 @@ class OracleFunctionChains:
                                             cp.ctypes.data_as(C.POINTER(C.c_uint64)), dptr(w)))
         return (cv, cp), w
 
+    def generate(self, constraints, rng_step=0):
+        keep, c = self._cons(constraints)
+        w = np.empty(self.n)
+        self._ck(self.L.oracle_mhfn_generate(self.h, C.c_uint32(rng_step), c[0], c[1], c[2], c[3], c[4], dptr(w)))
+        return w
+
+    def simulate(self, rng_step=0):
+        w = np.empty(self.n)
+        self._ck(self.L.oracle_mhfn_simulate(self.h, C.c_uint32(rng_step), dptr(w)))
+        return w
+
+    @classmethod
+    def importance(cls, kind, params, constraints, num_samples, num_ret, seed, canonical=True):
+        """importance_resampling(model, args, constraints, N, M) (importance.rs:37-50) through the checker's generic functions
+        -> (traces: OracleFunctionChains, log_normalized_weights, log_ml_estimate, resampled_indices)"""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.n = int(num_samples)
+        params = np.ascontiguousarray(params, dtype=np.float64).ravel()
+        sites = np.array(sorted(constraints), dtype=np.int32)
+        vals = np.array([constraints[int(k)] for k in sites], dtype=np.float64)
+        lnw, lml, idx = np.empty(self.n), C.c_double(), np.empty(max(int(num_ret), 1), dtype=np.uint64)
+        h = C.c_void_p()
+        self._ck(self.L.oracle_mhfn_importance(int(kind), dptr(params), int(params.size), sites.ctypes.data_as(C.POINTER(C.c_int32)), dptr(vals), int(sites.size),
+                                               C.c_uint64(num_samples), C.c_uint64(num_ret), C.c_uint64(seed), int(canonical), C.byref(lml), dptr(lnw),
+                                               idx.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(h)))
+        self.h = h
+        ns = C.c_int32()
+        self._ck(self.L.oracle_mhfn_n_sites(self.h, C.byref(ns)))
+        self.num_sites = ns.value
+        return self, lnw, lml.value, idx[:int(num_ret)]
+
     def logjp(self):
         out = np.empty(self.n)
         self._ck(self.L.oracle_mhfn_read_logjp(self.h, dptr(out)))

@@ -107,3 +107,30 @@ def test_product_handlers_on_the_host_update_across_a_structure_change(argdiff):
         dv, dp = dy.trace()
         assert np.array_equal(sp, dp) and np.array_equal(sv, dv)
         assert st.panics == 0
+
+
+def test_generate_simulate_and_importance_over_a_functor_model():
+    """The checker's entry points behind mp_fn_generate / mp_fn_simulate / mp_fn_importance_* (gfi.rs:51-55, importance.rs:12-50): assess is
+    generate's weight (gfi.rs:85-90), a generate whose constraints are every choice of a simulated trace returns that trace and its
+    logjp, and the generic importance_resampling over the hierarchical functor gives the same indices under the literal arithmetic
+    (libm, sequential sums, linear-scan categorical) as under the canonical one the GPU evaluates."""
+    xs = np.arange(-5.0, 6.0)                                   # modppl/tests/importance.rs:98
+    ys = 0.3 + 0.4 * xs + 0.5 * xs * xs + np.random.default_rng(1).normal(0.0, 0.1, xs.size)
+    cons = {4 + k: float(y) for k, y in enumerate(ys)}
+    n = 400
+    r = O.OracleFunctionChains(101, xs, cons, n, 9, canonical=True)
+    w = r.generate(cons, rng_step=3)
+    assert np.array_equal(w, r.assess(cons, rng_step=3))
+    lj = r.simulate(rng_step=4)
+    assert np.array_equal(lj, r.logjp())
+    tv, tp = r.trace()
+    assert np.allclose(r.generate((tv, tp), rng_step=5), lj, rtol=1e-13, atol=1e-12)
+    tv2, tp2 = r.trace()
+    assert np.array_equal(tp, tp2) and np.array_equal(tv, tv2)
+    assert np.all(r.generate({}, rng_step=6) == 0.0)            # nothing constrained: a prior draw, weight 0 (dyngenfn.rs:132-140)
+    tr, lnw, lml, idx = O.OracleFunctionChains.importance(101, xs, cons, n, 20, 9, canonical=True)
+    tr2, lnw2, lml2, idx2 = O.OracleFunctionChains.importance(101, xs, cons, n, 20, 9, canonical=False)
+    assert abs(lml - lml2) <= 1e-12 * abs(lml2) and np.array_equal(idx, idx2)
+    assert abs(np.exp(lnw2).sum() - 1.0) < 1e-9
+    # the N traces are generate's: chain i of a plain constructor with the same seed
+    assert np.array_equal(tr.trace()[0], O.OracleFunctionChains(101, xs, cons, n, 9, canonical=True).trace()[0])
