@@ -240,16 +240,22 @@ def sub_benches(steps, warmup, which):
                                   "peak": 78.6, "unit": "TFLOP/s", "frac": rate * flop_per_it / 1e12 / 78.6,
                                   "hbm_bytes_per_chain_per_launch": 2 * (8 * 3 + 8), "iterations_per_launch": 3 * sweeps,
                                   "hbm_GBps": rate / (3 * sweeps) * 2 * (8 * 3 + 8) / 1e9, "hbm_frac": rate / (3 * sweeps) * 2 * (8 * 3 + 8) / 1e9 / HBM_PEAK_GBPS}}
-        try:   # the same model and moves as a REGISTERED functor run by the generic Update / Regenerate handlers (mp_genfn.h): same results, bit for bit
-            fch = modppl_amd.HierarchicalChains(xs, ys, 1 << 20, 20241008, constrain_is_linear=False, functor=True)
-            fch.regen_mh([1, 2, 3], n_iters=3, cycle=True)
-            t0 = time.perf_counter()
-            fch.regen_mh([1, 2, 3], n_iters=3 * sweeps, cycle=True)
-            dtf = time.perf_counter() - t0
-            res["c4"]["registered_functor"] = {"chain_iterations_per_s": (1 << 20) * 3 * sweeps / dtf, "ratio_to_hand_written": dt / dtf,
-                                               "same_states": bool(np.array_equal(fch.states(), ch.states()))}
-        except Exception as e:   # noqa: BLE001
-            res["c4"]["registered_functor"] = {"error": repr(e)[:200]}
+        # the same model and moves as a REGISTERED functor run by the generic Update / Regenerate handlers (mp_genfn.h): same results, bit for bit.
+        # `registered_functor`: its observations DECLARED as data sites (kind 105: four sites of trace, any number of observations — what a
+        # model with data should be written as); `registered_functor_all_sites_in_registers`: every "(y, j)" an ordinary site (kind 101,
+        # rounds 2-4's form: 20 sites of trace in registers)
+        for key, fk in (("registered_functor", "data"), ("registered_functor_all_sites_in_registers", True)):
+            try:
+                fch = modppl_amd.HierarchicalChains(xs, ys, 1 << 20, 20241008, constrain_is_linear=False, functor=fk)
+                fch.regen_mh([1, 2, 3], n_iters=3, cycle=True)
+                t0 = time.perf_counter()
+                fch.regen_mh([1, 2, 3], n_iters=3 * sweeps, cycle=True)
+                dtf = time.perf_counter() - t0
+                res["c4"][key] = {"chain_iterations_per_s": (1 << 20) * 3 * sweeps / dtf, "ratio_to_hand_written": dt / dtf,
+                                  "same_states": bool(np.array_equal(fch.states(), ch.states())), "model_kind": 105 if fk == "data" else 101}
+                del fch
+            except Exception as e:   # noqa: BLE001
+                res["c4"][key] = {"error": repr(e)[:200]}
     return res
 
 

@@ -338,6 +338,9 @@ int32_t mp_importance_sampling(const mp_model_desc* model, const double* args0, 
  * Static site ids (the stand-in for trie addresses): */
 enum mp_mh_site { MP_SITE_IS_LINEAR = 0, MP_SITE_A = 1, MP_SITE_B = 2, MP_SITE_C = 3, MP_SITE_Y0 = 4 /* "(y, k)" = MP_SITE_Y0 + k */ };
 enum mp_mh_model_kind { MP_MH_MODEL_HIERARCHICAL = 1, MP_MH_MODEL_POINTED_2D = 2, MP_MH_MODEL_HIERARCHICAL_FN = 101 /* mp_mh_create_fn */,
+                       MP_MH_MODEL_HIERARCHICAL_DATA_FN = 105 /* mp_mh_create_fn: the same model with its "(y, j)" sites DECLARED as data — any number of
+                                                                 observations (params = xs[n_obs]; observation j = constraint on site id 4 + j), four
+                                                                 sites of trace; see "declared data sites" below */,
                        MP_MH_MODEL_POINTED_FN = 120 /* mp_mh_create_fn: pointed_2d_model as a registered functor (vector-valued sites: latent = slots 1, 2; obs = 3, 4) */ };
 enum mp_mh_proposal_kind {
     MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1, /* hierarchical_drift_proposal(tr, drift_std): hierarchical.rs:62-70; args = {drift_std} */
@@ -391,6 +394,15 @@ int32_t mp_mh_read_observations(mp_mh* h, double* out);
  * a move reaches such a case; the chains keep whatever the kernel left). */
 int32_t mp_mh_create_fn(int32_t model_kind, const double* params, int32_t n_params, const int32_t* constraint_sites, const double* constraint_values,
                         int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, mp_mh** out);
+/* Declared data sites (modppl_amd/csrc/mp_genfn.h).  A registered model may declare its observations as DATA instead of giving each a
+ * site id of its own: they are then not part of the register-resident trace (no value / log-density / presence bit per observation, no
+ * MP_FN_MAX_SITES = 64 cap: `hierarchical_model`'s loop over `xs`, hierarchical.rs:33-47, has no bound), their values live in one array
+ * shared by all chains, and the handlers apply `sample_at`'s rules to each of them in the reference's order, recomputing the previous
+ * trace's log-density where the reference reads the stored one (same bits).  Across this ABI observation j of such a model is site id
+ * n_sites + j, accepted ONLY among the constraints of the creating call (mp_mh_create_fn / mp_fn_generate_create / mp_fn_importance_*),
+ * where every one of them must appear.  What cannot be done with a declared data site — because it would turn an observation into a
+ * chain's own state — is MP_ERR_UNSUPPORTED: mp_fn_simulate[_create], and the empty mask of mp_regen_mh_step / mp_fn_regenerate (the
+ * whole schema, dyngenfn.rs:571, re-simulates observed sites too).  mp_mh_n_sites / mp_mh_read_trace cover the ordinary sites only. */
 /* Number of site ids of the model (the row width of mp_mh_read_trace). */
 int32_t mp_mh_n_sites(mp_mh* h, int32_t* out);
 /* Every chain's trace: values[n_chains][n_sites] (0 where the site is absent) and present[n_chains][W] — 32-bit words, W =

@@ -23,6 +23,7 @@ MP_MH_MODEL_HIERARCHICAL = 1
 MP_MH_MODEL_POINTED_2D = 2
 MP_ARGDIFF_NOCHANGE, MP_ARGDIFF_UNKNOWN = 0, 1   # gfi.rs:94-111
 MP_MH_MODEL_HIERARCHICAL_FN = 101
+MP_MH_MODEL_HIERARCHICAL_DATA_FN = 105   # the same model with its observations declared as data sites (any number of them)
 MP_MH_MODEL_POINTED_FN = 120        # pointed_2d_model as a registered functor with vector-valued sites   # the hierarchical model as a registered functor (mp_mh_create_fn)
 MP_MH_PROPOSAL_HIERARCHICAL_DRIFT = 1
 MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE = 2

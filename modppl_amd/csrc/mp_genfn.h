@@ -37,6 +37,23 @@
 //              history of its inserts and removes, not a fresh sum — so a trace carries it per sub-call (`subw`, indexed by the
 //              sub-call's lowest site) and the handler applies the trie's own += / -= to it, in the trie's order (trie.rs:118-184).
 // What is NOT restated: leftover constraints (the reference's panic): `panic`, which the kernels report as an error.
+//
+// DECLARED DATA SITES (round 5).  A model's observations are ordinary sites in the reference (`normal(mu, 0.1) %= ("y", i)` in a loop
+// of any length, hierarchical.rs:33-47) whose addresses are in the constraints when the trace is generated and are never masked or
+// proposed afterwards.  As register-resident sites they cost a model what its latents cost — a value, a log-density, presence /
+// visited / consumed bits, a slot in every accept select — and cap it at MP_FN_MAX_SITES.  A model may instead DECLARE them:
+//     static constexpr bool HAS_DATA = true;   int n_obs;            (any number: nothing about them lives in registers)
+//     struct latents { ... };                                         what the observations' distributions depend on
+//     latents latents_of(const V& view) const;                        ... read off a trace (view.val[site], view.has(site))
+//     mp_fn_normal datum(int j, const latents& l) const;              the distribution of observation j
+//     double obs(int j) const;                                        its observed value (a shared array: bind(cov, obs))
+// and visit them with ONE call `g.data(*this, latents{...})` at the point of the body where the loop over ("y", j) stands.  The handler
+// then applies sample_at's rules to each j in order with nothing stored: GENERATE weight += logp; UPDATE / REGENERATE under diff
+// Unknown weight += logp_new - logp_prev, where logp_prev — the log-density the previous trace holds for the site — is RECOMPUTED from
+// the previous trace's latents (the same expression on the same inputs: the same bits); under NoChange the site is kept as it is.
+// Across the C ABI observation j is site id NS + j (constraints of the creating generate only).  What a declared data site cannot do
+// is become a chain's own state: simulate, a generate that leaves one unconstrained, and the empty mask of regenerate (the whole
+// schema, dyngenfn.rs:571, re-simulates the observed sites too) are MP_ERR_UNSUPPORTED for such models.
 #pragma once
 #include "mp_dists.h"
 
@@ -131,6 +148,11 @@ struct mp_fn_mvnormal2 {
 
 enum mp_fn_mode { MP_FN_SIMULATE = 0, MP_FN_GENERATE = 1, MP_FN_UPDATE = 2, MP_FN_REGENERATE = 3 };
 
+template <class M, class = void>
+struct mp_fn_has_data : std::false_type {};
+template <class M>
+struct mp_fn_has_data<M, std::void_t<decltype(M::HAS_DATA)>> : std::integral_constant<bool, M::HAS_DATA> {};
+
 template <int NS, int MODE>
 struct mp_fn_handler {
     static_assert(NS <= MP_FN_MAX_SITES, "site ids are bits of a 64-bit word at most");
@@ -148,11 +170,34 @@ struct mp_fn_handler {
     double sw;            // inside a sub-call: the running weight of its trie
     bool in_sub;          // the sites visited belong to a sub-trie whose weight is being kept
     bool from_prev;       // REGENERATE through an unmasked sub-call after an upstream change: generate with the old choices as constraints
+    double dlp;           // GENERATE: the declared data sites' log-densities, summed in order (trace.logjp's share of them)
 
     MP_HD mp_fn_handler(const mp_stream& r, uint32_t dom_, const mp_fn_trace<NS>* prev_, const mp_fn_trace<NS>* cons_, bits_t mask_ = 0)
         : rng(r), dom(dom_), prev(prev_), cons(cons_), mask(mask_), weight(0.), changed(false), visited(0), consumed(0), discarded(0),
-          panic(false), sw(0.), in_sub(false), from_prev(false) {
+          panic(false), sw(0.), in_sub(false), from_prev(false), dlp(0.) {
         mp_fn_clear(tr);
+    }
+    // the model's declared data sites (top of this file), all of them, in order; `lat` = what their distributions depend on, as the
+    // body has just computed it.  Top level only (not inside a sub-call).
+    template <class Model, class L>
+    MP_HD void data(const Model& m, const L& lat) {
+        if constexpr (MODE == MP_FN_SIMULATE) {
+            panic = true;   // an observation drawn from its prior would be per-chain state: not what a declared data site is
+        } else if constexpr (MODE == MP_FN_GENERATE) {
+            for (int j = 0; j < m.n_obs; ++j) {
+                const double lp = m.datum(j, lat).logpdf(m.obs(j));
+                weight += lp;                                    // constrained: weight += logp (dyngenfn.rs:116-131)
+                dlp = j ? dlp + lp : lp;
+            }
+        } else {
+            if (changed) {                                       // diff Unknown: weight += logp - prev.logp (:180-190, :236-243)
+                const L old = m.latents_of(*prev);
+                for (int j = 0; j < m.n_obs; ++j) {
+                    const double y = m.obs(j);
+                    weight += m.datum(j, lat).logpdf(y) - m.datum(j, old).logpdf(y);
+                }
+            }                                                    // NoChange: every one is kept as it is
+        }
     }
     MP_HD double exp_(double x) const { return mp_exp(x); }
     MP_HD double log_(double x) const { return mp_log(x); }

@@ -405,6 +405,7 @@ struct mp_mh {
     uint32_t* gfi_present = nullptr; // [n]
     double* gfi_cons = nullptr;      // [n_sites][n]: per-chain constraint values
     uint32_t* gfi_cpresent = nullptr; // [n]: per-chain constraint presence
+    double* d_data = nullptr;        // models with declared data sites (mp_genfn.h): [2][n_obs] = the covariates (params), the observed values
 };
 #include "mp_mh_fn.h"
 
@@ -572,8 +573,36 @@ static int32_t fn_create_generate(int32_t model_kind, const double* params, int3
                                   int32_t n_constraints, uint64_t n_chains, uint64_t seed, int32_t device, void* stream, std::unique_ptr<mp_mh, mh_cleanup>& h) {
     int32_t rc = fn_alloc(model_kind, params, n_params, n_chains, seed, device, stream, h);
     if (rc != MP_OK) return rc;
+    if (n_constraints < 0 || (n_constraints > 0 && (!constraint_sites || !constraint_values))) return mp_set_error(MP_ERR_INVALID_ARG, "bad constraints");
+    // declared data sites (mp_genfn.h): observation j is site id ns + j here and nowhere else — its value goes into a shared array
+    const int ns = h->fn->ns(), nd = h->fn->n_data();
+    std::vector<int32_t> rsites;
+    std::vector<double> rvals;
+    if (nd > 0) {
+        if (n_params != nd) return mp_set_error(MP_ERR_INVALID_ARG, "a model with declared data sites takes one covariate per observation as its params");
+        std::vector<double> buf((size_t)2 * nd);
+        std::vector<char> seen((size_t)nd, 0);
+        for (int j = 0; j < nd; ++j) buf[(size_t)j] = params[j];
+        for (int q = 0; q < n_constraints; ++q) {
+            const int s = constraint_sites[q];
+            if (s >= ns && s < ns + nd) {
+                if (seen[(size_t)(s - ns)]) return mp_set_error(MP_ERR_INVALID_ARG, "a site is constrained twice");
+                seen[(size_t)(s - ns)] = 1;
+                buf[(size_t)nd + (size_t)(s - ns)] = constraint_values[q];
+            } else { rsites.push_back(s); rvals.push_back(constraint_values[q]); }
+        }
+        for (int j = 0; j < nd; ++j)
+            if (!seen[(size_t)j])
+                return mp_set_error(MP_ERR_UNSUPPORTED, "every declared data site must be constrained (an observation drawn from its prior would be per-chain state: "
+                                                        "write the model with ordinary sites for that)");
+        MHCK(hipMalloc(&h->d_data, sizeof(double) * buf.size()));
+        MHCK(hipMemcpyAsync(h->d_data, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice, h->stream));
+        MHCK(hipStreamSynchronize(h->stream));   // (`buf` is a local)
+        h->fn->bind_data(h->d_data, h->d_data + nd);
+        constraint_sites = rsites.data(); constraint_values = rvals.data(); n_constraints = (int32_t)rsites.size();
+    }
     mp_fn_consspec cs{};
-    rc = fn_shared_constraints(h->fn->ns(), constraint_sites, constraint_values, n_constraints, cs);
+    rc = fn_shared_constraints(ns, constraint_sites, constraint_values, n_constraints, cs);
     if (rc != MP_OK) return rc;
     rc = h->fn->generate(h.get(), cs, nullptr, nullptr, 0u);
     if (rc != MP_OK) return rc;
@@ -604,6 +633,7 @@ int32_t mp_fn_simulate_create(int32_t model_kind, const double* params, int32_t 
     std::unique_ptr<mp_mh, mh_cleanup> h;
     int32_t rc = fn_alloc(model_kind, params, n_params, n_chains, seed, device, stream, h);
     if (rc != MP_OK) return rc;
+    if (h->fn->n_data() > 0) return mp_set_error(MP_ERR_UNSUPPORTED, "simulate: the model declares data sites (observed by definition, mp_genfn.h)");
     rc = h->fn->simulate(h.get(), 0u);
     if (rc != MP_OK) return rc;
     if (logjp_out) MHCK(hipMemcpyAsync(logjp_out, h->tmp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
@@ -711,6 +741,8 @@ static int32_t mh_fn_regen(mp_mh* h, const int32_t* mask_sites, int32_t n_mask, 
         m.cycle[q] = (unsigned char)mask_sites[q];
     }
     m.n_cycle = (cycle && n_mask > 0) ? n_mask : 0;
+    if (n_mask == 0 && h->fn->n_data() > 0)
+        return mp_set_error(MP_ERR_UNSUPPORTED, "regen_mh with the empty mask re-simulates the whole schema, observed sites included (dyngenfn.rs:571): not for a model with declared data sites");
     MHCK(hipSetDevice(h->device));
     MHCK(hipMemsetAsync(h->d_acc, 0, sizeof(u64) * 2, h->stream));
     const int32_t rc = h->fn->regen(h, m, n_iters);
@@ -957,6 +989,8 @@ int32_t mp_fn_regenerate(mp_mh* h, int32_t argdiff, uint32_t rng_step, const int
         if (mask_sites[q] < 0 || mask_sites[q] >= h->fn->ns()) return mp_set_error(MP_ERR_INVALID_ARG, "mask site out of range");
         bits |= 1ull << mask_sites[q];
     }
+    if (n_mask == 0 && h->fn->n_data() > 0)
+        return mp_set_error(MP_ERR_UNSUPPORTED, "regenerate with the empty mask re-simulates the whole schema, observed sites included (dyngenfn.rs:571): not for a model with declared data sites");
     uint32_t step = 0;
     rc = gfi_take_step(h, rng_step, &step);
     if (rc != MP_OK) return rc;
@@ -1015,6 +1049,7 @@ int32_t mp_fn_generate(mp_mh* h, uint32_t rng_step, const int32_t* sites, const 
 int32_t mp_fn_simulate(mp_mh* h, uint32_t rng_step, double* logjp_out) {
     int32_t rc = gfi_check(h);
     if (rc != MP_OK) return rc;
+    if (h->fn->n_data() > 0) return mp_set_error(MP_ERR_UNSUPPORTED, "simulate: the model declares data sites (observed by definition, mp_genfn.h)");
     uint32_t step = 0;
     rc = gfi_take_step(h, rng_step, &step);
     if (rc != MP_OK) return rc;
@@ -1035,7 +1070,7 @@ int32_t mp_mh_destroy(mp_mh* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->is_lin); (void)hipFree(h->a); (void)hipFree(h->b); (void)hipFree(h->c); (void)hipFree(h->tmp); (void)hipFree(h->d_acc);
     (void)hipFree(h->lat); (void)hipFree(h->ys_chain); (void)hipFree(h->fvals); (void)hipFree(h->fpresent);
-    (void)hipFree(h->gfi_vals); (void)hipFree(h->gfi_present); (void)hipFree(h->gfi_cons); (void)hipFree(h->gfi_cpresent);
+    (void)hipFree(h->gfi_vals); (void)hipFree(h->gfi_present); (void)hipFree(h->gfi_cons); (void)hipFree(h->gfi_cpresent); (void)hipFree(h->d_data);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;

@@ -51,7 +51,7 @@ __device__ __forceinline__ void fn_bits_store(uint32_t* __restrict__ present, u6
 }
 template <class M>
 __device__ __forceinline__ void fn_load(const M& model, const mp_stream& s, u64 i, u64 n, const double* __restrict__ vals,
-                                        const uint32_t* __restrict__ present, mp_fn_trace<M::NS>& out) {
+                                        const uint32_t* __restrict__ present, mp_fn_trace<M::NS>& out, double* data_lp = nullptr) {
     mp_fn_trace<M::NS> c;
     c.present = fn_bits_load<M::NS>(present, i, n);
 #pragma unroll
@@ -63,6 +63,7 @@ __device__ __forceinline__ void fn_load(const M& model, const mp_stream& s, u64 
     mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
     model(g);
     out = g.tr;
+    if (data_lp) *data_lp = g.dlp;   // (declared data sites: their share of trace.logjp)
 #pragma unroll
     for (int k = 0; k < M::NS; ++k)
         if (fn_is_sub_id<M>(k)) out.subw[k] = vals[(u64)(M::NS + k) * n + i];
@@ -93,8 +94,9 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_logjp(u64 n, M model, const d
     mp_stream s;
     s.k0 = 0; s.k1 = 0; s.slot = 0; s.step = 0;   // nothing is drawn: every choice is constrained
     mp_fn_trace<M::NS> cur;
-    fn_load(model, s, i, n, vals, present, cur);
-    out[i] = mp_fn_logjp(cur);
+    double dlp = 0.;
+    fn_load(model, s, i, n, vals, present, cur, &dlp);
+    out[i] = mp_fn_has_data<M>::value ? mp_fn_logjp(cur) + dlp : mp_fn_logjp(cur);
 }
 
 template <class M>
@@ -344,6 +346,9 @@ struct mh_fn_ops {
     virtual int32_t regen(mp_mh* h, const mp_fn_maskspec& m, int n_iters) = 0;
     virtual int32_t mh(mp_mh* h, int proposal_kind, const double* args, int n_args, int n_iters) = 0;
     virtual int32_t logjp(mp_mh* h) = 0;
+    // declared data sites (mp_genfn.h): how many, and where the model finds the shared arrays {covariates, observed values}
+    virtual int n_data() const { return 0; }
+    virtual void bind_data(const double* /*d_cov*/, const double* /*d_obs*/) {}
     // the GFI operations one at a time (mp_fn_*): weights into h->tmp, discard / choices into h->gfi_vals / h->gfi_present
     virtual int32_t update(mp_mh* h, const mp_fn_consspec& cs, const double* d_cvals, const uint32_t* d_cpresent, int unknown, uint32_t step, bool want_discard) = 0;
     virtual int32_t regenerate(mp_mh* h, uint64_t mask, int unknown, uint32_t step) = 0;
@@ -371,6 +376,13 @@ template <class M>
 struct mh_fn_ops_t : mh_fn_ops {
     M model;
     int ns() const override { return M::NS; }
+    int n_data() const override {
+        if constexpr (mp_fn_has_data<M>::value) return model.n_obs;
+        else return 0;
+    }
+    void bind_data(const double* d_cov, const double* d_obs) override {
+        if constexpr (mp_fn_has_data<M>::value) model.bind(d_cov, d_obs);
+    }
     int32_t regen(mp_mh* h, const mp_fn_maskspec& m, int n_iters) override {
         hipLaunchKernelGGL(k_fn_regen<M>, dim3(fn_grid(h)), dim3(MH_THREADS), 0, h->stream, h->n, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
                            (uint32_t)(h->iters + 1), n_iters, model, m, h->fvals, h->fpresent, h->d_acc);

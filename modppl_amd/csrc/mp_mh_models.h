@@ -106,6 +106,64 @@ inline bool mp_parse_hier_add_or_remove_fn(const double*, int n_args, mp_hier_ad
 MP_REGISTER_MH_PROPOSAL(2, mp_hier_fn, mp_hier_add_or_remove_fn, mp_parse_hier_add_or_remove_fn)
 
 // ---------------------------------------------------------------------------------------
+// hierarchical_model with DECLARED data sites, kind 105 (round 5; mp_genfn.h "DECLARED DATA SITES"): the same model — same sites 0..3,
+// same sub-call, same expression for an observation's mean — whose "(y, j)" sites are not register-resident sites 4 + j but data:
+// any number of observations (`for (i, x) in xs.iter().enumerate()`, hierarchical.rs:36-45, has no bound), four sites of trace.
+//   params = xs[0 .. n_obs); the observations are constraints on the site ids NS + j = 4 + j of the creating call, all of them.
+// The same proposals (kinds 1, 2: they address sites 0..3 only).
+// ---------------------------------------------------------------------------------------
+struct mp_hier_data_fn {
+    static constexpr int NS = 4;
+    static constexpr bool HAS_DATA = true;
+    static constexpr int MAX_OBS = 1 << 20;
+    enum { IS_LINEAR = 0, A = 1, B = 2, C = 3 };
+    static constexpr uint32_t COEFFS = (1u << A) | (1u << B) | (1u << C);
+    static constexpr uint32_t sub_of(int site) { return (site >= A && site <= C) ? COEFFS : 0u; }
+    static constexpr bool is_bool(int site) { return site == IS_LINEAR; }
+    int n_obs;
+    const double* xs;   // [n_obs] the design (params), ...
+    const double* ys;   // [n_obs] ... the observed values: shared arrays in the handle's memory space (bind)
+    double ln_noise;    // mp_log(0.1)
+    struct latents { bool lin; double a, b, c; };
+    template <class V>
+    MP_HD latents latents_of(const V& v) const { return latents{v.val[IS_LINEAR] != 0., v.val[A], v.val[B], v.val[C]}; }
+    MP_HD mp_fn_normal datum(int j, const latents& l) const {
+        const double x = xs[j];
+        return mp_fn_normal{l.lin ? l.a + l.b * x : l.a + l.b * x + l.c * x * x, 0.1, ln_noise};   // hierarchical.rs:38 / :43
+    }
+    MP_HD double obs(int j) const { return ys[j]; }
+    void bind(const double* cov, const double* obs_) { xs = cov; ys = obs_; }
+    template <class H>
+    MP_HD void operator()(H& g) const {
+        const bool lin = g.template bernoulli<IS_LINEAR>(0.7);
+        const mp_fn_ret co = g.template call<COEFFS>([&](H& q) {
+            mp_fn_ret r{};
+            r.v[0] = q.template normal<A>(0., 1., 0.);
+            r.v[1] = q.template normal<B>(0., 1., 0.);
+            if (!lin) r.v[2] = q.template normal<C>(0., 1., 0.);
+            return r;
+        });
+        g.data(*this, latents{lin, co.v[0], co.v[1], co.v[2]});
+    }
+};
+inline bool mp_parse_hier_data_fn(const double* params, int n_params, mp_hier_data_fn& m, std::string& err) {
+    if (!params || n_params < 1 || n_params > mp_hier_data_fn::MAX_OBS) { err = "hierarchical model (declared data): params = xs[0 .. n_obs), n_obs >= 1"; return false; }
+    m.n_obs = n_params;
+    m.xs = nullptr; m.ys = nullptr;
+    m.ln_noise = mp_log(0.1);
+    return true;
+}
+MP_REGISTER_MH_MODEL(105, mp_hier_data_fn, mp_parse_hier_data_fn)
+struct mp_hier_data_drift_fn : mp_hier_drift_fn {};
+inline bool mp_parse_hier_data_drift_fn(const double* args, int n_args, mp_hier_data_drift_fn& p, std::string& err) { return mp_parse_hier_drift_fn(args, n_args, p, err); }
+MP_REGISTER_MH_PROPOSAL(1, mp_hier_data_fn, mp_hier_data_drift_fn, mp_parse_hier_data_drift_fn)
+struct mp_hier_data_add_or_remove_fn : mp_hier_add_or_remove_fn {};
+inline bool mp_parse_hier_data_add_or_remove_fn(const double* args, int n_args, mp_hier_data_add_or_remove_fn& p, std::string& err) {
+    return mp_parse_hier_add_or_remove_fn(args, n_args, p, err);
+}
+MP_REGISTER_MH_PROPOSAL(2, mp_hier_data_fn, mp_hier_data_add_or_remove_fn, mp_parse_hier_data_add_or_remove_fn)
+
+// ---------------------------------------------------------------------------------------
 // Robust regression with outlier indicators, kind 102 — a model that exists ONLY here (no hand-written kernel, no hand-written
 // restatement in the checker): the test of the generic layer proper.  The shape of Gen's MCMC tutorial model:
 //   line() /= "line":  slope ~ normal(0, 2) %= "slope";  intercept ~ normal(0, 2) %= "intercept"

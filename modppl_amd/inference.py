@@ -257,7 +257,10 @@ class HierarchicalChains:
 
     def __init__(self, xs, ys, num_chains, seed, *, constrain_is_linear=None, device=0, stream=None, functor=False):
         """functor=True: the same model as a REGISTERED generative function (csrc/mp_mh_models.h, kind 101) run by the
-        generic Update / Regenerate handlers instead of the hand-written kernels — same calls, same results bit for bit."""
+        generic Update / Regenerate handlers instead of the hand-written kernels — same calls, same results bit for bit.
+        functor="data": the registered function whose "(y, j)" sites are DECLARED data sites (kind 105): any number of observations
+        (the hand-written kernels and kind 101 stop at 16), same latents bit for bit; regen_mh with the empty mask and
+        observations() do not apply (an observation is not part of a chain's state there)."""
         self._L = capi.load()
         xs = np.ascontiguousarray(xs, dtype=np.float64)
         ys = np.ascontiguousarray(ys, dtype=np.float64)
@@ -270,7 +273,8 @@ class HierarchicalChains:
             cons = {capi.MP_SITE_Y0 + k: float(y) for k, y in enumerate(ys)}
             if constrain_is_linear is not None:
                 cons[capi.MP_SITE_IS_LINEAR] = float(bool(constrain_is_linear))
-            self._fn = FunctionChains(capi.MP_MH_MODEL_HIERARCHICAL_FN, xs, cons, num_chains, seed, device=device, stream=stream)
+            kind = capi.MP_MH_MODEL_HIERARCHICAL_DATA_FN if functor == "data" else capi.MP_MH_MODEL_HIERARCHICAL_FN
+            self._fn = FunctionChains(kind, xs, cons, num_chains, seed, device=device, stream=stream)
             self._h = self._fn._h
             return
         c = -1 if constrain_is_linear is None else int(bool(constrain_is_linear))

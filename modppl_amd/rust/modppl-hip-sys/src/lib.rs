@@ -26,6 +26,7 @@ pub const MP_RESAMPLE_MULTINOMIAL_SPLIT: i32 = 3;
 pub const MP_MH_MODEL_HIERARCHICAL: i32 = 1;
 pub const MP_MH_MODEL_POINTED_2D: i32 = 2;
 pub const MP_MH_MODEL_HIERARCHICAL_FN: i32 = 101;   // the hierarchical model as a registered functor (mp_mh_create_fn)
+pub const MP_MH_MODEL_HIERARCHICAL_DATA_FN: i32 = 105;   // the same model with its observations declared as data sites (any number)
 pub const MP_MH_PROPOSAL_POINTED_DRIFT: i32 = 3;
 pub const MP_SITE_IS_LINEAR: i32 = 0;
 pub const MP_SITE_A: i32 = 1;

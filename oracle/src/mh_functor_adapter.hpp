@@ -93,6 +93,15 @@ struct DynMhHandler {
         out[0] = v[0]; out[1] = v[1];
     }
 
+    // declared data sites (mp_genfn.h): here they are what they are in the reference — `normal(mu_j, sd_j) %= ("y", j)` in a loop, ordinary
+    // sample_at calls on the trie at address s<NS + j>, with the trie's own stored weights for the previous log-densities
+    template <class Model, class L>
+    void data(const Model& m, const L& lat) {
+        for (int j = 0; j < m.n_obs; ++j) {
+            const mp_fn_normal d = m.datum(j, lat);
+            (void)g.template sample_at<double>(oracle::normal, NormalParams{d.mu, d.sd}, mhfn_local_addr(M::NS + j));
+        }
+    }
     // trace_at: under Update / Regenerate with nothing touched and diff NoChange the body is NOT run and the stored retv comes
     // back (dyngenfn.rs:362-366, 415-419) — which is why a functor may take a sub-call's results from its return value only
     template <uint64_t SITES, class Body>
@@ -185,7 +194,12 @@ template <class M>
 struct MhFnModelT : MhFnModel {
     M m;
     MhFnGen gen;
-    explicit MhFnModelT(const M& m_) : m(m_) {
+    std::vector<double> cov;   // (declared data sites) the covariates the functor's datum() reads; the observed values live in the tries
+    explicit MhFnModelT(const M& m_, const double* params = nullptr, int n_params = 0) : m(m_) {
+        if constexpr (mp_fn_has_data<M>::value) {
+            cov.assign(params, params + n_params);
+            m.bind(cov.data(), nullptr);
+        }
         const M mm = m;
         gen = MhFnGen([mm](MhFnH& g, int) -> mp_fn_ret {
             DynMhHandler<M> h{g, false, false};
@@ -200,6 +214,9 @@ struct MhFnModelT : MhFnModel {
         DynTrie c;
         for (int q = 0; q < n; ++q) {
             const int s = sites[q];
+            if constexpr (mp_fn_has_data<M>::value) {
+                if (s >= M::NS && s < M::NS + m.n_obs) { c.observe(mhfn_local_addr(s), arc(vals[q])); continue; }   // observation s - NS
+            }
             if (s < 0 || s >= M::NS) throw Panic("constraint site out of range");
             const int d = mhfn_dim<M>(s);
             if (d == 0) continue;   // a vector's further slot: taken with its head below
@@ -257,7 +274,10 @@ struct MhFnStaticT : MhFnStatic {
     M model;
     std::vector<mp_fn_trace<M::NS>> tr;
     uint64_t seed = 0, iters = 0, n_panic = 0;
-    explicit MhFnStaticT(const M& m) : model(m) {}
+    std::vector<double> cov, obsv;   // (declared data sites) the shared arrays the product's handler reads
+    explicit MhFnStaticT(const M& m, const double* params = nullptr, int n_params = 0) : model(m) {
+        if constexpr (mp_fn_has_data<M>::value) cov.assign(params, params + n_params);
+    }
     int ns() const override { return M::NS; }
     uint64_t panics() const override { return n_panic; }
     mp_stream stream(size_t i, uint32_t step) const {
@@ -269,7 +289,16 @@ struct MhFnStaticT : MhFnStatic {
         seed = seed_; iters = 0;
         mp_fn_trace<M::NS> c;
         mp_fn_clear(c);
-        for (int q = 0; q < n_cons; ++q) { c.present |= mp_fn_bits_t<M::NS>(1) << sites[q]; c.val[sites[q]] = vals[q]; }
+        if constexpr (mp_fn_has_data<M>::value) {
+            obsv.assign((size_t)model.n_obs, 0.);
+            model.bind(cov.data(), obsv.data());
+        }
+        for (int q = 0; q < n_cons; ++q) {
+            if constexpr (mp_fn_has_data<M>::value) {
+                if (sites[q] >= M::NS) { obsv[(size_t)(sites[q] - M::NS)] = vals[q]; continue; }
+            }
+            c.present |= mp_fn_bits_t<M::NS>(1) << sites[q]; c.val[sites[q]] = vals[q];
+        }
         tr.resize(n_chains);
         for (size_t i = 0; i < tr.size(); ++i) {   // k_fn_init
             const mp_stream s = stream(i, 0);
@@ -376,13 +405,13 @@ int mhfn_register_model(int kind, bool (*parse)(const double*, int, M&, std::str
         M m{};
         std::string err;
         if (!parse(params, n, m, err)) throw Panic(err);
-        return std::make_shared<MhFnModelT<M>>(m);
+        return std::make_shared<MhFnModelT<M>>(m, params, n);
     };
     mhfn_static_models()[kind] = [parse](const double* params, int n) -> std::shared_ptr<MhFnStatic> {
         M m{};
         std::string err;
         if (!parse(params, n, m, err)) throw Panic(err);
-        return std::make_shared<MhFnStaticT<M>>(m);
+        return std::make_shared<MhFnStaticT<M>>(m, params, n);
     };
     return kind;
 }

@@ -302,3 +302,73 @@ def test_vector_valued_sites_pointed_model_three_ways(noise):
     v, p = d.trace()
     assert np.all(p == 0b11110)
     assert np.all(np.abs(v[:, 1:3]) <= 5.0)
+
+
+# ---- declared data sites (round 5; mp_genfn.h "DECLARED DATA SITES", mp_mh_models.h kind 105) --------------------------------------
+def _data_pair(n_obs, n, seed, constrain=None, static=False):
+    xs = np.linspace(-5.0, 5.0, n_obs)
+    ys = 0.3 + 0.4 * xs + 0.5 * xs * xs + 0.1 * np.random.default_rng(n_obs).normal(size=n_obs)
+    cons = {4 + j: float(y) for j, y in enumerate(ys)}
+    if constrain is not None:
+        cons[0] = float(constrain)
+    return xs, cons, O.OracleFunctionChains(105, xs, cons, n, seed, canonical=True)
+
+
+def _same_data(st, dyn):
+    av, ap = st.trace(4)
+    bv, bp = dyn.trace()
+    assert np.array_equal(np.asarray(ap, dtype=np.uint64), np.asarray(bp, dtype=np.uint64))
+    assert np.array_equal(av, bv)
+
+
+def test_declared_data_sites_are_the_same_model_as_ordinary_sites():
+    """hierarchical_model with its "(y, j)" sites declared as data (kind 105: four sites of trace, the observations in a shared
+    array) against the same model with them as ordinary sites (kind 101), both through the checker's tries: the latents of every chain,
+    the accept counts and trace.logjp agree through drift moves, the structure-changing move and cycled masks — a declared data site
+    is the reference's `normal(mu, 0.1) %= ("y", j)`, only stored differently."""
+    ys = make_ys()
+    cons101 = {Y0 + k: float(y) for k, y in enumerate(ys)}
+    n, seed = 50, 13
+    a = O.OracleFunctionChains(101, XS, cons101, n, seed, canonical=True)
+    b = O.OracleFunctionChains(105, XS, cons101, n, seed, canonical=True)   # (the same site ids 4 + j name the observations)
+
+    def same():
+        av, ap = a.trace()
+        bv, bp = b.trace()
+        assert np.array_equal(av[:, :4], bv) and np.array_equal(ap & np.uint64(15), bp)
+        assert np.array_equal(a.logjp(), b.logjp())
+
+    same()
+    for _ in range(3):
+        assert a.mh(1, [0.08], 3) == b.mh(1, [0.08], 3)
+        same()
+        assert a.mh(2, [], 2) == b.mh(2, [], 2)
+        same()
+        assert a.regen_mh([1, 2, 3], 5, cycle=True) == b.regen_mh([1, 2, 3], 5, cycle=True)
+        same()
+
+
+@pytest.mark.parametrize("n_obs", [11, 200])
+def test_product_handlers_on_the_host_with_declared_data_sites(n_obs):
+    """The product's static handler (mp_fn_handler::data: nothing stored per observation, the previous log-densities RECOMPUTED from the
+    previous trace's latents) compiled for the host, against the dynamic interpretation over tries with 11 and with 200 observations
+    (the latter beyond any register-resident trace: MP_FN_MAX_SITES = 64): traces and accept counts bit for bit through mh with both
+    proposals, regen_mh with single, joint and cycled masks, and update with either ArgDiff."""
+    xs, cons, dyn = _data_pair(n_obs, 48, 7)
+    st = O.HostStaticFunctionChains(105, xs, cons, 48, 7)
+    _same_data(st, dyn)
+    for rnd in range(3):
+        assert st.mh(1, [0.02], 4) == dyn.mh(1, [0.02], 4)
+        _same_data(st, dyn)
+        assert st.mh(2, [], 2) == dyn.mh(2, [], 2)
+        _same_data(st, dyn)
+        assert st.regen_mh([1, 2, 3], 6, cycle=True) == dyn.regen_mh([1, 2, 3], 6, cycle=True)
+        _same_data(st, dyn)
+        assert st.regen_mh([1, 2], 2) == dyn.regen_mh([1, 2], 2)
+        _same_data(st, dyn)
+    for diff in (0, 1):
+        sw, sdp = st.update({1: 0.25 + diff}, argdiff=diff, rng_step=90 + diff)
+        dw, (ddv, ddp) = dyn.update({1: 0.25 + diff}, argdiff=diff, rng_step=90 + diff)
+        assert np.array_equal(sw, dw) and np.array_equal(np.asarray(sdp, dtype=np.uint64), ddp)
+        _same_data(st, dyn)
+    assert st.panics == 0

@@ -18,7 +18,7 @@ xs = np.arange(-5.0, 6.0)
 rng = np.random.default_rng(0)
 ys = 0.3 + 0.4 * xs + 0.5 * xs * xs + 0.1 * rng.normal(size=xs.size)
 out = {}
-for functor in (False, True):
+for functor in (False, True, "data"):   # hand-written kernels; registered functor, every site in registers (kind 101); the same with declared data sites (kind 105)
     g = modppl_amd.HierarchicalChains(xs, ys, n, 3, constrain_is_linear=False, functor=functor)
     g.regen_mh(["coeffs/a", "coeffs/b", "coeffs/c"], 30, cycle=True)
     g.mh(0.1, 10)
@@ -29,7 +29,9 @@ for functor in (False, True):
         fn()
         dt = time.perf_counter() - t0
         res[name] = {"chain_iters_per_s": n * iters / dt, "ms": dt * 1e3}
-    out["functor" if functor else "handwritten"] = res
+    out["functor_data_sites" if functor == "data" else ("functor" if functor else "handwritten")] = res
     g.close()
 out["ratio_functor_over_handwritten"] = {k: out["functor"][k]["chain_iters_per_s"] / out["handwritten"][k]["chain_iters_per_s"] for k in out["functor"]}
+out["ratio_functor_data_sites_over_handwritten"] = {k: out["functor_data_sites"][k]["chain_iters_per_s"] / out["handwritten"][k]["chain_iters_per_s"]
+                                                    for k in out["functor_data_sites"]}
 print(json.dumps(out, indent=1))
