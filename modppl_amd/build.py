@@ -17,6 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libmodppl_hip.so")
 SO_STAMPS = os.path.join(CSRC, "libmodppl_hip_stamps.so")   # diagnostics build (-DMP_STAMPS), tools/stamp_probe.py only
+SO_DIAG = os.path.join(CSRC, "libmodppl_hip_diag.so")       # the same sources with -DMP_DIAGNOSTICS: the A/B and test switches (csrc/mp_diag.h) exist
+                                                            # in this build only; tests and tools that need one load it, the product never does
 SOURCES = ["mp_pf.hip", "mp_mh.hip", "mp_probe.hip"]
 # -ffp-contract=off: the only fused multiply-adds are the explicit fma() calls in mp_math.h, so the
 # device evaluates exp/log with exactly the operations the CPU checker uses (bit-exact indices).
@@ -108,7 +110,12 @@ def build(force=False, verbose=False, so=SO, extra_flags=()):
 
 def build_stamps(force=False):
     """the diagnostics library: same sources with per-workgroup clock stamps compiled in (never loaded by the product)"""
-    return build(force=force, so=SO_STAMPS, extra_flags=("-DMP_STAMPS",))
+    return build(force=force, so=SO_STAMPS, extra_flags=("-DMP_STAMPS", "-DMP_DIAGNOSTICS"))
+
+
+def build_diag(force=False):
+    """the same library with its A/B and test switches enabled (csrc/mp_diag.h); never loaded by the product"""
+    return build(force=force, so=SO_DIAG, extra_flags=("-DMP_DIAGNOSTICS",))
 
 
 if __name__ == "__main__":
@@ -116,5 +123,7 @@ if __name__ == "__main__":
 
     if len(sys.argv) > 1 and sys.argv[1] == "stamps":
         print(build_stamps(force=True))
+    elif len(sys.argv) > 1 and sys.argv[1] == "diag":
+        print(build_diag(force=True))
     else:
         print(build(force=True, verbose=True))

@@ -100,7 +100,28 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    so = os.environ.get("MODPPL_HIP_LIB") or _build.SO   # the override is for the diagnostics build (tools/stamp_probe.py)
+    _lib = _load_so(os.environ.get("MODPPL_HIP_LIB") or _build.SO)   # the override is for the diagnostics builds (tools/, tests' subprocesses)
+    return _lib
+
+
+_diag = None
+
+
+def load_diag():
+    """The DIAGNOSTICS build of the library (-DMP_DIAGNOSTICS, csrc/mp_diag.h): the same sources with their A/B and test switches (MP_K1_MT,
+    MP_DEFERRED_LOOKUPS, ...) enabled — for tests and tools; the product library reads no environment variable."""
+    global _diag
+    if _diag is None:
+        if _build.is_stale(_build.SO_DIAG, ("-DMP_DIAGNOSTICS",)):
+            try:
+                _build.build_diag()
+            except RuntimeError as e:
+                raise ModpplError(MP_ERR_HIP, f"{_build.SO_DIAG} is missing or stale and could not be rebuilt: {e}")
+        _diag = _load_so(_build.SO_DIAG)
+    return _diag
+
+
+def _load_so(so):
     if so == _build.SO and _build.is_stale():
         # never load a binary that does not correspond to the checked-out sources (content hash, not mtime): rebuild it
         # where hipcc exists, fail loudly where it does not — there is no CPU fallback either way
@@ -192,7 +213,6 @@ def load():
     L.mp_probe_u01.argtypes = [u64, u32, u32, u32, u32, u32, i64, dp, i32]
     L.mp_probe_mfma_f64.argtypes = [dp, dp, dp, dp, i32]
     L.mp_probe_mvnormal.argtypes = [i32, i32, dp, dp, dp, i64, dp, u64, u32, u32, u32, u32, dp, i32]
-    _lib = L
     return L
 
 

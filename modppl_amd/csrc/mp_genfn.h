@@ -98,8 +98,10 @@ MP_HD double mp_fn_logjp(const mp_fn_trace<NS>& t) {
 
 struct mp_fn_normal {
     double mu, sd, ln_sd;
+    double rcp_sd;   // mp_rcp_hoist(sd) for a model constant, or 0 (what `mp_fn_normal{mu, sd, ln_sd}` leaves it at): the division (x - mu) / sd then
+                     // costs no division — the same bits either way (mp_math.h mp_div_hoisted, held to `/` on host and device)
     MP_HD double sample(mp_site& st) const { return mp_normal_sample(st, mu, sd); }
-    MP_HD double logpdf(double x) const { return mp_normal_logpdf_ln(x, mu, sd, ln_sd); }
+    MP_HD double logpdf(double x) const { return mp_normal_logpdf_h(x, mu, sd, ln_sd, rcp_sd); }
 };
 struct mp_fn_bernoulli {
     double p;
@@ -153,7 +155,22 @@ struct mp_fn_has_data : std::false_type {};
 template <class M>
 struct mp_fn_has_data<M, std::void_t<decltype(M::HAS_DATA)>> : std::integral_constant<bool, M::HAS_DATA> {};
 
-template <int NS, int MODE>
+// Which sub-call of a frame an unvisited site belongs to, for gc: the LARGEST of the model's sub-call site sets around site k that lies
+// strictly inside the frame (the whole schema, or the SITES of the call whose gc this is) — 0 when k is one of the frame's own leaves.
+// SUBS = the model type (sub_of(site): the innermost call's sites; outer_of(site), models with two levels: the call around that one).
+template <class SUBS, class = void>
+struct mp_fn_subs_outer { static constexpr uint64_t of(int) { return 0u; } };
+template <class SUBS>
+struct mp_fn_subs_outer<SUBS, std::void_t<decltype(SUBS::outer_of(0))>> { static constexpr uint64_t of(int k) { return SUBS::outer_of(k); } };
+template <class SUBS>
+constexpr uint64_t mp_fn_child_call(int k, uint64_t frame) {
+    const uint64_t outer = mp_fn_subs_outer<SUBS>::of(k), inner = SUBS::sub_of(k);
+    if (outer && (outer & ~frame) == 0u && outer != frame) return outer;
+    if (inner && (inner & ~frame) == 0u && inner != frame) return inner;
+    return 0u;
+}
+
+template <int NS, int MODE, class SUBS = void>
 struct mp_fn_handler {
     static_assert(NS <= MP_FN_MAX_SITES, "site ids are bits of a 64-bit word at most");
     using bits_t = mp_fn_bits_t<NS>;
@@ -317,13 +334,35 @@ struct mp_fn_handler {
         at_k<SITE, 2>(mp_fn_mvnormal2{{mu[0], mu[1]}, {cov_inv[0], cov_inv[1], cov_inv[2], cov_inv[3]}, ln_det, chol[0], chol[2], chol[3]}, out);
     }
 
-    // previous choices of `sites` that this visit did not reach: they leave the trace; their log-densities in site order
-    MP_HD double collect(bits_t sites) {
+    // previous choices of the frame FRAME (a call's SITES, or everything) that this visit did not reach: they leave the trace.  What
+    // leaves is what `Trie::collect` removes (trie.rs:222-246): the frame's own unvisited leaves, each with its log-density, and — round 5 —
+    // every sub-call of the frame that the body did not enter at all, as ONE term: that sub-trie's RUNNING weight (`self.weight -=
+    // sub.weight`, trie.rs:161-184; the history of its inserts and removes, kept in subw[its lowest site]), not a fresh sum of its
+    // leaves' log-densities — the same real number, other last bits once the sub-trie has a history.  (A sub-call that was entered closed
+    // with a gc of its own, which marked what it took: an unvisited site inside a sub-call means the whole call was skipped.)  Whole
+    // sub-calls first, then leaves, each in site order.
+    template <uint64_t FRAME>
+    MP_HD double collect() {
+        constexpr bits_t sites = (bits_t)FRAME;
         const bits_t un = prev->present & sites & ~visited;
         double c = 0.;
+        bits_t leaves = un;
+        if constexpr (!std::is_void<SUBS>::value) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const bits_t X = (bits_t)mp_fn_child_call<SUBS>(k, FRAME);
+                if (X != 0u && (X & ((bits_t(1) << k) - 1u)) == 0u && ((X >> k) & 1u)) {   // k is the call's lowest site: where its running weight is kept
+                    if (un & X) {
+                        c += prev->subw[k];
+                        if (in_sub) sw -= prev->subw[k];   // trace.data.remove(addr) of the whole sub-trie
+                    }
+                    leaves &= ~X;
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NS; ++k)
-            if ((un >> k) & 1u) {
+            if ((leaves >> k) & 1u) {
                 c += prev->lp[k];
                 if (in_sub) sw -= prev->lp[k];   // collect removes them from the (sub-)trie
             }
@@ -414,7 +453,7 @@ struct mp_fn_handler {
             in_sub = true; sw = had ? prev->subw[ID] : 0.;
             auto r = body(*this);
             if (had) {
-                const double c = collect(SITES);
+                const double c = collect<SITES64>();
                 if constexpr (MODE == MP_FN_UPDATE) weight = weight - c;
             }
             const double w_new = sw;
@@ -429,11 +468,11 @@ struct mp_fn_handler {
     // the outer gc of update / regenerate (dyngenfn.rs:453-483); constraints nobody consumed are the reference's panic
     MP_HD void finish() {
         if constexpr (MODE == MP_FN_UPDATE) {
-            const double c = collect(~bits_t(0));
+            const double c = collect<~uint64_t(0)>();
             weight = weight - c;
             if (cons->present & ~consumed) panic = true;
         } else if constexpr (MODE == MP_FN_REGENERATE) {
-            (void)collect(~bits_t(0));
+            (void)collect<~uint64_t(0)>();
         } else if constexpr (MODE == MP_FN_GENERATE) {
             if (cons->present & ~consumed) panic = true;
         }

@@ -60,7 +60,7 @@ __device__ __forceinline__ void fn_load(const M& model, const mp_stream& s, u64 
         c.lp[k] = 0.;
         c.subw[k] = 0.;
     }
-    mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+    mp_fn_handler<M::NS, MP_FN_GENERATE, M> g(s, MP_DOM_MODEL, nullptr, &c);
     model(g);
     out = g.tr;
     if (data_lp) *data_lp = g.dlp;   // (declared data sites: their share of trace.logjp)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_regen(u64 n, uint32_t k0, uin
             mp_fn_bits_t<M::NS> m = (mp_fn_bits_t<M::NS>)mask.bits;
             if (mask.n_cycle > 0) m = mp_fn_bits_t<M::NS>(1) << mask.cycle[(iter0 - 1u + (uint32_t)it) % (uint32_t)mask.n_cycle];
             if (m == 0u) m = cur.present;   // mask.is_leaf(): the whole schema (dyngenfn.rs:571)
-            mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
+            mp_fn_handler<M::NS, MP_FN_REGENERATE, M> g(s, MP_DOM_MODEL, &cur, nullptr, m);
             model(g);
             g.finish();
             panic |= g.panic;
@@ -143,16 +143,16 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_mh(u64 n, uint32_t k0, uint32
         fn_load(model, s, i, n, vals, present, cur);
         for (int it = 0; it < n_iters; ++it) {
             s.step = iter0 + (uint32_t)it;
-            mp_fn_handler<M::NS, MP_FN_SIMULATE> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
+            mp_fn_handler<M::NS, MP_FN_SIMULATE, M> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
             proposal(p, cur);
             const double fwd = p.weight;
-            mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &cur, &p.tr);
+            mp_fn_handler<M::NS, MP_FN_UPDATE, M> g(s, MP_DOM_MODEL, &cur, &p.tr);
             model(g);
             g.finish();
             // the discard: the previous values of what update replaced or collected
             mp_fn_trace<M::NS> disc = cur;
             disc.present = g.discarded;
-            mp_fn_handler<M::NS, MP_FN_GENERATE> q(s, MP_DOM_PROPOSAL, nullptr, &disc);
+            mp_fn_handler<M::NS, MP_FN_GENERATE, M> q(s, MP_DOM_PROPOSAL, nullptr, &disc);
             proposal(q, g.tr);
             q.finish();
             panic |= g.panic | q.panic;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_update(u64 n, uint32_t k0, ui
         mp_fn_trace<M::NS> cur, c;
         fn_load(model, s, i, n, vals, present, cur);
         fn_cons<M::NS>(cs, cvals, cpresent, i, n, c);
-        mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &cur, &c);
+        mp_fn_handler<M::NS, MP_FN_UPDATE, M> g(s, MP_DOM_MODEL, &cur, &c);
         g.changed = unknown != 0;   // ArgDiff::Unknown: every revisited choice is re-scored (dyngenfn.rs:180-190)
         model(g);
         g.finish();
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_regenerate(u64 n, uint32_t k0
         mp_fn_trace<M::NS> cur;
         fn_load(model, s, i, n, vals, present, cur);
         const mp_fn_bits_t<M::NS> m = mask ? (mp_fn_bits_t<M::NS>)mask : cur.present;   // mask.is_leaf(): the whole schema (dyngenfn.rs:571)
-        mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
+        mp_fn_handler<M::NS, MP_FN_REGENERATE, M> g(s, MP_DOM_MODEL, &cur, nullptr, m);
         g.changed = unknown != 0;
         model(g);
         g.finish();
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_assess(u64 n, uint32_t k0, ui
         s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
         mp_fn_trace<M::NS> c;
         fn_cons<M::NS>(cs, cvals, cpresent, i, n, c);
-        mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+        mp_fn_handler<M::NS, MP_FN_GENERATE, M> g(s, MP_DOM_MODEL, nullptr, &c);
         model(g);
         g.finish();
         panic = g.panic;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_generate(u64 n, uint32_t k0, 
         s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
         mp_fn_trace<M::NS> c;
         fn_cons<M::NS>(cs, cvals, cpresent, i, n, c);
-        mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+        mp_fn_handler<M::NS, MP_FN_GENERATE, M> g(s, MP_DOM_MODEL, nullptr, &c);
         model(g);
         g.finish();
         panic = g.panic;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_simulate(u64 n, uint32_t k0, 
     if (i >= n) return;
     mp_stream s;
     s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
-    mp_fn_handler<M::NS, MP_FN_SIMULATE> g(s, MP_DOM_MODEL, nullptr, nullptr);
+    mp_fn_handler<M::NS, MP_FN_SIMULATE, M> g(s, MP_DOM_MODEL, nullptr, nullptr);
     model(g);
     fn_store<M>(g.tr, i, n, vals, present);
     w_out[i] = g.weight;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_propose(u64 n, uint32_t k0, u
     s.k0 = k0; s.k1 = k1; s.slot = (uint32_t)i; s.step = step;
     mp_fn_trace<M::NS> cur;
     fn_load(model, s, i, n, vals, present, cur);
-    mp_fn_handler<M::NS, MP_FN_SIMULATE> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
+    mp_fn_handler<M::NS, MP_FN_SIMULATE, M> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
     proposal(p, cur);
     w_out[i] = p.weight;
     fn_emit<M::NS>(p.tr, p.tr.present, i, n, cvals_out, cpresent_out);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(MH_THREADS) void k_fn_assess_proposal(u64 n, uint32
         mp_fn_trace<M::NS> cur, c;
         fn_load(model, s, i, n, vals, present, cur);
         fn_cons<M::NS>(cs, cvals, cpresent, i, n, c);
-        mp_fn_handler<M::NS, MP_FN_GENERATE> q(s, MP_DOM_PROPOSAL, nullptr, &c);
+        mp_fn_handler<M::NS, MP_FN_GENERATE, M> q(s, MP_DOM_PROPOSAL, nullptr, &c);
         proposal(q, cur);
         q.finish();
         panic = q.panic;

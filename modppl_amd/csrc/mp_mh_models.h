@@ -124,12 +124,13 @@ struct mp_hier_data_fn {
     const double* xs;   // [n_obs] the design (params), ...
     const double* ys;   // [n_obs] ... the observed values: shared arrays in the handle's memory space (bind)
     double ln_noise;    // mp_log(0.1)
+    double rcp_noise;   // mp_rcp_hoist(0.1): an observation's (y - mu) / 0.1 without a division, same bits
     struct latents { bool lin; double a, b, c; };
     template <class V>
     MP_HD latents latents_of(const V& v) const { return latents{v.val[IS_LINEAR] != 0., v.val[A], v.val[B], v.val[C]}; }
     MP_HD mp_fn_normal datum(int j, const latents& l) const {
         const double x = xs[j];
-        return mp_fn_normal{l.lin ? l.a + l.b * x : l.a + l.b * x + l.c * x * x, 0.1, ln_noise};   // hierarchical.rs:38 / :43
+        return mp_fn_normal{l.lin ? l.a + l.b * x : l.a + l.b * x + l.c * x * x, 0.1, ln_noise, rcp_noise};   // hierarchical.rs:38 / :43
     }
     MP_HD double obs(int j) const { return ys[j]; }
     void bind(const double* cov, const double* obs_) { xs = cov; ys = obs_; }
@@ -151,6 +152,7 @@ inline bool mp_parse_hier_data_fn(const double* params, int n_params, mp_hier_da
     m.n_obs = n_params;
     m.xs = nullptr; m.ys = nullptr;
     m.ln_noise = mp_log(0.1);
+    m.rcp_noise = mp_rcp_hoist(0.1);
     return true;
 }
 MP_REGISTER_MH_MODEL(105, mp_hier_data_fn, mp_parse_hier_data_fn)

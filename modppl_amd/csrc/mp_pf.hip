@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "../../include/modppl_hip.h"
+#include "mp_diag.h"
 #include "mp_linalg.h"
 // models register themselves (mp_models.h, MP_REGISTER_UNFOLD_MODEL): here a registration creates the device factory
 template <class M>
@@ -88,7 +89,7 @@ static size_t table_lds(int nt, int threads) {  // s_incl[nt] + s_W[nt] + s_red 
 // (can_draw) and the launch shape come from this one value — read at two different times they could disagree, and a kernel
 // that cannot draw would be handed draws to make
 static int k1_threads_override() {
-    static const int v = [] { const char* e = getenv("MP_K1_THREADS"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = mp_diag_env("MP_K1_THREADS"); return e ? atoi(e) : 0; }();
     return v;
 }
 
@@ -177,7 +178,7 @@ struct ModelOpsT : ModelOps {
         if constexpr (std::is_same<Model, mp_lgssm_dense<16>>::value) {
             // the dense transition's products on the matrix cores (k_propagate_dense16); MP_DENSE_MFMA=0 keeps the scalar
             // interpretation of the same functor (same bits)
-            static const bool mfma = [] { const char* e = getenv("MP_DENSE_MFMA"); return !(e && e[0] == '0'); }();
+            static const bool mfma = [] { const char* e = mp_diag_env("MP_DENSE_MFMA"); return !(e && e[0] == '0'); }();
             if (mfma) {
                 hipLaunchKernelGGL(a.walk_bisect ? k_propagate_dense16<true> : k_propagate_dense16<false>, dim3(a.grid), dim3(DENSE_THREADS), 0, a.stream, model, a.n, a.slot_offset, a.k0, a.k1, a.t, a.x_in,
                                    a.x_out, a.logw, a.obs, a.overwrite, a.dfr_row, a.dfr_lt, a.cx_old, a.cx, a.guide, a.tile_m, a.tile_W, a.tile_W2, a.aux,
@@ -952,28 +953,28 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     if (h->k3_grid > K3_MAX_BLOCKS) h->k3_grid = K3_MAX_BLOCKS;
     h->nchunks = (int)((n + DRAW_CHUNK - 1) / DRAW_CHUNK);
     {
-        const char* env = getenv("MP_DEFERRED_LOOKUPS");
+        const char* env = mp_diag_env("MP_DEFERRED_LOOKUPS");
         if (env && env[0] == '0') h->use_deferred = 0;
-        env = getenv("MP_K1_TABLE");
+        env = mp_diag_env("MP_K1_TABLE");
         if (env && env[0] == '0') h->use_k1_table = 0;
-        env = getenv("MP_FUSED_DRAWS");
+        env = mp_diag_env("MP_FUSED_DRAWS");
         if (env && env[0] == '0') h->use_fused_draws = 0;
-        env = getenv("MP_WALK_BISECT");
+        env = mp_diag_env("MP_WALK_BISECT");
         if (env && (env[0] == '0' || env[0] == '1')) h->walk_bisect_force = env[0] - '0';
-        env = getenv("MP_SHARD_SELF");
+        env = mp_diag_env("MP_SHARD_SELF");
         if (env && env[0] == '0') h->use_shard_self = 0;
-        env = getenv("MP_K1_MT");
+        env = mp_diag_env("MP_K1_MT");
         if (env && env[0] == '0') h->use_k1_mt = 0;
         HIPCK(hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device));
-        env = getenv("MP_K1_LAZY");
+        env = mp_diag_env("MP_K1_LAZY");
         if (env && env[0] == '0') h->use_lazy = 0;
-        env = getenv("MP_K1_MT_GRID");   // (A/B measurements: another number of workgroups)
+        env = mp_diag_env("MP_K1_MT_GRID");   // (A/B measurements: another number of workgroups)
         if (env && atoi(env) > 0) h->cus = atoi(env);
-        env = getenv("MP_K1_MT_FLAGS");  // (A/B measurements: MP_MT_SKIP_* for every launch — results of reads are then undefined)
+        env = mp_diag_env("MP_K1_MT_FLAGS");  // (A/B measurements: MP_MT_SKIP_* for every launch — results of reads are then undefined)
         if (env) h->mt_flags = atoi(env);
         // kernels that make their draws themselves build the job's tile table themselves too (MP_K1_LOCAL_TABLE=0: the last
         // workgroup of every level-0 launch builds it, as for every other kernel)
-        env = getenv("MP_K1_LOCAL_TABLE");
+        env = mp_diag_env("MP_K1_LOCAL_TABLE");
         h->local_table = !h->sharded && h->use_k1_table && h->use_fused_draws && h->use_deferred && h->ops->can_draw && h->nt <= 2048 &&
                          !(h->flags & MP_PF_RECORD_HISTORY) && !(env && env[0] == '0');
     }
@@ -1028,7 +1029,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     init.ess_stale = 1.0 / (double)h->n_global;  // exp(-logsumexp(zeros)) before any resample
     HIPCK(hipHostGetDevicePointer((void**)&init.host_flag, h->h_flag, 0));
     {
-        const char* env = getenv("MP_HOST_MIRROR");
+        const char* env = mp_diag_env("MP_HOST_MIRROR");
         if (env && env[0] == '0') h->use_mirror = 0;
     }
     if (!h->sharded && h->use_mirror) {   // (sharded handles fold, undo and re-fold through mp_pf_shard_*: they keep the copy)
@@ -1101,7 +1102,7 @@ static int32_t launch_draws(mp_pf* h, int32_t scheme, uint32_t rc) {
         const double* ratio = tabmode ? (const double*)h->tab_ratio : nullptr;
         const mp_tab_head* head = tabmode ? (const mp_tab_head*)h->tab_head : nullptr;
         // (two workgroups per CU when the table is copied to LDS; the L2-probing form has no table to amortise)
-        static const int draw_wgs = [] { const char* e = getenv("MP_DRAW_WGS"); return e ? atoi(e) : 512; }();
+        static const int draw_wgs = [] { const char* e = mp_diag_env("MP_DRAW_WGS"); return e ? atoi(e) : 512; }();
         // (measured: 2^22 particles / 2048 tiles 55 -> 45 us; at 1024 tiles one workgroup per chunk is the faster form, 26 against 29 us)
         const int draw_grid = (tabmode == 2 || h->nt <= 1024) ? h->nchunks : std::min(h->nchunks, std::max(1, draw_wgs));
 #define MP_LAUNCH_DRAW(TM, SC)                                                                                                              \
@@ -1533,11 +1534,11 @@ static void launch_shard_table(mp_pf* h, const u64* d_tiles_all, int world, unsi
                                u64* kthr, const mp_own_plan_args* plan = nullptr) {
     const mp_own_plan_args pa = plan ? *plan : mp_own_plan_args{};
     const int do_plan = plan ? 1 : 0;
-    static const bool one_wg = getenv("MP_SHARD_TABLE_ONE_WG") && atoi(getenv("MP_SHARD_TABLE_ONE_WG")) != 0;   // A/B
+    static const bool one_wg = mp_diag_env("MP_SHARD_TABLE_ONE_WG") && atoi(mp_diag_env("MP_SHARD_TABLE_ONE_WG")) != 0;   // A/B
     // (measured, 512 tiles per rank: one workgroup 8.3 us up to 4 ranks and 16.9 us at 8; one per rank 9.8 - 10.8 us at 2 .. 8)
     // (MP_SHARD_TABLE_MW_TILES: the job size from which one workgroup per rank builds the table — tests lower it to reach that
     // kernel with a few thousand particles)
-    const char* mw_env = getenv("MP_SHARD_TABLE_MW_TILES");   // (read per call: a resample, not a hot loop)
+    const char* mw_env = mp_diag_env("MP_SHARD_TABLE_MW_TILES");   // (read per call: a resample, not a hot loop)
     const size_t mw_tiles = mw_env ? (size_t)atoll(mw_env) : (size_t)2048;
     if (world > 1 && !one_wg && (size_t)world * (size_t)h->nt > mw_tiles) {
         h->sh_tab_seq += (unsigned)world;
@@ -1648,7 +1649,7 @@ static void owned_free(mp_pf* h) {
 // super-chunk shape of one resample: the multinomial draws of a rank are spread over all N draws, so a workgroup takes
 // min(world, 4) rounds of 1024 to collect ~1024 own ones; under a lattice scheme a rank's own draws are one contiguous range
 static void owned_shape(mp_pf* h, int world, int scheme) {
-    static const int r_env = getenv("MP_OWN_ROUNDS") ? atoi(getenv("MP_OWN_ROUNDS")) : 0;   // A/B
+    static const int r_env = mp_diag_env("MP_OWN_ROUNDS") ? atoi(mp_diag_env("MP_OWN_ROUNDS")) : 0;   // A/B
     h->ow_R = scheme ? 1 : (r_env > 0 ? std::min(r_env, mp_own_rounds(world)) : mp_own_rounds(world));
     const u64 Wd = (u64)h->ow_R * OWN_ROUND;
     h->ow_nsc = (int)((h->n_global + Wd - 1) / Wd);
@@ -1830,7 +1831,7 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
         // lattice: a rank's own draws are ~n consecutive ones, wherever they start: that many workgroups (a rank that owns more takes turns)
         // multinomial: resident workgroups (3 per CU with the 44 KB of LDS at R = 4) take turns over the super-chunks, so the LDS table is
         // filled once per workgroup and the per-rank counts leave as `world` atomics per workgroup
-        static const int mn_wgs = getenv("MP_OWN_WGS") ? atoi(getenv("MP_OWN_WGS")) : 768;
+        static const int mn_wgs = mp_diag_env("MP_OWN_WGS") ? atoi(mp_diag_env("MP_OWN_WGS")) : 768;
         const int own_wgs = scheme ? (int)std::min<u64>((u64)h->ow_nsc, 2 * ((h->n + OWN_ROUND - 1) / OWN_ROUND) + 2) : std::min(h->ow_nsc, mn_wgs);
         h->ow_wgs = own_wgs;
         hipLaunchKernelGGL(kern, dim3(own_wgs), dim3(OWN_THREADS), lds, h->stream, h->n, h->n_global, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),

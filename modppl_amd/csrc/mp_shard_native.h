@@ -64,10 +64,10 @@ static int32_t shard_native_init(mp_pf* h, int world) {
     // count plus the imbalance of the shard masses, both O(sqrt n): sd ~ sqrt(2 n) = 1400 rows at 2^20 particles per rank, so
     // 8192 rows per pair is ~6 sigma; a pair that needs more falls back once (exact sizes) and the capacity doubles.
     uint64_t cap = std::max<uint64_t>(4096, h->n / 128);
-    if (const char* e = getenv("MP_SHARD_OWNED_CAP")) { cap = strtoull(e, nullptr, 10); s->cap_forced = true; }   // tests: force the overflow path
+    if (const char* e = mp_diag_env("MP_SHARD_OWNED_CAP")) { cap = strtoull(e, nullptr, 10); s->cap_forced = true; }   // tests: force the overflow path
     cap = std::min<uint64_t>(cap, h->n);
-    if (const char* e = getenv("MP_SHARD_OWNED_FIXED_MAX_BYTES")) s->fixed_max_bytes = strtoull(e, nullptr, 10);
-    if (const char* e = getenv("MP_SHARD_FIXED")) s->fixed = e[0] != '0';
+    if (const char* e = mp_diag_env("MP_SHARD_OWNED_FIXED_MAX_BYTES")) s->fixed_max_bytes = strtoull(e, nullptr, 10);
+    if (const char* e = mp_diag_env("MP_SHARD_FIXED")) s->fixed = e[0] != '0';
     // The equal-split all-to-all moves `cap` rows to every peer whatever the surplus is: fine for 16-byte rows, not for wide
     // states whose shard masses differ by percents; beyond this many padded bytes per rank the exchange uses exact sizes
     // (one host round trip per resample, a few percent of such a step).

@@ -302,7 +302,7 @@ struct MhFnStaticT : MhFnStatic {
         tr.resize(n_chains);
         for (size_t i = 0; i < tr.size(); ++i) {   // k_fn_init
             const mp_stream s = stream(i, 0);
-            mp_fn_handler<M::NS, MP_FN_GENERATE> g(s, MP_DOM_MODEL, nullptr, &c);
+            mp_fn_handler<M::NS, MP_FN_GENERATE, M> g(s, MP_DOM_MODEL, nullptr, &c);
             model(g);
             g.finish();
             n_panic += g.panic;
@@ -320,7 +320,7 @@ struct MhFnStaticT : MhFnStatic {
                 const mp_stream s = stream(i, (uint32_t)(iters + 1 + (uint64_t)it));
                 bits_t m = (cycle && n_mask > 0) ? bits_t(1) << mask_sites[(iters + (uint64_t)it) % (uint64_t)n_mask] : bits;
                 if (m == 0u) m = cur.present;
-                mp_fn_handler<M::NS, MP_FN_REGENERATE> g(s, MP_DOM_MODEL, &cur, nullptr, m);
+                mp_fn_handler<M::NS, MP_FN_REGENERATE, M> g(s, MP_DOM_MODEL, &cur, nullptr, m);
                 model(g);
                 g.finish();
                 n_panic += g.panic;
@@ -339,15 +339,15 @@ struct MhFnStaticT : MhFnStatic {
             mp_fn_trace<M::NS> cur = tr[i];
             for (int it = 0; it < n_iters; ++it) {
                 const mp_stream s = stream(i, (uint32_t)(iters + 1 + (uint64_t)it));
-                mp_fn_handler<M::NS, MP_FN_SIMULATE> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
+                mp_fn_handler<M::NS, MP_FN_SIMULATE, M> p(s, MP_DOM_PROPOSAL, nullptr, nullptr);
                 proposal(p, cur);
                 const double fwd = p.weight;
-                mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &cur, &p.tr);
+                mp_fn_handler<M::NS, MP_FN_UPDATE, M> g(s, MP_DOM_MODEL, &cur, &p.tr);
                 model(g);
                 g.finish();
                 mp_fn_trace<M::NS> disc = cur;
                 disc.present = g.discarded;
-                mp_fn_handler<M::NS, MP_FN_GENERATE> q(s, MP_DOM_PROPOSAL, nullptr, &disc);
+                mp_fn_handler<M::NS, MP_FN_GENERATE, M> q(s, MP_DOM_PROPOSAL, nullptr, &disc);
                 proposal(q, g.tr);
                 q.finish();
                 n_panic += (g.panic || q.panic);
@@ -371,7 +371,7 @@ struct MhFnStaticT : MhFnStatic {
         for (int q = 0; q < n_cons; ++q) { c.present |= mp_fn_bits_t<M::NS>(1) << sites[q]; c.val[sites[q]] = vals[q]; }
         for (size_t i = 0; i < tr.size(); ++i) {
             const mp_stream s = stream(i, step);
-            mp_fn_handler<M::NS, MP_FN_UPDATE> g(s, MP_DOM_MODEL, &tr[i], &c);
+            mp_fn_handler<M::NS, MP_FN_UPDATE, M> g(s, MP_DOM_MODEL, &tr[i], &c);
             g.changed = unknown != 0;
             model(g);
             g.finish();

@@ -206,3 +206,27 @@ def test_every_host_kernel_stub_has_device_code(tmp_path):
         device |= {ln.split()[-1] for ln in syms.splitlines() if " FUNC " in ln}
     missing = sorted(stubs - device)
     assert not missing, "host stubs without device code: %s" % missing[:5]
+
+
+def test_the_product_library_reads_no_environment_switch():
+    """Round 4's review: twenty getenv("MP_...") A/B and test switches lived in the library a host links.  They are in the DIAGNOSTICS
+    build only now (csrc/mp_diag.h: mp_diag_env is a constant null without -DMP_DIAGNOSTICS): no product source calls getenv, and the
+    switch names are not even strings of libmodppl_hip.so, while libmodppl_hip_diag.so — same sources, -DMP_DIAGNOSTICS — has them."""
+    import re
+    import subprocess
+
+    from modppl_amd import build as B
+
+    csrc = os.path.join(os.path.dirname(B.__file__), "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")) and f != "mp_diag.h":
+            src = open(os.path.join(csrc, f)).read()
+            assert not re.search(r"(?<![A-Za-z_])getenv\s*\(", src), f
+    B.build()
+    B.build_diag()
+    names = [b"MP_K1_MT_FLAGS", b"MP_DEFERRED_LOOKUPS", b"MP_FUSED_DRAWS", b"MP_WALK_BISECT", b"MP_SHARD_OWNED_CAP", b"MP_HOST_MIRROR"]
+    prod = subprocess.run(["strings", B.SO], capture_output=True).stdout
+    diag = subprocess.run(["strings", B.SO_DIAG], capture_output=True).stdout
+    for n in names:
+        assert n not in prod, n
+        assert n in diag, n

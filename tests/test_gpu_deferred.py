@@ -99,7 +99,7 @@ def test_reads_between_resample_and_step_do_not_disturb_the_step():
     assert np.array_equal(pf.log_weights, ref.log_weights())
 
 
-def test_draws_made_by_the_step_equal_draws_made_by_the_resample(monkeypatch):
+def test_draws_made_by_the_step_equal_draws_made_by_the_resample(monkeypatch, diag):
     """An asynchronous multinomial resample of a filter whose k_propagate can draw (two adjacent slots per lane, d = 1) enqueues
     nothing: the next step makes the draws for its own slots.  MP_FUSED_DRAWS=0 (read at creation) keeps the k_draw_slots
     launch.  Same Philox blocks, same targets, same walk: every value must agree, bit for bit, and with the checker."""
@@ -147,7 +147,7 @@ def _wide_case(name, T):
 
 @pytest.mark.parametrize("name,n", [("bearings", 70001), ("band4", 70001), ("band2", 70001), ("spiral", 70001),
                                     ("bearings", (1 << 21) + 4096 + 7), ("band2", (1 << 22))])
-def test_wide_models_draw_for_themselves_too(name, n, monkeypatch):
+def test_wide_models_draw_for_themselves_too(name, n, monkeypatch, diag):
     """Every kernel whose lanes own two adjacent slots (1024 threads per 2048-slot tile: d <= 4, at most four normal sites) makes
     the previous resample's draws itself, up to 2048 tiles (two table entries per thread beyond 1024: the TAB2 instantiation).
     Against MP_FUSED_DRAWS=0 (k_draw_slots + the deferred lookups): same Philox blocks, same targets, same walk — parents, states,
@@ -179,7 +179,7 @@ def test_wide_models_draw_for_themselves_too(name, n, monkeypatch):
 @pytest.mark.parametrize("scheme", [1, 2])
 @pytest.mark.parametrize("name,n", [("lgssm1", 70001), ("lgssm1", 1 << 20), ("lgssm1", (1 << 21) + 2048), ("bearings", 70001), ("band2", 40000),
                                     ("bearings", (1 << 21) + 6144)])
-def test_lattice_draws_made_by_the_step(name, n, scheme, monkeypatch):
+def test_lattice_draws_made_by_the_step(name, n, scheme, monkeypatch, diag):
     """Systematic (1) and stratified (2) resampling, asynchronous: the next k_propagate makes these draws too (its LAT
     instantiation: targets from the lattice function, no Philox block per lane; both table forms).  Against
     MP_FUSED_DRAWS=0 (k_draw_slots<., scheme>) bit for bit, and for the LGSSM against the canonical checker; schemes alternate
@@ -269,7 +269,7 @@ def test_degenerate_population_on_the_fused_path():
 
 
 @pytest.mark.parametrize("n", [4097, 6143, 2048 * 5, 2048 * 6 + 1, 70001])
-def test_two_tiles_per_workgroup_kernel_at_small_sizes(monkeypatch, n):
+def test_two_tiles_per_workgroup_kernel_at_small_sizes(monkeypatch, n, diag):
     """k_propagate_mt (mp_pf_k1mt.h: one workgroup walks two tiles, row gathers under the other tile's arithmetic) is picked for
     jobs of at least two tiles per CU; MP_K1_MT_GRID=1 (read at creation) lowers that bar to two tiles, so that odd tile counts
     — a last workgroup without a second tile —, ragged last tiles and reads in every position meet it at sizes the checker
@@ -308,7 +308,7 @@ def test_two_tiles_per_workgroup_kernel_at_small_sizes(monkeypatch, n):
 
 
 @pytest.mark.parametrize("n", [2048 * 4 + 77, 2048 * 7])
-def test_log_weights_and_parents_left_out_by_the_step_are_reproduced_on_demand(monkeypatch, n):
+def test_log_weights_and_parents_left_out_by_the_step_are_reproduced_on_demand(monkeypatch, n, diag):
     """A drawing k_propagate_mt launch stores neither the log-weights nor the parents (round 5: `resample` zeroes the one and replaces
     the other, particle_filter.rs:109-114; 12 B per particle-step of dead stores in a step / resample loop).  Whoever reads them
     before the next resample gets them from a replay of that launch (mp_pf.hip ensure_lazy, MP_MT_REPLAY): every way of reaching that —
@@ -358,7 +358,7 @@ def test_log_weights_and_parents_left_out_by_the_step_are_reproduced_on_demand(m
 
 
 @pytest.mark.parametrize("n", [2048 * 4 + 77, 1 << 20])
-def test_run_owns_the_loop_and_skips_the_dead_stores(monkeypatch, n):
+def test_run_owns_the_loop_and_skips_the_dead_stores(monkeypatch, n, diag):
     """mp_pf_run knows that a resample follows every step: its k_propagate_mt launches store neither the log-weights (zeroed by
     `resample`, particle_filter.rs:114) nor the parents of any resample but the last, which is still pending when it returns.
     Whatever is read afterwards — parents, states, (zero) log-weights, ESS, log-ML, a further step — equals the checker's loop."""
@@ -390,7 +390,7 @@ def test_run_owns_the_loop_and_skips_the_dead_stores(monkeypatch, n):
 
 @pytest.mark.parametrize("force", [None, "0", "1"])
 @pytest.mark.parametrize("scheme", [0, 1, 2])
-def test_collapsed_weights_one_double_state(monkeypatch, scheme, force):
+def test_collapsed_weights_one_double_state(monkeypatch, scheme, force, diag):
     """An observation noise of 1e-4 leaves ONE particle with all the weight: every draw lands in one tile, a thousand of them start in
     the guide cell that holds the light rows in front of the heavy one and walk up to two thousand rows.  The propagate kernels have
     an instantiation whose long walks finish by bisection (k_propagate<…, WALKB>, k_propagate_mt<…, true>): the default for these
@@ -426,7 +426,7 @@ def test_collapsed_weights_one_double_state(monkeypatch, scheme, force):
 
 
 @pytest.mark.parametrize("scheme", [0, 1, 2])
-def test_collapsed_weights_single_kernel_resampler(monkeypatch, scheme):
+def test_collapsed_weights_single_kernel_resampler(monkeypatch, scheme, diag):
     """MP_DEFERRED_LOOKUPS=0: k_resample_gather (also the kernel behind importance_resampling) with ONE particle carrying the weight —
     its long row walks finish by bisection and its tile walk is budgeted; same parents as the checker's binary searches."""
     import modppl_amd

@@ -152,7 +152,7 @@ def lockstep_dense(n, T, seed, singular_q=False, resample_every=1):
 
 
 @pytest.mark.parametrize("mfma", ["1", "0"])
-def test_dense_lgssm_lockstep_bit_exact(monkeypatch, mfma):
+def test_dense_lgssm_lockstep_bit_exact(monkeypatch, mfma, diag):
     """d = 16 dense transition: the matrix-core kernel (MP_DENSE_MFMA=1, default) and the scalar handler form (=0) both equal
     the canonical checker bit for bit — states, log-weights, parents, log total weight, log-ML.  3000 particles: a ragged
     last tile; 2048 + 64: a tile with one 64-particle round."""

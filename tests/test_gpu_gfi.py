@@ -129,6 +129,23 @@ def test_gfi_calls_against_the_dynamic_interpretation(kind):
     assert np.allclose(g.assess((tv, tp), rng_step=step), g.logjp(), rtol=1e-13, atol=1e-12)
 
 
+def test_a_sub_call_skipped_on_a_later_visit_leaves_with_its_running_weight_on_the_device():
+    """kind 112 (modppl/tests/dyngenfn.rs:44-53), b flipped true -> false -> true -> false through mp_fn_update with the sub-trace given
+    a history in between: the enclosing gc removes a sub-call the body no longer reaches with that sub-trie's RUNNING weight
+    (trie.rs:161-184, dyngenfn.rs:454-470), as the trie engine does — weights, discards and traces bit for bit (the CPU suite holds the
+    host-compiled handlers to the same script: tests/test_oracle_mh_functor.py)."""
+    n, seed = 3000, 3
+    g, r = _pair(112, [], {0: 1.0}, n, seed)
+    _same_trace(g, r)
+    script = [({1: 0.7}, 1), ({2: -0.4}, 0), ({0: 0.0}, 0), ({0: 1.0}, 0), ({3: 1.9}, 1), ({0: 0.0}, 1), ({0: 1.0}, 1), ({1: 0.1, 3: -0.2}, 0), ({0: 0.0}, 0)]
+    for k, (cons, diff) in enumerate(script):
+        gw, (gdv, gdp) = g.update(cons, argdiff=diff, rng_step=20 + k)
+        rw, (rdv, rdp) = r.update(cons, argdiff=diff, rng_step=20 + k)
+        assert np.array_equal(gw, rw), (k, cons, diff)
+        assert np.array_equal(gdp, rdp) and np.array_equal(gdv, rdv)
+        _same_trace(g, r)
+
+
 def test_hand_composed_mh_equals_mp_mh_step():
     import modppl_amd
 

@@ -173,7 +173,7 @@ def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme, tail):
 
 
 @pytest.mark.parametrize("scheme", [1, 2])
-def test_lattice_schemes_window_form_still_agrees(monkeypatch, scheme):
+def test_lattice_schemes_window_form_still_agrees(monkeypatch, scheme, diag):
     """MP_SHARD_SELF=0: the lattice schemes through k_shard_own_draw / _plan / _place (round 3's form, kept for A/B) — the same
     offspring in the same slots as the self-drawn form and the checker"""
     monkeypatch.setenv("MP_SHARD_SELF", "0")
@@ -195,7 +195,7 @@ def test_lattice_schemes_window_form_still_agrees(monkeypatch, scheme):
 
 
 @pytest.mark.parametrize("world,scheme", [(2, 0), (5, 0), (8, 0), (5, 3), (8, 1)])
-def test_table_by_one_workgroup_per_rank_at_small_sizes(monkeypatch, world, scheme):
+def test_table_by_one_workgroup_per_rank_at_small_sizes(monkeypatch, world, scheme, diag):
     """k_shard_table_mw (one workgroup per rank; the library picks it beyond 2048 tiles per job) forced at a few thousand
     particles: L, counts, parents and the STALE ESS — i.e. Q2, summed over the ranks' partial sums by wave 0 with fewer than 64
     ranks active — against the checker (the sum read an inactive lane)."""
@@ -274,7 +274,7 @@ def test_self_drawn_resample_in_a_world_of_one_is_the_single_filter(scheme, exch
 
 @pytest.mark.parametrize("d", [1, 16])
 @pytest.mark.parametrize("sync", [True, False])
-def test_owner_keeps_exact_size_policy_in_a_world_of_one(monkeypatch, d, sync):
+def test_owner_keeps_exact_size_policy_in_a_world_of_one(monkeypatch, d, sync, diag):
     """MP_SHARD_OWNED_FIXED_MAX_BYTES below the padded buffer size: the exchange takes the exact-size path (host-read counts,
     grow-only cached buffers); in a world of one it still is the single filter, wide states included (kept offspring have no rows)."""
     import modppl_amd
@@ -397,7 +397,9 @@ def test_owner_keeps_through_process_groups(tmp_path, which, nproc, extra):
     splits, a capacity of 8 rows per pair (every resample overflows and falls back to exact sizes), exact sizes by policy."""
     script = tmp_path / "worker.py"
     script.write_text(NCCL_WORKER if which == "nccl" else GLOO_WORKER)
-    env = dict(os.environ, MP_ROOT=ROOT, OMP_NUM_THREADS="2", **extra)
+    from tests.conftest import diag_env
+
+    env = diag_env(dict(os.environ, MP_ROOT=ROOT, OMP_NUM_THREADS="2", **extra))
     if which == "nccl":
         env["MP_SHARD_ALWAYS_COLLECTIVE"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",

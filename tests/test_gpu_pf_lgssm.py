@@ -41,7 +41,7 @@ def test_lockstep_bit_exact_vs_canonical(n):
 
 
 @pytest.mark.parametrize("scheme", [0, 1])
-def test_single_kernel_resampler_mode_lockstep(monkeypatch, scheme):
+def test_single_kernel_resampler_mode_lockstep(monkeypatch, scheme, diag):
     """MP_DEFERRED_LOOKUPS=0 (a supported A/B mode: k_resample_gather draws, looks up and clones in one launch) with dim_state 1,
     whose states otherwise live in the row table only (the flag saying so survived that resample, and the next
     step read the PRE-resample rows).  step, resample, step, read_state against the checker, with and without reads in between."""

@@ -138,7 +138,9 @@ def test_rccl_collectives_world_of_one(tmp_path, mode):
     script = tmp_path / "worker.py"
     script.write_text(NCCL_WORKER)
     extra = {"fixed": {}, "fixed_overflow": {"MP_SHARD_CAP": "1000", "MP_EXPECT_FALLBACK": "1"}, "variable": {"MP_SHARD_FIXED": "0"}}[mode]
-    env = dict(os.environ, MP_ROOT=ROOT, MP_SHARD_ALWAYS_COLLECTIVE="1", **extra)
+    from tests.conftest import diag_env
+
+    env = diag_env(dict(os.environ, MP_ROOT=ROOT, MP_SHARD_ALWAYS_COLLECTIVE="1", **extra))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)

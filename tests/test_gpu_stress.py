@@ -93,7 +93,7 @@ def _random_program(rng, length):
 @pytest.mark.parametrize("rep", [0, 1, 2])
 @pytest.mark.parametrize("name,n,seed", [("lgssm1", 70001, 1), ("lgssm1", (1 << 20) + 4096 + 5, 2), ("lgssm1", (1 << 21) + 2048, 3),
                                          ("bearings", 50001, 4), ("band2", 2 * 2048 * 1024 + 2048, 5), ("spiral", 9000, 6)])
-def test_random_programs_fused_against_unfused(name, n, seed, rep, monkeypatch):
+def test_random_programs_fused_against_unfused(name, n, seed, rep, monkeypatch, diag):
     """The state machine around the draws a step may make for itself (pending scheme, flush on a read, synchronous resamples in
     between, both table forms, the lattice instantiation): a random program of steps, asynchronous / synchronous resamples of
     all three schemes and reads, run on a handle whose k_propagate draws and on one that always launches k_draw_slots

@@ -5,7 +5,8 @@
 # tools/collect_profiles.sh on the build side.
 set -u
 R=$PWD
-OUT=$R/gpurun_out/${1:-r04_prof}
+OUT=$R/gpurun_out/${1:-r05_prof}
+DIAG=$R/modppl_amd/csrc/libmodppl_hip_diag.so   # the A/B switches below exist in the diagnostics build only (csrc/mp_diag.h)
 mkdir -p $OUT
 # the content hash of the sources the library on THIS box was built from: tools/collect_profiles.sh refuses a run of another tree
 (cd $R && python3 -c "from modppl_amd import build as B; print(B.source_hash())") > $OUT/source_hash.txt
@@ -24,13 +25,13 @@ done
 cd $R && timeout -k 10 200 python3 tools/stamp_probe.py --raw $OUT/stamps.npy > $OUT/stamps.json 2> $OUT/stamps.err && python3 tools/stamp_report_mt.py $OUT/stamps.npy > $OUT/stamp_report.txt || echo "stamp probe failed"
 cd $R && MP_K1_MT=0 timeout -k 10 200 python3 tools/stamp_probe.py --raw $OUT/stamps_tile.npy > $OUT/stamps_tile.json 2> $OUT/stamps_tile.err && python3 tools/stamp_report.py $OUT/stamps_tile.npy > $OUT/stamp_report_tile_kernel.txt || echo "stamp probe (tile kernel) failed"
 # one tile pass against a tile's share of a CU, both forms of K1
-cd $R && { echo "# k_propagate_mt from two tiles per CU (default)"; timeout -k 10 300 python3 tools/k1_scaling.py; echo "# MP_K1_MT=0: k_propagate at every size"; MP_K1_MT=0 timeout -k 10 300 python3 tools/k1_scaling.py; } > $OUT/k1_scaling.txt 2>/dev/null || echo "k1_scaling failed"
+cd $R && { echo "# k_propagate_mt from two tiles per CU (default)"; timeout -k 10 300 python3 tools/k1_scaling.py; echo "# MP_K1_MT=0: k_propagate at every size"; MODPPL_HIP_LIB=$DIAG MP_K1_MT=0 timeout -k 10 300 python3 tools/k1_scaling.py; } > $OUT/k1_scaling.txt 2>/dev/null || echo "k1_scaling failed"
 # the same K = 200 bench with either form of K1, alternating (same box)
-cd $R && for i in 1 2 3; do for v in 1 0; do MP_K1_MT=$v timeout -k 10 200 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline --no-systematic-leg --repeats 3 2>/dev/null | python3 -c "
+cd $R && for i in 1 2 3; do for v in 1 0; do MODPPL_HIP_LIB=$DIAG MP_K1_MT=$v timeout -k 10 200 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline --no-systematic-leg --repeats 3 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); print('MP_K1_MT=$v', round(d['ms_per_step'] * 1e3, 2), 'us per step;', d['roofline']['kernel'], round(d['roofline']['kernel_us'], 2), 'us')"; done; done > $OUT/k1_forms_ab.txt || echo "k1 forms A/B failed"
 # the reference-shaped (synchronous) loop with and without the host-mapped mirror (MP_HOST_MIRROR=0: k_draw_slots + k_resolve_slots + a copy of the scalars per step, as in round 3)
-cd $R && for v in 1 0; do MP_HOST_MIRROR=$v timeout -k 10 300 python3 -c "
+cd $R && for v in 1 0; do MODPPL_HIP_LIB=$DIAG MP_HOST_MIRROR=$v timeout -k 10 300 python3 -c "
 import json, bench, modppl_amd
 ys = bench.lgssm_observations(80)
 r = bench.reference_shaped_loop(modppl_amd.lgssm_model(*bench.LGSSM_PARAMS), 1 << 20, ys, 50, 5)
