@@ -128,6 +128,9 @@ struct PropagateArgs {
                               // finish long walks by bisection (the WALKB instantiation)
     int mt_grid;              // > 0: a drawing launch may run as k_propagate_mt with this many workgroups (one per CU, several tiles each)
     int mt_flags;             // MP_MT_SKIP_* (mp_pf_k1mt.h)
+    unsigned int* peek_ticket;          // MP_MT_PEEK: the launch's last workgroup hands L / ESS of the NEW tile scalars to the host (mp_k1mt)
+    mp_host_mirror* peek_mirror;
+    unsigned long long peek_seq;
 };
 struct ModelOps {
     int dim_state = 0, dim_obs = 0;
@@ -198,6 +201,7 @@ struct ModelOpsT : ModelOps {
                 m.S = a.drw_v.S; m.flags = a.mt_flags; m.logw = a.logw; m.cx_old = a.cx_old; m.guide_old = a.drw_v.guide_old;
                 m.cx_new = a.cx; m.guide_new = a.guide; m.tm_new = a.tile_m_new; m.tW_new = a.tile_W_new; m.tW2_new = a.tile_W2_new;
                 m.parent = a.drw_v.parent; m.scal = a.drw_v.scal;
+                m.peek_ticket = a.peek_ticket; m.mirror = a.peek_mirror; m.peek_seq = a.peek_seq;
                 mp_obs_n<Model::DIM_OBS> ob;
                 for (int j = 0; j < Model::DIM_OBS; ++j) ob.v[j] = a.obs.v[j];
                 const int grid = (a.drw_v.nt + 1) / 2;   // two tiles per workgroup: b and b + grid
@@ -435,7 +439,9 @@ struct mp_pf {
     int* h_flag = nullptr;             // host-mapped: the device-side sticky error (mp_dev_scalars::host_flag points here)
     mp_host_mirror* h_mirror = nullptr;   // host-mapped: L / ESS / log-ML of every fold, and k_peek_level1's answers (mp_pf_kernels.h)
     mp_host_mirror* d_mirror = nullptr;   // its device address
-    unsigned long long peek_seq = 0;      // k_peek_level1 launches so far
+    unsigned long long peek_seq = 0;      // k_peek_level1 launches (and MP_MT_PEEK tails) so far
+    bool sync_loop = false;               // the last resample was synchronous (`L = resample()`): the next k_propagate_mt launch peeks for the one to come
+    bool peek_valid = false;              // ... and did: peek number peek_seq belongs to the current tile scalars
     int use_mirror = 1;                   // MP_HOST_MIRROR=0: synchronous calls copy mp_dev_scalars back as before (A/B measurements)
     // the draws of a multinomial resample, per output slot (k_draw_slots)
     u64* dfr_lt = nullptr;              // [n] tile-local target
@@ -797,6 +803,12 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
     a.mt_flags = h->mt_flags;
     const bool lazy = h->use_lazy && h->deferred && h->draw_pending && !h->pending_shard && h->pending_scheme == MP_RESAMPLE_MULTINOMIAL;
     if (lazy) a.mt_flags |= MP_MT_SKIP_LOGW | MP_MT_SKIP_PARENT;   // (read by k_propagate_mt only; below: whether that is what ran)
+    // The synchronous loop (`step; ESS; L = resample()`, tests/smc.rs:64-90): when the last resample was synchronous the next one will
+    // be — the launch's last workgroup computes its return value on the way out (mt_peek_tail: a ~3 us tail) instead of a k_peek_level1
+    // launch behind the step (a launch on an idle queue + a dependency gap)
+    const bool want_peek = h->sync_loop && h->d_mirror && h->tab_ticket && !h->sharded && h->local_table;
+    a.peek_ticket = nullptr; a.peek_mirror = nullptr; a.peek_seq = 0;
+    if (want_peek) { a.mt_flags |= MP_MT_PEEK; a.peek_ticket = h->tab_ticket; a.peek_mirror = h->d_mirror; a.peek_seq = h->peek_seq + 1; }
     // ... and made by it too, when the resample left them pending (kernels of two-slot lanes)
     a.drw = (h->deferred && h->draw_pending) ? (1 | (h->pending_scheme << 1)) : 0;   // bit 0: draw; bits 1..2: the scheme
     a.drw_v = mp_k1_draw{};
@@ -840,6 +852,8 @@ static int32_t launch_propagate(mp_pf* h, const double* args0, const double* obs
         h->lazy_pending = true;
         h->lazy_args = a;
     }
+    h->peek_valid = want_peek && h->last_k1_form == MP_K1_FORM_TWO_TILES;
+    if (h->peek_valid) h->peek_seq += 1;
     if (h->deferred) {   // the fresh table is the current one from here on; the old one stays intact for mp_pf_read_parents
         std::swap(h->cx, h->cx_alt);
         std::swap(h->guide, h->guide_alt);
@@ -894,6 +908,7 @@ static int32_t ensure_rows(mp_pf* h) {
     }
     h->table_fresh = tab_of(h).ticket != nullptr;
     h->rows_fresh = true;
+    h->peek_valid = false;   // (other tile scalars than the ones a k_propagate_mt tail peeked at)
     return check_launch("k_normalize_tiles");
 }
 
@@ -1023,7 +1038,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
     HIPCK(hipMemsetAsync(h->x[1], 0, sizeof(double) * n * d, h->stream));
     HIPCK(hipMemsetAsync(h->logw, 0, sizeof(double) * n, h->stream));
     HIPCK(hipMemsetAsync(h->parent, 0, sizeof(uint32_t) * n, h->stream));
-    HIPCK(hipHostMalloc(&h->h_flag, sizeof(int), hipHostMallocMapped));
+    HIPCK(hipHostMalloc(&h->h_flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     *h->h_flag = 0;
     mp_dev_scalars init{};
     init.ess_stale = 1.0 / (double)h->n_global;  // exp(-logsumexp(zeros)) before any resample
@@ -1033,7 +1048,7 @@ int32_t mp_pf_create(const mp_model_desc* model, uint64_t n_particles, uint64_t 
         if (env && env[0] == '0') h->use_mirror = 0;
     }
     if (!h->sharded && h->use_mirror) {   // (sharded handles fold, undo and re-fold through mp_pf_shard_*: they keep the copy)
-        HIPCK(hipHostMalloc(&h->h_mirror, sizeof(mp_host_mirror), hipHostMallocMapped));
+        HIPCK(hipHostMalloc(&h->h_mirror, sizeof(mp_host_mirror), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(h->h_mirror, 0, sizeof(mp_host_mirror));
         h->h_mirror->ess_stale = init.ess_stale;
         HIPCK(hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0));
@@ -1149,6 +1164,7 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
     if (h->sharded) return mp_fail(MP_ERR_STATE, "sharded handle: resample runs through the mp_pf_shard_* phases");
     HIPCK(hipSetDevice(h->device));
     h->lazy_pending = false;   // log_weights.fill(0.) and new parents (particle_filter.rs:109-114): what the last step did not store is dead
+    h->sync_loop = log_total_weight != nullptr;
     int32_t rc = ensure_rows(h);
     if (rc != MP_OK) return rc;
     h->parents_deferred = false;   // this resample's parents replace whatever was still waiting to be read
@@ -1226,11 +1242,14 @@ int32_t mp_pf_resample(mp_pf* h, int32_t scheme, double* log_total_weight) {
         // `resample() -> f64` without making the draws now: level 1 of the normalisation that is being resampled by one small
         // workgroup, its result in host-mapped memory; the draws, the lookups and the fold into log_ml happen inside the next
         // step's k_propagate as after an asynchronous resample (k_draw_slots + k_resolve_slots + a copy of the scalars before)
-        h->peek_seq += 1;
-        hipLaunchKernelGGL(k_peek_level1, dim3(1), dim3(1024), 0, h->stream, (const double*)h->tile_m, (const u64*)h->tile_W, (const u64*)h->tile_W2, h->nt, h->S,
-                           h->scal, h->d_mirror, h->peek_seq);
-        rc = check_launch("k_peek_level1");
-        if (rc != MP_OK) return rc;
+        if (!h->peek_valid) {   // (else: the step's own last workgroup has computed it, or is about to: mt_peek_tail)
+            h->peek_seq += 1;
+            hipLaunchKernelGGL(k_peek_level1, dim3(1), dim3(1024), 0, h->stream, (const double*)h->tile_m, (const u64*)h->tile_W, (const u64*)h->tile_W2, h->nt, h->S,
+                               h->scal, h->d_mirror, h->peek_seq);
+            rc = check_launch("k_peek_level1");
+            if (rc != MP_OK) return rc;
+        }
+        h->peek_valid = false;
         rc = wait_seq(h, &h->h_mirror->peek_seq, h->peek_seq, "resample");
         if (rc != MP_OK) return rc;
         if (h->h_mirror->peek_degenerate)
@@ -1497,7 +1516,7 @@ static int32_t shard_scratch(mp_pf* h, int world, u64 cap) {
     HIPCK(hipMemsetAsync(h->sh_overflow, 0, sizeof(int), h->stream));
     HIPCK(hipHostMalloc(&h->h_counts, sizeof(long long) * SH_MAX_WORLD));
     if (!h->h_pub) {
-        HIPCK(hipHostMalloc(&h->h_pub, sizeof(mp_shard_pub), hipHostMallocMapped));
+        HIPCK(hipHostMalloc(&h->h_pub, sizeof(mp_shard_pub), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(h->h_pub, 0, sizeof(mp_shard_pub));
         HIPCK(hipHostGetDevicePointer((void**)&h->d_pub, h->h_pub, 0));
         HIPCK(hipEventCreateWithFlags(&h->ev_resolved, hipEventDisableTiming));

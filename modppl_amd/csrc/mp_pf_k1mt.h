@@ -40,11 +40,18 @@ struct mp_k1mt {            // by value (kernel arguments)
     u64* tW2_new;
     uint32_t* parent;
     mp_dev_scalars* scal;
+    // MP_MT_PEEK (the caller's loop is synchronous: `L = resample()` follows, particle_filter.rs:103-116): the workgroup that finishes last
+    // folds level 1 of the tile scalars THIS launch wrote into the host-mapped mirror — what k_peek_level1 does as a launch of its own,
+    // without the launch, its dependency gap and its start on an idle queue
+    unsigned int* peek_ticket;
+    mp_host_mirror* mirror;
+    unsigned long long peek_seq;
 };
 constexpr int MP_MT_SKIP_LOGW = 1, MP_MT_SKIP_PARENT = 2;
 // MP_MT_REPLAY: the launch repeats an earlier one of the same arguments ONLY to produce what that one skipped — the log-weights and the
 // parents (mp_pf.hip ensure_lazy): nothing else is stored, nothing folded, no normalisation
 constexpr int MP_MT_REPLAY = 4;
+constexpr int MP_MT_PEEK = 8;
 
 // what a lane carries for one of its tiles between the stages of the pipeline
 struct mp_mt_tile {
@@ -402,9 +409,68 @@ __device__ __forceinline__ void mt_store_tile(const mp_k1mt& a, u64 tile, const 
         }
     }
     if (threadIdx.x == 0) {
-        mp_as_global(a.tm_new)[tile] = o.m;
-        mp_as_global(a.tW_new)[tile] = o.W;
-        mp_as_global(a.tW2_new)[tile] = o.W2;
+        if (a.flags & MP_MT_PEEK) {   // (read by another workgroup of THIS launch: agent-scope stores, mt_peek_tail)
+            mp_st_agent(mp_as_global(a.tm_new) + tile, o.m);
+            mp_st_agent(mp_as_global(a.tW_new) + tile, o.W);
+            mp_st_agent(mp_as_global(a.tW2_new) + tile, o.W2);
+        } else {
+            mp_as_global(a.tm_new)[tile] = o.m;
+            mp_as_global(a.tW_new)[tile] = o.W;
+            mp_as_global(a.tW2_new)[tile] = o.W2;
+        }
+    }
+}
+// MP_MT_PEEK: every workgroup takes a ticket once its tile scalars are out; the one whose ticket comes last computes level 1 of the NEW
+// tile scalars (k_peek_level1's arithmetic entry by entry: the same integer sums, the same L and ESS bits) and hands them to the host
+// through the mirror, sequence word last.  Nothing is folded into the filter's scalars: the resample's draws — and with them the fold
+// into log_ml — are still made by the next step's launch.
+__device__ __forceinline__ void mt_peek_tail(const mp_k1mt& a, int nt) {
+    __shared__ int s_last;
+    __shared__ double s_red[16];
+    __shared__ u64 s_q[16], s_q2[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's tile scalars are out before its ticket says so
+        const unsigned int t = __hip_atomic_fetch_add(a.peek_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;   // workgroup-uniform
+    const double* tm = mp_as_global(a.tm_new);
+    const u64 *tW = mp_as_global(a.tW_new), *tW2 = mp_as_global(a.tW2_new);
+    double m = MP_NEG_INF;
+    for (int b = tid; b < nt; b += 1024) m = fmax(m, mp_ld_agent(tm + b));
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll 1
+    for (int w = 1; w < 16; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + a.S - FIX_BITS) << 52);  // 2^(S-51)
+    u64 q = 0, q2 = 0;
+    for (int b = tid; b < nt; b += 1024) {
+        const double d = mp_ld_agent(tm + b) - m;
+        q += mp_quantize((double)mp_ld_agent(tW + b) * (ok ? mp_exp(d) : 0.) * sc, 1.0);
+        q2 += mp_quantize((double)mp_ld_agent(tW2 + b) * (ok ? mp_exp(2. * d) : 0.) * sc, 1.0);
+    }
+    q = wave_sum_u64(q);
+    q2 = wave_sum_u64(q2);
+    if (lane == 0) { s_q[wave] = q; s_q2[wave] = q2; }
+    __syncthreads();
+    if (tid == 0) {
+        u64 Q = 0, Q2 = 0;
+        for (int w = 0; w < 16; ++w) { Q += s_q[w]; Q2 += s_q2[w]; }
+        double L, ess;
+        finalize_scalars(Q, Q2, a.S, &L, &ess, m);
+        const int degenerate = (!ok || Q == 0) ? 1 : 0;
+        if (degenerate) mp_flag_degenerate(mp_as_global(a.scal));
+        mp_host_mirror* hm = a.mirror;
+        __hip_atomic_store(reinterpret_cast<u64*>(&hm->peek_L), mp_f2u(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<u64*>(&hm->peek_ess), mp_f2u(ess), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->peek_degenerate, degenerate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->peek_seq, a.peek_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.peek_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     }
 }
 // (MP_MT_REPLAY) only what the first launch of these arguments left out
@@ -587,6 +653,7 @@ __global__ __launch_bounds__(1024) void k_propagate_mt(const double* __restrict_
         __syncthreads();
         mt_store_guide(a, tileA, s_guideA);
     }
+    if ((a.flags & MP_MT_PEEK) && !replay) mt_peek_tail(a, pre_nt);   // (workgroup-uniform)
     MP_STAMP_L(4, 0); MP_STAMP_L(5, 1);
     MP_STAMP_L_FLUSH(0);
 }
