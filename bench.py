@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command;
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05", "traffic.json")  # tools/collect_traffic.py over the rocprofv3 --pmc passes of this command;
 # it carries the content hash of the kernel sources it was measured with: a summary of another build is refused
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 N_PER_GPU = 1 << 20
@@ -189,12 +189,33 @@ def sub_benches(steps, warmup, which):
             out["systematic_resampling"] = {"us_per_step": dts / steps * 1e6, "step_hbm_frac": b * n * steps / dts / 1e9 / HBM_PEAK_GBPS}
         return out
 
+    # The wide models' kernels are bound by VALU issue (sixteen polar normals per particle at d = 16), not by the bytes they move: next to
+    # step_hbm_frac each carries the share of the chip's VALU issue slots its propagate kernel uses — from the rocprofv3 --pmc passes of
+    # the profile round (profiles/r05/valu_issue.json, tools/collect_valu_issue.py), accepted only if they belong to THIS build
+    def valu_issue(kernel_substr):
+        try:
+            from modppl_amd import build as _b
+
+            vj = json.load(open(os.path.join(ROOT, "profiles", "r05", "valu_issue.json")))
+            if vj.get("_measured", {}).get("source_hash") != _b.source_hash():
+                return {"valu_issue_frac": None, "valu_issue_note": "profiles/r05/valu_issue.json is from another build"}
+            hits = [(k, v) for k, v in vj.items() if k != "_measured" and kernel_substr in k]
+            if not hits:
+                return {"valu_issue_frac": None, "valu_issue_note": "no kernel matching %r in profiles/r05/valu_issue.json" % kernel_substr}
+            k, v = max(hits, key=lambda kv: kv[1]["mean_launch_us"])
+            return {"valu_issue_frac": v["valu_issue_frac"], "valu_issue_kernel": k, "valu_issue_kernel_us": v["mean_launch_us"],
+                    "valu_issue_formula": vj["_measured"]["formula"], "bound": "VALU issue (instruction-bound: the bytes-based fraction measures the wrong resource)"}
+        except Exception as e:   # noqa: BLE001
+            return {"valu_issue_frac": None, "valu_issue_note": "no PMC summary for this build (%s)" % type(e).__name__}
+
     if "c3" in which:
         th = np.arctan2(1.0 + 0.05 * np.arange(T), 1.0 + 0.1 * np.arange(T)) + rng.normal(0, 0.02, T)
-        res["c3"] = dict(pf_case(modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), 4, also_systematic=True), workload="bearings-only tracker d=4, 2^22 particles (BASELINE.json configs[2])")
+        res["c3"] = dict(pf_case(modppl_amd.bearings_model(), 1 << 22, th.reshape(T, 1), 4, also_systematic=True), workload="bearings-only tracker d=4, 2^22 particles (BASELINE.json configs[2])",
+                         **valu_issue("k_propagate<mp_bearings"))
     if "c5" in which:
         res["c5_shard"] = dict(pf_case(modppl_amd.lgssm_band_model(16), 1 << 21, rng.normal(0, 1.2, size=(T, 16)), 16),
-                               workload="LGSSM d=16, 2^21 particles = one GPU's share of configs[4] (16M over 8 GPUs), unsharded code path")
+                               workload="LGSSM d=16, 2^21 particles = one GPU's share of configs[4] (16M over 8 GPUs), unsharded code path",
+                               **valu_issue("k_propagate<mp_lgssm_band<16>"))
     if "c5" in which:
         # the same shard with a DENSE transition (dense A, Q, R: two mvnormal sites): the 16 x 16 products on the matrix cores
         r5 = np.random.default_rng(5)
@@ -202,7 +223,8 @@ def sub_benches(steps, warmup, which):
         m = r5.normal(size=(16, 16)); Q = 0.25 * (m @ m.T / 16 + 0.5 * np.eye(16))
         m = r5.normal(size=(16, 16)); R = 4.0 * (m @ m.T / 16 + 0.5 * np.eye(16))
         res["c5_dense_shard"] = dict(pf_case(modppl_amd.lgssm_dense_model(A, Q, R, 1.0), 1 << 21, rng.normal(0, 1.5, size=(T, 16)), 16),
-                                     workload="dense-transition LGSSM d=16 (mvnormal(A x, Q), mvnormal(x, R)), 2^21 particles, v_mfma_f64_16x16x4_f64 kernel")
+                                     workload="dense-transition LGSSM d=16 (mvnormal(A x, Q), mvnormal(x, R)), 2^21 particles, v_mfma_f64_16x16x4_f64 kernel",
+                                     **valu_issue("k_propagate_dense16"))
     if "c4" in which:
         xs = np.arange(-5, 6, dtype=np.float64)
         ys = 0.3 + 0.4 * xs + 0.5 * xs * xs + rng.normal(0, 0.1, xs.size)
@@ -219,23 +241,28 @@ def sub_benches(steps, warmup, which):
         # the accept test's ln (37): ~350 fp64 instructions, ~400 flop with their fused multiply-adds counted twice; a division
         # or a square root counts as the ~10 instructions it expands to.  State: (a, b, c, is_linear) = 8 k + 8 bytes with k = 3,
         # read and written once per LAUNCH of 3 * sweeps iterations (it lives in registers in between).
-        # MEASURED where profiles/r04/c4_flops.json belongs to this build (tools/collect_c4_flops.py over the SQ_INSTS_VALU_*_F64 counters of
+        # MEASURED where profiles/r05/c4_flops.json belongs to this build (tools/collect_c4_flops.py over the SQ_INSTS_VALU_*_F64 counters of
         # k_mh_iterate<0>: 64 lanes x (ADD + MUL + TRANS + 2 FMA) per chain-iteration); the hand count (400) otherwise, and the line says which
         flop_per_it, flop_source = 400.0, "hand count of k_mh_iterate<0> (no PMC summary for this build)"
         try:
             from modppl_amd import build as _b
 
-            fj = json.load(open(os.path.join(ROOT, "profiles", "r04", "c4_flops.json")))
+            fj = json.load(open(os.path.join(ROOT, "profiles", "r05", "c4_flops.json")))
             if fj.get("_measured", {}).get("source_hash") == _b.source_hash() and "k_mh_iterate<0>" in fj:
                 flop_per_it = float(fj["k_mh_iterate<0>"]["flop_per_chain_iteration"])
-                flop_source = "profiles/r04/c4_flops.json: " + fj["_measured"]["formula"] + " (rocprofv3 --pmc passes of tools/mh_bench.py: profiles/r04/pmc_mh_summary.txt)"
+                flop_source = "profiles/r05/c4_flops.json: " + fj["_measured"]["formula"] + " (rocprofv3 --pmc passes of tools/mh_bench.py: profiles/r05/pmc_mh_summary.txt)"
             else:
-                flop_source += "; profiles/r04/c4_flops.json is from another build"
+                flop_source += "; profiles/r05/c4_flops.json is from another build"
         except Exception as e:   # noqa: BLE001
             flop_source += f" ({type(e).__name__})"
         res["c4"] = {"workload": "regen-MH on the hierarchical model, 2^20 chains, masks cycling a, b, c (BASELINE.json configs[3])",
                      "chains": 1 << 20, "chain_iterations": 3 * sweeps, "chain_iterations_per_s": rate,
                      "roofline": {"bound": "fp64 vector arithmetic", "flop_per_chain_iteration": flop_per_it, "flop_source": flop_source,
+                                  #  the PMC figure counts 64 lanes per wave-instruction, masked-off lanes (is_linear divergence, rejection
+                                  # loops) and the fp64 operations inside mp_exp / mp_log / the division corrections included: an UPPER bound of the
+                                  # useful work — the hand count of the model's own arithmetic stays beside it
+                                  "flop_per_chain_iteration_is": "an upper bound (lane-inclusive wave-instruction counts)" if flop_per_it != 400.0 else "a hand count",
+                                  "flop_per_chain_iteration_hand_count": 400.0, "frac_at_the_hand_count": rate * 400.0 / 1e12 / 78.6,
                                   "achieved": rate * flop_per_it / 1e12,
                                   "peak": 78.6, "unit": "TFLOP/s", "frac": rate * flop_per_it / 1e12 / 78.6,
                                   "hbm_bytes_per_chain_per_launch": 2 * (8 * 3 + 8), "iterations_per_launch": 3 * sweeps,
@@ -395,12 +422,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     shard_kw = {"host_staging": True} if rehearse else {}
-    # Several GPUs: the multinomial resample runs as the SPLIT form unless MP_SHARD_EXCHANGE says otherwise — the same law (offspring per
-    # GPU drawn first, then every GPU its own parents: O(n) per GPU), another seeded stream than the single filter's; the form whose
-    # parents are the single filter's multiset ("owned") enumerates all N draws on every GPU (52.6 against 20.6 us
-    # of count phase at 8 ranks).  A world of one (MP_BENCH_FORCE_SHARDED) keeps "owned" unless told otherwise.
-    if world > 1 and "MP_SHARD_EXCHANGE" not in os.environ:
-        shard_kw["exchange"] = "split"
+    # Several GPUs: `value` is the OWNER-KEEPS exchange ("owned", the library's default: the parents are the single filter's multiset for any
+    # number of GPUs — the algorithm of the single-GPU line and of rounds 1-3's lines), unless MP_SHARD_EXCHANGE says otherwise.  The split
+    # multinomial (same law, another seeded stream: offspring per GPU drawn first, then every GPU its own parents — O(n) per GPU where
+    # "owned" enumerates all N draws on every GPU) is timed as a supplementary leg beside it (`split_multinomial`), never as `value`
+    # (round 4's N > 1 line had silently become a different algorithm).
 
     import modppl_amd
     from modppl_amd import capi
@@ -578,6 +604,48 @@ def main():
               "step_hbm_frac_per_gpu": (32 * 16 + 64) * n5 * K / dt5 / 1e9 / HBM_PEAK_GBPS, "exchange": getattr(pf5, "exchange", None),
               "exchange_rows_last_step": surplus, "exchange_bytes_per_row": 8 * 17, "log_ml": pf5.log_marginal_likelihood_estimate()}
         del pf5
+    # ---- N > 1, supplementary: the same K steps with the split multinomial exchange (not `value`).  Every rank first agrees that a small
+    # trial of it works here (it has run on one GPU and over gloo only), so that a failure on one rank cannot leave the others in a collective.
+    split_leg = None
+    if world > 1 and getattr(pf, "exchange", "") == "owned" and os.environ.get("MP_BENCH_SPLIT_LEG", "1") == "1":
+        from modppl_amd.distributed import ShardedParticleSystem
+
+        kw2 = dict(shard_kw, exchange="split")
+        ok, why = 1, ""
+        try:
+            trial = ShardedParticleSystem(model, 2048 * 4 * world, 1, engine_kwargs={"device_index": local_rank}, **kw2)
+            trial.init_step(None, ys[:1])
+            trial.resample(sync=True)
+            trial.step(ys[1:2])
+            trial.log_marginal_likelihood_estimate()
+            trial.close()
+        except Exception as e:   # noqa: BLE001
+            ok, why = 0, repr(e)[:200]
+        flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            split_leg = {"error": "the trial of exchange='split' failed on a rank" + (": " + why if why else "")}
+        else:
+            pfs = ShardedParticleSystem(model, n * world, 20241008, engine_kwargs={"device_index": local_rank}, **kw2)
+            pfs.init_step(None, ys[:1])
+            pfs.resample(sync=False)
+            for t in range(1, 1 + W):
+                pfs.step(ys[t:t + 1])
+                pfs.resample(sync=False)
+            pfs.synchronize(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(1 + W, T):
+                pfs.step(ys[t:t + 1])
+                pfs.resample(sync=False)
+            pfs.synchronize(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            dsp = time.perf_counter() - t0
+            tt = torch.tensor([dsp], device="cpu" if rehearse else "cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dsp = float(tt.item())
+            split_leg = {"exchange": "split", "ms_per_step": dsp / K * 1e3, "particle_steps_per_s": n * world * K / dsp,
+                         "log_ml": pfs.log_marginal_likelihood_estimate(),
+                         "note": "same law as `value`'s resample, another seeded stream (parents are not the single filter's multiset): supplementary, never `value`"}
+            del pfs
     if rank == 0:
         # mean duration of one launch of each kernel (single GPU: one launch of each per step)
         timed = any(v[1] for v in fam.values())
@@ -676,6 +744,8 @@ def main():
             out["roofline"] = roofline
         if c5 is not None:
             out["c5"] = c5
+        if split_leg is not None:
+            out["split_multinomial"] = split_leg
         out["library"] = _library_identity()
         if world == 1 and not force_sharded and not args.no_sub_benches:
             try:

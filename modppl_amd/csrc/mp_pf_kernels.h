@@ -874,7 +874,10 @@ __device__ __forceinline__ void mp_run_particle(const Model& model, u64 n, u64 s
 // arrived for them (dfr_row: MP_DRAW_RECV | index)
 // WALKB: long walks finish by bisection (mp_resolve_draws' BISECT): wide-state kernels looking up a lattice's draws
 template <class Model, int THREADS, bool TAB2 = false, bool LAT = false, bool SHD = false, bool WALKB = false>
-__global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? 4 : 1))) void k_propagate(const double* __restrict__ pre_tm, const u64* __restrict__ pre_tW, const u64* __restrict__ pre_tW2, int pre_nt, int drw,
+#ifndef MP_K1_512_WAVES
+#define MP_K1_512_WAVES 4   // waves per SIMD the 512-thread kernels are compiled for (A/B builds: 2 = 256 VGPRs, no scratch, one workgroup per CU)
+#endif
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? MP_K1_512_WAVES : 1))) void k_propagate(const double* __restrict__ pre_tm, const u64* __restrict__ pre_tW, const u64* __restrict__ pre_tW2, int pre_nt, int drw,
                                                             Model model, u64 n, u64 slot_offset, uint32_t k0, uint32_t k1,
                                                             long long t, const double* x_in, double* x_out, double* logw,
                                                             mp_obs obs, mp_state0 s0, int overwrite,

@@ -1,7 +1,8 @@
 """GPU: the N > 1 control flow of bench.py — what the driver launches as `torch.distributed.run --nproc-per-node N bench.py --gpus N` —
 rehearsed on ONE card: two ranks over gloo sharing device 0 (MP_BENCH_REHEARSE=1: the library's collectives staged through the
 host).  The numbers mean nothing; every leg of the line must run, the filter must be ONE filter sharded over the ranks (log-ML
-against the Kalman filter), and the exchange the line names must be the split multinomial the N > 1 bench defaults to."""
+against the Kalman filter), the exchange `value` is measured with must be the library's default — owner-keeps, the single filter's
+multiset of parents —, and the split multinomial must be there as a supplementary leg."""
 import json
 import os
 import socket
@@ -34,7 +35,10 @@ def test_two_rank_bench_line_on_one_card():
     assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints ONE line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert d["config"]["particles_total"] == 2 * 65536 and d["config"]["exchange"] == "split"
+    assert d["config"]["particles_total"] == 2 * 65536 and d["config"]["exchange"] == "owned"
     assert d["value"] > 0 and abs(d["value"] - 2 * 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["log_ml_abs_err_vs_kalman"] < 0.2           # one filter of 131072 particles over both ranks
-    assert d["c5"]["particles_total"] == 2 * (1 << 21) and d["c5"]["exchange"] == "split" and d["c5"]["ms_per_step"] > 0
+    assert d["c5"]["particles_total"] == 2 * (1 << 21) and d["c5"]["exchange"] == "owned" and d["c5"]["ms_per_step"] > 0
+    sp = d["split_multinomial"]
+    assert sp.get("exchange") == "split" and sp["ms_per_step"] > 0, sp
+    assert abs(sp["log_ml"] - d["log_ml"]) < 0.5         # the same law: another seeded stream, the same filter
