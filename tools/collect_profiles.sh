@@ -15,6 +15,7 @@ else
 fi
 python3 tools/collect_traffic.py $SRC > $DST/traffic.json
 python3 tools/pmc_summary.py $SRC > $DST/counters_summary.txt
+[ -f $SRC/valu_issue.json ] && cp $SRC/valu_issue.json $DST/valu_issue.json
 for f in stamp_report.txt stamp_report_tile_kernel.txt k1_scaling.txt k1_forms_ab.txt reference_shaped_loop.jsonl reference_shaped_loop_cpp.txt stamps.json bench_n1.json bench_n1_k20.json bench_forced_sharded.json bench_forced_sharded_rccl.json bench_forced_sharded_split.json route_scale.txt model_bench.jsonl mh_functor_vs_handwritten.json sync_probe.jsonl; do
   [ -f $SRC/$f ] && cp $SRC/$f $DST/$f
 done
@@ -24,5 +25,5 @@ cp $SRC/trace_sharded/bench_kernel_stats.csv $DST/kernel_stats_forced_sharded.cs
 for i in 1 2 3 4 5 6 7; do cp $SRC/pmc$i/p_counter_collection.csv $DST/pmc${i}_counter_collection.csv; done
 for d in pmc_models pmc_mh pmc_dense pmc_sharded; do [ -f $SRC/$d/summary.txt ] && cp $SRC/$d/summary.txt $DST/${d}_summary.txt; done
 python3 tools/collect_c4_flops.py $SRC/pmc_mh 30 > $DST/c4_flops.json || echo "no C4 flop summary"
-python3 tools/collect_valu_issue.py $SRC/pmc_models $SRC/pmc_dense > $DST/valu_issue.json || echo "no VALU-issue summary"
+
 echo "collected into $DST"

@@ -10,6 +10,8 @@ DIAG=$R/modppl_amd/csrc/libmodppl_hip_diag.so   # the A/B switches below exist i
 mkdir -p $OUT
 # the content hash of the sources the library on THIS box was built from: tools/collect_profiles.sh refuses a run of another tree
 (cd $R && python3 -c "from modppl_amd import build as B; print(B.source_hash())") > $OUT/source_hash.txt
+PART=${2:-all}   # core | sharded | pmc | all: one gpurun call allows 20 minutes, the whole round takes about fifty
+if [ "$PART" = core ] || [ "$PART" = all ]; then
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-kernel-timing --no-sub-benches --no-systematic-leg"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $B --steps 50 --warmup 10 > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -n 5 $OUT/trace.log; exit 1; }
@@ -41,6 +43,13 @@ print(json.dumps(r))"; done > $OUT/reference_shaped_loop.jsonl 2>/dev/null || ec
 cd $R && g++ -std=c++17 -O2 tools/sync_loop.cpp -o $OUT/sync_loop -Lmodppl_amd/csrc -lmodppl_hip -Wl,-rpath,$R/modppl_amd/csrc 2> $OUT/sync_loop.err && { timeout -k 10 120 $OUT/sync_loop; MP_HOST_MIRROR=0 timeout -k 10 120 $OUT/sync_loop 1048576 100 | sed 's/^/MP_HOST_MIRROR=0: /'; } > $OUT/reference_shaped_loop_cpp.txt 2>&1 || echo "sync_loop (C++) failed"
 rm -f $OUT/sync_loop
 cd /tmp
+# the reference-shaped loop again, three times over (tools/sync_probe.py): the spread from run to run
+cd $R && timeout -k 10 200 python3 tools/sync_probe.py > $OUT/sync_probe.jsonl 2>/dev/null || echo "sync_probe failed"
+cd $R && timeout -k 10 600 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { echo "bench failed"; tail -n 5 $OUT/bench_n1.err; exit 1; }
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1_k20.json 2>> $OUT/bench_n1.err || { echo "bench k20 failed"; exit 1; }
+fi
+if [ "$PART" = sharded ] || [ "$PART" = all ]; then
+cd /tmp
 # the sharded code path in a world of one (owner-keeps exchange), kernel stats only
 MP_BENCH_FORCE_SHARDED=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sharded -o bench -- $B --steps 50 --warmup 10 > $OUT/trace_sharded.log 2>&1 || echo "sharded trace pass failed"
 MP_BENCH_FORCE_SHARDED=1 MP_SHARD_EXCHANGE=split timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sharded_split -o bench -- $B --steps 50 --warmup 10 > $OUT/trace_sharded_split.log 2>&1 || echo "sharded split trace pass failed"
@@ -50,14 +59,17 @@ cd $R && MP_BENCH_FORCE_SHARDED=1 MP_SHARD_EXCHANGE=split timeout -k 10 300 pyth
 cd $R && timeout -k 10 300 python3 tools/route_scale.py > $OUT/route_scale.txt 2>&1 || echo "route_scale failed"
 cd $R && timeout -k 10 200 python3 tools/mh_bench.py > $OUT/mh_functor_vs_handwritten.json 2> $OUT/mh_bench.err || echo "mh_bench failed"
 cd $R && timeout -k 10 300 python3 tools/model_bench.py --which c3,mid,c5,c4 > $OUT/model_bench.jsonl 2> $OUT/model_bench.err || echo "model_bench failed"
+fi
+if [ "$PART" = pmc ] || [ "$PART" = all ]; then
 # counters, fp64 operation counts and durations of the other configurations' kernels (C3 / C5 propagate kernels, the MH kernels)
 cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_models "inst busy f64 tcc fetch write tcp" "k_propagate|k_draw_slots" tools/model_bench.py --steps 8 --which c3,mid,c5 > $OUT/pmc_models.log 2>&1 || echo "pmc_models failed"
 cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_mh "inst busy f64" "k_mh|k_fn" tools/mh_bench.py 1048576 30 > $OUT/pmc_mh.log 2>&1 || echo "pmc_mh failed"
 # the sharded resample's kernels (one rank of emulated worlds of 1 .. 8): table + counts + plan, placement, the propagate kernel's SHD form
 cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_sharded "inst busy tcc" "k_shard_table|k_shard_self|k_shard_own|k_propagate" tools/route_scale.py > $OUT/pmc_sharded.log 2>&1 || echo "pmc_sharded failed"
 cd $R && bash tools/pmc_kernels.sh $(basename $OUT)/pmc_dense "inst busy f64 tcc" "k_propagate|k_draw" tools/dense_bench.py > $OUT/pmc_dense.log 2>&1 || echo "pmc_dense failed"
-cd $R && timeout -k 10 600 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { echo "bench failed"; tail -n 5 $OUT/bench_n1.err; exit 1; }
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1_k20.json 2>> $OUT/bench_n1.err || { echo "bench k20 failed"; exit 1; }
+# (the raw counter files of the model / dense passes are too large to travel back: their one derived figure is computed here)
+cd $R && python3 tools/collect_valu_issue.py $OUT/pmc_models $OUT/pmc_dense > $OUT/valu_issue.json 2> $OUT/valu_issue.err || echo "valu_issue failed"
+fi
 # what travels back is limited to 64 MiB: the raw per-launch traces and the stamp dumps have been summarised above
 find $OUT -name '*_kernel_trace.csv' -delete; find $OUT -name '*.npy' -delete; find $OUT -name '*_agent_info.csv' -delete
 rm -rf $OUT/pmc_sharded/pmc_* $OUT/pmc_sharded/trace $OUT/pmc_models/pmc_* $OUT/pmc_models/trace $OUT/pmc_dense/pmc_* $OUT/pmc_dense/trace
