@@ -343,7 +343,11 @@ def test_change_upstream_of_an_untouched_sub_call():
 def test_two_levels_of_sub_calls():
     """kind 113: a sub-call inside a sub-call — constraints that land in the inner call, a structure change in the middle one, a
     change upstream of both, and every mask placement — the device's static handlers (mp_genfn.h: `call` as a frame) against the
-    checker's recursive trace_at over real nested tries, through mh and regen_mh"""
+    checker's recursive trace_at over real nested tries, through mh and regen_mh.
+    WHAT THIS PINS AND WHAT IT DOES NOT: the checker interprets the product's own functor source (oracle/src/mh_functor_adapter.hpp), so
+    the HANDLER rules — sample_at / trace_at / gc at depth, dyngenfn.rs:100-486 — are held to an independent restatement, but the model
+    BODY is shared: a mis-written body would be invisible here.  The model is synthetic (no counterpart in the reference), so there is
+    no independent statement of it to hold it to; kinds 102 / 103 have one (tests/test_gpu_functor_logjoint.py: numpy log-joints)."""
     if FUNCTOR:
         pytest.skip("one engine: the model has no hand-written kernel")
     import modppl_amd
@@ -360,7 +364,11 @@ def test_two_levels_of_sub_calls():
 
 def test_more_than_32_sites():
     """kind 114: 41 sites — presence, masks, constraints and the discard are 64-bit words inside the kernels and two 32-bit words per
-    chain through the C ABI; the sub-call, its optional choice and six observations live above bit 32"""
+    chain through the C ABI; the sub-call, its optional choice and six observations live above bit 32.
+    WHAT THIS PINS AND WHAT IT DOES NOT: the checker interprets the product's own functor source (oracle/src/mh_functor_adapter.hpp), so
+    the HANDLER rules — sample_at / trace_at / gc at depth, dyngenfn.rs:100-486 — are held to an independent restatement, but the model
+    BODY is shared: a mis-written body would be invisible here.  The model is synthetic (no counterpart in the reference), so there is
+    no independent statement of it to hold it to; kinds 102 / 103 have one (tests/test_gpu_functor_logjoint.py: numpy log-joints)."""
     if FUNCTOR:
         pytest.skip("one engine: the model has no hand-written kernel")
     import modppl_amd

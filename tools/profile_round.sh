@@ -11,9 +11,9 @@ mkdir -p $OUT
 # the content hash of the sources the library on THIS box was built from: tools/collect_profiles.sh refuses a run of another tree
 (cd $R && python3 -c "from modppl_amd import build as B; print(B.source_hash())") > $OUT/source_hash.txt
 PART=${2:-all}   # core | sharded | pmc | all: one gpurun call allows 20 minutes, the whole round takes about fifty
-if [ "$PART" = core ] || [ "$PART" = all ]; then
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-kernel-timing --no-sub-benches --no-systematic-leg"
+if [ "$PART" = core ] || [ "$PART" = all ]; then
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $B --steps 50 --warmup 10 > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -n 5 $OUT/trace.log; exit 1; }
 echo "trace done"
 i=0
@@ -40,7 +40,7 @@ r = bench.reference_shaped_loop(modppl_amd.lgssm_model(*bench.LGSSM_PARAMS), 1 <
 r['MP_HOST_MIRROR'] = $v
 print(json.dumps(r))"; done > $OUT/reference_shaped_loop.jsonl 2>/dev/null || echo "reference-shaped loop failed"
 # ... and the same loop from compiled host code (tools/sync_loop.cpp over the C++ wrapper): without the interpreter's share
-cd $R && g++ -std=c++17 -O2 tools/sync_loop.cpp -o $OUT/sync_loop -Lmodppl_amd/csrc -lmodppl_hip -Wl,-rpath,$R/modppl_amd/csrc 2> $OUT/sync_loop.err && { timeout -k 10 120 $OUT/sync_loop; MP_HOST_MIRROR=0 timeout -k 10 120 $OUT/sync_loop 1048576 100 | sed 's/^/MP_HOST_MIRROR=0: /'; } > $OUT/reference_shaped_loop_cpp.txt 2>&1 || echo "sync_loop (C++) failed"
+cd $R && g++ -std=c++17 -O2 tools/sync_loop.cpp -o $OUT/sync_loop -Lmodppl_amd/csrc -lmodppl_hip -Wl,-rpath,$R/modppl_amd/csrc 2> $OUT/sync_loop.err && { timeout -k 10 120 $OUT/sync_loop; } > $OUT/reference_shaped_loop_cpp.txt 2>&1 || echo "sync_loop (C++) failed"
 rm -f $OUT/sync_loop
 cd /tmp
 # the reference-shaped loop again, three times over (tools/sync_probe.py): the spread from run to run
