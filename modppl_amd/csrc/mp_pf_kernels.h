@@ -675,6 +675,20 @@ __device__ __forceinline__ u64 mp_tile_last(uint32_t row, u64 n) {
 // is MP_DRAW_RECV | the index of its row {state[dim], parent's global slot id} in the exchange buffer (`rows`, rows of `rw`
 // doubles); the "parent" handed on keeps the flag, so that the consumer knows where the state is.
 constexpr uint32_t MP_DRAW_RECV = 0x80000000u;
+// (round 5) a draw whose guide cell has already decided it (mp_guide_q5 against the target's own 32nd of the cell, mp_start_row below):
+// the start row IS the parent — its row is fetched only by consumers that want the state out of it (dim_state 1), not to be compared.
+// Handles hold at most 2^24 rows (MAX_TILES), so bit 30 of a start row is free.
+constexpr uint32_t MP_DRAW_SURE0 = 0x40000000u;
+// what a draw kernel leaves as a draw's start row, from its guide cell: r0 | MP_DRAW_SURE0 when the target lies below cum[r0] (the
+// parent is r0), r0 + 1 when it lies above (cum[r0] < target: the forward scan may start one row on), r0 when the two fall into the
+// same 32nd of the cell.  The scan `first row at or after the start row whose cumulative weight reaches the target` finds the same
+// parent from either start.
+__device__ __forceinline__ uint32_t mp_start_row(uint32_t cell, uint32_t sub, uint32_t tbase, uint32_t tlen) {
+    const uint32_t j0 = mp_guide_row(cell), q5 = mp_guide_q5(cell);
+    const uint32_t j = j0 > tlen - 1 ? tlen - 1 : j0;
+    if (sub < q5) return (tbase + j) | MP_DRAW_SURE0;
+    return tbase + ((sub > q5 && j + 1 < tlen) ? j + 1 : j);
+}
 #ifndef MP_PAIR_SAME_LINE
 #define MP_PAIR_SAME_LINE 1
 #endif
@@ -695,18 +709,28 @@ constexpr uint32_t MP_DRAW_RECV = 0x80000000u;
                             //  waves even with healthy weights — cost more than walking on, and the waves of a workgroup wait for it: + 7 - 11 %)
 #endif
 
-template <int N, bool BISECT = false>
+// NEEDX0: the caller wants the parent's first state component out of its row (dim_state 1); wider states are gathered from x_in by
+// the parent's index, and a draw flagged MP_DRAW_SURE0 then needs no row at all
+template <int N, bool BISECT = false, bool NEEDX0 = true>
 __device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u64 n, const u64* lt, const uint32_t* row, uint32_t* parent, double* x0,
                                                  const double* __restrict__ rows = nullptr, int rw = 0) {
     mp_u64v2 a[N], b2[N];
     u64 last[N];
     uint32_t r0[N];
-    bool hb[N];
+    bool hb[N], sure[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        r0[k] = (rows && (row[k] & MP_DRAW_RECV)) ? 0u : row[k];
+        const bool recv = rows && (row[k] & MP_DRAW_RECV);
+        sure[k] = !recv && (row[k] & MP_DRAW_SURE0);
+        r0[k] = recv ? 0u : (row[k] & ~MP_DRAW_SURE0);
         last[k] = mp_tile_last(r0[k], n);
+        if (!NEEDX0 && sure[k]) {   // decided by the guide cell, and nobody wants the row's state: nothing to fetch
+            a[k].x = ~0ull; a[k].y = 0ull; b2[k] = a[k];
+            hb[k] = false;
+            continue;
+        }
         a[k] = mp_ld_row(cx + r0[k]);
+        if (sure[k]) { a[k].x = ~0ull; b2[k] = a[k]; hb[k] = false; continue; }   // (its cumulative weight reaches the target: mp_start_row)
         // the successor goes out with the start row only where it lies in the SAME 64-byte line (four rows): a successor in the
         // next line is needed by 37 % of the draws only, and fetching it for all of them was a quarter-line-miss per draw for
         // nothing — the lookups are bound by the fabric's miss rate (tools/gather_probe.hip); the few that need it walk on below
@@ -752,10 +776,10 @@ __device__ __forceinline__ void mp_resolve_draws(const mp_cx* __restrict__ cx, u
         x0[k] = __builtin_bit_cast(double, (u64)cur.y);
     }
 }
-template <bool BISECT = false>
+template <bool BISECT = false, bool NEEDX0 = true>
 __device__ __forceinline__ void mp_resolve_draw(const mp_cx* __restrict__ cx, u64 n, u64 lt, uint32_t row, uint32_t* parent, double* x0,
                                                 const double* __restrict__ rows = nullptr, int rw = 0) {
-    mp_resolve_draws<1, BISECT>(cx, n, &lt, &row, parent, x0, rows, rw);
+    mp_resolve_draws<1, BISECT, NEEDX0>(cx, n, &lt, &row, parent, x0, rows, rw);
 }
 // What k_propagate needs only in its LAST phase (level 0 / level 1 of the normalisation), constant per handle: kept in
 // device memory and read there — as kernel arguments these 11 pointers sat in SGPRs through the whole VALU-bound part of the
@@ -1091,7 +1115,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? M
             MP_STAMP(0, 17, 0);
             const u64 Q = s_incl[dw.nt - 1];   // (SHD: the rank's own share, hi - lo)
             const double nt_over_Q = (double)dw.nt / (double)Q;   // only a starting guess for the tile walk: no effect on results
-            uint32_t gslot[2], tile_of[2];
+            uint32_t gslot[2], tile_of[2], sp[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
             {
@@ -1103,17 +1127,17 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? M
                     if (!own) tg = 1ull;
                 } else if constexpr (LAT) tg = mp_target_lattice(drw >> 1, slot_offset + (base + q < n ? base + q : 0ull), lat_k32, rc, k0, k1, Q, dw.n_global);
                 else tg = mp_target(mp_u52(q ? blk.b : blk.a), Q);
-                mp_locate_r<WALKB>(s_incl, s_W, s_ratio, (uint32_t)dw.nt, tg, nt_over_Q, &tile_of[q], &plt[q], &gslot[q]);
+                mp_locate_r<WALKB>(s_incl, s_W, s_ratio, (uint32_t)dw.nt, tg, nt_over_Q, &tile_of[q], &plt[q], &gslot[q], &sp[q]);
             }
             uint32_t j0[2];
             MP_STAMP(0, 18, 0);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) j0[q] = mp_guide_row(dw.guide_old[gslot[q]]);
+            for (int q = 0; q < 2; ++q) j0[q] = dw.guide_old[gslot[q]];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const u64 tbase = (u64)tile_of[q] * TILE;
                 const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
-                pm[q] = (uint32_t)tbase + (j0[q] > tlen - 1 ? tlen - 1 : j0[q]);   // row where the forward scan starts
+                pm[q] = mp_start_row(j0[q], sp[q], (uint32_t)tbase, tlen);   // row where the forward scan starts (| MP_DRAW_SURE0: where it ends)
             }
             if constexpr (SHD) {   // the slots this rank could not fill itself: the row that arrived for them (k_shard_self_place flagged them)
 #pragma unroll
@@ -1237,7 +1261,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? M
                 u64 ltr[ITEMS];
 #pragma unroll
                 for (int pp = 0; pp < ITEMS; ++pp) ltr[pp] = (LT_LATE && !drew) ? (i0 + pp < n ? dfr_lt[i0 + pp] : 0ull) : plt[rd * ITEMS + pp];
-                mp_resolve_draws<ITEMS, WALKB>(cx_old, n, ltr, &pm[rd * ITEMS], &pm[rd * ITEMS], &px0[rd * ITEMS], inv ? nullptr : inv_rows, D + 1);
+                mp_resolve_draws<ITEMS, WALKB, D == 1>(cx_old, n, ltr, &pm[rd * ITEMS], &pm[rd * ITEMS], &px0[rd * ITEMS], inv ? nullptr : inv_rows, D + 1);
             }
 #pragma unroll
             for (int pp = 0; pp < ITEMS; ++pp) MP_RUN_PARTICLE(rd * ITEMS + pp, &zr[pp * NS]);
@@ -1342,7 +1366,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 ? 8 : (THREADS == 512 ? M
             } else {
 #pragma unroll
                 for (int p = 0; p < LANE_ITEMS; ++p)
-                    mp_resolve_draw<WALKB>(cx_old, n, drew ? plt[p] : (base + p < n ? dfr_lt[base + p] : 0ull), pm[p], &pm[p], &px0[p], inv ? nullptr : inv_rows, D + 1);
+                    mp_resolve_draw<WALKB, false>(cx_old, n, drew ? plt[p] : (base + p < n ? dfr_lt[base + p] : 0ull), pm[p], &pm[p], &px0[p], inv ? nullptr : inv_rows, D + 1);
                 if constexpr (CAN_DRAW) {
                     if (drew) {
                         uint32_t* pp2 = mp_as_global(drw_v.parent);
@@ -1449,7 +1473,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_propagate_dense16(mp_lgssm_de
         } else if (dfr_row && live) {   // a draw of the last resample, looked up here (mp_resolve_draw)
             uint32_t par;
             double x0;
-            mp_resolve_draw<WALKB>(cx_old, n, dfr_lt[p], dfr_row[p], &par, &x0, rows, D + 1);
+            mp_resolve_draw<WALKB, false>(cx_old, n, dfr_lt[p], dfr_row[p], &par, &x0, rows, D + 1);
             myrow = (rows && (par & MP_DRAW_RECV)) ? rows + (u64)(par & ~MP_DRAW_RECV) * (u64)(D + 1) : x_in + (u64)par * D;
         }
         const u64 myaddr = (u64)(uintptr_t)myrow;
@@ -1960,15 +1984,15 @@ __global__ __launch_bounds__(DRAW_THREADS) __attribute__((amdgpu_num_sgpr(80))) 
     }
     // the guide lookups (the guide is L2-resident on every XCD)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) j0[q] = mp_guide_row(guide[gslot[q]]);
+    for (int q = 0; q < 2; ++q) j0[q] = guide[gslot[q]];
     // {target, start row} of the two draws in SLOT order: one 16-byte and one 8-byte store per lane
     uint32_t srow[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const u64 tbase = (u64)tile_of[q] * TILE;
         const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
-        const uint32_t jj = j0[q] > tlen - 1 ? tlen - 1 : j0[q];
-        srow[q] = (uint32_t)tbase + jj;   // row where the forward scan starts
+        // row where the forward scan starts — or, flagged MP_DRAW_SURE0, where the guide cell says it ends (mp_start_row)
+        srow[q] = mp_start_row(j0[q], mp_guide_sub(lt[q], mp_guide_shift(s_W[tile_of[q]])), (uint32_t)tbase, tlen);
     }
     if (live[1]) {
         mp_u64v2 v2; v2.x = lt[0]; v2.y = lt[1];
