@@ -289,10 +289,10 @@ def sub_benches(steps, warmup, which):
 def reference_shaped_loop(model, n, ys, steps, warmup):
     """The loop a drop-in caller of the reference writes (modppl/tests/smc.rs:64-90 over particle_filter.rs:73-116): every call
     SYNCHRONOUS — `step`; `effective_sample_size()` (the reference's stale value, a host f64); `L = resample()` (a host f64) —
-    against bench.py's own loop, whose resample only enqueues.  The synchronous resample asks one small workgroup for L
-    (k_peek_level1 -> host-mapped memory) and leaves draws and lookups to the next step's k_propagate, the ESS comes out of
-    host-mapped memory written by that launch's first workgroup: one host round trip per step, no launch of k_draw_slots /
-    k_resolve_slots.  Also: the same loop with every particle's state copied to the host after each resample, as the reference's
+    against bench.py's own loop, whose resample only enqueues.  The synchronous resample's L comes out of host-mapped memory written by
+    the LAST workgroup of the step's own launch (round 5: mt_peek_tail; round 4 launched k_peek_level1 behind the step), the draws and
+    lookups are left to the next step's k_propagate, the ESS comes out of host-mapped memory written by that launch's first workgroup:
+    one launch and one host poll per step.  Also: the same loop with every particle's state copied to the host after each resample, as the reference's
     test does (PCIe-inclusive: 8 MB per step; never `value`), and the per-kernel durations of an instrumented repeat."""
     import modppl_amd
     from modppl_amd import capi
@@ -336,7 +336,7 @@ def reference_shaped_loop(model, n, ys, steps, warmup):
             "step_hbm_frac": BYTES_STEP * n * steps / dt / 1e9 / HBM_PEAK_GBPS,
             "kernel_launches_per_step": {k: v[1] / steps for k, v in fam.items()},
             "kernel_avg_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in fam.items()},
-            "k_peek_level1": "one 1024-thread workgroup per synchronous resample (not in a timing family: the difference between us_per_step and the kernels above is that launch plus one host round trip)",
+            "resample_return_value": "computed by the LAST workgroup of the step's own launch (mt_peek_tail: level 1 of the new tile scalars into host-mapped memory) once the loop is known to be synchronous; k_peek_level1, a launch of its own, only for the first synchronous resample — the difference between us_per_step and the kernel above is a launch on an idle queue plus one host poll",
             "with_states_copied_to_host_each_step": {"steps": k_states, "us_per_step": dts / k_states * 1e6,
                                                      "note": "PCIe-inclusive: k_draw_slots + k_resolve_slots + 8 MB device-to-host per step (tests/smc.rs:64-90 writes every state to disk)"},
             "sum_of_log_total_weights": Ls}

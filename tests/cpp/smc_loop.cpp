@@ -33,6 +33,17 @@ int main(int argc, char** argv) {
         const uint64_t f1 = fchains.mh(MP_MH_PROPOSAL_HIERARCHICAL_ADD_OR_REMOVE, {}, 2);
         const uint64_t f2 = fchains.mh(MP_MH_PROPOSAL_HIERARCHICAL_DRIFT, {0.1}, 3);
         std::printf("accepted_fn=%llu,%llu sites=%d\n", (unsigned long long)f1, (unsigned long long)f2, fchains.num_sites());
+        // (round 5) generate / simulate on a handle, and importance sampling over a registered function with DECLARED data sites (kind 105:
+        // the same model, its observations as data) — importance.rs:12-50 for `impl GenFn`
+        {
+            const std::vector<std::pair<int32_t, double>> obs = {{MP_SITE_Y0, 0.2}, {MP_SITE_Y0 + 1, 0.9}, {MP_SITE_Y0 + 2, 2.2}};
+            const std::vector<double> w = fchains.generate(obs, 40);
+            const std::vector<double> lj = fchains.simulate(41);
+            modppl::FnImportance is = modppl::fn_importance_resampling(MP_MH_MODEL_HIERARCHICAL_DATA_FN, {-1., 0., 1.}, obs, 2048, 8, seed);
+            std::printf("fn w0=%.17g lj0=%.17g lml=%.17g idx0=%llu idx7=%llu lnw0=%.17g sites=%d\n", w[0], lj[0], is.log_ml_estimate,
+                        (unsigned long long)is.resampled_indices[0], (unsigned long long)is.resampled_indices[7], is.log_normalized_weights[0],
+                        is.traces->num_sites());
+        }
         // the sharded filter in a world of one with both RCCL collectives forced: one library call per resample
         if (argc > 3 && std::atoi(argv[3])) {
             modppl::ShardedParticleSystem sf(modppl::UnfoldModel::lgssm(), n, seed, 1, 0, nullptr, nullptr, 0, true);

@@ -52,5 +52,14 @@ def test_cpp_wrapper_runs_the_smc_loop(tmp_path):
     # the same chains as a registered functor model through the generic entry points, and the sharded filter's native resample
     # (world of one, RCCL collectives forced): a world of one IS the single filter
     assert lines[2] == want2.replace("accepted=", "accepted_fn=") + " sites=20", lines
+    # generate / simulate on that handle and importance sampling over the declared-data functor: the Python mirror's values
+    fc = modppl_amd.FunctionChains(101, [-1.0, 0.0, 1.0], {4: 0.2, 5: 0.9, 6: 2.2}, 256, seed)
+    fc.mh(2, [], 2); fc.mh(1, [0.1], 3)
+    w = fc.generate({4: 0.2, 5: 0.9, 6: 2.2}, rng_step=40)
+    lj = fc.simulate(rng_step=41)
+    tr, idx, lml = modppl_amd.fn_importance_resampling(105, [-1.0, 0.0, 1.0], {4: 0.2, 5: 0.9, 6: 2.2}, 2048, 8, seed)
+    _, lnw, _ = modppl_amd.fn_importance_sampling(105, [-1.0, 0.0, 1.0], {4: 0.2, 5: 0.9, 6: 2.2}, 2048, seed, traces=False)
+    want3 = "fn w0=%.17g lj0=%.17g lml=%.17g idx0=%d idx7=%d lnw0=%.17g sites=%d" % (w[0], lj[0], lml, idx[0], idx[7], lnw[0], tr.num_sites)
+    assert [l for l in lines if l.startswith("fn ")] == [want3], (lines, want3)
     sharded = [l for l in lines if l.startswith("sharded ")]   # (RCCL prints its version banner to stdout in between)
     assert sharded == ["sharded " + want.split()[0]], (lines, want)
