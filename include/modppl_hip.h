@@ -240,6 +240,11 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
                                 uint64_t* counts_out);
 int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t capacity, double* d_send_out, double* d_rows, uint64_t recv_rows);
 int32_t mp_pf_shard_owned_commit(mp_pf* h, const double* d_rows, double* log_total_weight, uint64_t* counts_out);
+/* count + expand of the equal-split form (capacity > 0) as one call — what mp_pf_shard_resample issues.  Same results as the two
+ * calls; knowing the send buffer when the count is launched lets a self-drawn resample (lattice schemes, split multinomial) do the
+ * table, the offspring counts, the plan, the verdict and the placement of the surplus in ONE kernel launch instead of two. */
+int32_t mp_pf_shard_owned_count_expand(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
+                                       double* d_send_out, double* d_rows, uint64_t recv_rows);
 
 /* ---- the sharded resample as ONE call: the library runs the collectives itself ----------------------------------------
  * ParticleSystem::resample (particle_filter.rs:103-116) of a filter sharded over `world` devices, owner-keeps exchange: tiles

@@ -36,7 +36,7 @@ SYMBOLS = [
     "mp_pf_read_parents", "mp_pf_read_trajectory", "mp_pf_read_trajectories", "mp_pf_time", "mp_pf_run", "mp_pf_synchronize", "mp_pf_destroy",
     "mp_pf_set_timing", "mp_pf_get_timing", "mp_pf_region_begin", "mp_pf_region_end", "mp_pf_last_propagate_form", "mp_unfold_simulate", "mp_importance_resampling", "mp_importance_sampling",
     "mp_pf_shard_bind_tiles", "mp_pf_shard_tiles_packed", "mp_pf_shard_route_fixed", "mp_pf_shard_resolve_fixed", "mp_pf_shard_commit_fixed", "mp_pf_shard_query_packed",
-    "mp_pf_shard_owned_count", "mp_pf_shard_owned_expand", "mp_pf_shard_owned_commit",
+    "mp_pf_shard_owned_count", "mp_pf_shard_owned_expand", "mp_pf_shard_owned_commit", "mp_pf_shard_owned_count_expand",
     "mp_pf_shard_resample", "mp_pf_shard_resample_rccl", "mp_pf_shard_query_native", "mp_pf_shard_resample_stats", "mp_transport_rccl",
     "mp_rccl_available", "mp_rccl_unique_id", "mp_rccl_comm_create", "mp_rccl_comm_destroy", "mp_pf_stream_copy",
     "mp_pf_shard_tiles", "mp_pf_shard_route", "mp_pf_shard_resolve", "mp_pf_shard_scatter", "mp_pf_shard_query",
@@ -170,6 +170,7 @@ def _load_so(so):
     L.mp_pf_shard_query_packed.argtypes = [p, p, i32, dp, dp]
     L.mp_pf_shard_owned_count.argtypes = [p, i32, p, i32, i32, u64, C.POINTER(u64)]
     L.mp_pf_shard_owned_expand.argtypes = [p, i32, i32, u64, p, p, u64]
+    L.mp_pf_shard_owned_count_expand.argtypes = [p, i32, p, i32, i32, u64, p, p, u64]
     L.mp_pf_shard_owned_commit.argtypes = [p, p, dp, C.POINTER(u64)]
     L.mp_pf_shard_resample.argtypes = [p, C.POINTER(Transport), i32, i32, i32, i32, dp]
     L.mp_pf_shard_resample_rccl.argtypes = [p, p, i32, i32, i32, i32, dp]

@@ -36,6 +36,48 @@ MP_HD double mp_stirling_tail(double k) {
     return (1.0 / 12. - (1.0 / 360. - 1.0 / 1260. / kp1sq) / kp1sq) / kp1;
 }
 
+// BTRS in three pieces, so that a device caller can evaluate several attempts of one variate in different lanes (mp_pf_shard_kernels.h,
+// mp_split_counts) with the very operations the sequential sampler below performs: the constants of (n, p); the cheap part of an
+// attempt (candidate k, range check, squeeze); the expensive acceptance test of an attempt the squeeze did not decide.
+struct mp_btrs {
+    double n, p, spq, b, a, c, v_r, r, alpha, m;
+};
+MP_HD void mp_btrs_setup(mp_btrs& T, double n, double p) {
+    const double q = 1. - p;
+    T.n = n; T.p = p;
+    T.spq = mp_sqrt(n * p * q);
+    T.b = 1.15 + 2.53 * T.spq;
+    T.a = -0.0873 + 0.0248 * T.b + 0.01 * p;
+    T.c = n * p + 0.5;
+    T.v_r = 0.92 - 4.2 / T.b;
+    T.r = p / q;
+    T.alpha = (2.83 + 5.1 / T.b) * T.spq;
+    T.m = floor((n + 1.) * p);
+}
+// 0: rejected (k out of range); 1: accepted inside the squeeze (~ 86 % of the accepted pairs); 2: undecided — mp_btrs_slow says
+MP_HD int mp_btrs_fast(const mp_btrs& T, double U01, double V01, double* k_out) {
+    const double u = U01 - 0.5;
+    const double us = 0.5 - fabs(u);
+    const double k = floor((2. * T.a / us + T.b) * u + T.c);
+    *k_out = k;
+    if (!(k >= 0. && k <= T.n)) return 0;             // (also what an infinite or NaN k from us == 0 falls into)
+    if (us >= 0.07 && V01 <= T.v_r) return 1;
+    return 2;
+}
+// the acceptance test is v <= ub with v and the seven terms of ub below; written piece by piece so that a device caller can have the
+// eight pieces evaluated by eight lanes (each is one of two shapes: c * log(x / y), or a Stirling tail) and add them up in this order
+MP_HD double mp_btrs_logterm(double c, double x, double y) { return c * mp_log(x / y); }
+MP_HD bool mp_btrs_slow(const mp_btrs& T, double U01, double V01, double k) {
+    const double u = U01 - 0.5;
+    const double us = 0.5 - fabs(u);
+    const double n = T.n, m = T.m, r = T.r;
+    const double v = mp_btrs_logterm(1., V01 * T.alpha, T.a / (us * us) + T.b);
+    const double ub = mp_btrs_logterm(m + 0.5, m + 1., r * (n - m + 1.)) + mp_btrs_logterm(n + 1., n - m + 1., n - k + 1.) +
+                      mp_btrs_logterm(k + 0.5, r * (n - k + 1.), k + 1.) + mp_stirling_tail(m) + mp_stirling_tail(n - m) - mp_stirling_tail(k) -
+                      mp_stirling_tail(n - k);
+    return v <= ub;
+}
+
 // X ~ Binomial(n, p), 0 < p <= 1/2, n >= 1; uniforms: blocks 0, 1, ... of (node, rc, RESAMPLE << 16 | 3, .)
 MP_HD uint64_t mp_binomial_small_p(uint64_t n_u, double p, uint32_t node, uint32_t rc, uint32_t k0, uint32_t k1) {
     const double n = (double)n_u;
@@ -60,29 +102,16 @@ MP_HD uint64_t mp_binomial_small_p(uint64_t n_u, double p, uint32_t node, uint32
         }
         return 0ull;
     }
-    const double spq = mp_sqrt(n * p * q);
-    const double b = 1.15 + 2.53 * spq;
-    const double a = -0.0873 + 0.0248 * b + 0.01 * p;
-    const double c = n * p + 0.5;
-    const double v_r = 0.92 - 4.2 / b;
-    const double r = p / q;
-    const double alpha = (2.83 + 5.1 / b) * spq;
-    const double m = floor((n + 1.) * p);
+    mp_btrs T;
+    mp_btrs_setup(T, n, p);
     for (uint32_t att = 0; att < MP_BINOMIAL_MAX_ATTEMPTS; ++att) {
         const mp_u64x2 blk = mp_philox4x32_10(node, rc, c2, att, k0, k1);
-        const double u = mp_u01(blk.a) - 0.5;
-        double v = mp_u01(blk.b);
-        const double us = 0.5 - fabs(u);
-        const double k = floor((2. * a / us + b) * u + c);
-        if (!(k >= 0. && k <= n)) continue;             // (also what an infinite or NaN k from us == 0 falls into)
-        if (us >= 0.07 && v <= v_r) return (uint64_t)k;   // inside the squeeze: ~ 86 % of the accepted pairs
-        v = mp_log(v * alpha / (a / (us * us) + b));
-        const double ub = (m + 0.5) * mp_log((m + 1.) / (r * (n - m + 1.))) + (n + 1.) * mp_log((n - m + 1.) / (n - k + 1.)) +
-                          (k + 0.5) * mp_log(r * (n - k + 1.) / (k + 1.)) + mp_stirling_tail(m) + mp_stirling_tail(n - m) - mp_stirling_tail(k) -
-                          mp_stirling_tail(n - k);
-        if (v <= ub) return (uint64_t)k;
+        const double U = mp_u01(blk.a), V = mp_u01(blk.b);
+        double k;
+        const int st = mp_btrs_fast(T, U, V, &k);
+        if (st == 1 || (st == 2 && mp_btrs_slow(T, U, V, k))) return (uint64_t)k;
     }
-    return (uint64_t)m;
+    return (uint64_t)T.m;
 }
 
 // X ~ Binomial(n, a / b) for integer masses 0 <= a <= b, b > 0 (the left child's share of a node's mass)

@@ -494,6 +494,9 @@ struct mp_pf {
     uint32_t* sh_blockcount = nullptr;
     uint32_t* sh_blockoff = nullptr;
     long long* sh_counts = nullptr;
+    bool ow_placed = false;               // the last count's table launch also placed (self-drawn, equal-split capacity): expand launches nothing
+    uint64_t ow_placed_cap = 0;
+    double* ow_placed_send = nullptr;
     mp_tab_part* sh_tab_part = nullptr;   // [SH_MAX_WORLD] k_shard_table_mw: every rank's {sum T, sum T2}
     unsigned int* sh_tab_ticket = nullptr;   // counts up by `world` per launch
     unsigned int sh_tab_seq = 0;
@@ -1548,11 +1551,16 @@ int32_t mp_pf_shard_tiles_packed(mp_pf* h, uint64_t* d_tiles_out) {
     return MP_OK;
 }
 
-// the job's tile table from the gathered tiles: one workgroup per rank in a world of several (k_shard_table_mw), one in all otherwise
+// the job's tile table from the gathered tiles: one workgroup per rank in a world of several (k_shard_table_mw), one in all otherwise;
+// `plan` / `place`: what the table's leading workgroup does on its way out for a self-drawn resample (mp_pf_shard_kernels.h)
 static void launch_shard_table(mp_pf* h, const u64* d_tiles_all, int world, unsigned long long* c_all, int scheme, int rank, mp_own_range* range,
-                               u64* kthr, const mp_own_plan_args* plan = nullptr) {
-    const mp_own_plan_args pa = plan ? *plan : mp_own_plan_args{};
-    const int do_plan = plan ? 1 : 0;
+                               u64* kthr, const mp_own_plan_args* plan = nullptr, const mp_self_place_args* place = nullptr) {
+    mp_table_tail tail{};
+    tail.c_all = c_all; tail.scheme = scheme; tail.rank = rank;
+    tail.k0 = (uint32_t)h->seed; tail.k1 = (uint32_t)(h->seed >> 32); tail.rc = h->resample_count;
+    tail.range = range; tail.kthr = kthr;
+    if (plan) { tail.plan = *plan; tail.do_plan = 1; }
+    if (plan && place) { tail.place = *place; tail.do_place = 1; }
     static const bool one_wg = mp_diag_env("MP_SHARD_TABLE_ONE_WG") && atoi(mp_diag_env("MP_SHARD_TABLE_ONE_WG")) != 0;   // A/B
     // (measured, 512 tiles per rank: one workgroup 8.3 us up to 4 ranks and 16.9 us at 8; one per rank 9.8 - 10.8 us at 2 .. 8)
     // (MP_SHARD_TABLE_MW_TILES: the job size from which one workgroup per rank builds the table — tests lower it to reach that
@@ -1561,14 +1569,14 @@ static void launch_shard_table(mp_pf* h, const u64* d_tiles_all, int world, unsi
     const size_t mw_tiles = mw_env ? (size_t)atoll(mw_env) : (size_t)2048;
     if (world > 1 && !one_wg && (size_t)world * (size_t)h->nt > mw_tiles) {
         h->sh_tab_seq += (unsigned)world;
-        hipLaunchKernelGGL(k_shard_table_mw, dim3(world), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
-                           h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, c_all, scheme, rank,
-                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, range, kthr, h->sh_tab_part, h->sh_tab_ticket, h->sh_tab_seq,
-                           pa, do_plan);
+        auto kern = h->nt <= SHT_THREADS ? k_shard_table_mw<1> : k_shard_table_mw<SHT_PER>;
+        hipLaunchKernelGGL(kern, dim3(world), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
+                           h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, h->sh_tab_part,
+                           h->sh_tab_ticket, h->sh_tab_seq, tail);
     } else {
-        hipLaunchKernelGGL(k_shard_table, dim3(1), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
-                           h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, c_all, scheme, rank,
-                           (uint32_t)h->seed, (uint32_t)(h->seed >> 32), h->resample_count, range, kthr, pa, do_plan);
+        auto kern = (size_t)world * (size_t)h->nt <= 2 * (size_t)SHT_THREADS ? k_shard_table<2> : k_shard_table<SHT_PER>;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(SHT_THREADS), 0, h->stream, d_tiles_all, world, h->nt, h->S, h->n_global, h->sh_tm_all,
+                           h->sh_tW_all, h->sh_tW2_all, h->sh_incl_all, h->sh_ratio_all, h->sh_counts, h->scal, h->scal_undo, tail);
     }
 }
 
@@ -1767,8 +1775,21 @@ static int32_t launch_self_draws(mp_pf* h, int scheme, uint32_t rc, int world, i
     return check_launch("k_shard_self_draw");
 }
 
-int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
-                                uint64_t* counts_out) {
+// what the placement of a self-drawn resample reads and writes (k_shard_self_place, or the table kernel's leading workgroup)
+static mp_self_place_args self_place_args(const mp_pf* h, int rank, uint64_t capacity, double* d_send_out) {
+    const size_t off = (size_t)rank * (size_t)h->nt;
+    mp_self_place_args a{};
+    a.n = h->n; a.slot_offset = h->slot_offset; a.cap = (u64)capacity; a.D = h->ops->dim_state;
+    a.incl_sl = (const u64*)h->sh_incl_all + off; a.W_sl = (const u64*)h->sh_tW_all + off; a.ratio_sl = (const double*)h->sh_ratio_all + off;
+    a.guide = (const unsigned short*)h->guide; a.cx = (const mp_cx*)h->cx; a.x = (const double*)h->x[h->cur];
+    a.send = d_send_out; a.dfr_lt = h->dfr_lt; a.dfr_row = h->dfr_row;
+    return a;
+}
+
+// fuse_send: the caller will expand with this equal-split send buffer next (mp_pf_shard_owned_count_expand) — a self-drawn resample
+// then places in the table's launch
+static int32_t shard_owned_count_impl(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
+                                      uint64_t* counts_out, double* fuse_send) {
     if (!h || !d_tiles_all) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (!h->initialised) return mp_fail(MP_ERR_STATE, "resample before init_step");
     if (scheme != MP_RESAMPLE_MULTINOMIAL && scheme != MP_RESAMPLE_SYSTEMATIC && scheme != MP_RESAMPLE_STRATIFIED && scheme != MP_RESAMPLE_MULTINOMIAL_SPLIT)
@@ -1785,6 +1806,7 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     if (rc != MP_OK) return rc;
     h->ow_rank = rank;
     h->ow_self = false;
+    h->ow_placed = false;
     h->ow_solo_folded = false;
     // Self-drawn form (mp_pf_shard_kernels.h): the lattice schemes (unless MP_SHARD_SELF=0) and the split multinomial.  A world of
     // one needs the table the last level-0 launch left (ensure_table); without it the lattice schemes keep the window form and
@@ -1809,8 +1831,14 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
             pa.scal = h->scal; pa.undo = h->scal_undo; pa.head = nullptr;
             pa.base = h->ow_base; pa.plan_out = h->ow_plan; pa.pub = h->d_pub; pa.seq = ++h->ow_seq;
             pa.range = h->ow_range; pa.Wd = (u64)OWN_ROUND;
-            // (the plan needs nothing but the counts: the table kernel's first workgroup makes it on its way out — no launch of its own)
-            launch_shard_table(h, (const u64*)d_tiles_all, world, h->ow_call, (int)scheme, rank, h->ow_range, h->ow_kthr, &pa);
+            // (the plan needs nothing but the counts: the table kernel's leading workgroup makes it on its way out — no launch of its
+            // own; with an equal-split send buffer known now, and the kept draws left to the next k_propagate, it places too)
+            const bool fuse = fuse_send && capacity > 0 && self_k1_draws(h);
+            const mp_self_place_args pl = self_place_args(h, rank, capacity, fuse_send);
+            launch_shard_table(h, (const u64*)d_tiles_all, world, h->ow_call, (int)scheme, rank, h->ow_range, h->ow_kthr, &pa, fuse ? &pl : nullptr);
+            h->ow_placed = fuse;
+            h->ow_placed_cap = capacity;
+            h->ow_placed_send = fuse_send;
         }
         rc = check_launch("self-drawn resample: table / plan");
         if (rc != MP_OK) return rc;
@@ -1877,6 +1905,22 @@ int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tile
     return MP_OK;
 }
 
+int32_t mp_pf_shard_owned_count(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
+                                uint64_t* counts_out) {
+    return shard_owned_count_impl(h, scheme, d_tiles_all, world, rank, capacity, counts_out, nullptr);
+}
+
+int32_t mp_pf_shard_owned_count_expand(mp_pf* h, int32_t scheme, const uint64_t* d_tiles_all, int32_t world, int32_t rank, uint64_t capacity,
+                                       double* d_send_out, double* d_rows, uint64_t recv_rows) {
+    if (!h || !d_tiles_all || !d_send_out || !d_rows) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
+    if (capacity == 0) return mp_fail(MP_ERR_INVALID_ARG, "count_expand is the equal-split form: capacity must be > 0 (exact sizes: count, then expand)");
+    if (world >= 1 && recv_rows != (uint64_t)world * capacity) return mp_fail(MP_ERR_INVALID_ARG, "fixed capacity: recv_rows must be world * capacity");
+    if (recv_rows + h->n >= (1ull << 31)) return mp_fail(MP_ERR_INVALID_ARG, "exchange buffer rows must be < 2^31 (row indices carry a flag bit)");
+    int32_t rc = shard_owned_count_impl(h, scheme, d_tiles_all, world, rank, capacity, nullptr, d_send_out);
+    if (rc != MP_OK) return rc;
+    return mp_pf_shard_owned_expand(h, world, rank, capacity, d_send_out, d_rows, recv_rows);
+}
+
 int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t capacity, double* d_send_out, double* d_rows, uint64_t recv_rows) {
     if (!h || !d_send_out || !d_rows) return mp_fail(MP_ERR_INVALID_ARG, "null argument");
     if (!h->ow_seg_lt || h->ow_world != world) return mp_fail(MP_ERR_STATE, "shard_owned_expand before shard_owned_count");
@@ -1889,19 +1933,19 @@ int32_t mp_pf_shard_owned_expand(mp_pf* h, int32_t world, int32_t rank, uint64_t
         // the kept offspring are drawn by the next k_propagate itself where its kernel can (self_k1_draws), here otherwise; the
         // surplus is looked up now (it travels), the deficit slots are flagged with the rows that will arrive
         if (world == 1 && self_k1_draws(h)) return MP_OK;   // (nothing to launch: no surplus, no deficit, the draws are the next step's)
+        // nothing left to launch: the table's leading workgroup has placed — into THIS buffer with THIS capacity (the exact-size repeat
+        // after an overflow verdict comes with another buffer and capacity 0: placed again below)
+        if (h->ow_placed && self_k1_draws(h) && capacity == h->ow_placed_cap && d_send_out == h->ow_placed_send) return MP_OK;
         LaunchTimer lt(h, MP_K_RESAMPLE_GATHER);
         if (!self_k1_draws(h)) {
             int32_t rcs = launch_self_draws(h, h->ow_scheme, h->resample_count, world, rank);
             if (rcs != MP_OK) return rcs;
         }
         if (world > 1) {
-            const size_t off = (size_t)rank * (size_t)h->nt;
             auto kern = (h->ow_scheme == MP_RESAMPLE_MULTINOMIAL_SPLIT) ? k_shard_self_place<false> : k_shard_self_place<true>;
-            hipLaunchKernelGGL(kern, dim3(64), dim3(256), 0, h->stream, h->n, h->n_global, h->slot_offset, (uint32_t)h->seed, (uint32_t)(h->seed >> 32),
-                               h->resample_count, h->ow_scheme, h->ops->dim_state, world, rank, (u64)capacity, (const u64*)h->sh_incl_all + off,
-                               (const u64*)h->sh_tW_all + off, (const double*)h->sh_ratio_all + off, h->nt, (const unsigned short*)h->guide,
-                               (const mp_own_range*)h->ow_range, (const mp_cx*)h->cx, (const double*)h->x[h->cur], (const mp_owned_plan*)h->ow_plan,
-                               d_send_out, h->dfr_lt, h->dfr_row);
+            hipLaunchKernelGGL(kern, dim3(64), dim3(256), 0, h->stream, self_place_args(h, rank, capacity, d_send_out), h->n_global, (uint32_t)h->seed,
+                               (uint32_t)(h->seed >> 32), h->resample_count, h->ow_scheme, world, rank, h->nt, (const mp_own_range*)h->ow_range,
+                               (const mp_owned_plan*)h->ow_plan);
         }
         return check_launch("k_shard_self_place");
     }

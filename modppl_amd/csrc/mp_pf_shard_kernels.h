@@ -266,30 +266,164 @@ __global__ __launch_bounds__(SH_THREADS) void k_shard_route_fused(u64 n, u64 n_g
 // (mp_own_range — this rank's own draws of a resample — is declared in mp_pf_kernels.h: k_propagate's SHD form reads it too)
 constexpr int MP_SCHEME_SPLIT = 3;           // MP_RESAMPLE_MULTINOMIAL_SPLIT (include/modppl_hip.h): sharded resamples only
 // Offspring per rank of the split multinomial resample (mp_binomial.h): binary splitting of the N draws over the ranks, one binomial
-// variate per tree node, the nodes of a level by different lanes.  s_bound[r] = the job's inclusive prefix of T_b at the end of rank
-// r's tiles; s_n = [2 * 64] heap of draw counts (node k: children 2k, 2k + 1; leaf of rank r: P + r).  Called by EVERY thread of the
-// workgroup (barriers); the counts are s_n[P + r] afterwards, P = 1 << mp_split_levels(world).
-__device__ __forceinline__ void mp_split_counts(const u64* s_bound, int world, u64 n_global, uint32_t rc, uint32_t k0, uint32_t k1, u64* s_n) {
+// variate per tree node.  s_bound[r] = the job's inclusive prefix of T_b at the end of rank r's tiles; s_n = [2 * 64] heap of draw
+// counts (node k: children 2k, 2k + 1; leaf of rank r: P + r).  Called by EVERY thread of the workgroup (barriers), after a barrier
+// that made s_bound visible; the counts are s_n[P + r] afterwards, P = 1 << mp_split_levels(world).
+// A variate is what mp_binomial_ratio returns — the FIRST accepted attempt of the sampler — but one lane walking a level of the tree
+// is a chain of ~600 dependent double-precision instructions at ~4 ns each (2.3 us per level measured, cold or warm alike:
+// profiles/r05/table_stamps.txt), so the work is laid out across lanes: MP_SPLIT_LANES adjacent lanes per node take one attempt
+// each (mp_btrs_fast: the sampler's own operations); the uniforms (mp_split_uniforms: before the table is even there) and the node's
+// masses — everything that does not depend on the node's draw count — are ready before the first level; the expensive acceptance
+// test (mp_btrs_slow: v <= the sum of seven terms) runs only for an attempt in front of the first one the squeeze accepted, its eight
+// pieces in the eight lanes of the group, added up in the sampler's order.  Tiny n p (the inversion branch) and "nothing accepted among
+// the side-by-side attempts" fall back to the sequential sampler itself.
+constexpr int MP_SPLIT_LANES = 8;
+// a cold path as a real call: inlined, its constants (logarithms, the inversion loop) were hoisted over the level loop and spilled
+__device__ __attribute__((noinline)) u64 mp_binomial_ratio_cold(u64 n, u64 a, u64 b, uint32_t node, uint32_t rc, uint32_t k0, uint32_t k1) {
+    return mp_binomial_ratio(n, a, b, node, rc, k0, k1);
+}
+// thread tid's attempt: the pair (U, V) of attempt tid % 8 at tree node tid / 8 (a pure function of the seed and the resample number)
+__device__ __forceinline__ void mp_split_uniforms(uint32_t rc, uint32_t k0, uint32_t k1, double* U, double* V) {
+    const mp_u64x2 blk = mp_philox4x32_10((uint32_t)threadIdx.x / MP_SPLIT_LANES, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | MP_SITE_SPLIT_COUNTS,
+                                          (uint32_t)threadIdx.x % MP_SPLIT_LANES, k0, k1);
+    *U = mp_u01(blk.a);
+    *V = mp_u01(blk.b);
+}
+__device__ __forceinline__ double mp_shfl_f64(double x, int src_lane) {
+    const u64 b = __builtin_bit_cast(u64, x);
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)b, src_lane), hi = (uint32_t)__shfl((int)(uint32_t)(b >> 32), src_lane);
+    return __builtin_bit_cast(double, ((u64)hi << 32) | lo);
+}
+__device__ __forceinline__ void mp_split_counts(const u64* s_bound, int world, u64 n_global, uint32_t rc, uint32_t k0, uint32_t k1, u64* s_n, double U,
+                                                double V) {
+    constexpr int A = MP_SPLIT_LANES;
+    static_assert(A == 8, "the acceptance test is laid out over eight lanes");
     const int tid = threadIdx.x;
     const int L = mp_split_levels(world), P = 1 << L;
+    const int node = tid / A, att = tid % A;
+    const bool have = node >= 1 && node < P;   // (P <= 64: the first 512 threads at most)
+    const int sh = (tid & 63) & ~(A - 1);      // first lane of this node's group inside its wave
+    double p = 0.;
+    u64 ma = 0ull, mb = 0ull;
+    int lvl = -1;
+    bool flipped = false;
+    if (have) {
+        lvl = 31 - __clz(node);
+        const int width = P >> lvl;   // leaves under this node: [a, a + width), split at a + width / 2
+        const int a = (node - (1 << lvl)) * width, mid = a + width / 2, b = a + width;
+        // mass of the leaves [0, r): ranks beyond `world` are empty
+        const u64 pa = a <= 0 ? 0ull : s_bound[(a < world ? a : world) - 1];
+        const u64 pm = s_bound[(mid < world ? mid : world) - 1];   // (mid >= 1)
+        const u64 pb = s_bound[(b < world ? b : world) - 1];
+        ma = pm - pa;
+        mb = pb - pa;
+        const u64 other = mb - ma;
+        flipped = ma > other;   // mp_binomial_ratio samples the smaller of the two masses
+        p = (double)(flipped ? other : ma) / (double)mb;
+    }
     if (tid == 0) s_n[1] = n_global;
     __syncthreads();
+    MP_STAMP(2, 9, 1);
     for (int l = 0; l < L; ++l) {
-        if (tid < (1 << l)) {
-            const int node = (1 << l) + tid;
-            const int width = P >> l;   // leaves under this node: [a, a + width), split at a + width / 2
-            const int a = tid * width, mid = a + width / 2, b = a + width;
-            // mass of the leaves [0, r): ranks beyond `world` are empty
-            const u64 pa = a <= 0 ? 0ull : s_bound[(a < world ? a : world) - 1];
-            const u64 pm = s_bound[(mid < world ? mid : world) - 1];   // (mid >= 1)
-            const u64 pb = s_bound[(b < world ? b : world) - 1];
+        if (have && lvl == l) {   // (whole groups of A lanes; everything below that is not per attempt is the same in the A lanes)
             const u64 nk = s_n[node];
-            const u64 left = mp_binomial_ratio(nk, pm - pa, pb - pa, (uint32_t)node, rc, k0, k1);
-            s_n[2 * node] = left;
-            s_n[2 * node + 1] = nk - left;
+            const bool trivial = nk == 0ull || ma == 0ull || ma >= mb;
+            int st = 0;             // this lane's attempt: 0 rejected, 1 accepted, 2 the squeeze did not decide
+            double k = 0.;
+            mp_btrs T = {};
+            bool generic = false;   // the sequential sampler decides
+            if (!trivial) {
+                const double n = (double)nk;
+                if (n * p < 10.) generic = true;
+                else {
+                    mp_btrs_setup(T, n, p);
+                    st = mp_btrs_fast(T, U, V, &k);
+                }
+            }
+            uint32_t acc = (uint32_t)(__ballot(st == 1) >> sh) & 0xFFu;
+            // the sampler takes the FIRST accepted attempt: an undecided one matters only in front of the first the squeeze accepted
+            uint32_t und = (uint32_t)(__ballot(st == 2) >> sh) & 0xFFu & (acc ? ((acc & (0u - acc)) - 1u) : 0xFFu);
+            while (und) {   // (uniform in the group) the first undecided attempt, its test by the eight lanes
+                const int cand = __ffs((int)und) - 1;
+                const double Uc = mp_shfl_f64(U, sh + cand), Vc = mp_shfl_f64(V, sh + cand), kc = mp_shfl_f64(k, sh + cand);
+                const double us = 0.5 - fabs(Uc - 0.5);
+                const double n = T.n, m = T.m, r = T.r;
+                // mp_btrs_slow's pieces: lanes 0 .. 3 a term c log(x / y) each, lanes 4 .. 7 a Stirling tail each
+                const int j = att & 3;
+                const double c = j == 0 ? 1. : (j == 1 ? m + 0.5 : (j == 2 ? n + 1. : kc + 0.5));
+                const double x = j == 0 ? Vc * T.alpha : (j == 1 ? m + 1. : (j == 2 ? n - m + 1. : r * (n - kc + 1.)));
+                const double y = j == 0 ? T.a / (us * us) + T.b : (j == 1 ? r * (n - m + 1.) : (j == 2 ? n - kc + 1. : kc + 1.));
+                const double z = j == 0 ? m : (j == 1 ? n - m : (j == 2 ? kc : n - kc));
+                const double piece = att < 4 ? mp_btrs_logterm(c, x, y) : mp_stirling_tail(z);
+                const double v = mp_shfl_f64(piece, sh);
+                const double ub = mp_shfl_f64(piece, sh + 1) + mp_shfl_f64(piece, sh + 2) + mp_shfl_f64(piece, sh + 3) + mp_shfl_f64(piece, sh + 4) +
+                                  mp_shfl_f64(piece, sh + 5) - mp_shfl_f64(piece, sh + 6) - mp_shfl_f64(piece, sh + 7);
+                if (v <= ub) {   // accepted, and in front of every attempt the squeeze accepted
+                    acc |= 1u << cand;
+                    break;
+                }
+                und &= und - 1u;
+            }
+            if (!trivial && !generic && acc == 0u) generic = true;
+            u64 left = 0ull;
+            bool writer = att == 0;
+            if (trivial) {
+                left = (nk == 0ull || ma == 0ull) ? 0ull : nk;
+            } else if (generic) {
+                if (writer) left = mp_binomial_ratio_cold(nk, ma, mb, (uint32_t)node, rc, k0, k1);
+            } else {
+                writer = att == __ffs((int)acc) - 1;
+                const u64 kk = (u64)k;
+                left = flipped ? nk - kk : kk;
+            }
+            if (writer) {
+                s_n[2 * node] = left;
+                s_n[2 * node + 1] = nk - left;
+            }
         }
         __syncthreads();
+        MP_STAMP(2, 10 + (l < 6 ? l : 5), 1);
     }
+}
+// Owner-keeps exchange under a lattice scheme: targets are non-decreasing in g, so the draws that land in rank r's rows are the
+// range [G_{r-1}, G_r) with G_r = #{g : target(g) <= B_r}, B_r = the end of r's tiles — the same target function as the draw kernels,
+// so the ranges are exactly the draws those kernels will call their own.  target(g) = ((g 2^32 + k32_g) Q >> 32) / N + 1 crosses B_r
+// within a draw of g* = B_r N / Q: 8 adjacent lanes per rank evaluate g* - 4 .. g* + 3 and count the targets <= B_r; a pattern that
+// is not "true .. true false .. false" (it always is) would be settled by the bisection this replaces (33 serial probes, 3.3 - 5.5 us).
+// Called by every thread; s_G[r] = G_r afterwards (a barrier has passed).
+__device__ __forceinline__ void mp_lattice_ranges(const u64* s_bound, u64* s_G, int world, int scheme, u64 Q, u64 n_global, uint32_t rc, uint32_t k0,
+                                                  uint32_t k1) {
+    constexpr int W = 8;
+    const int tid = threadIdx.x, r = tid / W, j = tid % W;
+    if (r < world) {
+        const int sh = (tid & 63) & ~(W - 1);
+        const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
+        const u64 B = s_bound[r];
+        const double est = (double)B * (double)n_global / (double)Q;   // (Q == 0: NaN or inf)
+        const u64 gc = !(est >= 0.) ? 0ull : (est >= (double)n_global ? n_global : (u64)est);
+        const long long g = (long long)gc - W / 2 + j;
+        bool le;
+        if (g < 0) le = true;
+        else if ((u64)g >= n_global) le = false;
+        else le = mp_target_lattice(scheme, (u64)g, k32, rc, k0, k1, Q, n_global) <= B;
+        const uint32_t pat = (uint32_t)(__ballot(le) >> sh) & 0xFFu;
+        if (j == 0) {
+            u64 G;
+            if ((pat & 1u) && !(pat & 0x80u) && (pat & (pat + 1u)) == 0u) {
+                G = (u64)((long long)gc - W / 2 + (long long)__popc(pat));
+            } else {
+                u64 lo = 0, hi = n_global;
+                while (lo < hi) {   // at most 33 probes
+                    const u64 mid = lo + ((hi - lo) >> 1);
+                    if (mp_target_lattice(scheme, mid, k32, rc, k0, k1, Q, n_global) <= B) lo = mid + 1;
+                    else hi = mid;
+                }
+                G = lo;
+            }
+            s_G[r] = G;
+        }
+    }
+    __syncthreads();
 }
 // the exchange plan: unit u of the surplus (donors in rank order) fills unit u of the deficit (receivers in rank order)
 struct mp_owned_plan {
@@ -320,321 +454,6 @@ template <int THREADS>
 __device__ __forceinline__ void mp_own_plan(const mp_own_plan_args& a);
 constexpr int SHT_THREADS = 1024;
 constexpr int SHT_PER = MAX_TILES / SHT_THREADS;   // tiles per thread, held in registers (8)
-// the exchange plan of a self-drawn resample needs nothing but the counts: the table kernel's (first) workgroup makes it on its way out
-// instead of a launch of its own (do_plan 0: the window form, whose plan also scans the draw kernel's counts)
-__device__ __forceinline__ void mp_table_then_plan(const mp_own_plan_args& plan, int do_plan) {
-    if (!do_plan) return;       // (uniform)
-    __syncthreads();            // the counts and the scalars this workgroup just stored are out (a workgroup barrier waits for its stores)
-    mp_own_plan<SHT_THREADS>(plan);
-}
-__global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
-                                                             double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
-                                                             u64* __restrict__ incl_all, double* __restrict__ ratio_all,
-                                                             long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
-                                                             unsigned long long* __restrict__ c_all = nullptr, int scheme = 0, int rank = 0,
-                                                             uint32_t k0 = 0, uint32_t k1 = 0, uint32_t rc = 0, mp_own_range* range = nullptr,
-                                                             u64* __restrict__ kthr = nullptr, mp_own_plan_args plan = mp_own_plan_args{}, int do_plan = 0) {
-    __shared__ double s_red[SHT_THREADS / 64];
-    __shared__ u64 s_wtot[SHT_THREADS / 64];
-    __shared__ u64 s_wtot2[SHT_THREADS / 64];
-    const int nt = world * nt_local;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < SH_MAX_KEYS) zero_counts[tid] = 0;
-    __shared__ u64 s_bound[SH_MAX_WORLD];
-    __shared__ u64 s_G[SH_MAX_WORLD];
-    // thread t owns tiles t * per .. t * per + per - 1 (consecutive, so that a thread-local running sum is a prefix); each
-    // tile is read once, kept in registers, and its unpacked copy written for the kernels that want plain arrays
-    const int per = (nt + SHT_THREADS - 1) / SHT_THREADS;   // <= SHT_PER since nt <= MAX_TILES
-    const int b0 = tid * per;
-    double mb[SHT_PER];
-    u64 Wb[SHT_PER], W2b[SHT_PER];
-    double m = MP_NEG_INF;
-#pragma unroll
-    for (int j = 0; j < SHT_PER; ++j) {
-        const int i = b0 + j;
-        mb[j] = MP_NEG_INF; Wb[j] = 0; W2b[j] = 0;
-        if (j < per && i < nt) {
-            const int r = i / nt_local, b = i - r * nt_local;
-            const u64* base = packed + (u64)r * 3 * nt_local;
-            mb[j] = mp_u2f(base[b]);
-            Wb[j] = base[nt_local + b];
-            W2b[j] = base[2 * nt_local + b];
-            tm[i] = mb[j]; tW[i] = Wb[j]; tW2[i] = W2b[j];
-            m = fmax(m, mb[j]);
-        }
-    }
-    m = wave_max(m);
-    if (lane == 0) s_red[wave] = m;
-    __syncthreads();
-    m = s_red[0];
-#pragma unroll
-    for (int w = 1; w < SHT_THREADS / 64; ++w) m = fmax(m, s_red[w]);
-    // level 1 exactly as block_tile_table / block_sum_T2 state it: T_b = rint(W_b exp(m_b - m) 2^(S-51)), T2_b likewise with
-    // exp(2 (m_b - m)); integer sums, so the order of the reduction is immaterial
-    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
-    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
-    u64 pre[SHT_PER];
-    double ratio[SHT_PER];
-    u64 run = 0, run2 = 0;
-#pragma unroll
-    for (int j = 0; j < SHT_PER; ++j) {
-        const int i = b0 + j;
-        pre[j] = 0;
-        if (j < per && i < nt) {
-            const double f = ok ? mp_exp(mb[j] - m) : 0.;
-            const double f2 = ok ? mp_exp(2. * (mb[j] - m)) : 0.;
-            const u64 T = mp_quantize((double)Wb[j] * f * sc, 1.0);
-            run += T;
-            run2 += mp_quantize((double)W2b[j] * f2 * sc, 1.0);
-            pre[j] = run;
-            ratio[j] = (double)Wb[j] / (double)T;   // of mp_local_target; never used for a tile with T = 0 (no target lands in it)
-        }
-    }
-    const u64 incl = wave_incl_scan_u64(run, lane);
-    const u64 tot2 = wave_sum_u64(run2);
-    if (lane == 63) s_wtot[wave] = incl;
-    if (lane == 0) s_wtot2[wave] = tot2;
-    __syncthreads();
-    u64 woff = 0, Q = 0, Q2 = 0;
-#pragma unroll
-    for (int w = 0; w < SHT_THREADS / 64; ++w) {
-        if (w < wave) woff += s_wtot[w];
-        Q += s_wtot[w];
-        Q2 += s_wtot2[w];
-    }
-    const u64 off = woff + (incl - run);
-#pragma unroll
-    for (int j = 0; j < SHT_PER; ++j) {
-        const int i = b0 + j;
-        if (j < per && i < nt) { incl_all[i] = off + pre[j]; ratio_all[i] = ratio[j]; }
-    }
-    if (tid == 0) {
-        *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
-        fold_scalars(scal, Q, Q2, S, m, n_global, 0);
-    }
-    // Owner-keeps exchange under a lattice scheme: targets are non-decreasing in g, so the draws that land in rank r's rows
-    // are the range [G_{r-1}, G_r) with G_r = #{g : target(g) <= end of r's tiles}: one binary search per rank (the same target
-    // function as the draw kernels, so the ranges are exactly the draws those kernels will call their own).
-    if (c_all) {
-#pragma unroll
-        for (int j = 0; j < SHT_PER; ++j) {
-            const int i = b0 + j;
-            if (j < per && i < nt && (i + 1) % nt_local == 0) s_bound[i / nt_local] = off + pre[j];
-        }
-        __syncthreads();
-    }
-    // Owner-keeps exchange, multinomial: the rank boundaries as thresholds on the 52-bit uniforms themselves.  target(k) =
-    // max(1, ceil(k Q / 2^52)) is non-decreasing in k, so target(k) > B  <=>  k >= K(B) = the smallest such k (= floor(B 2^52 / Q)
-    // + 1, found from a double estimate and corrected with the target function itself): the draw kernel then tells whose a
-    // draw is with 64-bit compares and pays the 128-bit target only for its own.
-    if (c_all && kthr && scheme == 0) {
-        if (tid < world) {
-            const u64 B = s_bound[tid];
-            const u64 top = 1ull << 52;
-            double est = (double)B * 4503599627370496.0 / (double)Q;   // Q == 0: NaN / inf -> clamped below
-            u64 K = (est >= 4503599627370496.0) ? top : ((est >= 8.) ? (u64)est - 8ull : 0ull);
-            if (!(est == est)) K = 0ull;
-            while (K > 0ull && mp_target(K - 1ull, Q) > B) --K;          // (a few steps at most: the estimate is within a few units)
-            while (K < top && mp_target(K, Q) <= B) ++K;
-            kthr[tid] = K;
-            if (world > 1) c_all[tid] = 0ull;   // the draw kernel's workgroups add the offspring per rank up
-        }
-    }
-    if (c_all && scheme == MP_SCHEME_SPLIT) {   // (workgroup-uniform)
-        __shared__ u64 s_heap[2 * SH_MAX_WORLD];
-        mp_split_counts(s_bound, world, n_global, rc, k0, k1, s_heap);
-        if (tid < world) {
-            const u64 c = s_heap[(1 << mp_split_levels(world)) + tid];
-            c_all[tid] = c;
-            if (tid == rank) { range->g_lo = 0ull; range->g_hi = c; }
-        }
-    }
-    if (c_all && (scheme == 1 || scheme == 2)) {
-        if (tid < world) {
-            const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
-            const u64 B = s_bound[tid];
-            u64 lo = 0, hi = n_global;
-            while (lo < hi) {   // at most 33 probes
-                const u64 mid = lo + ((hi - lo) >> 1);
-                if (mp_target_lattice(scheme, mid, k32, rc, k0, k1, Q, n_global) <= B) lo = mid + 1;
-                else hi = mid;
-            }
-            s_G[tid] = lo;
-        }
-        __syncthreads();
-        if (tid < world) {
-            const u64 g0 = tid ? s_G[tid - 1] : 0ull;
-            c_all[tid] = s_G[tid] - g0;
-            if (tid == rank) { range->g_lo = g0; range->g_hi = s_G[tid]; }
-        }
-    }
-    mp_table_then_plan(plan, do_plan);
-}
-// The same table by `world` workgroups (worlds of more than one rank): workgroup r takes rank r's nt_local tiles, so the
-// serial part no longer grows with the job (16.9 us for 8 x 512 tiles by one workgroup, profiles/r03/route_scale.txt).
-// Every workgroup finds the job's maximum itself (world x nt_local loads), quantises its own tiles, publishes its two sums
-// {sum T, sum T2} and a ticket (agent scope), waits until all `world` tickets of this launch are there — the workgroups are
-// co-resident: world <= 64 of them on 256 CUs — and adds the sums of the ranks before it to its local prefix.  Workgroup 0
-// then folds the scalars and works out the per-rank boundaries (thresholds / lattice ranges) exactly as the one-workgroup
-// form does.  `ticket` counts up by `world` per launch (never reset): this launch waits for `ticket_target`.
-struct mp_tab_part {
-    u64 Q, Q2;
-};
-__global__ __launch_bounds__(SHT_THREADS) void k_shard_table_mw(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
-                                                                double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
-                                                                u64* __restrict__ incl_all, double* __restrict__ ratio_all,
-                                                                long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
-                                                                unsigned long long* __restrict__ c_all, int scheme, int rank, uint32_t k0, uint32_t k1,
-                                                                uint32_t rc, mp_own_range* range, u64* __restrict__ kthr, mp_tab_part* __restrict__ part,
-                                                                unsigned int* __restrict__ ticket, unsigned int ticket_target,
-                                                                mp_own_plan_args plan = mp_own_plan_args{}, int do_plan = 0) {
-    __shared__ double s_red[SHT_THREADS / 64];
-    __shared__ u64 s_wtot[SHT_THREADS / 64];
-    __shared__ u64 s_wtot2[SHT_THREADS / 64];
-    __shared__ u64 s_bound[SH_MAX_WORLD];
-    __shared__ u64 s_G[SH_MAX_WORLD];
-    __shared__ u64 s_off, s_Q, s_Q2;
-    const int nt = world * nt_local;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int me = (int)blockIdx.x;   // the rank whose tiles this workgroup quantises
-    if (me == 0 && tid < SH_MAX_KEYS) zero_counts[tid] = 0;
-    // the job's maximum: every tile maximum of the gathered buffer
-    double m = MP_NEG_INF;
-    for (int i = tid; i < nt; i += SHT_THREADS) {
-        const int r = i / nt_local, b = i - r * nt_local;
-        m = fmax(m, mp_u2f(packed[(u64)r * 3 * nt_local + b]));
-    }
-    // this rank's tiles: thread t owns tiles t * per .. t * per + per - 1 of them
-    const int per = (nt_local + SHT_THREADS - 1) / SHT_THREADS;   // <= SHT_PER
-    const int b0 = tid * per;
-    const u64* base = packed + (u64)me * 3 * nt_local;
-    double mb[SHT_PER];
-    u64 Wb[SHT_PER], W2b[SHT_PER];
-#pragma unroll
-    for (int j = 0; j < SHT_PER; ++j) {
-        const int b = b0 + j;
-        mb[j] = MP_NEG_INF; Wb[j] = 0; W2b[j] = 0;
-        if (j < per && b < nt_local) {
-            mb[j] = mp_u2f(base[b]);
-            Wb[j] = base[nt_local + b];
-            W2b[j] = base[2 * nt_local + b];
-            const int i = me * nt_local + b;
-            tm[i] = mb[j]; tW[i] = Wb[j]; tW2[i] = W2b[j];
-        }
-    }
-    m = wave_max(m);
-    if (lane == 0) s_red[wave] = m;
-    __syncthreads();
-    m = s_red[0];
-#pragma unroll
-    for (int w = 1; w < SHT_THREADS / 64; ++w) m = fmax(m, s_red[w]);
-    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
-    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
-    u64 pre[SHT_PER];
-    double ratio[SHT_PER];
-    u64 run = 0, run2 = 0;
-#pragma unroll
-    for (int j = 0; j < SHT_PER; ++j) {
-        const int b = b0 + j;
-        pre[j] = 0;
-        if (j < per && b < nt_local) {
-            const double f = ok ? mp_exp(mb[j] - m) : 0.;
-            const double f2 = ok ? mp_exp(2. * (mb[j] - m)) : 0.;
-            const u64 T = mp_quantize((double)Wb[j] * f * sc, 1.0);
-            run += T;
-            run2 += mp_quantize((double)W2b[j] * f2 * sc, 1.0);
-            pre[j] = run;
-            ratio[j] = (double)Wb[j] / (double)T;
-        }
-    }
-    const u64 incl = wave_incl_scan_u64(run, lane);
-    const u64 tot2 = wave_sum_u64(run2);
-    if (lane == 63) s_wtot[wave] = incl;
-    if (lane == 0) s_wtot2[wave] = tot2;
-    __syncthreads();
-    u64 woff = 0, Qr = 0, Q2r = 0;
-#pragma unroll
-    for (int w = 0; w < SHT_THREADS / 64; ++w) {
-        if (w < wave) woff += s_wtot[w];
-        Qr += s_wtot[w];
-        Q2r += s_wtot2[w];
-    }
-    // publish this rank's sums, then wait for everybody's
-    if (tid == 0) {
-        mp_st_agent(&part[me].Q, Qr);
-        mp_st_agent(&part[me].Q2, Q2r);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sums are out before the ticket says so
-        (void)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_target) < 0) __builtin_amdgcn_s_sleep(2);
-    }
-    __syncthreads();
-    if (tid < 64) {
-        // inclusive prefix over the ranks (world <= 64: one wave).  The WHOLE of wave 0 takes part, lanes beyond `world` with
-        // zeros: wave_sum_u64 reads lane 63 of the scan, which an inactive lane would never have written
-        const bool have = tid < world;
-        const u64 q = have ? mp_ld_agent(&part[tid].Q) : 0ull, q2 = have ? mp_ld_agent(&part[tid].Q2) : 0ull;
-        const u64 inc = wave_incl_scan_u64(q, lane);
-        const u64 t2 = wave_sum_u64(q2);
-        if (have) s_bound[tid] = inc;
-        if (tid == me) s_off = inc - q;
-        if (tid == world - 1) { s_Q = inc; s_Q2 = t2; }
-    }
-    __syncthreads();
-    const u64 off = s_off + woff + (incl - run);
-    const u64 Q = s_Q, Q2 = s_Q2;
-#pragma unroll
-    for (int j = 0; j < SHT_PER; ++j) {
-        const int b = b0 + j;
-        if (j < per && b < nt_local) { incl_all[me * nt_local + b] = off + pre[j]; ratio_all[me * nt_local + b] = ratio[j]; }
-    }
-    if (me != 0) return;
-    if (tid == 0) {
-        *undo = *scal;
-        fold_scalars(scal, Q, Q2, S, m, n_global, 0);
-    }
-    if (c_all && kthr && scheme == 0) {
-        if (tid < world) {
-            const u64 B = s_bound[tid];
-            const u64 top = 1ull << 52;
-            double est = (double)B * 4503599627370496.0 / (double)Q;
-            u64 K = (est >= 4503599627370496.0) ? top : ((est >= 8.) ? (u64)est - 8ull : 0ull);
-            if (!(est == est)) K = 0ull;
-            while (K > 0ull && mp_target(K - 1ull, Q) > B) --K;
-            while (K < top && mp_target(K, Q) <= B) ++K;
-            kthr[tid] = K;
-            c_all[tid] = 0ull;   // the draw kernel's workgroups add the offspring per rank up
-        }
-    }
-    if (c_all && scheme == MP_SCHEME_SPLIT) {   // (workgroup-uniform)
-        __shared__ u64 s_heap[2 * SH_MAX_WORLD];
-        mp_split_counts(s_bound, world, n_global, rc, k0, k1, s_heap);
-        if (tid < world) {
-            const u64 c = s_heap[(1 << mp_split_levels(world)) + tid];
-            c_all[tid] = c;
-            if (tid == rank) { range->g_lo = 0ull; range->g_hi = c; }
-        }
-    }
-    if (c_all && (scheme == 1 || scheme == 2)) {
-        if (tid < world) {
-            const uint32_t k32 = scheme == 1 ? mp_systematic_k32(rc, k0, k1) : 0u;
-            const u64 B = s_bound[tid];
-            u64 lo = 0, hi = n_global;
-            while (lo < hi) {
-                const u64 mid = lo + ((hi - lo) >> 1);
-                if (mp_target_lattice(scheme, mid, k32, rc, k0, k1, Q, n_global) <= B) lo = mid + 1;
-                else hi = mid;
-            }
-            s_G[tid] = lo;
-        }
-        __syncthreads();
-        if (tid < world) {
-            const u64 g0 = tid ? s_G[tid - 1] : 0ull;
-            c_all[tid] = s_G[tid] - g0;
-            if (tid == rank) { range->g_lo = g0; range->g_hi = s_G[tid]; }
-        }
-    }
-    mp_table_then_plan(plan, do_plan);
-}
 // owner side: blockIdx.x & 7 = eighth of this shard's tiles (workgroups are dealt round-robin to the 8 XCDs, gridDim.x is
 // a multiple of 8), blockIdx.y = asking rank.  Per request: guide cell -> first row -> short forward walk, all inside
 // the eighth.  Rows go back in the order the requests came.
@@ -1224,67 +1043,452 @@ __global__ __launch_bounds__(SELF_THREADS) void k_shard_self_draw(u64 n, u64 n_g
     }
 }
 // the surplus offspring p = n .. c_me - 1 (looked up here: row {state, parent's global id} into the send buffer where the plan says)
-// and the deficit slots [c_me, n) (MP_DRAW_RECV | the index of the row that will arrive); a handful of workgroups, grid-stride
+// and the deficit slots [c_me, n) (MP_DRAW_RECV | the index of the row that will arrive); threads t0, t0 + stride, ... of whoever runs it
+struct mp_self_place_args {
+    u64 n, slot_offset, cap;
+    int D;
+    const u64* incl_sl;            // this rank's slice of the job's table (k_shard_table's arrays)
+    const u64* W_sl;
+    const double* ratio_sl;
+    const unsigned short* guide;
+    const mp_cx* cx;
+    const double* x;
+    double* send;
+    u64* dfr_lt;
+    uint32_t* dfr_row;
+};
 template <bool LATTICE>
-__global__ __launch_bounds__(256) void k_shard_self_place(u64 n, u64 n_global, u64 slot_offset, uint32_t k0, uint32_t k1, uint32_t rc, int scheme, int D,
-                                                          int world, int rank, u64 cap, const u64* __restrict__ incl_sl, const u64* __restrict__ W_sl,
-                                                          const double* __restrict__ ratio_sl, int nt_local, const unsigned short* __restrict__ guide,
-                                                          const mp_own_range* __restrict__ range, const mp_cx* __restrict__ cx,
-                                                          const double* __restrict__ x, const mp_owned_plan* __restrict__ plan, double* __restrict__ send,
-                                                          u64* __restrict__ dfr_lt, uint32_t* __restrict__ dfr_row) {
-    const u64 lo = rank ? incl_sl[-1] : 0ull;
-    const u64 hi = incl_sl[nt_local - 1];
-    const u64 Q = incl_sl[(u64)(world - rank) * nt_local - 1];
-    const u64 g_lo = range->g_lo, c_me = range->g_hi - range->g_lo;
+__device__ __forceinline__ void mp_self_place(const mp_self_place_args& a, const mp_owned_plan* plan, int scheme, int world, int rank, int nt_local,
+                                              u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, u64 lo, u64 hi, u64 Q, u64 g_lo, u64 c_me, u64 t0,
+                                              u64 stride) {
+    const u64 n = a.n;
+    const int D = a.D;
     const u64 span = hi - lo;
     const double nt_over_span = (double)nt_local / (double)span;
     const uint32_t k32 = (LATTICE && scheme == 1) ? mp_systematic_k32(rc, k0, k1) : 0u;
     const u64 PS_me = plan->PS[rank];
-    const u64 stride = (u64)gridDim.x * blockDim.x, t0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (u64 p = n + t0; p < c_me; p += stride) {
         const u64 trel = mp_self_trel<LATTICE>(scheme, p, g_lo, lo, span, Q, n_global, k32, rank, rc, k0, k1);
         uint32_t tile, gslot;
         u64 lt;
-        mp_locate_own(incl_sl, W_sl, ratio_sl, (uint32_t)nt_local, trel + lo, trel, lo, nt_over_span, &tile, &lt, &gslot);
-        const uint32_t j0 = mp_guide_row(guide[gslot]);
+        mp_locate_own(a.incl_sl, a.W_sl, a.ratio_sl, (uint32_t)nt_local, trel + lo, trel, lo, nt_over_span, &tile, &lt, &gslot);
+        const uint32_t j0 = mp_guide_row(a.guide[gslot]);
         const u64 tbase = (u64)tile * TILE;
         const uint32_t tlen = (uint32_t)((n - tbase) < (u64)TILE ? (n - tbase) : (u64)TILE);
         const uint32_t row0 = (uint32_t)tbase + (j0 > tlen - 1 ? tlen - 1 : j0);
         uint32_t par;
         double x0;
-        mp_resolve_draw<true>(cx, n, lt, row0, &par, &x0);
+        mp_resolve_draw<true>(a.cx, n, lt, row0, &par, &x0);
         const u64 u = PS_me + (p - n);
         int s2 = 0;
         while (s2 + 1 < world && !(plan->D[s2] && u < plan->PD[s2] + plan->D[s2])) ++s2;
         double* dst = nullptr;
-        if (cap) {
+        if (a.cap) {
             const u64 first = PS_me > plan->PD[s2] ? PS_me : plan->PD[s2];
             const u64 jj = u - first;
-            if (jj < cap) dst = send + ((u64)s2 * cap + jj) * (u64)(D + 1);   // (jj >= cap: the plan has flagged it, nothing of this attempt is committed)
+            if (jj < a.cap) dst = a.send + ((u64)s2 * a.cap + jj) * (u64)(D + 1);   // (jj >= cap: the plan has flagged it, nothing of this attempt is committed)
         } else {
-            dst = send + (u - PS_me) * (u64)(D + 1);
+            dst = a.send + (u - PS_me) * (u64)(D + 1);
         }
         if (dst) {
             if (D == 1) dst[0] = x0;
             else
-                for (int d = 0; d < D; ++d) dst[d] = x[(u64)par * D + d];
-            dst[D] = (double)(slot_offset + par);
+                for (int d = 0; d < D; ++d) dst[d] = a.x[(u64)par * D + d];
+            dst[D] = (double)(a.slot_offset + par);
         }
     }
     const u64 PD_me = plan->PD[rank], D_me = plan->D[rank];
     for (u64 k = t0; k < D_me; k += stride) {
         u64 idx = k;
-        if (cap) {
+        if (a.cap) {
             const u64 u = PD_me + k;
             int r = 0;
             while (r + 1 < world && !(plan->S[r] && u < plan->PS[r] + plan->S[r])) ++r;
             const u64 first = plan->PS[r] > PD_me ? plan->PS[r] : PD_me;
             const u64 jj = u - first;
-            idx = jj >= cap ? 0ull : (u64)r * cap + jj;
+            idx = jj >= a.cap ? 0ull : (u64)r * a.cap + jj;
         }
-        dfr_lt[c_me + k] = 0ull;
-        dfr_row[c_me + k] = MP_DRAW_RECV | (uint32_t)idx;
+        a.dfr_lt[c_me + k] = 0ull;
+        a.dfr_row[c_me + k] = MP_DRAW_RECV | (uint32_t)idx;
     }
+}
+// a launch of its own (exact sizes: the host sized the send buffer from the counts first; models whose kept draws are a launch too)
+template <bool LATTICE>
+__global__ __launch_bounds__(256) void k_shard_self_place(mp_self_place_args a, u64 n_global, uint32_t k0, uint32_t k1, uint32_t rc, int scheme, int world,
+                                                          int rank, int nt_local, const mp_own_range* __restrict__ range,
+                                                          const mp_owned_plan* __restrict__ plan) {
+    MP_STAMP(3, 0, 1);
+    const u64 lo = rank ? a.incl_sl[-1] : 0ull;
+    const u64 hi = a.incl_sl[nt_local - 1];
+    const u64 Q = a.incl_sl[(u64)(world - rank) * nt_local - 1];
+    mp_self_place<LATTICE>(a, plan, scheme, world, rank, nt_local, n_global, k0, k1, rc, lo, hi, Q, range->g_lo, range->g_hi - range->g_lo,
+                           (u64)blockIdx.x * blockDim.x + threadIdx.x, (u64)gridDim.x * blockDim.x);
+    MP_STAMP(3, 2, 1);
+}
+// ---------------------------------------------------------------------------------------------
+// The job's tile table from the gathered tiles, and — by the table's LEADING workgroup, on its way out — everything of a resample
+// that needs nothing but the table: the filter scalars of this normalisation (L, ESS, log-ML; a copy kept for the case that a
+// fixed-capacity exchange overflows), the rank boundaries (multinomial: thresholds on the uniforms; lattice: every rank's range of
+// draws; split multinomial: the offspring per rank), and for a self-drawn resample the exchange plan, the host's verdict word and
+// the placement (surplus lookups into the send buffer, deficit slots flagged) — one launch where there were three.
+// ---------------------------------------------------------------------------------------------
+// the exchange plan of a self-drawn resample, by the workgroup that has just made the counts (s_c, LDS; *s_deg: degenerate weights):
+// no round trip through memory and nothing serial over the ranks (pub->L follows from the lane that folds the scalars).  The plan stays in LDS (pl) for the placement
+// that follows in the same launch, goes to memory for k_shard_self_place / the commit, and the host's part to its mapped page.
+template <int THREADS>
+__device__ __forceinline__ void mp_self_plan(const mp_own_plan_args& a, const u64* s_c, const int* s_deg, mp_owned_plan* pl, int* s_over) {
+    const int tid = threadIdx.x, world = a.world;
+    if (tid < 64) {   // (world <= 64: one wave, the WHOLE of it scans: lanes beyond `world` with zeros)
+        const bool have = tid < world;
+        const u64 c = have ? s_c[tid] : a.n;
+        const u64 S = c > a.n ? c - a.n : 0ull, D = c < a.n ? a.n - c : 0ull;
+        const u64 PS = wave_incl_scan_u64(S, tid) - S, PD = wave_incl_scan_u64(D, tid) - D;
+        if (have) {
+            pl->S[tid] = S; pl->D[tid] = D; pl->PS[tid] = PS; pl->PD[tid] = PD;
+            a.plan_out->S[tid] = S; a.plan_out->D[tid] = D; a.plan_out->PS[tid] = PS; a.plan_out->PD[tid] = PD;
+            mp_st_sys(&a.pub->counts[tid], (unsigned long long)c);
+        }
+        if (tid == 0) *s_over = 0;
+    }
+    __syncthreads();
+    // every rank must reach the same verdict on "some pair needs more than cap rows" (the collective that follows is symmetric),
+    // so every rank looks at every pair of the plan
+    int over = 0;
+    if (a.cap) {
+        for (int pq = tid; pq < world * world; pq += THREADS) {
+            const int r = pq / world, s2 = pq - r * world;
+            const u64 a0 = pl->PS[r] > pl->PD[s2] ? pl->PS[r] : pl->PD[s2];
+            const u64 e0 = pl->PS[r] + pl->S[r], e1 = pl->PD[s2] + pl->D[s2];
+            const u64 a1 = e0 < e1 ? e0 : e1;
+            if (a1 > a0 && a1 - a0 > a.cap) over = 1;
+        }
+    }
+    if (over) atomicOr(s_over, 1);
+    __syncthreads();
+    if (tid == 0) {
+        const int deg = *s_deg, ov = *s_over;
+        mp_st_sys(&a.pub->degenerate, deg);
+        mp_st_sys(&a.pub->overflow, ov);
+        // what the host polls between resamples: one word, so it needs no ordering against the fields above (those are read
+        // after the stream has drained: log total weight of a synchronous resample, counts of the exact-size repeat)
+        mp_st_sys(&a.pub->verdict, (a.seq << 8) | (unsigned long long)((deg ? 2 : 0) | (ov ? 1 : 0)));
+    }
+}
+struct mp_table_tail {
+    unsigned long long* c_all;   // [world] offspring per rank (null: the slot-order route — table and scalars only)
+    int scheme, rank;
+    uint32_t k0, k1, rc;
+    mp_own_range* range;
+    u64* kthr;                   // owner-keeps multinomial (the window form): [world] thresholds on the 52-bit uniforms
+    mp_own_plan_args plan;       // self-drawn resample: the plan from the counts alone
+    int do_plan;
+    mp_self_place_args place;    // and, with an equal-split capacity, the placement
+    int do_place;
+};
+// by the leading workgroup, every thread; s_bound (if c_all) is written and a barrier has passed.  lo / hi: the leader's own
+// share (lo, hi] of the job's mass — the leader quantised `rank`'s tiles itself, so the placement reads nothing but its own stores.
+// su, sv: mp_split_uniforms (split multinomial), made while the table was still on its way.
+template <int THREADS>
+__device__ __forceinline__ void mp_table_leader(const mp_table_tail& t, const u64* s_bound, u64* s_G, u64 Q, u64 Q2, double m, int world, int nt_local,
+                                                int S, u64 n_global, mp_dev_scalars* scal, mp_dev_scalars* undo, u64 lo, u64 hi, double su, double sv, int prev_deg) {
+    __shared__ u64 s_heap[2 * SH_MAX_WORLD];
+    __shared__ u64 s_c[SH_MAX_WORLD];
+    __shared__ mp_owned_plan s_pl;
+    __shared__ int s_deg, s_over;
+    const int tid = threadIdx.x;
+    MP_STAMP(2, 4, 1);
+    // The fold of this normalisation into the filter scalars (a logarithm, a dozen loads and stores: 1.1 us by one lane) is nobody's
+    // input in this launch except for the sticky "degenerate" flag, which is a comparison: one lane of a wave with nothing else to do
+    // (prev_deg: its early load of the flag) folds AFTER the last barrier, while the others place.
+    const bool folder = tid == THREADS - 64;
+    if (folder) s_deg = (prev_deg || !(m > MP_NEG_INF) || !(m < MP_INF) || Q == 0ull) ? 1 : 0;
+    if (!t.c_all || !t.do_plan) {
+        if (folder) {
+            *undo = *scal;   // a fixed-capacity exchange that overflows puts these back
+            fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+        }
+    }
+    if (!t.c_all) return;   // (workgroup-uniform, like every condition below)
+    // Owner-keeps exchange, multinomial: the rank boundaries as thresholds on the 52-bit uniforms themselves.  target(k) =
+    // max(1, ceil(k Q / 2^52)) is non-decreasing in k, so target(k) > B  <=>  k >= K(B) = the smallest such k (= floor(B 2^52 / Q)
+    // + 1, found from a double estimate and corrected with the target function itself): the draw kernel then tells whose a
+    // draw is with 64-bit compares and pays the 128-bit target only for its own.
+    if (t.kthr && t.scheme == 0) {
+        if (tid < world) {
+            const u64 B = s_bound[tid];
+            const u64 top = 1ull << 52;
+            double est = (double)B * 4503599627370496.0 / (double)Q;   // Q == 0: NaN / inf -> clamped below
+            u64 K = (est >= 4503599627370496.0) ? top : ((est >= 8.) ? (u64)est - 8ull : 0ull);
+            if (!(est == est)) K = 0ull;
+            while (K > 0ull && mp_target(K - 1ull, Q) > B) --K;          // (a few steps at most: the estimate is within a few units)
+            while (K < top && mp_target(K, Q) <= B) ++K;
+            t.kthr[tid] = K;
+            if (world > 1) t.c_all[tid] = 0ull;   // the draw kernel's workgroups add the offspring per rank up
+        }
+    }
+    u64 g_lo = 0ull;
+    if (t.scheme == MP_SCHEME_SPLIT) {
+        mp_split_counts(s_bound, world, n_global, t.rc, t.k0, t.k1, s_heap, su, sv);
+        if (tid < world) {
+            const u64 c = s_heap[(1 << mp_split_levels(world)) + tid];
+            s_c[tid] = c;
+            t.c_all[tid] = c;
+            if (tid == t.rank) { t.range->g_lo = 0ull; t.range->g_hi = c; }
+        }
+    }
+    if (t.scheme == 1 || t.scheme == 2) {
+        mp_lattice_ranges(s_bound, s_G, world, t.scheme, Q, n_global, t.rc, t.k0, t.k1);
+        if (tid < world) {
+            const u64 g0 = tid ? s_G[tid - 1] : 0ull;
+            s_c[tid] = s_G[tid] - g0;
+            t.c_all[tid] = s_G[tid] - g0;
+            if (tid == t.rank) { t.range->g_lo = g0; t.range->g_hi = s_G[tid]; }
+        }
+        g_lo = t.rank ? s_G[t.rank - 1] : 0ull;
+    }
+    MP_STAMP(2, 5, 1);
+    if (!t.do_plan) return;
+    __syncthreads();   // s_c, s_deg
+    mp_self_plan<THREADS>(t.plan, s_c, &s_deg, &s_pl, &s_over);
+    MP_STAMP(2, 6, 1);
+    if (folder) {
+        *undo = *scal;
+        fold_scalars(scal, Q, Q2, S, m, n_global, 0);
+        mp_st_sys(&t.plan.pub->L, scal->L);   // (read by a synchronous commit, after the stream has drained)
+        return;
+    }
+    if (!t.do_place || s_deg) return;   // (degenerate weights: the commit refuses, nothing to place)
+    const u64 c_me = s_c[t.rank];
+    if (t.scheme == MP_SCHEME_SPLIT)
+        mp_self_place<false>(t.place, &s_pl, t.scheme, world, t.rank, nt_local, n_global, t.k0, t.k1, t.rc, lo, hi, Q, g_lo, c_me, (u64)tid, (u64)THREADS);
+    else
+        mp_self_place<true>(t.place, &s_pl, t.scheme, world, t.rank, nt_local, n_global, t.k0, t.k1, t.rc, lo, hi, Q, g_lo, c_me, (u64)tid, (u64)THREADS);
+    MP_STAMP(2, 7, 1);
+}
+// One workgroup builds the whole table (jobs of up to 2048 tiles, and a world of one whose table no level-0 launch left)
+template <int PER_MAX>   // tiles per thread at most (registers): 2 covers the jobs this kernel is chosen for, SHT_PER every handle
+__global__ __launch_bounds__(SHT_THREADS) void k_shard_table(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
+                                                             double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
+                                                             u64* __restrict__ incl_all, double* __restrict__ ratio_all,
+                                                             long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
+                                                             mp_table_tail tail) {
+    __shared__ double s_red[SHT_THREADS / 64];
+    __shared__ u64 s_wtot[SHT_THREADS / 64];
+    __shared__ u64 s_wtot2[SHT_THREADS / 64];
+    __shared__ u64 s_bound[SH_MAX_WORLD];
+    __shared__ u64 s_G[SH_MAX_WORLD];
+    const int nt = world * nt_local;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < SH_MAX_KEYS) zero_counts[tid] = 0;
+    const int prev_deg = tid == SHT_THREADS - 64 ? scal->degenerate : 0;   // (the lane that folds: mp_table_leader)
+    double su = 0., sv = 0.;
+    if (tail.c_all && tail.scheme == MP_SCHEME_SPLIT) mp_split_uniforms(tail.rc, tail.k0, tail.k1, &su, &sv);
+    // thread t owns tiles t * per .. t * per + per - 1 (consecutive, so that a thread-local running sum is a prefix); each
+    // tile is read once, kept in registers, and its unpacked copy written for the kernels that want plain arrays
+    const int per = (nt + SHT_THREADS - 1) / SHT_THREADS;   // <= PER_MAX (the host picks the instance)
+    const int b0 = tid * per;
+    double mb[PER_MAX];
+    u64 Wb[PER_MAX], W2b[PER_MAX];
+    double m = MP_NEG_INF;
+#pragma unroll
+    for (int j = 0; j < PER_MAX; ++j) {
+        const int i = b0 + j;
+        mb[j] = MP_NEG_INF; Wb[j] = 0; W2b[j] = 0;
+        if (j < per && i < nt) {
+            const int r = i / nt_local, b = i - r * nt_local;
+            const u64* base = packed + (u64)r * 3 * nt_local;
+            mb[j] = mp_u2f(base[b]);
+            Wb[j] = base[nt_local + b];
+            W2b[j] = base[2 * nt_local + b];
+            tm[i] = mb[j]; tW[i] = Wb[j]; tW2[i] = W2b[j];
+            m = fmax(m, mb[j]);
+        }
+    }
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < SHT_THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    // level 1 exactly as block_tile_table / block_sum_T2 state it: T_b = rint(W_b exp(m_b - m) 2^(S-51)), T2_b likewise with
+    // exp(2 (m_b - m)); integer sums, so the order of the reduction is immaterial
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
+    u64 pre[PER_MAX];
+    double ratio[PER_MAX];
+    u64 run = 0, run2 = 0;
+#pragma unroll
+    for (int j = 0; j < PER_MAX; ++j) {
+        const int i = b0 + j;
+        pre[j] = 0;
+        if (j < per && i < nt) {
+            const double f = ok ? mp_exp(mb[j] - m) : 0.;
+            const double f2 = ok ? mp_exp(2. * (mb[j] - m)) : 0.;
+            const u64 T = mp_quantize((double)Wb[j] * f * sc, 1.0);
+            run += T;
+            run2 += mp_quantize((double)W2b[j] * f2 * sc, 1.0);
+            pre[j] = run;
+            ratio[j] = (double)Wb[j] / (double)T;   // of mp_local_target; never used for a tile with T = 0 (no target lands in it)
+        }
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    const u64 tot2 = wave_sum_u64(run2);
+    if (lane == 63) s_wtot[wave] = incl;
+    if (lane == 0) s_wtot2[wave] = tot2;
+    __syncthreads();
+    u64 woff = 0, Q = 0, Q2 = 0;
+#pragma unroll
+    for (int w = 0; w < SHT_THREADS / 64; ++w) {
+        if (w < wave) woff += s_wtot[w];
+        Q += s_wtot[w];
+        Q2 += s_wtot2[w];
+    }
+    const u64 off = woff + (incl - run);
+#pragma unroll
+    for (int j = 0; j < PER_MAX; ++j) {
+        const int i = b0 + j;
+        if (j < per && i < nt) { incl_all[i] = off + pre[j]; ratio_all[i] = ratio[j]; }
+    }
+    if (tail.c_all) {
+#pragma unroll
+        for (int j = 0; j < PER_MAX; ++j) {
+            const int i = b0 + j;
+            if (j < per && i < nt && (i + 1) % nt_local == 0) s_bound[i / nt_local] = off + pre[j];
+        }
+        __syncthreads();   // (also: this workgroup's stores of the table are out — the placement reads them)
+    }
+    const u64 lo = (tail.c_all && tail.rank) ? s_bound[tail.rank - 1] : 0ull;
+    const u64 hi = tail.c_all ? s_bound[tail.rank] : 0ull;
+    mp_table_leader<SHT_THREADS>(tail, s_bound, s_G, Q, Q2, m, world, nt_local, S, n_global, scal, undo, lo, hi, su, sv, prev_deg);
+}
+// The same table by `world` workgroups (worlds of more than one rank): workgroup r takes rank r's nt_local tiles, so the
+// serial part no longer grows with the job (16.9 us for 8 x 512 tiles by one workgroup, profiles/r03/route_scale.txt).
+// Every workgroup finds the job's maximum itself (world x nt_local loads), quantises its own tiles, publishes its two sums
+// {sum T, sum T2} and a ticket (agent scope), waits until all `world` tickets of this launch are there — the workgroups are
+// co-resident: world <= 64 of them on 256 CUs — and adds the sums of the ranks before it to its local prefix.  The workgroup of
+// THIS rank's tiles is the leader: what it goes on to read (its slice of the table, for the placement) it wrote itself.
+// `ticket` counts up by `world` per launch (never reset): this launch waits for `ticket_target`.
+struct mp_tab_part {
+    u64 Q, Q2;
+};
+template <int PER_MAX>   // tiles of a rank per thread at most: 1 up to 1024 tiles per rank (2^21 particles), SHT_PER beyond
+__global__ __launch_bounds__(SHT_THREADS) void k_shard_table_mw(const u64* __restrict__ packed, int world, int nt_local, int S, u64 n_global,
+                                                                double* __restrict__ tm, u64* __restrict__ tW, u64* __restrict__ tW2,
+                                                                u64* __restrict__ incl_all, double* __restrict__ ratio_all,
+                                                                long long* __restrict__ zero_counts, mp_dev_scalars* scal, mp_dev_scalars* undo,
+                                                                mp_tab_part* __restrict__ part, unsigned int* __restrict__ ticket,
+                                                                unsigned int ticket_target, mp_table_tail tail) {
+    __shared__ double s_red[SHT_THREADS / 64];
+    __shared__ u64 s_wtot[SHT_THREADS / 64];
+    __shared__ u64 s_wtot2[SHT_THREADS / 64];
+    __shared__ u64 s_bound[SH_MAX_WORLD];
+    __shared__ u64 s_G[SH_MAX_WORLD];
+    __shared__ u64 s_off, s_Q, s_Q2;
+    const int nt = world * nt_local;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int me = (int)blockIdx.x;   // the rank whose tiles this workgroup quantises
+    const bool leader = me == tail.rank;
+    MP_STAMP(2, 0, 1);
+    if (leader && tid < SH_MAX_KEYS) zero_counts[tid] = 0;
+    const int prev_deg = (leader && tid == SHT_THREADS - 64) ? scal->degenerate : 0;   // (the lane that folds: mp_table_leader)
+    // the job's maximum: every tile maximum of the gathered buffer
+    double m = MP_NEG_INF;
+    for (int i = tid; i < nt; i += SHT_THREADS) {
+        const int r = i / nt_local, b = i - r * nt_local;
+        m = fmax(m, mp_u2f(packed[(u64)r * 3 * nt_local + b]));
+    }
+    // this rank's tiles: thread t owns tiles t * per .. t * per + per - 1 of them
+    const int per = (nt_local + SHT_THREADS - 1) / SHT_THREADS;   // <= PER_MAX (the host picks the instance)
+    const int b0 = tid * per;
+    const u64* base = packed + (u64)me * 3 * nt_local;
+    double mb[PER_MAX];
+    u64 Wb[PER_MAX], W2b[PER_MAX];
+#pragma unroll
+    for (int j = 0; j < PER_MAX; ++j) {
+        const int b = b0 + j;
+        mb[j] = MP_NEG_INF; Wb[j] = 0; W2b[j] = 0;
+        if (j < per && b < nt_local) {
+            mb[j] = mp_u2f(base[b]);
+            Wb[j] = base[nt_local + b];
+            W2b[j] = base[2 * nt_local + b];
+            const int i = me * nt_local + b;
+            tm[i] = mb[j]; tW[i] = Wb[j]; tW2[i] = W2b[j];
+        }
+    }
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    MP_STAMP(2, 1, 1);
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < SHT_THREADS / 64; ++w) m = fmax(m, s_red[w]);
+    const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
+    const double sc = mp_u2f((u64)(1023 + S - FIX_BITS) << 52);
+    u64 pre[PER_MAX];
+    double ratio[PER_MAX];
+    u64 run = 0, run2 = 0;
+#pragma unroll
+    for (int j = 0; j < PER_MAX; ++j) {
+        const int b = b0 + j;
+        pre[j] = 0;
+        if (j < per && b < nt_local) {
+            const double f = ok ? mp_exp(mb[j] - m) : 0.;
+            const double f2 = ok ? mp_exp(2. * (mb[j] - m)) : 0.;
+            const u64 T = mp_quantize((double)Wb[j] * f * sc, 1.0);
+            run += T;
+            run2 += mp_quantize((double)W2b[j] * f2 * sc, 1.0);
+            pre[j] = run;
+            ratio[j] = (double)Wb[j] / (double)T;
+        }
+    }
+    const u64 incl = wave_incl_scan_u64(run, lane);
+    const u64 tot2 = wave_sum_u64(run2);
+    if (lane == 63) s_wtot[wave] = incl;
+    if (lane == 0) s_wtot2[wave] = tot2;
+    __syncthreads();
+    u64 woff = 0, Qr = 0, Q2r = 0;
+#pragma unroll
+    for (int w = 0; w < SHT_THREADS / 64; ++w) {
+        if (w < wave) woff += s_wtot[w];
+        Qr += s_wtot[w];
+        Q2r += s_wtot2[w];
+    }
+    MP_STAMP(2, 2, 1);
+    // (the leader's lanes make the uniforms of the split counts while the ticket goes round)
+    double su = 0., sv = 0.;
+    if (leader && tail.c_all && tail.scheme == MP_SCHEME_SPLIT && tid != 0) mp_split_uniforms(tail.rc, tail.k0, tail.k1, &su, &sv);
+    // publish this rank's sums, then wait for everybody's
+    if (tid == 0) {
+        mp_st_agent(&part[me].Q, Qr);
+        mp_st_agent(&part[me].Q2, Q2r);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sums are out before the ticket says so
+        (void)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_target) < 0) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    MP_STAMP(2, 3, 1);
+    if (tid < 64) {
+        // inclusive prefix over the ranks (world <= 64: one wave).  The WHOLE of wave 0 takes part, lanes beyond `world` with
+        // zeros: wave_sum_u64 reads lane 63 of the scan, which an inactive lane would never have written
+        const bool have = tid < world;
+        const u64 q = have ? mp_ld_agent(&part[tid].Q) : 0ull, q2 = have ? mp_ld_agent(&part[tid].Q2) : 0ull;
+        const u64 inc = wave_incl_scan_u64(q, lane);
+        const u64 t2 = wave_sum_u64(q2);
+        if (have) s_bound[tid] = inc;
+        if (tid == me) s_off = inc - q;
+        if (tid == world - 1) { s_Q = inc; s_Q2 = t2; }
+    }
+    __syncthreads();
+    const u64 off = s_off + woff + (incl - run);
+    const u64 Q = s_Q, Q2 = s_Q2;
+#pragma unroll
+    for (int j = 0; j < PER_MAX; ++j) {
+        const int b = b0 + j;
+        if (j < per && b < nt_local) { incl_all[me * nt_local + b] = off + pre[j]; ratio_all[me * nt_local + b] = ratio[j]; }
+    }
+    if (!leader) return;
+    if (tail.do_place) __syncthreads();   // this workgroup's slice of the table is out: the placement reads it
+    mp_table_leader<SHT_THREADS>(tail, s_bound, s_G, Q, Q2, m, world, nt_local, S, n_global, scal, undo, s_off, s_bound[me], su, sv, prev_deg);
 }
 // a world of one: the job's table is the one the last level-0 launch left; nobody has folded this normalisation into the filter
 // scalars yet (the next k_propagate does on the way, unless the host wants the resample's value first)

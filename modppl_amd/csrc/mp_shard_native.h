@@ -141,9 +141,7 @@ int32_t mp_pf_shard_resample(mp_pf* h, const mp_transport* t, int32_t world, int
         // 2 collectives, 3 phases, one host wait (for the plan's verdict word, while the rows are written and travel)
         double* rows = s->rows[s->flip];
         s->flip ^= 1;
-        rc = mp_pf_shard_owned_count(h, scheme, tiles_all, world, rank, s->cap, nullptr);
-        if (rc != MP_OK) return rc;
-        rc = mp_pf_shard_owned_expand(h, world, rank, s->cap, s->send, rows, (uint64_t)world * s->cap);
+        rc = mp_pf_shard_owned_count_expand(h, scheme, tiles_all, world, rank, s->cap, s->send, rows, (uint64_t)world * s->cap);
         if (rc != MP_OK) return rc;
         if (!solo) {
             for (int q = 0; q < world; ++q) { so[q] = ro[q] = (uint64_t)q * s->cap * row_b; sb[q] = rb[q] = s->cap * row_b; }

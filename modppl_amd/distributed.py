@@ -137,6 +137,10 @@ class HipShardEngine:
     def shard_owned_expand(self, world, rank, cap, send_ptr, rows_ptr, recv_rows):
         capi.check(self._L.mp_pf_shard_owned_expand(self._h, world, rank, cap, send_ptr, rows_ptr, recv_rows))
 
+    def shard_owned_count_expand(self, scheme, tiles_all_ptr, world, rank, cap, send_ptr, rows_ptr, recv_rows):
+        """count + expand of the equal-split form in one call (a self-drawn resample then needs one launch for both)"""
+        capi.check(self._L.mp_pf_shard_owned_count_expand(self._h, scheme, tiles_all_ptr, world, rank, cap, send_ptr, rows_ptr, recv_rows))
+
     def shard_owned_commit(self, rows_ptr, recv_rows, want_value, want_counts=True):
         """-> (committed, log total weight or None, offspring per rank or None).  Without value and counts the call waits for
         the plan's verdict word only (and not at all in a world of one); with either, for the stream."""

@@ -105,6 +105,7 @@ extern "C" {
     pub fn mp_pf_shard_query_packed(h: *mut mp_pf, d_tiles_all: *const u64, world: i32, log_ml: *mut f64, ess: *mut f64) -> i32;
     pub fn mp_pf_shard_owned_count(h: *mut mp_pf, scheme: i32, d_tiles_all: *const u64, world: i32, rank: i32, capacity: u64, counts_out: *mut u64) -> i32;
     pub fn mp_pf_shard_owned_expand(h: *mut mp_pf, world: i32, rank: i32, capacity: u64, d_send_out: *mut f64, d_rows: *mut f64, recv_rows: u64) -> i32;
+    pub fn mp_pf_shard_owned_count_expand(h: *mut mp_pf, scheme: i32, d_tiles_all: *const u64, world: i32, rank: i32, capacity: u64, d_send_out: *mut f64, d_rows: *mut f64, recv_rows: u64) -> i32;
     pub fn mp_pf_shard_owned_commit(h: *mut mp_pf, d_rows: *const f64, log_total_weight: *mut f64, counts_out: *mut u64) -> i32;
     // the whole sharded resample behind one call (the collectives go through `mp_transport`, or RCCL directly)
     pub fn mp_pf_shard_resample(h: *mut mp_pf, t: *const mp_transport, world: i32, rank: i32, scheme: i32, force_collectives: i32,

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--model", default="lgssm1", choices=["lgssm1", "band16"], help="band16: the C5 model (its propagate kernel cannot make the draws: k_shard_self_draw does)")
     ap.add_argument("--particles", type=int, default=1 << 20, help="per rank")
     ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--two-calls", action="store_true", help="count, then expand (before round 5: the placement as a launch of its own)")
     args = ap.parse_args()
     n = args.particles
     if args.model == "band16":
@@ -58,19 +59,28 @@ def main():
         ocap = max(4096, n // 128)
         send = torch.zeros(world * ocap * (dim + 1), dtype=torch.float64, device=dev)
         orow = torch.zeros((world * ocap + n) * (dim + 1), dtype=torch.float64, device=dev)
+
+        def count_expand(scheme):
+            # what mp_pf_shard_resample issues: count + expand of the equal-split form as one call (a self-drawn resample: one launch)
+            if args.two_calls:
+                eng.shard_owned_count(scheme, C.c_void_p(tiles_all.data_ptr()), world, 0, ocap, want_counts=False)
+                eng.shard_owned_expand(world, 0, ocap, C.c_void_p(send.data_ptr()), C.c_void_p(orow.data_ptr()), world * ocap)
+            else:
+                eng.shard_owned_count_expand(scheme, C.c_void_p(tiles_all.data_ptr()), world, 0, ocap, C.c_void_p(send.data_ptr()),
+                                             C.c_void_p(orow.data_ptr()), world * ocap)
+
         for scheme, name in ((0, "multinomial"), (1, "systematic"), (2, "stratified"), (3, "split multinomial")):
             eng.synchronize()
             eng.set_timing(False)
             eng.set_timing(True)
             for _ in range(12):
-                eng.shard_owned_count(scheme, C.c_void_p(tiles_all.data_ptr()), world, 0, ocap, want_counts=False)
-                eng.shard_owned_expand(world, 0, ocap, C.c_void_p(send.data_ptr()), C.c_void_p(orow.data_ptr()), world * ocap)
+                count_expand(scheme)
             eng.synchronize()
             r = eng.get_timing(capi.MP_K_BIN_DRAWS)
             g = eng.get_timing(capi.MP_K_RESAMPLE_GATHER)
             place = g[0] / g[1] * 1e3 if g[1] else 0.0   # (a world of one launches nothing there: the next k_propagate looks its draws up)
             count = r[0] / r[1] * 1e3 if r[1] else 0.0   # (a self-drawn resample in a world of one launches nothing at all)
-            print(f"world {world}: owner-keeps {name}: count (table + own draws + plan) {count:.1f} us, place + surplus lookups {place:.1f} us",
+            print(f"world {world}: owner-keeps {name}: count (table + own draws + plan [+ placement, self-drawn]) {count:.1f} us, place + surplus lookups {place:.1f} us",
                   flush=True)
         # a whole step of this rank, kernel by kernel (HIP events around every launch): count + expand + commit (asynchronous) + the
         # next propagate, which makes the kept draws of a self-drawn resample itself (the rows "received" for the deficit slots are
@@ -83,8 +93,7 @@ def main():
                 eng.set_timing(False)
                 eng.set_timing(True)      # (the first pass warms up)
                 for t in range(K):
-                    eng.shard_owned_count(scheme, C.c_void_p(tiles_all.data_ptr()), world, 0, ocap, want_counts=False)
-                    eng.shard_owned_expand(world, 0, ocap, C.c_void_p(send.data_ptr()), C.c_void_p(orow.data_ptr()), world * ocap)
+                    count_expand(scheme)
                     eng.shard_owned_commit(C.c_void_p(orow.data_ptr()), world * ocap, False, want_counts=False)
                     eng.step(ys2[1 + t % 60:2 + t % 60])
                     if world > 1:   # the tiles this rank would contribute to the next all-gather (its own, `world` times over)
