@@ -64,18 +64,29 @@ MP_HD int mp_btrs_fast(const mp_btrs& T, double U01, double V01, double* k_out) 
     if (us >= 0.07 && V01 <= T.v_r) return 1;
     return 2;
 }
-// the acceptance test is v <= ub with v and the seven terms of ub below; written piece by piece so that a device caller can have the
-// eight pieces evaluated by eight lanes (each is one of two shapes: c * log(x / y), or a Stirling tail) and add them up in this order
+// the acceptance test of an attempt (U, V, k) the squeeze did not decide is v <= ub, eight pieces of two shapes — piece 0 is v, pieces
+// 1 .. 3 the terms c log(x / y) of ub, pieces 4 .. 7 its Stirling tails — so that a device caller can have them evaluated by eight lanes
+// (mp_split_counts: lane j piece j) and add them up in the order mp_btrs_accept states
 MP_HD double mp_btrs_logterm(double c, double x, double y) { return c * mp_log(x / y); }
-MP_HD bool mp_btrs_slow(const mp_btrs& T, double U01, double V01, double k) {
-    const double u = U01 - 0.5;
-    const double us = 0.5 - fabs(u);
+MP_HD double mp_btrs_piece(const mp_btrs& T, int j, double U01, double V01, double k) {
+    const double us = 0.5 - fabs(U01 - 0.5);
     const double n = T.n, m = T.m, r = T.r;
-    const double v = mp_btrs_logterm(1., V01 * T.alpha, T.a / (us * us) + T.b);
-    const double ub = mp_btrs_logterm(m + 0.5, m + 1., r * (n - m + 1.)) + mp_btrs_logterm(n + 1., n - m + 1., n - k + 1.) +
-                      mp_btrs_logterm(k + 0.5, r * (n - k + 1.), k + 1.) + mp_stirling_tail(m) + mp_stirling_tail(n - m) - mp_stirling_tail(k) -
-                      mp_stirling_tail(n - k);
-    return v <= ub;
+    const int q = j & 3;
+    if (j < 4) {
+        const double c = q == 0 ? 1. : (q == 1 ? m + 0.5 : (q == 2 ? n + 1. : k + 0.5));
+        const double x = q == 0 ? V01 * T.alpha : (q == 1 ? m + 1. : (q == 2 ? n - m + 1. : r * (n - k + 1.)));
+        const double y = q == 0 ? T.a / (us * us) + T.b : (q == 1 ? r * (n - m + 1.) : (q == 2 ? n - k + 1. : k + 1.));
+        return mp_btrs_logterm(c, x, y);
+    }
+    return mp_stirling_tail(q == 0 ? m : (q == 1 ? n - m : (q == 2 ? k : n - k)));
+}
+MP_HD bool mp_btrs_accept(double v, double t1, double t2, double t3, double s_m, double s_nm, double s_k, double s_nk) {
+    return v <= t1 + t2 + t3 + s_m + s_nm - s_k - s_nk;
+}
+MP_HD bool mp_btrs_slow(const mp_btrs& T, double U01, double V01, double k) {
+    return mp_btrs_accept(mp_btrs_piece(T, 0, U01, V01, k), mp_btrs_piece(T, 1, U01, V01, k), mp_btrs_piece(T, 2, U01, V01, k),
+                          mp_btrs_piece(T, 3, U01, V01, k), mp_btrs_piece(T, 4, U01, V01, k), mp_btrs_piece(T, 5, U01, V01, k),
+                          mp_btrs_piece(T, 6, U01, V01, k), mp_btrs_piece(T, 7, U01, V01, k));
 }
 
 // X ~ Binomial(n, p), 0 < p <= 1/2, n >= 1; uniforms: blocks 0, 1, ... of (node, rc, RESAMPLE << 16 | 3, .)
@@ -121,6 +132,51 @@ MP_HD uint64_t mp_binomial_ratio(uint64_t n, uint64_t a, uint64_t b, uint32_t no
     const uint64_t other = b - a;
     if (a <= other) return mp_binomial_small_p(n, (double)a / (double)b, node, rc, k0, k1);
     return n - mp_binomial_small_p(n, (double)other / (double)b, node, rc, k0, k1);
+}
+
+// The same variate the way mp_split_counts' lanes find it (mp_pf_shard_kernels.h), restated sequentially for the host: A attempts
+// "side by side", the squeeze's verdicts first, the expensive test only for undecided attempts in front of the first accepted one, the
+// first accepted attempt wins; the sequential sampler where its inversion branch applies or nothing among the A attempts is accepted.
+// tests/test_split_binomial.py holds it to mp_binomial_ratio bit for bit.
+MP_HD uint64_t mp_binomial_ratio_lanes(uint64_t n, uint64_t a, uint64_t b, uint32_t node, uint32_t rc, uint32_t k0, uint32_t k1) {
+    constexpr int A = 8;
+    if (n == 0ull || a == 0ull) return 0ull;
+    if (a >= b) return n;
+    const uint64_t other = b - a;
+    const bool flipped = a > other;
+    const double p = (double)(flipped ? other : a) / (double)b;
+    const double nd = (double)n;
+    if (nd * p < 10.) return mp_binomial_ratio(n, a, b, node, rc, k0, k1);
+    mp_btrs T;
+    mp_btrs_setup(T, nd, p);
+    double U[A], V[A], k[A];
+    int st[A];
+    uint32_t acc = 0u, und = 0u;
+    for (int att = 0; att < A; ++att) {
+        const mp_u64x2 blk = mp_philox4x32_10(node, rc, ((uint32_t)MP_DOM_RESAMPLE << 16) | MP_SITE_SPLIT_COUNTS, (uint32_t)att, k0, k1);
+        U[att] = mp_u01(blk.a);
+        V[att] = mp_u01(blk.b);
+        st[att] = mp_btrs_fast(T, U[att], V[att], &k[att]);
+        if (st[att] == 1) acc |= 1u << att;
+        if (st[att] == 2) und |= 1u << att;
+    }
+    und &= acc ? ((acc & (0u - acc)) - 1u) : 0xFFu;
+    while (und) {
+        int cand = 0;
+        while (!((und >> cand) & 1u)) ++cand;
+        double pc[8];
+        for (int j = 0; j < 8; ++j) pc[j] = mp_btrs_piece(T, j, U[cand], V[cand], k[cand]);
+        if (mp_btrs_accept(pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], pc[6], pc[7])) {
+            acc |= 1u << cand;
+            break;
+        }
+        und &= und - 1u;
+    }
+    if (acc == 0u) return mp_binomial_ratio(n, a, b, node, rc, k0, k1);
+    int first = 0;
+    while (!((acc >> first) & 1u)) ++first;
+    const uint64_t kk = (uint64_t)k[first];
+    return flipped ? n - kk : kk;
 }
 
 // Levels of the splitting tree over `world` ranks: its leaves are the ranks padded with empty ones to a power of two

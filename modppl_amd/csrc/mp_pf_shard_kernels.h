@@ -278,7 +278,8 @@ constexpr int MP_SCHEME_SPLIT = 3;           // MP_RESAMPLE_MULTINOMIAL_SPLIT (i
 // pieces in the eight lanes of the group, added up in the sampler's order.  Tiny n p (the inversion branch) and "nothing accepted among
 // the side-by-side attempts" fall back to the sequential sampler itself.
 constexpr int MP_SPLIT_LANES = 8;
-// a cold path as a real call: inlined, its constants (logarithms, the inversion loop) were hoisted over the level loop and spilled
+// a cold path as a real call: inlined, its constants (logarithms, the inversion loop) are hoisted over the level loop and spilled
+// (measured both ways on one box: 20.6 us inlined against 19.8 for the whole count phase)
 __device__ __attribute__((noinline)) u64 mp_binomial_ratio_cold(u64 n, u64 a, u64 b, uint32_t node, uint32_t rc, uint32_t k0, uint32_t k1) {
     return mp_binomial_ratio(n, a, b, node, rc, k0, k1);
 }
@@ -294,38 +295,51 @@ __device__ __forceinline__ double mp_shfl_f64(double x, int src_lane) {
     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)b, src_lane), hi = (uint32_t)__shfl((int)(uint32_t)(b >> 32), src_lane);
     return __builtin_bit_cast(double, ((u64)hi << 32) | lo);
 }
-__device__ __forceinline__ void mp_split_counts(const u64* s_bound, int world, u64 n_global, uint32_t rc, uint32_t k0, uint32_t k1, u64* s_n, double U,
-                                                double V) {
+// what a lane needs at its node's level, parked in LDS meanwhile: nothing of it is live in registers across the levels of the tree
+// (and across the call of the cold path, whose caller-saved registers were spilled to scratch — a first touch of scratch memory in
+// front of a barrier, 1.5 us)
+struct mp_split_lds {
+    double U[SH_MAX_WORLD * MP_SPLIT_LANES], V[SH_MAX_WORLD * MP_SPLIT_LANES];   // [node * 8 + attempt]
+    double p[SH_MAX_WORLD];                                                      // [node] the smaller share of the node's mass
+    u64 ma[SH_MAX_WORLD], mb[SH_MAX_WORLD];                                      // [node] left mass, whole mass
+};
+__device__ __forceinline__ void mp_split_counts(const u64* s_bound, int world, u64 n_global, uint32_t rc, uint32_t k0, uint32_t k1, u64* s_n, double U0,
+                                                double V0, mp_split_lds* sl) {
     constexpr int A = MP_SPLIT_LANES;
     static_assert(A == 8, "the acceptance test is laid out over eight lanes");
     const int tid = threadIdx.x;
     const int L = mp_split_levels(world), P = 1 << L;
-    const int node = tid / A, att = tid % A;
-    const bool have = node >= 1 && node < P;   // (P <= 64: the first 512 threads at most)
-    const int sh = (tid & 63) & ~(A - 1);      // first lane of this node's group inside its wave
-    double p = 0.;
-    u64 ma = 0ull, mb = 0ull;
-    int lvl = -1;
-    bool flipped = false;
-    if (have) {
-        lvl = 31 - __clz(node);
-        const int width = P >> lvl;   // leaves under this node: [a, a + width), split at a + width / 2
-        const int a = (node - (1 << lvl)) * width, mid = a + width / 2, b = a + width;
-        // mass of the leaves [0, r): ranks beyond `world` are empty
-        const u64 pa = a <= 0 ? 0ull : s_bound[(a < world ? a : world) - 1];
-        const u64 pm = s_bound[(mid < world ? mid : world) - 1];   // (mid >= 1)
-        const u64 pb = s_bound[(b < world ? b : world) - 1];
-        ma = pm - pa;
-        mb = pb - pa;
-        const u64 other = mb - ma;
-        flipped = ma > other;   // mp_binomial_ratio samples the smaller of the two masses
-        p = (double)(flipped ? other : ma) / (double)mb;
+    {
+        const int node = tid / A;
+        if (node >= 1 && node < P) {   // (P <= 64: the first 512 threads at most)
+            sl->U[tid] = U0;
+            sl->V[tid] = V0;
+            if (tid % A == 0) {
+                const int lvl = 31 - __clz(node);
+                const int width = P >> lvl;   // leaves under this node: [a, a + width), split at a + width / 2
+                const int a = (node - (1 << lvl)) * width, mid = a + width / 2, b = a + width;
+                // mass of the leaves [0, r): ranks beyond `world` are empty
+                const u64 pa = a <= 0 ? 0ull : s_bound[(a < world ? a : world) - 1];
+                const u64 pm = s_bound[(mid < world ? mid : world) - 1];   // (mid >= 1)
+                const u64 pb = s_bound[(b < world ? b : world) - 1];
+                const u64 ma = pm - pa, mb = pb - pa, other = mb - ma;
+                sl->ma[node] = ma;
+                sl->mb[node] = mb;
+                sl->p[node] = (double)(ma > other ? other : ma) / (double)mb;   // mp_binomial_ratio samples the smaller of the two masses
+            }
+        }
     }
     if (tid == 0) s_n[1] = n_global;
     __syncthreads();
     MP_STAMP(2, 9, 1);
     for (int l = 0; l < L; ++l) {
-        if (have && lvl == l) {   // (whole groups of A lanes; everything below that is not per attempt is the same in the A lanes)
+        // the nodes of level l: 1 << l of them, A lanes each — threads [A << l, A << (l + 1))
+        if ((tid >> l) / A == 1) {   // (whole groups of A lanes; everything below that is not per attempt is the same in the A lanes)
+            const int node = tid / A, att = tid % A;
+            const int sh = (tid & 63) & ~(A - 1);      // first lane of this node's group inside its wave
+            const double U = sl->U[tid], V = sl->V[tid], p = sl->p[node];
+            const u64 ma = sl->ma[node], mb = sl->mb[node];
+            const bool flipped = ma > mb - ma;
             const u64 nk = s_n[node];
             const bool trivial = nk == 0ull || ma == 0ull || ma >= mb;
             int st = 0;             // this lane's attempt: 0 rejected, 1 accepted, 2 the squeeze did not decide
@@ -346,19 +360,10 @@ __device__ __forceinline__ void mp_split_counts(const u64* s_bound, int world, u
             while (und) {   // (uniform in the group) the first undecided attempt, its test by the eight lanes
                 const int cand = __ffs((int)und) - 1;
                 const double Uc = mp_shfl_f64(U, sh + cand), Vc = mp_shfl_f64(V, sh + cand), kc = mp_shfl_f64(k, sh + cand);
-                const double us = 0.5 - fabs(Uc - 0.5);
-                const double n = T.n, m = T.m, r = T.r;
-                // mp_btrs_slow's pieces: lanes 0 .. 3 a term c log(x / y) each, lanes 4 .. 7 a Stirling tail each
-                const int j = att & 3;
-                const double c = j == 0 ? 1. : (j == 1 ? m + 0.5 : (j == 2 ? n + 1. : kc + 0.5));
-                const double x = j == 0 ? Vc * T.alpha : (j == 1 ? m + 1. : (j == 2 ? n - m + 1. : r * (n - kc + 1.)));
-                const double y = j == 0 ? T.a / (us * us) + T.b : (j == 1 ? r * (n - m + 1.) : (j == 2 ? n - kc + 1. : kc + 1.));
-                const double z = j == 0 ? m : (j == 1 ? n - m : (j == 2 ? kc : n - kc));
-                const double piece = att < 4 ? mp_btrs_logterm(c, x, y) : mp_stirling_tail(z);
-                const double v = mp_shfl_f64(piece, sh);
-                const double ub = mp_shfl_f64(piece, sh + 1) + mp_shfl_f64(piece, sh + 2) + mp_shfl_f64(piece, sh + 3) + mp_shfl_f64(piece, sh + 4) +
-                                  mp_shfl_f64(piece, sh + 5) - mp_shfl_f64(piece, sh + 6) - mp_shfl_f64(piece, sh + 7);
-                if (v <= ub) {   // accepted, and in front of every attempt the squeeze accepted
+                const double piece = mp_btrs_piece(T, att, Uc, Vc, kc);   // (lanes 0 .. 3 a logarithm each, lanes 4 .. 7 a Stirling tail each)
+                const bool ok = mp_btrs_accept(mp_shfl_f64(piece, sh), mp_shfl_f64(piece, sh + 1), mp_shfl_f64(piece, sh + 2), mp_shfl_f64(piece, sh + 3),
+                                               mp_shfl_f64(piece, sh + 4), mp_shfl_f64(piece, sh + 5), mp_shfl_f64(piece, sh + 6), mp_shfl_f64(piece, sh + 7));
+                if (ok) {   // accepted, and in front of every attempt the squeeze accepted
                     acc |= 1u << cand;
                     break;
                 }
@@ -1228,7 +1233,8 @@ __device__ __forceinline__ void mp_table_leader(const mp_table_tail& t, const u6
     }
     u64 g_lo = 0ull;
     if (t.scheme == MP_SCHEME_SPLIT) {
-        mp_split_counts(s_bound, world, n_global, t.rc, t.k0, t.k1, s_heap, su, sv);
+        __shared__ mp_split_lds s_split;
+        mp_split_counts(s_bound, world, n_global, t.rc, t.k0, t.k1, s_heap, su, sv, &s_split);
         if (tid < world) {
             const u64 c = s_heap[(1 << mp_split_levels(world)) + tid];
             s_c[tid] = c;

@@ -882,6 +882,11 @@ void oracle_binomial_both(const uint64_t* n, const uint64_t* a, const uint64_t* 
         out_product[i] = mp_binomial_ratio(n[i], a[i], b[i], node[i], rc, (uint32_t)seed, (uint32_t)(seed >> 32));
     }
 }
+// the product header's lane-wise form of the same variate (what the device's eight lanes per tree node compute), host-compiled
+void oracle_binomial_lanes(const uint64_t* n, const uint64_t* a, const uint64_t* b, const uint32_t* node, int64_t cases, uint64_t seed, uint32_t rc,
+                           uint64_t* out) {
+    for (int64_t i = 0; i < cases; ++i) out[i] = mp_binomial_ratio_lanes(n[i], a[i], b[i], node[i], rc, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
 void oracle_split_counts(const uint64_t* mass, int32_t world, uint64_t n_global, uint64_t seed, uint32_t rc, uint64_t* out) {
     const std::vector<uint64_t> c = oracle::canonical_split_counts(std::vector<uint64_t>(mass, mass + world), n_global, seed, rc);
     for (int32_t r = 0; r < world; ++r) out[r] = c[(size_t)r];

@@ -107,6 +107,8 @@ def load():
     L.oracle_mp_log.argtypes = [dp, i64, dp]
     L.oracle_binomial_both.argtypes = [C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), i64, u64, u32, C.POINTER(u64), C.POINTER(u64)]
     L.oracle_binomial_both.restype = None
+    L.oracle_binomial_lanes.argtypes = [C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), i64, u64, u32, C.POINTER(u64)]
+    L.oracle_binomial_lanes.restype = None
     L.oracle_split_counts.argtypes = [C.POINTER(u64), i32, u64, u64, u32, C.POINTER(u64)]
     L.oracle_split_counts.restype = None
     L.oracle_stirling_tail.argtypes = [C.c_double]

@@ -40,6 +40,7 @@ class _ByHand:
         self.tiles = [torch.zeros(3 * self.nt, dtype=torch.int64, device=self.dev) for _ in range(world)]
         self.keep = None
         self.fallbacks = 0
+        self.fused = False   # count + expand of the equal-split form as ONE call (what mp_pf_shard_resample issues): a self-drawn resample then places in the table's launch
 
     def sync(self):
         for e in self.eng:
@@ -62,8 +63,11 @@ class _ByHand:
         torch.cuda.synchronize()   # torch's stream made these; the engines' kernels run on streams of their own
         if cap:
             for r, e in enumerate(self.eng):
-                e.shard_owned_count(scheme, ptr(tiles_all), w, r, cap, want_counts=False)
-                e.shard_owned_expand(w, r, cap, ptr(send[r]), ptr(rows[r]), w * cap)
+                if self.fused:
+                    e.shard_owned_count_expand(scheme, ptr(tiles_all), w, r, cap, ptr(send[r]), ptr(rows[r]), w * cap)
+                else:
+                    e.shard_owned_count(scheme, ptr(tiles_all), w, r, cap, want_counts=False)
+                    e.shard_owned_expand(w, r, cap, ptr(send[r]), ptr(rows[r]), w * cap)
             self.sync()
             seg = cap * (d + 1)
             for s in range(w):
@@ -192,6 +196,50 @@ def test_lattice_schemes_window_form_still_agrees(monkeypatch, scheme, diag):
             e.step(obs[t:t + 1])
         ref.step(obs[t:t + 1])
     assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
+
+
+@pytest.mark.parametrize("d,world,n,cap,scheme,tail", [
+    (1, 4, 4096, 512, 1, 14.0),
+    (1, 3, 4096, 64, 2, 6.0),
+    (1, 2, 8192, 8192, 3, 6.0),
+    (1, 4, 4096, 16, 3, 14.0),      # capacity too small: placed by the table's launch, refused by the verdict, placed again with exact sizes
+    (1, 8, 2048, 256, 3, 6.0),
+    (1, 64, 2048, 64, 3, 6.0),
+    (1, 33, 2048, 64, 1, 6.0),
+    (4, 3, 2048, 2048, 2, 6.0),     # wide states: the kept draws are a launch of their own, the placement stays one too
+    (1, 4, 4096, 512, 0, 6.0),      # the window form (owned multinomial): the one call is the two calls
+])
+@pytest.mark.parametrize("mw", [False, True])
+def test_count_and_expand_as_one_call(monkeypatch, d, world, n, cap, scheme, tail, mw, diag):
+    """mp_pf_shard_owned_count_expand: same offspring, slots and rows as count followed by expand (and as the checker) — with a
+    self-drawn resample the table kernel's leading workgroup (the one of THIS rank's tiles: every workgroup of k_shard_table_mw leads
+    on some rank here) makes the counts, the plan, the verdict and the placement in its one launch"""
+    if mw:
+        monkeypatch.setenv("MP_SHARD_TABLE_MW_TILES", "0")
+    model, obs = _model(d, 6)
+    if d == 1:
+        obs = obs.copy()
+        obs[3] = tail
+    seed = 37
+    hip = _ByHand(model, n, world, seed)
+    hip.fused = True
+    ref = OwnedReference(model, n * world, seed, world)
+    for e in hip.eng:
+        e.init_step(None, obs[:1])
+    ref.init_step(None, obs[:1])
+    for t in range(1, len(obs)):
+        assert hip.resample(cap, scheme) == ref.resample(scheme)
+        assert list(hip.counts) == list(ref.counts)
+        if t % 2:
+            assert np.array_equal(hip.cat(lambda e: e.parents()), ref.parents())
+            assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
+        for e in hip.eng:
+            e.step(obs[t:t + 1])
+        ref.step(obs[t:t + 1])
+        assert np.array_equal(hip.cat(lambda e: e.log_weights()), ref.log_weights())
+    assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
+    if cap < 64:
+        assert hip.fallbacks > 0
 
 
 @pytest.mark.parametrize("world,scheme", [(2, 0), (5, 0), (8, 0), (5, 3), (8, 1)])

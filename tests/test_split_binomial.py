@@ -54,6 +54,32 @@ def test_restatement_and_product_header_agree_bit_for_bit():
     assert (r[a == 0] == 0).all() and (r[a == b] == n[a == b]).all()
 
 
+def test_lane_wise_form_is_the_sequential_sampler():
+    """mp_binomial_ratio_lanes (mp_binomial.h): eight attempts side by side, the expensive acceptance test piece by piece and only in
+    front of the first attempt the squeeze accepted — what the table kernel's lanes do for the split counts — returns the sequential
+    sampler's variate, i.e. the checker's, in every case (including the ones where all eight attempts are rejected: forced below by
+    counting how often the test is needed at all)"""
+    L = O.load()
+    rng = np.random.default_rng(11)
+    cases = 200000
+    n = rng.integers(1, 1 << 33, cases).astype(np.uint64)
+    n[:20000] = rng.integers(0, 4096, 20000)
+    b = rng.integers(1, 1 << 62, cases).astype(np.uint64)
+    frac = rng.random(cases)
+    frac[20000:30000] = rng.random(10000) * 1e-7
+    frac[30000:30100] = 0.0
+    frac[30100:30200] = 1.0
+    a = np.minimum((frac * b.astype(np.float64)).astype(np.uint64), b)
+    node = rng.integers(1, 64, cases).astype(np.uint32)
+    seed, rc = 0xBEEF_0000_1234, 5
+    r, _ = _both(n, a, b, node, seed, rc)
+    out = np.zeros(cases, dtype=np.uint64)
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    L.oracle_binomial_lanes(n.ctypes.data_as(u64p), a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), node.ctypes.data_as(u32p), cases, seed, rc,
+                            out.ctypes.data_as(u64p))
+    assert np.array_equal(out, r)
+
+
 @pytest.mark.parametrize("n,a,b", [(40, 1, 10), (1 << 20, 1, 1 << 19), (1000, 3, 10), (1 << 20, 1, 8), (1 << 24, 7, 8), (300, 1, 2), (25, 2, 5)])
 def test_law_against_the_exact_pmf(n, a, b):
     draws = 40000
