@@ -16,7 +16,7 @@ fi
 python3 tools/collect_traffic.py $SRC > $DST/traffic.json
 python3 tools/pmc_summary.py $SRC > $DST/counters_summary.txt
 [ -f $SRC/valu_issue.json ] && cp $SRC/valu_issue.json $DST/valu_issue.json
-for f in stamp_report.txt stamp_report_tile_kernel.txt k1_scaling.txt k1_forms_ab.txt reference_shaped_loop.jsonl reference_shaped_loop_cpp.txt stamps.json bench_n1.json bench_n1_k20.json bench_forced_sharded.json bench_forced_sharded_rccl.json bench_forced_sharded_split.json route_scale.txt model_bench.jsonl mh_functor_vs_handwritten.json sync_probe.jsonl; do
+for f in stamp_report.txt stamp_report_tile_kernel.txt k1_scaling.txt k1_forms_ab.txt reference_shaped_loop.jsonl reference_shaped_loop_cpp.txt stamps.json bench_n1.json bench_n1_k20.json bench_forced_sharded.json bench_forced_sharded_rccl.json bench_forced_sharded_split.json route_scale.txt table_stamps.txt table_stamps_two_calls.txt model_bench.jsonl mh_functor_vs_handwritten.json sync_probe.jsonl; do
   [ -f $SRC/$f ] && cp $SRC/$f $DST/$f
 done
 cp $SRC/trace/bench_kernel_stats.csv $DST/kernel_stats.csv

@@ -57,6 +57,9 @@ cd $R && MP_BENCH_FORCE_SHARDED=1 timeout -k 10 300 python3 bench.py --steps 200
 cd $R && MP_BENCH_FORCE_SHARDED=1 MP_SHARD_ALWAYS_COLLECTIVE=1 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline > $OUT/bench_forced_sharded_rccl.json 2> $OUT/bench_forced_sharded_rccl.err || echo "forced-sharded RCCL bench failed"
 cd $R && MP_BENCH_FORCE_SHARDED=1 MP_SHARD_EXCHANGE=split timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-sub-benches --no-cpu-baseline --no-systematic-leg > $OUT/bench_forced_sharded_split.json 2> $OUT/bench_forced_sharded_split.err || echo "forced-sharded split bench failed"
 cd $R && timeout -k 10 300 python3 tools/route_scale.py > $OUT/route_scale.txt 2>&1 || echo "route_scale failed"
+# the timeline of one sharded resample + step on one clock (-DMP_STAMPS build): the table launch's phases, the host's gap, the propagate kernel
+cd $R && timeout -k 10 200 python3 tools/table_stamps.py > $OUT/table_stamps.txt 2>&1 || echo "table_stamps failed"
+cd $R && timeout -k 10 200 python3 tools/table_stamps.py --two-calls --schemes 3 > $OUT/table_stamps_two_calls.txt 2>&1 || echo "table_stamps (two calls) failed"
 cd $R && timeout -k 10 200 python3 tools/mh_bench.py > $OUT/mh_functor_vs_handwritten.json 2> $OUT/mh_bench.err || echo "mh_bench failed"
 cd $R && timeout -k 10 300 python3 tools/model_bench.py --which c3,mid,c5,c4 > $OUT/model_bench.jsonl 2> $OUT/model_bench.err || echo "model_bench failed"
 fi
