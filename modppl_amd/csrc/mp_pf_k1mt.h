@@ -438,9 +438,12 @@ __device__ __forceinline__ void mt_peek_tail(const mp_k1mt& a, int nt) {
     if (!s_last) return;   // workgroup-uniform
     const double* tm = mp_as_global(a.tm_new);
     const u64 *tW = mp_as_global(a.tW_new), *tW2 = mp_as_global(a.tW2_new);
-    double m = MP_NEG_INF;
-    for (int b = tid; b < nt; b += 1024) m = fmax(m, mp_ld_agent(tm + b));
-    m = wave_max(m);
+    // nt <= 1024 (the launch condition of this kernel): one tile per thread, its three scalars asked for together — one round trip
+    // through the L2, not two (the maximum first, the rest afterwards)
+    const bool have = tid < nt;
+    const double mb = have ? mp_ld_agent(tm + tid) : MP_NEG_INF;
+    const u64 Wb = have ? mp_ld_agent(tW + tid) : 0ull, W2b = have ? mp_ld_agent(tW2 + tid) : 0ull;
+    double m = wave_max(mb);
     if (lane == 0) s_red[wave] = m;
     __syncthreads();
     m = s_red[0];
@@ -449,10 +452,10 @@ __device__ __forceinline__ void mt_peek_tail(const mp_k1mt& a, int nt) {
     const bool ok = (m > MP_NEG_INF) && (m < MP_INF);
     const double sc = mp_u2f((u64)(1023 + a.S - FIX_BITS) << 52);  // 2^(S-51)
     u64 q = 0, q2 = 0;
-    for (int b = tid; b < nt; b += 1024) {
-        const double d = mp_ld_agent(tm + b) - m;
-        q += mp_quantize((double)mp_ld_agent(tW + b) * (ok ? mp_exp(d) : 0.) * sc, 1.0);
-        q2 += mp_quantize((double)mp_ld_agent(tW2 + b) * (ok ? mp_exp(2. * d) : 0.) * sc, 1.0);
+    if (have) {
+        const double d = mb - m;
+        q = mp_quantize((double)Wb * (ok ? mp_exp(d) : 0.) * sc, 1.0);
+        q2 = mp_quantize((double)W2b * (ok ? mp_exp(2. * d) : 0.) * sc, 1.0);
     }
     q = wave_sum_u64(q);
     q2 = wave_sum_u64(q2);
@@ -469,7 +472,7 @@ __device__ __forceinline__ void mt_peek_tail(const mp_k1mt& a, int nt) {
         __hip_atomic_store(reinterpret_cast<u64*>(&hm->peek_L), mp_f2u(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(reinterpret_cast<u64*>(&hm->peek_ess), mp_f2u(ess), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->peek_degenerate, degenerate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&hm->peek_seq, a.peek_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        mp_st_sys_seq(&hm->peek_seq, a.peek_seq);
         __hip_atomic_store(a.peek_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     }
 }

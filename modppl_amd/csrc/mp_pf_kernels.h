@@ -82,6 +82,14 @@ struct mp_host_mirror {
     int peek_degenerate, pad;
 };
 // `degenerate` goes up, on the device and in the host's mirror
+// The sequence word of a host-mapped record, AFTER the record's fields.  Those are system-scope atomic stores — write-through, counted by
+// vmcnt until they are visible to the host — so waiting for them IS the release the host's acquire needs; a release fence at system
+// scope would also write the XCD's whole L2 back (buffer_wbl2 sc0 sc1: up to 4 MB of freshly stored rows, microseconds, in the one
+// workgroup every launch waits for).  Only for records written with system-scope stores by the calling thread.
+__device__ __forceinline__ void mp_st_sys_seq(unsigned long long* seq, unsigned long long v) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(seq, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void mp_flag_degenerate(mp_dev_scalars* scal) {
     scal->degenerate = 1;
     if (scal->host_flag) __hip_atomic_store(scal->host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1652,7 +1660,7 @@ __device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2
             __hip_atomic_store(reinterpret_cast<u64*>(&hm->L), mp_f2u(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(reinterpret_cast<u64*>(&hm->ess_stale), mp_f2u(ess), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(reinterpret_cast<u64*>(&hm->log_ml), mp_f2u(lml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&hm->fold_seq, folds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            mp_st_sys_seq(&hm->fold_seq, folds);
         }
     } else {          // query (particle_filter.rs:119-121; fresh ESS)
         scal->L = L;
@@ -2101,7 +2109,7 @@ __global__ __launch_bounds__(1024) void k_peek_level1(const double* __restrict__
         __hip_atomic_store(reinterpret_cast<u64*>(&hm->peek_L), mp_f2u(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(reinterpret_cast<u64*>(&hm->peek_ess), mp_f2u(ess), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->peek_degenerate, degenerate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&hm->peek_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        mp_st_sys_seq(&hm->peek_seq, seq);
     }
 }
 

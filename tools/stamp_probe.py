@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--particles", type=int, default=1 << 20)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--raw", default=None, help="write the raw stamp array here (.npy)")
+    ap.add_argument("--sync", action="store_true", help="the stamped launches are steps of the synchronous loop (step; ESS; L = resample()): a launch on an idle queue, with the peek tail")
     args = ap.parse_args()
     from modppl_amd import build as B
 
@@ -48,9 +49,15 @@ def main():
     # several steps back to back: every launch overwrites the stamps, the last one's remain — a launch in the middle of a busy
     # queue, as in the bench (a launch behind an idle queue starts its workgroups up to 3 us apart, XCD by XCD)
     ys2 = lgssm_observations(args.steps + 8)
+    if args.sync:
+        pf.resample()
     for t in range(args.steps, args.steps + 5):
         pf.step(ys2[t:t + 1])
-        pf.resample(sync=False)
+        if args.sync:
+            pf.effective_sample_size()
+            pf.resample()
+        else:
+            pf.resample(sync=False)
     pf.synchronize()
     buf = np.zeros((KERNELS, MAX_WG, SLOTS), dtype=np.uint64)
     capi.check(L.mp_debug_stamps(buf.ctypes.data_as(C.c_void_p)))
