@@ -84,8 +84,9 @@ struct mp_host_mirror {
 // `degenerate` goes up, on the device and in the host's mirror
 // The sequence word of a host-mapped record, AFTER the record's fields.  Those are system-scope atomic stores — write-through, counted by
 // vmcnt until they are visible to the host — so waiting for them IS the release the host's acquire needs; a release fence at system
-// scope would also write the XCD's whole L2 back (buffer_wbl2 sc0 sc1: up to 4 MB of freshly stored rows, microseconds, in the one
-// workgroup every launch waits for).  Only for records written with system-scope stores by the calling thread.
+// scope would also write the XCD's whole L2 back (buffer_wbl2 sc0 sc1: up to 4 MB of freshly stored rows) — 1.2 us in the LAST workgroup
+// of a synchronous step (mt_peek_tail, k_peek_level1), which the host is waiting for.  Only for records written with system-scope
+// stores by the calling thread.
 __device__ __forceinline__ void mp_st_sys_seq(unsigned long long* seq, unsigned long long v) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(seq, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1660,7 +1661,8 @@ __device__ __forceinline__ void fold_scalars(mp_dev_scalars* scal, u64 Q, u64 Q2
             __hip_atomic_store(reinterpret_cast<u64*>(&hm->L), mp_f2u(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(reinterpret_cast<u64*>(&hm->ess_stale), mp_f2u(ess), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(reinterpret_cast<u64*>(&hm->log_ml), mp_f2u(lml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            mp_st_sys_seq(&hm->fold_seq, folds);
+            // (a release fence here — buffer_wbl2 and all — is at the START of the launch, in front of nobody's last instruction: kept)
+            __hip_atomic_store(&hm->fold_seq, folds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     } else {          // query (particle_filter.rs:119-121; fresh ESS)
         scal->L = L;
