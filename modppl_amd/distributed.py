@@ -560,8 +560,11 @@ class ShardedParticleSystem:
             cap = self._ow_cap
             rows = self._ow_rows[self._ow_flip]
             self._ow_flip ^= 1
-            e.shard_owned_count(scheme, p_tiles_all, w, self.rank, cap, want_counts=False)
-            e.shard_owned_expand(w, self.rank, cap, C.c_void_p(self._ow_send.data_ptr()), C.c_void_p(rows.data_ptr()), w * cap)
+            if hasattr(e, "shard_owned_count_expand"):   # one call (and, for a self-drawn resample, one launch): the HIP engine
+                e.shard_owned_count_expand(scheme, p_tiles_all, w, self.rank, cap, C.c_void_p(self._ow_send.data_ptr()), C.c_void_p(rows.data_ptr()), w * cap)
+            else:
+                e.shard_owned_count(scheme, p_tiles_all, w, self.rank, cap, want_counts=False)
+                e.shard_owned_expand(w, self.rank, cap, C.c_void_p(self._ow_send.data_ptr()), C.c_void_p(rows.data_ptr()), w * cap)
             if not solo:
                 dist.all_to_all_single(rows[: w * cap * (d + 1)], self._ow_send, group=self.group)
             p_rows = C.c_void_p(rows.data_ptr())

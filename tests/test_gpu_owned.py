@@ -496,6 +496,19 @@ def test_owner_keeps_error_paths():
     with pytest.raises(ModpplError) as err:                       # world differs from the count's
         e.shard_owned_expand(1, 0, 0, ptr(buf), ptr(buf), 0)
     assert err.value.code == capi.MP_ERR_STATE
+    # count + expand as one call: the equal-split form only, and nothing is launched for a call that is refused
+    with pytest.raises(ModpplError) as err:
+        e.shard_owned_count_expand(3, ptr(tiles), 2, 0, 0, ptr(buf), ptr(buf), 0)
+    assert err.value.code == capi.MP_ERR_INVALID_ARG
+    with pytest.raises(ModpplError) as err:
+        e.shard_owned_count_expand(3, ptr(tiles), 2, 0, 64, ptr(buf), ptr(buf), 100)
+    assert err.value.code == capi.MP_ERR_INVALID_ARG
+    with pytest.raises(ModpplError) as err:
+        e.shard_owned_count_expand(9, ptr(tiles), 2, 0, 64, ptr(buf), ptr(buf), 128)
+    assert err.value.code == capi.MP_ERR_INVALID_ARG
+    e.shard_owned_count_expand(3, ptr(tiles), 2, 0, 64, ptr(buf), ptr(buf), 128)
+    done, L, cnt = e.shard_owned_commit(ptr(buf), 128, True)
+    assert done and sum(cnt[:2]) == 2 * n and np.isfinite(L)
     e.close()
 
 
