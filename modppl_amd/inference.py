@@ -15,6 +15,9 @@ from . import capi
 _DP = C.POINTER(C.c_double)
 
 
+_F64 = np.dtype(np.float64)
+
+
 def _dptr(a):
     # (a float64 array's address for a `double*` argument: through the buffer protocol this costs 0.4 us, `a.ctypes.data_as` 2.1 us —
     # 4 % of a synchronous step; read-only or empty arrays take the slow way)
@@ -39,6 +42,12 @@ class ParticleSystem:
         capi.check(self._L.mp_pf_create(C.byref(self._desc), self.num_particles, int(seed), None, int(flags), int(device),
                                         C.c_void_p(stream) if stream else None, C.byref(h)))
         self._h = h
+        # the per-step calls of a synchronous caller's loop (step; ESS; L = resample()) are 45 us of GPU time: bound functions, the
+        # model's width and two reusable out-parameters instead of an attribute chain and a fresh ctypes object per call
+        self._dim_obs = int(model.dim_obs)
+        self._c_step, self._c_ess, self._c_resample = self._L.mp_pf_step, self._L.mp_pf_effective_sample_size, self._L.mp_pf_resample
+        self._out_ess, self._out_L = C.c_double(), C.c_double()
+        self._ref_ess, self._ref_L = C.byref(self._out_ess), C.byref(self._out_L)
 
     # ParticleSystem::new
     @classmethod
@@ -63,25 +72,36 @@ class ParticleSystem:
 
     def step(self, constraints):
         """step(constraints) -> Self: N x update(.., ArgDiff::Extend, constraints) — particle_filter.rs:73-96."""
-        obs = self._obs(constraints)
-        capi.check(self._L.mp_pf_step(self._h, _dptr(obs), obs.shape[0]))
+        obs = constraints
+        if type(obs) is np.ndarray and obs.dtype == _F64 and obs.flags.c_contiguous and obs.size and not obs.size % self._dim_obs:
+            steps = obs.size // self._dim_obs    # (already what _obs would make of it)
+        else:
+            obs = self._obs(constraints)
+            steps = obs.shape[0]
+        code = self._c_step(self._h, _dptr(obs), steps)
+        if code:
+            capi.check(code)
         return self
 
     def effective_sample_size(self, fresh=False):
         """particle_filter.rs:98-100.  The reference reads the weights normalised by the LAST resample
         (1/N before any); fresh=True evaluates the current log-weights instead."""
-        out = C.c_double()
-        capi.check(self._L.mp_pf_effective_sample_size(self._h, capi.MP_ESS_FRESH if fresh else capi.MP_ESS_REFERENCE, C.byref(out)))
-        return out.value
+        code = self._c_ess(self._h, capi.MP_ESS_FRESH if fresh else capi.MP_ESS_REFERENCE, self._ref_ess)
+        if code:
+            capi.check(code)
+        return self._out_ess.value
 
     def resample(self, scheme=capi.MP_RESAMPLE_MULTINOMIAL, sync=True):
         """resample() -> log total weight — particle_filter.rs:103-116.  sync=False only enqueues."""
         if not sync:
-            capi.check(self._L.mp_pf_resample(self._h, scheme, None))
+            code = self._c_resample(self._h, scheme, None)
+            if code:
+                capi.check(code)
             return None
-        out = C.c_double()
-        capi.check(self._L.mp_pf_resample(self._h, scheme, C.byref(out)))
-        return out.value
+        code = self._c_resample(self._h, scheme, self._ref_L)
+        if code:
+            capi.check(code)
+        return self._out_L.value
 
     def maybe_resample(self, ess_fraction=0.5, scheme=capi.MP_RESAMPLE_MULTINOMIAL):
         """ESS-triggered resampling (extension): resample iff ESS(current weights) < ess_fraction * N.
