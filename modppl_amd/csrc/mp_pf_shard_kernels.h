@@ -1265,10 +1265,12 @@ __device__ __forceinline__ void mp_table_leader(const mp_table_tail& t, const u6
     }
     if (!t.do_place || s_deg) return;   // (degenerate weights: the commit refuses, nothing to place)
     const u64 c_me = s_c[t.rank];
+    // (the folding lane has left: the other THREADS - 1 share the placement out among themselves)
+    const u64 t0 = (u64)(tid < THREADS - 64 ? tid : tid - 1), stride = (u64)(THREADS - 1);
     if (t.scheme == MP_SCHEME_SPLIT)
-        mp_self_place<false>(t.place, &s_pl, t.scheme, world, t.rank, nt_local, n_global, t.k0, t.k1, t.rc, lo, hi, Q, g_lo, c_me, (u64)tid, (u64)THREADS);
+        mp_self_place<false>(t.place, &s_pl, t.scheme, world, t.rank, nt_local, n_global, t.k0, t.k1, t.rc, lo, hi, Q, g_lo, c_me, t0, stride);
     else
-        mp_self_place<true>(t.place, &s_pl, t.scheme, world, t.rank, nt_local, n_global, t.k0, t.k1, t.rc, lo, hi, Q, g_lo, c_me, (u64)tid, (u64)THREADS);
+        mp_self_place<true>(t.place, &s_pl, t.scheme, world, t.rank, nt_local, n_global, t.k0, t.k1, t.rc, lo, hi, Q, g_lo, c_me, t0, stride);
     MP_STAMP(2, 7, 1);
 }
 // One workgroup builds the whole table (jobs of up to 2048 tiles, and a world of one whose table no level-0 launch left)

@@ -524,6 +524,8 @@ def test_owner_keeps_million_particles(world, n, cap, scheme):
     model, obs = _model(1, 4)
     N, seed = n * world, 99
     hip = _ByHand(model, n, world, seed)
+    hip.fused = bool(cap) and scheme != 0   # the self-drawn forms with a capacity: count + expand as one call, one launch (the table by one
+    #                                         workgroup per rank at these sizes: k_shard_table_mw<1>, <8> beyond 1024 tiles per rank)
     ref = OwnedReference(model, N, seed, world)
     for e in hip.eng:
         e.init_step(None, obs[:1])
