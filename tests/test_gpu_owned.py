@@ -390,7 +390,7 @@ from modppl_amd.distributed import ShardedParticleSystem
 from tests import oracle_lib as O
 from tests.owned_ref import OwnedReference
 rank, world = dist.get_rank(), dist.get_world_size()
-N, T, seed = 2048 * 2 * world * 2, 7, 5
+N, T, seed = int(os.environ.get("MP_T_PER_RANK", 2048 * 2 * 2)) * world, 7, 5
 model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
 obs = O.lgssm_observations(T).reshape(T, 1)
 EX, SCH = os.environ.get("MP_T_EXCHANGE", "owned"), int(os.environ.get("MP_T_SCHEME", "0"))
@@ -437,7 +437,10 @@ def _free_port():
                                                ("gloo", 3, {}),
                                                # the self-drawn forms through the same entry point: split multinomial, a lattice scheme
                                                ("nccl", 1, {"MP_T_EXCHANGE": "split"}), ("gloo", 2, {"MP_T_EXCHANGE": "split"}),
-                                               ("gloo", 3, {"MP_T_EXCHANGE": "split", "MP_SHARD_OWNED_CAP": "8"}), ("gloo", 2, {"MP_T_SCHEME": "1"})])
+                                               ("gloo", 3, {"MP_T_EXCHANGE": "split", "MP_SHARD_OWNED_CAP": "8"}), ("gloo", 2, {"MP_T_SCHEME": "1"}),
+                                               # half a million particles per rank: a surplus of a thousand rows, more than one placement entry per lane
+                                               ("gloo", 2, {"MP_T_EXCHANGE": "split", "MP_T_PER_RANK": "524288"}),
+                                               ("gloo", 2, {"MP_T_PER_RANK": "524288"})])
 def test_owner_keeps_through_process_groups(tmp_path, which, nproc, extra):
     """The whole resample as ONE library call (mp_pf_shard_resample) with the library issuing the collectives: over its own RCCL
     communicator with every collective forced in a world of one (the bench's transport: ncclAllGather + one group of ncclSend /
