@@ -529,7 +529,6 @@ struct mp_pf {
     mp_owned_plan* ow_plan = nullptr;
     mp_own_range* ow_range = nullptr;
     u64* ow_kthr = nullptr;               // [SH_MAX_WORLD] rank boundaries as thresholds on the 52-bit uniforms (multinomial)
-    unsigned int* ow_ticket = nullptr;
     u64 ow_last_cap = 0;                  // capacity of the last mp_pf_shard_owned_expand (0 = exact sizes: nothing can overflow)
     unsigned long long ow_seq = 0;        // owner-keeps resamples planned so far: the plan of number k writes pub->seq = k last
     int ow_nsc = 0, ow_R = 0, ow_wgs = 0;
@@ -1666,10 +1665,9 @@ int32_t mp_pf_shard_commit_fixed(mp_pf* h, const double* d_rows_in, double* log_
 static void owned_free(mp_pf* h) {
     (void)hipFree(h->ow_seg_lt); (void)hipFree(h->ow_seg_row);
     (void)hipFree(h->ow_sccnt); (void)hipFree(h->ow_base); (void)hipFree(h->ow_call); (void)hipFree(h->ow_plan);
-    (void)hipFree(h->ow_range); (void)hipFree(h->ow_ticket); (void)hipFree(h->ow_kthr); (void)hipFree(h->ow_range_solo);
+    (void)hipFree(h->ow_range); (void)hipFree(h->ow_kthr); (void)hipFree(h->ow_range_solo);
     h->ow_range_solo = nullptr;
     h->ow_kthr = nullptr;
-    h->ow_ticket = nullptr;
     h->ow_seg_lt = nullptr; h->ow_seg_row = nullptr;
     h->ow_sccnt = nullptr; h->ow_base = nullptr; h->ow_call = nullptr; h->ow_plan = nullptr; h->ow_range = nullptr;
 }
@@ -1714,8 +1712,6 @@ static int32_t owned_scratch(mp_pf* h, int world) {
     HIPCK(hipMalloc(&h->ow_plan, sizeof(mp_owned_plan)));
     HIPCK(hipMalloc(&h->ow_range, sizeof(mp_own_range)));
     HIPCK(hipMalloc(&h->ow_kthr, sizeof(u64) * SH_MAX_WORLD));
-    HIPCK(hipMalloc(&h->ow_ticket, sizeof(unsigned int)));
-    HIPCK(hipMemsetAsync(h->ow_ticket, 0, sizeof(unsigned int), h->stream));
     HIPCK(hipMemsetAsync(h->ow_call, 0, sizeof(unsigned long long) * SH_MAX_WORLD, h->stream));
     HIPCK(hipMemsetAsync(h->ow_plan, 0, sizeof(mp_owned_plan), h->stream));
     if (world == 1) {   // what k_shard_own_plan would find, every time (it is not launched in a world of one)
