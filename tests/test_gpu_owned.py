@@ -460,6 +460,30 @@ def test_owner_keeps_through_process_groups(tmp_path, which, nproc, extra):
     assert "RESULT ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
+@pytest.mark.parametrize("scheme,fused", [(3, True), (3, False), (1, True), (2, False), (0, False)])
+def test_degenerate_weights_in_a_sharded_resample(scheme, fused):
+    """An observation no particle of any rank can explain (every log-weight -inf, Q = 0): the plan's verdict says so, every rank's
+    commit raises where the reference's categorical asserts (categorical.rs:23), nothing is placed or committed — and nothing reads
+    out of bounds on the way (spans, ratios and shares of a zero mass)."""
+    from modppl_amd.capi import ModpplError
+    from modppl_amd import capi
+    world, n, cap = 3, 4096, 256
+    model, obs = _model(1, 3)
+    hip = _ByHand(model, n, world, 17)
+    hip.fused = fused
+    for e in hip.eng:
+        e.init_step(None, obs[:1])
+    hip.resample(cap, scheme)
+    for e in hip.eng:
+        e.step(np.array([[1e200]]))   # (y - x)^2 overflows
+    with pytest.raises(ModpplError) as err:
+        hip.resample(cap, scheme)
+    assert err.value.code == capi.MP_ERR_DEGENERATE
+    with pytest.raises(ModpplError) as err:   # (the flag is sticky, as for an unsharded filter: mp_pf_synchronize reports it)
+        hip.sync()
+    assert err.value.code == capi.MP_ERR_DEGENERATE
+
+
 def test_owner_keeps_error_paths():
     """Misuse of the phases is a status code, not a fault (the reference panics; the wrapper re-raises)."""
     import torch
