@@ -8,7 +8,7 @@
 // kernels by value) and are filled from the C ABI's double arrays by a parse function.
 //   MP_REGISTER_MH_MODEL(kind, Type, parse)                          kinds >= 100 are free
 //   MP_REGISTER_MH_PROPOSAL(proposal_kind, ModelType, Type, parse)
-// mp_mh.hip instantiates k_fn_init / k_fn_regen / k_fn_mh / k_fn_logjp for every registration; chains are created with
+// mp_mh.hip instantiates k_fn_generate / k_fn_simulate / k_fn_regen / k_fn_mh / k_fn_logjp for every registration; chains are created with
 // mp_mh_create_fn and driven by the same mp_mh_step / mp_regen_mh_step as the hand-written kernels.
 #pragma once
 #include <string>

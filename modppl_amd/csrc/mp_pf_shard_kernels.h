@@ -553,7 +553,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_shard_resolve_binned(u64 n, u64 
 // exactly as after an unsharded resample (the parent is local by construction); only the surplus is looked up early.
 //   k_shard_table[_mw]  the job's tile table (one workgroup, or one per rank beyond 2048 tiles); the rank boundaries as
 //                       thresholds on the uniforms (multinomial); for the lattice schemes every rank's own range of draws
-//                       [G_{r-1}, G_r) by binary search on the monotone target function: offspring counts in closed form,
+//                       [G_{r-1}, G_r) from the monotone target function (mp_lattice_ranges): offspring counts in closed form,
 //                       and a rank only looks at its own draws — O(n_local), whatever the world size.
 //   k_shard_own_draw    super-chunk = R x 1024 consecutive draws, R = min(world, 4) (multinomial: resident workgroups take
 //                       turns; a WAVE enumerates 128 R of them and compacts its own ones in LDS without a workgroup barrier;
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256) void k_shard_own_place(u64 n, u64 slot_offset,
 // ---------------------------------------------------------------------------------------------
 // Self-drawn owner-keeps resample (lattice schemes; split multinomial).  Offspring p of this rank — p = 0 .. c_me - 1, in the order
 // of its draws — has its target in CLOSED FORM:
-//   lattice             draw g = g_lo + p of the job's lattice (k_shard_table found the rank's range [g_lo, g_hi) by binary search)
+//   lattice             draw g = g_lo + p of the job's lattice (k_shard_table found the rank's range [g_lo, g_hi): mp_lattice_ranges)
 //   split multinomial   uniform p of the rank's own stream (Philox block p >> 1, word 3 = the rank) scaled to the rank's own share
 //                       (lo, hi] of the job's fixed-point mass (mp_binomial.h; k_shard_table drew the counts c_r)
 // so nothing is enumerated, compacted or scanned: kept offspring p < min(c_me, n) IS slot p.  The kept draws are made by the next

@@ -144,7 +144,7 @@ class _ByHand:
     (1, 8, 2048, 256, False, 3, 6.0),
     (1, 5, 2048, 0, True, 3, 6.0),         # odd world: the splitting tree's padded leaves
     (1, 64, 2048, 0, False, 3, 6.0),       # the largest world the library takes: six levels of the splitting tree, a 64-rank plan
-    (1, 33, 2048, 64, True, 1, 6.0),       # 33 ranks: lattice ranges by 33 binary searches, equal-split exchange over 33 peers
+    (1, 33, 2048, 64, True, 1, 6.0),       # 33 ranks: 33 lattice ranges (eight lanes each), equal-split exchange over 33 peers
 ])
 def test_owner_keeps_shards_in_process(d, world, n, cap, peek, scheme, tail):
     model, obs = _model(d, 7)
