@@ -68,6 +68,15 @@ template <bool WALKB>
 __device__ __forceinline__ void mt_draw(mp_mt_tile& T, u64 tile, const mp_u64x2& blk, const mp_k1mt& a, int nt,
                                         const u64* s_incl, const u64* s_W, const double* s_ratio, u64 Q, double nt_over_Q) {
     T.base = tile * TILE + (u64)threadIdx.x * 2;
+#if MP_MT_PROBE & 8
+    for (int q = 0; q < 2; ++q) {
+        T.tile_of[q] = (uint32_t)tile;
+        T.plt[q] = 1ull;
+        T.g[q] = (uint32_t)(threadIdx.x * 2 + q);
+        T.sp[q] = 0u;
+    }
+    return;
+#endif
     uint32_t gslot[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -85,6 +94,20 @@ __device__ __forceinline__ void mt_draw(mp_mt_tile& T, u64 tile, const mp_u64x2&
 #ifndef MP_MT_Q5
 #define MP_MT_Q5 1
 #endif
+// Timing probes (tools/build_variant.py builds of their own, NEVER the product: results are not the filter's): what the kernel takes
+// without one of its two big resources.  Bit 0: the standard deviates cost nothing (a hash of the slot instead of Philox, the polar
+// loop, a logarithm, a root and a division per deviate: same spread, so the weights stay healthy); bit 1: no row gathers (the parent
+// IS the guide cell's start row, its state a hash of the slot: no random 16-byte reads of the 16 MB table, the rest unchanged).
+// Bit 2: no normalisation arithmetic (every row weighs 2^40: no exponentials, scans, barriers or guide walk; the table stays valid);
+// bit 3: no draws (no Philox block, 128-bit target, tile walk or guide gather: a slot's parent is its own row; with bit 1).
+#ifndef MP_MT_PROBE
+#define MP_MT_PROBE 0
+#endif
+__device__ __forceinline__ double mt_probe_deviate(u64 slot, long long t, int salt) {
+    uint32_t h = (uint32_t)slot * 2654435761u ^ (uint32_t)t * 40503u ^ (uint32_t)salt * 97u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    return (double)(h & 0xFFFFFu) * (3.4641016 / 1048576.) - 1.7320508;   // uniform, variance 1
+}
 __device__ __forceinline__ void mt_rows(mp_mt_tile& T, const mp_k1mt& a) {
     bool hbv[2];
 #pragma unroll
@@ -104,6 +127,16 @@ __device__ __forceinline__ void mt_rows(mp_mt_tile& T, const mp_k1mt& a) {
         }
         T.tile_of[q] = r0;
     }
+#if MP_MT_PROBE & 2
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        T.a[q].x = ~0ull;
+        T.a[q].y = __builtin_bit_cast(u64, 0.8 * mt_probe_deviate(T.base + q, a.t, 7));
+        T.b2[q] = T.a[q];
+        T.sp[q] = 0u;
+    }
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t r0 = T.tile_of[q];
@@ -145,8 +178,12 @@ __device__ __forceinline__ void mt_resolve_first(mp_mt_tile& T, const mp_k1mt& a
         // branch the compiler no longer knows how many loads are in flight and waits for all of them, the next tile's included
 #pragma unroll
         for (int k = 0; k < MP_MT_WALK_ROWS; ++k) {
+#if MP_MT_PROBE & 2
+            W.nx[q][k] = W.cur[q];
+#else
             const u64 r = (u64)W.p[q] + 1 + k;
             W.nx[q][k] = mp_ld_row(a.cx_old + (W.more[q] ? (r < last ? r : last) : 0ull));
+#endif
         }
     }
 }
@@ -199,6 +236,10 @@ template <class Model>
 __device__ __forceinline__ void mt_deviates(const Model& model, int ns, const mp_k1mt& a, u64 base, u64 tile, uint32_t* s_it, double* z) {
     constexpr int NS = Model::MAX_NORMALS;
     constexpr int M = 2 * NS;
+#if MP_MT_PROBE & 1
+    for (int q = 0; q < M; ++q) z[q] = mt_probe_deviate(a.slot_offset + base + q / NS, a.t, q % NS);
+    return;
+#endif
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     double pu[M], pr[M];
     uint32_t pend = 0u;
@@ -305,6 +346,16 @@ __device__ __forceinline__ void mt_norm_compute(const double (&lw)[2], u64 n, u6
     constexpr int THREADS = 1024;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 base = tile * TILE + (u64)tid * 2;
+#if MP_MT_PROBE & 4
+    {
+        const u64 q0 = 1ull << 40;
+        cum[0] = (u64)(tid * 2 + 1) * q0; cum[1] = (u64)(tid * 2 + 2) * q0;
+        m_out = 0.; W_out = (u64)TILE * q0; W2_out = (u64)TILE * q0;
+        reinterpret_cast<uint32_t*>(s_guide)[tid] = (uint32_t)((tid * 2) | (31 << MP_GUIDE_Q_SHIFT)) | ((uint32_t)((tid * 2 + 1) | (31 << MP_GUIDE_Q_SHIFT)) << 16);
+        (void)lane; (void)wave; (void)base; (void)lw; (void)n; (void)L;
+        return;
+    }
+#endif
     double m = MP_NEG_INF;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
