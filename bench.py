@@ -334,6 +334,20 @@ def reference_shaped_loop(model, n, ys, steps, warmup):
         pf.resample()
         pf.states()
     dts = time.perf_counter() - t0
+    dts_pinned = None
+    try:   # the same with the states landing in ONE pinned host buffer (what a caller who keeps every state would hand over)
+        import torch
+        pinned = torch.empty((n, model.dim_state), dtype=torch.float64).pin_memory().numpy()
+        pf.states(out=pinned)
+        t0 = time.perf_counter()
+        for t in range(1, 1 + k_states):
+            pf.step(ys[t:t + 1])
+            pf.effective_sample_size()
+            pf.resample()
+            pf.states(out=pinned)
+        dts_pinned = time.perf_counter() - t0
+    except Exception:   # noqa: BLE001  (no pinned memory here: the figure is simply absent)
+        dts_pinned = None
     return {"what": "step; effective_sample_size() -> f64; resample() -> f64 (every call synchronous, as in particle_filter.rs:73-116)",
             "steps": steps, "loops": len(dts_loop), "us_per_step": dt / steps * 1e6, "us_per_step_min": min(dts_loop) / steps * 1e6,
             "us_per_step_max": max(dts_loop) / steps * 1e6, "particle_steps_per_s": n * steps / dt,
@@ -342,7 +356,8 @@ def reference_shaped_loop(model, n, ys, steps, warmup):
             "kernel_avg_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in fam.items()},
             "resample_return_value": "computed by the LAST workgroup of the step's own launch (mt_peek_tail: level 1 of the new tile scalars into host-mapped memory) once the loop is known to be synchronous; k_peek_level1, a launch of its own, only for the first synchronous resample — the difference between us_per_step and the kernel above is a launch on an idle queue plus one host poll",
             "with_states_copied_to_host_each_step": {"steps": k_states, "us_per_step": dts / k_states * 1e6,
-                                                     "note": "PCIe-inclusive: k_draw_slots + k_resolve_slots + 8 MB device-to-host per step (tests/smc.rs:64-90 writes every state to disk)"},
+                                                     "us_per_step_into_a_pinned_buffer": (dts_pinned / k_states * 1e6) if dts_pinned else None,
+                                                     "note": "PCIe-inclusive: k_draw_slots + k_resolve_slots + 8 MB device-to-host per step (tests/smc.rs:64-90 writes every state to disk); us_per_step: into a fresh pageable array each step"},
             "sum_of_log_total_weights": Ls}
 
 

@@ -127,8 +127,15 @@ class ParticleSystem:
         capi.check(self._L.mp_pf_synchronize(self._h))
 
     # the pub `traces` field, flattened: traces[i].retv.last()
-    def states(self):
-        x = np.empty((self.num_particles, self.model.dim_state))
+    def states(self, out=None):
+        """-> [num_particles, dim_state].  `out`: a float64 C-contiguous array of that size to fill instead of a fresh one — a PINNED one
+        (e.g. `torch.empty(..., pin_memory=True).numpy()`) takes the copy at the link's rate instead of through a staging buffer."""
+        if out is None:
+            x = np.empty((self.num_particles, self.model.dim_state))
+        else:
+            x = out
+            if not (isinstance(x, np.ndarray) and x.dtype == _F64 and x.flags.c_contiguous and x.size == self.num_particles * self.model.dim_state):
+                raise capi.ModpplError(capi.MP_ERR_INVALID_ARG, "states(out=): a C-contiguous float64 array of num_particles * dim_state values")
         capi.check(self._L.mp_pf_read_state(self._h, _dptr(x)))
         return x
 

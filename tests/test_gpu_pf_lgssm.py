@@ -172,6 +172,30 @@ def test_error_statuses():
     assert e.value.code == capi.MP_ERR_DEGENERATE
 
 
+def test_states_into_a_caller_buffer():
+    """states(out=): the copy lands in the caller's array (a pinned one takes it at the link's rate: bench.py's PCIe-inclusive
+    figure); a wrong shape or type is refused before anything is copied"""
+    import torch
+    import modppl_amd
+    from modppl_amd.capi import ModpplError
+
+    n = 70001
+    ys = O.lgssm_observations(3)
+    pf = modppl_amd.ParticleSystem(modppl_amd.lgssm_model(*O.LGSSM_PARAMS), n, 5)
+    pf.init_step(None, ys[:1])
+    pf.resample()
+    pf.step(ys[1:2])
+    want = pf.states()
+    pinned = torch.empty((n, 1), dtype=torch.float64).pin_memory().numpy()
+    got = pf.states(out=pinned)
+    assert got is pinned and np.array_equal(got, want)
+    plain = np.zeros((n, 1))
+    assert np.array_equal(pf.states(out=plain), want)
+    for bad in (np.zeros((n, 1), dtype=np.float32), np.zeros((n + 1, 1)), np.zeros((2 * n, 1))[::2], [0.0] * n):
+        with pytest.raises(ModpplError):
+            pf.states(out=bad)
+
+
 @pytest.mark.parametrize("d", [1, 4])
 def test_parents_survive_a_step_after_a_lazy_resample(d):
     """particle_filter.rs:73-96 keeps `parents` across `step`; here a resample that only drew leaves them as {target, start row} per slot and the
