@@ -570,6 +570,56 @@ def test_owner_keeps_million_particles(world, n, cap, scheme):
     assert hip.fallbacks == 0
 
 
+@pytest.mark.parametrize("scheme", [3, 0])
+def test_c5_as_stated_as_eight_shards_on_one_card(scheme):
+    """BASELINE.json configs[4] at its stated size — LGSSM d = 16, 2^24 particles over 8 ranks of 2^21 — as eight in-process shards
+    taking turns on the one GPU (the all-gather and the all-to-all are tensor copies): no checker runs at this size, so properties —
+    every rank reaches the same verdict, counts and log total weight; the counts add up to N and stay within a few sigma of n; the
+    job's log-ML estimate agrees with the exact matrix Kalman filter of the same data."""
+    from tests.test_gpu_dense import matrix_kalman_log_ml
+    import modppl_amd
+    D, world, n, T = 16, 8, 1 << 21, 4
+    a_, band, sig0, sig_x, sig_y = 0.9, 0.05, 1.0, 0.5, 1.0
+    A = a_ * (np.eye(D) + band * (np.eye(D, k=1) + np.eye(D, k=-1)))
+    rng = np.random.default_rng(12)
+    x = sig0 * rng.normal(size=D)
+    obs = []
+    for t in range(T):
+        if t > 0:
+            x = A @ x + sig_x * rng.normal(size=D)
+        obs.append(x + sig_y * rng.normal(size=D))
+    obs = np.array(obs)
+    model = modppl_amd.lgssm_band_model(D, a_, band, sig0, sig_x, sig_y)
+    hip = _ByHand(model, n, world, 41)
+    for e in hip.eng:
+        e.init_step(None, obs[:1])
+    for t in range(1, T):
+        L = hip.resample(0, scheme)   # exact sizes: what mp_pf_shard_resample picks for 136-byte rows (shard masses differ by percents at d = 16)
+        assert np.isfinite(L)
+        assert sum(hip.counts) == n * world
+        assert max(abs(int(c) - n) for c in hip.counts) < n // 4
+        for e in hip.eng:
+            e.step(obs[t:t + 1])
+    par = hip.eng[3].parents()
+    assert par.min() >= 0 and par.max() < n * world
+    tiles_all = torch_cat_tiles(hip)
+    lml = [e.shard_query_packed(C.c_void_p(tiles_all.data_ptr()), world)[0] for e in hip.eng[:2]]
+    want = matrix_kalman_log_ml(A, sig_x ** 2 * np.eye(D), sig_y ** 2 * np.eye(D), sig0, obs)
+    assert lml[0] == lml[1]
+    assert abs(lml[0] - want) < 0.05, (lml[0], want)   # (-102.311 split / -102.314 owned against -102.313 on the first run)
+
+
+def torch_cat_tiles(hip):
+    """the gathered tile scalars of every shard of a _ByHand job (what the all-gather would deliver), current weights"""
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    for r, e in enumerate(hip.eng):
+        e.shard_tiles_packed(ptr(hip.tiles[r]))
+    hip.sync()
+    hip._tiles_all = hip.torch.cat(hip.tiles)
+    hip.torch.cuda.synchronize()
+    return hip._tiles_all
+
+
 @pytest.mark.parametrize("exchange", ["owned", "exact"])
 def test_sharded_parents_survive_a_step(exchange):
     """the sharded filters leave the parents in the exchange rows; a step consumes the states from there and the parents must
