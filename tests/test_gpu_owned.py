@@ -609,6 +609,32 @@ def test_c5_as_stated_as_eight_shards_on_one_card(scheme):
     assert abs(lml[0] - want) < 0.05, (lml[0], want)   # (-102.311 split / -102.314 owned against -102.313 on the first run)
 
 
+@pytest.mark.parametrize("scheme", [0, 3, 1])
+def test_headline_size_as_eight_shards_on_one_card(scheme):
+    """The N = 8 bench workload — LGSSM d = 1, 2^20 particles per rank, 2^23 in the job — as eight in-process shards, the equal-split
+    exchange with the library's capacity, count + expand as one call: verdicts, counts and log total weights agree on every rank, no
+    pair overflows, the job's log-ML agrees with the Kalman filter (owned multinomial: the default exchange of `value`; split
+    multinomial and systematic: one launch per resample)."""
+    world, n, T = 8, 1 << 20, 6
+    model, obs = _model(1, T)
+    hip = _ByHand(model, n, world, 77)
+    hip.fused = True
+    for e in hip.eng:
+        e.init_step(None, obs[:1])
+    cap = max(4096, n // 128)
+    for t in range(1, T):
+        L = hip.resample(cap, scheme)
+        assert np.isfinite(L) and sum(hip.counts) == n * world
+        assert max(abs(int(c) - n) for c in hip.counts) < 12 * int(np.sqrt(n))
+        for e in hip.eng:
+            e.step(obs[t:t + 1])
+    tiles_all = torch_cat_tiles(hip)
+    lml = [e.shard_query_packed(C.c_void_p(tiles_all.data_ptr()), world)[0] for e in hip.eng[:2]]
+    assert lml[0] == lml[1]
+    assert abs(lml[0] - O.kalman_log_ml(obs.reshape(-1))) < 0.01, (lml[0], O.kalman_log_ml(obs.reshape(-1)))
+    assert hip.fallbacks == 0
+
+
 def torch_cat_tiles(hip):
     """the gathered tile scalars of every shard of a _ByHand job (what the all-gather would deliver), current weights"""
     ptr = lambda t: C.c_void_p(t.data_ptr())
