@@ -208,6 +208,8 @@ def test_lattice_schemes_window_form_still_agrees(monkeypatch, scheme, diag):
     (1, 33, 2048, 64, 1, 6.0),
     (4, 3, 2048, 2048, 2, 6.0),     # wide states: the kept draws are a launch of their own, the placement stays one too
     (1, 4, 4096, 512, 0, 6.0),      # the window form (owned multinomial): the one call is the two calls
+    (1, 4, 65536, 8192, 1, 6.0),    # shard masses a percent apart: a surplus / deficits of more than a thousand entries — more than one
+    (1, 4, 65536, 8192, 3, 6.0),    # placement entry per lane of the leading workgroup
 ])
 @pytest.mark.parametrize("mw", [False, True])
 def test_count_and_expand_as_one_call(monkeypatch, d, world, n, cap, scheme, tail, mw, diag):
@@ -227,9 +229,11 @@ def test_count_and_expand_as_one_call(monkeypatch, d, world, n, cap, scheme, tai
     for e in hip.eng:
         e.init_step(None, obs[:1])
     ref.init_step(None, obs[:1])
+    biggest = 0
     for t in range(1, len(obs)):
         assert hip.resample(cap, scheme) == ref.resample(scheme)
         assert list(hip.counts) == list(ref.counts)
+        biggest = max(biggest, max(abs(int(c) - n) for c in ref.counts))
         if t % 2:
             assert np.array_equal(hip.cat(lambda e: e.parents()), ref.parents())
             assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
@@ -240,6 +244,8 @@ def test_count_and_expand_as_one_call(monkeypatch, d, world, n, cap, scheme, tai
     assert np.array_equal(hip.cat(lambda e: e.states()), ref.states())
     if cap < 64:
         assert hip.fallbacks > 0
+    if n >= 65536:
+        assert biggest > 1024, biggest   # (what the case is for)
 
 
 @pytest.mark.parametrize("world,scheme", [(2, 0), (5, 0), (8, 0), (5, 3), (8, 1)])
