@@ -397,8 +397,12 @@ from tests import oracle_lib as O
 from tests.owned_ref import OwnedReference
 rank, world = dist.get_rank(), dist.get_world_size()
 N, T, seed = int(os.environ.get("MP_T_PER_RANK", 2048 * 2 * 2)) * world, 7, 5
-model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
-obs = O.lgssm_observations(T).reshape(T, 1)
+if os.environ.get("MP_T_MODEL") == "band16":   # BASELINE configs[4]'s model: 136-byte rows, exact-size exchange by policy
+    model = modppl_amd.lgssm_band_model(16)
+    obs = np.random.default_rng(3).normal(0, 1.2, size=(T, 16))
+else:
+    model = modppl_amd.lgssm_model(*O.LGSSM_PARAMS)
+    obs = O.lgssm_observations(T).reshape(T, 1)
 EX, SCH = os.environ.get("MP_T_EXCHANGE", "owned"), int(os.environ.get("MP_T_SCHEME", "0"))
 pf = ShardedParticleSystem(model, N, seed, host_staging=True, exchange=EX)   # both ranks on cuda:0, exact-size exchange
 ref = OwnedReference(model, N, seed, world) if rank == 0 else None
@@ -446,7 +450,9 @@ def _free_port():
                                                ("gloo", 3, {"MP_T_EXCHANGE": "split", "MP_SHARD_OWNED_CAP": "8"}), ("gloo", 2, {"MP_T_SCHEME": "1"}),
                                                # half a million particles per rank: a surplus of a thousand rows, more than one placement entry per lane
                                                ("gloo", 2, {"MP_T_EXCHANGE": "split", "MP_T_PER_RANK": "524288"}),
-                                               ("gloo", 2, {"MP_T_PER_RANK": "524288"})])
+                                               ("gloo", 2, {"MP_T_PER_RANK": "524288"}),
+                                               # the d = 16 model (C5) through the one call: exact sizes by policy, kept draws a launch of their own
+                                               ("gloo", 2, {"MP_T_MODEL": "band16"}), ("gloo", 3, {"MP_T_MODEL": "band16", "MP_T_EXCHANGE": "split"})])
 def test_owner_keeps_through_process_groups(tmp_path, which, nproc, extra):
     """The whole resample as ONE library call (mp_pf_shard_resample) with the library issuing the collectives: over its own RCCL
     communicator with every collective forced in a world of one (the bench's transport: ncclAllGather + one group of ncclSend /
